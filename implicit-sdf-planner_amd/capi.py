@@ -1,0 +1,95 @@
+"""ctypes mirror of include/isdf_accel.h (the C-ABI drop-in boundary).
+
+Host-side plumbing only: structure layouts, enum values and the loader of libisdf_accel.so.
+The library is the product; there is NO CPU fallback — if the shared object is missing, loading fails loudly.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libisdf_accel.so")
+
+# enums (keep in sync with include/isdf_accel.h)
+ISDF_OK = 0
+ISDF_ERR_INVALID_ARG, ISDF_ERR_NO_DEVICE, ISDF_ERR_HIP, ISDF_ERR_STATE, ISDF_ERR_OVERFLOW, ISDF_ERR_UNSUPPORTED = -1, -2, -3, -4, -5, -6
+V1_SWEPT, V2_OCC_TILE, V3_ESDF_TILE = 1, 2, 3
+GRID_OCCUPANCY, GRID_ESDF = 0, 1
+U8, F32, F64 = 0, 1, 2
+(SHAPE_TORUS, SHAPE_CAPPEDTORUS, SHAPE_CAPPEDCONE, SHAPE_ROUNDEDCONE, SHAPE_WIREFRAMEBOX, SHAPE_BENDLINEAR,
+ SHAPE_TWISTBOX, SHAPE_BENDBOX, SHAPE_TABLE, SHAPE_TREFOIL, SHAPE_SMOOTHDIFFERENCE, SHAPE_SMOOTHINTERSECTION,
+ SHAPE_CSG, SHAPE_BOX, SHAPE_BALL, SHAPE_MESH) = range(16)
+GRAD_DEFAULT, GRAD_CENTRAL, GRAD_BOX_FORWARD, GRAD_ANALYTIC_BALL = 0, 1, 2, 3
+
+SHAPE_NAMES = ["Torus", "Cappedtorus", "CappedCone", "RoundedCone", "WireframeBox", "BendLinear", "TwistBox",
+               "BendBox", "Table", "Trefoil", "SmoothDifference", "SmoothIntersection", "CSG", "Box", "Ball", "Mesh"]
+
+
+class IsdfShape(C.Structure):
+    _fields_ = [("kind", C.c_int32), ("grad_mode", C.c_int32), ("params", C.c_double * 16),
+                ("trans", C.c_double * 3), ("rotate", C.c_double * 9), ("bound_radius", C.c_double),
+                ("mesh_vertices", C.POINTER(C.c_double)), ("mesh_faces", C.POINTER(C.c_int32)),
+                ("n_vertices", C.c_int32), ("n_faces", C.c_int32)]
+
+
+class IsdfConfig(C.Structure):
+    _fields_ = [("device", C.c_int32), ("variant", C.c_int32), ("kernel_size", C.c_int32),
+                ("integral_intervs", C.c_int32), ("enable_dyn", C.c_int32), ("enable_pos", C.c_int32),
+                ("enable_cull", C.c_int32), ("reserved0", C.c_int32),
+                ("safety_hor", C.c_double), ("weight_p", C.c_double), ("weight_v", C.c_double),
+                ("weight_omg", C.c_double), ("weight_theta", C.c_double), ("vmax", C.c_double),
+                ("omgmax", C.c_double), ("thetamax", C.c_double), ("smoothing_eps", C.c_double),
+                ("occ_thresh", C.c_double), ("vehicle_mass", C.c_double), ("grav_acc", C.c_double),
+                ("horiz_drag", C.c_double), ("vert_drag", C.c_double), ("paras_drag", C.c_double),
+                ("speed_eps", C.c_double)]
+
+
+class IsdfStats(C.Structure):
+    _fields_ = [("n_units", C.c_int64), ("n_units_culled", C.c_int64), ("n_pairs", C.c_int64),
+                ("n_grad_pairs", C.c_int64), ("overflow", C.c_int32), ("reserved", C.c_int32)]
+
+
+# every symbol include/isdf_accel.h declares (tests check the .so exports all of them)
+EXPORTED_SYMBOLS = [
+    "isdf_config_default", "isdf_shape_default", "isdf_shape_from_name", "isdf_create", "isdf_destroy",
+    "isdf_last_error", "isdf_abi_version", "isdf_set_grid", "isdf_set_shape", "isdf_set_points",
+    "isdf_set_shard", "isdf_eval", "isdf_eval_device", "isdf_out_stride", "isdf_profile_enable",
+    "isdf_profile_read", "isdf_get_stats",
+]
+
+_lib = None
+
+
+def load_library(path=None):
+    """dlopen libisdf_accel.so (built by __graft_entry__.build()).  Raises if it is missing."""
+    global _lib
+    if _lib is not None and path is None:
+        return _lib
+    p = path or LIB_PATH
+    if not os.path.exists(p):
+        raise RuntimeError(f"{p} not found: build the HIP extension first (python -c 'import __graft_entry__ as g; g.build()'). "
+                           "There is no CPU fallback for the product path.")
+    lib = C.CDLL(p)
+    dp = C.POINTER(C.c_double)
+    lib.isdf_config_default.argtypes = [C.POINTER(IsdfConfig)]
+    lib.isdf_config_default.restype = None
+    lib.isdf_shape_default.argtypes = [C.POINTER(IsdfShape), C.c_int]
+    lib.isdf_shape_from_name.argtypes = [C.POINTER(IsdfShape), C.c_char_p]
+    lib.isdf_create.argtypes = [C.POINTER(C.c_void_p), C.POINTER(IsdfConfig)]
+    lib.isdf_destroy.argtypes = [C.c_void_p]
+    lib.isdf_last_error.argtypes = [C.c_void_p]
+    lib.isdf_last_error.restype = C.c_char_p
+    lib.isdf_set_grid.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, dp, dp, C.c_double, C.c_int]
+    lib.isdf_set_shape.argtypes = [C.c_void_p, C.POINTER(IsdfShape)]
+    lib.isdf_set_points.argtypes = [C.c_void_p, dp, C.c_int]
+    lib.isdf_set_shard.argtypes = [C.c_void_p, C.c_int, C.c_int]
+    lib.isdf_eval.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_int), C.POINTER(dp), C.POINTER(dp), dp,
+                              C.POINTER(dp), C.POINTER(dp), dp]
+    lib.isdf_eval_device.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    lib.isdf_out_stride.argtypes = [C.c_int]
+    lib.isdf_out_stride.restype = C.c_size_t
+    lib.isdf_profile_enable.argtypes = [C.c_void_p, C.c_int]
+    lib.isdf_profile_read.argtypes = [C.c_void_p, C.POINTER(C.c_int), dp]
+    lib.isdf_get_stats.argtypes = [C.c_void_p, C.POINTER(IsdfStats)]
+    if path is None:
+        _lib = lib
+    return lib

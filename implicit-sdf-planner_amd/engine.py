@@ -1,0 +1,126 @@
+"""Host-side mirror of the reference's cost-callback plumbing over the C-ABI (include/isdf_accel.h).
+
+``Engine`` plays the role TrajOptimizer's members play around the two sweeps
+(src/planner_algorithm/include/planner_algorithm/back_end_optimizer.hpp:59-62, :386-405, :667-725):
+setParam -> Engine(cfg), setGridMap -> set_grid, setEnvironment/initShape -> set_shape,
+parallel_points -> set_points, and eval() == addSaftyPenaOnSweptVolumeParallel / addTimeIntPenaltyParallel
+with the same ACCUMULATE semantics.  All arithmetic happens in libisdf_accel.so on the GPU; this file only
+marshals numpy arrays / device pointers.  No CPU fallback exists: errors raise IsdfError.
+"""
+import ctypes as C
+import numpy as np
+
+from . import capi
+
+_dp = C.POINTER(C.c_double)
+
+
+class IsdfError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"isdf error {code}: {msg}")
+        self.code = code
+
+
+def _p(a):
+    return a.ctypes.data_as(_dp)
+
+
+class Engine:
+    def __init__(self, cfg, lib=None):
+        self.lib = lib or capi.load_library()
+        self.cfg = cfg
+        h = C.c_void_p()
+        rc = self.lib.isdf_create(C.byref(h), C.byref(cfg))
+        if rc != capi.ISDF_OK:
+            msg = self.lib.isdf_last_error(None)
+            raise IsdfError(rc, (msg or b"").decode())
+        self.h = h
+        self._keep = []
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.isdf_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc):
+        if rc != capi.ISDF_OK:
+            msg = self.lib.isdf_last_error(self.h)
+            raise IsdfError(rc, (msg or b"").decode())
+
+    # ---- once-per-plan state
+    def set_grid(self, vox, origin, res, kind, bmax=None):
+        dt = {np.dtype(np.uint8): capi.U8, np.dtype(np.float32): capi.F32, np.dtype(np.float64): capi.F64}
+        vox = np.ascontiguousarray(vox)
+        o = np.asarray(origin, dtype=np.float64)
+        bm = None if bmax is None else np.asarray(bmax, dtype=np.float64)
+        self._check(self.lib.isdf_set_grid(self.h, vox.ctypes.data_as(C.c_void_p), dt[vox.dtype], vox.shape[0],
+                                           vox.shape[1], vox.shape[2], _p(o), None if bm is None else _p(bm),
+                                           float(res), kind))
+
+    def set_shape(self, shape):
+        self._keep.append(shape)
+        self._check(self.lib.isdf_set_shape(self.h, C.byref(shape)))
+
+    def set_points(self, pts):
+        pts = np.ascontiguousarray(pts, dtype=np.float64).reshape(-1, 3)
+        self._check(self.lib.isdf_set_points(self.h, _p(pts), pts.shape[0]))
+
+    def set_shard(self, rank, world):
+        self._check(self.lib.isdf_set_shard(self.h, rank, world))
+
+    # ---- per-step, host buffers (drop-in semantics: accumulate)
+    def eval(self, T_list, coeffs_list, tstar=None, accumulate_into=None):
+        """T_list[b]: N_b durations; coeffs_list[b]: 18*N_b doubles, column-major 6N x 3.
+        Returns (cost[n_traj], [gradT_b], [gradC_b]); pass accumulate_into=(cost, gTs, gCs) to add into existing
+        buffers exactly like the reference's += on cost / gradT / gradC."""
+        n = len(T_list)
+        Ts = [np.ascontiguousarray(t, dtype=np.float64) for t in T_list]
+        Cs = [np.ascontiguousarray(c, dtype=np.float64).reshape(-1) for c in coeffs_list]
+        Ns = (C.c_int * n)(*[t.size for t in Ts])
+        for t, c in zip(Ts, Cs):
+            if c.size != 18 * t.size:
+                raise ValueError("coeffs must hold 18*N doubles (6N x 3 column-major)")
+        if accumulate_into is None:
+            cost = np.zeros(n)
+            gTs = [np.zeros(t.size) for t in Ts]
+            gCs = [np.zeros(18 * t.size) for t in Ts]
+        else:
+            cost, gTs, gCs = accumulate_into
+        arr = lambda xs: (_dp * n)(*[_p(x) for x in xs])
+        self._check(self.lib.isdf_eval(self.h, n, Ns, arr(Ts), arr(Cs), _p(cost), arr(gTs), arr(gCs),
+                                       None if tstar is None else _p(tstar)))
+        return cost, gTs, gCs
+
+    def eval_single(self, T, coeffs_colmajor, tstar=None):
+        cost, gT, gC = self.eval([T], [coeffs_colmajor], tstar=tstar)
+        return float(cost[0]), gT[0], gC[0]
+
+    # ---- per-step, device-resident (async on `stream`); arguments are raw device pointers (ints)
+    def eval_device(self, n_traj, N, d_T, d_coeffs, d_out, d_tstar=0, stream=0):
+        self._check(self.lib.isdf_eval_device(self.h, n_traj, N, C.c_void_p(d_T), C.c_void_p(d_coeffs),
+                                              C.c_void_p(d_out), C.c_void_p(d_tstar), C.c_void_p(stream)))
+
+    def out_stride(self, N):
+        return int(self.lib.isdf_out_stride(N))
+
+    # ---- instrumentation
+    def stats(self):
+        s = capi.IsdfStats()
+        self._check(self.lib.isdf_get_stats(self.h, C.byref(s)))
+        return {"units": s.n_units, "culled": s.n_units_culled, "pairs": s.n_pairs,
+                "grad_pairs": s.n_grad_pairs, "overflow": s.overflow}
+
+    def profile_enable(self, on=True):
+        self._check(self.lib.isdf_profile_enable(self.h, 1 if on else 0))
+
+    def profile_read(self):
+        n = C.c_int(0)
+        ms = C.c_double(0)
+        self._check(self.lib.isdf_profile_read(self.h, C.byref(n), C.byref(ms)))
+        return n.value, ms.value

@@ -1,0 +1,199 @@
+/*
+ * isdf_accel.h — C ABI of the MI355X-native collision cost/gradient engine.
+ *
+ * This is the drop-in boundary for ONE hot path of ZJU-FAST-Lab/Implicit-SDF-Planner: the per-optimizer-step
+ * sweeps that TrajOptimizer::costFunctionLmbm calls
+ *   (src/planner_algorithm/include/planner_algorithm/back_end_optimizer.hpp:386-391 and :399-405).
+ * Plain C, plain pointers and sizes; no Eigen / torch / C++ types cross it.  Every entry point returns
+ * ISDF_OK (0) or a negative isdf_status and never throws; isdf_last_error() gives the message.
+ *
+ * Conventions (SURVEY.md §8 "Conventions"):
+ *   N  = pieces of one trajectory,  K = integralIntervs (K+1 samples per piece),  M = obstacle points.
+ *   coeffs = the optimizer's Eigen::MatrixX3d, 6N x 3, COLUMN-major: element (r,c) at data[c*6N + r];
+ *            rows 6i..6i+5 are the ascending-power coefficients c0..c5 of piece i (minco.hpp:402,545).
+ *   gradC  has the same layout; gradT and T have N entries.
+ *   Outputs of the host entry points are ACCUMULATED (+=) into caller-owned storage, exactly like
+ *   addSaftyPenaOnSweptVolumeParallel / addTimeIntPenaltyParallel (back_end_optimizer.hpp:557-562, :432-438).
+ *   A ctx may be used by one host thread at a time (the reference's LMBM trampolines are process-global
+ *   statics, lmbm.cpp:4-6, so the reference is not re-entrant either).
+ */
+#ifndef ISDF_ACCEL_H
+#define ISDF_ACCEL_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ISDF_ABI_VERSION 1
+
+typedef enum isdf_status {
+    ISDF_OK = 0,
+    ISDF_ERR_INVALID_ARG = -1,
+    ISDF_ERR_NO_DEVICE = -2,     /* no usable HIP device: the product path has NO CPU fallback */
+    ISDF_ERR_HIP = -3,           /* a HIP runtime call failed; see isdf_last_error */
+    ISDF_ERR_STATE = -4,         /* grid / shape / points not set for the requested sweep */
+    ISDF_ERR_OVERFLOW = -5,      /* a bounded device-side work list overflowed (result NOT valid) */
+    ISDF_ERR_UNSUPPORTED = -6
+} isdf_status;
+
+/* Which sweep isdf_eval runs.  V1 is the reference's live path, V2 its dormant integral path, V3 the
+ * ESDF-tile kernel of BASELINE.json's north_star (SURVEY.md §8 "Variants", Appendix A.3-A.5). */
+typedef enum isdf_variant {
+    ISDF_V1_SWEPT = 1,     /* addSaftyPenaOnSweptVolumeParallel, back_end_optimizer.hpp:557-649            */
+    ISDF_V2_OCC_TILE = 2,  /* addTimeIntPenaltyParallel :432-554 with grad_cost_p :766-824 (occupancy tile)  */
+    ISDF_V3_ESDF_TILE = 3  /* same sweep, voxel qualifies iff esdf <= occ_thresh, optional whole-tile cull   */
+} isdf_variant;
+
+typedef enum isdf_grid_kind { ISDF_GRID_OCCUPANCY = 0, ISDF_GRID_ESDF = 1 } isdf_grid_kind;
+typedef enum isdf_dtype { ISDF_U8 = 0, ISDF_F32 = 1, ISDF_F64 = 2 } isdf_dtype;
+
+/* Robot-shape plugin kinds = the analytic-shape registry of
+ * src/swept_volume/include/swept_volume/sw_manager.hpp:74-123 plus Box/Ball/mesh.
+ * params[] meaning per kind (reference constants are what isdf_shape_default() fills in):
+ *   TORUS              [0]=major radius (2.5 | Torus_big 3.5) [1]=minor radius (0.3)            Shape.hpp:824-893
+ *   CAPPEDTORUS        [0]=sc.x (sin(40 rad)) [1]=sc.y (cos(40 rad)) [2]=ra 3.5 [3]=rb 0.3      Shape.hpp:895-931
+ *   CAPPEDCONE         [0]=ra 2 [1]=rb 0.8 [2..4]=a (0,0,-1) [5..7]=b (0,0,1)                   Shape.hpp:933-998
+ *   ROUNDEDCONE        [0]=r1 1.5 [1]=r2 0.6 [2]=h 4.5                                          Shape.hpp:1000-1047
+ *   WIREFRAMEBOX       [0..2]=size (1.8,2.5,3.5) [3]=thickness 0.1                              Shape.hpp:1049-1103
+ *   BENDLINEAR         [0]=capsule half length (2 | _big 3.2) [1]=radius (0.25 | _big 0.45)     Shape.hpp:1105-1234
+ *   TWISTBOX           [0..2]=size (2,2,2) [3]=k (pi/6)                                         Shape.hpp:1236-1288
+ *   BENDBOX            [0..2]=size (2,2,2) [3]=k (0.5)                                          Shape.hpp:1290-1341
+ *   TABLE              [0..2]=a1 [3..5]=b1 [6..8]=a2 [9..11]=b2                                 Shape.hpp:1343-1405
+ *   TREFOIL            [0]=r 3.5 [1],[2]=box half sizes 0.2 [3]=rounding 0.05 [4]=scale 0.4     Shape.hpp:1442-1515
+ *   SMOOTHDIFFERENCE   [0..2]=box size (3,3,0.5) [3]=sphere radius 1 [4]=k 0.25                 Shape.hpp:1517-1570
+ *   SMOOTHINTERSECTION [0..2]=box size (3,3,0.5 | _big 9,9,1.5) [3]=radius (1 | 3) [4]=k 0.25   Shape.hpp:1572-1682
+ *   CSG                [0]=sphere r 3 [1]=box edge 4.5 [2]=cylinder r 1.5                       Shape.hpp:1684-2317
+ *   BOX                [0..2]=half extents (conf.box_x/y/z)                                     Shape.hpp:2320-2390
+ *   BALL               [0]=radius (Point == radius 0)                                           Shape.hpp:603-665
+ *   MESH               triangle soup: sign from the fast winding number, distance to the closest triangle
+ *                                                                                               Shape.cpp:105-151 */
+typedef enum isdf_shape_kind {
+    ISDF_SHAPE_TORUS = 0,
+    ISDF_SHAPE_CAPPEDTORUS = 1,
+    ISDF_SHAPE_CAPPEDCONE = 2,
+    ISDF_SHAPE_ROUNDEDCONE = 3,
+    ISDF_SHAPE_WIREFRAMEBOX = 4,
+    ISDF_SHAPE_BENDLINEAR = 5,
+    ISDF_SHAPE_TWISTBOX = 6,
+    ISDF_SHAPE_BENDBOX = 7,
+    ISDF_SHAPE_TABLE = 8,
+    ISDF_SHAPE_TREFOIL = 9,
+    ISDF_SHAPE_SMOOTHDIFFERENCE = 10,
+    ISDF_SHAPE_SMOOTHINTERSECTION = 11,
+    ISDF_SHAPE_CSG = 12,
+    ISDF_SHAPE_BOX = 13,
+    ISDF_SHAPE_BALL = 14,
+    ISDF_SHAPE_MESH = 15,
+    ISDF_SHAPE_KIND_COUNT = 16
+} isdf_shape_kind;
+
+/* How getonlyGrad1 / getSDFwithGrad1 form the body-frame gradient. */
+typedef enum isdf_grad_mode {
+    ISDF_GRAD_DEFAULT = 0,      /* what the reference class of this kind does                                  */
+    ISDF_GRAD_CENTRAL = 1,      /* DEFINE_USEFUL_FUNCTION: central difference dx=5e-6, normalised Shape.hpp:32-88 */
+    ISDF_GRAD_BOX_FORWARD = 2,  /* Box::getonlyGrad1: forward difference dx=0.01, NOT normalised  Shape.hpp:2363-2377 */
+    ISDF_GRAD_ANALYTIC_BALL = 3 /* Ball/Point: p / |p|                                           Shape.hpp:622-630 */
+} isdf_grad_mode;
+
+typedef struct isdf_shape {
+    int32_t kind;          /* isdf_shape_kind */
+    int32_t grad_mode;     /* isdf_grad_mode */
+    double params[16];
+    double trans[3];       /* yaml poly_params xyz; every analytic SDF first maps p -> (p - trans) * Rotate */
+    double rotate[9];      /* row-major 3x3 Rotate = yaw*pitch*roll (Shape.cpp:38-43)                       */
+    double bound_radius;   /* >0: a radius R with sdf(p) >= |p - trans| - R for all p (enables the V3 whole-tile
+                              cull); 0 disables the cull for this shape                                       */
+    /* MESH only (already transformed into the body frame exactly as Generalshape's constructor does): */
+    const double *mesh_vertices;  /* nV x 3 row-major */
+    const int32_t *mesh_faces;    /* nF x 3 row-major */
+    int32_t n_vertices;
+    int32_t n_faces;
+} isdf_shape;
+
+/* Mirrors the Config fields the hot path reads (src/utils/include/utils/config.hpp; yaml in
+ * src/plan_manager/config).  Defaults of isdf_config_default() are config_CappedCone.yaml (demo1). */
+typedef struct isdf_config {
+    int32_t device;            /* HIP device ordinal                                                        */
+    int32_t variant;           /* isdf_variant                                                              */
+    int32_t kernel_size;       /* tile edge in voxels; bd = kernel_size * occupancy_resolution (:692)        */
+    int32_t integral_intervs;  /* K                                                                         */
+    int32_t enable_dyn;        /* 1: velocity / body-rate / tilt penalties of addTimeIntPenaltyParallel      */
+    int32_t enable_pos;        /* 1: add the collision term grad_cost_p to that sweep (V2/V3)                */
+    int32_t enable_cull;       /* V3: skip a pose whose trilinear esdf(pos) proves every penalty is zero     */
+    int32_t reserved0;
+    double safety_hor;
+    double weight_p, weight_v, weight_omg, weight_theta;
+    double vmax, omgmax, thetamax;
+    double smoothing_eps;      /* mu of smoothedL1 in the integral sweep (V1 hard-codes 0.01, :851)          */
+    double occ_thresh;         /* V3: voxel qualifies iff esdf <= occ_thresh (0 == "occupied")               */
+    double vehicle_mass, grav_acc, horiz_drag, vert_drag, paras_drag, speed_eps;   /* flatness.hpp:36-51 */
+} isdf_config;
+
+typedef struct isdf_ctx isdf_ctx;   /* opaque; owns all device state */
+
+/* ---- lifetime -------------------------------------------------------------------------------------------- */
+void isdf_config_default(isdf_config *cfg);
+int isdf_shape_default(isdf_shape *shape, int kind);       /* reference constants for an analytic kind   */
+int isdf_shape_from_name(isdf_shape *shape, const char *obj_stem); /* registry lookup, sw_manager.hpp:74-123,
+                                                              e.g. "RoundedCone", "Torus_big"; <0 if the
+                                                              stem is not an analytic shape (=> mesh)     */
+int isdf_create(isdf_ctx **out, const isdf_config *cfg);
+int isdf_destroy(isdf_ctx *ctx);
+const char *isdf_last_error(const isdf_ctx *ctx);          /* ctx may be NULL: last create() failure      */
+int isdf_abi_version(void);
+
+/* ---- once-per-plan state (replaces TrajOptimizer::setGridMap / setEnvironment and the parallel_points
+ *      assembly of plan_manager.cpp:232-254) ------------------------------------------------------------------ */
+/* voxels: nx*ny*nz values, z fastest: addr = ix*ny*nz + iy*nz + iz (GridMap3D.h:194).
+ * origin = boundary_xyzmin; boundary_max = boundary_xyzmax (NULL => origin + n*resolution; the reference
+ * sizes the grid as ceil((max-min)/res), Gridmap3D.cpp:29-31, so max may lie inside the last voxel).
+ * An occupancy grid and an ESDF grid may both be set (same geometry); V2 reads the former, V3 the latter. */
+int isdf_set_grid(isdf_ctx *ctx, const void *voxels, int dtype, int nx, int ny, int nz,
+                  const double origin[3], const double boundary_max[3], double resolution, int grid_kind);
+int isdf_set_shape(isdf_ctx *ctx, const isdf_shape *shape);
+int isdf_set_points(isdf_ctx *ctx, const double *xyz, int M);   /* V1: M x 3 row-major obstacle points  */
+/* Multi-GPU: this ctx evaluates only its share of the constraint points (pieces for V2/V3, obstacle points
+ * for V1); outputs of all ranks SUM to the full result (one all-reduce of [cost|gradT|gradC] per step). */
+int isdf_set_shard(isdf_ctx *ctx, int rank, int world_size);
+
+/* ---- per-step evaluation ----------------------------------------------------------------------------------- */
+/* Host entry point, synchronous, drop-in for the reference sweeps.  n_traj trajectories (1 in the reference);
+ * N[b] pieces each; T[b] -> N[b] doubles; coeffs[b] -> 6N[b] x 3 column-major.
+ * cost_inout[b], gradT_inout[b][..], gradC_inout[b][..] are ACCUMULATED.  tstar_inout (V1 only, may be NULL,
+ * n_traj == 1): lastTstar[M], read and written like TrajOptimizer::lastTstar (:59-62, :576-578). */
+int isdf_eval(isdf_ctx *ctx, int n_traj, const int *N, const double *const *T,
+              const double *const *coeffs, double *cost_inout, double *const *gradT_inout,
+              double *const *gradC_inout, double *tstar_inout);
+
+/* Device-resident entry point, asynchronous on `stream` (a hipStream_t passed as void*; NULL = default
+ * stream).  All trajectories have N pieces.  d_T: n_traj*N, d_coeffs: n_traj * (6N x 3 col-major),
+ * d_out: n_traj * (1 + N + 18N) doubles, OVERWRITTEN with [cost | gradT | gradC(col-major)] per trajectory
+ * (shard-partial sums when a shard is set).  d_tstar: V1 only, M doubles, may be NULL. */
+int isdf_eval_device(isdf_ctx *ctx, int n_traj, int N, const double *d_T, const double *d_coeffs,
+                     double *d_out, double *d_tstar, void *stream);
+size_t isdf_out_stride(int N);   /* 1 + N + 18N */
+
+/* ---- instrumentation --------------------------------------------------------------------------------------- */
+/* When enabled, every isdf_eval_device records HIP events around its dominant kernel on `stream`;
+ * isdf_profile_read synchronises and returns the number of launches recorded since the last read and their
+ * mean duration in milliseconds. */
+int isdf_profile_enable(isdf_ctx *ctx, int on);
+int isdf_profile_read(isdf_ctx *ctx, int *n_launches, double *mean_ms);
+/* Counters of the last evaluation (for tests / roofline bookkeeping). */
+typedef struct isdf_stats {
+    int64_t n_units;          /* constraint-point evaluations (poses for V2/V3, obstacle points for V1)  */
+    int64_t n_units_culled;   /* V3 poses skipped by the whole-tile cull                                  */
+    int64_t n_pairs;          /* (pose, qualifying voxel) robot-SDF evaluations                           */
+    int64_t n_grad_pairs;     /* pairs whose penalty was active (gradient evaluated)                      */
+    int32_t overflow;         /* nonzero: a bounded list overflowed                                       */
+    int32_t reserved;
+} isdf_stats;
+int isdf_get_stats(isdf_ctx *ctx, isdf_stats *out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ISDF_ACCEL_H */

@@ -1,0 +1,225 @@
+"""ctypes binding of oracle/liboracle.so and oracle/_ref/*.so — TEST INFRASTRUCTURE ONLY.
+
+Importable only from tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg.  The product package
+(implicit-sdf-planner_amd/) never imports this module.
+"""
+import ctypes as C
+import os
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB = os.path.join(_HERE, "liboracle.so")
+REF_FLAT = os.path.join(_HERE, "_ref", "libref_flatness.so")
+REF_FWN = os.path.join(_HERE, "_ref", "libref_fwn.so")
+dp = C.POINTER(C.c_double)
+
+
+def _p(a):
+    return a.ctypes.data_as(dp)
+
+
+class Oracle:
+    """CPU restatement with the same once-per-plan / per-step call shape as the product's Engine."""
+
+    def __init__(self, cfg, threads=1):
+        self.lib = C.CDLL(LIB)
+        L = self.lib
+        L.orc_create.restype = C.c_void_p
+        L.orc_create.argtypes = [C.c_void_p]
+        L.orc_destroy.argtypes = [C.c_void_p]
+        L.orc_set_threads.argtypes = [C.c_void_p, C.c_int]
+        L.orc_set_grid.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, dp, dp, C.c_double, C.c_int]
+        L.orc_set_shape.argtypes = [C.c_void_p, C.c_void_p]
+        L.orc_set_points.argtypes = [C.c_void_p, dp, C.c_int]
+        L.orc_eval.argtypes = [C.c_void_p, C.c_int, dp, dp, dp, dp, dp, dp, C.POINTER(C.c_longlong)]
+        L.orc_shape_eval.argtypes = [C.c_void_p, dp, C.c_int, dp, dp]
+        L.orc_esdf_trilinear.argtypes = [C.c_void_p, dp, dp]
+        L.orc_esdf_trilinear.restype = C.c_double
+        L.orc_aabb_index_box.argtypes = [C.c_void_p, dp, C.c_double, C.POINTER(C.c_int), C.POINTER(C.c_int)]
+        L.orc_swept_sdf.argtypes = [C.c_void_p, C.c_int, dp, dp, dp, dp, dp, C.POINTER(C.c_int)]
+        L.orc_swept_sdf.restype = C.c_double
+        self.cfg = cfg
+        self.h = C.c_void_p(L.orc_create(C.byref(cfg)))
+        L.orc_set_threads(self.h, threads)
+        self._keep = []
+
+    def __del__(self):
+        try:
+            self.lib.orc_destroy(self.h)
+        except Exception:
+            pass
+
+    def set_threads(self, n):
+        self.lib.orc_set_threads(self.h, n)
+
+    def set_grid(self, vox, origin, res, kind, bmax=None):
+        from_dtype = {np.dtype(np.uint8): 0, np.dtype(np.float32): 1, np.dtype(np.float64): 2}
+        vox = np.ascontiguousarray(vox)
+        o = np.asarray(origin, dtype=np.float64)
+        bm = None if bmax is None else np.asarray(bmax, dtype=np.float64)
+        self.lib.orc_set_grid(self.h, vox.ctypes.data_as(C.c_void_p), from_dtype[vox.dtype], vox.shape[0], vox.shape[1],
+                              vox.shape[2], _p(o), None if bm is None else _p(bm), float(res), kind)
+
+    def set_shape(self, shape):
+        self._keep.append(shape)
+        self.lib.orc_set_shape(self.h, C.byref(shape))
+
+    def set_points(self, pts):
+        pts = np.ascontiguousarray(pts, dtype=np.float64)
+        self.lib.orc_set_points(self.h, _p(pts), pts.shape[0])
+
+    def eval(self, T, coeffs_colmajor, tstar=None, accumulate_into=None):
+        """Returns (cost, gradT[N], gradC[18N col-major], stats[4])."""
+        T = np.ascontiguousarray(T, dtype=np.float64)
+        Cc = np.ascontiguousarray(coeffs_colmajor, dtype=np.float64)
+        N = T.size
+        if accumulate_into is None:
+            cost = np.zeros(1); gT = np.zeros(N); gC = np.zeros(18 * N)
+        else:
+            cost, gT, gC = accumulate_into
+        st = (C.c_longlong * 4)()
+        self.lib.orc_eval(self.h, N, _p(T), _p(Cc), _p(cost), _p(gT), _p(gC), None if tstar is None else _p(tstar), st)
+        return float(cost[0]), gT, gC, list(st)
+
+    def shape_eval(self, pts):
+        pts = np.ascontiguousarray(pts, dtype=np.float64).reshape(-1, 3)
+        n = pts.shape[0]
+        s = np.zeros(n); g = np.zeros((n, 3))
+        self.lib.orc_shape_eval(self.h, _p(pts), n, _p(s), _p(g))
+        return s, g
+
+    def esdf_trilinear(self, pos):
+        pos = np.asarray(pos, dtype=np.float64)
+        g = np.zeros(3)
+        d = self.lib.orc_esdf_trilinear(self.h, _p(pos), _p(g))
+        return d, g
+
+    def aabb_index_box(self, pos, half):
+        pos = np.asarray(pos, dtype=np.float64)
+        lo = (C.c_int * 3)(); hi = (C.c_int * 3)()
+        self.lib.orc_aabb_index_box(self.h, _p(pos), float(half), lo, hi)
+        return list(lo), list(hi)
+
+    def swept_sdf(self, T, coeffs_colmajor, p, tstar0=0.0):
+        T = np.ascontiguousarray(T, dtype=np.float64)
+        Cc = np.ascontiguousarray(coeffs_colmajor, dtype=np.float64)
+        p = np.asarray(p, dtype=np.float64)
+        ts = np.array([tstar0]); g = np.zeros(3); nr = C.c_int(0)
+        s = self.lib.orc_swept_sdf(self.h, T.size, _p(T), _p(Cc), _p(p), _p(ts), _p(g), C.byref(nr))
+        return s, float(ts[0]), g, nr.value
+
+
+# ---- free functions --------------------------------------------------------------------------------------
+def _lib():
+    L = C.CDLL(LIB)
+    L.orc_smoothed_l1.restype = C.c_double
+    L.orc_smoothed_l1.argtypes = [C.c_double, C.c_double, dp]
+    L.orc_minco_energy.restype = C.c_double
+    return L
+
+
+def flat_forward(fp, vel, acc, jer, lib=None, prefix="orc"):
+    L = lib or C.CDLL(LIB)
+    fp, vel, acc, jer = (np.asarray(a, dtype=np.float64) for a in (fp, vel, acc, jer))
+    q = np.zeros(4); w = np.zeros(3)
+    if prefix == "orc":
+        L.orc_flat_forward(_p(fp), _p(vel), _p(acc), _p(jer), _p(q), _p(w))
+        return q, w
+    q2 = np.zeros(4)
+    L.ref_flat_forward(_p(fp), _p(vel), _p(acc), _p(jer), _p(q), _p(w), _p(q2))
+    assert np.array_equal(q, q2)
+    return q, w
+
+
+def flat_backward(fp, vel, acc, jer, pg, vg, qg, og, lib=None, prefix="orc"):
+    L = lib or C.CDLL(LIB)
+    arrs = [np.asarray(a, dtype=np.float64) for a in (fp, vel, acc, jer, pg, vg, qg, og)]
+    out = np.zeros(12)
+    fn = L.orc_flat_backward if prefix == "orc" else L.ref_flat_backward
+    fn(*[_p(a) for a in arrs], _p(out))
+    return out.reshape(4, 3)
+
+
+def ref_flat_lib():
+    return C.CDLL(REF_FLAT) if os.path.exists(REF_FLAT) else None
+
+
+def quat_to_rot(q):
+    L = C.CDLL(LIB)
+    q = np.asarray(q, dtype=np.float64); R = np.zeros(9)
+    L.orc_quat_to_rot(_p(q), _p(R))
+    return R.reshape(3, 3)
+
+
+def smoothed_l1(x, mu):
+    L = _lib()
+    df = C.c_double(0)
+    f = L.orc_smoothed_l1(float(x), float(mu), C.byref(df))
+    return f, df.value
+
+
+def build_esdf(occ, res):
+    L = C.CDLL(LIB)
+    occ = np.ascontiguousarray(occ, dtype=np.uint8)
+    out = np.zeros(occ.shape, dtype=np.float64)
+    L.orc_build_esdf(occ.ctypes.data_as(C.c_void_p), occ.shape[0], occ.shape[1], occ.shape[2], C.c_double(res), _p(out))
+    return out
+
+
+def traj_eval(T, coeffs_colmajor, t):
+    L = C.CDLL(LIB)
+    T = np.ascontiguousarray(T, dtype=np.float64); Cc = np.ascontiguousarray(coeffs_colmajor, dtype=np.float64)
+    out = np.zeros(12); piece = C.c_int(0); tl = C.c_double(0)
+    L.orc_traj_eval(C.c_int(T.size), _p(T), _p(Cc), C.c_double(t), _p(out), C.byref(piece), C.byref(tl))
+    return out.reshape(4, 3), piece.value, tl.value
+
+
+def minco_coeffs(head, tail, in_pts, T):
+    """head/tail 3x3 (cols pos,vel,acc), in_pts 3x(N-1) -> 6N x 3 array."""
+    L = C.CDLL(LIB)
+    T = np.ascontiguousarray(T, dtype=np.float64); N = T.size
+    h = np.ascontiguousarray(np.asarray(head, dtype=np.float64).T).reshape(-1)
+    t = np.ascontiguousarray(np.asarray(tail, dtype=np.float64).T).reshape(-1)
+    P = np.ascontiguousarray(np.asarray(in_pts, dtype=np.float64).T).reshape(-1)
+    out = np.zeros(18 * N)
+    L.orc_minco_coeffs(C.c_int(N), _p(h), _p(t), _p(P), _p(T), _p(out))
+    return out.reshape(3, 6 * N).T.copy()
+
+
+def minco_energy(coeffs_colmajor, T):
+    L = _lib()
+    T = np.ascontiguousarray(T, dtype=np.float64); N = T.size
+    Cc = np.ascontiguousarray(coeffs_colmajor, dtype=np.float64)
+    gC = np.zeros(18 * N); gT = np.zeros(N)
+    L.orc_minco_energy.argtypes = [C.c_int, dp, dp, dp, dp]
+    e = L.orc_minco_energy(N, _p(Cc), _p(T), _p(gC), _p(gT))
+    return e, gC, gT
+
+
+def minco_propagate(head, tail, in_pts, T, gradC, gradT):
+    L = C.CDLL(LIB)
+    T = np.ascontiguousarray(T, dtype=np.float64); N = T.size
+    h = np.ascontiguousarray(np.asarray(head, dtype=np.float64).T).reshape(-1)
+    t = np.ascontiguousarray(np.asarray(tail, dtype=np.float64).T).reshape(-1)
+    P = np.ascontiguousarray(np.asarray(in_pts, dtype=np.float64).T).reshape(-1)
+    gC = np.ascontiguousarray(gradC, dtype=np.float64); gT = np.ascontiguousarray(gradT, dtype=np.float64)
+    gP = np.zeros(3 * (N - 1)); gTo = np.zeros(N)
+    L.orc_minco_propagate(C.c_int(N), _p(h), _p(t), _p(P), _p(T), _p(gC), _p(gT), _p(gP), _p(gTo))
+    return gP.reshape(N - 1, 3).T.copy(), gTo
+
+
+class RefFwn:
+    """The vendored HDK fast winding number (oracle/_ref/libref_fwn.so)."""
+
+    def __init__(self, V, F, order=2):
+        self.lib = C.CDLL(REF_FWN)
+        self.lib.ref_fwn_create.restype = C.c_void_p
+        self.V = np.ascontiguousarray(V, dtype=np.float64); self.F = np.ascontiguousarray(F, dtype=np.int32)
+        self.h = C.c_void_p(self.lib.ref_fwn_create(_p(self.V), C.c_int(self.V.shape[0]),
+                                                    self.F.ctypes.data_as(C.c_void_p), C.c_int(self.F.shape[0]), C.c_int(order)))
+
+    def eval(self, Q, accuracy=2.0):
+        Q = np.ascontiguousarray(Q, dtype=np.float64).reshape(-1, 3)
+        W = np.zeros(Q.shape[0])
+        self.lib.ref_fwn_eval(self.h, _p(Q), C.c_int(Q.shape[0]), C.c_double(accuracy), _p(W))
+        return W
