@@ -1,0 +1,196 @@
+#!/usr/bin/env python
+"""bench.py — headline benchmark of the collision cost/gradient hot path on MI355X.
+
+Metric (BASELINE.json): SDF cost+grad point-evals/sec on a 256^3 map.  A "step" is one pass of the V3 ESDF-tile sweep
+(include/isdf_accel.h: isdf_eval_device) over every constraint sample of the trajectory; one "point-eval" is one sampled
+pose (piece i, sample j) incl. its kernel_size^3 ESDF tile.  Inputs are resident in HBM before the timed
+region; results stay on the device (the PCIe-inclusive host-API rate is reported separately as `host_api_ms`, never as
+`value`).
+
+Workload at 1 GPU = BASELINE.json configs[1]: one trajectory, 40 pieces x 64 intervals (65 samples / piece), 256^3 fp32 ESDF
+at 0.2 m, kernel_size 21, convex box robot (half extents 1.6/0.3/0.3 m, central-difference gradient).
+At N GPUs (weak scaling): one trajectory of 40*N pieces, pieces sharded contiguously across ranks, one all-reduce (RCCL)
+of the packed [cost | gradT | gradC] vector per step.
+
+Launch: python bench.py [--gpus N --steps K --warmup W]; for N>1 via torch.distributed.run (one rank per GPU).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+import __graft_entry__ as graft  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md
+
+
+def algorithmic_bytes_per_eval(k, s_vox=4):
+    """tile staged once + trilinear corners + 6x3 coefficients + T_i + 19 partial outputs."""
+    return k ** 3 * s_vox + 8 * s_vox + 144 + 8 + 152
+
+
+def build_workload(pkg, n_pieces, grid_n, res, seed_map=12345, seed_traj=777):
+    synth = pkg.synth
+    occ = synth.random_box_map((grid_n,) * 3, res=res, occupancy=0.15, seed=seed_map)
+    esdf = synth.esdf_from_occupancy(occ, res)
+    ext = np.array(occ.shape) * res
+    T, Cf = synth.random_trajectory(ext, n_pieces, seed=seed_traj, piece_T=1.0, jitter=0.5, margin=4.0, occ=occ, res=res)
+    return occ, esdf, T, synth.colmajor(Cf)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--pieces-per-gpu", type=int, default=40)
+    ap.add_argument("--grid", type=int, default=256)
+    ap.add_argument("--kernel-size", type=int, default=21)
+    ap.add_argument("--cull", type=int, default=0, help="1: enable the V3 whole-tile cull (reported separately, never as value)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N > 1")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the product path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    pkg = graft.load_package()
+    capi, synth = pkg.capi, pkg.synth
+    res = 0.2 * 256.0 / args.grid if args.grid != 256 else 0.2
+    K = 64
+    n_pieces = args.pieces_per_gpu * world
+    occ, esdf, T, cm = build_workload(pkg, n_pieces, args.grid, res)
+    shape = synth.bench_box_shape()
+    cfg = synth.default_config(capi.V3_ESDF_TILE, device=local_rank, kernel_size=args.kernel_size, integral_intervs=K,
+                               safety_hor=(3 ** 0.5 / 2) * res, weight_p=4000.0, smoothing_eps=0.01, enable_dyn=1,
+                               enable_pos=1, enable_cull=args.cull)
+    eng = pkg.Engine(cfg)
+    eng.set_grid(esdf, (0, 0, 0), res, capi.GRID_ESDF)
+    eng.set_shape(shape)
+    eng.set_shard(rank, world)
+
+    N = n_pieces
+    d_T = torch.from_numpy(T).to(dev)
+    d_C = torch.from_numpy(cm).to(dev)
+    d_out = torch.zeros(eng.out_stride(N), dtype=torch.float64, device=dev)
+    stream = torch.cuda.current_stream().cuda_stream
+
+    def step():
+        eng.eval_device(1, N, d_T.data_ptr(), d_C.data_ptr(), d_out.data_ptr(), 0, stream)
+        if world > 1:
+            dist.all_reduce(d_out)   # RCCL sum of [cost | gradT | gradC] over xGMI
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    eng.profile_enable(True)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    t1 = time.perf_counter()
+    n_launch, kern_ms = eng.profile_read()
+    eng.profile_enable(False)
+    elapsed = t1 - t0
+    if world > 1:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+
+    evals_per_step = N * (K + 1)
+    value = evals_per_step * args.steps / elapsed
+    ms_per_step = 1e3 * elapsed / args.steps
+    stats = eng.stats()
+    out_gpu = d_out.cpu().numpy().copy()
+
+    # roofline of the dominant kernel (tile_sweep_kernel): algorithmic bytes of the samples THIS rank's launch processed
+    B = algorithmic_bytes_per_eval(args.kernel_size)
+    evals_this_rank = (N // world) * (K + 1)
+    achieved = (evals_this_rank * B) / (kern_ms * 1e-3) / 1e9 if kern_ms > 0 else 0.0
+    roofline = {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                "kernel": "tile_sweep_kernel", "kernel_ms": round(kern_ms, 5), "launches": n_launch,
+                "algorithmic_bytes_per_eval": B}
+
+    result = None
+    if rank == 0:
+        # host-API (PCIe-inclusive, synchronous, accumulate) latency — informational
+        host_ms = None
+        if world == 1:
+            eng.set_shard(0, 1)
+            eng.eval_single(T, cm)
+            th0 = time.perf_counter()
+            for _ in range(20):
+                eng.eval_single(T, cm)
+            host_ms = 1e3 * (time.perf_counter() - th0) / 20
+
+        cpu = None
+        parity = None
+        if not args.no_cpu_baseline:
+            # cpu_baseline leg: the oracle (CPU restatement of the reference's OpenMP sweep) on the SAME workload,
+            # bounded to ~cpu-seconds of wall time.  This is the only place bench.py touches oracle/.
+            orc = graft.load_oracle()
+            threads = os.cpu_count() or 1
+            o = orc.Oracle(cfg, threads=threads)
+            o.set_grid(esdf, (0, 0, 0), res, capi.GRID_ESDF)
+            o.set_shape(shape)
+            c0, gT0, gC0, _ = o.eval(T, cm)   # warm-up + parity reference
+            n_cpu = 0
+            tc0 = time.perf_counter()
+            while True:
+                o.eval(T, cm)
+                n_cpu += 1
+                if time.perf_counter() - tc0 > args.cpu_seconds:
+                    break
+            cpu_el = time.perf_counter() - tc0
+            cpu = {"value": round(evals_per_step * n_cpu / cpu_el, 1), "unit": "point-evals/s", "cores": threads, "kind": "port",
+                   "sample": f"{n_cpu} full steps of the same workload ({evals_per_step} evals each) in {cpu_el:.1f} s, "
+                             f"oracle OpenMP schedule(dynamic), {threads} threads",
+                   "ms_per_step": round(1e3 * cpu_el / n_cpu, 2)}
+            ref = np.concatenate([[c0], gT0, gC0])
+            parity = float(np.linalg.norm(out_gpu - ref) / max(np.linalg.norm(ref), 1e-300))
+        result = {
+            "metric": "SDF cost+grad point-evals/sec", "value": round(value, 1), "unit": "point-evals/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 5),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": f"V3 ESDF-tile sweep: 1 trajectory x {N} pieces x {K + 1} samples/piece, {args.grid}^3 fp32 ESDF "
+                                   f"@ {res:g} m, kernel_size {args.kernel_size}, box robot (1.6,0.3,0.3) central-diff grad, "
+                                   f"cull {'on' if args.cull else 'off'}",
+                       "pieces": N, "samples_per_piece": K + 1, "grid": args.grid, "kernel_size": args.kernel_size,
+                       "sharding": "pieces contiguous by rank + all_reduce(sum) of 1+19N doubles" if world > 1 else "none"},
+            "roofline": roofline, "cpu_baseline": cpu,
+            "parity_rel_err_vs_oracle": parity, "host_api_ms": None if host_ms is None else round(host_ms, 4),
+            "stats_last_step_rank0": stats,
+        }
+        print(json.dumps(result), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

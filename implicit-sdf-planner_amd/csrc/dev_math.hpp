@@ -1,0 +1,249 @@
+// Device-side fp64 math of the collision sweeps (gfx950).  Product code: hand-written for the GPU, it shares
+// NOTHING with oracle/ — parity is established by tests, not by construction.
+//   quat_to_rot          Eigen::Quaterniond::toRotationMatrix as used at back_end_optimizer.hpp:492,614
+//   smoothed_l1          back_end_optimizer.hpp:332-356
+//   flat_forward/backward src/utils/include/utils/flatness.hpp:53-148, :230-406
+//   poly_basis           back_end_optimizer.hpp:472-488 (beta0..beta4)
+#pragma once
+#include <hip/hip_runtime.h>
+
+namespace isdf {
+
+struct d3 { double x, y, z; };
+struct d4 { double w, x, y, z; };
+struct m3 { double a[9]; };   // row-major
+
+__device__ __forceinline__ d3 mk3(double x, double y, double z) { d3 r; r.x = x; r.y = y; r.z = z; return r; }
+__device__ __forceinline__ d3 operator+(d3 a, d3 b) { return mk3(a.x + b.x, a.y + b.y, a.z + b.z); }
+__device__ __forceinline__ d3 operator-(d3 a, d3 b) { return mk3(a.x - b.x, a.y - b.y, a.z - b.z); }
+__device__ __forceinline__ d3 operator*(double s, d3 a) { return mk3(s * a.x, s * a.y, s * a.z); }
+__device__ __forceinline__ double dot3(d3 a, d3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+__device__ __forceinline__ double norm3(d3 a) { return sqrt(dot3(a, a)); }
+// Eigen normalized(): unchanged when the squared norm is not > 0
+__device__ __forceinline__ d3 normalized3(d3 a) {
+    const double z = dot3(a, a);
+    if (z > 0.0) { const double n = sqrt(z); return mk3(a.x / n, a.y / n, a.z / n); }
+    return a;
+}
+__device__ __forceinline__ d3 mat_mul(const m3 &R, d3 v) {
+    return mk3(R.a[0] * v.x + R.a[1] * v.y + R.a[2] * v.z, R.a[3] * v.x + R.a[4] * v.y + R.a[5] * v.z,
+               R.a[6] * v.x + R.a[7] * v.y + R.a[8] * v.z);
+}
+__device__ __forceinline__ d3 mat_tmul(const m3 &R, d3 v) {   // R^T v
+    return mk3(R.a[0] * v.x + R.a[3] * v.y + R.a[6] * v.z, R.a[1] * v.x + R.a[4] * v.y + R.a[7] * v.z,
+               R.a[2] * v.x + R.a[5] * v.y + R.a[8] * v.z);
+}
+
+__device__ __forceinline__ m3 quat_to_rot(d4 q) {
+    const double tx = 2.0 * q.x, ty = 2.0 * q.y, tz = 2.0 * q.z;
+    const double twx = tx * q.w, twy = ty * q.w, twz = tz * q.w;
+    const double txx = tx * q.x, txy = ty * q.x, txz = tz * q.x;
+    const double tyy = ty * q.y, tyz = tz * q.y, tzz = tz * q.z;
+    m3 R;
+    R.a[0] = 1.0 - (tyy + tzz); R.a[1] = txy - twz;         R.a[2] = txz + twy;
+    R.a[3] = txy + twz;         R.a[4] = 1.0 - (txx + tzz); R.a[5] = tyz - twx;
+    R.a[6] = txz - twy;         R.a[7] = tyz + twx;         R.a[8] = 1.0 - (txx + tyy);
+    return R;
+}
+
+// returns false (f, df untouched) for x < 0
+__device__ __forceinline__ bool smoothed_l1(double x, double mu, double &f, double &df) {
+    if (x < 0.0) return false;
+    if (x > mu) { f = x - 0.5 * mu; df = 1.0; return true; }
+    const double xdmu = x / mu;
+    const double sq = xdmu * xdmu;
+    const double mumxd2 = mu - 0.5 * x;
+    f = mumxd2 * sq * xdmu;
+    df = sq * ((-0.5) * xdmu + 3.0 * mumxd2 / mu);
+    return true;
+}
+
+// g^T * dR^T/dq_k * d for k = w,x,y,z (the four matrices of back_end_optimizer.hpp:127-173, multiplied out)
+__device__ __forceinline__ d4 quat_step_grad(d4 q, d3 g, d3 d) {
+    const double w = q.w, x = q.x, y = q.y, z = q.z;
+    d4 r;
+    {   // DW = [0 2z -2y; -2z 0 2x; 2y -2x 0];  (g^T DW) = columns
+        const double c0 = g.y * (-2 * z) + g.z * (2 * y);
+        const double c1 = g.x * (2 * z) + g.z * (-2 * x);
+        const double c2 = g.x * (-2 * y) + g.y * (2 * x);
+        r.w = c0 * d.x + c1 * d.y + c2 * d.z;
+    }
+    {   // DX = [0 2y 2z; 2y -4x 2w; 2z -2w -4x]
+        const double c0 = g.y * (2 * y) + g.z * (2 * z);
+        const double c1 = g.x * (2 * y) + g.y * (-4 * x) + g.z * (-2 * w);
+        const double c2 = g.x * (2 * z) + g.y * (2 * w) + g.z * (-4 * x);
+        r.x = c0 * d.x + c1 * d.y + c2 * d.z;
+    }
+    {   // DY = [-4y 2x -2w; 2x 0 2z; 2w 2z -4y]
+        const double c0 = g.x * (-4 * y) + g.y * (2 * x) + g.z * (2 * w);
+        const double c1 = g.x * (2 * x) + g.z * (2 * z);
+        const double c2 = g.x * (-2 * w) + g.y * (2 * z) + g.z * (-4 * y);
+        r.y = c0 * d.x + c1 * d.y + c2 * d.z;
+    }
+    {   // DZ = [-4z 2w 2x; -2w -4z 2y; 2x 2y 0]
+        const double c0 = g.x * (-4 * z) + g.y * (-2 * w) + g.z * (2 * x);
+        const double c1 = g.x * (2 * w) + g.y * (-4 * z) + g.z * (2 * y);
+        const double c2 = g.x * (2 * x) + g.y * (2 * y);
+        r.z = c0 * d.x + c1 * d.y + c2 * d.z;
+    }
+    return r;
+}
+
+struct FlatP { double mass, grav, dh, dv, cp, veps, dh_over_m; };
+
+// Shared forward intermediates of the flatness map.
+struct FlatS {
+    double cp_term, w_term, zu0, zu1, zu2, s0, s1, s2, zu_sqr_norm, zu_norm, z0, z1, z2, tilt_den;
+};
+__device__ __forceinline__ void flat_core(const FlatP &P, d3 v, d3 a, FlatS &s) {
+    s.cp_term = sqrt(v.x * v.x + v.y * v.y + v.z * v.z + P.veps);
+    s.w_term = 1.0 + P.cp * s.cp_term;
+    s.zu0 = a.x + P.dh_over_m * (s.w_term * v.x);
+    s.zu1 = a.y + P.dh_over_m * (s.w_term * v.y);
+    s.zu2 = a.z + P.dh_over_m * (s.w_term * v.z) + P.grav;
+    s.s0 = s.zu0 * s.zu0; s.s1 = s.zu1 * s.zu1; s.s2 = s.zu2 * s.zu2;
+    s.zu_sqr_norm = s.s0 + s.s1 + s.s2;
+    s.zu_norm = sqrt(s.zu_sqr_norm);
+    s.z0 = s.zu0 / s.zu_norm; s.z1 = s.zu1 / s.zu_norm; s.z2 = s.zu2 / s.zu_norm;
+    s.tilt_den = sqrt(2.0 * (1.0 + s.z2));
+}
+__device__ __forceinline__ d4 flat_quat(const FlatS &s) {
+    d4 q; q.w = 0.5 * s.tilt_den; q.x = -s.z1 / s.tilt_den; q.y = s.z0 / s.tilt_den; q.z = 0.0; return q;
+}
+struct FlatS2 {
+    double ng_den, ng00, ng01, ng02, ng11, ng12, ng22, zu01, zu12, zu02, v_dot_a, dw_term;
+    double dw0, dw1, dw2, dzt0, dzt1, dzt2, dz0, dz1, dz2, omg_den, omg_term;
+};
+__device__ __forceinline__ void flat_core2(const FlatP &P, d3 v, d3 a, d3 j, const FlatS &s, FlatS2 &t) {
+    t.ng_den = s.zu_sqr_norm * s.zu_norm;
+    t.ng00 = (s.s1 + s.s2) / t.ng_den;
+    t.zu01 = s.zu0 * s.zu1; t.zu12 = s.zu1 * s.zu2; t.zu02 = s.zu0 * s.zu2;
+    t.ng01 = -t.zu01 / t.ng_den;
+    t.ng02 = -t.zu02 / t.ng_den;
+    t.ng11 = (s.s0 + s.s2) / t.ng_den;
+    t.ng12 = -t.zu12 / t.ng_den;
+    t.ng22 = (s.s0 + s.s1) / t.ng_den;
+    t.v_dot_a = v.x * a.x + v.y * a.y + v.z * a.z;
+    t.dw_term = P.cp * t.v_dot_a / s.cp_term;
+    t.dw0 = s.w_term * a.x + t.dw_term * v.x;
+    t.dw1 = s.w_term * a.y + t.dw_term * v.y;
+    t.dw2 = s.w_term * a.z + t.dw_term * v.z;
+    t.dzt0 = j.x + P.dh_over_m * t.dw0;
+    t.dzt1 = j.y + P.dh_over_m * t.dw1;
+    t.dzt2 = j.z + P.dh_over_m * t.dw2;
+    t.dz0 = t.ng00 * t.dzt0 + t.ng01 * t.dzt1 + t.ng02 * t.dzt2;
+    t.dz1 = t.ng01 * t.dzt0 + t.ng11 * t.dzt1 + t.ng12 * t.dzt2;
+    t.dz2 = t.ng02 * t.dzt0 + t.ng12 * t.dzt1 + t.ng22 * t.dzt2;
+    t.omg_den = s.z2 + 1.0;
+    t.omg_term = t.dz2 / t.omg_den;
+}
+__device__ __forceinline__ d3 flat_omg(const FlatS &s, const FlatS2 &t) {
+    return mk3(-t.dz1 + s.z1 * t.omg_term, t.dz0 - s.z0 * t.omg_term, (s.z1 * t.dz0 - s.z0 * t.dz1) / t.omg_den);
+}
+
+// Reverse mode of (v,a,j) -> (quat, omega) with psi == 0; inputs are dL/dpos, dL/dvel, dL/dquat, dL/domega.
+__device__ __forceinline__ void flat_backward(const FlatP &P, d3 v, d3 a, d3 jer, d3 pos_grad, d3 vel_grad,
+                                              d4 quat_grad, d3 omg_grad, d3 &gP, d3 &gV, d3 &gA, d3 &gJ) {
+    FlatS s; FlatS2 t;
+    flat_core(P, v, a, s);
+    flat_core2(P, v, a, jer, s, t);
+    const double tilt0b = quat_grad.w, tilt1b = quat_grad.x, tilt2b = quat_grad.y;
+    const double tilt_den_sqr = s.tilt_den * s.tilt_den;
+    const double tilt_denb = (s.z1 * tilt1b - s.z0 * tilt2b) / tilt_den_sqr + 0.5 * tilt0b;
+    const double omg_termb = -s.z0 * omg_grad.y + s.z1 * omg_grad.x;
+    double tb = omg_grad.z / t.omg_den;
+    double z1b = t.dz0 * tb;
+    const double dz0b = s.z1 * tb + omg_grad.y;
+    double z0b = -(t.dz1 * tb);
+    const double dz1b = -s.z0 * tb - omg_grad.x;
+    const double omg_denb = -((s.z1 * t.dz0 - s.z0 * t.dz1) * tb / t.omg_den) - t.dz2 * omg_termb / (t.omg_den * t.omg_den);
+    tb = -(t.omg_term * omg_grad.y);
+    z0b += tb;
+    tb = -(t.omg_term * omg_grad.x);
+    z0b += tilt2b / s.tilt_den;
+    z1b += -tb - tilt1b / s.tilt_den;
+    const double dz2b = omg_termb / t.omg_den;
+    const double z2b = omg_denb + tilt_denb / s.tilt_den;
+
+    const double ng02b = t.dzt0 * dz2b + t.dzt2 * dz0b;
+    const double dzt0b = t.ng02 * dz2b + t.ng01 * dz1b + t.ng00 * dz0b;
+    const double ng12b = t.dzt1 * dz2b + t.dzt2 * dz1b;
+    const double dzt1b = t.ng12 * dz2b + t.ng11 * dz1b + t.ng01 * dz0b;
+    const double ng22b = t.dzt2 * dz2b;
+    const double dzt2b = t.ng22 * dz2b + t.ng12 * dz1b + t.ng02 * dz0b;
+    const double ng01b = t.dzt0 * dz1b + t.dzt1 * dz0b;
+    const double ng11b = t.dzt1 * dz1b;
+    const double ng00b = t.dzt0 * dz0b;
+    gJ = mk3(dzt0b, dzt1b, dzt2b);
+    const double dw0b = P.dh_over_m * dzt0b, dw1b = P.dh_over_m * dzt1b, dw2b = P.dh_over_m * dzt2b;
+    tb = P.cp * (v.z * dw2b + v.y * dw1b + v.x * dw0b) / s.cp_term;
+    gA = mk3(s.w_term * dw0b + v.x * tb, s.w_term * dw1b + v.y * tb, s.w_term * dw2b + v.z * tb);
+    gV = mk3(t.dw_term * dw0b + a.x * tb, t.dw_term * dw1b + a.y * tb, t.dw_term * dw2b + a.z * tb);
+    double cp_termb = -(t.v_dot_a * tb / s.cp_term);
+    tb = ng22b / t.ng_den;
+    double zs0b = tb, zs1b = tb;
+    double ng_denb = -((s.s0 + s.s1) * tb / t.ng_den);
+    const double zu12b = -(ng12b / t.ng_den);
+    tb = ng11b / t.ng_den;
+    ng_denb += t.zu12 * ng12b / (t.ng_den * t.ng_den) - (s.s0 + s.s2) * tb / t.ng_den;
+    zs0b += tb;
+    double zs2b = tb;
+    const double zu02b = -(ng02b / t.ng_den);
+    const double zu01b = -(ng01b / t.ng_den);
+    tb = ng00b / t.ng_den;
+    ng_denb += t.zu02 * ng02b / (t.ng_den * t.ng_den) + t.zu01 * ng01b / (t.ng_den * t.ng_den) - (s.s1 + s.s2) * tb / t.ng_den;
+    const double zu_normb = s.zu_sqr_norm * ng_denb - (s.zu2 * z2b + s.zu1 * z1b + s.zu0 * z0b) / s.zu_sqr_norm;
+    const double zu_sqr_normb = s.zu_norm * ng_denb + zu_normb / (2.0 * s.zu_norm);
+    tb += zu_sqr_normb;
+    zs1b += tb;
+    zs2b += tb;
+    const double zu2b = z2b / s.zu_norm + s.zu0 * zu02b + s.zu1 * zu12b + 2 * s.zu2 * zs2b;
+    const double w2b = P.dh_over_m * zu2b;
+    const double zu1b = z1b / s.zu_norm + s.zu2 * zu12b + s.zu0 * zu01b + 2 * s.zu1 * zs1b;
+    const double w1b = P.dh_over_m * zu1b;
+    zs0b += zu_sqr_normb;
+    const double zu0b = z0b / s.zu_norm + s.zu2 * zu02b + s.zu1 * zu01b + 2 * s.zu0 * zs0b;
+    const double w0b = P.dh_over_m * zu0b;
+    const double w_termb = a.z * dw2b + a.y * dw1b + a.x * dw0b + v.z * w2b + v.y * w1b + v.x * w0b;
+    gA.x += zu0b; gA.y += zu1b; gA.z += zu2b;
+    cp_termb += P.cp * w_termb;
+    const double vsb = cp_termb / (2.0 * s.cp_term);
+    gV.x += s.w_term * w0b + 2 * v.x * vsb + vel_grad.x;
+    gV.y += s.w_term * w1b + 2 * v.y * vsb + vel_grad.y;
+    gV.z += s.w_term * w2b + 2 * v.z * vsb + vel_grad.z;
+    gP = pos_grad;
+}
+
+// Piece-local monomial bases at local time s1.
+struct Basis { double b0[6], b1[6], b2[6], b3[6], b4[6]; };
+__device__ __forceinline__ void poly_basis(double s1, Basis &B) {
+    const double s2 = s1 * s1, s3 = s2 * s1, s4 = s2 * s2, s5 = s4 * s1;
+    B.b0[0] = 1.0; B.b0[1] = s1; B.b0[2] = s2; B.b0[3] = s3; B.b0[4] = s4; B.b0[5] = s5;
+    B.b1[0] = 0.0; B.b1[1] = 1.0; B.b1[2] = 2.0 * s1; B.b1[3] = 3.0 * s2; B.b1[4] = 4.0 * s3; B.b1[5] = 5.0 * s4;
+    B.b2[0] = 0.0; B.b2[1] = 0.0; B.b2[2] = 2.0; B.b2[3] = 6.0 * s1; B.b2[4] = 12.0 * s2; B.b2[5] = 20.0 * s3;
+    B.b3[0] = 0.0; B.b3[1] = 0.0; B.b3[2] = 0.0; B.b3[3] = 6.0; B.b3[4] = 24.0 * s1; B.b3[5] = 60.0 * s2;
+    B.b4[0] = 0.0; B.b4[1] = 0.0; B.b4[2] = 0.0; B.b4[3] = 0.0; B.b4[4] = 24.0; B.b4[5] = 120.0 * s1;
+}
+// c^T beta for one piece; c points at the piece's row block, `ld` = 6N is the column stride.
+__device__ __forceinline__ d3 ct_beta(const double *__restrict__ c, int ld, const double *b) {
+    d3 r;
+    double s = 0.0;
+#pragma unroll
+    for (int k = 0; k < 6; k++) s += c[k] * b[k];
+    r.x = s; s = 0.0;
+#pragma unroll
+    for (int k = 0; k < 6; k++) s += c[ld + k] * b[k];
+    r.y = s; s = 0.0;
+#pragma unroll
+    for (int k = 0; k < 6; k++) s += c[2 * ld + k] * b[k];
+    r.z = s;
+    return r;
+}
+
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+
+} // namespace isdf

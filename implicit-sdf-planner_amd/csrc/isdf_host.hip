@@ -1,0 +1,594 @@
+// Host side of the C ABI (include/isdf_accel.h): context, device memory, launches.
+// Replaces, for the two sweeps only, what TrajOptimizer holds around them in the reference
+// (back_end_optimizer.hpp:59-62 parallel_points/lastTstar, :667-725 setParam/setEnvironment/setGridMap) and the
+// shape registry lookup of sw_manager.hpp:74-123,:255-275.  No CPU compute path exists here.
+#include "isdf_internal.hpp"
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+#include <new>
+
+using namespace isdf;
+
+namespace {
+thread_local std::string g_create_error;
+
+struct ProfEvent { hipEvent_t a, b; };
+}
+
+struct isdf_ctx {
+    isdf_config cfg;
+    int device = 0;
+    std::string err;
+    // grid
+    DevGrid grid{};
+    float *d_esdf = nullptr;
+    uint8_t *d_occ = nullptr;
+    bool have_geom = false;
+    // shape
+    DevShape shape{};
+    isdf_shape shape_host{};
+    bool have_shape = false;
+    DevMesh *d_mesh = nullptr;
+    double *d_mesh_tri = nullptr;
+    float *d_mesh_trif = nullptr;
+    // points (V1)
+    double *d_points = nullptr;
+    int M = 0;
+    double *d_tstar = nullptr;       // internal lastTstar when the caller passes none
+    // shard
+    int rank = 0, world = 1;
+    // per-step scratch
+    double *d_partial = nullptr; size_t partial_cap = 0;
+    double *d_in = nullptr; size_t in_cap = 0;        // host-API staging: T | coeffs
+    double *d_out = nullptr; size_t out_cap = 0;
+    std::vector<double> h_out;
+    unsigned long long *d_stats = nullptr;
+    isdf_stats last_stats{};
+    bool stats_cached = false;
+    // V1 scratch
+    double *d_traj_duration = nullptr;
+    double *d_coarse_t = nullptr, *d_coarse_pose = nullptr;
+    int *d_n_coarse = nullptr;
+    double *d_point_partial = nullptr; int *d_point_piece = nullptr; int point_cap = 0;
+    // profiling
+    bool prof_on = false;
+    std::vector<ProfEvent> prof_events;
+    size_t prof_used = 0;
+    hipStream_t stream = nullptr;   // stream of the host API
+};
+
+#define HIPCHK(ctx, call)                                                                          \
+    do {                                                                                           \
+        hipError_t e_ = (call);                                                                    \
+        if (e_ != hipSuccess) {                                                                    \
+            (ctx)->err = std::string(#call) + ": " + hipGetErrorString(e_);                        \
+            return ISDF_ERR_HIP;                                                                   \
+        }                                                                                          \
+    } while (0)
+
+static int fail(isdf_ctx *c, int code, const char *msg) {
+    if (c) c->err = msg; else g_create_error = msg;
+    return code;
+}
+
+// --------------------------------------------------------------------------------------------------------------
+// defaults and the analytic-shape registry
+// --------------------------------------------------------------------------------------------------------------
+extern "C" int isdf_abi_version(void) { return ISDF_ABI_VERSION; }
+extern "C" size_t isdf_out_stride(int N) { return (size_t)1 + 19 * (size_t)N; }
+
+extern "C" void isdf_config_default(isdf_config *c) {   // config_CappedCone.yaml (demo1)
+    std::memset(c, 0, sizeof(*c));
+    c->device = 0;
+    c->variant = ISDF_V3_ESDF_TILE;
+    c->kernel_size = 13;
+    c->integral_intervs = 64;
+    c->enable_dyn = 1;
+    c->enable_pos = 1;
+    c->enable_cull = 0;
+    c->safety_hor = 0.866;
+    c->weight_p = 4000.0;
+    c->weight_v = c->weight_omg = c->weight_theta = 1000.0;
+    c->vmax = 10.0; c->omgmax = 10.0; c->thetamax = 100.0;
+    c->smoothing_eps = 1.0e-2;
+    c->occ_thresh = 0.0;
+    c->vehicle_mass = 0.61; c->grav_acc = 9.8; c->horiz_drag = 0.10; c->vert_drag = 0.10;
+    c->paras_drag = 0.01; c->speed_eps = 1.0e-4;
+}
+
+static void shape_identity(isdf_shape *s, int kind) {
+    std::memset(s, 0, sizeof(*s));
+    s->kind = kind;
+    s->grad_mode = ISDF_GRAD_DEFAULT;
+    s->rotate[0] = s->rotate[4] = s->rotate[8] = 1.0;
+}
+static void setp(isdf_shape *s, std::initializer_list<double> v) {
+    int i = 0;
+    for (double x : v) s->params[i++] = x;
+}
+
+extern "C" int isdf_shape_default(isdf_shape *s, int kind) {
+    if (!s || kind < 0 || kind >= ISDF_SHAPE_KIND_COUNT) return ISDF_ERR_INVALID_ARG;
+    shape_identity(s, kind);
+    switch (kind) {
+    case ISDF_SHAPE_TORUS: setp(s, {2.5, 0.3}); break;
+    case ISDF_SHAPE_CAPPEDTORUS: setp(s, {std::sin(40), std::cos(40), 3.5, 0.3}); break;
+    case ISDF_SHAPE_CAPPEDCONE: setp(s, {2.0, 0.8, 0, 0, -1, 0, 0, 1}); break;
+    case ISDF_SHAPE_ROUNDEDCONE: setp(s, {1.5, 0.6, 4.5}); break;
+    case ISDF_SHAPE_WIREFRAMEBOX: setp(s, {1.8, 2.5, 3.5, 0.1}); break;
+    case ISDF_SHAPE_BENDLINEAR: setp(s, {2.0, 0.25}); break;
+    case ISDF_SHAPE_TWISTBOX: setp(s, {2.0, 2.0, 2.0, 3.14159265358979323846 / 6}); break;
+    case ISDF_SHAPE_BENDBOX: setp(s, {2.0, 2.0, 2.0, 0.5}); break;
+    case ISDF_SHAPE_TABLE: setp(s, {0.0, 0.0, 0.0, 3.5, 1.75, 0.7, 2.8, 1.05, 0.0, 3.5, 1.75, 2.8}); break;
+    case ISDF_SHAPE_TREFOIL: setp(s, {3.5, 0.2, 0.2, 0.05, 0.4}); break;
+    case ISDF_SHAPE_SMOOTHDIFFERENCE: setp(s, {3.0, 3.0, 0.5, 1.0, 0.25}); break;
+    case ISDF_SHAPE_SMOOTHINTERSECTION: setp(s, {3.0, 3.0, 0.5, 1.0, 0.25}); break;
+    case ISDF_SHAPE_CSG: setp(s, {3.0, 4.5, 1.5}); break;
+    case ISDF_SHAPE_BOX: setp(s, {3.0, 0.3, 0.3}); break;
+    case ISDF_SHAPE_BALL: setp(s, {1.0}); break;
+    default: break;
+    }
+    return ISDF_OK;
+}
+
+extern "C" int isdf_shape_from_name(isdf_shape *s, const char *stem) {
+    if (!s || !stem) return ISDF_ERR_INVALID_ARG;
+    struct Ent { const char *name; int kind; };
+    static const Ent reg[] = {   // sw_manager.hpp:74-123
+        {"CSG", ISDF_SHAPE_CSG}, {"Torus", ISDF_SHAPE_TORUS}, {"Torus_big", ISDF_SHAPE_TORUS},
+        {"Cappedtorus", ISDF_SHAPE_CAPPEDTORUS}, {"Trefoil", ISDF_SHAPE_TREFOIL}, {"Table", ISDF_SHAPE_TABLE},
+        {"CappedCone", ISDF_SHAPE_CAPPEDCONE}, {"RoundedCone", ISDF_SHAPE_ROUNDEDCONE},
+        {"WireframeBox", ISDF_SHAPE_WIREFRAMEBOX}, {"BendLinear", ISDF_SHAPE_BENDLINEAR},
+        {"BendLinear_big", ISDF_SHAPE_BENDLINEAR}, {"TwistBox", ISDF_SHAPE_TWISTBOX}, {"BendBox", ISDF_SHAPE_BENDBOX},
+        {"SmoothDifference", ISDF_SHAPE_SMOOTHDIFFERENCE}, {"SmoothIntersection", ISDF_SHAPE_SMOOTHINTERSECTION},
+        {"SmoothIntersection_big", ISDF_SHAPE_SMOOTHINTERSECTION}};
+    for (const Ent &e : reg) {
+        if (std::strcmp(e.name, stem) == 0) {
+            isdf_shape_default(s, e.kind);
+            if (!std::strcmp(stem, "Torus_big")) setp(s, {3.5, 0.3});
+            if (!std::strcmp(stem, "BendLinear_big")) setp(s, {3.2, 0.45});
+            if (!std::strcmp(stem, "SmoothIntersection_big")) setp(s, {9.0, 9.0, 1.5, 3.0, 0.25});
+            return ISDF_OK;
+        }
+    }
+    return ISDF_ERR_UNSUPPORTED;   // not analytic: the reference falls back to the mesh Generalshape (:263-274)
+}
+
+// --------------------------------------------------------------------------------------------------------------
+// lifetime
+// --------------------------------------------------------------------------------------------------------------
+extern "C" const char *isdf_last_error(const isdf_ctx *c) { return c ? c->err.c_str() : g_create_error.c_str(); }
+
+extern "C" int isdf_create(isdf_ctx **out, const isdf_config *cfg) {
+    if (!out || !cfg) return fail(nullptr, ISDF_ERR_INVALID_ARG, "null argument");
+    *out = nullptr;
+    if (cfg->variant < ISDF_V1_SWEPT || cfg->variant > ISDF_V3_ESDF_TILE) return fail(nullptr, ISDF_ERR_INVALID_ARG, "bad variant");
+    if (cfg->kernel_size < 1 || cfg->kernel_size > 512) return fail(nullptr, ISDF_ERR_INVALID_ARG, "kernel_size must be in [1,512]");
+    if (cfg->integral_intervs < 1) return fail(nullptr, ISDF_ERR_INVALID_ARG, "integral_intervs must be >= 1");
+    int ndev = 0;
+    hipError_t e = hipGetDeviceCount(&ndev);
+    if (e != hipSuccess || ndev <= 0)
+        return fail(nullptr, ISDF_ERR_NO_DEVICE, "no HIP device available (the product path has no CPU fallback)");
+    if (cfg->device < 0 || cfg->device >= ndev) return fail(nullptr, ISDF_ERR_INVALID_ARG, "device ordinal out of range");
+    isdf_ctx *c = new (std::nothrow) isdf_ctx();
+    if (!c) return fail(nullptr, ISDF_ERR_HIP, "out of host memory");
+    c->cfg = *cfg;
+    c->device = cfg->device;
+    if (hipSetDevice(c->device) != hipSuccess || hipMalloc(&c->d_stats, 8 * sizeof(unsigned long long)) != hipSuccess ||
+        hipMalloc(&c->d_traj_duration, sizeof(double)) != hipSuccess || hipMalloc(&c->d_n_coarse, sizeof(int)) != hipSuccess ||
+        hipMemset(c->d_traj_duration, 0, sizeof(double)) != hipSuccess || hipStreamCreate(&c->stream) != hipSuccess) {
+        delete c;
+        return fail(nullptr, ISDF_ERR_HIP, "device initialisation failed");
+    }
+    *out = c;
+    return ISDF_OK;
+}
+
+static void free_mesh(isdf_ctx *c) {
+    if (c->d_mesh) (void)hipFree(c->d_mesh);
+    if (c->d_mesh_tri) (void)hipFree(c->d_mesh_tri);
+    if (c->d_mesh_trif) (void)hipFree(c->d_mesh_trif);
+    c->d_mesh = nullptr; c->d_mesh_tri = nullptr; c->d_mesh_trif = nullptr;
+}
+
+extern "C" int isdf_destroy(isdf_ctx *c) {
+    if (!c) return ISDF_OK;
+    (void)hipSetDevice(c->device);
+    (void)hipDeviceSynchronize();
+    for (auto &p : c->prof_events) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
+    void *ptrs[] = {c->d_esdf, c->d_occ, c->d_points, c->d_tstar, c->d_partial, c->d_in, c->d_out, c->d_stats,
+                    c->d_traj_duration, c->d_coarse_t, c->d_coarse_pose, c->d_n_coarse, c->d_point_partial, c->d_point_piece};
+    for (void *p : ptrs) if (p) (void)hipFree(p);
+    free_mesh(c);
+    if (c->stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+    return ISDF_OK;
+}
+
+// --------------------------------------------------------------------------------------------------------------
+// once-per-plan state
+// --------------------------------------------------------------------------------------------------------------
+extern "C" int isdf_set_grid(isdf_ctx *c, const void *vox, int dtype, int nx, int ny, int nz, const double origin[3],
+                             const double bmax[3], double res, int kind) {
+    if (!c) return ISDF_ERR_INVALID_ARG;
+    if (!vox || !origin || nx < 1 || ny < 1 || nz < 1 || !(res > 0)) return fail(c, ISDF_ERR_INVALID_ARG, "bad grid arguments");
+    if (dtype < ISDF_U8 || dtype > ISDF_F64) return fail(c, ISDF_ERR_INVALID_ARG, "bad dtype");
+    if (kind != ISDF_GRID_OCCUPANCY && kind != ISDF_GRID_ESDF) return fail(c, ISDF_ERR_INVALID_ARG, "bad grid kind");
+    HIPCHK(c, hipSetDevice(c->device));
+    const size_t n = (size_t)nx * ny * nz;
+    if (c->have_geom && (c->grid.X != nx || c->grid.Y != ny || c->grid.Z != nz)) {
+        // new geometry: drop the other grid kind, it no longer matches
+        if (c->d_esdf) { (void)hipFree(c->d_esdf); c->d_esdf = nullptr; }
+        if (c->d_occ) { (void)hipFree(c->d_occ); c->d_occ = nullptr; }
+    }
+    c->grid.X = nx; c->grid.Y = ny; c->grid.Z = nz; c->grid.res = res;
+    for (int a = 0; a < 3; a++) {
+        c->grid.bmin[a] = origin[a];
+        const int dim = a == 0 ? nx : (a == 1 ? ny : nz);
+        c->grid.bmax[a] = bmax ? bmax[a] : origin[a] + dim * res;
+    }
+    c->have_geom = true;
+    if (kind == ISDF_GRID_ESDF) {
+        std::vector<float> tmp;
+        const float *src = nullptr;
+        if (dtype == ISDF_F32) src = (const float *)vox;
+        else {
+            tmp.resize(n);
+            if (dtype == ISDF_F64) for (size_t i = 0; i < n; i++) tmp[i] = (float)((const double *)vox)[i];
+            else for (size_t i = 0; i < n; i++) tmp[i] = (float)((const uint8_t *)vox)[i];
+            src = tmp.data();
+        }
+        if (c->d_esdf) { (void)hipFree(c->d_esdf); c->d_esdf = nullptr; }
+        HIPCHK(c, hipMalloc(&c->d_esdf, n * sizeof(float)));
+        HIPCHK(c, hipMemcpy(c->d_esdf, src, n * sizeof(float), hipMemcpyHostToDevice));
+    } else {
+        std::vector<uint8_t> tmp(n);
+        if (dtype == ISDF_U8) for (size_t i = 0; i < n; i++) tmp[i] = ((const uint8_t *)vox)[i] != 0;
+        else if (dtype == ISDF_F32) for (size_t i = 0; i < n; i++) tmp[i] = ((const float *)vox)[i] != 0;
+        else for (size_t i = 0; i < n; i++) tmp[i] = ((const double *)vox)[i] != 0;
+        if (c->d_occ) { (void)hipFree(c->d_occ); c->d_occ = nullptr; }
+        HIPCHK(c, hipMalloc(&c->d_occ, n));
+        HIPCHK(c, hipMemcpy(c->d_occ, tmp.data(), n, hipMemcpyHostToDevice));
+    }
+    c->grid.esdf = c->d_esdf;
+    c->grid.occ = c->d_occ;
+    return ISDF_OK;
+}
+
+// rotate()/rotate_to() of the CSG class (Shape.hpp:2016-2053), evaluated once on the host
+static void csg_rotate_to(const double a_in[3], const double b_in[3], double R[9]) {
+    auto nrm = [](const double v[3], double o[3]) {
+        const double z = v[0] * v[0] + v[1] * v[1] + v[2] * v[2];
+        const double s = z > 0 ? std::sqrt(z) : 1.0;
+        for (int i = 0; i < 3; i++) o[i] = z > 0 ? v[i] / s : v[i];
+    };
+    double a[3], b[3];
+    nrm(a_in, a); nrm(b_in, b);
+    const double d = b[0] * a[0] + b[1] * a[1] + b[2] * a[2];
+    for (int i = 0; i < 9; i++) R[i] = (i % 4 == 0) ? 1.0 : 0.0;
+    if (std::fabs(d - 1) < 1.1920929e-07f) return;
+    const double angle = std::acos(d);
+    const double v[3] = {b[1] * a[2] - b[2] * a[1], b[2] * a[0] - b[0] * a[2], b[0] * a[1] - b[1] * a[0]};
+    double n[3];
+    nrm(v, n);
+    const double x = n[0], y = n[1], z = n[2], s = std::sin(angle), co = std::cos(angle), m = 1 - co;
+    R[0] = m * x * x + co;    R[1] = m * x * y + z * s; R[2] = m * z * x - y * s;
+    R[3] = m * x * y - z * s; R[4] = m * y * y + co;    R[5] = m * y * z + x * s;
+    R[6] = m * z * x + y * s; R[7] = m * y * z - x * s; R[8] = m * z * z + co;
+}
+
+extern "C" int isdf_set_shape(isdf_ctx *c, const isdf_shape *s) {
+    if (!c) return ISDF_ERR_INVALID_ARG;
+    if (!s || s->kind < 0 || s->kind >= ISDF_SHAPE_KIND_COUNT) return fail(c, ISDF_ERR_INVALID_ARG, "bad shape kind");
+    if (s->grad_mode < ISDF_GRAD_DEFAULT || s->grad_mode > ISDF_GRAD_ANALYTIC_BALL) return fail(c, ISDF_ERR_INVALID_ARG, "bad grad_mode");
+    HIPCHK(c, hipSetDevice(c->device));
+    DevShape d{};
+    d.kind = s->kind;
+    d.grad_mode = s->grad_mode;
+    if (d.grad_mode == ISDF_GRAD_DEFAULT)
+        d.grad_mode = s->kind == ISDF_SHAPE_BOX ? ISDF_GRAD_BOX_FORWARD : (s->kind == ISDF_SHAPE_BALL ? ISDF_GRAD_ANALYTIC_BALL : ISDF_GRAD_CENTRAL);
+    std::memcpy(d.p, s->params, sizeof(d.p));
+    std::memcpy(d.trans, s->trans, sizeof(d.trans));
+    std::memcpy(d.rot, s->rotate, sizeof(d.rot));
+    d.bound_radius = s->bound_radius;
+    const double X[3] = {1, 0, 0}, Y[3] = {0, 1, 0}, Z[3] = {0, 0, 1};
+    csg_rotate_to(X, Y, d.csg_r2);
+    csg_rotate_to(X, Z, d.csg_r3);
+    d.mesh = nullptr;
+    if (s->kind == ISDF_SHAPE_MESH) {
+        if (!s->mesh_vertices || !s->mesh_faces || s->n_faces < 1 || s->n_vertices < 3) return fail(c, ISDF_ERR_INVALID_ARG, "mesh shape needs vertices and faces");
+        std::vector<double> tri((size_t)9 * s->n_faces);
+        std::vector<float> trif((size_t)9 * s->n_faces);
+        for (int f = 0; f < s->n_faces; f++)
+            for (int k = 0; k < 3; k++) {
+                const int vi = s->mesh_faces[3 * f + k];
+                if (vi < 0 || vi >= s->n_vertices) return fail(c, ISDF_ERR_INVALID_ARG, "mesh face index out of range");
+                for (int a = 0; a < 3; a++) {
+                    tri[(size_t)9 * f + 3 * k + a] = s->mesh_vertices[3 * vi + a];
+                    trif[(size_t)9 * f + 3 * k + a] = (float)s->mesh_vertices[3 * vi + a];
+                }
+            }
+        free_mesh(c);
+        HIPCHK(c, hipMalloc(&c->d_mesh_tri, tri.size() * sizeof(double)));
+        HIPCHK(c, hipMalloc(&c->d_mesh_trif, trif.size() * sizeof(float)));
+        HIPCHK(c, hipMalloc(&c->d_mesh, sizeof(DevMesh)));
+        HIPCHK(c, hipMemcpy(c->d_mesh_tri, tri.data(), tri.size() * sizeof(double), hipMemcpyHostToDevice));
+        HIPCHK(c, hipMemcpy(c->d_mesh_trif, trif.data(), trif.size() * sizeof(float), hipMemcpyHostToDevice));
+        DevMesh hm{c->d_mesh_tri, c->d_mesh_trif, s->n_faces};
+        HIPCHK(c, hipMemcpy(c->d_mesh, &hm, sizeof(hm), hipMemcpyHostToDevice));
+        d.mesh = c->d_mesh;
+    }
+    c->shape = d;
+    c->shape_host = *s;
+    c->shape_host.mesh_vertices = nullptr;
+    c->shape_host.mesh_faces = nullptr;
+    c->have_shape = true;
+    return ISDF_OK;
+}
+
+extern "C" int isdf_set_points(isdf_ctx *c, const double *xyz, int M) {
+    if (!c) return ISDF_ERR_INVALID_ARG;
+    if (M < 0 || (M > 0 && !xyz)) return fail(c, ISDF_ERR_INVALID_ARG, "bad points");
+    HIPCHK(c, hipSetDevice(c->device));
+    if (c->d_points) { (void)hipFree(c->d_points); c->d_points = nullptr; }
+    if (c->d_tstar) { (void)hipFree(c->d_tstar); c->d_tstar = nullptr; }
+    c->M = M;
+    if (M > 0) {
+        HIPCHK(c, hipMalloc(&c->d_points, (size_t)3 * M * sizeof(double)));
+        HIPCHK(c, hipMemcpy(c->d_points, xyz, (size_t)3 * M * sizeof(double), hipMemcpyHostToDevice));
+        HIPCHK(c, hipMalloc(&c->d_tstar, (size_t)M * sizeof(double)));
+        HIPCHK(c, hipMemset(c->d_tstar, 0, (size_t)M * sizeof(double)));   // lastTstar starts at 0 (plan_manager.cpp:254)
+    }
+    return ISDF_OK;
+}
+
+extern "C" int isdf_set_shard(isdf_ctx *c, int rank, int world) {
+    if (!c) return ISDF_ERR_INVALID_ARG;
+    if (world < 1 || rank < 0 || rank >= world) return fail(c, ISDF_ERR_INVALID_ARG, "bad shard");
+    c->rank = rank; c->world = world;
+    return ISDF_OK;
+}
+
+// --------------------------------------------------------------------------------------------------------------
+// per-step evaluation
+// --------------------------------------------------------------------------------------------------------------
+static void shard_range(long long total, int rank, int world, long long &b, long long &e) {
+    const long long q = total / world, r = total % world;
+    b = rank * q + (rank < r ? rank : r);
+    e = b + q + (rank < r ? 1 : 0);
+}
+
+static int ensure(isdf_ctx *c, double **p, size_t *cap, size_t need) {
+    if (*cap >= need) return ISDF_OK;
+    if (*p) (void)hipFree(*p);
+    *p = nullptr; *cap = 0;
+    HIPCHK(c, hipMalloc(p, need * sizeof(double)));
+    *cap = need;
+    return ISDF_OK;
+}
+
+static void fill_flat(const isdf_config &cfg, FlatP &f) {
+    f.mass = cfg.vehicle_mass; f.grav = cfg.grav_acc; f.dh = cfg.horiz_drag; f.dv = cfg.vert_drag;
+    f.cp = cfg.paras_drag; f.veps = cfg.speed_eps; f.dh_over_m = f.dh / f.mass;
+}
+
+static int prof_begin(isdf_ctx *c, hipStream_t st, ProfEvent **ev) {
+    *ev = nullptr;
+    if (!c->prof_on) return ISDF_OK;
+    if (c->prof_used == c->prof_events.size()) {
+        ProfEvent p;
+        HIPCHK(c, hipEventCreate(&p.a));
+        HIPCHK(c, hipEventCreate(&p.b));
+        c->prof_events.push_back(p);
+    }
+    *ev = &c->prof_events[c->prof_used++];
+    HIPCHK(c, hipEventRecord((*ev)->a, st));
+    return ISDF_OK;
+}
+
+static int eval_device_impl(isdf_ctx *c, int n_traj, int N, const double *d_T, const double *d_coeffs, double *d_out,
+                            double *d_tstar, hipStream_t st) {
+    const isdf_config &cfg = c->cfg;
+    c->stats_cached = false;
+    if (n_traj < 1 || N < 1) return fail(c, ISDF_ERR_INVALID_ARG, "n_traj and N must be >= 1");
+    if (!d_T || !d_coeffs || !d_out) return fail(c, ISDF_ERR_INVALID_ARG, "null device buffer");
+    if (!c->have_shape && (cfg.variant == ISDF_V1_SWEPT || cfg.enable_pos)) return fail(c, ISDF_ERR_STATE, "shape not set");
+    HIPCHK(c, hipSetDevice(c->device));
+    const size_t ostride = isdf_out_stride(N);
+    HIPCHK(c, hipMemsetAsync(d_out, 0, (size_t)n_traj * ostride * sizeof(double), st));
+    HIPCHK(c, hipMemsetAsync(c->d_stats, 0, 8 * sizeof(unsigned long long), st));
+
+    if (cfg.variant == ISDF_V1_SWEPT) {
+        if (n_traj != 1) return fail(c, ISDF_ERR_UNSUPPORTED, "the swept-volume sweep takes one trajectory");
+        if (c->M <= 0) return ISDF_OK;   // no obstacle points: nothing to add
+        long long b, e;
+        shard_range(c->M, c->rank, c->world, b, e);
+        SweptParams P{};
+        P.shape = c->shape;
+        fill_flat(cfg, P.flat);
+        P.N = N; P.M = c->M; P.point_begin = (int)b; P.point_end = (int)e;
+        P.safety_hor = cfg.safety_hor; P.weight_p = cfg.weight_p;
+        P.T = d_T; P.coeffs = d_coeffs; P.points = c->d_points;
+        P.tstar = d_tstar ? d_tstar : c->d_tstar;
+        P.traj_duration = c->d_traj_duration;
+        P.max_coarse = 1536;   // traj_duration < 300 s, coarse step 0.2 s -> at most 1501 samples
+        if (!c->d_coarse_t) {
+            HIPCHK(c, hipMalloc(&c->d_coarse_t, (size_t)P.max_coarse * sizeof(double)));
+            HIPCHK(c, hipMalloc(&c->d_coarse_pose, (size_t)P.max_coarse * 12 * sizeof(double)));
+        }
+        if (c->point_cap < c->M) {
+            if (c->d_point_partial) (void)hipFree(c->d_point_partial);
+            if (c->d_point_piece) (void)hipFree(c->d_point_piece);
+            c->d_point_partial = nullptr; c->d_point_piece = nullptr; c->point_cap = 0;
+            HIPCHK(c, hipMalloc(&c->d_point_partial, (size_t)c->M * PARTIAL_STRIDE * sizeof(double)));
+            HIPCHK(c, hipMalloc(&c->d_point_piece, (size_t)c->M * sizeof(int)));
+            c->point_cap = c->M;
+        }
+        P.coarse_t = c->d_coarse_t; P.coarse_pose = c->d_coarse_pose; P.n_coarse = c->d_n_coarse;
+        P.point_partial = c->d_point_partial; P.point_piece = c->d_point_piece;
+        P.stats = c->d_stats;
+        launch_swept_prepare(P, st);
+        ProfEvent *ev;
+        int rc = prof_begin(c, st, &ev);
+        if (rc) return rc;
+        launch_swept_sweep(P, st);
+        if (ev) HIPCHK(c, hipEventRecord(ev->b, st));
+        launch_swept_reduce(P, d_out, st);
+        HIPCHK(c, hipGetLastError());
+        return ISDF_OK;
+    }
+
+    // ---- V2 / V3 integral sweep
+    if (cfg.enable_pos) {
+        if (!c->have_geom) return fail(c, ISDF_ERR_STATE, "grid not set");
+        if (cfg.variant == ISDF_V3_ESDF_TILE && !c->d_esdf) return fail(c, ISDF_ERR_STATE, "V3 needs an ESDF grid");
+        if (cfg.variant == ISDF_V2_OCC_TILE && !c->d_occ) return fail(c, ISDF_ERR_STATE, "V2 needs an occupancy grid");
+    }
+    const long long total_pieces = (long long)n_traj * N;
+    long long pb, pe;
+    shard_range(total_pieces, c->rank, c->world, pb, pe);
+    const size_t n_samples = (size_t)total_pieces * (cfg.integral_intervs + 1);
+    int rc = ensure(c, &c->d_partial, &c->partial_cap, n_samples * PARTIAL_STRIDE);
+    if (rc) return rc;
+    SweepParams P{};
+    P.grid = c->grid;
+    if (!c->have_geom) { P.grid.X = P.grid.Y = P.grid.Z = 1; P.grid.res = 1.0; }
+    P.shape = c->shape;
+    fill_flat(cfg, P.flat);
+    P.variant = cfg.variant; P.K = cfg.integral_intervs; P.enable_dyn = cfg.enable_dyn; P.enable_pos = cfg.enable_pos;
+    P.enable_cull = cfg.enable_cull;
+    P.n_traj = n_traj; P.N = N; P.piece_begin = (int)pb; P.piece_end = (int)pe;
+    P.bd_half = cfg.kernel_size * P.grid.res / 2;
+    P.safety_hor = cfg.safety_hor; P.weight_p = cfg.weight_p; P.weight_v = cfg.weight_v; P.weight_omg = cfg.weight_omg;
+    P.weight_theta = cfg.weight_theta;
+    P.vel_sqr_max = cfg.vmax * cfg.vmax; P.omg_sqr_max = cfg.omgmax * cfg.omgmax; P.theta_max = cfg.thetamax;
+    P.mu = cfg.smoothing_eps;
+    P.occ_thresh = (float)cfg.occ_thresh;
+    P.cull_threshold = 0.0;
+    if (cfg.variant == ISDF_V3_ESDF_TILE && cfg.enable_cull && c->shape.bound_radius > 0)
+        P.cull_threshold = c->shape.bound_radius + cfg.safety_hor + std::sqrt(3.0) * P.grid.res;
+    P.T = d_T; P.coeffs = d_coeffs; P.partial = c->d_partial; P.stats = c->d_stats;
+    ProfEvent *ev;
+    rc = prof_begin(c, st, &ev);
+    if (rc) return rc;
+    launch_tile_sweep(P, st);
+    if (ev) HIPCHK(c, hipEventRecord(ev->b, st));
+    ReduceParams Rp{};
+    Rp.n_traj = n_traj; Rp.N = N; Rp.K = cfg.integral_intervs; Rp.piece_begin = (int)pb; Rp.piece_end = (int)pe;
+    Rp.partial = c->d_partial; Rp.out = d_out; Rp.v1_mode = 0;
+    launch_tile_reduce(Rp, st);
+    HIPCHK(c, hipGetLastError());
+    return ISDF_OK;
+}
+
+extern "C" int isdf_eval_device(isdf_ctx *c, int n_traj, int N, const double *d_T, const double *d_coeffs, double *d_out,
+                                double *d_tstar, void *stream) {
+    if (!c) return ISDF_ERR_INVALID_ARG;
+    return eval_device_impl(c, n_traj, N, d_T, d_coeffs, d_out, d_tstar, (hipStream_t)stream);
+}
+
+static int fetch_stats(isdf_ctx *c) {
+    unsigned long long h[8];
+    HIPCHK(c, hipMemcpy(h, c->d_stats, sizeof(h), hipMemcpyDeviceToHost));
+    c->last_stats.n_units = (int64_t)h[0]; c->last_stats.n_units_culled = (int64_t)h[1];
+    c->last_stats.n_pairs = (int64_t)h[2]; c->last_stats.n_grad_pairs = (int64_t)h[3];
+    c->last_stats.overflow = (int32_t)h[4];
+    return ISDF_OK;
+}
+
+extern "C" int isdf_eval(isdf_ctx *c, int n_traj, const int *N, const double *const *T, const double *const *coeffs,
+                         double *cost_inout, double *const *gradT_inout, double *const *gradC_inout, double *tstar_inout) {
+    if (!c) return ISDF_ERR_INVALID_ARG;
+    if (n_traj < 1 || !N || !T || !coeffs || !cost_inout || !gradT_inout || !gradC_inout) return fail(c, ISDF_ERR_INVALID_ARG, "null argument");
+    HIPCHK(c, hipSetDevice(c->device));
+    // trajectories with equal N go out as one batched launch; ragged input is evaluated group by group
+    int start = 0;
+    isdf_stats total{};
+    while (start < n_traj) {
+        int end = start + 1;
+        while (end < n_traj && N[end] == N[start]) end++;
+        const int nb = end - start, n = N[start];
+        if (n < 1) return fail(c, ISDF_ERR_INVALID_ARG, "N must be >= 1");
+        const size_t in_per = (size_t)19 * n, ostride = isdf_out_stride(n);
+        int rc = ensure(c, &c->d_in, &c->in_cap, in_per * nb);
+        if (rc) return rc;
+        rc = ensure(c, &c->d_out, &c->out_cap, ostride * nb);
+        if (rc) return rc;
+        double *dT = c->d_in, *dC = c->d_in + (size_t)n * nb;
+        for (int b = 0; b < nb; b++) {
+            if (!T[start + b] || !coeffs[start + b] || !gradT_inout[start + b] || !gradC_inout[start + b])
+                return fail(c, ISDF_ERR_INVALID_ARG, "null trajectory buffer");
+            HIPCHK(c, hipMemcpyAsync(dT + (size_t)b * n, T[start + b], n * sizeof(double), hipMemcpyHostToDevice, c->stream));
+            HIPCHK(c, hipMemcpyAsync(dC + (size_t)b * 18 * n, coeffs[start + b], (size_t)18 * n * sizeof(double), hipMemcpyHostToDevice, c->stream));
+        }
+        double *dts = nullptr;
+        if (c->cfg.variant == ISDF_V1_SWEPT && tstar_inout && c->M > 0) {
+            dts = c->d_tstar;
+            HIPCHK(c, hipMemcpyAsync(dts, tstar_inout, (size_t)c->M * sizeof(double), hipMemcpyHostToDevice, c->stream));
+        }
+        rc = eval_device_impl(c, nb, n, dT, dC, c->d_out, dts, c->stream);
+        if (rc) return rc;
+        c->h_out.resize(ostride * nb);
+        HIPCHK(c, hipMemcpyAsync(c->h_out.data(), c->d_out, ostride * nb * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+        if (dts) HIPCHK(c, hipMemcpyAsync(tstar_inout, dts, (size_t)c->M * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        rc = fetch_stats(c);
+        if (rc) return rc;
+        total.n_units += c->last_stats.n_units; total.n_units_culled += c->last_stats.n_units_culled;
+        total.n_pairs += c->last_stats.n_pairs; total.n_grad_pairs += c->last_stats.n_grad_pairs;
+        total.overflow |= c->last_stats.overflow;
+        for (int b = 0; b < nb; b++) {
+            const double *o = c->h_out.data() + ostride * b;
+            cost_inout[start + b] += o[0];
+            double *gT = gradT_inout[start + b], *gC = gradC_inout[start + b];
+            for (int i = 0; i < n; i++) gT[i] += o[1 + i];
+            for (int i = 0; i < 18 * n; i++) gC[i] += o[1 + n + i];
+        }
+        start = end;
+    }
+    c->last_stats = total;
+    c->stats_cached = true;
+    if (total.overflow) return fail(c, ISDF_ERR_OVERFLOW, "a bounded device work list overflowed; result invalid");
+    return ISDF_OK;
+}
+
+// --------------------------------------------------------------------------------------------------------------
+// instrumentation
+// --------------------------------------------------------------------------------------------------------------
+extern "C" int isdf_profile_enable(isdf_ctx *c, int on) {
+    if (!c) return ISDF_ERR_INVALID_ARG;
+    c->prof_on = on != 0;
+    c->prof_used = 0;
+    return ISDF_OK;
+}
+
+extern "C" int isdf_profile_read(isdf_ctx *c, int *n, double *mean_ms) {
+    if (!c || !n || !mean_ms) return ISDF_ERR_INVALID_ARG;
+    HIPCHK(c, hipSetDevice(c->device));
+    double sum = 0.0;
+    for (size_t i = 0; i < c->prof_used; i++) {
+        HIPCHK(c, hipEventSynchronize(c->prof_events[i].b));
+        float ms = 0.f;
+        HIPCHK(c, hipEventElapsedTime(&ms, c->prof_events[i].a, c->prof_events[i].b));
+        sum += ms;
+    }
+    *n = (int)c->prof_used;
+    *mean_ms = c->prof_used ? sum / c->prof_used : 0.0;
+    c->prof_used = 0;
+    return ISDF_OK;
+}
+
+extern "C" int isdf_get_stats(isdf_ctx *c, isdf_stats *out) {
+    if (!c || !out) return ISDF_ERR_INVALID_ARG;
+    if (!c->stats_cached) {
+        HIPCHK(c, hipSetDevice(c->device));
+        HIPCHK(c, hipDeviceSynchronize());
+        int rc = fetch_stats(c);
+        if (rc) return rc;
+    }
+    *out = c->last_stats;
+    return ISDF_OK;
+}

@@ -1,0 +1,74 @@
+// Internal host<->kernel parameter blocks (not part of the ABI).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdint>
+#include "dev_shapes.hpp"
+
+namespace isdf {
+
+struct DevGrid {
+    int X, Y, Z;
+    double res;
+    double bmin[3], bmax[3];
+    const float *esdf;        // metres, unsigned; z fastest (GridMap3D.h:194)
+    const uint8_t *occ;       // 1 = occupied
+};
+
+// Partial record of one constraint-point evaluation: 18 gradC entries (index d*6 + r), gradT, cost.
+constexpr int PARTIAL_STRIDE = 20;
+
+struct SweepParams {
+    DevGrid grid;
+    DevShape shape;
+    FlatP flat;
+    int variant, K, enable_dyn, enable_pos, enable_cull;
+    int n_traj, N;              // all trajectories of a launch have N pieces
+    int piece_begin, piece_end; // this rank's range of GLOBAL piece indices (traj-major)
+    double bd_half;             // kernel_size * res / 2
+    double safety_hor, weight_p, weight_v, weight_omg, weight_theta;
+    double vel_sqr_max, omg_sqr_max, theta_max, mu;
+    float occ_thresh;
+    double cull_threshold;      // <= 0: cull disabled
+    const double *T;            // n_traj * N
+    const double *coeffs;       // n_traj * (6N x 3 col-major)
+    double *partial;            // [n_samples_total][PARTIAL_STRIDE], indexed by global sample id
+    unsigned long long *stats;  // [0]=units [1]=culled [2]=pairs [3]=grad pairs [4]=overflow
+};
+
+struct ReduceParams {
+    int n_traj, N, K;
+    int piece_begin, piece_end;
+    const double *partial;
+    double *out;                // n_traj * (1 + N + 18N)
+    int v1_mode;                // 0: integral sweep layout; 1: V1 (see swept_sweep.hip)
+};
+
+void launch_tile_sweep(const SweepParams &P, hipStream_t stream);
+void launch_tile_reduce(const ReduceParams &P, hipStream_t stream);
+
+// ---- V1 (swept volume) ----
+struct SweptParams {
+    DevShape shape;
+    FlatP flat;
+    int N;
+    int M, point_begin, point_end;
+    double safety_hor, weight_p;
+    const double *T;            // N
+    const double *coeffs;       // 6N x 3 col-major
+    const double *points;       // M x 3
+    double *tstar;              // M (in/out), may be null -> internal scratch
+    double *traj_duration;      // device scalar: persistent "traj_duration" state (sw_manager.hpp:287-296)
+    // per-step scratch
+    double *coarse_t;           // [max_coarse]
+    double *coarse_pose;        // [max_coarse][12] = pos(3) + R(9)
+    int *n_coarse;              // device scalar
+    int max_coarse;
+    double *point_partial;      // [M][PARTIAL_STRIDE] (gdC 18, gdT, pena)
+    int *point_piece;           // [M]
+    unsigned long long *stats;
+};
+void launch_swept_prepare(const SweptParams &P, hipStream_t stream);
+void launch_swept_sweep(const SweptParams &P, hipStream_t stream);
+void launch_swept_reduce(const SweptParams &P, double *out, hipStream_t stream);
+
+} // namespace isdf

@@ -1,0 +1,38 @@
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def pkg():
+    import __graft_entry__ as g
+    return g.load_package()
+
+
+@pytest.fixture(scope="session")
+def orc():
+    """The CPU oracle (test infrastructure).  Built by __graft_entry__.build(); rebuilt here if missing."""
+    import __graft_entry__ as g
+    lib = os.path.join(ROOT, "oracle", "liboracle.so")
+    if not os.path.exists(lib):
+        import subprocess
+        subprocess.check_call(["make", "liboracle.so"], cwd=os.path.join(ROOT, "oracle"))
+    return g.load_oracle()
+
+
+@pytest.fixture(scope="session")
+def product_lib(pkg):
+    """libisdf_accel.so; compiled on demand (hipcc cross-compiles without a GPU)."""
+    if not os.path.exists(pkg.capi.LIB_PATH):
+        import subprocess
+        subprocess.check_call(["make", "-j8"], cwd=os.path.join(ROOT, "implicit-sdf-planner_amd", "csrc"))
+    return pkg.capi.load_library()

@@ -1,0 +1,167 @@
+"""GPU parity proper: the HIP path through the C-ABI vs the CPU oracle on identical seeded inputs.
+Tolerance: 1e-5 relative (norm-wise on gradients), the figure BASELINE.json's north_star states."""
+import numpy as np
+import pytest
+
+from common import REL_TOL, assert_close, make_pair, small_world, traj
+
+pytestmark = pytest.mark.gpu
+
+
+def _check(eng, o, T, cm, what, tstar=False):
+    cost, gT, gC = eng.eval_single(T, cm)
+    c0, gT0, gC0, st0 = o.eval(T, cm)
+    assert abs(cost - c0) <= REL_TOL * max(abs(c0), 1e-9), (what, cost, c0)
+    assert_close(gT, gT0, what + " gradT")
+    assert_close(gC, gC0, what + " gradC")
+    return cost, st0
+
+
+@pytest.mark.parametrize("variant", ["V3", "V2"])
+@pytest.mark.parametrize("shape_name", ["RoundedCone", "Box"])
+def test_tile_sweep_matches_oracle(pkg, orc, product_lib, variant, shape_name):
+    capi, synth = pkg.capi, pkg.synth
+    occ, esdf, res = small_world(pkg)
+    T, cm = traj(pkg, occ, res)
+    v = capi.V3_ESDF_TILE if variant == "V3" else capi.V2_OCC_TILE
+    cfg = synth.default_config(v, kernel_size=9, integral_intervs=16, safety_hor=0.5)
+    if shape_name == "Box":
+        shape = synth.make_shape("Box", params=(1.2, 0.4, 0.3), grad_mode=capi.GRAD_CENTRAL)
+    else:
+        shape = synth.make_shape("RoundedCone", params=(0.8, 0.3, 1.6))
+    eng, o = make_pair(pkg, orc, cfg, shape, occ=occ, esdf=esdf, res=res)
+    cost, st0 = _check(eng, o, T, cm, f"{variant}/{shape_name}")
+    assert cost > 0, "scenario must exercise the collision term"
+    st = eng.stats()
+    assert st["units"] == st0[0] and st["pairs"] == st0[2] and st["grad_pairs"] == st0[3], (st, st0)
+
+
+def test_v3_equals_v2_at_zero_threshold(pkg, orc, product_lib):
+    """V3 with occ_thresh = 0 and culling off is V2 up to summation order."""
+    capi, synth = pkg.capi, pkg.synth
+    occ, esdf, res = small_world(pkg, seed=5)
+    T, cm = traj(pkg, occ, res, seed=12)
+    shape = synth.make_shape("RoundedCone", params=(0.8, 0.3, 1.6))
+    out = []
+    for v in (capi.V3_ESDF_TILE, capi.V2_OCC_TILE):
+        cfg = synth.default_config(v, kernel_size=9, integral_intervs=16, safety_hor=0.5)
+        eng = pkg.Engine(cfg)
+        eng.set_grid(esdf, (0, 0, 0), res, capi.GRID_ESDF)
+        eng.set_grid(occ, (0, 0, 0), res, capi.GRID_OCCUPANCY)
+        eng.set_shape(shape)
+        out.append(eng.eval_single(T, cm))
+    assert out[0][0] == out[1][0]
+    assert np.array_equal(out[0][1], out[1][1]) and np.array_equal(out[0][2], out[1][2])
+
+
+def test_cull_preserves_result(pkg, orc, product_lib):
+    capi, synth = pkg.capi, pkg.synth
+    occ, esdf, res = small_world(pkg, seed=7, occupancy=0.04)
+    T, cm = traj(pkg, occ, res, seed=13)
+    shape = synth.make_shape("RoundedCone", params=(0.8, 0.3, 1.6), bound_radius=1.9)
+    res_ = {}
+    for cull in (0, 1):
+        cfg = synth.default_config(capi.V3_ESDF_TILE, kernel_size=9, integral_intervs=16, safety_hor=0.5, enable_cull=cull)
+        eng, o = make_pair(pkg, orc, cfg, shape, esdf=esdf, res=res)
+        _check(eng, o, T, cm, f"cull={cull}")
+        res_[cull] = (eng.eval_single(T, cm), eng.stats())
+    assert res_[1][1]["culled"] > 0, "scenario must cull something"
+    assert res_[1][1]["pairs"] <= res_[0][1]["pairs"]
+    assert_close(res_[1][0][2], res_[0][0][2], "cull on vs off gradC", tol=1e-12)
+    assert abs(res_[1][0][0] - res_[0][0][0]) <= 1e-12 * max(1.0, abs(res_[0][0][0]))
+
+
+def test_dynamics_only_sweep(pkg, orc, product_lib):
+    """enable_pos = 0 is exactly the reference's live addTimeIntPenaltyParallel (velocity / body-rate / tilt)."""
+    capi, synth = pkg.capi, pkg.synth
+    occ, esdf, res = small_world(pkg)
+    T, cm = traj(pkg, occ, res, piece_T=0.35)     # fast => velocity / omega limits violated
+    cfg = synth.default_config(capi.V3_ESDF_TILE, integral_intervs=16, enable_pos=0, vmax=2.0, omgmax=1.0, thetamax=0.3)
+    eng, o = make_pair(pkg, orc, cfg, None)
+    cost, _ = _check(eng, o, T, cm, "dyn-only")
+    assert cost > 0
+
+
+def test_accumulate_semantics_and_batch(pkg, orc, product_lib):
+    """Outputs are += like the reference; a ragged batch equals per-trajectory calls."""
+    capi, synth = pkg.capi, pkg.synth
+    occ, esdf, res = small_world(pkg)
+    shape = synth.make_shape("RoundedCone", params=(0.8, 0.3, 1.6))
+    cfg = synth.default_config(capi.V3_ESDF_TILE, kernel_size=9, integral_intervs=8, safety_hor=0.5)
+    eng, o = make_pair(pkg, orc, cfg, shape, esdf=esdf, res=res)
+    trajs = [traj(pkg, occ, res, N=n, seed=20 + i) for i, n in enumerate([4, 4, 7, 3])]
+    Ts = [t for t, _ in trajs]
+    Cs = [c for _, c in trajs]
+    cost = np.full(4, 2.5)
+    gTs = [np.full(t.size, -1.0) for t in Ts]
+    gCs = [np.full(18 * t.size, 3.0) for t in Ts]
+    eng.eval(Ts, Cs, accumulate_into=(cost, gTs, gCs))
+    for b in range(4):
+        c0, gT0, gC0, _ = o.eval(Ts[b], Cs[b])
+        assert abs((cost[b] - 2.5) - c0) <= REL_TOL * max(abs(c0), 1.0)
+        assert_close(gTs[b] + 1.0, gT0, f"batch gradT[{b}]")
+        assert_close(gCs[b] - 3.0, gC0, f"batch gradC[{b}]")
+
+
+def test_shards_sum_to_full(pkg, orc, product_lib):
+    capi, synth = pkg.capi, pkg.synth
+    occ, esdf, res = small_world(pkg)
+    T, cm = traj(pkg, occ, res, N=7)
+    shape = synth.make_shape("RoundedCone", params=(0.8, 0.3, 1.6))
+    cfg = synth.default_config(capi.V3_ESDF_TILE, kernel_size=9, integral_intervs=8, safety_hor=0.5)
+    eng, o = make_pair(pkg, orc, cfg, shape, esdf=esdf, res=res)
+    full = eng.eval_single(T, cm)
+    for world in (2, 3, 8):
+        acc = [0.0, np.zeros(7), np.zeros(18 * 7)]
+        for r in range(world):
+            eng.set_shard(r, world)
+            c, gT, gC = eng.eval_single(T, cm)
+            acc[0] += c; acc[1] += gT; acc[2] += gC
+        eng.set_shard(0, 1)
+        assert abs(acc[0] - full[0]) <= 1e-12 * max(1.0, abs(full[0]))
+        assert_close(acc[1], full[1], f"world={world} gradT", tol=1e-12)
+        assert_close(acc[2], full[2], f"world={world} gradC", tol=1e-12)
+
+
+def test_edge_cases(pkg, orc, product_lib):
+    capi, synth = pkg.capi, pkg.synth
+    occ, esdf, res = small_world(pkg)
+    shape = synth.make_shape("RoundedCone", params=(0.8, 0.3, 1.6))
+    # single piece, K = 1
+    T, cm = traj(pkg, occ, res, N=1, seed=31)
+    cfg = synth.default_config(capi.V3_ESDF_TILE, kernel_size=9, integral_intervs=1, safety_hor=0.5)
+    eng, o = make_pair(pkg, orc, cfg, shape, esdf=esdf, res=res)
+    _check(eng, o, T, cm, "N=1,K=1")
+    # empty map: no collision term at all
+    cfg = synth.default_config(capi.V2_OCC_TILE, kernel_size=9, integral_intervs=8, safety_hor=0.5, enable_dyn=0)
+    eng, o = make_pair(pkg, orc, cfg, shape, occ=np.zeros_like(occ), res=res)
+    T, cm = traj(pkg, occ, res, N=3, seed=32)
+    c, gT, gC = eng.eval_single(T, cm)
+    assert c == 0.0 and not gT.any() and not gC.any()
+    # fully occupied map + trajectory hugging the map boundary (tiles clipped by projInMap), non-trivial bmax
+    full = np.ones_like(occ)
+    bmax = np.array(occ.shape) * res - 0.3
+    cfg = synth.default_config(capi.V2_OCC_TILE, kernel_size=7, integral_intervs=8, safety_hor=0.5)
+    eng, o = make_pair(pkg, orc, cfg, shape, occ=full, res=res, bmax=bmax)
+    T, cm = traj(pkg, np.zeros_like(occ), res, N=3, seed=33, margin=0.6)
+    _check(eng, o, T, cm, "boundary tiles")
+    # kernel_size larger than the map
+    cfg = synth.default_config(capi.V3_ESDF_TILE, kernel_size=101, integral_intervs=4, safety_hor=0.5)
+    eng, o = make_pair(pkg, orc, cfg, shape, esdf=esdf, res=res)
+    T, cm = traj(pkg, occ, res, N=2, seed=34)
+    _check(eng, o, T, cm, "kernel larger than map")
+
+
+@pytest.mark.parametrize("name", ["Torus", "Cappedtorus", "CappedCone", "WireframeBox", "BendLinear", "TwistBox", "BendBox",
+                                  "Table", "Trefoil", "SmoothDifference", "SmoothIntersection", "CSG", "Box", "Ball",
+                                  "Torus_big", "BendLinear_big", "SmoothIntersection_big"])
+def test_every_registered_shape(pkg, orc, product_lib, name):
+    """Each analytic kind of the registry (sw_manager.hpp:74-123) + Box/Ball with reference constants, rotated body offset."""
+    capi, synth = pkg.capi, pkg.synth
+    occ, esdf, res = small_world(pkg, shape=(40, 40, 40), occupancy=0.10, seed=9)
+    T, cm = traj(pkg, occ, res, N=3, seed=41, margin=6.0)
+    shape = synth.make_shape(name, poly_params=(0.2, -0.1, 0.15, 30, 10, 120))
+    cfg = synth.default_config(capi.V3_ESDF_TILE, kernel_size=17, integral_intervs=6, safety_hor=0.5)
+    eng, o = make_pair(pkg, orc, cfg, shape, esdf=esdf, res=res)
+    cost, st = _check(eng, o, T, cm, name)
+    assert st[2] > 0
