@@ -27,6 +27,7 @@ SHAPE_NAMES = ["Torus", "Cappedtorus", "CappedCone", "RoundedCone", "WireframeBo
 class IsdfShape(C.Structure):
     _fields_ = [("kind", C.c_int32), ("grad_mode", C.c_int32), ("params", C.c_double * 16),
                 ("trans", C.c_double * 3), ("rotate", C.c_double * 9), ("bound_radius", C.c_double),
+                ("bbox_center", C.c_double * 3), ("bbox_half", C.c_double * 3),
                 ("mesh_vertices", C.POINTER(C.c_double)), ("mesh_faces", C.POINTER(C.c_int32)),
                 ("n_vertices", C.c_int32), ("n_faces", C.c_int32)]
 
@@ -53,7 +54,7 @@ EXPORTED_SYMBOLS = [
     "isdf_config_default", "isdf_shape_default", "isdf_shape_from_name", "isdf_create", "isdf_destroy",
     "isdf_last_error", "isdf_abi_version", "isdf_set_grid", "isdf_set_shape", "isdf_set_points",
     "isdf_set_shard", "isdf_eval", "isdf_eval_device", "isdf_out_stride", "isdf_profile_enable",
-    "isdf_profile_read", "isdf_get_stats",
+    "isdf_profile_read", "isdf_profile_read_secondary", "isdf_get_stats",
 ]
 
 _lib = None
@@ -89,6 +90,7 @@ def load_library(path=None):
     lib.isdf_out_stride.restype = C.c_size_t
     lib.isdf_profile_enable.argtypes = [C.c_void_p, C.c_int]
     lib.isdf_profile_read.argtypes = [C.c_void_p, C.POINTER(C.c_int), dp]
+    lib.isdf_profile_read_secondary.argtypes = [C.c_void_p, dp]
     lib.isdf_get_stats.argtypes = [C.c_void_p, C.POINTER(IsdfStats)]
     if path is None:
         _lib = lib

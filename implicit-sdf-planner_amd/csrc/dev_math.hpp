@@ -9,16 +9,38 @@
 
 namespace isdf {
 
-struct d3 { double x, y, z; };
+// small fixed-size vectors, templated on the scalar so the conservative fp32 pre-filter of tile_kernel can reuse the
+// shape code that the exact fp64 path uses
+template <typename T> struct v3 { T x, y, z; };
+using d3 = v3<double>;
+using f3 = v3<float>;
 struct d4 { double w, x, y, z; };
 struct m3 { double a[9]; };   // row-major
 
-__device__ __forceinline__ d3 mk3(double x, double y, double z) { d3 r; r.x = x; r.y = y; r.z = z; return r; }
-__device__ __forceinline__ d3 operator+(d3 a, d3 b) { return mk3(a.x + b.x, a.y + b.y, a.z + b.z); }
-__device__ __forceinline__ d3 operator-(d3 a, d3 b) { return mk3(a.x - b.x, a.y - b.y, a.z - b.z); }
-__device__ __forceinline__ d3 operator*(double s, d3 a) { return mk3(s * a.x, s * a.y, s * a.z); }
-__device__ __forceinline__ double dot3(d3 a, d3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
-__device__ __forceinline__ double norm3(d3 a) { return sqrt(dot3(a, a)); }
+template <typename T> __device__ __forceinline__ v3<T> mkv(T x, T y, T z) { v3<T> r; r.x = x; r.y = y; r.z = z; return r; }
+__device__ __forceinline__ d3 mk3(double x, double y, double z) { return mkv<double>(x, y, z); }
+template <typename T> __device__ __forceinline__ v3<T> operator+(v3<T> a, v3<T> b) { return mkv<T>(a.x + b.x, a.y + b.y, a.z + b.z); }
+template <typename T> __device__ __forceinline__ v3<T> operator-(v3<T> a, v3<T> b) { return mkv<T>(a.x - b.x, a.y - b.y, a.z - b.z); }
+template <typename T> __device__ __forceinline__ v3<T> operator*(T s, v3<T> a) { return mkv<T>(s * a.x, s * a.y, s * a.z); }
+template <typename T> __device__ __forceinline__ T dot3(v3<T> a, v3<T> b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+
+// overloaded scalar math (float versions map to the single-instruction f32 ops)
+__device__ __forceinline__ double m_sqrt(double x) { return sqrt(x); }
+__device__ __forceinline__ float m_sqrt(float x) { return sqrtf(x); }
+__device__ __forceinline__ double m_abs(double x) { return fabs(x); }
+__device__ __forceinline__ float m_abs(float x) { return fabsf(x); }
+__device__ __forceinline__ double m_max(double a, double b) { return fmax(a, b); }
+__device__ __forceinline__ float m_max(float a, float b) { return fmaxf(a, b); }
+__device__ __forceinline__ double m_min(double a, double b) { return fmin(a, b); }
+__device__ __forceinline__ float m_min(float a, float b) { return fminf(a, b); }
+__device__ __forceinline__ double m_floor(double x) { return floor(x); }
+__device__ __forceinline__ float m_floor(float x) { return floorf(x); }
+__device__ __forceinline__ double m_atan2(double y, double x) { return atan2(y, x); }
+__device__ __forceinline__ float m_atan2(float y, float x) { return atan2f(y, x); }
+__device__ __forceinline__ void m_sincos(double a, double &s, double &c) { sincos(a, &s, &c); }
+__device__ __forceinline__ void m_sincos(float a, float &s, float &c) { sincosf(a, &s, &c); }
+
+template <typename T> __device__ __forceinline__ T norm3(v3<T> a) { return m_sqrt(dot3(a, a)); }
 // Eigen normalized(): unchanged when the squared norm is not > 0
 __device__ __forceinline__ d3 normalized3(d3 a) {
     const double z = dot3(a, a);

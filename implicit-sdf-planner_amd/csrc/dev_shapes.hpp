@@ -1,8 +1,10 @@
-// Device-side robot-shape plugin: analytic SDF kinds + body-frame gradient (gfx950, fp64).
+// Device-side robot-shape plugin: analytic SDF kinds + body-frame gradient (gfx950).
 // The host Shape registry (sw_manager.hpp:74-123) maps to DevShape.kind; the class constants of
-// src/utils/include/utils/Shape.hpp:824-2391 travel in DevShape.p (slot meaning: include/isdf_accel.h).
+// src/utils/include/utils/Shape.hpp:824-2391 travel in ShapeP (slot meaning: include/isdf_accel.h).
 // KIND is a template parameter so the hot kernels inline exactly one shape; KIND = -1 dispatches at run time
-// (kind is wave-uniform, so the switch does not diverge).
+// (kind is wave-uniform, so the switch does not diverge).  The scalar type T is double on the exact path; the
+// float instantiation is ONLY used by tile_kernel's conservative pre-filter (a voxel the filter rejects provably has
+// zero penalty; everything it keeps is re-evaluated in fp64).
 #pragma once
 #include "dev_math.hpp"
 #include "../../include/isdf_accel.h"
@@ -16,149 +18,154 @@ struct DevMesh {
     int nF;
 };
 
+template <typename T> struct ShapeP {
+    T p[16];
+    T trans[3];
+    T rot[9];
+    T csg_r2[9], csg_r3[9];   // rotate_to(c, X, Y) and rotate_to(c, X, Z) matrices, built on the host
+};
+
 struct DevShape {
     int kind, grad_mode;
-    double p[16];
-    double trans[3];
-    double rot[9];
-    double csg_r2[9], csg_r3[9];   // rotate_to(c, X, Y) and rotate_to(c, X, Z) matrices, built on the host
+    int filter_f32;           // 1: the fp32 pre-filter may be used for this shape (continuous analytic SDF)
+    int prune_rows;           // 1: bbox_lo/hi valid -> the scan may prune voxel rows outside the inflated box
+    float bbox_lo[3], bbox_hi[3];
+    ShapeP<double> d;
+    ShapeP<float> f;
     double bound_radius;
     const DevMesh *mesh;
 };
 
-__device__ __forceinline__ double clipd(double v, double lo, double hi) { return fmax(fmin(v, hi), lo); }
-__device__ __forceinline__ double box_q(double qx, double qy, double qz) {
-    const double mx = fmax(qx, 0.0), my = fmax(qy, 0.0), mz = fmax(qz, 0.0);
-    return sqrt(mx * mx + my * my + mz * mz) + fmin(fmax(qx, fmax(qy, qz)), 0.0);
+template <typename T> __device__ __forceinline__ T clipT(T v, T lo, T hi) { return m_max(m_min(v, hi), lo); }
+template <typename T> __device__ __forceinline__ T box_q(T qx, T qy, T qz) {
+    const T mx = m_max(qx, T(0)), my = m_max(qy, T(0)), mz = m_max(qz, T(0));
+    return m_sqrt(mx * mx + my * my + mz * mz) + m_min(m_max(qx, m_max(qy, qz)), T(0));
 }
 
-__device__ __forceinline__ double sdf_torus(const double *P, d3 p) {
-    const double qx = sqrt(p.x * p.x + p.z * p.z) - P[0];
-    return sqrt(qx * qx + p.y * p.y) - P[1];
+template <typename T> __device__ __forceinline__ T sdf_torus(const T *P, v3<T> p) {
+    const T qx = m_sqrt(p.x * p.x + p.z * p.z) - P[0];
+    return m_sqrt(qx * qx + p.y * p.y) - P[1];
 }
-__device__ __forceinline__ double sdf_cappedtorus(const double *P, d3 p) {
-    const double scx = P[0], scy = P[1], ra = P[2], rb = P[3];
-    p.x = fabs(p.x);
-    const double k = (scy * p.x > scx * p.y) ? (p.x * scx + p.y * scy) : sqrt(p.x * p.x + p.y * p.y);
-    return sqrt(dot3(p, p) + ra * ra - 2.0 * ra * k) - rb;
+template <typename T> __device__ __forceinline__ T sdf_cappedtorus(const T *P, v3<T> p) {
+    const T scx = P[0], scy = P[1], ra = P[2], rb = P[3];
+    p.x = m_abs(p.x);
+    const T k = (scy * p.x > scx * p.y) ? (p.x * scx + p.y * scy) : m_sqrt(p.x * p.x + p.y * p.y);
+    return m_sqrt(dot3(p, p) + ra * ra - T(2) * ra * k) - rb;
 }
-__device__ __forceinline__ double sdf_cappedcone(const double *P, d3 p) {
-    const double ra = P[0], rb = P[1];
-    const d3 a = mk3(P[2], P[3], P[4]), b = mk3(P[5], P[6], P[7]);
-    const double rba = rb - ra;
-    const d3 ba = b - a, pa = p - a;
-    const double baba = dot3(ba, ba);
-    const double papa = dot3(pa, pa);
-    const double paba = dot3(pa, ba) / baba;
-    const double x = sqrt(papa - paba * paba * baba);
-    const double cax = fmax(0.0, x - (paba < 0.5 ? ra : rb));
-    const double cay = fabs(paba - 0.5) - 0.5;
-    const double k = rba * rba + baba;
-    const double f = clipd((rba * (x - ra) + paba * baba) / k, 0.0, 1.0);
-    const double cbx = x - ra - f * rba;
-    const double cby = paba - f;
-    const double s = (cbx < 0 && cay < 0) ? -1.0 : 1.0;
-    const double d = sqrt(fmin(cax * cax + cay * cay * baba, cbx * cbx + cby * cby * baba));
-    return s * sqrt(fabs(d)) / fabs(baba);
+template <typename T> __device__ __forceinline__ T sdf_cappedcone(const T *P, v3<T> p) {
+    const T ra = P[0], rb = P[1];
+    const v3<T> a = mkv<T>(P[2], P[3], P[4]), b = mkv<T>(P[5], P[6], P[7]);
+    const T rba = rb - ra;
+    const v3<T> ba = b - a, pa = p - a;
+    const T baba = dot3(ba, ba);
+    const T papa = dot3(pa, pa);
+    const T paba = dot3(pa, ba) / baba;
+    const T x = m_sqrt(papa - paba * paba * baba);
+    const T cax = m_max(T(0), x - (paba < T(0.5) ? ra : rb));
+    const T cay = m_abs(paba - T(0.5)) - T(0.5);
+    const T k = rba * rba + baba;
+    const T f = clipT((rba * (x - ra) + paba * baba) / k, T(0), T(1));
+    const T cbx = x - ra - f * rba;
+    const T cby = paba - f;
+    const T s = (cbx < 0 && cay < 0) ? T(-1) : T(1);
+    const T d = m_sqrt(m_min(cax * cax + cay * cay * baba, cbx * cbx + cby * cby * baba));
+    return s * m_sqrt(m_abs(d)) / m_abs(baba);
 }
-__device__ __forceinline__ double sdf_roundedcone(const double *P, d3 p) {
-    const double r1 = P[0], r2 = P[1], h = P[2];
-    const double qx = sqrt(p.x * p.x + p.y * p.y), qy = p.z;
-    const double b = (r1 - r2) / h;
-    const double a = sqrt(1.0 - b * b);
-    const double k = -b * qx + a * qy;
-    const double c1 = sqrt(qx * qx + qy * qy) - r1;
-    const double c2 = sqrt(qx * qx + (qy - h) * (qy - h)) - r2;
-    const double c3 = (a * qx + b * qy) - r1;
+template <typename T> __device__ __forceinline__ T sdf_roundedcone(const T *P, v3<T> p) {
+    const T r1 = P[0], r2 = P[1], h = P[2];
+    const T qx = m_sqrt(p.x * p.x + p.y * p.y), qy = p.z;
+    const T b = (r1 - r2) / h;
+    const T a = m_sqrt(T(1) - b * b);
+    const T k = -b * qx + a * qy;
+    const T c1 = m_sqrt(qx * qx + qy * qy) - r1;
+    const T c2 = m_sqrt(qx * qx + (qy - h) * (qy - h)) - r2;
+    const T c3 = (a * qx + b * qy) - r1;
     return (k < 0) ? c1 : ((k > a * h) ? c2 : c3);
 }
-__device__ __forceinline__ double sdf_wireframebox(const double *P, d3 p) {
-    const double th = P[3];
-    const double px = fabs(p.x) - P[0] / 2 - th / 2, py = fabs(p.y) - P[1] / 2 - th / 2, pz = fabs(p.z) - P[2] / 2 - th / 2;
-    const double qx = fabs(px + th / 2) - th / 2, qy = fabs(py + th / 2) - th / 2, qz = fabs(pz + th / 2) - th / 2;
-    return fmin(fmin(box_q(px, qy, qz), box_q(qx, py, qz)), box_q(qx, qy, pz));
+template <typename T> __device__ __forceinline__ T sdf_wireframebox(const T *P, v3<T> p) {
+    const T th = P[3];
+    const T px = m_abs(p.x) - P[0] / 2 - th / 2, py = m_abs(p.y) - P[1] / 2 - th / 2, pz = m_abs(p.z) - P[2] / 2 - th / 2;
+    const T qx = m_abs(px + th / 2) - th / 2, qy = m_abs(py + th / 2) - th / 2, qz = m_abs(pz + th / 2) - th / 2;
+    return m_min(m_min(box_q(px, qy, qz), box_q(qx, py, qz)), box_q(qx, qy, pz));
 }
-__device__ __forceinline__ double sdf_bendlinear(const double *P, d3 p) {
-    const double L = P[0], radius = P[1];
+template <typename T> __device__ __forceinline__ T sdf_bendlinear(const T *P, v3<T> p) {
+    const T L = P[0], radius = P[1];
     // p0 = (0,0,-1), p1 = (0,0,1), v = (-1,0,0), ab = (0,0,2)
-    const double t = clipd(((p.x - 0.0) * 0.0 + (p.y - 0.0) * 0.0 + (p.z + 1.0) * 2.0) / 4.0, 0.0, 1.0);
-    const double u = 2 * t - 1;
-    const double e = (t < 0.5) ? (2 * t * t) : (-0.5 * (u * (u - 2) - 1));
-    const d3 pt = mk3(e * -1.0 + p.x, e * 0.0 + p.y, e * 0.0 + p.z);
-    const d3 pa = mk3(pt.x, pt.y, pt.z + L);
-    const d3 ba = mk3(0.0, 0.0, 2 * L);
-    const double h = fmax(fmin(dot3(pa, ba) / dot3(ba, ba), 1.0), 0.0);
+    const T t = clipT(((p.x - T(0)) * T(0) + (p.y - T(0)) * T(0) + (p.z + T(1)) * T(2)) / T(4), T(0), T(1));
+    const T u = 2 * t - 1;
+    const T e = (t < T(0.5)) ? (2 * t * t) : (T(-0.5) * (u * (u - 2) - 1));
+    const v3<T> pt = mkv<T>(e * T(-1) + p.x, e * T(0) + p.y, e * T(0) + p.z);
+    const v3<T> pa = mkv<T>(pt.x, pt.y, pt.z + L);
+    const v3<T> ba = mkv<T>(T(0), T(0), 2 * L);
+    const T h = m_max(m_min(dot3(pa, ba) / dot3(ba, ba), T(1)), T(0));
     return norm3(pa - h * ba) - radius;
 }
-__device__ __forceinline__ double sdf_twistbend(const double *P, d3 p, bool bend) {
-    const double ang = bend ? P[3] * p.x : P[3] * p.z;
-    double s, c;
-    sincos(ang, &s, &c);
-    const double rx = c * p.x - s * p.y, ry = s * p.x + c * p.y;
-    return box_q(fabs(rx) - P[0] / 2.0, fabs(ry) - P[1] / 2.0, fabs(p.z) - P[2] / 2.0);
+template <typename T> __device__ __forceinline__ T sdf_twistbend(const T *P, v3<T> p, bool bend) {
+    const T ang = bend ? P[3] * p.x : P[3] * p.z;
+    T s, c;
+    m_sincos(ang, s, c);
+    const T rx = c * p.x - s * p.y, ry = s * p.x + c * p.y;
+    return box_q(m_abs(rx) - P[0] / T(2), m_abs(ry) - P[1] / T(2), m_abs(p.z) - P[2] / T(2));
 }
-__device__ __forceinline__ double sdf_table(const double *P, d3 p) {
-    const double x = fabs(p.x), y = fabs(p.y), z = p.z;
-    const double f1 = box_q(fabs(x - (P[0] + P[3]) / 2) - (P[3] - P[0]) / 2.0, fabs(y - (P[1] + P[4]) / 2) - (P[4] - P[1]) / 2.0,
-                            fabs(z - (P[2] + P[5]) / 2) - (P[5] - P[2]) / 2.0);
-    const double f2 = box_q(fabs(x - (P[6] + P[9]) / 2) - (P[9] - P[6]) / 2.0, fabs(y - (P[7] + P[10]) / 2) - (P[10] - P[7]) / 2.0,
-                            fabs(z - (P[8] + P[11]) / 2) - (P[11] - P[8]) / 2.0);
-    return fmin(f1, f2);
+template <typename T> __device__ __forceinline__ T sdf_table(const T *P, v3<T> p) {
+    const T x = m_abs(p.x), y = m_abs(p.y), z = p.z;
+    const T f1 = box_q(m_abs(x - (P[0] + P[3]) / 2) - (P[3] - P[0]) / T(2), m_abs(y - (P[1] + P[4]) / 2) - (P[4] - P[1]) / T(2),
+                       m_abs(z - (P[2] + P[5]) / 2) - (P[5] - P[2]) / T(2));
+    const T f2 = box_q(m_abs(x - (P[6] + P[9]) / 2) - (P[9] - P[6]) / T(2), m_abs(y - (P[7] + P[10]) / 2) - (P[10] - P[7]) / T(2),
+                       m_abs(z - (P[8] + P[11]) / 2) - (P[11] - P[8]) / T(2));
+    return m_min(f1, f2);
 }
-__device__ __forceinline__ void rot2d(double &qx, double &qy, double a) {
-    double sa, ca;
-    sincos(a, &sa, &ca);
-    const double nx = qx * ca + qy * sa, ny = qy * ca + (-qx) * sa;
+template <typename T> __device__ __forceinline__ void rot2d(T &qx, T &qy, T a) {
+    T sa, ca;
+    m_sincos(a, sa, ca);
+    const T nx = qx * ca + qy * sa, ny = qy * ca + (-qx) * sa;
     qx = nx; qy = ny;
 }
-__device__ __forceinline__ double sdf_trefoil(const double *P, d3 p) {
-    const double PI = 3.14159265358979323846;
-    double qx = p.x, qy = p.y;
-    const double a = atan2(qy, qx);
-    qx = sqrt(qx * qx + qy * qy) - P[0];
+template <typename T> __device__ __forceinline__ T sdf_trefoil(const T *P, v3<T> p) {
+    const T PI = T(3.14159265358979323846);
+    T qx = p.x, qy = p.y;
+    const T a = m_atan2(qy, qx);
+    qx = m_sqrt(qx * qx + qy * qy) - P[0];
     qy = -p.z;
-    rot2d(qx, qy, 1.5 * a);
-    rot2d(qx, qy, -PI * (floor(atan2(qy, qx) / PI + 0.5)));
-    qx -= 1.0;
-    const double dx = fabs(qx) - P[1], dy = fabs(qy) - P[2];
-    const double mx = fmax(dx, 0.0), my = fmax(dy, 0.0);
-    const double d = (fmin(fmax(dx, dy), 0.0) + sqrt(mx * mx + my * my)) - P[3];
-    return P[4] * fmin(d, 100.0);
+    rot2d(qx, qy, T(1.5) * a);
+    rot2d(qx, qy, -PI * (m_floor(m_atan2(qy, qx) / PI + T(0.5))));
+    qx -= T(1);
+    const T dx = m_abs(qx) - P[1], dy = m_abs(qy) - P[2];
+    const T mx = m_max(dx, T(0)), my = m_max(dy, T(0));
+    const T d = (m_min(m_max(dx, dy), T(0)) + m_sqrt(mx * mx + my * my)) - P[3];
+    return P[4] * m_min(d, T(100));
 }
-__device__ __forceinline__ double sdf_smooth(const double *P, d3 p, bool intersection) {
-    const double box_sdf = box_q(fabs(p.x) - P[0] / 2.0, fabs(p.y) - P[1] / 2.0, fabs(p.z) - P[2] / 2.0);
-    const double sphere_sdf = norm3(p) - P[3];
-    const double kk = P[4];
+template <typename T> __device__ __forceinline__ T sdf_smooth(const T *P, v3<T> p, bool intersection) {
+    const T box_sdf = box_q(m_abs(p.x) - P[0] / T(2), m_abs(p.y) - P[1] / T(2), m_abs(p.z) - P[2] / T(2));
+    const T sphere_sdf = norm3(p) - P[3];
+    const T kk = P[4];
     if (!intersection) {
-        const double h = clipd(0.5 - 0.5 * (box_sdf + sphere_sdf) / kk, 0.0, 1.0);
-        return (box_sdf - (box_sdf + sphere_sdf) * h) + kk * h * (1.0 - h);
+        const T h = clipT(T(0.5) - T(0.5) * (box_sdf + sphere_sdf) / kk, T(0), T(1));
+        return (box_sdf - (box_sdf + sphere_sdf) * h) + kk * h * (T(1) - h);
     }
-    const double h = clipd(0.5 - 0.5 * (sphere_sdf - box_sdf) / kk, 0.0, 1.0);
-    return (sphere_sdf + (box_sdf - sphere_sdf) * h) + kk * h * (1.0 - h);
+    const T h = clipT(T(0.5) - T(0.5) * (sphere_sdf - box_sdf) / kk, T(0), T(1));
+    return (sphere_sdf + (box_sdf - sphere_sdf) * h) + kk * h * (T(1) - h);
 }
-__device__ __forceinline__ double sdf_csg(const DevShape &S, d3 p) {
-    const double *P = S.p;
-    const double f = fmax(norm3(p) - P[0], box_q(fabs(p.x) - P[1] / 2.0, fabs(p.y) - P[1] / 2.0, fabs(p.z) - P[1] / 2.0));
-    const double c1 = sqrt(p.x * p.x + p.y * p.y) - P[2];
-    const double *A = S.csg_r2, *B = S.csg_r3;
-    const double ax = A[0] * p.x + A[1] * p.y + A[2] * p.z, ay = A[3] * p.x + A[4] * p.y + A[5] * p.z;
-    const double bx = B[0] * p.x + B[1] * p.y + B[2] * p.z, by = B[3] * p.x + B[4] * p.y + B[5] * p.z;
-    const double c2 = sqrt(ax * ax + ay * ay) - P[2];
-    const double c3 = sqrt(bx * bx + by * by) - P[2];
-    return fmax(f, -fmin(fmin(c1, c2), c3));
+template <typename T> __device__ __forceinline__ T sdf_csg(const ShapeP<T> &S, v3<T> p) {
+    const T *P = S.p;
+    const T f = m_max(norm3(p) - P[0], box_q(m_abs(p.x) - P[1] / T(2), m_abs(p.y) - P[1] / T(2), m_abs(p.z) - P[1] / T(2)));
+    const T c1 = m_sqrt(p.x * p.x + p.y * p.y) - P[2];
+    const T *A = S.csg_r2, *B = S.csg_r3;
+    const T ax = A[0] * p.x + A[1] * p.y + A[2] * p.z, ay = A[3] * p.x + A[4] * p.y + A[5] * p.z;
+    const T bx = B[0] * p.x + B[1] * p.y + B[2] * p.z, by = B[3] * p.x + B[4] * p.y + B[5] * p.z;
+    const T c2 = m_sqrt(ax * ax + ay * ay) - P[2];
+    const T c3 = m_sqrt(bx * bx + by * by) - P[2];
+    return m_max(f, -m_min(m_min(c1, c2), c3));
 }
 
-__device__ double mesh_sdf(const DevMesh *m, d3 p);              // dev_mesh.hpp
-__device__ double mesh_sdf_grad(const DevMesh *m, d3 p, d3 &g);  // dev_mesh.hpp
-
-template <int KIND>
-__device__ __forceinline__ double shape_sdf(const DevShape &S, d3 pr) {
-    const int kind = (KIND >= 0) ? KIND : S.kind;
-    if (kind == ISDF_SHAPE_MESH) return mesh_sdf(S.mesh, pr);
+// analytic kinds only (kind != MESH)
+template <int KIND, typename T>
+__device__ __forceinline__ T analytic_sdf(const ShapeP<T> &S, int kind_rt, v3<T> pr) {
+    const int kind = (KIND >= 0) ? KIND : kind_rt;
     if (kind == ISDF_SHAPE_BALL) return norm3(pr) - S.p[0];
-    const double dx = pr.x - S.trans[0], dy = pr.y - S.trans[1], dz = pr.z - S.trans[2];
-    const double *R = S.rot;
-    const d3 p = mk3(dx * R[0] + dy * R[3] + dz * R[6], dx * R[1] + dy * R[4] + dz * R[7], dx * R[2] + dy * R[5] + dz * R[8]);
+    const T dx = pr.x - S.trans[0], dy = pr.y - S.trans[1], dz = pr.z - S.trans[2];
+    const T *R = S.rot;
+    const v3<T> p = mkv<T>(dx * R[0] + dy * R[3] + dz * R[6], dx * R[1] + dy * R[4] + dz * R[7], dx * R[2] + dy * R[5] + dz * R[8]);
     switch (kind) {
     case ISDF_SHAPE_TORUS: return sdf_torus(S.p, p);
     case ISDF_SHAPE_CAPPEDTORUS: return sdf_cappedtorus(S.p, p);
@@ -173,9 +180,20 @@ __device__ __forceinline__ double shape_sdf(const DevShape &S, d3 pr) {
     case ISDF_SHAPE_SMOOTHDIFFERENCE: return sdf_smooth(S.p, p, false);
     case ISDF_SHAPE_SMOOTHINTERSECTION: return sdf_smooth(S.p, p, true);
     case ISDF_SHAPE_CSG: return sdf_csg(S, p);
-    case ISDF_SHAPE_BOX: return box_q(fabs(p.x) - S.p[0], fabs(p.y) - S.p[1], fabs(p.z) - S.p[2]);
-    default: return 1e9;
+    case ISDF_SHAPE_BOX: return box_q(m_abs(p.x) - S.p[0], m_abs(p.y) - S.p[1], m_abs(p.z) - S.p[2]);
+    default: return T(1e9);
     }
+}
+
+__device__ double mesh_sdf(const DevMesh *m, d3 p);              // dev_mesh.hpp
+__device__ double mesh_sdf_grad(const DevMesh *m, d3 p, d3 &g);  // dev_mesh.hpp
+
+// BasicShape::getonlySDF(pos_rel), exact path (fp64)
+template <int KIND>
+__device__ __forceinline__ double shape_sdf(const DevShape &S, d3 pr) {
+    const int kind = (KIND >= 0) ? KIND : S.kind;
+    if (kind == ISDF_SHAPE_MESH) return mesh_sdf(S.mesh, pr);
+    return analytic_sdf<KIND, double>(S.d, S.kind, pr);
 }
 
 // getonlyGrad1: central difference dx = 5e-6 (temp -= dx; temp += 2dx), normalised — Shape.hpp:32-57;

@@ -6,6 +6,7 @@
 #include <cmath>
 #include <cstdio>
 #include <cstring>
+#include <cstdlib>
 #include <string>
 #include <vector>
 #include <new>
@@ -15,7 +16,7 @@ using namespace isdf;
 namespace {
 thread_local std::string g_create_error;
 
-struct ProfEvent { hipEvent_t a, b; };
+struct ProfEvent { hipEvent_t a, b, c; };
 }
 
 struct isdf_ctx {
@@ -26,6 +27,7 @@ struct isdf_ctx {
     DevGrid grid{};
     float *d_esdf = nullptr;
     uint8_t *d_occ = nullptr;
+    unsigned *d_bits = nullptr; size_t bits_cap = 0; bool bits_dirty = true;
     bool have_geom = false;
     // shape
     DevShape shape{};
@@ -41,7 +43,12 @@ struct isdf_ctx {
     // shard
     int rank = 0, world = 1;
     // per-step scratch
-    double *d_partial = nullptr; size_t partial_cap = 0;
+    PoseRec *d_pose = nullptr; int *d_sample_last = nullptr; size_t sample_cap = 0;
+    unsigned *d_pool_count = nullptr; unsigned *d_pool_entries = nullptr; int *d_slot_sample = nullptr, *d_slot_prev = nullptr;
+    double *d_slot_res = nullptr; unsigned *d_slot_cnt = nullptr; size_t pool_cap = 0;
+    SweepParams last_P{}; bool have_last_P = false; int parity = 0;
+    double last_exact_ms = 0.0;
+    double *d_piece_cost = nullptr; size_t piece_cap = 0;
     double *d_in = nullptr; size_t in_cap = 0;        // host-API staging: T | coeffs
     double *d_out = nullptr; size_t out_cap = 0;
     std::vector<double> h_out;
@@ -54,7 +61,7 @@ struct isdf_ctx {
     int *d_n_coarse = nullptr;
     double *d_point_partial = nullptr; int *d_point_piece = nullptr; int point_cap = 0;
     // profiling
-    bool prof_on = false;
+    bool prof_on = false; int prof_every = 1; long long prof_tick = 0;
     std::vector<ProfEvent> prof_events;
     size_t prof_used = 0;
     hipStream_t stream = nullptr;   // stream of the host API
@@ -179,7 +186,7 @@ extern "C" int isdf_create(isdf_ctx **out, const isdf_config *cfg) {
     c->device = cfg->device;
     if (hipSetDevice(c->device) != hipSuccess || hipMalloc(&c->d_stats, 8 * sizeof(unsigned long long)) != hipSuccess ||
         hipMalloc(&c->d_traj_duration, sizeof(double)) != hipSuccess || hipMalloc(&c->d_n_coarse, sizeof(int)) != hipSuccess ||
-        hipMemset(c->d_traj_duration, 0, sizeof(double)) != hipSuccess || hipStreamCreate(&c->stream) != hipSuccess) {
+        hipMemset(c->d_traj_duration, 0, sizeof(double)) != hipSuccess || hipMemset(c->d_stats, 0, 8 * sizeof(unsigned long long)) != hipSuccess || hipStreamCreate(&c->stream) != hipSuccess) {
         delete c;
         return fail(nullptr, ISDF_ERR_HIP, "device initialisation failed");
     }
@@ -198,8 +205,8 @@ extern "C" int isdf_destroy(isdf_ctx *c) {
     if (!c) return ISDF_OK;
     (void)hipSetDevice(c->device);
     (void)hipDeviceSynchronize();
-    for (auto &p : c->prof_events) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
-    void *ptrs[] = {c->d_esdf, c->d_occ, c->d_points, c->d_tstar, c->d_partial, c->d_in, c->d_out, c->d_stats,
+    for (auto &p : c->prof_events) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); (void)hipEventDestroy(p.c); }
+    void *ptrs[] = {c->d_esdf, c->d_occ, c->d_points, c->d_tstar, c->d_pose, c->d_sample_last, c->d_pool_count, c->d_pool_entries, c->d_slot_sample, c->d_slot_prev, c->d_slot_res, c->d_slot_cnt, c->d_bits, c->d_piece_cost, c->d_in, c->d_out, c->d_stats,
                     c->d_traj_duration, c->d_coarse_t, c->d_coarse_pose, c->d_n_coarse, c->d_point_partial, c->d_point_piece};
     for (void *p : ptrs) if (p) (void)hipFree(p);
     free_mesh(c);
@@ -255,6 +262,7 @@ extern "C" int isdf_set_grid(isdf_ctx *c, const void *vox, int dtype, int nx, in
     }
     c->grid.esdf = c->d_esdf;
     c->grid.occ = c->d_occ;
+    c->bits_dirty = true;
     return ISDF_OK;
 }
 
@@ -290,13 +298,20 @@ extern "C" int isdf_set_shape(isdf_ctx *c, const isdf_shape *s) {
     d.grad_mode = s->grad_mode;
     if (d.grad_mode == ISDF_GRAD_DEFAULT)
         d.grad_mode = s->kind == ISDF_SHAPE_BOX ? ISDF_GRAD_BOX_FORWARD : (s->kind == ISDF_SHAPE_BALL ? ISDF_GRAD_ANALYTIC_BALL : ISDF_GRAD_CENTRAL);
-    std::memcpy(d.p, s->params, sizeof(d.p));
-    std::memcpy(d.trans, s->trans, sizeof(d.trans));
-    std::memcpy(d.rot, s->rotate, sizeof(d.rot));
+    std::memcpy(d.d.p, s->params, sizeof(d.d.p));
+    std::memcpy(d.d.trans, s->trans, sizeof(d.d.trans));
+    std::memcpy(d.d.rot, s->rotate, sizeof(d.d.rot));
     d.bound_radius = s->bound_radius;
     const double X[3] = {1, 0, 0}, Y[3] = {0, 1, 0}, Z[3] = {0, 0, 1};
-    csg_rotate_to(X, Y, d.csg_r2);
-    csg_rotate_to(X, Z, d.csg_r3);
+    csg_rotate_to(X, Y, d.d.csg_r2);
+    csg_rotate_to(X, Z, d.d.csg_r3);
+    for (int i = 0; i < 16; i++) d.f.p[i] = (float)d.d.p[i];
+    for (int i = 0; i < 3; i++) d.f.trans[i] = (float)d.d.trans[i];
+    for (int i = 0; i < 9; i++) { d.f.rot[i] = (float)d.d.rot[i]; d.f.csg_r2[i] = (float)d.d.csg_r2[i]; d.f.csg_r3[i] = (float)d.d.csg_r3[i]; }
+    d.prune_rows = (s->bbox_half[0] > 0 && s->bbox_half[1] > 0 && s->bbox_half[2] > 0) && !(getenv("ISDF_NO_ROW_PRUNE") && getenv("ISDF_NO_ROW_PRUNE")[0] == '1');
+    for (int i = 0; i < 3; i++) { d.bbox_lo[i] = (float)(s->bbox_center[i] - s->bbox_half[i]); d.bbox_hi[i] = (float)(s->bbox_center[i] + s->bbox_half[i]); }
+    // the fp32 pre-filter of tile_kernel needs a continuous analytic SDF; ISDF_NO_F32_FILTER=1 disables it (A/B runs)
+    d.filter_f32 = (s->kind != ISDF_SHAPE_MESH) && !(getenv("ISDF_NO_F32_FILTER") && getenv("ISDF_NO_F32_FILTER")[0] == '1');
     d.mesh = nullptr;
     if (s->kind == ISDF_SHAPE_MESH) {
         if (!s->mesh_vertices || !s->mesh_faces || s->n_faces < 1 || s->n_vertices < 3) return fail(c, ISDF_ERR_INVALID_ARG, "mesh shape needs vertices and faces");
@@ -378,10 +393,12 @@ static void fill_flat(const isdf_config &cfg, FlatP &f) {
 static int prof_begin(isdf_ctx *c, hipStream_t st, ProfEvent **ev) {
     *ev = nullptr;
     if (!c->prof_on) return ISDF_OK;
+    if ((c->prof_tick++ % c->prof_every) != 0) return ISDF_OK;
     if (c->prof_used == c->prof_events.size()) {
         ProfEvent p;
         HIPCHK(c, hipEventCreate(&p.a));
         HIPCHK(c, hipEventCreate(&p.b));
+        HIPCHK(c, hipEventCreate(&p.c));
         c->prof_events.push_back(p);
     }
     *ev = &c->prof_events[c->prof_used++];
@@ -398,11 +415,11 @@ static int eval_device_impl(isdf_ctx *c, int n_traj, int N, const double *d_T, c
     if (!c->have_shape && (cfg.variant == ISDF_V1_SWEPT || cfg.enable_pos)) return fail(c, ISDF_ERR_STATE, "shape not set");
     HIPCHK(c, hipSetDevice(c->device));
     const size_t ostride = isdf_out_stride(N);
-    HIPCHK(c, hipMemsetAsync(d_out, 0, (size_t)n_traj * ostride * sizeof(double), st));
-    HIPCHK(c, hipMemsetAsync(c->d_stats, 0, 8 * sizeof(unsigned long long), st));
 
     if (cfg.variant == ISDF_V1_SWEPT) {
         if (n_traj != 1) return fail(c, ISDF_ERR_UNSUPPORTED, "the swept-volume sweep takes one trajectory");
+        HIPCHK(c, hipMemsetAsync(d_out, 0, (size_t)n_traj * ostride * sizeof(double), st));
+        HIPCHK(c, hipMemsetAsync(c->d_stats, 0, 8 * sizeof(unsigned long long), st));
         if (c->M <= 0) return ISDF_OK;   // no obstacle points: nothing to add
         long long b, e;
         shard_range(c->M, c->rank, c->world, b, e);
@@ -435,7 +452,7 @@ static int eval_device_impl(isdf_ctx *c, int n_traj, int N, const double *d_T, c
         int rc = prof_begin(c, st, &ev);
         if (rc) return rc;
         launch_swept_sweep(P, st);
-        if (ev) HIPCHK(c, hipEventRecord(ev->b, st));
+        if (ev) { HIPCHK(c, hipEventRecord(ev->b, st)); HIPCHK(c, hipEventRecord(ev->c, st)); }
         launch_swept_reduce(P, d_out, st);
         HIPCHK(c, hipGetLastError());
         return ISDF_OK;
@@ -451,7 +468,36 @@ static int eval_device_impl(isdf_ctx *c, int n_traj, int N, const double *d_T, c
     long long pb, pe;
     shard_range(total_pieces, c->rank, c->world, pb, pe);
     const size_t n_samples = (size_t)total_pieces * (cfg.integral_intervs + 1);
-    int rc = ensure(c, &c->d_partial, &c->partial_cap, n_samples * PARTIAL_STRIDE);
+    if (c->sample_cap < n_samples) {
+        if (c->d_pose) (void)hipFree(c->d_pose);
+        if (c->d_sample_last) (void)hipFree(c->d_sample_last);
+        c->d_pose = nullptr; c->d_sample_last = nullptr; c->sample_cap = 0;
+        HIPCHK(c, hipMalloc(&c->d_pose, n_samples * sizeof(PoseRec)));
+        HIPCHK(c, hipMalloc(&c->d_sample_last, n_samples * sizeof(int)));
+        c->sample_cap = n_samples;
+    }
+    // candidate pool: 4 slots (256 surviving voxels) per pose on average + slack; ISDF_POOL_SLOTS overrides.
+    // If it ever overflows the step reports ISDF_ERR_OVERFLOW (host API) / stats.overflow (device API).
+    size_t want_slots = n_samples * 4 + 65536;
+    if (const char *e = getenv("ISDF_POOL_SLOTS")) want_slots = (size_t)atoll(e);
+    if (want_slots > (size_t)0x7fffff00) want_slots = 0x7fffff00;
+    want_slots = (want_slots + POOL_SHARDS - 1) / POOL_SHARDS * POOL_SHARDS;
+    if (c->pool_cap < want_slots) {
+        void *old[] = {c->d_pool_entries, c->d_slot_sample, c->d_slot_prev, c->d_slot_res, c->d_slot_cnt};
+        for (void *p : old) if (p) (void)hipFree(p);
+        c->d_pool_entries = nullptr; c->d_slot_sample = nullptr; c->d_slot_prev = nullptr; c->d_slot_res = nullptr; c->d_slot_cnt = nullptr; c->pool_cap = 0;
+        if (!c->d_pool_count) {
+            HIPCHK(c, hipMalloc(&c->d_pool_count, (size_t)2 * POOL_SHARDS * POOL_COUNTER_STRIDE * sizeof(unsigned)));
+            HIPCHK(c, hipMemset(c->d_pool_count, 0, (size_t)2 * POOL_SHARDS * POOL_COUNTER_STRIDE * sizeof(unsigned)));
+        }
+        HIPCHK(c, hipMalloc(&c->d_slot_cnt, want_slots * sizeof(unsigned)));
+        HIPCHK(c, hipMalloc(&c->d_pool_entries, want_slots * 64 * sizeof(unsigned)));
+        HIPCHK(c, hipMalloc(&c->d_slot_sample, want_slots * sizeof(int)));
+        HIPCHK(c, hipMalloc(&c->d_slot_prev, want_slots * sizeof(int)));
+        HIPCHK(c, hipMalloc(&c->d_slot_res, want_slots * ACC_STRIDE * sizeof(double)));
+        c->pool_cap = want_slots;
+    }
+    int rc = ensure(c, &c->d_piece_cost, &c->piece_cap, (size_t)total_pieces);
     if (rc) return rc;
     SweepParams P{};
     P.grid = c->grid;
@@ -470,16 +516,36 @@ static int eval_device_impl(isdf_ctx *c, int n_traj, int N, const double *d_T, c
     P.cull_threshold = 0.0;
     if (cfg.variant == ISDF_V3_ESDF_TILE && cfg.enable_cull && c->shape.bound_radius > 0)
         P.cull_threshold = c->shape.bound_radius + cfg.safety_hor + std::sqrt(3.0) * P.grid.res;
-    P.T = d_T; P.coeffs = d_coeffs; P.partial = c->d_partial; P.stats = c->d_stats;
+    P.T = d_T; P.coeffs = d_coeffs; P.pose = c->d_pose; P.piece_cost = c->d_piece_cost;
+    P.pool_count = c->d_pool_count; P.pool_cap = (int)c->pool_cap; P.pool_entries = c->d_pool_entries;
+    P.slot_sample = c->d_slot_sample; P.slot_prev = c->d_slot_prev; P.slot_res = c->d_slot_res; P.slot_cnt = c->d_slot_cnt; P.sample_last = c->d_sample_last;
+    P.out = d_out; P.stats = c->d_stats;
+    if (cfg.enable_pos && c->bits_dirty) {
+        const size_t nw = (size_t)c->grid.X * c->grid.Y * ((c->grid.Z + 31) / 32);
+        if (c->bits_cap < nw) {
+            if (c->d_bits) (void)hipFree(c->d_bits);
+            c->d_bits = nullptr; c->bits_cap = 0;
+            HIPCHK(c, hipMalloc(&c->d_bits, nw * sizeof(unsigned)));
+            c->bits_cap = nw;
+        }
+        c->grid.ZW = (c->grid.Z + 31) / 32;
+        c->grid.bits = c->d_bits;
+        launch_build_bits(c->grid, cfg.variant == ISDF_V3_ESDF_TILE ? 1 : 0, (float)cfg.occ_thresh, c->d_bits, st);
+        c->bits_dirty = false;
+        P.grid = c->grid;
+    }
+    P.parity = c->parity;
+    c->parity ^= 1;
+    c->last_P = P; c->have_last_P = true;
     ProfEvent *ev;
     rc = prof_begin(c, st, &ev);
     if (rc) return rc;
-    launch_tile_sweep(P, st);
+    launch_scan(P, st);
     if (ev) HIPCHK(c, hipEventRecord(ev->b, st));
-    ReduceParams Rp{};
-    Rp.n_traj = n_traj; Rp.N = N; Rp.K = cfg.integral_intervs; Rp.piece_begin = (int)pb; Rp.piece_end = (int)pe;
-    Rp.partial = c->d_partial; Rp.out = d_out; Rp.v1_mode = 0;
-    launch_tile_reduce(Rp, st);
+    launch_exact(P, st);
+    if (ev) HIPCHK(c, hipEventRecord(ev->c, st));
+    launch_tail(P, st);
+    launch_finalize(P, st);
     HIPCHK(c, hipGetLastError());
     return ISDF_OK;
 }
@@ -492,10 +558,17 @@ extern "C" int isdf_eval_device(isdf_ctx *c, int n_traj, int N, const double *d_
 
 static int fetch_stats(isdf_ctx *c) {
     unsigned long long h[8];
+    if (c->cfg.variant != ISDF_V1_SWEPT && c->have_last_P) {
+        HIPCHK(c, hipDeviceSynchronize());
+        HIPCHK(c, hipMemset(c->d_stats, 0, 4 * sizeof(unsigned long long)));   // keep [4] = overflow flag
+        launch_stats(c->last_P, nullptr);
+        HIPCHK(c, hipDeviceSynchronize());
+    }
     HIPCHK(c, hipMemcpy(h, c->d_stats, sizeof(h), hipMemcpyDeviceToHost));
     c->last_stats.n_units = (int64_t)h[0]; c->last_stats.n_units_culled = (int64_t)h[1];
     c->last_stats.n_pairs = (int64_t)h[2]; c->last_stats.n_grad_pairs = (int64_t)h[3];
     c->last_stats.overflow = (int32_t)h[4];
+    if (h[4]) HIPCHK(c, hipMemset(c->d_stats + 4, 0, sizeof(unsigned long long)));   // sticky until read
     return ISDF_OK;
 }
 
@@ -560,7 +633,9 @@ extern "C" int isdf_eval(isdf_ctx *c, int n_traj, const int *N, const double *co
 // --------------------------------------------------------------------------------------------------------------
 extern "C" int isdf_profile_enable(isdf_ctx *c, int on) {
     if (!c) return ISDF_ERR_INVALID_ARG;
-    c->prof_on = on != 0;
+    c->prof_on = on != 0;          // on = N > 0: instrument every N-th launch (event records cost GPU time)
+    c->prof_every = on > 0 ? on : 1;
+    c->prof_tick = 0;
     c->prof_used = 0;
     return ISDF_OK;
 }
@@ -568,16 +643,25 @@ extern "C" int isdf_profile_enable(isdf_ctx *c, int on) {
 extern "C" int isdf_profile_read(isdf_ctx *c, int *n, double *mean_ms) {
     if (!c || !n || !mean_ms) return ISDF_ERR_INVALID_ARG;
     HIPCHK(c, hipSetDevice(c->device));
-    double sum = 0.0;
+    double sum = 0.0, sum2 = 0.0;
     for (size_t i = 0; i < c->prof_used; i++) {
-        HIPCHK(c, hipEventSynchronize(c->prof_events[i].b));
+        HIPCHK(c, hipEventSynchronize(c->prof_events[i].c));
         float ms = 0.f;
         HIPCHK(c, hipEventElapsedTime(&ms, c->prof_events[i].a, c->prof_events[i].b));
         sum += ms;
+        HIPCHK(c, hipEventElapsedTime(&ms, c->prof_events[i].b, c->prof_events[i].c));
+        sum2 += ms;
     }
     *n = (int)c->prof_used;
     *mean_ms = c->prof_used ? sum / c->prof_used : 0.0;
+    c->last_exact_ms = c->prof_used ? sum2 / c->prof_used : 0.0;
     c->prof_used = 0;
+    return ISDF_OK;
+}
+
+extern "C" int isdf_profile_read_secondary(isdf_ctx *c, double *mean_ms) {
+    if (!c || !mean_ms) return ISDF_ERR_INVALID_ARG;
+    *mean_ms = c->last_exact_ms;
     return ISDF_OK;
 }
 

@@ -116,11 +116,17 @@ class Engine:
         return {"units": s.n_units, "culled": s.n_units_culled, "pairs": s.n_pairs,
                 "grad_pairs": s.n_grad_pairs, "overflow": s.overflow}
 
-    def profile_enable(self, on=True):
-        self._check(self.lib.isdf_profile_enable(self.h, 1 if on else 0))
+    def profile_enable(self, every=1):
+        """every = N > 0: instrument every N-th eval_device; 0/False: off."""
+        self._check(self.lib.isdf_profile_enable(self.h, int(every)))
 
     def profile_read(self):
         n = C.c_int(0)
         ms = C.c_double(0)
         self._check(self.lib.isdf_profile_read(self.h, C.byref(n), C.byref(ms)))
         return n.value, ms.value
+
+    def profile_read_secondary(self):
+        ms = C.c_double(0)
+        self._check(self.lib.isdf_profile_read_secondary(self.h, C.byref(ms)))
+        return ms.value

@@ -46,7 +46,8 @@ def poly_rotation(roll_deg, pitch_deg, yaw_deg):
     return Rz @ Ry @ Rx
 
 
-def make_shape(name, params=None, poly_params=(0, 0, 0, 0, 0, 0), grad_mode=capi.GRAD_DEFAULT, bound_radius=0.0):
+def make_shape(name, params=None, poly_params=(0, 0, 0, 0, 0, 0), grad_mode=capi.GRAD_DEFAULT, bound_radius=0.0,
+               bbox=None):
     """isdf_shape for a registry name; poly_params = yaml [x, y, z, roll, pitch, yaw] (degrees)."""
     kind, defaults = _SHAPE_DEFAULTS[name]
     s = capi.IsdfShape()
@@ -62,6 +63,10 @@ def make_shape(name, params=None, poly_params=(0, 0, 0, 0, 0, 0), grad_mode=capi
         for j in range(3):
             s.rotate[3 * i + j] = float(R[i, j])
     s.bound_radius = float(bound_radius)
+    if bbox is not None:        # (center xyz, half xyz) in the body frame
+        for i in range(3):
+            s.bbox_center[i] = float(bbox[0][i])
+            s.bbox_half[i] = float(bbox[1][i])
     s.n_vertices = 0
     s.n_faces = 0
     return s
@@ -90,13 +95,14 @@ def bench_box_shape():
     way a plugin author would (Generalshape subclass + DEFINE_USEFUL_FUNCTION => central-difference gradient)."""
     half = (1.6, 0.3, 0.3)
     return make_shape("Box", params=half, grad_mode=capi.GRAD_CENTRAL,
-                      bound_radius=math.sqrt(sum(h * h for h in half)))
+                      bound_radius=math.sqrt(sum(h * h for h in half)), bbox=((0, 0, 0), half))
 
 
 def bench_rounded_cone_shape():
     """0.4x-scaled RoundedCone (r1 0.6, r2 0.24, h 1.8)."""
     r1, r2, h = 0.6, 0.24, 1.8
-    return make_shape("RoundedCone", params=(r1, r2, h), bound_radius=h + r2)
+    return make_shape("RoundedCone", params=(r1, r2, h), bound_radius=h + r2,
+                      bbox=((0, 0, (h + r2 - r1) / 2), (r1, r1, (h + r2 + r1) / 2)))
 
 
 # ---------------------------------------------------------------- config (demo yaml defaults)

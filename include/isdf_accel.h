@@ -104,8 +104,12 @@ typedef struct isdf_shape {
     double params[16];
     double trans[3];       /* yaml poly_params xyz; every analytic SDF first maps p -> (p - trans) * Rotate */
     double rotate[9];      /* row-major 3x3 Rotate = yaw*pitch*roll (Shape.cpp:38-43)                       */
-    double bound_radius;   /* >0: a radius R with sdf(p) >= |p - trans| - R for all p (enables the V3 whole-tile
-                              cull); 0 disables the cull for this shape                                       */
+    double bound_radius;   /* >0: a radius R with sdf(p) >= |p| - R for every body-frame point p (enables the V3
+                              whole-tile cull); 0 disables the cull for this shape                            */
+    double bbox_center[3]; /* body-frame box with sdf(p) >= distance(p, box) for every p outside it, i.e. the   */
+    double bbox_half[3];   /* shape lies inside the box and its SDF never under-estimates by more than the box  */
+                           /* does.  All bbox_half > 0 lets the scan prune voxel rows that cannot reach the      */
+                           /* penalty band; zeros disable the pruning.  Results are identical either way.        */
     /* MESH only (already transformed into the body frame exactly as Generalshape's constructor does): */
     const double *mesh_vertices;  /* nV x 3 row-major */
     const int32_t *mesh_faces;    /* nF x 3 row-major */
@@ -177,11 +181,15 @@ int isdf_eval_device(isdf_ctx *ctx, int n_traj, int N, const double *d_T, const 
 size_t isdf_out_stride(int N);   /* 1 + N + 18N */
 
 /* ---- instrumentation --------------------------------------------------------------------------------------- */
-/* When enabled, every isdf_eval_device records HIP events around its dominant kernel on `stream`;
+/* on = N > 0: every N-th isdf_eval_device records HIP events around its dominant kernel on `stream` (an event
+ * record costs a few microseconds of stream time, so N > 1 keeps the instrumented run representative);
  * isdf_profile_read synchronises and returns the number of launches recorded since the last read and their
- * mean duration in milliseconds. */
+ * mean duration in milliseconds.  on = 0 disables. */
 int isdf_profile_enable(isdf_ctx *ctx, int on);
 int isdf_profile_read(isdf_ctx *ctx, int *n_launches, double *mean_ms);
+/* Mean duration (ms) of the second-largest kernel of the same launches (the fp64 exact pass), valid after
+ * isdf_profile_read. */
+int isdf_profile_read_secondary(isdf_ctx *ctx, double *mean_ms);
 /* Counters of the last evaluation (for tests / roofline bookkeeping). */
 typedef struct isdf_stats {
     int64_t n_units;          /* constraint-point evaluations (poses for V2/V3, obstacle points for V1)  */

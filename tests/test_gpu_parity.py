@@ -33,7 +33,9 @@ def test_tile_sweep_matches_oracle(pkg, orc, product_lib, variant, shape_name):
     cost, st0 = _check(eng, o, T, cm, f"{variant}/{shape_name}")
     assert cost > 0, "scenario must exercise the collision term"
     st = eng.stats()
-    assert st["units"] == st0[0] and st["pairs"] == st0[2] and st["grad_pairs"] == st0[3], (st, st0)
+    # units and active-penalty pairs are exact counts; "pairs" on the GPU counts only the voxels that survive the
+    # conservative fp32 pre-filter (every active pair must be among them)
+    assert st["units"] == st0[0] and st["grad_pairs"] == st0[3] and st0[3] <= st["pairs"] <= st0[2], (st, st0)
 
 
 def test_v3_equals_v2_at_zero_threshold(pkg, orc, product_lib):

@@ -24,12 +24,12 @@ def run(name, esdf, T, cm, shape, steps=30, **cfgkw):
     d_out = torch.zeros(eng.out_stride(N), dtype=torch.float64, device=dev)
     st = torch.cuda.current_stream().cuda_stream
     for _ in range(5): eng.eval_device(1, N, d_T.data_ptr(), d_C.data_ptr(), d_out.data_ptr(), 0, st)
-    torch.cuda.synchronize(); eng.profile_enable(True)
+    torch.cuda.synchronize(); eng.profile_enable(4)
     t0 = time.perf_counter()
     for _ in range(steps): eng.eval_device(1, N, d_T.data_ptr(), d_C.data_ptr(), d_out.data_ptr(), 0, st)
     torch.cuda.synchronize(); t1 = time.perf_counter()
-    n, ms = eng.profile_read()
-    print(f"{name:40s} kernel {ms*1e3:9.2f} us   step {(t1-t0)/steps*1e6:9.2f} us   stats {eng.stats()}", flush=True)
+    n, ms = eng.profile_read(); ms2 = eng.profile_read_secondary()
+    print(f"{name:36s} scan {ms*1e3:8.2f} us  exact {ms2*1e3:8.2f} us  step {(t1-t0)/steps*1e6:9.2f} us   stats {eng.stats()}", flush=True)
 
 if __name__ == "__main__":
     npieces = int(sys.argv[1]) if len(sys.argv) > 1 else 40
@@ -42,3 +42,5 @@ if __name__ == "__main__":
     run("cull on", esdf, T, cm, box, enable_cull=1)
     run("rounded cone", esdf, T, cm, synth.bench_rounded_cone_shape())
     run("k=13", esdf, T, cm, box, kernel_size=13)
+    nob = synth.make_shape("Box", params=(1.6, 0.3, 0.3), grad_mode=capi.GRAD_CENTRAL)
+    run("box without bbox (no row pruning)", esdf, T, cm, nob)
