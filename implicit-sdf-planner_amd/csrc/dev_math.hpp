@@ -262,6 +262,35 @@ __device__ __forceinline__ d3 ct_beta(const double *__restrict__ c, int ld, cons
     return r;
 }
 
+// Piecewise-quintic trajectory as the swept-volume path evaluates it.
+//   traj_locate follows Trajectory::locatePieceIdx (src/utils/include/utils/trajectory.hpp:545-563): sequential
+//     subtraction of durations, strict '>' (a junction time belongs to the earlier piece), overflow clamps to the end.
+//   traj_eval follows Piece::getPos_Vel_Acc_Jerk (:105-149): running powers of t, ascending-power walk.
+struct TrajView { const double *T; const double *C; int N; };
+__device__ __forceinline__ int traj_locate(const TrajView &tr, double &t) {
+    int idx = 0;
+    double dur = 0.0;
+    for (idx = 0; idx < tr.N && t > (dur = tr.T[idx]); idx++) t -= dur;
+    if (idx == tr.N) { idx--; t += tr.T[idx]; }
+    return idx;
+}
+__device__ __forceinline__ void traj_eval(const TrajView &tr, int piece, double t, d3 &pos, d3 &vel, d3 &acc, d3 &jer) {
+    pos = mk3(0, 0, 0); vel = pos; acc = pos; jer = pos;
+    double pos_tn = 1.0, vel_tn = 1.0, acc_tn = 1.0, jer_tn = 1.0;
+    int vel_n = 1, acc_m = 1, acc_n = 2, jl = 1, jm = 2, jn = 3;
+    const int ld = 6 * tr.N;
+    const double *c = tr.C + 6 * piece;
+#pragma unroll
+    for (int power = 0; power <= 5; power++) {
+        const d3 ck = mk3(c[power], c[ld + power], c[2 * ld + power]);
+        pos = pos + pos_tn * ck;
+        pos_tn *= t;
+        if (power >= 1) { vel = vel + (vel_n * vel_tn) * ck; vel_tn *= t; vel_n++; }
+        if (power >= 2) { acc = acc + (acc_m * acc_n * acc_tn) * ck; acc_tn *= t; acc_m++; acc_n++; }
+        if (power >= 3) { jer = jer + (jl * jm * jn * jer_tn) * ck; jer_tn *= t; jl++; jm++; jn++; }
+    }
+}
+
 __device__ __forceinline__ double wave_sum(double v) {
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);

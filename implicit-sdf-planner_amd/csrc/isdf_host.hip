@@ -60,6 +60,7 @@ struct isdf_ctx {
     double *d_coarse_t = nullptr, *d_coarse_pose = nullptr;
     int *d_n_coarse = nullptr;
     double *d_point_partial = nullptr; int *d_point_piece = nullptr; int point_cap = 0;
+    double *d_hist = nullptr; size_t hist_cap = 0;
     // profiling
     bool prof_on = false; int prof_every = 1; long long prof_tick = 0;
     std::vector<ProfEvent> prof_events;
@@ -207,7 +208,7 @@ extern "C" int isdf_destroy(isdf_ctx *c) {
     (void)hipDeviceSynchronize();
     for (auto &p : c->prof_events) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); (void)hipEventDestroy(p.c); }
     void *ptrs[] = {c->d_esdf, c->d_occ, c->d_points, c->d_tstar, c->d_pose, c->d_sample_last, c->d_pool_count, c->d_pool_entries, c->d_slot_sample, c->d_slot_prev, c->d_slot_res, c->d_slot_cnt, c->d_bits, c->d_piece_cost, c->d_in, c->d_out, c->d_stats,
-                    c->d_traj_duration, c->d_coarse_t, c->d_coarse_pose, c->d_n_coarse, c->d_point_partial, c->d_point_piece};
+                    c->d_traj_duration, c->d_coarse_t, c->d_coarse_pose, c->d_n_coarse, c->d_point_partial, c->d_point_piece, c->d_hist};
     for (void *p : ptrs) if (p) (void)hipFree(p);
     free_mesh(c);
     if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -446,6 +447,8 @@ static int eval_device_impl(isdf_ctx *c, int n_traj, int N, const double *d_T, c
         }
         P.coarse_t = c->d_coarse_t; P.coarse_pose = c->d_coarse_pose; P.n_coarse = c->d_n_coarse;
         P.point_partial = c->d_point_partial; P.point_piece = c->d_point_piece;
+        { int rc2 = ensure(c, &c->d_hist, &c->hist_cap, (size_t)N); if (rc2) return rc2; }
+        P.hist = c->d_hist;
         P.stats = c->d_stats;
         launch_swept_prepare(P, st);
         ProfEvent *ev;

@@ -88,6 +88,7 @@ struct SweptParams {
     int max_coarse;
     double *point_partial;      // [M][PARTIAL_STRIDE] (gdC 18, gdT, pena)
     int *point_piece;           // [M]
+    double *hist;               // [N] per-piece sum of gdT
     unsigned long long *stats;
 };
 void launch_swept_prepare(const SweptParams &P, hipStream_t stream);

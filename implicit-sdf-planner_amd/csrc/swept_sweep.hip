@@ -1,7 +1,338 @@
-// V1 swept-volume sweep — placeholder translation unit (kernels land in the next commit).
+// V1 swept-volume sweep on gfx950: addSaftyPenaOnSweptVolumeParallel
+//   (src/planner_algorithm/include/planner_algorithm/back_end_optimizer.hpp:557-649)
+// with the swept-volume SDF query of src/swept_volume/include/swept_volume/sw_manager.hpp
+//   (getSDFofSweptVolume :710-747, choiceTInit :367-445, gradientDescent :1000-1062,
+//    getSDF_DOTAtTimeStampOptimized :593-662, getStateOnTrajStamp :332-341).
+//
+// One optimizer step = three launches:
+//   swept_prepare_kernel  one block: the "traj_duration" state (refreshed only when the total is < 300 s, :287-296),
+//                         the coarse time table t += 0.2 by repeated fp64 addition (one lane, like the reference loop),
+//                         then the pose (position + rotation) at every coarse time, shared by all obstacle points.
+//   swept_sweep_kernel    one WAVEFRONT per obstacle point:
+//                           coarse scan   lanes = coarse times (table poses), ballot -> maximal in-range runs
+//                                         (intervals; a run still open at the end is dropped, quirk q2);
+//                           fine scan     lanes = 0.02 s steps of one interval (each lane accumulates its own t by
+//                                         repeated addition), first-minimum reduction, running minimum and seed
+//                                         carried ACROSS intervals (quirk q1);
+//                           descent       the 9 step-halving candidates of one sign-descent iteration are evaluated
+//                                         by 9 lanes at once, the 6 central-difference SDF samples by 6 lanes;
+//                           back-prop     penalty (mu = 0.01), flatness reverse mode, 20-double record per point.
+//   swept_reduce_kernel   deterministic sums: gradC rows per piece, gradT(j) = sum over points with piece > j, cost.
+// Compute-/latency-bound: fp64 throughout, no tile traffic.
 #include "isdf_internal.hpp"
+#include "dev_mesh.hpp"
+
 namespace isdf {
-void launch_swept_prepare(const SweptParams &, hipStream_t) {}
-void launch_swept_sweep(const SweptParams &, hipStream_t) {}
-void launch_swept_reduce(const SweptParams &, double *, hipStream_t) {}
+
+constexpr int SW_WAVES = 4;
+constexpr int SW_MAX_RANGES = 32;
+
+struct PoseT { d3 x; m3 R; };
+
+__device__ __forceinline__ void pose_at(const SweptParams &P, const TrajView &tr, double t, d3 &x, m3 &R) {
+    double tl = t;
+    const int i = traj_locate(tr, tl);
+    d3 v, a, j;
+    traj_eval(tr, i, tl, x, v, a, j);
+    FlatS fs;
+    flat_core(P.flat, v, a, fs);
+    R = quat_to_rot(flat_quat(fs));
 }
+__device__ __forceinline__ double sdf_at_time(const SweptParams &P, const TrajView &tr, d3 p, double t) {
+    d3 x; m3 R;
+    pose_at(P, tr, t, x, R);
+    return shape_sdf<-1>(P.shape, mat_tmul(R, p - x));
+}
+
+__global__ __launch_bounds__(1024) void swept_prepare_kernel(const SweptParams P) {
+    __shared__ double s_D;
+    __shared__ int s_n;
+    const TrajView tr{P.T, P.coeffs, P.N};
+    if (threadIdx.x == 0) {
+        double td = 0.0;
+        for (int i = 0; i < P.N; i++) td += P.T[i];            // getTotalDuration, trajectory.hpp:457-466
+        double D = *P.traj_duration;
+        if (td < 3 * 1e2) { D = td; *P.traj_duration = D; }    // updateTraj, sw_manager.hpp:287-296
+        int n = 0;
+        for (double t = 0; t < D && n < P.max_coarse; t += 0.2) P.coarse_t[n++] = t;   // choiceTInit :392
+        s_D = D;
+        s_n = n;
+        *P.n_coarse = n;
+        for (int k = 0; k < 8; k++) P.stats[k] = 0ull;
+    }
+    __syncthreads();
+    const int n = s_n;
+    for (int k = threadIdx.x; k < n; k += blockDim.x) {
+        d3 x; m3 R;
+        pose_at(P, tr, P.coarse_t[k], x, R);
+        double *o = P.coarse_pose + (size_t)k * 12;
+        o[0] = x.x; o[1] = x.y; o[2] = x.z;
+#pragma unroll
+        for (int q = 0; q < 9; q++) o[3 + q] = R.a[q];
+    }
+}
+
+// first lane holding the minimum of `v` over the active prefix [0, n); returns the minimum
+__device__ __forceinline__ double wave_first_min(double v, int lane, int n, int &arg) {
+    double m = (lane < n) ? v : 1.7976931348623157e308;
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) m = fmin(m, __shfl_xor(m, off, 64));
+    const unsigned long long eq = __ballot((lane < n) && (v == m));
+    arg = eq ? (__ffsll((long long)eq) - 1) : -1;
+    return m;
+}
+
+__global__ __launch_bounds__(64 * SW_WAVES) void swept_sweep_kernel(const SweptParams P) {
+    __shared__ double s_rl[SW_WAVES][SW_MAX_RANGES], s_rr[SW_WAVES][SW_MAX_RANGES];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int pt = P.point_begin + blockIdx.x * SW_WAVES + wave;
+    if (pt >= P.point_end) return;
+    const TrajView tr{P.T, P.coeffs, P.N};
+    const d3 p = mk3(P.points[3 * pt], P.points[3 * pt + 1], P.points[3 * pt + 2]);
+    const double D = *P.traj_duration;
+    const int n_coarse = *P.n_coarse;
+    const double rough_dt = 0.2, dt = 0.02;
+    const double inf = 2 * P.safety_hor + 0.1;
+
+    // ---------------- coarse scan -> intervals (choiceTInit :392-421) ----------------
+    int n_ranges = 0;
+    bool in_range = false;
+    double tou_lb = 0.0, range_mindis = 1e9;
+    for (int base = 0; base < n_coarse; base += 64) {
+        const int k = base + lane;
+        double dis = 1e9;
+        if (k < n_coarse) {
+            const double *o = P.coarse_pose + (size_t)k * 12;
+            m3 R;
+#pragma unroll
+            for (int q = 0; q < 9; q++) R.a[q] = o[3 + q];
+            dis = shape_sdf<-1>(P.shape, mat_tmul(R, p - mk3(o[0], o[1], o[2])));
+        }
+        unsigned long long in_mask = __ballot((k < n_coarse) && (dis < inf));
+        const int nvalid = min(64, n_coarse - base);
+        // walk the transitions of this 64-sample window (wave-uniform scalar loop)
+        int b = 0;
+        while (b < nvalid) {
+            const unsigned long long rest = (b < 64) ? (in_mask >> b) : 0ull;
+            if (!in_range) {
+                if (!rest) break;                                  // no further entry in this window
+                b += __ffsll((long long)rest) - 1;                 // first in-range sample: run entry
+                in_range = true;
+                range_mindis = __shfl(dis, b, 64);
+                tou_lb = fmax(0.0, P.coarse_t[base + b] - rough_dt);
+                b++;
+            } else {
+                const unsigned long long nrest = (~rest) & ((nvalid - b >= 64) ? ~0ull : ((1ull << (nvalid - b)) - 1ull));
+                if (!nrest) break;                                 // run continues past this window
+                b += __ffsll((long long)nrest) - 1;                // first out-of-range sample: run exit
+                in_range = false;
+                const double tou_ub = fmin(D, P.coarse_t[base + b] + rough_dt);
+                if (n_ranges < SW_MAX_RANGES) {
+                    if (lane == 0) { s_rl[wave][n_ranges] = tou_lb; s_rr[wave][n_ranges] = tou_ub; }
+                } else if (lane == 0) {
+                    atomicOr((unsigned int *)&P.stats[4], 1u);
+                }
+                n_ranges++;
+                b++;
+            }
+        }
+    }
+    n_ranges = min(n_ranges, SW_MAX_RANGES);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+
+    // ---------------- per interval: fine scan (:423-438) then sign descent (:729-745, :1000-1062) ----------------
+    double range_time_seed = 0.0;
+    double min_sdf_star = 1e1, t_star_best = 0.0;
+    d3 grad_prel = mk3(0, 0, 0);
+    bool have = false;
+    unsigned n_iters_total = 0;
+    for (int r = 0; r < n_ranges; r++) {
+        const double lb = s_rl[wave][r], ub = s_rr[wave][r];
+        // fine scan: t = lb, lb+dt, ... (< ub) by repeated addition
+        double t_base = lb;
+        for (;;) {
+            double t = t_base;
+            for (int q = 0; q < 63; q++) if (q < lane) t += dt;     // each lane's own accumulated time
+            const bool valid = t < ub;
+            const unsigned long long vm = __ballot(valid);
+            if (!vm) break;
+            const int nv = __popcll(vm);                            // valid lanes form a prefix (t is increasing)
+            double dis = 1e300;
+            if (valid) dis = sdf_at_time(P, tr, p, t);
+            int arg;
+            const double m = wave_first_min(dis, lane, nv, arg);
+            if (arg >= 0 && m < range_mindis) { range_mindis = m; range_time_seed = __shfl(t, arg, 64); }
+            if (nv < 64) break;
+            t_base = __shfl(t, 63, 64) + dt;
+        }
+        // sign descent from the seed
+        const double t_min = fmax(0.0, lb), t_max = fmin(ub, D);
+        double x = range_time_seed, fx = 0.0, prev_x = 10000000.0;
+        int iter = 0;
+        bool stop = false;
+        while (iter < 300 && !stop && fabs(x - prev_x) > 1e-5) {
+            if (iter == 0) fx = sdf_at_time(P, tr, p, x);
+            // g = d/dt SDF at x: pose with omega, body-frame point, shape gradient, point velocity
+            double tl = x;
+            const int pi = traj_locate(tr, tl);
+            d3 xt, vt, at, jt;
+            traj_eval(tr, pi, tl, xt, vt, at, jt);
+            FlatS fs; FlatS2 ft;
+            flat_core(P.flat, vt, at, fs);
+            flat_core2(P.flat, vt, at, jt, fs, ft);
+            const m3 R = quat_to_rot(flat_quat(fs));
+            const d3 omg = flat_omg(fs, ft);
+            const d3 temp = mat_tmul(R, p - xt);
+            const d3 g1 = shape_grad<-1>(P.shape, temp);
+            const d3 wx = mk3(0 * temp.x + (-omg.z) * temp.y + omg.y * temp.z, omg.z * temp.x + 0 * temp.y + (-omg.x) * temp.z,
+                              (-omg.y) * temp.x + omg.x * temp.y + 0 * temp.z);
+            const d3 rv = mat_tmul(R, vt);
+            const d3 pv = mk3(-(rv.x + wx.x), -(rv.y + wx.y), -(rv.z + wx.z));
+            const double g = dot3(g1, pv);
+            const int sgn = (int)(g > 0) - (int)(g < 0);
+            prev_x = x;
+            // the nine halving candidates tau = 0.02 * 0.5^(div-1), div = 1..9, one lane each
+            double tau = 0.02;
+            for (int q = 0; q < 8; q++) if (q < lane) tau = 0.5 * tau;
+            double xc = x - tau * sgn;
+            xc = fmax(fmin(xc, t_max), t_min);
+            double fc = 1e300;
+            if (lane < 9) fc = sdf_at_time(P, tr, p, xc);
+            const unsigned long long acc = __ballot((lane < 9) && ((fc - fx) < 0));
+            if (acc) {
+                const int d = __ffsll((long long)acc) - 1;
+                iter += d + 1;
+                x = __shfl(xc, d, 64);
+                fx = __shfl(fc, d, 64);
+            } else {
+                iter += 9;
+                stop = true;
+            }
+        }
+        n_iters_total += (unsigned)iter;
+        if (fx < min_sdf_star) {
+            min_sdf_star = fx;
+            t_star_best = x;
+            have = true;
+            d3 xt; m3 R;
+            pose_at(P, tr, x, xt, R);
+            grad_prel = shape_grad<-1>(P.shape, mat_tmul(R, p - xt));
+        }
+    }
+
+    // ---------------- back-prop at t* (back_end_optimizer.hpp:578-646) ----------------
+    double tstar = P.tstar[pt];
+    if (have) tstar = t_star_best;
+    double time_local = tstar;
+    const int i = traj_locate(tr, time_local);
+    Basis B;
+    poly_basis(time_local, B);
+    const double *c = P.coeffs + 6 * i;
+    const int ld = 6 * P.N;
+    const d3 pos = ct_beta(c, ld, B.b0), vel = ct_beta(c, ld, B.b1), acc3 = ct_beta(c, ld, B.b2), jer = ct_beta(c, ld, B.b3),
+             sna = ct_beta(c, ld, B.b4);
+    FlatS fs;
+    flat_core(P.flat, vel, acc3, fs);
+    const d4 quat = flat_quat(fs);
+    const m3 rot = quat_to_rot(quat);
+    double pena = 0.0;
+    d3 gradPos = mk3(0, 0, 0), gradVel = gradPos, gradOmg = gradPos;
+    d4 gradQuat; gradQuat.w = gradQuat.x = gradQuat.y = gradQuat.z = 0.0;
+    double sdf_cost = -1.0, sdf_out_grad = 0.0;
+    smoothed_l1(P.safety_hor - min_sdf_star, 0.01, sdf_cost, sdf_out_grad);    // grad_cost_p_sw, mu hard-coded (:851)
+    bool active = false;
+    if (sdf_cost > 2.2204460492503131e-16) {                                    // costp > DBL_EPSILON (:865)
+        active = true;
+        const d3 wg = mat_mul(rot, grad_prel);
+        gradPos = mk3(P.weight_p * (sdf_out_grad * wg.x), P.weight_p * (sdf_out_grad * wg.y), P.weight_p * (sdf_out_grad * wg.z));
+        const d4 sq = quat_step_grad(quat, grad_prel, p - pos);
+        gradQuat.w = P.weight_p * (-sdf_out_grad * sq.w); gradQuat.x = P.weight_p * (-sdf_out_grad * sq.x);
+        gradQuat.y = P.weight_p * (-sdf_out_grad * sq.y); gradQuat.z = P.weight_p * (-sdf_out_grad * sq.z);
+        pena = P.weight_p * sdf_cost;
+    }
+    d3 gP, gV, gA, gJ;
+    flat_backward(P.flat, vel, acc3, jer, gradPos, gradVel, gradQuat, gradOmg, gP, gV, gA, gJ);
+    if (lane == 0) {
+        double *o = P.point_partial + (size_t)pt * PARTIAL_STRIDE;
+        const double gPv[3] = {gP.x, gP.y, gP.z}, gVv[3] = {gV.x, gV.y, gV.z}, gAv[3] = {gA.x, gA.y, gA.z}, gJv[3] = {gJ.x, gJ.y, gJ.z};
+#pragma unroll
+        for (int d = 0; d < 3; d++)
+#pragma unroll
+            for (int rr = 0; rr < 6; rr++)
+                o[d * 6 + rr] = B.b0[rr] * gPv[d] + B.b1[rr] * gVv[d] + B.b2[rr] * gAv[d] + B.b3[rr] * gJv[d];
+        o[18] = (-dot3(gP, vel) + -dot3(gV, acc3) + -dot3(gA, jer) + -dot3(gJ, sna));
+        o[19] = pena;
+        P.point_piece[pt] = i;
+        P.tstar[pt] = tstar;
+        atomicAdd(&P.stats[2], (unsigned long long)n_ranges);
+        if (active) atomicAdd(&P.stats[3], 1ull);
+        atomicAdd(&P.stats[5], (unsigned long long)n_iters_total);
+    }
+}
+
+// Deterministic reduction.  Blocks [0, N): gradC rows of piece i and H[i] = sum of gdT over the points whose t* lies in
+// piece i (fixed strided order + fixed tree).  Block N: cost.  The last launch (suffix kernel) turns H into gradT.
+__global__ __launch_bounds__(256) void swept_reduce_kernel(const SweptParams P, double *out, double *hist) {
+    __shared__ double s_red[256];
+    const int i = blockIdx.x;
+    const int tid = threadIdx.x;
+    double acc[20];
+#pragma unroll
+    for (int q = 0; q < 20; q++) acc[q] = 0.0;
+    const bool cost_block = (i == P.N);
+    for (int pt = P.point_begin + tid; pt < P.point_end; pt += 256) {
+        const double *o = P.point_partial + (size_t)pt * PARTIAL_STRIDE;
+        if (cost_block) acc[19] += o[19];
+        else if (P.point_piece[pt] == i) {
+#pragma unroll
+            for (int q = 0; q < 19; q++) acc[q] += o[q];
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < 20; q++) {
+        if (cost_block != (q == 19)) continue;     // wave-uniform
+        s_red[tid] = acc[q];
+        __syncthreads();
+        for (int off = 128; off >= 1; off >>= 1) {
+            if (tid < off) s_red[tid] += s_red[tid + off];
+            __syncthreads();
+        }
+        if (tid == 0) {
+            const double v = s_red[0];
+            if (q == 19) out[0] = v;
+            else if (q == 18) hist[i] = v;
+            else { const int d = q / 6, r = q - 6 * d; out[1 + P.N + (size_t)d * 6 * P.N + 6 * i + r] = v; }
+        }
+        __syncthreads();
+    }
+    if (cost_block && tid == 0) atomicAdd(&P.stats[0], (unsigned long long)(P.point_end - P.point_begin));
+}
+
+// gradT(j) = sum_{i > j} H[i]   ("for (j < i) gradT(j) += gdT", back_end_optimizer.hpp:642-645), fixed order
+__global__ void swept_suffix_kernel(int N, const double *hist, double *out) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        double s = 0.0;
+        for (int j = N - 1; j >= 0; j--) {
+            out[1 + j] = s;
+            s += hist[j];
+        }
+    }
+}
+
+void launch_swept_prepare(const SweptParams &P, hipStream_t stream) {
+    hipLaunchKernelGGL(swept_prepare_kernel, dim3(1), dim3(1024), 0, stream, P);
+}
+void launch_swept_sweep(const SweptParams &P, hipStream_t stream) {
+    const int n = P.point_end - P.point_begin;
+    if (n <= 0) return;
+    hipLaunchKernelGGL(swept_sweep_kernel, dim3((n + SW_WAVES - 1) / SW_WAVES), dim3(64 * SW_WAVES), 0, stream, P);
+}
+void launch_swept_reduce(const SweptParams &P, double *out, hipStream_t stream) {
+    hipLaunchKernelGGL(swept_reduce_kernel, dim3(P.N + 1), dim3(256), 0, stream, P, out, P.hist);
+    hipLaunchKernelGGL(swept_suffix_kernel, dim3(1), dim3(64), 0, stream, P.N, P.hist, out);
+}
+
+} // namespace isdf

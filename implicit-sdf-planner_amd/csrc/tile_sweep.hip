@@ -601,22 +601,28 @@ void launch_stats(const SweepParams &P, hipStream_t stream) {
     hipLaunchKernelGGL(stats_kernel, dim3(64), dim3(256), 0, stream, P);
 }
 
-// qualifier bit-grid: bit z&31 of dword (ix*Y + iy)*ZW + (z>>5) is set iff the voxel qualifies
+// qualifier bit-grid: bit z&31 of dword (ix*Y + iy)*ZW + (z>>5) is set iff the voxel qualifies.
+// One lane per voxel, 64 consecutive z per wavefront: coalesced reads, the ballot is the two output dwords.
 __global__ __launch_bounds__(256) void build_bits_kernel(DevGrid G, int use_esdf, float thresh, unsigned *out) {
-    const size_t n = (size_t)G.X * G.Y * G.ZW;
-    for (size_t w = (size_t)blockIdx.x * blockDim.x + threadIdx.x; w < n; w += (size_t)gridDim.x * blockDim.x) {
-        const size_t row = w / G.ZW;
-        const int zw = (int)(w - row * G.ZW);
-        unsigned bits = 0;
-        for (int k = 0; k < 32; k++) {
-            const int z = zw * 32 + k;
-            if (z < G.Z) {
-                const size_t a = row * G.Z + z;
-                const bool q = use_esdf ? (G.esdf[a] <= thresh) : (G.occ[a] != 0);
-                bits |= (q ? 1u : 0u) << k;
-            }
+    const int lane = threadIdx.x & 63;
+    const size_t n_rows = (size_t)G.X * G.Y;
+    const int chunks = (G.Z + 63) >> 6;                       // 64-voxel chunks per z-row
+    const size_t n_work = n_rows * chunks;
+    const size_t wave0 = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6, n_waves = ((size_t)gridDim.x * blockDim.x) >> 6;
+    for (size_t w = wave0; w < n_work; w += n_waves) {
+        const size_t row = w / chunks;
+        const int ch = (int)(w - row * chunks);
+        const int z = ch * 64 + lane;
+        bool q = false;
+        if (z < G.Z) {
+            const size_t a = row * G.Z + z;
+            q = use_esdf ? (G.esdf[a] <= thresh) : (G.occ[a] != 0);
         }
-        out[w] = bits;
+        const unsigned long long m = __ballot(q);
+        if (lane == 0) {
+            out[row * G.ZW + 2 * ch] = (unsigned)m;
+            if (2 * ch + 1 < G.ZW) out[row * G.ZW + 2 * ch + 1] = (unsigned)(m >> 32);
+        }
     }
 }
 void launch_build_bits(const DevGrid &G, int use_esdf, float thresh, unsigned *out, hipStream_t stream) {

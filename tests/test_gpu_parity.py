@@ -167,3 +167,77 @@ def test_every_registered_shape(pkg, orc, product_lib, name):
     eng, o = make_pair(pkg, orc, cfg, shape, esdf=esdf, res=res)
     cost, st = _check(eng, o, T, cm, name)
     assert st[2] > 0
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# V1: the reference's live swept-volume sweep (addSaftyPenaOnSweptVolumeParallel)
+# ------------------------------------------------------------------------------------------------------------------
+def _swept_world(pkg, seed=3, N=6, piece_T=1.5):
+    synth = pkg.synth
+    occ, esdf, res = small_world(pkg, seed=seed)
+    ext = np.array(occ.shape) * res
+    T, Cf = synth.random_trajectory(ext, N, seed=seed + 40, piece_T=piece_T, margin=4.0, occ=occ, res=res)
+    cm = synth.colmajor(Cf)
+    # waypoints = piece junctions (positions at the start of pieces 1..N-1): c0 coefficients
+    way = Cf.reshape(N, 6, 3)[1:, 0, :]
+    pts = synth.constraint_points(occ, (0, 0, 0), res, way, half=4 * res * 1.5)
+    return occ, esdf, res, T, cm, pts
+
+
+@pytest.mark.parametrize("shape_name", ["RoundedCone", "Torus", "Box"])
+def test_swept_sweep_matches_oracle(pkg, orc, product_lib, shape_name):
+    capi, synth = pkg.capi, pkg.synth
+    occ, esdf, res, T, cm, pts = _swept_world(pkg)
+    assert pts.shape[0] > 50
+    params = {"RoundedCone": (0.8, 0.3, 1.6), "Torus": (1.2, 0.25), "Box": (1.2, 0.4, 0.3)}[shape_name]
+    shape = synth.make_shape(shape_name, params=params)
+    cfg = synth.default_config(capi.V1_SWEPT, safety_hor=0.5)
+    eng, o = make_pair(pkg, orc, cfg, shape, points=pts)
+    ts_g = np.zeros(pts.shape[0]); ts_o = np.zeros(pts.shape[0])
+    cost, gT, gC = eng.eval_single(T, cm, tstar=ts_g)
+    c0, gT0, gC0, st0 = o.eval(T, cm, tstar=ts_o)
+    assert c0 > 0 and st0[3] > 0, "scenario must have active points"
+    assert abs(cost - c0) <= REL_TOL * abs(c0), (cost, c0)
+    assert_close(gT, gT0, "V1 gradT")
+    assert_close(gC, gC0, "V1 gradC")
+    # t* is the argmin of a flat-bottomed function: compare where the oracle found an interval, to descent resolution
+    assert np.max(np.abs(ts_g - ts_o)) <= 2e-5, np.max(np.abs(ts_g - ts_o))
+    st = eng.stats()
+    assert st["units"] == pts.shape[0] and st["grad_pairs"] == st0[3] and st["pairs"] == st0[2], (st, st0)
+    # second call: lastTstar persists for points without an interval (back_end_optimizer.hpp:578)
+    T2 = T * 1.1
+    cost2, gT2, gC2 = eng.eval_single(T2, cm, tstar=ts_g)
+    c2, gT20, gC20, _ = o.eval(T2, cm, tstar=ts_o)
+    assert abs(cost2 - c2) <= REL_TOL * max(abs(c2), 1e-9)
+    assert_close(gC2, gC20, "V1 gradC second call")
+    assert_close(gT2, gT20, "V1 gradT second call")
+
+
+def test_swept_shards_and_empty(pkg, orc, product_lib):
+    capi, synth = pkg.capi, pkg.synth
+    occ, esdf, res, T, cm, pts = _swept_world(pkg, seed=5)
+    shape = synth.make_shape("RoundedCone", params=(0.8, 0.3, 1.6))
+    cfg = synth.default_config(capi.V1_SWEPT, safety_hor=0.5)
+    eng, o = make_pair(pkg, orc, cfg, shape, points=pts)
+    full = eng.eval_single(T, cm)
+    acc = [0.0, np.zeros(T.size), np.zeros(18 * T.size)]
+    for r in range(3):
+        eng.set_shard(r, 3)
+        c, gT, gC = eng.eval_single(T, cm)
+        acc[0] += c; acc[1] += gT; acc[2] += gC
+    eng.set_shard(0, 1)
+    assert abs(acc[0] - full[0]) <= 1e-12 * max(1.0, abs(full[0]))
+    assert_close(acc[1], full[1], "V1 shards gradT", tol=1e-12)
+    assert_close(acc[2], full[2], "V1 shards gradC", tol=1e-12)
+    # no obstacle points: nothing is added
+    eng.set_points(np.zeros((0, 3)))
+    c, gT, gC = eng.eval_single(T, cm)
+    assert c == 0 and not gT.any() and not gC.any()
+    # a trajectory longer than 300 s keeps the stale duration (sw_manager.hpp:287-296): oracle and GPU agree
+    eng.set_points(pts); o.set_points(pts)
+    eng.eval_single(T, cm); o.eval(T, cm)
+    Tl = np.full(T.size, 60.0)
+    c, gT, gC = eng.eval_single(Tl, cm)
+    c0, gT0, gC0, _ = o.eval(Tl, cm)
+    assert abs(c - c0) <= REL_TOL * max(abs(c0), 1e-9)
+    assert_close(gC, gC0, "V1 stale-duration gradC")
