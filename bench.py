@@ -69,12 +69,10 @@ def main():
         raise SystemExit("bench.py needs a GPU: the product path has no CPU fallback")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
-
     pkg = graft.load_package()
-    capi, synth = pkg.capi, pkg.synth
+    capi, synth, par = pkg.capi, pkg.synth, pkg.parallel
+    if world > 1:
+        par.init_process_group("nccl", device=dev)      # "nccl" == RCCL on ROCm
     res = 0.2 * 256.0 / args.grid if args.grid != 256 else 0.2
     K = 64
     n_pieces = args.pieces_per_gpu * world
@@ -97,7 +95,7 @@ def main():
     def step():
         eng.eval_device(1, N, d_T.data_ptr(), d_C.data_ptr(), d_out.data_ptr(), 0, stream)
         if world > 1:
-            dist.all_reduce(d_out)   # RCCL sum of [cost | gradT | gradC] over xGMI
+            par.allreduce_packed(d_out)   # ONE RCCL sum of [cost | gradT | gradC] over xGMI per step
 
     for _ in range(args.warmup):
         step()

@@ -63,6 +63,12 @@ struct CostParams {
     double safety_hor = 0.866, weight_p = 4000, weight_v = 1000, weight_omg = 1000, weight_theta = 1000;
     double vmax = 10, omgmax = 10, thetamax = 100, smoothing_eps = 1e-2, occ_thresh = 0.0;
     int threads = 1;
+    int shard_rank = 0, shard_world = 1;   // isdf_set_shard mirror: contiguous range of pieces (integral) / points (V1)
+    void shard_range(long long total, long long &b, long long &e) const {
+        const long long q = total / shard_world, r = total % shard_world;
+        b = shard_rank * q + (shard_rank < r ? shard_rank : r);
+        e = b + q + (shard_rank < r ? 1 : 0);
+    }
     double bd() const { return kernel_size * grid->res; }
     // whole-tile cull threshold of V3 (DESIGN.md "cull"): every voxel centre within reach of a non-zero penalty
     // lies closer than bound_radius + safety_hor to the pose; the trilinear sample can over-estimate the distance
@@ -140,8 +146,10 @@ inline void sweep_integral(const CostParams &P, const Traj &tr, double &cost, do
     const int N = tr.N, K = P.K;
     const double integralFrac = 1.0 / K;
     SweepStats tot;
+    long long pb, pe;
+    P.shard_range(N, pb, pe);
 #pragma omp parallel for num_threads(P.threads) schedule(dynamic)
-    for (int count = 0; count < N * (K + 1); count++) {
+    for (int count = (int)pb * (K + 1); count < (int)pe * (K + 1); count++) {
         const int j = count % (K + 1), i = count / (K + 1);
         const double step = tr.T[i] * integralFrac;
         const double s1 = j * step;
@@ -210,8 +218,10 @@ inline void sweep_swept(const CostParams &P, SweptCtx &sv, const Traj &tr, const
     const int N = tr.N;
     sv.update_traj(tr);   // costFunctionLmbm :381-382
     SweepStats tot;
+    long long kb, ke;
+    P.shard_range(M, kb, ke);
 #pragma omp parallel for num_threads(P.threads) schedule(dynamic)
-    for (int k = 0; k < M; k++) {
+    for (int k = (int)kb; k < (int)ke; k++) {
         V3 gradp_rel;   // reference leaves it uninitialised; it is only used when an interval was found
         const V3 pos_eva(points[3 * k], points[3 * k + 1], points[3 * k + 2]);
         int nr = 0;

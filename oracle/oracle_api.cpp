@@ -46,6 +46,7 @@ void *orc_create(const isdf_config *cfg) {
 void orc_destroy(void *h) { delete (OrcCtx *)h; }
 void orc_set_threads(void *h, int n) { ((OrcCtx *)h)->P.threads = n > 0 ? n : 1; }
 int orc_max_threads(void) { return omp_get_max_threads(); }
+void orc_set_shard(void *h, int rank, int world) { ((OrcCtx *)h)->P.shard_rank = rank; ((OrcCtx *)h)->P.shard_world = world; }
 
 int orc_set_grid(void *h, const void *vox, int dtype, int nx, int ny, int nz, const double origin[3],
                  const double bmax[3], double res, int kind) {

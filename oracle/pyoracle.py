@@ -52,6 +52,9 @@ class Oracle:
     def set_threads(self, n):
         self.lib.orc_set_threads(self.h, n)
 
+    def set_shard(self, rank, world):
+        self.lib.orc_set_shard(self.h, C.c_int(rank), C.c_int(world))
+
     def set_grid(self, vox, origin, res, kind, bmax=None):
         from_dtype = {np.dtype(np.uint8): 0, np.dtype(np.float32): 1, np.dtype(np.float64): 2}
         vox = np.ascontiguousarray(vox)

@@ -1,0 +1,61 @@
+"""Pins the oracle against what can be built of the REAL reference (oracle/_ref, compiled from /root/reference by
+oracle/Makefile — see oracle/ref_build).  CPU only.  Skipped when the prebuilt _ref libraries are absent."""
+import os
+
+import numpy as np
+import pytest
+
+FP = [0.61, 9.8, 0.1, 0.1, 0.01, 1e-4]
+
+
+def test_flatness_bit_exact_vs_reference_header(orc):
+    ref = orc.ref_flat_lib()
+    if ref is None:
+        pytest.skip("oracle/_ref/libref_flatness.so not built")
+    rng = np.random.default_rng(0)
+    for _ in range(3000):
+        v, a, j = rng.normal(0, 3, 3), rng.normal(0, 4, 3), rng.normal(0, 6, 3)
+        q, w = orc.flat_forward(FP, v, a, j)
+        q2, w2 = orc.flat_forward(FP, v, a, j, lib=ref, prefix="ref")
+        assert np.array_equal(q, q2) and np.array_equal(w, w2)
+        pg, vg, og, qg = rng.normal(0, 1, 3), rng.normal(0, 1, 3), rng.normal(0, 1, 3), rng.normal(0, 1, 4)
+        b1 = orc.flat_backward(FP, v, a, j, pg, vg, qg, og)
+        b2 = orc.flat_backward(FP, v, a, j, pg, vg, qg, og, lib=ref, prefix="ref")
+        assert np.array_equal(b1, b2)
+
+
+def _cube():
+    V = np.array([[x, y, z] for x in (-0.5, 0.5) for y in (-0.4, 0.4) for z in (-0.3, 0.3)], dtype=np.float64)
+    F = np.array([[0, 1, 3], [0, 3, 2], [4, 6, 7], [4, 7, 5], [0, 4, 5], [0, 5, 1], [2, 3, 7], [2, 7, 6],
+                  [0, 2, 6], [0, 6, 4], [1, 5, 7], [1, 7, 3]], dtype=np.int32)
+    return V, F
+
+
+def test_mesh_winding_number_vs_vendored_fwn(pkg, orc):
+    """The oracle's exact solid-angle sum vs the vendored HDK fast winding number (order 2, accuracy 2.0, float).
+    libigl approximates clusters farther than 2x their radius by an order-2 Taylor expansion, so its w deviates from
+    the exact winding number by up to ~2e-3 (measured here) => the reference's mesh SDF is scaled by (1 - 2w) with a
+    few 1e-3 relative error away from the surface.  The round-1 mesh path (oracle AND device) uses the exact sum:
+    this test quantifies the gap that keeps the MESH kind at 'parity unpinned' (DESIGN.md)."""
+    if not os.path.exists(orc.REF_FWN):
+        pytest.skip("oracle/_ref/libref_fwn.so not built")
+    V, F = _cube()
+    fwn = orc.RefFwn(V, F)
+    cfg = pkg.synth.default_config()
+    o = orc.Oracle(cfg)
+    o.set_shape(pkg.synth.make_mesh_shape(V, F))
+    rng = np.random.default_rng(1)
+    Q = rng.uniform(-1.2, 1.2, (4000, 3))
+    w_ref = fwn.eval(Q)
+    sdf, _ = o.shape_eval(Q)
+    # reconstruct the oracle's w from sdf sign and magnitude: s = 1 - 2w = sdf / dist
+    inside = (np.abs(Q) < np.array([0.5, 0.4, 0.3])).all(axis=1)
+    assert np.all((w_ref > 0.5) == inside)
+    assert np.all((sdf < 0) == inside)
+    w_exact = np.where(inside, 1.0, 0.0)                      # closed mesh: the exact winding number is 0 / 1
+    err = np.abs(w_ref - w_exact)
+    assert err.max() < 5e-3                                   # size of libigl's far-field approximation error
+    # the oracle's own float solid-angle sum is exact to float rounding: |1 - 2w| == 1
+    d = np.linalg.norm(np.maximum(np.abs(Q) - np.array([0.5, 0.4, 0.3]), 0), axis=1)
+    out = ~inside
+    assert np.allclose(sdf[out], d[out], rtol=5e-6, atol=1e-6)
