@@ -43,10 +43,8 @@ struct isdf_ctx {
     // shard
     int rank = 0, world = 1;
     // per-step scratch
-    PoseRec *d_pose = nullptr; int *d_sample_last = nullptr; size_t sample_cap = 0;
-    unsigned *d_pool_count = nullptr; unsigned *d_pool_entries = nullptr; int *d_slot_sample = nullptr, *d_slot_prev = nullptr;
-    double *d_slot_res = nullptr; unsigned *d_slot_cnt = nullptr; size_t pool_cap = 0;
-    SweepParams last_P{}; bool have_last_P = false; int parity = 0;
+    double *d_acc = nullptr; int *d_sample_info = nullptr; size_t sample_cap = 0;
+    SweepParams last_P{}; bool have_last_P = false;
     double last_exact_ms = 0.0;
     double *d_piece_cost = nullptr; size_t piece_cap = 0;
     double *d_in = nullptr; size_t in_cap = 0;        // host-API staging: T | coeffs
@@ -66,6 +64,7 @@ struct isdf_ctx {
     std::vector<ProfEvent> prof_events;
     size_t prof_used = 0;
     hipStream_t stream = nullptr;   // stream of the host API
+    unsigned long long *d_dbg = nullptr; size_t dbg_cap = 0; size_t dbg_used = 0;   // ISDF_DEBUG_TIMING=1 (developer tool)
 };
 
 #define HIPCHK(ctx, call)                                                                          \
@@ -207,8 +206,8 @@ extern "C" int isdf_destroy(isdf_ctx *c) {
     (void)hipSetDevice(c->device);
     (void)hipDeviceSynchronize();
     for (auto &p : c->prof_events) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); (void)hipEventDestroy(p.c); }
-    void *ptrs[] = {c->d_esdf, c->d_occ, c->d_points, c->d_tstar, c->d_pose, c->d_sample_last, c->d_pool_count, c->d_pool_entries, c->d_slot_sample, c->d_slot_prev, c->d_slot_res, c->d_slot_cnt, c->d_bits, c->d_piece_cost, c->d_in, c->d_out, c->d_stats,
-                    c->d_traj_duration, c->d_coarse_t, c->d_coarse_pose, c->d_n_coarse, c->d_point_partial, c->d_point_piece, c->d_hist};
+    void *ptrs[] = {c->d_esdf, c->d_occ, c->d_points, c->d_tstar, c->d_acc, c->d_sample_info, c->d_bits, c->d_piece_cost, c->d_in, c->d_out, c->d_stats,
+                    c->d_traj_duration, c->d_coarse_t, c->d_coarse_pose, c->d_n_coarse, c->d_point_partial, c->d_point_piece, c->d_hist, c->d_dbg};
     for (void *p : ptrs) if (p) (void)hipFree(p);
     free_mesh(c);
     if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -472,33 +471,12 @@ static int eval_device_impl(isdf_ctx *c, int n_traj, int N, const double *d_T, c
     shard_range(total_pieces, c->rank, c->world, pb, pe);
     const size_t n_samples = (size_t)total_pieces * (cfg.integral_intervs + 1);
     if (c->sample_cap < n_samples) {
-        if (c->d_pose) (void)hipFree(c->d_pose);
-        if (c->d_sample_last) (void)hipFree(c->d_sample_last);
-        c->d_pose = nullptr; c->d_sample_last = nullptr; c->sample_cap = 0;
-        HIPCHK(c, hipMalloc(&c->d_pose, n_samples * sizeof(PoseRec)));
-        HIPCHK(c, hipMalloc(&c->d_sample_last, n_samples * sizeof(int)));
+        if (c->d_acc) (void)hipFree(c->d_acc);
+        if (c->d_sample_info) (void)hipFree(c->d_sample_info);
+        c->d_acc = nullptr; c->d_sample_info = nullptr; c->sample_cap = 0;
+        HIPCHK(c, hipMalloc(&c->d_acc, n_samples * ACC_STRIDE * sizeof(double)));
+        HIPCHK(c, hipMalloc(&c->d_sample_info, n_samples * 2 * sizeof(int)));
         c->sample_cap = n_samples;
-    }
-    // candidate pool: 4 slots (256 surviving voxels) per pose on average + slack; ISDF_POOL_SLOTS overrides.
-    // If it ever overflows the step reports ISDF_ERR_OVERFLOW (host API) / stats.overflow (device API).
-    size_t want_slots = n_samples * 4 + 65536;
-    if (const char *e = getenv("ISDF_POOL_SLOTS")) want_slots = (size_t)atoll(e);
-    if (want_slots > (size_t)0x7fffff00) want_slots = 0x7fffff00;
-    want_slots = (want_slots + POOL_SHARDS - 1) / POOL_SHARDS * POOL_SHARDS;
-    if (c->pool_cap < want_slots) {
-        void *old[] = {c->d_pool_entries, c->d_slot_sample, c->d_slot_prev, c->d_slot_res, c->d_slot_cnt};
-        for (void *p : old) if (p) (void)hipFree(p);
-        c->d_pool_entries = nullptr; c->d_slot_sample = nullptr; c->d_slot_prev = nullptr; c->d_slot_res = nullptr; c->d_slot_cnt = nullptr; c->pool_cap = 0;
-        if (!c->d_pool_count) {
-            HIPCHK(c, hipMalloc(&c->d_pool_count, (size_t)2 * POOL_SHARDS * POOL_COUNTER_STRIDE * sizeof(unsigned)));
-            HIPCHK(c, hipMemset(c->d_pool_count, 0, (size_t)2 * POOL_SHARDS * POOL_COUNTER_STRIDE * sizeof(unsigned)));
-        }
-        HIPCHK(c, hipMalloc(&c->d_slot_cnt, want_slots * sizeof(unsigned)));
-        HIPCHK(c, hipMalloc(&c->d_pool_entries, want_slots * 64 * sizeof(unsigned)));
-        HIPCHK(c, hipMalloc(&c->d_slot_sample, want_slots * sizeof(int)));
-        HIPCHK(c, hipMalloc(&c->d_slot_prev, want_slots * sizeof(int)));
-        HIPCHK(c, hipMalloc(&c->d_slot_res, want_slots * ACC_STRIDE * sizeof(double)));
-        c->pool_cap = want_slots;
     }
     int rc = ensure(c, &c->d_piece_cost, &c->piece_cap, (size_t)total_pieces);
     if (rc) return rc;
@@ -519,10 +497,21 @@ static int eval_device_impl(isdf_ctx *c, int n_traj, int N, const double *d_T, c
     P.cull_threshold = 0.0;
     if (cfg.variant == ISDF_V3_ESDF_TILE && cfg.enable_cull && c->shape.bound_radius > 0)
         P.cull_threshold = c->shape.bound_radius + cfg.safety_hor + std::sqrt(3.0) * P.grid.res;
-    P.T = d_T; P.coeffs = d_coeffs; P.pose = c->d_pose; P.piece_cost = c->d_piece_cost;
-    P.pool_count = c->d_pool_count; P.pool_cap = (int)c->pool_cap; P.pool_entries = c->d_pool_entries;
-    P.slot_sample = c->d_slot_sample; P.slot_prev = c->d_slot_prev; P.slot_res = c->d_slot_res; P.slot_cnt = c->d_slot_cnt; P.sample_last = c->d_sample_last;
+    P.T = d_T; P.coeffs = d_coeffs; P.acc = c->d_acc; P.sample_info = c->d_sample_info; P.piece_cost = c->d_piece_cost;
     P.out = d_out; P.stats = c->d_stats;
+    P.dbg = nullptr;
+    if (const char *e = getenv("ISDF_DEBUG_TIMING")) if (e[0] == '1') {
+        const size_t need = n_samples * 8 + (size_t)total_pieces * 4 + 4;
+        if (c->dbg_cap < need) {
+            if (c->d_dbg) (void)hipFree(c->d_dbg);
+            c->d_dbg = nullptr; c->dbg_cap = 0;
+            HIPCHK(c, hipMalloc(&c->d_dbg, need * sizeof(unsigned long long)));
+            c->dbg_cap = need;
+        }
+        HIPCHK(c, hipMemsetAsync(c->d_dbg, 0, need * sizeof(unsigned long long), st));
+        c->dbg_used = need;
+        P.dbg = c->d_dbg;
+    }
     if (cfg.enable_pos && c->bits_dirty) {
         const size_t nw = (size_t)c->grid.X * c->grid.Y * ((c->grid.Z + 31) / 32);
         if (c->bits_cap < nw) {
@@ -537,17 +526,14 @@ static int eval_device_impl(isdf_ctx *c, int n_traj, int N, const double *d_T, c
         c->bits_dirty = false;
         P.grid = c->grid;
     }
-    P.parity = c->parity;
-    c->parity ^= 1;
     c->last_P = P; c->have_last_P = true;
     ProfEvent *ev;
     rc = prof_begin(c, st, &ev);
     if (rc) return rc;
-    launch_scan(P, st);
+    launch_sweep(P, st);
     if (ev) HIPCHK(c, hipEventRecord(ev->b, st));
-    launch_exact(P, st);
-    if (ev) HIPCHK(c, hipEventRecord(ev->c, st));
     launch_tail(P, st);
+    if (ev) HIPCHK(c, hipEventRecord(ev->c, st));
     launch_finalize(P, st);
     HIPCHK(c, hipGetLastError());
     return ISDF_OK;
@@ -666,6 +652,16 @@ extern "C" int isdf_profile_read_secondary(isdf_ctx *c, double *mean_ms) {
     if (!c || !mean_ms) return ISDF_ERR_INVALID_ARG;
     *mean_ms = c->last_exact_ms;
     return ISDF_OK;
+}
+
+// developer tool (not declared in the ABI header): copies the timing words of the last step when ISDF_DEBUG_TIMING=1
+extern "C" long long isdf_debug_timing(isdf_ctx *c, unsigned long long *out, long long cap) {
+    if (!c || !c->d_dbg) return 0;
+    (void)hipSetDevice(c->device);
+    (void)hipDeviceSynchronize();
+    const long long n = (long long)c->dbg_used < cap ? (long long)c->dbg_used : cap;
+    if (out && n > 0) (void)hipMemcpy(out, c->d_dbg, (size_t)n * sizeof(unsigned long long), hipMemcpyDeviceToHost);
+    return (long long)c->dbg_used;
 }
 
 extern "C" int isdf_get_stats(isdf_ctx *c, isdf_stats *out) {

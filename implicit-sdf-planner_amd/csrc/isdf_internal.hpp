@@ -15,18 +15,6 @@ struct DevGrid {
     const unsigned *bits;     // qualifier bit-grid of the active variant, ZW dwords per z-row
     int ZW;                   // ceil(Z / 32)
 };
-constexpr int POOL_SHARDS = 256;            // allocation counters of the candidate pool
-constexpr int POOL_COUNTER_STRIDE = 32;     // dwords between counters (one 128-byte line each)
-
-// Per-sample pose record written by pose_kernel and read (wave-uniformly) by tile_kernel.
-struct PoseRec {
-    double pos[3];
-    double R[9];       // row-major body->world rotation
-    double quat[4];    // w x y z
-    int lo[3], hi[3];  // inclusive voxel index box of getPointsInAABB(pos, bd/2)
-    int flags;         // bit0: collision term active for this pose, bit1: culled by the whole-tile test
-    int pad;
-};
 constexpr int ACC_STRIDE = 8;       // costp, dL/dpos(3), dL/dquat(4) of one pose, before weight_p
 constexpr int PARTIAL_STRIDE = 20;  // V1: per-point record = 18 gradC entries (d*6 + r), gdT, pena
 
@@ -44,26 +32,16 @@ struct SweepParams {
     double cull_threshold;      // <= 0: cull disabled
     const double *T;            // n_traj * N
     const double *coeffs;       // n_traj * (6N x 3 col-major)
-    PoseRec *pose;              // [n_samples_total], indexed by global sample id
-    // candidate pool handed from scan_kernel to exact_kernel (slot = 64 voxels of one pose)
-    unsigned *pool_count;       // [2][POOL_SHARDS * POOL_COUNTER_STRIDE] allocation counters; set `parity` is live,
-                                // finalize_kernel resets the other set for the next step
-    int parity;
-    int pool_cap;               // slots
-    unsigned *pool_entries;     // [pool_cap][64] packed voxel offsets relative to the pose's lo[], 0xFFFFFFFF = empty
-    int *slot_sample;           // [pool_cap] sample index relative to this rank's first sample
-    int *slot_prev;             // [pool_cap] previous slot of the same sample, -1 = none
-    double *slot_res;           // [pool_cap][ACC_STRIDE]
-    unsigned *slot_cnt;         // [pool_cap] exact pairs | active pairs << 16 of the slot
-    int *sample_last;           // [n_samples_local] last slot of each sample, -1 = none
+    double *acc;                // [n_samples_local][ACC_STRIDE] per-pose collision sums written by sweep_kernel
+    int *sample_info;           // [n_samples_local][2] exact pairs, active pairs | culled << 31 (statistics)
     double *piece_cost;         // [n_traj * N]
     double *out;                // n_traj * (1 + N + 18N)
     unsigned long long *stats;  // [0]=units [1]=culled [2]=pairs [3]=grad pairs [4]=overflow
+    unsigned long long *dbg;    // developer timing buffer (ISDF_DEBUG_TIMING=1), null on the product path
 };
 
-// one optimizer step of the integral sweep = these four launches, in order, on `stream`
-void launch_scan(const SweepParams &P, hipStream_t stream);
-void launch_exact(const SweepParams &P, hipStream_t stream);
+// one optimizer step of the integral sweep = sweep, tail, finalize, in order, on `stream`
+void launch_sweep(const SweepParams &P, hipStream_t stream);
 void launch_stats(const SweepParams &P, hipStream_t stream);   // on demand, not part of the step
 void launch_build_bits(const DevGrid &G, int use_esdf, float thresh, unsigned *out, hipStream_t stream);
 void launch_tail(const SweepParams &P, hipStream_t stream);

@@ -3,35 +3,34 @@
 // with the per-pose tile term grad_cost_p (:766-824) plugged in before the flatness back-prop (:536), the voxel
 // qualifier being occupancy (V2) or esdf <= occ_thresh (V3).
 //
-// One optimizer step = four launches (DESIGN.md "integral sweep"):
-//   pose_kernel     one THREAD per constraint sample: quintic evaluation, flatness forward, rotation, the tile index
-//                   box of getPointsInAABB, optional whole-tile cull (trilinear ESDF at the pose) -> PoseRec.
-//                   (The serial fp64 chain runs once per sample, not once per lane of a wavefront.)
-//   tile_kernel     one WAVEFRONT per sample, 4 consecutive samples per 256-thread workgroup:
-//                     phase 1 (staging): the workgroup walks the UNION of its samples' tiles once with coalesced
-//                       z-row reads of the grid and stages the tile into LDS as a compacted list of qualifying voxels
-//                       (ballot/popcount compaction, per-wave segments => deterministic order, no atomics);
-//                       consecutive samples' tiles overlap >90 %, so the tile is fetched once per workgroup.
-//                     phase 2: each wave streams the LDS list against its own pose: body-frame transform,
-//                       |p_rel| cull, robot SDF; voxels with an active penalty are compacted again (per-wave LDS
-//                       list) and get the 6 extra SDF evaluations of the central-difference gradient in dense rounds.
-//                     phase 3: wave butterfly reduction of (cost, dL/dpos, dL/dquat) -> acc[sample][8].
+// One optimizer step = three launches (DESIGN.md "integral sweep"):
+//   sweep_kernel<KIND>  one WORKGROUP per 4 consecutive constraint samples, one wavefront per sample:
+//                     (1) poses: one LANE per sample runs the serial fp64 chain (quintic, flatness forward, rotation, the
+//                         tile index box of getPointsInAABB, optional whole-tile cull, the window of tile rows the
+//                         shape's inflated bounding box can reach) and publishes it through LDS;
+//                     (2) one lane per tile row: row pruning against the shape's inflated body-frame box, the row's
+//                         qualifier bits (1-2 dwords of the bit-grid, requested one round ahead), DPP prefix-sum
+//                         compaction of the surviving voxels into an LDS ring;
+//                     (3) conservative fp32 filter on full wavefronts (body-frame transform, cube cull, robot SDF);
+//                     (4) survivors, 64 at a time, get the exact fp64 treatment of grad_cost_p in the same wave:
+//                         voxel centre, R^T(c - x), cube cull (:800-803), robot SDF, smoothedL1 and - when the penalty
+//                         is active - the central-difference gradient and the pose-gradient terms (:805-820);
+//                     (5) wave butterfly -> acc[sample][8].
+//                   No atomics, no work lists: results are bitwise reproducible.
 //   tail_kernel     one block per piece, one thread per sample: dynamics penalties, flatness reverse mode,
 //                   beta (x) grad scatter, then a fixed-order in-block sum over the piece's K+1 samples written
 //                   straight into gradC rows 6i..6i+5 and gradT(i).
 //   finalize_kernel one block per trajectory: cost = sum of piece costs (fixed order); zero-fills the entries of
 //                   pieces outside this rank's shard so that the ranks' outputs sum to the full result.
-// Everything on the data path is fp64 except the stored ESDF (fp32).  No MFMA: gather/interpolate work.
+// Everything that reaches the result is fp64 except the stored ESDF (fp32).  No MFMA: gather/interpolate work.
 #include "isdf_internal.hpp"
 #include "dev_mesh.hpp"
 
 namespace isdf {
 
-constexpr int TS_WAVES = 1;                               // waves are independent (one constraint sample each)
-constexpr int TS_THREADS = 64 * TS_WAVES;
-constexpr int TS_LIST_CAP = 64 * 32;                      // ring capacity >= voxels of one round (64 z-rows x 32)
-constexpr int TS_BITS_CAP = 512;                          // z-rows whose qualifier bits are staged in LDS at a time
-constexpr int TS_NEAR_CAP = 128;                          // per-wave candidate ring (power of two; a slot of 64 leaves when full)
+constexpr int SW_LIST_CAP = 1024;                         // ring of compacted voxels (one pass adds <= 64 * SW_PASS)
+constexpr int SW_PASS = 8;                                // voxels one lane contributes to the ring per pass
+constexpr int SW_NEAR_CAP = 128;                          // per-wave candidate ring (64 leave for the exact pass when full)
 constexpr float TS_FILTER_EPS = 2e-3f;                    // slack (m) of the fp32 pre-filter, >> its rounding error
 
 __device__ __forceinline__ void wave_lds_sync() {
@@ -90,9 +89,6 @@ __device__ __forceinline__ double esdf_trilinear(const DevGrid &G, d3 pos) {
     return (1 - dz) * v0 + dz * v1;
 }
 
-// ---------------------------------------------------------------------------------------------------------------
-// pose_kernel: thread per sample
-// ---------------------------------------------------------------------------------------------------------------
 struct SampleId { int b, i, j; long long s; };
 __device__ __forceinline__ SampleId decode_sample(const SweepParams &P, long long s) {
     const int K1 = P.K + 1;
@@ -105,54 +101,6 @@ __device__ __forceinline__ SampleId decode_sample(const SweepParams &P, long lon
     return id;
 }
 
-__device__ __forceinline__ void compute_pose(const SweepParams &P, long long s, PoseRec &rec) {
-    const SampleId id = decode_sample(P, s);
-    const DevGrid &G = P.grid;
-    const double *c = P.coeffs + (size_t)id.b * 18 * P.N + 6 * id.i;
-    const int ld = 6 * P.N;
-    const double step = P.T[(size_t)id.b * P.N + id.i] * (1.0 / P.K);
-    Basis B;
-    poly_basis(id.j * step, B);
-    const d3 pos = ct_beta(c, ld, B.b0), vel = ct_beta(c, ld, B.b1), acc = ct_beta(c, ld, B.b2);
-    FlatS fs;
-    flat_core(P.flat, vel, acc, fs);
-    const d4 q = flat_quat(fs);
-    const m3 R = quat_to_rot(q);
-    rec.pos[0] = pos.x; rec.pos[1] = pos.y; rec.pos[2] = pos.z;
-#pragma unroll
-    for (int k = 0; k < 9; k++) rec.R[k] = R.a[k];
-    rec.quat[0] = q.w; rec.quat[1] = q.x; rec.quat[2] = q.y; rec.quat[3] = q.z;
-    rec.lo[0] = rec.lo[1] = rec.lo[2] = 0;
-    rec.hi[0] = rec.hi[1] = rec.hi[2] = -1;
-    rec.flags = 0;
-    rec.pad = 0;
-    if (P.enable_pos) {
-        bool active = true;
-        if (P.cull_threshold > 0.0 && esdf_trilinear(G, pos) > P.cull_threshold) { active = false; rec.flags |= 2; }
-        if (active) {
-            // getPointsInAABB(pos, bd/2): corners projected into the map, floor-indexed (PCSmap_manager.h:150-155)
-            const double p[3] = {pos.x, pos.y, pos.z};
-            const int dim[3] = {G.X, G.Y, G.Z};
-#pragma unroll
-            for (int a = 0; a < 3; a++) {
-                rec.lo[a] = axis_index(clampd(p[a] - P.bd_half, G.bmin[a], G.bmax[a]), G.bmin[a], G.res, dim[a]);
-                rec.hi[a] = axis_index(clampd(p[a] + P.bd_half, G.bmin[a], G.bmax[a]), G.bmin[a], G.res, dim[a]);
-            }
-            // NaN poses make every comparison false: keep the box sane
-            if (rec.hi[0] >= rec.lo[0] && rec.hi[1] >= rec.lo[1] && rec.hi[2] >= rec.lo[2]) rec.flags |= 1;
-        }
-    }
-}
-
-// ---------------------------------------------------------------------------------------------------------------
-// scan_kernel: wave per sample, 4 samples per workgroup share one staged union tile; fp32 + integer work only
-// ---------------------------------------------------------------------------------------------------------------
-// The grid is read through its QUALIFIER BIT-GRID (1 bit per voxel: esdf <= occ_thresh for V3, occupied for V2;
-// built once per set_grid by build_bits_kernel), 32 voxels of a z-row per dword.
-// Candidate slots: a wave hands every 64 surviving voxels of its sample to the exact pass as one slot of the global
-// pool.  Slot ids come from one atomicAdd on one of POOL_SHARDS counters (a single counter saturates at ~90
-// allocations/us); slots of a sample are chained through `prev`, so the order in which the exact results are summed
-// is fixed even though slot ids are not.
 // wave-wide exclusive prefix sum with DPP row shifts / row broadcasts (no LDS traffic)
 __device__ __forceinline__ int wave_excl_scan(int v, int lane, int &total) {
     int x = v;
@@ -166,85 +114,163 @@ __device__ __forceinline__ int wave_excl_scan(int v, int lane, int &total) {
     return x - v;
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// sweep_kernel: workgroup = SW_SAMPLES consecutive constraint samples, one wavefront each
+// ---------------------------------------------------------------------------------------------------------------
+// The grid is read through its QUALIFIER BIT-GRID (1 bit per voxel: esdf <= occ_thresh for V3, occupied for V2;
+// built once per set_grid by build_bits_kernel), 32 voxels of a z-row per dword.
+constexpr int SW_SAMPLES = 4;
+
+struct SweepPose {                 // LDS record of one sample, written by the pose lane
+    double pos[3];
+    double R[9];                   // row-major body->world rotation
+    double quat[4];                // w x y z
+    int lo[3];                     // first voxel of the tile (getPointsInAABB box)
+    int nzt;                       // tile extent along z
+    int rx0, ry0, rnx, rny;        // window of tile rows (lx, ly) that can reach the shape's inflated bounding box
+    int flags;                     // bit0 active, bit1 culled
+    int pad;
+};
+
+__device__ __forceinline__ double uni(double v) {     // wave-uniform double -> scalar registers
+    const int lo = __builtin_amdgcn_readfirstlane(__double2loint(v)), hi = __builtin_amdgcn_readfirstlane(__double2hiint(v));
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ float unif(float v) { return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v))); }
+
 template <int KIND>
-__global__ __launch_bounds__(TS_THREADS) void scan_kernel(const SweepParams P) {
-    __shared__ unsigned s_bits[TS_WAVES][TS_BITS_CAP];   // qualifier bits of up to TS_BITS_CAP z-rows of the tile
-    __shared__ unsigned s_list[TS_WAVES][TS_LIST_CAP];   // ring of compacted voxels awaiting the fp32 test
-    __shared__ unsigned s_near[TS_WAVES][TS_NEAR_CAP];   // ring of candidates awaiting a pool slot
+__global__ __launch_bounds__(64 * SW_SAMPLES, 3) void sweep_kernel(const SweepParams P) {
+    __shared__ SweepPose s_pose[SW_SAMPLES];
+    __shared__ unsigned s_list[SW_SAMPLES][SW_LIST_CAP];          // ring of compacted voxels awaiting the fp32 test
+    __shared__ unsigned s_near[SW_SAMPLES][SW_NEAR_CAP];          // ring of candidates awaiting the exact pass
 
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int K1 = P.K + 1;
     const long long s_begin = (long long)P.piece_begin * K1, s_end = (long long)P.piece_end * K1;
-    const long long sidx = s_begin + (long long)blockIdx.x * TS_WAVES + wave;
-    if (sidx >= s_end) return;                                 // waves are independent: no workgroup barriers below
+    const long long sidx0 = s_begin + (long long)blockIdx.x * SW_SAMPLES;
     const DevGrid &G = P.grid;
-    // pose of this wave's sample (wave-uniform fp64 chain), published for exact_kernel / stats
-    PoseRec rec;
-    compute_pose(P, sidx, rec);
-    if (lane == 0) P.pose[sidx] = rec;
-    int prev_slot = -1;
-    if (rec.flags & 1) {
-        const int lox = rec.lo[0], loy = rec.lo[1], loz = rec.lo[2];
-        const int nx = rec.hi[0] - lox + 1, ny = rec.hi[1] - loy + 1, nzt = rec.hi[2] - loz + 1;
-        const int n_rows = nx * ny;
-        const float inv_ny = 1.0f / (float)ny;
+    const long long sidx = sidx0 + wave;
+    unsigned long long *const dbg = (P.dbg && sidx < s_end) ? P.dbg + (size_t)(sidx - s_begin) * 8 : nullptr;
+    if (dbg && lane == 0) { dbg[0] = wall_clock64(); dbg[1] = clock64(); }
+
+    // ---- poses of the workgroup's samples: one LANE per sample (the serial fp64 chain is issued once, not per wave)
+    if (wave == 0 && lane < SW_SAMPLES && sidx0 + lane < s_end) {
+        const SampleId id = decode_sample(P, sidx0 + lane);
+        const double *c = P.coeffs + (size_t)id.b * 18 * P.N + 6 * id.i;
+        const int ld = 6 * P.N;
+        const double step = P.T[(size_t)id.b * P.N + id.i] * (1.0 / P.K);
+        Basis B;
+        poly_basis(id.j * step, B);
+        const d3 pos = ct_beta(c, ld, B.b0), vel = ct_beta(c, ld, B.b1), acc = ct_beta(c, ld, B.b2);
+        FlatS fs;
+        flat_core(P.flat, vel, acc, fs);
+        const d4 quat = flat_quat(fs);
+        const m3 R = quat_to_rot(quat);
+        SweepPose &sp = s_pose[lane];
+        sp.pos[0] = pos.x; sp.pos[1] = pos.y; sp.pos[2] = pos.z;
+#pragma unroll
+        for (int k = 0; k < 9; k++) sp.R[k] = R.a[k];
+        sp.quat[0] = quat.w; sp.quat[1] = quat.x; sp.quat[2] = quat.y; sp.quat[3] = quat.z;
+        int lo[3] = {0, 0, 0}, hi[3] = {-1, -1, -1};
+        int flags = 0;
+        if (P.enable_pos) {
+            bool active = true;
+            if (P.cull_threshold > 0.0 && esdf_trilinear(G, pos) > P.cull_threshold) { active = false; flags |= 2; }
+            if (active) {
+                // getPointsInAABB(pos, bd/2): corners projected into the map, floor-indexed (PCSmap_manager.h:150-155)
+                const double p[3] = {pos.x, pos.y, pos.z};
+                const int dim[3] = {G.X, G.Y, G.Z};
+#pragma unroll
+                for (int a = 0; a < 3; a++) {
+                    lo[a] = axis_index(clampd(p[a] - P.bd_half, G.bmin[a], G.bmax[a]), G.bmin[a], G.res, dim[a]);
+                    hi[a] = axis_index(clampd(p[a] + P.bd_half, G.bmin[a], G.bmax[a]), G.bmin[a], G.res, dim[a]);
+                }
+                // NaN poses make every comparison false: keep the box sane
+                if (hi[0] >= lo[0] && hi[1] >= lo[1] && hi[2] >= lo[2]) flags |= 1;
+            }
+        }
+        const int nx = hi[0] - lo[0] + 1, ny = hi[1] - lo[1] + 1;
+        int rx0 = 0, ry0 = 0, rnx = (flags & 1) ? nx : 0, rny = (flags & 1) ? ny : 0;
+        if ((flags & 1) && P.shape.prune_rows) {
+            // world-frame extent of the shape's body-frame bounding box inflated by the penalty band: rows whose
+            // (x, y) lies outside it cannot hold a voxel with a non-zero penalty (conservative: +-1 voxel, NaN keeps all)
+            const double infl = P.safety_hor + 4.0e-3 + 0.05 * G.res;
+            const double hb[3] = {0.5 * ((double)P.shape.bbox_hi[0] - (double)P.shape.bbox_lo[0]) + infl,
+                                  0.5 * ((double)P.shape.bbox_hi[1] - (double)P.shape.bbox_lo[1]) + infl,
+                                  0.5 * ((double)P.shape.bbox_hi[2] - (double)P.shape.bbox_lo[2]) + infl};
+            const double cb[3] = {0.5 * ((double)P.shape.bbox_hi[0] + (double)P.shape.bbox_lo[0]),
+                                  0.5 * ((double)P.shape.bbox_hi[1] + (double)P.shape.bbox_lo[1]),
+                                  0.5 * ((double)P.shape.bbox_hi[2] + (double)P.shape.bbox_lo[2])};
+            const double p[2] = {pos.x, pos.y};
+            const int nn[2] = {nx, ny};
+            int w0[2], w1[2];
+#pragma unroll
+            for (int a = 0; a < 2; a++) {
+                const double ctr = p[a] + R.a[3 * a] * cb[0] + R.a[3 * a + 1] * cb[1] + R.a[3 * a + 2] * cb[2];
+                const double ext = fabs(R.a[3 * a]) * hb[0] + fabs(R.a[3 * a + 1]) * hb[1] + fabs(R.a[3 * a + 2]) * hb[2];
+                const double l0 = (ctr - ext - G.bmin[a]) / G.res - 0.5 - lo[a], l1 = (ctr + ext - G.bmin[a]) / G.res - 0.5 - lo[a];
+                w0[a] = 0; w1[a] = nn[a] - 1;
+                if (l0 > 0.0) w0[a] = (int)fmin(floor(l0), (double)nn[a]);          // > nn-1 -> empty window
+                if (l1 < (double)(nn[a] - 1)) w1[a] = (int)fmax(ceil(l1), -1.0);
+            }
+            rx0 = w0[0]; ry0 = w0[1];
+            rnx = max(0, w1[0] - w0[0] + 1); rny = max(0, w1[1] - w0[1] + 1);
+        }
+        sp.lo[0] = lo[0]; sp.lo[1] = lo[1]; sp.lo[2] = lo[2];
+        sp.nzt = hi[2] - lo[2] + 1;
+        sp.rx0 = rx0; sp.ry0 = ry0; sp.rnx = rnx; sp.rny = rny;
+        sp.flags = flags;
+    }
+    __syncthreads();
+    if (sidx >= s_end) return;                                 // no workgroup barriers below
+    if (dbg && lane == 0) dbg[2] = clock64();
+
+    const SweepPose &sp = s_pose[wave];
+    const int flags = __builtin_amdgcn_readfirstlane(sp.flags);
+    const bool active = (flags & 1) != 0;
+    double a0 = 0, a1 = 0, a2 = 0, a3 = 0, a4 = 0, a5 = 0, a6 = 0, a7 = 0;   // per-lane partial sums of the exact pass
+    int n_pairs = 0, n_grads = 0, n_rounds = 0;
+    const int rnx = __builtin_amdgcn_readfirstlane(sp.rnx), rny = __builtin_amdgcn_readfirstlane(sp.rny);
+    const int n_rows = rnx * rny;
+    if (active && n_rows > 0) {
+        const d3 pos = mk3(uni(sp.pos[0]), uni(sp.pos[1]), uni(sp.pos[2]));
+        m3 R;
+#pragma unroll
+        for (int k = 0; k < 9; k++) R.a[k] = uni(sp.R[k]);
+        d4 quat; quat.w = uni(sp.quat[0]); quat.x = uni(sp.quat[1]); quat.y = uni(sp.quat[2]); quat.z = uni(sp.quat[3]);
+        const int lox = __builtin_amdgcn_readfirstlane(sp.lo[0]), loy = __builtin_amdgcn_readfirstlane(sp.lo[1]),
+                  loz = __builtin_amdgcn_readfirstlane(sp.lo[2]), nzt = __builtin_amdgcn_readfirstlane(sp.nzt);
+        const int rx0 = __builtin_amdgcn_readfirstlane(sp.rx0), ry0 = __builtin_amdgcn_readfirstlane(sp.ry0);
+        const float inv_rny = 1.0f / (float)rny;
         const bool small = n_rows < (1 << 24);
 
         // fp32 pre-filter constants (wave-uniform)
         const bool use_filter = P.shape.filter_f32 != 0;
         float Rf[9];
 #pragma unroll
-        for (int k = 0; k < 9; k++) Rf[k] = (float)rec.R[k];
+        for (int k = 0; k < 9; k++) Rf[k] = (float)R.a[k];
         const float resf = (float)G.res;
         const float bdh_f = (float)P.bd_half + TS_FILTER_EPS;
         const float thr_f = (float)P.safety_hor + TS_FILTER_EPS;
         // pose in the tile's voxel frame, pre-multiplied: m = l*res - pvr,  pvr = ((pos - bmin)/res - 0.5 - lo)*res
-        const float pvx = (float)(((rec.pos[0] - G.bmin[0]) / G.res - 0.5 - lox) * G.res);
-        const float pvy = (float)(((rec.pos[1] - G.bmin[1]) / G.res - 0.5 - loy) * G.res);
-        const float pvz = (float)(((rec.pos[2] - G.bmin[2]) / G.res - 0.5 - loz) * G.res);
+        const float pvx = unif((float)(((pos.x - G.bmin[0]) / G.res - 0.5 - lox) * G.res));
+        const float pvy = unif((float)(((pos.y - G.bmin[1]) / G.res - 0.5 - loy) * G.res));
+        const float pvz = unif((float)(((pos.z - G.bmin[2]) / G.res - 0.5 - loz) * G.res));
 
-        int near_head = 0, near_cnt = 0;
-        const int shard = (int)(blockIdx.x % POOL_SHARDS);
-        const int shard_cap = P.pool_cap / POOL_SHARDS;
-        unsigned *const pool_count = P.pool_count + (size_t)P.parity * POOL_SHARDS * POOL_COUNTER_STRIDE;
-        // hand the oldest `n` (<= 64) candidates to the exact pass
-        auto flush = [&](int n) {
-            wave_lds_sync();
-            int local = 0;
-            if (lane == 0) local = (int)atomicAdd(pool_count + shard * POOL_COUNTER_STRIDE, 1u);
-            local = __builtin_amdgcn_readfirstlane(local);
-            if (local < shard_cap) {
-                const int slot = shard * shard_cap + local;
-                P.pool_entries[(size_t)slot * 64 + lane] = (lane < n) ? s_near[wave][(near_head + lane) & (TS_NEAR_CAP - 1)] : 0xFFFFFFFFu;
-                if (lane == 0) {
-                    P.slot_sample[slot] = (int)(sidx - s_begin);
-                    P.slot_prev[slot] = prev_slot;
-                }
-                prev_slot = slot;
-            } else if (lane == 0) {
-                atomicOr((unsigned int *)&P.stats[4], 1u);   // pool overflow: result invalid, host reports ISDF_ERR_OVERFLOW
-            }
-            near_head = (near_head + n) & (TS_NEAR_CAP - 1);
-            near_cnt -= n;
-            wave_lds_sync();
-        };
-
-        // (lx, ly) of tile row r, packed lx | ly << 10
-        auto row_xy = [&](int r) -> unsigned {
-            unsigned lx, ly;
+        // (lx, ly) of window row t, packed lx | ly << 10
+        auto row_xy = [&](int t) -> unsigned {
+            unsigned wx, wy;
             if (small) {
-                lx = (unsigned)((float)r * inv_ny);
-                int rem = r - (int)lx * ny;
-                if (rem < 0) { lx--; rem += ny; } else if (rem >= ny) { lx++; rem -= ny; }
-                ly = (unsigned)rem;
-            } else { lx = (unsigned)(r / ny); ly = (unsigned)(r - (int)lx * ny); }
-            return lx | (ly << 10);
+                wx = (unsigned)((float)t * inv_rny);
+                int rem = t - (int)wx * rny;
+                if (rem < 0) { wx--; rem += rny; } else if (rem >= rny) { wx++; rem -= rny; }
+                wy = (unsigned)rem;
+            } else { wx = (unsigned)(t / rny); wy = (unsigned)(t - (int)wx * rny); }
+            return (wx + (unsigned)rx0) | ((wy + (unsigned)ry0) << 10);
         };
-        // the <= 32 qualifier bits of z-block zb of tile row r: 1-2 dwords of the bit-grid
-        auto row_bits = [&](int r, int zb) -> unsigned {
-            const bool rok = r < n_rows;
-            const unsigned pk = rok ? row_xy(r) : 0u;
+        // the <= 32 qualifier bits of z-block zb of tile row pk: 1-2 dwords of the bit-grid
+        auto row_bits = [&](unsigned pk, int zb) -> unsigned {
             const int z0 = loz + (zb << 5);
             const int nz = min(32, nzt - (zb << 5));
             const size_t rowbase = ((size_t)(lox + (int)(pk & 1023u)) * G.Y + (loy + (int)(pk >> 10))) * G.ZW;
@@ -253,7 +279,7 @@ __global__ __launch_bounds__(TS_THREADS) void scan_kernel(const SweepParams P) {
             const unsigned b1 = G.bits[rowbase + min(w0 + 1, G.ZW - 1)];
             unsigned bits = sh ? ((b0 >> sh) | (b1 << (32 - sh))) : b0;     // when w0+1 == ZW the b1 bits are masked off below
             if (nz < 32) bits &= (1u << nz) - 1u;
-            return rok ? bits : 0u;
+            return bits;
         };
 
         // Row pruning: in the body frame the voxels of one z-row lie on the line o + lz*dz.  Only the part of the line
@@ -292,155 +318,147 @@ __global__ __launch_bounds__(TS_THREADS) void scan_kernel(const SweepParams P) {
             return (n >= 32) ? 0xFFFFFFFFu : (((1u << n) - 1u) << zlo);
         };
 
-        int pend_head = 0, pend = 0;                 // ring of compacted voxels awaiting the fp32 test
-        // conservative fp32 test of the oldest min(pend, 64) listed voxels (branch-free body)
-        auto scan64 = [&]() {
-            const int n = min(pend, 64);
-            const unsigned ent = s_list[wave][(pend_head + min(lane, n - 1)) & (TS_LIST_CAP - 1)];
-            bool cand = lane < n;
-            if (use_filter) {
-                const float flx = (float)(ent & 1023u), fly = (float)((ent >> 10) & 1023u), flz = (float)(ent >> 20);
-                const float mx = fmaf(flx, resf, -pvx), my = fmaf(fly, resf, -pvy), mz = fmaf(flz, resf, -pvz);
-                const f3 pr = mkv<float>(Rf[0] * mx + Rf[3] * my + Rf[6] * mz, Rf[1] * mx + Rf[4] * my + Rf[7] * mz,
-                                         Rf[2] * mx + Rf[5] * my + Rf[8] * mz);
-                const bool incube = fmaxf(fabsf(pr.x), fmaxf(fabsf(pr.y), fabsf(pr.z))) <= bdh_f;
-                const float sdf = analytic_sdf<KIND, float>(P.shape.f, P.shape.kind, pr);
-                cand = cand & incube & !(sdf >= thr_f);   // reject only what provably has zero penalty; NaN => candidate
-            }
-            pend_head = (pend_head + n) & (TS_LIST_CAP - 1);
-            pend -= n;
-            const unsigned long long nm = __ballot(cand);
-            if (nm) {
-                if (cand) s_near[wave][(near_head + near_cnt + __popcll(nm & ((1ull << lane) - 1ull))) & (TS_NEAR_CAP - 1)] = ent;
-                near_cnt += __popcll(nm);
-                if (near_cnt >= 64) flush(64);
-            }
-        };
-
+        // One loop, three stages, each with a single code instance; the most downstream stage that has a full
+        // wavefront of work (or the last of it) runs next:
+        //   produce: rows -> s_list (ring of compacted voxels)       scan: s_list -> s_near (fp32 survivors)
+        //   exact  : s_near -> per-lane fp64 sums
         const int n_zb = (nzt + 31) >> 5;            // 32-voxel blocks along z (1 for kernel_size <= 31)
-        for (int zb = 0; zb < n_zb; zb++)
-        for (int rblk = 0; rblk < n_rows; rblk += TS_BITS_CAP) {
-            // ---- stage the qualifier bits of up to TS_BITS_CAP rows into LDS: all loads in flight together
-            const int nrb = min(TS_BITS_CAP, n_rows - rblk);
-#pragma unroll 8
-            for (int r = lane; r < nrb; r += 64) s_bits[wave][r] = row_bits(rblk + r, zb);
-            wave_lds_sync();
-            // ---- one lane per row, 64 rows per round: prune, compact into the ring, test full wavefronts
-            for (int r0 = 0; r0 < nrb; r0 += 64) {
-                const int r = r0 + lane;
-                unsigned bits_cur = (r < nrb) ? s_bits[wave][r] : 0u;
-                unsigned pk = 0;
-                if (bits_cur) {
-                    pk = row_xy(rblk + r);
-                    if (prune) bits_cur &= row_mask(pk, zb);
-                }
-                if (!__ballot(bits_cur != 0u)) continue;
-                int total;
-                int pos = wave_excl_scan(__popc(bits_cur), lane, total);
-                if (pend + total > TS_LIST_CAP) {           // make room: drain the (partial) backlog first
-                    while (pend > 0) scan64();
-                }
-                unsigned hb = bits_cur;
-                const unsigned zoff = (unsigned)(zb << 5);
-                pos += pend_head + pend;
-                while (hb) {
-                    const unsigned z = (unsigned)__ffs(hb) - 1u;
-                    hb &= hb - 1u;
-                    s_list[wave][(pos++) & (TS_LIST_CAP - 1)] = pk | ((zoff + z) << 20);
-                }
-                pend += total;
+        int near_head = 0, near_cnt = 0;             // ring of candidates awaiting the exact pass
+        int pend_head = 0, pend = 0;                 // ring of compacted voxels awaiting the fp32 test
+        int fzb = 0, ft = 0;                         // fetch cursor: z-block and first window row of the next round
+        bool rows_left = true;
+        unsigned hb = 0, pk = 0, zoff = 0;           // this lane's row: pending qualifier bits, packed (lx, ly), z offset
+        unsigned nbits = 0, nmask = 0, npk = 0, nzoff = 0;   // the NEXT round's row, requested one round ahead
+        int rounds_left = n_zb * ((n_rows + 63) >> 6);
+        bool primed = false;
+        for (;;) {
+            if (near_cnt >= 64 || (!rows_left && pend == 0 && near_cnt > 0)) {
+                // ---- (4) exact fp64 pass over the oldest n (<= 64) candidates: grad_cost_p (:766-824)
+                const int n = min(near_cnt, 64);
                 wave_lds_sync();
-                while (pend >= 64) scan64();
-            }
-            wave_lds_sync();    // s_bits is rewritten by the next block
-        }
-        while (pend > 0) scan64();
-        if (near_cnt > 0) flush(near_cnt);
-    }
-    if (lane == 0) P.sample_last[sidx - s_begin] = prev_slot;
-}
-
-// ---------------------------------------------------------------------------------------------------------------
-// exact_kernel: one wave per candidate slot (64 voxels of one pose), fp64
-// ---------------------------------------------------------------------------------------------------------------
-// Voxel centre, body-frame point, the |p_rel| > bd/2 cull of grad_cost_p (:800-803), robot SDF, smoothedL1 and — when
-// the penalty is active — the central-difference gradient and the pose-gradient terms (:805-820).  Slots are spread
-// over the whole chip, so a pose buried in obstacles does not serialise behind one wavefront.
-constexpr int EX_WAVES = 4;
-constexpr int EX_BLOCKS_PER_SHARD = 8;
-
-template <int KIND>
-__global__ __launch_bounds__(64 * EX_WAVES) void exact_kernel(const SweepParams P) {
-    const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int K1 = P.K + 1;
-    const long long s_begin = (long long)P.piece_begin * K1;
-    const int shard = blockIdx.x;
-    const int shard_cap = P.pool_cap / POOL_SHARDS;
-    const int n_local = (int)min(P.pool_count[((size_t)P.parity * POOL_SHARDS + shard) * POOL_COUNTER_STRIDE], (unsigned)shard_cap);
-    for (int local = blockIdx.y * EX_WAVES + wave; local < n_local; local += gridDim.y * EX_WAVES) {
-        const int slot = shard * shard_cap + local;
-        const PoseRec *rec = P.pose + (s_begin + P.slot_sample[slot]);   // wave-uniform
-        const unsigned ent = P.pool_entries[(size_t)slot * 64 + lane];
-        double a0 = 0, a1 = 0, a2 = 0, a3 = 0, a4 = 0, a5 = 0, a6 = 0, a7 = 0;
-        bool is_pair = false, is_grad = false;
-        if (ent != 0xFFFFFFFFu) {
-            const d3 pos = mk3(rec->pos[0], rec->pos[1], rec->pos[2]);
-            m3 R;
-#pragma unroll
-            for (int k = 0; k < 9; k++) R.a[k] = rec->R[k];
-            const int gx = rec->lo[0] + (int)(ent & 1023u), gy = rec->lo[1] + (int)((ent >> 10) & 1023u), gz = rec->lo[2] + (int)(ent >> 20);
-            const d3 c = mk3((gx + 0.5) * P.grid.res + P.grid.bmin[0], (gy + 0.5) * P.grid.res + P.grid.bmin[1],
-                             (gz + 0.5) * P.grid.res + P.grid.bmin[2]);
-            const d3 pm = c - pos;
-            const d3 prel = mat_tmul(R, pm);
-            if (!(fabs(prel.x) > P.bd_half || fabs(prel.y) > P.bd_half || fabs(prel.z) > P.bd_half)) {
-                const double sdf = shape_sdf<KIND>(P.shape, prel);
-                is_pair = true;
-                double f = 0.0, df = 0.0;
-                smoothed_l1(P.safety_hor - sdf, P.mu, f, df);
-                if (f > 0.0) {
-                    const d3 g = shape_grad<KIND>(P.shape, prel);
-                    is_grad = true;
-                    a0 = f;
-                    const d3 wg = mat_mul(R, g);
-                    a1 = df * wg.x; a2 = df * wg.y; a3 = df * wg.z;
-                    d4 quat; quat.w = rec->quat[0]; quat.x = rec->quat[1]; quat.y = rec->quat[2]; quat.z = rec->quat[3];
-                    const d4 sq = quat_step_grad(quat, g, pm);
-                    a4 = -df * sq.w; a5 = -df * sq.x; a6 = -df * sq.y; a7 = -df * sq.z;
+                const unsigned ent = s_near[wave][(near_head + min(lane, n - 1)) & (SW_NEAR_CAP - 1)];
+                bool is_pair = false, is_grad = false;
+                if (lane < n) {
+                    const int gx = lox + (int)(ent & 1023u), gy = loy + (int)((ent >> 10) & 1023u), gz = loz + (int)(ent >> 20);
+                    const d3 ctr = mk3((gx + 0.5) * G.res + G.bmin[0], (gy + 0.5) * G.res + G.bmin[1], (gz + 0.5) * G.res + G.bmin[2]);
+                    const d3 pm = ctr - pos;
+                    const d3 prel = mat_tmul(R, pm);
+                    if (!(fabs(prel.x) > P.bd_half || fabs(prel.y) > P.bd_half || fabs(prel.z) > P.bd_half)) {
+                        const double sdf = shape_sdf<KIND>(P.shape, prel);
+                        is_pair = true;
+                        double f = 0.0, df = 0.0;
+                        smoothed_l1(P.safety_hor - sdf, P.mu, f, df);
+                        if (f > 0.0) {
+                            const d3 g = shape_grad<KIND>(P.shape, prel);
+                            is_grad = true;
+                            a0 += f;
+                            const d3 wg = mat_mul(R, g);
+                            a1 += df * wg.x; a2 += df * wg.y; a3 += df * wg.z;
+                            const d4 sq = quat_step_grad(quat, g, pm);
+                            a4 += -df * sq.w; a5 += -df * sq.x; a6 += -df * sq.y; a7 += -df * sq.z;
+                        }
+                    }
                 }
-            }
-        }
-        a0 = wave_sum(a0); a1 = wave_sum(a1); a2 = wave_sum(a2); a3 = wave_sum(a3);
-        a4 = wave_sum(a4); a5 = wave_sum(a5); a6 = wave_sum(a6); a7 = wave_sum(a7);
-        const unsigned long long pm_ = __ballot(is_pair), gm_ = __ballot(is_grad);
-        if (lane == 0) {
-            double *o = P.slot_res + (size_t)slot * ACC_STRIDE;
-            o[0] = a0; o[1] = a1; o[2] = a2; o[3] = a3; o[4] = a4; o[5] = a5; o[6] = a6; o[7] = a7;
-            P.slot_cnt[slot] = (unsigned)__popcll(pm_) | ((unsigned)__popcll(gm_) << 16);   // summed on demand (stats_kernel)
+                n_pairs += __popcll(__ballot(is_pair));
+                n_grads += __popcll(__ballot(is_grad));
+                n_rounds++;
+                near_head = (near_head + n) & (SW_NEAR_CAP - 1);
+                near_cnt -= n;
+                wave_lds_sync();
+            } else if (pend >= 64 || (!rows_left && pend > 0)) {
+                // ---- (3) conservative fp32 test of the oldest min(pend, 64) listed voxels (branch-free body)
+                const int n = min(pend, 64);
+                const unsigned ent = s_list[wave][(pend_head + min(lane, n - 1)) & (SW_LIST_CAP - 1)];
+                bool cand = lane < n;
+                if (use_filter) {
+                    const float flx = (float)(ent & 1023u), fly = (float)((ent >> 10) & 1023u), flz = (float)(ent >> 20);
+                    const float mx = fmaf(flx, resf, -pvx), my = fmaf(fly, resf, -pvy), mz = fmaf(flz, resf, -pvz);
+                    const f3 pr = mkv<float>(Rf[0] * mx + Rf[3] * my + Rf[6] * mz, Rf[1] * mx + Rf[4] * my + Rf[7] * mz,
+                                             Rf[2] * mx + Rf[5] * my + Rf[8] * mz);
+                    const bool incube = fmaxf(fabsf(pr.x), fmaxf(fabsf(pr.y), fabsf(pr.z))) <= bdh_f;
+                    const float sdf = analytic_sdf<KIND, float>(P.shape.f, P.shape.kind, pr);
+                    cand = cand & incube & !(sdf >= thr_f);   // reject only what provably has zero penalty; NaN => candidate
+                }
+                pend_head = (pend_head + n) & (SW_LIST_CAP - 1);
+                pend -= n;
+                const unsigned long long nm = __ballot(cand);
+                if (cand) s_near[wave][(near_head + near_cnt + __popcll(nm & ((1ull << lane) - 1ull))) & (SW_NEAR_CAP - 1)] = ent;
+                near_cnt += __popcll(nm);
+            } else if (rows_left) {
+                if (!__ballot(hb != 0u)) {
+                    // ---- (2a) take the round requested earlier, request the one after it
+                    if (primed && rounds_left == 0) {
+                        rows_left = false;
+                        if (dbg && lane == 0) dbg[4] = clock64();
+                        continue;
+                    }
+                    if (primed) {
+                        rounds_left--;
+                        hb = nbits & nmask;          // waits for the loads requested one round ago
+                        pk = npk; zoff = nzoff;
+                    }
+                    primed = true;
+                    // request round (fzb, ft): its loads stay in flight while the current round is processed
+                    nmask = 0u; nbits = 0u;
+                    if (fzb < n_zb) {
+                        const int t = ft + lane;
+                        if (t < n_rows) {
+                            npk = row_xy(t);
+                            nmask = prune ? row_mask(npk, fzb) : 0xFFFFFFFFu;
+                            if (nmask) nbits = row_bits(npk, fzb);
+                        }
+                        nzoff = (unsigned)(fzb << 5);
+                        ft += 64;
+                        if (ft >= n_rows) { ft = 0; fzb++; }
+                    }
+                } else {
+                    // ---- (2b) one pass: every lane moves its lowest <= SW_PASS set bits into the ring
+                    unsigned take = hb;
+                    if (__ballot(__popc(hb) > SW_PASS)) {
+                        unsigned t = hb;
+#pragma unroll
+                        for (int k = 0; k < SW_PASS; k++) t &= t - 1u;
+                        take = hb ^ t;
+                    }
+                    hb ^= take;
+                    int total;
+                    int wpos = wave_excl_scan(__popc(take), lane, total) + pend_head + pend;
+                    while (take) {
+                        const unsigned z = (unsigned)__ffs(take) - 1u;
+                        take &= take - 1u;
+                        s_list[wave][(wpos++) & (SW_LIST_CAP - 1)] = pk | ((zoff + z) << 20);
+                    }
+                    pend += total;
+                    wave_lds_sync();
+                }
+            } else break;
         }
     }
+
+    // ---- (5) lanes -> wave, fixed order
+    a0 = wave_sum(a0); a1 = wave_sum(a1); a2 = wave_sum(a2); a3 = wave_sum(a3);
+    a4 = wave_sum(a4); a5 = wave_sum(a5); a6 = wave_sum(a6); a7 = wave_sum(a7);
+    const long long sl = sidx - s_begin;
+    if (lane == 0) {
+        double *o = P.acc + (size_t)sl * ACC_STRIDE;
+        o[0] = a0; o[1] = a1; o[2] = a2; o[3] = a3; o[4] = a4; o[5] = a5; o[6] = a6; o[7] = a7;
+        P.sample_info[2 * sl] = n_pairs;
+        P.sample_info[2 * sl + 1] = n_grads | ((flags & 2) ? (int)0x80000000 : 0);
+    }
+    if (dbg && lane == 0) { dbg[5] = clock64(); dbg[6] = wall_clock64(); dbg[7] = (unsigned long long)n_rounds; }
 }
 
 // on-demand statistics (isdf_get_stats / host API): culled poses, exact pairs, active pairs.  Not on the timed path.
 __global__ __launch_bounds__(256) void stats_kernel(const SweepParams P) {
     const int K1 = P.K + 1;
     const long long n_samples = (long long)(P.piece_end - P.piece_begin) * K1;
-    const long long s_begin = (long long)P.piece_begin * K1;
     unsigned long long culled = 0, pairs = 0, grads = 0;
     if (P.enable_pos)
-        for (long long s = (long long)blockIdx.x * blockDim.x + threadIdx.x; s < n_samples; s += (long long)gridDim.x * blockDim.x)
-            if (P.pose[s_begin + s].flags & 2) culled++;
-    if (P.enable_pos) {
-        const int shard_cap = P.pool_cap / POOL_SHARDS;
-        for (int shard = blockIdx.x; shard < POOL_SHARDS; shard += gridDim.x) {
-            const int n_local = (int)min(P.pool_count[((size_t)P.parity * POOL_SHARDS + shard) * POOL_COUNTER_STRIDE], (unsigned)shard_cap);
-            for (int l = threadIdx.x; l < n_local; l += blockDim.x) {
-                const unsigned c = P.slot_cnt[shard * shard_cap + l];
-                pairs += c & 0xFFFFu; grads += c >> 16;
-            }
+        for (long long s = (long long)blockIdx.x * blockDim.x + threadIdx.x; s < n_samples; s += (long long)gridDim.x * blockDim.x) {
+            const int a = P.sample_info[2 * s], b = P.sample_info[2 * s + 1];
+            pairs += (unsigned)a; grads += (unsigned)(b & 0x7fffffff);
+            if (b < 0) culled++;
         }
-    }
     if (culled) atomicAdd(&P.stats[1], culled);
     if (pairs) atomicAdd(&P.stats[2], pairs);
     if (grads) atomicAdd(&P.stats[3], grads);
@@ -462,6 +480,8 @@ __global__ __launch_bounds__(TL_THREADS) void tail_kernel(const SweepParams P) {
     const double integral_frac = 1.0 / P.K;
     const double step = P.T[(size_t)b * P.N + i] * integral_frac;
     double colsum = 0.0;   // threads 0..19: running sum of their output column, samples in ascending order
+    unsigned long long *const dbg = P.dbg ? P.dbg + (size_t)(P.piece_end - P.piece_begin) * K1 * 8 + (size_t)blockIdx.x * 4 : nullptr;
+    if (dbg && threadIdx.x == 0) dbg[0] = wall_clock64();
     for (int j0 = 0; j0 < K1; j0 += TL_THREADS) {
         const int j = j0 + threadIdx.x;
         if (j < K1) {
@@ -499,13 +519,8 @@ __global__ __launch_bounds__(TL_THREADS) void tail_kernel(const SweepParams P) {
                 }
             }
             if (P.enable_pos) {
-                // this pose's exact results: walk its slot chain (fixed order: last slot first)
-                double a[ACC_STRIDE] = {0, 0, 0, 0, 0, 0, 0, 0};
-                for (int sl = P.sample_last[s - (long long)P.piece_begin * K1]; sl >= 0; sl = P.slot_prev[sl]) {
-                    const double *r = P.slot_res + (size_t)sl * ACC_STRIDE;
-#pragma unroll
-                    for (int k = 0; k < ACC_STRIDE; k++) a[k] += r[k];
-                }
+                // this pose's exact results (sweep_kernel)
+                const double *a = P.acc + (size_t)(s - (long long)P.piece_begin * K1) * ACC_STRIDE;
                 if (a[0] > 0.0) {
                     gradPos.x += P.weight_p * a[1]; gradPos.y += P.weight_p * a[2]; gradPos.z += P.weight_p * a[3];
                     gradQuat.w += P.weight_p * a[4]; gradQuat.x += P.weight_p * a[5];
@@ -545,6 +560,7 @@ __global__ __launch_bounds__(TL_THREADS) void tail_kernel(const SweepParams P) {
             o[1 + P.N + (size_t)d * 6 * P.N + 6 * i + r] = colsum;
         }
     }
+    if (dbg && threadIdx.x == 0) dbg[1] = wall_clock64();
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -554,6 +570,8 @@ __global__ __launch_bounds__(256) void finalize_kernel(const SweepParams P) {
     const int b = blockIdx.x;
     const size_t ostride = (size_t)1 + 19 * (size_t)P.N;
     double *o = P.out + (size_t)b * ostride;
+    unsigned long long *const dbg = (P.dbg && b == 0) ? P.dbg + (size_t)(P.piece_end - P.piece_begin) * (P.K + 1) * 8 + (size_t)(P.piece_end - P.piece_begin) * 4 : nullptr;
+    if (dbg && threadIdx.x == 0) dbg[0] = wall_clock64();
     const int p0 = max(P.piece_begin, b * P.N) - b * P.N, p1 = min(P.piece_end, (b + 1) * P.N) - b * P.N;   // local piece range in shard
     // zero the entries of pieces that belong to other ranks
     for (int e = threadIdx.x; e < 19 * P.N; e += blockDim.x) {
@@ -562,10 +580,6 @@ __global__ __launch_bounds__(256) void finalize_kernel(const SweepParams P) {
         else { const int r = (e - P.N) % (6 * P.N); i = r / 6; }
         if (i < p0 || i >= p1) o[1 + e] = 0.0;
     }
-    if (b == 0) {   // the next step allocates from the other set of pool counters: reset it now
-        unsigned *nxt = P.pool_count + (size_t)(P.parity ^ 1) * POOL_SHARDS * POOL_COUNTER_STRIDE;
-        for (int k = threadIdx.x; k < POOL_SHARDS; k += blockDim.x) nxt[k * POOL_COUNTER_STRIDE] = 0u;
-    }
     if (threadIdx.x < 64) {
         double s = 0.0;
         if (p1 > p0)
@@ -573,27 +587,17 @@ __global__ __launch_bounds__(256) void finalize_kernel(const SweepParams P) {
         s = wave_sum(s);
         if (threadIdx.x == 0) o[0] = s;
     }
+    if (dbg && threadIdx.x == 0) dbg[1] = wall_clock64();
 }
 
-void launch_scan(const SweepParams &P, hipStream_t stream) {
+void launch_sweep(const SweepParams &P, hipStream_t stream) {
     const long long n_samples = (long long)(P.piece_end - P.piece_begin) * (P.K + 1);
     if (n_samples <= 0 || !P.enable_pos) return;
-    const int blocks = (int)((n_samples + TS_WAVES - 1) / TS_WAVES);
+    const int blocks = (int)((n_samples + SW_SAMPLES - 1) / SW_SAMPLES);
     switch (P.shape.kind) {
-    case ISDF_SHAPE_BOX: hipLaunchKernelGGL(scan_kernel<ISDF_SHAPE_BOX>, dim3(blocks), dim3(TS_THREADS), 0, stream, P); break;
-    case ISDF_SHAPE_ROUNDEDCONE: hipLaunchKernelGGL(scan_kernel<ISDF_SHAPE_ROUNDEDCONE>, dim3(blocks), dim3(TS_THREADS), 0, stream, P); break;
-    default: hipLaunchKernelGGL(scan_kernel<-1>, dim3(blocks), dim3(TS_THREADS), 0, stream, P); break;
-    }
-}
-
-void launch_exact(const SweepParams &P, hipStream_t stream) {
-    const long long n_samples = (long long)(P.piece_end - P.piece_begin) * (P.K + 1);
-    if (n_samples <= 0 || !P.enable_pos) return;
-    const dim3 grid(POOL_SHARDS, EX_BLOCKS_PER_SHARD);
-    switch (P.shape.kind) {
-    case ISDF_SHAPE_BOX: hipLaunchKernelGGL(exact_kernel<ISDF_SHAPE_BOX>, grid, dim3(64 * EX_WAVES), 0, stream, P); break;
-    case ISDF_SHAPE_ROUNDEDCONE: hipLaunchKernelGGL(exact_kernel<ISDF_SHAPE_ROUNDEDCONE>, grid, dim3(64 * EX_WAVES), 0, stream, P); break;
-    default: hipLaunchKernelGGL(exact_kernel<-1>, grid, dim3(64 * EX_WAVES), 0, stream, P); break;
+    case ISDF_SHAPE_BOX: hipLaunchKernelGGL(sweep_kernel<ISDF_SHAPE_BOX>, dim3(blocks), dim3(64 * SW_SAMPLES), 0, stream, P); break;
+    case ISDF_SHAPE_ROUNDEDCONE: hipLaunchKernelGGL(sweep_kernel<ISDF_SHAPE_ROUNDEDCONE>, dim3(blocks), dim3(64 * SW_SAMPLES), 0, stream, P); break;
+    default: hipLaunchKernelGGL(sweep_kernel<-1>, dim3(blocks), dim3(64 * SW_SAMPLES), 0, stream, P); break;
     }
 }
 
