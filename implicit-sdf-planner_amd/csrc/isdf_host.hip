@@ -500,6 +500,8 @@ static int eval_device_impl(isdf_ctx *c, int n_traj, int N, const double *d_T, c
     P.T = d_T; P.coeffs = d_coeffs; P.acc = c->d_acc; P.sample_info = c->d_sample_info; P.piece_cost = c->d_piece_cost;
     P.out = d_out; P.stats = c->d_stats;
     P.dbg = nullptr;
+    P.dbg_flags = 0;
+    if (const char *e = getenv("ISDF_DEBUG_FLAGS")) P.dbg_flags = atoi(e);
     if (const char *e = getenv("ISDF_DEBUG_TIMING")) if (e[0] == '1') {
         const size_t need = n_samples * 8 + (size_t)total_pieces * 4 + 4;
         if (c->dbg_cap < need) {

@@ -37,6 +37,7 @@ struct SweepParams {
     double *piece_cost;         // [n_traj * N]
     double *out;                // n_traj * (1 + N + 18N)
     unsigned long long *stats;  // [0]=units [1]=culled [2]=pairs [3]=grad pairs [4]=overflow
+    int dbg_flags;              // developer switches (ISDF_DEBUG_FLAGS): 1 = skip the exact pass body
     unsigned long long *dbg;    // developer timing buffer (ISDF_DEBUG_TIMING=1), null on the product path
 };
 

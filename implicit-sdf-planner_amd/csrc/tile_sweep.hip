@@ -30,7 +30,7 @@ namespace isdf {
 
 constexpr int SW_LIST_CAP = 1024;                         // ring of compacted voxels (one pass adds <= 64 * SW_PASS)
 constexpr int SW_PASS = 8;                                // voxels one lane contributes to the ring per pass
-constexpr int SW_NEAR_CAP = 128;                          // per-wave candidate ring (64 leave for the exact pass when full)
+constexpr int SW_NEAR_CAP = 512;                          // per-sample candidate ring (drained by the whole workgroup)
 constexpr float TS_FILTER_EPS = 2e-3f;                    // slack (m) of the fp32 pre-filter, >> its rounding error
 
 __device__ __forceinline__ void wave_lds_sync() {
@@ -143,20 +143,24 @@ __global__ __launch_bounds__(64 * SW_SAMPLES, 3) void sweep_kernel(const SweepPa
     __shared__ SweepPose s_pose[SW_SAMPLES];
     __shared__ unsigned s_list[SW_SAMPLES][SW_LIST_CAP];          // ring of compacted voxels awaiting the fp32 test
     __shared__ unsigned s_near[SW_SAMPLES][SW_NEAR_CAP];          // ring of candidates awaiting the exact pass
+    __shared__ int s_plan[SW_SAMPLES][4];                         // per sample: candidates, ring head, finished
+    __shared__ double s_res[SW_SAMPLES][SW_NEAR_CAP / 64][ACC_STRIDE];   // per chunk: the 8 collision sums
+    __shared__ int s_resn[SW_SAMPLES][SW_NEAR_CAP / 64][2];       // per chunk: exact pairs, active pairs
 
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int K1 = P.K + 1;
     const long long s_begin = (long long)P.piece_begin * K1, s_end = (long long)P.piece_end * K1;
-    const long long sidx0 = s_begin + (long long)blockIdx.x * SW_SAMPLES;
     const DevGrid &G = P.grid;
-    const long long sidx = sidx0 + wave;
+    // wave w of workgroup b takes sample b + w * gridDim.x: the samples of one workgroup are far apart on the
+    // trajectory, so their candidate counts are uncorrelated and the workgroup's exact work evens out
+    const long long sidx = s_begin + (long long)blockIdx.x + (long long)wave * gridDim.x;
     unsigned long long *const dbg = (P.dbg && sidx < s_end) ? P.dbg + (size_t)(sidx - s_begin) * 8 : nullptr;
     if (dbg && lane == 0) { dbg[0] = wall_clock64(); dbg[1] = clock64(); }
 
     // ---- poses of the workgroup's samples: one LANE per sample (the serial fp64 chain is issued once, not per wave)
-    if (wave == 0 && lane < SW_SAMPLES && sidx0 + lane < s_end) {
-        const SampleId id = decode_sample(P, sidx0 + lane);
+    if (wave == 0 && lane < SW_SAMPLES && s_begin + (long long)blockIdx.x + (long long)lane * gridDim.x < s_end) {
+        const SampleId id = decode_sample(P, s_begin + (long long)blockIdx.x + (long long)lane * gridDim.x);
         const double *c = P.coeffs + (size_t)id.b * 18 * P.N + 6 * id.i;
         const int ld = 6 * P.N;
         const double step = P.T[(size_t)id.b * P.N + id.i] * (1.0 / P.K);
@@ -223,149 +227,112 @@ __global__ __launch_bounds__(64 * SW_SAMPLES, 3) void sweep_kernel(const SweepPa
         sp.flags = flags;
     }
     __syncthreads();
-    if (sidx >= s_end) return;                                 // no workgroup barriers below
     if (dbg && lane == 0) dbg[2] = clock64();
 
+    const bool have_sample = sidx < s_end;
     const SweepPose &sp = s_pose[wave];
-    const int flags = __builtin_amdgcn_readfirstlane(sp.flags);
-    const bool active = (flags & 1) != 0;
-    double a0 = 0, a1 = 0, a2 = 0, a3 = 0, a4 = 0, a5 = 0, a6 = 0, a7 = 0;   // per-lane partial sums of the exact pass
-    int n_pairs = 0, n_grads = 0, n_rounds = 0;
-    const int rnx = __builtin_amdgcn_readfirstlane(sp.rnx), rny = __builtin_amdgcn_readfirstlane(sp.rny);
-    const int n_rows = rnx * rny;
-    if (active && n_rows > 0) {
-        const d3 pos = mk3(uni(sp.pos[0]), uni(sp.pos[1]), uni(sp.pos[2]));
-        m3 R;
+    const int flags = have_sample ? __builtin_amdgcn_readfirstlane(sp.flags) : 0;
+    const int rnx = have_sample ? __builtin_amdgcn_readfirstlane(sp.rnx) : 0, rny = have_sample ? __builtin_amdgcn_readfirstlane(sp.rny) : 0;
+    const int n_rows = (flags & 1) ? rnx * rny : 0;
+    const bool scanning = n_rows > 0;
+
+    // ---- own sample: scan-stage constants (fp32, wave-uniform)
+    const int lox = __builtin_amdgcn_readfirstlane(sp.lo[0]), loy = __builtin_amdgcn_readfirstlane(sp.lo[1]),
+              loz = __builtin_amdgcn_readfirstlane(sp.lo[2]), nzt = __builtin_amdgcn_readfirstlane(sp.nzt);
+    const int rx0 = __builtin_amdgcn_readfirstlane(sp.rx0), ry0 = __builtin_amdgcn_readfirstlane(sp.ry0);
+    const float inv_rny = 1.0f / (float)max(rny, 1);
+    const bool small = n_rows < (1 << 24);
+    const bool use_filter = P.shape.filter_f32 != 0;
+    float Rf[9];
 #pragma unroll
-        for (int k = 0; k < 9; k++) R.a[k] = uni(sp.R[k]);
-        d4 quat; quat.w = uni(sp.quat[0]); quat.x = uni(sp.quat[1]); quat.y = uni(sp.quat[2]); quat.z = uni(sp.quat[3]);
-        const int lox = __builtin_amdgcn_readfirstlane(sp.lo[0]), loy = __builtin_amdgcn_readfirstlane(sp.lo[1]),
-                  loz = __builtin_amdgcn_readfirstlane(sp.lo[2]), nzt = __builtin_amdgcn_readfirstlane(sp.nzt);
-        const int rx0 = __builtin_amdgcn_readfirstlane(sp.rx0), ry0 = __builtin_amdgcn_readfirstlane(sp.ry0);
-        const float inv_rny = 1.0f / (float)rny;
-        const bool small = n_rows < (1 << 24);
+    for (int k = 0; k < 9; k++) Rf[k] = unif((float)sp.R[k]);
+    const float resf = (float)G.res;
+    const float bdh_f = (float)P.bd_half + TS_FILTER_EPS;
+    const float thr_f = (float)P.safety_hor + TS_FILTER_EPS;
+    // pose in the tile's voxel frame, pre-multiplied: m = l*res - pvr,  pvr = ((pos - bmin)/res - 0.5 - lo)*res
+    const float pvx = unif((float)(((sp.pos[0] - G.bmin[0]) / G.res - 0.5 - lox) * G.res));
+    const float pvy = unif((float)(((sp.pos[1] - G.bmin[1]) / G.res - 0.5 - loy) * G.res));
+    const float pvz = unif((float)(((sp.pos[2] - G.bmin[2]) / G.res - 0.5 - loz) * G.res));
 
-        // fp32 pre-filter constants (wave-uniform)
-        const bool use_filter = P.shape.filter_f32 != 0;
-        float Rf[9];
+    // (lx, ly) of window row t, packed lx | ly << 10
+    auto row_xy = [&](int t) -> unsigned {
+        unsigned wx, wy;
+        if (small) {
+            wx = (unsigned)((float)t * inv_rny);
+            int rem = t - (int)wx * rny;
+            if (rem < 0) { wx--; rem += rny; } else if (rem >= rny) { wx++; rem -= rny; }
+            wy = (unsigned)rem;
+        } else { wx = (unsigned)(t / rny); wy = (unsigned)(t - (int)wx * rny); }
+        return (wx + (unsigned)rx0) | ((wy + (unsigned)ry0) << 10);
+    };
+    // the <= 32 qualifier bits of z-block zb of tile row pk: 1-2 dwords of the bit-grid
+    auto row_bits = [&](unsigned pk, int zb) -> unsigned {
+        const int z0 = loz + (zb << 5);
+        const int nz = min(32, nzt - (zb << 5));
+        const size_t rowbase = ((size_t)(lox + (int)(pk & 1023u)) * G.Y + (loy + (int)(pk >> 10))) * G.ZW;
+        const int w0 = z0 >> 5, sh = z0 & 31;
+        const unsigned b0 = G.bits[rowbase + w0];
+        const unsigned b1 = G.bits[rowbase + min(w0 + 1, G.ZW - 1)];
+        unsigned bits = sh ? ((b0 >> sh) | (b1 << (32 - sh))) : b0;     // when w0+1 == ZW the b1 bits are masked off below
+        if (nz < 32) bits &= (1u << nz) - 1u;
+        return bits;
+    };
+    // Row pruning: in the body frame the voxels of one z-row lie on the line o + lz*dz.  Only the part of the line
+    // inside (shape bounding box inflated by safety_hor) ∩ (the |p_rel| <= bd/2 cube) can carry a penalty
+    // (isdf_shape.bbox_* guarantee), so the rest of the row never enters the list.  Conservative by construction.
+    const bool prune = P.shape.prune_rows != 0;
+    float blo[3], bhi[3], dzv[3], dzi[3];
 #pragma unroll
-        for (int k = 0; k < 9; k++) Rf[k] = (float)R.a[k];
-        const float resf = (float)G.res;
-        const float bdh_f = (float)P.bd_half + TS_FILTER_EPS;
-        const float thr_f = (float)P.safety_hor + TS_FILTER_EPS;
-        // pose in the tile's voxel frame, pre-multiplied: m = l*res - pvr,  pvr = ((pos - bmin)/res - 0.5 - lo)*res
-        const float pvx = unif((float)(((pos.x - G.bmin[0]) / G.res - 0.5 - lox) * G.res));
-        const float pvy = unif((float)(((pos.y - G.bmin[1]) / G.res - 0.5 - loy) * G.res));
-        const float pvz = unif((float)(((pos.z - G.bmin[2]) / G.res - 0.5 - loz) * G.res));
-
-        // (lx, ly) of window row t, packed lx | ly << 10
-        auto row_xy = [&](int t) -> unsigned {
-            unsigned wx, wy;
-            if (small) {
-                wx = (unsigned)((float)t * inv_rny);
-                int rem = t - (int)wx * rny;
-                if (rem < 0) { wx--; rem += rny; } else if (rem >= rny) { wx++; rem -= rny; }
-                wy = (unsigned)rem;
-            } else { wx = (unsigned)(t / rny); wy = (unsigned)(t - (int)wx * rny); }
-            return (wx + (unsigned)rx0) | ((wy + (unsigned)ry0) << 10);
-        };
-        // the <= 32 qualifier bits of z-block zb of tile row pk: 1-2 dwords of the bit-grid
-        auto row_bits = [&](unsigned pk, int zb) -> unsigned {
-            const int z0 = loz + (zb << 5);
-            const int nz = min(32, nzt - (zb << 5));
-            const size_t rowbase = ((size_t)(lox + (int)(pk & 1023u)) * G.Y + (loy + (int)(pk >> 10))) * G.ZW;
-            const int w0 = z0 >> 5, sh = z0 & 31;
-            const unsigned b0 = G.bits[rowbase + w0];
-            const unsigned b1 = G.bits[rowbase + min(w0 + 1, G.ZW - 1)];
-            unsigned bits = sh ? ((b0 >> sh) | (b1 << (32 - sh))) : b0;     // when w0+1 == ZW the b1 bits are masked off below
-            if (nz < 32) bits &= (1u << nz) - 1u;
-            return bits;
-        };
-
-        // Row pruning: in the body frame the voxels of one z-row lie on the line o + lz*dz.  Only the part of the line
-        // inside (shape bounding box inflated by safety_hor) ∩ (the |p_rel| <= bd/2 cube) can carry a penalty
-        // (isdf_shape.bbox_* guarantee), so the rest of the row never enters the list.  Conservative by construction.
-        const bool prune = P.shape.prune_rows != 0;
-        float blo[3], bhi[3], dzv[3], dzi[3];
+    for (int a = 0; a < 3; a++) {
+        blo[a] = fmaxf(P.shape.bbox_lo[a] - thr_f, -bdh_f);
+        bhi[a] = fminf(P.shape.bbox_hi[a] + thr_f, bdh_f);
+        dzv[a] = Rf[6 + a] * resf;
+        dzi[a] = 1.0f / dzv[a];
+    }
+    auto row_mask = [&](unsigned pk, int zb) -> unsigned {
+        const float mx = fmaf((float)(pk & 1023u), resf, -pvx), my = fmaf((float)(pk >> 10), resf, -pvy);
+        float tmin = -1.0e30f, tmax = 1.0e30f;
+        bool empty = false;
 #pragma unroll
         for (int a = 0; a < 3; a++) {
-            blo[a] = fmaxf(P.shape.bbox_lo[a] - thr_f, -bdh_f);
-            bhi[a] = fminf(P.shape.bbox_hi[a] + thr_f, bdh_f);
-            dzv[a] = Rf[6 + a] * resf;
-            dzi[a] = 1.0f / dzv[a];
-        }
-        auto row_mask = [&](unsigned pk, int zb) -> unsigned {
-            const float mx = fmaf((float)(pk & 1023u), resf, -pvx), my = fmaf((float)(pk >> 10), resf, -pvy);
-            float tmin = -1.0e30f, tmax = 1.0e30f;
-            bool empty = false;
-#pragma unroll
-            for (int a = 0; a < 3; a++) {
-                const float o = Rf[a] * mx + Rf[3 + a] * my - Rf[6 + a] * pvz;
-                if (fabsf(dzv[a]) > 1.0e-12f) {
-                    const float t1 = (blo[a] - o) * dzi[a], t2 = (bhi[a] - o) * dzi[a];
-                    tmin = fmaxf(tmin, fminf(t1, t2));      // fmaxf/fminf drop NaNs: never tightens on garbage
-                    tmax = fminf(tmax, fmaxf(t1, t2));
-                } else {
-                    empty = empty | (o < blo[a] - 1.0e-3f) | (o > bhi[a] + 1.0e-3f);
-                }
+            const float o = Rf[a] * mx + Rf[3 + a] * my - Rf[6 + a] * pvz;
+            if (fabsf(dzv[a]) > 1.0e-12f) {
+                const float t1 = (blo[a] - o) * dzi[a], t2 = (bhi[a] - o) * dzi[a];
+                tmin = fmaxf(tmin, fminf(t1, t2));      // fmaxf/fminf drop NaNs: never tightens on garbage
+                tmax = fminf(tmax, fmaxf(t1, t2));
+            } else {
+                empty = empty | (o < blo[a] - 1.0e-3f) | (o > bhi[a] + 1.0e-3f);
             }
-            const float off = (float)(zb << 5);
-            const float flo = fminf(fmaxf(ceilf(tmin - 0.02f) - off, 0.0f), 32.0f);
-            const float fhi = fminf(fmaxf(floorf(tmax + 0.02f) - off, -1.0f), 31.0f);
-            const int zlo = (int)flo, zhi = (int)fhi;
-            if (empty || zlo > zhi) return 0u;
-            const int n = zhi - zlo + 1;
-            return (n >= 32) ? 0xFFFFFFFFu : (((1u << n) - 1u) << zlo);
-        };
+        }
+        const float off = (float)(zb << 5);
+        const float flo = fminf(fmaxf(ceilf(tmin - 0.02f) - off, 0.0f), 32.0f);
+        const float fhi = fminf(fmaxf(floorf(tmax + 0.02f) - off, -1.0f), 31.0f);
+        const int zlo = (int)flo, zhi = (int)fhi;
+        if (empty || zlo > zhi) return 0u;
+        const int n = zhi - zlo + 1;
+        return (n >= 32) ? 0xFFFFFFFFu : (((1u << n) - 1u) << zlo);
+    };
 
-        // One loop, three stages, each with a single code instance; the most downstream stage that has a full
-        // wavefront of work (or the last of it) runs next:
-        //   produce: rows -> s_list (ring of compacted voxels)       scan: s_list -> s_near (fp32 survivors)
-        //   exact  : s_near -> per-lane fp64 sums
-        const int n_zb = (nzt + 31) >> 5;            // 32-voxel blocks along z (1 for kernel_size <= 31)
-        int near_head = 0, near_cnt = 0;             // ring of candidates awaiting the exact pass
-        int pend_head = 0, pend = 0;                 // ring of compacted voxels awaiting the fp32 test
-        int fzb = 0, ft = 0;                         // fetch cursor: z-block and first window row of the next round
-        bool rows_left = true;
-        unsigned hb = 0, pk = 0, zoff = 0;           // this lane's row: pending qualifier bits, packed (lx, ly), z offset
-        unsigned nbits = 0, nmask = 0, npk = 0, nzoff = 0;   // the NEXT round's row, requested one round ahead
-        int rounds_left = n_zb * ((n_rows + 63) >> 6);
-        bool primed = false;
-        for (;;) {
-            if (near_cnt >= 64 || (!rows_left && pend == 0 && near_cnt > 0)) {
-                // ---- (4) exact fp64 pass over the oldest n (<= 64) candidates: grad_cost_p (:766-824)
-                const int n = min(near_cnt, 64);
-                wave_lds_sync();
-                const unsigned ent = s_near[wave][(near_head + min(lane, n - 1)) & (SW_NEAR_CAP - 1)];
-                bool is_pair = false, is_grad = false;
-                if (lane < n) {
-                    const int gx = lox + (int)(ent & 1023u), gy = loy + (int)((ent >> 10) & 1023u), gz = loz + (int)(ent >> 20);
-                    const d3 ctr = mk3((gx + 0.5) * G.res + G.bmin[0], (gy + 0.5) * G.res + G.bmin[1], (gz + 0.5) * G.res + G.bmin[2]);
-                    const d3 pm = ctr - pos;
-                    const d3 prel = mat_tmul(R, pm);
-                    if (!(fabs(prel.x) > P.bd_half || fabs(prel.y) > P.bd_half || fabs(prel.z) > P.bd_half)) {
-                        const double sdf = shape_sdf<KIND>(P.shape, prel);
-                        is_pair = true;
-                        double f = 0.0, df = 0.0;
-                        smoothed_l1(P.safety_hor - sdf, P.mu, f, df);
-                        if (f > 0.0) {
-                            const d3 g = shape_grad<KIND>(P.shape, prel);
-                            is_grad = true;
-                            a0 += f;
-                            const d3 wg = mat_mul(R, g);
-                            a1 += df * wg.x; a2 += df * wg.y; a3 += df * wg.z;
-                            const d4 sq = quat_step_grad(quat, g, pm);
-                            a4 += -df * sq.w; a5 += -df * sq.x; a6 += -df * sq.y; a7 += -df * sq.z;
-                        }
-                    }
-                }
-                n_pairs += __popcll(__ballot(is_pair));
-                n_grads += __popcll(__ballot(is_grad));
-                n_rounds++;
-                near_head = (near_head + n) & (SW_NEAR_CAP - 1);
-                near_cnt -= n;
-                wave_lds_sync();
-            } else if (pend >= 64 || (!rows_left && pend > 0)) {
+    // scan state of this wave's sample
+    const int n_zb = (nzt + 31) >> 5;            // 32-voxel blocks along z (1 for kernel_size <= 31)
+    int near_head = 0, near_cnt = 0;             // ring of candidates awaiting the exact pass
+    int pend_head = 0, pend = 0;                 // ring of compacted voxels awaiting the fp32 test
+    int fzb = 0, ft = 0;                         // fetch cursor: z-block and first window row of the next round
+    bool rows_left = scanning;
+    unsigned hb = 0, pk = 0, zoff = 0;           // this lane's row: pending qualifier bits, packed (lx, ly), z offset
+    unsigned nbits = 0, nmask = 0, npk = 0, nzoff = 0;   // the NEXT round's row, requested one round ahead
+    int rounds_left = scanning ? n_zb * ((n_rows + 63) >> 6) : 0;
+    bool primed = false;
+    double tot = 0.0;                            // wave `s`, lane k < 8: component k of sample s's collision sums
+    int tot_n = 0;                               // lanes 8 / 9: exact pairs / active pairs
+    int n_rounds = 0;
+
+    for (;;) {
+        // ================= scan phase: produce -> fp32 filter -> candidate ring, until done or the ring is full
+        bool finished = !rows_left && pend == 0;
+        while (!finished) {
+            if (pend >= 64 || (!rows_left && pend > 0)) {
+                if (near_cnt > SW_NEAR_CAP - 64) break;            // ring full: the workgroup drains it first
                 // ---- (3) conservative fp32 test of the oldest min(pend, 64) listed voxels (branch-free body)
                 const int n = min(pend, 64);
                 const unsigned ent = s_list[wave][(pend_head + min(lane, n - 1)) & (SW_LIST_CAP - 1)];
@@ -384,14 +351,12 @@ __global__ __launch_bounds__(64 * SW_SAMPLES, 3) void sweep_kernel(const SweepPa
                 const unsigned long long nm = __ballot(cand);
                 if (cand) s_near[wave][(near_head + near_cnt + __popcll(nm & ((1ull << lane) - 1ull))) & (SW_NEAR_CAP - 1)] = ent;
                 near_cnt += __popcll(nm);
-            } else if (rows_left) {
-                if (!__ballot(hb != 0u)) {
-                    // ---- (2a) take the round requested earlier, request the one after it
-                    if (primed && rounds_left == 0) {
-                        rows_left = false;
-                        if (dbg && lane == 0) dbg[4] = clock64();
-                        continue;
-                    }
+            } else if (!__ballot(hb != 0u)) {
+                // ---- (2a) take the round requested earlier, request the one after it
+                if (primed && rounds_left == 0) {
+                    rows_left = false;
+                    if (dbg && lane == 0) dbg[4] = clock64();
+                } else {
                     if (primed) {
                         rounds_left--;
                         hb = nbits & nmask;          // waits for the loads requested one round ago
@@ -411,39 +376,143 @@ __global__ __launch_bounds__(64 * SW_SAMPLES, 3) void sweep_kernel(const SweepPa
                         ft += 64;
                         if (ft >= n_rows) { ft = 0; fzb++; }
                     }
-                } else {
-                    // ---- (2b) one pass: every lane moves its lowest <= SW_PASS set bits into the ring
-                    unsigned take = hb;
-                    if (__ballot(__popc(hb) > SW_PASS)) {
-                        unsigned t = hb;
-#pragma unroll
-                        for (int k = 0; k < SW_PASS; k++) t &= t - 1u;
-                        take = hb ^ t;
-                    }
-                    hb ^= take;
-                    int total;
-                    int wpos = wave_excl_scan(__popc(take), lane, total) + pend_head + pend;
-                    while (take) {
-                        const unsigned z = (unsigned)__ffs(take) - 1u;
-                        take &= take - 1u;
-                        s_list[wave][(wpos++) & (SW_LIST_CAP - 1)] = pk | ((zoff + z) << 20);
-                    }
-                    pend += total;
-                    wave_lds_sync();
                 }
-            } else break;
+            } else {
+                // ---- (2b) one pass: every lane moves its lowest <= SW_PASS set bits into the ring
+                unsigned take = hb;
+                if (__ballot(__popc(hb) > SW_PASS)) {
+                    unsigned t = hb;
+#pragma unroll
+                    for (int k = 0; k < SW_PASS; k++) t &= t - 1u;
+                    take = hb ^ t;
+                }
+                hb ^= take;
+                int total;
+                int wpos = wave_excl_scan(__popc(take), lane, total) + pend_head + pend;
+                while (take) {
+                    const unsigned z = (unsigned)__ffs(take) - 1u;
+                    take &= take - 1u;
+                    s_list[wave][(wpos++) & (SW_LIST_CAP - 1)] = pk | ((zoff + z) << 20);
+                }
+                pend += total;
+                wave_lds_sync();
+            }
+            finished = !rows_left && pend == 0;
         }
+        if (lane == 0) { s_plan[wave][0] = near_cnt; s_plan[wave][1] = near_head; s_plan[wave][2] = finished ? 1 : 0; }
+        __syncthreads();
+
+        // ================= exact phase: the workgroup's candidate chunks (64 voxels of one sample), spread evenly
+        // over its waves.  Plan (identical in every wave): each wave keeps up to `quota` chunks of its own sample,
+        // the rest go to the waves with spare room, in sample order.
+        int cnt[SW_SAMPLES], head[SW_SAMPLES], nch[SW_SAMPLES], own[SW_SAMPLES];
+        int C = 0, all_done = 1;
+#pragma unroll
+        for (int w = 0; w < SW_SAMPLES; w++) {
+            cnt[w] = __builtin_amdgcn_readfirstlane(s_plan[w][0]);
+            head[w] = __builtin_amdgcn_readfirstlane(s_plan[w][1]);
+            all_done &= __builtin_amdgcn_readfirstlane(s_plan[w][2]);
+            nch[w] = (cnt[w] + 63) >> 6;
+            C += nch[w];
+        }
+        const int quota = (C + SW_SAMPLES - 1) / SW_SAMPLES;
+        int my_off = 0, my_spare = 0, my_own = 0;      // this wave: first leftover index it takes, how many, own chunks
+        {
+            int off = 0;
+#pragma unroll
+            for (int w = 0; w < SW_SAMPLES; w++) {
+                own[w] = min(nch[w], quota);
+                const int spare = quota - own[w];
+                if (w == wave) { my_off = off; my_spare = spare; my_own = own[w]; }
+                off += spare;
+            }
+        }
+        int cur_s = -1;
+        d3 pos = mk3(0, 0, 0); m3 R; d4 quat; int clx = 0, cly = 0, clz = 0;
+#pragma unroll
+        for (int k = 0; k < 9; k++) R.a[k] = 0.0;
+        quat.w = quat.x = quat.y = quat.z = 0.0;
+        for (int it = 0; it < my_own + my_spare; it++) {
+            // (sample, chunk) of this wave's it-th work item
+            int cs = wave, cc = it;
+            if (it >= my_own) {
+                int e = my_off + (it - my_own);
+                cs = -1;
+#pragma unroll
+                for (int w = 0; w < SW_SAMPLES; w++) {
+                    const int left = nch[w] - own[w];
+                    if (cs < 0) { if (e < left) { cs = w; cc = own[w] + e; } else e -= left; }
+                }
+                if (cs < 0) break;                     // no leftover chunk for this slot
+            }
+            if (cs != cur_s) {                         // pose of the chunk's sample -> scalar registers
+                const SweepPose &q = s_pose[cs];
+                pos = mk3(uni(q.pos[0]), uni(q.pos[1]), uni(q.pos[2]));
+#pragma unroll
+                for (int k = 0; k < 9; k++) R.a[k] = uni(q.R[k]);
+                quat.w = uni(q.quat[0]); quat.x = uni(q.quat[1]); quat.y = uni(q.quat[2]); quat.z = uni(q.quat[3]);
+                clx = __builtin_amdgcn_readfirstlane(q.lo[0]); cly = __builtin_amdgcn_readfirstlane(q.lo[1]);
+                clz = __builtin_amdgcn_readfirstlane(q.lo[2]);
+                cur_s = cs;
+            }
+            // ---- (4) exact fp64 pass over one chunk: grad_cost_p (:766-824)
+            int ccnt = 0, chead = 0;
+#pragma unroll
+            for (int w = 0; w < SW_SAMPLES; w++) if (w == cs) { ccnt = cnt[w]; chead = head[w]; }
+            const int n = min(64, ccnt - (cc << 6));
+            const unsigned ent = s_near[cs][(chead + (cc << 6) + min(lane, n - 1)) & (SW_NEAR_CAP - 1)];
+            double v[ACC_STRIDE] = {0, 0, 0, 0, 0, 0, 0, 0};
+            bool is_pair = false, is_grad = false;
+            if (lane < n && !(P.dbg_flags & 1)) {
+                const int gx = clx + (int)(ent & 1023u), gy = cly + (int)((ent >> 10) & 1023u), gz = clz + (int)(ent >> 20);
+                const d3 ctr = mk3((gx + 0.5) * G.res + G.bmin[0], (gy + 0.5) * G.res + G.bmin[1], (gz + 0.5) * G.res + G.bmin[2]);
+                const d3 pm = ctr - pos;
+                const d3 prel = mat_tmul(R, pm);
+                if (!(fabs(prel.x) > P.bd_half || fabs(prel.y) > P.bd_half || fabs(prel.z) > P.bd_half)) {
+                    const double sdf = shape_sdf<KIND>(P.shape, prel);
+                    is_pair = true;
+                    double f = 0.0, df = 0.0;
+                    smoothed_l1(P.safety_hor - sdf, P.mu, f, df);
+                    if (f > 0.0) {
+                        const d3 g = shape_grad<KIND>(P.shape, prel);
+                        is_grad = true;
+                        v[0] = f;
+                        const d3 wg = mat_mul(R, g);
+                        v[1] = df * wg.x; v[2] = df * wg.y; v[3] = df * wg.z;
+                        const d4 sq = quat_step_grad(quat, g, pm);
+                        v[4] = -df * sq.w; v[5] = -df * sq.x; v[6] = -df * sq.y; v[7] = -df * sq.z;
+                    }
+                }
+            }
+            wave_sum8(v, lane);                        // component k -> lane wave_sum8_lane(k)
+            const int np = __popcll(__ballot(is_pair)), ng = __popcll(__ballot(is_grad));
+            if ((lane & 7) == 0) s_res[cs][cc][((lane >> 3) & 1) | (((lane >> 4) & 1) << 1) | ((lane >> 5) << 2)] = v[0];
+            if (lane == 0) { s_resn[cs][cc][0] = np; s_resn[cs][cc][1] = ng; }
+            n_rounds++;
+        }
+        __syncthreads();
+        // chunk results of this wave's sample, in chunk order
+        {
+            int my_nch = 0;
+#pragma unroll
+            for (int w = 0; w < SW_SAMPLES; w++) if (w == wave) my_nch = nch[w];
+            for (int cidx = 0; cidx < my_nch; cidx++) {
+                if (lane < ACC_STRIDE) tot += s_res[wave][cidx][lane];
+                else if (lane < ACC_STRIDE + 2) tot_n += s_resn[wave][cidx][lane - ACC_STRIDE];
+            }
+        }
+        near_head = (near_head + near_cnt) & (SW_NEAR_CAP - 1);
+        near_cnt = 0;
+        if (all_done) break;
+        __syncthreads();        // s_plan / s_res are rewritten by the next round
     }
 
-    // ---- (5) lanes -> wave, fixed order
-    a0 = wave_sum(a0); a1 = wave_sum(a1); a2 = wave_sum(a2); a3 = wave_sum(a3);
-    a4 = wave_sum(a4); a5 = wave_sum(a5); a6 = wave_sum(a6); a7 = wave_sum(a7);
-    const long long sl = sidx - s_begin;
-    if (lane == 0) {
-        double *o = P.acc + (size_t)sl * ACC_STRIDE;
-        o[0] = a0; o[1] = a1; o[2] = a2; o[3] = a3; o[4] = a4; o[5] = a5; o[6] = a6; o[7] = a7;
-        P.sample_info[2 * sl] = n_pairs;
-        P.sample_info[2 * sl + 1] = n_grads | ((flags & 2) ? (int)0x80000000 : 0);
+    // ---- (5) results of this wave's sample
+    if (have_sample) {
+        const long long sl = sidx - s_begin;
+        if (lane < ACC_STRIDE) P.acc[(size_t)sl * ACC_STRIDE + lane] = tot;
+        else if (lane == ACC_STRIDE) P.sample_info[2 * sl] = tot_n;
+        else if (lane == ACC_STRIDE + 1) P.sample_info[2 * sl + 1] = tot_n | ((flags & 2) ? (int)0x80000000 : 0);
     }
     if (dbg && lane == 0) { dbg[5] = clock64(); dbg[6] = wall_clock64(); dbg[7] = (unsigned long long)n_rounds; }
 }
