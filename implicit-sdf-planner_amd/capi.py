@@ -55,6 +55,8 @@ EXPORTED_SYMBOLS = [
     "isdf_last_error", "isdf_abi_version", "isdf_set_grid", "isdf_set_shape", "isdf_set_points",
     "isdf_set_shard", "isdf_eval", "isdf_eval_device", "isdf_out_stride", "isdf_profile_enable",
     "isdf_profile_read", "isdf_profile_read_secondary", "isdf_get_stats",
+    "isdf_set_trajectory", "isdf_num_variables", "isdf_pack_variables", "isdf_unpack_variables",
+    "isdf_cost_function", "isdf_cost_function_lmbm", "isdf_cost_parts",
 ]
 
 _lib = None
@@ -92,6 +94,14 @@ def load_library(path=None):
     lib.isdf_profile_read.argtypes = [C.c_void_p, C.POINTER(C.c_int), dp]
     lib.isdf_profile_read_secondary.argtypes = [C.c_void_p, dp]
     lib.isdf_get_stats.argtypes = [C.c_void_p, C.POINTER(IsdfStats)]
+    lib.isdf_set_trajectory.argtypes = [C.c_void_p, C.c_int, dp, dp, C.c_double]
+    lib.isdf_num_variables.argtypes = [C.c_void_p]
+    lib.isdf_pack_variables.argtypes = [C.c_void_p, dp, dp, dp]
+    lib.isdf_unpack_variables.argtypes = [C.c_void_p, dp, dp, dp]
+    lib.isdf_cost_function.argtypes = [C.c_void_p, dp, dp, C.c_int, dp]
+    lib.isdf_cost_function_lmbm.argtypes = [C.c_void_p, dp, dp, C.c_int]
+    lib.isdf_cost_function_lmbm.restype = C.c_double
+    lib.isdf_cost_parts.argtypes = [C.c_void_p, dp]
     if path is None:
         _lib = lib
     return lib

@@ -3,6 +3,7 @@
 // (back_end_optimizer.hpp:59-62 parallel_points/lastTstar, :667-725 setParam/setEnvironment/setGridMap) and the
 // shape registry lookup of sw_manager.hpp:74-123,:255-275.  No CPU compute path exists here.
 #include "isdf_internal.hpp"
+#include "minco_host.hpp"
 #include <cmath>
 #include <cstdio>
 #include <cstring>
@@ -65,6 +66,12 @@ struct isdf_ctx {
     size_t prof_used = 0;
     hipStream_t stream = nullptr;   // stream of the host API
     unsigned long long *d_dbg = nullptr; size_t dbg_cap = 0; size_t dbg_used = 0;   // ISDF_DEBUG_TIMING=1 (developer tool)
+    // full objective callback (costFunctionLmbm): MINCO on the host, sweeps on the device
+    isdf_host::MincoS3 minco; bool have_traj = false; double rho = 0.0;
+    std::vector<double> cb_T, cb_gdC, cb_gdT, cb_gradP, cb_gradT;
+    double *h_pin = nullptr; size_t pin_cap = 0;      // pinned staging: [T | coeffs | out_a | out_b]
+    double *d_cb = nullptr; size_t cb_cap = 0;        // device twin of the staging buffer
+    double last_parts[4] = {0, 0, 0, 0};
 };
 
 #define HIPCHK(ctx, call)                                                                          \
@@ -206,7 +213,8 @@ extern "C" int isdf_destroy(isdf_ctx *c) {
     (void)hipSetDevice(c->device);
     (void)hipDeviceSynchronize();
     for (auto &p : c->prof_events) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); (void)hipEventDestroy(p.c); }
-    void *ptrs[] = {c->d_esdf, c->d_occ, c->d_points, c->d_tstar, c->d_acc, c->d_sample_info, c->d_bits, c->d_piece_cost, c->d_in, c->d_out, c->d_stats,
+    if (c->h_pin) (void)hipHostFree(c->h_pin);
+    void *ptrs[] = {c->d_cb, c->d_esdf, c->d_occ, c->d_points, c->d_tstar, c->d_acc, c->d_sample_info, c->d_bits, c->d_piece_cost, c->d_in, c->d_out, c->d_stats,
                     c->d_traj_duration, c->d_coarse_t, c->d_coarse_pose, c->d_n_coarse, c->d_point_partial, c->d_point_piece, c->d_hist, c->d_dbg};
     for (void *p : ptrs) if (p) (void)hipFree(p);
     free_mesh(c);
@@ -406,9 +414,13 @@ static int prof_begin(isdf_ctx *c, hipStream_t st, ProfEvent **ev) {
     return ISDF_OK;
 }
 
+// mode 0: the sweep cfg.variant names; 1: the swept-volume sweep; 2: the integral sweep with the collision term off
+// (modes 1 + 2 together are what costFunctionLmbm runs for the reference's live configuration)
 static int eval_device_impl(isdf_ctx *c, int n_traj, int N, const double *d_T, const double *d_coeffs, double *d_out,
-                            double *d_tstar, hipStream_t st) {
-    const isdf_config &cfg = c->cfg;
+                            double *d_tstar, hipStream_t st, int mode = 0) {
+    isdf_config cfg = c->cfg;
+    if (mode == 1) cfg.variant = ISDF_V1_SWEPT;
+    if (mode == 2) { cfg.variant = ISDF_V3_ESDF_TILE; cfg.enable_pos = 0; }
     c->stats_cached = false;
     if (n_traj < 1 || N < 1) return fail(c, ISDF_ERR_INVALID_ARG, "n_traj and N must be >= 1");
     if (!d_T || !d_coeffs || !d_out) return fail(c, ISDF_ERR_INVALID_ARG, "null device buffer");
@@ -616,6 +628,125 @@ extern "C" int isdf_eval(isdf_ctx *c, int n_traj, const int *N, const double *co
     c->last_stats = total;
     c->stats_cached = true;
     if (total.overflow) return fail(c, ISDF_ERR_OVERFLOW, "a bounded device work list overflowed; result invalid");
+    return ISDF_OK;
+}
+
+// --------------------------------------------------------------------------------------------------------------
+// full objective callback: TrajOptimizer::costFunctionLmbm (back_end_optimizer.hpp:358-430)
+// --------------------------------------------------------------------------------------------------------------
+extern "C" int isdf_set_trajectory(isdf_ctx *c, int N, const double head_pva[9], const double tail_pva[9], double rho) {
+    if (!c) return ISDF_ERR_INVALID_ARG;
+    if (N < 1 || !head_pva || !tail_pva) return fail(c, ISDF_ERR_INVALID_ARG, "bad trajectory setup");
+    c->minco.set_conditions(head_pva, tail_pva, N);
+    c->rho = rho;
+    c->have_traj = true;
+    c->cb_T.assign(N, 0.0); c->cb_gdC.assign((size_t)18 * N, 0.0); c->cb_gdT.assign(N, 0.0);
+    c->cb_gradP.assign((size_t)3 * (N > 1 ? N - 1 : 1), 0.0); c->cb_gradT.assign(N, 0.0);
+    return ISDF_OK;
+}
+
+extern "C" int isdf_num_variables(const isdf_ctx *c) { return (c && c->have_traj) ? c->minco.N + 3 * (c->minco.N - 1) : 0; }
+
+// x = [tau(N) | waypoints 3(N-1)]: backwardT / backwardP of optimize_traj_lmbm (back_end_optimizer.cpp:22-28)
+extern "C" int isdf_pack_variables(isdf_ctx *c, const double *T, const double *waypoints, double *x) {
+    if (!c || !T || !x) return ISDF_ERR_INVALID_ARG;
+    if (!c->have_traj) return fail(c, ISDF_ERR_STATE, "isdf_set_trajectory not called");
+    const int N = c->minco.N;
+    if (N > 1 && !waypoints) return fail(c, ISDF_ERR_INVALID_ARG, "null waypoints");
+    for (int i = 0; i < N; i++) {
+        if (!(T[i] > 0.0)) return fail(c, ISDF_ERR_INVALID_ARG, "durations must be positive");
+        x[i] = isdf_host::T_to_tau(T[i]);
+    }
+    for (int i = 0; i < 3 * (N - 1); i++) x[N + i] = waypoints[i];
+    return ISDF_OK;
+}
+
+// forwardT / forwardP + minco.setParameters: the trajectory x stands for (T: N, coeffs: 6N x 3 column-major)
+extern "C" int isdf_unpack_variables(isdf_ctx *c, const double *x, double *T, double *coeffs) {
+    if (!c || !x) return ISDF_ERR_INVALID_ARG;
+    if (!c->have_traj) return fail(c, ISDF_ERR_STATE, "isdf_set_trajectory not called");
+    const int N = c->minco.N;
+    for (int i = 0; i < N; i++) c->cb_T[i] = isdf_host::tau_to_T(x[i]);
+    c->minco.set_parameters(x + N, c->cb_T.data());
+    if (T) std::memcpy(T, c->cb_T.data(), (size_t)N * sizeof(double));
+    if (coeffs) std::memcpy(coeffs, c->minco.c.data(), (size_t)18 * N * sizeof(double));
+    return ISDF_OK;
+}
+
+extern "C" int isdf_cost_function(isdf_ctx *c, const double *x, double *g, int n, double *cost_out) {
+    if (!c) return ISDF_ERR_INVALID_ARG;
+    if (!x || !g || !cost_out) return fail(c, ISDF_ERR_INVALID_ARG, "null argument");
+    if (!c->have_traj) return fail(c, ISDF_ERR_STATE, "isdf_set_trajectory not called");
+    const int N = c->minco.N;
+    if (n != N + 3 * (N - 1)) return fail(c, ISDF_ERR_INVALID_ARG, "n must be N + 3(N-1)");
+    HIPCHK(c, hipSetDevice(c->device));
+    // tau -> T, xi -> waypoints, MINCO coefficients, energy and its partials (:363-381)
+    for (int i = 0; i < N; i++) c->cb_T[i] = isdf_host::tau_to_T(x[i]);
+    c->minco.set_parameters(x + N, c->cb_T.data());
+    double cost = c->minco.energy(c->cb_gdC.data(), c->cb_gdT.data());
+    const double energy = cost;
+    // the two sweeps on the device (:386-405), one round trip
+    const size_t in_len = (size_t)19 * N, ostride = isdf_out_stride(N);
+    const bool swept = c->cfg.variant == ISDF_V1_SWEPT;
+    const int n_out = swept ? 2 : 1;
+    const size_t need = in_len + n_out * ostride;
+    if (c->pin_cap < need) {
+        if (c->h_pin) (void)hipHostFree(c->h_pin);
+        c->h_pin = nullptr; c->pin_cap = 0;
+        HIPCHK(c, hipHostMalloc((void **)&c->h_pin, need * sizeof(double), hipHostMallocDefault));
+        c->pin_cap = need;
+    }
+    int rc = ensure(c, &c->d_cb, &c->cb_cap, need);
+    if (rc) return rc;
+    std::memcpy(c->h_pin, c->cb_T.data(), (size_t)N * sizeof(double));
+    std::memcpy(c->h_pin + N, c->minco.c.data(), (size_t)18 * N * sizeof(double));
+    HIPCHK(c, hipMemcpyAsync(c->d_cb, c->h_pin, in_len * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    double *d_T = c->d_cb, *d_C = c->d_cb + N, *d_o = c->d_cb + in_len;
+    if (swept) {
+        rc = eval_device_impl(c, 1, N, d_T, d_C, d_o, nullptr, c->stream, 1);
+        if (rc) return rc;
+        rc = eval_device_impl(c, 1, N, d_T, d_C, d_o + ostride, nullptr, c->stream, 2);
+    } else {
+        rc = eval_device_impl(c, 1, N, d_T, d_C, d_o, nullptr, c->stream, 0);
+    }
+    if (rc) return rc;
+    HIPCHK(c, hipMemcpyAsync(c->h_pin + in_len, d_o, n_out * ostride * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    double part[2] = {0.0, 0.0};
+    for (int k = 0; k < n_out; k++) {       // accumulate in the reference's order: swept-volume sweep, then integral sweep
+        const double *o = c->h_pin + in_len + k * ostride;
+        cost += o[0];
+        part[k] = o[0];
+        for (int i = 0; i < N; i++) c->cb_gdT[i] += o[1 + i];
+        for (int i = 0; i < 18 * N; i++) c->cb_gdC[i] += o[1 + N + i];
+    }
+    // dCost/d(c, T) -> dCost/d(waypoints, T) (:416), time regulariser (:417-420), chain rule to (tau, xi) (:426-427)
+    c->minco.propagate_grad(c->cb_gdC.data(), c->cb_gdT.data(), c->cb_gradP.data(), c->cb_gradT.data());
+    double tsum = 0.0;
+    for (int i = 0; i < N; i++) tsum += c->cb_T[i];
+    cost += c->rho * tsum;
+    for (int i = 0; i < N; i++) g[i] = isdf_host::grad_T_to_tau(x[i], c->cb_gradT[i] + c->rho);
+    for (int i = 0; i < 3 * (N - 1); i++) g[N + i] = c->cb_gradP[i];
+    c->last_parts[0] = energy;
+    c->last_parts[1] = swept ? part[0] : 0.0;            // swept-volume sweep
+    c->last_parts[2] = swept ? part[1] : part[0];        // integral sweep
+    c->last_parts[3] = c->rho * tsum;
+    *cost_out = cost;
+    return ISDF_OK;
+}
+
+// Same callback with the signature LMBM / the optimizer drivers bind (lmbm_evaluate_t, lmbm.h:206-209):
+// instance = isdf_ctx*.  Errors surface as +infinity (the reference has no error channel here).
+extern "C" double isdf_cost_function_lmbm(void *instance, const double *x, double *g, const int n) {
+    double cost = 0.0;
+    const int rc = isdf_cost_function((isdf_ctx *)instance, x, g, n, &cost);
+    return rc == ISDF_OK ? cost : INFINITY;
+}
+
+// energy | swept-volume sweep | integral sweep | rho * sum(T) of the last isdf_cost_function call
+extern "C" int isdf_cost_parts(const isdf_ctx *c, double parts[4]) {
+    if (!c || !parts) return ISDF_ERR_INVALID_ARG;
+    for (int k = 0; k < 4; k++) parts[k] = c->last_parts[k];
     return ISDF_OK;
 }
 

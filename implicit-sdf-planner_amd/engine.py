@@ -109,6 +109,44 @@ class Engine:
     def out_stride(self, N):
         return int(self.lib.isdf_out_stride(N))
 
+    # ---- full objective callback (TrajOptimizer::costFunctionLmbm)
+    def set_trajectory(self, N, head_pva, tail_pva, rho):
+        """head/tail: 3x3 arrays whose COLUMNS are position, velocity, acceleration (Eigen::Matrix3d of setConditions)."""
+        h = np.ascontiguousarray(np.asarray(head_pva, dtype=np.float64).T).reshape(-1)   # column-major
+        t = np.ascontiguousarray(np.asarray(tail_pva, dtype=np.float64).T).reshape(-1)
+        self._check(self.lib.isdf_set_trajectory(self.h, int(N), _p(h), _p(t), float(rho)))
+        self._N = int(N)
+
+    def num_variables(self):
+        return int(self.lib.isdf_num_variables(self.h))
+
+    def pack_variables(self, T, waypoints):
+        """T: N durations, waypoints: (N-1) x 3 -> x = [tau | xi]."""
+        T = np.ascontiguousarray(T, dtype=np.float64)
+        W = np.ascontiguousarray(np.asarray(waypoints, dtype=np.float64).reshape(-1))
+        x = np.zeros(self.num_variables())
+        self._check(self.lib.isdf_pack_variables(self.h, _p(T), _p(W) if W.size else None, _p(x)))
+        return x
+
+    def unpack_variables(self, x):
+        x = np.ascontiguousarray(x, dtype=np.float64)
+        T = np.zeros(self._N)
+        cm = np.zeros(18 * self._N)
+        self._check(self.lib.isdf_unpack_variables(self.h, _p(x), _p(T), _p(cm)))
+        return T, cm
+
+    def cost_function(self, x):
+        x = np.ascontiguousarray(x, dtype=np.float64)
+        g = np.zeros_like(x)
+        cost = C.c_double(0)
+        self._check(self.lib.isdf_cost_function(self.h, _p(x), _p(g), x.size, C.byref(cost)))
+        return cost.value, g
+
+    def cost_parts(self):
+        p = np.zeros(4)
+        self._check(self.lib.isdf_cost_parts(self.h, _p(p)))
+        return {"energy": p[0], "swept": p[1], "integral": p[2], "time": p[3]}
+
     # ---- instrumentation
     def stats(self):
         s = capi.IsdfStats()

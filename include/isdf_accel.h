@@ -180,6 +180,26 @@ int isdf_eval_device(isdf_ctx *ctx, int n_traj, int N, const double *d_T, const 
                      double *d_out, double *d_tstar, void *stream);
 size_t isdf_out_stride(int N);   /* 1 + N + 18N */
 
+/* ---- full objective callback ------------------------------------------------------------------------------ */
+/* TrajOptimizer::costFunctionLmbm (back_end_optimizer.hpp:358-430): x = [tau(N) | inner waypoints 3(N-1)] ->
+ * cost, g.  MINCO (minco.hpp:397-655: setParameters, energy and its partials, propogateGrad) runs on the host - a chain
+ * of 6N dependent pivots - and the sweeps on the device: for ISDF_V1_SWEPT the swept-volume sweep followed by the
+ * integral sweep without a collision term (the reference's live configuration), otherwise the integral sweep of
+ * cfg.variant.  cost = energy + sweeps + rho * sum(T).
+ * isdf_set_trajectory == minco.setConditions + the `rho` of setParam (head/tail: 3x3 column-major, columns =
+ * position, velocity, acceleration).  isdf_pack_variables == backwardT/backwardP (back_end_optimizer.cpp:22-28),
+ * isdf_unpack_variables == forwardT/forwardP + setParameters (T: N, coeffs: 6N x 3 column-major; either may be NULL). */
+int isdf_set_trajectory(isdf_ctx *ctx, int N, const double head_pva[9], const double tail_pva[9], double rho);
+int isdf_num_variables(const isdf_ctx *ctx);               /* N + 3(N-1), 0 before isdf_set_trajectory     */
+int isdf_pack_variables(isdf_ctx *ctx, const double *T, const double *waypoints, double *x);
+int isdf_unpack_variables(isdf_ctx *ctx, const double *x, double *T, double *coeffs);
+int isdf_cost_function(isdf_ctx *ctx, const double *x, double *g, int n, double *cost_out);
+/* the same with the lmbm_evaluate_t signature (src/utils/include/utils/lmbm.h:206-209); instance = isdf_ctx*,
+ * returns +inf on error */
+double isdf_cost_function_lmbm(void *instance, const double *x, double *g, const int n);
+/* energy | swept-volume sweep | integral sweep | rho*sum(T) of the last isdf_cost_function call */
+int isdf_cost_parts(const isdf_ctx *ctx, double parts[4]);
+
 /* ---- instrumentation --------------------------------------------------------------------------------------- */
 /* on = N > 0: every N-th isdf_eval_device records HIP events around its dominant kernel on `stream` (an event
  * record costs a few microseconds of stream time, so N > 1 keeps the instrumented run representative);

@@ -42,3 +42,35 @@ def assert_close(got, want, what, tol=REL_TOL):
     scale = max(np.linalg.norm(want.ravel()), 1e-12)
     err = np.linalg.norm((got - want).ravel())
     assert err <= tol * max(scale, 1e-9) + 1e-12, f"{what}: |diff|={err:.3e} vs |ref|={scale:.3e} (rel {err / scale:.3e} > {tol})"
+
+
+# ---- the full objective callback composed from oracle pieces (costFunctionLmbm, back_end_optimizer.hpp:358-430) ----
+def tau_to_T(tau):
+    tau = np.asarray(tau, dtype=np.float64)
+    return np.where(tau > 0.0, (0.5 * tau + 1.0) * tau + 1.0, 1.0 / ((0.5 * tau - 1.0) * tau + 1.0))
+
+
+def T_to_tau(T):
+    T = np.asarray(T, dtype=np.float64)
+    return np.where(T > 1.0, np.sqrt(np.abs(2.0 * T - 1.0)) - 1.0, 1.0 - np.sqrt(np.abs(2.0 / T - 1.0)))
+
+
+def oracle_cost_function(orc, sweeps, head, tail, rho, x, N):
+    """sweeps: list of oracle contexts whose eval() ACCUMULATES into (cost, gradT, gradC), in the reference's order.
+    head/tail: 3x3 with columns pos, vel, acc.  Returns (cost, g)."""
+    x = np.asarray(x, dtype=np.float64)
+    tau, xi = x[:N], x[N:]
+    T = tau_to_T(tau)
+    way = xi.reshape(N - 1, 3).T if N > 1 else np.zeros((3, 0))
+    C6 = orc.minco_coeffs(head, tail, way, T)                 # 6N x 3
+    cm = np.ascontiguousarray(C6.T).reshape(-1)               # column-major
+    e, gC, gT = orc.minco_energy(cm, T)
+    cost = np.array([e])
+    for o in sweeps:
+        o.eval(T, cm, accumulate_into=(cost, gT, gC))
+    gP, gTt = orc.minco_propagate(head, tail, way, T, gC, gT)
+    total = float(cost[0]) + rho * float(T.sum())
+    gTt = gTt + rho
+    den = (0.5 * tau - 1.0) * tau + 1.0
+    g_tau = np.where(tau > 0, gTt * (tau + 1.0), gTt * (1.0 - tau) / (den * den))
+    return total, np.concatenate([g_tau, gP.T.reshape(-1)])

@@ -1,0 +1,121 @@
+"""Full objective callback through the C-ABI (isdf_cost_function == TrajOptimizer::costFunctionLmbm,
+back_end_optimizer.hpp:358-430) vs the same callback composed from oracle pieces.  Tolerance 1e-5 relative."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from common import REL_TOL, assert_close, make_pair, small_world, oracle_cost_function, T_to_tau
+
+pytestmark = pytest.mark.gpu
+
+
+def _setup(pkg, occ, res, N, seed):
+    """Boundary states + a zig-zag of inner waypoints through free space, durations around 1.2 s."""
+    rng = np.random.default_rng(seed)
+    ext = np.array(occ.shape) * res
+    T0, Cf = pkg.synth.random_trajectory(ext, N, seed=seed, piece_T=1.2, margin=4.0, occ=occ, res=res)
+    c = Cf.reshape(N, 6, 3)
+    head = np.zeros((3, 3)); tail = np.zeros((3, 3))
+    head[:, 0] = c[0, 0]
+    T0 = T0 * rng.uniform(0.8, 1.3, N)
+    # end position of the last piece of the synthetic trajectory
+    tl = T0[-1] * 0 + 1.2
+    tail[:, 0] = sum(c[N - 1, p] * tl ** p for p in range(6))
+    way = c[1:, 0, :].copy()                                   # piece start points = inner waypoints
+    return head, tail, way, T0
+
+
+def _engines(pkg, orc, variant, occ, esdf, res, shape, points=None):
+    capi, synth = pkg.capi, pkg.synth
+    cfg = synth.default_config(variant, kernel_size=9, integral_intervs=16, safety_hor=0.5)
+    eng, o = make_pair(pkg, orc, cfg, shape, occ=occ, esdf=esdf, res=res, points=points)
+    return cfg, eng, o
+
+
+@pytest.mark.parametrize("variant", ["V3", "V2"])
+def test_callback_integral(pkg, orc, product_lib, variant):
+    capi, synth = pkg.capi, pkg.synth
+    occ, esdf, res = small_world(pkg)
+    N = 6
+    head, tail, way, T0 = _setup(pkg, occ, res, N, 21)
+    shape = synth.make_shape("RoundedCone", params=(0.8, 0.3, 1.6))
+    v = capi.V3_ESDF_TILE if variant == "V3" else capi.V2_OCC_TILE
+    cfg, eng, o = _engines(pkg, orc, v, occ, esdf, res, shape)
+    rho = 3.5
+    eng.set_trajectory(N, head, tail, rho)
+    assert eng.num_variables() == N + 3 * (N - 1)
+    x = eng.pack_variables(T0, way)
+    assert_close(x[:N], T_to_tau(T0), "backwardT", tol=1e-12)
+    T1, cm1 = eng.unpack_variables(x)
+    assert_close(T1, T0, "forwardT(backwardT(T))", tol=1e-9)
+    cost, g = eng.cost_function(x)
+    c0, g0 = oracle_cost_function(orc, [o], head, tail, rho, x, N)
+    assert abs(cost - c0) <= REL_TOL * abs(c0), (cost, c0)
+    assert_close(g, g0, "g")
+    parts = eng.cost_parts()
+    assert parts["integral"] > 0 and parts["swept"] == 0.0
+    assert abs(parts["energy"] + parts["integral"] + parts["time"] - cost) <= 1e-9 * abs(cost)
+    # lmbm_evaluate_t entry point: same numbers
+    gl = np.zeros_like(g)
+    dp = C.POINTER(C.c_double)
+    cl = eng.lib.isdf_cost_function_lmbm(eng.h, x.ctypes.data_as(dp), gl.ctypes.data_as(dp), x.size)
+    assert cl == cost and np.array_equal(gl, g)
+
+
+def test_callback_swept(pkg, orc, product_lib):
+    """The reference's live configuration: swept-volume sweep + integral sweep without collision term."""
+    capi, synth = pkg.capi, pkg.synth
+    occ, esdf, res = small_world(pkg, seed=4)
+    N = 5
+    head, tail, way, T0 = _setup(pkg, occ, res, N, 33)
+    pts = synth.constraint_points(occ, (0, 0, 0), res, way, half=4 * res * 1.5)
+    assert pts.shape[0] > 0
+    shape = synth.make_shape("RoundedCone", params=(0.8, 0.3, 1.6))
+    cfg, eng, o1 = _engines(pkg, orc, capi.V1_SWEPT, occ, esdf, res, shape, points=pts)
+    cfg2 = synth.default_config(capi.V3_ESDF_TILE, kernel_size=9, integral_intervs=16, safety_hor=0.5, enable_pos=0)
+    o2 = orc.Oracle(cfg2, threads=4)
+    rho = 1.0
+    eng.set_trajectory(N, head, tail, rho)
+    x = eng.pack_variables(T0 * 0.5, way)          # fast => dynamics penalties active as well
+    cost, g = eng.cost_function(x)
+    c0, g0 = oracle_cost_function(orc, [o1, o2], head, tail, rho, x, N)
+    assert abs(cost - c0) <= REL_TOL * abs(c0), (cost, c0)
+    assert_close(g, g0, "g")
+    parts = eng.cost_parts()
+    assert parts["swept"] > 0 and parts["integral"] > 0
+
+
+def test_callback_gradient_is_the_derivative(pkg, orc, product_lib):
+    """Directional central difference of the device callback itself (V3): g.d == dcost/deps."""
+    capi, synth = pkg.capi, pkg.synth
+    occ, esdf, res = small_world(pkg, seed=6)
+    N = 4
+    head, tail, way, T0 = _setup(pkg, occ, res, N, 44)
+    shape = synth.make_shape("RoundedCone", params=(0.8, 0.3, 1.6))
+    cfg, eng, o = _engines(pkg, orc, capi.V3_ESDF_TILE, occ, esdf, res, shape)
+    eng.set_trajectory(N, head, tail, 2.0)
+    x = eng.pack_variables(T0, way)
+    cost, g = eng.cost_function(x)
+    rng = np.random.default_rng(1)
+    for _ in range(3):
+        d = rng.normal(0, 1, x.size); d /= np.linalg.norm(d)
+        eps = 1e-6
+        fd = (eng.cost_function(x + eps * d)[0] - eng.cost_function(x - eps * d)[0]) / (2 * eps)
+        assert abs(fd - g @ d) <= 2e-4 * max(1.0, abs(fd)), (fd, g @ d)
+
+
+def test_callback_errors(pkg, product_lib):
+    capi, synth = pkg.capi, pkg.synth
+    cfg = synth.default_config(capi.V3_ESDF_TILE, enable_pos=0)
+    eng = pkg.Engine(cfg)
+    x = np.zeros(7)
+    with pytest.raises(pkg.engine.IsdfError) as e:
+        eng._N = 2
+        eng.cost_function(x)
+    assert e.value.code == capi.ISDF_ERR_STATE
+    eng.set_trajectory(2, np.zeros((3, 3)), np.eye(3), 1.0)
+    with pytest.raises(pkg.engine.IsdfError) as e:
+        eng.cost_function(np.zeros(9))
+    assert e.value.code == capi.ISDF_ERR_INVALID_ARG
+    assert eng.lib.isdf_cost_function_lmbm(eng.h, None, None, 5) == float("inf")
