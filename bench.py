@@ -53,6 +53,7 @@ def main():
     ap.add_argument("--kernel-size", type=int, default=21)
     ap.add_argument("--cull", type=int, default=0, help="1: enable the V3 whole-tile cull (reported separately, never as value)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--lbfgs-iters", type=int, default=40, help="iterations of the L-BFGS driver timed after the sweep (0: skip)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     args = ap.parse_args()
 
@@ -158,6 +159,24 @@ def main():
                 eng.eval_single(T, cm)
             host_ms = 1e3 * (time.perf_counter() - th0) / 20
 
+        # second half of BASELINE.json's metric: "L-BFGS iter ms" - the optimizer driver (isdf_optimize_lbfgs) on the
+        # full objective callback (host MINCO + the device sweeps), same map / robot / piece count.  Informational.
+        lbfgs = None
+        if world == 1 and args.lbfgs_iters > 0:
+            c6 = cm.reshape(3, 6 * N).T.reshape(N, 6, 3)
+            head = np.stack([c6[0, 0], c6[0, 1], 2.0 * c6[0, 2]], axis=1)
+            tl = T[-1]
+            pw = lambda k: sum(np.prod([p - q for q in range(k)]) * c6[N - 1, p] * tl ** (p - k) for p in range(k, 6))
+            tail = np.stack([pw(0), pw(1), pw(2)], axis=1)
+            eng.set_trajectory(N, head, tail, 1000.0)
+            x0 = eng.pack_variables(T, c6[1:, 0, :])
+            c_first = eng.cost_function(x0)[0]
+            xo, r = eng.optimize_lbfgs(x0, max_iterations=args.lbfgs_iters, g_epsilon=0.0, past=0)
+            lbfgs = {"iterations": r["iterations"], "evaluations": r["evaluations"], "status": r["status"],
+                     "ms_per_iteration": round(r["wall_ms"] / max(1, r["iterations"]), 4),
+                     "ms_per_evaluation": round(r["wall_ms"] / max(1, r["evaluations"]), 4),
+                     "cost_first": c_first, "cost_last": r["f"]}
+
         cpu = None
         parity = None
         if not args.no_cpu_baseline:
@@ -203,7 +222,7 @@ def main():
                        "sharding": "pieces contiguous by rank + all_reduce(sum) of 1+19N doubles" if world > 1 else "none"},
             "roofline": roofline, "cpu_baseline": cpu,
             "parity_rel_err_vs_oracle": parity, "host_api_ms": None if host_ms is None else round(host_ms, 4),
-            "stats_last_step_rank0": stats,
+            "stats_last_step_rank0": stats, "lbfgs": lbfgs,
         }
         print(json.dumps(result), flush=True)
     if world > 1:

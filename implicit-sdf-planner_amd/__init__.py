@@ -5,4 +5,4 @@ gfx950, built into lib/libisdf_accel.so); this package only marshals arrays.  Im
 (the directory name contains a hyphen; __graft_entry__.load_package() registers the alias).
 """
 from . import capi, synth, parallel  # noqa: F401
-from .engine import Engine, IsdfError  # noqa: F401
+from .engine import Engine, IsdfError, lbfgs_minimize  # noqa: F401

@@ -49,6 +49,22 @@ class IsdfStats(C.Structure):
                 ("n_grad_pairs", C.c_int64), ("overflow", C.c_int32), ("reserved", C.c_int32)]
 
 
+class IsdfLbfgsParams(C.Structure):
+    _fields_ = [("mem_size", C.c_int32), ("past", C.c_int32), ("max_iterations", C.c_int32), ("max_linesearch", C.c_int32),
+                ("weak_wolfe", C.c_int32), ("reference_patches", C.c_int32),
+                ("g_epsilon", C.c_double), ("delta", C.c_double), ("min_step", C.c_double), ("max_step", C.c_double),
+                ("f_dec_coeff", C.c_double), ("s_curv_coeff", C.c_double), ("cautious_factor", C.c_double),
+                ("machine_prec", C.c_double), ("dir_norm_cap", C.c_double)]
+
+
+class IsdfLbfgsResult(C.Structure):
+    _fields_ = [("f", C.c_double), ("wall_ms", C.c_double), ("status", C.c_int32), ("iterations", C.c_int32),
+                ("evaluations", C.c_int32), ("reserved", C.c_int32)]
+
+
+EVALUATE_FN = C.CFUNCTYPE(C.c_double, C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_double), C.c_int)
+
+
 # every symbol include/isdf_accel.h declares (tests check the .so exports all of them)
 EXPORTED_SYMBOLS = [
     "isdf_config_default", "isdf_shape_default", "isdf_shape_from_name", "isdf_create", "isdf_destroy",
@@ -57,6 +73,7 @@ EXPORTED_SYMBOLS = [
     "isdf_profile_read", "isdf_profile_read_secondary", "isdf_get_stats",
     "isdf_set_trajectory", "isdf_num_variables", "isdf_pack_variables", "isdf_unpack_variables",
     "isdf_cost_function", "isdf_cost_function_lmbm", "isdf_cost_parts",
+    "isdf_lbfgs_params_default", "isdf_lbfgs_minimize", "isdf_optimize_lbfgs",
 ]
 
 _lib = None
@@ -102,6 +119,10 @@ def load_library(path=None):
     lib.isdf_cost_function_lmbm.argtypes = [C.c_void_p, dp, dp, C.c_int]
     lib.isdf_cost_function_lmbm.restype = C.c_double
     lib.isdf_cost_parts.argtypes = [C.c_void_p, dp]
+    lib.isdf_lbfgs_params_default.argtypes = [C.POINTER(IsdfLbfgsParams)]
+    lib.isdf_lbfgs_params_default.restype = None
+    lib.isdf_lbfgs_minimize.argtypes = [EVALUATE_FN, C.c_void_p, dp, C.c_int, C.POINTER(IsdfLbfgsParams), C.POINTER(IsdfLbfgsResult)]
+    lib.isdf_optimize_lbfgs.argtypes = [C.c_void_p, dp, C.c_int, C.POINTER(IsdfLbfgsParams), C.POINTER(IsdfLbfgsResult)]
     if path is None:
         _lib = lib
     return lib

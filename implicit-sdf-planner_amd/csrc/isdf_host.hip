@@ -4,6 +4,8 @@
 // shape registry lookup of sw_manager.hpp:74-123,:255-275.  No CPU compute path exists here.
 #include "isdf_internal.hpp"
 #include "minco_host.hpp"
+#include "lbfgs_host.hpp"
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstring>
@@ -748,6 +750,46 @@ extern "C" int isdf_cost_parts(const isdf_ctx *c, double parts[4]) {
     if (!c || !parts) return ISDF_ERR_INVALID_ARG;
     for (int k = 0; k < 4; k++) parts[k] = c->last_parts[k];
     return ISDF_OK;
+}
+
+// --------------------------------------------------------------------------------------------------------------
+// optimizer driver: L-BFGS behind the callback (lbfgs::lbfgs_optimize, src/utils/include/utils/lbfgs.hpp:480-835)
+// --------------------------------------------------------------------------------------------------------------
+extern "C" void isdf_lbfgs_params_default(isdf_lbfgs_params *p) {
+    if (!p) return;
+    const isdf_host::LbfgsParams d;
+    p->mem_size = d.mem_size; p->past = d.past; p->max_iterations = d.max_iterations; p->max_linesearch = d.max_linesearch;
+    p->weak_wolfe = d.weak_wolfe; p->reference_patches = d.reference_patches;
+    p->g_epsilon = d.g_epsilon; p->delta = d.delta; p->min_step = d.min_step; p->max_step = d.max_step;
+    p->f_dec_coeff = d.f_dec_coeff; p->s_curv_coeff = d.s_curv_coeff; p->cautious_factor = d.cautious_factor;
+    p->machine_prec = d.machine_prec; p->dir_norm_cap = d.dir_norm_cap;
+}
+
+extern "C" int isdf_lbfgs_minimize(isdf_evaluate_fn evaluate, void *instance, double *x_inout, int n,
+                                   const isdf_lbfgs_params *p, isdf_lbfgs_result *out) {
+    if (!evaluate || !x_inout || !p || !out) return ISDF_ERR_INVALID_ARG;
+    isdf_host::Lbfgs opt;
+    opt.param.mem_size = p->mem_size; opt.param.past = p->past; opt.param.max_iterations = p->max_iterations;
+    opt.param.max_linesearch = p->max_linesearch; opt.param.weak_wolfe = p->weak_wolfe; opt.param.reference_patches = p->reference_patches;
+    opt.param.g_epsilon = p->g_epsilon; opt.param.delta = p->delta; opt.param.min_step = p->min_step; opt.param.max_step = p->max_step;
+    opt.param.f_dec_coeff = p->f_dec_coeff; opt.param.s_curv_coeff = p->s_curv_coeff; opt.param.cautious_factor = p->cautious_factor;
+    opt.param.machine_prec = p->machine_prec; opt.param.dir_norm_cap = p->dir_norm_cap;
+    opt.evaluate = evaluate;
+    opt.instance = instance;
+    const auto t0 = std::chrono::steady_clock::now();
+    const isdf_host::LbfgsResult r = opt.minimize(x_inout, n);
+    const auto t1 = std::chrono::steady_clock::now();
+    out->f = r.f; out->status = r.status; out->iterations = r.iterations; out->evaluations = r.evaluations;
+    out->wall_ms = std::chrono::duration<double, std::milli>(t1 - t0).count();
+    return ISDF_OK;
+}
+
+extern "C" int isdf_optimize_lbfgs(isdf_ctx *c, double *x_inout, int n, const isdf_lbfgs_params *p, isdf_lbfgs_result *out) {
+    if (!c) return ISDF_ERR_INVALID_ARG;
+    if (!x_inout || !p || !out) return fail(c, ISDF_ERR_INVALID_ARG, "null argument");
+    if (!c->have_traj) return fail(c, ISDF_ERR_STATE, "isdf_set_trajectory not called");
+    if (n != isdf_num_variables(c)) return fail(c, ISDF_ERR_INVALID_ARG, "n must be N + 3(N-1)");
+    return isdf_lbfgs_minimize(isdf_cost_function_lmbm, c, x_inout, n, p, out);
 }
 
 // --------------------------------------------------------------------------------------------------------------

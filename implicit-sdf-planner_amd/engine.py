@@ -25,6 +25,36 @@ def _p(a):
     return a.ctypes.data_as(_dp)
 
 
+def lbfgs_params(lib, **kw):
+    p = capi.IsdfLbfgsParams()
+    lib.isdf_lbfgs_params_default(C.byref(p))
+    for k, v in kw.items():
+        if not hasattr(p, k):
+            raise TypeError(f"unknown L-BFGS parameter {k}")
+        setattr(p, k, v)
+    return p
+
+
+def lbfgs_minimize(fun, x0, lib=None, **params):
+    """Driver on an arbitrary Python callback fun(x) -> (f, g) (host only; used by the CPU tests)."""
+    lib = lib or capi.load_library()
+    x = np.ascontiguousarray(x0, dtype=np.float64).copy()
+    n = x.size
+
+    def tramp(_inst, xp, gp, nn):
+        xv = np.ctypeslib.as_array(xp, shape=(nn,))
+        f, g = fun(xv.copy())
+        np.ctypeslib.as_array(gp, shape=(nn,))[:] = g
+        return float(f)
+    cb = capi.EVALUATE_FN(tramp)
+    p = lbfgs_params(lib, **params)
+    r = capi.IsdfLbfgsResult()
+    rc = lib.isdf_lbfgs_minimize(cb, None, _p(x), n, C.byref(p), C.byref(r))
+    if rc != capi.ISDF_OK:
+        raise IsdfError(rc, "isdf_lbfgs_minimize")
+    return x, {"f": r.f, "status": r.status, "iterations": r.iterations, "evaluations": r.evaluations, "wall_ms": r.wall_ms}
+
+
 class Engine:
     def __init__(self, cfg, lib=None):
         self.lib = lib or capi.load_library()
@@ -146,6 +176,15 @@ class Engine:
         p = np.zeros(4)
         self._check(self.lib.isdf_cost_parts(self.h, _p(p)))
         return {"energy": p[0], "swept": p[1], "integral": p[2], "time": p[3]}
+
+    # ---- optimizer driver (lbfgs::lbfgs_optimize behind the callback)
+    def optimize_lbfgs(self, x0, **params):
+        """Returns (x, result dict).  params override lbfgs_parameter_t defaults (mem_size, max_iterations, ...)."""
+        x = np.ascontiguousarray(x0, dtype=np.float64).copy()
+        p = lbfgs_params(self.lib, **params)
+        r = capi.IsdfLbfgsResult()
+        self._check(self.lib.isdf_optimize_lbfgs(self.h, _p(x), x.size, C.byref(p), C.byref(r)))
+        return x, {"f": r.f, "status": r.status, "iterations": r.iterations, "evaluations": r.evaluations, "wall_ms": r.wall_ms}
 
     # ---- instrumentation
     def stats(self):

@@ -200,6 +200,29 @@ double isdf_cost_function_lmbm(void *instance, const double *x, double *g, const
 /* energy | swept-volume sweep | integral sweep | rho*sum(T) of the last isdf_cost_function call */
 int isdf_cost_parts(const isdf_ctx *ctx, double parts[4]);
 
+/* ---- optimizer driver ----------------------------------------------------------------------------------------- */
+/* L-BFGS behind the callback: lbfgs::lbfgs_optimize of src/utils/include/utils/lbfgs.hpp:480-835 (the LBFGS-Lite fork
+ * the reference ships; its mid end calls it at src/planner_algorithm/src/mid_end.cpp:48-62).  Field names and defaults
+ * are lbfgs_parameter_t's (:15-129).  weak_wolfe = 0 is the fork's Armijo-only line search (:373-386), 1 the
+ * Lewis-Overton test it comments out; reference_patches = 1 keeps the fork's steepest-descent fallbacks (:788-819).
+ * status uses the reference's codes: 0 convergence, 1 stop (delta test), 2 cancelled, negative = LBFGSERR_* (:133-160). */
+typedef struct isdf_lbfgs_params {
+    int32_t mem_size, past, max_iterations, max_linesearch, weak_wolfe, reference_patches;
+    double g_epsilon, delta, min_step, max_step, f_dec_coeff, s_curv_coeff, cautious_factor, machine_prec, dir_norm_cap;
+} isdf_lbfgs_params;
+typedef struct isdf_lbfgs_result {
+    double f;                /* cost at the returned x                              */
+    double wall_ms;          /* host wall time of the whole minimisation            */
+    int32_t status, iterations, evaluations, reserved;
+} isdf_lbfgs_result;
+typedef double (*isdf_evaluate_fn)(void *instance, const double *x, double *g, const int n);   /* == lmbm_evaluate_t */
+void isdf_lbfgs_params_default(isdf_lbfgs_params *p);
+/* any callback (no device needed) */
+int isdf_lbfgs_minimize(isdf_evaluate_fn evaluate, void *instance, double *x_inout, int n,
+                        const isdf_lbfgs_params *p, isdf_lbfgs_result *out);
+/* the ctx's own objective: isdf_cost_function */
+int isdf_optimize_lbfgs(isdf_ctx *ctx, double *x_inout, int n, const isdf_lbfgs_params *p, isdf_lbfgs_result *out);
+
 /* ---- instrumentation --------------------------------------------------------------------------------------- */
 /* on = N > 0: every N-th isdf_eval_device records HIP events around its dominant kernel on `stream` (an event
  * record costs a few microseconds of stream time, so N > 1 keeps the instrumented run representative);

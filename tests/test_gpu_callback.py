@@ -119,3 +119,29 @@ def test_callback_errors(pkg, product_lib):
         eng.cost_function(np.zeros(9))
     assert e.value.code == capi.ISDF_ERR_INVALID_ARG
     assert eng.lib.isdf_cost_function_lmbm(eng.h, None, None, 5) == float("inf")
+
+
+def test_optimize_lbfgs_follows_oracle(pkg, orc, product_lib):
+    """The L-BFGS driver on the device callback vs the oracle's restatement of lbfgs_optimize on the oracle callback:
+    same iterates for the first iterations (both sides see costs equal to ~1e-14)."""
+    import importlib.util, os
+    spec = importlib.util.spec_from_file_location("lbfgs_ref", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle", "lbfgs_ref.py"))
+    ref = importlib.util.module_from_spec(spec); spec.loader.exec_module(ref)
+    capi, synth = pkg.capi, pkg.synth
+    occ, esdf, res = small_world(pkg, seed=8)
+    N = 4
+    head, tail, way, T0 = _setup(pkg, occ, res, N, 55)
+    shape = synth.make_shape("RoundedCone", params=(0.8, 0.3, 1.6))
+    cfg, eng, o = _engines(pkg, orc, capi.V3_ESDF_TILE, occ, esdf, res, shape)
+    rho = 10.0
+    eng.set_trajectory(N, head, tail, rho)
+    x0 = eng.pack_variables(T0, way)
+    iters = 6
+    fun = lambda x: oracle_cost_function(orc, [o], head, tail, rho, np.asarray(x), N)
+    xr, fr, sr, kr, er = ref.lbfgs_optimize(fun, list(x0), max_iterations=iters, g_epsilon=0.0, past=0)
+    x, r = eng.optimize_lbfgs(x0, max_iterations=iters, g_epsilon=0.0, past=0)
+    c_start = eng.cost_function(x0)[0]
+    assert r["status"] == sr and r["iterations"] == kr and r["evaluations"] == er, (r, sr, kr, er)
+    assert r["f"] < c_start
+    assert_close(x, np.array(xr), "x after %d L-BFGS iterations" % iters, tol=1e-6)
+    assert abs(r["f"] - fr) <= 1e-6 * abs(fr)
