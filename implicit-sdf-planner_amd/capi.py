@@ -74,6 +74,7 @@ EXPORTED_SYMBOLS = [
     "isdf_set_trajectory", "isdf_num_variables", "isdf_pack_variables", "isdf_unpack_variables",
     "isdf_cost_function", "isdf_cost_function_lmbm", "isdf_cost_parts",
     "isdf_lbfgs_params_default", "isdf_lbfgs_minimize", "isdf_optimize_lbfgs",
+    "isdf_set_pointcloud", "isdf_generate_esdf", "isdf_get_grid", "isdf_gather_points", "isdf_get_points",
 ]
 
 _lib = None
@@ -119,6 +120,12 @@ def load_library(path=None):
     lib.isdf_cost_function_lmbm.argtypes = [C.c_void_p, dp, dp, C.c_int]
     lib.isdf_cost_function_lmbm.restype = C.c_double
     lib.isdf_cost_parts.argtypes = [C.c_void_p, dp]
+    ip = C.POINTER(C.c_int)
+    lib.isdf_set_pointcloud.argtypes = [C.c_void_p, C.POINTER(C.c_float), C.c_longlong, dp, dp, C.c_double, C.c_int, ip]
+    lib.isdf_generate_esdf.argtypes = [C.c_void_p]
+    lib.isdf_get_grid.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, ip, dp, dp]
+    lib.isdf_gather_points.argtypes = [C.c_void_p, dp, C.c_int, dp, dp, ip]
+    lib.isdf_get_points.argtypes = [C.c_void_p, dp, C.c_int]
     lib.isdf_lbfgs_params_default.argtypes = [C.POINTER(IsdfLbfgsParams)]
     lib.isdf_lbfgs_params_default.restype = None
     lib.isdf_lbfgs_minimize.argtypes = [EVALUATE_FN, C.c_void_p, dp, C.c_int, C.POINTER(IsdfLbfgsParams), C.POINTER(IsdfLbfgsResult)]

@@ -2,8 +2,7 @@
 // Replaces, for the two sweeps only, what TrajOptimizer holds around them in the reference
 // (back_end_optimizer.hpp:59-62 parallel_points/lastTstar, :667-725 setParam/setEnvironment/setGridMap) and the
 // shape registry lookup of sw_manager.hpp:74-123,:255-275.  No CPU compute path exists here.
-#include "isdf_internal.hpp"
-#include "minco_host.hpp"
+#include "isdf_ctx.hpp"
 #include "lbfgs_host.hpp"
 #include <chrono>
 #include <cmath>
@@ -18,77 +17,13 @@ using namespace isdf;
 
 namespace {
 thread_local std::string g_create_error;
-
-struct ProfEvent { hipEvent_t a, b, c; };
 }
 
-struct isdf_ctx {
-    isdf_config cfg;
-    int device = 0;
-    std::string err;
-    // grid
-    DevGrid grid{};
-    float *d_esdf = nullptr;
-    uint8_t *d_occ = nullptr;
-    unsigned *d_bits = nullptr; size_t bits_cap = 0; bool bits_dirty = true;
-    bool have_geom = false;
-    // shape
-    DevShape shape{};
-    isdf_shape shape_host{};
-    bool have_shape = false;
-    DevMesh *d_mesh = nullptr;
-    double *d_mesh_tri = nullptr;
-    float *d_mesh_trif = nullptr;
-    // points (V1)
-    double *d_points = nullptr;
-    int M = 0;
-    double *d_tstar = nullptr;       // internal lastTstar when the caller passes none
-    // shard
-    int rank = 0, world = 1;
-    // per-step scratch
-    double *d_acc = nullptr; int *d_sample_info = nullptr; size_t sample_cap = 0;
-    SweepParams last_P{}; bool have_last_P = false;
-    double last_exact_ms = 0.0;
-    double *d_piece_cost = nullptr; size_t piece_cap = 0;
-    double *d_in = nullptr; size_t in_cap = 0;        // host-API staging: T | coeffs
-    double *d_out = nullptr; size_t out_cap = 0;
-    std::vector<double> h_out;
-    unsigned long long *d_stats = nullptr;
-    isdf_stats last_stats{};
-    bool stats_cached = false;
-    // V1 scratch
-    double *d_traj_duration = nullptr;
-    double *d_coarse_t = nullptr, *d_coarse_pose = nullptr;
-    int *d_n_coarse = nullptr;
-    double *d_point_partial = nullptr; int *d_point_piece = nullptr; int point_cap = 0;
-    double *d_hist = nullptr; size_t hist_cap = 0;
-    // profiling
-    bool prof_on = false; int prof_every = 1; long long prof_tick = 0;
-    std::vector<ProfEvent> prof_events;
-    size_t prof_used = 0;
-    hipStream_t stream = nullptr;   // stream of the host API
-    unsigned long long *d_dbg = nullptr; size_t dbg_cap = 0; size_t dbg_used = 0;   // ISDF_DEBUG_TIMING=1 (developer tool)
-    // full objective callback (costFunctionLmbm): MINCO on the host, sweeps on the device
-    isdf_host::MincoS3 minco; bool have_traj = false; double rho = 0.0;
-    std::vector<double> cb_T, cb_gdC, cb_gdT, cb_gradP, cb_gradT;
-    double *h_pin = nullptr; size_t pin_cap = 0;      // pinned staging: [T | coeffs | out_a | out_b]
-    double *d_cb = nullptr; size_t cb_cap = 0;        // device twin of the staging buffer
-    double last_parts[4] = {0, 0, 0, 0};
-};
-
-#define HIPCHK(ctx, call)                                                                          \
-    do {                                                                                           \
-        hipError_t e_ = (call);                                                                    \
-        if (e_ != hipSuccess) {                                                                    \
-            (ctx)->err = std::string(#call) + ": " + hipGetErrorString(e_);                        \
-            return ISDF_ERR_HIP;                                                                   \
-        }                                                                                          \
-    } while (0)
-
-static int fail(isdf_ctx *c, int code, const char *msg) {
+int isdf_fail(isdf_ctx *c, int code, const char *msg) {
     if (c) c->err = msg; else g_create_error = msg;
     return code;
 }
+static int fail(isdf_ctx *c, int code, const char *msg) { return isdf_fail(c, code, msg); }
 
 // --------------------------------------------------------------------------------------------------------------
 // defaults and the analytic-shape registry
@@ -386,7 +321,7 @@ static void shard_range(long long total, int rank, int world, long long &b, long
     e = b + q + (rank < r ? 1 : 0);
 }
 
-static int ensure(isdf_ctx *c, double **p, size_t *cap, size_t need) {
+int isdf_ensure_doubles(isdf_ctx *c, double **p, size_t *cap, size_t need) {
     if (*cap >= need) return ISDF_OK;
     if (*p) (void)hipFree(*p);
     *p = nullptr; *cap = 0;
@@ -394,6 +329,8 @@ static int ensure(isdf_ctx *c, double **p, size_t *cap, size_t need) {
     *cap = need;
     return ISDF_OK;
 }
+
+static int ensure(isdf_ctx *c, double **p, size_t *cap, size_t need) { return isdf_ensure_doubles(c, p, cap, need); }
 
 static void fill_flat(const isdf_config &cfg, FlatP &f) {
     f.mass = cfg.vehicle_mass; f.grav = cfg.grav_acc; f.dh = cfg.horiz_drag; f.dv = cfg.vert_drag;

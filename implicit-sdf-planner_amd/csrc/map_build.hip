@@ -1,0 +1,368 @@
+// Once-per-plan map products on the device:
+//   isdf_set_pointcloud   point cloud -> occupancy grid          PCSmapManager::rcvGlobalMapHandler, PCSmap_manager.cpp:87-200
+//                                                                 (createGridMap Gridmap3D.cpp:25-39, getGridIndex :135-175)
+//   isdf_generate_esdf    occupancy -> unsigned ESDF (metres)     GridMap3D::generateESDF3d, Gridmap3D.cpp:361-414 (+ fillESDF :497-533)
+//   isdf_gather_points    occupied voxel centres around waypoints plan_manager.cpp:232-254 with getPointsInAABBOutOfLastOne,
+//                                                                 PCSmap_manager.h:182-216
+// All integer / byte work, HBM-bound.  The ESDF is the exact Euclidean distance transform: the reference's three
+// passes of Felzenszwalb's 1-D lower envelope produce, for every voxel, the exact squared voxel distance to the nearest
+// occupied voxel, and that integer is unique - so the passes here compute the same integer a different way
+// (z: nearest set bit of the occupancy bit-row; y, x: bounded outward scan, exact because a candidate at offset r
+// cannot beat the current best once r^2 >= best) and res * sqrt(d2) is bit-identical to the reference's double.
+#include "isdf_ctx.hpp"
+#include <cmath>
+#include <cstring>
+#include <limits>
+
+namespace isdf {
+
+constexpr int EDT_INF = 0x3fffffff;        // "no occupied voxel on this line / plane yet"
+
+// ---------------------------------------------------------------------------------------------------------------
+// point cloud -> counts -> occupancy
+// ---------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void pc_count_kernel(const float *__restrict__ xyz, long long n, DevGrid G, unsigned *__restrict__ counts) {
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        const double x = (double)xyz[3 * i], y = (double)xyz[3 * i + 1], z = (double)xyz[3 * i + 2];
+        int ix = 0, iy = 0, iz = 0;      // getGridIndex: a point outside the map lands in voxel (0,0,0) (:137-140)
+        const bool in = !(x < G.bmin[0] || y < G.bmin[1] || z < G.bmin[2] || x > G.bmax[0] || y > G.bmax[1] || z > G.bmax[2]);
+        if (in) {
+            ix = (int)floor((x - G.bmin[0]) / G.res); iy = (int)floor((y - G.bmin[1]) / G.res); iz = (int)floor((z - G.bmin[2]) / G.res);
+            if (ix >= G.X) ix = G.X - 1;       // the lower clamps of :149-168 cannot trigger inside the map
+            if (iy >= G.Y) iy = G.Y - 1;
+            if (iz >= G.Z) iz = G.Z - 1;
+        }
+        atomicAdd(&counts[((size_t)ix * G.Y + iy) * G.Z + iz], 1u);
+    }
+}
+__global__ __launch_bounds__(256) void pc_threshold_kernel(const unsigned *__restrict__ counts, size_t n, unsigned thr, uint8_t *__restrict__ occ) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+        occ[i] = counts[i] >= thr ? 1 : 0;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// exact Euclidean distance transform
+// ---------------------------------------------------------------------------------------------------------------
+// z pass: one lane per voxel of a z-row chunk; the row's occupancy bits (ballot) give the nearest set bit on both sides.
+__global__ __launch_bounds__(256) void edt_z_kernel(DevGrid G, const unsigned *__restrict__ bits, int *__restrict__ d2) {
+    const size_t n_rows = (size_t)G.X * G.Y;
+    const size_t row0 = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6, n_waves = ((size_t)gridDim.x * blockDim.x) >> 6;
+    const int lane = threadIdx.x & 63;
+    for (size_t row = row0; row < n_rows; row += n_waves) {
+        const unsigned *rb = bits + row * G.ZW;
+        for (int z = lane; z < G.Z; z += 64) {
+            // nearest set bit at or below z, and above z
+            int best = EDT_INF;
+            int w = z >> 5;
+            unsigned m = rb[w] & (0xFFFFFFFFu >> (31 - (z & 31)));
+            int ww = w;
+            while (!m && ww > 0) m = rb[--ww];
+            if (m) { const int p = (ww << 5) + 31 - __clz(m); best = (z - p) * (z - p); }
+            m = (z & 31) == 31 ? 0u : (rb[w] & (0xFFFFFFFFu << ((z & 31) + 1)));
+            ww = w;
+            while (!m && ww + 1 < G.ZW) m = rb[++ww];
+            if (m) { const int p = (ww << 5) + __ffs(m) - 1; if (p < G.Z) best = min(best, (p - z) * (p - z)); }
+            d2[row * G.Z + z] = best;
+        }
+    }
+}
+// y / x pass: thread per voxel, lanes along z (coalesced); out(q) = min_p (q - p)^2 + in(p) over the line through q.
+// AXIS 1: line along y (stride Z); AXIS 0: line along x (stride Y*Z) and the final res * sqrt conversion.
+template <int AXIS>
+__global__ __launch_bounds__(256) void edt_line_kernel(DevGrid G, const int *__restrict__ in, int *__restrict__ out_i, float *__restrict__ out_f) {
+    const size_t total = (size_t)G.X * G.Y * G.Z;
+    const int n = AXIS == 1 ? G.Y : G.X;
+    const size_t stride = AXIS == 1 ? (size_t)G.Z : (size_t)G.Y * G.Z;
+    for (size_t a = (size_t)blockIdx.x * blockDim.x + threadIdx.x; a < total; a += (size_t)gridDim.x * blockDim.x) {
+        const int q = AXIS == 1 ? (int)((a / G.Z) % G.Y) : (int)(a / ((size_t)G.Y * G.Z));
+        int best = in[a];
+        for (int r = 1; r < n; r++) {
+            const int rr = r * r;
+            if (rr >= best) break;                       // farther samples cost at least r^2
+            if (q - r >= 0) best = min(best, rr + in[a - (size_t)r * stride]);      // INF + rr stays < 2^31
+            if (q + r < n) best = min(best, rr + in[a + (size_t)r * stride]);
+        }
+        if (AXIS == 1) out_i[a] = best;
+        else {
+            // grid_esdf = grid_resolution * std::sqrt(val) (Gridmap3D.cpp:409); no occupied voxel -> sqrt(DBL_MAX)
+            const double v = best >= EDT_INF ? 1.7976931348623157e308 : (double)best;
+            out_f[a] = (float)(G.res * sqrt(v));
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// constraint-point gather
+// ---------------------------------------------------------------------------------------------------------------
+struct GatherBox { int lo[3], hi[3], llo[3], lhi[3]; };    // this waypoint's index box and the previous waypoint's
+__global__ __launch_bounds__(256) void gather_mark_kernel(DevGrid G, const GatherBox *__restrict__ boxes, const unsigned *__restrict__ occ_bits,
+                                                          unsigned *__restrict__ marks) {
+    const GatherBox b = boxes[blockIdx.x];
+    const int nx = b.hi[0] - b.lo[0] + 1, ny = b.hi[1] - b.lo[1] + 1, nz = b.hi[2] - b.lo[2] + 1;
+    const long long nvox = (long long)nx * ny * nz;
+    for (long long t = threadIdx.x; t < nvox; t += blockDim.x) {
+        const int k = b.lo[2] + (int)(t % nz), j = b.lo[1] + (int)((t / nz) % ny), i = b.lo[0] + (int)(t / ((long long)nz * ny));
+        const bool outside_last = i > b.lhi[0] || i < b.llo[0] || j > b.lhi[1] || j < b.llo[1] || k > b.lhi[2] || k < b.llo[2];
+        if (!outside_last) continue;
+        const size_t w = ((size_t)i * G.Y + j) * G.ZW + (k >> 5);
+        const unsigned bit = 1u << (k & 31);
+        if (occ_bits[w] & bit) atomicOr(&marks[w], bit);
+    }
+}
+constexpr int GATHER_CHUNK = 1024;     // words per block in the count / emit kernels
+__global__ __launch_bounds__(256) void gather_count_kernel(const unsigned *__restrict__ marks, size_t n_words, unsigned *__restrict__ chunk_cnt) {
+    __shared__ unsigned s[256];
+    const size_t base = (size_t)blockIdx.x * GATHER_CHUNK;
+    unsigned c = 0;
+    for (int t = threadIdx.x; t < GATHER_CHUNK; t += 256) if (base + t < n_words) c += __popc(marks[base + t]);
+    s[threadIdx.x] = c;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) { if ((int)threadIdx.x < o) s[threadIdx.x] += s[threadIdx.x + o]; __syncthreads(); }
+    if (threadIdx.x == 0) chunk_cnt[blockIdx.x] = s[0];
+}
+__global__ __launch_bounds__(256) void gather_scan_kernel(unsigned *chunk_cnt, int n_chunks, unsigned *total) {   // one block
+    __shared__ unsigned s_carry;
+    __shared__ unsigned s[256];
+    if (threadIdx.x == 0) s_carry = 0;
+    __syncthreads();
+    for (int b0 = 0; b0 < n_chunks; b0 += 256) {
+        const int i = b0 + threadIdx.x;
+        const unsigned v = i < n_chunks ? chunk_cnt[i] : 0u;
+        s[threadIdx.x] = v;
+        __syncthreads();
+        for (int o = 1; o < 256; o <<= 1) {
+            const unsigned add = (int)threadIdx.x >= o ? s[threadIdx.x - o] : 0u;
+            __syncthreads();
+            s[threadIdx.x] += add;
+            __syncthreads();
+        }
+        if (i < n_chunks) chunk_cnt[i] = s_carry + s[threadIdx.x] - v;      // exclusive offset
+        __syncthreads();
+        if (threadIdx.x == 255) s_carry += s[255];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) *total = s_carry;
+}
+__global__ __launch_bounds__(64) void gather_emit_kernel(DevGrid G, const unsigned *__restrict__ marks, size_t n_words,
+                                                         const unsigned *__restrict__ chunk_off, double *__restrict__ pts, unsigned cap) {
+    // one wave per chunk: words in ascending order -> points sorted by (ix, iy, iz)
+    const size_t base = (size_t)blockIdx.x * GATHER_CHUNK;
+    unsigned off = chunk_off[blockIdx.x];
+    const int lane = threadIdx.x;
+    for (int t0 = 0; t0 < GATHER_CHUNK; t0 += 64) {
+        const size_t w = base + t0 + lane;
+        unsigned m = w < n_words ? marks[w] : 0u;
+        const int c = __popc(m);
+        int incl = c;                                        // inclusive scan over the wave
+        for (int o = 1; o < 64; o <<= 1) { const int v = __shfl_up(incl, o, 64); if (lane >= o) incl += v; }
+        unsigned pos = off + (unsigned)(incl - c);
+        const size_t row = w / G.ZW;
+        const int zw = (int)(w - row * G.ZW);
+        const int ix = (int)(row / G.Y), iy = (int)(row - (size_t)ix * G.Y);
+        while (m) {
+            const int z = (zw << 5) + __ffs(m) - 1;
+            m &= m - 1u;
+            if (pos < cap) {     // getGridCubeCenter (Gridmap3D.cpp:182-194)
+                pts[3 * (size_t)pos] = (ix + 0.5) * G.res + G.bmin[0];
+                pts[3 * (size_t)pos + 1] = (iy + 0.5) * G.res + G.bmin[1];
+                pts[3 * (size_t)pos + 2] = (z + 0.5) * G.res + G.bmin[2];
+            }
+            pos++;
+        }
+        off += (unsigned)__shfl(incl, 63, 64);
+    }
+}
+
+void launch_build_bits(const DevGrid &G, int use_esdf, float thresh, unsigned *out, hipStream_t stream);   // tile_sweep.hip
+
+} // namespace isdf
+
+using namespace isdf;
+
+static size_t n_bit_words(const DevGrid &G) { return (size_t)G.X * G.Y * ((G.Z + 31) / 32); }
+
+// occupancy bit-grid (padding bits of the last word of a row are zero)
+static int occupancy_bits(isdf_ctx *c, unsigned **out_bits) {
+    DevGrid G = c->grid;
+    G.ZW = (G.Z + 31) / 32;
+    unsigned *b = nullptr;
+    HIPCHK(c, hipMalloc(&b, n_bit_words(G) * sizeof(unsigned)));
+    G.occ = c->d_occ;
+    launch_build_bits(G, 0, 0.0f, b, c->stream);
+    *out_bits = b;
+    return ISDF_OK;
+}
+
+extern "C" int isdf_set_pointcloud(isdf_ctx *c, const float *xyz, long long n_points, const double *bmin_opt, const double *bmax_opt,
+                                   double resolution, int sta_threshold, int dims_out[3]) {
+    if (!c) return ISDF_ERR_INVALID_ARG;
+    if (!xyz || n_points < 1 || !(resolution > 0) || sta_threshold < 0) return isdf_fail(c, ISDF_ERR_INVALID_ARG, "bad point cloud arguments");
+    if ((bmin_opt == nullptr) != (bmax_opt == nullptr)) return isdf_fail(c, ISDF_ERR_INVALID_ARG, "give both boundaries or neither");
+    HIPCHK(c, hipSetDevice(c->device));
+    double bmin[3], bmax[3];
+    if (bmin_opt) { for (int a = 0; a < 3; a++) { bmin[a] = bmin_opt[a]; bmax[a] = bmax_opt[a]; } }
+    else {   // "measure boundary": the tight box of the cloud (PCSmap_manager.cpp:110-141)
+        for (int a = 0; a < 3; a++) { bmin[a] = 1.0e300; bmax[a] = -1.0e300; }
+        for (long long i = 0; i < n_points; i++)
+            for (int a = 0; a < 3; a++) {
+                const double v = (double)xyz[3 * i + a];
+                if (v > bmax[a]) bmax[a] = v;
+                if (v < bmin[a]) bmin[a] = v;
+            }
+    }
+    long long dim[3];
+    for (int a = 0; a < 3; a++) {
+        dim[a] = (long long)std::ceil((bmax[a] - bmin[a]) / resolution);      // createGridMap (Gridmap3D.cpp:29-31)
+        if (dim[a] < 1 || dim[a] > 4096) return isdf_fail(c, ISDF_ERR_INVALID_ARG, "grid dimension out of range [1, 4096]");
+    }
+    const size_t n = (size_t)dim[0] * dim[1] * dim[2];
+    if (c->d_esdf) { (void)hipFree(c->d_esdf); c->d_esdf = nullptr; }
+    if (c->d_occ) { (void)hipFree(c->d_occ); c->d_occ = nullptr; }
+    c->grid.X = (int)dim[0]; c->grid.Y = (int)dim[1]; c->grid.Z = (int)dim[2]; c->grid.res = resolution;
+    for (int a = 0; a < 3; a++) { c->grid.bmin[a] = bmin[a]; c->grid.bmax[a] = bmax[a]; }
+    c->have_geom = true;
+    float *d_xyz = nullptr; unsigned *d_cnt = nullptr;
+    HIPCHK(c, hipMalloc(&d_xyz, (size_t)n_points * 3 * sizeof(float)));
+    HIPCHK(c, hipMalloc(&d_cnt, n * sizeof(unsigned)));
+    HIPCHK(c, hipMalloc(&c->d_occ, n));
+    HIPCHK(c, hipMemcpyAsync(d_xyz, xyz, (size_t)n_points * 3 * sizeof(float), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemsetAsync(d_cnt, 0, n * sizeof(unsigned), c->stream));
+    hipLaunchKernelGGL(pc_count_kernel, dim3(2048), dim3(256), 0, c->stream, d_xyz, n_points, c->grid, d_cnt);
+    hipLaunchKernelGGL(pc_threshold_kernel, dim3(4096), dim3(256), 0, c->stream, d_cnt, n, (unsigned)sta_threshold, c->d_occ);
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    (void)hipFree(d_xyz); (void)hipFree(d_cnt);
+    c->grid.esdf = nullptr; c->grid.occ = c->d_occ;
+    c->bits_dirty = true;
+    if (dims_out) { dims_out[0] = (int)dim[0]; dims_out[1] = (int)dim[1]; dims_out[2] = (int)dim[2]; }
+    return ISDF_OK;
+}
+
+extern "C" int isdf_generate_esdf(isdf_ctx *c) {
+    if (!c) return ISDF_ERR_INVALID_ARG;
+    if (!c->have_geom || !c->d_occ) return isdf_fail(c, ISDF_ERR_STATE, "generate_esdf needs an occupancy grid");
+    HIPCHK(c, hipSetDevice(c->device));
+    DevGrid G = c->grid;
+    G.ZW = (G.Z + 31) / 32;
+    const size_t n = (size_t)G.X * G.Y * G.Z;
+    unsigned *bits = nullptr;
+    int rc = occupancy_bits(c, &bits);
+    if (rc) return rc;
+    int *a = nullptr, *b = nullptr;
+    HIPCHK(c, hipMalloc(&a, n * sizeof(int)));
+    HIPCHK(c, hipMalloc(&b, n * sizeof(int)));
+    if (c->d_esdf) { (void)hipFree(c->d_esdf); c->d_esdf = nullptr; }
+    HIPCHK(c, hipMalloc(&c->d_esdf, n * sizeof(float)));
+    hipLaunchKernelGGL(edt_z_kernel, dim3(4096), dim3(256), 0, c->stream, G, bits, a);
+    hipLaunchKernelGGL(edt_line_kernel<1>, dim3(8192), dim3(256), 0, c->stream, G, a, b, (float *)nullptr);
+    hipLaunchKernelGGL(edt_line_kernel<0>, dim3(8192), dim3(256), 0, c->stream, G, b, (int *)nullptr, c->d_esdf);
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    (void)hipFree(a); (void)hipFree(b); (void)hipFree(bits);
+    c->grid.esdf = c->d_esdf;
+    c->bits_dirty = true;
+    return ISDF_OK;
+}
+
+extern "C" int isdf_get_grid(isdf_ctx *c, int grid_kind, void *out, int dtype, int dims_out[3], double origin_out[3], double bmax_out[3]) {
+    if (!c) return ISDF_ERR_INVALID_ARG;
+    if (!c->have_geom) return isdf_fail(c, ISDF_ERR_STATE, "no grid set");
+    HIPCHK(c, hipSetDevice(c->device));
+    if (dims_out) { dims_out[0] = c->grid.X; dims_out[1] = c->grid.Y; dims_out[2] = c->grid.Z; }
+    for (int a = 0; a < 3; a++) { if (origin_out) origin_out[a] = c->grid.bmin[a]; if (bmax_out) bmax_out[a] = c->grid.bmax[a]; }
+    if (!out) return ISDF_OK;
+    const size_t n = (size_t)c->grid.X * c->grid.Y * c->grid.Z;
+    if (grid_kind == ISDF_GRID_ESDF) {
+        if (!c->d_esdf) return isdf_fail(c, ISDF_ERR_STATE, "no ESDF grid");
+        if (dtype != ISDF_F32) return isdf_fail(c, ISDF_ERR_UNSUPPORTED, "the ESDF is stored as float32");
+        HIPCHK(c, hipMemcpy(out, c->d_esdf, n * sizeof(float), hipMemcpyDeviceToHost));
+    } else if (grid_kind == ISDF_GRID_OCCUPANCY) {
+        if (!c->d_occ) return isdf_fail(c, ISDF_ERR_STATE, "no occupancy grid");
+        if (dtype != ISDF_U8) return isdf_fail(c, ISDF_ERR_UNSUPPORTED, "the occupancy grid is stored as uint8");
+        HIPCHK(c, hipMemcpy(out, c->d_occ, n, hipMemcpyDeviceToHost));
+    } else return isdf_fail(c, ISDF_ERR_INVALID_ARG, "bad grid kind");
+    return ISDF_OK;
+}
+
+// projInMap + getGridIndex of a box corner (PCSmap_manager.h:130-137, Gridmap3D.cpp:135-175)
+static void corner_index(const DevGrid &G, const double p[3], int idx[3]) {
+    const int dim[3] = {G.X, G.Y, G.Z};
+    for (int a = 0; a < 3; a++) {
+        double v = p[a];
+        if (v < G.bmin[a]) v = G.bmin[a];
+        if (v > G.bmax[a]) v = G.bmax[a];
+        int i = (int)std::floor((v - G.bmin[a]) / G.res);
+        if (i < 0) i = 0;
+        if (i >= dim[a]) i = dim[a] - 1;
+        idx[a] = i;
+    }
+}
+
+extern "C" int isdf_gather_points(isdf_ctx *c, const double *waypoints, int n_waypoints, const double half[3], const double *offset_opt,
+                                  int *M_out) {
+    if (!c) return ISDF_ERR_INVALID_ARG;
+    if (n_waypoints < 0 || (n_waypoints > 0 && !waypoints) || !half) return isdf_fail(c, ISDF_ERR_INVALID_ARG, "bad waypoint arguments");
+    if (!c->have_geom || !c->d_occ) return isdf_fail(c, ISDF_ERR_STATE, "gather_points needs an occupancy grid");
+    HIPCHK(c, hipSetDevice(c->device));
+    DevGrid G = c->grid;
+    G.ZW = (G.Z + 31) / 32;
+    const double off[3] = {offset_opt ? offset_opt[0] : 0.0, offset_opt ? offset_opt[1] : 0.0, offset_opt ? offset_opt[2] : 0.0};
+    std::vector<GatherBox> boxes(n_waypoints);
+    double last[3] = {999, 999, 999};             // tmp_pos of plan_manager.cpp:228
+    for (int w = 0; w < n_waypoints; w++) {
+        const double *p = waypoints + 3 * w;
+        double c1[3], c2[3], l1[3], l2[3];
+        for (int a = 0; a < 3; a++) {
+            c1[a] = p[a] - half[a] + off[a]; c2[a] = p[a] + half[a] + off[a];     // the offset shifts this box only (:184-185 vs :191-192)
+            l1[a] = last[a] - half[a]; l2[a] = last[a] + half[a];
+        }
+        corner_index(G, c1, boxes[w].lo); corner_index(G, c2, boxes[w].hi);
+        corner_index(G, l1, boxes[w].llo); corner_index(G, l2, boxes[w].lhi);
+        for (int a = 0; a < 3; a++) last[a] = p[a];
+    }
+    int M = 0;
+    if (c->d_points) { (void)hipFree(c->d_points); c->d_points = nullptr; }
+    if (c->d_tstar) { (void)hipFree(c->d_tstar); c->d_tstar = nullptr; }
+    c->M = 0;
+    if (n_waypoints > 0) {
+        const size_t nw = n_bit_words(G);
+        const int n_chunks = (int)((nw + GATHER_CHUNK - 1) / GATHER_CHUNK);
+        unsigned *bits = nullptr, *marks = nullptr, *chunk = nullptr;
+        GatherBox *d_boxes = nullptr;
+        int rc = occupancy_bits(c, &bits);
+        if (rc) return rc;
+        HIPCHK(c, hipMalloc(&marks, nw * sizeof(unsigned)));
+        HIPCHK(c, hipMalloc(&chunk, ((size_t)n_chunks + 1) * sizeof(unsigned)));
+        HIPCHK(c, hipMalloc(&d_boxes, boxes.size() * sizeof(GatherBox)));
+        HIPCHK(c, hipMemsetAsync(marks, 0, nw * sizeof(unsigned), c->stream));
+        HIPCHK(c, hipMemcpyAsync(d_boxes, boxes.data(), boxes.size() * sizeof(GatherBox), hipMemcpyHostToDevice, c->stream));
+        hipLaunchKernelGGL(gather_mark_kernel, dim3(n_waypoints), dim3(256), 0, c->stream, G, d_boxes, bits, marks);
+        hipLaunchKernelGGL(gather_count_kernel, dim3(n_chunks), dim3(256), 0, c->stream, marks, nw, chunk);
+        hipLaunchKernelGGL(gather_scan_kernel, dim3(1), dim3(256), 0, c->stream, chunk, n_chunks, chunk + n_chunks);
+        unsigned total = 0;
+        HIPCHK(c, hipMemcpyAsync(&total, chunk + n_chunks, sizeof(unsigned), hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        M = (int)total;
+        if (M > 0) {
+            HIPCHK(c, hipMalloc(&c->d_points, (size_t)3 * M * sizeof(double)));
+            HIPCHK(c, hipMalloc(&c->d_tstar, (size_t)M * sizeof(double)));
+            HIPCHK(c, hipMemsetAsync(c->d_tstar, 0, (size_t)M * sizeof(double), c->stream));     // lastTstar = 0 (plan_manager.cpp:254)
+            hipLaunchKernelGGL(gather_emit_kernel, dim3(n_chunks), dim3(64), 0, c->stream, G, marks, nw, chunk, c->d_points, total);
+            HIPCHK(c, hipGetLastError());
+            HIPCHK(c, hipStreamSynchronize(c->stream));
+        }
+        (void)hipFree(bits); (void)hipFree(marks); (void)hipFree(chunk); (void)hipFree(d_boxes);
+    }
+    c->M = M;
+    if (M_out) *M_out = M;
+    return ISDF_OK;
+}
+
+extern "C" int isdf_get_points(isdf_ctx *c, double *xyz_out, int capacity) {
+    if (!c) return ISDF_ERR_INVALID_ARG;
+    if (capacity < 0 || (capacity > 0 && !xyz_out)) return isdf_fail(c, ISDF_ERR_INVALID_ARG, "bad output buffer");
+    HIPCHK(c, hipSetDevice(c->device));
+    const int n = c->M < capacity ? c->M : capacity;
+    if (n > 0) HIPCHK(c, hipMemcpy(xyz_out, c->d_points, (size_t)3 * n * sizeof(double), hipMemcpyDeviceToHost));
+    return c->M;
+}

@@ -101,6 +101,53 @@ class Engine:
         pts = np.ascontiguousarray(pts, dtype=np.float64).reshape(-1, 3)
         self._check(self.lib.isdf_set_points(self.h, _p(pts), pts.shape[0]))
 
+    # ---- map products built on the device
+    def set_pointcloud(self, xyz, res, sta_threshold=1, bmin=None, bmax=None):
+        """xyz: n x 3 float32 (pcl::PointXYZ).  Returns the grid dimensions."""
+        pts = np.ascontiguousarray(xyz, dtype=np.float32).reshape(-1, 3)
+        dims = (C.c_int * 3)()
+        bm0 = None if bmin is None else np.asarray(bmin, dtype=np.float64)
+        bm1 = None if bmax is None else np.asarray(bmax, dtype=np.float64)
+        self._check(self.lib.isdf_set_pointcloud(self.h, pts.ctypes.data_as(C.POINTER(C.c_float)), pts.shape[0],
+                                                 None if bm0 is None else _p(bm0), None if bm1 is None else _p(bm1),
+                                                 float(res), int(sta_threshold), dims))
+        return tuple(dims)
+
+    def generate_esdf(self):
+        self._check(self.lib.isdf_generate_esdf(self.h))
+
+    def get_grid(self, kind):
+        dims = (C.c_int * 3)()
+        o = np.zeros(3); bm = np.zeros(3)
+        self._check(self.lib.isdf_get_grid(self.h, kind, None, capi.F32, dims, _p(o), _p(bm)))
+        shape = tuple(dims)
+        if kind == capi.GRID_ESDF:
+            out = np.zeros(shape, dtype=np.float32); dt = capi.F32
+        else:
+            out = np.zeros(shape, dtype=np.uint8); dt = capi.U8
+        self._check(self.lib.isdf_get_grid(self.h, kind, out.ctypes.data_as(C.c_void_p), dt, dims, _p(o), _p(bm)))
+        return out, o, bm
+
+    def gather_points(self, waypoints, half, offset=None):
+        W = np.ascontiguousarray(np.asarray(waypoints, dtype=np.float64).reshape(-1, 3))
+        h = np.asarray(half, dtype=np.float64) * np.ones(3)
+        off = None if offset is None else np.asarray(offset, dtype=np.float64)
+        M = C.c_int(0)
+        self._check(self.lib.isdf_gather_points(self.h, _p(W) if W.size else None, W.shape[0], _p(h),
+                                                None if off is None else _p(off), C.byref(M)))
+        return M.value
+
+    def get_points(self):
+        M = self.lib.isdf_get_points(self.h, None, 0)
+        if M < 0:
+            self._check(M)
+        out = np.zeros((M, 3))
+        if M:
+            rc = self.lib.isdf_get_points(self.h, _p(out), M)
+            if rc < 0:
+                self._check(rc)
+        return out
+
     def set_shard(self, rank, world):
         self._check(self.lib.isdf_set_shard(self.h, rank, world))
 

@@ -163,6 +163,30 @@ int isdf_set_points(isdf_ctx *ctx, const double *xyz, int M);   /* V1: M x 3 row
  * for V1); outputs of all ranks SUM to the full result (one all-reduce of [cost|gradT|gradC] per step). */
 int isdf_set_shard(isdf_ctx *ctx, int rank, int world_size);
 
+/* ---- once-per-plan map products, built on the device ------------------------------------------------------------ */
+/* Point cloud -> occupancy grid (PCSmapManager::rcvGlobalMapHandler, src/map_manager/src/PCSmap_manager.cpp:87-200):
+ * xyz = n_points x 3 floats (pcl::PointXYZ).  bmin/bmax NULL => the tight box of the cloud ("measure boundary",
+ * :110-141).  Grid size ceil((max-min)/res) (Gridmap3D.cpp:29-31); a voxel is occupied iff it collected >=
+ * sta_threshold points; points outside the box count for voxel (0,0,0) like getGridIndex does (:137-140).
+ * Replaces any grid set before.  dims_out (nullable) receives nx, ny, nz. */
+int isdf_set_pointcloud(isdf_ctx *ctx, const float *xyz, long long n_points, const double *bmin, const double *bmax,
+                        double resolution, int sta_threshold, int dims_out[3]);
+/* Occupancy -> unsigned ESDF in metres (GridMap3D::generateESDF3d, Gridmap3D.cpp:361-414: the exact Euclidean distance
+ * to the nearest occupied voxel centre, res*sqrt(d2)); installs it as the ISDF_GRID_ESDF grid (float32). */
+int isdf_generate_esdf(isdf_ctx *ctx);
+/* Download a grid (out may be NULL to query the geometry only).  dtype must be ISDF_F32 for the ESDF, ISDF_U8 for the
+ * occupancy grid. */
+int isdf_get_grid(isdf_ctx *ctx, int grid_kind, void *out, int dtype, int dims_out[3], double origin_out[3], double bmax_out[3]);
+/* Obstacle-point set of the swept-volume sweep (plan_manager.cpp:232-254): for every waypoint, the occupied voxel
+ * centres inside the box [w - half + offset, w + half + offset] that are outside the previous waypoint's box
+ * [w_prev - half, w_prev + half] (getPointsInAABBOutOfLastOne, PCSmap_manager.h:182-216; the first "previous" is
+ * (999,999,999)), united over the waypoints.  Installs the set like isdf_set_points (ordered by voxel index; the
+ * reference's unordered_map order is unspecified) and resets lastTstar to 0.  offset may be NULL. */
+int isdf_gather_points(isdf_ctx *ctx, const double *waypoints, int n_waypoints, const double half[3], const double *offset,
+                       int *M_out);
+/* Copies up to `capacity` points (M x 3 row-major) and returns M (>= 0), or a negative isdf_status. */
+int isdf_get_points(isdf_ctx *ctx, double *xyz_out, int capacity);
+
 /* ---- per-step evaluation ----------------------------------------------------------------------------------- */
 /* Host entry point, synchronous, drop-in for the reference sweeps.  n_traj trajectories (1 in the reference);
  * N[b] pieces each; T[b] -> N[b] doubles; coeffs[b] -> 6N[b] x 3 column-major.

@@ -226,3 +226,56 @@ class RefFwn:
         W = np.zeros(Q.shape[0])
         self.lib.ref_fwn_eval(self.h, _p(Q), C.c_int(Q.shape[0]), C.c_double(accuracy), _p(W))
         return W
+
+
+# ---- map products (integer / byte work restated with numpy) -----------------------------------------------------
+def pointcloud_to_occupancy(xyz_f32, res, sta_threshold=1, bmin=None, bmax=None):
+    """PCSmapManager::rcvGlobalMapHandler, src/map_manager/src/PCSmap_manager.cpp:108-175: tight boundary of the cloud
+    (:110-141) unless given, createGridMap sizes ceil((max-min)/res) (Gridmap3D.cpp:29-31), every point increments the
+    voxel getGridIndex returns (Gridmap3D.cpp:135-175: out-of-map points -> voxel (0,0,0); upper clamp), a voxel is
+    occupied iff its count >= sta_threshold (:163).  Returns (occ uint8 [X][Y][Z], bmin, bmax)."""
+    P = np.asarray(xyz_f32, dtype=np.float32).reshape(-1, 3).astype(np.float64)
+    if bmin is None:
+        bmin, bmax = P.min(axis=0), P.max(axis=0)
+    bmin = np.asarray(bmin, dtype=np.float64); bmax = np.asarray(bmax, dtype=np.float64)
+    dims = np.ceil((bmax - bmin) / res).astype(np.int64)
+    inside = np.all((P >= bmin) & (P <= bmax), axis=1)
+    idx = np.floor((P - bmin) / res).astype(np.int64)
+    idx = np.minimum(idx, dims - 1)
+    idx[~inside] = 0
+    counts = np.zeros(tuple(dims), dtype=np.int64)
+    np.add.at(counts, (idx[:, 0], idx[:, 1], idx[:, 2]), 1)
+    return (counts >= sta_threshold).astype(np.uint8), bmin, bmax
+
+
+def gather_points(occ, bmin, bmax, res, waypoints, half, offset=(0.0, 0.0, 0.0)):
+    """plan_manager.cpp:228-254 + getPointsInAABBOutOfLastOne (PCSmap_manager.h:182-216): for waypoint w the index box of
+    [w - half + offset, w + half + offset] (corners projected into the map, floor-indexed), minus the index box of the
+    PREVIOUS waypoint WITHOUT offset (first previous = (999,999,999)); occupied voxels only; a map keyed by voxel id
+    (here: sorted by (ix, iy, iz)).  Returns the voxel centres, M x 3."""
+    occ = np.asarray(occ)
+    dims = np.array(occ.shape)
+    bmin = np.asarray(bmin, dtype=np.float64); bmax = np.asarray(bmax, dtype=np.float64)
+    half = np.asarray(half, dtype=np.float64) * np.ones(3)
+    offset = np.asarray(offset, dtype=np.float64)
+
+    def corner(p):
+        q = np.minimum(np.maximum(p, bmin), bmax)
+        i = np.floor((q - bmin) / res).astype(np.int64)
+        return np.minimum(np.maximum(i, 0), dims - 1)
+    ids = set()
+    last = np.array([999.0, 999.0, 999.0])
+    for w in np.asarray(waypoints, dtype=np.float64).reshape(-1, 3):
+        lo, hi = corner(w - half + offset), corner(w + half + offset)
+        llo, lhi = corner(last - half), corner(last + half)
+        for i in range(lo[0], hi[0] + 1):
+            for j in range(lo[1], hi[1] + 1):
+                for k in range(lo[2], hi[2] + 1):
+                    out_last = i > lhi[0] or i < llo[0] or j > lhi[1] or j < llo[1] or k > lhi[2] or k < llo[2]
+                    if out_last and occ[i, j, k]:
+                        ids.add((i, j, k))
+        last = w
+    if not ids:
+        return np.zeros((0, 3))
+    I = np.array(sorted(ids), dtype=np.float64)
+    return (I + 0.5) * res + bmin

@@ -203,3 +203,25 @@ def test_swept_volume_query_properties(pkg, orc):
     assert abs(np.linalg.norm(g) - 1.0) < 1e-6
     s_far, ts_far, _, nr_far = o.swept_sdf(T, cm, st[0] + np.array([0, 0, 40.0]), tstar0=1.25)
     assert nr_far == 0 and s_far == 10.0 and ts_far == 1.25   # outputs untouched
+
+
+def test_map_product_restatements(pkg, orc):
+    """oracle.pointcloud_to_occupancy / gather_points (numpy restatements of rcvGlobalMapHandler and
+    getPointsInAABBOutOfLastOne) against first principles."""
+    synth = pkg.synth
+    rng = np.random.default_rng(2)
+    P = rng.uniform(0, 4, (5000, 3)).astype(np.float32)
+    occ, b0, b1 = orc.pointcloud_to_occupancy(P, 0.5, 1)
+    assert occ.shape == tuple(np.ceil((b1 - b0) / 0.5).astype(int)) and occ.all()      # 5000 points in 512 voxels
+    occ3, _, _ = orc.pointcloud_to_occupancy(P, 0.5, 30)
+    assert 0 <= occ3.sum() < occ.sum()
+    # brute force count for one voxel
+    idx = np.minimum(np.floor((P.astype(np.float64) - b0) / 0.5).astype(int), np.array(occ.shape) - 1)
+    cnt = np.sum(np.all(idx == np.array([2, 3, 1]), axis=1))
+    assert occ3[2, 3, 1] == (1 if cnt >= 30 else 0)
+    # with zero offset the "out of the last box" rule only avoids duplicates: same set as the plain union
+    occm = synth.random_box_map((30, 28, 20), res=0.5, occupancy=0.15, seed=4, edge=(1.0, 2.0))
+    way = rng.uniform(3, 11, (5, 3)) * np.array([1.0, 1.0, 0.7])
+    a = orc.gather_points(occm, np.zeros(3), np.array(occm.shape) * 0.5, 0.5, way, 1.6)
+    b = synth.constraint_points(occm, (0, 0, 0), 0.5, way, 1.6)
+    assert a.shape == b.shape and np.array_equal(a, b)
