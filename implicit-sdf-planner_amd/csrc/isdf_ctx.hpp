@@ -36,6 +36,7 @@ struct isdf_ctx {
     SweepParams last_P{}; bool have_last_P = false;
     double last_exact_ms = 0.0;
     double *d_piece_cost = nullptr; size_t piece_cap = 0;
+    unsigned *d_tail_ticket = nullptr; size_t ticket_cap = 0;
     double *d_in = nullptr; size_t in_cap = 0;        // host-API staging: T | coeffs
     double *d_out = nullptr; size_t out_cap = 0;
     std::vector<double> h_out;

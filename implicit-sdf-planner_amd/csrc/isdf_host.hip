@@ -151,7 +151,7 @@ extern "C" int isdf_destroy(isdf_ctx *c) {
     (void)hipDeviceSynchronize();
     for (auto &p : c->prof_events) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); (void)hipEventDestroy(p.c); }
     if (c->h_pin) (void)hipHostFree(c->h_pin);
-    void *ptrs[] = {c->d_cb, c->d_esdf, c->d_occ, c->d_points, c->d_tstar, c->d_acc, c->d_sample_info, c->d_bits, c->d_piece_cost, c->d_in, c->d_out, c->d_stats,
+    void *ptrs[] = {c->d_tail_ticket, c->d_cb, c->d_esdf, c->d_occ, c->d_points, c->d_tstar, c->d_acc, c->d_sample_info, c->d_bits, c->d_piece_cost, c->d_in, c->d_out, c->d_stats,
                     c->d_traj_duration, c->d_coarse_t, c->d_coarse_pose, c->d_n_coarse, c->d_point_partial, c->d_point_piece, c->d_hist, c->d_dbg};
     for (void *p : ptrs) if (p) (void)hipFree(p);
     free_mesh(c);
@@ -431,6 +431,13 @@ static int eval_device_impl(isdf_ctx *c, int n_traj, int N, const double *d_T, c
     }
     int rc = ensure(c, &c->d_piece_cost, &c->piece_cap, (size_t)total_pieces);
     if (rc) return rc;
+    if (c->ticket_cap < (size_t)n_traj) {
+        if (c->d_tail_ticket) (void)hipFree(c->d_tail_ticket);
+        c->d_tail_ticket = nullptr; c->ticket_cap = 0;
+        HIPCHK(c, hipMalloc(&c->d_tail_ticket, (size_t)n_traj * sizeof(unsigned)));
+        HIPCHK(c, hipMemset(c->d_tail_ticket, 0, (size_t)n_traj * sizeof(unsigned)));
+        c->ticket_cap = (size_t)n_traj;
+    }
     SweepParams P{};
     P.grid = c->grid;
     if (!c->have_geom) { P.grid.X = P.grid.Y = P.grid.Z = 1; P.grid.res = 1.0; }
@@ -448,7 +455,7 @@ static int eval_device_impl(isdf_ctx *c, int n_traj, int N, const double *d_T, c
     P.cull_threshold = 0.0;
     if (cfg.variant == ISDF_V3_ESDF_TILE && cfg.enable_cull && c->shape.bound_radius > 0)
         P.cull_threshold = c->shape.bound_radius + cfg.safety_hor + std::sqrt(3.0) * P.grid.res;
-    P.T = d_T; P.coeffs = d_coeffs; P.acc = c->d_acc; P.sample_info = c->d_sample_info; P.piece_cost = c->d_piece_cost;
+    P.T = d_T; P.coeffs = d_coeffs; P.acc = c->d_acc; P.sample_info = c->d_sample_info; P.piece_cost = c->d_piece_cost; P.tail_ticket = c->d_tail_ticket;
     P.out = d_out; P.stats = c->d_stats;
     P.dbg = nullptr;
     P.dbg_flags = 0;
@@ -487,7 +494,6 @@ static int eval_device_impl(isdf_ctx *c, int n_traj, int N, const double *d_T, c
     if (ev) HIPCHK(c, hipEventRecord(ev->b, st));
     launch_tail(P, st);
     if (ev) HIPCHK(c, hipEventRecord(ev->c, st));
-    launch_finalize(P, st);
     HIPCHK(c, hipGetLastError());
     return ISDF_OK;
 }

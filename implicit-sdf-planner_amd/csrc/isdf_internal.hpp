@@ -35,18 +35,18 @@ struct SweepParams {
     double *acc;                // [n_samples_local][ACC_STRIDE] per-pose collision sums written by sweep_kernel
     int *sample_info;           // [n_samples_local][2] exact pairs, active pairs | culled << 31 (statistics)
     double *piece_cost;         // [n_traj * N]
+    unsigned *tail_ticket;      // [n_traj] blocks of the trajectory that have published their piece cost (self-resetting)
     double *out;                // n_traj * (1 + N + 18N)
     unsigned long long *stats;  // [0]=units [1]=culled [2]=pairs [3]=grad pairs [4]=overflow
     int dbg_flags;              // developer switches (ISDF_DEBUG_FLAGS): 1 = skip the exact pass body
     unsigned long long *dbg;    // developer timing buffer (ISDF_DEBUG_TIMING=1), null on the product path
 };
 
-// one optimizer step of the integral sweep = sweep, tail, finalize, in order, on `stream`
+// one optimizer step of the integral sweep = sweep, tail, in order, on `stream`
 void launch_sweep(const SweepParams &P, hipStream_t stream);
 void launch_stats(const SweepParams &P, hipStream_t stream);   // on demand, not part of the step
 void launch_build_bits(const DevGrid &G, int use_esdf, float thresh, unsigned *out, hipStream_t stream);
 void launch_tail(const SweepParams &P, hipStream_t stream);
-void launch_finalize(const SweepParams &P, hipStream_t stream);
 
 // ---- V1 (swept volume) ----
 struct SweptParams {

@@ -3,7 +3,7 @@
 // with the per-pose tile term grad_cost_p (:766-824) plugged in before the flatness back-prop (:536), the voxel
 // qualifier being occupancy (V2) or esdf <= occ_thresh (V3).
 //
-// One optimizer step = three launches (DESIGN.md "integral sweep"):
+// One optimizer step = two launches (DESIGN.md "integral sweep"):
 //   sweep_kernel<KIND>  one WORKGROUP per 4 consecutive constraint samples, one wavefront per sample:
 //                     (1) poses: one LANE per sample runs the serial fp64 chain (quintic, flatness forward, rotation, the
 //                         tile index box of getPointsInAABB, optional whole-tile cull, the window of tile rows the
@@ -19,9 +19,9 @@
 //                   No atomics, no work lists: results are bitwise reproducible.
 //   tail_kernel     one block per piece, one thread per sample: dynamics penalties, flatness reverse mode,
 //                   beta (x) grad scatter, then a fixed-order in-block sum over the piece's K+1 samples written
-//                   straight into gradC rows 6i..6i+5 and gradT(i).
-//   finalize_kernel one block per trajectory: cost = sum of piece costs (fixed order); zero-fills the entries of
-//                   pieces outside this rank's shard so that the ranks' outputs sum to the full result.
+//                   straight into gradC rows 6i..6i+5 and gradT(i).  The block of a trajectory that finishes last
+//                   adds up the piece costs (fixed order); blocks of pieces outside this rank's shard write zeros so
+//                   that the ranks' outputs sum to the full result.
 // Everything that reaches the result is fp64 except the stored ESDF (fp32).  No MFMA: gather/interpolate work.
 #include "isdf_internal.hpp"
 #include "dev_mesh.hpp"
@@ -250,9 +250,10 @@ __global__ __launch_bounds__(64 * SW_SAMPLES, 3) void sweep_kernel(const SweepPa
     const float bdh_f = (float)P.bd_half + TS_FILTER_EPS;
     const float thr_f = (float)P.safety_hor + TS_FILTER_EPS;
     // pose in the tile's voxel frame, pre-multiplied: m = l*res - pvr,  pvr = ((pos - bmin)/res - 0.5 - lo)*res
-    const float pvx = unif((float)(((sp.pos[0] - G.bmin[0]) / G.res - 0.5 - lox) * G.res));
-    const float pvy = unif((float)(((sp.pos[1] - G.bmin[1]) / G.res - 0.5 - loy) * G.res));
-    const float pvz = unif((float)(((sp.pos[2] - G.bmin[2]) / G.res - 0.5 - loz) * G.res));
+    // (fp32 filter stage only: conservative by TS_FILTER_EPS, so the algebraically equal form without divisions is fine)
+    const float pvx = unif((float)(sp.pos[0] - G.bmin[0] - (0.5 + lox) * G.res));
+    const float pvy = unif((float)(sp.pos[1] - G.bmin[1] - (0.5 + loy) * G.res));
+    const float pvz = unif((float)(sp.pos[2] - G.bmin[2] - (0.5 + loz) * G.res));
 
     // (lx, ly) of window row t, packed lx | ly << 10
     auto row_xy = [&](int t) -> unsigned {
@@ -541,15 +542,27 @@ constexpr int TL_THREADS = 128;
 
 __global__ __launch_bounds__(TL_THREADS) void tail_kernel(const SweepParams P) {
     __shared__ double s_val[TL_THREADS][PARTIAL_STRIDE + 1];   // +1: column reads by 20 threads hit distinct banks
+    __shared__ unsigned s_ticket;
     const int K1 = P.K + 1;
-    const int gp = P.piece_begin + blockIdx.x;
+    const int gp = blockIdx.x;                       // global piece index (trajectory-major): one block per piece of the launch
     const int b = gp / P.N, i = gp - b * P.N;
+    const size_t ostride = (size_t)1 + 19 * (size_t)P.N;
+    const int p0 = max(P.piece_begin, b * P.N) - b * P.N, p1 = min(P.piece_end, (b + 1) * P.N) - b * P.N;   // this rank's pieces of trajectory b
+    if (i < p0 || i >= p1) {
+        // a piece of another rank: its entries are zero here, so that the ranks' outputs sum to the full result
+        double *o = P.out + (size_t)b * ostride;
+        const int q = threadIdx.x;
+        if (q == 18) o[1 + i] = 0.0;
+        else if (q < 18) { const int d = q / 6, r = q - 6 * d; o[1 + P.N + (size_t)d * 6 * P.N + 6 * i + r] = 0.0; }
+        else if (q == 19 && p1 <= p0 && i == 0) o[0] = 0.0;    // no piece of this trajectory is ours
+        return;
+    }
     const double *c = P.coeffs + (size_t)b * 18 * P.N + 6 * i;
     const int ld = 6 * P.N;
     const double integral_frac = 1.0 / P.K;
     const double step = P.T[(size_t)b * P.N + i] * integral_frac;
     double colsum = 0.0;   // threads 0..19: running sum of their output column, samples in ascending order
-    unsigned long long *const dbg = P.dbg ? P.dbg + (size_t)(P.piece_end - P.piece_begin) * K1 * 8 + (size_t)blockIdx.x * 4 : nullptr;
+    unsigned long long *const dbg = P.dbg ? P.dbg + (size_t)(P.piece_end - P.piece_begin) * K1 * 8 + (size_t)(gp - P.piece_begin) * 4 : nullptr;
     if (dbg && threadIdx.x == 0) dbg[0] = wall_clock64();
     for (int j0 = 0; j0 < K1; j0 += TL_THREADS) {
         const int j = j0 + threadIdx.x;
@@ -618,43 +631,30 @@ __global__ __launch_bounds__(TL_THREADS) void tail_kernel(const SweepParams P) {
         }
         __syncthreads();
     }
+    double *o = P.out + (size_t)b * ostride;
     if (threadIdx.x < PARTIAL_STRIDE) {
-        const size_t ostride = (size_t)1 + 19 * (size_t)P.N;
-        double *o = P.out + (size_t)b * ostride;
         const int q = threadIdx.x;
-        if (q == 19) P.piece_cost[gp] = colsum;
-        else if (q == 18) o[1 + i] = colsum;
-        else {
+        if (q == 18) o[1 + i] = colsum;
+        else if (q < 18) {
             const int d = q / 6, r = q - 6 * d;
             o[1 + P.N + (size_t)d * 6 * P.N + 6 * i + r] = colsum;
+        } else {
+            // Trajectory cost = fixed-order sum of the piece costs, formed by whichever block of the trajectory finishes
+            // last: publish this piece's cost write-through (agent-scope store), drain it, take a ticket.
+            __hip_atomic_store(&P.piece_cost[gp], colsum, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            s_ticket = atomicAdd(&P.tail_ticket[b], 1u);
         }
     }
-    if (dbg && threadIdx.x == 0) dbg[1] = wall_clock64();
-}
-
-// ---------------------------------------------------------------------------------------------------------------
-// finalize_kernel: block per trajectory
-// ---------------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void finalize_kernel(const SweepParams P) {
-    const int b = blockIdx.x;
-    const size_t ostride = (size_t)1 + 19 * (size_t)P.N;
-    double *o = P.out + (size_t)b * ostride;
-    unsigned long long *const dbg = (P.dbg && b == 0) ? P.dbg + (size_t)(P.piece_end - P.piece_begin) * (P.K + 1) * 8 + (size_t)(P.piece_end - P.piece_begin) * 4 : nullptr;
-    if (dbg && threadIdx.x == 0) dbg[0] = wall_clock64();
-    const int p0 = max(P.piece_begin, b * P.N) - b * P.N, p1 = min(P.piece_end, (b + 1) * P.N) - b * P.N;   // local piece range in shard
-    // zero the entries of pieces that belong to other ranks
-    for (int e = threadIdx.x; e < 19 * P.N; e += blockDim.x) {
-        int i;
-        if (e < P.N) i = e;
-        else { const int r = (e - P.N) % (6 * P.N); i = r / 6; }
-        if (i < p0 || i >= p1) o[1 + e] = 0.0;
-    }
-    if (threadIdx.x < 64) {
-        double s = 0.0;
-        if (p1 > p0)
-            for (int i = p0 + (int)threadIdx.x; i < p1; i += 64) s += P.piece_cost[(size_t)b * P.N + i];
-        s = wave_sum(s);
-        if (threadIdx.x == 0) o[0] = s;
+    __syncthreads();
+    if (s_ticket == (unsigned)(p1 - p0 - 1)) {       // every other block of this trajectory has published its cost
+        if (threadIdx.x < 64) {
+            double sum = 0.0;
+            for (int k = p0 + (int)threadIdx.x; k < p1; k += 64)
+                sum += __hip_atomic_load(&P.piece_cost[(size_t)b * P.N + k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            sum = wave_sum(sum);
+            if (threadIdx.x == 0) { o[0] = sum; P.tail_ticket[b] = 0u; }     // ticket ready for the next step
+        }
     }
     if (dbg && threadIdx.x == 0) dbg[1] = wall_clock64();
 }
@@ -703,13 +703,7 @@ void launch_build_bits(const DevGrid &G, int use_esdf, float thresh, unsigned *o
 }
 
 void launch_tail(const SweepParams &P, hipStream_t stream) {
-    const int n_pieces = P.piece_end - P.piece_begin;
-    if (n_pieces <= 0) return;
-    hipLaunchKernelGGL(tail_kernel, dim3(n_pieces), dim3(TL_THREADS), 0, stream, P);
-}
-
-void launch_finalize(const SweepParams &P, hipStream_t stream) {
-    hipLaunchKernelGGL(finalize_kernel, dim3(P.n_traj), dim3(256), 0, stream, P);
+    hipLaunchKernelGGL(tail_kernel, dim3(P.n_traj * P.N), dim3(TL_THREADS), 0, stream, P);
 }
 
 } // namespace isdf

@@ -63,7 +63,7 @@ def main():
     print("tail  start us:", pct(us(tl[:, 0])))
     print("tail  end   us:", pct(us(tl[:, 1])))
     print("tail  block duration us:", pct((tl[:, 1] - tl[:, 0]) / 100.0))
-    print("final start/end us:", us(fn[0]), us(fn[1]))
+
 
 
 if __name__ == "__main__":
