@@ -73,6 +73,7 @@ EXPORTED_SYMBOLS = [
     "isdf_profile_read", "isdf_profile_read_secondary", "isdf_get_stats",
     "isdf_set_trajectory", "isdf_num_variables", "isdf_pack_variables", "isdf_unpack_variables",
     "isdf_cost_function", "isdf_cost_function_lmbm", "isdf_cost_parts",
+    "isdf_cost_function_launch", "isdf_cost_function_finish",
     "isdf_lbfgs_params_default", "isdf_lbfgs_minimize", "isdf_optimize_lbfgs",
     "isdf_set_pointcloud", "isdf_generate_esdf", "isdf_get_grid", "isdf_gather_points", "isdf_get_points",
 ]
@@ -120,6 +121,8 @@ def load_library(path=None):
     lib.isdf_cost_function_lmbm.argtypes = [C.c_void_p, dp, dp, C.c_int]
     lib.isdf_cost_function_lmbm.restype = C.c_double
     lib.isdf_cost_parts.argtypes = [C.c_void_p, dp]
+    lib.isdf_cost_function_launch.argtypes = [C.c_void_p, dp, C.c_int, C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]
+    lib.isdf_cost_function_finish.argtypes = [C.c_void_p, dp, dp, C.c_void_p]
     ip = C.POINTER(C.c_int)
     lib.isdf_set_pointcloud.argtypes = [C.c_void_p, C.POINTER(C.c_float), C.c_longlong, dp, dp, C.c_double, C.c_int, ip]
     lib.isdf_generate_esdf.argtypes = [C.c_void_p]

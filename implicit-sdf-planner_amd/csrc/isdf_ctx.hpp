@@ -61,6 +61,7 @@ struct isdf_ctx {
     double *h_pin = nullptr; size_t pin_cap = 0;      // pinned staging: [T | coeffs | out_a | out_b]
     double *d_cb = nullptr; size_t cb_cap = 0;        // device twin of the staging buffer
     double last_parts[4] = {0, 0, 0, 0};
+    std::vector<double> cb_x; double cb_energy = 0.0; int cb_n_out = 1; bool cb_pending = false;
 };
 
 #define HIPCHK(ctx, call)                                                                          \

@@ -618,23 +618,24 @@ extern "C" int isdf_unpack_variables(isdf_ctx *c, const double *x, double *T, do
     return ISDF_OK;
 }
 
-extern "C" int isdf_cost_function(isdf_ctx *c, const double *x, double *g, int n, double *cost_out) {
-    if (!c) return ISDF_ERR_INVALID_ARG;
-    if (!x || !g || !cost_out) return fail(c, ISDF_ERR_INVALID_ARG, "null argument");
+// First half of the callback: tau -> T, MINCO, energy, and the sweeps queued on `st`.  Leaves this rank's partial sums
+// ([cost | gradT | gradC] per sweep, cb_n_out blocks) in c->d_cb + 19N on the device.
+static int cost_function_launch(isdf_ctx *c, const double *x, int n, hipStream_t st) {
+    if (!x) return fail(c, ISDF_ERR_INVALID_ARG, "null argument");
     if (!c->have_traj) return fail(c, ISDF_ERR_STATE, "isdf_set_trajectory not called");
     const int N = c->minco.N;
     if (n != N + 3 * (N - 1)) return fail(c, ISDF_ERR_INVALID_ARG, "n must be N + 3(N-1)");
     HIPCHK(c, hipSetDevice(c->device));
     // tau -> T, xi -> waypoints, MINCO coefficients, energy and its partials (:363-381)
+    c->cb_x.assign(x, x + n);
     for (int i = 0; i < N; i++) c->cb_T[i] = isdf_host::tau_to_T(x[i]);
     c->minco.set_parameters(x + N, c->cb_T.data());
-    double cost = c->minco.energy(c->cb_gdC.data(), c->cb_gdT.data());
-    const double energy = cost;
-    // the two sweeps on the device (:386-405), one round trip
+    c->cb_energy = c->minco.energy(c->cb_gdC.data(), c->cb_gdT.data());
+    // the two sweeps on the device (:386-405)
     const size_t in_len = (size_t)19 * N, ostride = isdf_out_stride(N);
     const bool swept = c->cfg.variant == ISDF_V1_SWEPT;
-    const int n_out = swept ? 2 : 1;
-    const size_t need = in_len + n_out * ostride;
+    c->cb_n_out = swept ? 2 : 1;
+    const size_t need = in_len + c->cb_n_out * ostride;
     if (c->pin_cap < need) {
         if (c->h_pin) (void)hipHostFree(c->h_pin);
         c->h_pin = nullptr; c->pin_cap = 0;
@@ -645,20 +646,35 @@ extern "C" int isdf_cost_function(isdf_ctx *c, const double *x, double *g, int n
     if (rc) return rc;
     std::memcpy(c->h_pin, c->cb_T.data(), (size_t)N * sizeof(double));
     std::memcpy(c->h_pin + N, c->minco.c.data(), (size_t)18 * N * sizeof(double));
-    HIPCHK(c, hipMemcpyAsync(c->d_cb, c->h_pin, in_len * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->d_cb, c->h_pin, in_len * sizeof(double), hipMemcpyHostToDevice, st));
     double *d_T = c->d_cb, *d_C = c->d_cb + N, *d_o = c->d_cb + in_len;
     if (swept) {
-        rc = eval_device_impl(c, 1, N, d_T, d_C, d_o, nullptr, c->stream, 1);
+        rc = eval_device_impl(c, 1, N, d_T, d_C, d_o, nullptr, st, 1);
         if (rc) return rc;
-        rc = eval_device_impl(c, 1, N, d_T, d_C, d_o + ostride, nullptr, c->stream, 2);
+        rc = eval_device_impl(c, 1, N, d_T, d_C, d_o + ostride, nullptr, st, 2);
     } else {
-        rc = eval_device_impl(c, 1, N, d_T, d_C, d_o, nullptr, c->stream, 0);
+        rc = eval_device_impl(c, 1, N, d_T, d_C, d_o, nullptr, st, 0);
     }
     if (rc) return rc;
-    HIPCHK(c, hipMemcpyAsync(c->h_pin + in_len, d_o, n_out * ostride * sizeof(double), hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
+    c->cb_pending = true;
+    return ISDF_OK;
+}
+
+// Second half: download the (all-reduced) sums, add them in the reference's order, propagateGrad, time term, chain rule.
+static int cost_function_finish(isdf_ctx *c, double *g, double *cost_out, hipStream_t st) {
+    if (!g || !cost_out) return fail(c, ISDF_ERR_INVALID_ARG, "null argument");
+    if (!c->cb_pending) return fail(c, ISDF_ERR_STATE, "no callback evaluation in flight");
+    c->cb_pending = false;
+    const int N = c->minco.N;
+    const size_t in_len = (size_t)19 * N, ostride = isdf_out_stride(N);
+    const int n_out = c->cb_n_out;
+    const bool swept = n_out == 2;
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipMemcpyAsync(c->h_pin + in_len, c->d_cb + in_len, n_out * ostride * sizeof(double), hipMemcpyDeviceToHost, st));
+    HIPCHK(c, hipStreamSynchronize(st));
+    double cost = c->cb_energy;
     double part[2] = {0.0, 0.0};
-    for (int k = 0; k < n_out; k++) {       // accumulate in the reference's order: swept-volume sweep, then integral sweep
+    for (int k = 0; k < n_out; k++) {       // swept-volume sweep first, then the integral sweep (:386-405)
         const double *o = c->h_pin + in_len + k * ostride;
         cost += o[0];
         part[k] = o[0];
@@ -670,14 +686,39 @@ extern "C" int isdf_cost_function(isdf_ctx *c, const double *x, double *g, int n
     double tsum = 0.0;
     for (int i = 0; i < N; i++) tsum += c->cb_T[i];
     cost += c->rho * tsum;
-    for (int i = 0; i < N; i++) g[i] = isdf_host::grad_T_to_tau(x[i], c->cb_gradT[i] + c->rho);
+    for (int i = 0; i < N; i++) g[i] = isdf_host::grad_T_to_tau(c->cb_x[i], c->cb_gradT[i] + c->rho);
     for (int i = 0; i < 3 * (N - 1); i++) g[N + i] = c->cb_gradP[i];
-    c->last_parts[0] = energy;
+    c->last_parts[0] = c->cb_energy;
     c->last_parts[1] = swept ? part[0] : 0.0;            // swept-volume sweep
     c->last_parts[2] = swept ? part[1] : part[0];        // integral sweep
     c->last_parts[3] = c->rho * tsum;
     *cost_out = cost;
     return ISDF_OK;
+}
+
+extern "C" int isdf_cost_function(isdf_ctx *c, const double *x, double *g, int n, double *cost_out) {
+    if (!c) return ISDF_ERR_INVALID_ARG;
+    if (!x || !g || !cost_out) return fail(c, ISDF_ERR_INVALID_ARG, "null argument");
+    const int rc = cost_function_launch(c, x, n, c->stream);
+    if (rc) return rc;
+    return cost_function_finish(c, g, cost_out, c->stream);
+}
+
+// Multi-GPU form (one process per GPU, isdf_set_shard): _launch queues this rank's share of the sweeps on `stream` and
+// hands back the device buffer of partial sums; the caller sums it over the ranks IN PLACE on the same stream (one
+// all-reduce, RCCL); _finish then yields the same (cost, g) on every rank.
+extern "C" int isdf_cost_function_launch(isdf_ctx *c, const double *x, int n, void *stream, double **d_partial_out, size_t *count_out) {
+    if (!c) return ISDF_ERR_INVALID_ARG;
+    if (!d_partial_out || !count_out) return fail(c, ISDF_ERR_INVALID_ARG, "null argument");
+    const int rc = cost_function_launch(c, x, n, (hipStream_t)stream);
+    if (rc) return rc;
+    *d_partial_out = c->d_cb + (size_t)19 * c->minco.N;
+    *count_out = (size_t)c->cb_n_out * isdf_out_stride(c->minco.N);
+    return ISDF_OK;
+}
+extern "C" int isdf_cost_function_finish(isdf_ctx *c, double *g, double *cost_out, void *stream) {
+    if (!c) return ISDF_ERR_INVALID_ARG;
+    return cost_function_finish(c, g, cost_out, (hipStream_t)stream);
 }
 
 // Same callback with the signature LMBM / the optimizer drivers bind (lmbm_evaluate_t, lmbm.h:206-209):

@@ -219,6 +219,21 @@ class Engine:
         self._check(self.lib.isdf_cost_function(self.h, _p(x), _p(g), x.size, C.byref(cost)))
         return cost.value, g
 
+    def cost_function_launch(self, x, stream=0):
+        """Multi-GPU form, first half: returns (device pointer, count) of this rank's partial sums (to be all-reduced)."""
+        x = np.ascontiguousarray(x, dtype=np.float64)
+        self._cb_x = x
+        ptr = C.c_void_p()
+        cnt = C.c_size_t(0)
+        self._check(self.lib.isdf_cost_function_launch(self.h, _p(x), x.size, C.c_void_p(stream), C.byref(ptr), C.byref(cnt)))
+        return ptr.value, cnt.value
+
+    def cost_function_finish(self, stream=0):
+        g = np.zeros_like(self._cb_x)
+        cost = C.c_double(0)
+        self._check(self.lib.isdf_cost_function_finish(self.h, _p(g), C.byref(cost), C.c_void_p(stream)))
+        return cost.value, g
+
     def cost_parts(self):
         p = np.zeros(4)
         self._check(self.lib.isdf_cost_parts(self.h, _p(p)))

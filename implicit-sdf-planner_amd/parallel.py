@@ -38,3 +38,22 @@ def allreduce_packed(out_tensor):
 def unpack_out(out, N):
     """(cost, gradT[N], gradC[18N col-major]) views of one trajectory's packed output."""
     return out[0], out[1:1 + N], out[1 + N:1 + 19 * N]
+
+
+class _DeviceDoubles:
+    """Zero-copy view of a raw device pointer for torch (__cuda_array_interface__)."""
+
+    def __init__(self, ptr, count):
+        self.__cuda_array_interface__ = {"shape": (int(count),), "typestr": "<f8", "data": (int(ptr), False), "version": 2}
+
+
+def cost_function_allreduced(engine, x):
+    """The full objective callback on a sharded engine (engine.set_shard(rank, world) done): MINCO + this rank's share of
+    the sweeps, ONE all-reduce of the partial sums over RCCL, then the rest of the callback - the same (cost, g) on every
+    rank.  Runs on torch's current stream so that the collective is ordered after the sweeps."""
+    import torch
+    stream = torch.cuda.current_stream().cuda_stream
+    ptr, count = engine.cost_function_launch(x, stream)
+    part = torch.as_tensor(_DeviceDoubles(ptr, count), device=torch.device("cuda", torch.cuda.current_device()))
+    allreduce_packed(part)
+    return engine.cost_function_finish(stream)

@@ -221,6 +221,12 @@ int isdf_cost_function(isdf_ctx *ctx, const double *x, double *g, int n, double 
 /* the same with the lmbm_evaluate_t signature (src/utils/include/utils/lmbm.h:206-209); instance = isdf_ctx*,
  * returns +inf on error */
 double isdf_cost_function_lmbm(void *instance, const double *x, double *g, const int n);
+/* Multi-GPU form (one process per GPU after isdf_set_shard): _launch runs MINCO and queues this rank's share of the
+ * sweeps on `stream` (hipStream_t as void*), returning the device buffer of partial sums (count doubles); the caller
+ * sums it over the ranks in place on the same stream (ONE all-reduce per step: ncclAllReduce(sum, ncclDouble) /
+ * torch.distributed.all_reduce); _finish downloads it and completes the callback - identical (cost, g) on every rank. */
+int isdf_cost_function_launch(isdf_ctx *ctx, const double *x, int n, void *stream, double **d_partial_out, size_t *count_out);
+int isdf_cost_function_finish(isdf_ctx *ctx, double *g, double *cost_out, void *stream);
 /* energy | swept-volume sweep | integral sweep | rho*sum(T) of the last isdf_cost_function call */
 int isdf_cost_parts(const isdf_ctx *ctx, double parts[4]);
 

@@ -45,6 +45,11 @@ def _worker(rank, world, port, variant_name, q):
     if variant_name == "V1":
         way = np.asarray(cm).reshape(3, 6 * N).T.reshape(N, 6, 3)[1:, 0, :]
         o.set_points(synth.constraint_points(occ, (0, 0, 0), res, way, half=3.0))
+    if variant_name == "callback":
+        _callback_worker(pkg, orc, o, rank, world, occ, res, q)
+        dist.barrier()
+        dist.destroy_process_group()
+        return
     o.set_shard(rank, world)
     c, gT, gC, _ = o.eval(T, cm)
     out = torch.from_numpy(np.concatenate([[c], gT, gC]))
@@ -64,7 +69,39 @@ def _worker(rank, world, port, variant_name, q):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,variant", [(2, "V3"), (3, "V3"), (2, "V1")])
+def _callback_worker(pkg, orc, o, rank, world, occ, res, q):
+    """The multi-GPU form of the full objective callback (isdf_cost_function_launch / all-reduce / _finish), with the
+    oracle standing in for the device sweeps: energy and MINCO are replicated, only the sweeps' partial sums are reduced."""
+    import torch
+    from common import oracle_cost_function, T_to_tau
+    par = pkg.parallel
+    N = 5
+    rng = np.random.default_rng(3)
+    T, cm = __import__("common").traj(pkg, occ, res, N=N, seed=5)
+    c6 = np.asarray(cm).reshape(3, 6 * N).T.reshape(N, 6, 3)
+    head = np.zeros((3, 3)); tail = np.zeros((3, 3))
+    head[:, 0] = c6[0, 0]; tail[:, 0] = sum(c6[N - 1, p] * T[-1] ** p for p in range(6))
+    way = c6[1:, 0, :]
+    x = np.concatenate([T_to_tau(T), way.reshape(-1)])
+    rho = 2.0
+    c_full, g_full = oracle_cost_function(orc, [o], head, tail, rho, x, N)
+
+    class Sharded:      # an oracle "sweep" whose partial sums are all-reduced before they are accumulated
+        def eval(self, T_, cm_, accumulate_into):
+            o.set_shard(rank, world)
+            c, gT, gC, _ = o.eval(T_, cm_)
+            o.set_shard(0, 1)
+            buf = torch.from_numpy(np.concatenate([[c], gT, gC]))
+            par.allreduce_packed(buf)
+            cost, gT0, gC0 = accumulate_into
+            b = buf.numpy()
+            cost[0] += b[0]; gT0 += b[1:1 + N]; gC0 += b[1 + N:]
+    c_sh, g_sh = oracle_cost_function(orc, [Sharded()], head, tail, rho, x, N)
+    ok = abs(c_sh - c_full) <= 1e-12 * abs(c_full) and np.allclose(g_sh, g_full, rtol=1e-10, atol=1e-9)
+    q.put((rank, bool(ok)))
+
+
+@pytest.mark.parametrize("world,variant", [(2, "V3"), (3, "V3"), (2, "V1"), (2, "callback")])
 def test_sharded_allreduce_matches_single_rank(world, variant):
     import torch.multiprocessing as mp
     ctx = mp.get_context("spawn")

@@ -145,3 +145,50 @@ def test_optimize_lbfgs_follows_oracle(pkg, orc, product_lib):
     assert r["f"] < c_start
     assert_close(x, np.array(xr), "x after %d L-BFGS iterations" % iters, tol=1e-6)
     assert abs(r["f"] - fr) <= 1e-6 * abs(fr)
+
+
+def test_callback_launch_finish_shards(pkg, orc, product_lib):
+    """Multi-GPU form of the callback on one GPU: two sharded contexts, partial sums added by hand where the all-reduce
+    would run, both finish with the unsharded (cost, g)."""
+    capi, synth = pkg.capi, pkg.synth
+    occ, esdf, res = small_world(pkg, seed=10)
+    N = 5
+    head, tail, way, T0 = _setup(pkg, occ, res, N, 66)
+    pts = synth.constraint_points(occ, (0, 0, 0), res, way, half=4 * res * 1.5)
+    shape = synth.make_shape("RoundedCone", params=(0.8, 0.3, 1.6))
+    for variant, points in ((capi.V3_ESDF_TILE, None), (capi.V1_SWEPT, pts)):
+        cfg, full, _ = _engines(pkg, orc, variant, occ, esdf, res, shape, points=points)
+        full.set_trajectory(N, head, tail, 2.0)
+        x = full.pack_variables(T0 * 0.7, way)
+        c_full, g_full = full.cost_function(x)
+        engs = []
+        for r in range(2):
+            _, e, _ = _engines(pkg, orc, variant, occ, esdf, res, shape, points=points)
+            e.set_trajectory(N, head, tail, 2.0)
+            e.set_shard(r, 2)
+            engs.append(e)
+        hip = C.CDLL("libamdhip64.so")
+        hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+        hip.hipDeviceSynchronize.argtypes = []
+        bufs = []
+        for e in engs:
+            ptr, cnt = e.cost_function_launch(x, 0)
+            bufs.append((ptr, cnt))
+        assert hip.hipDeviceSynchronize() == 0
+        parts = []
+        for ptr, cnt in bufs:
+            h = np.zeros(cnt)
+            assert hip.hipMemcpy(h.ctypes.data_as(C.c_void_p), C.c_void_p(ptr), cnt * 8, 2) == 0     # device -> host
+            parts.append(h)
+        assert np.abs(parts[0]).sum() > 0 and np.abs(parts[1]).sum() > 0          # both shards contribute
+        total = parts[0] + parts[1]                                               # where the all-reduce runs
+        for ptr, cnt in bufs:
+            assert hip.hipMemcpy(C.c_void_p(ptr), total.ctypes.data_as(C.c_void_p), cnt * 8, 1) == 0  # host -> device
+        for e in engs:
+            c, g = e.cost_function_finish(0)
+            assert abs(c - c_full) <= 1e-12 * abs(c_full)
+            assert_close(g, g_full, "sharded callback g", tol=1e-11)
+    # finish without launch is a state error
+    with pytest.raises(pkg.engine.IsdfError) as ei:
+        engs[0].cost_function_finish(0)
+    assert ei.value.code == capi.ISDF_ERR_STATE
