@@ -177,6 +177,19 @@ def main():
                      "ms_per_evaluation": round(r["wall_ms"] / max(1, r["evaluations"]), 4),
                      "cost_first": c_first, "cost_last": r["f"]}
 
+        # measured HBM copy rate of this box next to the spec peak the roofline uses
+        hbm_copy = None
+        if world == 1:
+            a = torch.empty(1 << 28, dtype=torch.float32, device=dev)      # 1 GiB
+            b_ = torch.empty_like(a)
+            b_.copy_(a); torch.cuda.synchronize()
+            tcp = time.perf_counter()
+            for _ in range(10):
+                b_.copy_(a)
+            torch.cuda.synchronize()
+            hbm_copy = round(10 * 2 * a.numel() * 4 / (time.perf_counter() - tcp) / 1e9, 1)
+            del a, b_
+
         cpu = None
         parity = None
         if not args.no_cpu_baseline:
@@ -222,7 +235,7 @@ def main():
                        "sharding": "pieces contiguous by rank + all_reduce(sum) of 1+19N doubles" if world > 1 else "none"},
             "roofline": roofline, "cpu_baseline": cpu,
             "parity_rel_err_vs_oracle": parity, "host_api_ms": None if host_ms is None else round(host_ms, 4),
-            "stats_last_step_rank0": stats, "lbfgs": lbfgs,
+            "stats_last_step_rank0": stats, "lbfgs": lbfgs, "hbm_copy_gbs_measured": hbm_copy,
         }
         print(json.dumps(result), flush=True)
     if world > 1:

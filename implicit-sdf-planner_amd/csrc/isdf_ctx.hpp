@@ -7,7 +7,7 @@
 
 using namespace isdf;
 
-struct ProfEvent { hipEvent_t a, b, c; };
+struct ProfEvent { hipEvent_t a, b, c, d; };   // start/stop of the dominant kernel, start/stop of the one after it
 struct isdf_ctx {
     isdf_config cfg;
     int device = 0;

@@ -149,7 +149,7 @@ extern "C" int isdf_destroy(isdf_ctx *c) {
     if (!c) return ISDF_OK;
     (void)hipSetDevice(c->device);
     (void)hipDeviceSynchronize();
-    for (auto &p : c->prof_events) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); (void)hipEventDestroy(p.c); }
+    for (auto &p : c->prof_events) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); (void)hipEventDestroy(p.c); (void)hipEventDestroy(p.d); }
     if (c->h_pin) (void)hipHostFree(c->h_pin);
     void *ptrs[] = {c->d_tail_ticket, c->d_cb, c->d_esdf, c->d_occ, c->d_points, c->d_tstar, c->d_acc, c->d_sample_info, c->d_bits, c->d_piece_cost, c->d_in, c->d_out, c->d_stats,
                     c->d_traj_duration, c->d_coarse_t, c->d_coarse_pose, c->d_n_coarse, c->d_point_partial, c->d_point_piece, c->d_hist, c->d_dbg};
@@ -346,10 +346,10 @@ static int prof_begin(isdf_ctx *c, hipStream_t st, ProfEvent **ev) {
         HIPCHK(c, hipEventCreate(&p.a));
         HIPCHK(c, hipEventCreate(&p.b));
         HIPCHK(c, hipEventCreate(&p.c));
+        HIPCHK(c, hipEventCreate(&p.d));
         c->prof_events.push_back(p);
     }
     *ev = &c->prof_events[c->prof_used++];
-    HIPCHK(c, hipEventRecord((*ev)->a, st));
     return ISDF_OK;
 }
 
@@ -404,9 +404,10 @@ static int eval_device_impl(isdf_ctx *c, int n_traj, int N, const double *d_T, c
         ProfEvent *ev;
         int rc = prof_begin(c, st, &ev);
         if (rc) return rc;
-        launch_swept_sweep(P, st);
-        if (ev) { HIPCHK(c, hipEventRecord(ev->b, st)); HIPCHK(c, hipEventRecord(ev->c, st)); }
+        launch_swept_sweep(P, st, ev ? ev->a : nullptr, ev ? ev->b : nullptr);
+        if (ev) { HIPCHK(c, hipEventRecord(ev->c, st)); }
         launch_swept_reduce(P, d_out, st);
+        if (ev) { HIPCHK(c, hipEventRecord(ev->d, st)); }
         HIPCHK(c, hipGetLastError());
         return ISDF_OK;
     }
@@ -490,10 +491,9 @@ static int eval_device_impl(isdf_ctx *c, int n_traj, int N, const double *d_T, c
     ProfEvent *ev;
     rc = prof_begin(c, st, &ev);
     if (rc) return rc;
-    launch_sweep(P, st);
-    if (ev) HIPCHK(c, hipEventRecord(ev->b, st));
-    launch_tail(P, st);
-    if (ev) HIPCHK(c, hipEventRecord(ev->c, st));
+    if (ev && !cfg.enable_pos) { ev = nullptr; c->prof_used--; }      // no dominant kernel in a dynamics-only step
+    launch_sweep(P, st, ev ? ev->a : nullptr, ev ? ev->b : nullptr);
+    launch_tail(P, st, ev ? ev->c : nullptr, ev ? ev->d : nullptr);
     HIPCHK(c, hipGetLastError());
     return ISDF_OK;
 }
@@ -793,11 +793,11 @@ extern "C" int isdf_profile_read(isdf_ctx *c, int *n, double *mean_ms) {
     HIPCHK(c, hipSetDevice(c->device));
     double sum = 0.0, sum2 = 0.0;
     for (size_t i = 0; i < c->prof_used; i++) {
-        HIPCHK(c, hipEventSynchronize(c->prof_events[i].c));
+        HIPCHK(c, hipEventSynchronize(c->prof_events[i].d));
         float ms = 0.f;
         HIPCHK(c, hipEventElapsedTime(&ms, c->prof_events[i].a, c->prof_events[i].b));
         sum += ms;
-        HIPCHK(c, hipEventElapsedTime(&ms, c->prof_events[i].b, c->prof_events[i].c));
+        HIPCHK(c, hipEventElapsedTime(&ms, c->prof_events[i].c, c->prof_events[i].d));
         sum2 += ms;
     }
     *n = (int)c->prof_used;

@@ -1,6 +1,7 @@
 // Internal host<->kernel parameter blocks (not part of the ABI).
 #pragma once
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 #include <cstdint>
 #include "dev_shapes.hpp"
 
@@ -43,10 +44,12 @@ struct SweepParams {
 };
 
 // one optimizer step of the integral sweep = sweep, tail, in order, on `stream`
-void launch_sweep(const SweepParams &P, hipStream_t stream);
+// ev_start / ev_stop (nullable): HIP events attached to the kernel dispatch itself (hipExtLaunchKernelGGL), i.e. its begin and
+// end timestamps - the same interval rocprofv3 reports for the kernel
+void launch_sweep(const SweepParams &P, hipStream_t stream, hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr);
 void launch_stats(const SweepParams &P, hipStream_t stream);   // on demand, not part of the step
 void launch_build_bits(const DevGrid &G, int use_esdf, float thresh, unsigned *out, hipStream_t stream);
-void launch_tail(const SweepParams &P, hipStream_t stream);
+void launch_tail(const SweepParams &P, hipStream_t stream, hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr);
 
 // ---- V1 (swept volume) ----
 struct SweptParams {
@@ -71,7 +74,7 @@ struct SweptParams {
     unsigned long long *stats;
 };
 void launch_swept_prepare(const SweptParams &P, hipStream_t stream);
-void launch_swept_sweep(const SweptParams &P, hipStream_t stream);
+void launch_swept_sweep(const SweptParams &P, hipStream_t stream, hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr);
 void launch_swept_reduce(const SweptParams &P, double *out, hipStream_t stream);
 
 } // namespace isdf

@@ -325,10 +325,10 @@ __global__ void swept_suffix_kernel(int N, const double *hist, double *out) {
 void launch_swept_prepare(const SweptParams &P, hipStream_t stream) {
     hipLaunchKernelGGL(swept_prepare_kernel, dim3(1), dim3(1024), 0, stream, P);
 }
-void launch_swept_sweep(const SweptParams &P, hipStream_t stream) {
+void launch_swept_sweep(const SweptParams &P, hipStream_t stream, hipEvent_t ev_start, hipEvent_t ev_stop) {
     const int n = P.point_end - P.point_begin;
     if (n <= 0) return;
-    hipLaunchKernelGGL(swept_sweep_kernel, dim3((n + SW_WAVES - 1) / SW_WAVES), dim3(64 * SW_WAVES), 0, stream, P);
+    hipExtLaunchKernelGGL(swept_sweep_kernel, dim3((n + SW_WAVES - 1) / SW_WAVES), dim3(64 * SW_WAVES), 0, stream, ev_start, ev_stop, 0, P);
 }
 void launch_swept_reduce(const SweptParams &P, double *out, hipStream_t stream) {
     hipLaunchKernelGGL(swept_reduce_kernel, dim3(P.N + 1), dim3(256), 0, stream, P, out, P.hist);

@@ -659,14 +659,14 @@ __global__ __launch_bounds__(TL_THREADS) void tail_kernel(const SweepParams P) {
     if (dbg && threadIdx.x == 0) dbg[1] = wall_clock64();
 }
 
-void launch_sweep(const SweepParams &P, hipStream_t stream) {
+void launch_sweep(const SweepParams &P, hipStream_t stream, hipEvent_t ev_start, hipEvent_t ev_stop) {
     const long long n_samples = (long long)(P.piece_end - P.piece_begin) * (P.K + 1);
     if (n_samples <= 0 || !P.enable_pos) return;
-    const int blocks = (int)((n_samples + SW_SAMPLES - 1) / SW_SAMPLES);
+    const dim3 grid((unsigned)((n_samples + SW_SAMPLES - 1) / SW_SAMPLES)), block(64 * SW_SAMPLES);
     switch (P.shape.kind) {
-    case ISDF_SHAPE_BOX: hipLaunchKernelGGL(sweep_kernel<ISDF_SHAPE_BOX>, dim3(blocks), dim3(64 * SW_SAMPLES), 0, stream, P); break;
-    case ISDF_SHAPE_ROUNDEDCONE: hipLaunchKernelGGL(sweep_kernel<ISDF_SHAPE_ROUNDEDCONE>, dim3(blocks), dim3(64 * SW_SAMPLES), 0, stream, P); break;
-    default: hipLaunchKernelGGL(sweep_kernel<-1>, dim3(blocks), dim3(64 * SW_SAMPLES), 0, stream, P); break;
+    case ISDF_SHAPE_BOX: hipExtLaunchKernelGGL(sweep_kernel<ISDF_SHAPE_BOX>, grid, block, 0, stream, ev_start, ev_stop, 0, P); break;
+    case ISDF_SHAPE_ROUNDEDCONE: hipExtLaunchKernelGGL(sweep_kernel<ISDF_SHAPE_ROUNDEDCONE>, grid, block, 0, stream, ev_start, ev_stop, 0, P); break;
+    default: hipExtLaunchKernelGGL(sweep_kernel<-1>, grid, block, 0, stream, ev_start, ev_stop, 0, P); break;
     }
 }
 
@@ -702,8 +702,8 @@ void launch_build_bits(const DevGrid &G, int use_esdf, float thresh, unsigned *o
     hipLaunchKernelGGL(build_bits_kernel, dim3(2048), dim3(256), 0, stream, G, use_esdf, thresh, out);
 }
 
-void launch_tail(const SweepParams &P, hipStream_t stream) {
-    hipLaunchKernelGGL(tail_kernel, dim3(P.n_traj * P.N), dim3(TL_THREADS), 0, stream, P);
+void launch_tail(const SweepParams &P, hipStream_t stream, hipEvent_t ev_start, hipEvent_t ev_stop) {
+    hipExtLaunchKernelGGL(tail_kernel, dim3(P.n_traj * P.N), dim3(TL_THREADS), 0, stream, ev_start, ev_stop, 0, P);
 }
 
 } // namespace isdf

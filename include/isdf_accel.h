@@ -254,14 +254,14 @@ int isdf_lbfgs_minimize(isdf_evaluate_fn evaluate, void *instance, double *x_ino
 int isdf_optimize_lbfgs(isdf_ctx *ctx, double *x_inout, int n, const isdf_lbfgs_params *p, isdf_lbfgs_result *out);
 
 /* ---- instrumentation --------------------------------------------------------------------------------------- */
-/* on = N > 0: every N-th isdf_eval_device records HIP events around its dominant kernel on `stream` (an event
- * record costs a few microseconds of stream time, so N > 1 keeps the instrumented run representative);
+/* on = N > 0: every N-th isdf_eval_device attaches HIP start/stop events to the dispatch of its dominant kernel on
+ * `stream` (hipExtLaunchKernel: the kernel's own begin/end timestamps, the interval rocprofv3 reports);
  * isdf_profile_read synchronises and returns the number of launches recorded since the last read and their
  * mean duration in milliseconds.  on = 0 disables. */
 int isdf_profile_enable(isdf_ctx *ctx, int on);
 int isdf_profile_read(isdf_ctx *ctx, int *n_launches, double *mean_ms);
-/* Mean duration (ms) of the second-largest kernel of the same launches (the fp64 exact pass), valid after
- * isdf_profile_read. */
+/* Mean duration (ms) of the kernel that follows the dominant one in the same launches (tail_kernel / the V1 reduce),
+ * valid after isdf_profile_read. */
 int isdf_profile_read_secondary(isdf_ctx *ctx, double *mean_ms);
 /* Counters of the last evaluation (for tests / roofline bookkeeping). */
 typedef struct isdf_stats {
