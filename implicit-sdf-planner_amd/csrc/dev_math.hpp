@@ -268,10 +268,19 @@ __device__ __forceinline__ d3 ct_beta(const double *__restrict__ c, int ld, cons
 //   traj_eval follows Piece::getPos_Vel_Acc_Jerk (:105-149): running powers of t, ascending-power walk.
 struct TrajView { const double *T; const double *C; int N; };
 __device__ __forceinline__ int traj_locate(const TrajView &tr, double &t) {
+    // Same arithmetic as the reference's loop (t -= dur while t > dur), written as a wave-uniform walk over the pieces:
+    // the duration of piece k is one scalar load for the whole wavefront and lanes that have found their piece idle.
     int idx = 0;
-    double dur = 0.0;
-    for (idx = 0; idx < tr.N && t > (dur = tr.T[idx]); idx++) t -= dur;
-    if (idx == tr.N) { idx--; t += tr.T[idx]; }
+    bool walking = true;
+    double last = 0.0;
+    for (int k = 0; k < tr.N; k++) {
+        const double dur = tr.T[k];
+        last = dur;
+        walking = walking && (t > dur);
+        if (walking) { t -= dur; idx = k + 1; }
+        if (!__builtin_amdgcn_ballot_w64(walking)) break;
+    }
+    if (idx == tr.N) { idx--; t += last; }       // ran off the end: clamp to the last piece (last == T[N-1] here)
     return idx;
 }
 __device__ __forceinline__ void traj_eval(const TrajView &tr, int piece, double t, d3 &pos, d3 &vel, d3 &acc, d3 &jer) {

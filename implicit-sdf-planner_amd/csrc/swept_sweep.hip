@@ -4,7 +4,7 @@
 //   (getSDFofSweptVolume :710-747, choiceTInit :367-445, gradientDescent :1000-1062,
 //    getSDF_DOTAtTimeStampOptimized :593-662, getStateOnTrajStamp :332-341).
 //
-// One optimizer step = three launches:
+// One optimizer step = four launches (prepare, sweep, back-prop, reduce + suffix):
 //   swept_prepare_kernel  one block: the "traj_duration" state (refreshed only when the total is < 300 s, :287-296),
 //                         the coarse time table t += 0.2 by repeated fp64 addition (one lane, like the reference loop),
 //                         then the pose (position + rotation) at every coarse time, shared by all obstacle points.
@@ -16,7 +16,8 @@
 //                                         carried ACROSS intervals (quirk q1);
 //                           descent       the 9 step-halving candidates of one sign-descent iteration are evaluated
 //                                         by 9 lanes at once, the 6 central-difference SDF samples by 6 lanes;
-//                           back-prop     penalty (mu = 0.01), flatness reverse mode, 20-double record per point.
+//                           -> (t*, sdf*, body-frame gradient) per point.
+//   swept_backprop_kernel one THREAD per obstacle point: penalty (mu = 0.01), flatness reverse mode, 20-double record.
 //   swept_reduce_kernel   deterministic sums: gradC rows per piece, gradT(j) = sum over points with piece > j, cost.
 // Compute-/latency-bound: fp64 throughout, no tile traffic.
 #include "isdf_internal.hpp"
@@ -38,10 +39,11 @@ __device__ __forceinline__ void pose_at(const SweptParams &P, const TrajView &tr
     flat_core(P.flat, v, a, fs);
     R = quat_to_rot(flat_quat(fs));
 }
+template <int KIND>
 __device__ __forceinline__ double sdf_at_time(const SweptParams &P, const TrajView &tr, d3 p, double t) {
     d3 x; m3 R;
     pose_at(P, tr, t, x, R);
-    return shape_sdf<-1>(P.shape, mat_tmul(R, p - x));
+    return shape_sdf<KIND>(P.shape, mat_tmul(R, p - x));
 }
 
 __global__ __launch_bounds__(1024) void swept_prepare_kernel(const SweptParams P) {
@@ -82,6 +84,7 @@ __device__ __forceinline__ double wave_first_min(double v, int lane, int n, int 
     return m;
 }
 
+template <int KIND>
 __global__ __launch_bounds__(64 * SW_WAVES) void swept_sweep_kernel(const SweptParams P) {
     __shared__ double s_rl[SW_WAVES][SW_MAX_RANGES], s_rr[SW_WAVES][SW_MAX_RANGES];
     const int lane = threadIdx.x & 63;
@@ -107,7 +110,7 @@ __global__ __launch_bounds__(64 * SW_WAVES) void swept_sweep_kernel(const SweptP
             m3 R;
 #pragma unroll
             for (int q = 0; q < 9; q++) R.a[q] = o[3 + q];
-            dis = shape_sdf<-1>(P.shape, mat_tmul(R, p - mk3(o[0], o[1], o[2])));
+            dis = shape_sdf<KIND>(P.shape, mat_tmul(R, p - mk3(o[0], o[1], o[2])));
         }
         unsigned long long in_mask = __ballot((k < n_coarse) && (dis < inf));
         const int nvalid = min(64, n_coarse - base);
@@ -144,88 +147,174 @@ __global__ __launch_bounds__(64 * SW_WAVES) void swept_sweep_kernel(const SweptP
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 
     // ---------------- per interval: fine scan (:423-438) then sign descent (:729-745, :1000-1062) ----------------
+    // One loop, ONE pose + SDF evaluation site; what the lanes evaluate depends on the phase:
+    //   FINE   lanes = 0.02 s steps of the interval (each lane accumulates its own t by repeated addition)
+    //   GD     one sign-descent iteration in a single pass: lanes 0-8 the nine halving candidates x - tau_k, lanes 9-17
+    //          x + tau_k (the sign of dSDF/dt picks the set afterwards), lane 18 the pose at x itself (f(x), body-frame
+    //          point velocity), lanes 19-24 the central-difference samples of the shape gradient at x (19-21: the
+    //          forward differences of Box's own gradient)
+    //   GRAD   lanes 18-24 only: shape gradient at the final x of the interval when the last step moved x
+    enum { PH_FINE = 0, PH_GD = 1, PH_GRAD = 2, PH_NEXT = 3, PH_END = 4 };
+    const int gmode = P.shape.grad_mode;
+    const bool fd_central = (KIND != ISDF_SHAPE_MESH) && (KIND >= 0 || P.shape.kind != ISDF_SHAPE_MESH) && gmode == ISDF_GRAD_CENTRAL;
+    const bool fd_forward = (KIND != ISDF_SHAPE_MESH) && (KIND >= 0 || P.shape.kind != ISDF_SHAPE_MESH) && gmode == ISDF_GRAD_BOX_FORWARD;
     double range_time_seed = 0.0;
     double min_sdf_star = 1e1, t_star_best = 0.0;
     d3 grad_prel = mk3(0, 0, 0);
     bool have = false;
     unsigned n_iters_total = 0;
-    for (int r = 0; r < n_ranges; r++) {
-        const double lb = s_rl[wave][r], ub = s_rr[wave][r];
-        // fine scan: t = lb, lb+dt, ... (< ub) by repeated addition
-        double t_base = lb;
-        for (;;) {
-            double t = t_base;
-            for (int q = 0; q < 63; q++) if (q < lane) t += dt;     // each lane's own accumulated time
-            const bool valid = t < ub;
-            const unsigned long long vm = __ballot(valid);
-            if (!vm) break;
-            const int nv = __popcll(vm);                            // valid lanes form a prefix (t is increasing)
-            double dis = 1e300;
-            if (valid) dis = sdf_at_time(P, tr, p, t);
-            int arg;
-            const double m = wave_first_min(dis, lane, nv, arg);
-            if (arg >= 0 && m < range_mindis) { range_mindis = m; range_time_seed = __shfl(t, arg, 64); }
-            if (nv < 64) break;
-            t_base = __shfl(t, 63, 64) + dt;
+    int r = 0, phase = n_ranges > 0 ? PH_FINE : PH_END;
+    double lb = 0.0, ub = 0.0, t_base = 0.0, t_min = 0.0, t_max = 0.0;
+    double x = 0.0, fx = 0.0, prev_x = 0.0;
+    d3 g1_at_x = mk3(0, 0, 0);                 // shape gradient at the current x (valid when g1_fresh)
+    bool g1_fresh = false;
+    int iter = 0;
+    if (phase == PH_FINE) { lb = s_rl[wave][0]; ub = s_rr[wave][0]; t_base = lb; }
+    while (phase != PH_END) {
+        if (phase == PH_NEXT) {
+            // interval r finished at (x, fx): keep the best (:739-744), move on
+            n_iters_total += (unsigned)iter;
+            if (fx < min_sdf_star) { min_sdf_star = fx; t_star_best = x; have = true; grad_prel = g1_at_x; }
+            r++;
+            if (r >= n_ranges) { phase = PH_END; break; }
+            lb = s_rl[wave][r]; ub = s_rr[wave][r]; t_base = lb;
+            phase = PH_FINE;
+            continue;
         }
-        // sign descent from the seed
-        const double t_min = fmax(0.0, lb), t_max = fmin(ub, D);
-        double x = range_time_seed, fx = 0.0, prev_x = 10000000.0;
-        int iter = 0;
-        bool stop = false;
-        while (iter < 300 && !stop && fabs(x - prev_x) > 1e-5) {
-            if (iter == 0) fx = sdf_at_time(P, tr, p, x);
-            // g = d/dt SDF at x: pose with omega, body-frame point, shape gradient, point velocity
-            double tl = x;
+        // ---- what this lane evaluates
+        double te = 0.0;
+        int pert = 0;                 // 0: the body-frame point itself; 1..6: central-difference sample; 7..9: forward difference
+        bool act = false;
+        if (phase == PH_FINE) {
+            te = t_base;
+            for (int q = 0; q < 63; q++) if (q < lane) te += dt;     // each lane's own accumulated time
+            act = te < ub;
+            if (!__ballot(act)) {     // nothing (left) to scan in this interval: descend from the seed
+                x = range_time_seed; prev_x = 10000000.0; iter = 0; g1_fresh = false;
+                t_min = fmax(0.0, lb); t_max = fmin(ub, D);
+                phase = PH_GD;
+                continue;
+            }
+        } else {
+            if (lane < 18 && phase == PH_GD) {
+                double tau = 0.02;
+                const int k = lane < 9 ? lane : lane - 9;
+                for (int q = 0; q < 8; q++) if (q < k) tau = 0.5 * tau;
+                te = x - tau * (lane < 9 ? 1 : -1);
+                te = fmax(fmin(te, t_max), t_min);
+                act = true;
+            } else if (lane == 18) { te = x; act = true; }
+            else if (lane >= 19 && lane < 25 && fd_central) { te = x; pert = lane - 18; act = true; }
+            else if (lane >= 19 && lane < 22 && fd_forward) { te = x; pert = lane - 12; act = true; }
+        }
+        // ---- the evaluation: pose at te, body-frame point, shape SDF (one code instance)
+        double val = 1e300;
+        d3 pvel = mk3(0, 0, 0), g_direct = mk3(0, 0, 0);
+        if (act) {
+            double tl = te;
             const int pi = traj_locate(tr, tl);
             d3 xt, vt, at, jt;
             traj_eval(tr, pi, tl, xt, vt, at, jt);
-            FlatS fs; FlatS2 ft;
+            FlatS fs;
             flat_core(P.flat, vt, at, fs);
-            flat_core2(P.flat, vt, at, jt, fs, ft);
             const m3 R = quat_to_rot(flat_quat(fs));
-            const d3 omg = flat_omg(fs, ft);
-            const d3 temp = mat_tmul(R, p - xt);
-            const d3 g1 = shape_grad<-1>(P.shape, temp);
-            const d3 wx = mk3(0 * temp.x + (-omg.z) * temp.y + omg.y * temp.z, omg.z * temp.x + 0 * temp.y + (-omg.x) * temp.z,
-                              (-omg.y) * temp.x + omg.x * temp.y + 0 * temp.z);
-            const d3 rv = mat_tmul(R, vt);
-            const d3 pv = mk3(-(rv.x + wx.x), -(rv.y + wx.y), -(rv.z + wx.z));
-            const double g = dot3(g1, pv);
-            const int sgn = (int)(g > 0) - (int)(g < 0);
-            prev_x = x;
-            // the nine halving candidates tau = 0.02 * 0.5^(div-1), div = 1..9, one lane each
-            double tau = 0.02;
-            for (int q = 0; q < 8; q++) if (q < lane) tau = 0.5 * tau;
-            double xc = x - tau * sgn;
-            xc = fmax(fmin(xc, t_max), t_min);
-            double fc = 1e300;
-            if (lane < 9) fc = sdf_at_time(P, tr, p, xc);
-            const unsigned long long acc = __ballot((lane < 9) && ((fc - fx) < 0));
-            if (acc) {
-                const int d = __ffsll((long long)acc) - 1;
-                iter += d + 1;
-                x = __shfl(xc, d, 64);
-                fx = __shfl(fc, d, 64);
-            } else {
-                iter += 9;
-                stop = true;
+            d3 pr = mat_tmul(R, p - xt);
+            if (lane == 18 && phase != PH_FINE) {
+                // d/dt of the body-frame point: -(R^T v + omega x p_rel) (getSDF_DOTAtTimeStampOptimized :593-662)
+                FlatS2 ft;
+                flat_core2(P.flat, vt, at, jt, fs, ft);
+                const d3 omg = flat_omg(fs, ft);
+                const d3 wx = mk3(0 * pr.x + (-omg.z) * pr.y + omg.y * pr.z, omg.z * pr.x + 0 * pr.y + (-omg.x) * pr.z,
+                                  (-omg.y) * pr.x + omg.x * pr.y + 0 * pr.z);
+                const d3 rv = mat_tmul(R, vt);
+                pvel = mk3(-(rv.x + wx.x), -(rv.y + wx.y), -(rv.z + wx.z));
+                if (!fd_central && !fd_forward) g_direct = shape_grad<KIND>(P.shape, pr);     // Ball / mesh: own gradient
             }
+            if (pert >= 1 && pert <= 6) {            // temp(a) -= dx; [temp(a) += 2 dx]  (Shape.hpp:36-54)
+                const int a = (pert - 1) >> 1;
+                const double dx = 0.000005;
+                double c = a == 0 ? pr.x : (a == 1 ? pr.y : pr.z);
+                c = c - dx;
+                if ((pert - 1) & 1) c = c + 2 * dx;
+                if (a == 0) pr.x = c; else if (a == 1) pr.y = c; else pr.z = c;
+            } else if (pert >= 7) {                  // Box::getonlyGrad1: forward difference, dx = 0.01 (Shape.hpp:2363-2377)
+                const int a = pert - 7;
+                if (a == 0) pr.x += 0.01; else if (a == 1) pr.y += 0.01; else pr.z += 0.01;
+            }
+            val = shape_sdf<KIND>(P.shape, pr);
         }
-        n_iters_total += (unsigned)iter;
-        if (fx < min_sdf_star) {
-            min_sdf_star = fx;
-            t_star_best = x;
-            have = true;
-            d3 xt; m3 R;
-            pose_at(P, tr, x, xt, R);
-            grad_prel = shape_grad<-1>(P.shape, mat_tmul(R, p - xt));
+        // ---- consume
+        if (phase == PH_FINE) {
+            const int nv = __popcll(__ballot(act));                  // valid lanes form a prefix (t is increasing)
+            int arg;
+            const double m = wave_first_min(val, lane, nv, arg);
+            if (arg >= 0 && m < range_mindis) { range_mindis = m; range_time_seed = __shfl(te, arg, 64); }
+            if (nv < 64) {
+                x = range_time_seed; prev_x = 10000000.0; iter = 0; g1_fresh = false;
+                t_min = fmax(0.0, lb); t_max = fmin(ub, D);
+                phase = PH_GD;
+            } else t_base = __shfl(te, 63, 64) + dt;
+            continue;
         }
+        // shape gradient at x from the samples (getonlyGrad1)
+        d3 g1;
+        if (fd_central) {
+            const double dx = 0.000005;
+            const double gx = __shfl(val, 20, 64) - __shfl(val, 19, 64), gy = __shfl(val, 22, 64) - __shfl(val, 21, 64),
+                         gz = __shfl(val, 24, 64) - __shfl(val, 23, 64);
+            g1 = normalized3(mk3(gx / (2 * dx), gy / (2 * dx), gz / (2 * dx)));
+        } else if (fd_forward) {
+            const double s0 = __shfl(val, 18, 64), dx = 0.01;
+            g1 = mk3((__shfl(val, 19, 64) - s0) / dx, (__shfl(val, 20, 64) - s0) / dx, (__shfl(val, 21, 64) - s0) / dx);
+        } else {
+            g1 = mk3(__shfl(g_direct.x, 18, 64), __shfl(g_direct.y, 18, 64), __shfl(g_direct.z, 18, 64));
+        }
+        g1_at_x = g1; g1_fresh = true;
+        if (phase == PH_GRAD) { phase = PH_NEXT; continue; }
+        // sign-descent step (gradientDescent :1000-1062)
+        if (iter == 0) fx = __shfl(val, 18, 64);
+        const d3 pv = mk3(__shfl(pvel.x, 18, 64), __shfl(pvel.y, 18, 64), __shfl(pvel.z, 18, 64));
+        const double g = dot3(g1, pv);
+        const int sgn = (int)(g > 0) - (int)(g < 0);
+        prev_x = x;
+        const bool in_set = sgn > 0 ? (lane < 9) : (sgn < 0 ? (lane >= 9 && lane < 18) : false);
+        const unsigned long long accm = __ballot(in_set && ((val - fx) < 0));
+        bool stop = false;
+        if (accm) {
+            const int src = __ffsll((long long)accm) - 1;            // first (largest) step that decreases the SDF
+            const int d = sgn > 0 ? src : src - 9;
+            iter += d + 1;
+            x = __shfl(te, src, 64);
+            fx = __shfl(val, src, 64);
+            g1_fresh = false;
+        } else {
+            iter += 9;
+            stop = true;
+        }
+        if (!(iter < 300 && !stop && fabs(x - prev_x) > 1e-5)) phase = g1_fresh ? PH_NEXT : PH_GRAD;
     }
 
-    // ---------------- back-prop at t* (back_end_optimizer.hpp:578-646) ----------------
-    double tstar = P.tstar[pt];
-    if (have) tstar = t_star_best;
+    // ---------------- hand the minimiser to swept_backprop_kernel ----------------
+    if (lane == 0) {
+        double *o = P.point_partial + (size_t)pt * PARTIAL_STRIDE;     // reused as [t*, sdf*, grad_prel(3)] until back-prop
+        o[0] = have ? t_star_best : P.tstar[pt];                       // no interval qualified: lastTstar stays (:717, :576-578)
+        o[1] = min_sdf_star;
+        o[2] = grad_prel.x; o[3] = grad_prel.y; o[4] = grad_prel.z;
+        atomicAdd(&P.stats[2], (unsigned long long)n_ranges);
+        atomicAdd(&P.stats[5], (unsigned long long)n_iters_total);
+    }
+}
+
+// Back-prop at t* (back_end_optimizer.hpp:578-646): one THREAD per obstacle point - penalty (mu = 0.01), pose Jacobians,
+// flatness reverse mode, the 18 + 1 + 1 doubles the reduction sums.
+__global__ __launch_bounds__(128) void swept_backprop_kernel(const SweptParams P) {
+    const int pt = P.point_begin + blockIdx.x * blockDim.x + threadIdx.x;
+    if (pt >= P.point_end) return;
+    const TrajView tr{P.T, P.coeffs, P.N};
+    double *o = P.point_partial + (size_t)pt * PARTIAL_STRIDE;
+    const d3 p = mk3(P.points[3 * pt], P.points[3 * pt + 1], P.points[3 * pt + 2]);
+    const double tstar = o[0], min_sdf_star = o[1];
+    const d3 grad_prel = mk3(o[2], o[3], o[4]);
     double time_local = tstar;
     const int i = traj_locate(tr, time_local);
     Basis B;
@@ -255,22 +344,17 @@ __global__ __launch_bounds__(64 * SW_WAVES) void swept_sweep_kernel(const SweptP
     }
     d3 gP, gV, gA, gJ;
     flat_backward(P.flat, vel, acc3, jer, gradPos, gradVel, gradQuat, gradOmg, gP, gV, gA, gJ);
-    if (lane == 0) {
-        double *o = P.point_partial + (size_t)pt * PARTIAL_STRIDE;
-        const double gPv[3] = {gP.x, gP.y, gP.z}, gVv[3] = {gV.x, gV.y, gV.z}, gAv[3] = {gA.x, gA.y, gA.z}, gJv[3] = {gJ.x, gJ.y, gJ.z};
+    const double gPv[3] = {gP.x, gP.y, gP.z}, gVv[3] = {gV.x, gV.y, gV.z}, gAv[3] = {gA.x, gA.y, gA.z}, gJv[3] = {gJ.x, gJ.y, gJ.z};
 #pragma unroll
-        for (int d = 0; d < 3; d++)
+    for (int d = 0; d < 3; d++)
 #pragma unroll
-            for (int rr = 0; rr < 6; rr++)
-                o[d * 6 + rr] = B.b0[rr] * gPv[d] + B.b1[rr] * gVv[d] + B.b2[rr] * gAv[d] + B.b3[rr] * gJv[d];
-        o[18] = (-dot3(gP, vel) + -dot3(gV, acc3) + -dot3(gA, jer) + -dot3(gJ, sna));
-        o[19] = pena;
-        P.point_piece[pt] = i;
-        P.tstar[pt] = tstar;
-        atomicAdd(&P.stats[2], (unsigned long long)n_ranges);
-        if (active) atomicAdd(&P.stats[3], 1ull);
-        atomicAdd(&P.stats[5], (unsigned long long)n_iters_total);
-    }
+        for (int rr = 0; rr < 6; rr++)
+            o[d * 6 + rr] = B.b0[rr] * gPv[d] + B.b1[rr] * gVv[d] + B.b2[rr] * gAv[d] + B.b3[rr] * gJv[d];
+    o[18] = (-dot3(gP, vel) + -dot3(gV, acc3) + -dot3(gA, jer) + -dot3(gJ, sna));
+    o[19] = pena;
+    P.point_piece[pt] = i;
+    P.tstar[pt] = tstar;
+    if (active) atomicAdd(&P.stats[3], 1ull);
 }
 
 // Deterministic reduction.  Blocks [0, N): gradC rows of piece i and H[i] = sum of gdT over the points whose t* lies in
@@ -328,9 +412,16 @@ void launch_swept_prepare(const SweptParams &P, hipStream_t stream) {
 void launch_swept_sweep(const SweptParams &P, hipStream_t stream, hipEvent_t ev_start, hipEvent_t ev_stop) {
     const int n = P.point_end - P.point_begin;
     if (n <= 0) return;
-    hipExtLaunchKernelGGL(swept_sweep_kernel, dim3((n + SW_WAVES - 1) / SW_WAVES), dim3(64 * SW_WAVES), 0, stream, ev_start, ev_stop, 0, P);
+    const dim3 grid((n + SW_WAVES - 1) / SW_WAVES), block(64 * SW_WAVES);
+    switch (P.shape.kind) {
+    case ISDF_SHAPE_BOX: hipExtLaunchKernelGGL(swept_sweep_kernel<ISDF_SHAPE_BOX>, grid, block, 0, stream, ev_start, ev_stop, 0, P); break;
+    case ISDF_SHAPE_ROUNDEDCONE: hipExtLaunchKernelGGL(swept_sweep_kernel<ISDF_SHAPE_ROUNDEDCONE>, grid, block, 0, stream, ev_start, ev_stop, 0, P); break;
+    default: hipExtLaunchKernelGGL(swept_sweep_kernel<-1>, grid, block, 0, stream, ev_start, ev_stop, 0, P); break;
+    }
 }
 void launch_swept_reduce(const SweptParams &P, double *out, hipStream_t stream) {
+    const int n = P.point_end - P.point_begin;
+    if (n > 0) hipLaunchKernelGGL(swept_backprop_kernel, dim3((n + 127) / 128), dim3(128), 0, stream, P);
     hipLaunchKernelGGL(swept_reduce_kernel, dim3(P.N + 1), dim3(256), 0, stream, P, out, P.hist);
     hipLaunchKernelGGL(swept_suffix_kernel, dim3(1), dim3(64), 0, stream, P.N, P.hist, out);
 }
