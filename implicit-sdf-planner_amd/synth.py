@@ -90,6 +90,25 @@ def make_mesh_shape(vertices, faces):
     return s
 
 
+def l_prism_mesh(a=1.6, b=1.0, t=0.4, h=0.5):
+    """Closed, concave triangle mesh: an L-shaped prism (arms a and b long, t thick, height h), centred on its bounding
+    box - the kind of robot demo6 loads (config_L.yaml, Lthick.obj: 20 triangles).  Returns (V 12x3, F 20x3), outward."""
+    poly = np.array([[0, 0], [a, 0], [a, t], [t, t], [t, b], [0, b]], dtype=np.float64)     # counter-clockwise
+    n = poly.shape[0]
+    V = np.concatenate([np.c_[poly, np.full(n, -h / 2)], np.c_[poly, np.full(n, h / 2)]])
+    V[:, 0] -= a / 2
+    V[:, 1] -= b / 2
+    F = []
+    for i in range(n):                      # side walls
+        j = (i + 1) % n
+        F += [[i, j, n + j], [i, n + j, n + i]]
+    tris = [[0, 1, 2], [0, 2, 3], [0, 3, 4], [0, 4, 5]]           # fan is valid for this L (vertex 0 sees every edge)
+    for t3 in tris:
+        F.append([n + t3[0], n + t3[1], n + t3[2]])                # top (+z)
+        F.append([t3[0], t3[2], t3[1]])                            # bottom (-z)
+    return V, np.array(F, dtype=np.int32)
+
+
 def bench_box_shape():
     """convex box, half-extents (1.6, 0.3, 0.3) m, the Box formula (Shape.hpp:2343-2351) used the
     way a plugin author would (Generalshape subclass + DEFINE_USEFUL_FUNCTION => central-difference gradient)."""
