@@ -211,6 +211,31 @@ def minco_propagate(head, tail, in_pts, T, gradC, gradT):
     return gP.reshape(N - 1, 3).T.copy(), gTo
 
 
+REF_LBFGS = os.path.join(os.path.dirname(os.path.abspath(__file__)), "_ref", "libref_lbfgs.so")
+
+
+def ref_lbfgs_optimize(fun, x0, mem_size=8, g_epsilon=1e-5, past=3, delta=1e-6, max_iterations=0):
+    """The reference's OWN lbfgs::lbfgs_optimize (oracle/_ref/libref_lbfgs.so: utils/lbfgs.hpp compiled from
+    /root/reference against the Eigen stand-in).  fun(x ndarray) -> (f, g).  Returns (x, f, status, evaluations).
+    The reference prints progress to stdout."""
+    L = C.CDLL(REF_LBFGS)
+    cbt = C.CFUNCTYPE(C.c_double, C.c_void_p, dp, dp, C.c_int)
+    n_eval = [0]
+
+    def tramp(_i, xp, gp, n):
+        n_eval[0] += 1
+        xv = np.ctypeslib.as_array(xp, shape=(n,)).copy()
+        f, g = fun(xv)
+        np.ctypeslib.as_array(gp, shape=(n,))[:] = g
+        return float(f)
+    cb = cbt(tramp)
+    x = np.ascontiguousarray(x0, dtype=np.float64).copy()
+    f = C.c_double(0)
+    L.ref_lbfgs_optimize.argtypes = [cbt, C.c_void_p, dp, C.c_int, C.c_int, C.c_double, C.c_int, C.c_double, C.c_int, C.POINTER(C.c_double)]
+    st = L.ref_lbfgs_optimize(cb, None, _p(x), x.size, mem_size, g_epsilon, past, delta, max_iterations, C.byref(f))
+    return x, f.value, st, n_eval[0]
+
+
 class RefFwn:
     """The vendored HDK fast winding number (oracle/_ref/libref_fwn.so)."""
 

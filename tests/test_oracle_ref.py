@@ -5,6 +5,8 @@ import os
 import numpy as np
 import pytest
 
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
 FP = [0.61, 9.8, 0.1, 0.1, 0.01, 1e-4]
 
 
@@ -59,3 +61,42 @@ def test_mesh_winding_number_vs_vendored_fwn(pkg, orc):
     d = np.linalg.norm(np.maximum(np.abs(Q) - np.array([0.5, 0.4, 0.3]), 0), axis=1)
     out = ~inside
     assert np.allclose(sdf[out], d[out], rtol=5e-6, atol=1e-6)
+
+
+def test_lbfgs_vs_reference_header(pkg, orc, product_lib, capfd):
+    """The reference's own lbfgs_optimize (utils/lbfgs.hpp compiled from /root/reference against the Eigen stand-in) vs
+    the oracle's restatement (oracle/lbfgs_ref.py) AND the product driver (csrc/lbfgs_host.hpp): same status, same number
+    of callback evaluations, same iterate after a fixed number of iterations."""
+    if not os.path.exists(orc.REF_LBFGS):
+        pytest.skip("oracle/_ref/libref_lbfgs.so not built")
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("lbfgs_ref", os.path.join(ROOT, "oracle", "lbfgs_ref.py"))
+    ref_py = importlib.util.module_from_spec(spec); spec.loader.exec_module(ref_py)
+
+    def rosen(x):
+        x = np.asarray(x, dtype=np.float64)
+        f = float(np.sum(100.0 * (x[1:] - x[:-1] ** 2) ** 2 + (1 - x[:-1]) ** 2))
+        g = np.zeros_like(x)
+        g[:-1] += -400.0 * x[:-1] * (x[1:] - x[:-1] ** 2) - 2 * (1 - x[:-1])
+        g[1:] += 200.0 * (x[1:] - x[:-1] ** 2)
+        return f, g
+
+    def quad(x):
+        x = np.asarray(x, dtype=np.float64)
+        d = np.arange(1, x.size + 1, dtype=np.float64)
+        return float(0.5 * np.sum(d * x * x) + np.sum(x)), d * x + 1.0
+    for fun, x0, iters in ((rosen, np.full(6, -0.01) + 0.002 * np.arange(6), 25), (quad, 0.02 * np.cos(np.arange(12.0)), 15),
+                           (rosen, np.array([-1.2, 1.0, -0.5, 0.8]), 40)):
+        xr, fr, sr, er = orc.ref_lbfgs_optimize(fun, x0, max_iterations=iters, g_epsilon=0.0, past=0)
+        capfd.readouterr()        # the reference prints its progress
+        xo, fo, so, ko, eo = ref_py.lbfgs_optimize(lambda x: fun(x), list(x0), max_iterations=iters, g_epsilon=0.0, past=0)
+        xp, rp = pkg.lbfgs_minimize(fun, x0, lib=product_lib, max_iterations=iters, g_epsilon=0.0, past=0)
+        assert sr == so == rp["status"], (sr, so, rp)
+        assert er == eo == rp["evaluations"], (er, eo, rp)
+        assert np.allclose(xo, xr, rtol=1e-9, atol=1e-11) and np.allclose(xp, xr, rtol=1e-9, atol=1e-11)
+        assert abs(fo - fr) <= 1e-9 * max(1.0, abs(fr)) and abs(rp["f"] - fr) <= 1e-9 * max(1.0, abs(fr))
+    # convergence / stop codes of the real thing match too
+    xr, fr, sr, er = orc.ref_lbfgs_optimize(quad, np.ones(4) * 1e-3, g_epsilon=0.0, past=2, delta=0.5)
+    capfd.readouterr()
+    _, rp = pkg.lbfgs_minimize(quad, np.ones(4) * 1e-3, lib=product_lib, g_epsilon=0.0, past=2, delta=0.5)
+    assert sr == rp["status"] == 1 and er == rp["evaluations"]
