@@ -211,6 +211,47 @@ def minco_propagate(head, tail, in_pts, T, gradC, gradT):
     return gP.reshape(N - 1, 3).T.copy(), gTo
 
 
+REF_MINCO = os.path.join(os.path.dirname(os.path.abspath(__file__)), "_ref", "libref_minco.so")
+
+
+def _minco_args(head, tail, in_pts, T):
+    T = np.ascontiguousarray(T, dtype=np.float64)
+    h = np.ascontiguousarray(np.asarray(head, dtype=np.float64).T).reshape(-1)
+    t = np.ascontiguousarray(np.asarray(tail, dtype=np.float64).T).reshape(-1)
+    P = np.ascontiguousarray(np.asarray(in_pts, dtype=np.float64).T).reshape(-1)      # 3 x (N-1) column-major
+    if P.size == 0:
+        P = np.zeros(3)
+    return T.size, h, t, P, T
+
+
+def ref_minco(head, tail, in_pts, T):
+    """The reference's OWN MINCO_S3NU (oracle/_ref/libref_minco.so: utils/minco.hpp from /root/reference against the Eigen
+    stand-in): returns (coeffs 18N column-major, energy, dE/dc 18N, dE/dT N)."""
+    L = C.CDLL(REF_MINCO)
+    N, h, t, P, T = _minco_args(head, tail, in_pts, T)
+    cm = np.zeros(18 * N); gC = np.zeros(18 * N); gT = np.zeros(N); e = C.c_double(0)
+    L.ref_minco(C.c_int(N), _p(h), _p(t), _p(P), _p(T), _p(cm), C.byref(e), _p(gC), _p(gT))
+    return cm, e.value, gC, gT
+
+
+def ref_minco_propagate(head, tail, in_pts, T, gradC, gradT):
+    L = C.CDLL(REF_MINCO)
+    N, h, t, P, T = _minco_args(head, tail, in_pts, T)
+    gC = np.ascontiguousarray(gradC, dtype=np.float64); gTp = np.ascontiguousarray(gradT, dtype=np.float64)
+    gP = np.zeros(3 * max(N - 1, 1)); gT = np.zeros(N)
+    L.ref_minco_propagate(C.c_int(N), _p(h), _p(t), _p(P), _p(T), _p(gC), _p(gTp), _p(gP), _p(gT))
+    return gP[:3 * (N - 1)].reshape(N - 1, 3).T.copy(), gT
+
+
+def ref_traj_eval(head, tail, in_pts, T, t):
+    """Trajectory<5>::getPos_Vel_Acc_Jerk of the MINCO trajectory, from the reference's own trajectory.hpp."""
+    L = C.CDLL(REF_MINCO)
+    N, h, tl, P, T = _minco_args(head, tail, in_pts, T)
+    out = np.zeros(12); dur = C.c_double(0)
+    L.ref_traj_eval(C.c_int(N), _p(h), _p(tl), _p(P), _p(T), C.c_double(t), _p(out), C.byref(dur))
+    return out.reshape(4, 3), dur.value
+
+
 REF_LBFGS = os.path.join(os.path.dirname(os.path.abspath(__file__)), "_ref", "libref_lbfgs.so")
 
 

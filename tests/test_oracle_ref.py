@@ -100,3 +100,38 @@ def test_lbfgs_vs_reference_header(pkg, orc, product_lib, capfd):
     capfd.readouterr()
     _, rp = pkg.lbfgs_minimize(quad, np.ones(4) * 1e-3, lib=product_lib, g_epsilon=0.0, past=2, delta=0.5)
     assert sr == rp["status"] == 1 and er == rp["evaluations"]
+
+
+@pytest.mark.parametrize("N", [2, 5, 40])
+def test_minco_and_trajectory_vs_reference_headers(pkg, orc, N):
+    """The reference's own MINCO_S3NU + Trajectory<5> (utils/minco.hpp, trajectory.hpp, root_finder.hpp compiled from
+    /root/reference against the Eigen stand-in) vs the oracle's restatements - which tests/test_minco_host.py shows
+    bitwise equal to the product's host MINCO."""
+    if not os.path.exists(orc.REF_MINCO):
+        pytest.skip("oracle/_ref/libref_minco.so not built")
+    rng = np.random.default_rng(50 + N)
+    head = np.zeros((3, 3)); tail = np.zeros((3, 3))
+    head[:, 0] = rng.uniform(0, 5, 3); head[:, 1] = rng.normal(0, 1, 3); head[:, 2] = rng.normal(0, 0.5, 3)
+    tail[:, 0] = rng.uniform(15, 20, 3); tail[:, 1] = rng.normal(0, 1, 3)
+    way = (np.linspace(head[:, 0], tail[:, 0], N + 1)[1:-1] + rng.normal(0, 0.6, (N - 1, 3))).T          # 3 x (N-1)
+    T = rng.uniform(0.4, 2.5, N)
+    cm_r, e_r, gC_r, gT_r = orc.ref_minco(head, tail, way, T)
+    C6 = orc.minco_coeffs(head, tail, way, T)
+    cm_o = np.ascontiguousarray(C6.T).reshape(-1)
+    assert np.allclose(cm_o, cm_r, rtol=1e-12, atol=1e-12 * np.abs(cm_r).max())
+    e_o, gC_o, gT_o = orc.minco_energy(cm_o, T)
+    assert abs(e_o - e_r) <= 1e-12 * abs(e_r)
+    assert np.allclose(gC_o, gC_r, rtol=1e-11, atol=1e-12 * np.abs(gC_r).max()) and np.allclose(gT_o, gT_r, rtol=1e-11)
+    gc = rng.normal(0, 1, 18 * N); gt = rng.normal(0, 1, N)
+    gP_r, gTt_r = orc.ref_minco_propagate(head, tail, way, T, gc, gt)
+    gP_o, gTt_o = orc.minco_propagate(head, tail, way, T, gc, gt)
+    sc = max(np.abs(gP_r).max(), np.abs(gTt_r).max())
+    assert np.allclose(gP_o, gP_r, rtol=1e-10, atol=1e-12 * sc) and np.allclose(gTt_o, gTt_r, rtol=1e-10, atol=1e-12 * sc)
+    # trajectory: piece lookup (junction time belongs to the earlier piece; overflow clamps) + state evaluation
+    total = float(T.sum())
+    times = list(rng.uniform(0, total, 12)) + [0.0, float(T[0]), float(np.cumsum(T)[N // 2]), total, total + 0.7]
+    for t in times:
+        st_r, dur = orc.ref_traj_eval(head, tail, way, T, t)
+        st_o, piece, tl = orc.traj_eval(T, cm_o, t)
+        assert abs(dur - total) <= 1e-12 * total
+        assert np.allclose(st_o, st_r, rtol=1e-9, atol=1e-9 * max(1.0, np.abs(st_r).max())), (t, st_o, st_r)
