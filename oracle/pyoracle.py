@@ -211,6 +211,37 @@ def minco_propagate(head, tail, in_pts, T, gradC, gradT):
     return gP.reshape(N - 1, 3).T.copy(), gTo
 
 
+REF_SHAPES = os.path.join(os.path.dirname(os.path.abspath(__file__)), "_ref", "libref_shapes.so")
+
+
+class RefShape:
+    """One of the reference's OWN analytic shape classes (oracle/_ref/libref_shapes.so: Shape.hpp:824-2391 extracted from
+    /root/reference at build time, compiled against the Eigen stand-in).  name = the class name (registry stem or "Box")."""
+
+    def __init__(self, name, trans=(0, 0, 0), rotate=None, box=None):
+        self.lib = C.CDLL(REF_SHAPES)
+        self.lib.ref_shape_create.restype = C.c_void_p
+        t = np.asarray(trans, dtype=np.float64)
+        R = np.ascontiguousarray(np.eye(3) if rotate is None else np.asarray(rotate, dtype=np.float64)).reshape(-1)
+        b = None if box is None else np.asarray(box, dtype=np.float64)
+        self.h = C.c_void_p(self.lib.ref_shape_create(name.encode(), _p(t), _p(R), None if b is None else _p(b)))
+        if not self.h.value:
+            raise ValueError(f"unknown reference shape class {name}")
+
+    def eval(self, pts):
+        pts = np.ascontiguousarray(pts, dtype=np.float64).reshape(-1, 3)
+        n = pts.shape[0]
+        s = np.zeros(n); g = np.zeros((n, 3))
+        self.lib.ref_shape_eval(self.h, _p(pts), C.c_int(n), _p(s), _p(g))
+        return s, g
+
+    def __del__(self):
+        try:
+            self.lib.ref_shape_destroy(self.h)
+        except Exception:
+            pass
+
+
 REF_MINCO = os.path.join(os.path.dirname(os.path.abspath(__file__)), "_ref", "libref_minco.so")
 
 

@@ -135,3 +135,33 @@ def test_minco_and_trajectory_vs_reference_headers(pkg, orc, N):
         st_o, piece, tl = orc.traj_eval(T, cm_o, t)
         assert abs(dur - total) <= 1e-12 * total
         assert np.allclose(st_o, st_r, rtol=1e-9, atol=1e-9 * max(1.0, np.abs(st_r).max())), (t, st_o, st_r)
+
+
+@pytest.mark.parametrize("name", ["Torus", "Torus_big", "Cappedtorus", "CappedCone", "RoundedCone", "WireframeBox", "BendLinear",
+                                  "BendLinear_big", "TwistBox", "BendBox", "Table", "Trefoil", "SmoothDifference",
+                                  "SmoothIntersection", "SmoothIntersection_big", "CSG", "Box"])
+def test_analytic_shapes_vs_reference_classes(pkg, orc, name, capfd):
+    """Every analytic robot shape of the registry (sw_manager.hpp:74-123) + Box: the reference's OWN class (Shape.hpp
+    :824-2391, extracted at build time and compiled against the Eigen stand-in) vs the oracle's restatement - SDF and
+    getonlyGrad1 (DEFINE_USEFUL_FUNCTION central difference / Box's forward difference), with a rotated body offset."""
+    if not os.path.exists(orc.REF_SHAPES):
+        pytest.skip("oracle/_ref/libref_shapes.so not built")
+    synth = pkg.synth
+    shape = synth.make_shape(name, poly_params=(0.2, -0.1, 0.15, 30, 10, 120))
+    trans = np.array([shape.trans[i] for i in range(3)])
+    R = np.array([shape.rotate[i] for i in range(9)]).reshape(3, 3)
+    box = [shape.params[i] for i in range(3)] if name == "Box" else None
+    ref = orc.RefShape(name, trans, R, box)
+    capfd.readouterr()
+    o = orc.Oracle(synth.default_config())
+    o.set_shape(shape)
+    rng = np.random.default_rng(len(name))
+    Q = rng.uniform(-4.5, 4.5, (3000, 3))
+    s_r, g_r = ref.eval(Q)
+    s_o, g_o = o.shape_eval(Q)
+    assert np.all(np.isfinite(s_r))
+    assert np.allclose(s_o, s_r, rtol=1e-12, atol=1e-12), np.abs(s_o - s_r).max()
+    # gradients are difference quotients with dx = 5e-6: rounding differences of the SDF are amplified by 1/dx
+    ok = np.isfinite(g_r).all(axis=1)
+    assert ok.mean() > 0.99
+    assert np.allclose(g_o[ok], g_r[ok], rtol=0, atol=2e-7), np.abs(g_o[ok] - g_r[ok]).max()
