@@ -112,6 +112,19 @@ int orc_eval(void *h, int N, const double *T, const double *coeffs, double *cost
 }
 
 // ---- unit-level probes used by the oracle self-tests and the GPU parity tests ----
+// grad_cost_p for one pose (position, quaternion w x y z); returns costp
+double orc_grad_cost_p(void *h, const double pos[3], const double quat[4], double gradp[3], double gradq[4], int *active) {
+    OrcCtx &c = *(OrcCtx *)h;
+    c.sync();
+    V4 q; q.w = quat[0]; q.x = quat[1]; q.y = quat[2]; q.z = quat[3];
+    const M3 R = quat_to_rot(q);
+    V3 gp; V4 gq; double costp = 0.0;
+    const bool a = grad_cost_p(c.P, V3(pos[0], pos[1], pos[2]), R, q, gp, gq, costp, nullptr);
+    *active = a ? 1 : 0;
+    gradp[0] = gp.x; gradp[1] = gp.y; gradp[2] = gp.z;
+    gradq[0] = gq.w; gradq[1] = gq.x; gradq[2] = gq.y; gradq[3] = gq.z;
+    return costp;
+}
 void orc_flat_forward(const double fp[6], const double vel[3], const double acc[3], const double jer[3],
                       double quat[4], double omg[3]) {
     FlatParams P{fp[0], fp[1], fp[2], fp[3], fp[4], fp[5]};

@@ -103,6 +103,13 @@ class Oracle:
         self.lib.orc_aabb_index_box(self.h, _p(pos), float(half), lo, hi)
         return list(lo), list(hi)
 
+    def grad_cost_p(self, pos, quat):
+        pos = np.asarray(pos, dtype=np.float64); quat = np.asarray(quat, dtype=np.float64)
+        gp = np.zeros(3); gq = np.zeros(4); a = C.c_int(0)
+        self.lib.orc_grad_cost_p.restype = C.c_double
+        c = self.lib.orc_grad_cost_p(self.h, _p(pos), _p(quat), _p(gp), _p(gq), C.byref(a))
+        return c, gp, gq, bool(a.value)
+
     def swept_sdf(self, T, coeffs_colmajor, p, tstar0=0.0):
         T = np.ascontiguousarray(T, dtype=np.float64)
         Cc = np.ascontiguousarray(coeffs_colmajor, dtype=np.float64)
@@ -240,6 +247,94 @@ class RefShape:
             self.lib.ref_shape_destroy(self.h)
         except Exception:
             pass
+
+
+REF_SWEEPS = os.path.join(os.path.dirname(os.path.abspath(__file__)), "_ref", "libref_sweeps.so")
+
+
+class RefWorld:
+    """The reference's OWN hot loop (oracle/_ref/libref_sweeps.so): SweptVolumeManager's swept-volume query, TrajOptimizer's
+    two sweeps and grad_cost_p, PCSmapManager::getPointsInAABB, GridMap3D incl. generateESDF3d and the trilinear sampler -
+    the line ranges listed in oracle/ref_build/ref_sweeps.cpp, extracted from /root/reference at build time and compiled
+    against the Eigen stand-in.  cfg: an isdf_config (the same one the oracle / engine get); shape: an isdf_shape of an
+    analytic kind created by synth.make_shape(name, ...)."""
+
+    def __init__(self, cfg, shape_name, shape, res, threads=1):
+        self.lib = L = C.CDLL(REF_SWEEPS)
+        L.ref_world_create.restype = C.c_void_p
+        for f in (L.ref_swept_sdf, L.ref_grad_cost_p, L.ref_world_esdf_sample):
+            f.restype = C.c_double
+        c = np.array([cfg.safety_hor, cfg.weight_p, cfg.weight_v, cfg.weight_omg, cfg.weight_theta, cfg.vmax, cfg.omgmax,
+                      cfg.thetamax, cfg.smoothing_eps, cfg.kernel_size * res, cfg.vehicle_mass, cfg.grav_acc, cfg.horiz_drag,
+                      cfg.vert_drag, cfg.paras_drag, cfg.speed_eps, res], dtype=np.float64)
+        trans = np.array([shape.trans[i] for i in range(3)])
+        rot = np.array([shape.rotate[i] for i in range(9)])
+        box = np.array([shape.params[i] for i in range(3)]) if shape_name == "Box" else None
+        self.h = C.c_void_p(L.ref_world_create(_p(c), C.c_int(cfg.integral_intervs), C.c_int(threads), shape_name.encode(),
+                                               _p(trans), _p(rot), None if box is None else _p(box)))
+        if not self.h.value:
+            raise ValueError(f"unknown reference shape class {shape_name}")
+        self.M = 0
+
+    def __del__(self):
+        try:
+            self.lib.ref_world_destroy(self.h)
+        except Exception:
+            pass
+
+    def set_occupancy(self, occ, origin, res, bmax=None):
+        occ = np.ascontiguousarray(occ, dtype=np.uint8)
+        o = np.asarray(origin, dtype=np.float64)
+        bm = o + np.array(occ.shape) * res if bmax is None else np.asarray(bmax, dtype=np.float64)
+        self.shape3 = occ.shape
+        self.lib.ref_world_set_occupancy(self.h, occ.ctypes.data_as(C.c_void_p), occ.shape[0], occ.shape[1], occ.shape[2], _p(o), _p(bm), C.c_double(res))
+
+    def generate_esdf(self):
+        out = np.zeros(self.shape3, dtype=np.float64)
+        self.lib.ref_world_generate_esdf(self.h, _p(out))
+        return out
+
+    def esdf_sample(self, pos):
+        pos = np.asarray(pos, dtype=np.float64); g = np.zeros(3)
+        return self.lib.ref_world_esdf_sample(self.h, _p(pos), _p(g)), g
+
+    def points_in_aabb(self, center, half):
+        c = np.asarray(center, dtype=np.float64)
+        n = self.lib.ref_world_points_in_aabb(self.h, _p(c), C.c_double(half), None, 0)
+        out = np.zeros((n, 3))
+        if n:
+            self.lib.ref_world_points_in_aabb(self.h, _p(c), C.c_double(half), _p(out), n)
+        return out
+
+    def set_points(self, pts):
+        pts = np.ascontiguousarray(pts, dtype=np.float64).reshape(-1, 3)
+        self.M = pts.shape[0]
+        self.lib.ref_world_set_points(self.h, _p(pts), pts.shape[0])
+
+    def sweep_swept(self, T, cm, tstar=None):
+        T = np.ascontiguousarray(T, dtype=np.float64); cm = np.ascontiguousarray(cm, dtype=np.float64); N = T.size
+        cost = np.zeros(1); gT = np.zeros(N); gC = np.zeros(18 * N)
+        ts = np.zeros(self.M) if tstar is None else tstar
+        self.lib.ref_sweep_swept(self.h, N, _p(T), _p(cm), _p(cost), _p(gT), _p(gC), _p(ts))
+        return float(cost[0]), gT, gC, ts
+
+    def sweep_integral(self, T, cm):
+        T = np.ascontiguousarray(T, dtype=np.float64); cm = np.ascontiguousarray(cm, dtype=np.float64); N = T.size
+        cost = np.zeros(1); gT = np.zeros(N); gC = np.zeros(18 * N)
+        self.lib.ref_sweep_integral(self.h, N, _p(T), _p(cm), _p(cost), _p(gT), _p(gC))
+        return float(cost[0]), gT, gC
+
+    def swept_sdf(self, T, cm, p, tstar0=0.0):
+        T = np.ascontiguousarray(T, dtype=np.float64); cm = np.ascontiguousarray(cm, dtype=np.float64)
+        p = np.asarray(p, dtype=np.float64); ts = C.c_double(tstar0); g = np.zeros(3)
+        s = self.lib.ref_swept_sdf(self.h, T.size, _p(T), _p(cm), _p(p), C.byref(ts), _p(g))
+        return s, ts.value, g
+
+    def grad_cost_p(self, pos, quat):
+        pos = np.asarray(pos, dtype=np.float64); quat = np.asarray(quat, dtype=np.float64)
+        gp = np.zeros(3); gq = np.zeros(4); a = C.c_int(0)
+        c = self.lib.ref_grad_cost_p(self.h, _p(pos), _p(quat), _p(gp), _p(gq), C.byref(a))
+        return c, gp, gq, bool(a.value)
 
 
 REF_MINCO = os.path.join(os.path.dirname(os.path.abspath(__file__)), "_ref", "libref_minco.so")

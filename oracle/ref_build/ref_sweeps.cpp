@@ -1,0 +1,257 @@
+// Builds the reference's own hot loop behind a C ABI so that tests can pin the oracle against the REAL code:
+//   SweptVolumeManager  updateTraj / getStateOnTrajStamp / posEva2Rel   sw_manager.hpp:287-358
+//                       choiceTInit :367-445, getSDF...AtTimeStamp :537-572, getSDF_DOTAtTimeStampOptimized :593-662,
+//                       getSDFofSweptVolume<> :710-747, gradientDescent :1000-1062
+//   TrajOptimizer       getQuatTransD* back_end_optimizer.hpp:127-173, smoothedL1 :332-356,
+//                       addTimeIntPenaltyParallel :432-554, addSaftyPenaOnSweptVolumeParallel :557-649,
+//                       grad_cost_p :766-824, grad_cost_p_sw :827-866
+//   PCSmapManager       projInMap + getPointsInAABB PCSmap_manager.h:130-170
+//   GridMap3D           Gridmap3D.cpp:41-258 (isInMap .. isIndexOccupied), generateESDF3d + fillESDF :361-533,
+//                       getGridSDFValue :535-553, trilinear samplers GridMap3D.h:114-195
+// sw_manager.hpp / back_end_optimizer.hpp / PCSmap_manager.h as a whole need ROS, PCL, libigl and yaml, so the Makefile
+// EXTRACTS exactly those line ranges from /root/reference into oracle/_ref/gen/ at build time (generated, git-ignored,
+// never committed); this file supplies the class shells (the data members those functions read) around them.
+// flatness.hpp, trajectory.hpp, minco.hpp are included whole.  Eigen is the stand-in of eigen_shim/.
+// TEST INFRASTRUCTURE ONLY.
+#include "ref_shapes_common.hpp"
+#include <cfloat>
+#include <ros/ros.h>
+#include <cassert>
+#include <limits>
+#include <utils/flatness.hpp>
+#include <utils/minco.hpp>          // brings trajectory.hpp (Trajectory<5>, Piece)
+#define TRAJ_ORDER 5
+#define ROS_ERROR(...) do { } while (0)
+using Eigen::Vector3i; using Eigen::Vector3d; using Eigen::Matrix3d;
+
+// ---------------------------------------------------------------- GridMap3D (map_manager)
+class GridMap3D {
+public:
+    int X_size = 0, Y_size = 0, Z_size = 0, totalsize = 0;
+    double grid_resolution = 1.0;
+    Vector3d boundary_xyzmin, boundary_xyzmax;
+    double *grid_map = nullptr, *grid_map_buffer_neg = nullptr, *grid_map_buffer_all = nullptr;
+    bool *grid_map_flags = nullptr;
+    double *grid_esdf = nullptr, *grid_esdf_buffer1 = nullptr, *grid_esdf_buffer2 = nullptr;
+    ~GridMap3D() { delete[] grid_map; delete[] grid_map_buffer_neg; delete[] grid_map_buffer_all; delete[] grid_map_flags;
+                   delete[] grid_esdf; delete[] grid_esdf_buffer1; delete[] grid_esdf_buffer2; }
+    void createGridMap(const Vector3d &boundary_xyzmin, const Vector3d &boundary_xyzmax);
+    bool isInMap(const Vector3d &pos_w) const;
+    bool isIndexValid(const Vector3i &index) const;
+    bool isIndexValid(const int ix, const int iy, const int iz) const;
+    Vector3i getGridIndex(const Vector3d &pos_w);
+    Vector3d getGridCubeCenter(int ix, int iy, int iz);
+    Vector3d getGridCubeCenter(const Vector3i &index);
+    bool isIndexOccupied(const Vector3i &index);
+    bool isIndexOccupiedFlate(const Vector3i &index, const int flate_pix);
+    bool isIndexOccupied(int ix, int iy, int iz);
+    int getVoxelNum(int dim);
+    void generateESDF3d();
+    template <typename F_get_val, typename F_set_val>
+    void fillESDF(F_get_val f_get_val, F_set_val f_set_val, int start, int end, int dim);
+    double getGridSDFValue(const Vector3i &index);
+    double getGridSDFValue(int ix, int iy, int iz);
+#include "../_ref/gen/gridmap_h.inc"          // GridMap3D.h:114-197: getSDFValue, getSDFValueWithGrad, toAddr
+};
+#include "../_ref/gen/gridmap_cpp_a.inc"      // Gridmap3D.cpp:25-39 createGridMap, :41-258 isInMap .. isIndexOccupied
+#include "../_ref/gen/gridmap_cpp_b.inc"      // Gridmap3D.cpp:339-353 getVoxelNum, :361-553 generateESDF3d, fillESDF, getGridSDFValue
+
+// ---------------------------------------------------------------- PCSmapManager (map_manager)
+class PCSmapManager {
+public:
+    GridMap3D *occupancy_map = nullptr;
+    Vector3d boundary_xyzmin, boundary_xyzmax;
+#include "../_ref/gen/pcsmap.inc"             // PCSmap_manager.h:130-170 projInMap, getPointsInAABB
+};
+
+// ---------------------------------------------------------------- SweptVolumeManager (swept_volume)
+class SweptVolumeManager {
+public:
+    Config config;
+    Trajectory<TRAJ_ORDER> traj;
+    double traj_duration = 0.0, t_min = 0.0, t_max = 0.0, momentum = 0.0;
+    double veps = 0, cp = 0, dh_over_m = 0, grav = 0;            // set like the constructor does (sw_manager.hpp:205-216)
+    flatness::FlatnessMap flatness;
+    shape::Generalshape *current_robot_shape = nullptr;
+#include "../_ref/gen/swm_a.inc"              // :287-358
+#include "../_ref/gen/swm_b.inc"              // :367-445
+#include "../_ref/gen/swm_c.inc"              // :537-572
+#include "../_ref/gen/swm_d.inc"              // :593-662
+#include "../_ref/gen/swm_e.inc"              // :710-747
+#include "../_ref/gen/swm_f.inc"              // :1000-1062
+};
+
+// ---------------------------------------------------------------- TrajOptimizer (planner_algorithm)
+class TrajOptimizer {
+public:
+    Config conf;
+    double vmax = 0, omgmax = 0, thetamax = 0, weight_v = 0, weight_p = 0, weight_omg = 0, weight_theta = 0;
+    double smooth_fac = 0, safety_hor = 0, bdx = 0, bdy = 0, bdz = 0;
+    int integralRes = 1, threads_num = 1, parallel_points_num = 0;
+    std::vector<Eigen::Vector3d> parallel_points;
+    std::vector<double> lastTstar;
+    SweptVolumeManager *sv_manager = nullptr;
+    PCSmapManager *pcsmap_manager = nullptr;
+    Trajectory<TRAJ_ORDER> step_traj;
+    flatness::FlatnessMap flatmap;
+#include "../_ref/gen/beo_a.inc"              // :127-173
+#include "../_ref/gen/beo_b.inc"              // :332-356
+#include "../_ref/gen/beo_c.inc"              // :432-554
+#include "../_ref/gen/beo_d.inc"              // :557-649
+#include "../_ref/gen/beo_e.inc"              // :766-824
+#include "../_ref/gen/beo_f.inc"              // :827-866
+};
+
+namespace {
+struct World {
+    Config conf;
+    GridMap3D grid;
+    PCSmapManager pcs;
+    SweptVolumeManager sv;
+    TrajOptimizer opt;
+    shape::Generalshape *shape = nullptr;
+    ~World() { delete shape; }
+};
+// Trajectory<5> from the optimizer's coefficient matrix, exactly like MINCO_S3NU::getTrajectory (minco.hpp:515-528)
+void make_traj(int N, const double *T, const double *coeffs, Trajectory<5> &traj, Eigen::VectorXd &Tv, Eigen::MatrixX3d &b) {
+    Tv.resize(N);
+    b.resize(6 * N, 3);
+    for (int i = 0; i < N; i++) Tv(i) = T[i];
+    for (int c = 0; c < 3; c++) for (int r = 0; r < 6 * N; r++) b(r, c) = coeffs[(size_t)c * 6 * N + r];
+    traj.clear();
+    traj.reserve(N);
+    for (int i = 0; i < N; i++) traj.emplace_back(Tv(i), b.block<6, 3>(6 * i, 0).transpose().rowwise().reverse());
+}
+}
+
+extern "C" {
+// cfg doubles: [safety_hor, weight_p, weight_v, weight_omg, weight_theta, vmax, omgmax, thetamax, smooth_fac, bd (= kernel_size*res),
+//               mass, grav, horiz_drag, vert_drag, paras_drag, speed_eps, occupancy_resolution];  K = integralIntervs
+void *ref_world_create(const double *cfg, int K, int threads, const char *shape_name, const double *trans, const double *rotate,
+                       const double *box) {
+    World *w = new World();
+    Config &c = w->conf;
+    c.safety_hor = cfg[0]; c.occupancy_resolution = cfg[16];
+    c.trans = Eigen::RowVector3d(trans[0], trans[1], trans[2]);
+    for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) c.rotate(i, j) = rotate[3 * i + j];
+    if (box) { c.box_x = box[0]; c.box_y = box[1]; c.box_z = box[2]; }
+    w->shape = make(shape_name, c);
+    if (!w->shape) { delete w; return nullptr; }
+    SweptVolumeManager &sv = w->sv;
+    sv.config = c;
+    sv.current_robot_shape = w->shape;
+    sv.flatness.reset(cfg[10], cfg[11], cfg[12], cfg[13], cfg[14], cfg[15]);
+    // the members getSDF_DOTAtTimeStampOptimized reads (sw_manager.hpp constructor)
+    sv.veps = cfg[15]; sv.cp = cfg[14]; sv.dh_over_m = cfg[12] / cfg[10]; sv.grav = cfg[11];
+    TrajOptimizer &o = w->opt;
+    o.conf = c;
+    o.safety_hor = cfg[0]; o.weight_p = cfg[1]; o.weight_v = cfg[2]; o.weight_omg = cfg[3]; o.weight_theta = cfg[4];
+    o.vmax = cfg[5]; o.omgmax = cfg[6]; o.thetamax = cfg[7]; o.smooth_fac = cfg[8];
+    o.bdx = o.bdy = o.bdz = cfg[9];
+    o.integralRes = K; o.threads_num = threads;
+    o.sv_manager = &w->sv;
+    o.pcsmap_manager = &w->pcs;
+    o.flatmap.reset(cfg[10], cfg[11], cfg[12], cfg[13], cfg[14], cfg[15]);
+    w->pcs.occupancy_map = &w->grid;
+    return w;
+}
+void ref_world_destroy(void *h) { delete (World *)h; }
+
+// occupancy grid (uint8, z fastest) -> GridMap3D::grid_map; optionally the reference's own generateESDF3d
+void ref_world_set_occupancy(void *h, const unsigned char *occ, int nx, int ny, int nz, const double *bmin, const double *bmax, double res) {
+    World *w = (World *)h;
+    GridMap3D &g = w->grid;
+    g.grid_resolution = res;
+    Vector3d lo(bmin[0], bmin[1], bmin[2]), hi(bmax[0], bmax[1], bmax[2]);
+    g.createGridMap(lo, hi);
+    assert(g.X_size == nx && g.Y_size == ny && g.Z_size == nz);
+    for (int i = 0; i < g.totalsize; i++) g.grid_map[i] = occ[i] ? 1.0 : 0.0;
+    w->pcs.boundary_xyzmin = lo; w->pcs.boundary_xyzmax = hi;
+}
+void ref_world_generate_esdf(void *h, double *out) {
+    World *w = (World *)h;
+    w->grid.generateESDF3d();
+    for (int i = 0; i < w->grid.totalsize; i++) out[i] = w->grid.grid_esdf[i];
+}
+// trilinear samplers of GridMap3D.h:114-193 on the reference's ESDF
+double ref_world_esdf_sample(void *h, const double *pos, double *grad) {
+    World *w = (World *)h;
+    Vector3d p(pos[0], pos[1], pos[2]), g;
+    const double v = w->grid.getSDFValueWithGrad(p, g);
+    for (int i = 0; i < 3; i++) grad[i] = g(i);
+    return v;
+}
+int ref_world_points_in_aabb(void *h, const double *center, double half, double *out, int cap) {
+    World *w = (World *)h;
+    std::vector<Eigen::Vector3d> pts;
+    w->pcs.getPointsInAABB(Vector3d(center[0], center[1], center[2]), half, half, half, pts);
+    const int n = (int)pts.size();
+    for (int i = 0; i < std::min(n, cap); i++) for (int a = 0; a < 3; a++) out[3 * i + a] = pts[i](a);
+    return n;
+}
+void ref_world_set_points(void *h, const double *xyz, int M) {
+    World *w = (World *)h;
+    w->opt.parallel_points.clear();
+    for (int i = 0; i < M; i++) w->opt.parallel_points.push_back(Vector3d(xyz[3 * i], xyz[3 * i + 1], xyz[3 * i + 2]));
+    w->opt.parallel_points_num = M;
+    w->opt.lastTstar.assign(M, 0.0);
+}
+
+// addSaftyPenaOnSweptVolumeParallel: accumulates into cost / gradT / gradC (column-major 6N x 3); tstar: M
+void ref_sweep_swept(void *h, int N, const double *T, const double *coeffs, double *cost, double *gradT, double *gradC, double *tstar) {
+    World *w = (World *)h;
+    Eigen::VectorXd Tv; Eigen::MatrixX3d b;
+    make_traj(N, T, coeffs, w->opt.step_traj, Tv, b);
+    w->sv.updateTraj(w->opt.step_traj);                 // costFunctionLmbm :381-382
+    Eigen::VectorXd gT(N); Eigen::MatrixX3d gC(6 * N, 3);
+    for (int i = 0; i < N; i++) gT(i) = gradT[i];
+    for (int c = 0; c < 3; c++) for (int r = 0; r < 6 * N; r++) gC(r, c) = gradC[(size_t)c * 6 * N + r];
+    for (size_t i = 0; i < w->opt.lastTstar.size(); i++) w->opt.lastTstar[i] = tstar[i];
+    double cst = *cost;
+    TrajOptimizer::addSaftyPenaOnSweptVolumeParallel(&w->opt, Tv, b, cst, gT, gC);
+    *cost = cst;
+    for (int i = 0; i < N; i++) gradT[i] = gT(i);
+    for (int c = 0; c < 3; c++) for (int r = 0; r < 6 * N; r++) gradC[(size_t)c * 6 * N + r] = gC(r, c);
+    for (size_t i = 0; i < w->opt.lastTstar.size(); i++) tstar[i] = w->opt.lastTstar[i];
+}
+// addTimeIntPenaltyParallel
+void ref_sweep_integral(void *h, int N, const double *T, const double *coeffs, double *cost, double *gradT, double *gradC) {
+    World *w = (World *)h;
+    Eigen::VectorXd Tv; Eigen::MatrixX3d b;
+    Trajectory<5> tr;
+    make_traj(N, T, coeffs, tr, Tv, b);
+    Eigen::VectorXd gT(N); Eigen::MatrixX3d gC(6 * N, 3);
+    for (int i = 0; i < N; i++) gT(i) = gradT[i];
+    for (int c = 0; c < 3; c++) for (int r = 0; r < 6 * N; r++) gC(r, c) = gradC[(size_t)c * 6 * N + r];
+    double cst = *cost, pos_cost = 0.0;
+    TrajOptimizer::addTimeIntPenaltyParallel(&w->opt, Tv, b, cst, pos_cost, gT, gC);
+    *cost = cst;
+    for (int i = 0; i < N; i++) gradT[i] = gT(i);
+    for (int c = 0; c < 3; c++) for (int r = 0; r < 6 * N; r++) gradC[(size_t)c * 6 * N + r] = gC(r, c);
+}
+// one swept-volume query: getSDFofSweptVolume<true>(p, t*, grad, false)
+double ref_swept_sdf(void *h, int N, const double *T, const double *coeffs, const double *p, double *tstar, double *grad) {
+    World *w = (World *)h;
+    Eigen::VectorXd Tv; Eigen::MatrixX3d b;
+    make_traj(N, T, coeffs, w->opt.step_traj, Tv, b);
+    w->sv.updateTraj(w->opt.step_traj);
+    Vector3d g(grad[0], grad[1], grad[2]);
+    double ts = *tstar;
+    const double s = w->sv.getSDFofSweptVolume<true>(Vector3d(p[0], p[1], p[2]), ts, g, false);
+    *tstar = ts;
+    for (int i = 0; i < 3; i++) grad[i] = g(i);
+    return s;
+}
+// grad_cost_p for one pose (pos, quat w x y z): returns costp, fills gradp[3], grad_quat[4]
+double ref_grad_cost_p(void *h, const double *pos, const double *quat, double *gradp, double *gradq, int *active) {
+    World *w = (World *)h;
+    Eigen::Vector4d q(quat[0], quat[1], quat[2], quat[3]);
+    Matrix3d R = Eigen::Quaterniond(quat[0], quat[1], quat[2], quat[3]).toRotationMatrix();
+    Vector3d gp; Eigen::Vector4d gq; double costp = 0.0;
+    const bool a = w->opt.grad_cost_p(Vector3d(pos[0], pos[1], pos[2]), R, q, gp, gq, costp);
+    *active = a ? 1 : 0;
+    for (int i = 0; i < 3; i++) gradp[i] = gp(i);
+    for (int i = 0; i < 4; i++) gradq[i] = gq(i);
+    return costp;
+}
+}

@@ -165,3 +165,107 @@ def test_analytic_shapes_vs_reference_classes(pkg, orc, name, capfd):
     ok = np.isfinite(g_r).all(axis=1)
     assert ok.mean() > 0.99
     assert np.allclose(g_o[ok], g_r[ok], rtol=0, atol=2e-7), np.abs(g_o[ok] - g_r[ok]).max()
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# The hot loop itself: the oracle vs the reference's OWN code (oracle/_ref/libref_sweeps.so)
+# ---------------------------------------------------------------------------------------------------------------------
+def _ref_world(pkg, orc, variant, shape_name="RoundedCone", seed=3, threads=4, **cfgkw):
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from common import small_world, traj
+    if not os.path.exists(orc.REF_SWEEPS):
+        pytest.skip("oracle/_ref/libref_sweeps.so not built")
+    capi, synth = pkg.capi, pkg.synth
+    occ, esdf, res = small_world(pkg, seed=seed)
+    kw = dict(kernel_size=9, integral_intervs=16, safety_hor=0.5)
+    kw.update(cfgkw)
+    cfg = synth.default_config(variant, **kw)
+    shape = synth.make_shape(shape_name, poly_params=(0.1, -0.05, 0.08, 20, -10, 40)) if shape_name != "RoundedCone" else \
+        synth.make_shape("RoundedCone", params=(1.5, 0.6, 4.5), poly_params=(0.1, -0.05, 0.08, 20, -10, 40))
+    ref = orc.RefWorld(cfg, shape_name, shape, res, threads=threads)
+    ref.set_occupancy(occ, (0, 0, 0), res)
+    o = orc.Oracle(cfg, threads=threads)
+    o.set_grid(occ, (0, 0, 0), res, capi.GRID_OCCUPANCY)
+    o.set_shape(shape)
+    return cfg, occ, res, shape, ref, o
+
+
+@pytest.mark.parametrize("shape_name", ["RoundedCone", "Torus", "Box"])
+def test_swept_sweep_vs_reference_code(pkg, orc, shape_name):
+    """addSaftyPenaOnSweptVolumeParallel + getSDFofSweptVolume (choiceTInit, gradientDescent, getSDF_DOT...) of the
+    reference itself vs the oracle's restatement: cost, gradT, gradC, t* per point."""
+    from common import traj
+    capi, synth = pkg.capi, pkg.synth
+    cfg, occ, res, shape, ref, o = _ref_world(pkg, orc, capi.V1_SWEPT, shape_name, seed=3)
+    N = 6
+    T, cm = traj(pkg, occ, res, N=N, seed=43)
+    way = cm.reshape(3, -1).T.reshape(N, 6, 3)[1:, 0, :]
+    pts = synth.constraint_points(occ, (0, 0, 0), res, way, half=3.0)
+    assert pts.shape[0] > 50
+    ref.set_points(pts); o.set_points(pts)
+    c_r, gT_r, gC_r, ts_r = ref.sweep_swept(T, cm)
+    ts_o = np.zeros(pts.shape[0])
+    c_o, gT_o, gC_o, st = o.eval(T, cm, tstar=ts_o)
+    assert c_r > 0
+    assert abs(c_o - c_r) <= 1e-9 * abs(c_r), (c_o, c_r)
+    assert np.allclose(ts_o, ts_r, rtol=0, atol=1e-9)
+    sc = np.abs(gC_r).max()
+    assert np.allclose(gC_o, gC_r, rtol=1e-7, atol=1e-9 * sc) and np.allclose(gT_o, gT_r, rtol=1e-7, atol=1e-9 * np.abs(gT_r).max())
+    # single queries incl. points with no qualifying interval (returns 10, t* untouched)
+    for p in (pts[0], pts[len(pts) // 2], np.array([1.0, 1.0, 14.0])):
+        s_r, t_r, g_r = ref.swept_sdf(T, cm, p, tstar0=0.3)
+        s_o, t_o, g_o, nr = o.swept_sdf(T, cm, p, tstar0=0.3)
+        assert abs(s_o - s_r) <= 1e-10 * max(1.0, abs(s_r)) and abs(t_o - t_r) <= 1e-9
+
+
+def test_integral_sweep_vs_reference_code(pkg, orc):
+    """addTimeIntPenaltyParallel of the reference itself (velocity / body-rate / tilt penalties, flatness back-prop,
+    trapezoid weights) vs the oracle with the collision term off."""
+    from common import traj
+    capi, synth = pkg.capi, pkg.synth
+    cfg, occ, res, shape, ref, o = _ref_world(pkg, orc, capi.V3_ESDF_TILE, seed=3, enable_pos=0, vmax=1.5, omgmax=0.6, thetamax=0.25)
+    T, cm = traj(pkg, occ, res, N=6, seed=11, piece_T=0.45)
+    c_r, gT_r, gC_r = ref.sweep_integral(T, cm)
+    c_o, gT_o, gC_o, _ = o.eval(T, cm)
+    assert c_r > 0
+    assert abs(c_o - c_r) <= 1e-11 * abs(c_r)
+    assert np.allclose(gC_o, gC_r, rtol=1e-9, atol=1e-11 * np.abs(gC_r).max()) and np.allclose(gT_o, gT_r, rtol=1e-9, atol=1e-11 * np.abs(gT_r).max())
+
+
+def test_grad_cost_p_and_grid_vs_reference_code(pkg, orc):
+    """grad_cost_p (per-pose tile term), getPointsInAABB, generateESDF3d and the trilinear ESDF sampler of the reference
+    itself vs the oracle."""
+    capi, synth = pkg.capi, pkg.synth
+    cfg, occ, res, shape, ref, o = _ref_world(pkg, orc, capi.V2_OCC_TILE, seed=5)
+    # ESDF: bit-exact
+    e_r = ref.generate_esdf()
+    e_o = orc.build_esdf(occ, res)
+    assert np.array_equal(e_o, e_r)
+    o2 = orc.Oracle(cfg); o2.set_grid(e_o, (0, 0, 0), res, capi.GRID_ESDF)
+    rng = np.random.default_rng(8)
+    ext = np.array(occ.shape) * res
+    for _ in range(200):
+        p = rng.uniform(-0.5, 1.0, 3) * 0 + rng.uniform(0.3, 0.97, 3) * ext
+        v_r, g_r = ref.esdf_sample(p)
+        v_o, g_o = o2.esdf_trilinear(p)
+        # the oracle (like the device) stores the ESDF as float32 - the only place where it departs from the reference's doubles
+        assert abs(v_o - v_r) <= 2e-7 * max(1.0, abs(v_r)) and np.allclose(g_o, g_r, rtol=1e-5, atol=2e-6)
+    # the tile of a pose + the per-pose collision term
+    n_active = 0
+    for k in range(60):
+        pos = rng.uniform(0.15, 0.85, 3) * ext
+        lo, hi = o.aabb_index_box(pos, cfg.kernel_size * res / 2)
+        pts_r = ref.points_in_aabb(pos, cfg.kernel_size * res / 2)
+        sub = occ[lo[0]:hi[0] + 1, lo[1]:hi[1] + 1, lo[2]:hi[2] + 1]
+        assert pts_r.shape[0] == int(sub.sum())
+        tilt = rng.normal(0, 0.25, 2)
+        q = np.array([1.0, tilt[0], tilt[1], 0.0]); q /= np.linalg.norm(q)
+        c_r, gp_r, gq_r, a_r = ref.grad_cost_p(pos, q)
+        c_o, gp_o, gq_o, a_o = o.grad_cost_p(pos, q)
+        assert a_r == a_o
+        assert abs(c_o - c_r) <= 1e-11 * max(1.0, abs(c_r))
+        assert np.allclose(gp_o, gp_r, rtol=1e-8, atol=1e-9 * max(1.0, np.abs(gp_r).max()))
+        assert np.allclose(gq_o, gq_r, rtol=1e-8, atol=1e-9 * max(1.0, np.abs(gq_r).max()))
+        n_active += int(a_r)
+    assert n_active > 10
