@@ -2,7 +2,7 @@
 (src/utils/include/utils/lbfgs.hpp: line_search_lewisoverton :290-440, lbfgs_optimize :480-835 - the LBFGS-Lite fork with
 the Armijo-only acceptance :373-386 and the steepest-descent "patches" :788-819), written as plain sequential Python so
 that the product driver (csrc/lbfgs_host.hpp) can be compared iterate by iterate on small problems.
-Parity unpinned against a reference binary (lbfgs.hpp needs Eigen, absent here); Eigen's vectorised dot/norm reductions
+Pinned against the reference's own lbfgs.hpp (oracle/_ref/libref_lbfgs.so, tests/test_oracle_ref.py); real Eigen's vectorised dot/norm reductions
 may order their sums differently, which only matters at rounding level."""
 import math
 

@@ -2,8 +2,8 @@
 // CPU restatement of the robot-shape plugin (SDF + body-frame gradient) used on the hot path.
 // Each function names the class in src/utils/include/utils/Shape.hpp whose getonlySDF it follows; the
 // class constants are carried in isdf_shape.params (include/isdf_accel.h documents the slot meaning).
-// Parity status: analytic kinds are pinned by the reference source text only (the header needs Eigen, ROS
-// and libigl, none of which exist in the build container) — "parity unpinned" against a reference binary.
+// Parity status: every analytic kind is pinned against the reference's OWN class (oracle/_ref/libref_shapes.so:
+// Shape.hpp:824-2391 extracted at build time, compiled against the Eigen stand-in; tests/test_oracle_ref.py).
 #pragma once
 #include "vecmath.hpp"
 #include "mesh_sdf.hpp"

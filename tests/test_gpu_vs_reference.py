@@ -1,0 +1,119 @@
+"""The device path through the C ABI against the reference's OWN code (oracle/_ref/*.so: line ranges of the reference
+compiled from /root/reference against a mini-Eigen stand-in; the prebuilt libraries travel to the GPU box).
+No oracle restatement in between: swept-volume sweep, integral sweep, ESDF, and the full costFunctionLmbm assembled from
+the reference's MINCO_S3NU + its two sweeps + its propogateGrad."""
+import os
+
+import numpy as np
+import pytest
+
+from common import REL_TOL, assert_close, small_world, traj, tau_to_T, T_to_tau
+
+pytestmark = pytest.mark.gpu
+
+
+def _need(orc, *libs):
+    for l in libs:
+        if not os.path.exists(l):
+            pytest.skip(f"{os.path.basename(l)} not built (needs /root/reference at build time)")
+
+
+def _world(pkg, orc, variant, shape_name, seed, **cfgkw):
+    capi, synth = pkg.capi, pkg.synth
+    occ, esdf, res = small_world(pkg, seed=seed)
+    kw = dict(kernel_size=9, integral_intervs=16, safety_hor=0.5)
+    kw.update(cfgkw)
+    cfg = synth.default_config(variant, **kw)
+    pp = (0.1, -0.05, 0.08, 20, -10, 40)
+    shape = synth.make_shape(shape_name, poly_params=pp)
+    ref = orc.RefWorld(cfg, shape_name, shape, res, threads=8)
+    ref.set_occupancy(occ, (0, 0, 0), res)
+    eng = pkg.Engine(cfg)
+    eng.set_grid(occ, (0, 0, 0), res, capi.GRID_OCCUPANCY)
+    eng.set_shape(shape)
+    return cfg, occ, res, ref, eng
+
+
+@pytest.mark.parametrize("shape_name", ["RoundedCone", "Torus_big", "Box", "SmoothIntersection_big"])
+def test_device_swept_sweep_vs_reference(pkg, orc, product_lib, shape_name):
+    _need(orc, orc.REF_SWEEPS)
+    capi, synth = pkg.capi, pkg.synth
+    cfg, occ, res, ref, eng = _world(pkg, orc, capi.V1_SWEPT, shape_name, 3)
+    N = 6
+    T, cm = traj(pkg, occ, res, N=N, seed=43)
+    way = cm.reshape(3, -1).T.reshape(N, 6, 3)[1:, 0, :]
+    M = eng.gather_points(way, 3.0)
+    pts = eng.get_points()
+    assert M > 50
+    ref.set_points(pts)
+    c_r, gT_r, gC_r, ts_r = ref.sweep_swept(T, cm)
+    ts = np.zeros(M)
+    c, gT, gC = eng.eval_single(T, cm, tstar=ts)
+    if shape_name in ("RoundedCone", "Box"):
+        assert c_r > 0                              # these two are large enough to touch the obstacles of this scenario
+    assert abs(c - c_r) <= REL_TOL * max(abs(c_r), 1e-9)
+    assert_close(gT, gT_r, "gradT vs reference"); assert_close(gC, gC_r, "gradC vs reference")
+    assert np.allclose(ts, ts_r, rtol=0, atol=1e-7)
+
+
+def test_device_integral_sweep_vs_reference(pkg, orc, product_lib):
+    _need(orc, orc.REF_SWEEPS)
+    capi = pkg.capi
+    cfg, occ, res, ref, eng = _world(pkg, orc, capi.V3_ESDF_TILE, "RoundedCone", 3, enable_pos=0, vmax=1.5, omgmax=0.6, thetamax=0.25)
+    T, cm = traj(pkg, occ, res, N=6, seed=11, piece_T=0.45)
+    c_r, gT_r, gC_r = ref.sweep_integral(T, cm)
+    c, gT, gC = eng.eval_single(T, cm)
+    assert c_r > 0 and abs(c - c_r) <= REL_TOL * abs(c_r)
+    assert_close(gT, gT_r, "gradT vs reference"); assert_close(gC, gC_r, "gradC vs reference")
+
+
+def test_device_esdf_vs_reference(pkg, orc, product_lib):
+    _need(orc, orc.REF_SWEEPS)
+    capi = pkg.capi
+    cfg, occ, res, ref, eng = _world(pkg, orc, capi.V3_ESDF_TILE, "RoundedCone", 9)
+    eng.generate_esdf()
+    e, _, _ = eng.get_grid(capi.GRID_ESDF)
+    e_r = ref.generate_esdf()                       # GridMap3D::generateESDF3d, the reference's doubles
+    assert np.array_equal(e, e_r.astype(np.float32))
+
+
+@pytest.mark.parametrize("variant", ["V1", "dyn"])
+def test_device_callback_vs_reference_pieces(pkg, orc, product_lib, variant):
+    """costFunctionLmbm assembled from the reference's own MINCO_S3NU (setParameters, getEnergy*, propogateGrad) and its
+    own sweeps vs isdf_cost_function."""
+    _need(orc, orc.REF_SWEEPS, orc.REF_MINCO)
+    capi, synth = pkg.capi, pkg.synth
+    v = capi.V1_SWEPT if variant == "V1" else capi.V3_ESDF_TILE
+    kw = {} if variant == "V1" else dict(enable_pos=0)
+    cfg, occ, res, ref, eng = _world(pkg, orc, v, "RoundedCone", 4, vmax=1.5, omgmax=0.6, thetamax=0.25, **kw)
+    N = 5
+    T0, cm0 = traj(pkg, occ, res, N=N, seed=33, piece_T=0.6)
+    c6 = cm0.reshape(3, 6 * N).T.reshape(N, 6, 3)
+    head = np.zeros((3, 3)); tail = np.zeros((3, 3))
+    head[:, 0] = c6[0, 0]; tail[:, 0] = sum(c6[N - 1, p] * T0[-1] ** p for p in range(6))
+    way = c6[1:, 0, :]
+    rho = 2.5
+    if variant == "V1":
+        M = eng.gather_points(way, 3.0)
+        ref.set_points(eng.get_points())
+    eng.set_trajectory(N, head, tail, rho)
+    x = eng.pack_variables(T0, way)
+    cost, g = eng.cost_function(x)
+    # the reference side
+    tau, xi = x[:N], x[N:]
+    T = tau_to_T(tau)
+    cm_r, e_r, gC, gT = orc.ref_minco(head, tail, xi.reshape(N - 1, 3).T, T)
+    total = e_r
+    if variant == "V1":
+        c1, gT1, gC1, _ = ref.sweep_swept(T, cm_r)
+        total += c1; gT = gT + gT1; gC = gC + gC1
+    c2, gT2, gC2 = ref.sweep_integral(T, cm_r)
+    total += c2; gT = gT + gT2; gC = gC + gC2
+    gP, gTt = orc.ref_minco_propagate(head, tail, xi.reshape(N - 1, 3).T, T, gC, gT)
+    total += rho * T.sum()
+    gTt = gTt + rho
+    den = (0.5 * tau - 1.0) * tau + 1.0
+    g_tau = np.where(tau > 0, gTt * (tau + 1.0), gTt * (1.0 - tau) / (den * den))
+    g_r = np.concatenate([g_tau, gP.T.reshape(-1)])
+    assert abs(cost - total) <= REL_TOL * abs(total), (cost, total)
+    assert_close(g, g_r, "g vs reference pieces")
