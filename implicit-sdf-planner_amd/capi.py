@@ -74,7 +74,7 @@ EXPORTED_SYMBOLS = [
     "isdf_set_trajectory", "isdf_num_variables", "isdf_pack_variables", "isdf_unpack_variables",
     "isdf_cost_function", "isdf_cost_function_lmbm", "isdf_cost_parts",
     "isdf_cost_function_launch", "isdf_cost_function_finish",
-    "isdf_lbfgs_params_default", "isdf_lbfgs_minimize", "isdf_optimize_lbfgs",
+    "isdf_lbfgs_params_default", "isdf_lbfgs_minimize", "isdf_optimize_lbfgs", "isdf_optimize_lbfgs_batch",
     "isdf_set_pointcloud", "isdf_generate_esdf", "isdf_get_grid", "isdf_gather_points", "isdf_get_points",
 ]
 
@@ -132,6 +132,8 @@ def load_library(path=None):
     lib.isdf_lbfgs_params_default.argtypes = [C.POINTER(IsdfLbfgsParams)]
     lib.isdf_lbfgs_params_default.restype = None
     lib.isdf_lbfgs_minimize.argtypes = [EVALUATE_FN, C.c_void_p, dp, C.c_int, C.POINTER(IsdfLbfgsParams), C.POINTER(IsdfLbfgsResult)]
+    lib.isdf_optimize_lbfgs_batch.argtypes = [C.c_void_p, C.c_int, C.c_int, dp, dp, C.c_double, dp, C.POINTER(IsdfLbfgsParams),
+                                              C.POINTER(IsdfLbfgsResult), dp]
     lib.isdf_optimize_lbfgs.argtypes = [C.c_void_p, dp, C.c_int, C.POINTER(IsdfLbfgsParams), C.POINTER(IsdfLbfgsResult)]
     if path is None:
         _lib = lib

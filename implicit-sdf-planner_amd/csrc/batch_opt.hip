@@ -1,0 +1,180 @@
+// Concurrent optimisation of a batch of trajectories on one shared map (BASELINE.json configs[2]: "batch of 128 random
+// start/goal trajectories optimized concurrently").  Every trajectory runs the reference's L-BFGS driver
+// (csrc/lbfgs_host.hpp == lbfgs::lbfgs_optimize, lbfgs.hpp:480-835) on its own objective callback
+// (costFunctionLmbm, back_end_optimizer.hpp:358-430) with its own boundary states; the callbacks of one round are
+// evaluated TOGETHER: each trajectory's host thread does its serial part (tau -> T, MINCO, energy) in parallel with the
+// others, then the coordinator uploads the coefficients of all trajectories that asked for an evaluation, runs ONE batched
+// integral sweep on the device (isdf_eval_device, n_traj = active count), downloads, and the threads finish their
+// callbacks (propogateGrad, chain rule).  Line searches that need more evaluations simply take part in more rounds.
+#include "isdf_ctx.hpp"
+#include "lbfgs_host.hpp"
+#include <chrono>
+#include <condition_variable>
+#include <cstring>
+#include <mutex>
+#include <thread>
+
+namespace {
+
+struct Batch;
+struct Worker {
+    Batch *batch = nullptr;
+    int id = 0;
+    isdf_host::MincoS3 minco;
+    std::vector<double> T, gdC, gdT, gradP, gradT;
+    double energy = 0.0;
+    isdf_host::LbfgsResult result;
+};
+
+struct Batch {
+    isdf_ctx *ctx = nullptr;
+    int n_traj = 0, N = 0, n = 0;
+    double rho = 0.0;
+    size_t in_per = 0, ostride = 0;
+    std::vector<Worker> workers;
+    // round state (guarded by m)
+    std::mutex m;
+    std::condition_variable cv_workers, cv_coord;
+    std::vector<char> submitted, finished;
+    int n_submitted = 0, n_finished = 0;
+    long long round = 0;
+    int error = ISDF_OK;
+    // staging: slot t holds [T(N) | coeffs(18N)] of trajectory t; out slot t holds [cost | gradT | gradC]
+    std::vector<double> stage_in, stage_out;
+    long long rounds_run = 0, evals_run = 0;
+};
+
+// the objective of one trajectory; blocks until the coordinator has evaluated the round it joined
+double worker_evaluate(void *instance, const double *x, double *g, const int n) {
+    Worker &w = *(Worker *)instance;
+    Batch &b = *w.batch;
+    const int N = b.N;
+    for (int i = 0; i < N; i++) w.T[i] = isdf_host::tau_to_T(x[i]);
+    w.minco.set_parameters(x + N, w.T.data());
+    w.energy = w.minco.energy(w.gdC.data(), w.gdT.data());
+    double *in = b.stage_in.data() + (size_t)w.id * b.in_per;
+    std::memcpy(in, w.T.data(), (size_t)N * sizeof(double));
+    std::memcpy(in + N, w.minco.c.data(), (size_t)18 * N * sizeof(double));
+    {
+        std::unique_lock<std::mutex> lk(b.m);
+        const long long my_round = b.round;
+        b.submitted[w.id] = 1;
+        b.n_submitted++;
+        b.cv_coord.notify_one();
+        b.cv_workers.wait(lk, [&] { return b.round != my_round; });
+        if (b.error != ISDF_OK) return INFINITY;
+    }
+    const double *o = b.stage_out.data() + (size_t)w.id * b.ostride;
+    double cost = w.energy + o[0];
+    for (int i = 0; i < N; i++) w.gdT[i] += o[1 + i];
+    for (int i = 0; i < 18 * N; i++) w.gdC[i] += o[1 + N + i];
+    w.minco.propagate_grad(w.gdC.data(), w.gdT.data(), w.gradP.data(), w.gradT.data());
+    double tsum = 0.0;
+    for (int i = 0; i < N; i++) tsum += w.T[i];
+    cost += b.rho * tsum;
+    for (int i = 0; i < N; i++) g[i] = isdf_host::grad_T_to_tau(x[i], w.gradT[i] + b.rho);
+    for (int i = 0; i < 3 * (N - 1); i++) g[N + i] = w.gradP[i];
+    (void)n;
+    return cost;
+}
+
+}  // namespace
+
+extern "C" int isdf_optimize_lbfgs_batch(isdf_ctx *c, int n_traj, int N, const double *heads_pva, const double *tails_pva, double rho,
+                                         double *x_inout, const isdf_lbfgs_params *p, isdf_lbfgs_result *results, double *wall_ms_out) {
+    if (!c) return ISDF_ERR_INVALID_ARG;
+    if (n_traj < 1 || N < 1 || !heads_pva || !tails_pva || !x_inout || !p || !results) return isdf_fail(c, ISDF_ERR_INVALID_ARG, "bad batch arguments");
+    if (c->cfg.variant == ISDF_V1_SWEPT) return isdf_fail(c, ISDF_ERR_UNSUPPORTED, "the batched optimizer drives the integral sweep (V2/V3)");
+    HIPCHK(c, hipSetDevice(c->device));
+    Batch b;
+    b.ctx = c; b.n_traj = n_traj; b.N = N; b.n = N + 3 * (N - 1); b.rho = rho;
+    b.in_per = (size_t)19 * N; b.ostride = isdf_out_stride(N);
+    b.workers.resize(n_traj);
+    b.submitted.assign(n_traj, 0); b.finished.assign(n_traj, 0);
+    b.stage_in.assign((size_t)n_traj * b.in_per, 0.0);
+    b.stage_out.assign((size_t)n_traj * b.ostride, 0.0);
+    for (int t = 0; t < n_traj; t++) {
+        Worker &w = b.workers[t];
+        w.batch = &b; w.id = t;
+        w.minco.set_conditions(heads_pva + 9 * t, tails_pva + 9 * t, N);
+        w.T.assign(N, 0.0); w.gdC.assign((size_t)18 * N, 0.0); w.gdT.assign(N, 0.0);
+        w.gradP.assign((size_t)3 * (N > 1 ? N - 1 : 1), 0.0); w.gradT.assign(N, 0.0);
+    }
+    // device + pinned buffers for a full batch
+    const size_t in_all = (size_t)n_traj * b.in_per, out_all = (size_t)n_traj * b.ostride;
+    double *h_pin = nullptr, *d_buf = nullptr;
+    HIPCHK(c, hipHostMalloc((void **)&h_pin, (in_all + out_all) * sizeof(double), hipHostMallocDefault));
+    if (hipMalloc(&d_buf, (in_all + out_all) * sizeof(double)) != hipSuccess) { (void)hipHostFree(h_pin); return isdf_fail(c, ISDF_ERR_HIP, "device allocation failed"); }
+
+    const auto t0 = std::chrono::steady_clock::now();
+    std::vector<std::thread> threads;
+    threads.reserve(n_traj);
+    for (int t = 0; t < n_traj; t++) {
+        threads.emplace_back([&b, p, x_inout, t] {
+            Worker &w = b.workers[t];
+            isdf_host::Lbfgs opt;
+            opt.param.mem_size = p->mem_size; opt.param.past = p->past; opt.param.max_iterations = p->max_iterations;
+            opt.param.max_linesearch = p->max_linesearch; opt.param.weak_wolfe = p->weak_wolfe; opt.param.reference_patches = p->reference_patches;
+            opt.param.g_epsilon = p->g_epsilon; opt.param.delta = p->delta; opt.param.min_step = p->min_step; opt.param.max_step = p->max_step;
+            opt.param.f_dec_coeff = p->f_dec_coeff; opt.param.s_curv_coeff = p->s_curv_coeff; opt.param.cautious_factor = p->cautious_factor;
+            opt.param.machine_prec = p->machine_prec; opt.param.dir_norm_cap = p->dir_norm_cap;
+            opt.evaluate = worker_evaluate;
+            opt.instance = &w;
+            w.result = opt.minimize(x_inout + (size_t)t * b.n, b.n);
+            std::unique_lock<std::mutex> lk(b.m);
+            b.finished[t] = 1;
+            b.n_finished++;
+            b.cv_coord.notify_one();
+        });
+    }
+    // coordinator: one device round per set of pending evaluations
+    std::vector<int> active;
+    int rc = ISDF_OK;
+    for (;;) {
+        {
+            std::unique_lock<std::mutex> lk(b.m);
+            b.cv_coord.wait(lk, [&] { return b.n_submitted + b.n_finished == b.n_traj; });
+            if (b.n_submitted == 0) break;          // every trajectory is done
+            active.clear();
+            for (int t = 0; t < n_traj; t++) if (b.submitted[t]) active.push_back(t);
+        }
+        // no worker touches the staging buffers while it waits: safe to read without the lock
+        const int na = (int)active.size();
+        double *hT = h_pin, *hC = h_pin + (size_t)na * N;            // compacted [T of all | coeffs of all]
+        for (int k = 0; k < na; k++) {
+            const double *in = b.stage_in.data() + (size_t)active[k] * b.in_per;
+            std::memcpy(hT + (size_t)k * N, in, (size_t)N * sizeof(double));
+            std::memcpy(hC + (size_t)k * 18 * N, in + N, (size_t)18 * N * sizeof(double));
+        }
+        double *dT = d_buf, *dC = d_buf + (size_t)na * N, *dO = d_buf + in_all;
+        if (rc == ISDF_OK && hipMemcpyAsync(d_buf, h_pin, (size_t)na * b.in_per * sizeof(double), hipMemcpyHostToDevice, c->stream) != hipSuccess) rc = ISDF_ERR_HIP;
+        if (rc == ISDF_OK) rc = isdf_eval_device(c, na, N, dT, dC, dO, nullptr, c->stream);
+        if (rc == ISDF_OK && hipMemcpyAsync(h_pin + in_all, dO, (size_t)na * b.ostride * sizeof(double), hipMemcpyDeviceToHost, c->stream) != hipSuccess) rc = ISDF_ERR_HIP;
+        if (rc == ISDF_OK && hipStreamSynchronize(c->stream) != hipSuccess) rc = ISDF_ERR_HIP;
+        for (int k = 0; k < na && rc == ISDF_OK; k++)
+            std::memcpy(b.stage_out.data() + (size_t)active[k] * b.ostride, h_pin + in_all + (size_t)k * b.ostride, b.ostride * sizeof(double));
+        b.rounds_run++;
+        b.evals_run += na;
+        {
+            std::unique_lock<std::mutex> lk(b.m);
+            if (rc != ISDF_OK) b.error = rc;
+            for (int t : active) b.submitted[t] = 0;
+            b.n_submitted = 0;
+            b.round++;
+            b.cv_workers.notify_all();
+        }
+    }
+    for (auto &th : threads) th.join();
+    const auto t1 = std::chrono::steady_clock::now();
+    (void)hipFree(d_buf);
+    (void)hipHostFree(h_pin);
+    const double wall = std::chrono::duration<double, std::milli>(t1 - t0).count();
+    for (int t = 0; t < n_traj; t++) {
+        const isdf_host::LbfgsResult &r = b.workers[t].result;
+        results[t].f = r.f; results[t].status = r.status; results[t].iterations = r.iterations; results[t].evaluations = r.evaluations;
+        results[t].wall_ms = wall; results[t].reserved = (int32_t)b.rounds_run;
+    }
+    if (wall_ms_out) *wall_ms_out = wall;
+    if (b.error != ISDF_OK) return isdf_fail(c, b.error, "a device round of the batched optimizer failed");
+    return ISDF_OK;
+}

@@ -248,6 +248,19 @@ class Engine:
         self._check(self.lib.isdf_optimize_lbfgs(self.h, _p(x), x.size, C.byref(p), C.byref(r)))
         return x, {"f": r.f, "status": r.status, "iterations": r.iterations, "evaluations": r.evaluations, "wall_ms": r.wall_ms}
 
+    def optimize_lbfgs_batch(self, N, heads, tails, rho, x0s, **params):
+        """heads / tails: n_traj x 3 x 3 (columns pos, vel, acc); x0s: n_traj x n.  Returns (xs, [result dicts], wall_ms)."""
+        x = np.ascontiguousarray(x0s, dtype=np.float64).copy()
+        n_traj = x.shape[0]
+        h = np.ascontiguousarray(np.asarray(heads, dtype=np.float64).transpose(0, 2, 1)).reshape(-1)     # column-major 3x3 each
+        t = np.ascontiguousarray(np.asarray(tails, dtype=np.float64).transpose(0, 2, 1)).reshape(-1)
+        p = lbfgs_params(self.lib, **params)
+        res = (capi.IsdfLbfgsResult * n_traj)()
+        wall = C.c_double(0)
+        self._check(self.lib.isdf_optimize_lbfgs_batch(self.h, n_traj, int(N), _p(h), _p(t), float(rho), _p(x), C.byref(p), res, C.byref(wall)))
+        out = [{"f": r.f, "status": r.status, "iterations": r.iterations, "evaluations": r.evaluations, "rounds": r.reserved} for r in res]
+        return x, out, wall.value
+
     # ---- instrumentation
     def stats(self):
         s = capi.IsdfStats()

@@ -253,6 +253,16 @@ int isdf_lbfgs_minimize(isdf_evaluate_fn evaluate, void *instance, double *x_ino
 /* the ctx's own objective: isdf_cost_function */
 int isdf_optimize_lbfgs(isdf_ctx *ctx, double *x_inout, int n, const isdf_lbfgs_params *p, isdf_lbfgs_result *out);
 
+/* A batch of trajectories optimised CONCURRENTLY on the shared map (BASELINE.json configs[2]): trajectory t has its own
+ * boundary states heads_pva[9t..], tails_pva[9t..] (3x3 column-major each, like isdf_set_trajectory) and its own
+ * variables x_inout[t*n .. (t+1)*n), n = N + 3(N-1); all share N, rho and the ctx's map / robot / weights.  Each runs
+ * the same L-BFGS driver on its own callback; the callbacks of a round are evaluated as ONE batched integral sweep on the
+ * device (host MINCO of the trajectories in parallel threads).  The iterates are identical to optimising every
+ * trajectory alone with isdf_optimize_lbfgs.  results[t].reserved = number of device rounds of the whole batch.
+ * V2 / V3 contexts only. */
+int isdf_optimize_lbfgs_batch(isdf_ctx *ctx, int n_traj, int N, const double *heads_pva, const double *tails_pva, double rho,
+                              double *x_inout, const isdf_lbfgs_params *p, isdf_lbfgs_result *results, double *wall_ms_out);
+
 /* ---- instrumentation --------------------------------------------------------------------------------------- */
 /* on = N > 0: every N-th isdf_eval_device attaches HIP start/stop events to the dispatch of its dominant kernel on
  * `stream` (hipExtLaunchKernel: the kernel's own begin/end timestamps, the interval rocprofv3 reports);

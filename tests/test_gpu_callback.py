@@ -192,3 +192,35 @@ def test_callback_launch_finish_shards(pkg, orc, product_lib):
     with pytest.raises(pkg.engine.IsdfError) as ei:
         engs[0].cost_function_finish(0)
     assert ei.value.code == capi.ISDF_ERR_STATE
+
+
+def test_optimize_lbfgs_batch_equals_individual(pkg, orc, product_lib):
+    """configs[2] at test size: 6 trajectories with different boundary states optimised concurrently (one batched device
+    sweep per round) end on exactly the iterates they reach when optimised one at a time."""
+    capi, synth = pkg.capi, pkg.synth
+    occ, esdf, res = small_world(pkg, seed=16)
+    N = 4
+    shape = synth.make_shape("RoundedCone", params=(0.8, 0.3, 1.6))
+    cfg, eng, _ = _engines(pkg, orc, capi.V3_ESDF_TILE, occ, esdf, res, shape)
+    heads, tails, x0s = [], [], []
+    rho = 5.0
+    for b in range(6):
+        head, tail, way, T0 = _setup(pkg, occ, res, N, 70 + b)
+        eng.set_trajectory(N, head, tail, rho)
+        x0s.append(eng.pack_variables(T0, way))
+        heads.append(head); tails.append(tail)
+    iters = 5 + np.arange(6) % 3        # not used per trajectory: the batch shares one parameter set
+    xs, results, wall = eng.optimize_lbfgs_batch(N, np.array(heads), np.array(tails), rho, np.array(x0s), max_iterations=7,
+                                                 g_epsilon=0.0, past=0)
+    assert results[0]["rounds"] >= 8
+    for b in range(6):
+        eng.set_trajectory(N, heads[b], tails[b], rho)
+        x1, r1 = eng.optimize_lbfgs(x0s[b], max_iterations=7, g_epsilon=0.0, past=0)
+        assert r1["status"] == results[b]["status"] and r1["evaluations"] == results[b]["evaluations"]
+        assert r1["f"] == results[b]["f"] and np.array_equal(x1, xs[b]), (b, np.abs(x1 - xs[b]).max())
+        assert results[b]["f"] < eng.cost_function(x0s[b])[0]
+    # V1 contexts are refused
+    cfg1, eng1, _ = _engines(pkg, orc, capi.V1_SWEPT, occ, esdf, res, shape)
+    with pytest.raises(pkg.engine.IsdfError) as ei:
+        eng1.optimize_lbfgs_batch(N, np.array(heads), np.array(tails), rho, np.array(x0s))
+    assert ei.value.code == capi.ISDF_ERR_UNSUPPORTED
