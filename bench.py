@@ -68,12 +68,18 @@ def main():
             raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N > 1")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the product path has no CPU fallback")
+    # developer switches (not used by the driver): run an N > 1 launch on a box with ONE GPU to exercise the multi-process
+    # flow - every rank on cuda:0, gloo instead of RCCL (which refuses two ranks on one device)
+    single_dev = os.environ.get("ISDF_BENCH_SINGLE_DEVICE") == "1"
+    backend = os.environ.get("ISDF_BENCH_BACKEND", "nccl")
+    if single_dev:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     pkg = graft.load_package()
     capi, synth, par = pkg.capi, pkg.synth, pkg.parallel
     if world > 1:
-        par.init_process_group("nccl", device=dev)      # "nccl" == RCCL on ROCm
+        par.init_process_group(backend, device=dev)     # "nccl" == RCCL on ROCm
     res = 0.2 * 256.0 / args.grid if args.grid != 256 else 0.2
     K = 64
     n_pieces = args.pieces_per_gpu * world

@@ -1,0 +1,82 @@
+"""The product's fast-winding-number hierarchy (csrc/fwn_host.hpp: BVH build, order-2 coefficients, evaluation) against
+the vendored HDK library itself (oracle/_ref/libref_fwn.so): same tree, same coefficients, same w.  CPU only."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+dp = C.POINTER(C.c_double)
+
+
+@pytest.fixture(scope="module")
+def shim(tmp_path_factory):
+    out = str(tmp_path_factory.mktemp("fwn") / "libfwn_shim.so")
+    subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off", "-Wno-unknown-pragmas",
+                           "-I", os.path.join(ROOT, "implicit-sdf-planner_amd", "csrc"),
+                           os.path.join(ROOT, "tests", "native", "fwn_shim.cpp"), "-o", out])
+    L = C.CDLL(out)
+    L.shim_fwn_build.restype = C.c_void_p
+    return L
+
+
+def _meshes(pkg):
+    synth = pkg.synth
+    rng = np.random.default_rng(5)
+    out = {}
+    V, F = synth.l_prism_mesh(); out["L prism (20)"] = (V, F)
+    # box (12 triangles)
+    c = np.array([[x, y, z] for x in (-.5, .5) for y in (-.4, .4) for z in (-.3, .3)])
+    Fb = np.array([[0, 1, 3], [0, 3, 2], [4, 6, 7], [4, 7, 5], [0, 4, 5], [0, 5, 1], [2, 3, 7], [2, 7, 6], [0, 2, 6], [0, 6, 4], [1, 5, 7], [1, 7, 3]], dtype=np.int32)
+    out["box (12)"] = (c, Fb)
+    # UV sphere-ish closed meshes of growing size: exercise the <= 6, <= 32 and binned split paths, and n > 1024
+    for nu, nv in ((4, 3), (8, 6), (24, 16), (64, 40)):
+        th = np.linspace(0, np.pi, nv + 1)[1:-1]
+        ph = np.linspace(0, 2 * np.pi, nu, endpoint=False)
+        P = [[0, 0, 1.0]] + [[np.sin(t) * np.cos(p) * (1 + 0.2 * np.cos(3 * p)), np.sin(t) * np.sin(p), np.cos(t) * 0.8] for t in th for p in ph] + [[0, 0, -1.0]]
+        P = np.array(P) + rng.normal(0, 1e-3, (len(P), 3))
+        Fs = []
+        for j in range(nu):
+            Fs.append([0, 1 + j, 1 + (j + 1) % nu])
+        for i in range(nv - 2):
+            for j in range(nu):
+                a = 1 + i * nu + j; b = 1 + i * nu + (j + 1) % nu; c2 = a + nu; d = b + nu
+                Fs += [[a, c2, d], [a, d, b]]
+        last = len(P) - 1
+        base = 1 + (nv - 2) * nu
+        for j in range(nu):
+            Fs.append([last, base + (j + 1) % nu, base + j])
+        out[f"blob ({len(Fs)})"] = (P, np.array(Fs, dtype=np.int32))
+    return out
+
+
+def test_hierarchy_matches_hdk(pkg, orc, shim):
+    if not os.path.exists(orc.REF_FWN):
+        pytest.skip("oracle/_ref/libref_fwn.so not built")
+    rng = np.random.default_rng(2)
+    for name, (V, F) in _meshes(pkg).items():
+        V = np.ascontiguousarray(V, dtype=np.float64); F = np.ascontiguousarray(F, dtype=np.int32)
+        ref = orc.RefFwn(V, F)
+        n_ref = ref.lib.ref_fwn_num_nodes(ref.h)
+        c_ref = np.zeros((n_ref, 4), dtype=np.int32); b_ref = np.zeros((n_ref, 92), dtype=np.float32)
+        ref.lib.ref_fwn_dump_nodes(ref.h, c_ref.ctypes.data_as(C.c_void_p))
+        ref.lib.ref_fwn_dump_boxdata(ref.h, b_ref.ctypes.data_as(C.c_void_p))
+        h = C.c_void_p(shim.shim_fwn_build(V.ctypes.data_as(dp), V.shape[0], F.ctypes.data_as(C.c_void_p), F.shape[0]))
+        n = shim.shim_fwn_num_nodes(h)
+        assert n == n_ref, (name, n, n_ref)
+        c = np.zeros((n, 4), dtype=np.int32); b = np.zeros((n, 92), dtype=np.float32)
+        shim.shim_fwn_dump(h, c.ctypes.data_as(C.c_void_p), b.ctypes.data_as(C.c_void_p))
+        assert np.array_equal(c, c_ref), name                                   # same topology, same child order
+        fin = np.isfinite(b_ref)
+        assert np.array_equal(np.isfinite(b), fin), name
+        scale = np.abs(b_ref[fin]).max()
+        assert np.allclose(b[fin], b_ref[fin], rtol=2e-5, atol=2e-6 * scale), (name, np.abs(b[fin] - b_ref[fin]).max())
+        ext = np.abs(V).max()
+        Q = rng.uniform(-2.5 * ext, 2.5 * ext, (3000, 3))
+        w_ref = ref.eval(Q)
+        w = np.zeros(Q.shape[0])
+        shim.shim_fwn_eval(h, Q.ctypes.data_as(dp), Q.shape[0], C.c_double(2.0), w.ctypes.data_as(dp))
+        assert np.abs(w - w_ref).max() < 5e-6, (name, np.abs(w - w_ref).max())
+        shim.shim_fwn_destroy(h)
