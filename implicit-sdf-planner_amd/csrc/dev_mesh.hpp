@@ -1,9 +1,13 @@
 // Device-side mesh robot shape (Generalshape, src/utils/src/Shape.cpp:105-151):
 //   sdf = (1 - 2 w) * dist,  grad = normalize((1 - 2 w) * (p - c)),
-// w = winding number of the triangle soup (float, like libigl's UT_SolidAngle<float,float>), c = closest point.
-// Round-1 implementation: flat loops over the triangles (exact solid-angle sum, exact closest point), triangles
-// stored SoA-packed as 9 doubles + 9 floats per face.  Suited to the demo meshes (mybox 12, Lthick 20 faces);
-// a BVH with libigl's far-field expansion is the planned follow-up for the 2-12 k face meshes.
+// w = igl::fast_winding_number(fwn_bvh, 2.0, p): libigl's HDK UT_SolidAngle<float,float>, order 2 - a 4-wide BVH whose far
+// children are replaced by a Taylor expansion about their area-weighted centre.  That approximation moves w by up to ~2e-3,
+// so the device walks the SAME hierarchy with the SAME coefficients (built on the host by csrc/fwn_host.hpp, which
+// tests/test_fwn_host.py checks node by node against the vendored library) and applies the same descend test
+// (|q - P|^2 <= maxP2 * accuracy^2, FastWindingNumberForSoups.h:7119-7258), all in float like the reference.
+// c = closest point, dist = |p - c|: exact (igl::AABB::squared_distance is exact, Shape.cpp:112), found by a
+// branch-and-bound walk of the same hierarchy using each child's bounding sphere (centre P, radius sqrt(maxP2)), in fp64.
+// Both walks keep a per-lane stack of MESH_STACK node numbers; isdf_set_shape refuses meshes whose tree is deeper.
 #pragma once
 #include "dev_shapes.hpp"
 
@@ -31,31 +35,108 @@ __device__ __forceinline__ d3 closest_on_triangle(d3 p, d3 a, d3 b, d3 c) {
     return a + (vb * denom) * ab + (vc * denom) * ac;
 }
 
-__device__ inline double mesh_query(const DevMesh *m, d3 p, d3 &closest, double &s_out) {
-    double best = 1.7976931348623157e308;
-    float total = 0.0f;
-    const float qx = (float)p.x, qy = (float)p.y, qz = (float)p.z;
-    for (int f = 0; f < m->nF; f++) {
-        const double *t = m->tri + 9 * f;
-        const d3 c = closest_on_triangle(p, mk3(t[0], t[1], t[2]), mk3(t[3], t[4], t[5]), mk3(t[6], t[7], t[8]));
-        const d3 dd = p - c;
-        const double d = dot3(dd, dd);
-        if (d < best) { best = d; closest = c; }
-        const float *u = m->trif + 9 * f;
-        float ax = u[0] - qx, ay = u[1] - qy, az = u[2] - qz;
-        float bx = u[3] - qx, by = u[4] - qy, bz = u[5] - qz;
-        float cx = u[6] - qx, cy = u[7] - qy, cz = u[8] - qz;
-        const float la = sqrtf(ax * ax + ay * ay + az * az), lb = sqrtf(bx * bx + by * by + bz * bz),
-                    lc = sqrtf(cx * cx + cy * cy + cz * cz);
-        if (la == 0 || lb == 0 || lc == 0) continue;
-        ax /= la; ay /= la; az /= la; bx /= lb; by /= lb; bz /= lb; cx /= lc; cy /= lc; cz /= lc;
-        const float det = ax * (by * cz - bz * cy) - ay * (bx * cz - bz * cx) + az * (bx * cy - by * cx);
-        const float den = 1.0f + (ax * bx + ay * by + az * bz) + (bx * cx + by * cy + bz * cz) + (cx * ax + cy * ay + cz * az);
-        total += 2.0f * atan2f(det, den);
+
+// UTsignedSolidAngleTri (FastWindingNumberForSoups.h:6044-6082), float
+__device__ __forceinline__ float mesh_tri_solid_angle(const float *u, float qx, float qy, float qz) {
+#pragma clang fp contract(off)
+    float ax = u[0] - qx, ay = u[1] - qy, az = u[2] - qz;
+    float bx = u[3] - qx, by = u[4] - qy, bz = u[5] - qz;
+    float cx = u[6] - qx, cy = u[7] - qy, cz = u[8] - qz;
+    const float la = sqrtf(ax * ax + ay * ay + az * az), lb = sqrtf(bx * bx + by * by + bz * bz), lc = sqrtf(cx * cx + cy * cy + cz * cz);
+    if (la == 0 || lb == 0 || lc == 0) return 0.f;
+    ax /= la; ay /= la; az /= la; bx /= lb; by /= lb; bz /= lb; cx /= lc; cy /= lc; cz /= lc;
+    const float ux = bx - ax, uy = by - ay, uz = bz - az, vx = cx - ax, vy = cy - ay, vz = cz - az;
+    const float num = ax * (uy * vz - uz * vy) + ay * (uz * vx - ux * vz) + az * (ux * vy - uy * vx);
+    if (num == 0) return 0.f;
+    const float den = 1.0f + (ax * bx + ay * by + az * bz) + (ax * cx + ay * cy + az * cz) + (bx * cx + by * cy + bz * cz);
+    return 2.0f * atan2f(num, den);
+}
+
+// UT_SolidAngle::computeSolidAngle, order 2 (SolidAngleFunctors, :7119-7258); returns the solid angle (w = it / 4 pi)
+__device__ inline float mesh_solid_angle(const DevMesh *m, float qx, float qy, float qz) {
+#pragma clang fp contract(off)
+    const float acc2 = MESH_FWN_ACCURACY * MESH_FWN_ACCURACY;
+    int stk[MESH_STACK];
+    int sp = 0;
+    float total = 0.f;
+    stk[sp++] = 0;
+    while (sp > 0) {
+        const int nodei = stk[--sp];
+        const float *r = m->fwn_box + (size_t)92 * nodei;
+        const int *ch = m->fwn_child + 4 * nodei;
+        for (int l = 0; l < 4; l++) {
+            const int ci = ch[l];
+            if (ci == -1) break;                                  // empty children are last
+            float x = qx - r[4 + l], y = qy - r[8 + l], z = qz - r[12 + l];
+            const float ql2 = x * x + y * y + z * z;
+            if (!(ql2 <= r[l] * acc2)) {
+                const float m2 = 1.0f / ql2, m1 = sqrtf(m2);
+                x *= m1; y *= m1; z *= m1;
+                float om = -m2 * (x * r[16 + l] + y * r[20 + l] + z * r[24 + l]);
+                const float x2 = x * x, y2 = y * y, z2 = z * z;
+                const float m3 = m2 * m1;
+                om += m3 * (r[28 + l] + r[32 + l] + r[36 + l]
+                            - 3.0f * ((x2 * r[28 + l] + y2 * r[32 + l] + z2 * r[36 + l]) + x * y * r[40 + l] + x * z * r[48 + l] + y * z * r[44 + l]));
+                const float x3 = x2 * x, y3 = y2 * y, z3 = z2 * z;
+                const float m4 = m2 * m2;
+                const float t0x = r[80 + l] + r[84 + l], t0y = r[88 + l] + r[68 + l], t0z = r[72 + l] + r[76 + l];
+                const float t1x = y * r[68 + l] + z * r[72 + l], t1y = z * r[76 + l] + x * r[80 + l], t1z = x * r[84 + l] + y * r[88 + l];
+                om += m4 * (1.5f * (x * (3.0f * r[52 + l] + t0x) + y * (3.0f * r[56 + l] + t0y) + z * (3.0f * r[60 + l] + t0z))
+                            - 7.5f * ((x3 * r[52 + l] + y3 * r[56 + l] + z3 * r[60 + l]) + x * y * z * r[64 + l] + (x2 * t1x + y2 * t1y + z2 * t1z)));
+                if (isfinite(om)) { total += om; continue; }
+            }
+            if (ci < 0) stk[sp++] = ci & 0x7fffffff;
+            else total += mesh_tri_solid_angle(m->trif + (size_t)9 * ci, qx, qy, qz);
+        }
     }
-    const double w = (double)(total / (4.0f * 3.14159265358979323846f));
-    s_out = 1. - 2. * w;
+    return total;
+}
+
+// squared distance to the closest triangle and that point: branch and bound over the hierarchy's bounding spheres
+__device__ inline double mesh_closest(const DevMesh *m, d3 p, d3 &closest) {
+    int stk[MESH_STACK];
+    double stk_lb[MESH_STACK];
+    int sp = 0;
+    double best = 1.7976931348623157e308;
+    stk[0] = 0; stk_lb[0] = 0.0; sp = 1;
+    while (sp > 0) {
+        --sp;
+        if (stk_lb[sp] >= best) continue;
+        const int nodei = stk[sp];
+        const float *r = m->fwn_box + (size_t)92 * nodei;
+        const int *ch = m->fwn_child + 4 * nodei;
+        int cid[4]; double clb[4]; int n = 0;
+        for (int l = 0; l < 4; l++) {
+            const int ci = ch[l];
+            if (ci == -1) break;
+            const double px = r[4 + l], py = r[8 + l], pz = r[12 + l];
+            const double dx = p.x - px, dy = p.y - py, dz = p.z - pz;
+            // radius padded for the float rounding of P / maxP2 and the float copies of the vertices they were built from
+            const double rad = (double)sqrtf(r[l]) * 1.00001 + 1e-6 * (fabs(px) + fabs(py) + fabs(pz) + 1.0);
+            const double lb = fmax(sqrt(dx * dx + dy * dy + dz * dz) - rad, 0.0), lb2 = lb * lb;
+            if (lb2 >= best) continue;
+            if (ci >= 0) {
+                const double *t = m->tri + (size_t)9 * ci;
+                const d3 c = closest_on_triangle(p, mk3(t[0], t[1], t[2]), mk3(t[3], t[4], t[5]), mk3(t[6], t[7], t[8]));
+                const d3 dd = p - c;
+                const double d = dot3(dd, dd);
+                if (d < best) { best = d; closest = c; }
+            } else {
+                int k = n++;                                       // keep (cid, clb) sorted by decreasing bound
+                while (k > 0 && clb[k - 1] < lb2) { clb[k] = clb[k - 1]; cid[k] = cid[k - 1]; --k; }
+                clb[k] = lb2; cid[k] = ci & 0x7fffffff;
+            }
+        }
+        for (int k = 0; k < n; k++) if (clb[k] < best) { stk[sp] = cid[k]; stk_lb[sp] = clb[k]; ++sp; }     // nearest child on top
+    }
     return best;
+}
+
+__device__ inline double mesh_query(const DevMesh *m, d3 p, d3 &closest, double &s_out) {
+    const float sa = mesh_solid_angle(m, (float)p.x, (float)p.y, (float)p.z);
+    const double w = (double)sa / (4.0 * 3.14159265358979323846);      // libigl: computeSolidAngle(...) / (4.0 * igl::PI)
+    s_out = 1. - 2. * w;
+    return mesh_closest(m, p, closest);
 }
 
 __device__ inline double mesh_sdf(const DevMesh *m, d3 p) {

@@ -12,10 +12,15 @@
 namespace isdf {
 
 // mesh kind (functions in dev_mesh.hpp)
+constexpr int MESH_STACK = 64;             // per-lane traversal stack: >= 3 * depth + 1, checked by isdf_set_shape
+constexpr float MESH_FWN_ACCURACY = 2.0f;  // accuracy_scale of igl::fast_winding_number(fwn_bvh, 2.0, ...), Shape.cpp:110
 struct DevMesh {
     const double *tri;   // nF x 9: a.xyz b.xyz c.xyz
     const float *trif;   // nF x 9 (float copies for the winding number)
     int nF;
+    const int *fwn_child;   // 4 per node: triangle index | -1 empty | node number with the top bit set (csrc/fwn_host.hpp)
+    const float *fwn_box;   // 92 per node: per-child radius^2, centre and order-2 expansion coefficients
+    int fwn_nodes;
 };
 
 template <typename T> struct ShapeP {
@@ -191,17 +196,15 @@ __device__ double mesh_sdf_grad(const DevMesh *m, d3 p, d3 &g);  // dev_mesh.hpp
 // BasicShape::getonlySDF(pos_rel), exact path (fp64)
 template <int KIND>
 __device__ __forceinline__ double shape_sdf(const DevShape &S, d3 pr) {
-    const int kind = (KIND >= 0) ? KIND : S.kind;
-    if (kind == ISDF_SHAPE_MESH) return mesh_sdf(S.mesh, pr);
-    return analytic_sdf<KIND, double>(S.d, S.kind, pr);
+    if constexpr (KIND == ISDF_SHAPE_MESH) return mesh_sdf(S.mesh, pr);     // the mesh kind has its own instantiation
+    else return analytic_sdf<KIND, double>(S.d, S.kind, pr);
 }
 
 // getonlyGrad1: central difference dx = 5e-6 (temp -= dx; temp += 2dx), normalised — Shape.hpp:32-57;
 // Box: forward difference dx = 0.01, not normalised — Shape.hpp:2363-2377; Ball: p/|p| — Shape.hpp:622-625.
 template <int KIND>
 __device__ __forceinline__ d3 shape_grad(const DevShape &S, d3 pr) {
-    const int kind = (KIND >= 0) ? KIND : S.kind;
-    if (kind == ISDF_SHAPE_MESH) { d3 g; mesh_sdf_grad(S.mesh, pr, g); return g; }
+    if constexpr (KIND == ISDF_SHAPE_MESH) { d3 g; mesh_sdf_grad(S.mesh, pr, g); return g; }
     const int mode = S.grad_mode;   // resolved (never DEFAULT) by the host
     if (mode == ISDF_GRAD_ANALYTIC_BALL) return normalized3(pr);
     if (mode == ISDF_GRAD_BOX_FORWARD) {

@@ -525,6 +525,23 @@ inline void fwn_build(const double *vertices, int nV, const int32_t *faces, int 
     P.traverse(0, root);
 }
 
+// depth of the hierarchy (root = 1): bounds the device traversal stack
+inline int fwn_depth(const FwnTree &tr) {
+    if (tr.child.empty()) return 0;
+    std::vector<std::pair<int, int>> stack{{0, 1}};
+    int depth = 0;
+    while (!stack.empty()) {
+        const auto [node, d] = stack.back();
+        stack.pop_back();
+        depth = std::max(depth, d);
+        for (int s = 0; s < 4; s++) {
+            const int32_t ci = tr.child[4 * node + s];
+            if (ci != FWN_EMPTY && ci < 0) stack.push_back({(int)((uint32_t)ci & ~FWN_INTERNAL_BIT), d + 1});
+        }
+    }
+    return depth;
+}
+
 // Host evaluation of the solid angle (the device walks the same records: csrc/dev_mesh.hpp); used by the tests.
 // UT_SolidAngle::computeSolidAngle (:7119-7258): returns the solid angle, w = result / (4 pi).
 inline float fwn_tri_solid_angle(const float *a, const float *b, const float *c, const float *q) {     // UTsignedSolidAngleTri (:6044-6082)
@@ -593,3 +610,7 @@ inline float fwn_solid_angle(const FwnTree &tr, const float q[3], float accuracy
 }
 
 }  // namespace isdf_host
+
+#ifdef __clang__
+#pragma clang fp contract(fast)    // back to the compiler default for the including file
+#endif

@@ -25,6 +25,8 @@ struct isdf_ctx {
     DevMesh *d_mesh = nullptr;
     double *d_mesh_tri = nullptr;
     float *d_mesh_trif = nullptr;
+    int *d_fwn_child = nullptr;
+    float *d_fwn_box = nullptr;
     // points (V1)
     double *d_points = nullptr;
     int M = 0;

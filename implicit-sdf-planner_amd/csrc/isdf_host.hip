@@ -12,6 +12,7 @@
 #include <string>
 #include <vector>
 #include <new>
+#include "fwn_host.hpp"
 
 using namespace isdf;
 
@@ -142,7 +143,9 @@ static void free_mesh(isdf_ctx *c) {
     if (c->d_mesh) (void)hipFree(c->d_mesh);
     if (c->d_mesh_tri) (void)hipFree(c->d_mesh_tri);
     if (c->d_mesh_trif) (void)hipFree(c->d_mesh_trif);
-    c->d_mesh = nullptr; c->d_mesh_tri = nullptr; c->d_mesh_trif = nullptr;
+    if (c->d_fwn_child) (void)hipFree(c->d_fwn_child);
+    if (c->d_fwn_box) (void)hipFree(c->d_fwn_box);
+    c->d_mesh = nullptr; c->d_mesh_tri = nullptr; c->d_mesh_trif = nullptr; c->d_fwn_child = nullptr; c->d_fwn_box = nullptr;
 }
 
 extern "C" int isdf_destroy(isdf_ctx *c) {
@@ -271,13 +274,21 @@ extern "C" int isdf_set_shape(isdf_ctx *c, const isdf_shape *s) {
                     trif[(size_t)9 * f + 3 * k + a] = (float)s->mesh_vertices[3 * vi + a];
                 }
             }
+        // the reference's winding-number hierarchy (igl::fast_winding_number(V, F, 2, fwn_bvh), Shape.cpp:86)
+        isdf_host::FwnTree tree;
+        isdf_host::fwn_build(s->mesh_vertices, s->n_vertices, s->mesh_faces, s->n_faces, tree);
+        if (3 * isdf_host::fwn_depth(tree) + 1 > isdf::MESH_STACK) return fail(c, ISDF_ERR_UNSUPPORTED, "mesh hierarchy too deep for the device traversal stack");
         free_mesh(c);
+        HIPCHK(c, hipMalloc(&c->d_fwn_child, tree.child.size() * sizeof(int32_t)));
+        HIPCHK(c, hipMalloc(&c->d_fwn_box, tree.box.size() * sizeof(float)));
+        HIPCHK(c, hipMemcpy(c->d_fwn_child, tree.child.data(), tree.child.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+        HIPCHK(c, hipMemcpy(c->d_fwn_box, tree.box.data(), tree.box.size() * sizeof(float), hipMemcpyHostToDevice));
         HIPCHK(c, hipMalloc(&c->d_mesh_tri, tri.size() * sizeof(double)));
         HIPCHK(c, hipMalloc(&c->d_mesh_trif, trif.size() * sizeof(float)));
         HIPCHK(c, hipMalloc(&c->d_mesh, sizeof(DevMesh)));
         HIPCHK(c, hipMemcpy(c->d_mesh_tri, tri.data(), tri.size() * sizeof(double), hipMemcpyHostToDevice));
         HIPCHK(c, hipMemcpy(c->d_mesh_trif, trif.data(), trif.size() * sizeof(float), hipMemcpyHostToDevice));
-        DevMesh hm{c->d_mesh_tri, c->d_mesh_trif, s->n_faces};
+        DevMesh hm{c->d_mesh_tri, c->d_mesh_trif, s->n_faces, c->d_fwn_child, c->d_fwn_box, tree.n_nodes()};
         HIPCHK(c, hipMemcpy(c->d_mesh, &hm, sizeof(hm), hipMemcpyHostToDevice));
         d.mesh = c->d_mesh;
     }

@@ -1,0 +1,47 @@
+// The robot-shape plugin by itself: BasicShape::getonlySDF / getonlyGrad1 / getSDFwithGrad1 (Shape.hpp:32-88 for the
+// analytic classes, Shape.cpp:105-151 for the mesh Generalshape) on a batch of BODY-FRAME points, one lane per point.
+// The sweeps inline the same device functions (dev_shapes.hpp / dev_mesh.hpp); this entry point exists so a caller (and
+// the parity tests) can query the installed shape directly, like the reference's planners and visualisers do.
+#include "isdf_ctx.hpp"
+#include "dev_mesh.hpp"
+
+namespace isdf {
+
+template <int KIND>
+__global__ __launch_bounds__(256) void shape_eval_kernel(DevShape S, const double *__restrict__ pts, int n, double *__restrict__ sdf_out, double *__restrict__ grad_out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const d3 p = mk3(pts[3 * i], pts[3 * i + 1], pts[3 * i + 2]);
+    if (sdf_out) sdf_out[i] = shape_sdf<KIND>(S, p);
+    if (grad_out) {
+        const d3 g = shape_grad<KIND>(S, p);
+        grad_out[3 * i] = g.x; grad_out[3 * i + 1] = g.y; grad_out[3 * i + 2] = g.z;
+    }
+}
+
+}  // namespace isdf
+
+extern "C" int isdf_shape_eval(isdf_ctx *c, const double *p_rel, int n, double *sdf_out, double *grad_out) {
+    if (!c) return ISDF_ERR_INVALID_ARG;
+    if (n < 0 || (n > 0 && !p_rel)) return isdf_fail(c, ISDF_ERR_INVALID_ARG, "bad points");
+    if (!c->have_shape) return isdf_fail(c, ISDF_ERR_STATE, "isdf_set_shape has not been called");
+    if (n == 0 || (!sdf_out && !grad_out)) return ISDF_OK;
+    HIPCHK(c, hipSetDevice(c->device));
+    double *d = nullptr;
+    HIPCHK(c, hipMalloc(&d, (size_t)n * 7 * sizeof(double)));
+    double *d_p = d, *d_s = d + (size_t)3 * n, *d_g = d + (size_t)4 * n;
+    int rc = ISDF_OK;
+    auto chk = [&](hipError_t e, const char *what) { if (e != hipSuccess && rc == ISDF_OK) { c->err = std::string(what) + ": " + hipGetErrorString(e); rc = ISDF_ERR_HIP; } };
+    chk(hipMemcpyAsync(d_p, p_rel, (size_t)3 * n * sizeof(double), hipMemcpyHostToDevice, c->stream), "upload points");
+    if (rc == ISDF_OK) {
+        const dim3 grid((n + 255) / 256), block(256);
+        if (c->shape.kind == ISDF_SHAPE_MESH) hipLaunchKernelGGL(isdf::shape_eval_kernel<ISDF_SHAPE_MESH>, grid, block, 0, c->stream, c->shape, d_p, n, sdf_out ? d_s : nullptr, grad_out ? d_g : nullptr);
+        else hipLaunchKernelGGL(isdf::shape_eval_kernel<-1>, grid, block, 0, c->stream, c->shape, d_p, n, sdf_out ? d_s : nullptr, grad_out ? d_g : nullptr);
+        chk(hipGetLastError(), "shape_eval_kernel");
+    }
+    if (rc == ISDF_OK && sdf_out) chk(hipMemcpyAsync(sdf_out, d_s, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, c->stream), "download sdf");
+    if (rc == ISDF_OK && grad_out) chk(hipMemcpyAsync(grad_out, d_g, (size_t)3 * n * sizeof(double), hipMemcpyDeviceToHost, c->stream), "download grad");
+    chk(hipStreamSynchronize(c->stream), "shape_eval sync");
+    (void)hipFree(d);
+    return rc;
+}

@@ -156,8 +156,8 @@ __global__ __launch_bounds__(64 * SW_WAVES) void swept_sweep_kernel(const SweptP
     //   GRAD   lanes 18-24 only: shape gradient at the final x of the interval when the last step moved x
     enum { PH_FINE = 0, PH_GD = 1, PH_GRAD = 2, PH_NEXT = 3, PH_END = 4 };
     const int gmode = P.shape.grad_mode;
-    const bool fd_central = (KIND != ISDF_SHAPE_MESH) && (KIND >= 0 || P.shape.kind != ISDF_SHAPE_MESH) && gmode == ISDF_GRAD_CENTRAL;
-    const bool fd_forward = (KIND != ISDF_SHAPE_MESH) && (KIND >= 0 || P.shape.kind != ISDF_SHAPE_MESH) && gmode == ISDF_GRAD_BOX_FORWARD;
+    const bool fd_central = (KIND != ISDF_SHAPE_MESH) && gmode == ISDF_GRAD_CENTRAL;
+    const bool fd_forward = (KIND != ISDF_SHAPE_MESH) && gmode == ISDF_GRAD_BOX_FORWARD;
     double range_time_seed = 0.0;
     double min_sdf_star = 1e1, t_star_best = 0.0;
     d3 grad_prel = mk3(0, 0, 0);
@@ -416,6 +416,7 @@ void launch_swept_sweep(const SweptParams &P, hipStream_t stream, hipEvent_t ev_
     switch (P.shape.kind) {
     case ISDF_SHAPE_BOX: hipExtLaunchKernelGGL(swept_sweep_kernel<ISDF_SHAPE_BOX>, grid, block, 0, stream, ev_start, ev_stop, 0, P); break;
     case ISDF_SHAPE_ROUNDEDCONE: hipExtLaunchKernelGGL(swept_sweep_kernel<ISDF_SHAPE_ROUNDEDCONE>, grid, block, 0, stream, ev_start, ev_stop, 0, P); break;
+    case ISDF_SHAPE_MESH: hipExtLaunchKernelGGL(swept_sweep_kernel<ISDF_SHAPE_MESH>, grid, block, 0, stream, ev_start, ev_stop, 0, P); break;
     default: hipExtLaunchKernelGGL(swept_sweep_kernel<-1>, grid, block, 0, stream, ev_start, ev_stop, 0, P); break;
     }
 }

@@ -666,6 +666,7 @@ void launch_sweep(const SweepParams &P, hipStream_t stream, hipEvent_t ev_start,
     switch (P.shape.kind) {
     case ISDF_SHAPE_BOX: hipExtLaunchKernelGGL(sweep_kernel<ISDF_SHAPE_BOX>, grid, block, 0, stream, ev_start, ev_stop, 0, P); break;
     case ISDF_SHAPE_ROUNDEDCONE: hipExtLaunchKernelGGL(sweep_kernel<ISDF_SHAPE_ROUNDEDCONE>, grid, block, 0, stream, ev_start, ev_stop, 0, P); break;
+    case ISDF_SHAPE_MESH: hipExtLaunchKernelGGL(sweep_kernel<ISDF_SHAPE_MESH>, grid, block, 0, stream, ev_start, ev_stop, 0, P); break;
     default: hipExtLaunchKernelGGL(sweep_kernel<-1>, grid, block, 0, stream, ev_start, ev_stop, 0, P); break;
     }
 }

@@ -148,6 +148,14 @@ class Engine:
                 self._check(rc)
         return out
 
+    def shape_eval(self, p_rel, want_grad=True):
+        """(sdf[n], grad[n, 3]) of the installed shape at body-frame points (getonlySDF / getonlyGrad1)."""
+        p_rel = np.ascontiguousarray(p_rel, dtype=np.float64).reshape(-1, 3)
+        n = p_rel.shape[0]
+        sdf = np.zeros(n); grad = np.zeros((n, 3)) if want_grad else None
+        self._check(self.lib.isdf_shape_eval(self.h, _p(p_rel), n, _p(sdf), _p(grad) if want_grad else None))
+        return sdf, grad
+
     def set_shard(self, rank, world):
         self._check(self.lib.isdf_set_shard(self.h, rank, world))
 

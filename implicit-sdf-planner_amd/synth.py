@@ -109,6 +109,29 @@ def l_prism_mesh(a=1.6, b=1.0, t=0.4, h=0.5):
     return V, np.array(F, dtype=np.int32)
 
 
+def blob_mesh(nu, nv, seed=5, scale=1.0):
+    """Closed triangle mesh with 2 * nu * (nv - 1) faces: a lobed, flattened UV sphere with jittered vertices - stands in
+    for the reference's scanned robot meshes (2-12 k faces) at any size.  Returns (V, F), outward orientation."""
+    rng = np.random.default_rng(seed)
+    th = np.linspace(0, np.pi, nv + 1)[1:-1]
+    ph = np.linspace(0, 2 * np.pi, nu, endpoint=False)
+    P = [[0, 0, 1.0]] + [[np.sin(t) * np.cos(p) * (1 + 0.2 * np.cos(3 * p)), np.sin(t) * np.sin(p), np.cos(t) * 0.8]
+                         for t in th for p in ph] + [[0, 0, -1.0]]
+    P = (np.array(P) + rng.normal(0, 1e-3, (len(P), 3))) * scale
+    F = []
+    for j in range(nu):
+        F.append([0, 1 + j, 1 + (j + 1) % nu])
+    for i in range(nv - 2):
+        for j in range(nu):
+            a = 1 + i * nu + j; b = 1 + i * nu + (j + 1) % nu; c = a + nu; d = b + nu
+            F += [[a, c, d], [a, d, b]]
+    last = len(P) - 1
+    base = 1 + (nv - 2) * nu
+    for j in range(nu):
+        F.append([last, base + (j + 1) % nu, base + j])
+    return P, np.array(F, dtype=np.int32)
+
+
 def bench_box_shape():
     """convex box, half-extents (1.6, 0.3, 0.3) m, the Box formula (Shape.hpp:2343-2351) used the
     way a plugin author would (Generalshape subclass + DEFINE_USEFUL_FUNCTION => central-difference gradient)."""

@@ -187,6 +187,12 @@ int isdf_gather_points(isdf_ctx *ctx, const double *waypoints, int n_waypoints, 
 /* Copies up to `capacity` points (M x 3 row-major) and returns M (>= 0), or a negative isdf_status. */
 int isdf_get_points(isdf_ctx *ctx, double *xyz_out, int capacity);
 
+/* The installed robot shape by itself, on n BODY-FRAME points (p_rel: n x 3 row-major): sdf_out[i] =
+ * BasicShape::getonlySDF(pos_rel) and grad_out[i] (n x 3) = getonlyGrad1(pos_rel) (Shape.hpp:32-57: central difference
+ * dx = 5e-6, normalised; Box :2363-2377; Ball :622-625; mesh Generalshape Shape.cpp:105-139: (1 - 2 w) * distance with
+ * w = igl::fast_winding_number(fwn_bvh, 2.0, ...)).  Either output may be NULL.  Evaluated on the device. */
+int isdf_shape_eval(isdf_ctx *ctx, const double *p_rel, int n, double *sdf_out, double *grad_out);
+
 /* ---- per-step evaluation ----------------------------------------------------------------------------------- */
 /* Host entry point, synchronous, drop-in for the reference sweeps.  n_traj trajectories (1 in the reference);
  * N[b] pieces each; T[b] -> N[b] doubles; coeffs[b] -> 6N[b] x 3 column-major.

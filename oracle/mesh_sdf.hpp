@@ -3,32 +3,73 @@
 //   follows src/utils/src/Shape.cpp:105-151 (Generalshape::getonlySDF / getonlyGrad1 / getSDFwithGrad1).
 // The reference gets w from libigl 2.4.0 igl::fast_winding_number(fwn_bvh, 2.0, p, w)
 // (UT_SolidAngle<float,float>, order 2, Shape.cpp:86,110) and (c, dist^2) from igl::AABB::squared_distance
-// (Shape.cpp:85,112).  libigl's core .cpp files and lib/libigl.a are NOT in /root/reference
-// (SURVEY.md §8c), so:
+// (Shape.cpp:85,112).  libigl's core .cpp files and lib/libigl.a are NOT in /root/reference, but the
+// HDK winding-number core IS (vendored header src/utils/include/igl/FastWindingNumberForSoups.h), so:
+//   * winding number: the REFERENCE'S OWN library - oracle/_ref/libref_fwn.so (that header compiled where it lies, see
+//     ref_build/ref_fwn.cpp) is loaded at run time and asked for w.  Its far-field order-2 clusters deviate from the
+//     exact winding number by up to ~2e-3, so a restatement of "the exact sum" is NOT the reference's function; the
+//     exact float sum (Van Oosterom & Strackee 1983, the leaf formula of UT_SolidAngle) is kept only as the fallback
+//     when libref_fwn.so has not been built (backend() == 0: parity UNPINNED for the mesh kind in that case, and the
+//     mesh parity tests skip);
 //   * distance / closest point: exact geometry, brute force over triangles with the region-based
-//     closest-point-on-triangle test (Ericson, Real-Time Collision Detection §5.1.5 — the algorithm behind
-//     igl::point_simplex_squared_distance);
-//   * winding number: the exact sum of triangle solid angles (Van Oosterom & Strackee 1983 — the formula
-//     UT_SolidAngle uses for leaf triangles), evaluated in float like the reference, divided by 4*pi.
-//     libigl's far-field order-2 Taylor clusters are an approximation of this sum; they are only used for
-//     queries farther than 2x a cluster's radius, where the collision penalty is inactive.
-// PARITY UNPINNED for this kind: no reference test or golden vector exists at this boundary; oracle/_ref
-// builds the vendored FastWindingNumberForSoups.h to quantify the far-field deviation (tests/test_oracle_ref.py).
+//     closest-point-on-triangle test (Ericson, Real-Time Collision Detection 5.1.5 - the algorithm behind
+//     igl::point_simplex_squared_distance); igl::AABB only accelerates the same exact query.
 #pragma once
 #include "vecmath.hpp"
 #include <vector>
 #include <cstdint>
+#include <cstdlib>
+#include <string>
+#include <dlfcn.h>
 
 namespace orc {
+
+// oracle/_ref/libref_fwn.so (the vendored HDK library behind libigl's fast_winding_number), loaded once
+struct HdkFwn {
+    void *(*create)(const double *, int, const int *, int, int) = nullptr;
+    void (*destroy)(void *) = nullptr;
+    void (*eval)(void *, const double *, int, double, double *) = nullptr;
+    bool ok = false;
+    static const HdkFwn &get() {
+        static HdkFwn inst = [] {
+            HdkFwn h;
+            const char *off = std::getenv("ORACLE_MESH_EXACT_WINDING");
+            if (off && off[0] == '1') return h;
+            Dl_info info;
+            if (!dladdr((const void *)&HdkFwn::get, &info) || !info.dli_fname) return h;
+            std::string dir(info.dli_fname);
+            const size_t slash = dir.find_last_of('/');
+            dir = (slash == std::string::npos) ? std::string(".") : dir.substr(0, slash);
+            void *lib = dlopen((dir + "/_ref/libref_fwn.so").c_str(), RTLD_NOW | RTLD_LOCAL);
+            if (!lib) return h;
+            h.create = (decltype(h.create))dlsym(lib, "ref_fwn_create");
+            h.destroy = (decltype(h.destroy))dlsym(lib, "ref_fwn_destroy");
+            h.eval = (decltype(h.eval))dlsym(lib, "ref_fwn_eval");
+            h.ok = h.create && h.destroy && h.eval;
+            return h;
+        }();
+        return inst;
+    }
+};
 
 struct MeshSdf {
     std::vector<V3> V;
     std::vector<int32_t> F;   // 3 per face
+    void *hdk = nullptr;      // fwn_bvh of Shape.cpp:86 when the vendored library is available
+
+    MeshSdf() = default;
+    MeshSdf(const MeshSdf &) = delete;
+    MeshSdf &operator=(const MeshSdf &) = delete;
+    ~MeshSdf() { if (hdk) HdkFwn::get().destroy(hdk); }
+    int backend() const { return hdk ? 1 : 0; }     // 1: vendored HDK library, 0: exact sum (fallback)
 
     void set(const double *verts, int nV, const int32_t *faces, int nF) {
         V.resize(nV);
         for (int i = 0; i < nV; i++) V[i] = V3(verts[3 * i], verts[3 * i + 1], verts[3 * i + 2]);
         F.assign(faces, faces + 3 * (size_t)nF);
+        const HdkFwn &lib = HdkFwn::get();
+        if (hdk) { lib.destroy(hdk); hdk = nullptr; }
+        if (lib.ok) hdk = lib.create(verts, nV, faces, nF, 2);            // igl::fast_winding_number(V, F, 2, fwn_bvh)
     }
     int n_faces() const { return (int)(F.size() / 3); }
 
@@ -72,8 +113,15 @@ struct MeshSdf {
         return best;
     }
 
-    // float arithmetic like UT_SolidAngle<float,float>; 2*atan2(det, denom) per triangle
+    // igl::fast_winding_number(fwn_bvh, 2.0, p, w) (Shape.cpp:110); fallback: the exact sum in float arithmetic like
+    // UT_SolidAngle<float,float>, 2*atan2(det, denom) per triangle
     double winding_number(const V3 &p) const {
+        if (hdk) {
+            const double q[3] = {p.x, p.y, p.z};
+            double w;
+            HdkFwn::get().eval(hdk, q, 1, 2.0, &w);
+            return w;
+        }
         float total = 0.0f;
         const float qx = (float)p.x, qy = (float)p.y, qz = (float)p.z;
         for (int f = 0; f < n_faces(); f++) {

@@ -85,6 +85,9 @@ int orc_set_shape(void *h, const isdf_shape *s) {
     return 0;
 }
 
+// 1: the mesh winding number comes from the vendored HDK library (oracle/_ref/libref_fwn.so); 0: exact-sum fallback
+int orc_mesh_backend(void *h) { return ((OrcCtx *)h)->mesh.backend(); }
+
 int orc_set_points(void *h, const double *xyz, int M) {
     OrcCtx &c = *(OrcCtx *)h;
     c.points.assign(xyz, xyz + 3 * (size_t)M);

@@ -67,6 +67,10 @@ class Oracle:
         self._keep.append(shape)
         self.lib.orc_set_shape(self.h, C.byref(shape))
 
+    def mesh_backend(self):
+        """1: the mesh winding number comes from the vendored HDK library (oracle/_ref/libref_fwn.so); 0: exact-sum fallback."""
+        return int(self.lib.orc_mesh_backend(self.h))
+
     def set_points(self, pts):
         pts = np.ascontiguousarray(pts, dtype=np.float64)
         self.lib.orc_set_points(self.h, _p(pts), pts.shape[0])

@@ -24,31 +24,19 @@ def shim(tmp_path_factory):
 
 def _meshes(pkg):
     synth = pkg.synth
-    rng = np.random.default_rng(5)
     out = {}
+    # degenerate sizes first: 1, 2 and 4 triangles (a root with fewer than 4 children)
+    tet = np.array([[0, 0, 0], [1, 0, 0], [0, 1, 0], [0, 0, 1.0]])
+    Ft = np.array([[0, 2, 1], [0, 1, 3], [1, 2, 3], [0, 3, 2]], dtype=np.int32)
+    out["one triangle"] = (tet, Ft[:1]); out["two triangles"] = (tet, Ft[:2]); out["tetrahedron (4)"] = (tet, Ft)
     V, F = synth.l_prism_mesh(); out["L prism (20)"] = (V, F)
-    # box (12 triangles)
     c = np.array([[x, y, z] for x in (-.5, .5) for y in (-.4, .4) for z in (-.3, .3)])
     Fb = np.array([[0, 1, 3], [0, 3, 2], [4, 6, 7], [4, 7, 5], [0, 4, 5], [0, 5, 1], [2, 3, 7], [2, 7, 6], [0, 2, 6], [0, 6, 4], [1, 5, 7], [1, 7, 3]], dtype=np.int32)
     out["box (12)"] = (c, Fb)
-    # UV sphere-ish closed meshes of growing size: exercise the <= 6, <= 32 and binned split paths, and n > 1024
-    for nu, nv in ((4, 3), (8, 6), (24, 16), (64, 40)):
-        th = np.linspace(0, np.pi, nv + 1)[1:-1]
-        ph = np.linspace(0, 2 * np.pi, nu, endpoint=False)
-        P = [[0, 0, 1.0]] + [[np.sin(t) * np.cos(p) * (1 + 0.2 * np.cos(3 * p)), np.sin(t) * np.sin(p), np.cos(t) * 0.8] for t in th for p in ph] + [[0, 0, -1.0]]
-        P = np.array(P) + rng.normal(0, 1e-3, (len(P), 3))
-        Fs = []
-        for j in range(nu):
-            Fs.append([0, 1 + j, 1 + (j + 1) % nu])
-        for i in range(nv - 2):
-            for j in range(nu):
-                a = 1 + i * nu + j; b = 1 + i * nu + (j + 1) % nu; c2 = a + nu; d = b + nu
-                Fs += [[a, c2, d], [a, d, b]]
-        last = len(P) - 1
-        base = 1 + (nv - 2) * nu
-        for j in range(nu):
-            Fs.append([last, base + (j + 1) % nu, base + j])
-        out[f"blob ({len(Fs)})"] = (P, np.array(Fs, dtype=np.int32))
+    # closed meshes of growing size: exercise the <= 6, <= 32 and binned split paths, and n > 1024
+    for nu, nv in ((3, 2), (4, 3), (8, 6), (24, 16), (64, 40)):
+        P, Fs = synth.blob_mesh(nu, nv)
+        out[f"blob ({len(Fs)})"] = (P, Fs)
     return out
 
 

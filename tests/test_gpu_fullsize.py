@@ -92,7 +92,8 @@ def test_c4_eight_shards_sum_to_full(pkg, orc, product_lib, world256):
 
 
 def test_mesh_kind_matches_oracle(pkg, orc, product_lib):
-    """MESH robot (exact solid-angle winding number + exact closest point on both sides): V3 tile sweep and V1 sweep."""
+    """MESH robot (libigl's fast winding number: the device walks the HDK hierarchy, the oracle calls the vendored
+    library; exact closest point on both sides): V3 tile sweep and V1 sweep."""
     capi, synth = pkg.capi, pkg.synth
     occ, esdf, res = small_world(pkg, seed=14)
     T, cm = traj(pkg, occ, res, N=5, seed=23)

@@ -33,12 +33,12 @@ def _cube():
     return V, F
 
 
-def test_mesh_winding_number_vs_vendored_fwn(pkg, orc):
-    """The oracle's exact solid-angle sum vs the vendored HDK fast winding number (order 2, accuracy 2.0, float).
-    libigl approximates clusters farther than 2x their radius by an order-2 Taylor expansion, so its w deviates from
-    the exact winding number by up to ~2e-3 (measured here) => the reference's mesh SDF is scaled by (1 - 2w) with a
-    few 1e-3 relative error away from the surface.  The round-1 mesh path (oracle AND device) uses the exact sum:
-    this test quantifies the gap that keeps the MESH kind at 'parity unpinned' (DESIGN.md)."""
+def test_mesh_winding_number_is_the_vendored_fwn(pkg, orc):
+    """The oracle's mesh SDF takes w from the vendored HDK fast winding number itself (order 2, accuracy 2.0, float;
+    oracle/_ref/libref_fwn.so, loaded by oracle/mesh_sdf.hpp): sdf == (1 - 2 w_hdk) * exact distance.  libigl approximates
+    clusters farther than 2x their radius by an order-2 Taylor expansion, so w deviates from the exact winding number
+    (0 / 1 for a closed mesh) by up to a few 1e-3 - measured here; that is why the exact solid-angle sum is NOT the
+    reference's function and why the product walks the same hierarchy (csrc/fwn_host.hpp, tests/test_fwn_host.py)."""
     if not os.path.exists(orc.REF_FWN):
         pytest.skip("oracle/_ref/libref_fwn.so not built")
     V, F = _cube()
@@ -46,21 +46,22 @@ def test_mesh_winding_number_vs_vendored_fwn(pkg, orc):
     cfg = pkg.synth.default_config()
     o = orc.Oracle(cfg)
     o.set_shape(pkg.synth.make_mesh_shape(V, F))
+    assert o.mesh_backend() == 1
     rng = np.random.default_rng(1)
     Q = rng.uniform(-1.2, 1.2, (4000, 3))
     w_ref = fwn.eval(Q)
     sdf, _ = o.shape_eval(Q)
-    # reconstruct the oracle's w from sdf sign and magnitude: s = 1 - 2w = sdf / dist
     inside = (np.abs(Q) < np.array([0.5, 0.4, 0.3])).all(axis=1)
     assert np.all((w_ref > 0.5) == inside)
     assert np.all((sdf < 0) == inside)
     w_exact = np.where(inside, 1.0, 0.0)                      # closed mesh: the exact winding number is 0 / 1
     err = np.abs(w_ref - w_exact)
-    assert err.max() < 5e-3                                   # size of libigl's far-field approximation error
-    # the oracle's own float solid-angle sum is exact to float rounding: |1 - 2w| == 1
-    d = np.linalg.norm(np.maximum(np.abs(Q) - np.array([0.5, 0.4, 0.3]), 0), axis=1)
-    out = ~inside
-    assert np.allclose(sdf[out], d[out], rtol=5e-6, atol=1e-6)
+    assert 1e-5 < err.max() < 5e-3                            # size of libigl's far-field approximation error
+    half = np.array([0.5, 0.4, 0.3])
+    d_out = np.linalg.norm(np.maximum(np.abs(Q) - half, 0), axis=1)
+    d_in = np.min(half - np.abs(Q), axis=1)
+    d = np.where(inside, d_in, d_out)
+    assert np.allclose(sdf, (1.0 - 2.0 * w_ref) * d, rtol=1e-12, atol=1e-14)
 
 
 def test_lbfgs_vs_reference_header(pkg, orc, product_lib, capfd):
