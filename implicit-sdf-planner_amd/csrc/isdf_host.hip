@@ -256,8 +256,16 @@ extern "C" int isdf_set_shape(isdf_ctx *c, const isdf_shape *s) {
     for (int i = 0; i < 16; i++) d.f.p[i] = (float)d.d.p[i];
     for (int i = 0; i < 3; i++) d.f.trans[i] = (float)d.d.trans[i];
     for (int i = 0; i < 9; i++) { d.f.rot[i] = (float)d.d.rot[i]; d.f.csg_r2[i] = (float)d.d.csg_r2[i]; d.f.csg_r3[i] = (float)d.d.csg_r3[i]; }
-    d.prune_rows = (s->bbox_half[0] > 0 && s->bbox_half[1] > 0 && s->bbox_half[2] > 0) && !(getenv("ISDF_NO_ROW_PRUNE") && getenv("ISDF_NO_ROW_PRUNE")[0] == '1');
-    for (int i = 0; i < 3; i++) { d.bbox_lo[i] = (float)(s->bbox_center[i] - s->bbox_half[i]); d.bbox_hi[i] = (float)(s->bbox_center[i] + s->bbox_half[i]); }
+    double bb_c[3] = {s->bbox_center[0], s->bbox_center[1], s->bbox_center[2]}, bb_h[3] = {s->bbox_half[0], s->bbox_half[1], s->bbox_half[2]};
+    if (s->kind == ISDF_SHAPE_MESH && s->mesh_vertices && s->n_vertices > 0 && !(bb_h[0] > 0 && bb_h[1] > 0 && bb_h[2] > 0)) {
+        // a mesh lies inside the box of its vertices: use it for row pruning when the caller gave none
+        double lo[3] = {1e300, 1e300, 1e300}, hi[3] = {-1e300, -1e300, -1e300};
+        for (int v = 0; v < s->n_vertices; v++)
+            for (int a = 0; a < 3; a++) { lo[a] = std::min(lo[a], s->mesh_vertices[3 * v + a]); hi[a] = std::max(hi[a], s->mesh_vertices[3 * v + a]); }
+        for (int a = 0; a < 3; a++) { bb_c[a] = 0.5 * (lo[a] + hi[a]); bb_h[a] = 0.5 * (hi[a] - lo[a]) + 1e-6 * (std::fabs(lo[a]) + std::fabs(hi[a]) + 1.0); }
+    }
+    d.prune_rows = (bb_h[0] > 0 && bb_h[1] > 0 && bb_h[2] > 0) && !(getenv("ISDF_NO_ROW_PRUNE") && getenv("ISDF_NO_ROW_PRUNE")[0] == '1');
+    for (int i = 0; i < 3; i++) { d.bbox_lo[i] = (float)(bb_c[i] - bb_h[i]); d.bbox_hi[i] = (float)(bb_c[i] + bb_h[i]); }
     // the fp32 pre-filter of tile_kernel needs a continuous analytic SDF; ISDF_NO_F32_FILTER=1 disables it (A/B runs)
     d.filter_f32 = (s->kind != ISDF_SHAPE_MESH) && !(getenv("ISDF_NO_F32_FILTER") && getenv("ISDF_NO_F32_FILTER")[0] == '1');
     d.mesh = nullptr;

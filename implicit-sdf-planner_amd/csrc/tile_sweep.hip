@@ -138,6 +138,10 @@ __device__ __forceinline__ double uni(double v) {     // wave-uniform double -> 
 }
 __device__ __forceinline__ float unif(float v) { return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v))); }
 
+// Row pruning needs "sdf(p) >= distance(p, bbox)".  The mesh kind's sdf is (1 - 2 w) * distance with libigl's APPROXIMATE
+// winding number (|w error| up to a few 1e-3 outside, Shape.cpp:110), so its penalty band is widened by 5 % for pruning.
+__device__ __forceinline__ double mesh_band_scale(int kind) { return kind == ISDF_SHAPE_MESH ? 1.05 : 1.0; }
+
 template <int KIND>
 __global__ __launch_bounds__(64 * SW_SAMPLES, 3) void sweep_kernel(const SweepParams P) {
     __shared__ SweepPose s_pose[SW_SAMPLES];
@@ -199,7 +203,7 @@ __global__ __launch_bounds__(64 * SW_SAMPLES, 3) void sweep_kernel(const SweepPa
         if ((flags & 1) && P.shape.prune_rows) {
             // world-frame extent of the shape's body-frame bounding box inflated by the penalty band: rows whose
             // (x, y) lies outside it cannot hold a voxel with a non-zero penalty (conservative: +-1 voxel, NaN keeps all)
-            const double infl = P.safety_hor + 4.0e-3 + 0.05 * G.res;
+            const double infl = P.safety_hor * mesh_band_scale(P.shape.kind) + 4.0e-3 + 0.05 * G.res;
             const double hb[3] = {0.5 * ((double)P.shape.bbox_hi[0] - (double)P.shape.bbox_lo[0]) + infl,
                                   0.5 * ((double)P.shape.bbox_hi[1] - (double)P.shape.bbox_lo[1]) + infl,
                                   0.5 * ((double)P.shape.bbox_hi[2] - (double)P.shape.bbox_lo[2]) + infl};
@@ -248,7 +252,7 @@ __global__ __launch_bounds__(64 * SW_SAMPLES, 3) void sweep_kernel(const SweepPa
     for (int k = 0; k < 9; k++) Rf[k] = unif((float)sp.R[k]);
     const float resf = (float)G.res;
     const float bdh_f = (float)P.bd_half + TS_FILTER_EPS;
-    const float thr_f = (float)P.safety_hor + TS_FILTER_EPS;
+    const float thr_f = (float)P.safety_hor * (float)mesh_band_scale(KIND >= 0 ? KIND : P.shape.kind) + TS_FILTER_EPS;
     // pose in the tile's voxel frame, pre-multiplied: m = l*res - pvr,  pvr = ((pos - bmin)/res - 0.5 - lo)*res
     // (fp32 filter stage only: conservative by TS_FILTER_EPS, so the algebraically equal form without divisions is fine)
     const float pvx = unif((float)(sp.pos[0] - G.bmin[0] - (0.5 + lox) * G.res));
