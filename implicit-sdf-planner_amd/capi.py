@@ -57,6 +57,19 @@ class IsdfLbfgsParams(C.Structure):
                 ("machine_prec", C.c_double), ("dir_norm_cap", C.c_double)]
 
 
+class IsdfFrontendConfig(C.Structure):
+    _fields_ = [("kernel_size", C.c_int32), ("reserved", C.c_int32), ("kernel_max_roll", C.c_double), ("kernel_max_pitch", C.c_double),
+                ("kernel_ang_res", C.c_double), ("front_end_safeh", C.c_double)]
+
+
+def frontend_config(kernel_size=13, max_roll=45.0, max_pitch=45.0, ang_res=9.0, safeh=0.0):
+    """The shipped configs' front-end values (config_*.yaml: kernel_max_roll 45, kernel_ang_res 9, front_end_safeh 0)."""
+    c = IsdfFrontendConfig()
+    c.kernel_size = int(kernel_size); c.kernel_max_roll = float(max_roll); c.kernel_max_pitch = float(max_pitch)
+    c.kernel_ang_res = float(ang_res); c.front_end_safeh = float(safeh)
+    return c
+
+
 class IsdfLbfgsResult(C.Structure):
     _fields_ = [("f", C.c_double), ("wall_ms", C.c_double), ("status", C.c_int32), ("iterations", C.c_int32),
                 ("evaluations", C.c_int32), ("reserved", C.c_int32)]

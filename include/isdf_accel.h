@@ -269,6 +269,41 @@ int isdf_optimize_lbfgs(isdf_ctx *ctx, double *x_inout, int n, const isdf_lbfgs_
 int isdf_optimize_lbfgs_batch(isdf_ctx *ctx, int n_traj, int N, const double *heads_pva, const double *tails_pva, double rho,
                               double *x_inout, const isdf_lbfgs_params *p, isdf_lbfgs_result *results, double *wall_ms_out);
 
+/* ---- front end: pose feasibility by kernel convolution ------------------------------------- */
+/* The A* front end decides whether the robot fits at a voxel by AND-ing a bit-packed voxelisation of the robot at a
+ * (roll, pitch) attitude against the bit-packed occupancy map, trying attitudes breadth-first from the parent's
+ * (SweptVolumeManager::checkKernelValue, sw_manager.hpp:911-942).  The tables are built on the device from the installed
+ * shape and occupancy grid; queries are answered in batches.  All results are integer / byte work: bit-identical to the
+ * reference's. */
+typedef struct isdf_frontend_config {
+    int32_t kernel_size;        /* Config::kernel_size: odd, side of the robot voxelisation in voxels (<= 31)            */
+    int32_t reserved;
+    double kernel_max_roll;     /* degrees: attitudes -max .. +max in steps of kernel_ang_res (Shape.hpp:297-298,          */
+    double kernel_max_pitch;    /*          :416-421); the shipped configs use 45 / 45 / 9 -> 11 x 11 attitudes            */
+    double kernel_ang_res;
+    double front_end_safeh;     /* a voxel belongs to the robot when sdf <= max(front_end_safeh, resolution / 2) (:415)    */
+} isdf_frontend_config;
+/* Builds (a) the robot's attitude kernels - BasicShape::initShape<true,...> kernel part (Shape.hpp:400-459): for every
+ * attitude, voxel (a, b, c) is set when getonlySDF(pos, Rx(roll) * Ry(pitch)) <= margin - and (b) the inflated, bit-packed
+ * occupancy map of PCSmapManager::generateMapKernel (PCSmap_manager.h:46-78).  Needs isdf_set_shape and an occupancy grid
+ * (isdf_set_grid ISDF_GRID_OCCUPANCY or isdf_set_pointcloud).  Call again after either changes. */
+int isdf_frontend_build(isdf_ctx *ctx, const isdf_frontend_config *cfg);
+/* Read-back in the REFERENCE's byte layouts (bit z of a row in byte z / 8 under mask 0x80 >> (z % 8)).
+ * Shape kernels: ByteShapeKernel::map of every attitude, attitude-major ((i * ykernel + j) * k * k * ((k + 7) / 8) bytes;
+ * what plan_manager.cpp:545 reads through getOccupied).  dims_out = {xkernel_size, ykernel_size, bytes per attitude}.
+ * Map kernel: the array SweptVolumeManager::setMapKernel receives; dims_out = inflated {X, Y, bytes per z-row}.
+ * `out` may be NULL to query the sizes. */
+int isdf_frontend_get_shape_kernels(isdf_ctx *ctx, uint8_t *out, int dims_out[3]);
+int isdf_frontend_get_map_kernel(isdf_ctx *ctx, uint8_t *out, int dims_out[3]);
+/* n queries of the per-neighbour test of AstarPathSearcher::AstarGetSucc (front_end_Astar.hpp:214-217):
+ *   ok[q] = isIndexValid(ind) && !isIndexOccupiedFlate(ind, 0) && checkKernelValue(father_roll, father_pitch, cr, cp, ind)
+ * with ind = index[3q..3q+2] (voxel of the ORIGINAL map), and child_roll / child_pitch (degrees) of the first collision-free
+ * attitude in the reference's breadth-first order (visit_kernels_by_distance, :850-909: level attitude first, then outward
+ * from the parent's attitude, neighbours pushed in the order (0,+1) (0,-1) (+1,0) (-1,0)).  child_* are written only where
+ * ok[q] = 1.  kernel_index_out (optional) receives i * ykernel + j of that attitude, -1 where ok = 0. */
+int isdf_frontend_check(isdf_ctx *ctx, int n, const int32_t *index, const double *father_roll, const double *father_pitch,
+                        uint8_t *ok, double *child_roll, double *child_pitch, int32_t *kernel_index_out);
+
 /* ---- instrumentation --------------------------------------------------------------------------------------- */
 /* on = N > 0: every N-th isdf_eval_device attaches HIP start/stop events to the dispatch of its dominant kernel on
  * `stream` (hipExtLaunchKernel: the kernel's own begin/end timestamps, the interval rocprofv3 reports);

@@ -3,6 +3,7 @@
 // bench.py's cpu_baseline leg may load liboracle.so; the product library (libisdf_accel.so) never does.
 #include "cost.hpp"
 #include "minco.hpp"
+#include "frontend.hpp"
 #include <cstring>
 #include <memory>
 #include <string>
@@ -20,6 +21,7 @@ struct OrcCtx {
     std::vector<double> mesh_v;
     std::vector<int32_t> mesh_f;
     bool has_shape = false;
+    FrontEnd fe;
     void sync() {
         P.flat.mass = cfg.vehicle_mass; P.flat.grav = cfg.grav_acc; P.flat.dh = cfg.horiz_drag;
         P.flat.dv = cfg.vert_drag; P.flat.cp = cfg.paras_drag; P.flat.veps = cfg.speed_eps;
@@ -84,6 +86,39 @@ int orc_set_shape(void *h, const isdf_shape *s) {
     c.sync();
     return 0;
 }
+
+// ---- front end (kernel convolution), oracle/frontend.hpp
+int orc_frontend_build(void *h, const isdf_frontend_config *cfg) {
+    OrcCtx &c = *(OrcCtx *)h;
+    if (!c.has_shape || !c.grid.has_occ) return -1;
+    c.fe.configure(*cfg, c.grid.res);
+    c.fe.build_shape_kernels(c.P.shape, &c.mesh);
+    c.fe.build_map_kernel(c.grid);
+    return 0;
+}
+void orc_frontend_dims(void *h, int *out) {     // xk, yk, bytes per attitude, inflated X, Y, bytes per z-row
+    OrcCtx &c = *(OrcCtx *)h;
+    const int hh = (c.fe.k - 1) / 2;
+    out[0] = c.fe.xk; out[1] = c.fe.yk; out[2] = c.fe.k * c.fe.k * c.fe.bl;
+    out[3] = c.fe.mX + 2 * hh; out[4] = c.fe.mY + 2 * hh; out[5] = (c.fe.mZ + 2 * hh + 7) / 8;
+}
+void orc_frontend_shape_kernels(void *h, uint8_t *out) { OrcCtx &c = *(OrcCtx *)h; std::memcpy(out, c.fe.shape_bytes.data(), c.fe.shape_bytes.size()); }
+void orc_frontend_map_kernel(void *h, uint8_t *out) { OrcCtx &c = *(OrcCtx *)h; std::memcpy(out, c.fe.map_kernel.data(), c.fe.map_kernel.size() - 1); }
+void orc_frontend_rotations(void *h, double *out) { OrcCtx &c = *(OrcCtx *)h; std::memcpy(out, c.fe.rot.data(), c.fe.rot.size() * sizeof(double)); }
+void orc_frontend_check(void *h, int n, const int32_t *index, const double *fr, const double *fp, uint8_t *ok, double *cr, double *cp, int32_t *kidx) {
+    OrcCtx &c = *(OrcCtx *)h;
+#pragma omp parallel for schedule(dynamic, 64) num_threads(c.P.threads)
+    for (int q = 0; q < n; q++) {
+        const int ind[3] = {index[3 * q], index[3 * q + 1], index[3 * q + 2]};
+        double r = 0, p = 0;
+        int ki = -1;
+        const bool good = c.fe.successor_ok(c.grid, fr[q], fp[q], r, p, ind, &ki);
+        ok[q] = good ? 1 : 0;
+        if (good) { cr[q] = r; cp[q] = p; }
+        if (kidx) kidx[q] = ki;
+    }
+}
+int orc_frontend_kernel_conv(void *h, int ki, int kj, const int32_t *ind) { OrcCtx &c = *(OrcCtx *)h; const int i3[3] = {ind[0], ind[1], ind[2]}; return c.fe.kernel_conv(ki, kj, i3) ? 1 : 0; }
 
 // 1: the mesh winding number comes from the vendored HDK library (oracle/_ref/libref_fwn.so); 0: exact-sum fallback
 int orc_mesh_backend(void *h) { return ((OrcCtx *)h)->mesh.backend(); }

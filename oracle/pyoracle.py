@@ -67,6 +67,45 @@ class Oracle:
         self._keep.append(shape)
         self.lib.orc_set_shape(self.h, C.byref(shape))
 
+    # ---- front end (kernel convolution), oracle/frontend.hpp
+    def frontend_build(self, fe_cfg):
+        self._keep.append(fe_cfg)
+        rc = self.lib.orc_frontend_build(self.h, C.byref(fe_cfg))
+        if rc != 0:
+            raise RuntimeError("orc_frontend_build: needs a shape and an occupancy grid")
+        d = (C.c_int * 6)()
+        self.lib.orc_frontend_dims(self.h, d)
+        self.fe_dims = list(d)
+
+    def frontend_shape_kernels(self):
+        xk, yk, per = self.fe_dims[:3]
+        out = np.zeros((xk * yk, per), dtype=np.uint8)
+        self.lib.orc_frontend_shape_kernels(self.h, out.ctypes.data_as(C.c_void_p))
+        return out
+
+    def frontend_map_kernel(self):
+        X, Y, zb = self.fe_dims[3:]
+        out = np.zeros((X, Y, zb), dtype=np.uint8)
+        self.lib.orc_frontend_map_kernel(self.h, out.ctypes.data_as(C.c_void_p))
+        return out
+
+    def frontend_rotations(self):
+        xk, yk = self.fe_dims[:2]
+        out = np.zeros((xk * yk, 3, 3))
+        self.lib.orc_frontend_rotations(self.h, _p(out))
+        return out
+
+    def frontend_check(self, index, father_roll, father_pitch):
+        """(ok[n] uint8, child_roll[n], child_pitch[n], kernel_index[n]) of AstarGetSucc's per-neighbour test."""
+        index = np.ascontiguousarray(index, dtype=np.int32).reshape(-1, 3)
+        n = index.shape[0]
+        fr = np.ascontiguousarray(np.broadcast_to(father_roll, (n,)), dtype=np.float64)
+        fp = np.ascontiguousarray(np.broadcast_to(father_pitch, (n,)), dtype=np.float64)
+        ok = np.zeros(n, dtype=np.uint8); cr = np.zeros(n); cp = np.zeros(n); ki = np.zeros(n, dtype=np.int32)
+        self.lib.orc_frontend_check(self.h, n, index.ctypes.data_as(C.c_void_p), _p(fr), _p(fp), ok.ctypes.data_as(C.c_void_p),
+                                    _p(cr), _p(cp), ki.ctypes.data_as(C.c_void_p))
+        return ok, cr, cp, ki
+
     def mesh_backend(self):
         """1: the mesh winding number comes from the vendored HDK library (oracle/_ref/libref_fwn.so); 0: exact-sum fallback."""
         return int(self.lib.orc_mesh_backend(self.h))
@@ -301,6 +340,34 @@ class RefWorld:
     def esdf_sample(self, pos):
         pos = np.asarray(pos, dtype=np.float64); g = np.zeros(3)
         return self.lib.ref_world_esdf_sample(self.h, _p(pos), _p(g)), g
+
+    # ---- front end: the reference's own kernel generation / generateMapKernel / checkKernelValue
+    def frontend_build(self, fe_cfg, shape_name):
+        fe = np.array([fe_cfg.kernel_size, fe_cfg.kernel_max_roll, fe_cfg.kernel_max_pitch, fe_cfg.kernel_ang_res, fe_cfg.front_end_safeh], dtype=np.float64)
+        if self.lib.ref_frontend_build(self.h, _p(fe), shape_name.encode()) != 0:
+            raise ValueError(shape_name)
+        d = (C.c_int * 6)()
+        self.lib.ref_frontend_dims(self.h, d)
+        self.fe_dims = list(d)
+
+    def frontend_shape_kernels(self):
+        xk, yk, per = self.fe_dims[:3]
+        out = np.zeros((xk * yk, per), dtype=np.uint8)
+        self.lib.ref_frontend_shape_kernels(self.h, out.ctypes.data_as(C.c_void_p))
+        return out
+
+    def frontend_map_kernel(self):
+        X, Y, zb = self.fe_dims[3:]
+        out = np.zeros((X, Y, zb), dtype=np.uint8)
+        self.lib.ref_frontend_map_kernel(self.h, out.ctypes.data_as(C.c_void_p))
+        return out
+
+    def frontend_check(self, index, father_roll, father_pitch):
+        """checkKernelValue for one voxel index (caller has already tested validity / occupancy)."""
+        ind = np.ascontiguousarray(index, dtype=np.int32)
+        cr = C.c_double(0.0); cp = C.c_double(0.0)
+        ok = self.lib.ref_frontend_check(self.h, ind.ctypes.data_as(C.c_void_p), C.c_double(father_roll), C.c_double(father_pitch), C.byref(cr), C.byref(cp))
+        return ok, cr.value, cp.value
 
     def points_in_aabb(self, center, half):
         c = np.asarray(center, dtype=np.float64)

@@ -16,6 +16,8 @@ using namespace std;
 struct Config {
     double box_x = 0, box_y = 0, box_z = 0;
     double safety_hor = 0, occupancy_resolution = 0;
+    int kernel_size = 0;                                                       // front end (kernel convolution)
+    double kernel_max_roll = 0, kernel_max_pitch = 0, kernel_ang_res = 1, front_end_safeh = 0;
     Eigen::RowVector3d trans;
     Eigen::Matrix3d rotate;
 };
@@ -23,11 +25,30 @@ struct Config {
 namespace shape {
 using Eigen::Vector3d; using Eigen::Vector2d; using Eigen::Matrix3d; using Eigen::RowVector3d;   // Shape.hpp gets these through `using namespace vis`
 typedef std::function<double(const Eigen::Vector3d &)> SDFFunction;
+const uint8_t or_mask[8] = {0x80, 0x40, 0x20, 0x10, 0x08, 0x04, 0x02, 0x01};     // Shape.hpp:92
 class Generalshape {
 public:
     Config config;
-    Generalshape(const Config &conf, bool /*analytic*/) : config(conf) {}
-    virtual ~Generalshape() {}
+#include "../_ref/gen/shape_kernel_types.inc"     // Shape.hpp:103-256: Shapekernel, ByteShapeKernel
+    // the members BasicShape's kernel generation reads (Shape.hpp:258-306)
+    int xkernel_size = -1, ykernel_size = -1, kernelsize = -1;
+    double kernelresu = -1, kernel_max_roll = 0, kernel_max_pitch = 0, kernel_ang_res = 1;
+    bool initselfkerneldone = false;
+    Shapekernel *shape_kernels = nullptr;
+    ByteShapeKernel *byte_shape_kernels = nullptr;
+    Generalshape(const Config &conf, bool /*analytic*/) : config(conf) {
+        xkernel_size = floor(2 * conf.kernel_max_roll / conf.kernel_ang_res) + 1;          // Shape.hpp:297-305
+        ykernel_size = floor(2 * conf.kernel_max_pitch / conf.kernel_ang_res) + 1;
+        kernelsize = config.kernel_size;
+        kernelresu = config.occupancy_resolution;
+        kernel_max_roll = config.kernel_max_roll; kernel_max_pitch = config.kernel_max_pitch; kernel_ang_res = config.kernel_ang_res;
+    }
+    virtual ~Generalshape() { delete[] shape_kernels; delete[] byte_shape_kernels; }
+    // the `if (enablekernel)` block of BasicShape::initShape (Shape.hpp:406-462), verbatim
+    void initShapeKernels() {
+        const bool enablekernel = true;
+#include "../_ref/gen/shape_kernel_gen.inc"
+    }
     void getTransform(Eigen::Matrix3d &R, Eigen::RowVector3d &t) const { R = config.rotate; t = config.trans; }
     virtual double getonlySDF(const Eigen::RowVector3d &pos_rel) = 0;
     virtual double getonlySDF(const Eigen::RowVector3d &pos_rel, const Eigen::Matrix3d &R_obj) = 0;

@@ -15,6 +15,9 @@
 // TEST INFRASTRUCTURE ONLY.
 #include "ref_shapes_common.hpp"
 #include <cfloat>
+#include <chrono>
+#include <queue>
+#include <cstring>
 #include <ros/ros.h>
 #include <cassert>
 #include <limits>
@@ -23,6 +26,15 @@
 #define TRAJ_ORDER 5
 #define ROS_ERROR(...) do { } while (0)
 using Eigen::Vector3i; using Eigen::Vector3d; using Eigen::Matrix3d;
+
+// ByteShapeKernel::generateByteKernel (Shape.hpp:238) allocates its bit array with `new uint8_t[n]` - NOT value-initialised -
+// and then only ORs bits into it, i.e. the reference relies on fresh heap memory being zero.  Inside this library (linked
+// -Bsymbolic) array-new hands out zeroed memory, which is the one behaviour under which that code does what it means.
+#include <cstdlib>
+#include <new>
+void *operator new[](std::size_t n) { void *p = std::calloc(n ? n : 1, 1); if (!p) throw std::bad_alloc(); return p; }
+void operator delete[](void *p) noexcept { std::free(p); }
+void operator delete[](void *p, std::size_t) noexcept { std::free(p); }
 
 // ---------------------------------------------------------------- GridMap3D (map_manager)
 class GridMap3D {
@@ -62,7 +74,11 @@ public:
     GridMap3D *occupancy_map = nullptr;
     Vector3d boundary_xyzmin, boundary_xyzmax;
 #include "../_ref/gen/pcsmap.inc"             // PCSmap_manager.h:130-170 projInMap, getPointsInAABB
+    static constexpr uint8_t or_mask[8] = {0x80, 0x40, 0x20, 0x10, 0x08, 0x04, 0x02, 0x01};      // PCSmap_manager.h:32
+    uint8_t *mk = nullptr;
+#include "../_ref/gen/pcsmap_kernel.inc"      // PCSmap_manager.h:46-78 generateMapKernel
 };
+constexpr uint8_t PCSmapManager::or_mask[8];
 
 // ---------------------------------------------------------------- SweptVolumeManager (swept_volume)
 class SweptVolumeManager {
@@ -79,6 +95,12 @@ public:
 #include "../_ref/gen/swm_d.inc"              // :593-662
 #include "../_ref/gen/swm_e.inc"              // :710-747
 #include "../_ref/gen/swm_f.inc"              // :1000-1062
+    // front end: kernelConv / visit_kernels_by_distance / checkKernelValue (sw_manager.hpp:775-942) and what they read
+    uint8_t *map_kernel = nullptr;
+    int map_Xsize = 0, map_Ysize = 0, map_Zsize = 0, xkernel_size = 0, ykernel_size = 0, kernelsize = 0;
+    bool isIndexValid(const int, const int, const int) const { return false; }      // empty bodies in the reference (:768-773);
+    bool isIndexOccupied(int, int, int) { return false; }                             // only the never-used bool-kernel path calls them
+#include "../_ref/gen/swm_g.inc"              // :775-942
 };
 
 // ---------------------------------------------------------------- TrajOptimizer (planner_algorithm)
@@ -156,6 +178,52 @@ void *ref_world_create(const double *cfg, int K, int threads, const char *shape_
     return w;
 }
 void ref_world_destroy(void *h) { delete (World *)h; }
+
+// ---- front end: the reference's kernel generation, map kernel and checkKernelValue
+// fe: [kernel_size, kernel_max_roll, kernel_max_pitch, kernel_ang_res, front_end_safeh]; the shape is re-made with them
+int ref_frontend_build(void *h, const double *fe, const char *shape_name) {
+    World *w = (World *)h;
+    Config &c = w->conf;
+    c.kernel_size = (int)fe[0]; c.kernel_max_roll = fe[1]; c.kernel_max_pitch = fe[2]; c.kernel_ang_res = fe[3]; c.front_end_safeh = fe[4];
+    delete w->shape;
+    w->shape = make(shape_name, c);
+    if (!w->shape) return -1;
+    w->shape->initShapeKernels();
+    SweptVolumeManager &sv = w->sv;
+    sv.config = c;
+    sv.current_robot_shape = w->shape;
+    sv.xkernel_size = floor(2 * c.kernel_max_roll / c.kernel_ang_res) + 1;         // sw_manager.hpp:135-137
+    sv.ykernel_size = floor(2 * c.kernel_max_pitch / c.kernel_ang_res) + 1;
+    sv.kernelsize = c.kernel_size;
+    delete[] sv.map_kernel;
+    uint8_t *mk = w->pcs.generateMapKernel(c.kernel_size);                            // plan_manager.cpp:400-406
+    sv.map_kernel = mk; sv.map_Xsize = w->grid.X_size; sv.map_Ysize = w->grid.Y_size; sv.map_Zsize = w->grid.Z_size;      // setMapKernel, sw_manager.hpp:158-164
+    return 0;
+}
+void ref_frontend_dims(void *h, int *out) {
+    World *w = (World *)h;
+    const int k = w->conf.kernel_size, hh = (k - 1) / 2;
+    out[0] = w->sv.xkernel_size; out[1] = w->sv.ykernel_size; out[2] = k * k * ((k + 7) / 8);
+    out[3] = w->grid.X_size + 2 * hh; out[4] = w->grid.Y_size + 2 * hh; out[5] = (w->grid.Z_size + 2 * hh + 7) / 8;
+}
+void ref_frontend_shape_kernels(void *h, unsigned char *out) {
+    World *w = (World *)h;
+    const int k = w->conf.kernel_size, per = k * k * ((k + 7) / 8), n = w->sv.xkernel_size * w->sv.ykernel_size;
+    for (int i = 0; i < n; i++) memcpy(out + (size_t)i * per, w->shape->byte_shape_kernels[i].map, per);
+}
+void ref_frontend_map_kernel(void *h, unsigned char *out) {
+    World *w = (World *)h;
+    int d[6]; ref_frontend_dims(h, d);
+    memcpy(out, w->sv.map_kernel, (size_t)d[3] * d[4] * d[5]);
+}
+int ref_frontend_check(void *h, const int *ind, double fr, double fp, double *cr, double *cp) {
+    World *w = (World *)h;
+    return w->sv.checkKernelValue(fr, fp, *cr, *cp, Vector3i(ind[0], ind[1], ind[2])) ? 1 : 0;
+}
+int ref_frontend_kernel_conv(void *h, int ki, int kj, const int *ind) {
+    World *w = (World *)h;
+    return w->sv.kernelConv<true>(ki, kj, Vector3i(ind[0], ind[1], ind[2])) ? 1 : 0;
+}
 
 // occupancy grid (uint8, z fastest) -> GridMap3D::grid_map; optionally the reference's own generateESDF3d
 void ref_world_set_occupancy(void *h, const unsigned char *occ, int nx, int ny, int nz, const double *bmin, const double *bmax, double res) {

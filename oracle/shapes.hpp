@@ -200,11 +200,8 @@ inline double sdf_box(const double *P, const V3 &p) {
     return box_q(V3(std::fabs(p.x) - P[0], std::fabs(p.y) - P[1], std::fabs(p.z) - P[2]));
 }
 
-// BasicShape::getonlySDF(pos_rel)  (Shape.hpp:469)
-inline double shape_sdf(const isdf_shape &S, const MeshSdf *mesh, const V3 &p_rel) {
-    if (S.kind == ISDF_SHAPE_MESH) return mesh->sdf(p_rel);          // vertices are already body-frame
-    if (S.kind == ISDF_SHAPE_BALL) return norm(p_rel) - S.params[0]; // Ball/Point ignore trans/Rotate :617-620
-    const V3 p = body_offset(S, p_rel);
+// the class formula at a point already in the shape's own frame (after the body offset)
+inline double analytic_local(const isdf_shape &S, const V3 &p) {
     const double *P = S.params;
     switch (S.kind) {
     case ISDF_SHAPE_TORUS: return sdf_torus(P, p);
@@ -223,6 +220,24 @@ inline double shape_sdf(const isdf_shape &S, const MeshSdf *mesh, const V3 &p_re
     case ISDF_SHAPE_BOX: return sdf_box(P, p);
     default: return 1e9;
     }
+}
+
+// BasicShape::getonlySDF(pos_rel)  (Shape.hpp:469)
+inline double shape_sdf(const isdf_shape &S, const MeshSdf *mesh, const V3 &p_rel) {
+    if (S.kind == ISDF_SHAPE_MESH) return mesh->sdf(p_rel);          // vertices are already body-frame
+    if (S.kind == ISDF_SHAPE_BALL) return norm(p_rel) - S.params[0]; // Ball/Point ignore trans/Rotate :617-620
+    return analytic_local(S, body_offset(S, p_rel));
+}
+
+// BasicShape::getonlySDF(pos, R_obj)  (Shape.hpp:470): every analytic class evaluates its formula at
+// (pos - trans) * Rotate * R_obj (e.g. :850-855, Box :2353-2361) - the body offset FIRST, then R_obj; Ball ignores both
+// (:621-624); the mesh Generalshape uses pos * R_obj (Shape.cpp:115-124).  R_obj row-major.
+inline double shape_sdf_rotated(const isdf_shape &S, const MeshSdf *mesh, const V3 &pos, const double *Ro) {
+    if (S.kind == ISDF_SHAPE_BALL) return norm(pos) - S.params[0];
+    if (S.kind == ISDF_SHAPE_MESH)
+        return mesh->sdf(V3(pos.x * Ro[0] + pos.y * Ro[3] + pos.z * Ro[6], pos.x * Ro[1] + pos.y * Ro[4] + pos.z * Ro[7], pos.x * Ro[2] + pos.y * Ro[5] + pos.z * Ro[8]));
+    const V3 q = body_offset(S, pos);
+    return analytic_local(S, V3(q.x * Ro[0] + q.y * Ro[3] + q.z * Ro[6], q.x * Ro[1] + q.y * Ro[4] + q.z * Ro[7], q.x * Ro[2] + q.y * Ro[5] + q.z * Ro[8]));
 }
 
 inline int effective_grad_mode(const isdf_shape &S) {

@@ -270,3 +270,52 @@ def test_grad_cost_p_and_grid_vs_reference_code(pkg, orc):
         assert np.allclose(gq_o, gq_r, rtol=1e-8, atol=1e-9 * max(1.0, np.abs(gq_r).max()))
         n_active += int(a_r)
     assert n_active > 10
+
+
+# ---- front end (kernel convolution): oracle/frontend.hpp vs the reference's own code ----------------------
+def _frontend_world(pkg, seed=5, dims=(40, 36, 20), res=0.5):
+    occ = pkg.synth.random_box_map(dims, res=res, occupancy=0.10, seed=seed, edge=(0.5, 2.0))
+    return occ, res
+
+
+@pytest.mark.parametrize("name", ["Box", "RoundedCone", "Torus_big", "BendLinear_big", "SmoothIntersection_big", "Trefoil", "CSG", "Table"])
+def test_frontend_kernels_and_checks_vs_reference_code(pkg, orc, name):
+    """Robot attitude kernels (BasicShape::initShape kernel part, Shape.hpp:406-462), the inflated bit-packed map
+    (generateMapKernel, PCSmap_manager.h:46-78) and checkKernelValue (sw_manager.hpp:775-942: kernelConv + breadth-first
+    attitude search) - the oracle's restatement against the reference's own code, byte for byte and query for query."""
+    if not os.path.exists(orc.REF_SWEEPS):
+        pytest.skip("oracle/_ref/libref_sweeps.so not built")
+    capi, synth = pkg.capi, pkg.synth
+    occ, res = _frontend_world(pkg)
+    kw = dict(params=(0.9, 0.35, 0.25)) if name == "Box" else {}
+    shape = synth.make_shape(name, poly_params=(0.05, -0.1, 0.02, 12, -8, 25), **kw)
+    cfg = synth.default_config(capi.V1_SWEPT)
+    k = 13 if name in ("Box", "RoundedCone") else 15
+    fe = capi.frontend_config(kernel_size=k, max_roll=45.0, max_pitch=45.0, ang_res=9.0, safeh=0.0)
+    o = orc.Oracle(cfg, threads=8)
+    o.set_grid(occ, (0, 0, 0), res, capi.GRID_OCCUPANCY); o.set_shape(shape)
+    o.frontend_build(fe)
+    w = orc.RefWorld(cfg, name, shape, res)
+    w.set_occupancy(occ, (0, 0, 0), res)
+    w.frontend_build(fe, name)
+    assert o.fe_dims == w.fe_dims and o.fe_dims[:2] == [11, 11]
+    sk, sk_ref = o.frontend_shape_kernels(), w.frontend_shape_kernels()
+    assert sk_ref.any()
+    assert np.array_equal(sk, sk_ref), (name, np.argwhere(sk != sk_ref)[:5])
+    assert np.array_equal(o.frontend_map_kernel(), w.frontend_map_kernel())
+    # queries: free voxels all over the map incl. the borders, random parent attitudes on the attitude grid and off it
+    rng = np.random.default_rng(3)
+    free = np.argwhere(occ == 0)
+    idx = free[rng.choice(len(free), 600, replace=False)].astype(np.int32)
+    fr = rng.choice(np.arange(-45.0, 45.1, 9.0), 600) + rng.choice([0.0, 0.0, 2.5], 600) * (rng.random(600) < 0.3)
+    fp = rng.choice(np.arange(-45.0, 45.1, 9.0), 600)
+    fr = np.clip(fr, -45.0, 45.0)
+    ok, cr, cp, ki = o.frontend_check(idx, fr, fp)
+    n_ok = 0
+    for q in range(600):
+        r_ok, r_cr, r_cp = w.frontend_check(idx[q], fr[q], fp[q])
+        assert r_ok == ok[q], (name, q)
+        if r_ok:
+            n_ok += 1
+            assert r_cr == cr[q] and r_cp == cp[q], (name, q, r_cr, cr[q], r_cp, cp[q])
+    assert 0 < n_ok < 600, n_ok        # the scenario exercises both outcomes
