@@ -163,14 +163,10 @@ template <typename T> __device__ __forceinline__ T sdf_csg(const ShapeP<T> &S, v
     return m_max(f, -m_min(m_min(c1, c2), c3));
 }
 
-// analytic kinds only (kind != MESH)
+// the class formula at a point already in the shape's own frame (after the body offset); analytic kinds except Ball
 template <int KIND, typename T>
-__device__ __forceinline__ T analytic_sdf(const ShapeP<T> &S, int kind_rt, v3<T> pr) {
+__device__ __forceinline__ T analytic_local(const ShapeP<T> &S, int kind_rt, v3<T> p) {
     const int kind = (KIND >= 0) ? KIND : kind_rt;
-    if (kind == ISDF_SHAPE_BALL) return norm3(pr) - S.p[0];
-    const T dx = pr.x - S.trans[0], dy = pr.y - S.trans[1], dz = pr.z - S.trans[2];
-    const T *R = S.rot;
-    const v3<T> p = mkv<T>(dx * R[0] + dy * R[3] + dz * R[6], dx * R[1] + dy * R[4] + dz * R[7], dx * R[2] + dy * R[5] + dz * R[8]);
     switch (kind) {
     case ISDF_SHAPE_TORUS: return sdf_torus(S.p, p);
     case ISDF_SHAPE_CAPPEDTORUS: return sdf_cappedtorus(S.p, p);
@@ -189,6 +185,20 @@ __device__ __forceinline__ T analytic_sdf(const ShapeP<T> &S, int kind_rt, v3<T>
     default: return T(1e9);
     }
 }
+// (pos_rel - trans) * Rotate: the body offset every analytic class applies first (e.g. Shape.hpp:843)
+template <typename T> __device__ __forceinline__ v3<T> body_offset(const ShapeP<T> &S, v3<T> pr) {
+    const T dx = pr.x - S.trans[0], dy = pr.y - S.trans[1], dz = pr.z - S.trans[2];
+    const T *R = S.rot;
+    return mkv<T>(dx * R[0] + dy * R[3] + dz * R[6], dx * R[1] + dy * R[4] + dz * R[7], dx * R[2] + dy * R[5] + dz * R[8]);
+}
+
+// analytic kinds only (kind != MESH)
+template <int KIND, typename T>
+__device__ __forceinline__ T analytic_sdf(const ShapeP<T> &S, int kind_rt, v3<T> pr) {
+    const int kind = (KIND >= 0) ? KIND : kind_rt;
+    if (kind == ISDF_SHAPE_BALL) return norm3(pr) - S.p[0];
+    return analytic_local<KIND, T>(S, kind_rt, body_offset(S, pr));
+}
 
 __device__ double mesh_sdf(const DevMesh *m, d3 p);              // dev_mesh.hpp
 __device__ double mesh_sdf_grad(const DevMesh *m, d3 p, d3 &g);  // dev_mesh.hpp
@@ -198,6 +208,20 @@ template <int KIND>
 __device__ __forceinline__ double shape_sdf(const DevShape &S, d3 pr) {
     if constexpr (KIND == ISDF_SHAPE_MESH) return mesh_sdf(S.mesh, pr);     // the mesh kind has its own instantiation
     else return analytic_sdf<KIND, double>(S.d, S.kind, pr);
+}
+
+// BasicShape::getonlySDF(pos, R_obj) (Shape.hpp:470), the form the front end's kernel generation uses (:451): every
+// analytic class evaluates its formula at (pos - trans) * Rotate * R_obj (e.g. :850-855, Box :2353-2361) - the body offset
+// first, then R_obj; Ball ignores both (:621-624); the mesh Generalshape uses pos * R_obj (Shape.cpp:115-124).
+template <int KIND>
+__device__ __forceinline__ double shape_sdf_rotated(const DevShape &S, d3 pos, const double *Ro) {
+    if constexpr (KIND == ISDF_SHAPE_MESH) {
+        return mesh_sdf(S.mesh, mk3(pos.x * Ro[0] + pos.y * Ro[3] + pos.z * Ro[6], pos.x * Ro[1] + pos.y * Ro[4] + pos.z * Ro[7], pos.x * Ro[2] + pos.y * Ro[5] + pos.z * Ro[8]));
+    } else {
+        if (S.kind == ISDF_SHAPE_BALL) return norm3(pos) - S.d.p[0];
+        const d3 q = body_offset(S.d, pos);
+        return analytic_local<KIND, double>(S.d, S.kind, mk3(q.x * Ro[0] + q.y * Ro[3] + q.z * Ro[6], q.x * Ro[1] + q.y * Ro[4] + q.z * Ro[7], q.x * Ro[2] + q.y * Ro[5] + q.z * Ro[8]));
+    }
 }
 
 // getonlyGrad1: central difference dx = 5e-6 (temp -= dx; temp += 2dx), normalised — Shape.hpp:32-57;

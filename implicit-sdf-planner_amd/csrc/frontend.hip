@@ -1,0 +1,365 @@
+// Front end: pose feasibility by kernel convolution.  Integer / bit work on the device:
+//   fe_shape_rows_kernel   the robot voxelised at every (roll, pitch) attitude - BasicShape::initShape kernel part
+//                          (Shape.hpp:406-462): voxel (a, b, c) is set when getonlySDF(pos, Rx * Ry) <= margin; one lane per
+//                          (attitude, a, b) row writes the row's k bits as one dword (bit c = voxel c);
+//   fe_map_bits_kernel     the occupancy map inflated by (k - 1) / 2 voxels of free space on every side and bit-packed along z
+//                          (PCSmapManager::generateMapKernel, PCSmap_manager.h:46-78), 32 voxels per dword;
+//   fe_check_kernel        one WAVEFRONT per query of AstarGetSucc's per-neighbour test (front_end_Astar.hpp:214-217):
+//                          every lane keeps the map bits of its <= ceil(k^2 / 64) tile rows in registers (loaded once), then
+//                          attitudes are tried in the reference's breadth-first order (a host-built table per parent
+//                          attitude, visit_kernels_by_distance sw_manager.hpp:850-909): row dword AND map bits, wave ballot,
+//                          stop at the first attitude with no overlap (kernelConv<true>, :813-847).
+// The reference's byte layouts (bit z in byte z / 8 under mask 0x80 >> (z % 8)) are produced for read-back only.
+// This file is compiled with -ffp-contract=off: the voxelisation compares an SDF with a margin, and robots aligned with
+// the grid put voxel centres exactly ON that margin - the comparison must see the reference's roundings.
+#include "isdf_ctx.hpp"
+#include "dev_mesh.hpp"
+#include <cmath>
+#include <queue>
+#include <vector>
+
+namespace isdf {
+
+struct FeParams {
+    int k, n_att, side;          // kernel_size, attitudes, (k - 1) / 2
+    double res, margin;
+    int iX, iY, iZW;             // inflated map: X + 2h, Y + 2h, dwords per z-row (one spare dword at the end of every row)
+    int X, Y, Z;
+};
+
+template <int KIND>
+__global__ __launch_bounds__(256) void fe_shape_rows_kernel(DevShape S, FeParams F, const double *__restrict__ rot, unsigned *__restrict__ rows) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    const int kk = F.k * F.k;
+    if (t >= F.n_att * kk) return;
+    const int att = t / kk, ab = t - att * kk, a = ab / F.k, b = ab - a * F.k;
+    const double *R = rot + (size_t)9 * att;
+    const double x = F.res * a - F.side * F.res, y = F.res * b - F.side * F.res;       // Shape.hpp:444-446
+    unsigned w = 0;
+    for (int c = 0; c < F.k; c++) {
+        const double z = F.res * c - F.side * F.res;
+        if (shape_sdf_rotated<KIND>(S, mk3(x, y, z), R) <= F.margin) w |= 1u << c;
+    }
+    rows[t] = w;
+}
+
+__global__ __launch_bounds__(256) void fe_map_bits_kernel(FeParams F, const uint8_t *__restrict__ occ, unsigned *__restrict__ bits) {
+    const size_t n = (size_t)F.iX * F.iY * F.iZW;
+    for (size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x; t < n; t += (size_t)gridDim.x * blockDim.x) {
+        const int w = (int)(t % F.iZW);
+        const size_t xy = t / F.iZW;
+        const int fy = (int)(xy % F.iY), fx = (int)(xy / F.iY);
+        const int x = fx - F.side, y = fy - F.side;
+        unsigned v = 0;
+        if (x >= 0 && x < F.X && y >= 0 && y < F.Y) {
+            const uint8_t *row = occ + ((size_t)x * F.Y + y) * F.Z;
+            for (int bit = 0; bit < 32; bit++) {
+                const int z = (w << 5) + bit - F.side;
+                if (z >= 0 && z < F.Z && row[z] == 1) v |= 1u << bit;
+            }
+        }
+        bits[t] = v;
+    }
+}
+
+// reference byte layouts for read-back
+__global__ __launch_bounds__(256) void fe_pack_shape_bytes_kernel(FeParams F, const unsigned *__restrict__ rows, uint8_t *__restrict__ out) {
+    const int bl = (F.k + 7) / 8;
+    const int n = F.n_att * F.k * F.k * bl;
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n) return;
+    const int q = t % bl, row = t / bl;
+    const unsigned w = rows[row] >> (q * 8);
+    unsigned byte = 0;
+    for (int bit = 0; bit < 8; bit++) if ((w >> bit) & 1u) byte |= 0x80u >> bit;
+    out[t] = (uint8_t)byte;
+}
+__global__ __launch_bounds__(256) void fe_pack_map_bytes_kernel(FeParams F, const unsigned *__restrict__ bits, uint8_t *__restrict__ out, int zb) {
+    const size_t n = (size_t)F.iX * F.iY * zb;
+    for (size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x; t < n; t += (size_t)gridDim.x * blockDim.x) {
+        const int q = (int)(t % zb);
+        const size_t xy = t / zb;
+        const unsigned w = bits[xy * F.iZW + (q >> 2)] >> ((q & 3) * 8);
+        unsigned byte = 0;
+        for (int bit = 0; bit < 8; bit++) if ((w >> bit) & 1u) byte |= 0x80u >> bit;
+        out[t] = (uint8_t)byte;
+    }
+}
+
+constexpr int FE_MAX_ROWS_PER_LANE = 16;     // k <= 31: 961 rows / 64 lanes
+
+struct FeQuery {
+    int n, yk, xk;
+    double max_roll, max_pitch, ang_res;
+    const int *index; const double *fr, *fp;
+    uint8_t *ok; double *cr, *cp; int *kidx;
+    const unsigned short *seq; const int *seq_len; int seq_stride;
+};
+
+__global__ __launch_bounds__(256) void fe_check_kernel(FeParams F, FeQuery Q, const uint8_t *__restrict__ occ, const unsigned *__restrict__ rows,
+                                                        const unsigned *__restrict__ bits) {
+    const int lane = threadIdx.x & 63;
+    const int q = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (q >= Q.n) return;
+    const int ix = Q.index[3 * q], iy = Q.index[3 * q + 1], iz = Q.index[3 * q + 2];
+    const double fr = Q.fr[q], fp = Q.fp[q];
+    const int fi = (int)((fr + Q.max_roll) / Q.ang_res), fj = (int)((fp + Q.max_pitch) / Q.ang_res);      // sw_manager.hpp:914-915
+    bool good = ix >= 0 && ix < F.X && iy >= 0 && iy < F.Y && iz >= 0 && iz < F.Z;                           // isIndexValid
+    good = good && fi >= 0 && fi < Q.xk && fj >= 0 && fj < Q.yk;                                             // the reference indexes visited[][] with these
+    if (good) good = occ[((size_t)ix * F.Y + iy) * F.Z + iz] != 1;                                           // !isIndexOccupiedFlate(vi, 0)
+    int found = -1;
+    if (good) {
+        // the tile's map bits: inflated voxel (ix + i, iy + j, iz .. iz + k - 1) for this lane's rows
+        const int kk = F.k * F.k;
+        const unsigned kmask = (F.k >= 32) ? 0xFFFFFFFFu : ((1u << F.k) - 1u);
+        unsigned mb[FE_MAX_ROWS_PER_LANE];
+        const int w0 = iz >> 5, sh = iz & 31;
+#pragma unroll
+        for (int r = 0; r < FE_MAX_ROWS_PER_LANE; r++) {
+            const int row = lane + (r << 6);
+            unsigned v = 0;
+            if (row < kk) {
+                const int i = row / F.k, j = row - i * F.k;
+                const unsigned *p = bits + ((size_t)(ix + i) * F.iY + (iy + j)) * F.iZW + w0;
+                const unsigned b0 = p[0], b1 = p[1];
+                v = (sh ? ((b0 >> sh) | (b1 << (32 - sh))) : b0) & kmask;
+            }
+            mb[r] = v;
+        }
+        const int start = fi * Q.yk + fj;
+        const unsigned short *seq = Q.seq + (size_t)start * Q.seq_stride;
+        const int len = Q.seq_len[start];
+        for (int t = 0; t < len; t++) {
+            const int att = seq[t];
+            const unsigned *rw = rows + (size_t)att * kk;
+            unsigned hit = 0;
+#pragma unroll
+            for (int r = 0; r < FE_MAX_ROWS_PER_LANE; r++) {
+                const int row = lane + (r << 6);
+                if (row < kk) hit |= rw[row] & mb[r];
+            }
+            if (!__ballot(hit != 0u)) { found = att; break; }
+        }
+    }
+    if (lane == 0) {
+        Q.ok[q] = found >= 0 ? 1 : 0;
+        if (found >= 0) {
+            const int ri = found / Q.yk, rj = found - ri * Q.yk;
+            Q.cr[q] = fr + (ri - fi) * Q.ang_res;                                                            // :931-932
+            Q.cp[q] = fp + (rj - fj) * Q.ang_res;
+        }
+        if (Q.kidx) Q.kidx[q] = found;
+    }
+}
+
+}  // namespace isdf
+
+using namespace isdf;
+
+namespace {
+
+// Eigen::AngleAxisd(rx, UnitX) * Eigen::AngleAxisd(ry, UnitY) -> Matrix3d (Shape.hpp:429): quaternion product, then
+// QuaternionBase::toRotationMatrix.  Row-major.
+void attitude_rotation(double rx, double ry, double *R) {
+    const double aw = std::cos(0.5 * rx), ax = std::sin(0.5 * rx);
+    const double bw = std::cos(0.5 * ry), by = std::sin(0.5 * ry);
+    const double w = aw * bw - ax * 0.0 - 0.0 * by - 0.0 * 0.0;
+    const double x = aw * 0.0 + ax * bw + 0.0 * 0.0 - 0.0 * by;
+    const double y = aw * by + 0.0 * bw + 0.0 * 0.0 - ax * 0.0;
+    const double z = aw * 0.0 + 0.0 * bw + ax * by - 0.0 * 0.0;
+    const double tx = 2.0 * x, ty = 2.0 * y, tz = 2.0 * z;
+    const double twx = tx * w, twy = ty * w, twz = tz * w;
+    const double txx = tx * x, txy = ty * x, txz = tz * x;
+    const double tyy = ty * y, tyz = tz * y, tzz = tz * z;
+    R[0] = 1.0 - (tyy + tzz); R[1] = txy - twz; R[2] = txz + twy;
+    R[3] = txy + twz; R[4] = 1.0 - (txx + tzz); R[5] = tyz - twx;
+    R[6] = txz - twy; R[7] = tyz + twx; R[8] = 1.0 - (txx + tyy);
+}
+
+// the order in which visit_kernels_by_distance (sw_manager.hpp:850-909) tests attitudes when the parent's is (sx, sy):
+// the level attitude first, then breadth-first from the parent (neighbours pushed as (0,+1) (0,-1) (+1,0) (-1,0)), the level
+// attitude skipped when it comes up again, at most maxdeepth + 1 = 801 queue pops
+void bfs_order(int xk, int yk, int sx, int sy, std::vector<unsigned short> &out) {
+    out.clear();
+    const int zi = (xk - 1) / 2, zj = (yk - 1) / 2;
+    out.push_back((unsigned short)(zi * yk + zj));
+    std::vector<char> visited((size_t)xk * yk, 0);
+    std::queue<std::pair<int, int>> q;
+    q.push({sx, sy});
+    visited[(size_t)sx * yk + sy] = 1;
+    const int dirs[4][2] = {{0, 1}, {0, -1}, {1, 0}, {-1, 0}};
+    int deep = 0;
+    while (!q.empty()) {
+        deep++;
+        const int x = q.front().first, y = q.front().second;
+        q.pop();
+        if (x != zi || y != zj) out.push_back((unsigned short)(x * yk + y));
+        for (const auto &d : dirs) {
+            const int nx = x + d[0], ny = y + d[1];
+            if (nx < 0 || nx >= xk || ny < 0 || ny >= yk || visited[(size_t)nx * yk + ny]) continue;
+            visited[(size_t)nx * yk + ny] = 1;
+            q.push({nx, ny});
+        }
+        if (deep > 800) break;
+    }
+}
+
+void fe_free(isdf_ctx *c) {
+    void *ptrs[] = {c->fe.d_rows, c->fe.d_bits, c->fe.d_rot, c->fe.d_seq, c->fe.d_seq_len};
+    for (void *p : ptrs) if (p) (void)hipFree(p);
+    c->fe = isdf_ctx::FrontEnd{};
+}
+
+FeParams fe_params(const isdf_ctx *c) {
+    FeParams F{};
+    F.k = c->fe.cfg.kernel_size; F.n_att = c->fe.xk * c->fe.yk; F.side = (F.k - 1) / 2;
+    F.res = c->grid.res; F.margin = c->fe.margin;
+    F.X = c->grid.X; F.Y = c->grid.Y; F.Z = c->grid.Z;
+    F.iX = F.X + 2 * F.side; F.iY = F.Y + 2 * F.side; F.iZW = (F.Z + 2 * F.side + 31) / 32 + 1;
+    return F;
+}
+
+}  // namespace
+
+void isdf_frontend_release(isdf_ctx *c) { fe_free(c); }
+
+extern "C" int isdf_frontend_build(isdf_ctx *c, const isdf_frontend_config *cfg) {
+    if (!c) return ISDF_ERR_INVALID_ARG;
+    if (!cfg) return isdf_fail(c, ISDF_ERR_INVALID_ARG, "null front-end config");
+    if (cfg->kernel_size < 1 || cfg->kernel_size > 31 || (cfg->kernel_size & 1) == 0) return isdf_fail(c, ISDF_ERR_INVALID_ARG, "kernel_size must be odd and <= 31");
+    if (!(cfg->kernel_ang_res > 0.0) || cfg->kernel_max_roll < 0.0 || cfg->kernel_max_pitch < 0.0) return isdf_fail(c, ISDF_ERR_INVALID_ARG, "bad attitude grid");
+    if (!c->have_shape) return isdf_fail(c, ISDF_ERR_STATE, "isdf_set_shape has not been called");
+    if (!c->have_geom || !c->d_occ) return isdf_fail(c, ISDF_ERR_STATE, "the front end needs an occupancy grid");
+    HIPCHK(c, hipSetDevice(c->device));
+    fe_free(c);
+    isdf_ctx::FrontEnd &fe = c->fe;
+    fe.cfg = *cfg;
+    fe.xk = (int)std::floor(2 * cfg->kernel_max_roll / cfg->kernel_ang_res) + 1;        // Shape.hpp:297-298
+    fe.yk = (int)std::floor(2 * cfg->kernel_max_pitch / cfg->kernel_ang_res) + 1;
+    if ((long long)fe.xk * fe.yk > 65535) return isdf_fail(c, ISDF_ERR_UNSUPPORTED, "more than 65535 attitudes");
+    fe.margin = std::max(cfg->front_end_safeh, c->grid.res / 2);                          // Shape.hpp:415
+    const int n_att = fe.xk * fe.yk;
+    // attitudes in the order of the reference's accumulating loops (:416-421); slots its loops never reach stay empty
+    std::vector<double> rot((size_t)n_att * 9, 0.0);
+    std::vector<char> reached((size_t)n_att, 0);
+    int i = 0;
+    for (double roll = -cfg->kernel_max_roll; roll <= cfg->kernel_max_roll; roll += cfg->kernel_ang_res, i++) {
+        int j = 0;
+        for (double pitch = -cfg->kernel_max_pitch; pitch <= cfg->kernel_max_pitch; pitch += cfg->kernel_ang_res, j++) {
+            if (i >= fe.xk || j >= fe.yk) continue;
+            attitude_rotation(roll * M_PI / 180.0, pitch * M_PI / 180.0, rot.data() + (size_t)(i * fe.yk + j) * 9);
+            reached[(size_t)i * fe.yk + j] = 1;
+        }
+    }
+    const FeParams F = fe_params(c);
+    HIPCHK(c, hipMalloc(&fe.d_rot, rot.size() * sizeof(double)));
+    HIPCHK(c, hipMemcpy(fe.d_rot, rot.data(), rot.size() * sizeof(double), hipMemcpyHostToDevice));
+    const size_t n_rows = (size_t)n_att * F.k * F.k;
+    HIPCHK(c, hipMalloc(&fe.d_rows, n_rows * sizeof(unsigned)));
+    {
+        const dim3 grid((unsigned)((n_rows + 255) / 256)), block(256);
+        if (c->shape.kind == ISDF_SHAPE_MESH) hipLaunchKernelGGL(fe_shape_rows_kernel<ISDF_SHAPE_MESH>, grid, block, 0, c->stream, c->shape, F, fe.d_rot, fe.d_rows);
+        else hipLaunchKernelGGL(fe_shape_rows_kernel<-1>, grid, block, 0, c->stream, c->shape, F, fe.d_rot, fe.d_rows);
+        HIPCHK(c, hipGetLastError());
+    }
+    // attitudes the reference's loops never initialise hold no voxels (an all-zero kernel never collides)
+    for (int a = 0; a < n_att; a++)
+        if (!reached[a]) HIPCHK(c, hipMemsetAsync(fe.d_rows + (size_t)a * F.k * F.k, 0, (size_t)F.k * F.k * sizeof(unsigned), c->stream));
+    const size_t n_bits = (size_t)F.iX * F.iY * F.iZW;
+    HIPCHK(c, hipMalloc(&fe.d_bits, (n_bits + 2) * sizeof(unsigned)));
+    HIPCHK(c, hipMemsetAsync(fe.d_bits + n_bits, 0, 2 * sizeof(unsigned), c->stream));
+    hipLaunchKernelGGL(fe_map_bits_kernel, dim3(2048), dim3(256), 0, c->stream, F, c->d_occ, fe.d_bits);
+    HIPCHK(c, hipGetLastError());
+    // breadth-first order tables
+    std::vector<std::vector<unsigned short>> orders(n_att);
+    size_t stride = 1;
+    for (int sx = 0; sx < fe.xk; sx++)
+        for (int sy = 0; sy < fe.yk; sy++) { bfs_order(fe.xk, fe.yk, sx, sy, orders[(size_t)sx * fe.yk + sy]); stride = std::max(stride, orders[(size_t)sx * fe.yk + sy].size()); }
+    std::vector<unsigned short> seq((size_t)n_att * stride, 0);
+    std::vector<int> seq_len(n_att);
+    for (int a = 0; a < n_att; a++) { std::copy(orders[a].begin(), orders[a].end(), seq.begin() + (size_t)a * stride); seq_len[a] = (int)orders[a].size(); }
+    fe.seq_stride = (int)stride;
+    HIPCHK(c, hipMalloc(&fe.d_seq, seq.size() * sizeof(unsigned short)));
+    HIPCHK(c, hipMalloc(&fe.d_seq_len, seq_len.size() * sizeof(int)));
+    HIPCHK(c, hipMemcpyAsync(fe.d_seq, seq.data(), seq.size() * sizeof(unsigned short), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(fe.d_seq_len, seq_len.data(), seq_len.size() * sizeof(int), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    fe.built = true;
+    return ISDF_OK;
+}
+
+extern "C" int isdf_frontend_get_shape_kernels(isdf_ctx *c, uint8_t *out, int dims_out[3]) {
+    if (!c) return ISDF_ERR_INVALID_ARG;
+    if (!c->fe.built) return isdf_fail(c, ISDF_ERR_STATE, "isdf_frontend_build has not been called");
+    const FeParams F = fe_params(c);
+    const int bl = (F.k + 7) / 8, per = F.k * F.k * bl;
+    if (dims_out) { dims_out[0] = c->fe.xk; dims_out[1] = c->fe.yk; dims_out[2] = per; }
+    if (!out) return ISDF_OK;
+    HIPCHK(c, hipSetDevice(c->device));
+    const size_t n = (size_t)F.n_att * per;
+    uint8_t *d = nullptr;
+    HIPCHK(c, hipMalloc(&d, n));
+    hipLaunchKernelGGL(fe_pack_shape_bytes_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, F, c->fe.d_rows, d);
+    hipError_t e = hipMemcpyAsync(out, d, n, hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    (void)hipFree(d);
+    HIPCHK(c, e);
+    return ISDF_OK;
+}
+
+extern "C" int isdf_frontend_get_map_kernel(isdf_ctx *c, uint8_t *out, int dims_out[3]) {
+    if (!c) return ISDF_ERR_INVALID_ARG;
+    if (!c->fe.built) return isdf_fail(c, ISDF_ERR_STATE, "isdf_frontend_build has not been called");
+    const FeParams F = fe_params(c);
+    const int zb = (F.Z + 2 * F.side + 7) / 8;
+    if (dims_out) { dims_out[0] = F.iX; dims_out[1] = F.iY; dims_out[2] = zb; }
+    if (!out) return ISDF_OK;
+    HIPCHK(c, hipSetDevice(c->device));
+    const size_t n = (size_t)F.iX * F.iY * zb;
+    uint8_t *d = nullptr;
+    HIPCHK(c, hipMalloc(&d, n));
+    hipLaunchKernelGGL(fe_pack_map_bytes_kernel, dim3(2048), dim3(256), 0, c->stream, F, c->fe.d_bits, d, zb);
+    hipError_t e = hipMemcpyAsync(out, d, n, hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    (void)hipFree(d);
+    HIPCHK(c, e);
+    return ISDF_OK;
+}
+
+extern "C" int isdf_frontend_check(isdf_ctx *c, int n, const int32_t *index, const double *father_roll, const double *father_pitch,
+                                   uint8_t *ok, double *child_roll, double *child_pitch, int32_t *kernel_index_out) {
+    if (!c) return ISDF_ERR_INVALID_ARG;
+    if (n < 0 || (n > 0 && (!index || !father_roll || !father_pitch || !ok || !child_roll || !child_pitch))) return isdf_fail(c, ISDF_ERR_INVALID_ARG, "bad front-end query");
+    if (!c->fe.built) return isdf_fail(c, ISDF_ERR_STATE, "isdf_frontend_build has not been called");
+    if (n == 0) return ISDF_OK;
+    HIPCHK(c, hipSetDevice(c->device));
+    const FeParams F = fe_params(c);
+    // one allocation: [index 3n int | fr n | fp n | cr n | cp n | kidx n int | ok n]
+    const size_t bytes = (size_t)n * (3 * 4 + 8 * 4 + 4 + 1) + 64;
+    char *d = nullptr;
+    HIPCHK(c, hipMalloc(&d, bytes));
+    double *d_fr = (double *)d, *d_fp = d_fr + n, *d_cr = d_fp + n, *d_cp = d_cr + n;
+    int *d_idx = (int *)(d_cp + n), *d_kidx = d_idx + (size_t)3 * n;
+    uint8_t *d_ok = (uint8_t *)(d_kidx + n);
+    int rc = ISDF_OK;
+    auto chk = [&](hipError_t e, const char *what) { if (e != hipSuccess && rc == ISDF_OK) { c->err = std::string(what) + ": " + hipGetErrorString(e); rc = ISDF_ERR_HIP; } };
+    chk(hipMemcpyAsync(d_idx, index, (size_t)3 * n * sizeof(int), hipMemcpyHostToDevice, c->stream), "upload index");
+    chk(hipMemcpyAsync(d_fr, father_roll, (size_t)n * sizeof(double), hipMemcpyHostToDevice, c->stream), "upload roll");
+    chk(hipMemcpyAsync(d_fp, father_pitch, (size_t)n * sizeof(double), hipMemcpyHostToDevice, c->stream), "upload pitch");
+    if (rc == ISDF_OK) {
+        FeQuery Q{};
+        Q.n = n; Q.xk = c->fe.xk; Q.yk = c->fe.yk;
+        Q.max_roll = c->fe.cfg.kernel_max_roll; Q.max_pitch = c->fe.cfg.kernel_max_pitch; Q.ang_res = c->fe.cfg.kernel_ang_res;
+        Q.index = d_idx; Q.fr = d_fr; Q.fp = d_fp; Q.ok = d_ok; Q.cr = d_cr; Q.cp = d_cp; Q.kidx = d_kidx;
+        Q.seq = c->fe.d_seq; Q.seq_len = c->fe.d_seq_len; Q.seq_stride = c->fe.seq_stride;
+        hipLaunchKernelGGL(fe_check_kernel, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, c->stream, F, Q, c->d_occ, c->fe.d_rows, c->fe.d_bits);
+        chk(hipGetLastError(), "fe_check_kernel");
+    }
+    if (rc == ISDF_OK) chk(hipMemcpyAsync(ok, d_ok, (size_t)n, hipMemcpyDeviceToHost, c->stream), "download ok");
+    if (rc == ISDF_OK) chk(hipMemcpyAsync(child_roll, d_cr, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, c->stream), "download roll");
+    if (rc == ISDF_OK) chk(hipMemcpyAsync(child_pitch, d_cp, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, c->stream), "download pitch");
+    if (rc == ISDF_OK && kernel_index_out) chk(hipMemcpyAsync(kernel_index_out, d_kidx, (size_t)n * sizeof(int), hipMemcpyDeviceToHost, c->stream), "download index");
+    chk(hipStreamSynchronize(c->stream), "front-end sync");
+    (void)hipFree(d);
+    return rc;
+}

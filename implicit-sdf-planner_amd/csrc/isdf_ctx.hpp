@@ -64,7 +64,14 @@ struct isdf_ctx {
     double *d_cb = nullptr; size_t cb_cap = 0;        // device twin of the staging buffer
     double last_parts[4] = {0, 0, 0, 0};
     std::vector<double> cb_x; double cb_energy = 0.0; int cb_n_out = 1; bool cb_pending = false;
+    // front end (csrc/frontend.hip): attitude kernels of the robot, inflated bit-packed occupancy, breadth-first order tables
+    struct FrontEnd {
+        isdf_frontend_config cfg{}; int xk = 0, yk = 0; double margin = 0.0; bool built = false;
+        unsigned *d_rows = nullptr, *d_bits = nullptr; double *d_rot = nullptr;
+        unsigned short *d_seq = nullptr; int *d_seq_len = nullptr; int seq_stride = 0;
+    } fe;
 };
+void isdf_frontend_release(isdf_ctx *c);      // frontend.hip: frees the tables (isdf_destroy)
 
 #define HIPCHK(ctx, call)                                                                          \
     do {                                                                                           \

@@ -154,6 +154,7 @@ extern "C" int isdf_destroy(isdf_ctx *c) {
     (void)hipDeviceSynchronize();
     for (auto &p : c->prof_events) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); (void)hipEventDestroy(p.c); (void)hipEventDestroy(p.d); }
     if (c->h_pin) (void)hipHostFree(c->h_pin);
+    isdf_frontend_release(c);
     void *ptrs[] = {c->d_tail_ticket, c->d_cb, c->d_esdf, c->d_occ, c->d_points, c->d_tstar, c->d_acc, c->d_sample_info, c->d_bits, c->d_piece_cost, c->d_in, c->d_out, c->d_stats,
                     c->d_traj_duration, c->d_coarse_t, c->d_coarse_pose, c->d_n_coarse, c->d_point_partial, c->d_point_piece, c->d_hist, c->d_dbg};
     for (void *p : ptrs) if (p) (void)hipFree(p);
@@ -173,6 +174,7 @@ extern "C" int isdf_set_grid(isdf_ctx *c, const void *vox, int dtype, int nx, in
     if (dtype < ISDF_U8 || dtype > ISDF_F64) return fail(c, ISDF_ERR_INVALID_ARG, "bad dtype");
     if (kind != ISDF_GRID_OCCUPANCY && kind != ISDF_GRID_ESDF) return fail(c, ISDF_ERR_INVALID_ARG, "bad grid kind");
     HIPCHK(c, hipSetDevice(c->device));
+    isdf_frontend_release(c);       // the inflated bit-packed map was built from the previous grid
     const size_t n = (size_t)nx * ny * nz;
     if (c->have_geom && (c->grid.X != nx || c->grid.Y != ny || c->grid.Z != nz)) {
         // new geometry: drop the other grid kind, it no longer matches
@@ -300,6 +302,7 @@ extern "C" int isdf_set_shape(isdf_ctx *c, const isdf_shape *s) {
         HIPCHK(c, hipMemcpy(c->d_mesh, &hm, sizeof(hm), hipMemcpyHostToDevice));
         d.mesh = c->d_mesh;
     }
+    isdf_frontend_release(c);       // the attitude kernels were voxelised from the previous shape
     c->shape = d;
     c->shape_host = *s;
     c->shape_host.mesh_vertices = nullptr;

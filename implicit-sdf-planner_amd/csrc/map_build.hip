@@ -217,6 +217,7 @@ extern "C" int isdf_set_pointcloud(isdf_ctx *c, const float *xyz, long long n_po
     }
     const size_t n = (size_t)dim[0] * dim[1] * dim[2];
     if (c->d_esdf) { (void)hipFree(c->d_esdf); c->d_esdf = nullptr; }
+    isdf_frontend_release(c);
     if (c->d_occ) { (void)hipFree(c->d_occ); c->d_occ = nullptr; }
     c->grid.X = (int)dim[0]; c->grid.Y = (int)dim[1]; c->grid.Z = (int)dim[2]; c->grid.res = resolution;
     for (int a = 0; a < 3; a++) { c->grid.bmin[a] = bmin[a]; c->grid.bmax[a] = bmax[a]; }

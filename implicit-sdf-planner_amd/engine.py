@@ -156,6 +156,38 @@ class Engine:
         self._check(self.lib.isdf_shape_eval(self.h, _p(p_rel), n, _p(sdf), _p(grad) if want_grad else None))
         return sdf, grad
 
+    # ---- front end: pose feasibility by kernel convolution (SweptVolumeManager::checkKernelValue)
+    def frontend_build(self, fe_cfg):
+        self._fe_cfg = fe_cfg
+        self._check(self.lib.isdf_frontend_build(self.h, C.byref(fe_cfg)))
+
+    def frontend_shape_kernels(self):
+        """ByteShapeKernel::map of every attitude (reference byte layout): uint8 [xk * yk, k * k * ceil(k / 8)]."""
+        d = (C.c_int * 3)()
+        self._check(self.lib.isdf_frontend_get_shape_kernels(self.h, None, d))
+        out = np.zeros((d[0] * d[1], d[2]), dtype=np.uint8)
+        self._check(self.lib.isdf_frontend_get_shape_kernels(self.h, out.ctypes.data_as(C.c_void_p), d))
+        return out
+
+    def frontend_map_kernel(self):
+        """The array generateMapKernel produces (reference byte layout): uint8 [X + 2h, Y + 2h, ceil((Z + 2h) / 8)]."""
+        d = (C.c_int * 3)()
+        self._check(self.lib.isdf_frontend_get_map_kernel(self.h, None, d))
+        out = np.zeros((d[0], d[1], d[2]), dtype=np.uint8)
+        self._check(self.lib.isdf_frontend_get_map_kernel(self.h, out.ctypes.data_as(C.c_void_p), d))
+        return out
+
+    def frontend_check(self, index, father_roll, father_pitch):
+        """(ok[n] uint8, child_roll[n], child_pitch[n], kernel_index[n]) of AstarGetSucc's per-neighbour test."""
+        index = np.ascontiguousarray(index, dtype=np.int32).reshape(-1, 3)
+        n = index.shape[0]
+        fr = np.ascontiguousarray(np.broadcast_to(father_roll, (n,)), dtype=np.float64)
+        fp = np.ascontiguousarray(np.broadcast_to(father_pitch, (n,)), dtype=np.float64)
+        ok = np.zeros(n, dtype=np.uint8); cr = np.zeros(n); cp = np.zeros(n); ki = np.zeros(n, dtype=np.int32)
+        self._check(self.lib.isdf_frontend_check(self.h, n, index.ctypes.data_as(C.c_void_p), _p(fr), _p(fp), ok.ctypes.data_as(C.c_void_p),
+                                                 _p(cr), _p(cp), ki.ctypes.data_as(C.c_void_p)))
+        return ok, cr, cp, ki
+
     def set_shard(self, rank, world):
         self._check(self.lib.isdf_set_shard(self.h, rank, world))
 

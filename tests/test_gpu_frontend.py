@@ -1,0 +1,99 @@
+"""Front end on the device (pose feasibility by kernel convolution) against the oracle, whose restatement is
+pinned byte for byte against the reference's own code (tests/test_oracle_ref.py): integer / bit work => bit-exact."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _pair(pkg, orc, shape, occ, res, fe):
+    capi, synth = pkg.capi, pkg.synth
+    cfg = synth.default_config(capi.V1_SWEPT)
+    eng = pkg.Engine(cfg); o = orc.Oracle(cfg, threads=16)
+    for t in (eng, o):
+        t.set_grid(occ, (0, 0, 0), res, capi.GRID_OCCUPANCY)
+        t.set_shape(shape)
+        t.frontend_build(fe)
+    return eng, o
+
+
+def _queries(occ, rng, n, xk=11):
+    X, Y, Z = occ.shape
+    idx = np.stack([rng.integers(-1, X + 1, n), rng.integers(-1, Y + 1, n), rng.integers(-1, Z + 1, n)], axis=1).astype(np.int32)   # incl. invalid and occupied voxels
+    fr = rng.choice(np.arange(-45.0, 45.1, 9.0), n)
+    fp = rng.choice(np.arange(-45.0, 45.1, 9.0), n)
+    off = rng.random(n) < 0.3                       # parents whose attitude is not on the grid (the reference truncates)
+    fr = np.clip(fr + off * rng.uniform(0.0, 8.9, n), -45.0, 45.0)
+    return idx, fr, fp
+
+
+@pytest.mark.parametrize("name", ["Box", "RoundedCone", "Torus_big", "BendLinear_big", "SmoothIntersection_big", "Trefoil", "CSG", "Table",
+                                  "Cappedtorus", "WireframeBox", "TwistBox", "Ball", "mesh"])
+def test_frontend_matches_oracle_bit_for_bit(pkg, orc, product_lib, name):
+    capi, synth = pkg.capi, pkg.synth
+    res = 0.5
+    occ = synth.random_box_map((40, 36, 20), res=res, occupancy=0.10, seed=5, edge=(0.5, 2.0))
+    if name == "mesh":
+        V, F = synth.l_prism_mesh()
+        shape = synth.make_mesh_shape(V * 1.5, F)
+    elif name == "Box":
+        shape = synth.make_shape("Box", params=(0.9, 0.35, 0.25), poly_params=(0.05, -0.1, 0.02, 12, -8, 25))
+    elif name == "Ball":
+        shape = synth.make_shape("Ball", params=(0.8,))
+    else:
+        shape = synth.make_shape(name, poly_params=(0.05, -0.1, 0.02, 12, -8, 25))
+    k = 13 if name in ("Box", "RoundedCone", "Ball", "mesh") else 15
+    fe = capi.frontend_config(kernel_size=k, max_roll=45.0, max_pitch=45.0, ang_res=9.0, safeh=0.0)
+    eng, o = _pair(pkg, orc, shape, occ, res, fe)
+    if name == "mesh" and o.mesh_backend() != 1:
+        pytest.skip("oracle/_ref/libref_fwn.so not built")
+    sk, sk0 = eng.frontend_shape_kernels(), o.frontend_shape_kernels()
+    assert sk0.any() and sk.shape == sk0.shape == (121, k * k * ((k + 7) // 8))
+    nbad = int((np.unpackbits(sk ^ sk0)).sum())
+    # transcendental shapes: device and host sin/cos/atan2 may differ in the last ulp, which can only matter for a voxel whose
+    # SDF is within 1e-15 of the margin - none observed; the polynomial / sqrt-only shapes must be exact by construction
+    assert nbad == 0, (name, nbad)
+    assert np.array_equal(eng.frontend_map_kernel(), o.frontend_map_kernel())
+    rng = np.random.default_rng(9)
+    idx, fr, fp = _queries(occ, rng, 20000)
+    ok, cr, cp, ki = eng.frontend_check(idx, fr, fp)
+    ok0, cr0, cp0, ki0 = o.frontend_check(idx, fr, fp)
+    assert np.array_equal(ok, ok0) and np.array_equal(ki, ki0)
+    m = ok0 == 1
+    assert 0 < m.sum() < len(m)
+    assert np.array_equal(cr[m], cr0[m]) and np.array_equal(cp[m], cp0[m])
+    # not every accepted query is the level attitude: the breadth-first search is exercised
+    assert name == "Ball" or (ki0[m] != 60).any()      # (a ball looks the same at every attitude)
+
+
+def test_frontend_axis_aligned_box_on_the_margin(pkg, orc, product_lib):
+    """A box whose faces sit exactly half a voxel from voxel centres at the level attitude (sdf == margin up to rounding):
+    the comparison sdf <= margin must round like the reference's - the reason frontend.hip is built without FMA contraction."""
+    capi, synth = pkg.capi, pkg.synth
+    res = 0.2
+    occ = synth.random_box_map((32, 32, 32), res=res, occupancy=0.12, seed=8, edge=(0.4, 1.6))
+    shape = synth.make_shape("Box", params=(0.9, 0.3, 0.3))            # identity body offset; 0.3 + res / 2 = 0.4 = 2 voxels
+    fe = capi.frontend_config(kernel_size=21, max_roll=45.0, max_pitch=45.0, ang_res=9.0, safeh=0.0)
+    eng, o = _pair(pkg, orc, shape, occ, res, fe)
+    assert np.array_equal(eng.frontend_shape_kernels(), o.frontend_shape_kernels())
+    rng = np.random.default_rng(1)
+    idx, fr, fp = _queries(occ, rng, 5000)
+    a, b = eng.frontend_check(idx, fr, fp), o.frontend_check(idx, fr, fp)
+    assert np.array_equal(a[0], b[0]) and np.array_equal(a[3], b[3])
+
+
+def test_frontend_needs_build_and_tracks_state(pkg, product_lib):
+    capi, synth = pkg.capi, pkg.synth
+    eng = pkg.Engine(synth.default_config(capi.V1_SWEPT))
+    with pytest.raises(Exception):
+        eng.frontend_check(np.zeros((1, 3), dtype=np.int32), 0.0, 0.0)
+    occ = synth.random_box_map((16, 16, 16), res=0.5, occupancy=0.1, seed=2, edge=(0.5, 1.0))
+    eng.set_grid(occ, (0, 0, 0), 0.5, capi.GRID_OCCUPANCY)
+    eng.set_shape(synth.make_shape("Box", params=(0.5, 0.3, 0.2)))
+    with pytest.raises(Exception):
+        eng.frontend_build(capi.frontend_config(kernel_size=12))       # even
+    eng.frontend_build(capi.frontend_config(kernel_size=9))
+    eng.frontend_check(np.array([[8, 8, 8]], dtype=np.int32), 0.0, 0.0)
+    eng.set_shape(synth.make_shape("Box", params=(0.6, 0.3, 0.2)))      # tables are stale now
+    with pytest.raises(Exception):
+        eng.frontend_check(np.array([[8, 8, 8]], dtype=np.int32), 0.0, 0.0)
