@@ -89,7 +89,7 @@ EXPORTED_SYMBOLS = [
     "isdf_cost_function_launch", "isdf_cost_function_finish",
     "isdf_lbfgs_params_default", "isdf_lbfgs_minimize", "isdf_optimize_lbfgs", "isdf_optimize_lbfgs_batch",
     "isdf_set_pointcloud", "isdf_generate_esdf", "isdf_get_grid", "isdf_gather_points", "isdf_get_points", "isdf_shape_eval",
-    "isdf_frontend_build", "isdf_frontend_get_shape_kernels", "isdf_frontend_get_map_kernel", "isdf_frontend_check",
+    "isdf_frontend_build", "isdf_frontend_get_shape_kernels", "isdf_frontend_get_map_kernel", "isdf_frontend_check", "isdf_frontend_cspace",
 ]
 
 _lib = None
@@ -147,6 +147,7 @@ def load_library(path=None):
     lib.isdf_frontend_build.argtypes = [C.c_void_p, C.POINTER(IsdfFrontendConfig)]
     lib.isdf_frontend_get_shape_kernels.argtypes = [C.c_void_p, C.c_void_p, ip]
     lib.isdf_frontend_get_map_kernel.argtypes = [C.c_void_p, C.c_void_p, ip]
+    lib.isdf_frontend_cspace.argtypes = [C.c_void_p, C.c_void_p, dp]
     lib.isdf_frontend_check.argtypes = [C.c_void_p, C.c_int, C.c_void_p, dp, dp, C.c_void_p, dp, dp, C.c_void_p]
     lib.isdf_lbfgs_params_default.argtypes = [C.POINTER(IsdfLbfgsParams)]
     lib.isdf_lbfgs_params_default.restype = None

@@ -14,6 +14,7 @@
 // the grid put voxel centres exactly ON that margin - the comparison must see the reference's roundings.
 #include "isdf_ctx.hpp"
 #include "dev_mesh.hpp"
+#include <hip/hip_ext.h>
 #include <cmath>
 #include <queue>
 #include <vector>
@@ -152,6 +153,48 @@ __global__ __launch_bounds__(256) void fe_check_kernel(FeParams F, FeQuery Q, co
     }
 }
 
+// Whole configuration space at once: for every voxel of the map, which attitudes fit (kernelConv<true> for all of them).
+// One lane per voxel, 64 consecutive z per wavefront, so neighbouring lanes read the same map dwords; the robot's rows are
+// wave-uniform (scalar loads) and only the NON-EMPTY rows of an attitude are visited (host-built lists: the robot fills a
+// small part of its k^3 box).  Output: 4 dwords per voxel, bit a = attitude a is collision-free; occupied voxels get 0
+// (AstarGetSucc never asks about them).
+struct FeRow { unsigned off, word; };      // off = (i * iY + j) * iZW: where the tile row starts relative to the voxel's own row
+
+__global__ __launch_bounds__(256) void fe_cspace_kernel(FeParams F, const uint8_t *__restrict__ occ, const unsigned *__restrict__ bits,
+                                                         const FeRow *__restrict__ rows, const int *__restrict__ row_ptr, uint4 *__restrict__ out) {
+    const int zblocks = (F.Z + 63) >> 6;
+    const long long wv = (long long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const long long n_wv = (long long)F.X * F.Y * zblocks;
+    if (wv >= n_wv) return;
+    const int lane = threadIdx.x & 63;
+    const int zb = (int)(wv % zblocks);
+    const long long xy = wv / zblocks;
+    const int y = (int)(xy % F.Y), x = (int)(xy / F.Y);
+    const int z = (zb << 6) + lane;
+    const bool valid = z < F.Z;
+    const int zc = valid ? z : F.Z - 1;
+    const bool is_occ = occ[((size_t)x * F.Y + y) * F.Z + zc] == 1;
+    const unsigned *base = bits + ((size_t)x * F.iY + y) * F.iZW + (zc >> 5);
+    const int sh = zc & 31;
+    const unsigned kmask = (F.k >= 32) ? 0xFFFFFFFFu : ((1u << F.k) - 1u);
+    unsigned m[4] = {0u, 0u, 0u, 0u};
+    const bool work = valid && !is_occ;
+    for (int a = 0; a < F.n_att; a++) {
+        const int r0 = row_ptr[a], r1 = row_ptr[a + 1];
+        unsigned hit = work ? 0u : 1u;
+        for (int r = r0; r < r1; r++) {
+            if ((r & 7) == 0 && __ballot(hit == 0u) == 0ull) break;          // every lane has already collided (or has no work)
+            const FeRow e = rows[r];                                           // wave-uniform
+            const unsigned *p = base + e.off;
+            const unsigned b0 = p[0], b1 = p[1];
+            const unsigned mb = (sh ? ((b0 >> sh) | (b1 << (32 - sh))) : b0) & kmask;
+            hit |= mb & e.word;
+        }
+        if (hit == 0u) m[a >> 5] |= 1u << (a & 31);
+    }
+    if (valid) out[((size_t)x * F.Y + y) * F.Z + z] = make_uint4(m[0], m[1], m[2], m[3]);
+}
+
 }  // namespace isdf
 
 using namespace isdf;
@@ -205,7 +248,7 @@ void bfs_order(int xk, int yk, int sx, int sy, std::vector<unsigned short> &out)
 }
 
 void fe_free(isdf_ctx *c) {
-    void *ptrs[] = {c->fe.d_rows, c->fe.d_bits, c->fe.d_rot, c->fe.d_seq, c->fe.d_seq_len};
+    void *ptrs[] = {c->fe.d_rows, c->fe.d_bits, c->fe.d_rot, c->fe.d_seq, c->fe.d_seq_len, c->fe.d_row_list, c->fe.d_row_ptr, c->fe.d_cspace};
     for (void *p : ptrs) if (p) (void)hipFree(p);
     c->fe = isdf_ctx::FrontEnd{};
 }
@@ -284,7 +327,51 @@ extern "C" int isdf_frontend_build(isdf_ctx *c, const isdf_frontend_config *cfg)
     HIPCHK(c, hipMemcpyAsync(fe.d_seq, seq.data(), seq.size() * sizeof(unsigned short), hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, hipMemcpyAsync(fe.d_seq_len, seq_len.data(), seq_len.size() * sizeof(int), hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
+    // non-empty rows of every attitude (for the whole-map pass)
+    {
+        std::vector<unsigned> rows_h(n_rows);
+        HIPCHK(c, hipMemcpy(rows_h.data(), fe.d_rows, n_rows * sizeof(unsigned), hipMemcpyDeviceToHost));
+        std::vector<FeRow> list;
+        std::vector<int> ptr(n_att + 1, 0);
+        for (int a = 0; a < n_att; a++) {
+            for (int ii = 0; ii < F.k; ii++)
+                for (int jj = 0; jj < F.k; jj++) {
+                    const unsigned w = rows_h[((size_t)a * F.k + ii) * F.k + jj];
+                    if (w) list.push_back(FeRow{(unsigned)(((size_t)ii * F.iY + jj) * F.iZW), w});
+                }
+            ptr[a + 1] = (int)list.size();
+        }
+        fe.n_row_list = (int)list.size();
+        HIPCHK(c, hipMalloc(&fe.d_row_list, std::max<size_t>(1, list.size()) * sizeof(FeRow)));
+        HIPCHK(c, hipMalloc(&fe.d_row_ptr, ptr.size() * sizeof(int)));
+        if (!list.empty()) HIPCHK(c, hipMemcpy(fe.d_row_list, list.data(), list.size() * sizeof(FeRow), hipMemcpyHostToDevice));
+        HIPCHK(c, hipMemcpy(fe.d_row_ptr, ptr.data(), ptr.size() * sizeof(int), hipMemcpyHostToDevice));
+    }
     fe.built = true;
+    return ISDF_OK;
+}
+
+extern "C" int isdf_frontend_cspace(isdf_ctx *c, uint32_t *free_mask_out, double *kernel_ms_out) {
+    if (!c) return ISDF_ERR_INVALID_ARG;
+    if (!c->fe.built) return isdf_fail(c, ISDF_ERR_STATE, "isdf_frontend_build has not been called");
+    const FeParams F = fe_params(c);
+    if (F.n_att > 128) return isdf_fail(c, ISDF_ERR_UNSUPPORTED, "the whole-map pass packs at most 128 attitudes per voxel");
+    HIPCHK(c, hipSetDevice(c->device));
+    const size_t n = (size_t)F.X * F.Y * F.Z;
+    if (!c->fe.d_cspace) HIPCHK(c, hipMalloc(&c->fe.d_cspace, n * 4 * sizeof(unsigned)));
+    hipEvent_t e0, e1;
+    HIPCHK(c, hipEventCreate(&e0)); HIPCHK(c, hipEventCreate(&e1));
+    const long long n_wv = (long long)F.X * F.Y * ((F.Z + 63) >> 6);
+    hipExtLaunchKernelGGL(fe_cspace_kernel, dim3((unsigned)((n_wv + 3) / 4)), dim3(256), 0, c->stream, e0, e1, 0, F, c->d_occ, c->fe.d_bits,
+                          (const FeRow *)c->fe.d_row_list, c->fe.d_row_ptr, (uint4 *)c->fe.d_cspace);
+    hipError_t e = hipGetLastError();
+    if (e == hipSuccess && free_mask_out) e = hipMemcpyAsync(free_mask_out, c->fe.d_cspace, n * 4 * sizeof(unsigned), hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    float ms = 0.f;
+    if (e == hipSuccess) e = hipEventElapsedTime(&ms, e0, e1);
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    HIPCHK(c, e);
+    if (kernel_ms_out) *kernel_ms_out = ms;
     return ISDF_OK;
 }
 

@@ -69,6 +69,8 @@ struct isdf_ctx {
         isdf_frontend_config cfg{}; int xk = 0, yk = 0; double margin = 0.0; bool built = false;
         unsigned *d_rows = nullptr, *d_bits = nullptr; double *d_rot = nullptr;
         unsigned short *d_seq = nullptr; int *d_seq_len = nullptr; int seq_stride = 0;
+        void *d_row_list = nullptr; int *d_row_ptr = nullptr; int n_row_list = 0;      // non-empty rows per attitude
+        unsigned *d_cspace = nullptr;                                                    // 4 dwords per voxel
     } fe;
 };
 void isdf_frontend_release(isdf_ctx *c);      // frontend.hip: frees the tables (isdf_destroy)

@@ -304,6 +304,13 @@ int isdf_frontend_get_map_kernel(isdf_ctx *ctx, uint8_t *out, int dims_out[3]);
 int isdf_frontend_check(isdf_ctx *ctx, int n, const int32_t *index, const double *father_roll, const double *father_pitch,
                         uint8_t *ok, double *child_roll, double *child_pitch, int32_t *kernel_index_out);
 
+/* The whole configuration space in one pass: for EVERY voxel of the map, which attitudes are collision-free
+ * (kernelConv<true>(i, j, voxel), sw_manager.hpp:813-847, for all i, j).  free_mask_out (may be NULL: the table then only
+ * stays on the device): 4 dwords per voxel in the grid's own order (z fastest), bit (i * ykernel + j) set = that attitude
+ * fits; occupied voxels get 0.  At most 128 attitudes.  An A* that holds this table answers checkKernelValue with a few
+ * bit tests in the breadth-first order instead of k^2 byte-ANDs per attitude.  kernel_ms_out (optional): device time. */
+int isdf_frontend_cspace(isdf_ctx *ctx, uint32_t *free_mask_out, double *kernel_ms_out);
+
 /* ---- instrumentation --------------------------------------------------------------------------------------- */
 /* on = N > 0: every N-th isdf_eval_device attaches HIP start/stop events to the dispatch of its dominant kernel on
  * `stream` (hipExtLaunchKernel: the kernel's own begin/end timestamps, the interval rocprofv3 reports);

@@ -106,6 +106,12 @@ class Oracle:
                                     _p(cr), _p(cp), ki.ctypes.data_as(C.c_void_p))
         return ok, cr, cp, ki
 
+    def frontend_cspace(self, grid_shape):
+        """uint32 [X, Y, Z, 4]: bit (i * yk + j) of a voxel's mask = kernelConv(i, j, voxel); occupied voxels 0."""
+        out = np.zeros(tuple(grid_shape) + (4,), dtype=np.uint32)
+        self.lib.orc_frontend_cspace(self.h, out.ctypes.data_as(C.c_void_p))
+        return out
+
     def mesh_backend(self):
         """1: the mesh winding number comes from the vendored HDK library (oracle/_ref/libref_fwn.so); 0: exact-sum fallback."""
         return int(self.lib.orc_mesh_backend(self.h))

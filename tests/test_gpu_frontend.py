@@ -97,3 +97,39 @@ def test_frontend_needs_build_and_tracks_state(pkg, product_lib):
     eng.set_shape(synth.make_shape("Box", params=(0.6, 0.3, 0.2)))      # tables are stale now
     with pytest.raises(Exception):
         eng.frontend_check(np.array([[8, 8, 8]], dtype=np.int32), 0.0, 0.0)
+
+
+@pytest.mark.parametrize("name", ["Box", "Torus_big", "mesh"])
+def test_whole_configuration_space_matches_kernel_conv(pkg, orc, product_lib, name):
+    """isdf_frontend_cspace: every voxel x every attitude in one pass == the oracle's kernelConv per (voxel, attitude), and the
+    batched checkKernelValue answers are reproduced from the table with the breadth-first order."""
+    capi, synth = pkg.capi, pkg.synth
+    res = 0.5
+    occ = synth.random_box_map((40, 36, 70), res=res, occupancy=0.10, seed=6, edge=(0.5, 2.0))      # Z > 64: two z-blocks per column
+    if name == "mesh":
+        V, F = synth.l_prism_mesh()
+        shape = synth.make_mesh_shape(V * 1.5, F)
+    elif name == "Box":
+        shape = synth.make_shape("Box", params=(0.9, 0.35, 0.25), poly_params=(0.05, -0.1, 0.02, 12, -8, 25))
+    else:
+        shape = synth.make_shape(name, poly_params=(0.05, -0.1, 0.02, 12, -8, 25))
+    fe = capi.frontend_config(kernel_size=13 if name != "Torus_big" else 15)
+    eng, o = _pair(pkg, orc, shape, occ, res, fe)
+    if name == "mesh" and o.mesh_backend() != 1:
+        pytest.skip("oracle/_ref/libref_fwn.so not built")
+    table, ms = eng.frontend_cspace()
+    ref = o.frontend_cspace(occ.shape)
+    assert table.shape == ref.shape and np.array_equal(table, ref)
+    assert ref.any() and (ref[occ == 1] == 0).all()
+    # checkKernelValue from the table: first attitude of the breadth-first order whose bit is set
+    rng = np.random.default_rng(4)
+    idx, fr, fp = _queries(occ, rng, 3000)
+    ok, cr, cp, ki = eng.frontend_check(idx, fr, fp)
+    X, Y, Z = occ.shape
+    inside = (idx >= 0).all(axis=1) & (idx[:, 0] < X) & (idx[:, 1] < Y) & (idx[:, 2] < Z)
+    for q in np.flatnonzero(inside)[:1500]:
+        m = table[idx[q, 0], idx[q, 1], idx[q, 2]]
+        bit = lambda a: (int(m[a >> 5]) >> (a & 31)) & 1
+        assert (ok[q] == 1) == any(bit(a) for a in range(121))      # some attitude fits <=> the search succeeds (it visits all 121)
+        if ok[q]:
+            assert bit(int(ki[q]))

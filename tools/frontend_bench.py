@@ -30,3 +30,7 @@ for name, shape, k in (("box 3.2x0.6x0.6 m", synth.bench_box_shape(), 21), ("rou
     same = np.array_equal(ok[:m], ok0) and np.array_equal(ki[:m], ki0)
     print(f"{name:20s} k={k} 11x11 attitudes, 256^3 map: build device {tb*1e3:7.1f} ms | oracle {tbo*1e3:8.1f} ms || check device {n/td:10.4g} queries/s (host in/out) | "
           f"oracle 30 threads {m/tc:10.4g} queries/s | x{(n/td)/(m/tc):6.1f} | feasible {ok.mean():.3f}, level attitude {np.mean(ki[ok==1]==60):.3f} | identical: {same}", flush=True)
+    tab, ms = eng.frontend_cspace(download=False)
+    t0 = time.perf_counter(); tab, ms2 = eng.frontend_cspace(download=True); tdl = time.perf_counter() - t0
+    print(f"{'':20s} whole configuration space (256^3 voxels x 121 attitudes = {256**3*121:.3g} kernelConv): kernel {ms:8.2f} ms (= {256**3*121/ms*1e3:.3g} conv/s), "
+          f"with download of the 268 MB table {tdl*1e3:8.1f} ms; free voxel-attitudes {np.unpackbits(tab.view(np.uint8)).sum() / (256**3 * 121):.3f}", flush=True)
