@@ -28,6 +28,7 @@ template <typename T> struct ShapeP {
     T trans[3];
     T rot[9];
     T csg_r2[9], csg_r3[9];   // rotate_to(c, X, Y) and rotate_to(c, X, Z) matrices, built on the host
+    int ident;                // 1: trans == 0 and rot == I exactly (poly_params all zero, the shipped configs): the body offset is a no-op
 };
 
 struct DevShape {
@@ -187,6 +188,7 @@ __device__ __forceinline__ T analytic_local(const ShapeP<T> &S, int kind_rt, v3<
 }
 // (pos_rel - trans) * Rotate: the body offset every analytic class applies first (e.g. Shape.hpp:843)
 template <typename T> __device__ __forceinline__ v3<T> body_offset(const ShapeP<T> &S, v3<T> pr) {
+    if (S.ident) return pr;               // wave-uniform; (p - 0) * I == p bit for bit (finite p)
     const T dx = pr.x - S.trans[0], dy = pr.y - S.trans[1], dz = pr.z - S.trans[2];
     const T *R = S.rot;
     return mkv<T>(dx * R[0] + dy * R[3] + dz * R[6], dx * R[1] + dy * R[4] + dz * R[7], dx * R[2] + dy * R[5] + dz * R[8]);

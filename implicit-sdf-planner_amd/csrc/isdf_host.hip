@@ -257,6 +257,11 @@ extern "C" int isdf_set_shape(isdf_ctx *c, const isdf_shape *s) {
     csg_rotate_to(X, Z, d.d.csg_r3);
     for (int i = 0; i < 16; i++) d.f.p[i] = (float)d.d.p[i];
     for (int i = 0; i < 3; i++) d.f.trans[i] = (float)d.d.trans[i];
+    {
+        bool ident = d.d.trans[0] == 0.0 && d.d.trans[1] == 0.0 && d.d.trans[2] == 0.0;
+        for (int i = 0; i < 9; i++) ident = ident && d.d.rot[i] == ((i % 4 == 0) ? 1.0 : 0.0);
+        d.d.ident = d.f.ident = ident ? 1 : 0;
+    }
     for (int i = 0; i < 9; i++) { d.f.rot[i] = (float)d.d.rot[i]; d.f.csg_r2[i] = (float)d.d.csg_r2[i]; d.f.csg_r3[i] = (float)d.d.csg_r3[i]; }
     double bb_c[3] = {s->bbox_center[0], s->bbox_center[1], s->bbox_center[2]}, bb_h[3] = {s->bbox_half[0], s->bbox_half[1], s->bbox_half[2]};
     if (s->kind == ISDF_SHAPE_MESH && s->mesh_vertices && s->n_vertices > 0 && !(bb_h[0] > 0 && bb_h[1] > 0 && bb_h[2] > 0)) {

@@ -142,8 +142,10 @@ __device__ __forceinline__ float unif(float v) { return __int_as_float(__builtin
 // winding number (|w error| up to a few 1e-3 outside, Shape.cpp:110), so its penalty band is widened by 5 % for pruning.
 __device__ __forceinline__ double mesh_band_scale(int kind) { return kind == ISDF_SHAPE_MESH ? 1.05 : 1.0; }
 
+// Box and RoundedCone fit 128 VGPRs (4 waves per SIMD), which is worth ~10 % when the device is full (C3); the generic and
+// mesh instantiations need more and are held to 3 waves.
 template <int KIND>
-__global__ __launch_bounds__(64 * SW_SAMPLES, 3) void sweep_kernel(const SweepParams P) {
+__global__ __launch_bounds__(64 * SW_SAMPLES, (KIND == ISDF_SHAPE_BOX || KIND == ISDF_SHAPE_ROUNDEDCONE) ? 4 : 3) void sweep_kernel(const SweepParams P) {
     __shared__ SweepPose s_pose[SW_SAMPLES];
     __shared__ unsigned s_list[SW_SAMPLES][SW_LIST_CAP];          // ring of compacted voxels awaiting the fp32 test
     __shared__ unsigned s_near[SW_SAMPLES][SW_NEAR_CAP];          // ring of candidates awaiting the exact pass
