@@ -93,11 +93,13 @@ __device__ inline float mesh_solid_angle(const DevMesh *m, float qx, float qy, f
 }
 
 // squared distance to the closest triangle and that point: branch and bound over the hierarchy's bounding spheres
-__device__ inline double mesh_closest(const DevMesh *m, d3 p, d3 &closest) {
+// `cutoff2`: only triangles closer than sqrt(cutoff2) are of interest; the result is min(exact squared distance, cutoff2)
+// and `closest` is written only when a triangle beat the cutoff (the walk prunes against it from the start)
+__device__ inline double mesh_closest(const DevMesh *m, d3 p, d3 &closest, double cutoff2 = 1.7976931348623157e308) {
     int stk[MESH_STACK];
     double stk_lb[MESH_STACK];
     int sp = 0;
-    double best = 1.7976931348623157e308;
+    double best = cutoff2;
     stk[0] = 0; stk_lb[0] = 0.0; sp = 1;
     while (sp > 0) {
         --sp;
@@ -137,6 +139,28 @@ __device__ inline double mesh_query(const DevMesh *m, d3 p, d3 &closest, double 
     const double w = (double)sa / (4.0 * 3.14159265358979323846);      // libigl: computeSolidAngle(...) / (4.0 * igl::PI)
     s_out = 1. - 2. * w;
     return mesh_closest(m, p, closest);
+}
+
+// For the tile term (grad_cost_p): the penalty smoothedL1(cap - sdf) vanishes for sdf >= cap, which is the case for almost
+// every voxel of the tile.  Outside the mesh (s = 1 - 2w > 0) sdf = s * dist < cap <=> dist < cap / s, so the closest-point
+// walk starts with that cutoff and usually ends at the root.  Returns false when sdf >= cap is proven; otherwise the exact
+// sdf and gradient, identical to mesh_sdf_grad.
+__device__ inline bool mesh_sdf_grad_below(const DevMesh *m, d3 p, double cap, double &sdf, d3 &g) {
+    const float sa = mesh_solid_angle(m, (float)p.x, (float)p.y, (float)p.z);
+    const double w = (double)sa / (4.0 * 3.14159265358979323846);
+    const double s = 1. - 2. * w;
+    double cutoff2 = 1.7976931348623157e308;
+    if (s > 0.0) {
+        if (!(cap > 0.0)) return false;                 // outside and sdf >= 0 >= cap
+        const double dc = cap / s;
+        cutoff2 = dc * dc * (1.0 + 1e-12);                 // a hair above: the comparison below errs towards "evaluate"
+    }
+    d3 c = mk3(0, 0, 0);
+    const double d2 = mesh_closest(m, p, c, cutoff2);
+    if (d2 >= cutoff2) return false;
+    sdf = s * sqrt(d2);
+    g = normalized3(s * (p - c));
+    return true;
 }
 
 __device__ inline double mesh_sdf(const DevMesh *m, d3 p) {

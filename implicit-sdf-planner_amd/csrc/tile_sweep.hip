@@ -476,12 +476,18 @@ __global__ __launch_bounds__(64 * SW_SAMPLES, (KIND == ISDF_SHAPE_BOX || KIND ==
                 const d3 pm = ctr - pos;
                 const d3 prel = mat_tmul(R, pm);
                 if (!(fabs(prel.x) > P.bd_half || fabs(prel.y) > P.bd_half || fabs(prel.z) > P.bd_half)) {
-                    const double sdf = shape_sdf<KIND>(P.shape, prel);
                     is_pair = true;
                     double f = 0.0, df = 0.0;
-                    smoothed_l1(P.safety_hor - sdf, P.mu, f, df);
+                    d3 g = mk3(0, 0, 0);
+                    if constexpr (KIND == ISDF_SHAPE_MESH) {
+                        // one hierarchy query gives sdf AND gradient, and proves "no penalty" early for far voxels
+                        double sdf;
+                        if (mesh_sdf_grad_below(P.shape.mesh, prel, P.safety_hor, sdf, g)) smoothed_l1(P.safety_hor - sdf, P.mu, f, df);
+                    } else {
+                        smoothed_l1(P.safety_hor - shape_sdf<KIND>(P.shape, prel), P.mu, f, df);
+                    }
                     if (f > 0.0) {
-                        const d3 g = shape_grad<KIND>(P.shape, prel);
+                        if constexpr (KIND != ISDF_SHAPE_MESH) g = shape_grad<KIND>(P.shape, prel);
                         is_grad = true;
                         v[0] = f;
                         const d3 wg = mat_mul(R, g);
