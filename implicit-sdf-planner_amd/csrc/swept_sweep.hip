@@ -110,7 +110,16 @@ __global__ __launch_bounds__(64 * SW_WAVES) void swept_sweep_kernel(const SweptP
             m3 R;
 #pragma unroll
             for (int q = 0; q < 9; q++) R.a[q] = o[3 + q];
-            dis = shape_sdf<KIND>(P.shape, mat_tmul(R, p - mk3(o[0], o[1], o[2])));
+            const d3 pr = mat_tmul(R, p - mk3(o[0], o[1], o[2]));
+            if constexpr (KIND == ISDF_SHAPE_MESH) {
+                // the scan only asks "dis < inf?" (and keeps dis where the answer is yes): far samples are rejected by the
+                // hierarchy's distance cutoff without a full query
+                d3 g_unused;
+                double sdf;
+                dis = mesh_sdf_grad_below(P.shape.mesh, pr, inf, sdf, g_unused) ? sdf : 1e9;
+            } else {
+                dis = shape_sdf<KIND>(P.shape, pr);
+            }
         }
         unsigned long long in_mask = __ballot((k < n_coarse) && (dis < inf));
         const int nvalid = min(64, n_coarse - base);
@@ -228,7 +237,7 @@ __global__ __launch_bounds__(64 * SW_WAVES) void swept_sweep_kernel(const SweptP
                                   (-omg.y) * pr.x + omg.x * pr.y + 0 * pr.z);
                 const d3 rv = mat_tmul(R, vt);
                 pvel = mk3(-(rv.x + wx.x), -(rv.y + wx.y), -(rv.z + wx.z));
-                if (!fd_central && !fd_forward) g_direct = shape_grad<KIND>(P.shape, pr);     // Ball / mesh: own gradient
+                if constexpr (KIND != ISDF_SHAPE_MESH) if (!fd_central && !fd_forward) g_direct = shape_grad<KIND>(P.shape, pr);     // Ball: own gradient
             }
             if (pert >= 1 && pert <= 6) {            // temp(a) -= dx; [temp(a) += 2 dx]  (Shape.hpp:36-54)
                 const int a = (pert - 1) >> 1;
@@ -241,7 +250,15 @@ __global__ __launch_bounds__(64 * SW_WAVES) void swept_sweep_kernel(const SweptP
                 const int a = pert - 7;
                 if (a == 0) pr.x += 0.01; else if (a == 1) pr.y += 0.01; else pr.z += 0.01;
             }
-            val = shape_sdf<KIND>(P.shape, pr);
+            if constexpr (KIND == ISDF_SHAPE_MESH) {
+                // one hierarchy query per lane gives value AND gradient (lane 18 keeps the gradient): no second, divergent
+                // query for the lane that needs both
+                d3 gq;
+                val = mesh_sdf_grad(P.shape.mesh, pr, gq);
+                if (lane == 18) g_direct = gq;
+            } else {
+                val = shape_sdf<KIND>(P.shape, pr);
+            }
         }
         // ---- consume
         if (phase == PH_FINE) {
