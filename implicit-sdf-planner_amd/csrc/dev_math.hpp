@@ -25,7 +25,26 @@ template <typename T> __device__ __forceinline__ v3<T> operator*(T s, v3<T> a) {
 template <typename T> __device__ __forceinline__ T dot3(v3<T> a, v3<T> b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
 
 // overloaded scalar math (float versions map to the single-instruction f32 ops)
+#ifdef ISDF_LEAN_MATH
+// Translation units that define ISDF_LEAN_MATH (the exact pass of the tile sweep, where fp64 instruction issue is the
+// bound) get the compiler's own rsq + Newton sequence for sqrt WITHOUT its range scaling and class handling: same
+// arithmetic, hence the same bits, for arguments in the normal range - which sums of squares of metre-scale lengths are -
+// and 0 -> 0.  10 instructions instead of 18.
+__device__ __forceinline__ double m_sqrt(double x) {
+    const double y = __builtin_amdgcn_rsq(x);
+    double g = x * y, h = 0.5 * y;
+    const double r = fma(-h, g, 0.5);
+    g = fma(g, r, g);
+    h = fma(h, r, h);
+    double d = fma(-g, g, x);
+    g = fma(d, h, g);
+    d = fma(-g, g, x);
+    g = fma(d, h, g);
+    return x > 0.0 ? g : x;
+}
+#else
 __device__ __forceinline__ double m_sqrt(double x) { return sqrt(x); }
+#endif
 __device__ __forceinline__ float m_sqrt(float x) { return sqrtf(x); }
 __device__ __forceinline__ double m_abs(double x) { return fabs(x); }
 __device__ __forceinline__ float m_abs(float x) { return fabsf(x); }
@@ -42,6 +61,21 @@ __device__ __forceinline__ void m_sincos(float a, float &s, float &c) { sincosf(
 
 template <typename T> __device__ __forceinline__ T norm3(v3<T> a) { return m_sqrt(dot3(a, a)); }
 // Eigen normalized(): unchanged when the squared norm is not > 0
+// a / |a| through one refined reciprocal square root (no sqrt, no division): |error| ~ 1 ulp.  Zero stays zero
+// (Eigen's normalized()).
+__device__ __forceinline__ d3 normalized3_lean(d3 a) {
+    const double z = dot3(a, a);
+    if (!(z > 0.0)) return a;
+    const double y = __builtin_amdgcn_rsq(z);
+    const double g = z * y;
+    double h = 0.5 * y;
+    const double r = fma(-h, g, 0.5);
+    h = fma(h, r, h);                       // 0.5 / sqrt(z) after one Newton step
+    const double r2 = fma(-h, z * (h + h), 0.5);   // second step on the reciprocal root itself
+    h = fma(h, r2, h);
+    const double inv = h + h;
+    return mk3(a.x * inv, a.y * inv, a.z * inv);
+}
 __device__ __forceinline__ d3 normalized3(d3 a) {
     const double z = dot3(a, a);
     if (z > 0.0) { const double n = sqrt(z); return mk3(a.x / n, a.y / n, a.z / n); }
@@ -69,6 +103,17 @@ __device__ __forceinline__ m3 quat_to_rot(d4 q) {
 }
 
 // returns false (f, df untouched) for x < 0
+// the same with the reciprocal of mu precomputed (two divisions fewer per voxel in the exact tile pass)
+__device__ __forceinline__ bool smoothed_l1_inv(double x, double mu, double inv_mu, double &f, double &df) {
+    if (x < 0.0) return false;
+    if (x > mu) { f = x - 0.5 * mu; df = 1.0; return true; }
+    const double xdmu = x * inv_mu;
+    const double sq = xdmu * xdmu;
+    const double mumxd2 = mu - 0.5 * x;
+    f = mumxd2 * sq * xdmu;
+    df = sq * ((-0.5) * xdmu + 3.0 * mumxd2 * inv_mu);
+    return true;
+}
 __device__ __forceinline__ bool smoothed_l1(double x, double mu, double &f, double &df) {
     if (x < 0.0) return false;
     if (x > mu) { f = x - 0.5 * mu; df = 1.0; return true; }

@@ -249,7 +249,11 @@ __device__ __forceinline__ d3 shape_grad(const DevShape &S, d3 pr) {
     const double gy = shape_sdf<KIND>(S, mk3(pr.x, hi, pr.z)) - shape_sdf<KIND>(S, mk3(pr.x, lo, pr.z));
     lo = pr.z - dx; hi = lo + 2 * dx;
     const double gz = shape_sdf<KIND>(S, mk3(pr.x, pr.y, hi)) - shape_sdf<KIND>(S, mk3(pr.x, pr.y, lo));
+#ifdef ISDF_LEAN_MATH
+    return normalized3_lean(mk3(gx, gy, gz));      // normalising makes the common factor 1 / (2 dx) irrelevant
+#else
     return normalized3(mk3(gx / (2 * dx), gy / (2 * dx), gz / (2 * dx)));
+#endif
 }
 
 } // namespace isdf

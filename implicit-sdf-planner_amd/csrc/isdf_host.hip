@@ -478,7 +478,7 @@ static int eval_device_impl(isdf_ctx *c, int n_traj, int N, const double *d_T, c
     P.safety_hor = cfg.safety_hor; P.weight_p = cfg.weight_p; P.weight_v = cfg.weight_v; P.weight_omg = cfg.weight_omg;
     P.weight_theta = cfg.weight_theta;
     P.vel_sqr_max = cfg.vmax * cfg.vmax; P.omg_sqr_max = cfg.omgmax * cfg.omgmax; P.theta_max = cfg.thetamax;
-    P.mu = cfg.smoothing_eps;
+    P.mu = cfg.smoothing_eps; P.inv_mu = 1.0 / cfg.smoothing_eps;
     P.occ_thresh = (float)cfg.occ_thresh;
     P.cull_threshold = 0.0;
     if (cfg.variant == ISDF_V3_ESDF_TILE && cfg.enable_cull && c->shape.bound_radius > 0)

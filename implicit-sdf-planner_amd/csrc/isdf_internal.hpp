@@ -28,7 +28,7 @@ struct SweepParams {
     int piece_begin, piece_end; // this rank's range of GLOBAL piece indices (traj-major)
     double bd_half;             // kernel_size * res / 2
     double safety_hor, weight_p, weight_v, weight_omg, weight_theta;
-    double vel_sqr_max, omg_sqr_max, theta_max, mu;
+    double vel_sqr_max, omg_sqr_max, theta_max, mu, inv_mu;
     float occ_thresh;
     double cull_threshold;      // <= 0: cull disabled
     const double *T;            // n_traj * N

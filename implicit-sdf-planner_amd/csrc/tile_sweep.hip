@@ -23,6 +23,7 @@
 //                   adds up the piece costs (fixed order); blocks of pieces outside this rank's shard write zeros so
 //                   that the ranks' outputs sum to the full result.
 // Everything that reaches the result is fp64 except the stored ESDF (fp32).  No MFMA: gather/interpolate work.
+#define ISDF_LEAN_MATH 1      // dev_math.hpp / dev_shapes.hpp: lean sqrt and normalisation in this translation unit
 #include "isdf_internal.hpp"
 #include "dev_mesh.hpp"
 
@@ -333,6 +334,7 @@ __global__ __launch_bounds__(64 * SW_SAMPLES, (KIND == ISDF_SHAPE_BOX || KIND ==
     double tot = 0.0;                            // wave `s`, lane k < 8: component k of sample s's collision sums
     int tot_n = 0;                               // lanes 8 / 9: exact pairs / active pairs
     int n_rounds = 0;
+    unsigned cnt_rounds = 0, cnt_passes = 0, cnt_filters = 0, cnt_listed = 0, cnt_cand = 0;      // ISDF_DEBUG_TIMING only
 
     for (;;) {
         // ================= scan phase: produce -> fp32 filter -> candidate ring, until done or the ring is full
@@ -355,9 +357,11 @@ __global__ __launch_bounds__(64 * SW_SAMPLES, (KIND == ISDF_SHAPE_BOX || KIND ==
                 }
                 pend_head = (pend_head + n) & (SW_LIST_CAP - 1);
                 pend -= n;
+                cnt_filters++;
                 const unsigned long long nm = __ballot(cand);
                 if (cand) s_near[wave][(near_head + near_cnt + __popcll(nm & ((1ull << lane) - 1ull))) & (SW_NEAR_CAP - 1)] = ent;
                 near_cnt += __popcll(nm);
+                cnt_cand += (unsigned)__popcll(nm);
             } else if (!__ballot(hb != 0u)) {
                 // ---- (2a) take the round requested earlier, request the one after it
                 if (primed && rounds_left == 0) {
@@ -365,6 +369,7 @@ __global__ __launch_bounds__(64 * SW_SAMPLES, (KIND == ISDF_SHAPE_BOX || KIND ==
                     if (dbg && lane == 0) dbg[4] = clock64();
                 } else {
                     if (primed) {
+                        cnt_rounds++;
                         rounds_left--;
                         hb = nbits & nmask;          // waits for the loads requested one round ago
                         pk = npk; zoff = nzoff;
@@ -402,6 +407,7 @@ __global__ __launch_bounds__(64 * SW_SAMPLES, (KIND == ISDF_SHAPE_BOX || KIND ==
                     s_list[wave][(wpos++) & (SW_LIST_CAP - 1)] = pk | ((zoff + z) << 20);
                 }
                 pend += total;
+                cnt_passes++; cnt_listed += (unsigned)total;
                 wave_lds_sync();
             }
             finished = !rows_left && pend == 0;
@@ -482,9 +488,9 @@ __global__ __launch_bounds__(64 * SW_SAMPLES, (KIND == ISDF_SHAPE_BOX || KIND ==
                     if constexpr (KIND == ISDF_SHAPE_MESH) {
                         // one hierarchy query gives sdf AND gradient, and proves "no penalty" early for far voxels
                         double sdf;
-                        if (mesh_sdf_grad_below(P.shape.mesh, prel, P.safety_hor, sdf, g)) smoothed_l1(P.safety_hor - sdf, P.mu, f, df);
+                        if (mesh_sdf_grad_below(P.shape.mesh, prel, P.safety_hor, sdf, g)) smoothed_l1_inv(P.safety_hor - sdf, P.mu, P.inv_mu, f, df);
                     } else {
-                        smoothed_l1(P.safety_hor - shape_sdf<KIND>(P.shape, prel), P.mu, f, df);
+                        smoothed_l1_inv(P.safety_hor - shape_sdf<KIND>(P.shape, prel), P.mu, P.inv_mu, f, df);
                     }
                     if (f > 0.0) {
                         if constexpr (KIND != ISDF_SHAPE_MESH) g = shape_grad<KIND>(P.shape, prel);
@@ -527,7 +533,10 @@ __global__ __launch_bounds__(64 * SW_SAMPLES, (KIND == ISDF_SHAPE_BOX || KIND ==
         else if (lane == ACC_STRIDE) P.sample_info[2 * sl] = tot_n;
         else if (lane == ACC_STRIDE + 1) P.sample_info[2 * sl + 1] = tot_n | ((flags & 2) ? (int)0x80000000 : 0);
     }
-    if (dbg && lane == 0) { dbg[5] = clock64(); dbg[6] = wall_clock64(); dbg[7] = (unsigned long long)n_rounds; }
+    if (dbg && lane == 0) {
+        dbg[5] = clock64(); dbg[6] = wall_clock64(); dbg[7] = (unsigned long long)n_rounds;
+        dbg[3] = (unsigned long long)cnt_rounds | ((unsigned long long)cnt_passes << 8) | ((unsigned long long)cnt_filters << 16) | ((unsigned long long)cnt_listed << 24) | ((unsigned long long)cnt_cand << 44);
+    }
 }
 
 // on-demand statistics (isdf_get_stats / host API): culled poses, exact pairs, active pairs.  Not on the timed path.

@@ -59,6 +59,9 @@ def main():
     ok = sc[:, 4] > 0
     print("  rows      cycles:", pct(sc[ok, 4] - sc[ok, 2]))
     print("  drain+sum cycles:", pct(sc[ok, 5] - sc[ok, 4]))
+    c3 = sc[:, 3]
+    print("  row rounds:", pct(c3 & 255), " compaction passes:", pct((c3 >> 8) & 255), " filter passes:", pct((c3 >> 16) & 255))
+    print("  listed voxels:", pct((c3 >> 24) & 0xFFFFF), " candidates:", pct((c3 >> 44) & 0xFFFFF))
     print("  exact rounds per wave:", pct(sc[:, 7]), " waves:", sc.shape[0])
     print("tail  start us:", pct(us(tl[:, 0])))
     print("tail  end   us:", pct(us(tl[:, 1])))
