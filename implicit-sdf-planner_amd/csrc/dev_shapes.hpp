@@ -187,7 +187,10 @@ __device__ __forceinline__ T analytic_local(const ShapeP<T> &S, int kind_rt, v3<
     }
 }
 // (pos_rel - trans) * Rotate: the body offset every analytic class applies first (e.g. Shape.hpp:843)
-template <typename T> __device__ __forceinline__ v3<T> body_offset(const ShapeP<T> &S, v3<T> pr) {
+// IDENT = true: the caller (a kernel instantiation chosen on the host) KNOWS the offset is the identity, so the general path
+// and the 12 scalars it keeps alive are not even compiled in.
+template <bool IDENT = false, typename T> __device__ __forceinline__ v3<T> body_offset(const ShapeP<T> &S, v3<T> pr) {
+    if constexpr (IDENT) return pr;
     if (S.ident) return pr;               // wave-uniform; (p - 0) * I == p bit for bit (finite p)
     const T dx = pr.x - S.trans[0], dy = pr.y - S.trans[1], dz = pr.z - S.trans[2];
     const T *R = S.rot;
@@ -195,21 +198,21 @@ template <typename T> __device__ __forceinline__ v3<T> body_offset(const ShapeP<
 }
 
 // analytic kinds only (kind != MESH)
-template <int KIND, typename T>
+template <int KIND, typename T, bool IDENT = false>
 __device__ __forceinline__ T analytic_sdf(const ShapeP<T> &S, int kind_rt, v3<T> pr) {
     const int kind = (KIND >= 0) ? KIND : kind_rt;
     if (kind == ISDF_SHAPE_BALL) return norm3(pr) - S.p[0];
-    return analytic_local<KIND, T>(S, kind_rt, body_offset(S, pr));
+    return analytic_local<KIND, T>(S, kind_rt, body_offset<IDENT>(S, pr));
 }
 
 __device__ double mesh_sdf(const DevMesh *m, d3 p);              // dev_mesh.hpp
 __device__ double mesh_sdf_grad(const DevMesh *m, d3 p, d3 &g);  // dev_mesh.hpp
 
 // BasicShape::getonlySDF(pos_rel), exact path (fp64)
-template <int KIND>
+template <int KIND, bool IDENT = false>
 __device__ __forceinline__ double shape_sdf(const DevShape &S, d3 pr) {
     if constexpr (KIND == ISDF_SHAPE_MESH) return mesh_sdf(S.mesh, pr);     // the mesh kind has its own instantiation
-    else return analytic_sdf<KIND, double>(S.d, S.kind, pr);
+    else return analytic_sdf<KIND, double, IDENT>(S.d, S.kind, pr);
 }
 
 // BasicShape::getonlySDF(pos, R_obj) (Shape.hpp:470), the form the front end's kernel generation uses (:451): every
@@ -228,27 +231,27 @@ __device__ __forceinline__ double shape_sdf_rotated(const DevShape &S, d3 pos, c
 
 // getonlyGrad1: central difference dx = 5e-6 (temp -= dx; temp += 2dx), normalised — Shape.hpp:32-57;
 // Box: forward difference dx = 0.01, not normalised — Shape.hpp:2363-2377; Ball: p/|p| — Shape.hpp:622-625.
-template <int KIND>
+template <int KIND, bool IDENT = false>
 __device__ __forceinline__ d3 shape_grad(const DevShape &S, d3 pr) {
     if constexpr (KIND == ISDF_SHAPE_MESH) { d3 g; mesh_sdf_grad(S.mesh, pr, g); return g; }
     const int mode = S.grad_mode;   // resolved (never DEFAULT) by the host
     if (mode == ISDF_GRAD_ANALYTIC_BALL) return normalized3(pr);
     if (mode == ISDF_GRAD_BOX_FORWARD) {
         const double dx = 0.01;
-        const double s0 = shape_sdf<KIND>(S, pr);
-        const double gx = shape_sdf<KIND>(S, mk3(pr.x + dx, pr.y, pr.z)) - s0;
-        const double gy = shape_sdf<KIND>(S, mk3(pr.x, pr.y + dx, pr.z)) - s0;
-        const double gz = shape_sdf<KIND>(S, mk3(pr.x, pr.y, pr.z + dx)) - s0;
+        const double s0 = shape_sdf<KIND, IDENT>(S, pr);
+        const double gx = shape_sdf<KIND, IDENT>(S, mk3(pr.x + dx, pr.y, pr.z)) - s0;
+        const double gy = shape_sdf<KIND, IDENT>(S, mk3(pr.x, pr.y + dx, pr.z)) - s0;
+        const double gz = shape_sdf<KIND, IDENT>(S, mk3(pr.x, pr.y, pr.z + dx)) - s0;
         return mk3(gx / dx, gy / dx, gz / dx);
     }
     const double dx = 0.000005;
     double lo, hi;
     lo = pr.x - dx; hi = lo + 2 * dx;
-    const double gx = shape_sdf<KIND>(S, mk3(hi, pr.y, pr.z)) - shape_sdf<KIND>(S, mk3(lo, pr.y, pr.z));
+    const double gx = shape_sdf<KIND, IDENT>(S, mk3(hi, pr.y, pr.z)) - shape_sdf<KIND, IDENT>(S, mk3(lo, pr.y, pr.z));
     lo = pr.y - dx; hi = lo + 2 * dx;
-    const double gy = shape_sdf<KIND>(S, mk3(pr.x, hi, pr.z)) - shape_sdf<KIND>(S, mk3(pr.x, lo, pr.z));
+    const double gy = shape_sdf<KIND, IDENT>(S, mk3(pr.x, hi, pr.z)) - shape_sdf<KIND, IDENT>(S, mk3(pr.x, lo, pr.z));
     lo = pr.z - dx; hi = lo + 2 * dx;
-    const double gz = shape_sdf<KIND>(S, mk3(pr.x, pr.y, hi)) - shape_sdf<KIND>(S, mk3(pr.x, pr.y, lo));
+    const double gz = shape_sdf<KIND, IDENT>(S, mk3(pr.x, pr.y, hi)) - shape_sdf<KIND, IDENT>(S, mk3(pr.x, pr.y, lo));
 #ifdef ISDF_LEAN_MATH
     return normalized3_lean(mk3(gx, gy, gz));      // normalising makes the common factor 1 / (2 dx) irrelevant
 #else

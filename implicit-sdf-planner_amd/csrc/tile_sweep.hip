@@ -145,8 +145,10 @@ __device__ __forceinline__ double mesh_band_scale(int kind) { return kind == ISD
 
 // Box and RoundedCone fit 128 VGPRs (4 waves per SIMD), which is worth ~10 % when the device is full (C3); the generic and
 // mesh instantiations need more and are held to 3 waves.
-template <int KIND>
-__global__ __launch_bounds__(64 * SW_SAMPLES, (KIND == ISDF_SHAPE_BOX || KIND == ISDF_SHAPE_ROUNDEDCONE) ? 4 : 3) void sweep_kernel(const SweepParams P) {
+// IDENT: the shape's body offset is the identity (poly_params all zero - every shipped config): those instantiations drop
+// the offset and the 24 scalar registers it pins, which takes Box to 91 VGPRs and a fifth wave per SIMD.
+template <int KIND, bool IDENT>
+__global__ __launch_bounds__(64 * SW_SAMPLES, (KIND == ISDF_SHAPE_BOX || KIND == ISDF_SHAPE_ROUNDEDCONE) ? (IDENT ? 5 : 4) : 3) void sweep_kernel(const SweepParams P) {
     __shared__ SweepPose s_pose[SW_SAMPLES];
     __shared__ unsigned s_list[SW_SAMPLES][SW_LIST_CAP];          // ring of compacted voxels awaiting the fp32 test
     __shared__ unsigned s_near[SW_SAMPLES][SW_NEAR_CAP];          // ring of candidates awaiting the exact pass
@@ -243,7 +245,27 @@ __global__ __launch_bounds__(64 * SW_SAMPLES, (KIND == ISDF_SHAPE_BOX || KIND ==
     const int n_rows = (flags & 1) ? rnx * rny : 0;
     const bool scanning = n_rows > 0;
 
-    // ---- own sample: scan-stage constants (fp32, wave-uniform)
+    // scan state of this wave's sample
+    const int n_zb = ((have_sample ? __builtin_amdgcn_readfirstlane(sp.nzt) : 0) + 31) >> 5;   // 32-voxel blocks along z (1 for kernel_size <= 31)
+    int near_head = 0, near_cnt = 0;             // ring of candidates awaiting the exact pass
+    int pend_head = 0, pend = 0;                 // ring of compacted voxels awaiting the fp32 test
+    int fzb = 0, ft = 0;                         // fetch cursor: z-block and first window row of the next round
+    bool rows_left = scanning;
+    unsigned hb = 0, pk = 0, zoff = 0;           // this lane's row: pending qualifier bits, packed (lx, ly), z offset
+    unsigned nbits = 0, nmask = 0, npk = 0, nzoff = 0;   // the NEXT round's row, requested one round ahead
+    int rounds_left = scanning ? n_zb * ((n_rows + 63) >> 6) : 0;
+    bool primed = false;
+    double tot = 0.0;                            // wave `s`, lane k < 8: component k of sample s's collision sums
+    int tot_n = 0;                               // lanes 8 / 9: exact pairs / active pairs
+    int n_rounds = 0;
+    unsigned cnt_rounds = 0, cnt_passes = 0, cnt_filters = 0, cnt_listed = 0, cnt_cand = 0;      // ISDF_DEBUG_TIMING only
+
+    for (;;) {
+        // ================= scan phase: produce -> fp32 filter -> candidate ring, until done or the ring is full
+        bool finished = !rows_left && pend == 0;
+        if (!finished) {
+        // The scan-stage constants live only inside this block: they are rebuilt from the LDS pose record when the scan is
+        // (re)entered, so that they do not hold scalar registers during the exact phase (SGPR spills cost VALU issue slots).
     const int lox = __builtin_amdgcn_readfirstlane(sp.lo[0]), loy = __builtin_amdgcn_readfirstlane(sp.lo[1]),
               loz = __builtin_amdgcn_readfirstlane(sp.lo[2]), nzt = __builtin_amdgcn_readfirstlane(sp.nzt);
     const int rx0 = __builtin_amdgcn_readfirstlane(sp.rx0), ry0 = __builtin_amdgcn_readfirstlane(sp.ry0);
@@ -321,24 +343,6 @@ __global__ __launch_bounds__(64 * SW_SAMPLES, (KIND == ISDF_SHAPE_BOX || KIND ==
         return (n >= 32) ? 0xFFFFFFFFu : (((1u << n) - 1u) << zlo);
     };
 
-    // scan state of this wave's sample
-    const int n_zb = (nzt + 31) >> 5;            // 32-voxel blocks along z (1 for kernel_size <= 31)
-    int near_head = 0, near_cnt = 0;             // ring of candidates awaiting the exact pass
-    int pend_head = 0, pend = 0;                 // ring of compacted voxels awaiting the fp32 test
-    int fzb = 0, ft = 0;                         // fetch cursor: z-block and first window row of the next round
-    bool rows_left = scanning;
-    unsigned hb = 0, pk = 0, zoff = 0;           // this lane's row: pending qualifier bits, packed (lx, ly), z offset
-    unsigned nbits = 0, nmask = 0, npk = 0, nzoff = 0;   // the NEXT round's row, requested one round ahead
-    int rounds_left = scanning ? n_zb * ((n_rows + 63) >> 6) : 0;
-    bool primed = false;
-    double tot = 0.0;                            // wave `s`, lane k < 8: component k of sample s's collision sums
-    int tot_n = 0;                               // lanes 8 / 9: exact pairs / active pairs
-    int n_rounds = 0;
-    unsigned cnt_rounds = 0, cnt_passes = 0, cnt_filters = 0, cnt_listed = 0, cnt_cand = 0;      // ISDF_DEBUG_TIMING only
-
-    for (;;) {
-        // ================= scan phase: produce -> fp32 filter -> candidate ring, until done or the ring is full
-        bool finished = !rows_left && pend == 0;
         while (!finished) {
             if (pend >= 64 || (!rows_left && pend > 0)) {
                 if (near_cnt > SW_NEAR_CAP - 64) break;            // ring full: the workgroup drains it first
@@ -352,7 +356,7 @@ __global__ __launch_bounds__(64 * SW_SAMPLES, (KIND == ISDF_SHAPE_BOX || KIND ==
                     const f3 pr = mkv<float>(Rf[0] * mx + Rf[3] * my + Rf[6] * mz, Rf[1] * mx + Rf[4] * my + Rf[7] * mz,
                                              Rf[2] * mx + Rf[5] * my + Rf[8] * mz);
                     const bool incube = fmaxf(fabsf(pr.x), fmaxf(fabsf(pr.y), fabsf(pr.z))) <= bdh_f;
-                    const float sdf = analytic_sdf<KIND, float>(P.shape.f, P.shape.kind, pr);
+                    const float sdf = analytic_sdf<KIND, float, IDENT>(P.shape.f, P.shape.kind, pr);
                     cand = cand & incube & !(sdf >= thr_f);   // reject only what provably has zero penalty; NaN => candidate
                 }
                 pend_head = (pend_head + n) & (SW_LIST_CAP - 1);
@@ -411,6 +415,7 @@ __global__ __launch_bounds__(64 * SW_SAMPLES, (KIND == ISDF_SHAPE_BOX || KIND ==
                 wave_lds_sync();
             }
             finished = !rows_left && pend == 0;
+        }
         }
         if (lane == 0) { s_plan[wave][0] = near_cnt; s_plan[wave][1] = near_head; s_plan[wave][2] = finished ? 1 : 0; }
         __syncthreads();
@@ -490,10 +495,10 @@ __global__ __launch_bounds__(64 * SW_SAMPLES, (KIND == ISDF_SHAPE_BOX || KIND ==
                         double sdf;
                         if (mesh_sdf_grad_below(P.shape.mesh, prel, P.safety_hor, sdf, g)) smoothed_l1_inv(P.safety_hor - sdf, P.mu, P.inv_mu, f, df);
                     } else {
-                        smoothed_l1_inv(P.safety_hor - shape_sdf<KIND>(P.shape, prel), P.mu, P.inv_mu, f, df);
+                        smoothed_l1_inv(P.safety_hor - shape_sdf<KIND, IDENT>(P.shape, prel), P.mu, P.inv_mu, f, df);
                     }
                     if (f > 0.0) {
-                        if constexpr (KIND != ISDF_SHAPE_MESH) g = shape_grad<KIND>(P.shape, prel);
+                        if constexpr (KIND != ISDF_SHAPE_MESH) g = shape_grad<KIND, IDENT>(P.shape, prel);
                         is_grad = true;
                         v[0] = f;
                         const d3 wg = mat_mul(R, g);
@@ -684,12 +689,15 @@ void launch_sweep(const SweepParams &P, hipStream_t stream, hipEvent_t ev_start,
     const long long n_samples = (long long)(P.piece_end - P.piece_begin) * (P.K + 1);
     if (n_samples <= 0 || !P.enable_pos) return;
     const dim3 grid((unsigned)((n_samples + SW_SAMPLES - 1) / SW_SAMPLES)), block(64 * SW_SAMPLES);
+    const bool ident = P.shape.d.ident != 0;
+#define ISDF_LAUNCH_SWEEP(K, I) hipExtLaunchKernelGGL((sweep_kernel<K, I>), grid, block, 0, stream, ev_start, ev_stop, 0, P)
     switch (P.shape.kind) {
-    case ISDF_SHAPE_BOX: hipExtLaunchKernelGGL(sweep_kernel<ISDF_SHAPE_BOX>, grid, block, 0, stream, ev_start, ev_stop, 0, P); break;
-    case ISDF_SHAPE_ROUNDEDCONE: hipExtLaunchKernelGGL(sweep_kernel<ISDF_SHAPE_ROUNDEDCONE>, grid, block, 0, stream, ev_start, ev_stop, 0, P); break;
-    case ISDF_SHAPE_MESH: hipExtLaunchKernelGGL(sweep_kernel<ISDF_SHAPE_MESH>, grid, block, 0, stream, ev_start, ev_stop, 0, P); break;
-    default: hipExtLaunchKernelGGL(sweep_kernel<-1>, grid, block, 0, stream, ev_start, ev_stop, 0, P); break;
+    case ISDF_SHAPE_BOX: if (ident) ISDF_LAUNCH_SWEEP(ISDF_SHAPE_BOX, true); else ISDF_LAUNCH_SWEEP(ISDF_SHAPE_BOX, false); break;
+    case ISDF_SHAPE_ROUNDEDCONE: if (ident) ISDF_LAUNCH_SWEEP(ISDF_SHAPE_ROUNDEDCONE, true); else ISDF_LAUNCH_SWEEP(ISDF_SHAPE_ROUNDEDCONE, false); break;
+    case ISDF_SHAPE_MESH: ISDF_LAUNCH_SWEEP(ISDF_SHAPE_MESH, false); break;
+    default: if (ident) ISDF_LAUNCH_SWEEP(-1, true); else ISDF_LAUNCH_SWEEP(-1, false); break;
     }
+#undef ISDF_LAUNCH_SWEEP
 }
 
 void launch_stats(const SweepParams &P, hipStream_t stream) {
