@@ -143,12 +143,25 @@ __device__ __forceinline__ float unif(float v) { return __int_as_float(__builtin
 // winding number (|w error| up to a few 1e-3 outside, Shape.cpp:110), so its penalty band is widened by 5 % for pruning.
 __device__ __forceinline__ double mesh_band_scale(int kind) { return kind == ISDF_SHAPE_MESH ? 1.05 : 1.0; }
 
-// Box and RoundedCone fit 128 VGPRs (4 waves per SIMD), which is worth ~10 % when the device is full (C3); the generic and
-// mesh instantiations need more and are held to 3 waves.
+// Dedicated instantiations (Box, RoundedCone and the robots of the shipped configs) are held to 128 VGPRs (4 waves per SIMD),
+// their identity-offset variants to 102 (5 waves) - worth 10-30 % when the device is full (C3); the generic and mesh
+// instantiations need more and are held to 3 waves.
+// waves per SIMD the register allocator is held to, by formula size (measured: no scratch spills at these settings except a
+// few dwords for the smooth-min shapes): 5 needs <= 102 VGPRs, 4 <= 128, 3 <= 168
+constexpr int sweep_waves_per_simd(int kind, bool ident) {
+    switch (kind) {
+    case ISDF_SHAPE_TORUS: case ISDF_SHAPE_CAPPEDTORUS: case ISDF_SHAPE_ROUNDEDCONE: case ISDF_SHAPE_BENDLINEAR:
+    case ISDF_SHAPE_SMOOTHDIFFERENCE: case ISDF_SHAPE_SMOOTHINTERSECTION: case ISDF_SHAPE_BOX: return ident ? 5 : 4;
+    case ISDF_SHAPE_CAPPEDCONE: case ISDF_SHAPE_WIREFRAMEBOX: return 4;
+    case ISDF_SHAPE_TWISTBOX: case ISDF_SHAPE_BENDBOX: case ISDF_SHAPE_TABLE: case ISDF_SHAPE_TREFOIL: case ISDF_SHAPE_CSG: return ident ? 4 : 3;
+    default: return 3;      // mesh, generic
+    }
+}
+
 // IDENT: the shape's body offset is the identity (poly_params all zero - every shipped config): those instantiations drop
 // the offset and the 24 scalar registers it pins, which takes Box to 91 VGPRs and a fifth wave per SIMD.
 template <int KIND, bool IDENT>
-__global__ __launch_bounds__(64 * SW_SAMPLES, (KIND == ISDF_SHAPE_BOX || KIND == ISDF_SHAPE_ROUNDEDCONE) ? (IDENT ? 5 : 4) : 3) void sweep_kernel(const SweepParams P) {
+__global__ __launch_bounds__(64 * SW_SAMPLES, sweep_waves_per_simd(KIND, IDENT)) void sweep_kernel(const SweepParams P) {
     __shared__ SweepPose s_pose[SW_SAMPLES];
     __shared__ unsigned s_list[SW_SAMPLES][SW_LIST_CAP];          // ring of compacted voxels awaiting the fp32 test
     __shared__ unsigned s_near[SW_SAMPLES][SW_NEAR_CAP];          // ring of candidates awaiting the exact pass
@@ -691,12 +704,18 @@ void launch_sweep(const SweepParams &P, hipStream_t stream, hipEvent_t ev_start,
     const dim3 grid((unsigned)((n_samples + SW_SAMPLES - 1) / SW_SAMPLES)), block(64 * SW_SAMPLES);
     const bool ident = P.shape.d.ident != 0;
 #define ISDF_LAUNCH_SWEEP(K, I) hipExtLaunchKernelGGL((sweep_kernel<K, I>), grid, block, 0, stream, ev_start, ev_stop, 0, P)
+#define ISDF_SWEEP_CASE(K) case K: if (ident) ISDF_LAUNCH_SWEEP(K, true); else ISDF_LAUNCH_SWEEP(K, false); break;
     switch (P.shape.kind) {
-    case ISDF_SHAPE_BOX: if (ident) ISDF_LAUNCH_SWEEP(ISDF_SHAPE_BOX, true); else ISDF_LAUNCH_SWEEP(ISDF_SHAPE_BOX, false); break;
-    case ISDF_SHAPE_ROUNDEDCONE: if (ident) ISDF_LAUNCH_SWEEP(ISDF_SHAPE_ROUNDEDCONE, true); else ISDF_LAUNCH_SWEEP(ISDF_SHAPE_ROUNDEDCONE, false); break;
+    // one instantiation per analytic class (sw_manager.hpp:74-123 + Box): each inlines exactly one SDF formula
+    ISDF_SWEEP_CASE(ISDF_SHAPE_TORUS) ISDF_SWEEP_CASE(ISDF_SHAPE_CAPPEDTORUS) ISDF_SWEEP_CASE(ISDF_SHAPE_CAPPEDCONE)
+    ISDF_SWEEP_CASE(ISDF_SHAPE_ROUNDEDCONE) ISDF_SWEEP_CASE(ISDF_SHAPE_WIREFRAMEBOX) ISDF_SWEEP_CASE(ISDF_SHAPE_BENDLINEAR)
+    ISDF_SWEEP_CASE(ISDF_SHAPE_TWISTBOX) ISDF_SWEEP_CASE(ISDF_SHAPE_BENDBOX) ISDF_SWEEP_CASE(ISDF_SHAPE_TABLE)
+    ISDF_SWEEP_CASE(ISDF_SHAPE_TREFOIL) ISDF_SWEEP_CASE(ISDF_SHAPE_SMOOTHDIFFERENCE) ISDF_SWEEP_CASE(ISDF_SHAPE_SMOOTHINTERSECTION)
+    ISDF_SWEEP_CASE(ISDF_SHAPE_CSG) ISDF_SWEEP_CASE(ISDF_SHAPE_BOX)
     case ISDF_SHAPE_MESH: ISDF_LAUNCH_SWEEP(ISDF_SHAPE_MESH, false); break;
-    default: if (ident) ISDF_LAUNCH_SWEEP(-1, true); else ISDF_LAUNCH_SWEEP(-1, false); break;
+    default: if (ident) ISDF_LAUNCH_SWEEP(-1, true); else ISDF_LAUNCH_SWEEP(-1, false); break;      // Ball (and anything new)
     }
+#undef ISDF_SWEEP_CASE
 #undef ISDF_LAUNCH_SWEEP
 }
 
