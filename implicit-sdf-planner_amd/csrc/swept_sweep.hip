@@ -430,12 +430,18 @@ void launch_swept_sweep(const SweptParams &P, hipStream_t stream, hipEvent_t ev_
     const int n = P.point_end - P.point_begin;
     if (n <= 0) return;
     const dim3 grid((n + SW_WAVES - 1) / SW_WAVES), block(64 * SW_WAVES);
+#define ISDF_SWEPT_CASE(K) case K: hipExtLaunchKernelGGL(swept_sweep_kernel<K>, grid, block, 0, stream, ev_start, ev_stop, 0, P); break;
     switch (P.shape.kind) {
-    case ISDF_SHAPE_BOX: hipExtLaunchKernelGGL(swept_sweep_kernel<ISDF_SHAPE_BOX>, grid, block, 0, stream, ev_start, ev_stop, 0, P); break;
-    case ISDF_SHAPE_ROUNDEDCONE: hipExtLaunchKernelGGL(swept_sweep_kernel<ISDF_SHAPE_ROUNDEDCONE>, grid, block, 0, stream, ev_start, ev_stop, 0, P); break;
-    case ISDF_SHAPE_MESH: hipExtLaunchKernelGGL(swept_sweep_kernel<ISDF_SHAPE_MESH>, grid, block, 0, stream, ev_start, ev_stop, 0, P); break;
-    default: hipExtLaunchKernelGGL(swept_sweep_kernel<-1>, grid, block, 0, stream, ev_start, ev_stop, 0, P); break;
+    // one instantiation per shape class (each inlines exactly one SDF formula; the run-time switch of the generic kernel costs
+    // 272 VGPRs = one wave per SIMD)
+    ISDF_SWEPT_CASE(ISDF_SHAPE_TORUS) ISDF_SWEPT_CASE(ISDF_SHAPE_CAPPEDTORUS) ISDF_SWEPT_CASE(ISDF_SHAPE_CAPPEDCONE)
+    ISDF_SWEPT_CASE(ISDF_SHAPE_ROUNDEDCONE) ISDF_SWEPT_CASE(ISDF_SHAPE_WIREFRAMEBOX) ISDF_SWEPT_CASE(ISDF_SHAPE_BENDLINEAR)
+    ISDF_SWEPT_CASE(ISDF_SHAPE_TWISTBOX) ISDF_SWEPT_CASE(ISDF_SHAPE_BENDBOX) ISDF_SWEPT_CASE(ISDF_SHAPE_TABLE)
+    ISDF_SWEPT_CASE(ISDF_SHAPE_TREFOIL) ISDF_SWEPT_CASE(ISDF_SHAPE_SMOOTHDIFFERENCE) ISDF_SWEPT_CASE(ISDF_SHAPE_SMOOTHINTERSECTION)
+    ISDF_SWEPT_CASE(ISDF_SHAPE_CSG) ISDF_SWEPT_CASE(ISDF_SHAPE_BOX) ISDF_SWEPT_CASE(ISDF_SHAPE_MESH)
+    default: hipExtLaunchKernelGGL(swept_sweep_kernel<-1>, grid, block, 0, stream, ev_start, ev_stop, 0, P); break;      // Ball
     }
+#undef ISDF_SWEPT_CASE
 }
 void launch_swept_reduce(const SweptParams &P, double *out, hipStream_t stream) {
     const int n = P.point_end - P.point_begin;

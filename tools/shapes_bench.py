@@ -40,4 +40,18 @@ for name, shape in shapes.items():
         torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / steps
         out.append((dt, n_traj * 2600 / dt))
     s = eng.stats()
+    # V1 swept-volume sweep with the same robot
+    cfg1 = synth.default_config(capi.V1_SWEPT, safety_hor=(3 ** 0.5 / 2) * res, weight_p=4000.0)
+    e1 = pkg.Engine(cfg1); e1.set_grid(occ, (0, 0, 0), res, capi.GRID_OCCUPANCY); e1.set_shape(shape)
+    way = cm.reshape(3, -1).T.reshape(40, 6, 3)[1:, 0, :]
+    M = e1.gather_points(way, 1.4)
+    d_T = torch.from_numpy(T).to(dev); d_C = torch.from_numpy(cm).to(dev)
+    d_o1 = torch.zeros(e1.out_stride(40), dtype=torch.float64, device=dev)
+    for _ in range(2):
+        e1.eval_device(1, 40, d_T.data_ptr(), d_C.data_ptr(), d_o1.data_ptr(), 0, st)
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    for _ in range(10):
+        e1.eval_device(1, 40, d_T.data_ptr(), d_C.data_ptr(), d_o1.data_ptr(), 0, st)
+    torch.cuda.synchronize(); dv1 = (time.perf_counter() - t0) / 10
+    print(f"{'':34s} V1 M={M}: {dv1*1e3:7.3f} ms/step = {M/dv1:10.4g} points/s", flush=True)
     print(f"{name:34s} C2 {out[0][0]*1e6:8.1f} us/step {out[0][1]:10.4g} evals/s | C3 {out[1][0]*1e6:9.1f} us/step {out[1][1]:10.4g} evals/s | pairs/eval {s['pairs']/s['units']:.1f}", flush=True)
