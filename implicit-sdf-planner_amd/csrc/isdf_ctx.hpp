@@ -60,6 +60,7 @@ struct isdf_ctx {
     // full objective callback (costFunctionLmbm): MINCO on the host, sweeps on the device
     isdf_host::MincoS3 minco; bool have_traj = false; double rho = 0.0;
     std::vector<double> cb_T, cb_gdC, cb_gdT, cb_gradP, cb_gradT;
+    double *h_eval_pin = nullptr; size_t eval_pin_cap = 0;   // pinned staging of isdf_eval: [inputs | outputs | statistics]
     double *h_pin = nullptr; size_t pin_cap = 0;      // pinned staging: [T | coeffs | out_a | out_b]
     double *d_cb = nullptr; size_t cb_cap = 0;        // device twin of the staging buffer
     double last_parts[4] = {0, 0, 0, 0};

@@ -154,6 +154,7 @@ extern "C" int isdf_destroy(isdf_ctx *c) {
     (void)hipDeviceSynchronize();
     for (auto &p : c->prof_events) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); (void)hipEventDestroy(p.c); (void)hipEventDestroy(p.d); }
     if (c->h_pin) (void)hipHostFree(c->h_pin);
+    if (c->h_eval_pin) (void)hipHostFree(c->h_eval_pin);
     isdf_frontend_release(c);
     void *ptrs[] = {c->d_tail_ticket, c->d_cb, c->d_esdf, c->d_occ, c->d_points, c->d_tstar, c->d_acc, c->d_sample_info, c->d_bits, c->d_piece_cost, c->d_in, c->d_out, c->d_stats,
                     c->d_traj_duration, c->d_coarse_t, c->d_coarse_pose, c->d_n_coarse, c->d_point_partial, c->d_point_piece, c->d_hist, c->d_dbg};
@@ -547,31 +548,51 @@ static int fetch_stats(isdf_ctx *c) {
     return ISDF_OK;
 }
 
+// pinned staging buffer of the host entry points (isdf_eval): [inputs | outputs | 8 statistics words]
+static int ensure_eval_pin(isdf_ctx *c, size_t doubles) {
+    if (c->eval_pin_cap >= doubles) return ISDF_OK;
+    if (c->h_eval_pin) (void)hipHostFree(c->h_eval_pin);
+    c->h_eval_pin = nullptr; c->eval_pin_cap = 0;
+    HIPCHK(c, hipHostMalloc((void **)&c->h_eval_pin, doubles * sizeof(double), hipHostMallocDefault));
+    c->eval_pin_cap = doubles;
+    return ISDF_OK;
+}
+
 extern "C" int isdf_eval(isdf_ctx *c, int n_traj, const int *N, const double *const *T, const double *const *coeffs,
                          double *cost_inout, double *const *gradT_inout, double *const *gradC_inout, double *tstar_inout) {
     if (!c) return ISDF_ERR_INVALID_ARG;
     if (n_traj < 1 || !N || !T || !coeffs || !cost_inout || !gradT_inout || !gradC_inout) return fail(c, ISDF_ERR_INVALID_ARG, "null argument");
     HIPCHK(c, hipSetDevice(c->device));
-    // trajectories with equal N go out as one batched launch; ragged input is evaluated group by group
-    int start = 0;
+    // trajectories with equal N go out as one batched launch; ragged input is evaluated group by group.
+    // Per group: inputs gathered into one pinned buffer, ONE upload, the launches, ONE download (outputs + the overflow
+    // word), ONE synchronisation.  The pair statistics are computed on demand (isdf_get_stats) unless the input is ragged.
+    int start = 0, groups = 0;
     isdf_stats total{};
+    bool overflow = false;
+    for (int s0 = 0; s0 < n_traj;) { int e = s0 + 1; while (e < n_traj && N[e] == N[s0]) e++; groups++; s0 = e; }
     while (start < n_traj) {
         int end = start + 1;
         while (end < n_traj && N[end] == N[start]) end++;
         const int nb = end - start, n = N[start];
         if (n < 1) return fail(c, ISDF_ERR_INVALID_ARG, "N must be >= 1");
         const size_t in_per = (size_t)19 * n, ostride = isdf_out_stride(n);
-        int rc = ensure(c, &c->d_in, &c->in_cap, in_per * nb);
+        const size_t in_all = in_per * nb, out_all = ostride * nb;
+        int rc = ensure(c, &c->d_in, &c->in_cap, in_all);
         if (rc) return rc;
-        rc = ensure(c, &c->d_out, &c->out_cap, ostride * nb);
+        rc = ensure(c, &c->d_out, &c->out_cap, out_all);
         if (rc) return rc;
+        rc = ensure_eval_pin(c, in_all + out_all + 8);
+        if (rc) return rc;
+        double *hin = c->h_eval_pin, *hout = c->h_eval_pin + in_all;
+        unsigned long long *hstat = (unsigned long long *)(c->h_eval_pin + in_all + out_all);
         double *dT = c->d_in, *dC = c->d_in + (size_t)n * nb;
         for (int b = 0; b < nb; b++) {
             if (!T[start + b] || !coeffs[start + b] || !gradT_inout[start + b] || !gradC_inout[start + b])
                 return fail(c, ISDF_ERR_INVALID_ARG, "null trajectory buffer");
-            HIPCHK(c, hipMemcpyAsync(dT + (size_t)b * n, T[start + b], n * sizeof(double), hipMemcpyHostToDevice, c->stream));
-            HIPCHK(c, hipMemcpyAsync(dC + (size_t)b * 18 * n, coeffs[start + b], (size_t)18 * n * sizeof(double), hipMemcpyHostToDevice, c->stream));
+            std::memcpy(hin + (size_t)b * n, T[start + b], (size_t)n * sizeof(double));
+            std::memcpy(hin + (size_t)n * nb + (size_t)b * 18 * n, coeffs[start + b], (size_t)18 * n * sizeof(double));
         }
+        HIPCHK(c, hipMemcpyAsync(c->d_in, hin, in_all * sizeof(double), hipMemcpyHostToDevice, c->stream));
         double *dts = nullptr;
         if (c->cfg.variant == ISDF_V1_SWEPT && tstar_inout && c->M > 0) {
             dts = c->d_tstar;
@@ -579,17 +600,22 @@ extern "C" int isdf_eval(isdf_ctx *c, int n_traj, const int *N, const double *co
         }
         rc = eval_device_impl(c, nb, n, dT, dC, c->d_out, dts, c->stream);
         if (rc) return rc;
-        c->h_out.resize(ostride * nb);
-        HIPCHK(c, hipMemcpyAsync(c->h_out.data(), c->d_out, ostride * nb * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipMemcpyAsync(hout, c->d_out, out_all * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipMemcpyAsync(hstat, c->d_stats, 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost, c->stream));
         if (dts) HIPCHK(c, hipMemcpyAsync(tstar_inout, dts, (size_t)c->M * sizeof(double), hipMemcpyDeviceToHost, c->stream));
         HIPCHK(c, hipStreamSynchronize(c->stream));
-        rc = fetch_stats(c);
-        if (rc) return rc;
-        total.n_units += c->last_stats.n_units; total.n_units_culled += c->last_stats.n_units_culled;
-        total.n_pairs += c->last_stats.n_pairs; total.n_grad_pairs += c->last_stats.n_grad_pairs;
-        total.overflow |= c->last_stats.overflow;
+        if (hstat[4]) { overflow = true; HIPCHK(c, hipMemset(c->d_stats + 4, 0, sizeof(unsigned long long))); }   // sticky until read
+        if (c->cfg.variant == ISDF_V1_SWEPT) {       // the V1 kernels count straight into the statistics words
+            total.n_units += (int64_t)hstat[0]; total.n_units_culled += (int64_t)hstat[1];
+            total.n_pairs += (int64_t)hstat[2]; total.n_grad_pairs += (int64_t)hstat[3];
+        } else if (groups > 1) {
+            rc = fetch_stats(c);                 // ragged input: the per-group counts have to be added up now
+            if (rc) return rc;
+            total.n_units += c->last_stats.n_units; total.n_units_culled += c->last_stats.n_units_culled;
+            total.n_pairs += c->last_stats.n_pairs; total.n_grad_pairs += c->last_stats.n_grad_pairs;
+        }
         for (int b = 0; b < nb; b++) {
-            const double *o = c->h_out.data() + ostride * b;
+            const double *o = hout + ostride * b;
             cost_inout[start + b] += o[0];
             double *gT = gradT_inout[start + b], *gC = gradC_inout[start + b];
             for (int i = 0; i < n; i++) gT[i] += o[1 + i];
@@ -597,9 +623,14 @@ extern "C" int isdf_eval(isdf_ctx *c, int n_traj, const int *N, const double *co
         }
         start = end;
     }
-    c->last_stats = total;
-    c->stats_cached = true;
-    if (total.overflow) return fail(c, ISDF_ERR_OVERFLOW, "a bounded device work list overflowed; result invalid");
+    if (groups > 1 || c->cfg.variant == ISDF_V1_SWEPT) {
+        total.overflow = overflow ? 1 : 0;
+        c->last_stats = total;
+        c->stats_cached = true;
+    } else {
+        c->stats_cached = false;                 // isdf_get_stats counts the pairs of the last launch when asked
+    }
+    if (overflow) return fail(c, ISDF_ERR_OVERFLOW, "a bounded device work list overflowed; result invalid");
     return ISDF_OK;
 }
 
