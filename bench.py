@@ -29,6 +29,23 @@ import __graft_entry__ as graft  # noqa: E402
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md
 
 
+def compulsory_bytes(T, cm, N, K, k, grid, res):
+    """Unique ESDF voxels under the tiles of all N*(K+1) samples x 4 B + per-sample coefficients / T / outputs (the
+    compulsory traffic if every byte were read once): numpy restatement of the tile boxes (getPointsInAABB floor indexing)."""
+    c6 = cm.reshape(3, 6 * N).T.reshape(N, 6, 3)                   # piece, power, axis
+    touched = np.zeros((grid, grid, grid), dtype=bool)
+    half = k * res / 2
+    for i in range(N):
+        t = np.arange(K + 1) * (T[i] / K)
+        pw = np.stack([t ** p for p in range(6)], axis=1)          # (K+1, 6)
+        pos = pw @ c6[i]                                           # (K+1, 3)
+        lo = np.clip(np.floor((np.clip(pos - half, 0, grid * res)) / res).astype(int), 0, grid - 1)
+        hi = np.clip(np.floor((np.clip(pos + half, 0, grid * res)) / res).astype(int), 0, grid - 1)
+        for a, b in zip(lo, hi):
+            touched[a[0]:b[0] + 1, a[1]:b[1] + 1, a[2]:b[2] + 1] = True
+    return int(touched.sum()) * 4 + N * (K + 1) * (144 + 8 + 152)
+
+
 def algorithmic_bytes_per_eval(k, s_vox=4):
     """tile staged once + trilinear corners + 6x3 coefficients + T_i + 19 partial outputs."""
     return k ** 3 * s_vox + 8 * s_vox + 144 + 8 + 152
@@ -148,10 +165,19 @@ def main():
                 traffic = tj.get("sweep_kernel_bytes_per_launch")
         except Exception:
             traffic = None
+    # SURVEY.md 8(d) asks for the COMPULSORY lower bound next to the algorithmic figure: the unique voxels that the tiles of
+    # this rank's launch touch (neighbouring samples' tiles overlap heavily) x 4 B, plus the per-sample inputs / outputs
+    compulsory = None
+    if world == 1:
+        compulsory = compulsory_bytes(T, cm, N, K, args.kernel_size, args.grid, res)
     roofline = {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                 "kernel": "sweep_kernel", "kernel_ms": round(kern_ms, 5), "launches": n_launch,
-                "algorithmic_bytes_per_eval": B, "algorithmic_bytes_per_launch": evals_this_rank * B}
+                "algorithmic_bytes_per_eval": B, "algorithmic_bytes_per_launch": evals_this_rank * B,
+                "compulsory_bytes_per_launch": compulsory,
+                # secondary figure of SURVEY 8(d): robot-SDF evaluations per second inside the tiles (every pair costs one
+                # evaluation, every pair with a non-zero penalty six more for the central-difference gradient)
+                "pair_sdf_evals_per_s": round((stats["pairs"] + 6 * stats["grad_pairs"]) / (ms_per_step * 1e-3), 1)}
 
     result = None
     if rank == 0:
