@@ -47,7 +47,6 @@ __device__ __forceinline__ double sdf_at_time(const SweptParams &P, const TrajVi
 }
 
 __global__ __launch_bounds__(1024) void swept_prepare_kernel(const SweptParams P) {
-    __shared__ double s_D;
     __shared__ int s_n;
     const TrajView tr{P.T, P.coeffs, P.N};
     if (threadIdx.x == 0) {
@@ -57,7 +56,6 @@ __global__ __launch_bounds__(1024) void swept_prepare_kernel(const SweptParams P
         if (td < 3 * 1e2) { D = td; *P.traj_duration = D; }    // updateTraj, sw_manager.hpp:287-296
         int n = 0;
         for (double t = 0; t < D && n < P.max_coarse; t += 0.2) P.coarse_t[n++] = t;   // choiceTInit :392
-        s_D = D;
         s_n = n;
         *P.n_coarse = n;
         for (int k = 0; k < 8; k++) P.stats[k] = 0ull;
