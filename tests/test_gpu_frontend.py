@@ -133,3 +133,30 @@ def test_whole_configuration_space_matches_kernel_conv(pkg, orc, product_lib, na
         assert (ok[q] == 1) == any(bit(a) for a in range(121))      # some attitude fits <=> the search succeeds (it visits all 121)
         if ok[q]:
             assert bit(int(ki[q]))
+
+
+def test_frontend_edge_configurations(pkg, orc, product_lib):
+    """Degenerate attitude grids and kernels: a single attitude (ang_res > 2 * max), kernel_size 1 (the robot is one voxel),
+    rectangular grids (roll range != pitch range), parents outside the attitude range (rejected, never indexed)."""
+    capi, synth = pkg.capi, pkg.synth
+    res = 0.5
+    occ = synth.random_box_map((24, 20, 16), res=res, occupancy=0.15, seed=3, edge=(0.5, 1.5))
+    shape = synth.make_shape("Box", params=(0.7, 0.3, 0.2))
+    rng = np.random.default_rng(0)
+    X, Y, Z = occ.shape
+    idx = np.stack([rng.integers(0, X, 4000), rng.integers(0, Y, 4000), rng.integers(0, Z, 4000)], axis=1).astype(np.int32)
+    for fe, rolls, pitches in (
+            (capi.frontend_config(kernel_size=9, max_roll=10.0, max_pitch=10.0, ang_res=30.0), [-10.0], [-10.0]),          # 1 x 1
+            (capi.frontend_config(kernel_size=1, max_roll=45.0, max_pitch=45.0, ang_res=9.0), np.arange(-45.0, 45.1, 9.0), np.arange(-45.0, 45.1, 9.0)),
+            (capi.frontend_config(kernel_size=7, max_roll=20.0, max_pitch=40.0, ang_res=10.0), np.arange(-20.0, 20.1, 10.0), np.arange(-40.0, 40.1, 10.0))):
+        eng, o = _pair(pkg, orc, shape, occ, res, fe)
+        assert np.array_equal(eng.frontend_shape_kernels(), o.frontend_shape_kernels())
+        assert np.array_equal(eng.frontend_map_kernel(), o.frontend_map_kernel())
+        fr = rng.choice(rolls, 4000); fp = rng.choice(pitches, 4000)
+        a, b = eng.frontend_check(idx, fr, fp), o.frontend_check(idx, fr, fp)
+        assert np.array_equal(a[0], b[0]) and np.array_equal(a[3], b[3])
+        m = b[0] == 1
+        assert np.array_equal(a[1][m], b[1][m]) and np.array_equal(a[2][m], b[2][m])
+    # a parent attitude outside the grid: the reference would index visited[][] out of bounds; here the query is rejected
+    ok, _, _, ki = eng.frontend_check(idx[:8], 500.0, 0.0)
+    assert not ok.any() and (ki == -1).all()

@@ -83,3 +83,25 @@ def test_mesh_sweeps_with_a_720_face_robot(pkg, orc, product_lib):
     dt = np.abs(tg - to)
     assert dt.max() <= 2e-3 and (dt > 1e-6).mean() < 0.05, (dt.max(), (dt > 1e-6).sum())
     assert_close(gT, gT0, "mesh-720 V1 gradT", tol=2e-2); assert_close(gC, gC0, "mesh-720 V1 gradC", tol=1e-3)
+
+
+def test_mesh_with_degenerate_and_duplicate_triangles(pkg, orc, product_lib):
+    """Zero-area triangles, duplicated triangles and an open surface: the winding-number hierarchy (zero-area items get zero
+    coefficients, HDK :6700) and the closest-point walk must still agree with the reference library / the exact search."""
+    synth = pkg.synth
+    V, F = synth.blob_mesh(8, 6)
+    V = np.concatenate([V, V[:3] + 0.0])                        # duplicate vertices
+    deg = np.array([[0, 0, 1], [2, 2, 2], [len(V) - 3, len(V) - 2, len(V) - 1]], dtype=np.int32)     # degenerate + a copy of face material
+    F2 = np.concatenate([F[:-5], deg, F[:4]]).astype(np.int32)                                       # 5 faces removed (open), 4 doubled
+    shape = synth.make_mesh_shape(V, F2)
+    cfg = synth.default_config()
+    eng = pkg.Engine(cfg); o = orc.Oracle(cfg, threads=8)
+    eng.set_shape(shape); o.set_shape(shape)
+    _need_hdk(o)
+    rng = np.random.default_rng(5)
+    Q = _queries(np.asarray(V, dtype=np.float64), rng, 1500)
+    s, g = eng.shape_eval(Q)
+    s0, g0 = o.shape_eval(Q)
+    assert np.all(np.isfinite(s)) and np.all(np.isfinite(s0))
+    assert np.all(np.abs(s - s0) <= 5e-6 * np.abs(s0) + 4e-6 * np.abs(Q).max())
+    assert (np.linalg.norm(g - g0, axis=1) <= 1e-6).mean() > 0.995     # doubled faces tie exactly: either copy's closest point
