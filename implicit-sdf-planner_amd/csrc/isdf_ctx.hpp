@@ -8,6 +8,7 @@
 using namespace isdf;
 
 struct ProfEvent { hipEvent_t a, b, c, d; };   // start/stop of the dominant kernel, start/stop of the one after it
+struct isdf_xchg;
 struct isdf_ctx {
     isdf_config cfg;
     int device = 0;
@@ -73,7 +74,9 @@ struct isdf_ctx {
         void *d_row_list = nullptr; int *d_row_ptr = nullptr; int n_row_list = 0;      // non-empty rows per attitude
         unsigned *d_cspace = nullptr;                                                    // 4 dwords per voxel
     } fe;
+    struct isdf_xchg *xchg = nullptr;           // peer-to-peer exchange of the multi-GPU path (csrc/xchg.hip)
 };
+void isdf_xchg_release(isdf_ctx *c);          // xchg.hip: closes the peer mappings, frees the mailbox (isdf_destroy)
 void isdf_frontend_release(isdf_ctx *c);      // frontend.hip: frees the tables (isdf_destroy)
 
 #define HIPCHK(ctx, call)                                                                          \

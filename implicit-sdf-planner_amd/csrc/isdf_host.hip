@@ -156,6 +156,7 @@ extern "C" int isdf_destroy(isdf_ctx *c) {
     if (c->h_pin) (void)hipHostFree(c->h_pin);
     if (c->h_eval_pin) (void)hipHostFree(c->h_eval_pin);
     isdf_frontend_release(c);
+    isdf_xchg_release(c);
     void *ptrs[] = {c->d_tail_ticket, c->d_cb, c->d_esdf, c->d_occ, c->d_points, c->d_tstar, c->d_acc, c->d_sample_info, c->d_bits, c->d_piece_cost, c->d_in, c->d_out, c->d_stats,
                     c->d_traj_duration, c->d_coarse_t, c->d_coarse_pose, c->d_n_coarse, c->d_point_partial, c->d_point_piece, c->d_hist, c->d_dbg};
     for (void *p : ptrs) if (p) (void)hipFree(p);

@@ -1,0 +1,189 @@
+// The one exchange step of the multi-GPU path: the sum of the ranks' packed [cost | gradT | gradC] vectors.
+// RCCL's all-reduce costs ~20-30 us for these 6-50 KB on one xGMI node - about as long as the whole optimizer step - so the
+// library also offers a ONE-SHOT peer-to-peer form for the ranks of one node: every rank stores its vector straight into a
+// mailbox slot on every peer (xGMI peer stores through IPC-mapped, uncached device memory), raises a sequence flag there,
+// waits for its own mailbox to fill, and adds the slots in RANK ORDER - one kernel, no ring, and every rank forms bit for bit
+// the same sum.  Mailboxes are double-buffered by sequence parity (a rank can only be one exchange ahead of a peer, because
+// finishing exchange k needs every peer's flag k).  Every wait is bounded: on a time-out the status word is set and the
+// caller falls back to RCCL (implicit-sdf-planner_amd/parallel.py checks the path against RCCL before using it).
+#include "isdf_ctx.hpp"
+#include <hip/hip_runtime.h>
+#include <algorithm>
+#include <cstring>
+
+namespace isdf {
+
+constexpr int XCHG_MAX_WORLD = 16;
+constexpr long long XCHG_SPIN_LIMIT = 1ll << 22;       // x ~64 ns sleep + one flag load: ~0.5 s
+
+struct XchgParams {
+    int rank, world;
+    size_t slot_doubles;                  // capacity of one slot
+    unsigned long long seq;               // this exchange (1, 2, ...)
+    double *peer_slots[XCHG_MAX_WORLD];   // base of rank r's mailbox data: [2 parities][world slots][slot_doubles]
+    unsigned long long *peer_flags[XCHG_MAX_WORLD];   // rank r's flags: [2][world]
+    unsigned *status;                     // device word: != 0 after a time-out
+    unsigned long long *pushes;           // device counter of completed pushes (world - 1 per exchange), local to this rank
+};
+
+// grid: one block per PEER pushes (blockIdx.x < world - 1), then every block takes part in the wait + rank-order sum
+__global__ __launch_bounds__(1024) void xchg_allreduce_kernel(XchgParams X, double *__restrict__ buf, size_t count) {
+    const int par = (int)(X.seq & 1ull);
+    const int nb = gridDim.x;
+    // ---- push: this rank's vector into slot [par][rank] of every peer, then the flag
+    for (int pb = blockIdx.x; pb < X.world - 1; pb += nb) {
+        const int peer = pb < X.rank ? pb : pb + 1;
+        double *dst = X.peer_slots[peer] + ((size_t)par * X.world + X.rank) * X.slot_doubles;
+        for (size_t i = threadIdx.x; i < count; i += blockDim.x) __builtin_nontemporal_store(buf[i], dst + i);
+        __threadfence_system();
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            __hip_atomic_store(X.peer_flags[peer] + (size_t)par * X.world + X.rank, X.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+            __hip_atomic_fetch_add(X.pushes, 1ull, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        __syncthreads();
+    }
+    // ---- wait: every peer's flag in MY mailbox (bounded)
+    __shared__ int s_ok;
+    if (threadIdx.x == 0) {
+        int ok = 1;
+        const unsigned long long *mine = X.peer_flags[X.rank] + (size_t)par * X.world;
+        for (int r = 0; r < X.world && ok; r++) {
+            if (r == X.rank) continue;
+            long long spins = 0;
+            while (__hip_atomic_load(mine + r, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) != X.seq) {
+                __builtin_amdgcn_s_sleep(1);
+                if (++spins > XCHG_SPIN_LIMIT) { ok = 0; break; }
+            }
+        }
+        // the sum below overwrites buf: every push of THIS rank (possibly by another block) must have read it first
+        {
+            const unsigned long long want = X.seq * (unsigned long long)(X.world - 1);
+            long long spins = 0;
+            while (ok && __hip_atomic_load(X.pushes, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < want) {
+                __builtin_amdgcn_s_sleep(1);
+                if (++spins > XCHG_SPIN_LIMIT) ok = 0;
+            }
+        }
+        if (!ok) atomicExch(X.status, 1u);
+        s_ok = ok;
+    }
+    __syncthreads();
+    if (!s_ok) return;
+    __threadfence_system();
+    // ---- sum in rank order (own contribution straight from buf); every rank performs the same additions
+    const double *slots = X.peer_slots[X.rank] + (size_t)par * X.world * X.slot_doubles;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += (size_t)nb * blockDim.x) {
+        double s = 0.0;
+        for (int r = 0; r < X.world; r++) s += (r == X.rank) ? buf[i] : __builtin_nontemporal_load(slots + (size_t)r * X.slot_doubles + i);
+        buf[i] = s;
+    }
+}
+
+}  // namespace isdf
+
+using namespace isdf;
+
+struct isdf_xchg {
+    int rank = 0, world = 1;
+    size_t slot_doubles = 0;
+    void *own = nullptr;                        // this rank's mailbox (uncached device memory): data, then flags
+    size_t own_bytes = 0, flags_offset = 0;
+    void *peer_base[XCHG_MAX_WORLD] = {nullptr};
+    bool opened[XCHG_MAX_WORLD] = {false};
+    unsigned *d_status = nullptr;               // [status word | pad | 64-bit push counter]
+    unsigned long long seq = 0;
+    bool connected = false;
+};
+
+static void xchg_free(isdf_ctx *c) {
+    isdf_xchg *x = c->xchg;
+    if (!x) return;
+    for (int r = 0; r < x->world; r++)
+        if (x->opened[r] && x->peer_base[r]) (void)hipIpcCloseMemHandle(x->peer_base[r]);
+    if (x->own) (void)hipFree(x->own);
+    if (x->d_status) (void)hipFree(x->d_status);
+    delete x;
+    c->xchg = nullptr;
+}
+void isdf_xchg_release(isdf_ctx *c) { xchg_free(c); }
+
+extern "C" int isdf_xchg_create(isdf_ctx *c, int rank, int world, size_t max_doubles, void *handle_out64) {
+    if (!c) return ISDF_ERR_INVALID_ARG;
+    if (world < 2 || world > XCHG_MAX_WORLD || rank < 0 || rank >= world || max_doubles == 0 || !handle_out64) return isdf_fail(c, ISDF_ERR_INVALID_ARG, "bad exchange setup");
+    static_assert(sizeof(hipIpcMemHandle_t) == 64, "IPC handle size");
+    HIPCHK(c, hipSetDevice(c->device));
+    xchg_free(c);
+    isdf_xchg *x = new isdf_xchg();
+    c->xchg = x;
+    x->rank = rank; x->world = world;
+    x->slot_doubles = (max_doubles + 63) / 64 * 64;
+    const size_t data_bytes = (size_t)2 * world * x->slot_doubles * sizeof(double);
+    x->flags_offset = (data_bytes + 255) / 256 * 256;
+    x->own_bytes = x->flags_offset + (size_t)2 * world * sizeof(unsigned long long);
+    // uncached (fine-grained) device memory: peers' stores over xGMI become visible to this device's loads without cache games
+    if (hipExtMallocWithFlags(&x->own, x->own_bytes, hipDeviceMallocUncached) != hipSuccess) { xchg_free(c); return isdf_fail(c, ISDF_ERR_HIP, "uncached mailbox allocation failed"); }
+    HIPCHK(c, hipMemset(x->own, 0, x->own_bytes));
+    HIPCHK(c, hipMalloc(&x->d_status, 16));
+    HIPCHK(c, hipMemset(x->d_status, 0, 16));
+    HIPCHK(c, hipDeviceSynchronize());
+    hipIpcMemHandle_t h;
+    if (hipIpcGetMemHandle(&h, x->own) != hipSuccess) { xchg_free(c); return isdf_fail(c, ISDF_ERR_HIP, "hipIpcGetMemHandle failed"); }
+    std::memcpy(handle_out64, &h, 64);
+    return ISDF_OK;
+}
+
+extern "C" int isdf_xchg_connect(isdf_ctx *c, const void *handles) {
+    if (!c || !handles) return ISDF_ERR_INVALID_ARG;
+    isdf_xchg *x = c->xchg;
+    if (!x) return isdf_fail(c, ISDF_ERR_STATE, "isdf_xchg_create has not been called");
+    HIPCHK(c, hipSetDevice(c->device));
+    for (int r = 0; r < x->world; r++) {
+        if (r == x->rank) { x->peer_base[r] = x->own; continue; }
+        hipIpcMemHandle_t h;
+        std::memcpy(&h, (const char *)handles + (size_t)64 * r, 64);
+        void *p = nullptr;
+        if (hipIpcOpenMemHandle(&p, h, hipIpcMemLazyEnablePeerAccess) != hipSuccess || !p) {
+            (void)hipGetLastError();
+            return isdf_fail(c, ISDF_ERR_HIP, "hipIpcOpenMemHandle failed (peer memory not reachable)");
+        }
+        x->peer_base[r] = p; x->opened[r] = true;
+    }
+    x->connected = true;
+    return ISDF_OK;
+}
+
+extern "C" int isdf_xchg_allreduce(isdf_ctx *c, double *d_buf, size_t count, void *stream) {
+    if (!c || !d_buf) return ISDF_ERR_INVALID_ARG;
+    isdf_xchg *x = c->xchg;
+    if (!x || !x->connected) return isdf_fail(c, ISDF_ERR_STATE, "exchange not connected");
+    if (count > x->slot_doubles) return isdf_fail(c, ISDF_ERR_INVALID_ARG, "vector longer than the exchange was created for");
+    XchgParams X{};
+    X.rank = x->rank; X.world = x->world; X.slot_doubles = x->slot_doubles; X.seq = ++x->seq; X.status = x->d_status; X.pushes = (unsigned long long *)((char *)x->d_status + 8);
+    for (int r = 0; r < x->world; r++) {
+        X.peer_slots[r] = (double *)x->peer_base[r];
+        X.peer_flags[r] = (unsigned long long *)((char *)x->peer_base[r] + x->flags_offset);
+    }
+    const int blocks = std::max(x->world - 1, (int)std::min<size_t>(8, (count + 1023) / 1024));
+    hipLaunchKernelGGL(xchg_allreduce_kernel, dim3(blocks), dim3(1024), 0, (hipStream_t)stream, X, d_buf, count);
+    HIPCHK(c, hipGetLastError());
+    return ISDF_OK;
+}
+
+extern "C" int isdf_xchg_status(isdf_ctx *c) {
+    if (!c) return ISDF_ERR_INVALID_ARG;
+    isdf_xchg *x = c->xchg;
+    if (!x) return ISDF_ERR_STATE;
+    unsigned s = 0;
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipMemcpy(&s, x->d_status, sizeof(s), hipMemcpyDeviceToHost));      // synchronises with the exchanges issued so far
+    return s ? 1 : 0;
+}
+
+extern "C" int isdf_xchg_destroy(isdf_ctx *c) {
+    if (!c) return ISDF_ERR_INVALID_ARG;
+    HIPCHK(c, hipSetDevice(c->device));
+    (void)hipDeviceSynchronize();
+    xchg_free(c);
+    return ISDF_OK;
+}

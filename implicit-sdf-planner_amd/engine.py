@@ -198,6 +198,25 @@ class Engine:
         self._check(self.lib.isdf_frontend_cspace(self.h, out.ctypes.data_as(C.c_void_p) if download else None, C.byref(ms)))
         return out, ms.value
 
+    # ---- one-shot peer-to-peer exchange of the multi-GPU path (csrc/xchg.hip); see parallel.XgmiExchange
+    def xchg_create(self, rank, world, max_doubles):
+        h = (C.c_ubyte * 64)()
+        self._check(self.lib.isdf_xchg_create(self.h, int(rank), int(world), int(max_doubles), h))
+        return bytes(h)
+
+    def xchg_connect(self, handles_bytes):
+        buf = (C.c_ubyte * len(handles_bytes)).from_buffer_copy(handles_bytes)
+        self._check(self.lib.isdf_xchg_connect(self.h, buf))
+
+    def xchg_allreduce(self, d_ptr, count, stream=0):
+        self._check(self.lib.isdf_xchg_allreduce(self.h, C.c_void_p(d_ptr), int(count), C.c_void_p(stream)))
+
+    def xchg_status(self):
+        return int(self.lib.isdf_xchg_status(self.h))
+
+    def xchg_destroy(self):
+        self._check(self.lib.isdf_xchg_destroy(self.h))
+
     def set_shard(self, rank, world):
         self._check(self.lib.isdf_set_shard(self.h, rank, world))
 

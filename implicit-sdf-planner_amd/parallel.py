@@ -1,6 +1,6 @@
 """Multi-GPU plumbing of the hot path: one process per GPU, constraint points sharded across ranks
-with no data-path collective, then ONE all-reduce (RCCL over xGMI; gloo in the CPU tests) of the packed
-[cost | gradT(N) | gradC(6N x 3)] vector per optimizer step.  torch.distributed is plumbing only."""
+with no data-path collective, then ONE sum of the packed [cost | gradT(N) | gradC(6N x 3)] vector per optimizer step: RCCL's all-reduce (gloo
+in the CPU tests) or, between the GPUs of one node, the library's one-shot peer-to-peer exchange over xGMI (XgmiExchange).  torch.distributed is plumbing only."""
 import os
 
 
@@ -35,6 +35,84 @@ def allreduce_packed(out_tensor):
     return out_tensor
 
 
+class XgmiExchange:
+    """One-shot peer-to-peer all-reduce of the packed vector between the ranks of ONE node (csrc/xchg.hip), set up over an
+    initialised torch.distributed group and verified against the group's own all-reduce before use.  `ok` is False (and
+    allreduce() must not be called) when the set-up, the verification or the agreement between ranks fails - the caller then
+    stays on RCCL.  Never raises during construction."""
+
+    def __init__(self, engine, max_doubles, device):
+        import torch
+        import torch.distributed as dist
+        self.ok = False
+        self.engine = engine
+        self.why = ""
+        try:
+            rank, world = dist.get_rank(), dist.get_world_size()
+            if world < 2 or world > 16 or os.environ.get("ISDF_NO_XGMI_EXCHANGE") == "1":
+                self.why = "disabled or unsupported world size"
+                raise RuntimeError(self.why)
+            # plumbing tensors go where the group's backend wants them (RCCL: device, gloo: host)
+            self._pd = device if dist.get_backend() == "nccl" else torch.device("cpu")
+            local_ok = 1
+            handle = b"\0" * 64
+            try:
+                handle = engine.xchg_create(rank, world, max_doubles)
+            except Exception as e:        # noqa: BLE001 - any failure means "use RCCL"
+                local_ok = 0; self.why = f"create: {e}"
+            # all-gather the 64-byte IPC handles through the group (works on nccl and gloo alike)
+            mine = torch.tensor(list(handle), dtype=torch.uint8, device=self._pd)
+            allh = [torch.zeros(64, dtype=torch.uint8, device=self._pd) for _ in range(world)]
+            dist.all_gather(allh, mine)
+            if self._agree(local_ok, self._pd):
+                try:
+                    engine.xchg_connect(b"".join(bytes(t.cpu().numpy().tobytes()) for t in allh))
+                except Exception as e:    # noqa: BLE001
+                    local_ok = 0; self.why = f"connect: {e}"
+            else:
+                local_ok = 0
+            if not self._agree(local_ok, self._pd):
+                raise RuntimeError(self.why or "a peer could not set the exchange up")
+            # verification: random vectors, this path vs the group's all-reduce, several rounds (also exercises both parities)
+            gen = torch.Generator(device="cpu"); gen.manual_seed(1234 + rank)
+            good = 1
+            stream = torch.cuda.current_stream().cuda_stream
+            for it in range(6):
+                n = max(1, min(max_doubles, (max_doubles * (it + 1)) // 6))
+                v = torch.randn(n, dtype=torch.float64, generator=gen).to(device)
+                ref = v.to(self._pd).clone(); dist.all_reduce(ref); ref = ref.to(device)
+                got = v.clone()
+                engine.xchg_allreduce(got.data_ptr(), n, stream)
+                torch.cuda.synchronize()
+                scale = float(ref.abs().max().item()) + 1e-300
+                if engine.xchg_status() != 0 or not bool(((got - ref).abs().max() <= 1e-12 * scale).item()):
+                    good = 0; self.why = "verification against the group's all-reduce failed"
+                    break
+            if not self._agree(good, self._pd):
+                raise RuntimeError(self.why or "verification failed on a peer")
+            self.ok = True
+        except Exception as e:            # noqa: BLE001
+            self.why = self.why or str(e)
+            try:
+                engine.xchg_destroy()
+            except Exception:             # noqa: BLE001
+                pass
+
+    @staticmethod
+    def _agree(flag, device):
+        import torch
+        import torch.distributed as dist
+        t = torch.tensor([int(flag)], dtype=torch.int32, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MIN)
+        return int(t.item()) == 1
+
+    def allreduce(self, tensor):
+        """In-place sum over the ranks, asynchronous on torch's current stream."""
+        import torch
+        self.engine.xchg_allreduce(tensor.data_ptr(), tensor.numel(), torch.cuda.current_stream().cuda_stream)
+        return tensor
+
+
 def unpack_out(out, N):
     """(cost, gradT[N], gradC[18N col-major]) views of one trajectory's packed output."""
     return out[0], out[1:1 + N], out[1 + N:1 + 19 * N]
@@ -47,7 +125,7 @@ class _DeviceDoubles:
         self.__cuda_array_interface__ = {"shape": (int(count),), "typestr": "<f8", "data": (int(ptr), False), "version": 2}
 
 
-def cost_function_allreduced(engine, x):
+def cost_function_allreduced(engine, x, exchange=None):
     """The full objective callback on a sharded engine (engine.set_shard(rank, world) done): MINCO + this rank's share of
     the sweeps, ONE all-reduce of the partial sums over RCCL, then the rest of the callback - the same (cost, g) on every
     rank.  Runs on torch's current stream so that the collective is ordered after the sweeps."""
@@ -55,5 +133,8 @@ def cost_function_allreduced(engine, x):
     stream = torch.cuda.current_stream().cuda_stream
     ptr, count = engine.cost_function_launch(x, stream)
     part = torch.as_tensor(_DeviceDoubles(ptr, count), device=torch.device("cuda", torch.cuda.current_device()))
-    allreduce_packed(part)
+    if exchange is not None and exchange.ok:
+        exchange.allreduce(part)          # one-shot peer-to-peer sum over xGMI (XgmiExchange)
+    else:
+        allreduce_packed(part)
     return engine.cost_function_finish(stream)

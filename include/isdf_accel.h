@@ -236,6 +236,22 @@ int isdf_cost_function_finish(isdf_ctx *ctx, double *g, double *cost_out, void *
 /* energy | swept-volume sweep | integral sweep | rho*sum(T) of the last isdf_cost_function call */
 int isdf_cost_parts(const isdf_ctx *ctx, double parts[4]);
 
+/* ---- multi-GPU exchange over xGMI peer stores (one node) -------------------------------------------------------- */
+/* The sum of the ranks' packed vectors is the ONE exchange step of the sharded path.  Any all-reduce works (RCCL through
+ * torch.distributed: INTEGRATION.md); for vectors this small (6-50 KB) its latency rivals the whole optimizer step, so the
+ * library also provides a one-shot peer-to-peer form: every rank stores its vector into a mailbox slot on every peer
+ * (IPC-mapped, uncached device memory), raises a flag, waits (bounded) for its own mailbox and adds the slots in rank order -
+ * one kernel per step, bit-identical sums on all ranks.  Setup: every rank calls isdf_xchg_create (64-byte IPC handle out),
+ * the host all-gathers the handles (any transport), every rank calls isdf_xchg_connect with the world x 64 bytes in rank
+ * order.  isdf_xchg_allreduce is asynchronous on `stream` and sums d_buf[0..count) in place; isdf_xchg_status returns 1 if
+ * a wait ever timed out (the result of that exchange is invalid: fall back to RCCL).  All ranks must be on one node with
+ * peer access between their devices. */
+int isdf_xchg_create(isdf_ctx *ctx, int rank, int world_size, size_t max_doubles, void *ipc_handle_out_64bytes);
+int isdf_xchg_connect(isdf_ctx *ctx, const void *ipc_handles_world_x_64bytes);
+int isdf_xchg_allreduce(isdf_ctx *ctx, double *d_buf, size_t count, void *stream);
+int isdf_xchg_status(isdf_ctx *ctx);
+int isdf_xchg_destroy(isdf_ctx *ctx);
+
 /* ---- optimizer driver ----------------------------------------------------------------------------------------- */
 /* L-BFGS behind the callback: lbfgs::lbfgs_optimize of src/utils/include/utils/lbfgs.hpp:480-835 (the LBFGS-Lite fork
  * the reference ships; its mid end calls it at src/planner_algorithm/src/mid_end.cpp:48-62).  Field names and defaults

@@ -1,0 +1,70 @@
+"""Worker of tests/test_gpu_xchg.py: one of several processes that all use GPU 0 (the exchange's IPC, flag and double-buffer
+logic does not care which device a peer's mailbox lives on), rendezvous over gloo."""
+import os, sys
+import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+import torch
+import torch.distributed as dist
+import __graft_entry__ as graft
+
+pkg = graft.load_package(); capi, synth, par = pkg.capi, pkg.synth, pkg.parallel
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+dist.init_process_group("gloo", rank=rank, world_size=world)
+dev = torch.device("cuda", 0)
+torch.cuda.set_device(dev)
+eng = pkg.Engine(synth.default_config(capi.V3_ESDF_TILE, device=0))
+N_MAX = 7601                                   # 1 + 19 * 400: the packed vector of the 400-piece configuration
+x = par.XgmiExchange(eng, N_MAX, dev)
+assert x.ok, f"rank {rank}: exchange not usable: {x.why}"
+gen = torch.Generator(device="cpu"); gen.manual_seed(99 + rank)
+for it in range(300):
+    n = [1, 7, 761, 4096, N_MAX][it % 5]
+    v = torch.randn(n, dtype=torch.float64, generator=gen)
+    ref = v.clone(); dist.all_reduce(ref)
+    d = v.to(dev)
+    x.allreduce(d)
+    if it % 7 == 0:
+        torch.cuda.synchronize()               # most exchanges are queued back to back (ranks run ahead of each other)
+    got = d.cpu()
+    assert eng.xchg_status() == 0
+    assert torch.allclose(got, ref, rtol=0, atol=1e-12 * float(ref.abs().max() + 1)), (rank, it, float((got - ref).abs().max()))
+    # every rank forms the SAME sum bit for bit (rank-order addition)
+    allv = [torch.zeros_like(got) for _ in range(world)]
+    dist.all_gather(allv, got)
+    assert all(torch.equal(allv[0], a) for a in allv), (rank, it)
+# run-ahead: 2000 exchanges queued back to back with no host synchronisation in between (a fast rank is at most one
+# exchange ahead of a slow one: the double-buffered mailboxes must cope).  d <- allreduce(d) / world keeps d at the mean.
+d = torch.full((N_MAX,), float(rank + 1), dtype=torch.float64, device=dev)
+for it in range(2000):
+    x.allreduce(d)
+    d.mul_(1.0 / world)
+    if rank == it % world and it % 97 == 0:
+        torch.cuda.synchronize()               # perturb the ranks' relative timing
+torch.cuda.synchronize()
+assert eng.xchg_status() == 0
+assert torch.allclose(d.cpu(), torch.full((N_MAX,), (world + 1) / 2.0, dtype=torch.float64), rtol=1e-12, atol=0), (rank, float(d[0]))
+
+# a sharded engine step through the exchange == through the group's all-reduce
+occ = synth.random_box_map((48, 48, 32), res=0.5, occupancy=0.12, seed=3, edge=(1.0, 3.0))
+esdf = synth.esdf_from_occupancy(occ, 0.5)
+ext = np.array(occ.shape) * 0.5
+T, Cf = synth.random_trajectory(ext, 6, seed=21, piece_T=1.0, jitter=0.5, margin=4.0, occ=occ, res=0.5)
+cm = synth.colmajor(Cf)
+cfg = synth.default_config(capi.V3_ESDF_TILE, device=0, kernel_size=9, integral_intervs=12, safety_hor=0.5)
+e2 = pkg.Engine(cfg); e2.set_grid(esdf, (0, 0, 0), 0.5, capi.GRID_ESDF); e2.set_shape(synth.make_shape("RoundedCone", params=(0.6, 0.25, 1.6)))
+e2.set_shard(rank, world)
+x2 = par.XgmiExchange(e2, e2.out_stride(6), dev)
+assert x2.ok, x2.why
+d_T = torch.from_numpy(T).to(dev); d_C = torch.from_numpy(cm).to(dev)
+out = torch.zeros(e2.out_stride(6), dtype=torch.float64, device=dev)
+st = torch.cuda.current_stream().cuda_stream
+e2.eval_device(1, 6, d_T.data_ptr(), d_C.data_ptr(), out.data_ptr(), 0, st)
+part = out.cpu().clone(); dist.all_reduce(part)
+x2.allreduce(out); torch.cuda.synchronize()
+assert torch.allclose(out.cpu(), part, rtol=1e-13, atol=1e-13 * float(part.abs().max()))
+assert float(part[0]) > 0
+dist.barrier()
+if rank == 0:
+    print("XCHG WORKERS OK", flush=True)
+dist.destroy_process_group()

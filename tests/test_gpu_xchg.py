@@ -1,0 +1,21 @@
+"""One-shot peer-to-peer exchange of the multi-GPU path (csrc/xchg.hip) with several processes sharing the one GPU of the
+test box: IPC mapping, sequence flags, double buffering and the rank-order sum are the same code that runs between the
+GPUs of a node; what a single GPU cannot show is xGMI itself (parallel.XgmiExchange therefore verifies the path against the
+group's all-reduce at start-up on the real node and stays on RCCL if anything disagrees)."""
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_xchg_processes_sharing_one_gpu(product_lib, world):
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr", "127.0.0.1",
+           "--master-port", str(29600 + world), os.path.join(ROOT, "tests", "native", "xchg_worker.py")]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "XCHG WORKERS OK" in r.stdout, (r.stdout[-3000:], r.stderr[-3000:])
