@@ -65,6 +65,9 @@ def main():
     print("  exact rounds per wave:", pct(sc[:, 7]), " waves:", sc.shape[0])
     print("tail  start us:", pct(us(tl[:, 0])))
     print("tail  end   us:", pct(us(tl[:, 1])))
+    mk = tl[:, 2]
+    f = lambda k: ((mk >> (16 * k)) & 0xFFFF) * 16
+    print("tail  thread 0 cycles since start: derivatives", pct(f(0)), "| forward+dynamics", pct(f(1)), "| collision terms", pct(f(2)), "| backward", pct(f(3)), "| partials+sums", pct(tl[:, 3] * 16))
     print("tail  block duration us:", pct((tl[:, 1] - tl[:, 0]) / 100.0))
 
 
