@@ -438,15 +438,15 @@ __global__ __launch_bounds__(64 * SW_SAMPLES, sweep_waves_per_simd(KIND, IDENT))
         // ================= exact phase: the workgroup's candidate chunks (64 voxels of one sample), spread evenly
         // over its waves.  Plan (identical in every wave): each wave keeps up to `quota` chunks of its own sample,
         // the rest go to the waves with spare room, in sample order.
-        int cnt[SW_SAMPLES], head[SW_SAMPLES], nch[SW_SAMPLES], own[SW_SAMPLES];
-        int C = 0, all_done = 1;
+        // (the per-sample chunk counts are kept packed, 4 bits each, and everything else is re-derived where needed: scalar
+        // registers are the scarce resource of this kernel - what does not fit is spilled through VALU lanes)
+        int nch_pk = 0, C = 0, all_done = 1;
 #pragma unroll
         for (int w = 0; w < SW_SAMPLES; w++) {
-            cnt[w] = __builtin_amdgcn_readfirstlane(s_plan[w][0]);
-            head[w] = __builtin_amdgcn_readfirstlane(s_plan[w][1]);
+            const int n_w = (__builtin_amdgcn_readfirstlane(s_plan[w][0]) + 63) >> 6;
             all_done &= __builtin_amdgcn_readfirstlane(s_plan[w][2]);
-            nch[w] = (cnt[w] + 63) >> 6;
-            C += nch[w];
+            nch_pk |= n_w << (4 * w);
+            C += n_w;
         }
         const int quota = (C + SW_SAMPLES - 1) / SW_SAMPLES;
         int my_off = 0, my_spare = 0, my_own = 0;      // this wave: first leftover index it takes, how many, own chunks
@@ -454,9 +454,9 @@ __global__ __launch_bounds__(64 * SW_SAMPLES, sweep_waves_per_simd(KIND, IDENT))
             int off = 0;
 #pragma unroll
             for (int w = 0; w < SW_SAMPLES; w++) {
-                own[w] = min(nch[w], quota);
-                const int spare = quota - own[w];
-                if (w == wave) { my_off = off; my_spare = spare; my_own = own[w]; }
+                const int own_w = min((nch_pk >> (4 * w)) & 15, quota);
+                const int spare = quota - own_w;
+                if (w == wave) { my_off = off; my_spare = spare; my_own = own_w; }
                 off += spare;
             }
         }
@@ -473,8 +473,8 @@ __global__ __launch_bounds__(64 * SW_SAMPLES, sweep_waves_per_simd(KIND, IDENT))
                 cs = -1;
 #pragma unroll
                 for (int w = 0; w < SW_SAMPLES; w++) {
-                    const int left = nch[w] - own[w];
-                    if (cs < 0) { if (e < left) { cs = w; cc = own[w] + e; } else e -= left; }
+                    const int nch_w = (nch_pk >> (4 * w)) & 15, own_w = min(nch_w, quota), left = nch_w - own_w;
+                    if (cs < 0) { if (e < left) { cs = w; cc = own_w + e; } else e -= left; }
                 }
                 if (cs < 0) break;                     // no leftover chunk for this slot
             }
@@ -489,9 +489,7 @@ __global__ __launch_bounds__(64 * SW_SAMPLES, sweep_waves_per_simd(KIND, IDENT))
                 cur_s = cs;
             }
             // ---- (4) exact fp64 pass over one chunk: grad_cost_p (:766-824)
-            int ccnt = 0, chead = 0;
-#pragma unroll
-            for (int w = 0; w < SW_SAMPLES; w++) if (w == cs) { ccnt = cnt[w]; chead = head[w]; }
+            const int ccnt = __builtin_amdgcn_readfirstlane(s_plan[cs][0]), chead = __builtin_amdgcn_readfirstlane(s_plan[cs][1]);
             const int n = min(64, ccnt - (cc << 6));
             const unsigned ent = s_near[cs][(chead + (cc << 6) + min(lane, n - 1)) & (SW_NEAR_CAP - 1)];
             double v[ACC_STRIDE] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -532,9 +530,7 @@ __global__ __launch_bounds__(64 * SW_SAMPLES, sweep_waves_per_simd(KIND, IDENT))
         __syncthreads();
         // chunk results of this wave's sample, in chunk order
         {
-            int my_nch = 0;
-#pragma unroll
-            for (int w = 0; w < SW_SAMPLES; w++) if (w == wave) my_nch = nch[w];
+            const int my_nch = (nch_pk >> (4 * wave)) & 15;
             for (int cidx = 0; cidx < my_nch; cidx++) {
                 if (lane < ACC_STRIDE) tot += s_res[wave][cidx][lane];
                 else if (lane < ACC_STRIDE + 2) tot_n += s_resn[wave][cidx][lane - ACC_STRIDE];
