@@ -1,0 +1,82 @@
+#!/usr/bin/env python
+"""Generates tests/golden/ref_*.npz: outputs of THE REFERENCE'S OWN CODE (oracle/_ref/libref_sweeps.so - line ranges of the
+reference compiled from /root/reference, see oracle/ref_build) on seeded small worlds.  The fixtures travel with the repository,
+so the oracle (CPU tests) and the device (GPU tests) are checked against the reference even where neither /root/reference nor
+oracle/_ref exists.  Needs /root/reference at generation time only:
+    make -C oracle ref && python tests/golden/make_golden_ref.py
+"""
+import os
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import __graft_entry__ as g  # noqa: E402
+from common import small_world, traj  # noqa: E402
+
+POLY = (0.1, -0.05, 0.08, 20, -10, 40)          # body offset of the robot (yaml poly_params)
+V1_SHAPES = ["RoundedCone", "Box", "Torus_big"]
+
+
+def world(pkg, orc, variant, shape_name, seed, **cfgkw):
+    capi, synth = pkg.capi, pkg.synth
+    occ, esdf, res = small_world(pkg, seed=seed)
+    kw = dict(kernel_size=9, integral_intervs=16, safety_hor=0.5)
+    kw.update(cfgkw)
+    cfg = synth.default_config(variant, **kw)
+    shape = synth.make_shape(shape_name, poly_params=POLY)
+    return cfg, kw, occ, res, shape
+
+
+def main():
+    pkg = g.load_package(); orc = g.load_oracle(); capi, synth = pkg.capi, pkg.synth
+    # ---- V1 swept-volume sweep (addSaftyPenaOnSweptVolumeParallel + the swept SDF query)
+    for name in V1_SHAPES:
+        cfg, kw, occ, res, shape = world(pkg, orc, capi.V1_SWEPT, name, 3)
+        ref = orc.RefWorld(cfg, name, shape, res, threads=8); ref.set_occupancy(occ, (0, 0, 0), res)
+        N = 6
+        T, cm = traj(pkg, occ, res, N=N, seed=43)
+        way = cm.reshape(3, -1).T.reshape(N, 6, 3)[1:, 0, :]
+        pts = synth.constraint_points(occ, (0, 0, 0), res, way, half=3.0)
+        ref.set_points(pts)
+        c, gT, gC, ts = ref.sweep_swept(T, cm)
+        np.savez_compressed(os.path.join(HERE, f"ref_v1_{name}.npz"), occ=occ, res=res, T=T, coeffs=cm, points=pts, cost=c, gradT=gT, gradC=gC, tstar=ts,
+                            cfg_safety_hor=kw["safety_hor"])
+        print(f"ref_v1_{name}: M={len(pts)} cost={c:.9g}")
+    # ---- integral sweep, dynamics penalties (addTimeIntPenaltyParallel)
+    dyn = dict(enable_pos=0, vmax=1.5, omgmax=0.6, thetamax=0.25)
+    cfg, kw, occ, res, shape = world(pkg, orc, capi.V3_ESDF_TILE, "RoundedCone", 3, **dyn)
+    ref = orc.RefWorld(cfg, "RoundedCone", shape, res, threads=8); ref.set_occupancy(occ, (0, 0, 0), res)
+    T, cm = traj(pkg, occ, res, N=6, seed=11, piece_T=0.45)
+    c, gT, gC = ref.sweep_integral(T, cm)
+    np.savez_compressed(os.path.join(HERE, "ref_integral.npz"), occ=occ, res=res, T=T, coeffs=cm, cost=c, gradT=gT, gradC=gC, **{f"cfg_{k}": v for k, v in dyn.items()})
+    print(f"ref_integral: cost={c:.9g}")
+    # ---- ESDF (GridMap3D::generateESDF3d)
+    occ9, _, res9 = small_world(pkg, seed=9)
+    ref.set_occupancy(occ9, (0, 0, 0), res9)
+    e = ref.generate_esdf()
+    np.savez_compressed(os.path.join(HERE, "ref_esdf.npz"), occ=occ9, res=res9, esdf=e.astype(np.float32))
+    # ---- front end (attitude kernels, generateMapKernel, checkKernelValue)
+    occf = synth.random_box_map((40, 36, 20), res=0.5, occupancy=0.10, seed=5, edge=(0.5, 2.0))
+    for name, k in (("Box", 13), ("Torus_big", 15)):
+        kwf = dict(params=(0.9, 0.35, 0.25)) if name == "Box" else {}
+        shape = synth.make_shape(name, poly_params=(0.05, -0.1, 0.02, 12, -8, 25), **kwf)
+        cfg = synth.default_config(capi.V1_SWEPT)
+        fe = capi.frontend_config(kernel_size=k)
+        w = orc.RefWorld(cfg, name, shape, 0.5); w.set_occupancy(occf, (0, 0, 0), 0.5); w.frontend_build(fe, name)
+        rng = np.random.default_rng(3)
+        free = np.argwhere(occf == 0)
+        idx = free[rng.choice(len(free), 400, replace=False)].astype(np.int32)
+        fr = rng.choice(np.arange(-45.0, 45.1, 9.0), 400); fp = rng.choice(np.arange(-45.0, 45.1, 9.0), 400)
+        res_q = np.array([w.frontend_check(idx[q], fr[q], fp[q]) for q in range(400)])
+        np.savez_compressed(os.path.join(HERE, f"ref_frontend_{name}.npz"), occ=occf, res=0.5, kernel_size=k, shape_kernels=w.frontend_shape_kernels(),
+                            map_kernel=w.frontend_map_kernel(), index=idx, father_roll=fr, father_pitch=fp, ok=res_q[:, 0].astype(np.uint8),
+                            child_roll=res_q[:, 1], child_pitch=res_q[:, 2], box_params=np.array(kwf.get("params", (0, 0, 0))))
+        print(f"ref_frontend_{name}: feasible {res_q[:, 0].mean():.2f}")
+
+
+if __name__ == "__main__":
+    main()
