@@ -160,3 +160,41 @@ def test_c5_swept_mesh_512_shards(pkg, orc, product_lib):
     c0, gT0, gC0, _ = o.eval(T, cm)
     assert c0 > 0 and abs(c - c0) <= REL_TOL * abs(c0)
     assert_close(gC, gC0, "C5 gradC vs oracle", tol=1e-3)      # float winding-number noise, see test_mesh_kind_matches_oracle
+
+
+def test_c1_narrow_slit_mesh_robot(pkg, orc, product_lib):
+    """configs[0] (demo1.launch): a narrow-slit map, a mesh robot (the concave L prism) and a ~20-piece trajectory through the
+    slit on the reference's live path - the swept-volume sweep - device vs the oracle (reference winding-number library)."""
+    capi, synth = pkg.capi, pkg.synth
+    res = 0.25
+    occ = np.zeros((96, 64, 40), dtype=np.uint8)
+    occ[46:50, :, :] = 1                     # a wall across the corridor ...
+    occ[46:50, 28:36, 6:30] = 0              # ... with a 2 m x 6 m slit: the 1.6 x 1.0 x 0.5 m robot has to thread it
+    occ[20:24, 10:30, :20] = 1; occ[70:74, 34:54, 10:] = 1      # two more obstacles off the straight line
+    ext = np.array(occ.shape) * res
+    N = 20
+    p0 = np.array([3.0, 8.0, 4.5]); p1 = np.array([21.0, 8.0, 4.5])
+    lam = np.linspace(0, 1, N + 1)[1:-1]
+    rng = np.random.default_rng(7)
+    way = p0[:, None] + (p1 - p0)[:, None] * lam[None, :] + rng.normal(0, 0.15, (3, N - 1))
+    head = np.zeros((3, 3)); head[:, 0] = p0
+    tail = np.zeros((3, 3)); tail[:, 0] = p1
+    T = np.full(N, 0.8)
+    cm = synth.colmajor(synth.minco_coeffs(head, tail, way, T))
+    V, F = synth.l_prism_mesh()
+    shape = synth.make_mesh_shape(V, F)
+    cfg = synth.default_config(capi.V1_SWEPT, safety_hor=(3 ** 0.5 / 2) * res, weight_p=4000.0)
+    eng, o = make_pair(pkg, orc, cfg, shape, occ=occ, res=res, threads=30)
+    if o.mesh_backend() != 1:
+        pytest.skip("oracle/_ref/libref_fwn.so not built")
+    M = eng.gather_points(way.T, 2.0)
+    pts = eng.get_points()
+    assert M > 300
+    o.set_points(pts)
+    tg = np.zeros(M); to = np.zeros(M)
+    c, gT, gC = eng.eval_single(T, cm, tstar=tg)
+    c0, gT0, gC0, _ = o.eval(T, cm, tstar=to)
+    assert c0 > 0 and abs(c - c0) <= REL_TOL * abs(c0)
+    dt = np.abs(tg - to)
+    assert dt.max() <= 2e-3 and (dt > 1e-6).mean() < 0.05       # mesh SDF noise vs the descent's comparison chain (DESIGN 6)
+    assert_close(gC, gC0, "C1 gradC", tol=1e-3); assert_close(gT, gT0, "C1 gradT", tol=2e-2)
