@@ -576,6 +576,7 @@ __global__ __launch_bounds__(256) void stats_kernel(const SweepParams P) {
 // tail_kernel: block per piece, thread per sample
 // ---------------------------------------------------------------------------------------------------------------
 constexpr int TL_THREADS = 128;
+constexpr int TL_GROUPS = TL_THREADS / PARTIAL_STRIDE;     // 6 row groups x 20 columns
 
 __global__ __launch_bounds__(TL_THREADS) void tail_kernel(const SweepParams P) {
     __shared__ double s_val[TL_THREADS][PARTIAL_STRIDE + 1];   // +1: column reads by 20 threads hit distinct banks
@@ -607,6 +608,13 @@ __global__ __launch_bounds__(TL_THREADS) void tail_kernel(const SweepParams P) {
         const int j = j0 + threadIdx.x;
         if (j < K1) {
             const long long s = (long long)gp * K1 + j;
+            // this pose's collision sums (sweep_kernel): requested first, so the loads fly under the flatness forward pass
+            double a[ACC_STRIDE] = {0, 0, 0, 0, 0, 0, 0, 0};
+            if (P.enable_pos) {
+                const double *ap = P.acc + (size_t)(s - (long long)P.piece_begin * K1) * ACC_STRIDE;
+#pragma unroll
+                for (int q = 0; q < ACC_STRIDE; q++) a[q] = ap[q];
+            }
             Basis B;
             poly_basis(j * step, B);
             const d3 vel = ct_beta(c, ld, B.b1), acc3 = ct_beta(c, ld, B.b2), jer = ct_beta(c, ld, B.b3), sna = ct_beta(c, ld, B.b4);
@@ -642,8 +650,6 @@ __global__ __launch_bounds__(TL_THREADS) void tail_kernel(const SweepParams P) {
             }
             TL_MARK(1);
             if (P.enable_pos) {
-                // this pose's exact results (sweep_kernel)
-                const double *a = P.acc + (size_t)(s - (long long)P.piece_begin * K1) * ACC_STRIDE;
                 if (a[0] > 0.0) {
                     gradPos.x += P.weight_p * a[1]; gradPos.y += P.weight_p * a[2]; gradPos.z += P.weight_p * a[3];
                     gradQuat.w += P.weight_p * a[4]; gradQuat.x += P.weight_p * a[5];
@@ -668,9 +674,19 @@ __global__ __launch_bounds__(TL_THREADS) void tail_kernel(const SweepParams P) {
             o[19] = node * step * pena;
         }
         __syncthreads();
-        if (threadIdx.x < PARTIAL_STRIDE) {
+        // column sums in two fixed-shape stages: TL_GROUPS partial sums per column (rows g, g + TL_GROUPS, ...), then their sum
+        {
             const int n = min(TL_THREADS, K1 - j0);
-            for (int t = 0; t < n; t++) colsum += s_val[t][threadIdx.x];
+            const int col = threadIdx.x % PARTIAL_STRIDE, grp = threadIdx.x / PARTIAL_STRIDE;
+            double part = 0.0;
+            if (grp < TL_GROUPS) for (int t = grp; t < n; t += TL_GROUPS) part += s_val[t][col];
+            __syncthreads();                                   // every row has been read: rows 0..TL_GROUPS-1 are reused
+            if (grp < TL_GROUPS) s_val[grp][col] = part;
+            __syncthreads();
+            if (threadIdx.x < PARTIAL_STRIDE) {
+#pragma unroll
+                for (int g = 0; g < TL_GROUPS; g++) colsum += s_val[g][threadIdx.x];
+            }
         }
         __syncthreads();
     }
