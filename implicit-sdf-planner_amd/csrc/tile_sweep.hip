@@ -286,7 +286,8 @@ __global__ __launch_bounds__(64 * SW_SAMPLES, sweep_waves_per_simd(KIND, IDENT))
     const bool small = n_rows < (1 << 24);
     // Box: the row masks already cut the rows to the box's own inflated extent, which IS the set the fp32 test would keep (but
     // for the rounded corners): measured 52 listed -> 48 kept, so the test is skipped for this kind
-    const bool use_filter = (KIND != ISDF_SHAPE_BOX) && P.shape.filter_f32 != 0;
+    constexpr bool DIRECT = (KIND == ISDF_SHAPE_BOX);
+    const bool use_filter = !DIRECT && P.shape.filter_f32 != 0;
     float Rf[9];
 #pragma unroll
     for (int k = 0; k < 9; k++) Rf[k] = unif((float)sp.R[k]);
@@ -410,6 +411,25 @@ __global__ __launch_bounds__(64 * SW_SAMPLES, sweep_waves_per_simd(KIND, IDENT))
                 }
             } else {
                 // ---- (2b) one pass: every lane moves its lowest <= SW_PASS set bits into the ring
+                if constexpr (DIRECT) {
+                    // no fp32 test for this kind: the listed voxels ARE the candidates, written straight into the candidate ring
+                    const int room = SW_NEAR_CAP - near_cnt;
+                    if (room < 64) break;                              // ring full: the workgroup drains it first
+                    const int lim = min(SW_PASS, room >> 6);           // bits per lane that are guaranteed to fit
+                    unsigned t = hb;
+                    for (int k = 0; k < lim; k++) t &= t - 1u;
+                    unsigned take = hb ^ t;
+                    hb = t;
+                    int total;
+                    int wpos = wave_excl_scan(__popc(take), lane, total) + near_head + near_cnt;
+                    while (take) {
+                        const unsigned z = (unsigned)__ffs(take) - 1u;
+                        take &= take - 1u;
+                        s_near[wave][(wpos++) & (SW_NEAR_CAP - 1)] = pk | ((zoff + z) << 20);
+                    }
+                    near_cnt += total;
+                    cnt_passes++; cnt_listed += (unsigned)total; cnt_cand += (unsigned)total;
+                } else {
                 unsigned take = hb;
                 if (__ballot(__popc(hb) > SW_PASS)) {
                     unsigned t = hb;
@@ -427,6 +447,7 @@ __global__ __launch_bounds__(64 * SW_SAMPLES, sweep_waves_per_simd(KIND, IDENT))
                 }
                 pend += total;
                 cnt_passes++; cnt_listed += (unsigned)total;
+                }
                 wave_lds_sync();
             }
             finished = !rows_left && pend == 0;

@@ -241,3 +241,25 @@ def test_swept_shards_and_empty(pkg, orc, product_lib):
     c0, gT0, gC0, _ = o.eval(Tl, cm)
     assert abs(c - c0) <= REL_TOL * max(abs(c0), 1e-9)
     assert_close(gC, gC0, "V1 stale-duration gradC")
+
+
+@pytest.mark.parametrize("shape_name", ["Box", "RoundedCone"])
+def test_crowded_tiles_fill_the_candidate_ring(pkg, orc, product_lib, shape_name):
+    """A map that is 55 % occupied with a wide penalty band: samples gather far more than the 512 candidates their ring holds,
+    so the scan has to stop, let the workgroup drain the ring and resume (both the filtered path and Box's direct path)."""
+    capi, synth = pkg.capi, pkg.synth
+    occ, esdf, res = small_world(pkg, seed=31, shape=(56, 56, 48), res=0.2, occupancy=0.55)
+    T, cm = traj(pkg, occ, res, N=4, seed=5, piece_T=0.8)
+    if shape_name == "Box":
+        shape = synth.make_shape("Box", params=(1.3, 1.0, 0.8), grad_mode=capi.GRAD_CENTRAL, bbox=((0, 0, 0), (1.3, 1.0, 0.8)))
+    else:
+        shape = synth.make_shape("RoundedCone", params=(1.0, 0.6, 1.3), bbox=((0, 0, 0.45), (1.0, 1.0, 1.45)))
+    cfg = synth.default_config(capi.V3_ESDF_TILE, kernel_size=21, integral_intervs=10, safety_hor=0.5)
+    eng, o = make_pair(pkg, orc, cfg, shape, esdf=esdf, res=res, threads=16)
+    c, gT, gC = eng.eval_single(T, cm)
+    c0, gT0, gC0, st0 = o.eval(T, cm)
+    st = eng.stats()
+    assert st0[3] / st0[0] > 520                     # more active voxels per sample (on average!) than a ring holds
+    assert st["grad_pairs"] == st0[3]
+    assert abs(c - c0) <= REL_TOL * abs(c0)
+    assert_close(gT, gT0, "crowded gradT"); assert_close(gC, gC0, "crowded gradC")
