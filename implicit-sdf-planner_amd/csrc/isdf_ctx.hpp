@@ -52,7 +52,6 @@ struct isdf_ctx {
     int *d_n_coarse = nullptr;
     double *d_point_partial = nullptr; int *d_point_piece = nullptr; int point_cap = 0;
     double *d_hist = nullptr; size_t hist_cap = 0;
-    void *d_tasks = nullptr; double *d_task_result = nullptr; int *d_point_task = nullptr; unsigned *d_task_counters = nullptr; int task_cap = 0;   // V1 descent task list
     // profiling
     bool prof_on = false; int prof_every = 1; long long prof_tick = 0;
     std::vector<ProfEvent> prof_events;

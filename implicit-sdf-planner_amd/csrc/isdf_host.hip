@@ -158,8 +158,7 @@ extern "C" int isdf_destroy(isdf_ctx *c) {
     isdf_frontend_release(c);
     isdf_xchg_release(c);
     void *ptrs[] = {c->d_tail_ticket, c->d_cb, c->d_esdf, c->d_occ, c->d_points, c->d_tstar, c->d_acc, c->d_sample_info, c->d_bits, c->d_piece_cost, c->d_in, c->d_out, c->d_stats,
-                    c->d_traj_duration, c->d_coarse_t, c->d_coarse_pose, c->d_n_coarse, c->d_point_partial, c->d_point_piece, c->d_hist, c->d_dbg,
-                    c->d_tasks, c->d_task_result, c->d_point_task, c->d_task_counters};
+                    c->d_traj_duration, c->d_coarse_t, c->d_coarse_pose, c->d_n_coarse, c->d_point_partial, c->d_point_piece, c->d_hist, c->d_dbg};
     for (void *p : ptrs) if (p) (void)hipFree(p);
     free_mesh(c);
     if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -427,21 +426,6 @@ static int eval_device_impl(isdf_ctx *c, int n_traj, int N, const double *d_T, c
         }
         P.coarse_t = c->d_coarse_t; P.coarse_pose = c->d_coarse_pose; P.n_coarse = c->d_n_coarse;
         P.point_partial = c->d_point_partial; P.point_piece = c->d_point_piece;
-        {   // descent task list: an interval per point on average is typical; 4 per point + slack is the capacity (overflow is flagged)
-            const int cap = 4 * c->M + 1024;
-            if (c->task_cap < cap) {
-                void *old[] = {c->d_tasks, c->d_task_result, c->d_point_task, c->d_task_counters};
-                for (void *q : old) if (q) (void)hipFree(q);
-                c->d_tasks = nullptr; c->d_task_result = nullptr; c->d_point_task = nullptr; c->d_task_counters = nullptr; c->task_cap = 0;
-                HIPCHK(c, hipMalloc(&c->d_tasks, (size_t)cap * sizeof(GdTask)));
-                HIPCHK(c, hipMalloc(&c->d_task_result, (size_t)cap * GD_RESULT_STRIDE * sizeof(double)));
-                HIPCHK(c, hipMalloc(&c->d_point_task, (size_t)c->M * 2 * sizeof(int)));
-                HIPCHK(c, hipMalloc(&c->d_task_counters, 2 * sizeof(unsigned)));
-                c->task_cap = cap;
-            }
-            P.tasks = (GdTask *)c->d_tasks; P.task_result = c->d_task_result; P.task_cap = c->task_cap;
-            P.point_task = c->d_point_task; P.task_count = c->d_task_counters; P.task_next = c->d_task_counters + 1;
-        }
         { int rc2 = ensure(c, &c->d_hist, &c->hist_cap, (size_t)N); if (rc2) return rc2; }
         P.hist = c->d_hist;
         P.stats = c->d_stats;

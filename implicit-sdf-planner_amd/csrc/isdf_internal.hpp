@@ -52,10 +52,6 @@ void launch_build_bits(const DevGrid &G, int use_esdf, float thresh, unsigned *o
 void launch_tail(const SweepParams &P, hipStream_t stream, hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr);
 
 // ---- V1 (swept volume) ----
-// V1: one sign descent to run = one in-range interval of one obstacle point (written by swept_scan_kernel)
-struct GdTask { int pt, r; double lb, ub, seed; };
-constexpr int GD_RESULT_STRIDE = 6;      // x, sdf(x), shape gradient at x (3), iterations
-
 struct SweptParams {
     DevShape shape;
     FlatP flat;
@@ -76,10 +72,6 @@ struct SweptParams {
     int *point_piece;           // [M]
     double *hist;               // [N] per-piece sum of gdT
     unsigned long long *stats;
-    // descent task list
-    GdTask *tasks; double *task_result; int task_cap;
-    int *point_task;            // [M][2]: first task, number of tasks (= intervals) of the point
-    unsigned *task_count, *task_next;   // device counters: tasks written / next task to take
 };
 void launch_swept_prepare(const SweptParams &P, hipStream_t stream);
 void launch_swept_sweep(const SweptParams &P, hipStream_t stream, hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr);

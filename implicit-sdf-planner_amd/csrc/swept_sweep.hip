@@ -4,27 +4,24 @@
 //   (getSDFofSweptVolume :710-747, choiceTInit :367-445, gradientDescent :1000-1062,
 //    getSDF_DOTAtTimeStampOptimized :593-662, getStateOnTrajStamp :332-341).
 //
-// One optimizer step = six small launches (prepare, scan, descent, back-prop, reduce, suffix):
+// One optimizer step = four launches (prepare, sweep, back-prop, reduce + suffix):
 //   swept_prepare_kernel  one block: the "traj_duration" state (refreshed only when the total is < 300 s, :287-296),
 //                         the coarse time table t += 0.2 by repeated fp64 addition (one lane, like the reference loop),
 //                         then the pose (position + rotation) at every coarse time, shared by all obstacle points.
-//   swept_scan_kernel     one WAVEFRONT per obstacle point:
+//   swept_sweep_kernel    one WAVEFRONT per obstacle point:
 //                           coarse scan   lanes = coarse times (table poses), ballot -> maximal in-range runs
 //                                         (intervals; a run still open at the end is dropped, quirk q2);
 //                           fine scan     lanes = 0.02 s steps of one interval (each lane accumulates its own t by
 //                                         repeated addition), first-minimum reduction, running minimum and seed
 //                                         carried ACROSS intervals (quirk q1);
-//                           -> one descent task (interval, seed) per interval in a device-side list.
-//   swept_descent_kernel  persistent wavefronts pull tasks: the 9 step-halving candidates of one sign-descent iteration
-//                         are evaluated by 9 lanes at once, the 6 central-difference SDF samples by 6 lanes
-//                           -> (t, sdf, body-frame gradient) per interval.
-//   swept_backprop_kernel one THREAD per obstacle point: best interval (in interval order), penalty (mu = 0.01), flatness
-//                         reverse mode, 20-double record.
+//                           descent       the 9 step-halving candidates of one sign-descent iteration are evaluated
+//                                         by 9 lanes at once, the 6 central-difference SDF samples by 6 lanes;
+//                           -> (t*, sdf*, body-frame gradient) per point.
+//   swept_backprop_kernel one THREAD per obstacle point: penalty (mu = 0.01), flatness reverse mode, 20-double record.
 //   swept_reduce_kernel   deterministic sums: gradC rows per piece, gradT(j) = sum over points with piece > j, cost.
 // Compute-/latency-bound: fp64 throughout, no tile traffic.
 #include "isdf_internal.hpp"
 #include "dev_mesh.hpp"
-#include <algorithm>
 
 namespace isdf {
 
@@ -62,7 +59,6 @@ __global__ __launch_bounds__(1024) void swept_prepare_kernel(const SweptParams P
         s_n = n;
         *P.n_coarse = n;
         for (int k = 0; k < 8; k++) P.stats[k] = 0ull;
-        *P.task_count = 0u; *P.task_next = 0u;
     }
     __syncthreads();
     const int n = s_n;
@@ -86,60 +82,8 @@ __device__ __forceinline__ double wave_first_min(double v, int lane, int n, int 
     return m;
 }
 
-// One pose + SDF evaluation for one lane: body-frame point of obstacle point p at time te (optionally perturbed for the
-// finite-difference gradient samples), shape SDF; `want_vel` additionally yields the body-frame point velocity and, for
-// shapes with their own gradient (Ball), that gradient.  For the mesh kind value and gradient come from ONE hierarchy query.
 template <int KIND>
-__device__ __forceinline__ double swept_eval_lane(const SweptParams &P, const TrajView &tr, d3 p, double te, int pert, bool want_vel,
-                                                  bool own_grad, d3 &pvel, d3 &g_direct) {
-    double tl = te;
-    const int pi = traj_locate(tr, tl);
-    d3 xt, vt, at, jt;
-    traj_eval(tr, pi, tl, xt, vt, at, jt);
-    FlatS fs;
-    flat_core(P.flat, vt, at, fs);
-    const m3 R = quat_to_rot(flat_quat(fs));
-    d3 pr = mat_tmul(R, p - xt);
-    if (want_vel) {
-        // d/dt of the body-frame point: -(R^T v + omega x p_rel) (getSDF_DOTAtTimeStampOptimized :593-662)
-        FlatS2 ft;
-        flat_core2(P.flat, vt, at, jt, fs, ft);
-        const d3 omg = flat_omg(fs, ft);
-        const d3 wx = mk3(0 * pr.x + (-omg.z) * pr.y + omg.y * pr.z, omg.z * pr.x + 0 * pr.y + (-omg.x) * pr.z,
-                          (-omg.y) * pr.x + omg.x * pr.y + 0 * pr.z);
-        const d3 rv = mat_tmul(R, vt);
-        pvel = mk3(-(rv.x + wx.x), -(rv.y + wx.y), -(rv.z + wx.z));
-        if constexpr (KIND != ISDF_SHAPE_MESH) if (own_grad) g_direct = shape_grad<KIND>(P.shape, pr);     // Ball: own gradient
-    }
-    if (pert >= 1 && pert <= 6) {            // temp(a) -= dx; [temp(a) += 2 dx]  (Shape.hpp:36-54)
-        const int a = (pert - 1) >> 1;
-        const double dx = 0.000005;
-        double c = a == 0 ? pr.x : (a == 1 ? pr.y : pr.z);
-        c = c - dx;
-        if ((pert - 1) & 1) c = c + 2 * dx;
-        if (a == 0) pr.x = c; else if (a == 1) pr.y = c; else pr.z = c;
-    } else if (pert >= 7) {                  // Box::getonlyGrad1: forward difference, dx = 0.01 (Shape.hpp:2363-2377)
-        const int a = pert - 7;
-        if (a == 0) pr.x += 0.01; else if (a == 1) pr.y += 0.01; else pr.z += 0.01;
-    }
-    if constexpr (KIND == ISDF_SHAPE_MESH) {
-        d3 gq;
-        const double val = mesh_sdf_grad(P.shape.mesh, pr, gq);
-        if (want_vel) g_direct = gq;
-        return val;
-    } else {
-        return shape_sdf<KIND>(P.shape, pr);
-    }
-}
-
-// ---------------------------------------------------------------------------------------------------------------
-// swept_scan_kernel: one WAVEFRONT per obstacle point - coarse scan -> intervals, fine scan of every interval -> one
-// DESCENT TASK per interval (interval, seed).  Most points have 0-1 intervals, a few have 3-5: handing the descents to a
-// task queue (swept_descent_kernel) keeps the launch from waiting for the few wavefronts that would otherwise run five
-// descents back to back (measured before the split: 785 of 3 072 wave slots busy on average).
-// ---------------------------------------------------------------------------------------------------------------
-template <int KIND>
-__global__ __launch_bounds__(64 * SW_WAVES) void swept_scan_kernel(const SweptParams P) {
+__global__ __launch_bounds__(64 * SW_WAVES) void swept_sweep_kernel(const SweptParams P) {
     __shared__ double s_rl[SW_WAVES][SW_MAX_RANGES], s_rr[SW_WAVES][SW_MAX_RANGES];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -209,86 +153,57 @@ __global__ __launch_bounds__(64 * SW_WAVES) void swept_scan_kernel(const SweptPa
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 
-    // ---------------- a slot per interval in the task list ----------------
-    int task_base = 0;
-    if (n_ranges > 0) {
-        if (lane == 0) task_base = (int)atomicAdd(P.task_count, (unsigned)n_ranges);
-        task_base = __builtin_amdgcn_readfirstlane(task_base);
-        if (task_base + n_ranges > P.task_cap) {                   // list full: the result of this step is invalid
-            if (lane == 0) atomicOr((unsigned int *)&P.stats[4], 1u);
-            n_ranges = max(0, P.task_cap - task_base);
-        }
-    }
-    if (lane == 0) {
-        P.point_task[2 * pt] = task_base; P.point_task[2 * pt + 1] = n_ranges;
-        atomicAdd(&P.stats[2], (unsigned long long)n_ranges);
-    }
-
-    // ---------------- fine scan of every interval (:423-438): lanes = 0.02 s steps (each lane accumulates its own t by repeated
-    // addition), first-minimum reduction; the running minimum and the seed are carried ACROSS intervals (quirk q1) -------------
-    double range_time_seed = 0.0;
-    for (int r = 0; r < n_ranges; r++) {
-        const double lb = s_rl[wave][r], ub = s_rr[wave][r];
-        double t_base = lb;
-        for (int pass = 0; pass < 4096; pass++) {
-            double te = t_base;
-            for (int q = 0; q < 63; q++) if (q < lane) te += dt;
-            const bool act = te < ub;
-            const unsigned long long am = __ballot(act);
-            if (!am) break;                                        // nothing (left) to scan in this interval
-            double val = 1e300;
-            d3 pv_unused = mk3(0, 0, 0), g_unused = mk3(0, 0, 0);
-            if (act) val = swept_eval_lane<KIND>(P, tr, p, te, 0, false, false, pv_unused, g_unused);
-            const int nv = __popcll(am);                           // valid lanes form a prefix (t is increasing)
-            int arg;
-            const double m = wave_first_min(val, lane, nv, arg);
-            if (arg >= 0 && m < range_mindis) { range_mindis = m; range_time_seed = __shfl(te, arg, 64); }
-            if (nv < 64) break;
-            t_base = __shfl(te, 63, 64) + dt;
-        }
-        if (lane == 0) {
-            GdTask &tk = P.tasks[task_base + r];
-            tk.pt = pt; tk.r = r; tk.lb = lb; tk.ub = ub; tk.seed = range_time_seed;
-        }
-    }
-}
-
-// ---------------------------------------------------------------------------------------------------------------
-// swept_descent_kernel: persistent wavefronts pull descent tasks (one interval of one obstacle point) from the list:
-// sign descent (gradientDescent :1000-1062) - one iteration in a single pass: lanes 0-8 the nine halving candidates x - tau_k,
-// lanes 9-17 x + tau_k (the sign of dSDF/dt picks the set afterwards), lane 18 the pose at x itself (f(x), body-frame point
-// velocity), lanes 19-24 the central-difference samples of the shape gradient at x (19-21: the forward differences of Box's
-// own gradient) - then, when the last step moved x, one more pass for the shape gradient at the final x.
-// ---------------------------------------------------------------------------------------------------------------
-template <int KIND>
-__global__ __launch_bounds__(64 * SW_WAVES) void swept_descent_kernel(const SweptParams P) {
-    const int lane = threadIdx.x & 63;
-    const TrajView tr{P.T, P.coeffs, P.N};
-    const double D = *P.traj_duration;
-    const int n_tasks = min((int)*P.task_count, P.task_cap);
+    // ---------------- per interval: fine scan (:423-438) then sign descent (:729-745, :1000-1062) ----------------
+    // One loop, ONE pose + SDF evaluation site; what the lanes evaluate depends on the phase:
+    //   FINE   lanes = 0.02 s steps of the interval (each lane accumulates its own t by repeated addition)
+    //   GD     one sign-descent iteration in a single pass: lanes 0-8 the nine halving candidates x - tau_k, lanes 9-17
+    //          x + tau_k (the sign of dSDF/dt picks the set afterwards), lane 18 the pose at x itself (f(x), body-frame
+    //          point velocity), lanes 19-24 the central-difference samples of the shape gradient at x (19-21: the
+    //          forward differences of Box's own gradient)
+    //   GRAD   lanes 18-24 only: shape gradient at the final x of the interval when the last step moved x
+    enum { PH_FINE = 0, PH_GD = 1, PH_GRAD = 2, PH_NEXT = 3, PH_END = 4 };
     const int gmode = P.shape.grad_mode;
     const bool fd_central = (KIND != ISDF_SHAPE_MESH) && gmode == ISDF_GRAD_CENTRAL;
     const bool fd_forward = (KIND != ISDF_SHAPE_MESH) && gmode == ISDF_GRAD_BOX_FORWARD;
-    for (int fetch = 0; fetch < (1 << 24); fetch++) {
-        int task = 0;
-        if (lane == 0) task = (int)atomicAdd(P.task_next, 1u);
-        task = __builtin_amdgcn_readfirstlane(task);
-        if (task >= n_tasks) break;
-        const GdTask tk = P.tasks[task];
-        const d3 p = mk3(P.points[3 * tk.pt], P.points[3 * tk.pt + 1], P.points[3 * tk.pt + 2]);
-        const double t_min = fmax(0.0, tk.lb), t_max = fmin(tk.ub, D);
-        double x = tk.seed, fx = 0.0, prev_x = 10000000.0;
-        d3 g1_at_x = mk3(0, 0, 0);
-        bool g1_fresh = false, grad_only = false;
-        int iter = 0;
-        // (bounded loops throughout: the descent stops by itself after at most 300 halving candidates; with open-ended `for (;;)`
-        //  loops around the wave-level exchanges this kernel did not terminate when built with ROCm 7.2)
-        for (int pass = 0; pass < 400; pass++) {
-            // ---- what this lane evaluates
-            double te = 0.0;
-            int pert = 0;             // 0: the body-frame point itself; 1..6: central-difference sample; 7..9: forward difference
-            bool act = false;
-            if (lane < 18 && !grad_only) {
+    double range_time_seed = 0.0;
+    double min_sdf_star = 1e1, t_star_best = 0.0;
+    d3 grad_prel = mk3(0, 0, 0);
+    bool have = false;
+    unsigned n_iters_total = 0;
+    int r = 0, phase = n_ranges > 0 ? PH_FINE : PH_END;
+    double lb = 0.0, ub = 0.0, t_base = 0.0, t_min = 0.0, t_max = 0.0;
+    double x = 0.0, fx = 0.0, prev_x = 0.0;
+    d3 g1_at_x = mk3(0, 0, 0);                 // shape gradient at the current x (valid when g1_fresh)
+    bool g1_fresh = false;
+    int iter = 0;
+    if (phase == PH_FINE) { lb = s_rl[wave][0]; ub = s_rr[wave][0]; t_base = lb; }
+    while (phase != PH_END) {
+        if (phase == PH_NEXT) {
+            // interval r finished at (x, fx): keep the best (:739-744), move on
+            n_iters_total += (unsigned)iter;
+            if (fx < min_sdf_star) { min_sdf_star = fx; t_star_best = x; have = true; grad_prel = g1_at_x; }
+            r++;
+            if (r >= n_ranges) { phase = PH_END; break; }
+            lb = s_rl[wave][r]; ub = s_rr[wave][r]; t_base = lb;
+            phase = PH_FINE;
+            continue;
+        }
+        // ---- what this lane evaluates
+        double te = 0.0;
+        int pert = 0;                 // 0: the body-frame point itself; 1..6: central-difference sample; 7..9: forward difference
+        bool act = false;
+        if (phase == PH_FINE) {
+            te = t_base;
+            for (int q = 0; q < 63; q++) if (q < lane) te += dt;     // each lane's own accumulated time
+            act = te < ub;
+            if (!__ballot(act)) {     // nothing (left) to scan in this interval: descend from the seed
+                x = range_time_seed; prev_x = 10000000.0; iter = 0; g1_fresh = false;
+                t_min = fmax(0.0, lb); t_max = fmin(ub, D);
+                phase = PH_GD;
+                continue;
+            }
+        } else {
+            if (lane < 18 && phase == PH_GD) {
                 double tau = 0.02;
                 const int k = lane < 9 ? lane : lane - 9;
                 for (int q = 0; q < 8; q++) if (q < k) tau = 0.5 * tau;
@@ -298,53 +213,110 @@ __global__ __launch_bounds__(64 * SW_WAVES) void swept_descent_kernel(const Swep
             } else if (lane == 18) { te = x; act = true; }
             else if (lane >= 19 && lane < 25 && fd_central) { te = x; pert = lane - 18; act = true; }
             else if (lane >= 19 && lane < 22 && fd_forward) { te = x; pert = lane - 12; act = true; }
-            double val = 1e300;
-            d3 pvel = mk3(0, 0, 0), g_direct = mk3(0, 0, 0);
-            if (act) val = swept_eval_lane<KIND>(P, tr, p, te, pert, lane == 18, !fd_central && !fd_forward, pvel, g_direct);
-            // ---- shape gradient at x from the samples (getonlyGrad1)
-            d3 g1;
-            if (fd_central) {
+        }
+        // ---- the evaluation: pose at te, body-frame point, shape SDF (one code instance)
+        double val = 1e300;
+        d3 pvel = mk3(0, 0, 0), g_direct = mk3(0, 0, 0);
+        if (act) {
+            double tl = te;
+            const int pi = traj_locate(tr, tl);
+            d3 xt, vt, at, jt;
+            traj_eval(tr, pi, tl, xt, vt, at, jt);
+            FlatS fs;
+            flat_core(P.flat, vt, at, fs);
+            const m3 R = quat_to_rot(flat_quat(fs));
+            d3 pr = mat_tmul(R, p - xt);
+            if (lane == 18 && phase != PH_FINE) {
+                // d/dt of the body-frame point: -(R^T v + omega x p_rel) (getSDF_DOTAtTimeStampOptimized :593-662)
+                FlatS2 ft;
+                flat_core2(P.flat, vt, at, jt, fs, ft);
+                const d3 omg = flat_omg(fs, ft);
+                const d3 wx = mk3(0 * pr.x + (-omg.z) * pr.y + omg.y * pr.z, omg.z * pr.x + 0 * pr.y + (-omg.x) * pr.z,
+                                  (-omg.y) * pr.x + omg.x * pr.y + 0 * pr.z);
+                const d3 rv = mat_tmul(R, vt);
+                pvel = mk3(-(rv.x + wx.x), -(rv.y + wx.y), -(rv.z + wx.z));
+                if constexpr (KIND != ISDF_SHAPE_MESH) if (!fd_central && !fd_forward) g_direct = shape_grad<KIND>(P.shape, pr);     // Ball: own gradient
+            }
+            if (pert >= 1 && pert <= 6) {            // temp(a) -= dx; [temp(a) += 2 dx]  (Shape.hpp:36-54)
+                const int a = (pert - 1) >> 1;
                 const double dx = 0.000005;
-                const double gx = __shfl(val, 20, 64) - __shfl(val, 19, 64), gy = __shfl(val, 22, 64) - __shfl(val, 21, 64),
-                             gz = __shfl(val, 24, 64) - __shfl(val, 23, 64);
-                g1 = normalized3(mk3(gx / (2 * dx), gy / (2 * dx), gz / (2 * dx)));
-            } else if (fd_forward) {
-                const double s0 = __shfl(val, 18, 64), dx = 0.01;
-                g1 = mk3((__shfl(val, 19, 64) - s0) / dx, (__shfl(val, 20, 64) - s0) / dx, (__shfl(val, 21, 64) - s0) / dx);
-            } else {
-                g1 = mk3(__shfl(g_direct.x, 18, 64), __shfl(g_direct.y, 18, 64), __shfl(g_direct.z, 18, 64));
+                double c = a == 0 ? pr.x : (a == 1 ? pr.y : pr.z);
+                c = c - dx;
+                if ((pert - 1) & 1) c = c + 2 * dx;
+                if (a == 0) pr.x = c; else if (a == 1) pr.y = c; else pr.z = c;
+            } else if (pert >= 7) {                  // Box::getonlyGrad1: forward difference, dx = 0.01 (Shape.hpp:2363-2377)
+                const int a = pert - 7;
+                if (a == 0) pr.x += 0.01; else if (a == 1) pr.y += 0.01; else pr.z += 0.01;
             }
-            g1_at_x = g1; g1_fresh = true;
-            if (grad_only) break;
-            // ---- sign-descent step
-            if (iter == 0) fx = __shfl(val, 18, 64);
-            const d3 pv = mk3(__shfl(pvel.x, 18, 64), __shfl(pvel.y, 18, 64), __shfl(pvel.z, 18, 64));
-            const double g = dot3(g1, pv);
-            const int sgn = (int)(g > 0) - (int)(g < 0);
-            prev_x = x;
-            const bool in_set = sgn > 0 ? (lane < 9) : (sgn < 0 ? (lane >= 9 && lane < 18) : false);
-            const unsigned long long accm = __ballot(in_set && ((val - fx) < 0));
-            bool stop = false;
-            if (accm) {
-                const int src = __ffsll((long long)accm) - 1;            // first (largest) step that decreases the SDF
-                const int d = sgn > 0 ? src : src - 9;
-                iter += d + 1;
-                x = __shfl(te, src, 64);
-                fx = __shfl(val, src, 64);
-                g1_fresh = false;
+            if constexpr (KIND == ISDF_SHAPE_MESH) {
+                // one hierarchy query per lane gives value AND gradient (lane 18 keeps the gradient): no second, divergent
+                // query for the lane that needs both
+                d3 gq;
+                val = mesh_sdf_grad(P.shape.mesh, pr, gq);
+                if (lane == 18) g_direct = gq;
             } else {
-                iter += 9;
-                stop = true;
-            }
-            if (!(iter < 300 && !stop && fabs(x - prev_x) > 1e-5)) {
-                if (g1_fresh) break;
-                grad_only = true;                                        // the last step moved x: shape gradient there
+                val = shape_sdf<KIND>(P.shape, pr);
             }
         }
-        if (lane == 0) {
-            double *o = P.task_result + (size_t)task * GD_RESULT_STRIDE;
-            o[0] = x; o[1] = fx; o[2] = g1_at_x.x; o[3] = g1_at_x.y; o[4] = g1_at_x.z; o[5] = (double)iter;
+        // ---- consume
+        if (phase == PH_FINE) {
+            const int nv = __popcll(__ballot(act));                  // valid lanes form a prefix (t is increasing)
+            int arg;
+            const double m = wave_first_min(val, lane, nv, arg);
+            if (arg >= 0 && m < range_mindis) { range_mindis = m; range_time_seed = __shfl(te, arg, 64); }
+            if (nv < 64) {
+                x = range_time_seed; prev_x = 10000000.0; iter = 0; g1_fresh = false;
+                t_min = fmax(0.0, lb); t_max = fmin(ub, D);
+                phase = PH_GD;
+            } else t_base = __shfl(te, 63, 64) + dt;
+            continue;
         }
+        // shape gradient at x from the samples (getonlyGrad1)
+        d3 g1;
+        if (fd_central) {
+            const double dx = 0.000005;
+            const double gx = __shfl(val, 20, 64) - __shfl(val, 19, 64), gy = __shfl(val, 22, 64) - __shfl(val, 21, 64),
+                         gz = __shfl(val, 24, 64) - __shfl(val, 23, 64);
+            g1 = normalized3(mk3(gx / (2 * dx), gy / (2 * dx), gz / (2 * dx)));
+        } else if (fd_forward) {
+            const double s0 = __shfl(val, 18, 64), dx = 0.01;
+            g1 = mk3((__shfl(val, 19, 64) - s0) / dx, (__shfl(val, 20, 64) - s0) / dx, (__shfl(val, 21, 64) - s0) / dx);
+        } else {
+            g1 = mk3(__shfl(g_direct.x, 18, 64), __shfl(g_direct.y, 18, 64), __shfl(g_direct.z, 18, 64));
+        }
+        g1_at_x = g1; g1_fresh = true;
+        if (phase == PH_GRAD) { phase = PH_NEXT; continue; }
+        // sign-descent step (gradientDescent :1000-1062)
+        if (iter == 0) fx = __shfl(val, 18, 64);
+        const d3 pv = mk3(__shfl(pvel.x, 18, 64), __shfl(pvel.y, 18, 64), __shfl(pvel.z, 18, 64));
+        const double g = dot3(g1, pv);
+        const int sgn = (int)(g > 0) - (int)(g < 0);
+        prev_x = x;
+        const bool in_set = sgn > 0 ? (lane < 9) : (sgn < 0 ? (lane >= 9 && lane < 18) : false);
+        const unsigned long long accm = __ballot(in_set && ((val - fx) < 0));
+        bool stop = false;
+        if (accm) {
+            const int src = __ffsll((long long)accm) - 1;            // first (largest) step that decreases the SDF
+            const int d = sgn > 0 ? src : src - 9;
+            iter += d + 1;
+            x = __shfl(te, src, 64);
+            fx = __shfl(val, src, 64);
+            g1_fresh = false;
+        } else {
+            iter += 9;
+            stop = true;
+        }
+        if (!(iter < 300 && !stop && fabs(x - prev_x) > 1e-5)) phase = g1_fresh ? PH_NEXT : PH_GRAD;
+    }
+
+    // ---------------- hand the minimiser to swept_backprop_kernel ----------------
+    if (lane == 0) {
+        double *o = P.point_partial + (size_t)pt * PARTIAL_STRIDE;     // reused as [t*, sdf*, grad_prel(3)] until back-prop
+        o[0] = have ? t_star_best : P.tstar[pt];                       // no interval qualified: lastTstar stays (:717, :576-578)
+        o[1] = min_sdf_star;
+        o[2] = grad_prel.x; o[3] = grad_prel.y; o[4] = grad_prel.z;
+        atomicAdd(&P.stats[2], (unsigned long long)n_ranges);
+        atomicAdd(&P.stats[5], (unsigned long long)n_iters_total);
     }
 }
 
@@ -356,21 +328,8 @@ __global__ __launch_bounds__(128) void swept_backprop_kernel(const SweptParams P
     const TrajView tr{P.T, P.coeffs, P.N};
     double *o = P.point_partial + (size_t)pt * PARTIAL_STRIDE;
     const d3 p = mk3(P.points[3 * pt], P.points[3 * pt + 1], P.points[3 * pt + 2]);
-    // the point's intervals in order: keep the best minimiser (getSDFofSweptVolume :739-744, strict <)
-    double min_sdf_star = 1e1, t_star_best = 0.0;
-    d3 grad_prel = mk3(0, 0, 0);
-    bool have = false;
-    unsigned long long n_iters_total = 0;
-    {
-        const int tb = P.point_task[2 * pt], tn = P.point_task[2 * pt + 1];
-        for (int r = 0; r < tn; r++) {
-            const double *q = P.task_result + (size_t)(tb + r) * GD_RESULT_STRIDE;
-            n_iters_total += (unsigned long long)q[5];
-            if (q[1] < min_sdf_star) { min_sdf_star = q[1]; t_star_best = q[0]; have = true; grad_prel = mk3(q[2], q[3], q[4]); }
-        }
-    }
-    const double tstar = have ? t_star_best : P.tstar[pt];          // no interval qualified: lastTstar stays (:717, :576-578)
-    if (n_iters_total) atomicAdd(&P.stats[5], n_iters_total);
+    const double tstar = o[0], min_sdf_star = o[1];
+    const d3 grad_prel = mk3(o[2], o[3], o[4]);
     double time_local = tstar;
     const int i = traj_locate(tr, time_local);
     Basis B;
@@ -469,12 +428,7 @@ void launch_swept_sweep(const SweptParams &P, hipStream_t stream, hipEvent_t ev_
     const int n = P.point_end - P.point_begin;
     if (n <= 0) return;
     const dim3 grid((n + SW_WAVES - 1) / SW_WAVES), block(64 * SW_WAVES);
-    // persistent descent waves: enough to fill the device at the kernels' occupancy, never more than there can be tasks
-    const dim3 dgrid((unsigned)std::max(1, std::min((P.task_cap + SW_WAVES - 1) / SW_WAVES, 256 * 4)));
-    // the profiling events bracket the pair: start of the scan, end of the descent
-#define ISDF_SWEPT_CASE(K) case K: \
-        hipExtLaunchKernelGGL(swept_scan_kernel<K>, grid, block, 0, stream, ev_start, nullptr, 0, P); \
-        hipExtLaunchKernelGGL(swept_descent_kernel<K>, dgrid, block, 0, stream, nullptr, ev_stop, 0, P); break;
+#define ISDF_SWEPT_CASE(K) case K: hipExtLaunchKernelGGL(swept_sweep_kernel<K>, grid, block, 0, stream, ev_start, ev_stop, 0, P); break;
     switch (P.shape.kind) {
     // one instantiation per shape class (each inlines exactly one SDF formula; the run-time switch of the generic kernel costs
     // 272 VGPRs = one wave per SIMD)
@@ -483,9 +437,7 @@ void launch_swept_sweep(const SweptParams &P, hipStream_t stream, hipEvent_t ev_
     ISDF_SWEPT_CASE(ISDF_SHAPE_TWISTBOX) ISDF_SWEPT_CASE(ISDF_SHAPE_BENDBOX) ISDF_SWEPT_CASE(ISDF_SHAPE_TABLE)
     ISDF_SWEPT_CASE(ISDF_SHAPE_TREFOIL) ISDF_SWEPT_CASE(ISDF_SHAPE_SMOOTHDIFFERENCE) ISDF_SWEPT_CASE(ISDF_SHAPE_SMOOTHINTERSECTION)
     ISDF_SWEPT_CASE(ISDF_SHAPE_CSG) ISDF_SWEPT_CASE(ISDF_SHAPE_BOX) ISDF_SWEPT_CASE(ISDF_SHAPE_MESH)
-    default:      // Ball
-        hipExtLaunchKernelGGL(swept_scan_kernel<-1>, grid, block, 0, stream, ev_start, nullptr, 0, P);
-        hipExtLaunchKernelGGL(swept_descent_kernel<-1>, dgrid, block, 0, stream, nullptr, ev_stop, 0, P); break;
+    default: hipExtLaunchKernelGGL(swept_sweep_kernel<-1>, grid, block, 0, stream, ev_start, ev_stop, 0, P); break;      // Ball
     }
 #undef ISDF_SWEPT_CASE
 }
