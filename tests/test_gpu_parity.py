@@ -169,6 +169,41 @@ def test_every_registered_shape(pkg, orc, product_lib, name):
     assert st[2] > 0
 
 
+_ALL_KINDS = ["Torus", "Cappedtorus", "CappedCone", "RoundedCone", "WireframeBox", "BendLinear", "TwistBox", "BendBox", "Table", "Trefoil",
+              "SmoothDifference", "SmoothIntersection", "CSG", "Box", "Ball"]
+
+
+@pytest.mark.parametrize("name", _ALL_KINDS)
+def test_every_shape_with_identity_body_offset(pkg, orc, product_lib, name):
+    """poly_params all zero (every shipped config): the sweep kernel's identity-offset instantiation of every shape class."""
+    capi, synth = pkg.capi, pkg.synth
+    occ, esdf, res = small_world(pkg, shape=(40, 40, 40), occupancy=0.10, seed=9)
+    T, cm = traj(pkg, occ, res, N=3, seed=41, margin=6.0)
+    shape = synth.make_shape(name)
+    cfg = synth.default_config(capi.V3_ESDF_TILE, kernel_size=17, integral_intervs=6, safety_hor=0.5)
+    eng, o = make_pair(pkg, orc, cfg, shape, esdf=esdf, res=res)
+    cost, st = _check(eng, o, T, cm, name + " (identity offset)")
+    assert st[2] > 0
+
+
+@pytest.mark.parametrize("name", _ALL_KINDS)
+def test_swept_sweep_every_shape_class(pkg, orc, product_lib, name):
+    """The V1 kernel's instantiation of every shape class (with and without a body offset) against the oracle."""
+    capi, synth = pkg.capi, pkg.synth
+    occ, esdf, res, T, cm, pts = _swept_world(pkg, seed=5, N=5)
+    pts = pts[:: max(1, len(pts) // 120)]
+    for pp in ((0, 0, 0, 0, 0, 0), (0.2, -0.1, 0.15, 30, 10, 120)):
+        shape = synth.make_shape(name, poly_params=pp)
+        cfg = synth.default_config(capi.V1_SWEPT, safety_hor=0.5)
+        eng, o = make_pair(pkg, orc, cfg, shape, occ=occ, res=res, points=pts)
+        tg = np.zeros(len(pts)); to = np.zeros(len(pts))
+        c, gT, gC = eng.eval_single(T, cm, tstar=tg)
+        c0, gT0, gC0, _ = o.eval(T, cm, tstar=to)
+        assert abs(c - c0) <= REL_TOL * max(abs(c0), 1e-9), (name, pp)
+        assert_close(gT, gT0, f"{name} V1 gradT"); assert_close(gC, gC0, f"{name} V1 gradC")
+        assert np.max(np.abs(tg - to)) <= 2e-5
+
+
 # ------------------------------------------------------------------------------------------------------------------
 # V1: the reference's live swept-volume sweep (addSaftyPenaOnSweptVolumeParallel)
 # ------------------------------------------------------------------------------------------------------------------
