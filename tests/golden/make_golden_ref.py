@@ -54,6 +54,40 @@ def main():
     c, gT, gC = ref.sweep_integral(T, cm)
     np.savez_compressed(os.path.join(HERE, "ref_integral.npz"), occ=occ, res=res, T=T, coeffs=cm, cost=c, gradT=gT, gradC=gC, **{f"cfg_{k}": v for k, v in dyn.items()})
     print(f"ref_integral: cost={c:.9g}")
+    # ---- the full objective callback: costFunctionLmbm assembled from the reference's own MINCO_S3NU (setParameters, getEnergy*,
+    # propogateGrad) and its own two sweeps (back_end_optimizer.hpp:358-430)
+    from common import tau_to_T  # noqa: E402
+    cfg, kw, occ, res, shape = world(pkg, orc, capi.V1_SWEPT, "RoundedCone", 4, vmax=1.5, omgmax=0.6, thetamax=0.25)
+    ref = orc.RefWorld(cfg, "RoundedCone", shape, res, threads=8); ref.set_occupancy(occ, (0, 0, 0), res)
+    N = 5
+    T0, cm0 = traj(pkg, occ, res, N=N, seed=33, piece_T=0.6)
+    c6 = cm0.reshape(3, 6 * N).T.reshape(N, 6, 3)
+    head = np.zeros((3, 3)); tail = np.zeros((3, 3))
+    head[:, 0] = c6[0, 0]; tail[:, 0] = sum(c6[N - 1, p] * T0[-1] ** p for p in range(6))
+    way = c6[1:, 0, :]
+    rho = 2.5
+    pts = synth.constraint_points(occ, (0, 0, 0), res, way, half=3.0)
+    ref.set_points(pts)
+    # x = [tau | waypoints] exactly as isdf_pack_variables builds it
+    from common import T_to_tau  # noqa: E402
+    x = np.concatenate([T_to_tau(T0), way.reshape(-1)])
+    tau, xi = x[:N], x[N:]
+    T = tau_to_T(tau)
+    cm_r, e_r, gC, gT = orc.ref_minco(head, tail, xi.reshape(N - 1, 3).T, T)
+    total = e_r
+    c1, gT1, gC1, _ = ref.sweep_swept(T, cm_r)
+    total += c1; gT = gT + gT1; gC = gC + gC1
+    c2, gT2, gC2 = ref.sweep_integral(T, cm_r)
+    total += c2; gT = gT + gT2; gC = gC + gC2
+    gP, gTt = orc.ref_minco_propagate(head, tail, xi.reshape(N - 1, 3).T, T, gC, gT)
+    total += rho * T.sum()
+    gTt = gTt + rho
+    den = (0.5 * tau - 1.0) * tau + 1.0
+    g_tau = np.where(tau > 0, gTt * (tau + 1.0), gTt * (1.0 - tau) / (den * den))
+    grad_x = np.concatenate([g_tau, gP.T.reshape(-1)])
+    np.savez_compressed(os.path.join(HERE, "ref_callback_v1.npz"), occ=occ, res=res, N=N, head=head, tail=tail, rho=rho, x=x, points=pts, cost=total, g=grad_x,
+                        energy=e_r, cost_swept=c1, cost_integral=c2, cfg_vmax=1.5, cfg_omgmax=0.6, cfg_thetamax=0.25)
+    print(f"ref_callback_v1: cost={total:.9g} (energy {e_r:.6g}, swept {c1:.6g}, integral {c2:.6g})")
     # ---- ESDF (GridMap3D::generateESDF3d)
     occ9, _, res9 = small_world(pkg, seed=9)
     ref.set_occupancy(occ9, (0, 0, 0), res9)

@@ -80,7 +80,38 @@ def _check_frontend(pkg, orc, gpu, name):
     assert np.array_equal(cr[m], w["child_roll"][m]) and np.array_equal(cp[m], w["child_pitch"][m])
 
 
+def _check_callback(pkg, orc, gpu):
+    from common import oracle_cost_function
+    capi, synth = pkg.capi, pkg.synth
+    w = _load("ref_callback_v1")
+    N = int(w["N"]); res = float(w["res"])
+    kw = dict(kernel_size=9, integral_intervs=16, safety_hor=0.5, vmax=float(w["cfg_vmax"]), omgmax=float(w["cfg_omgmax"]), thetamax=float(w["cfg_thetamax"]))
+    shape = synth.make_shape("RoundedCone", poly_params=mg.POLY)
+    if gpu:
+        eng = pkg.Engine(synth.default_config(capi.V1_SWEPT, **kw))
+        eng.set_grid(w["occ"], (0, 0, 0), res, capi.GRID_OCCUPANCY); eng.set_shape(shape); eng.set_points(w["points"])
+        eng.set_trajectory(N, w["head"], w["tail"], float(w["rho"]))
+        cost, g = eng.cost_function(w["x"])
+        tol = REL_TOL
+    else:
+        sw = orc.Oracle(synth.default_config(capi.V1_SWEPT, **kw), threads=4)
+        integ = orc.Oracle(synth.default_config(capi.V3_ESDF_TILE, enable_pos=0, **kw), threads=4)
+        for o in (sw, integ):
+            o.set_grid(w["occ"], (0, 0, 0), res, capi.GRID_OCCUPANCY); o.set_shape(shape)
+        sw.set_points(w["points"])
+        cost, g = oracle_cost_function(orc, [sw, integ], w["head"], w["tail"], float(w["rho"]), w["x"], N)
+        tol = 1e-7
+    c_r = float(w["cost"])
+    assert abs(cost - c_r) <= tol * abs(c_r), (cost, c_r)
+    assert_close(g, w["g"], "callback gradient vs reference fixture", tol=tol)
+
+
 # ---- CPU: the oracle restatement against the reference's outputs
+def test_oracle_callback_vs_reference_fixture(pkg, orc):
+    _check_callback(pkg, orc, False)
+
+
+
 @pytest.mark.parametrize("name", mg.V1_SHAPES)
 def test_oracle_swept_sweep_vs_reference_fixture(pkg, orc, name):
     _check_v1(pkg, orc, False, name)
@@ -127,3 +158,9 @@ def test_hip_esdf_vs_reference_fixture(pkg, product_lib):
 @pytest.mark.parametrize("name", ["Box", "Torus_big"])
 def test_hip_frontend_vs_reference_fixture(pkg, orc, product_lib, name):
     _check_frontend(pkg, orc, True, name)
+
+
+@pytest.mark.gpu
+def test_hip_callback_vs_reference_fixture(pkg, orc, product_lib):
+    """isdf_cost_function against costFunctionLmbm assembled from the reference's own MINCO + sweeps + propogateGrad."""
+    _check_callback(pkg, orc, True)
