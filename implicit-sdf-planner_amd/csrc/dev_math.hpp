@@ -158,6 +158,14 @@ __device__ __forceinline__ d4 quat_step_grad(d4 q, d3 g, d3 d) {
 
 struct FlatP { double mass, grav, dh, dv, cp, veps, dh_over_m; };
 
+// a / b where several quotients share the divisor b: translation units that define ISDF_LEAN_MATH (the tile sweep, bound by
+// fp64 instruction issue) form 1 / b once and multiply (<= 1 ulp per quotient); everywhere else it is the plain division.
+#ifdef ISDF_LEAN_MATH
+#define ISDF_QUOT(a, b, inv_b) ((a) * (inv_b))
+#else
+#define ISDF_QUOT(a, b, inv_b) ((a) / (b))
+#endif
+
 // Shared forward intermediates of the flatness map.
 struct FlatS {
     double cp_term, w_term, zu0, zu1, zu2, s0, s1, s2, zu_sqr_norm, zu_norm, z0, z1, z2, tilt_den;
@@ -171,11 +179,13 @@ __device__ __forceinline__ void flat_core(const FlatP &P, d3 v, d3 a, FlatS &s) 
     s.s0 = s.zu0 * s.zu0; s.s1 = s.zu1 * s.zu1; s.s2 = s.zu2 * s.zu2;
     s.zu_sqr_norm = s.s0 + s.s1 + s.s2;
     s.zu_norm = sqrt(s.zu_sqr_norm);
-    s.z0 = s.zu0 / s.zu_norm; s.z1 = s.zu1 / s.zu_norm; s.z2 = s.zu2 / s.zu_norm;
+    const double inv_zn = 1.0 / s.zu_norm;
+    s.z0 = ISDF_QUOT(s.zu0, s.zu_norm, inv_zn); s.z1 = ISDF_QUOT(s.zu1, s.zu_norm, inv_zn); s.z2 = ISDF_QUOT(s.zu2, s.zu_norm, inv_zn);
     s.tilt_den = sqrt(2.0 * (1.0 + s.z2));
 }
 __device__ __forceinline__ d4 flat_quat(const FlatS &s) {
-    d4 q; q.w = 0.5 * s.tilt_den; q.x = -s.z1 / s.tilt_den; q.y = s.z0 / s.tilt_den; q.z = 0.0; return q;
+    const double inv_t = 1.0 / s.tilt_den;
+    d4 q; q.w = 0.5 * s.tilt_den; q.x = ISDF_QUOT(-s.z1, s.tilt_den, inv_t); q.y = ISDF_QUOT(s.z0, s.tilt_den, inv_t); q.z = 0.0; return q;
 }
 struct FlatS2 {
     double ng_den, ng00, ng01, ng02, ng11, ng12, ng22, zu01, zu12, zu02, v_dot_a, dw_term;
@@ -183,13 +193,14 @@ struct FlatS2 {
 };
 __device__ __forceinline__ void flat_core2(const FlatP &P, d3 v, d3 a, d3 j, const FlatS &s, FlatS2 &t) {
     t.ng_den = s.zu_sqr_norm * s.zu_norm;
-    t.ng00 = (s.s1 + s.s2) / t.ng_den;
+    const double inv_ng = 1.0 / t.ng_den;
+    t.ng00 = ISDF_QUOT(s.s1 + s.s2, t.ng_den, inv_ng);
     t.zu01 = s.zu0 * s.zu1; t.zu12 = s.zu1 * s.zu2; t.zu02 = s.zu0 * s.zu2;
-    t.ng01 = -t.zu01 / t.ng_den;
-    t.ng02 = -t.zu02 / t.ng_den;
-    t.ng11 = (s.s0 + s.s2) / t.ng_den;
-    t.ng12 = -t.zu12 / t.ng_den;
-    t.ng22 = (s.s0 + s.s1) / t.ng_den;
+    t.ng01 = ISDF_QUOT(-t.zu01, t.ng_den, inv_ng);
+    t.ng02 = ISDF_QUOT(-t.zu02, t.ng_den, inv_ng);
+    t.ng11 = ISDF_QUOT(s.s0 + s.s2, t.ng_den, inv_ng);
+    t.ng12 = ISDF_QUOT(-t.zu12, t.ng_den, inv_ng);
+    t.ng22 = ISDF_QUOT(s.s0 + s.s1, t.ng_den, inv_ng);
     t.v_dot_a = v.x * a.x + v.y * a.y + v.z * a.z;
     t.dw_term = P.cp * t.v_dot_a / s.cp_term;
     t.dw0 = s.w_term * a.x + t.dw_term * v.x;
@@ -214,23 +225,24 @@ __device__ __forceinline__ void flat_backward(const FlatP &P, d3 v, d3 a, d3 jer
     FlatS s; FlatS2 t;
     flat_core(P, v, a, s);
     flat_core2(P, v, a, jer, s, t);
+    const double inv_tilt = 1.0 / s.tilt_den, inv_omg = 1.0 / t.omg_den, inv_ng = 1.0 / t.ng_den, inv_zn = 1.0 / s.zu_norm, inv_cp = 1.0 / s.cp_term;
     const double tilt0b = quat_grad.w, tilt1b = quat_grad.x, tilt2b = quat_grad.y;
     const double tilt_den_sqr = s.tilt_den * s.tilt_den;
     const double tilt_denb = (s.z1 * tilt1b - s.z0 * tilt2b) / tilt_den_sqr + 0.5 * tilt0b;
     const double omg_termb = -s.z0 * omg_grad.y + s.z1 * omg_grad.x;
-    double tb = omg_grad.z / t.omg_den;
+    double tb = ISDF_QUOT(omg_grad.z, t.omg_den, inv_omg);
     double z1b = t.dz0 * tb;
     const double dz0b = s.z1 * tb + omg_grad.y;
     double z0b = -(t.dz1 * tb);
     const double dz1b = -s.z0 * tb - omg_grad.x;
-    const double omg_denb = -((s.z1 * t.dz0 - s.z0 * t.dz1) * tb / t.omg_den) - t.dz2 * omg_termb / (t.omg_den * t.omg_den);
+    const double omg_denb = -ISDF_QUOT((s.z1 * t.dz0 - s.z0 * t.dz1) * tb, t.omg_den, inv_omg) - ISDF_QUOT(ISDF_QUOT(t.dz2 * omg_termb, t.omg_den, inv_omg), t.omg_den, inv_omg);
     tb = -(t.omg_term * omg_grad.y);
     z0b += tb;
     tb = -(t.omg_term * omg_grad.x);
-    z0b += tilt2b / s.tilt_den;
-    z1b += -tb - tilt1b / s.tilt_den;
-    const double dz2b = omg_termb / t.omg_den;
-    const double z2b = omg_denb + tilt_denb / s.tilt_den;
+    z0b += ISDF_QUOT(tilt2b, s.tilt_den, inv_tilt);
+    z1b += -tb - ISDF_QUOT(tilt1b, s.tilt_den, inv_tilt);
+    const double dz2b = ISDF_QUOT(omg_termb, t.omg_den, inv_omg);
+    const double z2b = omg_denb + ISDF_QUOT(tilt_denb, s.tilt_den, inv_tilt);
 
     const double ng02b = t.dzt0 * dz2b + t.dzt2 * dz0b;
     const double dzt0b = t.ng02 * dz2b + t.ng01 * dz1b + t.ng00 * dz0b;
@@ -243,38 +255,38 @@ __device__ __forceinline__ void flat_backward(const FlatP &P, d3 v, d3 a, d3 jer
     const double ng00b = t.dzt0 * dz0b;
     gJ = mk3(dzt0b, dzt1b, dzt2b);
     const double dw0b = P.dh_over_m * dzt0b, dw1b = P.dh_over_m * dzt1b, dw2b = P.dh_over_m * dzt2b;
-    tb = P.cp * (v.z * dw2b + v.y * dw1b + v.x * dw0b) / s.cp_term;
+    tb = ISDF_QUOT(P.cp * (v.z * dw2b + v.y * dw1b + v.x * dw0b), s.cp_term, inv_cp);
     gA = mk3(s.w_term * dw0b + v.x * tb, s.w_term * dw1b + v.y * tb, s.w_term * dw2b + v.z * tb);
     gV = mk3(t.dw_term * dw0b + a.x * tb, t.dw_term * dw1b + a.y * tb, t.dw_term * dw2b + a.z * tb);
-    double cp_termb = -(t.v_dot_a * tb / s.cp_term);
-    tb = ng22b / t.ng_den;
+    double cp_termb = -ISDF_QUOT(t.v_dot_a * tb, s.cp_term, inv_cp);
+    tb = ISDF_QUOT(ng22b, t.ng_den, inv_ng);
     double zs0b = tb, zs1b = tb;
-    double ng_denb = -((s.s0 + s.s1) * tb / t.ng_den);
-    const double zu12b = -(ng12b / t.ng_den);
-    tb = ng11b / t.ng_den;
-    ng_denb += t.zu12 * ng12b / (t.ng_den * t.ng_den) - (s.s0 + s.s2) * tb / t.ng_den;
+    double ng_denb = -ISDF_QUOT((s.s0 + s.s1) * tb, t.ng_den, inv_ng);
+    const double zu12b = -ISDF_QUOT(ng12b, t.ng_den, inv_ng);
+    tb = ISDF_QUOT(ng11b, t.ng_den, inv_ng);
+    ng_denb += ISDF_QUOT(ISDF_QUOT(t.zu12 * ng12b, t.ng_den, inv_ng), t.ng_den, inv_ng) - ISDF_QUOT((s.s0 + s.s2) * tb, t.ng_den, inv_ng);
     zs0b += tb;
     double zs2b = tb;
-    const double zu02b = -(ng02b / t.ng_den);
-    const double zu01b = -(ng01b / t.ng_den);
-    tb = ng00b / t.ng_den;
-    ng_denb += t.zu02 * ng02b / (t.ng_den * t.ng_den) + t.zu01 * ng01b / (t.ng_den * t.ng_den) - (s.s1 + s.s2) * tb / t.ng_den;
+    const double zu02b = -ISDF_QUOT(ng02b, t.ng_den, inv_ng);
+    const double zu01b = -ISDF_QUOT(ng01b, t.ng_den, inv_ng);
+    tb = ISDF_QUOT(ng00b, t.ng_den, inv_ng);
+    ng_denb += ISDF_QUOT(ISDF_QUOT(t.zu02 * ng02b, t.ng_den, inv_ng), t.ng_den, inv_ng) + ISDF_QUOT(ISDF_QUOT(t.zu01 * ng01b, t.ng_den, inv_ng), t.ng_den, inv_ng) - ISDF_QUOT((s.s1 + s.s2) * tb, t.ng_den, inv_ng);
     const double zu_normb = s.zu_sqr_norm * ng_denb - (s.zu2 * z2b + s.zu1 * z1b + s.zu0 * z0b) / s.zu_sqr_norm;
-    const double zu_sqr_normb = s.zu_norm * ng_denb + zu_normb / (2.0 * s.zu_norm);
+    const double zu_sqr_normb = s.zu_norm * ng_denb + ISDF_QUOT(0.5 * zu_normb, s.zu_norm, inv_zn);
     tb += zu_sqr_normb;
     zs1b += tb;
     zs2b += tb;
-    const double zu2b = z2b / s.zu_norm + s.zu0 * zu02b + s.zu1 * zu12b + 2 * s.zu2 * zs2b;
+    const double zu2b = ISDF_QUOT(z2b, s.zu_norm, inv_zn) + s.zu0 * zu02b + s.zu1 * zu12b + 2 * s.zu2 * zs2b;
     const double w2b = P.dh_over_m * zu2b;
-    const double zu1b = z1b / s.zu_norm + s.zu2 * zu12b + s.zu0 * zu01b + 2 * s.zu1 * zs1b;
+    const double zu1b = ISDF_QUOT(z1b, s.zu_norm, inv_zn) + s.zu2 * zu12b + s.zu0 * zu01b + 2 * s.zu1 * zs1b;
     const double w1b = P.dh_over_m * zu1b;
     zs0b += zu_sqr_normb;
-    const double zu0b = z0b / s.zu_norm + s.zu2 * zu02b + s.zu1 * zu01b + 2 * s.zu0 * zs0b;
+    const double zu0b = ISDF_QUOT(z0b, s.zu_norm, inv_zn) + s.zu2 * zu02b + s.zu1 * zu01b + 2 * s.zu0 * zs0b;
     const double w0b = P.dh_over_m * zu0b;
     const double w_termb = a.z * dw2b + a.y * dw1b + a.x * dw0b + v.z * w2b + v.y * w1b + v.x * w0b;
     gA.x += zu0b; gA.y += zu1b; gA.z += zu2b;
     cp_termb += P.cp * w_termb;
-    const double vsb = cp_termb / (2.0 * s.cp_term);
+    const double vsb = ISDF_QUOT(0.5 * cp_termb, s.cp_term, inv_cp);
     gV.x += s.w_term * w0b + 2 * v.x * vsb + vel_grad.x;
     gV.y += s.w_term * w1b + 2 * v.y * vsb + vel_grad.y;
     gV.z += s.w_term * w2b + 2 * v.z * vsb + vel_grad.z;

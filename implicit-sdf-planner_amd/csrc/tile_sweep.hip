@@ -654,15 +654,15 @@ __global__ __launch_bounds__(TL_THREADS) void tail_kernel(const SweepParams P) {
                 const double violaOmg = dot3(omg, omg) - P.omg_sqr_max;
                 const double violaTheta = acos(cos_theta) - P.theta_max;
                 double pe, pd;
-                if (smoothed_l1(violaVel, P.mu, pe, pd)) {
+                if (smoothed_l1_inv(violaVel, P.mu, P.inv_mu, pe, pd)) {
                     gradVel = (P.weight_v * pd * 2.0) * vel;
                     pena += P.weight_v * pe;
                 }
-                if (smoothed_l1(violaOmg, P.mu, pe, pd)) {
+                if (smoothed_l1_inv(violaOmg, P.mu, P.inv_mu, pe, pd)) {
                     gradOmg = (P.weight_omg * pd * 2.0) * omg;
                     pena += P.weight_omg * pe;
                 }
-                if (smoothed_l1(violaTheta, P.mu, pe, pd)) {
+                if (smoothed_l1_inv(violaTheta, P.mu, P.inv_mu, pe, pd)) {
                     const double f = P.weight_theta * pd / sqrt(1.0 - cos_theta * cos_theta) * 4.0;
                     gradQuat.x += f * quat.x;
                     gradQuat.y += f * quat.y;
