@@ -42,8 +42,18 @@ __device__ __forceinline__ double m_sqrt(double x) {
     g = fma(d, h, g);
     return x > 0.0 ? g : x;
 }
+// 1 / x for the shared-divisor quotients below: rcp + two Newton steps (<= 1 ulp, normal range; 5 instructions instead of
+// the 11 of the correctly-rounded division with its scaling and fix-up).
+__device__ __forceinline__ double m_rcp(double x) {
+    double r = __builtin_amdgcn_rcp(x);
+    double e = fma(-x, r, 1.0);
+    r = fma(r, e, r);
+    e = fma(-x, r, 1.0);
+    return fma(r, e, r);
+}
 #else
 __device__ __forceinline__ double m_sqrt(double x) { return sqrt(x); }
+__device__ __forceinline__ double m_rcp(double x) { return 1.0 / x; }
 #endif
 __device__ __forceinline__ float m_sqrt(float x) { return sqrtf(x); }
 __device__ __forceinline__ double m_abs(double x) { return fabs(x); }
@@ -179,12 +189,12 @@ __device__ __forceinline__ void flat_core(const FlatP &P, d3 v, d3 a, FlatS &s) 
     s.s0 = s.zu0 * s.zu0; s.s1 = s.zu1 * s.zu1; s.s2 = s.zu2 * s.zu2;
     s.zu_sqr_norm = s.s0 + s.s1 + s.s2;
     s.zu_norm = sqrt(s.zu_sqr_norm);
-    const double inv_zn = 1.0 / s.zu_norm;
+    [[maybe_unused]] const double inv_zn = m_rcp(s.zu_norm);
     s.z0 = ISDF_QUOT(s.zu0, s.zu_norm, inv_zn); s.z1 = ISDF_QUOT(s.zu1, s.zu_norm, inv_zn); s.z2 = ISDF_QUOT(s.zu2, s.zu_norm, inv_zn);
     s.tilt_den = sqrt(2.0 * (1.0 + s.z2));
 }
 __device__ __forceinline__ d4 flat_quat(const FlatS &s) {
-    const double inv_t = 1.0 / s.tilt_den;
+    [[maybe_unused]] const double inv_t = m_rcp(s.tilt_den);
     d4 q; q.w = 0.5 * s.tilt_den; q.x = ISDF_QUOT(-s.z1, s.tilt_den, inv_t); q.y = ISDF_QUOT(s.z0, s.tilt_den, inv_t); q.z = 0.0; return q;
 }
 struct FlatS2 {
@@ -193,7 +203,7 @@ struct FlatS2 {
 };
 __device__ __forceinline__ void flat_core2(const FlatP &P, d3 v, d3 a, d3 j, const FlatS &s, FlatS2 &t) {
     t.ng_den = s.zu_sqr_norm * s.zu_norm;
-    const double inv_ng = 1.0 / t.ng_den;
+    [[maybe_unused]] const double inv_ng = m_rcp(t.ng_den);
     t.ng00 = ISDF_QUOT(s.s1 + s.s2, t.ng_den, inv_ng);
     t.zu01 = s.zu0 * s.zu1; t.zu12 = s.zu1 * s.zu2; t.zu02 = s.zu0 * s.zu2;
     t.ng01 = ISDF_QUOT(-t.zu01, t.ng_den, inv_ng);
@@ -202,7 +212,8 @@ __device__ __forceinline__ void flat_core2(const FlatP &P, d3 v, d3 a, d3 j, con
     t.ng12 = ISDF_QUOT(-t.zu12, t.ng_den, inv_ng);
     t.ng22 = ISDF_QUOT(s.s0 + s.s1, t.ng_den, inv_ng);
     t.v_dot_a = v.x * a.x + v.y * a.y + v.z * a.z;
-    t.dw_term = P.cp * t.v_dot_a / s.cp_term;
+    [[maybe_unused]] const double inv_cp = m_rcp(s.cp_term);
+    t.dw_term = ISDF_QUOT(P.cp * t.v_dot_a, s.cp_term, inv_cp);
     t.dw0 = s.w_term * a.x + t.dw_term * v.x;
     t.dw1 = s.w_term * a.y + t.dw_term * v.y;
     t.dw2 = s.w_term * a.z + t.dw_term * v.z;
@@ -213,22 +224,22 @@ __device__ __forceinline__ void flat_core2(const FlatP &P, d3 v, d3 a, d3 j, con
     t.dz1 = t.ng01 * t.dzt0 + t.ng11 * t.dzt1 + t.ng12 * t.dzt2;
     t.dz2 = t.ng02 * t.dzt0 + t.ng12 * t.dzt1 + t.ng22 * t.dzt2;
     t.omg_den = s.z2 + 1.0;
-    t.omg_term = t.dz2 / t.omg_den;
+    [[maybe_unused]] const double inv_omg = m_rcp(t.omg_den);
+    t.omg_term = ISDF_QUOT(t.dz2, t.omg_den, inv_omg);
 }
 __device__ __forceinline__ d3 flat_omg(const FlatS &s, const FlatS2 &t) {
-    return mk3(-t.dz1 + s.z1 * t.omg_term, t.dz0 - s.z0 * t.omg_term, (s.z1 * t.dz0 - s.z0 * t.dz1) / t.omg_den);
+    [[maybe_unused]] const double inv_omg = m_rcp(t.omg_den);
+    return mk3(-t.dz1 + s.z1 * t.omg_term, t.dz0 - s.z0 * t.omg_term, ISDF_QUOT(s.z1 * t.dz0 - s.z0 * t.dz1, t.omg_den, inv_omg));
 }
 
 // Reverse mode of (v,a,j) -> (quat, omega) with psi == 0; inputs are dL/dpos, dL/dvel, dL/dquat, dL/domega.
-__device__ __forceinline__ void flat_backward(const FlatP &P, d3 v, d3 a, d3 jer, d3 pos_grad, d3 vel_grad,
-                                              d4 quat_grad, d3 omg_grad, d3 &gP, d3 &gV, d3 &gA, d3 &gJ) {
-    FlatS s; FlatS2 t;
-    flat_core(P, v, a, s);
-    flat_core2(P, v, a, jer, s, t);
-    const double inv_tilt = 1.0 / s.tilt_den, inv_omg = 1.0 / t.omg_den, inv_ng = 1.0 / t.ng_den, inv_zn = 1.0 / s.zu_norm, inv_cp = 1.0 / s.cp_term;
+// flat_backward_from takes the forward intermediates the caller already holds (flat_core + flat_core2 of the same v, a, j).
+__device__ __forceinline__ void flat_backward_from(const FlatP &P, d3 v, d3 a, const FlatS &s, const FlatS2 &t, d3 pos_grad, d3 vel_grad,
+                                                   d4 quat_grad, d3 omg_grad, d3 &gP, d3 &gV, d3 &gA, d3 &gJ) {
+    [[maybe_unused]] const double inv_tilt = m_rcp(s.tilt_den), inv_omg = m_rcp(t.omg_den), inv_ng = m_rcp(t.ng_den), inv_zn = m_rcp(s.zu_norm), inv_cp = m_rcp(s.cp_term);
     const double tilt0b = quat_grad.w, tilt1b = quat_grad.x, tilt2b = quat_grad.y;
-    const double tilt_den_sqr = s.tilt_den * s.tilt_den;
-    const double tilt_denb = (s.z1 * tilt1b - s.z0 * tilt2b) / tilt_den_sqr + 0.5 * tilt0b;
+    [[maybe_unused]] const double tilt_den_sqr = s.tilt_den * s.tilt_den;
+    const double tilt_denb = ISDF_QUOT(s.z1 * tilt1b - s.z0 * tilt2b, tilt_den_sqr, inv_tilt * inv_tilt) + 0.5 * tilt0b;
     const double omg_termb = -s.z0 * omg_grad.y + s.z1 * omg_grad.x;
     double tb = ISDF_QUOT(omg_grad.z, t.omg_den, inv_omg);
     double z1b = t.dz0 * tb;
@@ -292,6 +303,13 @@ __device__ __forceinline__ void flat_backward(const FlatP &P, d3 v, d3 a, d3 jer
     gV.z += s.w_term * w2b + 2 * v.z * vsb + vel_grad.z;
     gP = pos_grad;
 }
+__device__ __forceinline__ void flat_backward(const FlatP &P, d3 v, d3 a, d3 jer, d3 pos_grad, d3 vel_grad,
+                                              d4 quat_grad, d3 omg_grad, d3 &gP, d3 &gV, d3 &gA, d3 &gJ) {
+    FlatS s; FlatS2 t;
+    flat_core(P, v, a, s);
+    flat_core2(P, v, a, jer, s, t);
+    flat_backward_from(P, v, a, s, t, pos_grad, vel_grad, quat_grad, omg_grad, gP, gV, gA, gJ);
+}
 
 // Piece-local monomial bases at local time s1.
 struct Basis { double b0[6], b1[6], b2[6], b3[6], b4[6]; };
@@ -303,18 +321,20 @@ __device__ __forceinline__ void poly_basis(double s1, Basis &B) {
     B.b3[0] = 0.0; B.b3[1] = 0.0; B.b3[2] = 0.0; B.b3[3] = 6.0; B.b3[4] = 24.0 * s1; B.b3[5] = 60.0 * s2;
     B.b4[0] = 0.0; B.b4[1] = 0.0; B.b4[2] = 0.0; B.b4[3] = 0.0; B.b4[4] = 24.0; B.b4[5] = 120.0 * s1;
 }
-// c^T beta for one piece; c points at the piece's row block, `ld` = 6N is the column stride.
-__device__ __forceinline__ d3 ct_beta(const double *__restrict__ c, int ld, const double *b) {
+// c^T beta for one piece; c points at the piece's row block, `ld` = 6N is the column stride.  K0 = the derivative order of
+// the basis: its first K0 entries are structural zeros (poly_basis) and `s + c * 0.0 == s` for every finite c, so those
+// terms may be skipped without changing a bit.
+template <int K0 = 0> __device__ __forceinline__ d3 ct_beta(const double *__restrict__ c, int ld, const double *b) {
     d3 r;
     double s = 0.0;
 #pragma unroll
-    for (int k = 0; k < 6; k++) s += c[k] * b[k];
+    for (int k = K0; k < 6; k++) s += c[k] * b[k];
     r.x = s; s = 0.0;
 #pragma unroll
-    for (int k = 0; k < 6; k++) s += c[ld + k] * b[k];
+    for (int k = K0; k < 6; k++) s += c[ld + k] * b[k];
     r.y = s; s = 0.0;
 #pragma unroll
-    for (int k = 0; k < 6; k++) s += c[2 * ld + k] * b[k];
+    for (int k = K0; k < 6; k++) s += c[2 * ld + k] * b[k];
     r.z = s;
     return r;
 }

@@ -39,7 +39,6 @@ struct isdf_ctx {
     SweepParams last_P{}; bool have_last_P = false;
     double last_exact_ms = 0.0;
     double *d_piece_cost = nullptr; size_t piece_cap = 0;
-    unsigned *d_tail_ticket = nullptr; size_t ticket_cap = 0;
     double *d_in = nullptr; size_t in_cap = 0;        // host-API staging: T | coeffs
     double *d_out = nullptr; size_t out_cap = 0;
     std::vector<double> h_out;
@@ -53,7 +52,7 @@ struct isdf_ctx {
     double *d_point_partial = nullptr; int *d_point_piece = nullptr; int point_cap = 0;
     double *d_hist = nullptr; size_t hist_cap = 0;
     // profiling
-    bool prof_on = false; int prof_every = 1; long long prof_tick = 0;
+    bool prof_on = false, prof_secondary = false; int prof_every = 1; long long prof_tick = 0;
     std::vector<ProfEvent> prof_events;
     size_t prof_used = 0;
     hipStream_t stream = nullptr;   // stream of the host API

@@ -157,7 +157,7 @@ extern "C" int isdf_destroy(isdf_ctx *c) {
     if (c->h_eval_pin) (void)hipHostFree(c->h_eval_pin);
     isdf_frontend_release(c);
     isdf_xchg_release(c);
-    void *ptrs[] = {c->d_tail_ticket, c->d_cb, c->d_esdf, c->d_occ, c->d_points, c->d_tstar, c->d_acc, c->d_sample_info, c->d_bits, c->d_piece_cost, c->d_in, c->d_out, c->d_stats,
+    void *ptrs[] = {c->d_cb, c->d_esdf, c->d_occ, c->d_points, c->d_tstar, c->d_acc, c->d_sample_info, c->d_bits, c->d_piece_cost, c->d_in, c->d_out, c->d_stats,
                     c->d_traj_duration, c->d_coarse_t, c->d_coarse_pose, c->d_n_coarse, c->d_point_partial, c->d_point_piece, c->d_hist, c->d_dbg};
     for (void *p : ptrs) if (p) (void)hipFree(p);
     free_mesh(c);
@@ -434,9 +434,10 @@ static int eval_device_impl(isdf_ctx *c, int n_traj, int N, const double *d_T, c
         int rc = prof_begin(c, st, &ev);
         if (rc) return rc;
         launch_swept_sweep(P, st, ev ? ev->a : nullptr, ev ? ev->b : nullptr);
-        if (ev) { HIPCHK(c, hipEventRecord(ev->c, st)); }
+        const bool ev2 = ev && c->prof_secondary;
+        if (ev2) { HIPCHK(c, hipEventRecord(ev->c, st)); }
         launch_swept_reduce(P, d_out, st);
-        if (ev) { HIPCHK(c, hipEventRecord(ev->d, st)); }
+        if (ev2) { HIPCHK(c, hipEventRecord(ev->d, st)); }
         HIPCHK(c, hipGetLastError());
         return ISDF_OK;
     }
@@ -459,15 +460,16 @@ static int eval_device_impl(isdf_ctx *c, int n_traj, int N, const double *d_T, c
         HIPCHK(c, hipMalloc(&c->d_sample_info, n_samples * 2 * sizeof(int)));
         c->sample_cap = n_samples;
     }
-    int rc = ensure(c, &c->d_piece_cost, &c->piece_cap, (size_t)total_pieces);
-    if (rc) return rc;
-    if (c->ticket_cap < (size_t)n_traj) {
-        if (c->d_tail_ticket) (void)hipFree(c->d_tail_ticket);
-        c->d_tail_ticket = nullptr; c->ticket_cap = 0;
-        HIPCHK(c, hipMalloc(&c->d_tail_ticket, (size_t)n_traj * sizeof(unsigned)));
-        HIPCHK(c, hipMemset(c->d_tail_ticket, 0, (size_t)n_traj * sizeof(unsigned)));
-        c->ticket_cap = (size_t)n_traj;
+    if (c->piece_cap < (size_t)total_pieces) {
+        // piece-cost slots are created EMPTY (all-ones, tile_sweep.hip TL_COST_EMPTY) and every step leaves them empty again
+        if (c->d_piece_cost) (void)hipFree(c->d_piece_cost);
+        c->d_piece_cost = nullptr; c->piece_cap = 0;
+        HIPCHK(c, hipMalloc(&c->d_piece_cost, (size_t)total_pieces * sizeof(double)));
+        HIPCHK(c, hipMemset(c->d_piece_cost, 0xFF, (size_t)total_pieces * sizeof(double)));
+        HIPCHK(c, hipDeviceSynchronize());
+        c->piece_cap = (size_t)total_pieces;
     }
+    int rc = ISDF_OK;
     SweepParams P{};
     P.grid = c->grid;
     if (!c->have_geom) { P.grid.X = P.grid.Y = P.grid.Z = 1; P.grid.res = 1.0; }
@@ -480,12 +482,12 @@ static int eval_device_impl(isdf_ctx *c, int n_traj, int N, const double *d_T, c
     P.safety_hor = cfg.safety_hor; P.weight_p = cfg.weight_p; P.weight_v = cfg.weight_v; P.weight_omg = cfg.weight_omg;
     P.weight_theta = cfg.weight_theta;
     P.vel_sqr_max = cfg.vmax * cfg.vmax; P.omg_sqr_max = cfg.omgmax * cfg.omgmax; P.theta_max = cfg.thetamax;
-    P.mu = cfg.smoothing_eps; P.inv_mu = 1.0 / cfg.smoothing_eps;
+    P.mu = cfg.smoothing_eps; P.inv_mu = 1.0 / cfg.smoothing_eps; P.inv_K = 1.0 / cfg.integral_intervs;
     P.occ_thresh = (float)cfg.occ_thresh;
     P.cull_threshold = 0.0;
     if (cfg.variant == ISDF_V3_ESDF_TILE && cfg.enable_cull && c->shape.bound_radius > 0)
         P.cull_threshold = c->shape.bound_radius + cfg.safety_hor + std::sqrt(3.0) * P.grid.res;
-    P.T = d_T; P.coeffs = d_coeffs; P.acc = c->d_acc; P.sample_info = c->d_sample_info; P.piece_cost = c->d_piece_cost; P.tail_ticket = c->d_tail_ticket;
+    P.T = d_T; P.coeffs = d_coeffs; P.acc = c->d_acc; P.sample_info = c->d_sample_info; P.piece_cost = c->d_piece_cost;
     P.out = d_out; P.stats = c->d_stats;
     P.dbg = nullptr;
     P.dbg_flags = 0;
@@ -522,7 +524,8 @@ static int eval_device_impl(isdf_ctx *c, int n_traj, int N, const double *d_T, c
     if (rc) return rc;
     if (ev && !cfg.enable_pos) { ev = nullptr; c->prof_used--; }      // no dominant kernel in a dynamics-only step
     launch_sweep(P, st, ev ? ev->a : nullptr, ev ? ev->b : nullptr);
-    launch_tail(P, st, ev ? ev->c : nullptr, ev ? ev->d : nullptr);
+    const bool ev2 = ev && c->prof_secondary;
+    launch_tail(P, st, ev2 ? ev->c : nullptr, ev2 ? ev->d : nullptr);
     HIPCHK(c, hipGetLastError());
     return ISDF_OK;
 }
@@ -841,6 +844,8 @@ extern "C" int isdf_optimize_lbfgs(isdf_ctx *c, double *x_inout, int n, const is
 extern "C" int isdf_profile_enable(isdf_ctx *c, int on) {
     if (!c) return ISDF_ERR_INVALID_ARG;
     c->prof_on = on != 0;          // on = N > 0: instrument every N-th launch (event records cost GPU time)
+    c->prof_secondary = on > 0 && (on & ISDF_PROFILE_SECONDARY) != 0;
+    on &= ~ISDF_PROFILE_SECONDARY;
     c->prof_every = on > 0 ? on : 1;
     c->prof_tick = 0;
     c->prof_used = 0;
@@ -852,12 +857,14 @@ extern "C" int isdf_profile_read(isdf_ctx *c, int *n, double *mean_ms) {
     HIPCHK(c, hipSetDevice(c->device));
     double sum = 0.0, sum2 = 0.0;
     for (size_t i = 0; i < c->prof_used; i++) {
-        HIPCHK(c, hipEventSynchronize(c->prof_events[i].d));
+        HIPCHK(c, hipEventSynchronize(c->prof_secondary ? c->prof_events[i].d : c->prof_events[i].b));
         float ms = 0.f;
         HIPCHK(c, hipEventElapsedTime(&ms, c->prof_events[i].a, c->prof_events[i].b));
         sum += ms;
-        HIPCHK(c, hipEventElapsedTime(&ms, c->prof_events[i].c, c->prof_events[i].d));
-        sum2 += ms;
+        if (c->prof_secondary) {
+            HIPCHK(c, hipEventElapsedTime(&ms, c->prof_events[i].c, c->prof_events[i].d));
+            sum2 += ms;
+        }
     }
     *n = (int)c->prof_used;
     *mean_ms = c->prof_used ? sum / c->prof_used : 0.0;

@@ -29,14 +29,14 @@ struct SweepParams {
     double bd_half;             // kernel_size * res / 2
     double safety_hor, weight_p, weight_v, weight_omg, weight_theta;
     double vel_sqr_max, omg_sqr_max, theta_max, mu, inv_mu;
+    double inv_K;               // 1.0 / K formed on the host (the reference's integralFrac, correctly rounded)
     float occ_thresh;
     double cull_threshold;      // <= 0: cull disabled
     const double *T;            // n_traj * N
     const double *coeffs;       // n_traj * (6N x 3 col-major)
     double *acc;                // [n_samples_local][ACC_STRIDE] per-pose collision sums written by sweep_kernel
     int *sample_info;           // [n_samples_local][2] exact pairs, active pairs | culled << 31 (statistics)
-    double *piece_cost;         // [n_traj * N]
-    unsigned *tail_ticket;      // [n_traj] blocks of the trajectory that have published their piece cost (self-resetting)
+    double *piece_cost;         // [n_traj * N] slots: a piece's cost once its block has published it, all-ones while empty (self-resetting)
     double *out;                // n_traj * (1 + N + 18N)
     unsigned long long *stats;  // [0]=units [1]=culled [2]=pairs [3]=grad pairs [4]=overflow
     int dbg_flags;              // developer switches (ISDF_DEBUG_FLAGS): 1 = skip the exact pass body

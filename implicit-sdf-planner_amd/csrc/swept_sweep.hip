@@ -336,8 +336,8 @@ __global__ __launch_bounds__(128) void swept_backprop_kernel(const SweptParams P
     poly_basis(time_local, B);
     const double *c = P.coeffs + 6 * i;
     const int ld = 6 * P.N;
-    const d3 pos = ct_beta(c, ld, B.b0), vel = ct_beta(c, ld, B.b1), acc3 = ct_beta(c, ld, B.b2), jer = ct_beta(c, ld, B.b3),
-             sna = ct_beta(c, ld, B.b4);
+    const d3 pos = ct_beta(c, ld, B.b0), vel = ct_beta<1>(c, ld, B.b1), acc3 = ct_beta<2>(c, ld, B.b2), jer = ct_beta<3>(c, ld, B.b3),
+             sna = ct_beta<4>(c, ld, B.b4);
     FlatS fs;
     flat_core(P.flat, vel, acc3, fs);
     const d4 quat = flat_quat(fs);

@@ -185,10 +185,10 @@ __global__ __launch_bounds__(64 * SW_SAMPLES, sweep_waves_per_simd(KIND, IDENT))
         const SampleId id = decode_sample(P, s_begin + (long long)blockIdx.x + (long long)lane * gridDim.x);
         const double *c = P.coeffs + (size_t)id.b * 18 * P.N + 6 * id.i;
         const int ld = 6 * P.N;
-        const double step = P.T[(size_t)id.b * P.N + id.i] * (1.0 / P.K);
+        const double step = P.T[(size_t)id.b * P.N + id.i] * P.inv_K;
         Basis B;
         poly_basis(id.j * step, B);
-        const d3 pos = ct_beta(c, ld, B.b0), vel = ct_beta(c, ld, B.b1), acc = ct_beta(c, ld, B.b2);
+        const d3 pos = ct_beta(c, ld, B.b0), vel = ct_beta<1>(c, ld, B.b1), acc = ct_beta<2>(c, ld, B.b2);
         FlatS fs;
         flat_core(P.flat, vel, acc, fs);
         const d4 quat = flat_quat(fs);
@@ -222,6 +222,7 @@ __global__ __launch_bounds__(64 * SW_SAMPLES, sweep_waves_per_simd(KIND, IDENT))
             // world-frame extent of the shape's body-frame bounding box inflated by the penalty band: rows whose
             // (x, y) lies outside it cannot hold a voxel with a non-zero penalty (conservative: +-1 voxel, NaN keeps all)
             const double infl = P.safety_hor * mesh_band_scale(P.shape.kind) + 4.0e-3 + 0.05 * G.res;
+            const double inv_res = m_rcp(G.res);     // the window has 0.05 voxel of slack: one reciprocal serves its four quotients
             const double hb[3] = {0.5 * ((double)P.shape.bbox_hi[0] - (double)P.shape.bbox_lo[0]) + infl,
                                   0.5 * ((double)P.shape.bbox_hi[1] - (double)P.shape.bbox_lo[1]) + infl,
                                   0.5 * ((double)P.shape.bbox_hi[2] - (double)P.shape.bbox_lo[2]) + infl};
@@ -235,7 +236,7 @@ __global__ __launch_bounds__(64 * SW_SAMPLES, sweep_waves_per_simd(KIND, IDENT))
             for (int a = 0; a < 2; a++) {
                 const double ctr = p[a] + R.a[3 * a] * cb[0] + R.a[3 * a + 1] * cb[1] + R.a[3 * a + 2] * cb[2];
                 const double ext = fabs(R.a[3 * a]) * hb[0] + fabs(R.a[3 * a + 1]) * hb[1] + fabs(R.a[3 * a + 2]) * hb[2];
-                const double l0 = (ctr - ext - G.bmin[a]) / G.res - 0.5 - lo[a], l1 = (ctr + ext - G.bmin[a]) / G.res - 0.5 - lo[a];
+                const double l0 = (ctr - ext - G.bmin[a]) * inv_res - 0.5 - lo[a], l1 = (ctr + ext - G.bmin[a]) * inv_res - 0.5 - lo[a];
                 w0[a] = 0; w1[a] = nn[a] - 1;
                 if (l0 > 0.0) w0[a] = (int)fmin(floor(l0), (double)nn[a]);          // > nn-1 -> empty window
                 if (l1 < (double)(nn[a] - 1)) w1[a] = (int)fmax(ceil(l1), -1.0);
@@ -598,10 +599,11 @@ __global__ __launch_bounds__(256) void stats_kernel(const SweepParams P) {
 // ---------------------------------------------------------------------------------------------------------------
 constexpr int TL_THREADS = 128;
 constexpr int TL_GROUPS = TL_THREADS / PARTIAL_STRIDE;     // 6 row groups x 20 columns
+constexpr unsigned long long TL_COST_EMPTY = ~0ull;        // piece-cost slot not yet published (slots are created and left in this state)
+constexpr int TL_SPIN_MAX = 1 << 20;
 
 __global__ __launch_bounds__(TL_THREADS) void tail_kernel(const SweepParams P) {
     __shared__ double s_val[TL_THREADS][PARTIAL_STRIDE + 1];   // +1: column reads by 20 threads hit distinct banks
-    __shared__ unsigned s_ticket;
     const int K1 = P.K + 1;
     const int gp = blockIdx.x;                       // global piece index (trajectory-major): one block per piece of the launch
     const int b = gp / P.N, i = gp - b * P.N;
@@ -618,7 +620,7 @@ __global__ __launch_bounds__(TL_THREADS) void tail_kernel(const SweepParams P) {
     }
     const double *c = P.coeffs + (size_t)b * 18 * P.N + 6 * i;
     const int ld = 6 * P.N;
-    const double integral_frac = 1.0 / P.K;
+    const double integral_frac = P.inv_K;
     const double step = P.T[(size_t)b * P.N + i] * integral_frac;
     double colsum = 0.0;   // threads 0..19: running sum of their output column, samples in ascending order
     unsigned long long *const dbg = P.dbg ? P.dbg + (size_t)(P.piece_end - P.piece_begin) * K1 * 8 + (size_t)(gp - P.piece_begin) * 4 : nullptr;
@@ -638,15 +640,15 @@ __global__ __launch_bounds__(TL_THREADS) void tail_kernel(const SweepParams P) {
             }
             Basis B;
             poly_basis(j * step, B);
-            const d3 vel = ct_beta(c, ld, B.b1), acc3 = ct_beta(c, ld, B.b2), jer = ct_beta(c, ld, B.b3), sna = ct_beta(c, ld, B.b4);
+            const d3 vel = ct_beta<1>(c, ld, B.b1), acc3 = ct_beta<2>(c, ld, B.b2), jer = ct_beta<3>(c, ld, B.b3), sna = ct_beta<4>(c, ld, B.b4);
             TL_MARK(0);
             double pena = 0.0;
             d3 gradVel = mk3(0, 0, 0), gradPos = gradVel, gradOmg = gradVel;
             d4 gradQuat; gradQuat.w = gradQuat.x = gradQuat.y = gradQuat.z = 0.0;
+            FlatS fs; FlatS2 ft;               // forward intermediates: shared by the penalties and the reverse mode
+            flat_core(P.flat, vel, acc3, fs);
+            flat_core2(P.flat, vel, acc3, jer, fs, ft);
             if (P.enable_dyn) {
-                FlatS fs; FlatS2 ft;
-                flat_core(P.flat, vel, acc3, fs);
-                flat_core2(P.flat, vel, acc3, jer, fs, ft);
                 const d4 quat = flat_quat(fs);
                 const d3 omg = flat_omg(fs, ft);
                 const double cos_theta = 1.0 - 2.0 * (quat.x * quat.x + quat.y * quat.y);
@@ -680,17 +682,23 @@ __global__ __launch_bounds__(TL_THREADS) void tail_kernel(const SweepParams P) {
             }
             d3 gP, gV, gA, gJ;
             TL_MARK(2);
-            flat_backward(P.flat, vel, acc3, jer, gradPos, gradVel, gradQuat, gradOmg, gP, gV, gA, gJ);
+            flat_backward_from(P.flat, vel, acc3, fs, ft, gradPos, gradVel, gradQuat, gradOmg, gP, gV, gA, gJ);
             TL_MARK(3);
             const double node = (j == 0 || j == P.K) ? 0.5 : 1.0;
             const double alpha = j * integral_frac;
             double *o = s_val[threadIdx.x];
             const double gPv[3] = {gP.x, gP.y, gP.z}, gVv[3] = {gV.x, gV.y, gV.z}, gAv[3] = {gA.x, gA.y, gA.z}, gJv[3] = {gJ.x, gJ.y, gJ.z};
+            // rows below a basis' derivative order meet its structural zeros: those products are skipped (same bits)
 #pragma unroll
             for (int d = 0; d < 3; d++)
 #pragma unroll
-                for (int r = 0; r < 6; r++)
-                    o[d * 6 + r] = (B.b0[r] * gPv[d] + B.b1[r] * gVv[d] + B.b2[r] * gAv[d] + B.b3[r] * gJv[d]) * node * step;
+                for (int r = 0; r < 6; r++) {
+                    double v = B.b0[r] * gPv[d];
+                    if (r >= 1) v += B.b1[r] * gVv[d];
+                    if (r >= 2) v += B.b2[r] * gAv[d];
+                    if (r >= 3) v += B.b3[r] * gJv[d];
+                    o[d * 6 + r] = v * node * step;
+                }
             o[18] = (dot3(gP, vel) + dot3(gV, acc3) + dot3(gA, jer) + dot3(gJ, sna)) * alpha * node * step + node * integral_frac * pena;
             o[19] = node * step * pena;
         }
@@ -721,22 +729,33 @@ __global__ __launch_bounds__(TL_THREADS) void tail_kernel(const SweepParams P) {
             const int d = q / 6, r = q - 6 * d;
             o[1 + P.N + (size_t)d * 6 * P.N + 6 * i + r] = colsum;
         } else {
-            // Trajectory cost = fixed-order sum of the piece costs, formed by whichever block of the trajectory finishes
-            // last: publish this piece's cost write-through (agent-scope store), drain it, take a ticket.
-            __hip_atomic_store(&P.piece_cost[gp], colsum, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            s_ticket = atomicAdd(&P.tail_ticket[b], 1u);
+            // Trajectory cost = fixed-order sum of the piece costs.  Each block publishes its piece's cost in the piece's slot
+            // (agent-scope store: value and "ready" flag are the same 8 bytes, an empty slot holds TL_COST_EMPTY).
+            unsigned long long bits = (unsigned long long)__double_as_longlong(colsum);
+            if (bits == TL_COST_EMPTY) bits = 0x7FF8000000000000ull;          // an all-ones NaN would read as "not published"
+            __hip_atomic_store((unsigned long long *)&P.piece_cost[gp], bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
     }
-    __syncthreads();
-    if (s_ticket == (unsigned)(p1 - p0 - 1)) {       // every other block of this trajectory has published its cost
-        if (threadIdx.x < 64) {
-            double sum = 0.0;
-            for (int k = p0 + (int)threadIdx.x; k < p1; k += 64)
-                sum += __hip_atomic_load(&P.piece_cost[(size_t)b * P.N + k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            sum = wave_sum(sum);
-            if (threadIdx.x == 0) { o[0] = sum; P.tail_ticket[b] = 0u; }     // ticket ready for the next step
+    // The block of the trajectory's LAST piece collects them: workgroups are dispatched in index order, so every block it
+    // waits for is already resident or finished.  One lane per piece polls its slot, takes the value and empties the slot
+    // for the next step; the poll is bounded (a lost block must not hang the stream: NaN cost + the overflow flag instead).
+    if (i == p1 - 1 && threadIdx.x < 64) {
+        double sum = 0.0;
+        bool lost = false;
+        for (int k = p0 + (int)threadIdx.x; k < p1; k += 64) {
+            unsigned long long *slot = (unsigned long long *)&P.piece_cost[(size_t)b * P.N + k];
+            unsigned long long v = __hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            for (int spin = 0; v == TL_COST_EMPTY && spin < TL_SPIN_MAX; spin++) {
+                __builtin_amdgcn_s_sleep(1);
+                v = __hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            lost = lost || v == TL_COST_EMPTY;
+            __hip_atomic_store(slot, TL_COST_EMPTY, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            sum += __longlong_as_double((long long)v);
         }
+        sum = wave_sum(sum);
+        if (__ballot(lost) != 0ull) { sum = __longlong_as_double(0x7FF8000000000000ll); if (threadIdx.x == 0) atomicMax(&P.stats[4], 1ull); }
+        if (threadIdx.x == 0) o[0] = sum;
     }
     if (dbg && threadIdx.x == 0) dbg[1] = wall_clock64();
 }

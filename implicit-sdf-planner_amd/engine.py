@@ -337,9 +337,11 @@ class Engine:
         return {"units": s.n_units, "culled": s.n_units_culled, "pairs": s.n_pairs,
                 "grad_pairs": s.n_grad_pairs, "overflow": s.overflow}
 
-    def profile_enable(self, every=1):
-        """every = N > 0: instrument every N-th eval_device; 0/False: off."""
-        self._check(self.lib.isdf_profile_enable(self.h, int(every)))
+    def profile_enable(self, every=1, secondary=False):
+        """every = N > 0: instrument every N-th eval_device (dominant kernel; secondary=True: also the kernel after it);
+        0/False: off."""
+        every = int(every)
+        self._check(self.lib.isdf_profile_enable(self.h, every | (0x10000 if (secondary and every > 0) else 0)))
 
     def profile_read(self):
         n = C.c_int(0)

@@ -331,11 +331,13 @@ int isdf_frontend_cspace(isdf_ctx *ctx, uint32_t *free_mask_out, double *kernel_
 /* on = N > 0: every N-th isdf_eval_device attaches HIP start/stop events to the dispatch of its dominant kernel on
  * `stream` (hipExtLaunchKernel: the kernel's own begin/end timestamps, the interval rocprofv3 reports);
  * isdf_profile_read synchronises and returns the number of launches recorded since the last read and their
- * mean duration in milliseconds.  on = 0 disables. */
+ * mean duration in milliseconds.  on = 0 disables.  on = N | ISDF_PROFILE_SECONDARY also times the kernel that follows
+ * the dominant one (two more events per instrumented launch; each timed dispatch costs the stream a few microseconds). */
+#define ISDF_PROFILE_SECONDARY 0x10000
 int isdf_profile_enable(isdf_ctx *ctx, int on);
 int isdf_profile_read(isdf_ctx *ctx, int *n_launches, double *mean_ms);
 /* Mean duration (ms) of the kernel that follows the dominant one in the same launches (tail_kernel / the V1 reduce),
- * valid after isdf_profile_read. */
+ * valid after isdf_profile_read when ISDF_PROFILE_SECONDARY was set (0 otherwise). */
 int isdf_profile_read_secondary(isdf_ctx *ctx, double *mean_ms);
 /* Counters of the last evaluation (for tests / roofline bookkeeping). */
 typedef struct isdf_stats {
