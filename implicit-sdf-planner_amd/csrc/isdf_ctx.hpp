@@ -52,6 +52,7 @@ struct isdf_ctx {
     double *d_point_partial = nullptr; int *d_point_piece = nullptr; int point_cap = 0;
     double *d_hist = nullptr; size_t hist_cap = 0;
     // profiling
+    bool fuse_small = true;     // developer switch ISDF_NO_FUSE=1: always sweep + tail as two launches
     bool prof_on = false, prof_secondary = false; int prof_every = 1; long long prof_tick = 0;
     std::vector<ProfEvent> prof_events;
     size_t prof_used = 0;

@@ -458,10 +458,13 @@ static int eval_device_impl(isdf_ctx *c, int n_traj, int N, const double *d_T, c
         c->d_acc = nullptr; c->d_sample_info = nullptr; c->sample_cap = 0;
         HIPCHK(c, hipMalloc(&c->d_acc, n_samples * ACC_STRIDE * sizeof(double)));
         HIPCHK(c, hipMalloc(&c->d_sample_info, n_samples * 2 * sizeof(int)));
+        // result slots are created EMPTY (all-ones, tile_sweep.hip SLOT_EMPTY); every step leaves them empty again
+        HIPCHK(c, hipMemset(c->d_acc, 0xFF, n_samples * ACC_STRIDE * sizeof(double)));
+        HIPCHK(c, hipDeviceSynchronize());
         c->sample_cap = n_samples;
     }
     if (c->piece_cap < (size_t)total_pieces) {
-        // piece-cost slots are created EMPTY (all-ones, tile_sweep.hip TL_COST_EMPTY) and every step leaves them empty again
+        // piece-cost slots: created EMPTY like the collision sums' slots
         if (c->d_piece_cost) (void)hipFree(c->d_piece_cost);
         c->d_piece_cost = nullptr; c->piece_cap = 0;
         HIPCHK(c, hipMalloc(&c->d_piece_cost, (size_t)total_pieces * sizeof(double)));
@@ -492,6 +495,7 @@ static int eval_device_impl(isdf_ctx *c, int n_traj, int N, const double *d_T, c
     P.dbg = nullptr;
     P.dbg_flags = 0;
     if (const char *e = getenv("ISDF_DEBUG_FLAGS")) P.dbg_flags = atoi(e);
+    if (const char *e = getenv("ISDF_NO_FUSE")) c->fuse_small = e[0] != '1';
     if (const char *e = getenv("ISDF_DEBUG_TIMING")) if (e[0] == '1') {
         const size_t need = n_samples * 8 + (size_t)total_pieces * 4 + 4;
         if (c->dbg_cap < need) {
@@ -523,9 +527,11 @@ static int eval_device_impl(isdf_ctx *c, int n_traj, int N, const double *d_T, c
     rc = prof_begin(c, st, &ev);
     if (rc) return rc;
     if (ev && !cfg.enable_pos) { ev = nullptr; c->prof_used--; }      // no dominant kernel in a dynamics-only step
-    launch_sweep(P, st, ev ? ev->a : nullptr, ev ? ev->b : nullptr);
     const bool ev2 = ev && c->prof_secondary;
-    launch_tail(P, st, ev2 ? ev->c : nullptr, ev2 ? ev->d : nullptr);
+    // a small step (one trajectory) is ONE launch: the tail's workgroups ride behind the sweep's (tile_sweep.hip, FUSED)
+    const bool fused = c->fuse_small && !ev2 && sweep_can_fuse(P);
+    launch_sweep(P, st, ev ? ev->a : nullptr, ev ? ev->b : nullptr, fused);
+    if (!fused) launch_tail(P, st, ev2 ? ev->c : nullptr, ev2 ? ev->d : nullptr);
     HIPCHK(c, hipGetLastError());
     return ISDF_OK;
 }

@@ -29,6 +29,7 @@ struct SweepParams {
     double bd_half;             // kernel_size * res / 2
     double safety_hor, weight_p, weight_v, weight_omg, weight_theta;
     double vel_sqr_max, omg_sqr_max, theta_max, mu, inv_mu;
+    int n_sweep_blocks;         // set by launch_sweep: sweep workgroups of the launch (a fused launch appends one tail workgroup per piece)
     double inv_K;               // 1.0 / K formed on the host (the reference's integralFrac, correctly rounded)
     float occ_thresh;
     double cull_threshold;      // <= 0: cull disabled
@@ -46,7 +47,8 @@ struct SweepParams {
 // one optimizer step of the integral sweep = sweep, tail, in order, on `stream`
 // ev_start / ev_stop (nullable): HIP events attached to the kernel dispatch itself (hipExtLaunchKernelGGL), i.e. its begin and
 // end timestamps - the same interval rocprofv3 reports for the kernel
-void launch_sweep(const SweepParams &P, hipStream_t stream, hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr);
+bool sweep_can_fuse(const SweepParams &P);      // small launch, analytic shape with identity body offset: sweep + tail in one launch
+void launch_sweep(const SweepParams &P, hipStream_t stream, hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr, bool fused = false);
 void launch_stats(const SweepParams &P, hipStream_t stream);   // on demand, not part of the step
 void launch_build_bits(const DevGrid &G, int use_esdf, float thresh, unsigned *out, hipStream_t stream);
 void launch_tail(const SweepParams &P, hipStream_t stream, hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr);

@@ -122,6 +122,26 @@ __device__ __forceinline__ int wave_excl_scan(int v, int lane, int &total) {
 // built once per set_grid by build_bits_kernel), 32 voxels of a z-row per dword.
 constexpr int SW_SAMPLES = 4;
 
+// Hand-over between the sweep and the per-piece tail: every 8-byte result slot (the 8 collision sums of a sample, the cost
+// of a piece) is its own "ready" flag.  A slot is created EMPTY (all-ones), the producer fills it with one agent-scope
+// store, the consumer polls it, takes the value and empties it again - so the consumer may already be running while the
+// producer still works (the fused launch below), and nothing has to be cleared between steps.
+constexpr int TL_THREADS = 128;                        // tail: threads per piece (one per sample, K + 1 <= 128 per pass)
+constexpr int TL_GROUPS = TL_THREADS / PARTIAL_STRIDE;     // 6 row groups x 20 columns
+constexpr unsigned long long SLOT_EMPTY = ~0ull;
+constexpr int SLOT_SPIN_MAX = 1 << 20;                 // bounded wait: a lost producer must not hang the stream
+__device__ __forceinline__ void slot_publish(double *slot, double v) {
+    unsigned long long bits = (unsigned long long)__double_as_longlong(v);
+    if (bits == SLOT_EMPTY) bits = 0x7FF8000000000000ull;          // an all-ones NaN would read as "not published"
+    __hip_atomic_store((unsigned long long *)slot, bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ unsigned long long slot_peek(const double *slot) {
+    return __hip_atomic_load((const unsigned long long *)slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void slot_clear(double *slot) {
+    __hip_atomic_store((unsigned long long *)slot, SLOT_EMPTY, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
 struct SweepPose {                 // LDS record of one sample, written by the pose lane
     double pos[3];
     double R[9];                   // row-major body->world rotation
@@ -160,8 +180,19 @@ constexpr int sweep_waves_per_simd(int kind, bool ident) {
 
 // IDENT: the shape's body offset is the identity (poly_params all zero - every shipped config): those instantiations drop
 // the offset and the 24 scalar registers it pins, which takes Box to 91 VGPRs and a fifth wave per SIMD.
-template <int KIND, bool IDENT>
-__global__ __launch_bounds__(64 * SW_SAMPLES, sweep_waves_per_simd(KIND, IDENT)) void sweep_kernel(const SweepParams P) {
+template <bool EARLY> __device__ __forceinline__ void tail_piece(const SweepParams &P, const int gp, double (*s_val)[PARTIAL_STRIDE + 1]);
+
+// FUSED: the launch carries, after its P.n_sweep_blocks sweep workgroups, one workgroup per piece that runs the tail
+// (tail_piece) - dispatched last, it does the collision-independent part of its samples while the sweep works and picks the
+// collision sums up from their slots as they arrive, so a small step (one trajectory) is one launch without the inter-kernel
+// gap.  Only launches whose workgroups are all resident at 3 per CU use it (launch_sweep); register budget: 3 waves per SIMD.
+template <int KIND, bool IDENT, bool FUSED>
+__global__ __launch_bounds__(64 * SW_SAMPLES, FUSED ? 3 : sweep_waves_per_simd(KIND, IDENT)) void sweep_kernel(const SweepParams P) {
+    const int n_blocks = FUSED ? P.n_sweep_blocks : (int)gridDim.x;       // sweep workgroups of this launch
+    if constexpr (FUSED) {
+        __shared__ double s_tail[TL_THREADS][PARTIAL_STRIDE + 1];
+        if ((int)blockIdx.x >= n_blocks) { tail_piece<false>(P, (int)blockIdx.x - n_blocks, s_tail); return; }
+    }
     __shared__ SweepPose s_pose[SW_SAMPLES];
     __shared__ unsigned s_list[SW_SAMPLES][SW_LIST_CAP];          // ring of compacted voxels awaiting the fp32 test
     __shared__ unsigned s_near[SW_SAMPLES][SW_NEAR_CAP];          // ring of candidates awaiting the exact pass
@@ -174,15 +205,15 @@ __global__ __launch_bounds__(64 * SW_SAMPLES, sweep_waves_per_simd(KIND, IDENT))
     const int K1 = P.K + 1;
     const long long s_begin = (long long)P.piece_begin * K1, s_end = (long long)P.piece_end * K1;
     const DevGrid &G = P.grid;
-    // wave w of workgroup b takes sample b + w * gridDim.x: the samples of one workgroup are far apart on the
+    // wave w of workgroup b takes sample b + w * n_blocks: the samples of one workgroup are far apart on the
     // trajectory, so their candidate counts are uncorrelated and the workgroup's exact work evens out
-    const long long sidx = s_begin + (long long)blockIdx.x + (long long)wave * gridDim.x;
+    const long long sidx = s_begin + (long long)blockIdx.x + (long long)wave * n_blocks;
     unsigned long long *const dbg = (P.dbg && sidx < s_end) ? P.dbg + (size_t)(sidx - s_begin) * 8 : nullptr;
     if (dbg && lane == 0) { dbg[0] = wall_clock64(); dbg[1] = clock64(); }
 
     // ---- poses of the workgroup's samples: one LANE per sample (the serial fp64 chain is issued once, not per wave)
-    if (wave == 0 && lane < SW_SAMPLES && s_begin + (long long)blockIdx.x + (long long)lane * gridDim.x < s_end) {
-        const SampleId id = decode_sample(P, s_begin + (long long)blockIdx.x + (long long)lane * gridDim.x);
+    if (wave == 0 && lane < SW_SAMPLES && s_begin + (long long)blockIdx.x + (long long)lane * n_blocks < s_end) {
+        const SampleId id = decode_sample(P, s_begin + (long long)blockIdx.x + (long long)lane * n_blocks);
         const double *c = P.coeffs + (size_t)id.b * 18 * P.N + 6 * id.i;
         const int ld = 6 * P.N;
         const double step = P.T[(size_t)id.b * P.N + id.i] * P.inv_K;
@@ -567,7 +598,7 @@ __global__ __launch_bounds__(64 * SW_SAMPLES, sweep_waves_per_simd(KIND, IDENT))
     // ---- (5) results of this wave's sample
     if (have_sample) {
         const long long sl = sidx - s_begin;
-        if (lane < ACC_STRIDE) P.acc[(size_t)sl * ACC_STRIDE + lane] = tot;
+        if (lane < ACC_STRIDE) slot_publish(&P.acc[(size_t)sl * ACC_STRIDE + lane], tot);
         else if (lane == ACC_STRIDE) P.sample_info[2 * sl] = tot_n;
         else if (lane == ACC_STRIDE + 1) P.sample_info[2 * sl + 1] = tot_n | ((flags & 2) ? (int)0x80000000 : 0);
     }
@@ -595,24 +626,19 @@ __global__ __launch_bounds__(256) void stats_kernel(const SweepParams P) {
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-// tail_kernel: block per piece, thread per sample
+// tail: workgroup per piece, thread per sample (tail_kernel, or the trailing workgroups of a fused sweep launch)
 // ---------------------------------------------------------------------------------------------------------------
-constexpr int TL_THREADS = 128;
-constexpr int TL_GROUPS = TL_THREADS / PARTIAL_STRIDE;     // 6 row groups x 20 columns
-constexpr unsigned long long TL_COST_EMPTY = ~0ull;        // piece-cost slot not yet published (slots are created and left in this state)
-constexpr int TL_SPIN_MAX = 1 << 20;
-
-__global__ __launch_bounds__(TL_THREADS) void tail_kernel(const SweepParams P) {
-    __shared__ double s_val[TL_THREADS][PARTIAL_STRIDE + 1];   // +1: column reads by 20 threads hit distinct banks
+// EARLY: the collision sums are already there (separate launch after the sweep): request them before the forward pass
+template <bool EARLY> __device__ __forceinline__ void tail_piece(const SweepParams &P, const int gp, double (*s_val)[PARTIAL_STRIDE + 1]) {
     const int K1 = P.K + 1;
-    const int gp = blockIdx.x;                       // global piece index (trajectory-major): one block per piece of the launch
-    const int b = gp / P.N, i = gp - b * P.N;
+    const int tid = threadIdx.x;                     // threads >= TL_THREADS (fused launch: 256 per workgroup) only keep the barriers
+    const int b = gp / P.N, i = gp - b * P.N;        // gp = global piece index (trajectory-major)
     const size_t ostride = (size_t)1 + 19 * (size_t)P.N;
     const int p0 = max(P.piece_begin, b * P.N) - b * P.N, p1 = min(P.piece_end, (b + 1) * P.N) - b * P.N;   // this rank's pieces of trajectory b
     if (i < p0 || i >= p1) {
         // a piece of another rank: its entries are zero here, so that the ranks' outputs sum to the full result
         double *o = P.out + (size_t)b * ostride;
-        const int q = threadIdx.x;
+        const int q = tid;
         if (q == 18) o[1 + i] = 0.0;
         else if (q < 18) { const int d = q / 6, r = q - 6 * d; o[1 + P.N + (size_t)d * 6 * P.N + 6 * i + r] = 0.0; }
         else if (q == 19 && p1 <= p0 && i == 0) o[0] = 0.0;    // no piece of this trajectory is ours
@@ -623,20 +649,20 @@ __global__ __launch_bounds__(TL_THREADS) void tail_kernel(const SweepParams P) {
     const double integral_frac = P.inv_K;
     const double step = P.T[(size_t)b * P.N + i] * integral_frac;
     double colsum = 0.0;   // threads 0..19: running sum of their output column, samples in ascending order
+    bool lost = false;     // a result slot that never arrived
     unsigned long long *const dbg = P.dbg ? P.dbg + (size_t)(P.piece_end - P.piece_begin) * K1 * 8 + (size_t)(gp - P.piece_begin) * 4 : nullptr;
     unsigned long long tl_c0 = 0, tl_marks = 0;
-    if (dbg && threadIdx.x == 0) { dbg[0] = wall_clock64(); tl_c0 = clock64(); }
-#define TL_MARK(k) do { if (dbg && threadIdx.x == 0) tl_marks |= (((clock64() - tl_c0) >> 4) & 0xFFFFull) << (16 * (k)); } while (0)
+    if (dbg && tid == 0) { dbg[0] = wall_clock64(); tl_c0 = clock64(); }
+#define TL_MARK(k) do { if (dbg && tid == 0) tl_marks |= (((clock64() - tl_c0) >> 4) & 0xFFFFull) << (16 * (k)); } while (0)
     for (int j0 = 0; j0 < K1; j0 += TL_THREADS) {
-        const int j = j0 + threadIdx.x;
-        if (j < K1) {
+        const int j = j0 + tid;
+        if (tid < TL_THREADS && j < K1) {
             const long long s = (long long)gp * K1 + j;
-            // this pose's collision sums (sweep_kernel): requested first, so the loads fly under the flatness forward pass
-            double a[ACC_STRIDE] = {0, 0, 0, 0, 0, 0, 0, 0};
-            if (P.enable_pos) {
-                const double *ap = P.acc + (size_t)(s - (long long)P.piece_begin * K1) * ACC_STRIDE;
+            double *const ap = P.acc + (size_t)(s - (long long)P.piece_begin * K1) * ACC_STRIDE;
+            unsigned long long ab[EARLY ? ACC_STRIDE : 1];
+            if (EARLY && P.enable_pos) {
 #pragma unroll
-                for (int q = 0; q < ACC_STRIDE; q++) a[q] = ap[q];
+                for (int q = 0; q < ACC_STRIDE; q++) ab[q] = slot_peek(ap + q);
             }
             Basis B;
             poly_basis(j * step, B);
@@ -673,6 +699,28 @@ __global__ __launch_bounds__(TL_THREADS) void tail_kernel(const SweepParams P) {
             }
             TL_MARK(1);
             if (P.enable_pos) {
+                // the sums may still be on their way (fused launch: the sweep's workgroups run beside this one): poll what
+                // is missing, then hand the slots back empty
+                double a[ACC_STRIDE];
+                {
+                    unsigned long long v[ACC_STRIDE];
+                    bool ok = false;
+                    for (int spin = 0; spin < SLOT_SPIN_MAX; spin++) {          // one poll = the 8 slots requested together
+                        ok = true;
+#pragma unroll
+                        for (int q = 0; q < ACC_STRIDE; q++) {
+                            v[q] = (EARLY && spin == 0) ? ab[EARLY ? q : 0] : slot_peek(ap + q);
+                            ok = ok && v[q] != SLOT_EMPTY;
+                        }
+                        if (ok) break;
+                        __builtin_amdgcn_s_sleep(2);
+                    }
+                    lost = lost || !ok;
+#pragma unroll
+                    for (int q = 0; q < ACC_STRIDE; q++) a[q] = __longlong_as_double((long long)v[q]);
+                }
+#pragma unroll
+                for (int q = 0; q < ACC_STRIDE; q++) slot_clear(ap + q);
                 if (a[0] > 0.0) {
                     gradPos.x += P.weight_p * a[1]; gradPos.y += P.weight_p * a[2]; gradPos.z += P.weight_p * a[3];
                     gradQuat.w += P.weight_p * a[4]; gradQuat.x += P.weight_p * a[5];
@@ -686,7 +734,7 @@ __global__ __launch_bounds__(TL_THREADS) void tail_kernel(const SweepParams P) {
             TL_MARK(3);
             const double node = (j == 0 || j == P.K) ? 0.5 : 1.0;
             const double alpha = j * integral_frac;
-            double *o = s_val[threadIdx.x];
+            double *o = s_val[tid];
             const double gPv[3] = {gP.x, gP.y, gP.z}, gVv[3] = {gV.x, gV.y, gV.z}, gAv[3] = {gA.x, gA.y, gA.z}, gJv[3] = {gJ.x, gJ.y, gJ.z};
             // rows below a basis' derivative order meet its structural zeros: those products are skipped (same bits)
 #pragma unroll
@@ -706,67 +754,83 @@ __global__ __launch_bounds__(TL_THREADS) void tail_kernel(const SweepParams P) {
         // column sums in two fixed-shape stages: TL_GROUPS partial sums per column (rows g, g + TL_GROUPS, ...), then their sum
         {
             const int n = min(TL_THREADS, K1 - j0);
-            const int col = threadIdx.x % PARTIAL_STRIDE, grp = threadIdx.x / PARTIAL_STRIDE;
+            const int col = tid % PARTIAL_STRIDE, grp = tid / PARTIAL_STRIDE;
             double part = 0.0;
             if (grp < TL_GROUPS) for (int t = grp; t < n; t += TL_GROUPS) part += s_val[t][col];
             __syncthreads();                                   // every row has been read: rows 0..TL_GROUPS-1 are reused
             if (grp < TL_GROUPS) s_val[grp][col] = part;
             __syncthreads();
-            if (threadIdx.x < PARTIAL_STRIDE) {
+            if (tid < PARTIAL_STRIDE) {
 #pragma unroll
-                for (int g = 0; g < TL_GROUPS; g++) colsum += s_val[g][threadIdx.x];
+                for (int g = 0; g < TL_GROUPS; g++) colsum += s_val[g][tid];
             }
         }
         __syncthreads();
     }
-    if (dbg && threadIdx.x == 0) { dbg[2] = tl_marks; dbg[3] = (clock64() - tl_c0) >> 4; }
+    if (dbg && tid == 0) { dbg[2] = tl_marks; dbg[3] = (clock64() - tl_c0) >> 4; }
 #undef TL_MARK
+    if (lost && P.stats) atomicMax(&P.stats[4], 1ull);
     double *o = P.out + (size_t)b * ostride;
-    if (threadIdx.x < PARTIAL_STRIDE) {
-        const int q = threadIdx.x;
+    if (tid < PARTIAL_STRIDE) {
+        const int q = tid;
         if (q == 18) o[1 + i] = colsum;
         else if (q < 18) {
             const int d = q / 6, r = q - 6 * d;
             o[1 + P.N + (size_t)d * 6 * P.N + 6 * i + r] = colsum;
         } else {
-            // Trajectory cost = fixed-order sum of the piece costs.  Each block publishes its piece's cost in the piece's slot
-            // (agent-scope store: value and "ready" flag are the same 8 bytes, an empty slot holds TL_COST_EMPTY).
-            unsigned long long bits = (unsigned long long)__double_as_longlong(colsum);
-            if (bits == TL_COST_EMPTY) bits = 0x7FF8000000000000ull;          // an all-ones NaN would read as "not published"
-            __hip_atomic_store((unsigned long long *)&P.piece_cost[gp], bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            // Trajectory cost = fixed-order sum of the piece costs: each workgroup publishes its piece's cost in the piece's slot
+            slot_publish(&P.piece_cost[gp], colsum);
         }
     }
-    // The block of the trajectory's LAST piece collects them: workgroups are dispatched in index order, so every block it
+    // The workgroup of the trajectory's LAST piece collects them: workgroups are dispatched in index order, so every one it
     // waits for is already resident or finished.  One lane per piece polls its slot, takes the value and empties the slot
-    // for the next step; the poll is bounded (a lost block must not hang the stream: NaN cost + the overflow flag instead).
-    if (i == p1 - 1 && threadIdx.x < 64) {
+    // for the next step; the poll is bounded (NaN cost + the overflow flag instead of a hung stream).
+    if (i == p1 - 1 && tid < 64) {
         double sum = 0.0;
-        bool lost = false;
-        for (int k = p0 + (int)threadIdx.x; k < p1; k += 64) {
-            unsigned long long *slot = (unsigned long long *)&P.piece_cost[(size_t)b * P.N + k];
-            unsigned long long v = __hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            for (int spin = 0; v == TL_COST_EMPTY && spin < TL_SPIN_MAX; spin++) {
+        bool gone = false;
+        for (int k = p0 + tid; k < p1; k += 64) {
+            double *slot = &P.piece_cost[(size_t)b * P.N + k];
+            unsigned long long v = slot_peek(slot);
+            for (int spin = 0; v == SLOT_EMPTY && spin < SLOT_SPIN_MAX; spin++) {
                 __builtin_amdgcn_s_sleep(1);
-                v = __hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                v = slot_peek(slot);
             }
-            lost = lost || v == TL_COST_EMPTY;
-            __hip_atomic_store(slot, TL_COST_EMPTY, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            gone = gone || v == SLOT_EMPTY;
+            slot_clear(slot);
             sum += __longlong_as_double((long long)v);
         }
         sum = wave_sum(sum);
-        if (__ballot(lost) != 0ull) { sum = __longlong_as_double(0x7FF8000000000000ll); if (threadIdx.x == 0) atomicMax(&P.stats[4], 1ull); }
-        if (threadIdx.x == 0) o[0] = sum;
+        if (__ballot(gone) != 0ull) { sum = __longlong_as_double(0x7FF8000000000000ll); if (tid == 0 && P.stats) atomicMax(&P.stats[4], 1ull); }
+        if (tid == 0) o[0] = sum;
     }
-    if (dbg && threadIdx.x == 0) dbg[1] = wall_clock64();
+    if (dbg && tid == 0) dbg[1] = wall_clock64();
 }
 
-void launch_sweep(const SweepParams &P, hipStream_t stream, hipEvent_t ev_start, hipEvent_t ev_stop) {
+__global__ __launch_bounds__(TL_THREADS) void tail_kernel(const SweepParams P) {
+    __shared__ double s_val[TL_THREADS][PARTIAL_STRIDE + 1];   // +1: column reads by 20 threads hit distinct banks
+    tail_piece<true>(P, (int)blockIdx.x, s_val);               // one workgroup per piece of the launch
+}
+
+// Workgroups a fused launch may have: all of them resident at once, 3 per CU (the fused kernels' register budget)
+constexpr int FUSED_MAX_BLOCKS = 3 * 256;
+
+bool sweep_can_fuse(const SweepParams &P) {
+    if (!P.enable_pos || P.shape.kind == ISDF_SHAPE_MESH || P.shape.d.ident == 0) return false;
+    const long long n_samples = (long long)(P.piece_end - P.piece_begin) * (P.K + 1);
+    if (n_samples <= 0) return false;
+    return (n_samples + SW_SAMPLES - 1) / SW_SAMPLES + (long long)P.n_traj * P.N <= FUSED_MAX_BLOCKS;
+}
+
+// fused = true: sweep workgroups + one tail workgroup per piece in ONE launch (the caller then skips launch_tail)
+void launch_sweep(const SweepParams &P0, hipStream_t stream, hipEvent_t ev_start, hipEvent_t ev_stop, bool fused) {
+    SweepParams P = P0;
     const long long n_samples = (long long)(P.piece_end - P.piece_begin) * (P.K + 1);
     if (n_samples <= 0 || !P.enable_pos) return;
-    const dim3 grid((unsigned)((n_samples + SW_SAMPLES - 1) / SW_SAMPLES)), block(64 * SW_SAMPLES);
+    P.n_sweep_blocks = (int)((n_samples + SW_SAMPLES - 1) / SW_SAMPLES);
+    const dim3 grid((unsigned)(P.n_sweep_blocks + (fused ? P.n_traj * P.N : 0))), block(64 * SW_SAMPLES);
     const bool ident = P.shape.d.ident != 0;
-#define ISDF_LAUNCH_SWEEP(K, I) hipExtLaunchKernelGGL((sweep_kernel<K, I>), grid, block, 0, stream, ev_start, ev_stop, 0, P)
-#define ISDF_SWEEP_CASE(K) case K: if (ident) ISDF_LAUNCH_SWEEP(K, true); else ISDF_LAUNCH_SWEEP(K, false); break;
+#define ISDF_LAUNCH_SWEEP(K, I, F) hipExtLaunchKernelGGL((sweep_kernel<K, I, F>), grid, block, 0, stream, ev_start, ev_stop, 0, P)
+#define ISDF_SWEEP_CASE(K) case K: if (fused) ISDF_LAUNCH_SWEEP(K, true, true); else if (ident) ISDF_LAUNCH_SWEEP(K, true, false); else ISDF_LAUNCH_SWEEP(K, false, false); break;
     switch (P.shape.kind) {
     // one instantiation per analytic class (sw_manager.hpp:74-123 + Box): each inlines exactly one SDF formula
     ISDF_SWEEP_CASE(ISDF_SHAPE_TORUS) ISDF_SWEEP_CASE(ISDF_SHAPE_CAPPEDTORUS) ISDF_SWEEP_CASE(ISDF_SHAPE_CAPPEDCONE)
@@ -774,8 +838,8 @@ void launch_sweep(const SweepParams &P, hipStream_t stream, hipEvent_t ev_start,
     ISDF_SWEEP_CASE(ISDF_SHAPE_TWISTBOX) ISDF_SWEEP_CASE(ISDF_SHAPE_BENDBOX) ISDF_SWEEP_CASE(ISDF_SHAPE_TABLE)
     ISDF_SWEEP_CASE(ISDF_SHAPE_TREFOIL) ISDF_SWEEP_CASE(ISDF_SHAPE_SMOOTHDIFFERENCE) ISDF_SWEEP_CASE(ISDF_SHAPE_SMOOTHINTERSECTION)
     ISDF_SWEEP_CASE(ISDF_SHAPE_CSG) ISDF_SWEEP_CASE(ISDF_SHAPE_BOX)
-    case ISDF_SHAPE_MESH: ISDF_LAUNCH_SWEEP(ISDF_SHAPE_MESH, false); break;
-    default: if (ident) ISDF_LAUNCH_SWEEP(-1, true); else ISDF_LAUNCH_SWEEP(-1, false); break;      // Ball (and anything new)
+    case ISDF_SHAPE_MESH: ISDF_LAUNCH_SWEEP(ISDF_SHAPE_MESH, false, false); break;
+    default: if (fused) ISDF_LAUNCH_SWEEP(-1, true, true); else if (ident) ISDF_LAUNCH_SWEEP(-1, true, false); else ISDF_LAUNCH_SWEEP(-1, false, false); break;      // Ball (and anything new)
     }
 #undef ISDF_SWEEP_CASE
 #undef ISDF_LAUNCH_SWEEP

@@ -125,6 +125,34 @@ def test_shards_sum_to_full(pkg, orc, product_lib):
         assert_close(acc[2], full[2], f"world={world} gradC", tol=1e-12)
 
 
+def test_cost_slots_survive_changing_launch_geometry(pkg, orc, product_lib):
+    """The trajectory cost is collected from per-piece slots that every step must leave empty again: one context,
+    alternating piece counts (incl. > 64 pieces: more than one slot per collecting lane), batches and shards, repeated."""
+    capi, synth = pkg.capi, pkg.synth
+    occ, esdf, res = small_world(pkg)
+    shape = synth.make_shape("RoundedCone", params=(0.8, 0.3, 1.6))
+    cfg = synth.default_config(capi.V3_ESDF_TILE, kernel_size=9, integral_intervs=8, safety_hor=0.5)
+    eng, o = make_pair(pkg, orc, cfg, shape, esdf=esdf, res=res)
+    cases = {n: traj(pkg, occ, res, N=n, seed=40 + n) for n in (3, 70, 9)}
+    want = {n: o.eval(*cases[n])[0] for n in cases}
+    for rep in range(3):
+        for n in (70, 3, 9, 70):
+            T, cm = cases[n]
+            c = eng.eval_single(T, cm)[0]
+            assert abs(c - want[n]) <= REL_TOL * max(abs(want[n]), 1e-9), (rep, n, c, want[n])
+            parts = 0.0
+            for r in range(3):
+                eng.set_shard(r, 3)
+                parts += eng.eval_single(T, cm)[0]
+            eng.set_shard(0, 1)
+            assert abs(parts - c) <= 1e-12 * max(1.0, abs(c)), (rep, n, parts, c)
+        Ts = [cases[9][0]] * 5
+        Cs = [cases[9][1]] * 5
+        cost = np.zeros(5)
+        eng.eval(Ts, Cs, accumulate_into=(cost, [np.zeros(9) for _ in range(5)], [np.zeros(18 * 9) for _ in range(5)]))
+        assert np.all(cost == cost[0]) and abs(cost[0] - want[9]) <= REL_TOL * max(abs(want[9]), 1e-9)
+
+
 def test_edge_cases(pkg, orc, product_lib):
     capi, synth = pkg.capi, pkg.synth
     occ, esdf, res = small_world(pkg)
