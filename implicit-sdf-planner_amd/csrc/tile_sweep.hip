@@ -598,7 +598,10 @@ __global__ __launch_bounds__(64 * SW_SAMPLES, FUSED ? 3 : sweep_waves_per_simd(K
     // ---- (5) results of this wave's sample
     if (have_sample) {
         const long long sl = sidx - s_begin;
-        if (lane < ACC_STRIDE) slot_publish(&P.acc[(size_t)sl * ACC_STRIDE + lane], tot);
+        if (lane < ACC_STRIDE) {
+            if constexpr (FUSED) slot_publish(&P.acc[(size_t)sl * ACC_STRIDE + lane], tot);    // the tail may already be polling
+            else P.acc[(size_t)sl * ACC_STRIDE + lane] = tot;                                  // read by the next launch
+        }
         else if (lane == ACC_STRIDE) P.sample_info[2 * sl] = tot_n;
         else if (lane == ACC_STRIDE + 1) P.sample_info[2 * sl + 1] = tot_n | ((flags & 2) ? (int)0x80000000 : 0);
     }
@@ -659,21 +662,24 @@ template <bool EARLY> __device__ __forceinline__ void tail_piece(const SweepPara
         if (tid < TL_THREADS && j < K1) {
             const long long s = (long long)gp * K1 + j;
             double *const ap = P.acc + (size_t)(s - (long long)P.piece_begin * K1) * ACC_STRIDE;
-            unsigned long long ab[EARLY ? ACC_STRIDE : 1];
-            if (EARLY && P.enable_pos) {
+            double ab[EARLY ? ACC_STRIDE : 1];
+            if (EARLY && P.enable_pos) {           // requested first, so the loads fly under the flatness forward pass
 #pragma unroll
-                for (int q = 0; q < ACC_STRIDE; q++) ab[q] = slot_peek(ap + q);
+                for (int q = 0; q < ACC_STRIDE; q++) ab[q] = ap[q];
             }
-            Basis B;
-            poly_basis(j * step, B);
-            const d3 vel = ct_beta<1>(c, ld, B.b1), acc3 = ct_beta<2>(c, ld, B.b2), jer = ct_beta<3>(c, ld, B.b3), sna = ct_beta<4>(c, ld, B.b4);
+            d3 vel, acc3, jer0;
+            {
+                Basis B;
+                poly_basis(j * step, B);
+                vel = ct_beta<1>(c, ld, B.b1); acc3 = ct_beta<2>(c, ld, B.b2); jer0 = ct_beta<3>(c, ld, B.b3);
+            }
             TL_MARK(0);
             double pena = 0.0;
             d3 gradVel = mk3(0, 0, 0), gradPos = gradVel, gradOmg = gradVel;
             d4 gradQuat; gradQuat.w = gradQuat.x = gradQuat.y = gradQuat.z = 0.0;
             FlatS fs; FlatS2 ft;               // forward intermediates: shared by the penalties and the reverse mode
             flat_core(P.flat, vel, acc3, fs);
-            flat_core2(P.flat, vel, acc3, jer, fs, ft);
+            flat_core2(P.flat, vel, acc3, jer0, fs, ft);
             if (P.enable_dyn) {
                 const d4 quat = flat_quat(fs);
                 const d3 omg = flat_omg(fs, ft);
@@ -699,28 +705,27 @@ template <bool EARLY> __device__ __forceinline__ void tail_piece(const SweepPara
             }
             TL_MARK(1);
             if (P.enable_pos) {
-                // the sums may still be on their way (fused launch: the sweep's workgroups run beside this one): poll what
-                // is missing, then hand the slots back empty
+                // separate launch: the sums are there; fused launch: the sweep's workgroups run beside this one and the sums
+                // may still be on their way - poll the 8 slots (requested together) until all have arrived.  Either way the
+                // slots are handed back empty.
                 double a[ACC_STRIDE];
-                {
+                if constexpr (EARLY) {
+#pragma unroll
+                    for (int q = 0; q < ACC_STRIDE; q++) { a[q] = ab[q]; ap[q] = __longlong_as_double((long long)SLOT_EMPTY); }
+                } else {
                     unsigned long long v[ACC_STRIDE];
                     bool ok = false;
-                    for (int spin = 0; spin < SLOT_SPIN_MAX; spin++) {          // one poll = the 8 slots requested together
+                    for (int spin = 0; spin < SLOT_SPIN_MAX; spin++) {
                         ok = true;
 #pragma unroll
-                        for (int q = 0; q < ACC_STRIDE; q++) {
-                            v[q] = (EARLY && spin == 0) ? ab[EARLY ? q : 0] : slot_peek(ap + q);
-                            ok = ok && v[q] != SLOT_EMPTY;
-                        }
+                        for (int q = 0; q < ACC_STRIDE; q++) { v[q] = slot_peek(ap + q); ok = ok && v[q] != SLOT_EMPTY; }
                         if (ok) break;
                         __builtin_amdgcn_s_sleep(2);
                     }
                     lost = lost || !ok;
 #pragma unroll
-                    for (int q = 0; q < ACC_STRIDE; q++) a[q] = __longlong_as_double((long long)v[q]);
+                    for (int q = 0; q < ACC_STRIDE; q++) { a[q] = __longlong_as_double((long long)v[q]); slot_clear(ap + q); }
                 }
-#pragma unroll
-                for (int q = 0; q < ACC_STRIDE; q++) slot_clear(ap + q);
                 if (a[0] > 0.0) {
                     gradPos.x += P.weight_p * a[1]; gradPos.y += P.weight_p * a[2]; gradPos.z += P.weight_p * a[3];
                     gradQuat.w += P.weight_p * a[4]; gradQuat.x += P.weight_p * a[5];
@@ -735,6 +740,12 @@ template <bool EARLY> __device__ __forceinline__ void tail_piece(const SweepPara
             const double node = (j == 0 || j == P.K) ? 0.5 : 1.0;
             const double alpha = j * integral_frac;
             double *o = s_val[tid];
+            // the basis is formed again here (15 multiplications) instead of living in 60 registers across the passes above
+            double s1 = j * step;
+            asm volatile("" : "+v"(s1));
+            Basis B;
+            poly_basis(s1, B);
+            const d3 jer = ct_beta<3>(c, ld, B.b3), sna = ct_beta<4>(c, ld, B.b4);      // likewise jerk and snap (same bits as above)
             const double gPv[3] = {gP.x, gP.y, gP.z}, gVv[3] = {gV.x, gV.y, gV.z}, gAv[3] = {gA.x, gA.y, gA.z}, gJv[3] = {gJ.x, gJ.y, gJ.z};
             // rows below a basis' derivative order meet its structural zeros: those products are skipped (same bits)
 #pragma unroll
@@ -818,7 +829,8 @@ bool sweep_can_fuse(const SweepParams &P) {
     if (!P.enable_pos || P.shape.kind == ISDF_SHAPE_MESH || P.shape.d.ident == 0) return false;
     const long long n_samples = (long long)(P.piece_end - P.piece_begin) * (P.K + 1);
     if (n_samples <= 0) return false;
-    return (n_samples + SW_SAMPLES - 1) / SW_SAMPLES + (long long)P.n_traj * P.N <= FUSED_MAX_BLOCKS;
+    // tail workgroups of OTHER ranks' pieces only write zeros and leave: they do not count
+    return (n_samples + SW_SAMPLES - 1) / SW_SAMPLES + (long long)(P.piece_end - P.piece_begin) <= FUSED_MAX_BLOCKS && (long long)P.n_traj * P.N <= 8 * FUSED_MAX_BLOCKS;
 }
 
 // fused = true: sweep workgroups + one tail workgroup per piece in ONE launch (the caller then skips launch_tail)

@@ -146,11 +146,13 @@ def test_cost_slots_survive_changing_launch_geometry(pkg, orc, product_lib):
                 parts += eng.eval_single(T, cm)[0]
             eng.set_shard(0, 1)
             assert abs(parts - c) <= 1e-12 * max(1.0, abs(c)), (rep, n, parts, c)
-        Ts = [cases[9][0]] * 5
-        Cs = [cases[9][1]] * 5
-        cost = np.zeros(5)
-        eng.eval(Ts, Cs, accumulate_into=(cost, [np.zeros(9) for _ in range(5)], [np.zeros(18 * 9) for _ in range(5)]))
-        assert np.all(cost == cost[0]) and abs(cost[0] - want[9]) <= REL_TOL * max(abs(want[9]), 1e-9)
+        # 5 trajectories: still one fused launch; 40: sweep and tail as two launches (the slots change hands differently)
+        for nb in (5, 40):
+            Ts = [cases[9][0]] * nb
+            Cs = [cases[9][1]] * nb
+            cost = np.zeros(nb)
+            eng.eval(Ts, Cs, accumulate_into=(cost, [np.zeros(9) for _ in range(nb)], [np.zeros(18 * 9) for _ in range(nb)]))
+            assert np.all(cost == cost[0]) and abs(cost[0] - want[9]) <= REL_TOL * max(abs(want[9]), 1e-9)
 
 
 def test_edge_cases(pkg, orc, product_lib):
