@@ -127,11 +127,18 @@ def main():
                 print(f"[bench] peer-to-peer exchange not used ({xchg.why}); RCCL all_reduce", file=sys.stderr, flush=True)
             xchg = None
 
-    def make_step(use_xchg):
+    def eval_only():
+        eng.eval_device(1, N, d_T.data_ptr(), d_C.data_ptr(), d_out.data_ptr(), 0, stream)
+
+    # Preferred: the exchange INSIDE the step's one launch (isdf_xchg_fuse: the owning workgroups store their rows into the
+    # peers' outputs) - used when it reproduces "step + the group's all-reduce" on every rank.
+    in_kernel = bool(xchg is not None and os.environ.get("ISDF_NO_FUSED_EXCHANGE") != "1" and xchg.try_fused_step(eval_only, d_out))
+
+    def make_step(mode):       # "fused": exchange inside the launch | "xchg": one-shot peer-to-peer kernel | "rccl"
         def step():
-            eng.eval_device(1, N, d_T.data_ptr(), d_C.data_ptr(), d_out.data_ptr(), 0, stream)
-            if world > 1:
-                if use_xchg:
+            eval_only()
+            if world > 1 and mode != "fused":
+                if mode == "xchg":
                     xchg.allreduce(d_out)
                 else:
                     par.allreduce_packed(d_out)
@@ -156,15 +163,26 @@ def main():
         eng.profile_enable(0)
         return t1 - t0, n_l, k_ms
 
-    collective = "none" if world == 1 else ("xgmi peer-to-peer one-shot sum (csrc/xchg.hip), verified against RCCL at start-up" if xchg else "RCCL all_reduce")
-    elapsed, n_launch, kern_ms = timed(make_step(xchg is not None))
-    if xchg is not None:
-        # a bounded wait that timed out anywhere invalidates the run: measure again on RCCL
-        bad = torch.tensor([eng.xchg_status()], dtype=torch.int32, device=dev)
-        dist.all_reduce(bad, op=dist.ReduceOp.MAX)
-        if int(bad.item()) != 0:
-            collective = "RCCL all_reduce (the peer-to-peer exchange timed out and was abandoned)"
-            elapsed, n_launch, kern_ms = timed(make_step(False))
+    def any_rank(flag):
+        t = torch.tensor([int(flag)], dtype=torch.int32, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return int(t.item()) != 0
+
+    mode = "none" if world == 1 else ("fused" if in_kernel else ("xchg" if xchg else "rccl"))
+    names = {"none": "none", "fused": "in-kernel peer-to-peer exchange over xGMI (rows stored into the peers' outputs by the owning workgroups of the fused launch), verified against RCCL at start-up",
+             "xchg": "xgmi peer-to-peer one-shot sum (csrc/xchg.hip), verified against RCCL at start-up", "rccl": "RCCL all_reduce"}
+    elapsed, n_launch, kern_ms = timed(make_step(mode))
+    # a bounded wait that timed out anywhere invalidates the run: measure again one level down
+    if mode == "fused" and any_rank(eng.stats()["overflow"] != 0 or not np.isfinite(float(d_out[0].item()))):
+        eng.xchg_fuse(False)
+        mode = "xchg"
+        elapsed, n_launch, kern_ms = timed(make_step(mode))
+        names["xchg"] += " (the in-kernel exchange timed out and was abandoned)"
+    if mode == "xchg" and any_rank(eng.xchg_status()):
+        mode = "rccl"
+        names["rccl"] = "RCCL all_reduce (the peer-to-peer exchange timed out and was abandoned)"
+        elapsed, n_launch, kern_ms = timed(make_step(mode))
+    collective = names[mode]
     if world > 1:
         tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -291,7 +309,7 @@ def main():
                                    f"@ {res:g} m, kernel_size {args.kernel_size}, box robot (1.6,0.3,0.3) central-diff grad, "
                                    f"cull {'on' if args.cull else 'off'}",
                        "pieces": N, "samples_per_piece": K + 1, "grid": args.grid, "kernel_size": args.kernel_size,
-                       "sharding": "pieces contiguous by rank + all_reduce(sum) of 1+19N doubles" if world > 1 else "none",
+                       "sharding": ("none" if world == 1 else ("pieces contiguous by rank; each piece's 19 rows + cost stored by its owner into every peer's output inside the step's launch" if mode == "fused" else "pieces contiguous by rank + all_reduce(sum) of 1+19N doubles")),
                        "collective": collective},
             "roofline": roofline, "cpu_baseline": cpu,
             "parity_rel_err_vs_oracle": parity, "host_api_ms": None if host_ms is None else round(host_ms, 4),

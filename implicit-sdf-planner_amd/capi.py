@@ -90,7 +90,7 @@ EXPORTED_SYMBOLS = [
     "isdf_lbfgs_params_default", "isdf_lbfgs_minimize", "isdf_optimize_lbfgs", "isdf_optimize_lbfgs_batch",
     "isdf_set_pointcloud", "isdf_generate_esdf", "isdf_get_grid", "isdf_gather_points", "isdf_get_points", "isdf_shape_eval",
     "isdf_frontend_build", "isdf_frontend_get_shape_kernels", "isdf_frontend_get_map_kernel", "isdf_frontend_check", "isdf_frontend_cspace",
-    "isdf_xchg_create", "isdf_xchg_connect", "isdf_xchg_allreduce", "isdf_xchg_status", "isdf_xchg_destroy",
+    "isdf_xchg_create", "isdf_xchg_connect", "isdf_xchg_allreduce", "isdf_xchg_fuse", "isdf_xchg_status", "isdf_xchg_destroy",
 ]
 
 _lib = None
@@ -151,6 +151,7 @@ def load_library(path=None):
     lib.isdf_xchg_create.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_size_t, C.c_void_p]
     lib.isdf_xchg_connect.argtypes = [C.c_void_p, C.c_void_p]
     lib.isdf_xchg_allreduce.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
+    lib.isdf_xchg_fuse.argtypes = [C.c_void_p, C.c_int]
     lib.isdf_xchg_status.argtypes = [C.c_void_p]
     lib.isdf_xchg_destroy.argtypes = [C.c_void_p]
     lib.isdf_frontend_cspace.argtypes = [C.c_void_p, C.c_void_p, dp]

@@ -76,6 +76,11 @@ struct isdf_ctx {
     } fe;
     struct isdf_xchg *xchg = nullptr;           // peer-to-peer exchange of the multi-GPU path (csrc/xchg.hip)
 };
+namespace isdf { struct XFuse; }
+// xchg.hip: fills the in-kernel exchange block of a fused step when isdf_xchg_fuse is on (returns false: not requested;
+// *err != ISDF_OK: requested but impossible for this launch)
+bool isdf_xchg_fill(isdf_ctx *c, isdf::XFuse *xf, size_t pieces, int *err);
+bool isdf_xchg_fuse_on(const isdf_ctx *c);     // isdf_xchg_fuse(ctx, 1) is in force
 void isdf_xchg_release(isdf_ctx *c);          // xchg.hip: closes the peer mappings, frees the mailbox (isdf_destroy)
 void isdf_frontend_release(isdf_ctx *c);      // frontend.hip: frees the tables (isdf_destroy)
 

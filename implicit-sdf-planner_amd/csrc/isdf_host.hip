@@ -398,6 +398,7 @@ static int eval_device_impl(isdf_ctx *c, int n_traj, int N, const double *d_T, c
 
     if (cfg.variant == ISDF_V1_SWEPT) {
         if (n_traj != 1) return fail(c, ISDF_ERR_UNSUPPORTED, "the swept-volume sweep takes one trajectory");
+        if (isdf_xchg_fuse_on(c)) return fail(c, ISDF_ERR_UNSUPPORTED, "the in-kernel exchange belongs to the integral sweep (V2/V3)");
         HIPCHK(c, hipMemsetAsync(d_out, 0, (size_t)n_traj * ostride * sizeof(double), st));
         HIPCHK(c, hipMemsetAsync(c->d_stats, 0, 8 * sizeof(unsigned long long), st));
         if (c->M <= 0) return ISDF_OK;   // no obstacle points: nothing to add
@@ -530,6 +531,13 @@ static int eval_device_impl(isdf_ctx *c, int n_traj, int N, const double *d_T, c
     const bool ev2 = ev && c->prof_secondary;
     // a small step (one trajectory) is ONE launch: the tail's workgroups ride behind the sweep's (tile_sweep.hip, FUSED)
     const bool fused = c->fuse_small && !ev2 && sweep_can_fuse(P);
+    {   // multi-GPU step with the exchange inside that launch (isdf_xchg_fuse): only possible when the step IS one launch
+        int xerr = ISDF_OK;
+        if (isdf_xchg_fill(c, &P.xf, (size_t)total_pieces, &xerr)) {
+            if (xerr != ISDF_OK) return xerr;
+            if (!fused) { P.xf.world = 0; return fail(c, ISDF_ERR_UNSUPPORTED, "in-kernel exchange needs a step that runs as one fused launch"); }
+        }
+    }
     launch_sweep(P, st, ev ? ev->a : nullptr, ev ? ev->b : nullptr, fused);
     if (!fused) launch_tail(P, st, ev2 ? ev->c : nullptr, ev2 ? ev->d : nullptr);
     HIPCHK(c, hipGetLastError());

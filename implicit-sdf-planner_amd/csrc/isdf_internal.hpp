@@ -19,7 +19,19 @@ struct DevGrid {
 constexpr int ACC_STRIDE = 8;       // costp, dL/dpos(3), dL/dquat(4) of one pose, before weight_p
 constexpr int PARTIAL_STRIDE = 20;  // V1: per-point record = 18 gradC entries (d*6 + r), gdT, pena
 
+// In-kernel exchange of a fused multi-GPU step (set up by csrc/xchg.hip, used by tile_sweep.hip's tail): every rank has a
+// BOARD in IPC-mapped uncached memory, [2 step parities][pieces of the launch][XF_ROW] result slots (19 output rows + cost of
+// a piece), all-ones while empty.  The workgroup that owns a piece stores its rows straight into every peer's board; the
+// peer's workgroup for that piece polls them into its own output.  world <= 1: off.
+constexpr int XCHG_MAX_WORLD = 16;
+constexpr int XF_ROW = 20;
+struct XFuse {
+    int world, rank, parity, pad;
+    double *board[XCHG_MAX_WORLD];
+};
+
 struct SweepParams {
+    XFuse xf;
     DevGrid grid;
     DevShape shape;
     FlatP flat;

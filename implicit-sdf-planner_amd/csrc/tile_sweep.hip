@@ -141,6 +141,23 @@ __device__ __forceinline__ unsigned long long slot_peek(const double *slot) {
 __device__ __forceinline__ void slot_clear(double *slot) {
     __hip_atomic_store((unsigned long long *)slot, SLOT_EMPTY, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
+// the same three for slots other GPUs write or read (boards of the in-kernel exchange: IPC-mapped uncached memory)
+constexpr int XF_SPIN_MAX = 1 << 22;                   // peers may start their step later than this rank: ~4 s
+__device__ __forceinline__ void xslot_publish(double *slot, double v) {
+    unsigned long long bits = (unsigned long long)__double_as_longlong(v);
+    if (bits == SLOT_EMPTY) bits = 0x7FF8000000000000ull;
+    __hip_atomic_store((unsigned long long *)slot, bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+__device__ __forceinline__ bool xslot_take(double *slot, double &v) {        // bounded poll, then hands the slot back empty
+    unsigned long long b = __hip_atomic_load((unsigned long long *)slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    for (int spin = 0; b == SLOT_EMPTY && spin < XF_SPIN_MAX; spin++) {
+        __builtin_amdgcn_s_sleep(4);
+        b = __hip_atomic_load((unsigned long long *)slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+    __hip_atomic_store((unsigned long long *)slot, SLOT_EMPTY, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    v = __longlong_as_double((long long)b);
+    return b != SLOT_EMPTY;
+}
 
 struct SweepPose {                 // LDS record of one sample, written by the pose lane
     double pos[3];
@@ -180,7 +197,7 @@ constexpr int sweep_waves_per_simd(int kind, bool ident) {
 
 // IDENT: the shape's body offset is the identity (poly_params all zero - every shipped config): those instantiations drop
 // the offset and the 24 scalar registers it pins, which takes Box to 91 VGPRs and a fifth wave per SIMD.
-template <bool EARLY> __device__ __forceinline__ void tail_piece(const SweepParams &P, const int gp, double (*s_val)[PARTIAL_STRIDE + 1]);
+template <bool EARLY, bool XF> __device__ __forceinline__ void tail_piece(const SweepParams &P, const int t, double (*s_val)[PARTIAL_STRIDE + 1]);
 
 // FUSED: the launch carries, after its P.n_sweep_blocks sweep workgroups, one workgroup per piece that runs the tail
 // (tail_piece) - dispatched last, it does the collision-independent part of its samples while the sweep works and picks the
@@ -191,7 +208,11 @@ __global__ __launch_bounds__(64 * SW_SAMPLES, FUSED ? 3 : sweep_waves_per_simd(K
     const int n_blocks = FUSED ? P.n_sweep_blocks : (int)gridDim.x;       // sweep workgroups of this launch
     if constexpr (FUSED) {
         __shared__ double s_tail[TL_THREADS][PARTIAL_STRIDE + 1];
-        if ((int)blockIdx.x >= n_blocks) { tail_piece<false>(P, (int)blockIdx.x - n_blocks, s_tail); return; }
+        if ((int)blockIdx.x >= n_blocks) {
+            if (P.xf.world > 1) tail_piece<false, true>(P, (int)blockIdx.x - n_blocks, s_tail);      // multi-GPU step: exchange inside
+            else tail_piece<false, false>(P, (int)blockIdx.x - n_blocks, s_tail);
+            return;
+        }
     }
     __shared__ SweepPose s_pose[SW_SAMPLES];
     __shared__ unsigned s_list[SW_SAMPLES][SW_LIST_CAP];          // ring of compacted voxels awaiting the fp32 test
@@ -631,29 +652,46 @@ __global__ __launch_bounds__(256) void stats_kernel(const SweepParams P) {
 // ---------------------------------------------------------------------------------------------------------------
 // tail: workgroup per piece, thread per sample (tail_kernel, or the trailing workgroups of a fused sweep launch)
 // ---------------------------------------------------------------------------------------------------------------
-// EARLY: the collision sums are already there (separate launch after the sweep): request them before the forward pass
-template <bool EARLY> __device__ __forceinline__ void tail_piece(const SweepParams &P, const int gp, double (*s_val)[PARTIAL_STRIDE + 1]) {
+// EARLY: the collision sums are already there (separate launch after the sweep): request them before the forward pass.
+// XF: multi-GPU step with the exchange inside the launch (XFuse): tail workgroup t takes this rank's pieces first (they have
+// work to overlap with the sweep), then the other ranks' pieces, whose rows it fetches from this rank's board.
+template <bool EARLY, bool XF> __device__ __forceinline__ void tail_piece(const SweepParams &P, const int t, double (*s_val)[PARTIAL_STRIDE + 1]) {
     const int K1 = P.K + 1;
     const int tid = threadIdx.x;                     // threads >= TL_THREADS (fused launch: 256 per workgroup) only keep the barriers
-    const int b = gp / P.N, i = gp - b * P.N;        // gp = global piece index (trajectory-major)
+    const int n_own = P.piece_end - P.piece_begin, n_all = P.n_traj * P.N;
+    int gp = t;                                      // global piece index (trajectory-major)
+    if constexpr (XF) gp = t < n_own ? P.piece_begin + t : (t - n_own < P.piece_begin ? t - n_own : t);
+    const int b = gp / P.N, i = gp - b * P.N;
     const size_t ostride = (size_t)1 + 19 * (size_t)P.N;
     const int p0 = max(P.piece_begin, b * P.N) - b * P.N, p1 = min(P.piece_end, (b + 1) * P.N) - b * P.N;   // this rank's pieces of trajectory b
-    if (i < p0 || i >= p1) {
-        // a piece of another rank: its entries are zero here, so that the ranks' outputs sum to the full result
-        double *o = P.out + (size_t)b * ostride;
+    double *const o = P.out + (size_t)b * ostride;
+    double *const my_board = XF ? P.xf.board[P.xf.rank] + (size_t)P.xf.parity * n_all * XF_ROW : nullptr;
+    bool lost = false;     // a result slot that never arrived
+    const bool mine = i >= p0 && i < p1;
+    unsigned long long *const dbg = (P.dbg && mine) ? P.dbg + (size_t)(P.piece_end - P.piece_begin) * K1 * 8 + (size_t)(gp - P.piece_begin) * 4 : nullptr;
+    if (!mine) {
         const int q = tid;
-        if (q == 18) o[1 + i] = 0.0;
-        else if (q < 18) { const int d = q / 6, r = q - 6 * d; o[1 + P.N + (size_t)d * 6 * P.N + 6 * i + r] = 0.0; }
-        else if (q == 19 && p1 <= p0 && i == 0) o[0] = 0.0;    // no piece of this trajectory is ours
-        return;
-    }
+        if constexpr (XF) {
+            // a piece of another rank: its owner stores the 19 rows into this rank's board (the cost slot is the collector's)
+            if (q < 19) {
+                double v;
+                lost = !xslot_take(my_board + (size_t)gp * XF_ROW + q, v);
+                if (q == 18) o[1 + i] = v;
+                else { const int d = q / 6, r = q - 6 * d; o[1 + P.N + (size_t)d * 6 * P.N + 6 * i + r] = v; }
+            }
+        } else {
+            // a piece of another rank: its entries are zero here, so that the ranks' outputs sum to the full result
+            if (q == 18) o[1 + i] = 0.0;
+            else if (q < 18) { const int d = q / 6, r = q - 6 * d; o[1 + P.N + (size_t)d * 6 * P.N + 6 * i + r] = 0.0; }
+            else if (q == 19 && p1 <= p0 && i == 0) o[0] = 0.0;    // no piece of this trajectory is ours
+            return;
+        }
+    } else {
     const double *c = P.coeffs + (size_t)b * 18 * P.N + 6 * i;
     const int ld = 6 * P.N;
     const double integral_frac = P.inv_K;
     const double step = P.T[(size_t)b * P.N + i] * integral_frac;
     double colsum = 0.0;   // threads 0..19: running sum of their output column, samples in ascending order
-    bool lost = false;     // a result slot that never arrived
-    unsigned long long *const dbg = P.dbg ? P.dbg + (size_t)(P.piece_end - P.piece_begin) * K1 * 8 + (size_t)(gp - P.piece_begin) * 4 : nullptr;
     unsigned long long tl_c0 = 0, tl_marks = 0;
     if (dbg && tid == 0) { dbg[0] = wall_clock64(); tl_c0 = clock64(); }
 #define TL_MARK(k) do { if (dbg && tid == 0) tl_marks |= (((clock64() - tl_c0) >> 4) & 0xFFFFull) << (16 * (k)); } while (0)
@@ -767,7 +805,7 @@ template <bool EARLY> __device__ __forceinline__ void tail_piece(const SweepPara
             const int n = min(TL_THREADS, K1 - j0);
             const int col = tid % PARTIAL_STRIDE, grp = tid / PARTIAL_STRIDE;
             double part = 0.0;
-            if (grp < TL_GROUPS) for (int t = grp; t < n; t += TL_GROUPS) part += s_val[t][col];
+            if (grp < TL_GROUPS) for (int row = grp; row < n; row += TL_GROUPS) part += s_val[row][col];
             __syncthreads();                                   // every row has been read: rows 0..TL_GROUPS-1 are reused
             if (grp < TL_GROUPS) s_val[grp][col] = part;
             __syncthreads();
@@ -780,35 +818,61 @@ template <bool EARLY> __device__ __forceinline__ void tail_piece(const SweepPara
     }
     if (dbg && tid == 0) { dbg[2] = tl_marks; dbg[3] = (clock64() - tl_c0) >> 4; }
 #undef TL_MARK
-    if (lost && P.stats) atomicMax(&P.stats[4], 1ull);
-    double *o = P.out + (size_t)b * ostride;
     if (tid < PARTIAL_STRIDE) {
         const int q = tid;
-        if (q == 18) o[1 + i] = colsum;
-        else if (q < 18) {
-            const int d = q / 6, r = q - 6 * d;
-            o[1 + P.N + (size_t)d * 6 * P.N + 6 * i + r] = colsum;
+        if (q < 19) {
+            if (q == 18) o[1 + i] = colsum;
+            else { const int d = q / 6, r = q - 6 * d; o[1 + P.N + (size_t)d * 6 * P.N + 6 * i + r] = colsum; }
+            if constexpr (XF) {               // the same row into every peer's board
+                for (int r = 0; r < P.xf.world; r++)
+                    if (r != P.xf.rank) xslot_publish(P.xf.board[r] + ((size_t)P.xf.parity * n_all + gp) * XF_ROW + q, colsum);
+            }
         } else {
             // Trajectory cost = fixed-order sum of the piece costs: each workgroup publishes its piece's cost in the piece's slot
-            slot_publish(&P.piece_cost[gp], colsum);
+            // (multi-GPU step: in the piece's cost slot of EVERY rank's board, this rank's included)
+            if constexpr (XF) {
+                for (int r = 0; r < P.xf.world; r++) xslot_publish(P.xf.board[r] + ((size_t)P.xf.parity * n_all + gp) * XF_ROW + 19, colsum);
+            } else slot_publish(&P.piece_cost[gp], colsum);
         }
     }
-    // The workgroup of the trajectory's LAST piece collects them: workgroups are dispatched in index order, so every one it
-    // waits for is already resident or finished.  One lane per piece polls its slot, takes the value and empties the slot
-    // for the next step; the poll is bounded (NaN cost + the overflow flag instead of a hung stream).
-    if (i == p1 - 1 && tid < 64) {
+    }   // mine
+    if (lost && P.stats) atomicMax(&P.stats[4], 1ull);
+    // One workgroup per trajectory collects the piece costs: the one dispatched LAST among the trajectory's (workgroups are
+    // dispatched in index order, so every one it waits for is already resident or finished - here: the last piece of this
+    // rank's range; multi-GPU step: the highest t, and the costs of all N pieces come from this rank's board, where their
+    // owners put them).  One lane per piece polls its slot, takes the value and empties the slot for the next step; the poll
+    // is bounded (NaN cost + the overflow flag instead of a hung stream).
+    bool collector;
+    int k0, k1;
+    if constexpr (XF) {
+        const int first = b * P.N, last = first + P.N - 1;
+        const int t_last = (last >= P.piece_begin && last < P.piece_end) ? last - P.piece_begin : (last < P.piece_begin ? last + n_own : last);
+        const int below = P.piece_begin - 1;                                   // highest piece before this rank's range
+        const int t_below = (below >= first && below <= last) ? below + n_own : -1;
+        collector = t == max(t_last, t_below);
+        k0 = 0; k1 = P.N;
+    } else {
+        collector = i == p1 - 1;
+        k0 = p0; k1 = p1;
+    }
+    if (collector && tid < 64) {
         double sum = 0.0;
         bool gone = false;
-        for (int k = p0 + tid; k < p1; k += 64) {
-            double *slot = &P.piece_cost[(size_t)b * P.N + k];
-            unsigned long long v = slot_peek(slot);
-            for (int spin = 0; v == SLOT_EMPTY && spin < SLOT_SPIN_MAX; spin++) {
-                __builtin_amdgcn_s_sleep(1);
-                v = slot_peek(slot);
+        for (int k = k0 + tid; k < k1; k += 64) {
+            double v;
+            if constexpr (XF) gone = !xslot_take(my_board + ((size_t)b * P.N + k) * XF_ROW + 19, v) || gone;
+            else {
+                double *slot = &P.piece_cost[(size_t)b * P.N + k];
+                unsigned long long bits = slot_peek(slot);
+                for (int spin = 0; bits == SLOT_EMPTY && spin < SLOT_SPIN_MAX; spin++) {
+                    __builtin_amdgcn_s_sleep(1);
+                    bits = slot_peek(slot);
+                }
+                gone = gone || bits == SLOT_EMPTY;
+                slot_clear(slot);
+                v = __longlong_as_double((long long)bits);
             }
-            gone = gone || v == SLOT_EMPTY;
-            slot_clear(slot);
-            sum += __longlong_as_double((long long)v);
+            sum += v;
         }
         sum = wave_sum(sum);
         if (__ballot(gone) != 0ull) { sum = __longlong_as_double(0x7FF8000000000000ll); if (tid == 0 && P.stats) atomicMax(&P.stats[4], 1ull); }
@@ -819,7 +883,7 @@ template <bool EARLY> __device__ __forceinline__ void tail_piece(const SweepPara
 
 __global__ __launch_bounds__(TL_THREADS) void tail_kernel(const SweepParams P) {
     __shared__ double s_val[TL_THREADS][PARTIAL_STRIDE + 1];   // +1: column reads by 20 threads hit distinct banks
-    tail_piece<true>(P, (int)blockIdx.x, s_val);               // one workgroup per piece of the launch
+    tail_piece<true, false>(P, (int)blockIdx.x, s_val);        // one workgroup per piece of the launch
 }
 
 // Workgroups a fused launch may have: all of them resident at once, 3 per CU (the fused kernels' register budget)

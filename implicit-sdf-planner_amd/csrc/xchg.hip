@@ -7,13 +7,13 @@
 // finishing exchange k needs every peer's flag k).  Every wait is bounded: on a time-out the status word is set and the
 // caller falls back to RCCL (implicit-sdf-planner_amd/parallel.py checks the path against RCCL before using it).
 #include "isdf_ctx.hpp"
+#include "isdf_internal.hpp"
 #include <hip/hip_runtime.h>
 #include <algorithm>
 #include <cstring>
 
 namespace isdf {
 
-constexpr int XCHG_MAX_WORLD = 16;
 constexpr long long XCHG_SPIN_LIMIT = 1ll << 22;       // x ~64 ns sleep + one flag load: ~0.5 s
 
 struct XchgParams {
@@ -87,8 +87,11 @@ using namespace isdf;
 struct isdf_xchg {
     int rank = 0, world = 1;
     size_t slot_doubles = 0;
-    void *own = nullptr;                        // this rank's mailbox (uncached device memory): data, then flags
+    void *own = nullptr;                        // this rank's mailbox (uncached device memory): data, flags, then the board
     size_t own_bytes = 0, flags_offset = 0;
+    size_t board_offset = 0, board_doubles = 0; // board of the in-kernel exchange (isdf_internal.hpp XFuse): 2 parities
+    bool fuse_on = false;
+    unsigned long long fuse_seq = 0;
     void *peer_base[XCHG_MAX_WORLD] = {nullptr};
     bool opened[XCHG_MAX_WORLD] = {false};
     unsigned *d_status = nullptr;               // [status word | pad | 64-bit push counter]
@@ -120,10 +123,14 @@ extern "C" int isdf_xchg_create(isdf_ctx *c, int rank, int world, size_t max_dou
     x->slot_doubles = (max_doubles + 63) / 64 * 64;
     const size_t data_bytes = (size_t)2 * world * x->slot_doubles * sizeof(double);
     x->flags_offset = (data_bytes + 255) / 256 * 256;
-    x->own_bytes = x->flags_offset + (size_t)2 * world * sizeof(unsigned long long);
+    // board: XF_ROW slots per piece and parity; a packed vector of max_doubles holds at most max_doubles / 19 pieces
+    x->board_offset = (x->flags_offset + (size_t)2 * world * sizeof(unsigned long long) + 255) / 256 * 256;
+    x->board_doubles = (size_t)2 * XF_ROW * (max_doubles / 19 + 1);
+    x->own_bytes = x->board_offset + x->board_doubles * sizeof(double);
     // uncached (fine-grained) device memory: peers' stores over xGMI become visible to this device's loads without cache games
     if (hipExtMallocWithFlags(&x->own, x->own_bytes, hipDeviceMallocUncached) != hipSuccess) { xchg_free(c); return isdf_fail(c, ISDF_ERR_HIP, "uncached mailbox allocation failed"); }
     HIPCHK(c, hipMemset(x->own, 0, x->own_bytes));
+    HIPCHK(c, hipMemset((char *)x->own + x->board_offset, 0xFF, x->board_doubles * sizeof(double)));    // every slot empty
     HIPCHK(c, hipMalloc(&x->d_status, 16));
     HIPCHK(c, hipMemset(x->d_status, 0, 16));
     HIPCHK(c, hipDeviceSynchronize());
@@ -168,6 +175,32 @@ extern "C" int isdf_xchg_allreduce(isdf_ctx *c, double *d_buf, size_t count, voi
     hipLaunchKernelGGL(xchg_allreduce_kernel, dim3(blocks), dim3(1024), 0, (hipStream_t)stream, X, d_buf, count);
     HIPCHK(c, hipGetLastError());
     return ISDF_OK;
+}
+
+// In-kernel exchange of fused steps (tile_sweep.hip, XFuse): on = 1 makes every following isdf_eval_device a COMPLETE
+// multi-GPU step - its output is the full result on every rank, no isdf_xchg_allreduce afterwards.  All ranks must switch
+// together and evaluate in lock-step (same launches in the same order).
+extern "C" int isdf_xchg_fuse(isdf_ctx *c, int on) {
+    if (!c) return ISDF_ERR_INVALID_ARG;
+    isdf_xchg *x = c->xchg;
+    if (!x || !x->connected) return isdf_fail(c, ISDF_ERR_STATE, "exchange not connected");
+    if (on && (x->rank != c->rank || x->world != c->world)) return isdf_fail(c, ISDF_ERR_STATE, "isdf_set_shard and the exchange disagree on rank / world");
+    x->fuse_on = on != 0;
+    return ISDF_OK;
+}
+
+bool isdf_xchg_fuse_on(const isdf_ctx *c) { return c->xchg && c->xchg->fuse_on; }
+
+bool isdf_xchg_fill(isdf_ctx *c, isdf::XFuse *xf, size_t pieces, int *err) {
+    *err = ISDF_OK;
+    xf->world = 0;
+    isdf_xchg *x = c->xchg;
+    if (!x || !x->fuse_on) return false;
+    if (!x->connected || x->rank != c->rank || x->world != c->world) { *err = isdf_fail(c, ISDF_ERR_STATE, "in-kernel exchange: shard and exchange disagree"); return true; }
+    if ((size_t)2 * XF_ROW * pieces > x->board_doubles) { *err = isdf_fail(c, ISDF_ERR_INVALID_ARG, "in-kernel exchange: more pieces than the exchange was created for"); return true; }
+    xf->world = x->world; xf->rank = x->rank; xf->parity = (int)(++x->fuse_seq & 1ull); xf->pad = 0;
+    for (int r = 0; r < x->world; r++) xf->board[r] = (double *)((char *)x->peer_base[r] + x->board_offset);
+    return true;
 }
 
 extern "C" int isdf_xchg_status(isdf_ctx *c) {

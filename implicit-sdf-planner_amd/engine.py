@@ -211,6 +211,10 @@ class Engine:
     def xchg_allreduce(self, d_ptr, count, stream=0):
         self._check(self.lib.isdf_xchg_allreduce(self.h, C.c_void_p(d_ptr), int(count), C.c_void_p(stream)))
 
+    def xchg_fuse(self, on):
+        """on: every following eval_device is a complete multi-GPU step (exchange inside the fused launch)."""
+        self._check(self.lib.isdf_xchg_fuse(self.h, 1 if on else 0))
+
     def xchg_status(self):
         return int(self.lib.isdf_xchg_status(self.h))
 

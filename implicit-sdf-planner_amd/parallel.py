@@ -106,6 +106,39 @@ class XgmiExchange:
         dist.all_reduce(t, op=dist.ReduceOp.MIN)
         return int(t.item()) == 1
 
+    def try_fused_step(self, step, out):
+        """Switch the engine to the exchange INSIDE the step (isdf_xchg_fuse) if that reproduces the ordinary path.
+        step(): the caller's eval_device launch into the device tensor `out` (this rank's shard set with set_shard).
+        Reference: the same launch with the exchange off, summed by the group's all-reduce.  Three fused steps (both board
+        parities) must match it on every rank; otherwise the engine is left as it was.  Never raises."""
+        import torch
+        import torch.distributed as dist
+        if not self.ok:
+            return False
+        eng = self.engine
+        good = 1
+        try:
+            step(); torch.cuda.synchronize()
+            ref = out.to(self._pd).clone(); dist.all_reduce(ref); ref = ref.to(out.device)
+            scale = float(ref.abs().max().item()) + 1e-300
+            eng.xchg_fuse(True)
+            for _ in range(3):
+                out.zero_(); step(); torch.cuda.synchronize()
+                if not bool(((out - ref).abs().max() <= 1e-12 * scale).item()) or eng.stats()["overflow"] != 0:
+                    good = 0
+                    break
+        except Exception:                 # noqa: BLE001 - e.g. ISDF_ERR_UNSUPPORTED: the step is not one fused launch
+            good = 0
+        fused = self._agree(good, self._pd)
+        if not fused:
+            try:
+                eng.xchg_fuse(False)
+                dist.barrier()
+                step(); torch.cuda.synchronize()      # drain: every rank back on the ordinary path
+            except Exception:             # noqa: BLE001
+                pass
+        return fused
+
     def allreduce(self, tensor):
         """In-place sum over the ranks, asynchronous on torch's current stream."""
         import torch

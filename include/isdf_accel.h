@@ -237,6 +237,16 @@ int isdf_cost_function_finish(isdf_ctx *ctx, double *g, double *cost_out, void *
 int isdf_cost_parts(const isdf_ctx *ctx, double parts[4]);
 
 /* ---- multi-GPU exchange over xGMI peer stores (one node) -------------------------------------------------------- */
+/* The exchange INSIDE the step (csrc/tile_sweep.hip, fused launch): on = 1 makes every following isdf_eval_device a complete
+ * multi-GPU step - the workgroup that owns a piece stores its 19 output rows and its cost straight into every peer's board
+ * (IPC-mapped, uncached), the peers' workgroups for that piece poll them into their own output, so on return every rank's
+ * output holds the FULL [cost | gradT | gradC] (bitwise identical on all ranks) and no isdf_xchg_allreduce / ncclAllReduce
+ * follows.  Requires isdf_set_shard(rank, world) equal to the exchange's, all ranks switching together and evaluating in
+ * lock-step, and a step that runs as one fused launch (analytic shape with identity body offset, one trajectory or a small
+ * batch); otherwise isdf_eval_device returns ISDF_ERR_UNSUPPORTED and the caller uses isdf_xchg_allreduce.  Waits are
+ * bounded (~4 s): a missing peer sets the overflow flag and a NaN cost instead of hanging the stream.
+ * Replaces: the reference has no multi-GPU path; SURVEY 8(e) "prefer one-shot P2P reduce over xGMI". */
+int isdf_xchg_fuse(isdf_ctx *ctx, int on);
 /* The sum of the ranks' packed vectors is the ONE exchange step of the sharded path.  Any all-reduce works (RCCL through
  * torch.distributed: INTEGRATION.md); for vectors this small (6-50 KB) its latency rivals the whole optimizer step, so the
  * library also provides a one-shot peer-to-peer form: every rank stores its vector into a mailbox slot on every peer

@@ -64,6 +64,26 @@ part = out.cpu().clone(); dist.all_reduce(part)
 x2.allreduce(out); torch.cuda.synchronize()
 assert torch.allclose(out.cpu(), part, rtol=1e-13, atol=1e-13 * float(part.abs().max()))
 assert float(part[0]) > 0
+# the exchange INSIDE the step (isdf_xchg_fuse): every rank's launch returns the full result, bitwise the same on all ranks
+def _step():
+    e2.eval_device(1, 6, d_T.data_ptr(), d_C.data_ptr(), out.data_ptr(), 0, st)
+assert x2.try_fused_step(_step, out), "in-kernel exchange did not reproduce step + all-reduce"
+for it in range(40):
+    out.zero_(); _step()
+    if it % 5 == rank % 5:
+        torch.cuda.synchronize()               # perturb the ranks' relative timing
+    if it % 8 == 0:
+        got = out.cpu()
+        assert torch.allclose(got, part, rtol=1e-12, atol=1e-12 * float(part.abs().max())), (rank, it, float((got - part).abs().max()))
+        allv = [torch.zeros_like(got) for _ in range(world)]
+        dist.all_gather(allv, got)
+        assert all(torch.equal(allv[0], a) for a in allv), (rank, it)
+torch.cuda.synchronize()
+assert e2.stats()["overflow"] == 0
+e2.xchg_fuse(False)
+out.zero_(); _step(); torch.cuda.synchronize()     # back on the ordinary path: this rank's partial sums again
+p2 = out.cpu().clone(); dist.all_reduce(p2)
+assert torch.allclose(p2, part, rtol=1e-13, atol=1e-13 * float(part.abs().max()))
 dist.barrier()
 if rank == 0:
     print("XCHG WORKERS OK", flush=True)
