@@ -43,30 +43,33 @@ __global__ __launch_bounds__(1024) void xchg_allreduce_kernel(XchgParams X, doub
         }
         __syncthreads();
     }
-    // ---- wait: every peer's flag in MY mailbox (bounded)
+    // ---- wait (bounded): lane r of the first wavefront polls peer r's flag in MY mailbox, lane `world` this rank's own push
+    // counter (the sum below overwrites buf: every push of THIS rank, possibly by another block, must have read it first) -
+    // all at once, one round trip instead of one per peer
     __shared__ int s_ok;
-    if (threadIdx.x == 0) {
-        int ok = 1;
-        const unsigned long long *mine = X.peer_flags[X.rank] + (size_t)par * X.world;
-        for (int r = 0; r < X.world && ok; r++) {
-            if (r == X.rank) continue;
+    if (threadIdx.x < 64) {
+        const int lane = threadIdx.x;
+        bool ok = true;
+        if (lane < X.world && lane != X.rank) {
+            const unsigned long long *mine = X.peer_flags[X.rank] + (size_t)par * X.world;
             long long spins = 0;
-            while (__hip_atomic_load(mine + r, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) != X.seq) {
+            while (__hip_atomic_load(mine + lane, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) != X.seq) {
                 __builtin_amdgcn_s_sleep(1);
-                if (++spins > XCHG_SPIN_LIMIT) { ok = 0; break; }
+                if (++spins > XCHG_SPIN_LIMIT) { ok = false; break; }
             }
-        }
-        // the sum below overwrites buf: every push of THIS rank (possibly by another block) must have read it first
-        {
+        } else if (lane == X.world) {
             const unsigned long long want = X.seq * (unsigned long long)(X.world - 1);
             long long spins = 0;
-            while (ok && __hip_atomic_load(X.pushes, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < want) {
+            while (__hip_atomic_load(X.pushes, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < want) {
                 __builtin_amdgcn_s_sleep(1);
-                if (++spins > XCHG_SPIN_LIMIT) ok = 0;
+                if (++spins > XCHG_SPIN_LIMIT) { ok = false; break; }
             }
         }
-        if (!ok) atomicExch(X.status, 1u);
-        s_ok = ok;
+        const bool all_ok = __ballot(!ok) == 0ull;
+        if (lane == 0) {
+            if (!all_ok) atomicExch(X.status, 1u);
+            s_ok = all_ok ? 1 : 0;
+        }
     }
     __syncthreads();
     if (!s_ok) return;

@@ -84,6 +84,22 @@ e2.xchg_fuse(False)
 out.zero_(); _step(); torch.cuda.synchronize()     # back on the ordinary path: this rank's partial sums again
 p2 = out.cpu().clone(); dist.all_reduce(p2)
 assert torch.allclose(p2, part, rtol=1e-13, atol=1e-13 * float(part.abs().max()))
+# a batch of 3 trajectories (shard boundaries fall inside trajectories: the cost collector of each trajectory changes place)
+x3 = par.XgmiExchange(e2, 3 * e2.out_stride(6), dev)
+assert x3.ok, x3.why
+d_T3 = d_T.repeat(3); d_C3 = d_C.repeat(3)
+out3 = torch.zeros(3 * e2.out_stride(6), dtype=torch.float64, device=dev)
+def _step3():
+    e2.eval_device(3, 6, d_T3.data_ptr(), d_C3.data_ptr(), out3.data_ptr(), 0, st)
+assert x3.try_fused_step(_step3, out3), "in-kernel exchange (batch) did not reproduce step + all-reduce"
+for it in range(6):
+    out3.zero_(); _step3()
+torch.cuda.synchronize()
+got3 = out3.cpu().reshape(3, -1)
+for b in range(3):
+    assert torch.allclose(got3[b], part, rtol=1e-12, atol=1e-12 * float(part.abs().max())), (rank, b, float((got3[b] - part).abs().max()))
+assert e2.stats()["overflow"] == 0
+e2.xchg_fuse(False)
 dist.barrier()
 if rank == 0:
     print("XCHG WORKERS OK", flush=True)
