@@ -1,6 +1,8 @@
 """Multi-GPU plumbing of the hot path: one process per GPU, constraint points sharded across ranks
 with no data-path collective, then ONE sum of the packed [cost | gradT(N) | gradC(6N x 3)] vector per optimizer step: RCCL's all-reduce (gloo
-in the CPU tests) or, between the GPUs of one node, the library's one-shot peer-to-peer exchange over xGMI (XgmiExchange).  torch.distributed is plumbing only."""
+in the CPU tests) or, between the GPUs of one node, the library's one-shot peer-to-peer exchange over xGMI (XgmiExchange) -
+as a kernel after the step, or INSIDE the step's fused launch (XgmiExchange.try_fused_step / isdf_xchg_fuse), in which case no
+collective call follows at all.  torch.distributed is plumbing only."""
 import os
 
 
@@ -45,6 +47,7 @@ class XgmiExchange:
         import torch
         import torch.distributed as dist
         self.ok = False
+        self.fused = False             # True after try_fused_step: every eval_device already returns the full sums
         self.engine = engine
         self.why = ""
         try:
@@ -130,6 +133,7 @@ class XgmiExchange:
         except Exception:                 # noqa: BLE001 - e.g. ISDF_ERR_UNSUPPORTED: the step is not one fused launch
             good = 0
         fused = self._agree(good, self._pd)
+        self.fused = fused
         if not fused:
             try:
                 eng.xchg_fuse(False)
@@ -166,7 +170,9 @@ def cost_function_allreduced(engine, x, exchange=None):
     stream = torch.cuda.current_stream().cuda_stream
     ptr, count = engine.cost_function_launch(x, stream)
     part = torch.as_tensor(_DeviceDoubles(ptr, count), device=torch.device("cuda", torch.cuda.current_device()))
-    if exchange is not None and exchange.ok:
+    if exchange is not None and exchange.ok and getattr(exchange, "fused", False):
+        pass                              # the exchange happened inside the sweep's launch (try_fused_step): already the full sums
+    elif exchange is not None and exchange.ok:
         exchange.allreduce(part)          # one-shot peer-to-peer sum over xGMI (XgmiExchange)
     else:
         allreduce_packed(part)
