@@ -152,16 +152,22 @@ def main():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
+        # ... and one pair of HIP events around the whole timed region on the launch stream (torch's current stream IS the
+        # stream handed to isdf_eval_device): steps are serialised on it, so region / steps bounds the kernel's duration from
+        # above without touching any dispatch
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         t0 = time.perf_counter()
+        e0.record()
         for _ in range(args.steps):
             step()
+        e1.record()
         torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
         t1 = time.perf_counter()
         n_l, k_ms = eng.profile_read()
         eng.profile_enable(0)
-        return t1 - t0, n_l, k_ms
+        return t1 - t0, n_l, (k_ms, e0.elapsed_time(e1) / args.steps)
 
     def any_rank(flag):
         t = torch.tensor([int(flag)], dtype=torch.int32, device=dev)
@@ -197,6 +203,13 @@ def main():
     # roofline of the dominant kernel (sweep_kernel): algorithmic bytes of the samples THIS rank's launch processed
     B = algorithmic_bytes_per_eval(args.kernel_size)
     evals_this_rank = (N // world) * (K + 1)
+    # duration of the dominant kernel: two live measurements, both upper bounds - (a) start/stop events attached to the
+    # dispatch itself on every 8th step (an instrumented dispatch runs 1-3 us longer than a plain one: its mean exceeds even
+    # the step period when the step is a single launch), (b) the region events / steps (kernel + inter-launch gap; exact up
+    # to that gap when the step is ONE launch, i.e. the fused step).  The smaller of the two is used; rocprofv3's average of
+    # the same command is committed under profiles/.
+    kern_ms_dispatch, kern_ms_region = kern_ms
+    kern_ms = min(kern_ms_dispatch, kern_ms_region) if kern_ms_dispatch > 0 else kern_ms_region
     achieved = (evals_this_rank * B) / (kern_ms * 1e-3) / 1e9 if kern_ms > 0 else 0.0
     # measured HBM traffic of the same kernel (bytes per launch): from the committed rocprofv3 PMC passes of this very
     # command (profiles/hbm_traffic.json, written by tools/pmc_traffic.py; FETCH_SIZE x2 gfx950 correction + WRITE_SIZE)
@@ -218,6 +231,7 @@ def main():
     roofline = {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                 "kernel": "sweep_kernel", "kernel_ms": round(kern_ms, 5), "launches": n_launch,
+                "kernel_ms_dispatch_events": round(kern_ms_dispatch, 5), "kernel_ms_region_events": round(kern_ms_region, 5),
                 "algorithmic_bytes_per_eval": B, "algorithmic_bytes_per_launch": evals_this_rank * B,
                 "compulsory_bytes_per_launch": compulsory,
                 # secondary figure of SURVEY 8(d): robot-SDF evaluations per second inside the tiles (every pair costs one
