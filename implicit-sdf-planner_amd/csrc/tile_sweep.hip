@@ -142,7 +142,7 @@ __device__ __forceinline__ void slot_clear(double *slot) {
     __hip_atomic_store((unsigned long long *)slot, SLOT_EMPTY, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 // the same three for slots other GPUs write or read (boards of the in-kernel exchange: IPC-mapped uncached memory)
-constexpr int XF_SPIN_MAX = 1 << 22;                   // peers may start their step later than this rank: ~4 s
+constexpr int XF_SPIN_MAX = 1 << 21;                   // peers may start their step later than this rank: about one second of polling
 __device__ __forceinline__ void xslot_publish(double *slot, double v) {
     unsigned long long bits = (unsigned long long)__double_as_longlong(v);
     if (bits == SLOT_EMPTY) bits = 0x7FF8000000000000ull;

@@ -244,7 +244,7 @@ int isdf_cost_parts(const isdf_ctx *ctx, double parts[4]);
  * follows.  Requires isdf_set_shard(rank, world) equal to the exchange's, all ranks switching together and evaluating in
  * lock-step, and a step that runs as one fused launch (analytic shape with identity body offset, one trajectory or a small
  * batch); otherwise isdf_eval_device returns ISDF_ERR_UNSUPPORTED and the caller uses isdf_xchg_allreduce.  Waits are
- * bounded (~4 s): a missing peer sets the overflow flag and a NaN cost instead of hanging the stream.
+ * bounded (about one second): a missing peer sets the overflow flag and a NaN cost instead of hanging the stream.
  * Replaces: the reference has no multi-GPU path; SURVEY 8(e) "prefer one-shot P2P reduce over xGMI". */
 int isdf_xchg_fuse(isdf_ctx *ctx, int on);
 /* The sum of the ranks' packed vectors is the ONE exchange step of the sharded path.  Any all-reduce works (RCCL through

@@ -101,6 +101,20 @@ for b in range(3):
 assert e2.stats()["overflow"] == 0
 e2.xchg_fuse(False)
 dist.barrier()
+# a peer that never shows up must not hang the stream: rank 0 runs one fused step ALONE - its polls run into their bound,
+# the step ends with the overflow flag and a NaN cost (last check: the boards are out of step afterwards)
+x4 = par.XgmiExchange(e2, e2.out_stride(6), dev)
+assert x4.ok, x4.why
+assert x4.try_fused_step(_step, out)
+dist.barrier()
+if rank == 0:
+    import time
+    t0 = time.perf_counter()
+    out.zero_(); _step(); torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    assert e2.stats()["overflow"] != 0 and not np.isfinite(float(out[0].item())), (e2.stats(), float(out[0].item()))
+    assert dt < 60.0, dt
+dist.barrier()
 if rank == 0:
     print("XCHG WORKERS OK", flush=True)
 dist.destroy_process_group()
