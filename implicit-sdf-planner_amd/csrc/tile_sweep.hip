@@ -3,8 +3,9 @@
 // with the per-pose tile term grad_cost_p (:766-824) plugged in before the flatness back-prop (:536), the voxel
 // qualifier being occupancy (V2) or esdf <= occ_thresh (V3).
 //
-// One optimizer step = two launches (DESIGN.md "integral sweep"):
-//   sweep_kernel<KIND>  one WORKGROUP per 4 consecutive constraint samples, one wavefront per sample:
+// One optimizer step = ONE launch when all its workgroups are resident (one trajectory, a rank's shard, small batches: the
+// tail's workgroups ride behind the sweep's, FUSED), otherwise two (DESIGN.md "integral sweep"):
+//   sweep_kernel<KIND, IDENT, FUSED>  one WORKGROUP per 4 constraint samples, one wavefront per sample:
 //                     (1) poses: one LANE per sample runs the serial fp64 chain (quintic, flatness forward, rotation, the
 //                         tile index box of getPointsInAABB, optional whole-tile cull, the window of tile rows the
 //                         shape's inflated bounding box can reach) and publishes it through LDS;
@@ -12,16 +13,19 @@
 //                         qualifier bits (1-2 dwords of the bit-grid, requested one round ahead), DPP prefix-sum
 //                         compaction of the surviving voxels into an LDS ring;
 //                     (3) conservative fp32 filter on full wavefronts (body-frame transform, cube cull, robot SDF);
-//                     (4) survivors, 64 at a time, get the exact fp64 treatment of grad_cost_p in the same wave:
-//                         voxel centre, R^T(c - x), cube cull (:800-803), robot SDF, smoothedL1 and - when the penalty
-//                         is active - the central-difference gradient and the pose-gradient terms (:805-820);
+//                     (4) survivors, 64 at a time, get the exact fp64 treatment of grad_cost_p, dealt over the workgroup's
+//                         waves: voxel centre, R^T(c - x), cube cull (:800-803), robot SDF, smoothedL1 and - when the
+//                         penalty is active - the central-difference gradient and the pose-gradient terms (:805-820);
 //                     (5) wave butterfly -> acc[sample][8].
-//                   No atomics, no work lists: results are bitwise reproducible.
-//   tail_kernel     one block per piece, one thread per sample: dynamics penalties, flatness reverse mode,
-//                   beta (x) grad scatter, then a fixed-order in-block sum over the piece's K+1 samples written
-//                   straight into gradC rows 6i..6i+5 and gradT(i).  The block of a trajectory that finishes last
-//                   adds up the piece costs (fixed order); blocks of pieces outside this rank's shard write zeros so
-//                   that the ranks' outputs sum to the full result.
+//                   No read-modify-write atomics, no work lists: results are bitwise reproducible.
+//   tail_piece      (tail_kernel, or the trailing workgroups of a fused launch) one workgroup per piece, one thread per
+//                   sample: dynamics penalties, flatness reverse mode, beta (x) grad scatter, then a fixed-order in-block
+//                   sum over the piece's K+1 samples written straight into gradC rows 6i..6i+5 and gradT(i).  Results
+//                   change hands through self-resetting 8-byte slots (value == ready flag): the sweep's sums per sample,
+//                   the piece costs that the last-dispatched workgroup of a trajectory adds up in fixed order, and - in a
+//                   multi-GPU step with the exchange inside the launch (XFuse) - the rows and costs the owner of a piece
+//                   stores into every peer's board.  Workgroups of pieces outside this rank's shard write zeros (or, with
+//                   XFuse, fetch the owner's rows) so that every rank ends up with, or sums to, the full result.
 // Everything that reaches the result is fp64 except the stored ESDF (fp32).  No MFMA: gather/interpolate work.
 #define ISDF_LEAN_MATH 1      // dev_math.hpp / dev_shapes.hpp: lean sqrt and normalisation in this translation unit
 #include "isdf_internal.hpp"
