@@ -105,7 +105,19 @@ dist.barrier()
 # the step ends with the overflow flag and a NaN cost (last check: the boards are out of step afterwards)
 x4 = par.XgmiExchange(e2, e2.out_stride(6), dev)
 assert x4.ok, x4.why
-assert x4.try_fused_step(_step, out)
+# callback level (MINCO + sweeps + adjoint): exchange kernel after the sweep vs exchange inside the sweep's launch
+Cf6 = Cf.reshape(6, 6, 3)
+head = np.zeros((3, 3)); head[:, 0] = Cf6[0, 0, :]
+tail = np.zeros((3, 3)); tail[:, 0] = sum(Cf6[5, k, :] * T[5] ** k for k in range(6))
+e2.set_trajectory(6, head, tail, 2.0)
+xv = e2.pack_variables(T, Cf6[1:, 0, :])
+c1, g1 = par.cost_function_allreduced(e2, xv, x4)
+assert x4.try_fused_step(_step, out) and x4.fused
+c2, g2 = par.cost_function_allreduced(e2, xv, x4)
+assert abs(c1 - c2) <= 1e-12 * abs(c1) and np.allclose(g1, g2, rtol=0, atol=1e-12 * np.abs(g1).max()), (rank, c1, c2)
+gg = [torch.zeros(g2.size, dtype=torch.float64) for _ in range(world)]
+dist.all_gather(gg, torch.from_numpy(np.ascontiguousarray(g2)))
+assert all(torch.equal(gg[0], a) for a in gg), rank
 dist.barrier()
 if rank == 0:
     import time
