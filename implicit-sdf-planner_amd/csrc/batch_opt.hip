@@ -3,12 +3,18 @@
 // (csrc/lbfgs_host.hpp == lbfgs::lbfgs_optimize, lbfgs.hpp:480-835) on its own objective callback
 // (costFunctionLmbm, back_end_optimizer.hpp:358-430) with its own boundary states; the callbacks of one round are
 // evaluated TOGETHER: each trajectory's host thread does its serial part (tau -> T, MINCO, energy) in parallel with the
-// others, then the coordinator uploads the coefficients of all trajectories that asked for an evaluation, runs ONE batched
-// integral sweep on the device (isdf_eval_device, n_traj = active count), downloads, and the threads finish their
-// callbacks (propogateGrad, chain rule).  Line searches that need more evaluations simply take part in more rounds.
+// others, then the coordinator uploads the coefficients of the trajectories that asked for an evaluation, runs ONE batched
+// integral sweep on the device (isdf_eval_device, n_traj = active count), downloads, and those threads finish their
+// callbacks (propogateGrad, chain rule).  Rounds are GREEDY: a round starts as soon as a share of the live trajectories
+// (min_share, default a quarter) is waiting, so the host part of one group (MINCO, adjoint, the L-BFGS update) runs while
+// the device evaluates another; which trajectories share a round has no influence on their results (the sweep treats every
+// trajectory independently, all sums have a fixed order).  Line searches that need more evaluations simply take part in
+// more rounds.
 #include "isdf_ctx.hpp"
 #include "lbfgs_host.hpp"
 #include <chrono>
+#include <cmath>
+#include <cstdlib>
 #include <condition_variable>
 #include <cstring>
 #include <mutex>
@@ -35,9 +41,9 @@ struct Batch {
     // round state (guarded by m)
     std::mutex m;
     std::condition_variable cv_workers, cv_coord;
-    std::vector<char> submitted, finished;
-    int n_submitted = 0, n_finished = 0;
-    long long round = 0;
+    std::vector<char> submitted, finished, ready;     // ready[t]: the round trajectory t joined has been evaluated
+    int n_submitted = 0, n_finished = 0, n_inflight = 0;
+    double min_share = 0.25;      // a round starts when this share of the live trajectories waits (1.0: all of them)
     int error = ISDF_OK;
     // staging: slot t holds [T(N) | coeffs(18N)] of trajectory t; out slot t holds [cost | gradT | gradC]
     std::vector<double> stage_in, stage_out;
@@ -57,11 +63,11 @@ double worker_evaluate(void *instance, const double *x, double *g, const int n) 
     std::memcpy(in + N, w.minco.c.data(), (size_t)18 * N * sizeof(double));
     {
         std::unique_lock<std::mutex> lk(b.m);
-        const long long my_round = b.round;
         b.submitted[w.id] = 1;
         b.n_submitted++;
         b.cv_coord.notify_one();
-        b.cv_workers.wait(lk, [&] { return b.round != my_round; });
+        b.cv_workers.wait(lk, [&] { return b.ready[w.id] != 0; });
+        b.ready[w.id] = 0;
         if (b.error != ISDF_OK) return INFINITY;
     }
     const double *o = b.stage_out.data() + (size_t)w.id * b.ostride;
@@ -90,7 +96,8 @@ extern "C" int isdf_optimize_lbfgs_batch(isdf_ctx *c, int n_traj, int N, const d
     b.ctx = c; b.n_traj = n_traj; b.N = N; b.n = N + 3 * (N - 1); b.rho = rho;
     b.in_per = (size_t)19 * N; b.ostride = isdf_out_stride(N);
     b.workers.resize(n_traj);
-    b.submitted.assign(n_traj, 0); b.finished.assign(n_traj, 0);
+    b.submitted.assign(n_traj, 0); b.finished.assign(n_traj, 0); b.ready.assign(n_traj, 0);
+    if (const char *e = getenv("ISDF_BATCH_MIN_SHARE")) { const double v = atof(e); if (v > 0.0 && v <= 1.0) b.min_share = v; }
     b.stage_in.assign((size_t)n_traj * b.in_per, 0.0);
     b.stage_out.assign((size_t)n_traj * b.ostride, 0.0);
     for (int t = 0; t < n_traj; t++) {
@@ -100,11 +107,17 @@ extern "C" int isdf_optimize_lbfgs_batch(isdf_ctx *c, int n_traj, int N, const d
         w.T.assign(N, 0.0); w.gdC.assign((size_t)18 * N, 0.0); w.gdT.assign(N, 0.0);
         w.gradP.assign((size_t)3 * (N > 1 ? N - 1 : 1), 0.0); w.gradT.assign(N, 0.0);
     }
-    // device + pinned buffers for a full batch
+    // device + pinned buffers for a full batch, twice: up to TWO rounds are in flight (the second queued behind the first on
+    // the stream), so the device never waits for the host to deliver one round's results before the next one starts
     const size_t in_all = (size_t)n_traj * b.in_per, out_all = (size_t)n_traj * b.ostride;
-    double *h_pin = nullptr, *d_buf = nullptr;
-    HIPCHK(c, hipHostMalloc((void **)&h_pin, (in_all + out_all) * sizeof(double), hipHostMallocDefault));
-    if (hipMalloc(&d_buf, (in_all + out_all) * sizeof(double)) != hipSuccess) { (void)hipHostFree(h_pin); return isdf_fail(c, ISDF_ERR_HIP, "device allocation failed"); }
+    struct Slot { double *h_pin = nullptr, *d_buf = nullptr; std::vector<int> active; hipEvent_t done = nullptr; bool busy = false; } slots[2];
+    auto release = [&] { for (Slot &q : slots) { if (q.h_pin) (void)hipHostFree(q.h_pin); if (q.d_buf) (void)hipFree(q.d_buf); if (q.done) (void)hipEventDestroy(q.done); } };
+    for (Slot &q : slots) {
+        if (hipHostMalloc((void **)&q.h_pin, (in_all + out_all) * sizeof(double), hipHostMallocDefault) != hipSuccess ||
+            hipMalloc(&q.d_buf, (in_all + out_all) * sizeof(double)) != hipSuccess ||
+            hipEventCreateWithFlags(&q.done, hipEventDisableTiming) != hipSuccess) { release(); return isdf_fail(c, ISDF_ERR_HIP, "batch buffers: allocation failed"); }
+    }
+    { int rc0 = isdf_reserve_sweep_buffers(c, (long long)n_traj * N); if (rc0) { release(); return rc0; } }
 
     const auto t0 = std::chrono::steady_clock::now();
     std::vector<std::thread> threads;
@@ -127,47 +140,71 @@ extern "C" int isdf_optimize_lbfgs_batch(isdf_ctx *c, int n_traj, int N, const d
             b.cv_coord.notify_one();
         });
     }
-    // coordinator: one device round per set of pending evaluations
-    std::vector<int> active;
+    // coordinator: greedy rounds, two in flight
     int rc = ISDF_OK;
-    for (;;) {
-        {
-            std::unique_lock<std::mutex> lk(b.m);
-            b.cv_coord.wait(lk, [&] { return b.n_submitted + b.n_finished == b.n_traj; });
-            if (b.n_submitted == 0) break;          // every trajectory is done
-            active.clear();
-            for (int t = 0; t < n_traj; t++) if (b.submitted[t]) active.push_back(t);
-        }
-        // no worker touches the staging buffers while it waits: safe to read without the lock
-        const int na = (int)active.size();
-        double *hT = h_pin, *hC = h_pin + (size_t)na * N;            // compacted [T of all | coeffs of all]
+    auto issue = [&](Slot &q) {               // q.active holds the trajectories of the round; their staging slots are quiescent
+        const int na = (int)q.active.size();
+        double *hT = q.h_pin, *hC = q.h_pin + (size_t)na * N;          // compacted [T of all | coeffs of all]
         for (int k = 0; k < na; k++) {
-            const double *in = b.stage_in.data() + (size_t)active[k] * b.in_per;
+            const double *in = b.stage_in.data() + (size_t)q.active[k] * b.in_per;
             std::memcpy(hT + (size_t)k * N, in, (size_t)N * sizeof(double));
             std::memcpy(hC + (size_t)k * 18 * N, in + N, (size_t)18 * N * sizeof(double));
         }
-        double *dT = d_buf, *dC = d_buf + (size_t)na * N, *dO = d_buf + in_all;
-        if (rc == ISDF_OK && hipMemcpyAsync(d_buf, h_pin, (size_t)na * b.in_per * sizeof(double), hipMemcpyHostToDevice, c->stream) != hipSuccess) rc = ISDF_ERR_HIP;
+        double *dT = q.d_buf, *dC = q.d_buf + (size_t)na * N, *dO = q.d_buf + in_all;
+        if (rc == ISDF_OK && hipMemcpyAsync(q.d_buf, q.h_pin, (size_t)na * b.in_per * sizeof(double), hipMemcpyHostToDevice, c->stream) != hipSuccess) rc = ISDF_ERR_HIP;
         if (rc == ISDF_OK) rc = isdf_eval_device(c, na, N, dT, dC, dO, nullptr, c->stream);
-        if (rc == ISDF_OK && hipMemcpyAsync(h_pin + in_all, dO, (size_t)na * b.ostride * sizeof(double), hipMemcpyDeviceToHost, c->stream) != hipSuccess) rc = ISDF_ERR_HIP;
-        if (rc == ISDF_OK && hipStreamSynchronize(c->stream) != hipSuccess) rc = ISDF_ERR_HIP;
-        for (int k = 0; k < na && rc == ISDF_OK; k++)
-            std::memcpy(b.stage_out.data() + (size_t)active[k] * b.ostride, h_pin + in_all + (size_t)k * b.ostride, b.ostride * sizeof(double));
+        if (rc == ISDF_OK && hipMemcpyAsync(q.h_pin + in_all, dO, (size_t)na * b.ostride * sizeof(double), hipMemcpyDeviceToHost, c->stream) != hipSuccess) rc = ISDF_ERR_HIP;
+        if (rc == ISDF_OK && hipEventRecord(q.done, c->stream) != hipSuccess) rc = ISDF_ERR_HIP;
+        q.busy = true;
         b.rounds_run++;
         b.evals_run += na;
+    };
+    auto deliver = [&](Slot &q) {             // waits for the round, hands the results to its trajectories
+        if (rc == ISDF_OK && hipEventSynchronize(q.done) != hipSuccess) rc = ISDF_ERR_HIP;
+        const int na = (int)q.active.size();
+        for (int k = 0; k < na && rc == ISDF_OK; k++)
+            std::memcpy(b.stage_out.data() + (size_t)q.active[k] * b.ostride, q.h_pin + in_all + (size_t)k * b.ostride, b.ostride * sizeof(double));
+        std::unique_lock<std::mutex> lk(b.m);
+        if (rc != ISDF_OK) b.error = rc;
+        for (int t : q.active) b.ready[t] = 1;
+        b.n_inflight -= na;
+        q.busy = false;
+        b.cv_workers.notify_all();
+    };
+    int cur = 0;
+    for (;;) {
+        Slot &q = slots[cur], &other = slots[cur ^ 1];
+        if (q.busy) deliver(q);                      // both in flight: the older one first
+        bool take = false, done = false;
         {
             std::unique_lock<std::mutex> lk(b.m);
-            if (rc != ISDF_OK) b.error = rc;
-            for (int t : active) b.submitted[t] = 0;
-            b.n_submitted = 0;
-            b.round++;
-            b.cv_workers.notify_all();
+            for (;;) {
+                // trajectories in flight cannot submit: the share refers to those that can
+                const int free_live = b.n_traj - b.n_finished - b.n_inflight;
+                const int need = std::max(1, (int)std::ceil(b.min_share * free_live));
+                if (b.n_submitted > 0 && b.n_submitted >= std::min(need, free_live)) { take = true; break; }
+                if (other.busy) {
+                    if (rc != ISDF_OK || hipEventQuery(other.done) != hipErrorNotReady) break;   // finished (or failed): deliver it - that is where new work comes from
+                    b.cv_coord.wait_for(lk, std::chrono::microseconds(20));
+                    continue;
+                }
+                if (b.n_traj - b.n_finished == 0) { done = true; break; }
+                b.cv_coord.wait(lk);
+            }
+            if (take) {
+                q.active.clear();
+                for (int t = 0; t < n_traj; t++) if (b.submitted[t]) { q.active.push_back(t); b.submitted[t] = 0; }
+                b.n_inflight += b.n_submitted;
+                b.n_submitted = 0;
+            }
         }
+        if (done) break;
+        if (take) { issue(q); cur ^= 1; }
+        else deliver(other);
     }
     for (auto &th : threads) th.join();
     const auto t1 = std::chrono::steady_clock::now();
-    (void)hipFree(d_buf);
-    (void)hipHostFree(h_pin);
+    release();
     const double wall = std::chrono::duration<double, std::milli>(t1 - t0).count();
     for (int t = 0; t < n_traj; t++) {
         const isdf_host::LbfgsResult &r = b.workers[t].result;

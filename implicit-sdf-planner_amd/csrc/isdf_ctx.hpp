@@ -81,6 +81,7 @@ namespace isdf { struct XFuse; }
 // *err != ISDF_OK: requested but impossible for this launch)
 bool isdf_xchg_fill(isdf_ctx *c, isdf::XFuse *xf, size_t pieces, int *err);
 bool isdf_xchg_fuse_on(const isdf_ctx *c);     // isdf_xchg_fuse(ctx, 1) is in force
+int isdf_reserve_sweep_buffers(isdf_ctx *c, long long total_pieces);   // isdf_host.hip: scratch of the integral sweep (grows only)
 void isdf_xchg_release(isdf_ctx *c);          // xchg.hip: closes the peer mappings, frees the mailbox (isdf_destroy)
 void isdf_frontend_release(isdf_ctx *c);      // frontend.hip: frees the tables (isdf_destroy)
 

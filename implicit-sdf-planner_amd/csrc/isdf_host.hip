@@ -382,6 +382,33 @@ static int prof_begin(isdf_ctx *c, hipStream_t st, ProfEvent **ev) {
     return ISDF_OK;
 }
 
+// scratch of the integral sweep for `total_pieces` pieces per launch (grows only; the batched optimizer reserves its largest
+// round up front so that no round reallocates while another is in flight)
+int isdf_reserve_sweep_buffers(isdf_ctx *c, long long total_pieces) {
+    const size_t n_samples = (size_t)total_pieces * (c->cfg.integral_intervs + 1);
+    if (c->sample_cap < n_samples) {
+        if (c->d_acc) (void)hipFree(c->d_acc);
+        if (c->d_sample_info) (void)hipFree(c->d_sample_info);
+        c->d_acc = nullptr; c->d_sample_info = nullptr; c->sample_cap = 0;
+        HIPCHK(c, hipMalloc(&c->d_acc, n_samples * ACC_STRIDE * sizeof(double)));
+        HIPCHK(c, hipMalloc(&c->d_sample_info, n_samples * 2 * sizeof(int)));
+        // result slots are created EMPTY (all-ones, tile_sweep.hip SLOT_EMPTY); every step leaves them empty again
+        HIPCHK(c, hipMemset(c->d_acc, 0xFF, n_samples * ACC_STRIDE * sizeof(double)));
+        HIPCHK(c, hipDeviceSynchronize());
+        c->sample_cap = n_samples;
+    }
+    if (c->piece_cap < (size_t)total_pieces) {
+        // piece-cost slots: created EMPTY like the collision sums' slots
+        if (c->d_piece_cost) (void)hipFree(c->d_piece_cost);
+        c->d_piece_cost = nullptr; c->piece_cap = 0;
+        HIPCHK(c, hipMalloc(&c->d_piece_cost, (size_t)total_pieces * sizeof(double)));
+        HIPCHK(c, hipMemset(c->d_piece_cost, 0xFF, (size_t)total_pieces * sizeof(double)));
+        HIPCHK(c, hipDeviceSynchronize());
+        c->piece_cap = (size_t)total_pieces;
+    }
+    return ISDF_OK;
+}
+
 // mode 0: the sweep cfg.variant names; 1: the swept-volume sweep; 2: the integral sweep with the collision term off
 // (modes 1 + 2 together are what costFunctionLmbm runs for the reference's live configuration)
 static int eval_device_impl(isdf_ctx *c, int n_traj, int N, const double *d_T, const double *d_coeffs, double *d_out,
@@ -453,26 +480,7 @@ static int eval_device_impl(isdf_ctx *c, int n_traj, int N, const double *d_T, c
     long long pb, pe;
     shard_range(total_pieces, c->rank, c->world, pb, pe);
     const size_t n_samples = (size_t)total_pieces * (cfg.integral_intervs + 1);
-    if (c->sample_cap < n_samples) {
-        if (c->d_acc) (void)hipFree(c->d_acc);
-        if (c->d_sample_info) (void)hipFree(c->d_sample_info);
-        c->d_acc = nullptr; c->d_sample_info = nullptr; c->sample_cap = 0;
-        HIPCHK(c, hipMalloc(&c->d_acc, n_samples * ACC_STRIDE * sizeof(double)));
-        HIPCHK(c, hipMalloc(&c->d_sample_info, n_samples * 2 * sizeof(int)));
-        // result slots are created EMPTY (all-ones, tile_sweep.hip SLOT_EMPTY); every step leaves them empty again
-        HIPCHK(c, hipMemset(c->d_acc, 0xFF, n_samples * ACC_STRIDE * sizeof(double)));
-        HIPCHK(c, hipDeviceSynchronize());
-        c->sample_cap = n_samples;
-    }
-    if (c->piece_cap < (size_t)total_pieces) {
-        // piece-cost slots: created EMPTY like the collision sums' slots
-        if (c->d_piece_cost) (void)hipFree(c->d_piece_cost);
-        c->d_piece_cost = nullptr; c->piece_cap = 0;
-        HIPCHK(c, hipMalloc(&c->d_piece_cost, (size_t)total_pieces * sizeof(double)));
-        HIPCHK(c, hipMemset(c->d_piece_cost, 0xFF, (size_t)total_pieces * sizeof(double)));
-        HIPCHK(c, hipDeviceSynchronize());
-        c->piece_cap = (size_t)total_pieces;
-    }
+    { int rc0 = isdf_reserve_sweep_buffers(c, total_pieces); if (rc0) return rc0; }
     int rc = ISDF_OK;
     SweepParams P{};
     P.grid = c->grid;
