@@ -890,15 +890,19 @@ __global__ __launch_bounds__(TL_THREADS) void tail_kernel(const SweepParams P) {
     tail_piece<true, false>(P, (int)blockIdx.x, s_val);        // one workgroup per piece of the launch
 }
 
-// Workgroups a fused launch may have: all of them resident at once, 3 per CU (the fused kernels' register budget)
-constexpr int FUSED_MAX_BLOCKS = 3 * 256;
+// Workgroups a fused launch may have: all of them resident at once, 3 per CU (the fused kernels' register budget).
+// Developer override: ISDF_FUSE_MAX_BLOCKS.
+static int fused_max_blocks() {
+    static const int v = [] { const char *e = getenv("ISDF_FUSE_MAX_BLOCKS"); const int n = e ? atoi(e) : 0; return n > 0 ? n : 3 * 256; }();
+    return v;
+}
 
 bool sweep_can_fuse(const SweepParams &P) {
     if (!P.enable_pos || P.shape.kind == ISDF_SHAPE_MESH || P.shape.d.ident == 0) return false;
     const long long n_samples = (long long)(P.piece_end - P.piece_begin) * (P.K + 1);
     if (n_samples <= 0) return false;
     // tail workgroups of OTHER ranks' pieces only write zeros and leave: they do not count
-    return (n_samples + SW_SAMPLES - 1) / SW_SAMPLES + (long long)(P.piece_end - P.piece_begin) <= FUSED_MAX_BLOCKS && (long long)P.n_traj * P.N <= 8 * FUSED_MAX_BLOCKS;
+    return (n_samples + SW_SAMPLES - 1) / SW_SAMPLES + (long long)(P.piece_end - P.piece_begin) <= fused_max_blocks() && (long long)P.n_traj * P.N <= 8 * fused_max_blocks();
 }
 
 // fused = true: sweep workgroups + one tail workgroup per piece in ONE launch (the caller then skips launch_tail)
