@@ -412,7 +412,7 @@ int isdf_reserve_sweep_buffers(isdf_ctx *c, long long total_pieces) {
 // mode 0: the sweep cfg.variant names; 1: the swept-volume sweep; 2: the integral sweep with the collision term off
 // (modes 1 + 2 together are what costFunctionLmbm runs for the reference's live configuration)
 static int eval_device_impl(isdf_ctx *c, int n_traj, int N, const double *d_T, const double *d_coeffs, double *d_out,
-                            double *d_tstar, hipStream_t st, int mode = 0) {
+                            double *d_tstar, hipStream_t st, int mode = 0, bool fixed_tstar = false) {
     isdf_config cfg = c->cfg;
     if (mode == 1) cfg.variant = ISDF_V1_SWEPT;
     if (mode == 2) { cfg.variant = ISDF_V3_ESDF_TILE; cfg.enable_pos = 0; }
@@ -426,9 +426,12 @@ static int eval_device_impl(isdf_ctx *c, int n_traj, int N, const double *d_T, c
     if (cfg.variant == ISDF_V1_SWEPT) {
         if (n_traj != 1) return fail(c, ISDF_ERR_UNSUPPORTED, "the swept-volume sweep takes one trajectory");
         if (isdf_xchg_fuse_on(c)) return fail(c, ISDF_ERR_UNSUPPORTED, "the in-kernel exchange belongs to the integral sweep (V2/V3)");
-        HIPCHK(c, hipMemsetAsync(d_out, 0, (size_t)n_traj * ostride * sizeof(double), st));
-        HIPCHK(c, hipMemsetAsync(c->d_stats, 0, 8 * sizeof(unsigned long long), st));
-        if (c->M <= 0) return ISDF_OK;   // no obstacle points: nothing to add
+        if (c->M <= 0) {                 // no obstacle points: nothing to add
+            HIPCHK(c, hipMemsetAsync(d_out, 0, (size_t)n_traj * ostride * sizeof(double), st));
+            HIPCHK(c, hipMemsetAsync(c->d_stats, 0, 8 * sizeof(unsigned long long), st));
+            return ISDF_OK;
+        }
+        // (no clearing here: the prepare / fixed kernel zeroes the statistics words and the reduction writes every output)
         long long b, e;
         shard_range(c->M, c->rank, c->world, b, e);
         SweptParams P{};
@@ -437,7 +440,7 @@ static int eval_device_impl(isdf_ctx *c, int n_traj, int N, const double *d_T, c
         P.N = N; P.M = c->M; P.point_begin = (int)b; P.point_end = (int)e;
         P.safety_hor = cfg.safety_hor; P.weight_p = cfg.weight_p;
         P.T = d_T; P.coeffs = d_coeffs; P.points = c->d_points;
-        P.tstar = d_tstar ? d_tstar : c->d_tstar;
+        P.tstar = (d_tstar && !fixed_tstar) ? d_tstar : c->d_tstar;
         P.traj_duration = c->d_traj_duration;
         P.max_coarse = 1536;   // traj_duration < 300 s, coarse step 0.2 s -> at most 1501 samples
         if (!c->d_coarse_t) {
@@ -457,6 +460,12 @@ static int eval_device_impl(isdf_ctx *c, int n_traj, int N, const double *d_T, c
         { int rc2 = ensure(c, &c->d_hist, &c->hist_cap, (size_t)N); if (rc2) return rc2; }
         P.hist = c->d_hist;
         P.stats = c->d_stats;
+        if (fixed_tstar) {               // the minimisers are given (isdf_eval_swept_at_tstar): no search
+            launch_swept_fixed(P, d_tstar, st);
+            launch_swept_reduce(P, d_out, st);
+            HIPCHK(c, hipGetLastError());
+            return ISDF_OK;
+        }
         launch_swept_prepare(P, st);
         ProfEvent *ev;
         int rc = prof_begin(c, st, &ev);
@@ -556,6 +565,15 @@ extern "C" int isdf_eval_device(isdf_ctx *c, int n_traj, int N, const double *d_
                                 double *d_tstar, void *stream) {
     if (!c) return ISDF_ERR_INVALID_ARG;
     return eval_device_impl(c, n_traj, N, d_T, d_coeffs, d_out, d_tstar, (hipStream_t)stream);
+}
+
+// The swept-volume sweep's back-prop with the minimisers GIVEN: for every obstacle point the robot SDF and its body-frame
+// gradient are evaluated at d_tstar[pt] instead of being searched for (a negative / NaN entry = "no interval qualified").
+extern "C" int isdf_eval_swept_at_tstar(isdf_ctx *c, int N, const double *d_T, const double *d_coeffs, double *d_out,
+                                        const double *d_tstar, void *stream) {
+    if (!c) return ISDF_ERR_INVALID_ARG;
+    if (!d_tstar) return fail(c, ISDF_ERR_INVALID_ARG, "null t* buffer");
+    return eval_device_impl(c, 1, N, d_T, d_coeffs, d_out, const_cast<double *>(d_tstar), (hipStream_t)stream, 1, true);
 }
 
 static int fetch_stats(isdf_ctx *c) {

@@ -85,10 +85,11 @@ struct SweptParams {
     double *point_partial;      // [M][PARTIAL_STRIDE] (gdC 18, gdT, pena)
     int *point_piece;           // [M]
     double *hist;               // [N] per-piece sum of gdT
-    unsigned long long *stats;
+    unsigned long long *stats;  // [0]=units [2]=intervals [3]=active points [4]=overflow [5]=descent iterations [6]=reduce ticket [7]=passes
 };
 void launch_swept_prepare(const SweptParams &P, hipStream_t stream);
 void launch_swept_sweep(const SweptParams &P, hipStream_t stream, hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr);
-void launch_swept_reduce(const SweptParams &P, double *out, hipStream_t stream);
+void launch_swept_reduce(const SweptParams &P, double *out, hipStream_t stream);      // back-prop + sums (writes every entry of `out`)
+void launch_swept_fixed(const SweptParams &P, const double *tstar_in, hipStream_t stream);   // minimisers given: replaces prepare + sweep
 
 } // namespace isdf

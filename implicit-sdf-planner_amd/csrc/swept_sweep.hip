@@ -4,21 +4,30 @@
 //   (getSDFofSweptVolume :710-747, choiceTInit :367-445, gradientDescent :1000-1062,
 //    getSDF_DOTAtTimeStampOptimized :593-662, getStateOnTrajStamp :332-341).
 //
-// One optimizer step = four launches (prepare, sweep, back-prop, reduce + suffix):
+// One optimizer step = four launches (prepare, sweep, back-prop, reduce):
 //   swept_prepare_kernel  one block: the "traj_duration" state (refreshed only when the total is < 300 s, :287-296),
 //                         the coarse time table t += 0.2 by repeated fp64 addition (one lane, like the reference loop),
 //                         then the pose (position + rotation) at every coarse time, shared by all obstacle points.
-//   swept_sweep_kernel    one WAVEFRONT per obstacle point:
+//   swept_sweep_kernel    one WAVEFRONT per obstacle point; the trajectory (durations + 6N x 3 coefficients, 152 B per
+//                         piece) is staged ONCE per workgroup into LDS - every pose evaluation of every pass reads it from
+//                         there (the rocprofv3 counters of the first version showed 64 % of the wave cycles parked in
+//                         s_waitcnt on the global trajectory table, profiles/r2a_v1_pmc_sq.txt):
 //                           coarse scan   lanes = coarse times (table poses), ballot -> maximal in-range runs
 //                                         (intervals; a run still open at the end is dropped, quirk q2);
 //                           fine scan     lanes = 0.02 s steps of one interval (each lane accumulates its own t by
 //                                         repeated addition), first-minimum reduction, running minimum and seed
 //                                         carried ACROSS intervals (quirk q1);
 //                           descent       the 9 step-halving candidates of one sign-descent iteration are evaluated
-//                                         by 9 lanes at once, the 6 central-difference SDF samples by 6 lanes;
+//                                         by 9 lanes at once, the 6 central-difference SDF samples by 6 lanes; the
+//                                         remaining lanes evaluate AHEAD along the current direction (pose, point
+//                                         velocity and gradient samples at the next five full steps), so a descent that
+//                                         is marching with full steps advances up to six iterations per pass - same
+//                                         evaluations, same accept tests, same t* as the one-by-one loop;
 //                           -> (t*, sdf*, body-frame gradient) per point.
 //   swept_backprop_kernel one THREAD per obstacle point: penalty (mu = 0.01), flatness reverse mode, 20-double record.
-//   swept_reduce_kernel   deterministic sums: gradC rows per piece, gradT(j) = sum over points with piece > j, cost.
+//   swept_reduce_kernel   deterministic sums: gradC rows per piece, cost, and - in the workgroup that finishes last -
+//                         gradT(j) = sum over points with piece > j.
+//   swept_fixed_kernel    (isdf_eval_swept_at_tstar) replaces prepare + sweep when the minimisers t* are GIVEN.
 // Compute-/latency-bound: fp64 throughout, no tile traffic.
 #include "isdf_internal.hpp"
 #include "dev_mesh.hpp"
@@ -28,30 +37,70 @@ namespace isdf {
 constexpr int SW_WAVES = 4;
 constexpr int SW_MAX_RANGES = 32;
 
-struct PoseT { d3 x; m3 R; };
+// The trajectory as the kernels of this file see it: durations T[0..N) (LDS copies are padded to a multiple of 4 with a
+// huge value, which no time exceeds) and the 6N x 3 column-major coefficients.
+template <bool LDS> struct TrajL { const double *T; const double *C; int N; };
 
-__device__ __forceinline__ void pose_at(const SweptParams &P, const TrajView &tr, double t, d3 &x, m3 &R) {
+// Trajectory::locatePieceIdx (trajectory.hpp:545-563): the same sequential subtraction as dev_math.hpp's traj_locate; the
+// LDS form reads four durations per round (independent ds_reads in flight) before the wave-level "anyone still walking?".
+template <bool LDS> __device__ __forceinline__ int traj_locate_l(const TrajL<LDS> &tr, double &t) {
+    if constexpr (!LDS) { const TrajView v{tr.T, tr.C, tr.N}; return traj_locate(v, t); }
+    else {
+        int idx = 0;
+        bool walking = true;
+        for (int k = 0; k < tr.N; k += 4) {
+            const double d0 = tr.T[k], d1 = tr.T[k + 1], d2 = tr.T[k + 2], d3_ = tr.T[k + 3];
+            walking = walking && (t > d0); if (walking) { t -= d0; idx = k + 1; }
+            walking = walking && (t > d1); if (walking) { t -= d1; idx = k + 2; }
+            walking = walking && (t > d2); if (walking) { t -= d2; idx = k + 3; }
+            walking = walking && (t > d3_); if (walking) { t -= d3_; idx = k + 4; }
+            if (!__builtin_amdgcn_ballot_w64(walking)) break;
+        }
+        if (idx == tr.N) { idx--; t += tr.T[tr.N - 1]; }       // ran off the end: clamp to the last piece
+        return idx;
+    }
+}
+template <bool LDS> __device__ __forceinline__ void traj_eval_l(const TrajL<LDS> &tr, int piece, double t, d3 &pos, d3 &vel, d3 &acc, d3 &jer) {
+    const TrajView v{tr.T, tr.C, tr.N};
+    traj_eval(v, piece, t, pos, vel, acc, jer);
+}
+// cooperative copy of the trajectory into LDS ([T padded | coeffs]); returns the LDS view.  All threads of the block call it.
+__device__ __forceinline__ TrajL<true> traj_stage(double *lds, const double *T, const double *C, int N) {
+    const int Npad = (N + 3) & ~3;
+    for (int k = threadIdx.x; k < Npad; k += blockDim.x) lds[k] = k < N ? T[k] : 1.7976931348623157e308;
+    for (int k = threadIdx.x; k < 18 * N; k += blockDim.x) lds[Npad + k] = C[k];
+    __syncthreads();
+    return TrajL<true>{lds, lds + Npad, N};
+}
+static size_t traj_lds_bytes(int N) { return ((size_t)((N + 3) & ~3) + (size_t)18 * N) * sizeof(double); }
+constexpr size_t TRAJ_LDS_MAX = 60 * 1024;      // beyond this (N > ~400) the kernels read the trajectory from global memory
+
+template <bool LDS>
+__device__ __forceinline__ void pose_at(const SweptParams &P, const TrajL<LDS> &tr, double t, d3 &x, m3 &R) {
     double tl = t;
-    const int i = traj_locate(tr, tl);
+    const int i = traj_locate_l(tr, tl);
     d3 v, a, j;
-    traj_eval(tr, i, tl, x, v, a, j);
+    traj_eval_l(tr, i, tl, x, v, a, j);
     FlatS fs;
     flat_core(P.flat, v, a, fs);
     R = quat_to_rot(flat_quat(fs));
 }
-template <int KIND>
-__device__ __forceinline__ double sdf_at_time(const SweptParams &P, const TrajView &tr, d3 p, double t) {
-    d3 x; m3 R;
-    pose_at(P, tr, t, x, R);
-    return shape_sdf<KIND>(P.shape, mat_tmul(R, p - x));
+
+// wave-uniform lane -> every lane (two v_readlane; `l` must be uniform)
+__device__ __forceinline__ double rlane(double v, int l) {
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), l), hi = __builtin_amdgcn_readlane(__double2hiint(v), l);
+    return __hiloint2double(hi, lo);
 }
 
+template <bool LDS>
 __global__ __launch_bounds__(1024) void swept_prepare_kernel(const SweptParams P) {
+    extern __shared__ double s_dyn[];
     __shared__ int s_n;
-    const TrajView tr{P.T, P.coeffs, P.N};
+    TrajL<LDS> tr{P.T, P.coeffs, P.N};
+    if constexpr (LDS) tr = traj_stage(s_dyn, P.T, P.coeffs, P.N);
     if (threadIdx.x == 0) {
         double td = 0.0;
-        for (int i = 0; i < P.N; i++) td += P.T[i];            // getTotalDuration, trajectory.hpp:457-466
+        for (int i = 0; i < P.N; i++) td += tr.T[i];           // getTotalDuration, trajectory.hpp:457-466
         double D = *P.traj_duration;
         if (td < 3 * 1e2) { D = td; *P.traj_duration = D; }    // updateTraj, sw_manager.hpp:287-296
         int n = 0;
@@ -82,14 +131,25 @@ __device__ __forceinline__ double wave_first_min(double v, int lane, int n, int 
     return m;
 }
 
-template <int KIND>
+// lanes of one sign-descent pass (PH_GD):
+//   0-8    candidates x - tau_k        9-17  candidates x + tau_k          (tau_k = 0.02 / 2^k)
+//   18     pose at x (f(x), body-frame point velocity)      19-24  gradient samples at x
+//   block m = 1..5, base 25 + 7 (m - 1):  base = pose at y_m, base+1..base+6 = gradient samples at y_m
+//   60     f(y_6)
+// with y_0 = x, y_(m+1) = clamp(y_m - 0.02 s): the next full steps in the direction s of the previous pass.
+constexpr int GD_SPEC = 5;                       // look-ahead blocks
+__device__ __forceinline__ int gd_block_base(int m) { return m == 0 ? 18 : 25 + 7 * (m - 1); }
+
+template <int KIND, bool LDS>
 __global__ __launch_bounds__(64 * SW_WAVES) void swept_sweep_kernel(const SweptParams P) {
+    extern __shared__ double s_dyn[];
     __shared__ double s_rl[SW_WAVES][SW_MAX_RANGES], s_rr[SW_WAVES][SW_MAX_RANGES];
+    TrajL<LDS> tr{P.T, P.coeffs, P.N};
+    if constexpr (LDS) tr = traj_stage(s_dyn, P.T, P.coeffs, P.N);
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int pt = P.point_begin + blockIdx.x * SW_WAVES + wave;
     if (pt >= P.point_end) return;
-    const TrajView tr{P.T, P.coeffs, P.N};
     const d3 p = mk3(P.points[3 * pt], P.points[3 * pt + 1], P.points[3 * pt + 2]);
     const double D = *P.traj_duration;
     const int n_coarse = *P.n_coarse;
@@ -156,26 +216,27 @@ __global__ __launch_bounds__(64 * SW_WAVES) void swept_sweep_kernel(const SweptP
     // ---------------- per interval: fine scan (:423-438) then sign descent (:729-745, :1000-1062) ----------------
     // One loop, ONE pose + SDF evaluation site; what the lanes evaluate depends on the phase:
     //   FINE   lanes = 0.02 s steps of the interval (each lane accumulates its own t by repeated addition)
-    //   GD     one sign-descent iteration in a single pass: lanes 0-8 the nine halving candidates x - tau_k, lanes 9-17
-    //          x + tau_k (the sign of dSDF/dt picks the set afterwards), lane 18 the pose at x itself (f(x), body-frame
-    //          point velocity), lanes 19-24 the central-difference samples of the shape gradient at x (19-21: the
-    //          forward differences of Box's own gradient)
+    //   GD     one pass of the sign descent, lanes as listed above gd_block_base
     //   GRAD   lanes 18-24 only: shape gradient at the final x of the interval when the last step moved x
     enum { PH_FINE = 0, PH_GD = 1, PH_GRAD = 2, PH_NEXT = 3, PH_END = 4 };
     const int gmode = P.shape.grad_mode;
     const bool fd_central = (KIND != ISDF_SHAPE_MESH) && gmode == ISDF_GRAD_CENTRAL;
     const bool fd_forward = (KIND != ISDF_SHAPE_MESH) && gmode == ISDF_GRAD_BOX_FORWARD;
+    // this lane's role in a GD / GRAD pass: block (0..6) and offset inside it (0 = the pose lane)
+    const int gd_blk = lane < 18 ? -1 : (lane < 25 ? 0 : (lane < 60 ? (lane - 25) / 7 + 1 : (lane == 60 ? GD_SPEC + 1 : -1)));
+    const int gd_off = lane < 18 ? 0 : (lane < 25 ? lane - 18 : (lane < 60 ? (lane - 25) % 7 : 0));
     double range_time_seed = 0.0;
     double min_sdf_star = 1e1, t_star_best = 0.0;
     d3 grad_prel = mk3(0, 0, 0);
     bool have = false;
-    unsigned n_iters_total = 0;
+    unsigned n_iters_total = 0, n_passes = 0;
     int r = 0, phase = n_ranges > 0 ? PH_FINE : PH_END;
     double lb = 0.0, ub = 0.0, t_base = 0.0, t_min = 0.0, t_max = 0.0;
     double x = 0.0, fx = 0.0, prev_x = 0.0;
     d3 g1_at_x = mk3(0, 0, 0);                 // shape gradient at the current x (valid when g1_fresh)
     bool g1_fresh = false;
     int iter = 0;
+    int s_spec = 0;                            // direction of the look-ahead blocks (0: none)
     if (phase == PH_FINE) { lb = s_rl[wave][0]; ub = s_rr[wave][0]; t_base = lb; }
     while (phase != PH_END) {
         if (phase == PH_NEXT) {
@@ -191,42 +252,49 @@ __global__ __launch_bounds__(64 * SW_WAVES) void swept_sweep_kernel(const SweptP
         // ---- what this lane evaluates
         double te = 0.0;
         int pert = 0;                 // 0: the body-frame point itself; 1..6: central-difference sample; 7..9: forward difference
-        bool act = false;
+        bool act = false, pose_lane = false;
         if (phase == PH_FINE) {
             te = t_base;
             for (int q = 0; q < 63; q++) if (q < lane) te += dt;     // each lane's own accumulated time
             act = te < ub;
             if (!__ballot(act)) {     // nothing (left) to scan in this interval: descend from the seed
-                x = range_time_seed; prev_x = 10000000.0; iter = 0; g1_fresh = false;
+                x = range_time_seed; prev_x = 10000000.0; iter = 0; g1_fresh = false; s_spec = 0;
                 t_min = fmax(0.0, lb); t_max = fmin(ub, D);
                 phase = PH_GD;
                 continue;
             }
         } else {
-            if (lane < 18 && phase == PH_GD) {
-                double tau = 0.02;
-                const int k = lane < 9 ? lane : lane - 9;
-                for (int q = 0; q < 8; q++) if (q < k) tau = 0.5 * tau;
-                te = x - tau * (lane < 9 ? 1 : -1);
-                te = fmax(fmin(te, t_max), t_min);
-                act = true;
-            } else if (lane == 18) { te = x; act = true; }
-            else if (lane >= 19 && lane < 25 && fd_central) { te = x; pert = lane - 18; act = true; }
-            else if (lane >= 19 && lane < 22 && fd_forward) { te = x; pert = lane - 12; act = true; }
+            if (lane < 18) {
+                if (phase == PH_GD) {
+                    double tau = 0.02;
+                    const int k = lane < 9 ? lane : lane - 9;
+                    for (int q = 0; q < 8; q++) if (q < k) tau = 0.5 * tau;
+                    te = x - tau * (lane < 9 ? 1 : -1);
+                    te = fmax(fmin(te, t_max), t_min);
+                    act = true;
+                }
+            } else if (gd_blk == 0 || (gd_blk > 0 && phase == PH_GD && s_spec != 0)) {
+                // y_blk: gd_blk full steps from x in the direction s_spec, clamped like every candidate (:1046-1047)
+                te = x;
+                for (int q = 0; q < GD_SPEC + 1; q++) if (q < gd_blk) te = fmax(fmin(te - 0.02 * s_spec, t_max), t_min);
+                if (gd_off == 0) { act = true; pose_lane = gd_blk <= GD_SPEC; }
+                else if (fd_central) { pert = gd_off; act = true; }
+                else if (fd_forward && gd_off <= 3) { pert = gd_off + 6; act = true; }
+            }
         }
         // ---- the evaluation: pose at te, body-frame point, shape SDF (one code instance)
         double val = 1e300;
         d3 pvel = mk3(0, 0, 0), g_direct = mk3(0, 0, 0);
         if (act) {
             double tl = te;
-            const int pi = traj_locate(tr, tl);
+            const int pi = traj_locate_l(tr, tl);
             d3 xt, vt, at, jt;
-            traj_eval(tr, pi, tl, xt, vt, at, jt);
+            traj_eval_l(tr, pi, tl, xt, vt, at, jt);
             FlatS fs;
             flat_core(P.flat, vt, at, fs);
             const m3 R = quat_to_rot(flat_quat(fs));
             d3 pr = mat_tmul(R, p - xt);
-            if (lane == 18 && phase != PH_FINE) {
+            if (pose_lane) {
                 // d/dt of the body-frame point: -(R^T v + omega x p_rel) (getSDF_DOTAtTimeStampOptimized :593-662)
                 FlatS2 ft;
                 flat_core2(P.flat, vt, at, jt, fs, ft);
@@ -249,15 +317,16 @@ __global__ __launch_bounds__(64 * SW_WAVES) void swept_sweep_kernel(const SweptP
                 if (a == 0) pr.x += 0.01; else if (a == 1) pr.y += 0.01; else pr.z += 0.01;
             }
             if constexpr (KIND == ISDF_SHAPE_MESH) {
-                // one hierarchy query per lane gives value AND gradient (lane 18 keeps the gradient): no second, divergent
-                // query for the lane that needs both
+                // one hierarchy query per lane gives value AND gradient (the pose lanes keep the gradient): no second,
+                // divergent query for the lane that needs both
                 d3 gq;
                 val = mesh_sdf_grad(P.shape.mesh, pr, gq);
-                if (lane == 18) g_direct = gq;
+                if (pose_lane) g_direct = gq;
             } else {
                 val = shape_sdf<KIND>(P.shape, pr);
             }
         }
+        n_passes++;
         // ---- consume
         if (phase == PH_FINE) {
             const int nv = __popcll(__ballot(act));                  // valid lanes form a prefix (t is increasing)
@@ -265,48 +334,78 @@ __global__ __launch_bounds__(64 * SW_WAVES) void swept_sweep_kernel(const SweptP
             const double m = wave_first_min(val, lane, nv, arg);
             if (arg >= 0 && m < range_mindis) { range_mindis = m; range_time_seed = __shfl(te, arg, 64); }
             if (nv < 64) {
-                x = range_time_seed; prev_x = 10000000.0; iter = 0; g1_fresh = false;
+                x = range_time_seed; prev_x = 10000000.0; iter = 0; g1_fresh = false; s_spec = 0;
                 t_min = fmax(0.0, lb); t_max = fmin(ub, D);
                 phase = PH_GD;
             } else t_base = __shfl(te, 63, 64) + dt;
             continue;
         }
-        // shape gradient at x from the samples (getonlyGrad1)
-        d3 g1;
-        if (fd_central) {
-            const double dx = 0.000005;
-            const double gx = __shfl(val, 20, 64) - __shfl(val, 19, 64), gy = __shfl(val, 22, 64) - __shfl(val, 21, 64),
-                         gz = __shfl(val, 24, 64) - __shfl(val, 23, 64);
-            g1 = normalized3(mk3(gx / (2 * dx), gy / (2 * dx), gz / (2 * dx)));
-        } else if (fd_forward) {
-            const double s0 = __shfl(val, 18, 64), dx = 0.01;
-            g1 = mk3((__shfl(val, 19, 64) - s0) / dx, (__shfl(val, 20, 64) - s0) / dx, (__shfl(val, 21, 64) - s0) / dx);
-        } else {
-            g1 = mk3(__shfl(g_direct.x, 18, 64), __shfl(g_direct.y, 18, 64), __shfl(g_direct.z, 18, 64));
-        }
-        g1_at_x = g1; g1_fresh = true;
+        // shape gradient at the pose of block `base` from its samples (getonlyGrad1)
+        auto grad_of = [&](int base) -> d3 {
+            if (fd_central) {
+                const double dx = 0.000005;
+                const double gx = rlane(val, base + 2) - rlane(val, base + 1), gy = rlane(val, base + 4) - rlane(val, base + 3),
+                             gz = rlane(val, base + 6) - rlane(val, base + 5);
+                return normalized3(mk3(gx / (2 * dx), gy / (2 * dx), gz / (2 * dx)));
+            } else if (fd_forward) {
+                const double s0 = rlane(val, base), dx = 0.01;
+                return mk3((rlane(val, base + 1) - s0) / dx, (rlane(val, base + 2) - s0) / dx, (rlane(val, base + 3) - s0) / dx);
+            }
+            return mk3(rlane(g_direct.x, base), rlane(g_direct.y, base), rlane(g_direct.z, base));
+        };
+        g1_at_x = grad_of(18); g1_fresh = true;
         if (phase == PH_GRAD) { phase = PH_NEXT; continue; }
-        // sign-descent step (gradientDescent :1000-1062)
-        if (iter == 0) fx = __shfl(val, 18, 64);
-        const d3 pv = mk3(__shfl(pvel.x, 18, 64), __shfl(pvel.y, 18, 64), __shfl(pvel.z, 18, 64));
-        const double g = dot3(g1, pv);
-        const int sgn = (int)(g > 0) - (int)(g < 0);
-        prev_x = x;
-        const bool in_set = sgn > 0 ? (lane < 9) : (sgn < 0 ? (lane >= 9 && lane < 18) : false);
-        const unsigned long long accm = __ballot(in_set && ((val - fx) < 0));
-        bool stop = false;
-        if (accm) {
-            const int src = __ffsll((long long)accm) - 1;            // first (largest) step that decreases the SDF
-            const int d = sgn > 0 ? src : src - 9;
-            iter += d + 1;
-            x = __shfl(te, src, 64);
-            fx = __shfl(val, src, 64);
-            g1_fresh = false;
-        } else {
-            iter += 9;
-            stop = true;
+        // sign-descent iterations (gradientDescent :1000-1062): the one at x in full, then - while every step is the
+        // full step in the direction the look-ahead blocks were laid out for - the ones at y_1, y_2, ...
+        if (iter == 0) fx = rlane(val, 18);
+        bool finished = false;
+        int spec_next = 0;
+        for (int m = 0;; m++) {
+            const int base = gd_block_base(m);
+            const d3 g1 = m == 0 ? g1_at_x : grad_of(base);
+            if (m > 0) { g1_at_x = g1; g1_fresh = true; }
+            const d3 pv = mk3(rlane(pvel.x, base), rlane(pvel.y, base), rlane(pvel.z, base));
+            const double g = dot3(g1, pv);
+            const int sgn = (int)(g > 0) - (int)(g < 0);
+            spec_next = 0;
+            if (m == 0) {
+                prev_x = x;
+                const bool in_set = sgn > 0 ? (lane < 9) : (sgn < 0 ? (lane >= 9 && lane < 18) : false);
+                const unsigned long long accm = __ballot(in_set && ((val - fx) < 0));
+                bool stop = false, full = false;
+                if (accm) {
+                    const int src = __ffsll((long long)accm) - 1;            // first (largest) step that decreases the SDF
+                    const int d = sgn > 0 ? src : src - 9;
+                    iter += d + 1;
+                    x = rlane(te, src);
+                    fx = rlane(val, src);
+                    g1_fresh = false;
+                    full = d == 0;
+                    if (full) spec_next = sgn;
+                } else {
+                    iter += 9;
+                    stop = true;
+                }
+                if (!(iter < 300 && !stop && fabs(x - prev_x) > 1e-5)) { finished = true; break; }
+                if (!(full && s_spec != 0 && sgn == s_spec)) break;          // x is not y_1: the next pass starts from it
+            } else {
+                // at x = y_m only the full step along s_spec has been evaluated: f(y_(m+1))
+                if (sgn != s_spec) break;                                    // direction changed: regular pass from here
+                const int nb = m < GD_SPEC ? gd_block_base(m + 1) : 60;
+                const double fc = rlane(val, nb);
+                if (!((fc - fx) < 0)) break;                                 // full step rejected: its halvings need a regular pass
+                prev_x = x;
+                iter += 1;
+                x = rlane(te, nb);
+                fx = fc;
+                g1_fresh = false;
+                spec_next = s_spec;
+                if (!(iter < 300 && fabs(x - prev_x) > 1e-5)) { finished = true; break; }
+                if (m == GD_SPEC) break;
+            }
         }
-        if (!(iter < 300 && !stop && fabs(x - prev_x) > 1e-5)) phase = g1_fresh ? PH_NEXT : PH_GRAD;
+        s_spec = spec_next;
+        if (finished) phase = g1_fresh ? PH_NEXT : PH_GRAD;
     }
 
     // ---------------- hand the minimiser to swept_backprop_kernel ----------------
@@ -317,7 +416,31 @@ __global__ __launch_bounds__(64 * SW_WAVES) void swept_sweep_kernel(const SweptP
         o[2] = grad_prel.x; o[3] = grad_prel.y; o[4] = grad_prel.z;
         atomicAdd(&P.stats[2], (unsigned long long)n_ranges);
         atomicAdd(&P.stats[5], (unsigned long long)n_iters_total);
+        atomicAdd(&P.stats[7], (unsigned long long)n_passes);
     }
+}
+
+// The minimisers are GIVEN (isdf_eval_swept_at_tstar): one thread per obstacle point evaluates the robot SDF and its
+// body-frame gradient at tstar[pt] (getSDFAtTimeStamp :550-556, getGradPrelAtTimeStamp :566-572) and leaves the same record
+// the sweep kernel leaves; a negative or NaN tstar means "no interval qualified" (min sdf 10, no penalty; :717).
+template <int KIND>
+__global__ __launch_bounds__(64) void swept_fixed_kernel(const SweptParams P, const double *tstar_in) {
+    const int pt = P.point_begin + blockIdx.x * blockDim.x + threadIdx.x;
+    if (blockIdx.x == 0 && threadIdx.x == 0) for (int k = 0; k < 8; k++) if (k != 4) P.stats[k] = 0ull;
+    if (pt >= P.point_end) return;
+    const TrajL<false> tr{P.T, P.coeffs, P.N};
+    const d3 p = mk3(P.points[3 * pt], P.points[3 * pt + 1], P.points[3 * pt + 2]);
+    const double ts = tstar_in[pt];
+    double *o = P.point_partial + (size_t)pt * PARTIAL_STRIDE;
+    if (!(ts >= 0.0)) { o[0] = P.tstar[pt]; o[1] = 1e1; o[2] = o[3] = o[4] = 0.0; return; }
+    d3 x; m3 R;
+    pose_at(P, tr, ts, x, R);
+    const d3 pr = mat_tmul(R, p - x);
+    d3 g;
+    double sdf;
+    if constexpr (KIND == ISDF_SHAPE_MESH) sdf = mesh_sdf_grad(P.shape.mesh, pr, g);
+    else { sdf = shape_sdf<KIND>(P.shape, pr); g = shape_grad<KIND>(P.shape, pr); }
+    o[0] = ts; o[1] = sdf; o[2] = g.x; o[3] = g.y; o[4] = g.z;
 }
 
 // Back-prop at t* (back_end_optimizer.hpp:578-646): one THREAD per obstacle point - penalty (mu = 0.01), pose Jacobians,
@@ -373,11 +496,15 @@ __global__ __launch_bounds__(128) void swept_backprop_kernel(const SweptParams P
 }
 
 // Deterministic reduction.  Blocks [0, N): gradC rows of piece i and H[i] = sum of gdT over the points whose t* lies in
-// piece i (fixed strided order + fixed tree).  Block N: cost.  The last launch (suffix kernel) turns H into gradT.
+// piece i; block N: cost.  Every thread adds its strided points in ascending order, the 20 columns then go through ONE
+// fixed-shape butterfly per wavefront (no serial per-column tree) and the four wave sums are added in wave order.  The
+// workgroup that finishes LAST (ticket in stats[6], zeroed by the prepare / fixed kernel of the step) turns H into
+// gradT(j) = sum_{i > j} H[i]   ("for (j < i) gradT(j) += gdT", back_end_optimizer.hpp:642-645), in fixed order.
 __global__ __launch_bounds__(256) void swept_reduce_kernel(const SweptParams P, double *out, double *hist) {
-    __shared__ double s_red[256];
+    __shared__ double s_red[4][20];
+    __shared__ int s_last;
     const int i = blockIdx.x;
-    const int tid = threadIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     double acc[20];
 #pragma unroll
     for (int q = 0; q < 20; q++) acc[q] = 0.0;
@@ -392,43 +519,51 @@ __global__ __launch_bounds__(256) void swept_reduce_kernel(const SweptParams P, 
     }
 #pragma unroll
     for (int q = 0; q < 20; q++) {
-        if (cost_block != (q == 19)) continue;     // wave-uniform
-        s_red[tid] = acc[q];
-        __syncthreads();
-        for (int off = 128; off >= 1; off >>= 1) {
-            if (tid < off) s_red[tid] += s_red[tid + off];
-            __syncthreads();
-        }
-        if (tid == 0) {
-            const double v = s_red[0];
-            if (q == 19) out[0] = v;
-            else if (q == 18) hist[i] = v;
-            else { const int d = q / 6, r = q - 6 * d; out[1 + P.N + (size_t)d * 6 * P.N + 6 * i + r] = v; }
-        }
-        __syncthreads();
+        double v = acc[q];
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
+        if (lane == 0) s_red[wave][q] = v;
+    }
+    __syncthreads();
+    if (tid < 20) {
+        const int q = tid;
+        const double v = ((s_red[0][q] + s_red[1][q]) + s_red[2][q]) + s_red[3][q];
+        if (cost_block) { if (q == 19) out[0] = v; }
+        else if (q == 18) __hip_atomic_store(&hist[i], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        else if (q < 18) { const int d = q / 6, r = q - 6 * d; out[1 + P.N + (size_t)d * 6 * P.N + 6 * i + r] = v; }
     }
     if (cost_block && tid == 0) atomicAdd(&P.stats[0], (unsigned long long)(P.point_end - P.point_begin));
-}
-
-// gradT(j) = sum_{i > j} H[i]   ("for (j < i) gradT(j) += gdT", back_end_optimizer.hpp:642-645), fixed order
-__global__ void swept_suffix_kernel(int N, const double *hist, double *out) {
-    if (threadIdx.x == 0 && blockIdx.x == 0) {
-        double s = 0.0;
-        for (int j = N - 1; j >= 0; j--) {
-            out[1 + j] = s;
-            s += hist[j];
+    // last workgroup of the N piece blocks: suffix sums
+    __syncthreads();
+    if (tid == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        const unsigned long long t = cost_block ? 0ull : atomicAdd(&P.stats[6], 1ull);
+        s_last = (!cost_block && t == (unsigned long long)(P.N - 1)) ? 1 : 0;
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    }
+    __syncthreads();
+    if (s_last && tid == 0) {
+        double sfx = 0.0;
+        for (int j = P.N - 1; j >= 0; j--) {
+            out[1 + j] = sfx;
+            sfx += __hip_atomic_load(&hist[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
     }
 }
 
 void launch_swept_prepare(const SweptParams &P, hipStream_t stream) {
-    hipLaunchKernelGGL(swept_prepare_kernel, dim3(1), dim3(1024), 0, stream, P);
+    const size_t lds = traj_lds_bytes(P.N);
+    if (lds <= TRAJ_LDS_MAX) hipLaunchKernelGGL(swept_prepare_kernel<true>, dim3(1), dim3(1024), lds, stream, P);
+    else hipLaunchKernelGGL(swept_prepare_kernel<false>, dim3(1), dim3(1024), 0, stream, P);
 }
 void launch_swept_sweep(const SweptParams &P, hipStream_t stream, hipEvent_t ev_start, hipEvent_t ev_stop) {
     const int n = P.point_end - P.point_begin;
     if (n <= 0) return;
     const dim3 grid((n + SW_WAVES - 1) / SW_WAVES), block(64 * SW_WAVES);
-#define ISDF_SWEPT_CASE(K) case K: hipExtLaunchKernelGGL(swept_sweep_kernel<K>, grid, block, 0, stream, ev_start, ev_stop, 0, P); break;
+    const size_t lds = traj_lds_bytes(P.N);
+    const bool in_lds = lds <= TRAJ_LDS_MAX;
+#define ISDF_SWEPT_CASE(K) case K: if (in_lds) hipExtLaunchKernelGGL((swept_sweep_kernel<K, true>), grid, block, lds, stream, ev_start, ev_stop, 0, P); \
+                                   else hipExtLaunchKernelGGL((swept_sweep_kernel<K, false>), grid, block, 0, stream, ev_start, ev_stop, 0, P); break;
     switch (P.shape.kind) {
     // one instantiation per shape class (each inlines exactly one SDF formula; the run-time switch of the generic kernel costs
     // 272 VGPRs = one wave per SIMD)
@@ -437,15 +572,31 @@ void launch_swept_sweep(const SweptParams &P, hipStream_t stream, hipEvent_t ev_
     ISDF_SWEPT_CASE(ISDF_SHAPE_TWISTBOX) ISDF_SWEPT_CASE(ISDF_SHAPE_BENDBOX) ISDF_SWEPT_CASE(ISDF_SHAPE_TABLE)
     ISDF_SWEPT_CASE(ISDF_SHAPE_TREFOIL) ISDF_SWEPT_CASE(ISDF_SHAPE_SMOOTHDIFFERENCE) ISDF_SWEPT_CASE(ISDF_SHAPE_SMOOTHINTERSECTION)
     ISDF_SWEPT_CASE(ISDF_SHAPE_CSG) ISDF_SWEPT_CASE(ISDF_SHAPE_BOX) ISDF_SWEPT_CASE(ISDF_SHAPE_MESH)
-    default: hipExtLaunchKernelGGL(swept_sweep_kernel<-1>, grid, block, 0, stream, ev_start, ev_stop, 0, P); break;      // Ball
+    default: if (in_lds) hipExtLaunchKernelGGL((swept_sweep_kernel<-1, true>), grid, block, lds, stream, ev_start, ev_stop, 0, P);
+             else hipExtLaunchKernelGGL((swept_sweep_kernel<-1, false>), grid, block, 0, stream, ev_start, ev_stop, 0, P);
+             break;      // Ball
     }
 #undef ISDF_SWEPT_CASE
+}
+// the minimisers are given: replaces prepare + sweep (isdf_eval_swept_at_tstar)
+void launch_swept_fixed(const SweptParams &P, const double *tstar_in, hipStream_t stream) {
+    const int n = P.point_end - P.point_begin;
+    const dim3 grid((unsigned)((max(n, 1) + 63) / 64)), block(64);
+#define ISDF_FIXED_CASE(K) case K: hipLaunchKernelGGL(swept_fixed_kernel<K>, grid, block, 0, stream, P, tstar_in); break;
+    switch (P.shape.kind) {
+    ISDF_FIXED_CASE(ISDF_SHAPE_TORUS) ISDF_FIXED_CASE(ISDF_SHAPE_CAPPEDTORUS) ISDF_FIXED_CASE(ISDF_SHAPE_CAPPEDCONE)
+    ISDF_FIXED_CASE(ISDF_SHAPE_ROUNDEDCONE) ISDF_FIXED_CASE(ISDF_SHAPE_WIREFRAMEBOX) ISDF_FIXED_CASE(ISDF_SHAPE_BENDLINEAR)
+    ISDF_FIXED_CASE(ISDF_SHAPE_TWISTBOX) ISDF_FIXED_CASE(ISDF_SHAPE_BENDBOX) ISDF_FIXED_CASE(ISDF_SHAPE_TABLE)
+    ISDF_FIXED_CASE(ISDF_SHAPE_TREFOIL) ISDF_FIXED_CASE(ISDF_SHAPE_SMOOTHDIFFERENCE) ISDF_FIXED_CASE(ISDF_SHAPE_SMOOTHINTERSECTION)
+    ISDF_FIXED_CASE(ISDF_SHAPE_CSG) ISDF_FIXED_CASE(ISDF_SHAPE_BOX) ISDF_FIXED_CASE(ISDF_SHAPE_MESH)
+    default: hipLaunchKernelGGL(swept_fixed_kernel<-1>, grid, block, 0, stream, P, tstar_in); break;
+    }
+#undef ISDF_FIXED_CASE
 }
 void launch_swept_reduce(const SweptParams &P, double *out, hipStream_t stream) {
     const int n = P.point_end - P.point_begin;
     if (n > 0) hipLaunchKernelGGL(swept_backprop_kernel, dim3((n + 127) / 128), dim3(128), 0, stream, P);
     hipLaunchKernelGGL(swept_reduce_kernel, dim3(P.N + 1), dim3(256), 0, stream, P, out, P.hist);
-    hipLaunchKernelGGL(swept_suffix_kernel, dim3(1), dim3(64), 0, stream, P.N, P.hist, out);
 }
 
 } // namespace isdf

@@ -256,6 +256,27 @@ class Engine:
         self._check(self.lib.isdf_eval_device(self.h, n_traj, N, C.c_void_p(d_T), C.c_void_p(d_coeffs),
                                               C.c_void_p(d_out), C.c_void_p(d_tstar), C.c_void_p(stream)))
 
+    def eval_swept_at_tstar(self, N, d_T, d_coeffs, d_out, d_tstar, stream=0):
+        """The swept-volume sweep's back-prop at GIVEN minimisers (device pointers; a negative t* = no interval)."""
+        self._check(self.lib.isdf_eval_swept_at_tstar(self.h, N, C.c_void_p(d_T), C.c_void_p(d_coeffs), C.c_void_p(d_out),
+                                                      C.c_void_p(d_tstar), C.c_void_p(stream)))
+
+    def eval_swept_at_tstar_host(self, T, coeffs_colmajor, tstar):
+        """Host-array convenience around eval_swept_at_tstar (torch only carries the device buffers): returns
+        (cost, gradT, gradC) of the swept-volume sweep evaluated AT the given minimisers."""
+        import torch
+        dev = torch.device("cuda", self.cfg.device)
+        T = np.ascontiguousarray(T, dtype=np.float64); N = T.size
+        d_T = torch.from_numpy(T).to(dev)
+        d_C = torch.from_numpy(np.ascontiguousarray(coeffs_colmajor, dtype=np.float64).reshape(-1)).to(dev)
+        d_ts = torch.from_numpy(np.ascontiguousarray(tstar, dtype=np.float64)).to(dev)
+        d_out = torch.zeros(self.out_stride(N), dtype=torch.float64, device=dev)
+        st = torch.cuda.current_stream(dev).cuda_stream
+        self.eval_swept_at_tstar(N, d_T.data_ptr(), d_C.data_ptr(), d_out.data_ptr(), d_ts.data_ptr(), st)
+        torch.cuda.synchronize(dev)
+        o = d_out.cpu().numpy()
+        return float(o[0]), o[1:1 + N].copy(), o[1 + N:].copy()
+
     def out_stride(self, N):
         return int(self.lib.isdf_out_stride(N))
 

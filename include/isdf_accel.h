@@ -209,6 +209,14 @@ int isdf_eval(isdf_ctx *ctx, int n_traj, const int *N, const double *const *T,
 int isdf_eval_device(isdf_ctx *ctx, int n_traj, int N, const double *d_T, const double *d_coeffs,
                      double *d_out, double *d_tstar, void *stream);
 size_t isdf_out_stride(int N);   /* 1 + N + 18N */
+/* The swept-volume sweep with the minimisers GIVEN instead of searched for: obstacle point k is evaluated at time
+ * d_tstar[k] (M doubles on the device; a negative or NaN entry means "no time interval qualified": min sdf = 10, no penalty,
+ * sw_manager.hpp:717) - i.e. lines :578-646 of addSaftyPenaOnSweptVolumeParallel after getSDFofSweptVolume returned
+ * (getSDFAtTimeStamp sw_manager.hpp:550-556 + getGradPrelAtTimeStamp :566-572 at that time).  Same output as
+ * isdf_eval_device; the ctx's internal lastTstar takes the given values.  Use: re-evaluating cost / gradient at minimisers found elsewhere (the
+ * argmin over t is a chain of accept/reject comparisons; this entry point isolates the arithmetic behind it). */
+int isdf_eval_swept_at_tstar(isdf_ctx *ctx, int N, const double *d_T, const double *d_coeffs, double *d_out,
+                             const double *d_tstar, void *stream);
 
 /* ---- full objective callback ------------------------------------------------------------------------------ */
 /* TrajOptimizer::costFunctionLmbm (back_end_optimizer.hpp:358-430): x = [tau(N) | inner waypoints 3(N-1)] ->

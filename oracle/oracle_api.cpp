@@ -268,6 +268,45 @@ double orc_swept_sdf(void *h, int N, const double *T, const double *coeffs, cons
     return s;
 }
 
+// developer probe (tools/v1_trace.py): per interval of one point's swept-volume query, the number of sign-descent passes
+// (outer iterations of gradientDescent), the iteration counter it ends with, and how many passes accepted the FULL step
+// (div == 1) in the same direction as the pass before - the marching part of a descent.  out: 3 ints per interval.
+int orc_swept_trace(void *h, int N, const double *T, const double *coeffs, const double p[3], int cap, int *out) {
+    OrcCtx &c = *(OrcCtx *)h;
+    c.sync();
+    Traj tr; tr.N = N; tr.T = T; tr.C = coeffs;
+    c.sv.update_traj(tr);
+    const V3 P3(p[0], p[1], p[2]);
+    std::vector<double> rl, rr, rts;
+    c.sv.choice_t_init(P3, 0.02, rl, rr, rts);
+    const int n = (int)rl.size();
+    for (int i = 0; i < n && i < cap; i++) {
+        const double t_min = std::max(0.0, rl[i]), t_max = std::min(rr[i], c.sv.traj_duration);
+        double x = rts[i], prev_x = 10000000.0, fx = 0.0;
+        int iter = 0, passes = 0, march = 0, last_sgn = 0;
+        bool stop = false;
+        while (iter < 300 && !stop && std::fabs(x - prev_x) > 1e-5) {
+            if (iter == 0) fx = c.sv.sdf_at_time(P3, x);
+            const double g = c.sv.sdf_dot_at_time(P3, x);
+            const int sgn = (int)(g > 0) - (int)(g < 0);
+            double tau = 0.02;
+            prev_x = x;
+            passes++;
+            for (int div = 1; div < 10; div++) {
+                iter++;
+                double xc = std::max(std::min(x - tau * sgn, t_max), t_min);
+                const double fc = c.sv.sdf_at_time(P3, xc);
+                if ((fc - fx) < 0) { x = xc; fx = fc; if (div == 1 && sgn == last_sgn) march++; break; }
+                tau *= 0.5;
+                if (div == 9) stop = true;
+            }
+            last_sgn = sgn;
+        }
+        out[3 * i] = passes; out[3 * i + 1] = iter; out[3 * i + 2] = march;
+    }
+    return n;
+}
+
 // ---- MINCO (N1 "next" row; also the synthetic-trajectory generator of the tests) ----
 // head/tail: 3x3 column-major state matrices [pos vel acc] (Eigen::Matrix3d, col(0)=pos ...).
 // inPs: 3 x (N-1) column-major waypoints.  coeffs_out: 6N x 3 column-major.

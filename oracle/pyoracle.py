@@ -388,6 +388,23 @@ class RefWorld:
         self.M = pts.shape[0]
         self.lib.ref_world_set_points(self.h, _p(pts), pts.shape[0])
 
+    def set_mesh(self, V, F):
+        """The robot becomes the mesh Generalshape (Shape.cpp:105-151, extracted) over body-frame vertices V and faces F."""
+        V = np.ascontiguousarray(V, dtype=np.float64); F = np.ascontiguousarray(F, dtype=np.int32)
+        self.lib.ref_world_set_mesh(self.h, _p(V), V.shape[0], F.ctypes.data_as(C.c_void_p), F.shape[0])
+
+    def mesh_perturb(self, ulps):
+        """Sensitivity hook: the float solid angle of every winding-number query moves by `ulps` x 2^-23 (one ulp of an
+        order-one atan2f term; pseudo-random sign per query), i.e. w by ulps x 9.5e-9.  Process-wide for libref_sweeps.so;
+        0 switches it off."""
+        self.lib.ref_mesh_perturb(C.c_int(int(ulps)))
+
+    def shape_eval(self, pts):
+        pts = np.ascontiguousarray(pts, dtype=np.float64).reshape(-1, 3)
+        s = np.zeros(pts.shape[0]); g = np.zeros((pts.shape[0], 3))
+        self.lib.ref_world_shape_eval(self.h, _p(pts), pts.shape[0], _p(s), _p(g))
+        return s, g
+
     def sweep_swept(self, T, cm, tstar=None):
         T = np.ascontiguousarray(T, dtype=np.float64); cm = np.ascontiguousarray(cm, dtype=np.float64); N = T.size
         cost = np.zeros(1); gT = np.zeros(N); gC = np.zeros(18 * N)

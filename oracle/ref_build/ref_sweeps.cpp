@@ -36,6 +36,116 @@ void *operator new[](std::size_t n) { void *p = std::calloc(n ? n : 1, 1); if (!
 void operator delete[](void *p) noexcept { std::free(p); }
 void operator delete[](void *p, std::size_t) noexcept { std::free(p); }
 
+// ---------------------------------------------------------------- the mesh Generalshape (utils/src/Shape.cpp:105-151)
+// Generalshape's four SDF members are EXTRACTED from Shape.cpp into gen/shape_mesh.inc (the Makefile renames the class
+// qualifier to MeshGeneralshape, nothing else) and compiled against the two libigl calls they make:
+//   igl::fast_winding_number(fwn_bvh, 2.0, p, w)   the vendored HDK core (igl/FastWindingNumberForSoups.h, included from
+//                                                  /root/reference) behind the thin wrapper libigl 2.4.0 puts around it
+//                                                  (cast the query to float, w = computeSolidAngle(q, accuracy) / (4 pi));
+//   tree.squared_distance(V, F, p, i, c)           igl::AABB's exact closest point - exact geometry, here by exhaustive
+//                                                  search over the triangles (the library's .cpp is absent).
+// g_fwn_ulps != 0 (ref_mesh_perturb) moves the float solid angle by that many units of 2^-23 (one ulp of a float in [1, 2):
+// what ONE of the per-triangle atan2f terms, which are of order one, can differ by between two libm implementations), with a
+// pseudo-random sign per query - for the sensitivity test of the argmin-over-t chain.
+#include <igl/FastWindingNumberForSoups.h>
+namespace igl {
+unsigned int default_num_threads(unsigned int) { return 1; }
+static int g_fwn_ulps = 0;
+struct FastWindingNumberBVH {
+    FastWindingNumber::HDK_Sample::UT_SolidAngle<float, float> ut_solid_angle;
+    std::vector<FastWindingNumber::HDK_Sample::UT_Vector3T<float>> U;
+    std::vector<int> F;
+};
+inline void fast_winding_number(const FastWindingNumberBVH &bvh, const float accuracy_scale, const Eigen::RowVector3d &Q, Eigen::VectorXd &WN) {
+    FastWindingNumber::HDK_Sample::UT_Vector3T<float> Pt;
+    Pt[0] = Q(0); Pt[1] = Q(1); Pt[2] = Q(2);
+    float sa = bvh.ut_solid_angle.computeSolidAngle(Pt, accuracy_scale);
+    if (g_fwn_ulps) {
+        uint32_t hsh; float f0 = Pt[0] * 3.1f + Pt[1] * 5.3f + Pt[2] * 7.7f; std::memcpy(&hsh, &f0, 4);
+        hsh ^= hsh >> 13; hsh *= 0x9E3779B1u; hsh ^= hsh >> 15;
+        sa += ((hsh & 1u) ? 1.0f : -1.0f) * (float)g_fwn_ulps * 1.1920929e-07f;
+    }
+    WN(0) = sa / (4.0 * 3.1415926535897932384626433832795);
+}
+struct MeshTree {
+    // exact closest point on the triangle soup (igl::AABB::squared_distance returns the same point and distance)
+    double squared_distance(const Eigen::MatrixXd &V, const std::vector<int> &F, const Eigen::RowVector3d &p, int &idx, Eigen::RowVector3d &c) const {
+        double best = 1.7976931348623157e308;
+        const double P[3] = {p(0), p(1), p(2)};
+        for (size_t f = 0; f < F.size() / 3; f++) {
+            double a[3], b[3], cc[3];
+            for (int k = 0; k < 3; k++) { a[k] = V(F[3 * f], k); b[k] = V(F[3 * f + 1], k); cc[k] = V(F[3 * f + 2], k); }
+            // Ericson, Real-Time Collision Detection 5.1.5
+            double ab[3], ac[3], ap[3], q[3];
+            for (int k = 0; k < 3; k++) { ab[k] = b[k] - a[k]; ac[k] = cc[k] - a[k]; ap[k] = P[k] - a[k]; }
+            auto dot = [](const double *x, const double *y) { return x[0] * y[0] + x[1] * y[1] + x[2] * y[2]; };
+            const double d1 = dot(ab, ap), d2 = dot(ac, ap);
+            bool done = false;
+            if (d1 <= 0 && d2 <= 0) { for (int k = 0; k < 3; k++) q[k] = a[k]; done = true; }
+            double bp[3], cp[3], d3 = 0, d4 = 0, d5 = 0, d6 = 0;
+            if (!done) {
+                for (int k = 0; k < 3; k++) bp[k] = P[k] - b[k];
+                d3 = dot(ab, bp); d4 = dot(ac, bp);
+                if (d3 >= 0 && d4 <= d3) { for (int k = 0; k < 3; k++) q[k] = b[k]; done = true; }
+            }
+            if (!done) {
+                const double vc = d1 * d4 - d3 * d2;
+                if (vc <= 0 && d1 >= 0 && d3 <= 0) { const double v = d1 / (d1 - d3); for (int k = 0; k < 3; k++) q[k] = a[k] + v * ab[k]; done = true; }
+            }
+            if (!done) {
+                for (int k = 0; k < 3; k++) cp[k] = P[k] - cc[k];
+                d5 = dot(ab, cp); d6 = dot(ac, cp);
+                if (d6 >= 0 && d5 <= d6) { for (int k = 0; k < 3; k++) q[k] = cc[k]; done = true; }
+            }
+            if (!done) {
+                const double vb = d5 * d2 - d1 * d6;
+                if (vb <= 0 && d2 >= 0 && d6 <= 0) { const double w = d2 / (d2 - d6); for (int k = 0; k < 3; k++) q[k] = a[k] + w * ac[k]; done = true; }
+            }
+            if (!done) {
+                const double va = d3 * d6 - d5 * d4;
+                if (va <= 0 && (d4 - d3) >= 0 && (d5 - d6) >= 0) {
+                    const double w = (d4 - d3) / ((d4 - d3) + (d5 - d6));
+                    for (int k = 0; k < 3; k++) q[k] = b[k] + w * (cc[k] - b[k]);
+                    done = true;
+                }
+            }
+            if (!done) {
+                const double va = d3 * d6 - d5 * d4, vb = d5 * d2 - d1 * d6, vc = d1 * d4 - d3 * d2;
+                const double den = 1.0 / (va + vb + vc), v = vb * den, w = vc * den;
+                for (int k = 0; k < 3; k++) q[k] = a[k] + ab[k] * v + ac[k] * w;
+            }
+            const double d2q = (P[0] - q[0]) * (P[0] - q[0]) + (P[1] - q[1]) * (P[1] - q[1]) + (P[2] - q[2]) * (P[2] - q[2]);
+            if (d2q < best) { best = d2q; idx = (int)f; c = Eigen::RowVector3d(q[0], q[1], q[2]); }
+        }
+        return best;
+    }
+};
+}  // namespace igl
+namespace shape {
+class MeshGeneralshape : public Generalshape {
+public:
+    Eigen::MatrixXd V;
+    std::vector<int> F;
+    igl::MeshTree tree;
+    igl::FastWindingNumberBVH fwn_bvh;
+    MeshGeneralshape(const Config &c, const double *Vin, int nV, const int *Fin, int nF) : Generalshape(c, false) {
+        V.resize(nV, 3);
+        for (int i = 0; i < nV; i++) for (int k = 0; k < 3; k++) V(i, k) = Vin[3 * i + k];
+        F.assign(Fin, Fin + 3 * (size_t)nF);
+        // igl::fast_winding_number(V, F, 2, fwn_bvh) (Shape.cpp:86): vertices cast to float, order-2 expansion
+        fwn_bvh.U.resize(nV);
+        for (int i = 0; i < nV; i++) for (int k = 0; k < 3; k++) fwn_bvh.U[i][k] = (float)Vin[3 * i + k];
+        fwn_bvh.F = F;
+        fwn_bvh.ut_solid_angle.init(nF, fwn_bvh.F.data(), nV, fwn_bvh.U.data(), 2);
+    }
+    double getonlySDF(const Eigen::RowVector3d &pos_rel) override;
+    double getonlySDF(const Eigen::RowVector3d &pos_rel, const Eigen::Matrix3d &R_obj) override;
+    Eigen::Vector3d getonlyGrad1(const Eigen::RowVector3d &pos_rel) override;
+    double getSDFwithGrad1(const Eigen::RowVector3d &pos_rel, Eigen::Vector3d &grad) override;
+};
+#include "../_ref/gen/shape_mesh.inc"         // Shape.cpp:105-151
+}  // namespace shape
+
 // ---------------------------------------------------------------- GridMap3D (map_manager)
 class GridMap3D {
 public:
@@ -178,6 +288,25 @@ void *ref_world_create(const double *cfg, int K, int threads, const char *shape_
     return w;
 }
 void ref_world_destroy(void *h) { delete (World *)h; }
+// replaces the robot by the mesh Generalshape over (V, F) - vertices already in the body frame, i.e. after the constructor's
+// poly_params transform (Shape.cpp:36-49)
+void ref_world_set_mesh(void *h, const double *V, int nV, const int *F, int nF) {
+    World *w = (World *)h;
+    delete w->shape;
+    w->shape = new shape::MeshGeneralshape(w->conf, V, nV, F, nF);
+    w->sv.current_robot_shape = w->shape;
+}
+void ref_mesh_perturb(int ulps) { igl::g_fwn_ulps = ulps; }
+// the robot shape by itself: getonlySDF + getonlyGrad1 on n body-frame points
+void ref_world_shape_eval(void *h, const double *P, int n, double *sdf, double *grad) {
+    World *w = (World *)h;
+    for (int i = 0; i < n; i++) {
+        const Eigen::RowVector3d p(P[3 * i], P[3 * i + 1], P[3 * i + 2]);
+        sdf[i] = w->shape->getonlySDF(p);
+        const Eigen::Vector3d g = w->shape->getonlyGrad1(p);
+        for (int k = 0; k < 3; k++) grad[3 * i + k] = g(k);
+    }
+}
 
 // ---- front end: the reference's kernel generation, map kernel and checkKernelValue
 // fe: [kernel_size, kernel_max_roll, kernel_max_pitch, kernel_ang_res, front_end_safeh]; the shape is re-made with them

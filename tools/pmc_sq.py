@@ -3,7 +3,9 @@
 import sqlite3, sys
 cur = sqlite3.connect(sys.argv[1]).cursor()
 rows = cur.execute("select kernel_name, counter_name, count(*), avg(value) from counters_collection group by kernel_name, counter_name order by kernel_name, counter_name").fetchall()
-lines = ["# rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_SMEM SQ_WAVE_CYCLES SQ_ACTIVE_INST_ANY SQ_WAIT_ANY -- python bench.py --steps 20 --warmup 3 --no-cpu-baseline --lbfgs-iters 0",
+cmd = sys.argv[3] if len(sys.argv) > 3 else "python bench.py --steps 20 --warmup 3 --no-cpu-baseline --lbfgs-iters 0"
+ctrs = " ".join(sorted({r[1] for r in rows}))
+lines = [f"# rocprofv3 --kernel-trace --pmc {ctrs} -- {cmd}",
          "# per-dispatch means; SQ_WAVE_CYCLES / SQ_ACTIVE_INST_ANY / SQ_WAIT_ANY count quad-cycles (MI355X_MICROARCH.md)"]
 for k, c, n, a in rows:
     if "isdf::" in k:

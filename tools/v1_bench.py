@@ -27,6 +27,9 @@ for shape_name, shape in (("rounded cone", synth.bench_rounded_cone_shape()), ("
     torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / 20
     n, kms = eng.profile_read()
     out = d_out.cpu().numpy()
+    if "--no-oracle" in sys.argv:
+        print(f"V1 {shape_name:13s} M={M}: device {dt*1e3:7.3f} ms/step (sweep kernel {kms:7.3f} ms) = {M/dt:10.4g} points/s | stats {eng.stats()}", flush=True)
+        continue
     o = orc.Oracle(cfg1, threads=30); o.set_grid(occ, (0, 0, 0), res, capi.GRID_OCCUPANCY); o.set_shape(shape); o.set_points(pts)
     c0, gT0, gC0, st0 = o.eval(T, cm)
     t0 = time.perf_counter(); reps = 3
