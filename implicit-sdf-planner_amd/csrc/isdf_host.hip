@@ -158,7 +158,7 @@ extern "C" int isdf_destroy(isdf_ctx *c) {
     isdf_frontend_release(c);
     isdf_xchg_release(c);
     void *ptrs[] = {c->d_cb, c->d_esdf, c->d_occ, c->d_points, c->d_tstar, c->d_acc, c->d_sample_info, c->d_bits, c->d_piece_cost, c->d_in, c->d_out, c->d_stats,
-                    c->d_traj_duration, c->d_coarse_t, c->d_coarse_pose, c->d_n_coarse, c->d_point_partial, c->d_point_piece, c->d_hist, c->d_dbg};
+                    c->d_traj_duration, c->d_coarse_t, c->d_coarse_pose, c->d_n_coarse, c->d_point_partial, c->d_point_piece, c->d_point_stat, c->d_point_nr, c->d_task_buf, c->d_task_map, c->d_v1_words, c->d_hist, c->d_dbg};
     for (void *p : ptrs) if (p) (void)hipFree(p);
     free_mesh(c);
     if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -450,16 +450,44 @@ static int eval_device_impl(isdf_ctx *c, int n_traj, int N, const double *d_T, c
         if (c->point_cap < c->M) {
             if (c->d_point_partial) (void)hipFree(c->d_point_partial);
             if (c->d_point_piece) (void)hipFree(c->d_point_piece);
-            c->d_point_partial = nullptr; c->d_point_piece = nullptr; c->point_cap = 0;
+            if (c->d_point_stat) (void)hipFree(c->d_point_stat);
+            if (c->d_point_nr) (void)hipFree(c->d_point_nr);
+            if (c->d_task_buf) (void)hipFree(c->d_task_buf);
+            if (c->d_task_map) (void)hipFree(c->d_task_map);
+            c->d_point_partial = nullptr; c->d_point_piece = nullptr; c->d_point_stat = nullptr; c->point_cap = 0;
+            c->d_point_nr = nullptr; c->d_task_buf = nullptr; c->d_task_map = nullptr;
             HIPCHK(c, hipMalloc(&c->d_point_partial, (size_t)c->M * PARTIAL_STRIDE * sizeof(double)));
             HIPCHK(c, hipMalloc(&c->d_point_piece, (size_t)c->M * sizeof(int)));
+            HIPCHK(c, hipMalloc(&c->d_point_stat, (size_t)c->M * sizeof(unsigned long long)));
+            HIPCHK(c, hipMalloc(&c->d_point_nr, (size_t)c->M * sizeof(int)));
+            HIPCHK(c, hipMalloc(&c->d_task_buf, (size_t)c->M * 32 * 6 * sizeof(double)));       // SW_MAX_RANGES x TASK_STRIDE per point
+            HIPCHK(c, hipMalloc(&c->d_task_map, (size_t)c->M * 32 * sizeof(unsigned)));
+            if (!c->d_v1_words) {
+                HIPCHK(c, hipMalloc(&c->d_v1_words, 4 * sizeof(unsigned)));
+                HIPCHK(c, hipMemset(c->d_v1_words, 0, 4 * sizeof(unsigned)));
+            }
             c->point_cap = c->M;
         }
         P.coarse_t = c->d_coarse_t; P.coarse_pose = c->d_coarse_pose; P.n_coarse = c->d_n_coarse;
-        P.point_partial = c->d_point_partial; P.point_piece = c->d_point_piece;
+        P.point_partial = c->d_point_partial; P.point_piece = c->d_point_piece; P.point_stat = c->d_point_stat;
+        P.point_nr = c->d_point_nr; P.task_buf = c->d_task_buf; P.task_map = c->d_task_map; P.words = c->d_v1_words;
+        P.direct_records = fixed_tstar ? 1 : 0;
         { int rc2 = ensure(c, &c->d_hist, &c->hist_cap, (size_t)N); if (rc2) return rc2; }
         P.hist = c->d_hist;
         P.stats = c->d_stats;
+        P.dbg = nullptr;
+        if (const char *e = getenv("ISDF_DEBUG_TIMING")) if (e[0] == '1') {
+            const size_t need = (size_t)c->M * 4 + (size_t)(N + 1) * 8;
+            if (c->dbg_cap < need) {
+                if (c->d_dbg) (void)hipFree(c->d_dbg);
+                c->d_dbg = nullptr; c->dbg_cap = 0;
+                HIPCHK(c, hipMalloc(&c->d_dbg, need * sizeof(unsigned long long)));
+                c->dbg_cap = need;
+            }
+            HIPCHK(c, hipMemsetAsync(c->d_dbg, 0, need * sizeof(unsigned long long), st));
+            c->dbg_used = need;
+            P.dbg = c->d_dbg;
+        }
         if (fixed_tstar) {               // the minimisers are given (isdf_eval_swept_at_tstar): no search
             launch_swept_fixed(P, d_tstar, st);
             launch_swept_reduce(P, d_out, st);

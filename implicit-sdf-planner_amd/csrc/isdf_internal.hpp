@@ -84,7 +84,14 @@ struct SweptParams {
     int max_coarse;
     double *point_partial;      // [M][PARTIAL_STRIDE] (gdC 18, gdT, pena)
     int *point_piece;           // [M]
+    int *point_nr;              // [M] scan kernel: intervals | scan passes << 8
+    double *task_buf;           // [M][32][6] per (point, interval): in (lb, ub, seed), out (t, sdf, gradient, counters)
+    unsigned *task_map;         // [<= 32 M] task list of the descent kernel: point (relative to point_begin) << 5 | interval
+    unsigned *words;            // [0] number of tasks  [1] scan ticket
+    int direct_records;         // 1: the records in point_partial were written by the fixed-t* kernel (no task slots)
+    unsigned long long *point_stat;   // [M] active | intervals << 1 | passes << 9 | descent iterations << 25 (statistics)
     double *hist;               // [N] per-piece sum of gdT
+    unsigned long long *dbg;    // developer timing buffer (ISDF_DEBUG_TIMING=1): 4 words per point, null on the product path
     unsigned long long *stats;  // [0]=units [2]=intervals [3]=active points [4]=overflow [5]=descent iterations [6]=reduce ticket [7]=passes
 };
 void launch_swept_prepare(const SweptParams &P, hipStream_t stream);

@@ -4,14 +4,16 @@
 //   (getSDFofSweptVolume :710-747, choiceTInit :367-445, gradientDescent :1000-1062,
 //    getSDF_DOTAtTimeStampOptimized :593-662, getStateOnTrajStamp :332-341).
 //
-// One optimizer step = four launches (prepare, sweep, back-prop, reduce):
+// One optimizer step = five launches (prepare, scan, descent, back-prop, reduce):
 //   swept_prepare_kernel  one block: the "traj_duration" state (refreshed only when the total is < 300 s, :287-296),
 //                         the coarse time table t += 0.2 by repeated fp64 addition (one lane, like the reference loop),
 //                         then the pose (position + rotation) at every coarse time, shared by all obstacle points.
-//   swept_sweep_kernel    one WAVEFRONT per obstacle point; the trajectory (durations + 6N x 3 coefficients, 152 B per
-//                         piece) is staged ONCE per workgroup into LDS - every pose evaluation of every pass reads it from
-//                         there (the rocprofv3 counters of the first version showed 64 % of the wave cycles parked in
-//                         s_waitcnt on the global trajectory table, profiles/r2a_v1_pmc_sq.txt):
+//   swept_scan_kernel     one WAVEFRONT per obstacle point, swept_descent_kernel one per (point, time interval): a point
+//                         whose trajectory passes it several times used to run its descents one after the other (31
+//                         dependent passes against 13 for the longest single interval), and the launch lasts as long as its
+//                         longest wavefront.  The trajectory (durations + 6N x 3 coefficients, 152 B per piece) is staged
+//                         ONCE per workgroup into LDS - every pose evaluation of every pass reads it from there (the first
+//                         version spent 64 % of its wave cycles in s_waitcnt on the global table, profiles/r2a_v1_pmc_sq.txt):
 //                           coarse scan   lanes = coarse times (table poses), ballot -> maximal in-range runs
 //                                         (intervals; a run still open at the end is dropped, quirk q2);
 //                           fine scan     lanes = 0.02 s steps of one interval (each lane accumulates its own t by
@@ -35,7 +37,9 @@
 namespace isdf {
 
 constexpr int SW_WAVES = 4;
-constexpr int SW_MAX_RANGES = 32;
+constexpr int SW_MAX_RANGES = 32;                // intervals kept per point (more set the overflow flag); 5 bits of a task word
+constexpr int TASK_STRIDE = 6;                   // doubles per (point, interval) slot: in (lb, ub, seed) / out (t, sdf, grad(3), counters)
+constexpr int SCAN_PER = 16;                     // points per thread and round in the task-list scan
 
 // The trajectory as the kernels of this file see it: durations T[0..N) (LDS copies are padded to a multiple of 4 with a
 // huge value, which no time exceeds) and the 6N x 3 column-major coefficients.
@@ -114,10 +118,12 @@ __global__ __launch_bounds__(1024) void swept_prepare_kernel(const SweptParams P
     for (int k = threadIdx.x; k < n; k += blockDim.x) {
         d3 x; m3 R;
         pose_at(P, tr, P.coarse_t[k], x, R);
-        double *o = P.coarse_pose + (size_t)k * 12;
-        o[0] = x.x; o[1] = x.y; o[2] = x.z;
+        // component-major: the scan's lanes (consecutive coarse times) read consecutive doubles
+        double *o = P.coarse_pose + k;
+        const size_t st = (size_t)P.max_coarse;
+        o[0] = x.x; o[st] = x.y; o[2 * st] = x.z;
 #pragma unroll
-        for (int q = 0; q < 9; q++) o[3 + q] = R.a[q];
+        for (int q = 0; q < 9; q++) o[(3 + q) * st] = R.a[q];
     }
 }
 
@@ -131,32 +137,78 @@ __device__ __forceinline__ double wave_first_min(double v, int lane, int n, int 
     return m;
 }
 
-// lanes of one sign-descent pass (PH_GD):
-//   0-8    candidates x - tau_k        9-17  candidates x + tau_k          (tau_k = 0.02 / 2^k)
-//   18     pose at x (f(x), body-frame point velocity)      19-24  gradient samples at x
-//   block m = 1..5, base 25 + 7 (m - 1):  base = pose at y_m, base+1..base+6 = gradient samples at y_m
-//   60     f(y_6)
-// with y_0 = x, y_(m+1) = clamp(y_m - 0.02 s): the next full steps in the direction s of the previous pass.
-constexpr int GD_SPEC = 5;                       // look-ahead blocks
-__device__ __forceinline__ int gd_block_base(int m) { return m == 0 ? 18 : 25 + 7 * (m - 1); }
-
+// ---- the ONE pose + SDF evaluation both kernels below are built around: pose at `te`, body-frame point (perturbed for a
+// gradient sample), shape SDF; pose lanes also form the body-frame point velocity (getSDF_DOTAtTimeStampOptimized :593-662)
 template <int KIND, bool LDS>
-__global__ __launch_bounds__(64 * SW_WAVES) void swept_sweep_kernel(const SweptParams P) {
+__device__ __forceinline__ void eval_lane(const SweptParams &P, const TrajL<LDS> &tr, const d3 p, const double te, const int pert,
+                                          const bool pose_lane, const bool own_grad, double &val, d3 &pvel, d3 &g_direct) {
+    double tl = te;
+    const int pi = traj_locate_l(tr, tl);
+    d3 xt, vt, at, jt;
+    traj_eval_l(tr, pi, tl, xt, vt, at, jt);
+    FlatS fs;
+    flat_core(P.flat, vt, at, fs);
+    const m3 R = quat_to_rot(flat_quat(fs));
+    d3 pr = mat_tmul(R, p - xt);
+    if (pose_lane) {
+        FlatS2 ft;
+        flat_core2(P.flat, vt, at, jt, fs, ft);
+        const d3 omg = flat_omg(fs, ft);
+        const d3 wx = mk3(0 * pr.x + (-omg.z) * pr.y + omg.y * pr.z, omg.z * pr.x + 0 * pr.y + (-omg.x) * pr.z,
+                          (-omg.y) * pr.x + omg.x * pr.y + 0 * pr.z);
+        const d3 rv = mat_tmul(R, vt);
+        pvel = mk3(-(rv.x + wx.x), -(rv.y + wx.y), -(rv.z + wx.z));
+        if constexpr (KIND != ISDF_SHAPE_MESH) if (own_grad) g_direct = shape_grad<KIND>(P.shape, pr);     // Ball: own gradient
+    }
+    if (pert >= 1 && pert <= 6) {            // temp(a) -= dx; [temp(a) += 2 dx]  (Shape.hpp:36-54)
+        const int a = (pert - 1) >> 1;
+        const double dx = 0.000005;
+        double c = a == 0 ? pr.x : (a == 1 ? pr.y : pr.z);
+        c = c - dx;
+        if ((pert - 1) & 1) c = c + 2 * dx;
+        if (a == 0) pr.x = c; else if (a == 1) pr.y = c; else pr.z = c;
+    } else if (pert >= 7) {                  // Box::getonlyGrad1: forward difference, dx = 0.01 (Shape.hpp:2363-2377)
+        const int a = pert - 7;
+        if (a == 0) pr.x += 0.01; else if (a == 1) pr.y += 0.01; else pr.z += 0.01;
+    }
+    if constexpr (KIND == ISDF_SHAPE_MESH) {
+        // one hierarchy query per lane gives value AND gradient (the pose lanes keep the gradient)
+        d3 gq;
+        val = mesh_sdf_grad(P.shape.mesh, pr, gq);
+        if (pose_lane) g_direct = gq;
+    } else {
+        val = shape_sdf<KIND>(P.shape, pr);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// swept_scan_kernel: one wavefront per obstacle point - choiceTInit (:367-445)
+// ---------------------------------------------------------------------------------------------------------------
+// coarse scan (lanes = coarse times, table poses) -> maximal in-range runs; then the fine scans of the runs, one after the
+// other because the running minimum and the seed are carried ACROSS runs (quirk q1).  Leaves, per point, the number of
+// intervals and per interval (lb, ub, seed) in the point's task slots.  The workgroup that finishes last turns the interval
+// counts into the task list of the descent kernel (exclusive scan in point order: deterministic).
+template <int KIND, bool LDS>
+__global__ __launch_bounds__(64 * SW_WAVES) void swept_scan_kernel(const SweptParams P) {
     extern __shared__ double s_dyn[];
     __shared__ double s_rl[SW_WAVES][SW_MAX_RANGES], s_rr[SW_WAVES][SW_MAX_RANGES];
+    __shared__ int s_w[SW_WAVES], s_last;
+    const unsigned long long dbg_t0 = P.dbg ? wall_clock64() : 0ull;
     TrajL<LDS> tr{P.T, P.coeffs, P.N};
     if constexpr (LDS) tr = traj_stage(s_dyn, P.T, P.coeffs, P.N);
-    const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int pt = P.point_begin + blockIdx.x * SW_WAVES + wave;
-    if (pt >= P.point_end) return;
+    if (pt < P.point_end) {
+    unsigned long long *const dbg = P.dbg ? P.dbg + (size_t)pt * 4 : nullptr;
+    if (dbg && lane == 0) { dbg[0] = dbg_t0; dbg[1] = wall_clock64(); }
     const d3 p = mk3(P.points[3 * pt], P.points[3 * pt + 1], P.points[3 * pt + 2]);
     const double D = *P.traj_duration;
     const int n_coarse = *P.n_coarse;
     const double rough_dt = 0.2, dt = 0.02;
     const double inf = 2 * P.safety_hor + 0.1;
 
-    // ---------------- coarse scan -> intervals (choiceTInit :392-421) ----------------
+    // ---------------- coarse scan -> intervals (:392-421) ----------------
     int n_ranges = 0;
     bool in_range = false;
     double tou_lb = 0.0, range_mindis = 1e9;
@@ -164,11 +216,12 @@ __global__ __launch_bounds__(64 * SW_WAVES) void swept_sweep_kernel(const SweptP
         const int k = base + lane;
         double dis = 1e9;
         if (k < n_coarse) {
-            const double *o = P.coarse_pose + (size_t)k * 12;
+            const double *o = P.coarse_pose + k;          // component-major table: coalesced across the lanes
+            const size_t st = (size_t)P.max_coarse;
             m3 R;
 #pragma unroll
-            for (int q = 0; q < 9; q++) R.a[q] = o[3 + q];
-            const d3 pr = mat_tmul(R, p - mk3(o[0], o[1], o[2]));
+            for (int q = 0; q < 9; q++) R.a[q] = o[(3 + q) * st];
+            const d3 pr = mat_tmul(R, p - mk3(o[0], o[st], o[2 * st]));
             if constexpr (KIND == ISDF_SHAPE_MESH) {
                 // the scan only asks "dis < inf?" (and keeps dis where the answer is yes): far samples are rejected by the
                 // hierarchy's distance cutoff without a full query
@@ -209,63 +262,133 @@ __global__ __launch_bounds__(64 * SW_WAVES) void swept_sweep_kernel(const SweptP
         }
     }
     n_ranges = min(n_ranges, SW_MAX_RANGES);
+    if (dbg && lane == 0) dbg[2] = wall_clock64();
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 
-    // ---------------- per interval: fine scan (:423-438) then sign descent (:729-745, :1000-1062) ----------------
-    // One loop, ONE pose + SDF evaluation site; what the lanes evaluate depends on the phase:
-    //   FINE   lanes = 0.02 s steps of the interval (each lane accumulates its own t by repeated addition)
-    //   GD     one pass of the sign descent, lanes as listed above gd_block_base
-    //   GRAD   lanes 18-24 only: shape gradient at the final x of the interval when the last step moved x
-    enum { PH_FINE = 0, PH_GD = 1, PH_GRAD = 2, PH_NEXT = 3, PH_END = 4 };
+    // ---------------- fine scans (:423-438): lanes = 0.02 s steps, each accumulating its own t by repeated addition
+    double range_time_seed = 0.0;
+    int n_pass = 0;
+    double *const slots = P.task_buf + (size_t)(pt - P.point_begin) * SW_MAX_RANGES * TASK_STRIDE;
+    for (int r = 0; r < n_ranges; r++) {
+        const double lb = s_rl[wave][r], ub = s_rr[wave][r];
+        double t_base = lb;
+        for (int guard = 0; guard < (1 << 20); guard++) {
+            double te = t_base;
+            for (int q = 0; q < 63; q++) if (q < lane) te += dt;
+            const bool act = te < ub;
+            if (!__ballot(act)) break;          // nothing (left) to scan in this interval
+            double val = 1e300;
+            d3 pv_unused = mk3(0, 0, 0), g_unused = pv_unused;
+            if (act) eval_lane<KIND, LDS>(P, tr, p, te, 0, false, false, val, pv_unused, g_unused);
+            n_pass++;
+            const int nv = __popcll(__ballot(act));                  // valid lanes form a prefix (t is increasing)
+            int arg;
+            const double m = wave_first_min(val, lane, nv, arg);
+            if (arg >= 0 && m < range_mindis) { range_mindis = m; range_time_seed = __shfl(te, arg, 64); }
+            if (nv < 64) break;
+            t_base = __shfl(te, 63, 64) + dt;
+        }
+        if (lane == 0) { double *o = slots + (size_t)r * TASK_STRIDE; o[0] = lb; o[1] = ub; o[2] = range_time_seed; }
+    }
+    if (lane == 0) {
+        P.point_nr[pt] = n_ranges | (n_pass << 8);
+        if (dbg) dbg[3] = (wall_clock64() << 16) | (unsigned long long)(n_pass & 0xFFF) | ((unsigned long long)(n_ranges & 0xF) << 12);
+    }
+    }   // pt < point_end
+
+    // ---------------- the last workgroup builds the task list: exclusive scan of the interval counts in point order
+    __syncthreads();
+    if (tid == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        const unsigned t = atomicAdd(&P.words[1], 1u);
+        s_last = t == gridDim.x - 1 ? 1 : 0;
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    }
+    __syncthreads();
+    if (!s_last) return;
+    const int n = P.point_end - P.point_begin;
+    int running = 0;
+    for (int sb = 0; sb < n; sb += 256 * SCAN_PER) {
+        const int p0 = sb + tid * SCAN_PER;
+        int v[SCAN_PER], local = 0;
+#pragma unroll
+        for (int k = 0; k < SCAN_PER; k++) {
+            v[k] = p0 + k < n ? (P.point_nr[P.point_begin + p0 + k] & 0xFF) : 0;      // plain loads: the acquire fence above made the other workgroups' stores visible
+            local += v[k];
+        }
+        int incl = local;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) { const int up = __shfl_up(incl, off, 64); if (lane >= off) incl += up; }
+        if (lane == 63) s_w[wave] = incl;
+        __syncthreads();
+        int wbase = 0, tile = 0;
+#pragma unroll
+        for (int w = 0; w < SW_WAVES; w++) { if (w < wave) wbase += s_w[w]; tile += s_w[w]; }
+        int off = running + wbase + incl - local;
+#pragma unroll
+        for (int k = 0; k < SCAN_PER; k++)
+            if (p0 + k < n) {
+                for (int r = 0; r < v[k]; r++) P.task_map[off + r] = ((unsigned)(p0 + k) << 5) | (unsigned)r;
+                off += v[k];
+            }
+        running += tile;
+        __syncthreads();
+    }
+    if (tid == 0) { P.words[0] = (unsigned)running; P.words[1] = 0u; }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// swept_descent_kernel: one wavefront per (point, interval) - gradientDescent (:1000-1062) from the interval's seed
+// ---------------------------------------------------------------------------------------------------------------
+// lanes of one sign-descent pass:
+//   0-8    candidates x - tau_k        9-17  candidates x + tau_k          (tau_k = 0.02 / 2^k)
+//   18     pose at x (f(x), body-frame point velocity)      19-24  gradient samples at x
+//   block m = 1..5, base 25 + 7 (m - 1):  base = pose at y_m, base+1..base+6 = gradient samples at y_m
+//   60     f(y_6)
+// with y_0 = x, y_(m+1) = clamp(y_m - 0.02 s): the next full steps in the direction s of the previous pass.
+constexpr int GD_SPEC = 5;                       // look-ahead blocks
+__device__ __forceinline__ int gd_block_base(int m) { return m == 0 ? 18 : 25 + 7 * (m - 1); }
+
+template <int KIND, bool LDS>
+__global__ __launch_bounds__(64 * SW_WAVES) void swept_descent_kernel(const SweptParams P) {
+    extern __shared__ double s_dyn[];
+    TrajL<LDS> tr{P.T, P.coeffs, P.N};
+    if constexpr (LDS) tr = traj_stage(s_dyn, P.T, P.coeffs, P.N);
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const unsigned n_tasks = P.words[0];
+    const unsigned n_waves = gridDim.x * SW_WAVES;
+    const double D = *P.traj_duration;
     const int gmode = P.shape.grad_mode;
     const bool fd_central = (KIND != ISDF_SHAPE_MESH) && gmode == ISDF_GRAD_CENTRAL;
     const bool fd_forward = (KIND != ISDF_SHAPE_MESH) && gmode == ISDF_GRAD_BOX_FORWARD;
-    // this lane's role in a GD / GRAD pass: block (0..6) and offset inside it (0 = the pose lane)
+    const bool own_grad = !fd_central && !fd_forward;
+    // this lane's role in a pass: block (0..6) and offset inside it (0 = the pose lane)
     const int gd_blk = lane < 18 ? -1 : (lane < 25 ? 0 : (lane < 60 ? (lane - 25) / 7 + 1 : (lane == 60 ? GD_SPEC + 1 : -1)));
     const int gd_off = lane < 18 ? 0 : (lane < 25 ? lane - 18 : (lane < 60 ? (lane - 25) % 7 : 0));
-    double range_time_seed = 0.0;
-    double min_sdf_star = 1e1, t_star_best = 0.0;
-    d3 grad_prel = mk3(0, 0, 0);
-    bool have = false;
-    unsigned n_iters_total = 0, n_passes = 0;
-    int r = 0, phase = n_ranges > 0 ? PH_FINE : PH_END;
-    double lb = 0.0, ub = 0.0, t_base = 0.0, t_min = 0.0, t_max = 0.0;
-    double x = 0.0, fx = 0.0, prev_x = 0.0;
-    d3 g1_at_x = mk3(0, 0, 0);                 // shape gradient at the current x (valid when g1_fresh)
-    bool g1_fresh = false;
-    int iter = 0;
-    int s_spec = 0;                            // direction of the look-ahead blocks (0: none)
-    if (phase == PH_FINE) { lb = s_rl[wave][0]; ub = s_rr[wave][0]; t_base = lb; }
-    while (phase != PH_END) {
-        if (phase == PH_NEXT) {
-            // interval r finished at (x, fx): keep the best (:739-744), move on
-            n_iters_total += (unsigned)iter;
-            if (fx < min_sdf_star) { min_sdf_star = fx; t_star_best = x; have = true; grad_prel = g1_at_x; }
-            r++;
-            if (r >= n_ranges) { phase = PH_END; break; }
-            lb = s_rl[wave][r]; ub = s_rr[wave][r]; t_base = lb;
-            phase = PH_FINE;
-            continue;
-        }
-        // ---- what this lane evaluates
-        double te = 0.0;
-        int pert = 0;                 // 0: the body-frame point itself; 1..6: central-difference sample; 7..9: forward difference
-        bool act = false, pose_lane = false;
-        if (phase == PH_FINE) {
-            te = t_base;
-            for (int q = 0; q < 63; q++) if (q < lane) te += dt;     // each lane's own accumulated time
-            act = te < ub;
-            if (!__ballot(act)) {     // nothing (left) to scan in this interval: descend from the seed
-                x = range_time_seed; prev_x = 10000000.0; iter = 0; g1_fresh = false; s_spec = 0;
-                t_min = fmax(0.0, lb); t_max = fmin(ub, D);
-                phase = PH_GD;
-                continue;
-            }
-        } else {
+    for (unsigned task = blockIdx.x * SW_WAVES + wave, rounds = 0; task < n_tasks && rounds < (1u << 16); task += n_waves, rounds++) {
+        const unsigned tm = P.task_map[task];
+        const int rel = (int)(tm >> 5), r = (int)(tm & 31u);
+        const int pt = P.point_begin + rel;
+        double *const slot = P.task_buf + ((size_t)rel * SW_MAX_RANGES + r) * TASK_STRIDE;
+        const d3 p = mk3(P.points[3 * pt], P.points[3 * pt + 1], P.points[3 * pt + 2]);
+        const double lb = slot[0], ub = slot[1];
+        const double t_min = fmax(0.0, lb), t_max = fmin(ub, D);
+        double x = slot[2], fx = 0.0, prev_x = 10000000.0;
+        d3 g1_at_x = mk3(0, 0, 0);                 // shape gradient at the current x (valid when g1_fresh)
+        bool g1_fresh = false;
+        int iter = 0, n_pass = 0;
+        int s_spec = 0;                            // direction of the look-ahead blocks (0: none)
+        bool grad_only = false;                    // final pass: lanes 18-24 only, the gradient at the final x
+        for (int guard = 0; guard < 4096; guard++) {
+            // ---- what this lane evaluates
+            double te = 0.0;
+            int pert = 0;                 // 0: the body-frame point itself; 1..6: central-difference sample; 7..9: forward difference
+            bool act = false, pose_lane = false;
             if (lane < 18) {
-                if (phase == PH_GD) {
+                if (!grad_only) {
                     double tau = 0.02;
                     const int k = lane < 9 ? lane : lane - 9;
                     for (int q = 0; q < 8; q++) if (q < k) tau = 0.5 * tau;
@@ -273,7 +396,7 @@ __global__ __launch_bounds__(64 * SW_WAVES) void swept_sweep_kernel(const SweptP
                     te = fmax(fmin(te, t_max), t_min);
                     act = true;
                 }
-            } else if (gd_blk == 0 || (gd_blk > 0 && phase == PH_GD && s_spec != 0)) {
+            } else if (gd_blk == 0 || (gd_blk > 0 && !grad_only && s_spec != 0)) {
                 // y_blk: gd_blk full steps from x in the direction s_spec, clamped like every candidate (:1046-1047)
                 te = x;
                 for (int q = 0; q < GD_SPEC + 1; q++) if (q < gd_blk) te = fmax(fmin(te - 0.02 * s_spec, t_max), t_min);
@@ -281,142 +404,85 @@ __global__ __launch_bounds__(64 * SW_WAVES) void swept_sweep_kernel(const SweptP
                 else if (fd_central) { pert = gd_off; act = true; }
                 else if (fd_forward && gd_off <= 3) { pert = gd_off + 6; act = true; }
             }
-        }
-        // ---- the evaluation: pose at te, body-frame point, shape SDF (one code instance)
-        double val = 1e300;
-        d3 pvel = mk3(0, 0, 0), g_direct = mk3(0, 0, 0);
-        if (act) {
-            double tl = te;
-            const int pi = traj_locate_l(tr, tl);
-            d3 xt, vt, at, jt;
-            traj_eval_l(tr, pi, tl, xt, vt, at, jt);
-            FlatS fs;
-            flat_core(P.flat, vt, at, fs);
-            const m3 R = quat_to_rot(flat_quat(fs));
-            d3 pr = mat_tmul(R, p - xt);
-            if (pose_lane) {
-                // d/dt of the body-frame point: -(R^T v + omega x p_rel) (getSDF_DOTAtTimeStampOptimized :593-662)
-                FlatS2 ft;
-                flat_core2(P.flat, vt, at, jt, fs, ft);
-                const d3 omg = flat_omg(fs, ft);
-                const d3 wx = mk3(0 * pr.x + (-omg.z) * pr.y + omg.y * pr.z, omg.z * pr.x + 0 * pr.y + (-omg.x) * pr.z,
-                                  (-omg.y) * pr.x + omg.x * pr.y + 0 * pr.z);
-                const d3 rv = mat_tmul(R, vt);
-                pvel = mk3(-(rv.x + wx.x), -(rv.y + wx.y), -(rv.z + wx.z));
-                if constexpr (KIND != ISDF_SHAPE_MESH) if (!fd_central && !fd_forward) g_direct = shape_grad<KIND>(P.shape, pr);     // Ball: own gradient
-            }
-            if (pert >= 1 && pert <= 6) {            // temp(a) -= dx; [temp(a) += 2 dx]  (Shape.hpp:36-54)
-                const int a = (pert - 1) >> 1;
-                const double dx = 0.000005;
-                double c = a == 0 ? pr.x : (a == 1 ? pr.y : pr.z);
-                c = c - dx;
-                if ((pert - 1) & 1) c = c + 2 * dx;
-                if (a == 0) pr.x = c; else if (a == 1) pr.y = c; else pr.z = c;
-            } else if (pert >= 7) {                  // Box::getonlyGrad1: forward difference, dx = 0.01 (Shape.hpp:2363-2377)
-                const int a = pert - 7;
-                if (a == 0) pr.x += 0.01; else if (a == 1) pr.y += 0.01; else pr.z += 0.01;
-            }
-            if constexpr (KIND == ISDF_SHAPE_MESH) {
-                // one hierarchy query per lane gives value AND gradient (the pose lanes keep the gradient): no second,
-                // divergent query for the lane that needs both
-                d3 gq;
-                val = mesh_sdf_grad(P.shape.mesh, pr, gq);
-                if (pose_lane) g_direct = gq;
-            } else {
-                val = shape_sdf<KIND>(P.shape, pr);
-            }
-        }
-        n_passes++;
-        // ---- consume
-        if (phase == PH_FINE) {
-            const int nv = __popcll(__ballot(act));                  // valid lanes form a prefix (t is increasing)
-            int arg;
-            const double m = wave_first_min(val, lane, nv, arg);
-            if (arg >= 0 && m < range_mindis) { range_mindis = m; range_time_seed = __shfl(te, arg, 64); }
-            if (nv < 64) {
-                x = range_time_seed; prev_x = 10000000.0; iter = 0; g1_fresh = false; s_spec = 0;
-                t_min = fmax(0.0, lb); t_max = fmin(ub, D);
-                phase = PH_GD;
-            } else t_base = __shfl(te, 63, 64) + dt;
-            continue;
-        }
-        // shape gradient at the pose of block `base` from its samples (getonlyGrad1)
-        auto grad_of = [&](int base) -> d3 {
-            if (fd_central) {
-                const double dx = 0.000005;
-                const double gx = rlane(val, base + 2) - rlane(val, base + 1), gy = rlane(val, base + 4) - rlane(val, base + 3),
-                             gz = rlane(val, base + 6) - rlane(val, base + 5);
-                return normalized3(mk3(gx / (2 * dx), gy / (2 * dx), gz / (2 * dx)));
-            } else if (fd_forward) {
-                const double s0 = rlane(val, base), dx = 0.01;
-                return mk3((rlane(val, base + 1) - s0) / dx, (rlane(val, base + 2) - s0) / dx, (rlane(val, base + 3) - s0) / dx);
-            }
-            return mk3(rlane(g_direct.x, base), rlane(g_direct.y, base), rlane(g_direct.z, base));
-        };
-        g1_at_x = grad_of(18); g1_fresh = true;
-        if (phase == PH_GRAD) { phase = PH_NEXT; continue; }
-        // sign-descent iterations (gradientDescent :1000-1062): the one at x in full, then - while every step is the
-        // full step in the direction the look-ahead blocks were laid out for - the ones at y_1, y_2, ...
-        if (iter == 0) fx = rlane(val, 18);
-        bool finished = false;
-        int spec_next = 0;
-        for (int m = 0;; m++) {
-            const int base = gd_block_base(m);
-            const d3 g1 = m == 0 ? g1_at_x : grad_of(base);
-            if (m > 0) { g1_at_x = g1; g1_fresh = true; }
-            const d3 pv = mk3(rlane(pvel.x, base), rlane(pvel.y, base), rlane(pvel.z, base));
-            const double g = dot3(g1, pv);
-            const int sgn = (int)(g > 0) - (int)(g < 0);
-            spec_next = 0;
-            if (m == 0) {
-                prev_x = x;
-                const bool in_set = sgn > 0 ? (lane < 9) : (sgn < 0 ? (lane >= 9 && lane < 18) : false);
-                const unsigned long long accm = __ballot(in_set && ((val - fx) < 0));
-                bool stop = false, full = false;
-                if (accm) {
-                    const int src = __ffsll((long long)accm) - 1;            // first (largest) step that decreases the SDF
-                    const int d = sgn > 0 ? src : src - 9;
-                    iter += d + 1;
-                    x = rlane(te, src);
-                    fx = rlane(val, src);
-                    g1_fresh = false;
-                    full = d == 0;
-                    if (full) spec_next = sgn;
-                } else {
-                    iter += 9;
-                    stop = true;
+            double val = 1e300;
+            d3 pvel = mk3(0, 0, 0), g_direct = mk3(0, 0, 0);
+            if (act) eval_lane<KIND, LDS>(P, tr, p, te, pert, pose_lane, own_grad, val, pvel, g_direct);
+            n_pass++;
+            // shape gradient at the pose of block `base` from its samples (getonlyGrad1)
+            auto grad_of = [&](int base) -> d3 {
+                if (fd_central) {
+                    const double dx = 0.000005;
+                    const double gx = rlane(val, base + 2) - rlane(val, base + 1), gy = rlane(val, base + 4) - rlane(val, base + 3),
+                                 gz = rlane(val, base + 6) - rlane(val, base + 5);
+                    return normalized3(mk3(gx / (2 * dx), gy / (2 * dx), gz / (2 * dx)));
+                } else if (fd_forward) {
+                    const double s0 = rlane(val, base), dx = 0.01;
+                    return mk3((rlane(val, base + 1) - s0) / dx, (rlane(val, base + 2) - s0) / dx, (rlane(val, base + 3) - s0) / dx);
                 }
-                if (!(iter < 300 && !stop && fabs(x - prev_x) > 1e-5)) { finished = true; break; }
-                if (!(full && s_spec != 0 && sgn == s_spec)) break;          // x is not y_1: the next pass starts from it
-            } else {
-                // at x = y_m only the full step along s_spec has been evaluated: f(y_(m+1))
-                if (sgn != s_spec) break;                                    // direction changed: regular pass from here
-                const int nb = m < GD_SPEC ? gd_block_base(m + 1) : 60;
-                const double fc = rlane(val, nb);
-                if (!((fc - fx) < 0)) break;                                 // full step rejected: its halvings need a regular pass
-                prev_x = x;
-                iter += 1;
-                x = rlane(te, nb);
-                fx = fc;
-                g1_fresh = false;
-                spec_next = s_spec;
-                if (!(iter < 300 && fabs(x - prev_x) > 1e-5)) { finished = true; break; }
-                if (m == GD_SPEC) break;
+                return mk3(rlane(g_direct.x, base), rlane(g_direct.y, base), rlane(g_direct.z, base));
+            };
+            g1_at_x = grad_of(18); g1_fresh = true;
+            if (grad_only) break;
+            // sign-descent iterations: the one at x in full, then - while every step is the full step in the direction the
+            // look-ahead blocks were laid out for - the ones at y_1, y_2, ...
+            if (iter == 0) fx = rlane(val, 18);
+            bool finished = false;
+            int spec_next = 0;
+            for (int m = 0;; m++) {
+                const int base = gd_block_base(m);
+                const d3 g1 = m == 0 ? g1_at_x : grad_of(base);
+                if (m > 0) { g1_at_x = g1; g1_fresh = true; }
+                const d3 pv = mk3(rlane(pvel.x, base), rlane(pvel.y, base), rlane(pvel.z, base));
+                const double g = dot3(g1, pv);
+                const int sgn = (int)(g > 0) - (int)(g < 0);
+                spec_next = 0;
+                if (m == 0) {
+                    prev_x = x;
+                    const bool in_set = sgn > 0 ? (lane < 9) : (sgn < 0 ? (lane >= 9 && lane < 18) : false);
+                    const unsigned long long accm = __ballot(in_set && ((val - fx) < 0));
+                    bool stop = false, full = false;
+                    if (accm) {
+                        const int src = __ffsll((long long)accm) - 1;            // first (largest) step that decreases the SDF
+                        const int d = sgn > 0 ? src : src - 9;
+                        iter += d + 1;
+                        x = rlane(te, src);
+                        fx = rlane(val, src);
+                        g1_fresh = false;
+                        full = d == 0;
+                        if (full) spec_next = sgn;
+                    } else {
+                        iter += 9;
+                        stop = true;
+                    }
+                    if (!(iter < 300 && !stop && fabs(x - prev_x) > 1e-5)) { finished = true; break; }
+                    if (!(full && s_spec != 0 && sgn == s_spec)) break;          // x is not y_1: the next pass starts from it
+                } else {
+                    // at x = y_m only the full step along s_spec has been evaluated: f(y_(m+1))
+                    if (sgn != s_spec) break;                                    // direction changed: regular pass from here
+                    const int nb = m < GD_SPEC ? gd_block_base(m + 1) : 60;
+                    const double fc = rlane(val, nb);
+                    if (!((fc - fx) < 0)) break;                                 // full step rejected: its halvings need a regular pass
+                    prev_x = x;
+                    iter += 1;
+                    x = rlane(te, nb);
+                    fx = fc;
+                    g1_fresh = false;
+                    spec_next = s_spec;
+                    if (!(iter < 300 && fabs(x - prev_x) > 1e-5)) { finished = true; break; }
+                    if (m == GD_SPEC) break;
+                }
+            }
+            s_spec = spec_next;
+            if (finished) {
+                if (g1_fresh) break;
+                grad_only = true;          // the last step moved x: one more pass for the gradient there
             }
         }
-        s_spec = spec_next;
-        if (finished) phase = g1_fresh ? PH_NEXT : PH_GRAD;
-    }
-
-    // ---------------- hand the minimiser to swept_backprop_kernel ----------------
-    if (lane == 0) {
-        double *o = P.point_partial + (size_t)pt * PARTIAL_STRIDE;     // reused as [t*, sdf*, grad_prel(3)] until back-prop
-        o[0] = have ? t_star_best : P.tstar[pt];                       // no interval qualified: lastTstar stays (:717, :576-578)
-        o[1] = min_sdf_star;
-        o[2] = grad_prel.x; o[3] = grad_prel.y; o[4] = grad_prel.z;
-        atomicAdd(&P.stats[2], (unsigned long long)n_ranges);
-        atomicAdd(&P.stats[5], (unsigned long long)n_iters_total);
-        atomicAdd(&P.stats[7], (unsigned long long)n_passes);
+        // interval result: (t_r, sdf_r, gradient at t_r) - the best interval is picked in order by the back-prop kernel (:739-744)
+        if (lane == 0) {
+            slot[0] = x; slot[1] = fx; slot[2] = g1_at_x.x; slot[3] = g1_at_x.y; slot[4] = g1_at_x.z;
+            slot[5] = __longlong_as_double((long long)(((unsigned long long)n_pass & 0xFFFFull) | ((unsigned long long)iter << 16)));
+        }
     }
 }
 
@@ -432,6 +498,7 @@ __global__ __launch_bounds__(64) void swept_fixed_kernel(const SweptParams P, co
     const d3 p = mk3(P.points[3 * pt], P.points[3 * pt + 1], P.points[3 * pt + 2]);
     const double ts = tstar_in[pt];
     double *o = P.point_partial + (size_t)pt * PARTIAL_STRIDE;
+    o[5] = 0.0;
     if (!(ts >= 0.0)) { o[0] = P.tstar[pt]; o[1] = 1e1; o[2] = o[3] = o[4] = 0.0; return; }
     d3 x; m3 R;
     pose_at(P, tr, ts, x, R);
@@ -451,8 +518,30 @@ __global__ __launch_bounds__(128) void swept_backprop_kernel(const SweptParams P
     const TrajView tr{P.T, P.coeffs, P.N};
     double *o = P.point_partial + (size_t)pt * PARTIAL_STRIDE;
     const d3 p = mk3(P.points[3 * pt], P.points[3 * pt + 1], P.points[3 * pt + 2]);
-    const double tstar = o[0], min_sdf_star = o[1];
-    const d3 grad_prel = mk3(o[2], o[3], o[4]);
+    double tstar, min_sdf_star;
+    d3 grad_prel;
+    unsigned long long counters;
+    if (P.direct_records) {           // the fixed-t* kernel left (t*, sdf*, gradient) in the point's record
+        tstar = o[0]; min_sdf_star = o[1];
+        grad_prel = mk3(o[2], o[3], o[4]);
+        counters = (unsigned long long)__double_as_longlong(o[5]);
+    } else {
+        // the best interval, in interval order with a strict '<' (getSDFofSweptVolume :729-745); no interval: lastTstar stays
+        // and the SDF reads 10 (:717, :576-578)
+        const int nrw = P.point_nr[pt], nr = nrw & 0xFF;
+        const double *slots = P.task_buf + (size_t)(pt - P.point_begin) * SW_MAX_RANGES * TASK_STRIDE;
+        tstar = P.tstar[pt]; min_sdf_star = 1e1;
+        grad_prel = mk3(0, 0, 0);
+        unsigned long long passes = (unsigned long long)(nrw >> 8), iters = 0;
+        for (int r = 0; r < nr; r++) {
+            const double *sl = slots + (size_t)r * TASK_STRIDE;
+            const double f_r = sl[1];
+            if (f_r < min_sdf_star) { min_sdf_star = f_r; tstar = sl[0]; grad_prel = mk3(sl[2], sl[3], sl[4]); }
+            const unsigned long long c = (unsigned long long)__double_as_longlong(sl[5]);
+            passes += c & 0xFFFFull; iters += c >> 16;
+        }
+        counters = ((unsigned long long)nr & 0xFFull) | ((passes & 0xFFFFull) << 8) | (iters << 24);
+    }
     double time_local = tstar;
     const int i = traj_locate(tr, time_local);
     Basis B;
@@ -490,41 +579,94 @@ __global__ __launch_bounds__(128) void swept_backprop_kernel(const SweptParams P
             o[d * 6 + rr] = B.b0[rr] * gPv[d] + B.b1[rr] * gVv[d] + B.b2[rr] * gAv[d] + B.b3[rr] * gJv[d];
     o[18] = (-dot3(gP, vel) + -dot3(gV, acc3) + -dot3(gA, jer) + -dot3(gJ, sna));
     o[19] = pena;
-    P.point_piece[pt] = i;
+    // a point without an active penalty contributes exact zeros (more than half of the points, all of them in piece 0 when
+    // their lastTstar is still 0): the per-piece sums skip it (x + 0.0 == x)
+    bool all_zero = !active;
+#pragma unroll
+    for (int q = 0; q < 19; q++) all_zero = all_zero && (o[q] == 0.0);
+    P.point_piece[pt] = all_zero ? -1 : i;
+    P.point_stat[pt] = (counters << 1) | (active ? 1ull : 0ull);
     P.tstar[pt] = tstar;
-    if (active) atomicAdd(&P.stats[3], 1ull);
 }
 
 // Deterministic reduction.  Blocks [0, N): gradC rows of piece i and H[i] = sum of gdT over the points whose t* lies in
-// piece i; block N: cost.  Every thread adds its strided points in ascending order, the 20 columns then go through ONE
-// fixed-shape butterfly per wavefront (no serial per-column tree) and the four wave sums are added in wave order.  The
-// workgroup that finishes LAST (ticket in stats[6], zeroed by the prepare / fixed kernel of the step) turns H into
+// piece i; block N: cost and the statistics words.  Every thread adds its strided points in ascending order (the loads of a
+// round of RED_U points are issued together - a dependent load per point made this kernel 36 us), the 20 columns then go
+// through ONE fixed-shape butterfly per wavefront and the four wave sums are added in wave order.  The workgroup that finishes
+// LAST (ticket in stats[6], zeroed by the prepare / fixed kernel of the step) turns H into
 // gradT(j) = sum_{i > j} H[i]   ("for (j < i) gradT(j) += gdT", back_end_optimizer.hpp:642-645), in fixed order.
+constexpr int RED_U = 8;
+// wave-wide sum with DPP lane exchanges (fixed shape: quads, half rows, rows, then the four row totals in row order)
+template <int CTRL> __device__ __forceinline__ double dpp_f64(double v) {
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, 0xf, 0xf, false);
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xf, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double wave_sum_dpp(double v) {
+    v += dpp_f64<0xB1>(v);        // quad_perm [1,0,3,2]
+    v += dpp_f64<0x4E>(v);        // quad_perm [2,3,0,1]
+    v += dpp_f64<0x141>(v);       // row_half_mirror
+    v += dpp_f64<0x140>(v);       // row_mirror: every lane of a row of 16 holds the row total
+    return ((rlane(v, 0) + rlane(v, 16)) + rlane(v, 32)) + rlane(v, 48);
+}
 __global__ __launch_bounds__(256) void swept_reduce_kernel(const SweptParams P, double *out, double *hist) {
     __shared__ double s_red[4][20];
+    __shared__ unsigned long long s_cnt[4][4];
     __shared__ int s_last;
     const int i = blockIdx.x;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     double acc[20];
 #pragma unroll
     for (int q = 0; q < 20; q++) acc[q] = 0.0;
+    unsigned long long n_act = 0, n_rng = 0, n_pass = 0, n_it = 0;
     const bool cost_block = (i == P.N);
-    for (int pt = P.point_begin + tid; pt < P.point_end; pt += 256) {
-        const double *o = P.point_partial + (size_t)pt * PARTIAL_STRIDE;
-        if (cost_block) acc[19] += o[19];
-        else if (P.point_piece[pt] == i) {
+    unsigned long long *const rdbg = P.dbg ? P.dbg + (size_t)P.M * 4 + (size_t)i * 8 : nullptr;
+    if (rdbg && tid == 0) rdbg[0] = wall_clock64();
+    for (int base = P.point_begin + tid; base < P.point_end; base += 256 * RED_U) {
+        if (cost_block) {
+            double pena[RED_U]; unsigned long long st[RED_U];
 #pragma unroll
-            for (int q = 0; q < 19; q++) acc[q] += o[q];
+            for (int u = 0; u < RED_U; u++) {
+                const int pt = base + u * 256;
+                const bool ok = pt < P.point_end;
+                pena[u] = ok ? P.point_partial[(size_t)pt * PARTIAL_STRIDE + 19] : 0.0;
+                st[u] = ok ? P.point_stat[pt] : 0ull;
+            }
+#pragma unroll
+            for (int u = 0; u < RED_U; u++) {
+                if (base + u * 256 < P.point_end) acc[19] += pena[u];
+                n_act += st[u] & 1ull; n_rng += (st[u] >> 1) & 0xFFull; n_pass += (st[u] >> 9) & 0xFFFFull; n_it += st[u] >> 25;
+            }
+        } else {
+            int pid[RED_U];
+#pragma unroll
+            for (int u = 0; u < RED_U; u++) { const int pt = base + u * 256; pid[u] = pt < P.point_end ? P.point_piece[pt] : -1; }
+#pragma unroll
+            for (int u = 0; u < RED_U; u++)
+                if (pid[u] == i) {
+                    const double *o = P.point_partial + (size_t)(base + u * 256) * PARTIAL_STRIDE;
+#pragma unroll
+                    for (int q = 0; q < 19; q++) acc[q] += o[q];
+                }
         }
     }
+    if (rdbg && tid == 0) rdbg[1] = wall_clock64();
 #pragma unroll
     for (int q = 0; q < 20; q++) {
-        double v = acc[q];
-#pragma unroll
-        for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
+        if (cost_block != (q == 19)) continue;     // wave-uniform
+        const double v = wave_sum_dpp(acc[q]);
         if (lane == 0) s_red[wave][q] = v;
     }
+    if (cost_block) {
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) {
+            n_act += __shfl_xor(n_act, off, 64); n_rng += __shfl_xor(n_rng, off, 64);
+            n_pass += __shfl_xor(n_pass, off, 64); n_it += __shfl_xor(n_it, off, 64);
+        }
+        if (lane == 0) { s_cnt[wave][0] = n_act; s_cnt[wave][1] = n_rng; s_cnt[wave][2] = n_pass; s_cnt[wave][3] = n_it; }
+    }
     __syncthreads();
+    if (rdbg && tid == 0) rdbg[2] = wall_clock64();
     if (tid < 20) {
         const int q = tid;
         const double v = ((s_red[0][q] + s_red[1][q]) + s_red[2][q]) + s_red[3][q];
@@ -532,9 +674,16 @@ __global__ __launch_bounds__(256) void swept_reduce_kernel(const SweptParams P, 
         else if (q == 18) __hip_atomic_store(&hist[i], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         else if (q < 18) { const int d = q / 6, r = q - 6 * d; out[1 + P.N + (size_t)d * 6 * P.N + 6 * i + r] = v; }
     }
-    if (cost_block && tid == 0) atomicAdd(&P.stats[0], (unsigned long long)(P.point_end - P.point_begin));
+    if (cost_block && tid == 0) {                  // single writer: no atomics on the statistics words
+        P.stats[0] = (unsigned long long)(P.point_end - P.point_begin);
+        P.stats[3] = s_cnt[0][0] + s_cnt[1][0] + s_cnt[2][0] + s_cnt[3][0];
+        P.stats[2] = s_cnt[0][1] + s_cnt[1][1] + s_cnt[2][1] + s_cnt[3][1];
+        P.stats[7] = s_cnt[0][2] + s_cnt[1][2] + s_cnt[2][2] + s_cnt[3][2];
+        P.stats[5] = s_cnt[0][3] + s_cnt[1][3] + s_cnt[2][3] + s_cnt[3][3];
+    }
     // last workgroup of the N piece blocks: suffix sums
     __syncthreads();
+    if (rdbg && tid == 0) rdbg[3] = wall_clock64();
     if (tid == 0) {
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
         const unsigned long long t = cost_block ? 0ull : atomicAdd(&P.stats[6], 1ull);
@@ -542,13 +691,24 @@ __global__ __launch_bounds__(256) void swept_reduce_kernel(const SweptParams P, 
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
     }
     __syncthreads();
-    if (s_last && tid == 0) {
+    if (rdbg && tid == 0) rdbg[4] = wall_clock64();
+    if (s_last) {
+        // H is fetched by all threads at once (one agent-scope load each: 40 of them one after the other on a single lane
+        // were most of this kernel's 32 us), the running sum itself stays serial and in fixed order
+        __shared__ double s_h[256];
         double sfx = 0.0;
-        for (int j = P.N - 1; j >= 0; j--) {
-            out[1 + j] = sfx;
-            sfx += __hip_atomic_load(&hist[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        for (int top = P.N; top > 0; top -= 256) {
+            const int j = top - 1 - tid;                       // thread 0 holds the highest piece of this round
+            if (j >= 0) s_h[tid] = __hip_atomic_load(&hist[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __syncthreads();
+            if (tid == 0) {
+                const int n = min(256, top);
+                for (int k = 0; k < n; k++) { out[1 + (top - 1 - k)] = sfx; sfx += s_h[k]; }
+            }
+            __syncthreads();
         }
     }
+    if (rdbg && tid == 0) rdbg[5] = wall_clock64();
 }
 
 void launch_swept_prepare(const SweptParams &P, hipStream_t stream) {
@@ -562,8 +722,12 @@ void launch_swept_sweep(const SweptParams &P, hipStream_t stream, hipEvent_t ev_
     const dim3 grid((n + SW_WAVES - 1) / SW_WAVES), block(64 * SW_WAVES);
     const size_t lds = traj_lds_bytes(P.N);
     const bool in_lds = lds <= TRAJ_LDS_MAX;
-#define ISDF_SWEPT_CASE(K) case K: if (in_lds) hipExtLaunchKernelGGL((swept_sweep_kernel<K, true>), grid, block, lds, stream, ev_start, ev_stop, 0, P); \
-                                   else hipExtLaunchKernelGGL((swept_sweep_kernel<K, false>), grid, block, 0, stream, ev_start, ev_stop, 0, P); break;
+    // scan, then descent (one wavefront per task while there are no more tasks than points, which is the rule); the start
+    // event rides on the first dispatch, the stop event on the second
+#define ISDF_SWEPT_CASE(K) case K: if (in_lds) { hipExtLaunchKernelGGL((swept_scan_kernel<K, true>), grid, block, lds, stream, ev_start, nullptr, 0, P); \
+                                                 hipExtLaunchKernelGGL((swept_descent_kernel<K, true>), grid, block, lds, stream, nullptr, ev_stop, 0, P); } \
+                                   else { hipExtLaunchKernelGGL((swept_scan_kernel<K, false>), grid, block, 0, stream, ev_start, nullptr, 0, P); \
+                                          hipExtLaunchKernelGGL((swept_descent_kernel<K, false>), grid, block, 0, stream, nullptr, ev_stop, 0, P); } break;
     switch (P.shape.kind) {
     // one instantiation per shape class (each inlines exactly one SDF formula; the run-time switch of the generic kernel costs
     // 272 VGPRs = one wave per SIMD)
@@ -572,9 +736,7 @@ void launch_swept_sweep(const SweptParams &P, hipStream_t stream, hipEvent_t ev_
     ISDF_SWEPT_CASE(ISDF_SHAPE_TWISTBOX) ISDF_SWEPT_CASE(ISDF_SHAPE_BENDBOX) ISDF_SWEPT_CASE(ISDF_SHAPE_TABLE)
     ISDF_SWEPT_CASE(ISDF_SHAPE_TREFOIL) ISDF_SWEPT_CASE(ISDF_SHAPE_SMOOTHDIFFERENCE) ISDF_SWEPT_CASE(ISDF_SHAPE_SMOOTHINTERSECTION)
     ISDF_SWEPT_CASE(ISDF_SHAPE_CSG) ISDF_SWEPT_CASE(ISDF_SHAPE_BOX) ISDF_SWEPT_CASE(ISDF_SHAPE_MESH)
-    default: if (in_lds) hipExtLaunchKernelGGL((swept_sweep_kernel<-1, true>), grid, block, lds, stream, ev_start, ev_stop, 0, P);
-             else hipExtLaunchKernelGGL((swept_sweep_kernel<-1, false>), grid, block, 0, stream, ev_start, ev_stop, 0, P);
-             break;      // Ball
+    default: ISDF_SWEPT_CASE(-1)      // Ball
     }
 #undef ISDF_SWEPT_CASE
 }
