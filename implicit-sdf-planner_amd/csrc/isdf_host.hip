@@ -158,7 +158,7 @@ extern "C" int isdf_destroy(isdf_ctx *c) {
     isdf_frontend_release(c);
     isdf_xchg_release(c);
     void *ptrs[] = {c->d_cb, c->d_esdf, c->d_occ, c->d_points, c->d_tstar, c->d_acc, c->d_sample_info, c->d_bits, c->d_piece_cost, c->d_in, c->d_out, c->d_stats,
-                    c->d_traj_duration, c->d_coarse_t, c->d_coarse_pose, c->d_n_coarse, c->d_point_partial, c->d_point_piece, c->d_point_stat, c->d_point_nr, c->d_task_buf, c->d_task_map, c->d_v1_words, c->d_hist, c->d_dbg};
+                    c->d_traj_duration, c->d_coarse_t, c->d_coarse_pose, c->d_n_coarse, c->d_point_partial, c->d_point_piece, c->d_point_stat, c->d_point_nr, c->d_task_buf, c->d_task_map, c->d_v1_words, c->d_point_lmask, c->d_hist, c->d_dbg};
     for (void *p : ptrs) if (p) (void)hipFree(p);
     free_mesh(c);
     if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -325,6 +325,7 @@ extern "C" int isdf_set_points(isdf_ctx *c, const double *xyz, int M) {
     if (c->d_points) { (void)hipFree(c->d_points); c->d_points = nullptr; }
     if (c->d_tstar) { (void)hipFree(c->d_tstar); c->d_tstar = nullptr; }
     c->M = M;
+    if (c->d_v1_words) HIPCHK(c, hipMemset(c->d_v1_words, 0, 8 * sizeof(unsigned)));
     if (M > 0) {
         HIPCHK(c, hipMalloc(&c->d_points, (size_t)3 * M * sizeof(double)));
         HIPCHK(c, hipMemcpy(c->d_points, xyz, (size_t)3 * M * sizeof(double), hipMemcpyHostToDevice));
@@ -454,6 +455,8 @@ static int eval_device_impl(isdf_ctx *c, int n_traj, int N, const double *d_T, c
             if (c->d_point_nr) (void)hipFree(c->d_point_nr);
             if (c->d_task_buf) (void)hipFree(c->d_task_buf);
             if (c->d_task_map) (void)hipFree(c->d_task_map);
+            if (c->d_point_lmask) (void)hipFree(c->d_point_lmask);
+            c->d_point_lmask = nullptr;
             c->d_point_partial = nullptr; c->d_point_piece = nullptr; c->d_point_stat = nullptr; c->point_cap = 0;
             c->d_point_nr = nullptr; c->d_task_buf = nullptr; c->d_task_map = nullptr;
             HIPCHK(c, hipMalloc(&c->d_point_partial, (size_t)c->M * PARTIAL_STRIDE * sizeof(double)));
@@ -462,15 +465,15 @@ static int eval_device_impl(isdf_ctx *c, int n_traj, int N, const double *d_T, c
             HIPCHK(c, hipMalloc(&c->d_point_nr, (size_t)c->M * sizeof(int)));
             HIPCHK(c, hipMalloc(&c->d_task_buf, (size_t)c->M * 32 * 6 * sizeof(double)));       // SW_MAX_RANGES x TASK_STRIDE per point
             HIPCHK(c, hipMalloc(&c->d_task_map, (size_t)c->M * 32 * sizeof(unsigned)));
-            if (!c->d_v1_words) {
-                HIPCHK(c, hipMalloc(&c->d_v1_words, 4 * sizeof(unsigned)));
-                HIPCHK(c, hipMemset(c->d_v1_words, 0, 4 * sizeof(unsigned)));
-            }
+            HIPCHK(c, hipMalloc(&c->d_point_lmask, (size_t)c->M * sizeof(unsigned)));
+            HIPCHK(c, hipMemset(c->d_point_lmask, 0, (size_t)c->M * sizeof(unsigned)));
+            if (!c->d_v1_words) HIPCHK(c, hipMalloc(&c->d_v1_words, 8 * sizeof(unsigned)));
+            HIPCHK(c, hipMemset(c->d_v1_words, 0, 8 * sizeof(unsigned)));
             c->point_cap = c->M;
         }
         P.coarse_t = c->d_coarse_t; P.coarse_pose = c->d_coarse_pose; P.n_coarse = c->d_n_coarse;
         P.point_partial = c->d_point_partial; P.point_piece = c->d_point_piece; P.point_stat = c->d_point_stat;
-        P.point_nr = c->d_point_nr; P.task_buf = c->d_task_buf; P.task_map = c->d_task_map; P.words = c->d_v1_words;
+        P.point_nr = c->d_point_nr; P.task_buf = c->d_task_buf; P.task_map = c->d_task_map; P.words = c->d_v1_words; P.point_lmask = c->d_point_lmask;
         P.direct_records = fixed_tstar ? 1 : 0;
         { int rc2 = ensure(c, &c->d_hist, &c->hist_cap, (size_t)N); if (rc2) return rc2; }
         P.hist = c->d_hist;
