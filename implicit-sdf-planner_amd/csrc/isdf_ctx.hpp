@@ -65,6 +65,14 @@ struct isdf_ctx {
     double *h_eval_pin = nullptr; size_t eval_pin_cap = 0;   // pinned staging of isdf_eval: [inputs | outputs | statistics]
     double *h_pin = nullptr; size_t pin_cap = 0;      // pinned staging: [T | coeffs | out_a | out_b]
     double *d_cb = nullptr; size_t cb_cap = 0;        // device twin of the staging buffer
+    // host-direct steps (isdf_eval / isdf_cost_function on one GPU when the step is one fused launch): pinned, device-mapped
+    // [inputs | outputs | one flag per trajectory]; the launch reads the inputs and writes the outputs over PCIe itself
+    double *h_dir = nullptr, *h_dir_dev = nullptr; size_t dir_cap = 0; size_t dir_in = 0, dir_out = 0, dir_flags = 0;
+    double *d_stage = nullptr; size_t stage_cap = 0;
+    unsigned long long *d_stage_flags = nullptr; size_t stage_flags_cap = 0;
+    unsigned long long dir_seq = 0;
+    int bar_state = 0;          // 0: untested, 1: the host can write device memory through the PCIe BAR (verified), -1: it cannot
+    bool dir_pending = false; int dir_nb = 0, dir_n = 0; bool cb_direct = false;
     double last_parts[4] = {0, 0, 0, 0};
     std::vector<double> cb_x; double cb_energy = 0.0; int cb_n_out = 1; bool cb_pending = false;
     // front end (csrc/frontend.hip): attitude kernels of the robot, inflated bit-packed occupancy, breadth-first order tables

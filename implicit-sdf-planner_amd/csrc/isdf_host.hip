@@ -4,6 +4,7 @@
 // shape registry lookup of sw_manager.hpp:74-123,:255-275.  No CPU compute path exists here.
 #include "isdf_ctx.hpp"
 #include "lbfgs_host.hpp"
+#include <atomic>
 #include <chrono>
 #include <cmath>
 #include <cstdio>
@@ -155,10 +156,12 @@ extern "C" int isdf_destroy(isdf_ctx *c) {
     for (auto &p : c->prof_events) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); (void)hipEventDestroy(p.c); (void)hipEventDestroy(p.d); }
     if (c->h_pin) (void)hipHostFree(c->h_pin);
     if (c->h_eval_pin) (void)hipHostFree(c->h_eval_pin);
+    if (c->h_dir) (void)hipHostFree(c->h_dir);
     isdf_frontend_release(c);
     isdf_xchg_release(c);
     void *ptrs[] = {c->d_cb, c->d_esdf, c->d_occ, c->d_points, c->d_tstar, c->d_acc, c->d_sample_info, c->d_bits, c->d_piece_cost, c->d_in, c->d_out, c->d_stats,
-                    c->d_traj_duration, c->d_coarse_t, c->d_coarse_pose, c->d_n_coarse, c->d_point_partial, c->d_point_piece, c->d_point_stat, c->d_point_nr, c->d_task_buf, c->d_task_map, c->d_v1_words, c->d_point_lmask, c->d_hist, c->d_dbg};
+                    c->d_traj_duration, c->d_coarse_t, c->d_coarse_pose, c->d_n_coarse, c->d_point_partial, c->d_point_piece, c->d_point_stat, c->d_point_nr, c->d_task_buf,
+                    c->d_task_map, c->d_v1_words, c->d_point_lmask, c->d_hist, c->d_dbg, c->d_stage, c->d_stage_flags};
     for (void *p : ptrs) if (p) (void)hipFree(p);
     free_mesh(c);
     if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -412,8 +415,12 @@ int isdf_reserve_sweep_buffers(isdf_ctx *c, long long total_pieces) {
 
 // mode 0: the sweep cfg.variant names; 1: the swept-volume sweep; 2: the integral sweep with the collision term off
 // (modes 1 + 2 together are what costFunctionLmbm runs for the reference's live configuration)
+// host-direct step (see isdf_ctx.hpp): device-visible addresses of the pinned inputs / outputs / flags of this step
+struct HostDirect { const double *T, *coeffs; double *out; unsigned long long *flags; unsigned long long seq; bool via_bar; };
+constexpr int ISDF_DIRECT_NA = 1;        // eval_device_impl: the step cannot run host-direct (nothing was launched)
+
 static int eval_device_impl(isdf_ctx *c, int n_traj, int N, const double *d_T, const double *d_coeffs, double *d_out,
-                            double *d_tstar, hipStream_t st, int mode = 0, bool fixed_tstar = false) {
+                            double *d_tstar, hipStream_t st, int mode = 0, bool fixed_tstar = false, const HostDirect *hd = nullptr) {
     isdf_config cfg = c->cfg;
     if (mode == 1) cfg.variant = ISDF_V1_SWEPT;
     if (mode == 2) { cfg.variant = ISDF_V3_ESDF_TILE; cfg.enable_pos = 0; }
@@ -425,6 +432,7 @@ static int eval_device_impl(isdf_ctx *c, int n_traj, int N, const double *d_T, c
     const size_t ostride = isdf_out_stride(N);
 
     if (cfg.variant == ISDF_V1_SWEPT) {
+        if (hd) return ISDF_DIRECT_NA;
         if (n_traj != 1) return fail(c, ISDF_ERR_UNSUPPORTED, "the swept-volume sweep takes one trajectory");
         if (isdf_xchg_fuse_on(c)) return fail(c, ISDF_ERR_UNSUPPORTED, "the in-kernel exchange belongs to the integral sweep (V2/V3)");
         if (c->M <= 0) {                 // no obstacle points: nothing to add
@@ -586,6 +594,21 @@ static int eval_device_impl(isdf_ctx *c, int n_traj, int N, const double *d_T, c
             if (!fused) { P.xf.world = 0; return fail(c, ISDF_ERR_UNSUPPORTED, "in-kernel exchange needs a step that runs as one fused launch"); }
         }
     }
+    if (hd) {
+        if (!fused || P.xf.world > 1 || P.dbg) return ISDF_DIRECT_NA;
+        const size_t n_groups = ((size_t)total_pieces + STAGE_G - 1) / STAGE_G;
+        { int rc1 = ensure(c, &c->d_stage, &c->stage_cap, (size_t)total_pieces * 19); if (rc1) return rc1; }
+        if (c->stage_flags_cap < n_groups) {
+            if (c->d_stage_flags) (void)hipFree(c->d_stage_flags);
+            c->d_stage_flags = nullptr; c->stage_flags_cap = 0;
+            HIPCHK(c, hipMalloc(&c->d_stage_flags, n_groups * sizeof(unsigned long long)));
+            HIPCHK(c, hipMemset(c->d_stage_flags, 0, n_groups * sizeof(unsigned long long)));
+            c->stage_flags_cap = n_groups;
+        }
+        P.out = hd->out; P.host_flag = hd->flags; P.seq = hd->seq;
+        if (!hd->via_bar) { P.host_T = hd->T; P.host_coeffs = hd->coeffs; P.stage = c->d_stage; P.stage_flags = c->d_stage_flags; }
+        c->last_P = P;
+    }
     launch_sweep(P, st, ev ? ev->a : nullptr, ev ? ev->b : nullptr, fused);
     if (!fused) launch_tail(P, st, ev2 ? ev->c : nullptr, ev2 ? ev->d : nullptr);
     HIPCHK(c, hipGetLastError());
@@ -633,6 +656,95 @@ static int ensure_eval_pin(isdf_ctx *c, size_t doubles) {
     return ISDF_OK;
 }
 
+// ---- host-direct steps -----------------------------------------------------------------------------------------------
+static bool direct_enabled(const isdf_ctx *c) {
+    static const bool off = [] { const char *e = getenv("ISDF_NO_HOST_DIRECT"); return e && e[0] == '1'; }();
+    return !off && !c->prof_on && c->world == 1 && c->cfg.variant != ISDF_V1_SWEPT && c->cfg.enable_pos;
+}
+// pinned, device-mapped [inputs 19 n nb | outputs (1 + 19 n) nb | nb flags]
+static int direct_reserve(isdf_ctx *c, int nb, int n) {
+    const size_t in = (size_t)19 * n * nb, out = isdf_out_stride(n) * nb, need = in + out + (size_t)nb;
+    if (c->dir_cap < need) {
+        if (c->h_dir) (void)hipHostFree(c->h_dir);
+        c->h_dir = nullptr; c->dir_cap = 0;
+        HIPCHK(c, hipHostMalloc((void **)&c->h_dir, need * sizeof(double), hipHostMallocDefault));      // pinned host memory is device-visible (unified addressing)
+        HIPCHK(c, hipHostGetDevicePointer((void **)&c->h_dir_dev, c->h_dir, 0));
+        c->dir_cap = need;
+        std::memset(c->h_dir, 0, need * sizeof(double));
+    }
+    c->dir_in = in; c->dir_out = out; c->dir_flags = (size_t)nb;
+    return ISDF_OK;
+}
+// Can the host write device memory directly (large PCIe BAR)?  Verified once per ctx: a pattern written by the CPU into a
+// device buffer must come back through hipMemcpy.  Writes only - host READS over the BAR cost ~1 us per access.
+static bool bar_usable(isdf_ctx *c, double *d_buf, size_t n) {
+    if (c->bar_state != 0) return c->bar_state > 0;
+    c->bar_state = -1;
+    if (getenv("ISDF_NO_BAR_WRITES") && getenv("ISDF_NO_BAR_WRITES")[0] == '1') return false;
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, c->device) != hipSuccess || !prop.isLargeBar) return false;
+    hipPointerAttribute_t at;
+    if (hipPointerGetAttributes(&at, d_buf) != hipSuccess) { (void)hipGetLastError(); return false; }
+    const size_t m = n < 64 ? n : 64;
+    std::vector<double> pat(m), back(m, 0.0);
+    for (size_t i = 0; i < m; i++) pat[i] = 1.0 + (double)i * 0.5;
+    std::memcpy(d_buf, pat.data(), m * sizeof(double));          // CPU stores into device memory
+    __sync_synchronize();
+    if (hipMemcpy(back.data(), d_buf, m * sizeof(double), hipMemcpyDeviceToHost) != hipSuccess) { (void)hipGetLastError(); return false; }
+    if (std::memcmp(pat.data(), back.data(), m * sizeof(double)) != 0) return false;
+    c->bar_state = 1;
+    return true;
+}
+// Places the inputs of nb trajectories of n pieces for a host-direct step and launches it.  ISDF_DIRECT_NA: not applicable
+// (the step is not one fused launch), nothing launched.  T / coeffs: per-trajectory host arrays (trajectory `first` onwards).
+static int direct_launch(isdf_ctx *c, int nb, int n, const double *const *T, const double *const *coeffs, int first, hipStream_t st, int mode) {
+    int rc = direct_reserve(c, nb, n);
+    if (rc) return rc;
+    const size_t in_all = (size_t)19 * n * nb;
+    rc = ensure(c, &c->d_in, &c->in_cap, in_all);
+    if (rc) return rc;
+    HostDirect hd;
+    hd.via_bar = bar_usable(c, c->d_in, in_all);
+    // inputs: through the BAR straight into device memory (posted writes, done before the doorbell is rung), or into the
+    // pinned buffer the first workgroups of the launch read
+    double *dst = hd.via_bar ? c->d_in : c->h_dir;
+    for (int b = 0; b < nb; b++) {
+        std::memcpy(dst + (size_t)b * n, T[first + b], (size_t)n * sizeof(double));
+        std::memcpy(dst + (size_t)n * nb + (size_t)b * 18 * n, coeffs[first + b], (size_t)18 * n * sizeof(double));
+    }
+    __sync_synchronize();
+    hd.T = c->h_dir_dev; hd.coeffs = c->h_dir_dev + (size_t)n * nb;
+    hd.out = c->h_dir_dev + c->dir_in;
+    hd.flags = (unsigned long long *)(c->h_dir_dev + c->dir_in + c->dir_out);
+    hd.seq = ++c->dir_seq;
+    rc = eval_device_impl(c, nb, n, c->d_in, c->d_in + (size_t)n * nb, hd.out, nullptr, st, mode, false, &hd);
+    if (rc == ISDF_OK) { c->dir_pending = true; c->dir_nb = nb; c->dir_n = n; }
+    return rc;
+}
+// the host's side of the hand-over: spin on the trajectories' flags (the launch stores them last); bounded - a launch that
+// never finishes is reported, not waited for forever
+static int direct_wait(isdf_ctx *c, hipStream_t st, bool *overflow) {
+    c->dir_pending = false;
+    volatile unsigned long long *flags = (volatile unsigned long long *)(c->h_dir + c->dir_in + c->dir_out);
+    const unsigned long long seq = c->dir_seq;
+    const auto t0 = std::chrono::steady_clock::now();
+    *overflow = false;
+    for (int b = 0; b < c->dir_nb; b++) {
+        unsigned long long f;
+        for (unsigned spin = 0;; spin++) {
+            f = flags[b];
+            if ((f & ~HOST_FLAG_OVERFLOW) == seq) break;
+            if ((spin & 0x3FFFu) == 0x3FFFu && std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > 5.0) {
+                (void)hipStreamSynchronize(st);
+                return fail(c, ISDF_ERR_HIP, "host-direct step did not complete (flag never arrived)");
+            }
+        }
+        if (f & HOST_FLAG_OVERFLOW) *overflow = true;
+    }
+    std::atomic_thread_fence(std::memory_order_acquire);
+    return ISDF_OK;
+}
+
 extern "C" int isdf_eval(isdf_ctx *c, int n_traj, const int *N, const double *const *T, const double *const *coeffs,
                          double *cost_inout, double *const *gradT_inout, double *const *gradC_inout, double *tstar_inout) {
     if (!c) return ISDF_ERR_INVALID_ARG;
@@ -652,6 +764,39 @@ extern "C" int isdf_eval(isdf_ctx *c, int n_traj, const int *N, const double *co
         if (n < 1) return fail(c, ISDF_ERR_INVALID_ARG, "N must be >= 1");
         const size_t in_per = (size_t)19 * n, ostride = isdf_out_stride(n);
         const size_t in_all = in_per * nb, out_all = ostride * nb;
+        for (int b = 0; b < nb; b++)
+            if (!T[start + b] || !coeffs[start + b] || !gradT_inout[start + b] || !gradC_inout[start + b])
+                return fail(c, ISDF_ERR_INVALID_ARG, "null trajectory buffer");
+        if (direct_enabled(c)) {
+            // ONE launch, no copy commands, no stream synchronisation: the inputs go straight into device memory through the
+            // PCIe BAR (or are fetched from host-mapped memory by the launch itself), the launch copies [cost | gradT | gradC]
+            // and a completion flag per trajectory into host-mapped memory (csrc/tile_sweep.hip)
+            int rcd = direct_launch(c, nb, n, T, coeffs, start, c->stream, 0);
+            if (rcd < 0) return rcd;
+            if (rcd == ISDF_OK) {
+                bool ovf = false;
+                rcd = direct_wait(c, c->stream, &ovf);
+                if (rcd) return rcd;
+                if (ovf) { overflow = true; HIPCHK(c, hipMemset(c->d_stats + 4, 0, sizeof(unsigned long long))); }
+                const double *hout = c->h_dir + c->dir_in;
+                for (int b = 0; b < nb; b++) {
+                    const double *o = hout + ostride * b;
+                    cost_inout[start + b] += o[0];
+                    double *gT = gradT_inout[start + b], *gC = gradC_inout[start + b];
+                    for (int i = 0; i < n; i++) gT[i] += o[1 + i];
+                    for (int i = 0; i < 18 * n; i++) gC[i] += o[1 + n + i];
+                }
+                if (groups > 1) {
+                    rcd = fetch_stats(c);
+                    if (rcd) return rcd;
+                    total.n_units += c->last_stats.n_units; total.n_units_culled += c->last_stats.n_units_culled;
+                    total.n_pairs += c->last_stats.n_pairs; total.n_grad_pairs += c->last_stats.n_grad_pairs;
+                }
+                start = end;
+                continue;
+            }
+            // ISDF_DIRECT_NA: this step is not one fused launch - the copy path below
+        }
         int rc = ensure(c, &c->d_in, &c->in_cap, in_all);
         if (rc) return rc;
         rc = ensure(c, &c->d_out, &c->out_cap, out_all);
@@ -753,7 +898,7 @@ extern "C" int isdf_unpack_variables(isdf_ctx *c, const double *x, double *T, do
 
 // First half of the callback: tau -> T, MINCO, energy, and the sweeps queued on `st`.  Leaves this rank's partial sums
 // ([cost | gradT | gradC] per sweep, cb_n_out blocks) in c->d_cb + 19N on the device.
-static int cost_function_launch(isdf_ctx *c, const double *x, int n, hipStream_t st) {
+static int cost_function_launch(isdf_ctx *c, const double *x, int n, hipStream_t st, bool allow_direct = false) {
     if (!x) return fail(c, ISDF_ERR_INVALID_ARG, "null argument");
     if (!c->have_traj) return fail(c, ISDF_ERR_STATE, "isdf_set_trajectory not called");
     const int N = c->minco.N;
@@ -768,6 +913,15 @@ static int cost_function_launch(isdf_ctx *c, const double *x, int n, hipStream_t
     const size_t in_len = (size_t)19 * N, ostride = isdf_out_stride(N);
     const bool swept = c->cfg.variant == ISDF_V1_SWEPT;
     c->cb_n_out = swept ? 2 : 1;
+    c->cb_direct = false;
+    if (allow_direct && !swept && direct_enabled(c)) {
+        // one launch that reads (T, coefficients) from host-mapped memory and writes the sums back into it: no copy commands,
+        // no stream synchronisation (csrc/tile_sweep.hip, host-direct step)
+        const double *Tp = c->cb_T.data(), *Cp = c->minco.c.data();
+        const int rcd = direct_launch(c, 1, N, &Tp, &Cp, 0, st, 0);
+        if (rcd < 0) return rcd;
+        if (rcd == ISDF_OK) { c->cb_direct = true; c->cb_pending = true; return ISDF_OK; }
+    }
     const size_t need = in_len + c->cb_n_out * ostride;
     if (c->pin_cap < need) {
         if (c->h_pin) (void)hipHostFree(c->h_pin);
@@ -802,13 +956,23 @@ static int cost_function_finish(isdf_ctx *c, double *g, double *cost_out, hipStr
     const size_t in_len = (size_t)19 * N, ostride = isdf_out_stride(N);
     const int n_out = c->cb_n_out;
     const bool swept = n_out == 2;
-    HIPCHK(c, hipSetDevice(c->device));
-    HIPCHK(c, hipMemcpyAsync(c->h_pin + in_len, c->d_cb + in_len, n_out * ostride * sizeof(double), hipMemcpyDeviceToHost, st));
-    HIPCHK(c, hipStreamSynchronize(st));
+    const double *res = nullptr;
+    if (c->cb_direct) {
+        bool ovf = false;
+        const int rcd = direct_wait(c, st, &ovf);
+        if (rcd) return rcd;
+        if (ovf) { (void)hipMemset(c->d_stats + 4, 0, sizeof(unsigned long long)); return fail(c, ISDF_ERR_OVERFLOW, "a bounded device work list overflowed; result invalid"); }
+        res = c->h_dir + c->dir_in;
+    } else {
+        HIPCHK(c, hipSetDevice(c->device));
+        HIPCHK(c, hipMemcpyAsync(c->h_pin + in_len, c->d_cb + in_len, n_out * ostride * sizeof(double), hipMemcpyDeviceToHost, st));
+        HIPCHK(c, hipStreamSynchronize(st));
+        res = c->h_pin + in_len;
+    }
     double cost = c->cb_energy;
     double part[2] = {0.0, 0.0};
     for (int k = 0; k < n_out; k++) {       // swept-volume sweep first, then the integral sweep (:386-405)
-        const double *o = c->h_pin + in_len + k * ostride;
+        const double *o = res + k * ostride;
         cost += o[0];
         part[k] = o[0];
         for (int i = 0; i < N; i++) c->cb_gdT[i] += o[1 + i];
@@ -832,7 +996,7 @@ static int cost_function_finish(isdf_ctx *c, double *g, double *cost_out, hipStr
 extern "C" int isdf_cost_function(isdf_ctx *c, const double *x, double *g, int n, double *cost_out) {
     if (!c) return ISDF_ERR_INVALID_ARG;
     if (!x || !g || !cost_out) return fail(c, ISDF_ERR_INVALID_ARG, "null argument");
-    const int rc = cost_function_launch(c, x, n, c->stream);
+    const int rc = cost_function_launch(c, x, n, c->stream, true);
     if (rc) return rc;
     return cost_function_finish(c, g, cost_out, c->stream);
 }
@@ -971,3 +1135,6 @@ extern "C" int isdf_get_stats(isdf_ctx *c, isdf_stats *out) {
     *out = c->last_stats;
     return ISDF_OK;
 }
+
+// developer tool (not declared in the ABI header): the HIP runtime's pending error of the calling thread, without clearing it
+extern "C" const char *isdf_debug_peek_hip_error(void) { return hipGetErrorString(hipPeekAtLastError()); }

@@ -23,6 +23,8 @@ constexpr int PARTIAL_STRIDE = 20;  // V1: per-point record = 18 gradC entries (
 // BOARD in IPC-mapped uncached memory, [2 step parities][pieces of the launch][XF_ROW] result slots (19 output rows + cost of
 // a piece), all-ones while empty.  The workgroup that owns a piece stores its rows straight into every peer's board; the
 // peer's workgroup for that piece polls them into its own output.  world <= 1: off.
+constexpr int STAGE_G = 4;           // pieces staged per workgroup / per ready flag of a host-direct step
+constexpr unsigned long long HOST_FLAG_OVERFLOW = 1ull << 62;
 constexpr int XCHG_MAX_WORLD = 16;
 constexpr int XF_ROW = 20;
 struct XFuse {
@@ -52,6 +54,17 @@ struct SweepParams {
     double *piece_cost;         // [n_traj * N] slots: a piece's cost once its block has published it, all-ones while empty (self-resetting)
     double *out;                // n_traj * (1 + N + 18N)
     unsigned long long *stats;  // [0]=units [1]=culled [2]=pairs [3]=grad pairs [4]=overflow
+    // host-direct step (isdf_eval / the callback on one GPU, fused launch only).  Outputs: `out` points into host-mapped
+    // memory - every piece's workgroup stores its rows there and releases them (system scope) before its cost; the
+    // trajectory's collector then stores host_flag[b] = seq (| overflow bit), the only thing the host waits for.  Inputs: either the host has written them straight into P.T / P.coeffs in
+    // device memory through the PCIe BAR (host_T == null), or - no large BAR - the first workgroups copy them from
+    // host-mapped memory into `stage` ([piece][19] = T, c(6x3)) and raise stage_flags[piece / STAGE_G] = seq, for which every
+    // consumer waits.
+    const double *host_T, *host_coeffs;   // device-visible addresses of the pinned inputs (null: inputs are P.T / P.coeffs)
+    double *stage;
+    unsigned long long *stage_flags;
+    unsigned long long seq;
+    unsigned long long *host_flag;
     int dbg_flags;              // developer switches (ISDF_DEBUG_FLAGS): 1 = skip the exact pass body
     unsigned long long *dbg;    // developer timing buffer (ISDF_DEBUG_TIMING=1), null on the product path
 };

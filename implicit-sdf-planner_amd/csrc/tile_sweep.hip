@@ -163,6 +163,46 @@ __device__ __forceinline__ bool xslot_take(double *slot, double &v) {        // 
     return b != SLOT_EMPTY;
 }
 
+// ---- inputs of one piece: from the caller's device arrays, or - host-direct step - from the staging buffer the first
+// workgroups of the launch fill from host-mapped memory
+struct PieceIn { const double *c; int ld; double T; };
+__device__ __forceinline__ PieceIn piece_in(const SweepParams &P, int b, int i) {
+    PieceIn r;
+    if (P.host_T) { const double *s = P.stage + ((size_t)b * P.N + i) * 19; r.c = s + 1; r.ld = 6; r.T = s[0]; }
+    else { r.c = P.coeffs + (size_t)b * 18 * P.N + 6 * i; r.ld = 6 * P.N; r.T = P.T[(size_t)b * P.N + i]; }
+    return r;
+}
+// one lane: wait (bounded) until the group of global piece `gp` has been staged, then make the staged doubles readable
+__device__ __forceinline__ bool stage_wait(const SweepParams &P, int gp) {
+    const unsigned long long *f = P.stage_flags + gp / STAGE_G;
+    bool ok = false;
+    for (int spin = 0; spin < SLOT_SPIN_MAX; spin++) {
+        if (__hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == P.seq) { ok = true; break; }
+        __builtin_amdgcn_s_sleep(1);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    return ok;
+}
+// workgroup `blk` of a host-direct launch copies the inputs of pieces [blk * STAGE_G, +STAGE_G) host -> stage, raises their flag
+__device__ __forceinline__ void stage_in(const SweepParams &P, int blk) {
+    const int n_pieces = P.n_traj * P.N;
+    for (int e = threadIdx.x; e < STAGE_G * 19; e += blockDim.x) {
+        const int gp = blk * STAGE_G + e / 19, k = e % 19;
+        if (gp < n_pieces) {
+            const int b = gp / P.N, i = gp - b * P.N;
+            double v;
+            if (k == 0) v = P.host_T[gp];
+            else { const int d = (k - 1) / 6, r = (k - 1) - 6 * d; v = P.host_coeffs[(size_t)b * 18 * P.N + (size_t)d * 6 * P.N + 6 * i + r]; }
+            P.stage[(size_t)gp * 19 + k] = v;
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        __hip_atomic_store(P.stage_flags + blk, P.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+
 struct SweepPose {                 // LDS record of one sample, written by the pose lane
     double pos[3];
     double R[9];                   // row-major body->world rotation
@@ -218,6 +258,11 @@ __global__ __launch_bounds__(64 * SW_SAMPLES, FUSED ? 3 : sweep_waves_per_simd(K
             return;
         }
     }
+    if constexpr (FUSED) {
+        // host-direct step: the first workgroups bring the inputs in (one PCIe read round trip, instead of a copy command and
+        // its completion in front of the launch)
+        if (P.host_T && (int)blockIdx.x < (P.n_traj * P.N + STAGE_G - 1) / STAGE_G) stage_in(P, (int)blockIdx.x);
+    }
     __shared__ SweepPose s_pose[SW_SAMPLES];
     __shared__ unsigned s_list[SW_SAMPLES][SW_LIST_CAP];          // ring of compacted voxels awaiting the fp32 test
     __shared__ unsigned s_near[SW_SAMPLES][SW_NEAR_CAP];          // ring of candidates awaiting the exact pass
@@ -239,9 +284,13 @@ __global__ __launch_bounds__(64 * SW_SAMPLES, FUSED ? 3 : sweep_waves_per_simd(K
     // ---- poses of the workgroup's samples: one LANE per sample (the serial fp64 chain is issued once, not per wave)
     if (wave == 0 && lane < SW_SAMPLES && s_begin + (long long)blockIdx.x + (long long)lane * n_blocks < s_end) {
         const SampleId id = decode_sample(P, s_begin + (long long)blockIdx.x + (long long)lane * n_blocks);
-        const double *c = P.coeffs + (size_t)id.b * 18 * P.N + 6 * id.i;
-        const int ld = 6 * P.N;
-        const double step = P.T[(size_t)id.b * P.N + id.i] * P.inv_K;
+        bool staged = true;
+        if constexpr (FUSED) if (P.host_T) staged = stage_wait(P, id.b * P.N + id.i);
+        if (!staged && P.stats) atomicMax(&P.stats[4], 1ull);
+        const PieceIn pin = piece_in(P, id.b, id.i);
+        const double *c = pin.c;
+        const int ld = pin.ld;
+        const double step = pin.T * P.inv_K;
         Basis B;
         poly_basis(id.j * step, B);
         const d3 pos = ct_beta(c, ld, B.b0), vel = ct_beta<1>(c, ld, B.b1), acc = ct_beta<2>(c, ld, B.b2);
@@ -691,10 +740,19 @@ template <bool EARLY, bool XF> __device__ __forceinline__ void tail_piece(const 
             return;
         }
     } else {
-    const double *c = P.coeffs + (size_t)b * 18 * P.N + 6 * i;
-    const int ld = 6 * P.N;
+    if constexpr (!EARLY) {
+        if (P.host_T) {          // host-direct step: this piece's inputs come through the staging buffer
+            __shared__ int s_staged;
+            if (tid == 0) s_staged = stage_wait(P, gp) ? 1 : 0;
+            __syncthreads();
+            lost = lost || !s_staged;
+        }
+    }
+    const PieceIn pin = piece_in(P, b, i);
+    const double *c = pin.c;
+    const int ld = pin.ld;
     const double integral_frac = P.inv_K;
-    const double step = P.T[(size_t)b * P.N + i] * integral_frac;
+    const double step = pin.T * integral_frac;
     double colsum = 0.0;   // threads 0..19: running sum of their output column, samples in ascending order
     unsigned long long tl_c0 = 0, tl_marks = 0;
     if (dbg && tid == 0) { dbg[0] = wall_clock64(); tl_c0 = clock64(); }
@@ -822,6 +880,7 @@ template <bool EARLY, bool XF> __device__ __forceinline__ void tail_piece(const 
     }
     if (dbg && tid == 0) { dbg[2] = tl_marks; dbg[3] = (clock64() - tl_c0) >> 4; }
 #undef TL_MARK
+    if (P.host_flag) lost = __syncthreads_or(lost ? 1 : 0) != 0;      // host-direct step: the overflow word must be up before the piece's cost is
     if (tid < PARTIAL_STRIDE) {
         const int q = tid;
         if (q < 19) {
@@ -834,6 +893,11 @@ template <bool EARLY, bool XF> __device__ __forceinline__ void tail_piece(const 
         } else {
             // Trajectory cost = fixed-order sum of the piece costs: each workgroup publishes its piece's cost in the piece's slot
             // (multi-GPU step: in the piece's cost slot of EVERY rank's board, this rank's included)
+            // host-direct step: `out` is host-mapped memory - the rows above (same wavefront, lanes 0..18) went over PCIe and
+            // have to be there before the collector, which waits for this cost, tells the host that the trajectory is
+            // complete.  (Measured against the alternative - rows into device memory, the collector copying the whole
+            // trajectory to the host in one coalesced sweep: 3 us slower, its copy sits on the critical path.)
+            if (P.host_flag) { if (lost && P.stats) atomicMax(&P.stats[4], 1ull); __builtin_amdgcn_fence(__ATOMIC_RELEASE, ""); }
             if constexpr (XF) {
                 for (int r = 0; r < P.xf.world; r++) xslot_publish(P.xf.board[r] + ((size_t)P.xf.parity * n_all + gp) * XF_ROW + 19, colsum);
             } else slot_publish(&P.piece_cost[gp], colsum);
@@ -881,6 +945,16 @@ template <bool EARLY, bool XF> __device__ __forceinline__ void tail_piece(const 
         sum = wave_sum(sum);
         if (__ballot(gone) != 0ull) { sum = __longlong_as_double(0x7FF8000000000000ll); if (tid == 0 && P.stats) atomicMax(&P.stats[4], 1ull); }
         if (tid == 0) o[0] = sum;
+    }
+    if constexpr (!XF) {
+        if (P.host_flag && collector && tid == 0) {
+            // every piece's rows were released (system scope) before its cost became visible above: after this acquire /
+            // release pair the host, once it sees the flag, sees the whole [cost | gradT | gradC] of the trajectory - the flag
+            // is the ONLY thing it waits for (no copy command, no stream synchronisation)
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            const unsigned long long ovf = P.stats ? __hip_atomic_load(&P.stats[4], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ull;
+            __hip_atomic_store(&P.host_flag[b], P.seq | (ovf ? HOST_FLAG_OVERFLOW : 0ull), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
     }
     if (dbg && tid == 0) dbg[1] = wall_clock64();
 }
