@@ -4,20 +4,26 @@
 Metric (BASELINE.json): SDF cost+grad point-evals/sec on a 256^3 map.  A "step" is one pass of the V3 ESDF-tile sweep
 (include/isdf_accel.h: isdf_eval_device) over every constraint sample of the trajectory; one "point-eval" is one sampled
 pose (piece i, sample j) incl. its kernel_size^3 ESDF tile.  Inputs are resident in HBM before the timed
-region; results stay on the device (the PCIe-inclusive host-API rate is reported separately as `host_api_ms`, never as
-`value`).
+region; results stay on the device (the PCIe-inclusive rate through the drop-in boundary is reported separately as
+`host_api_ms`, never as `value`).  Nothing but the steps is inside the timed region: kernel durations come from separate
+passes.
 
 Workload at 1 GPU = BASELINE.json configs[1]: one trajectory, 40 pieces x 64 intervals (65 samples / piece), 256^3 fp32 ESDF
 at 0.2 m, kernel_size 21, convex box robot (half extents 1.6/0.3/0.3 m, central-difference gradient).
-At N GPUs (weak scaling): one trajectory of 40*N pieces, pieces sharded contiguously across ranks, one all-reduce (RCCL)
-of the packed [cost | gradT | gradC] vector per step.
+At N > 1 GPUs = BASELINE.json configs[3]: ONE 400-piece trajectory, its pieces sharded contiguously across the ranks
+(50 per rank at 8), the one exchange of [cost | gradT | gradC] per step inside the step's launches (xGMI peer stores), as a
+one-shot exchange kernel, or as RCCL's all-reduce - whichever verifies, in that order; the RCCL figure is reported beside it.
+Total work is fixed (26 000 evals per step): strong scaling.  (`--weak`: 40 pieces per rank instead.)
 
 Launch: python bench.py [--gpus N --steps K --warmup W]; for N>1 via torch.distributed.run (one rank per GPU).
 """
 import argparse
+import hashlib
 import json
 import os
+import subprocess
 import sys
+import tempfile
 import time
 
 import numpy as np
@@ -26,7 +32,20 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 import __graft_entry__ as graft  # noqa: E402
 
-HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md
+HBM_PEAK_GBS = 8000.0        # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md
+FP64_VALU_PEAK_TFLOPS = 78.6  # fp64 vector peak: half the 157.3 TFLOP/s fp32 vector rate of the same guide
+N_SIMD = 1024                # 256 CUs x 4 SIMDs
+PEAK_CLOCK_HZ = 2.4e9        # max shader clock (same guide)
+
+
+def kernel_source_hash():
+    """sha256 over the sources the step's dominant kernel is compiled from: PMC counters measured on another version of them
+    are not reported (profiles/pmc_counters.json carries the hash it was measured on)."""
+    h = hashlib.sha256()
+    for f in ("tile_sweep.hip", "dev_math.hpp", "dev_shapes.hpp", "dev_mesh.hpp", "isdf_internal.hpp"):
+        with open(os.path.join(ROOT, "implicit-sdf-planner_amd", "csrc", f), "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]
 
 
 def compulsory_bytes(T, cm, N, K, k, grid, res):
@@ -60,16 +79,47 @@ def build_workload(pkg, n_pieces, grid_n, res, seed_map=12345, seed_traj=777):
     return occ, esdf, T, synth.colmajor(Cf)
 
 
+def native_boundary_ms(pkg, eng, N, T, cm, x0):
+    """isdf_eval and the lmbm_evaluate_t callback as a C++ caller sees them: timed inside the compiled reference-side
+    binding (tests/native/binding_stub.cpp, built here with g++) - ctypes marshalling costs as much as the call itself.
+    Returns (eval_ms, callback_ms) medians, or None when no compiler is at hand."""
+    import ctypes as C
+    try:
+        out = os.path.join(tempfile.mkdtemp(), "libbinding_stub.so")
+        libdir = os.path.dirname(pkg.capi.LIB_PATH)
+        subprocess.check_call(["g++", "-O2", "-std=c++14", "-fPIC", "-shared", "-I", os.path.join(ROOT, "include"),
+                               "-I", os.path.join(ROOT, "oracle", "ref_build", "eigen_shim"),
+                               os.path.join(ROOT, "tests", "native", "binding_stub.cpp"), "-o", out,
+                               "-L", libdir, "-lisdf_accel", f"-Wl,-rpath,{libdir}"], stderr=subprocess.DEVNULL)
+        stub = C.CDLL(out)
+    except Exception:
+        return None
+    dp = C.POINTER(C.c_double)
+    stub.stub_time_eval.argtypes = [C.c_void_p, C.c_int, dp, dp, C.c_int, dp]
+    stub.stub_time_callback.argtypes = [C.c_void_p, C.c_int, dp, C.c_int, dp, dp]
+    lat = np.zeros(1000)
+    if stub.stub_time_eval(eng.h, N, T.ctypes.data_as(dp), cm.ctypes.data_as(dp), lat.size, lat.ctypes.data_as(dp)) != 0:
+        return None
+    cb = None
+    if x0 is not None:
+        cbl = np.zeros(500); cst = np.zeros(1)
+        stub.stub_time_callback(eng.h, x0.size, x0.ctypes.data_as(dp), cbl.size, cbl.ctypes.data_as(dp), cst.ctypes.data_as(dp))
+        cb = float(np.median(cbl)) * 1e-3
+    return float(np.median(lat)) * 1e-3, cb
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--pieces-per-gpu", type=int, default=40)
+    ap.add_argument("--pieces", type=int, default=0, help="pieces of the trajectory (default: 40 at 1 GPU = configs[1], 400 at N > 1 = configs[3])")
+    ap.add_argument("--weak", action="store_true", help="N > 1: 40 pieces per rank (weak scaling) instead of the fixed 400-piece trajectory")
     ap.add_argument("--grid", type=int, default=256)
     ap.add_argument("--kernel-size", type=int, default=21)
     ap.add_argument("--cull", type=int, default=0, help="1: enable the V3 whole-tile cull (reported separately, never as value)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extra-configs", action="store_true", help="skip the C3 / C4 / 512^3 entries of `configs`")
     ap.add_argument("--lbfgs-iters", type=int, default=40, help="iterations of the L-BFGS driver timed after the sweep (0: skip)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     args = ap.parse_args()
@@ -99,7 +149,13 @@ def main():
         par.init_process_group(backend, device=dev)     # "nccl" == RCCL on ROCm
     res = 0.2 * 256.0 / args.grid if args.grid != 256 else 0.2
     K = 64
-    n_pieces = args.pieces_per_gpu * world
+    if args.pieces > 0:
+        n_pieces = args.pieces
+    elif world == 1:
+        n_pieces = 40                    # configs[1]
+    else:
+        n_pieces = 40 * world if args.weak else 400      # configs[3]: ONE 400-piece trajectory
+    scaling = "weak" if (world > 1 and args.weak) else "strong"
     occ, esdf, T, cm = build_workload(pkg, n_pieces, args.grid, res)
     shape = synth.bench_box_shape()
     cfg = synth.default_config(capi.V3_ESDF_TILE, device=local_rank, kernel_size=args.kernel_size, integral_intervs=K,
@@ -120,7 +176,7 @@ def main():
     # over xGMI (csrc/xchg.hip) is used when it sets up and verifies against the group's all-reduce on this node; otherwise
     # (or with ISDF_NO_XGMI_EXCHANGE=1) RCCL's all_reduce.
     xchg = None
-    if world > 1:
+    if world > 1 and os.environ.get("ISDF_NO_XGMI_EXCHANGE") != "1":
         xchg = par.XgmiExchange(eng, eng.out_stride(N), dev)
         if not xchg.ok:
             if rank == 0:
@@ -130,11 +186,11 @@ def main():
     def eval_only():
         eng.eval_device(1, N, d_T.data_ptr(), d_C.data_ptr(), d_out.data_ptr(), 0, stream)
 
-    # Preferred: the exchange INSIDE the step's one launch (isdf_xchg_fuse: the owning workgroups store their rows into the
+    # Preferred: the exchange INSIDE the step's launches (isdf_xchg_fuse: the owning workgroups store their rows into the
     # peers' outputs) - used when it reproduces "step + the group's all-reduce" on every rank.
     in_kernel = bool(xchg is not None and os.environ.get("ISDF_NO_FUSED_EXCHANGE") != "1" and xchg.try_fused_step(eval_only, d_out))
 
-    def make_step(mode):       # "fused": exchange inside the launch | "xchg": one-shot peer-to-peer kernel | "rccl"
+    def make_step(mode):       # "fused": exchange inside the launches | "xchg": one-shot peer-to-peer kernel | "rccl"
         def step():
             eval_only()
             if world > 1 and mode != "fused":
@@ -144,30 +200,27 @@ def main():
                     par.allreduce_packed(d_out)
         return step
 
-    def timed(step):
+    def timed(step, steps):
+        """warm-up, then EXACTLY `steps` steps between barrier + synchronize on both sides; nothing else in the region.  Also
+        returns the region's duration on the launch stream itself (HIP events: torch's current stream IS the stream handed to
+        isdf_eval_device) / steps - for a one-launch step that bounds the kernel's duration from above without touching it."""
         for _ in range(args.warmup):
             step()
         torch.cuda.synchronize()
-        eng.profile_enable(8)      # HIP events around the dominant kernel on every 8th step of the timed region
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
-        # ... and one pair of HIP events around the whole timed region on the launch stream (torch's current stream IS the
-        # stream handed to isdf_eval_device): steps are serialised on it, so region / steps bounds the kernel's duration from
-        # above without touching any dispatch
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         t0 = time.perf_counter()
         e0.record()
-        for _ in range(args.steps):
+        for _ in range(steps):
             step()
         e1.record()
         torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
         t1 = time.perf_counter()
-        n_l, k_ms = eng.profile_read()
-        eng.profile_enable(0)
-        return t1 - t0, n_l, (k_ms, e0.elapsed_time(e1) / args.steps)
+        return t1 - t0, e0.elapsed_time(e1) / steps
 
     def any_rank(flag):
         t = torch.tensor([int(flag)], dtype=torch.int32, device=dev)
@@ -175,19 +228,19 @@ def main():
         return int(t.item()) != 0
 
     mode = "none" if world == 1 else ("fused" if in_kernel else ("xchg" if xchg else "rccl"))
-    names = {"none": "none", "fused": "in-kernel peer-to-peer exchange over xGMI (rows stored into the peers' outputs by the owning workgroups of the fused launch), verified against RCCL at start-up",
+    names = {"none": "none", "fused": "in-kernel peer-to-peer exchange over xGMI (rows stored into the peers' outputs by the owning workgroups of the step's launches), verified against RCCL at start-up",
              "xchg": "xgmi peer-to-peer one-shot sum (csrc/xchg.hip), verified against RCCL at start-up", "rccl": "RCCL all_reduce"}
-    elapsed, n_launch, kern_ms = timed(make_step(mode))
+    elapsed, region_ms = timed(make_step(mode), args.steps)
     # a bounded wait that timed out anywhere invalidates the run: measure again one level down
     if mode == "fused" and any_rank(eng.stats()["overflow"] != 0 or not np.isfinite(float(d_out[0].item()))):
         eng.xchg_fuse(False)
         mode = "xchg"
-        elapsed, n_launch, kern_ms = timed(make_step(mode))
+        elapsed, region_ms = timed(make_step(mode), args.steps)
         names["xchg"] += " (the in-kernel exchange timed out and was abandoned)"
     if mode == "xchg" and any_rank(eng.xchg_status()):
         mode = "rccl"
         names["rccl"] = "RCCL all_reduce (the peer-to-peer exchange timed out and was abandoned)"
-        elapsed, n_launch, kern_ms = timed(make_step(mode))
+        elapsed, region_ms = timed(make_step(mode), args.steps)
     collective = names[mode]
     if world > 1:
         tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
@@ -200,38 +253,82 @@ def main():
     stats = eng.stats()
     out_gpu = d_out.cpu().numpy().copy()
 
-    # roofline of the dominant kernel (sweep_kernel): algorithmic bytes of the samples THIS rank's launch processed
+    # the same trajectory with the exchange done by RCCL, for comparison (shorter; after the headline run)
+    rccl_ms = None
+    if world > 1 and mode != "rccl":
+        if mode == "fused":
+            eng.xchg_fuse(False)
+        el2, _ = timed(make_step("rccl"), max(20, args.steps // 4))
+        t2 = torch.tensor([el2], dtype=torch.float64, device=dev)
+        dist.all_reduce(t2, op=dist.ReduceOp.MAX)
+        rccl_ms = 1e3 * float(t2.item()) / max(20, args.steps // 4)
+        if mode == "fused":
+            eng.xchg_fuse(True)
+
+    # ---- duration of the dominant kernel, in a SEPARATE pass (events attached to every dispatch cost the stream 1-3 us each)
+    eng.profile_enable(1)
+    for _ in range(40):
+        eval_only()
+    torch.cuda.synchronize()
+    n_launch, kern_ms_dispatch = eng.profile_read()
+    eng.profile_enable(0)
+    evals_this_rank = (par.shard_range(N, rank, world)[1] - par.shard_range(N, rank, world)[0]) * (K + 1)
+    one_launch = evals_this_rank // 4 + (N // world) <= 768 and world == 1
+    # two live bounds of the kernel's duration, both from above: the dispatch-attached events (an instrumented dispatch runs
+    # 1-3 us longer than a plain one) and - when the step IS one launch - the timed region's own stream duration / steps
+    kern_ms = min(kern_ms_dispatch, region_ms) if (one_launch and kern_ms_dispatch > 0) else (kern_ms_dispatch if kern_ms_dispatch > 0 else region_ms)
     B = algorithmic_bytes_per_eval(args.kernel_size)
-    evals_this_rank = (N // world) * (K + 1)
-    # duration of the dominant kernel: two live measurements, both upper bounds - (a) start/stop events attached to the
-    # dispatch itself on every 8th step (an instrumented dispatch runs 1-3 us longer than a plain one: its mean exceeds even
-    # the step period when the step is a single launch), (b) the region events / steps (kernel + inter-launch gap; exact up
-    # to that gap when the step is ONE launch, i.e. the fused step).  The smaller of the two is used; rocprofv3's average of
-    # the same command is committed under profiles/.
-    kern_ms_dispatch, kern_ms_region = kern_ms
-    kern_ms = min(kern_ms_dispatch, kern_ms_region) if kern_ms_dispatch > 0 else kern_ms_region
     achieved = (evals_this_rank * B) / (kern_ms * 1e-3) / 1e9 if kern_ms > 0 else 0.0
-    # measured HBM traffic of the same kernel (bytes per launch): from the committed rocprofv3 PMC passes of this very
-    # command (profiles/hbm_traffic.json, written by tools/pmc_traffic.py; FETCH_SIZE x2 gfx950 correction + WRITE_SIZE)
+
+    # ---- what the counters say (profiles/pmc_counters.json: rocprofv3 PMC passes of THIS command, tools/profile_round.sh),
+    # used only while the kernel sources are the ones it was measured on
     traffic = None
-    tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")
-    if world == 1 and os.path.exists(tpath):
+    issue = None
+    hbm_meas = None
+    bound = "unknown (no counters for this version of the kernel; nominal figure only)"
+    tpath = os.path.join(ROOT, "profiles", "pmc_counters.json")
+    if world == 1 and N == 40 and args.grid == 256 and args.kernel_size == 21 and os.path.exists(tpath):
         try:
             with open(tpath) as f:
-                tj = json.load(f)
-            if tj.get("pieces") == N and tj.get("kernel_size") == args.kernel_size and tj.get("grid") == args.grid:
-                traffic = tj.get("sweep_kernel_bytes_per_launch")
-        except Exception:
-            traffic = None
+                pj = json.load(f)
+            if pj.get("source_hash") == kernel_source_hash():
+                c = pj["counters"]
+                traffic = int(round((2.0 * c["FETCH_SIZE"] + c["WRITE_SIZE"]) * 1024))        # gfx950: FETCH_SIZE x 2 (guide, HBM)
+                k_us = pj["avg_kernel_us"]
+                hbm_meas = traffic / (k_us * 1e-6) / 1e9
+                # kernel duration in shader cycles at the 2.4 GHz peak clock (GRBM_GUI_ACTIVE also counts the dispatch overhead
+                # around a 20 us kernel; a lower actual clock makes the busy fractions below slightly LOW, never high)
+                cyc = k_us * 1e-6 * PEAK_CLOCK_HZ
+                f64 = c["SQ_INSTS_VALU_ADD_F64"] + c["SQ_INSTS_VALU_MUL_F64"] + c["SQ_INSTS_VALU_FMA_F64"] + c["SQ_INSTS_VALU_TRANS_F64"]
+                flops64 = (c["SQ_INSTS_VALU_ADD_F64"] + c["SQ_INSTS_VALU_MUL_F64"] + 2 * c["SQ_INSTS_VALU_FMA_F64"] + c["SQ_INSTS_VALU_TRANS_F64"]) * 64
+                issue = {"valu_issue_busy_frac": round(4.0 * c["SQ_ACTIVE_INST_VALU"] / (N_SIMD * cyc), 4),
+                         "any_inst_active_frac_of_wave_cycles": round(c["SQ_ACTIVE_INST_ANY"] / c["SQ_WAVE_CYCLES"], 4),
+                         "wait_frac_of_wave_cycles": round(c["SQ_WAIT_ANY"] / c["SQ_WAVE_CYCLES"], 4),
+                         "issue_stall_frac_of_wave_cycles": round(c["SQ_WAIT_INST_ANY"] / c["SQ_WAVE_CYCLES"], 4),
+                         "waves_per_simd_avg": round(4.0 * c["SQ_WAVE_CYCLES"] / (N_SIMD * cyc), 3),
+                         "valu_insts_per_launch": int(c["SQ_INSTS_VALU"]), "fp64_share_of_valu_insts": round(f64 / c["SQ_INSTS_VALU"], 4),
+                         "salu_insts_per_launch": int(c["SQ_INSTS_SALU"]),
+                         "fp64_tflops_upper": round(flops64 / (k_us * 1e-6) / 1e12, 3), "fp64_valu_peak_tflops": FP64_VALU_PEAK_TFLOPS,
+                         "fp64_frac_of_peak_upper": round(flops64 / (k_us * 1e-6) / 1e12 / FP64_VALU_PEAK_TFLOPS, 4),
+                         "peak": "1.0 = a VALU instruction issuing on every SIMD in every cycle (fp64 instructions hold the SIMD 4 cycles each)",
+                         "kernel_us_under_rocprof": round(k_us, 3), "clock_assumed_ghz": PEAK_CLOCK_HZ / 1e9,
+                         "measured_on_commit": pj.get("commit"), "source": "profiles/pmc_counters.json"}
+                bound = ("valu-issue" if issue["valu_issue_busy_frac"] > hbm_meas / HBM_PEAK_GBS else "hbm") + \
+                        " (by the counters: see roofline_issue / hbm_frac_measured; the `frac` below is SURVEY 8(d)'s nominal byte model, not traffic)"
+        except Exception as e:          # noqa: BLE001
+            bound = f"unknown (counter file unreadable: {e})"
     # SURVEY.md 8(d) asks for the COMPULSORY lower bound next to the algorithmic figure: the unique voxels that the tiles of
     # this rank's launch touch (neighbouring samples' tiles overlap heavily) x 4 B, plus the per-sample inputs / outputs
     compulsory = None
     if world == 1:
         compulsory = compulsory_bytes(T, cm, N, K, args.kernel_size, args.grid, res)
-    roofline = {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+    roofline = {"bound": bound, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+                "definition": "achieved = ALGORITHMIC bytes (SURVEY 8(d): k^3 x 4 B tile + corners + coefficients + outputs per eval) x evals per launch / kernel duration - a work-rate proxy; the kernel reads a 1-bit qualifier grid, its real HBM traffic is `traffic` (PMC)",
+                "hbm_frac_measured": None if hbm_meas is None else round(hbm_meas / HBM_PEAK_GBS, 5),
+                "hbm_gbs_measured": None if hbm_meas is None else round(hbm_meas, 1),
                 "kernel": "sweep_kernel", "kernel_ms": round(kern_ms, 5), "launches": n_launch,
-                "kernel_ms_dispatch_events": round(kern_ms_dispatch, 5), "kernel_ms_region_events": round(kern_ms_region, 5),
+                "kernel_ms_dispatch_events": round(kern_ms_dispatch, 5), "kernel_ms_region_events": round(region_ms, 5),
                 "algorithmic_bytes_per_eval": B, "algorithmic_bytes_per_launch": evals_this_rank * B,
                 "compulsory_bytes_per_launch": compulsory,
                 # secondary figure of SURVEY 8(d): robot-SDF evaluations per second inside the tiles (every pair costs one
@@ -240,32 +337,91 @@ def main():
 
     result = None
     if rank == 0:
-        # host-API (PCIe-inclusive, synchronous, accumulate) latency — informational
+        # ---- the other single-GPU configurations SURVEY 7 names as the memory-side-heavy ones, same JSON (device resident)
+        extra = None
+        if world == 1 and not args.no_extra_configs:
+            extra = []
+
+            def run_cfg(name, e, n_traj, Np, Ts, Cs, steps, kk=args.kernel_size):
+                dT = torch.from_numpy(Ts).to(dev); dC = torch.from_numpy(Cs).to(dev)
+                dO = torch.zeros(n_traj * e.out_stride(Np), dtype=torch.float64, device=dev)
+                for _ in range(5):
+                    e.eval_device(n_traj, Np, dT.data_ptr(), dC.data_ptr(), dO.data_ptr(), 0, stream)
+                torch.cuda.synchronize(); t0 = time.perf_counter()
+                for _ in range(steps):
+                    e.eval_device(n_traj, Np, dT.data_ptr(), dC.data_ptr(), dO.data_ptr(), 0, stream)
+                torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / steps
+                units = n_traj * Np * (K + 1)
+                nom = units * algorithmic_bytes_per_eval(kk) / dt / 1e9
+                extra.append({"name": name, "evals_per_step": units, "ms_per_step": round(dt * 1e3, 5), "evals_per_s": round(units / dt, 1),
+                              "nominal_gbs": round(nom, 1), "nominal_frac": round(nom / HBM_PEAK_GBS, 4)})
+
+            Ts, Cs = [], []
+            ext = np.array(occ.shape) * res
+            for b in range(128):
+                Tb, Cf = synth.random_trajectory(ext, 40, seed=777 + b, piece_T=1.0, jitter=0.5, margin=4.0, occ=occ, res=res)
+                Ts.append(Tb); Cs.append(synth.colmajor(Cf))
+            run_cfg("C3 (configs[2]): 128 trajectories x 40 pieces, shared 256^3 map, one batched launch pair", eng, 128, 40, np.concatenate(Ts), np.concatenate(Cs), 20)
+            _, _, T4, cm4 = build_workload(pkg, 400, args.grid, res)
+            run_cfg("C4 on ONE GPU (configs[3]'s trajectory unsharded): 1 x 400 pieces", eng, 1, 400, T4, cm4, 50)
+            # 512^3 map at 0.1 m (512 MiB fp32 ESDF, built on the device), the robot and the tile halved with the voxel
+            try:
+                res5 = 0.1
+                occ5 = synth.random_box_map((512,) * 3, res=res5, occupancy=0.15, seed=12345, edge=(0.4, 2.0))
+                cfg5 = synth.default_config(capi.V3_ESDF_TILE, device=local_rank, kernel_size=21, integral_intervs=K, safety_hor=(3 ** 0.5 / 2) * res5,
+                                            weight_p=4000.0, smoothing_eps=0.01, enable_dyn=1, enable_pos=1)
+                e5 = pkg.Engine(cfg5)
+                e5.set_grid(occ5, (0, 0, 0), res5, capi.GRID_OCCUPANCY)
+                e5.generate_esdf()
+                e5.set_shape(synth.make_shape("Box", params=(0.8, 0.15, 0.15), grad_mode=capi.GRAD_CENTRAL, bound_radius=0.83,
+                                              bbox=((0, 0, 0), (0.8, 0.15, 0.15))))
+                ext5 = np.array(occ5.shape) * res5
+                Ts, Cs = [], []
+                for b in range(128):
+                    Tb, Cf = synth.random_trajectory(ext5, 40, seed=900 + b, piece_T=1.0, jitter=0.5, margin=4.0, occ=occ5, res=res5)
+                    Ts.append(Tb); Cs.append(synth.colmajor(Cf))
+                run_cfg("512^3 map @ 0.1 m (512 MiB fp32 ESDF built on the device), 1 x 40 pieces, robot and tile scaled with the voxel", e5, 1, 40, Ts[0], Cs[0], 100)
+                run_cfg("512^3 map @ 0.1 m, batch of 128 x 40 pieces", e5, 128, 40, np.concatenate(Ts), np.concatenate(Cs), 20)
+                del e5
+            except Exception as e:      # noqa: BLE001
+                extra.append({"name": "512^3 map", "error": str(e)})
+
+        # ---- through the drop-in boundary (PCIe inclusive, synchronous, accumulate) - informational, never `value`
         host_ms = None
+        host_timer = None
+        cb_native_ms = None
+        x0 = None
+        c6 = cm.reshape(3, 6 * N).T.reshape(N, 6, 3)
         if world == 1:
             eng.set_shard(0, 1)
-            eng.eval_single(T, cm)
-            th0 = time.perf_counter()
-            for _ in range(20):
-                eng.eval_single(T, cm)
-            host_ms = 1e3 * (time.perf_counter() - th0) / 20
-
-        # second half of BASELINE.json's metric: "L-BFGS iter ms" - the optimizer driver (isdf_optimize_lbfgs) on the
-        # full objective callback (host MINCO + the device sweeps), same map / robot / piece count.  Informational.
-        lbfgs = None
-        if world == 1 and args.lbfgs_iters > 0:
-            c6 = cm.reshape(3, 6 * N).T.reshape(N, 6, 3)
             head = np.stack([c6[0, 0], c6[0, 1], 2.0 * c6[0, 2]], axis=1)
             tl = T[-1]
             pw = lambda k: sum(np.prod([p - q for q in range(k)]) * c6[N - 1, p] * tl ** (p - k) for p in range(k, 6))
             tail = np.stack([pw(0), pw(1), pw(2)], axis=1)
             eng.set_trajectory(N, head, tail, 1000.0)
             x0 = eng.pack_variables(T, c6[1:, 0, :])
+            nat = native_boundary_ms(pkg, eng, N, T, cm, x0)
+            if nat is not None:
+                host_ms, cb_native_ms = nat
+                host_timer = "native: median of 1000 isdf_eval calls inside the compiled reference-side binding (tests/native/binding_stub.cpp)"
+            else:
+                eng.eval_single(T, cm)
+                th0 = time.perf_counter()
+                for _ in range(20):
+                    eng.eval_single(T, cm)
+                host_ms = 1e3 * (time.perf_counter() - th0) / 20
+                host_timer = "python/ctypes (no C++ compiler at hand): includes ~15 us of marshalling per call"
+
+        # second half of BASELINE.json's metric: "L-BFGS iter ms" - the optimizer driver (isdf_optimize_lbfgs) on the
+        # full objective callback (host MINCO + the device sweeps), same map / robot / piece count.  Informational.
+        lbfgs = None
+        if world == 1 and args.lbfgs_iters > 0:
             c_first = eng.cost_function(x0)[0]
             xo, r = eng.optimize_lbfgs(x0, max_iterations=args.lbfgs_iters, g_epsilon=0.0, past=0)
             lbfgs = {"iterations": r["iterations"], "evaluations": r["evaluations"], "status": r["status"],
                      "ms_per_iteration": round(r["wall_ms"] / max(1, r["iterations"]), 4),
                      "ms_per_evaluation": round(r["wall_ms"] / max(1, r["evaluations"]), 4),
+                     "callback_ms_native": None if cb_native_ms is None else round(cb_native_ms, 4),
                      "cost_first": c_first, "cost_last": r["f"]}
 
         # measured HBM copy rate of this box next to the spec peak the roofline uses
@@ -318,15 +474,17 @@ def main():
         result = {
             "metric": "SDF cost+grad point-evals/sec", "value": round(value, 1), "unit": "point-evals/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 5),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "higher_is_better": True, "scaling": scaling, "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": f"V3 ESDF-tile sweep: 1 trajectory x {N} pieces x {K + 1} samples/piece, {args.grid}^3 fp32 ESDF "
                                    f"@ {res:g} m, kernel_size {args.kernel_size}, box robot (1.6,0.3,0.3) central-diff grad, "
-                                   f"cull {'on' if args.cull else 'off'}",
+                                   f"cull {'on' if args.cull else 'off'}"
+                                   + ("" if world == 1 else (f" = BASELINE configs[3], {N // world}-{-(-N // world)} pieces per rank" if N == 400 else "")),
                        "pieces": N, "samples_per_piece": K + 1, "grid": args.grid, "kernel_size": args.kernel_size,
-                       "sharding": ("none" if world == 1 else ("pieces contiguous by rank; each piece's 19 rows + cost stored by its owner into every peer's output inside the step's launch" if mode == "fused" else "pieces contiguous by rank + all_reduce(sum) of 1+19N doubles")),
-                       "collective": collective},
-            "roofline": roofline, "cpu_baseline": cpu,
-            "parity_rel_err_vs_oracle": parity, "host_api_ms": None if host_ms is None else round(host_ms, 4),
+                       "sharding": ("none" if world == 1 else ("pieces contiguous by rank; each piece's 19 rows + cost stored by its owner into every peer's output inside the step's launches" if mode == "fused" else "pieces contiguous by rank + all_reduce(sum) of 1+19N doubles")),
+                       "collective": collective,
+                       "rccl_all_reduce_ms_per_step": None if rccl_ms is None else round(rccl_ms, 5)},
+            "roofline": roofline, "roofline_issue": issue, "cpu_baseline": cpu, "configs": extra,
+            "parity_rel_err_vs_oracle": parity, "host_api_ms": None if host_ms is None else round(host_ms, 4), "host_api_timer": host_timer,
             "stats_last_step_rank0": stats, "lbfgs": lbfgs, "hbm_copy_gbs_measured": hbm_copy,
         }
         print(json.dumps(result), flush=True)

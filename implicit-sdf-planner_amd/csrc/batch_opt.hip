@@ -91,6 +91,7 @@ extern "C" int isdf_optimize_lbfgs_batch(isdf_ctx *c, int n_traj, int N, const d
     if (!c) return ISDF_ERR_INVALID_ARG;
     if (n_traj < 1 || N < 1 || !heads_pva || !tails_pva || !x_inout || !p || !results) return isdf_fail(c, ISDF_ERR_INVALID_ARG, "bad batch arguments");
     if (c->cfg.variant == ISDF_V1_SWEPT) return isdf_fail(c, ISDF_ERR_UNSUPPORTED, "the batched optimizer drives the integral sweep (V2/V3)");
+    if (c->world > 1) return isdf_fail(c, ISDF_ERR_STATE, "sharded ctx: the batched optimizer would optimise on this rank's partial sums (shard the BATCH across ranks instead: one ctx per rank, isdf_set_shard(0, 1))");
     HIPCHK(c, hipSetDevice(c->device));
     Batch b;
     b.ctx = c; b.n_traj = n_traj; b.N = N; b.n = N + 3 * (N - 1); b.rho = rho;

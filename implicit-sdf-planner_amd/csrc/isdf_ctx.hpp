@@ -91,6 +91,8 @@ namespace isdf { struct XFuse; }
 bool isdf_xchg_fill(isdf_ctx *c, isdf::XFuse *xf, size_t pieces, int *err);
 bool isdf_xchg_fuse_on(const isdf_ctx *c);     // isdf_xchg_fuse(ctx, 1) is in force
 int isdf_reserve_sweep_buffers(isdf_ctx *c, long long total_pieces);   // isdf_host.hip: scratch of the integral sweep (grows only)
+void isdf_xchg_reset_board(isdf_ctx *c);  // xchg.hip: empties this rank's board again (after an overflow)
+int isdf_reset_result_slots(isdf_ctx *c); // isdf_host.hip: drains the device and empties every self-resetting slot again (after an overflow)
 void isdf_xchg_release(isdf_ctx *c);          // xchg.hip: closes the peer mappings, frees the mailbox (isdf_destroy)
 void isdf_frontend_release(isdf_ctx *c);      // frontend.hip: frees the tables (isdf_destroy)
 

@@ -413,6 +413,19 @@ int isdf_reserve_sweep_buffers(isdf_ctx *c, long long total_pieces) {
     return ISDF_OK;
 }
 
+// The result slots empty themselves only when their single consumer takes them.  Once a bounded wait has expired (overflow
+// word, NaN cost) a producer may still publish late into a slot nobody takes any more, and the NEXT step would consume that
+// stale value without any flag being raised.  Whoever sees the overflow word calls this: drain, then every slot empty again.
+int isdf_reset_result_slots(isdf_ctx *c) {
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipDeviceSynchronize());
+    if (c->d_acc) HIPCHK(c, hipMemset(c->d_acc, 0xFF, c->sample_cap * ACC_STRIDE * sizeof(double)));
+    if (c->d_piece_cost) HIPCHK(c, hipMemset(c->d_piece_cost, 0xFF, c->piece_cap * sizeof(double)));
+    isdf_xchg_reset_board(c);
+    HIPCHK(c, hipDeviceSynchronize());
+    return ISDF_OK;
+}
+
 // mode 0: the sweep cfg.variant names; 1: the swept-volume sweep; 2: the integral sweep with the collision term off
 // (modes 1 + 2 together are what costFunctionLmbm runs for the reference's live configuration)
 // host-direct step (see isdf_ctx.hpp): device-visible addresses of the pinned inputs / outputs / flags of this step
@@ -587,11 +600,12 @@ static int eval_device_impl(isdf_ctx *c, int n_traj, int N, const double *d_T, c
     const bool ev2 = ev && c->prof_secondary;
     // a small step (one trajectory) is ONE launch: the tail's workgroups ride behind the sweep's (tile_sweep.hip, FUSED)
     const bool fused = c->fuse_small && !ev2 && sweep_can_fuse(P);
-    {   // multi-GPU step with the exchange inside that launch (isdf_xchg_fuse): only possible when the step IS one launch
+    {   // multi-GPU step with the exchange inside the step's launches (isdf_xchg_fuse)
         int xerr = ISDF_OK;
         if (isdf_xchg_fill(c, &P.xf, (size_t)total_pieces, &xerr)) {
             if (xerr != ISDF_OK) return xerr;
-            if (!fused) { P.xf.world = 0; return fail(c, ISDF_ERR_UNSUPPORTED, "in-kernel exchange needs a step that runs as one fused launch"); }
+            // a step that is not one fused launch carries the exchange in its tail launch (tail_kernel_xf); a step without a
+            // collision term has no sweep launch either way
         }
     }
     if (hd) {
@@ -642,7 +656,11 @@ static int fetch_stats(isdf_ctx *c) {
     c->last_stats.n_units = (int64_t)h[0]; c->last_stats.n_units_culled = (int64_t)h[1];
     c->last_stats.n_pairs = (int64_t)h[2]; c->last_stats.n_grad_pairs = (int64_t)h[3];
     c->last_stats.overflow = (int32_t)h[4];
-    if (h[4]) HIPCHK(c, hipMemset(c->d_stats + 4, 0, sizeof(unsigned long long)));   // sticky until read
+    if (h[4]) {                                                                       // sticky until read
+        HIPCHK(c, hipMemset(c->d_stats + 4, 0, sizeof(unsigned long long)));
+        const int rr = isdf_reset_result_slots(c);                                      // a late producer must not feed the next step
+        if (rr) return rr;
+    }
     return ISDF_OK;
 }
 
@@ -777,7 +795,12 @@ extern "C" int isdf_eval(isdf_ctx *c, int n_traj, const int *N, const double *co
                 bool ovf = false;
                 rcd = direct_wait(c, c->stream, &ovf);
                 if (rcd) return rcd;
-                if (ovf) { overflow = true; HIPCHK(c, hipMemset(c->d_stats + 4, 0, sizeof(unsigned long long))); }
+                if (ovf) {
+                    overflow = true;
+                    HIPCHK(c, hipMemset(c->d_stats + 4, 0, sizeof(unsigned long long)));
+                    const int rr = isdf_reset_result_slots(c);
+                    if (rr) return rr;
+                }
                 const double *hout = c->h_dir + c->dir_in;
                 for (int b = 0; b < nb; b++) {
                     const double *o = hout + ostride * b;
@@ -824,7 +847,12 @@ extern "C" int isdf_eval(isdf_ctx *c, int n_traj, const int *N, const double *co
         HIPCHK(c, hipMemcpyAsync(hstat, c->d_stats, 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost, c->stream));
         if (dts) HIPCHK(c, hipMemcpyAsync(tstar_inout, dts, (size_t)c->M * sizeof(double), hipMemcpyDeviceToHost, c->stream));
         HIPCHK(c, hipStreamSynchronize(c->stream));
-        if (hstat[4]) { overflow = true; HIPCHK(c, hipMemset(c->d_stats + 4, 0, sizeof(unsigned long long))); }   // sticky until read
+        if (hstat[4]) {   // sticky until read; slots a late producer may still fill are emptied again
+            overflow = true;
+            HIPCHK(c, hipMemset(c->d_stats + 4, 0, sizeof(unsigned long long)));
+            const int rr = isdf_reset_result_slots(c);
+            if (rr) return rr;
+        }
         if (c->cfg.variant == ISDF_V1_SWEPT) {       // the V1 kernels count straight into the statistics words
             total.n_units += (int64_t)hstat[0]; total.n_units_culled += (int64_t)hstat[1];
             total.n_pairs += (int64_t)hstat[2]; total.n_grad_pairs += (int64_t)hstat[3];
@@ -961,7 +989,11 @@ static int cost_function_finish(isdf_ctx *c, double *g, double *cost_out, hipStr
         bool ovf = false;
         const int rcd = direct_wait(c, st, &ovf);
         if (rcd) return rcd;
-        if (ovf) { (void)hipMemset(c->d_stats + 4, 0, sizeof(unsigned long long)); return fail(c, ISDF_ERR_OVERFLOW, "a bounded device work list overflowed; result invalid"); }
+        if (ovf) {
+            (void)hipMemset(c->d_stats + 4, 0, sizeof(unsigned long long));
+            (void)isdf_reset_result_slots(c);
+            return fail(c, ISDF_ERR_OVERFLOW, "a bounded device work list overflowed; result invalid");
+        }
         res = c->h_dir + c->dir_in;
     } else {
         HIPCHK(c, hipSetDevice(c->device));
@@ -996,6 +1028,10 @@ static int cost_function_finish(isdf_ctx *c, double *g, double *cost_out, hipStr
 extern "C" int isdf_cost_function(isdf_ctx *c, const double *x, double *g, int n, double *cost_out) {
     if (!c) return ISDF_ERR_INVALID_ARG;
     if (!x || !g || !cost_out) return fail(c, ISDF_ERR_INVALID_ARG, "null argument");
+    // a sharded ctx returns only this rank's partial sums from the sweeps: the un-split callback (and the drivers built on it)
+    // would optimise on them without any error - the split form (_launch / all-reduce / _finish) is the one to use
+    if (c->world > 1 && !isdf_xchg_fuse_on(c))
+        return fail(c, ISDF_ERR_STATE, "sharded ctx: use isdf_cost_function_launch / _finish around the all-reduce (or switch the in-kernel exchange on)");
     const int rc = cost_function_launch(c, x, n, c->stream, true);
     if (rc) return rc;
     return cost_function_finish(c, g, cost_out, c->stream);

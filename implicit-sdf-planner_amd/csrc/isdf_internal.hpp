@@ -29,6 +29,9 @@ constexpr int XCHG_MAX_WORLD = 16;
 constexpr int XF_ROW = 20;
 struct XFuse {
     int world, rank, parity, pad;
+    unsigned long long parity_stride;   // doubles between the two parities' regions of a board: half the board, FIXED for the
+                                        // life of the exchange (a stride derived from the launch's piece count would make
+                                        // consecutive steps of different size overlap while a rank is one step ahead)
     double *board[XCHG_MAX_WORLD];
 };
 

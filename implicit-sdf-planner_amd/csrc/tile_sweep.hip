@@ -718,7 +718,7 @@ template <bool EARLY, bool XF> __device__ __forceinline__ void tail_piece(const 
     const size_t ostride = (size_t)1 + 19 * (size_t)P.N;
     const int p0 = max(P.piece_begin, b * P.N) - b * P.N, p1 = min(P.piece_end, (b + 1) * P.N) - b * P.N;   // this rank's pieces of trajectory b
     double *const o = P.out + (size_t)b * ostride;
-    double *const my_board = XF ? P.xf.board[P.xf.rank] + (size_t)P.xf.parity * n_all * XF_ROW : nullptr;
+    double *const my_board = XF ? P.xf.board[P.xf.rank] + (size_t)P.xf.parity * P.xf.parity_stride : nullptr;
     bool lost = false;     // a result slot that never arrived
     const bool mine = i >= p0 && i < p1;
     unsigned long long *const dbg = (P.dbg && mine) ? P.dbg + (size_t)(P.piece_end - P.piece_begin) * K1 * 8 + (size_t)(gp - P.piece_begin) * 4 : nullptr;
@@ -888,7 +888,7 @@ template <bool EARLY, bool XF> __device__ __forceinline__ void tail_piece(const 
             else { const int d = q / 6, r = q - 6 * d; o[1 + P.N + (size_t)d * 6 * P.N + 6 * i + r] = colsum; }
             if constexpr (XF) {               // the same row into every peer's board
                 for (int r = 0; r < P.xf.world; r++)
-                    if (r != P.xf.rank) xslot_publish(P.xf.board[r] + ((size_t)P.xf.parity * n_all + gp) * XF_ROW + q, colsum);
+                    if (r != P.xf.rank) xslot_publish(P.xf.board[r] + (size_t)P.xf.parity * P.xf.parity_stride + (size_t)gp * XF_ROW + q, colsum);
             }
         } else {
             // Trajectory cost = fixed-order sum of the piece costs: each workgroup publishes its piece's cost in the piece's slot
@@ -899,7 +899,7 @@ template <bool EARLY, bool XF> __device__ __forceinline__ void tail_piece(const 
             // trajectory to the host in one coalesced sweep: 3 us slower, its copy sits on the critical path.)
             if (P.host_flag) { if (lost && P.stats) atomicMax(&P.stats[4], 1ull); __builtin_amdgcn_fence(__ATOMIC_RELEASE, ""); }
             if constexpr (XF) {
-                for (int r = 0; r < P.xf.world; r++) xslot_publish(P.xf.board[r] + ((size_t)P.xf.parity * n_all + gp) * XF_ROW + 19, colsum);
+                for (int r = 0; r < P.xf.world; r++) xslot_publish(P.xf.board[r] + (size_t)P.xf.parity * P.xf.parity_stride + (size_t)gp * XF_ROW + 19, colsum);
             } else slot_publish(&P.piece_cost[gp], colsum);
         }
     }
@@ -962,6 +962,13 @@ template <bool EARLY, bool XF> __device__ __forceinline__ void tail_piece(const 
 __global__ __launch_bounds__(TL_THREADS) void tail_kernel(const SweepParams P) {
     __shared__ double s_val[TL_THREADS][PARTIAL_STRIDE + 1];   // +1: column reads by 20 threads hit distinct banks
     tail_piece<true, false>(P, (int)blockIdx.x, s_val);        // one workgroup per piece of the launch
+}
+// Multi-GPU step that is NOT one fused launch (a 50-piece shard of a 400-piece trajectory: 813 + 50 workgroups, beyond what is
+// resident at once; mesh robots; body offsets): the exchange rides in the tail launch instead - the workgroups of this
+// rank's pieces (dispatched first) store their rows into every peer's board, the others poll theirs out of this rank's.
+__global__ __launch_bounds__(TL_THREADS) void tail_kernel_xf(const SweepParams P) {
+    __shared__ double s_val[TL_THREADS][PARTIAL_STRIDE + 1];
+    tail_piece<true, true>(P, (int)blockIdx.x, s_val);
 }
 
 // Workgroups a fused launch may have: all of them resident at once, 3 per CU (the fused kernels' register budget).
@@ -1036,7 +1043,8 @@ void launch_build_bits(const DevGrid &G, int use_esdf, float thresh, unsigned *o
 }
 
 void launch_tail(const SweepParams &P, hipStream_t stream, hipEvent_t ev_start, hipEvent_t ev_stop) {
-    hipExtLaunchKernelGGL(tail_kernel, dim3(P.n_traj * P.N), dim3(TL_THREADS), 0, stream, ev_start, ev_stop, 0, P);
+    if (P.xf.world > 1) hipExtLaunchKernelGGL(tail_kernel_xf, dim3(P.n_traj * P.N), dim3(TL_THREADS), 0, stream, ev_start, ev_stop, 0, P);
+    else hipExtLaunchKernelGGL(tail_kernel, dim3(P.n_traj * P.N), dim3(TL_THREADS), 0, stream, ev_start, ev_stop, 0, P);
 }
 
 } // namespace isdf

@@ -72,7 +72,13 @@ __global__ __launch_bounds__(1024) void xchg_allreduce_kernel(XchgParams X, doub
         }
     }
     __syncthreads();
-    if (!s_ok) return;
+    if (!s_ok) {
+        // a peer was later than the bounded wait: buf still holds this rank's PARTIAL sums, and a late peer may well have
+        // received everybody's - make the failure visible in the data too (like the fused path does), not only in the status
+        // word: the caller sees a NaN cost and redoes the step on the group's all-reduce
+        if (blockIdx.x == 0 && threadIdx.x == 0) buf[0] = __longlong_as_double(0x7FF8000000000000ll);
+        return;
+    }
     __threadfence_system();
     // ---- sum in rank order (own contribution straight from buf); every rank performs the same additions
     const double *slots = X.peer_slots[X.rank] + (size_t)par * X.world * X.slot_doubles;
@@ -202,8 +208,21 @@ bool isdf_xchg_fill(isdf_ctx *c, isdf::XFuse *xf, size_t pieces, int *err) {
     if (!x->connected || x->rank != c->rank || x->world != c->world) { *err = isdf_fail(c, ISDF_ERR_STATE, "in-kernel exchange: shard and exchange disagree"); return true; }
     if ((size_t)2 * XF_ROW * pieces > x->board_doubles) { *err = isdf_fail(c, ISDF_ERR_INVALID_ARG, "in-kernel exchange: more pieces than the exchange was created for"); return true; }
     xf->world = x->world; xf->rank = x->rank; xf->parity = (int)(++x->fuse_seq & 1ull); xf->pad = 0;
+    xf->parity_stride = (unsigned long long)(x->board_doubles / 2);
     for (int r = 0; r < x->world; r++) xf->board[r] = (double *)((char *)x->peer_base[r] + x->board_offset);
     return true;
+}
+
+// After a bounded wait expired (overflow flag / NaN cost) a producer may still publish late into a slot nobody takes any
+// more; the next step of that parity would consume the stale value.  Called by the host whenever it has seen the overflow
+// word: the stream is drained and this rank's board is emptied again.  (The peers do the same when they see theirs; the
+// in-kernel exchange should be switched off after an overflow - parallel.py does.)
+void isdf_xchg_reset_board(isdf_ctx *c) {
+    isdf_xchg *x = c->xchg;
+    if (!x || !x->own) return;
+    (void)hipDeviceSynchronize();
+    (void)hipMemset((char *)x->own + x->board_offset, 0xFF, x->board_doubles * sizeof(double));
+    (void)hipDeviceSynchronize();
 }
 
 extern "C" int isdf_xchg_status(isdf_ctx *c) {

@@ -88,9 +88,11 @@ class XgmiExchange:
                 engine.xchg_allreduce(got.data_ptr(), n, stream)
                 torch.cuda.synchronize()
                 scale = float(ref.abs().max().item()) + 1e-300
+                # no early exit: every rank issues the same collectives in every round whatever it saw locally (failures are
+                # naturally one-sided - a time-out seen by one mailbox only - and a rank that left the loop would meet its
+                # peers' next all_reduce with _agree's)
                 if engine.xchg_status() != 0 or not bool(((got - ref).abs().max() <= 1e-12 * scale).item()):
                     good = 0; self.why = "verification against the group's all-reduce failed"
-                    break
             if not self._agree(good, self._pd):
                 raise RuntimeError(self.why or "verification failed on a peer")
             self.ok = True
@@ -125,11 +127,10 @@ class XgmiExchange:
             ref = out.to(self._pd).clone(); dist.all_reduce(ref); ref = ref.to(out.device)
             scale = float(ref.abs().max().item()) + 1e-300
             eng.xchg_fuse(True)
-            for _ in range(3):
+            for _ in range(3):            # all three on every rank (a rank that stopped early would leave its peers polling)
                 out.zero_(); step(); torch.cuda.synchronize()
                 if not bool(((out - ref).abs().max() <= 1e-12 * scale).item()) or eng.stats()["overflow"] != 0:
                     good = 0
-                    break
         except Exception:                 # noqa: BLE001 - e.g. ISDF_ERR_UNSUPPORTED: the step is not one fused launch
             good = 0
         fused = self._agree(good, self._pd)
@@ -174,6 +175,18 @@ def cost_function_allreduced(engine, x, exchange=None):
         pass                              # the exchange happened inside the sweep's launch (try_fused_step): already the full sums
     elif exchange is not None and exchange.ok:
         exchange.allreduce(part)          # one-shot peer-to-peer sum over xGMI (XgmiExchange)
+        # A bounded wait that expired leaves THIS rank with its partial sums (the kernel then writes a NaN cost and raises the
+        # status word) while a late peer may hold the full ones: the ranks agree on whether anybody saw that, and if so redo
+        # the step's sum on the group's all-reduce and stay there
+        torch.cuda.current_stream().synchronize()
+        bad = engine.xchg_status() != 0 or not bool(torch.isfinite(part[0]).item())
+        flag = torch.tensor([int(bad)], dtype=torch.int32, device=exchange._pd)
+        torch.distributed.all_reduce(flag, op=torch.distributed.ReduceOp.MAX)
+        if int(flag.item()) != 0:
+            exchange.ok = False
+            ptr, count = engine.cost_function_launch(x, stream)
+            part = torch.as_tensor(_DeviceDoubles(ptr, count), device=torch.device("cuda", torch.cuda.current_device()))
+            allreduce_packed(part)
     else:
         allreduce_packed(part)
     return engine.cost_function_finish(stream)

@@ -205,7 +205,13 @@ int isdf_eval(isdf_ctx *ctx, int n_traj, const int *N, const double *const *T,
 /* Device-resident entry point, asynchronous on `stream` (a hipStream_t passed as void*; NULL = default
  * stream).  All trajectories have N pieces.  d_T: n_traj*N, d_coeffs: n_traj * (6N x 3 col-major),
  * d_out: n_traj * (1 + N + 18N) doubles, OVERWRITTEN with [cost | gradT | gradC(col-major)] per trajectory
- * (shard-partial sums when a shard is set).  d_tstar: V1 only, M doubles, may be NULL. */
+ * (shard-partial sums when a shard is set).  d_tstar: V1 only, M doubles, may be NULL.
+ * Results change hands between workgroups through self-resetting slots behind BOUNDED waits (forward progress of a launch is
+ * not something the hardware contract promises): a wait that expires never hangs the stream - it raises the overflow word
+ * and leaves a NaN cost.  isdf_eval reports that as ISDF_ERR_OVERFLOW by itself; a caller of THIS entry point must look:
+ * a non-finite d_out[0], or isdf_get_stats(...).overflow != 0 (reading it drains the device, clears the word and empties
+ * every slot again, so that a producer that published late cannot feed the next step; the in-kernel exchange of a
+ * multi-GPU step should be switched off after an overflow, isdf_xchg_fuse(ctx, 0)). */
 int isdf_eval_device(isdf_ctx *ctx, int n_traj, int N, const double *d_T, const double *d_coeffs,
                      double *d_out, double *d_tstar, void *stream);
 size_t isdf_out_stride(int N);   /* 1 + N + 18N */
@@ -249,10 +255,11 @@ int isdf_cost_parts(const isdf_ctx *ctx, double parts[4]);
  * multi-GPU step - the workgroup that owns a piece stores its 19 output rows and its cost straight into every peer's board
  * (IPC-mapped, uncached), the peers' workgroups for that piece poll them into their own output, so on return every rank's
  * output holds the FULL [cost | gradT | gradC] (bitwise identical on all ranks) and no isdf_xchg_allreduce / ncclAllReduce
- * follows.  Requires isdf_set_shard(rank, world) equal to the exchange's, all ranks switching together and evaluating in
- * lock-step, and a step that runs as one fused launch (analytic shape with identity body offset, one trajectory or a small
- * batch); otherwise isdf_eval_device returns ISDF_ERR_UNSUPPORTED and the caller uses isdf_xchg_allreduce.  Waits are
- * bounded (about one second): a missing peer sets the overflow flag and a NaN cost instead of hanging the stream.
+ * follows.  A step that runs as one fused launch (analytic shape with identity body offset, one trajectory or a small batch)
+ * carries the exchange in that launch; any other step of the integral sweep (larger shards, body offsets, mesh robots) in its
+ * tail launch.  Requires isdf_set_shard(rank, world) equal to the exchange's, all ranks switching together and evaluating in
+ * lock-step.  Waits are bounded (about one second): a missing peer sets the overflow flag and a NaN cost instead of hanging
+ * the stream - after which the exchange should be switched off (the boards may be out of step).
  * Replaces: the reference has no multi-GPU path; SURVEY 8(e) "prefer one-shot P2P reduce over xGMI". */
 int isdf_xchg_fuse(isdf_ctx *ctx, int on);
 /* The sum of the ranks' packed vectors is the ONE exchange step of the sharded path.  Any all-reduce works (RCCL through

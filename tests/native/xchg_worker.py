@@ -101,6 +101,34 @@ for b in range(3):
 assert e2.stats()["overflow"] == 0
 e2.xchg_fuse(False)
 dist.barrier()
+# a step that is NOT one fused launch (here: a body offset; likewise shards beyond the residency limit, mesh robots) carries the
+# exchange in its tail launch (tail_kernel_xf)
+e5 = pkg.Engine(cfg); e5.set_grid(esdf, (0, 0, 0), 0.5, capi.GRID_ESDF)
+e5.set_shape(synth.make_shape("RoundedCone", params=(0.6, 0.25, 1.6), poly_params=(0.05, -0.02, 0.03, 10, -5, 20)))
+e5.set_shard(rank, world)
+x5 = par.XgmiExchange(e5, e5.out_stride(6), dev)
+assert x5.ok, x5.why
+out5 = torch.zeros(e5.out_stride(6), dtype=torch.float64, device=dev)
+def _step5():
+    e5.eval_device(1, 6, d_T.data_ptr(), d_C.data_ptr(), out5.data_ptr(), 0, st)
+_step5(); torch.cuda.synchronize()
+part5 = out5.cpu().clone(); dist.all_reduce(part5)
+assert float(part5[0]) > 0
+assert x5.try_fused_step(_step5, out5), "exchange in the tail launch did not reproduce step + all-reduce"
+for it in range(20):
+    out5.zero_(); _step5()
+    if it % 5 == rank % 5:
+        torch.cuda.synchronize()
+    if it % 6 == 0:
+        got = out5.cpu()
+        assert torch.allclose(got, part5, rtol=1e-12, atol=1e-12 * float(part5.abs().max())), (rank, it)
+        allv = [torch.zeros_like(got) for _ in range(world)]
+        dist.all_gather(allv, got)
+        assert all(torch.equal(allv[0], a) for a in allv), (rank, it)
+torch.cuda.synchronize()
+assert e5.stats()["overflow"] == 0
+e5.xchg_fuse(False)
+dist.barrier()
 # a peer that never shows up must not hang the stream: rank 0 runs one fused step ALONE - its polls run into their bound,
 # the step ends with the overflow flag and a NaN cost (last check: the boards are out of step afterwards)
 x4 = par.XgmiExchange(e2, e2.out_stride(6), dev)
