@@ -4,5 +4,5 @@ Host-side Python mirror of the C-ABI in include/isdf_accel.h.  The compute lives
 gfx950, built into lib/libisdf_accel.so); this package only marshals arrays.  Import name: ``isdf_amd``
 (the directory name contains a hyphen; __graft_entry__.load_package() registers the alias).
 """
-from . import capi, synth, parallel  # noqa: F401
+from . import capi, synth, parallel, fixtures  # noqa: F401
 from .engine import Engine, IsdfError, lbfgs_minimize  # noqa: F401

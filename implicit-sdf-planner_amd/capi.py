@@ -70,6 +70,15 @@ def frontend_config(kernel_size=13, max_roll=45.0, max_pitch=45.0, ang_res=9.0, 
     return c
 
 
+class IsdfPlanConfig(C.Structure):
+    """isdf_plan_config: what a plan needs from the reference's yaml files (include/isdf_accel.h)."""
+    _fields_ = [("sweep", IsdfConfig), ("frontend", IsdfFrontendConfig), ("occupancy_resolution", C.c_double),
+                ("sta_threshold", C.c_int32), ("threads_num", C.c_int32), ("rho", C.c_double), ("inittime", C.c_double),
+                ("momentum", C.c_double), ("traj_parlength", C.c_double), ("poly_params", C.c_double * 6),
+                ("offset_aabb", C.c_double * 3), ("box", C.c_double * 3), ("map_bound", C.c_double * 6),
+                ("inputdata", C.c_char * 256), ("pcdmapname", C.c_char * 128)]
+
+
 class IsdfLbfgsResult(C.Structure):
     _fields_ = [("f", C.c_double), ("wall_ms", C.c_double), ("status", C.c_int32), ("iterations", C.c_int32),
                 ("evaluations", C.c_int32), ("reserved", C.c_int32)]
@@ -90,6 +99,8 @@ EXPORTED_SYMBOLS = [
     "isdf_lbfgs_params_default", "isdf_lbfgs_minimize", "isdf_optimize_lbfgs", "isdf_optimize_lbfgs_batch",
     "isdf_set_pointcloud", "isdf_generate_esdf", "isdf_get_grid", "isdf_gather_points", "isdf_get_points", "isdf_shape_eval",
     "isdf_frontend_build", "isdf_frontend_get_shape_kernels", "isdf_frontend_get_map_kernel", "isdf_frontend_check", "isdf_frontend_cspace",
+    "isdf_read_pcd", "isdf_read_obj", "isdf_poly_rotation", "isdf_body_transform", "isdf_plan_config_default", "isdf_load_yaml_config",
+    "isdf_shape_from_config",
     "isdf_xchg_create", "isdf_xchg_connect", "isdf_xchg_allreduce", "isdf_xchg_fuse", "isdf_xchg_status", "isdf_xchg_destroy",
 ]
 
@@ -163,6 +174,15 @@ def load_library(path=None):
     lib.isdf_optimize_lbfgs_batch.argtypes = [C.c_void_p, C.c_int, C.c_int, dp, dp, C.c_double, dp, C.POINTER(IsdfLbfgsParams),
                                               C.POINTER(IsdfLbfgsResult), dp]
     lib.isdf_optimize_lbfgs.argtypes = [C.c_void_p, dp, C.c_int, C.POINTER(IsdfLbfgsParams), C.POINTER(IsdfLbfgsResult)]
+    lib.isdf_read_pcd.argtypes = [C.c_char_p, C.POINTER(C.c_float), C.c_longlong]
+    lib.isdf_read_pcd.restype = C.c_longlong
+    lib.isdf_read_obj.argtypes = [C.c_char_p, dp, C.c_int, C.POINTER(C.c_int32), C.c_int, ip, ip]
+    lib.isdf_poly_rotation.argtypes = [dp, dp]
+    lib.isdf_body_transform.argtypes = [dp, dp, C.c_int, dp, dp]
+    lib.isdf_plan_config_default.argtypes = [C.POINTER(IsdfPlanConfig)]
+    lib.isdf_plan_config_default.restype = None
+    lib.isdf_load_yaml_config.argtypes = [C.c_char_p, C.POINTER(IsdfPlanConfig)]
+    lib.isdf_shape_from_config.argtypes = [C.POINTER(IsdfShape), C.POINTER(IsdfPlanConfig), C.c_char_p, dp, C.c_int, C.POINTER(C.c_int32), C.c_int]
     if path is None:
         _lib = lib
     return lib

@@ -711,7 +711,7 @@ __global__ __launch_bounds__(256) void stats_kernel(const SweepParams P) {
 template <bool EARLY, bool XF> __device__ __forceinline__ void tail_piece(const SweepParams &P, const int t, double (*s_val)[PARTIAL_STRIDE + 1]) {
     const int K1 = P.K + 1;
     const int tid = threadIdx.x;                     // threads >= TL_THREADS (fused launch: 256 per workgroup) only keep the barriers
-    const int n_own = P.piece_end - P.piece_begin, n_all = P.n_traj * P.N;
+    const int n_own = P.piece_end - P.piece_begin;
     int gp = t;                                      // global piece index (trajectory-major)
     if constexpr (XF) gp = t < n_own ? P.piece_begin + t : (t - n_own < P.piece_begin ? t - n_own : t);
     const int b = gp / P.N, i = gp - b * P.N;

@@ -352,6 +352,46 @@ int isdf_frontend_check(isdf_ctx *ctx, int n, const int32_t *index, const double
  * bit tests in the breadth-first order instead of k^2 byte-ANDs per attitude.  kernel_ms_out (optional): device time. */
 int isdf_frontend_cspace(isdf_ctx *ctx, uint32_t *free_mask_out, double *kernel_ms_out);
 
+/* ---- the reference's own input files (host side; no device needed) ---------------------------------------------------- */
+/* ASCII .pcd global map as pcl::io::loadPCDFile<pcl::PointXYZ> reads it (src/map_manager/src/globalmap_gene.cpp:433-460;
+ * the shipped src/plan_manager/map_pcds are "FIELDS x y z / DATA ascii"): xyz_out = up to `capacity` points x 3 floats (may be
+ * NULL to count).  Returns the number of points in the file, or a negative isdf_status (ISDF_ERR_UNSUPPORTED: binary data).
+ * The points go to isdf_set_pointcloud (= PCSmapManager::rcvGlobalMapHandler, PCSmap_manager.cpp:87-200). */
+long long isdf_read_pcd(const char *path, float *xyz_out, long long capacity);
+/* Wavefront .obj as igl::read_triangle_mesh reads it (src/utils/src/Shape.cpp:36): vertices V_out (capV x 3), triangles F_out
+ * (capF x 3, zero based; polygons fanned from their first vertex).  nV_out / nF_out always receive the counts in the file. */
+int isdf_read_obj(const char *path, double *V_out, int capV, int32_t *F_out, int capF, int *nV_out, int *nF_out);
+/* yaml poly_params [x, y, z, roll, pitch, yaw (degrees)] -> Rotate = yaw * pitch * roll with Eigen's AngleAxis matrices and
+ * PI = 3.14159265358979323846 (Shape.cpp:23,38-43), row-major. */
+int isdf_poly_rotation(const double poly_params[6], double rotate_out[9]);
+/* Generalshape's constructor transform (Shape.cpp:37-49): V <- (V.homogeneous() * Trans^T).hnormalized() in place, with
+ * Trans = [Rotate | trans]; trans_out / rotate_out (nullable) receive what isdf_shape.trans / .rotate take. */
+int isdf_body_transform(const double poly_params[6], double *V_inout, int nV, double trans_out[3], double rotate_out[9]);
+/* What a plan needs from the yaml files of src/plan_manager/config (rosparam -> Config::loadParameters,
+ * src/utils/include/utils/config.hpp:13-203).  Fields a file leaves out keep Config's in-class defaults. */
+typedef struct isdf_plan_config {
+    isdf_config sweep;             /* the hot path's fields; variant = ISDF_V1_SWEPT (the live configuration)                  */
+    isdf_frontend_config frontend; /* kernel_size, kernel_max_roll / _pitch, kernel_ang_res, front_end_safeh                   */
+    double occupancy_resolution;   /* voxel edge of the occupancy grid                                                        */
+    int32_t sta_threshold;         /* points per voxel for "occupied" (PCSmap_manager.cpp:160)                                */
+    int32_t threads_num;           /* the reference's OpenMP team (baseline only)                                             */
+    double rho, inittime, momentum;
+    double traj_parlength;         /* 3.0: waypoint spacing in metres (plan_manager.cpp:153,206-213)                          */
+    double poly_params[6];         /* body offset of the robot: x y z roll pitch yaw(deg)                                     */
+    double offset_aabb[3];         /* offsetAABBbox                                                                           */
+    double box[3];                 /* box_x / box_y / box_z                                                                   */
+    double map_bound[6];           /* mapBound                                                                                */
+    char inputdata[256];           /* e.g. "shapes/RoundedCone.obj" (relative to the plan_manager package)                    */
+    char pcdmapname[128];
+} isdf_plan_config;
+void isdf_plan_config_default(isdf_plan_config *out);
+int isdf_load_yaml_config(const char *yaml_path, isdf_plan_config *out);
+/* SweptVolumeManager::initShape (sw_manager.hpp:239-275): the stem of inputdata is looked up in the analytic registry
+ * (isdf_shape_from_name; trans / rotate from poly_params); any other stem is the mesh Generalshape - the obj is read from
+ * package_dir/inputdata into the caller's buffers and put through isdf_body_transform.  ISDF_ERR_OVERFLOW: buffers too small. */
+int isdf_shape_from_config(isdf_shape *shape, const isdf_plan_config *cfg, const char *package_dir, double *V_buf, int capV,
+                           int32_t *F_buf, int capF);
+
 /* ---- instrumentation --------------------------------------------------------------------------------------- */
 /* on = N > 0: every N-th isdf_eval_device attaches HIP start/stop events to the dispatch of its dominant kernel on
  * `stream` (hipExtLaunchKernel: the kernel's own begin/end timestamps, the interval rocprofv3 reports);
