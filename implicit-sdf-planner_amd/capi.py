@@ -91,7 +91,7 @@ EVALUATE_FN = C.CFUNCTYPE(C.c_double, C.c_void_p, C.POINTER(C.c_double), C.POINT
 EXPORTED_SYMBOLS = [
     "isdf_config_default", "isdf_shape_default", "isdf_shape_from_name", "isdf_create", "isdf_destroy",
     "isdf_last_error", "isdf_abi_version", "isdf_set_grid", "isdf_set_shape", "isdf_set_points",
-    "isdf_set_shard", "isdf_eval", "isdf_eval_device", "isdf_eval_swept_at_tstar", "isdf_out_stride", "isdf_profile_enable",
+    "isdf_set_shard", "isdf_eval", "isdf_eval_device", "isdf_eval_swept_at_tstar", "isdf_eval_swept_at_tstar_host", "isdf_out_stride", "isdf_profile_enable",
     "isdf_profile_read", "isdf_profile_read_secondary", "isdf_get_stats",
     "isdf_set_trajectory", "isdf_num_variables", "isdf_pack_variables", "isdf_unpack_variables",
     "isdf_cost_function", "isdf_cost_function_lmbm", "isdf_cost_parts",
@@ -134,6 +134,7 @@ def load_library(path=None):
                               C.POINTER(dp), C.POINTER(dp), dp]
     lib.isdf_eval_device.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     lib.isdf_eval_swept_at_tstar.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    lib.isdf_eval_swept_at_tstar_host.argtypes = [C.c_void_p, C.c_int, dp, dp, dp, dp, dp, dp]
     lib.isdf_out_stride.argtypes = [C.c_int]
     lib.isdf_out_stride.restype = C.c_size_t
     lib.isdf_profile_enable.argtypes = [C.c_void_p, C.c_int]

@@ -644,6 +644,32 @@ extern "C" int isdf_eval_swept_at_tstar(isdf_ctx *c, int N, const double *d_T, c
     return eval_device_impl(c, 1, N, d_T, d_coeffs, d_out, const_cast<double *>(d_tstar), (hipStream_t)stream, 1, true);
 }
 
+// Host-array form of the above (accumulate semantics like isdf_eval): tstar = M doubles.
+extern "C" int isdf_eval_swept_at_tstar_host(isdf_ctx *c, int N, const double *T, const double *coeffs, const double *tstar,
+                                             double *cost_inout, double *gradT_inout, double *gradC_inout) {
+    if (!c) return ISDF_ERR_INVALID_ARG;
+    if (N < 1 || !T || !coeffs || !tstar || !cost_inout || !gradT_inout || !gradC_inout) return fail(c, ISDF_ERR_INVALID_ARG, "null argument");
+    if (c->M <= 0) return ISDF_OK;
+    HIPCHK(c, hipSetDevice(c->device));
+    const size_t in_all = (size_t)19 * N, ostride = isdf_out_stride(N);
+    int rc = ensure(c, &c->d_in, &c->in_cap, in_all + (size_t)c->M);
+    if (rc) return rc;
+    rc = ensure(c, &c->d_out, &c->out_cap, ostride);
+    if (rc) return rc;
+    HIPCHK(c, hipMemcpyAsync(c->d_in, T, (size_t)N * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->d_in + N, coeffs, (size_t)18 * N * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->d_in + in_all, tstar, (size_t)c->M * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    rc = eval_device_impl(c, 1, N, c->d_in, c->d_in + N, c->d_out, c->d_in + in_all, c->stream, 1, true);
+    if (rc) return rc;
+    std::vector<double> h(ostride);
+    HIPCHK(c, hipMemcpyAsync(h.data(), c->d_out, ostride * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    *cost_inout += h[0];
+    for (int i = 0; i < N; i++) gradT_inout[i] += h[1 + i];
+    for (int i = 0; i < 18 * N; i++) gradC_inout[i] += h[1 + N + i];
+    return ISDF_OK;
+}
+
 static int fetch_stats(isdf_ctx *c) {
     unsigned long long h[8];
     if (c->cfg.variant != ISDF_V1_SWEPT && c->have_last_P) {

@@ -262,20 +262,13 @@ class Engine:
                                                       C.c_void_p(d_tstar), C.c_void_p(stream)))
 
     def eval_swept_at_tstar_host(self, T, coeffs_colmajor, tstar):
-        """Host-array convenience around eval_swept_at_tstar (torch only carries the device buffers): returns
-        (cost, gradT, gradC) of the swept-volume sweep evaluated AT the given minimisers."""
-        import torch
-        dev = torch.device("cuda", self.cfg.device)
+        """Host arrays in, (cost, gradT, gradC) of the swept-volume sweep evaluated AT the given minimisers out."""
         T = np.ascontiguousarray(T, dtype=np.float64); N = T.size
-        d_T = torch.from_numpy(T).to(dev)
-        d_C = torch.from_numpy(np.ascontiguousarray(coeffs_colmajor, dtype=np.float64).reshape(-1)).to(dev)
-        d_ts = torch.from_numpy(np.ascontiguousarray(tstar, dtype=np.float64)).to(dev)
-        d_out = torch.zeros(self.out_stride(N), dtype=torch.float64, device=dev)
-        st = torch.cuda.current_stream(dev).cuda_stream
-        self.eval_swept_at_tstar(N, d_T.data_ptr(), d_C.data_ptr(), d_out.data_ptr(), d_ts.data_ptr(), st)
-        torch.cuda.synchronize(dev)
-        o = d_out.cpu().numpy()
-        return float(o[0]), o[1:1 + N].copy(), o[1 + N:].copy()
+        Cc = np.ascontiguousarray(coeffs_colmajor, dtype=np.float64).reshape(-1)
+        ts = np.ascontiguousarray(tstar, dtype=np.float64)
+        cost = np.zeros(1); gT = np.zeros(N); gC = np.zeros(18 * N)
+        self._check(self.lib.isdf_eval_swept_at_tstar_host(self.h, N, _p(T), _p(Cc), _p(ts), _p(cost), _p(gT), _p(gC)))
+        return float(cost[0]), gT, gC
 
     def out_stride(self, N):
         return int(self.lib.isdf_out_stride(N))

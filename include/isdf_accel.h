@@ -223,6 +223,9 @@ size_t isdf_out_stride(int N);   /* 1 + N + 18N */
  * argmin over t is a chain of accept/reject comparisons; this entry point isolates the arithmetic behind it). */
 int isdf_eval_swept_at_tstar(isdf_ctx *ctx, int N, const double *d_T, const double *d_coeffs, double *d_out,
                              const double *d_tstar, void *stream);
+/* the same with host arrays, synchronous, ACCUMULATING into cost / gradT[N] / gradC[18N] like isdf_eval (tstar: M doubles) */
+int isdf_eval_swept_at_tstar_host(isdf_ctx *ctx, int N, const double *T, const double *coeffs, const double *tstar,
+                                  double *cost_inout, double *gradT_inout, double *gradC_inout);
 
 /* ---- full objective callback ------------------------------------------------------------------------------ */
 /* TrajOptimizer::costFunctionLmbm (back_end_optimizer.hpp:358-430): x = [tau(N) | inner waypoints 3(N-1)] ->

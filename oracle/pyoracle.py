@@ -565,3 +565,46 @@ def gather_points(occ, bmin, bmax, res, waypoints, half, offset=(0.0, 0.0, 0.0))
         return np.zeros((0, 3))
     I = np.array(sorted(ids), dtype=np.float64)
     return (I + 0.5) * res + bmin
+
+
+REF_LMBM = os.path.join(os.path.dirname(os.path.abspath(__file__)), "_ref", "liblmbm.so")
+
+
+def ref_lmbm_optimize(evaluate, x0, instance=None, max_iterations=0, max_evaluations=0, timeout=0.0):
+    """The reference's LIVE back-end optimizer: lmbm::lmbm_optimize (src/utils/include/lmbm/lmbm.cpp:27-129 over the Fortran 77
+    limited-memory bundle method lmbm_{main,sub,math,call}.f, built by AMD flang into oracle/_ref/liblmbm.so), called like
+    TrajOptimizer::optimize_traj_lmbm does (back_end_optimizer.cpp:125-132): default lmbm_parameter_t unless overridden.
+    evaluate: EITHER a Python callable fun(x ndarray) -> (f, g ndarray) OR a (function pointer address, instance pointer)
+    pair with the lmbm_evaluate_t signature - e.g. (libisdf_accel's isdf_cost_function_lmbm, isdf_ctx*), the way the
+    reference would bind the product.  Returns dict(x, f, status, iterations, evaluations)."""
+    L = C.CDLL(REF_LMBM)
+    cbt = C.CFUNCTYPE(C.c_double, C.c_void_p, dp, dp, C.c_int)
+    pgt = C.CFUNCTYPE(C.c_int, C.c_void_p, dp, C.c_int)
+    n = int(np.asarray(x0).size)
+    counts = {"evals": 0, "iters": 0}
+    if callable(evaluate):
+        def tramp(_i, xp, gp, nn):
+            counts["evals"] += 1
+            xv = np.ctypeslib.as_array(xp, shape=(nn,)).copy()
+            f, g = evaluate(xv)
+            np.ctypeslib.as_array(gp, shape=(nn,))[:] = np.asarray(g, dtype=np.float64)
+            return float(f)
+        cb = cbt(tramp); inst = None
+    else:
+        # a native callback: count its calls with a thin trampoline that forwards the raw pointers (no array marshalling)
+        native = cbt(evaluate[0]); native_inst = evaluate[1]
+
+        def tramp(_i, xp, gp, nn):
+            counts["evals"] += 1
+            return native(native_inst, xp, gp, nn)
+        cb = cbt(tramp); inst = None
+
+    def prog(_i, xp, k):
+        counts["iters"] = max(counts["iters"], int(k))
+        return 0
+    pg = pgt(prog)
+    x = np.ascontiguousarray(x0, dtype=np.float64).copy()
+    fx = C.c_double(0.0)
+    L.ref_lmbm_optimize.argtypes = [C.c_int, dp, C.POINTER(C.c_double), cbt, C.c_void_p, pgt, C.c_int, C.c_int, C.c_double]
+    status = L.ref_lmbm_optimize(n, _p(x), C.byref(fx), cb, inst, pg, int(max_iterations), int(max_evaluations), float(timeout))
+    return {"x": x, "f": fx.value, "status": int(status), "iterations": counts["iters"], "evaluations": counts["evals"]}

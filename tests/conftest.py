@@ -12,6 +12,19 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+@pytest.fixture(scope="session", autouse=True)
+def _torch_first():
+    """PyTorch bundles its own HIP runtime; when the product library (linked against /opt/rocm's) initialises the device
+    first, torch's later initialisation reports "No HIP GPUs are available".  The tests that hand torch tensors to the library
+    (exchange workers, bench) import torch first anyway; make the order deterministic for the whole session."""
+    try:
+        import torch
+        if torch.cuda.is_available():
+            torch.zeros(1, device="cuda")
+    except Exception:       # noqa: BLE001 - no torch / no GPU: nothing to order
+        pass
+
+
 @pytest.fixture(scope="session")
 def pkg():
     import __graft_entry__ as g

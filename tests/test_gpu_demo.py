@@ -1,0 +1,120 @@
+"""The reference's demos, headless, on its own inputs (tests/golden/ref_demo_inputs.npz = the product's readers applied to
+src/plan_manager/map_pcds/CappedCone.pcd, config_CappedCone.yaml / config_L.yaml, shapes/Lthick.obj):
+  demo1  CappedCone.pcd @ 1 m (51 x 51 x 35) + the analytic RoundedCone with its 120 degree roll + kernel_size 13, the live
+         swept-volume sweep: device vs the reference's own sweep (libref_sweeps.so), then the whole plan - the reference's
+         Fortran LMBM (oracle/_ref/liblmbm.so) driving the DEVICE callback and, beside it, the oracle callback;
+  demo6  Lthick.obj through the mesh path on the same map: device vs the reference's own mesh code.
+The real BASELINE configs[0]."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+from common import REL_TOL, assert_close, oracle_cost_function
+from demo_headless import build_plan, plan_config_from_golden
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLD = os.path.join(ROOT, "tests", "golden", "ref_demo_inputs.npz")
+
+
+def _demo(pkg, tag, start=(5, 25, 17), goal=(48, 25, 17), inflate=1):
+    """start / goal either side of the three slit walls of the map (x = 10-11, 24-26, 42-44; holes of about 8 x 5 cells)"""
+    capi = pkg.capi
+    g = np.load(GOLD)
+    plan = plan_config_from_golden(pkg, g, tag)
+    if tag == "CappedCone":
+        shape = pkg.fixtures.shape_from_config(plan, "")             # analytic class: no file needed
+    else:
+        shape = pkg.synth.make_mesh_shape(g["Lthick_V"], g["Lthick_F"])
+    cfg = capi.IsdfConfig.from_buffer_copy(plan.sweep)
+    eng = pkg.Engine(cfg)
+    eng.set_shape(shape)
+    P = build_plan(pkg, eng, plan, g["CappedCone_xyz"], start, goal, inflate)
+    return g, plan, cfg, shape, eng, P
+
+
+def test_demo1_swept_sweep_vs_reference_code(pkg, orc, product_lib):
+    """demo1's map and robot, the initial trajectory of the plan: addSaftyPenaOnSweptVolumeParallel on the device vs the
+    reference's own (RoundedCone class with Rotate from poly_params = [0 0 0 120 0 0])."""
+    if not os.path.exists(orc.REF_SWEEPS):
+        pytest.skip("oracle/_ref/libref_sweeps.so not built")
+    g, plan, cfg, shape, eng, P = _demo(pkg, "CappedCone")
+    assert P["occ"].shape == (51, 51, 35) and P["M"] > 200 and P["N"] >= 8
+    T, cm = eng.unpack_variables(P["x0"])
+    ref = orc.RefWorld(cfg, "RoundedCone", shape, plan.occupancy_resolution, threads=30)
+    ref.set_points(P["points"])
+    c_r, gT_r, gC_r, ts_r = ref.sweep_swept(T, cm)
+    ts = np.zeros(P["M"])
+    c, gT, gC = eng.eval_single(T, cm, tstar=ts)
+    assert c_r > 0 and abs(c - c_r) <= REL_TOL * abs(c_r), (c, c_r)
+    assert np.abs(ts - ts_r).max() <= 2e-5
+    assert_close(gC, gC_r, "demo1 gradC vs the reference's sweep"); assert_close(gT, gT_r, "demo1 gradT vs the reference's sweep")
+
+
+def test_demo6_mesh_robot_vs_reference_code(pkg, orc, product_lib):
+    """demo6's robot (Lthick.obj, 60 vertices / 20 triangles, through the constructor's transform) on the mesh path."""
+    if not os.path.exists(orc.REF_SWEEPS):
+        pytest.skip("oracle/_ref/libref_sweeps.so not built")
+    g, plan, cfg, shape, eng, P = _demo(pkg, "L")
+    T, cm = eng.unpack_variables(P["x0"])
+    ref = orc.RefWorld(cfg, "Box", pkg.synth.make_shape("Box"), plan.occupancy_resolution, threads=30)
+    ref.set_mesh(g["Lthick_V"], g["Lthick_F"])
+    ref.set_points(P["points"])
+    ref.mesh_perturb(0)
+    ts_r = -np.ones(P["M"])
+    c_r, gT_r, gC_r, _ = ref.sweep_swept(T, cm, tstar=ts_r)
+    assert c_r > 0
+    # at the reference's minimisers: 1e-5; free running: the reference's own spread under a device-sized perturbation of w
+    c, gT, gC = eng.eval_swept_at_tstar_host(T, cm, ts_r)
+    assert abs(c - c_r) <= REL_TOL * abs(c_r)
+    assert_close(gC, gC_r, "demo6 gradC at the reference's t*"); assert_close(gT, gT_r, "demo6 gradT at the reference's t*")
+    from test_gpu_mesh import _reference_spread
+    sp = _reference_spread(pkg, orc, cfg, plan.occupancy_resolution, T, cm, P["points"], g["Lthick_V"], g["Lthick_F"])
+    ts = -np.ones(P["M"])
+    c, gT, gC = eng.eval_single(T, cm, tstar=ts)
+    assert abs(c - c_r) <= REL_TOL * abs(c_r)
+    dt = np.abs(ts - ts_r)
+    assert dt.max() <= max(2e-5, 2 * sp["dt_max"]), (dt.max(), sp)
+    assert_close(gC, gC_r, "demo6 gradC", tol=max(REL_TOL, 2 * sp["gradC_rel"])); assert_close(gT, gT_r, "demo6 gradT", tol=max(REL_TOL, 2 * sp["gradT_rel"]))
+
+
+def test_demo1_headless_plan_with_the_reference_lmbm(pkg, orc, product_lib):
+    """PCD + yaml in -> trajectory out: the reference's LMBM (Fortran, flang-built) on isdf_cost_function_lmbm, bound through
+    its lmbm_evaluate_t signature exactly as lmbm::lmbm_optimize would be handed it; the same driver on the oracle callback
+    beside it.  Two optimizers fed values that differ in the 12th digit do not stay in lock step for hundreds of nonsmooth
+    bundle iterations, so the plans are compared by what they achieve, the first evaluations by value."""
+    if not os.path.exists(orc.REF_LMBM):
+        pytest.skip("oracle/_ref/liblmbm.so not built (no flang)")
+    capi, synth = pkg.capi, pkg.synth
+    g, plan, cfg, shape, eng, P = _demo(pkg, "CappedCone")
+    N, x0 = P["N"], P["x0"]
+    lib = capi.load_library()
+    fptr = C.cast(lib.isdf_cost_function_lmbm, C.c_void_p).value
+    r_dev = orc.ref_lmbm_optimize((fptr, eng.h), x0, max_iterations=400, max_evaluations=1200)
+    c_first, g_first = eng.cost_function(x0)
+    # the oracle callback: costFunctionLmbm composed from the CPU restatement (V1 sweep + integral sweep without collision)
+    o1 = orc.Oracle(cfg, threads=30)
+    o1.set_grid(P["occ"], P["origin"], plan.occupancy_resolution, capi.GRID_OCCUPANCY); o1.set_shape(shape); o1.set_points(P["points"])
+    cfg2 = capi.IsdfConfig.from_buffer_copy(cfg); cfg2.variant = capi.V3_ESDF_TILE; cfg2.enable_pos = 0
+    o2 = orc.Oracle(cfg2, threads=30)
+    fun = lambda x: oracle_cost_function(orc, [o1, o2], P["head"], P["tail"], plan.rho, x, N)
+    c0, g0 = fun(x0)
+    assert abs(c_first - c0) <= REL_TOL * abs(c0)
+    assert_close(g_first, g0, "demo1 callback gradient at the initial guess")
+    r_cpu = orc.ref_lmbm_optimize(fun, x0, max_iterations=400, max_evaluations=1200)
+    print(f"demo1 headless: N={N} M={P['M']} cost {c_first:.6g} -> device {r_dev['f']:.6g} ({r_dev['iterations']} it, {r_dev['evaluations']} ev, status {r_dev['status']})"
+          f" | oracle {r_cpu['f']:.6g} ({r_cpu['iterations']} it, {r_cpu['evaluations']} ev, status {r_cpu['status']})")
+    assert r_dev["status"] >= 0 and r_cpu["status"] >= 0
+    assert r_dev["f"] < 0.5 * c_first and r_cpu["f"] < 0.5 * c_first                 # both plans are real improvements
+    assert abs(r_dev["f"] - r_cpu["f"]) <= 0.05 * abs(r_cpu["f"])                      # ... and equally good
+    # the device's optimum, judged by the oracle, is what the device said it was
+    c_chk, _ = fun(r_dev["x"])
+    assert abs(c_chk - r_dev["f"]) <= 1e-4 * abs(c_chk)
+    # the optimized trajectory clears the map: the collision term is (almost) gone
+    eng.cost_function(r_dev["x"])
+    parts = eng.cost_parts()
+    eng.cost_function(x0)
+    parts0 = eng.cost_parts()
+    assert parts["swept"] <= 0.05 * parts0["swept"] + 1e-9
