@@ -1,17 +1,21 @@
 // Concurrent optimisation of a batch of trajectories on one shared map (BASELINE.json configs[2]: "batch of 128 random
 // start/goal trajectories optimized concurrently").  Every trajectory runs the reference's L-BFGS driver
-// (csrc/lbfgs_host.hpp == lbfgs::lbfgs_optimize, lbfgs.hpp:480-835) on its own objective callback
-// (costFunctionLmbm, back_end_optimizer.hpp:358-430) with its own boundary states; the callbacks of one round are
-// evaluated TOGETHER: each trajectory's host thread does its serial part (tau -> T, MINCO, energy) in parallel with the
-// others, then the coordinator uploads the coefficients of the trajectories that asked for an evaluation, runs ONE batched
-// integral sweep on the device (isdf_eval_device, n_traj = active count), downloads, and those threads finish their
-// callbacks (propogateGrad, chain rule).  Rounds are GREEDY: a round starts as soon as a share of the live trajectories
-// (min_share, default a quarter) is waiting, so the host part of one group (MINCO, adjoint, the L-BFGS update) runs while
-// the device evaluates another; which trajectories share a round has no influence on their results (the sweep treats every
-// trajectory independently, all sums have a fixed order).  Line searches that need more evaluations simply take part in
-// more rounds.
+// (csrc/lbfgs_host.hpp == lbfgs::lbfgs_optimize, lbfgs.hpp:480-835) in its own host thread on its own objective
+// (costFunctionLmbm, back_end_optimizer.hpp:358-430) with its own boundary states; the callbacks of a round of trajectories are
+// evaluated TOGETHER as one batched integral sweep.  Rounds are GREEDY (a round starts as soon as a share of the trajectories
+// that can submit is waiting) and several are in flight, each on its own stream, the sweeps ordered by events because they
+// share the ctx's scratch - so one round's uploads, downloads and host work run under another round's sweep.
+// MINCO (tau -> T, setParameters, energy; propogateGrad, chain rule) runs
+//   on the trajectories' host threads (csrc/minco_host.hpp; ~10 us per solve on a CPU core) - the default: 128 x 30 iterations
+//       in 124 ms = 2.95e8 point-evals/s end to end, 97 % of the sweep kernel's own rate (tools/batch_opt_bench.py), or
+//   on the device (csrc/minco_dev.hip: one wavefront per trajectory, only x goes up and (cost, g) comes down): a round is then
+//       [forward 148 us | sweep | backward 93 us] - 6N dependent pivots per solve - and the same batch takes 209-324 ms; it is
+//       selected when the batch outnumbers the host's cores four to one, or with ISDF_BATCH_DEVICE_MINCO=1.
+// Which trajectories share a round has no influence on results, and the device MINCO performs the host MINCO's operations one
+// for one: either way the iterates are bitwise those of isdf_optimize_lbfgs on each trajectory alone.
 #include "isdf_ctx.hpp"
 #include "lbfgs_host.hpp"
+#include "minco_dev.hpp"
 #include <chrono>
 #include <cmath>
 #include <cstdlib>
@@ -26,17 +30,18 @@ struct Batch;
 struct Worker {
     Batch *batch = nullptr;
     int id = 0;
+    isdf_host::LbfgsResult result;
+    // host-MINCO rounds only
     isdf_host::MincoS3 minco;
     std::vector<double> T, gdC, gdT, gradP, gradT;
     double energy = 0.0;
-    isdf_host::LbfgsResult result;
 };
 
 struct Batch {
     isdf_ctx *ctx = nullptr;
     int n_traj = 0, N = 0, n = 0;
     double rho = 0.0;
-    size_t in_per = 0, ostride = 0;
+    size_t ostride = 0;
     std::vector<Worker> workers;
     // round state (guarded by m)
     std::mutex m;
@@ -45,7 +50,11 @@ struct Batch {
     int n_submitted = 0, n_finished = 0, n_inflight = 0;
     double min_share = 0.25;      // a round starts when this share of the live trajectories waits (1.0: all of them)
     int error = ISDF_OK;
-    // staging: slot t holds [T(N) | coeffs(18N)] of trajectory t; out slot t holds [cost | gradT | gradC]
+    bool device_minco = true;
+    // staging, device MINCO: slot t holds the variables x (n) of trajectory t; res slot t holds [cost | g(n)]
+    std::vector<double> stage_x, stage_res;
+    // staging, host MINCO: slot t holds [T(N) | coeffs(18N)]; out slot t holds the sweep's [cost | gradT | gradC]
+    size_t in_per = 0;
     std::vector<double> stage_in, stage_out;
     long long rounds_run = 0, evals_run = 0;
 };
@@ -54,13 +63,37 @@ struct Batch {
 double worker_evaluate(void *instance, const double *x, double *g, const int n) {
     Worker &w = *(Worker *)instance;
     Batch &b = *w.batch;
-    const int N = b.N;
-    for (int i = 0; i < N; i++) w.T[i] = isdf_host::tau_to_T(x[i]);
-    w.minco.set_parameters(x + N, w.T.data());
-    w.energy = w.minco.energy(w.gdC.data(), w.gdT.data());
-    double *in = b.stage_in.data() + (size_t)w.id * b.in_per;
-    std::memcpy(in, w.T.data(), (size_t)N * sizeof(double));
-    std::memcpy(in + N, w.minco.c.data(), (size_t)18 * N * sizeof(double));
+    if (!b.device_minco) {
+        // serial part on this trajectory's host thread (tau -> T, MINCO, energy), the sweep in the round, then the adjoint here
+        const int N = b.N;
+        for (int i = 0; i < N; i++) w.T[i] = isdf_host::tau_to_T(x[i]);
+        w.minco.set_parameters(x + N, w.T.data());
+        w.energy = w.minco.energy(w.gdC.data(), w.gdT.data());
+        double *in = b.stage_in.data() + (size_t)w.id * b.in_per;
+        std::memcpy(in, w.T.data(), (size_t)N * sizeof(double));
+        std::memcpy(in + N, w.minco.c.data(), (size_t)18 * N * sizeof(double));
+        {
+            std::unique_lock<std::mutex> lk(b.m);
+            b.submitted[w.id] = 1;
+            b.n_submitted++;
+            b.cv_coord.notify_one();
+            b.cv_workers.wait(lk, [&] { return b.ready[w.id] != 0; });
+            b.ready[w.id] = 0;
+            if (b.error != ISDF_OK) return INFINITY;
+        }
+        const double *o = b.stage_out.data() + (size_t)w.id * b.ostride;
+        double cost = w.energy + o[0];
+        for (int i = 0; i < N; i++) w.gdT[i] += o[1 + i];
+        for (int i = 0; i < 18 * N; i++) w.gdC[i] += o[1 + N + i];
+        w.minco.propagate_grad(w.gdC.data(), w.gdT.data(), w.gradP.data(), w.gradT.data());
+        double tsum = 0.0;
+        for (int i = 0; i < N; i++) tsum += w.T[i];
+        cost += b.rho * tsum;
+        for (int i = 0; i < N; i++) g[i] = isdf_host::grad_T_to_tau(x[i], w.gradT[i] + b.rho);
+        for (int i = 0; i < 3 * (N - 1); i++) g[N + i] = w.gradP[i];
+        return cost;
+    }
+    std::memcpy(b.stage_x.data() + (size_t)w.id * b.n, x, (size_t)n * sizeof(double));
     {
         std::unique_lock<std::mutex> lk(b.m);
         b.submitted[w.id] = 1;
@@ -70,18 +103,9 @@ double worker_evaluate(void *instance, const double *x, double *g, const int n) 
         b.ready[w.id] = 0;
         if (b.error != ISDF_OK) return INFINITY;
     }
-    const double *o = b.stage_out.data() + (size_t)w.id * b.ostride;
-    double cost = w.energy + o[0];
-    for (int i = 0; i < N; i++) w.gdT[i] += o[1 + i];
-    for (int i = 0; i < 18 * N; i++) w.gdC[i] += o[1 + N + i];
-    w.minco.propagate_grad(w.gdC.data(), w.gdT.data(), w.gradP.data(), w.gradT.data());
-    double tsum = 0.0;
-    for (int i = 0; i < N; i++) tsum += w.T[i];
-    cost += b.rho * tsum;
-    for (int i = 0; i < N; i++) g[i] = isdf_host::grad_T_to_tau(x[i], w.gradT[i] + b.rho);
-    for (int i = 0; i < 3 * (N - 1); i++) g[N + i] = w.gradP[i];
-    (void)n;
-    return cost;
+    const double *r = b.stage_res.data() + (size_t)w.id * (1 + b.n);
+    std::memcpy(g, r + 1, (size_t)n * sizeof(double));
+    return r[0];
 }
 
 }  // namespace
@@ -95,30 +119,65 @@ extern "C" int isdf_optimize_lbfgs_batch(isdf_ctx *c, int n_traj, int N, const d
     HIPCHK(c, hipSetDevice(c->device));
     Batch b;
     b.ctx = c; b.n_traj = n_traj; b.N = N; b.n = N + 3 * (N - 1); b.rho = rho;
-    b.in_per = (size_t)19 * N; b.ostride = isdf_out_stride(N);
+    b.ostride = isdf_out_stride(N);
     b.workers.resize(n_traj);
     b.submitted.assign(n_traj, 0); b.finished.assign(n_traj, 0); b.ready.assign(n_traj, 0);
     if (const char *e = getenv("ISDF_BATCH_MIN_SHARE")) { const double v = atof(e); if (v > 0.0 && v <= 1.0) b.min_share = v; }
-    b.stage_in.assign((size_t)n_traj * b.in_per, 0.0);
-    b.stage_out.assign((size_t)n_traj * b.ostride, 0.0);
+    b.stage_x.assign((size_t)n_traj * b.n, 0.0);
+    b.stage_res.assign((size_t)n_traj * (1 + b.n), 0.0);
+    // Where MINCO runs (see the head of this file): the host threads unless the batch outnumbers the cores four to one.
+    b.device_minco = n_traj > 4 * (int)std::max(1u, std::thread::hardware_concurrency());
+    if (const char *e = getenv("ISDF_BATCH_DEVICE_MINCO")) b.device_minco = e[0] == '1';
+    if (isdf::minco_backward_lds(N) > 64 * 1024) b.device_minco = false;       // a trajectory's band system must fit in LDS
+    b.in_per = (size_t)19 * N;
     for (int t = 0; t < n_traj; t++) {
         Worker &w = b.workers[t];
         w.batch = &b; w.id = t;
-        w.minco.set_conditions(heads_pva + 9 * t, tails_pva + 9 * t, N);
-        w.T.assign(N, 0.0); w.gdC.assign((size_t)18 * N, 0.0); w.gdT.assign(N, 0.0);
-        w.gradP.assign((size_t)3 * (N > 1 ? N - 1 : 1), 0.0); w.gradT.assign(N, 0.0);
+        if (!b.device_minco) {
+            w.minco.set_conditions(heads_pva + 9 * t, tails_pva + 9 * t, N);
+            w.T.assign(N, 0.0); w.gdC.assign((size_t)18 * N, 0.0); w.gdT.assign(N, 0.0);
+            w.gradP.assign((size_t)3 * (N > 1 ? N - 1 : 1), 0.0); w.gradT.assign(N, 0.0);
+        }
     }
-    // device + pinned buffers for a full batch, twice: up to TWO rounds are in flight (the second queued behind the first on
-    // the stream), so the device never waits for the host to deliver one round's results before the next one starts
-    const size_t in_all = (size_t)n_traj * b.in_per, out_all = (size_t)n_traj * b.ostride;
-    struct Slot { double *h_pin = nullptr, *d_buf = nullptr; std::vector<int> active; hipEvent_t done = nullptr; bool busy = false; } slots[2];
-    auto release = [&] { for (Slot &q : slots) { if (q.h_pin) (void)hipHostFree(q.h_pin); if (q.d_buf) (void)hipFree(q.d_buf); if (q.done) (void)hipEventDestroy(q.done); } };
+    if (!b.device_minco) { b.stage_in.assign((size_t)n_traj * b.in_per, 0.0); b.stage_out.assign((size_t)n_traj * b.ostride, 0.0); }
+    // device + pinned buffers for a full batch per slot: up to N_SLOTS rounds are in flight, each on its own stream
+    constexpr int N_SLOTS = 6;
+    const size_t nv = (size_t)b.n, n6 = (size_t)6 * N;
+    struct Slot {
+        double *h_pin = nullptr, *d_buf = nullptr; int *d_ids = nullptr; int *h_ids = nullptr;
+        std::vector<int> active; hipStream_t stream = nullptr; hipEvent_t done = nullptr, sweep_done = nullptr; bool busy = false;
+    } slots[N_SLOTS];
+    double *d_cond = nullptr;
+    const size_t x_all = (size_t)n_traj * nv, res_all = (size_t)n_traj * (1 + nv), T_all = (size_t)n_traj * N, C_all = (size_t)n_traj * 3 * n6,
+                 lu_all = (size_t)n_traj * 13 * n6, out_all = (size_t)n_traj * b.ostride;
+    auto release = [&] {
+        for (Slot &q : slots) {
+            if (q.h_pin) (void)hipHostFree(q.h_pin); if (q.h_ids) (void)hipHostFree(q.h_ids);
+            if (q.d_buf) (void)hipFree(q.d_buf); if (q.d_ids) (void)hipFree(q.d_ids);
+            if (q.done) (void)hipEventDestroy(q.done); if (q.sweep_done) (void)hipEventDestroy(q.sweep_done);
+            if (q.stream) (void)hipStreamDestroy(q.stream);
+        }
+        if (d_cond) (void)hipFree(d_cond);
+    };
     for (Slot &q : slots) {
-        if (hipHostMalloc((void **)&q.h_pin, (in_all + out_all) * sizeof(double), hipHostMallocDefault) != hipSuccess ||
-            hipMalloc(&q.d_buf, (in_all + out_all) * sizeof(double)) != hipSuccess ||
-            hipEventCreateWithFlags(&q.done, hipEventDisableTiming) != hipSuccess) { release(); return isdf_fail(c, ISDF_ERR_HIP, "batch buffers: allocation failed"); }
+        // pinned: [x | res | overflow word]; device: [x | res | T | coeffs | band factors | sweep out]
+        if (hipHostMalloc((void **)&q.h_pin, (std::max(x_all + res_all, (size_t)n_traj * b.in_per + out_all) + 1) * sizeof(double), hipHostMallocDefault) != hipSuccess ||
+            hipHostMalloc((void **)&q.h_ids, (size_t)n_traj * sizeof(int), hipHostMallocDefault) != hipSuccess ||
+            hipMalloc(&q.d_buf, (x_all + res_all + T_all + C_all + lu_all + out_all) * sizeof(double)) != hipSuccess ||
+            hipMalloc(&q.d_ids, (size_t)n_traj * sizeof(int)) != hipSuccess ||
+            hipStreamCreate(&q.stream) != hipSuccess ||
+            hipEventCreateWithFlags(&q.done, hipEventDisableTiming) != hipSuccess ||
+            hipEventCreateWithFlags(&q.sweep_done, hipEventDisableTiming) != hipSuccess) { release(); return isdf_fail(c, ISDF_ERR_HIP, "batch buffers: allocation failed"); }
+    }
+    {   // boundary states of every trajectory: head (9) | tail (9)
+        std::vector<double> cond((size_t)n_traj * 18);
+        for (int t = 0; t < n_traj; t++) { std::memcpy(&cond[(size_t)t * 18], heads_pva + 9 * t, 9 * sizeof(double)); std::memcpy(&cond[(size_t)t * 18 + 9], tails_pva + 9 * t, 9 * sizeof(double)); }
+        if (hipMalloc(&d_cond, cond.size() * sizeof(double)) != hipSuccess || hipMemcpy(d_cond, cond.data(), cond.size() * sizeof(double), hipMemcpyHostToDevice) != hipSuccess) {
+            release(); return isdf_fail(c, ISDF_ERR_HIP, "batch buffers: allocation failed");
+        }
     }
     { int rc0 = isdf_reserve_sweep_buffers(c, (long long)n_traj * N); if (rc0) { release(); return rc0; } }
+    (void)hipDeviceSynchronize();
 
     const auto t0 = std::chrono::steady_clock::now();
     std::vector<std::thread> threads;
@@ -141,21 +200,52 @@ extern "C" int isdf_optimize_lbfgs_batch(isdf_ctx *c, int n_traj, int N, const d
             b.cv_coord.notify_one();
         });
     }
-    // coordinator: greedy rounds, two in flight
+    // coordinator: greedy rounds, N_SLOTS in flight
     int rc = ISDF_OK;
+    hipEvent_t last_sweep = nullptr;          // the sweeps share the ctx's scratch: each waits for the one issued before it
+    const size_t in_all = (size_t)n_traj * b.in_per, word_at = std::max(x_all + res_all, in_all + out_all);
     auto issue = [&](Slot &q) {               // q.active holds the trajectories of the round; their staging slots are quiescent
         const int na = (int)q.active.size();
-        double *hT = q.h_pin, *hC = q.h_pin + (size_t)na * N;          // compacted [T of all | coeffs of all]
-        for (int k = 0; k < na; k++) {
-            const double *in = b.stage_in.data() + (size_t)q.active[k] * b.in_per;
-            std::memcpy(hT + (size_t)k * N, in, (size_t)N * sizeof(double));
-            std::memcpy(hC + (size_t)k * 18 * N, in + N, (size_t)18 * N * sizeof(double));
+        if (!b.device_minco) {
+            double *hT = q.h_pin, *hC = q.h_pin + (size_t)na * N;          // compacted [T of all | coeffs of all]
+            for (int k = 0; k < na; k++) {
+                const double *in = b.stage_in.data() + (size_t)q.active[k] * b.in_per;
+                std::memcpy(hT + (size_t)k * N, in, (size_t)N * sizeof(double));
+                std::memcpy(hC + (size_t)k * 18 * N, in + N, (size_t)18 * N * sizeof(double));
+            }
+            double *dT = q.d_buf, *dC = q.d_buf + (size_t)na * N, *dO = q.d_buf + in_all;
+            if (rc == ISDF_OK && hipMemcpyAsync(q.d_buf, q.h_pin, (size_t)na * b.in_per * sizeof(double), hipMemcpyHostToDevice, q.stream) != hipSuccess) rc = ISDF_ERR_HIP;
+            if (rc == ISDF_OK && last_sweep && hipStreamWaitEvent(q.stream, last_sweep, 0) != hipSuccess) rc = ISDF_ERR_HIP;
+            if (rc == ISDF_OK) rc = isdf_eval_device(c, na, N, dT, dC, dO, nullptr, q.stream);
+            if (rc == ISDF_OK && hipEventRecord(q.sweep_done, q.stream) != hipSuccess) rc = ISDF_ERR_HIP;
+            last_sweep = q.sweep_done;
+            if (rc == ISDF_OK && hipMemcpyAsync(q.h_pin + in_all, dO, (size_t)na * b.ostride * sizeof(double), hipMemcpyDeviceToHost, q.stream) != hipSuccess) rc = ISDF_ERR_HIP;
+            if (rc == ISDF_OK && hipMemcpyAsync(q.h_pin + word_at, c->d_stats + 4, sizeof(double), hipMemcpyDeviceToHost, q.stream) != hipSuccess) rc = ISDF_ERR_HIP;
+            if (rc == ISDF_OK && hipEventRecord(q.done, q.stream) != hipSuccess) rc = ISDF_ERR_HIP;
+            q.busy = true;
+            b.rounds_run++;
+            b.evals_run += na;
+            return;
         }
-        double *dT = q.d_buf, *dC = q.d_buf + (size_t)na * N, *dO = q.d_buf + in_all;
-        if (rc == ISDF_OK && hipMemcpyAsync(q.d_buf, q.h_pin, (size_t)na * b.in_per * sizeof(double), hipMemcpyHostToDevice, c->stream) != hipSuccess) rc = ISDF_ERR_HIP;
-        if (rc == ISDF_OK) rc = isdf_eval_device(c, na, N, dT, dC, dO, nullptr, c->stream);
-        if (rc == ISDF_OK && hipMemcpyAsync(q.h_pin + in_all, dO, (size_t)na * b.ostride * sizeof(double), hipMemcpyDeviceToHost, c->stream) != hipSuccess) rc = ISDF_ERR_HIP;
-        if (rc == ISDF_OK && hipEventRecord(q.done, c->stream) != hipSuccess) rc = ISDF_ERR_HIP;
+        for (int k = 0; k < na; k++) {
+            std::memcpy(q.h_pin + (size_t)k * nv, b.stage_x.data() + (size_t)q.active[k] * nv, nv * sizeof(double));
+            q.h_ids[k] = q.active[k];
+        }
+        double *dX = q.d_buf, *dR = dX + x_all, *dT = dR + res_all, *dC = dT + T_all, *dL = dC + C_all, *dO = dL + lu_all;
+        isdf::MincoDevParams M{};
+        M.N = N; M.rho = rho; M.x = dX; M.ids = q.d_ids; M.cond = d_cond; M.T = dT; M.coeffs = dC; M.lu = dL; M.out = dO; M.res = dR;
+        if (rc == ISDF_OK && hipMemcpyAsync(dX, q.h_pin, (size_t)na * nv * sizeof(double), hipMemcpyHostToDevice, q.stream) != hipSuccess) rc = ISDF_ERR_HIP;
+        if (rc == ISDF_OK && hipMemcpyAsync(q.d_ids, q.h_ids, (size_t)na * sizeof(int), hipMemcpyHostToDevice, q.stream) != hipSuccess) rc = ISDF_ERR_HIP;
+        if (rc == ISDF_OK) isdf::launch_minco_forward(M, na, q.stream);
+        if (rc == ISDF_OK && last_sweep && hipStreamWaitEvent(q.stream, last_sweep, 0) != hipSuccess) rc = ISDF_ERR_HIP;
+        if (rc == ISDF_OK) rc = isdf_eval_device(c, na, N, dT, dC, dO, nullptr, q.stream);
+        if (rc == ISDF_OK && hipEventRecord(q.sweep_done, q.stream) != hipSuccess) rc = ISDF_ERR_HIP;
+        last_sweep = q.sweep_done;
+        if (rc == ISDF_OK) isdf::launch_minco_backward(M, na, q.stream);
+        if (rc == ISDF_OK && hipMemcpyAsync(q.h_pin + x_all, dR, (size_t)na * (1 + nv) * sizeof(double), hipMemcpyDeviceToHost, q.stream) != hipSuccess) rc = ISDF_ERR_HIP;
+        // the overflow word of the sweeps (a bounded wait that expired): a round that saw it is not delivered as a result
+        if (rc == ISDF_OK && hipMemcpyAsync(q.h_pin + word_at, c->d_stats + 4, sizeof(double), hipMemcpyDeviceToHost, q.stream) != hipSuccess) rc = ISDF_ERR_HIP;
+        if (rc == ISDF_OK && hipEventRecord(q.done, q.stream) != hipSuccess) rc = ISDF_ERR_HIP;
         q.busy = true;
         b.rounds_run++;
         b.evals_run += na;
@@ -163,8 +253,15 @@ extern "C" int isdf_optimize_lbfgs_batch(isdf_ctx *c, int n_traj, int N, const d
     auto deliver = [&](Slot &q) {             // waits for the round, hands the results to its trajectories
         if (rc == ISDF_OK && hipEventSynchronize(q.done) != hipSuccess) rc = ISDF_ERR_HIP;
         const int na = (int)q.active.size();
-        for (int k = 0; k < na && rc == ISDF_OK; k++)
-            std::memcpy(b.stage_out.data() + (size_t)q.active[k] * b.ostride, q.h_pin + in_all + (size_t)k * b.ostride, b.ostride * sizeof(double));
+        if (rc == ISDF_OK) {
+            unsigned long long ovf = 0;
+            std::memcpy(&ovf, q.h_pin + word_at, sizeof(ovf));
+            if (ovf) { rc = ISDF_ERR_OVERFLOW; (void)hipMemset(c->d_stats + 4, 0, sizeof(unsigned long long)); (void)isdf_reset_result_slots(c); }
+        }
+        for (int k = 0; k < na && rc == ISDF_OK; k++) {
+            if (b.device_minco) std::memcpy(b.stage_res.data() + (size_t)q.active[k] * (1 + nv), q.h_pin + x_all + (size_t)k * (1 + nv), (1 + nv) * sizeof(double));
+            else std::memcpy(b.stage_out.data() + (size_t)q.active[k] * b.ostride, q.h_pin + in_all + (size_t)k * b.ostride, b.ostride * sizeof(double));
+        }
         std::unique_lock<std::mutex> lk(b.m);
         if (rc != ISDF_OK) b.error = rc;
         for (int t : q.active) b.ready[t] = 1;
@@ -172,10 +269,11 @@ extern "C" int isdf_optimize_lbfgs_batch(isdf_ctx *c, int n_traj, int N, const d
         q.busy = false;
         b.cv_workers.notify_all();
     };
-    int cur = 0;
+    const int round_cap = b.device_minco ? std::max(8, (n_traj + 3) / 4) : n_traj;
+    const int slots_used = b.device_minco ? N_SLOTS : 2;
+    int head_slot = 0, tail_slot = 0, n_busy = 0;      // ring: rounds are delivered in the order they were issued
     for (;;) {
-        Slot &q = slots[cur], &other = slots[cur ^ 1];
-        if (q.busy) deliver(q);                      // both in flight: the older one first
+        if (n_busy == slots_used) { deliver(slots[tail_slot]); tail_slot = (tail_slot + 1) % slots_used; n_busy--; }
         bool take = false, done = false;
         {
             std::unique_lock<std::mutex> lk(b.m);
@@ -184,8 +282,8 @@ extern "C" int isdf_optimize_lbfgs_batch(isdf_ctx *c, int n_traj, int N, const d
                 const int free_live = b.n_traj - b.n_finished - b.n_inflight;
                 const int need = std::max(1, (int)std::ceil(b.min_share * free_live));
                 if (b.n_submitted > 0 && b.n_submitted >= std::min(need, free_live)) { take = true; break; }
-                if (other.busy) {
-                    if (rc != ISDF_OK || hipEventQuery(other.done) != hipErrorNotReady) break;   // finished (or failed): deliver it - that is where new work comes from
+                if (n_busy > 0) {
+                    if (rc != ISDF_OK || hipEventQuery(slots[tail_slot].done) != hipErrorNotReady) break;   // finished (or failed): deliver it - that is where new work comes from
                     b.cv_coord.wait_for(lk, std::chrono::microseconds(20));
                     continue;
                 }
@@ -193,15 +291,18 @@ extern "C" int isdf_optimize_lbfgs_batch(isdf_ctx *c, int n_traj, int N, const d
                 b.cv_coord.wait(lk);
             }
             if (take) {
+                Slot &q = slots[head_slot];
+                // at most round_cap trajectories per round: a herd that submits together is split into several rounds whose
+                // MINCO kernels run side by side and whose sweeps follow each other without a gap
                 q.active.clear();
-                for (int t = 0; t < n_traj; t++) if (b.submitted[t]) { q.active.push_back(t); b.submitted[t] = 0; }
-                b.n_inflight += b.n_submitted;
-                b.n_submitted = 0;
+                for (int t = 0; t < n_traj && (int)q.active.size() < round_cap; t++) if (b.submitted[t]) { q.active.push_back(t); b.submitted[t] = 0; }
+                b.n_inflight += (int)q.active.size();
+                b.n_submitted -= (int)q.active.size();
             }
         }
         if (done) break;
-        if (take) { issue(q); cur ^= 1; }
-        else deliver(other);
+        if (take) { issue(slots[head_slot]); head_slot = (head_slot + 1) % slots_used; n_busy++; }
+        else { deliver(slots[tail_slot]); tail_slot = (tail_slot + 1) % slots_used; n_busy--; }
     }
     for (auto &th : threads) th.join();
     const auto t1 = std::chrono::steady_clock::now();
