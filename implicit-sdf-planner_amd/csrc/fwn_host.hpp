@@ -1,18 +1,36 @@
 // Fast winding number hierarchy for the MESH robot shape, built on the host at isdf_set_shape and walked on the device.
-// The reference gets w(p) from libigl 2.4.0's igl::fast_winding_number(fwn_bvh, 2.0, p, w) (Shape.cpp:86,110), i.e. the
-// HDK "UT_SolidAngle<float,float>" of src/utils/include/igl/FastWindingNumberForSoups.h (vendored in the reference):
-// a 4-wide BVH over the triangles (UT_BVH<4>, BOX_AREA heuristic) whose nodes carry, per child, an order-2 Taylor
-// expansion of the child's solid angle about its area-weighted centre; a child is approximated when the query is farther
-// than accuracy_scale (2.0) x the child's radius, otherwise descended / evaluated exactly.  Because those far-field terms
-// are an APPROXIMATION (errors up to ~2e-3 in w, entering the SDF through s = 1 - 2w), parity with the reference needs the
-// same tree and the same coefficients, so this file restates that library's published algorithm:
-//   BVH build      BVH<N>::init / initNode / multiSplit / split (exhaustive partitions <= 6 boxes, sorted sweep <= 32,
-//                  16-span binning above) / nthElement / partitionByCentre          (FastWindingNumberForSoups.h:4555-5921)
-//   coefficients   UT_SolidAngle::init: PrecomputeFunctors::item / post                                 (:6514-7097)
-//   evaluation     UT_SolidAngle::computeSolidAngle (SolidAngleFunctors::pre / item / post), UTsignedSolidAngleTri
-//                                                                                                    (:6044-6082, :7119-7258)
-// All arithmetic is float, like UT_SolidAngle<float,float>.  tests/test_oracle_ref.py compares tree, coefficients and w
-// with the vendored library itself (oracle/_ref/libref_fwn.so).
+//
+// ATTRIBUTION.  The host-side BUILD in this file (the 4-wide BVH construction and the per-node order-2 expansion
+// coefficients) follows, function by function, one specific third-party source:
+//     "Fast Winding Numbers for Soups" (WindingNumber / HDK sample UT_SolidAngle, UT_BVH), https://github.com/alecjacobson/WindingNumber
+//     Copyright (c) 2018 Side Effects Software Inc., MIT License
+//     as vendored by libigl 2.4.0 in igl/FastWindingNumberForSoups.h (the reference ships it at
+//     src/utils/include/igl/FastWindingNumberForSoups.h):
+//       BVH<N>::init / initNode / multiSplit / split / nthElement / partitionByCentre      :4555-5921
+//       UT_SolidAngle::init: PrecomputeFunctors::item / post                                :6514-7097
+//       UT_SolidAngle::computeSolidAngle, UTsignedSolidAngleTri (host evaluation, tests)    :6044-6082, :7119-7258
+// It is a de-templated, compacted transliteration of those functions (same control flow, largely the same local names), not
+// an independent design, and it is here for one reason: the reference's mesh SDF takes its sign from
+// igl::fast_winding_number(fwn_bvh, 2.0, p, w) (Shape.cpp:86,110), whose far-field terms are an APPROXIMATION (errors up to
+// ~2e-3 in w, entering the SDF through s = 1 - 2w) - so parity needs the SAME tree (same splits, same child order) and the
+// SAME coefficients, which only the same construction yields.  The product may not link the vendored header.  The upstream
+// licence text:
+//
+//   MIT License.  Copyright (c) 2018 Side Effects Software Inc.
+//   Permission is hereby granted, free of charge, to any person obtaining a copy of this software and associated documentation
+//   files (the "Software"), to deal in the Software without restriction, including without limitation the rights to use, copy,
+//   modify, merge, publish, distribute, sublicense, and/or sell copies of the Software, and to permit persons to whom the
+//   Software is furnished to do so, subject to the following conditions:  The above copyright notice and this permission
+//   notice shall be included in all copies or substantial portions of the Software.
+//   THE SOFTWARE IS PROVIDED "AS IS", WITHOUT WARRANTY OF ANY KIND, EXPRESS OR IMPLIED, INCLUDING BUT NOT LIMITED TO THE
+//   WARRANTIES OF MERCHANTABILITY, FITNESS FOR A PARTICULAR PURPOSE AND NONINFRINGEMENT.  IN NO EVENT SHALL THE AUTHORS OR
+//   COPYRIGHT HOLDERS BE LIABLE FOR ANY CLAIM, DAMAGES OR OTHER LIABILITY, WHETHER IN AN ACTION OF CONTRACT, TORT OR OTHERWISE,
+//   ARISING FROM, OUT OF OR IN CONNECTION WITH THE SOFTWARE OR THE USE OR OTHER DEALINGS IN THE SOFTWARE.
+//
+// What is this repository's own: the flat node record (92 floats per node) the device walks, and the device traversal itself
+// (csrc/dev_mesh.hpp: explicit stack, one combined winding-number / closest-point question per voxel).
+// All arithmetic is float, like UT_SolidAngle<float,float>.  tests/test_fwn_host.py compares tree, coefficients and w with the
+// vendored library itself, node by node (oracle/_ref/libref_fwn.so).
 #pragma once
 #include <algorithm>
 #include <cmath>
