@@ -26,6 +26,28 @@ def test_flatness_bit_exact_vs_reference_header(orc):
         assert np.array_equal(b1, b2)
 
 
+def test_lmbm_flang_build_solves_nonsmooth_problems(orc):
+    """The reference's live optimizer (Fortran 77 LMBM + the C++ shim lmbm.cpp, built by AMD flang into oracle/_ref/liblmbm.so,
+    default lmbm_parameter_t like optimize_traj_lmbm): a smooth and a nonsmooth known-answer problem (MAXQ is one of the test
+    problems of the upstream lmbm_test.f)."""
+    if not os.path.exists(orc.REF_LMBM):
+        pytest.skip("oracle/_ref/liblmbm.so not built (no flang)")
+
+    def rosen(x):
+        f = np.sum(100 * (x[1:] - x[:-1] ** 2) ** 2 + (1 - x[:-1]) ** 2)
+        g = np.zeros_like(x)
+        g[:-1] += -400 * x[:-1] * (x[1:] - x[:-1] ** 2) - 2 * (1 - x[:-1]); g[1:] += 200 * (x[1:] - x[:-1] ** 2)
+        return f, g
+
+    def maxq(x):
+        i = int(np.argmax(x * x)); g = np.zeros_like(x); g[i] = 2 * x[i]
+        return x[i] ** 2, g
+    r = orc.ref_lmbm_optimize(rosen, np.full(10, -1.2))
+    assert r["status"] >= 0 and r["f"] < 1e-8 and np.abs(r["x"] - 1.0).max() < 1e-3 and r["evaluations"] >= r["iterations"] > 10
+    r = orc.ref_lmbm_optimize(maxq, np.arange(1, 21, dtype=float) * np.where(np.arange(20) < 10, 1, -1))
+    assert r["status"] >= 0 and r["f"] < 1e-4
+
+
 def _cube():
     V = np.array([[x, y, z] for x in (-0.5, 0.5) for y in (-0.4, 0.4) for z in (-0.3, 0.3)], dtype=np.float64)
     F = np.array([[0, 1, 3], [0, 3, 2], [4, 6, 7], [4, 7, 5], [0, 4, 5], [0, 5, 1], [2, 3, 7], [2, 7, 6],
