@@ -484,6 +484,7 @@ static int eval_device_impl(isdf_ctx *c, int n_traj, int N, const double *d_T, c
             HIPCHK(c, hipMalloc(&c->d_point_piece, (size_t)c->M * sizeof(int)));
             HIPCHK(c, hipMalloc(&c->d_point_stat, (size_t)c->M * sizeof(unsigned long long)));
             HIPCHK(c, hipMalloc(&c->d_point_nr, (size_t)c->M * sizeof(int)));
+            HIPCHK(c, hipMemset(c->d_point_nr, 0, (size_t)c->M * sizeof(int)));          // "scan passes last step": none yet
             HIPCHK(c, hipMalloc(&c->d_task_buf, (size_t)c->M * 32 * 6 * sizeof(double)));       // SW_MAX_RANGES x TASK_STRIDE per point
             HIPCHK(c, hipMalloc(&c->d_task_map, (size_t)c->M * 32 * sizeof(unsigned)));
             HIPCHK(c, hipMalloc(&c->d_point_lmask, (size_t)c->M * sizeof(unsigned)));
@@ -501,7 +502,7 @@ static int eval_device_impl(isdf_ctx *c, int n_traj, int N, const double *d_T, c
         P.stats = c->d_stats;
         P.dbg = nullptr;
         if (const char *e = getenv("ISDF_DEBUG_TIMING")) if (e[0] == '1') {
-            const size_t need = (size_t)c->M * 4 + (size_t)(N + 1) * 8;
+            const size_t need = (size_t)c->M * 7 + (size_t)(N + 1) * 8;
             if (c->dbg_cap < need) {
                 if (c->d_dbg) (void)hipFree(c->d_dbg);
                 c->d_dbg = nullptr; c->dbg_cap = 0;

@@ -401,6 +401,7 @@ __global__ __launch_bounds__(64 * SW_WAVES) void swept_descent_kernel(const Swep
     const int gd_off = lane < 18 ? 0 : (lane < 25 ? lane - 18 : (lane < 60 ? (lane - 25) % 7 : 0));
     for (unsigned task = blockIdx.x * SW_WAVES + wave, rounds = 0; task < n_tasks && rounds < (1u << 16); task += n_waves, rounds++) {
         const unsigned tm = task < n_front ? P.task_map[task] : P.task_map[cap - 1u - (task - n_front)];
+        const unsigned long long dbg_t0 = P.dbg ? wall_clock64() : 0ull;
         const int rel = (int)(tm >> 5), r = (int)(tm & 31u);
         const int pt = P.point_begin + rel;
         double *const slot = P.task_buf + ((size_t)rel * SW_MAX_RANGES + r) * TASK_STRIDE;
@@ -514,6 +515,10 @@ __global__ __launch_bounds__(64 * SW_WAVES) void swept_descent_kernel(const Swep
             slot[0] = x; slot[1] = fx; slot[2] = g1_at_x.x; slot[3] = g1_at_x.y; slot[4] = g1_at_x.z;
             slot[5] = __longlong_as_double((long long)(((unsigned long long)n_pass & 0xFFFFull) | ((unsigned long long)iter << 16)));
             if (n_pass >= LPT_TASK) atomicOr(&P.point_lmask[pt], 1u << r);      // next step: dispatch this interval's descent early
+            if (P.dbg && task < (unsigned)P.M) {      // developer timing (ISDF_DEBUG_TIMING=1): start, end, passes of this task
+                unsigned long long *d = P.dbg + (size_t)P.M * 4 + (size_t)(P.N + 1) * 8 + (size_t)task * 3;
+                d[0] = dbg_t0; d[1] = wall_clock64(); d[2] = (unsigned long long)n_pass | ((unsigned long long)(task < n_front) << 32);
+            }
         }
     }
 }

@@ -22,11 +22,12 @@ d_out = torch.zeros(eng.out_stride(40), dtype=torch.float64, device=dev)
 for _ in range(3):
     eng.eval_device(1, 40, d_T.data_ptr(), d_C.data_ptr(), d_out.data_ptr(), 0, st)
 torch.cuda.synchronize()
-buf = np.zeros(M * 4 + 41 * 8, dtype=np.uint64)
+buf = np.zeros(M * 7 + 41 * 8, dtype=np.uint64)
 eng.lib.isdf_debug_timing.restype = C.c_longlong
 n = eng.lib.isdf_debug_timing(eng.h, buf.ctypes.data_as(C.c_void_p), C.c_longlong(buf.size))
 d = buf[:M * 4].reshape(M, 4)
-rd = buf[M * 4:].reshape(41, 8).astype(np.int64)
+rd = buf[M * 4:M * 4 + 41 * 8].reshape(41, 8).astype(np.int64)
+td = buf[M * 4 + 41 * 8:].reshape(M, 3)
 t0 = d[:, 0].astype(np.int64); t1 = d[:, 1].astype(np.int64); t2 = d[:, 2].astype(np.int64)
 t3 = (d[:, 3] >> np.uint64(16)).astype(np.int64); npass = (d[:, 3] & np.uint64(0xFFF)).astype(np.int64); nrng = ((d[:, 3] >> np.uint64(12)) & np.uint64(0xF)).astype(np.int64)
 base = t0.min()
@@ -52,3 +53,12 @@ print("reduce kernel, per block (us from first block start): start / loop / butt
 for i in (0, 1, 20, 39, 40):
     print(f"  block {i}: " + " ".join(f"{us(rd[i, k] - rb):7.2f}" for k in range(6)))
 print(f"  all blocks: latest end {us(rd[:, 5].max() - rb):.2f} us; loop mean {us((rd[:,1]-rd[:,0]).mean()):.2f}; butterfly mean {us((rd[:,2]-rd[:,1]).mean()):.2f}; ticket mean {us((rd[:,4]-rd[:,3]).mean()):.2f}")
+
+tt = td[td[:, 1] > 0]
+ts, te, tp = tt[:, 0].astype(np.int64), tt[:, 1].astype(np.int64), (tt[:, 2] & np.uint64(0xFFFFFFFF)).astype(np.int64)
+heavy = (tt[:, 2] >> np.uint64(32)).astype(np.int64)
+b0 = ts.min()
+print(f"descent kernel: {len(tt)} tasks ({heavy.sum()} dispatched first), span {us(te.max() - b0):.1f} us; task life mean {us((te - ts).mean()):.1f} max {us((te - ts).max()):.1f}; passes mean {tp.mean():.1f} max {tp.max()}")
+print(f"  start times: p50 {us(np.percentile(ts - b0, 50)):.1f} p90 {us(np.percentile(ts - b0, 90)):.1f} max {us((ts - b0).max()):.1f} us;  us per pass: p50 {np.percentile(us(te - ts) / np.maximum(tp, 1), 50):.2f} p90 {np.percentile(us(te - ts) / np.maximum(tp, 1), 90):.2f}")
+for k in np.argsort(-(te - b0))[:8]:
+    print(f"  task {k}: heavy {heavy[k]} passes {tp[k]} start {us(ts[k] - b0):.1f} end {us(te[k] - b0):.1f} ({us(te[k]-ts[k])/max(tp[k],1):.2f} us/pass)")
