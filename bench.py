@@ -120,6 +120,7 @@ def main():
     ap.add_argument("--cull", type=int, default=0, help="1: enable the V3 whole-tile cull (reported separately, never as value)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra-configs", action="store_true", help="skip the C3 / C4 / 512^3 entries of `configs`")
+    ap.add_argument("--no-host-api", action="store_true", help="skip the host-pointer boundary timing (its ~1 500 host-direct launches of the same kernel run ~2 us longer and would dilute a rocprofv3 average of the device-resident step)")
     ap.add_argument("--lbfgs-iters", type=int, default=40, help="iterations of the L-BFGS driver timed after the sweep (0: skip)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     args = ap.parse_args()
@@ -392,7 +393,7 @@ def main():
         cb_native_ms = None
         x0 = None
         c6 = cm.reshape(3, 6 * N).T.reshape(N, 6, 3)
-        if world == 1:
+        if world == 1 and not (args.no_host_api and args.lbfgs_iters <= 0):
             eng.set_shard(0, 1)
             head = np.stack([c6[0, 0], c6[0, 1], 2.0 * c6[0, 2]], axis=1)
             tl = T[-1]
@@ -400,8 +401,10 @@ def main():
             tail = np.stack([pw(0), pw(1), pw(2)], axis=1)
             eng.set_trajectory(N, head, tail, 1000.0)
             x0 = eng.pack_variables(T, c6[1:, 0, :])
-            nat = native_boundary_ms(pkg, eng, N, T, cm, x0)
-            if nat is not None:
+            nat = None if args.no_host_api else native_boundary_ms(pkg, eng, N, T, cm, x0)
+            if args.no_host_api:
+                pass
+            elif nat is not None:
                 host_ms, cb_native_ms = nat
                 host_timer = "native: median of 1000 isdf_eval calls inside the compiled reference-side binding (tests/native/binding_stub.cpp)"
             else:

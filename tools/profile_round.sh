@@ -8,8 +8,8 @@ REPO=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$REPO/gpurun_out
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-BENCH="python $REPO/bench.py --steps 200 --warmup 20 --no-cpu-baseline --lbfgs-iters 0 --no-extra-configs"
-BENCHS="python $REPO/bench.py --steps 20 --warmup 3 --no-cpu-baseline --lbfgs-iters 0 --no-extra-configs"
+BENCH="python $REPO/bench.py --steps 200 --warmup 20 --no-cpu-baseline --lbfgs-iters 0 --no-extra-configs --no-host-api"
+BENCHS="python $REPO/bench.py --steps 20 --warmup 3 --no-cpu-baseline --lbfgs-iters 0 --no-extra-configs --no-host-api"
 finddb() { find "$1" -name "*results.db" | head -1; }
 rm -rf /tmp/prof_kt /tmp/prof_f /tmp/prof_w /tmp/prof_sq /tmp/prof_sq2 /tmp/prof_sq3
 timeout 600 rocprofv3 --kernel-trace --stats -d /tmp/prof_kt -- $BENCH > $OUT/${TAG}_bench_under_rocprof.log 2>&1
