@@ -161,7 +161,7 @@ extern "C" int isdf_destroy(isdf_ctx *c) {
     isdf_xchg_release(c);
     void *ptrs[] = {c->d_cb, c->d_esdf, c->d_occ, c->d_points, c->d_tstar, c->d_acc, c->d_sample_info, c->d_bits, c->d_piece_cost, c->d_in, c->d_out, c->d_stats,
                     c->d_traj_duration, c->d_coarse_t, c->d_coarse_pose, c->d_n_coarse, c->d_point_partial, c->d_point_piece, c->d_point_stat, c->d_point_nr, c->d_task_buf,
-                    c->d_task_map, c->d_v1_words, c->d_point_lmask, c->d_hist, c->d_dbg, c->d_stage, c->d_stage_flags};
+                    c->d_task_map, c->d_v1_words, c->d_point_lmask, c->d_hist, c->d_dbg, c->d_stage, c->d_stage_flags, c->d_sample_map, c->d_plan_cls, c->d_plan_map};
     for (void *p : ptrs) if (p) (void)hipFree(p);
     free_mesh(c);
     if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -564,6 +564,7 @@ static int eval_device_impl(isdf_ctx *c, int n_traj, int N, const double *d_T, c
     P.T = d_T; P.coeffs = d_coeffs; P.acc = c->d_acc; P.sample_info = c->d_sample_info; P.piece_cost = c->d_piece_cost;
     P.out = d_out; P.stats = c->d_stats;
     P.dbg = nullptr;
+    P.sample_map = (c->d_sample_map && c->sample_map_n == 4 * (((size_t)(pe - pb) * (cfg.integral_intervs + 1) + 3) / 4)) ? c->d_sample_map : nullptr;
     P.dbg_flags = 0;
     if (const char *e = getenv("ISDF_DEBUG_FLAGS")) P.dbg_flags = atoi(e);
     if (const char *e = getenv("ISDF_NO_FUSE")) c->fuse_small = e[0] != '1';
@@ -623,6 +624,30 @@ static int eval_device_impl(isdf_ctx *c, int n_traj, int N, const double *d_T, c
         P.out = hd->out; P.host_flag = hd->flags; P.seq = hd->seq;
         if (!hd->via_bar) { P.host_T = hd->T; P.host_coeffs = hd->coeffs; P.stage = c->d_stage; P.stage_flags = c->d_stage_flags; }
         c->last_P = P;
+    }
+    // longest-first dispatch order of a fused step whose workgroups outnumber the CUs (tile_sweep.hip, plan_piece)
+    P.plan_cls_in = nullptr; P.plan_cls_out = nullptr; P.plan_map_out = nullptr; P.plan_zone = 0;
+    {
+        const long long ns_local = (long long)(pe - pb) * (cfg.integral_intervs + 1);
+        const int nb = (int)((ns_local + 3) / 4);
+        if (c->n_cus == 0) { hipDeviceProp_t pr; c->n_cus = (hipGetDeviceProperties(&pr, c->device) == hipSuccess && pr.multiProcessorCount > 0) ? pr.multiProcessorCount : 256; }
+        static const bool no_plan = [] { const char *e = getenv("ISDF_NO_LPT"); return e && e[0] == '1'; }();
+        const bool plan = fused && !no_plan && !P.sample_map && P.xf.world <= 1 && pb == 0 && pe == total_pieces && ns_local <= PLAN_MAX_SAMPLES && nb > c->n_cus;
+        if (!plan) c->plan_k = 0;
+        else {
+            if (!c->d_plan_cls) {
+                HIPCHK(c, hipMalloc(&c->d_plan_cls, 2 * (size_t)PLAN_MAX_SAMPLES));
+                HIPCHK(c, hipMalloc(&c->d_plan_map, 2 * (size_t)PLAN_MAX_SAMPLES * sizeof(int)));
+            }
+            if (c->plan_ns != ns_local || c->plan_nb != nb) { c->plan_k = 0; c->plan_ns = ns_local; c->plan_nb = nb; }
+            const int par = c->plan_k & 1;
+            P.plan_zone = c->n_cus;
+            P.plan_cls_out = c->d_plan_cls + (size_t)par * PLAN_MAX_SAMPLES;
+            P.plan_map_out = c->d_plan_map + (size_t)(1 - par) * PLAN_MAX_SAMPLES;
+            if (c->plan_k >= 1) P.plan_cls_in = c->d_plan_cls + (size_t)(1 - par) * PLAN_MAX_SAMPLES;
+            if (c->plan_k >= 2) P.sample_map = c->d_plan_map + (size_t)par * PLAN_MAX_SAMPLES;
+            if (c->plan_k < (1 << 30)) c->plan_k++;
+        }
     }
     launch_sweep(P, st, ev ? ev->a : nullptr, ev ? ev->b : nullptr, fused);
     if (!fused) launch_tail(P, st, ev2 ? ev->c : nullptr, ev2 ? ev->d : nullptr);
@@ -1197,6 +1222,31 @@ extern "C" int isdf_get_stats(isdf_ctx *c, isdf_stats *out) {
     }
     *out = c->last_stats;
     return ISDF_OK;
+}
+
+// developer tool (not declared in the ABI header): dispatch order of the tile sweep's samples (a permutation of 0..n-1)
+extern "C" int isdf_debug_set_sample_map(isdf_ctx *c, const int *map, long long n) {
+    if (!c) return ISDF_ERR_INVALID_ARG;
+    (void)hipSetDevice(c->device);
+    (void)hipDeviceSynchronize();
+    if (c->d_sample_map) (void)hipFree(c->d_sample_map);
+    c->d_sample_map = nullptr; c->sample_map_n = 0;
+    if (!map || n <= 0) return ISDF_OK;
+    if (hipMalloc(&c->d_sample_map, (size_t)n * sizeof(int)) != hipSuccess) return ISDF_ERR_HIP;
+    (void)hipMemcpy(c->d_sample_map, map, (size_t)n * sizeof(int), hipMemcpyHostToDevice);
+    c->sample_map_n = (size_t)n;
+    return ISDF_OK;
+}
+
+// developer tool (not declared in the ABI header): the longest-first dispatch order the NEXT fused step would use
+// (4 * workgroups entries, -1 = none); returns the number of consecutive steps the plan has been running, 0 = inactive
+extern "C" int isdf_debug_plan_map(isdf_ctx *c, int *out, long long cap) {
+    if (!c || c->plan_k < 2 || !c->d_plan_map) return 0;
+    (void)hipSetDevice(c->device);
+    (void)hipDeviceSynchronize();
+    const long long n = 4LL * c->plan_nb < cap ? 4LL * c->plan_nb : cap;
+    if (out && n > 0) (void)hipMemcpy(out, c->d_plan_map + (size_t)(c->plan_k & 1) * PLAN_MAX_SAMPLES, (size_t)n * sizeof(int), hipMemcpyDeviceToHost);
+    return c->plan_k;
 }
 
 // developer tool (not declared in the ABI header): the HIP runtime's pending error of the calling thread, without clearing it

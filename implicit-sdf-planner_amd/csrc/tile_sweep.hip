@@ -239,6 +239,85 @@ constexpr int sweep_waves_per_simd(int kind, bool ident) {
     }
 }
 
+// Longest-first dispatch order of a fused single-launch step.  Such a launch is resident as a whole, 2 - 3 workgroups per CU,
+// and a CU's instruction issue is what its workgroups share: the step lasts as long as the CU with the most work.  The
+// dispatcher hands workgroup b to XCD b % 8 and, there, to the next CU in turn, so workgroups [0, #CUs) are the first on their
+// CU: they get the heaviest samples, everyone after them the lighter ones (measured with orders built on the host,
+// tools/lpt_experiment.py: rounded cone 33.1 -> 26.3 us per step, box 22.2 -> 21.5; orders that only even out the workgroups, or
+// per-piece quotas, gain nothing).  Order = stable counting sort of the samples by work class (exact pairs / 32 of the step
+// BEFORE the last - the trajectory moves little between optimizer steps), classes descending, trajectory order inside a class
+// (neighbouring workgroups keep neighbouring tiles).  Built by the tail workgroups while they wait for the sweep: every one of
+// them scans all classes (<= 4 KB) and writes the entries of its own piece's samples.  Scheduling only: which wave evaluates a
+// sample has no influence on any result.
+__device__ __forceinline__ int plan_rank(int pos, int Z, int nb) {
+    const int q0 = 4 * Z;
+    if (pos < q0) { const int w = pos / Z; return w * nb + (pos - w * Z); }
+    const int n3 = nb - Z, p1 = pos - q0, w = p1 / n3;
+    return w * nb + Z + (p1 - w * n3);
+}
+__device__ __forceinline__ unsigned plan_field(unsigned long long lo, unsigned long long hi, int c) {
+    return (unsigned)(((c < 4 ? lo : hi) >> (16 * (c & 3))) & 0xFFFFull);
+}
+__device__ void plan_piece(const SweepParams &P, const int t) {
+    constexpr int SEG = PLAN_MAX_SAMPLES / (64 * SW_SAMPLES);       // samples per thread
+    __shared__ unsigned long long s_wsum[SW_SAMPLES][2];
+    const int K1 = P.K + 1;
+    const int ns = (P.piece_end - P.piece_begin) * K1, nb = P.n_sweep_blocks, Z = P.plan_zone;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    // classes of this thread's stretch of samples, counted per class in 16-bit fields (classes 0-3 | 4-7)
+    unsigned char cls[SEG];
+    unsigned long long lo = 0, hi = 0;
+    {
+        const uint4 v = (tid * SEG < ns) ? reinterpret_cast<const uint4 *>(P.plan_cls_in)[tid] : make_uint4(0, 0, 0, 0);
+        const unsigned wds[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int e = 0; e < SEG; e++) {
+            cls[e] = (unsigned char)((wds[e >> 2] >> (8 * (e & 3))) & 7u);
+            if (tid * SEG + e < ns) { if (cls[e] < 4) lo += 1ull << (16 * cls[e]); else hi += 1ull << (16 * (cls[e] - 4)); }
+        }
+    }
+    // inclusive scan over the workgroup's threads
+    unsigned long long ilo = lo, ihi = hi;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const unsigned long long a = __shfl_up(ilo, d), b = __shfl_up(ihi, d);
+        if (lane >= d) { ilo += a; ihi += b; }
+    }
+    if (lane == 63) { s_wsum[wave][0] = ilo; s_wsum[wave][1] = ihi; }
+    __syncthreads();
+    unsigned long long tlo = 0, thi = 0;          // totals per class
+#pragma unroll
+    for (int w = 0; w < SW_SAMPLES; w++) {
+        if (w < wave) { ilo += s_wsum[w][0]; ihi += s_wsum[w][1]; }
+        tlo += s_wsum[w][0]; thi += s_wsum[w][1];
+    }
+    unsigned long long rlo = ilo - lo, rhi = ihi - hi;      // samples of each class before this thread's stretch
+    // first position of each class: classes descending
+    unsigned long long blo = 0, bhi = 0;
+    {
+        unsigned run = 0;
+#pragma unroll
+        for (int c = 7; c >= 0; c--) {
+            if (c < 4) blo |= (unsigned long long)run << (16 * c); else bhi |= (unsigned long long)run << (16 * (c - 4));
+            run += plan_field(tlo, thi, c);
+        }
+    }
+    const int s_lo = t * K1, s_hi = s_lo + K1;    // this workgroup writes its own piece's samples (t = local piece: all pieces are local)
+#pragma unroll
+    for (int e = 0; e < SEG; e++) {
+        const int s = tid * SEG + e;
+        if (s < ns) {
+            const int c = cls[e];
+            const int pos = (int)(plan_field(blo, bhi, c) + plan_field(rlo, rhi, c));
+            if (c < 4) rlo += 1ull << (16 * c); else rhi += 1ull << (16 * (c - 4));
+            if (s >= s_lo && s < s_hi) P.plan_map_out[plan_rank(pos, Z, nb)] = s;
+        }
+    }
+    // ranks behind the last sample stay empty
+    if (t == 0) for (int pos = ns + tid; pos < 4 * nb; pos += 64 * SW_SAMPLES) P.plan_map_out[plan_rank(pos, Z, nb)] = -1;
+    __syncthreads();
+}
+
 // IDENT: the shape's body offset is the identity (poly_params all zero - every shipped config): those instantiations drop
 // the offset and the 24 scalar registers it pins, which takes Box to 91 VGPRs and a fifth wave per SIMD.
 template <bool EARLY, bool XF> __device__ __forceinline__ void tail_piece(const SweepParams &P, const int t, double (*s_val)[PARTIAL_STRIDE + 1]);
@@ -253,6 +332,7 @@ __global__ __launch_bounds__(64 * SW_SAMPLES, FUSED ? 3 : sweep_waves_per_simd(K
     if constexpr (FUSED) {
         __shared__ double s_tail[TL_THREADS][PARTIAL_STRIDE + 1];
         if ((int)blockIdx.x >= n_blocks) {
+            if (P.plan_cls_in) plan_piece(P, (int)blockIdx.x - n_blocks);       // while the sweep works: the NEXT step's dispatch order
             if (P.xf.world > 1) tail_piece<false, true>(P, (int)blockIdx.x - n_blocks, s_tail);      // multi-GPU step: exchange inside
             else tail_piece<false, false>(P, (int)blockIdx.x - n_blocks, s_tail);
             return;
@@ -275,15 +355,23 @@ __global__ __launch_bounds__(64 * SW_SAMPLES, FUSED ? 3 : sweep_waves_per_simd(K
     const int K1 = P.K + 1;
     const long long s_begin = (long long)P.piece_begin * K1, s_end = (long long)P.piece_end * K1;
     const DevGrid &G = P.grid;
-    // wave w of workgroup b takes sample b + w * n_blocks: the samples of one workgroup are far apart on the
-    // trajectory, so their candidate counts are uncorrelated and the workgroup's exact work evens out
-    const long long sidx = s_begin + (long long)blockIdx.x + (long long)wave * n_blocks;
+    // rank of this wave in the launch -> its sample: b + w * n_blocks (the samples of one workgroup are far apart on the
+    // trajectory, so their candidate counts are uncorrelated), or through the longest-first order of plan_piece
+    const long long rank_w = (long long)blockIdx.x + (long long)wave * n_blocks;
+    long long sidx = s_begin + rank_w;
+    if (P.sample_map) { const int m = __builtin_amdgcn_readfirstlane(P.sample_map[rank_w]); sidx = m >= 0 ? s_begin + m : s_end; }
     unsigned long long *const dbg = (P.dbg && sidx < s_end) ? P.dbg + (size_t)(sidx - s_begin) * 8 : nullptr;
     if (dbg && lane == 0) { dbg[0] = wall_clock64(); dbg[1] = clock64(); }
 
     // ---- poses of the workgroup's samples: one LANE per sample (the serial fp64 chain is issued once, not per wave)
-    if (wave == 0 && lane < SW_SAMPLES && s_begin + (long long)blockIdx.x + (long long)lane * n_blocks < s_end) {
-        const SampleId id = decode_sample(P, s_begin + (long long)blockIdx.x + (long long)lane * n_blocks);
+    long long pose_sidx = s_end;
+    if (wave == 0 && lane < SW_SAMPLES) {
+        const long long rank_l = (long long)blockIdx.x + (long long)lane * n_blocks;
+        pose_sidx = s_begin + rank_l;
+        if (P.sample_map) { const int m = P.sample_map[rank_l]; pose_sidx = m >= 0 ? s_begin + m : s_end; }
+    }
+    if (pose_sidx < s_end) {
+        const SampleId id = decode_sample(P, pose_sidx);
         bool staged = true;
         if constexpr (FUSED) if (P.host_T) staged = stage_wait(P, id.b * P.N + id.i);
         if (!staged && P.stats) atomicMax(&P.stats[4], 1ull);
@@ -676,7 +764,10 @@ __global__ __launch_bounds__(64 * SW_SAMPLES, FUSED ? 3 : sweep_waves_per_simd(K
             if constexpr (FUSED) slot_publish(&P.acc[(size_t)sl * ACC_STRIDE + lane], tot);    // the tail may already be polling
             else P.acc[(size_t)sl * ACC_STRIDE + lane] = tot;                                  // read by the next launch
         }
-        else if (lane == ACC_STRIDE) P.sample_info[2 * sl] = tot_n;
+        else if (lane == ACC_STRIDE) {
+            P.sample_info[2 * sl] = tot_n;
+            if (P.plan_cls_out) P.plan_cls_out[sl] = (unsigned char)min((tot_n + 31) >> 5, 7);     // work class: exact pairs / 32
+        }
         else if (lane == ACC_STRIDE + 1) P.sample_info[2 * sl + 1] = tot_n | ((flags & 2) ? (int)0x80000000 : 0);
     }
     if (dbg && lane == 0) {

@@ -328,3 +328,58 @@ def test_crowded_tiles_fill_the_candidate_ring(pkg, orc, product_lib, shape_name
     assert st["grad_pairs"] == st0[3]
     assert abs(c - c0) <= REL_TOL * abs(c0)
     assert_close(gT, gT0, "crowded gradT"); assert_close(gC, gC0, "crowded gradC")
+
+
+@pytest.mark.parametrize("shape_name", ["RoundedCone", "Box"])
+def test_longest_first_order_is_scheduling_only(pkg, orc, product_lib, shape_name):
+    """A fused single-launch step with more workgroups than CUs dispatches its samples longest-first from the third step on
+    (tile_sweep.hip, plan_piece).  The order is a permutation built on the device from the previous steps' work; results must
+    be bit for bit those of the plain order - same trajectory repeated, trajectory changed under a running plan, batch of two."""
+    import ctypes as C
+    capi, synth = pkg.capi, pkg.synth
+    occ, esdf, res = small_world(pkg)
+    cfg = synth.default_config(capi.V3_ESDF_TILE, kernel_size=9, integral_intervs=16, safety_hor=0.5)
+    if shape_name == "Box":
+        shape = synth.make_shape("Box", params=(1.2, 0.4, 0.3), grad_mode=capi.GRAD_CENTRAL)
+    else:
+        shape = synth.make_shape("RoundedCone", params=(0.8, 0.3, 1.6))
+    N, K1 = 70, 17
+    ns, nb = N * K1, (N * K1 + 3) // 4
+    Ta, ca = traj(pkg, occ, res, N=N, seed=5)
+    Tb, cb = traj(pkg, occ, res, N=N, seed=6)
+    fresh = {}
+    for name, (T, cm) in (("a", (Ta, ca)), ("b", (Tb, cb))):
+        e0, o = make_pair(pkg, orc, cfg, shape, esdf=esdf, res=res)
+        fresh[name] = e0.eval_single(T, cm)               # first step of a context: plain order
+        c0, gT0, gC0, _ = o.eval(T, cm)
+        assert abs(fresh[name][0] - c0) <= REL_TOL * max(abs(c0), 1e-9)
+        assert_close(fresh[name][2], gC0, "gradC vs oracle")
+    eng = pkg.Engine(cfg)
+    eng.set_grid(esdf, (0, 0, 0), res, capi.GRID_ESDF); eng.set_shape(shape)
+    lib = eng.lib
+    lib.isdf_debug_plan_map.restype = C.c_int
+    lib.isdf_debug_plan_map.argtypes = [C.c_void_p, C.c_void_p, C.c_longlong]
+    for step in range(6):
+        got = eng.eval_single(Ta, ca)
+        assert got[0] == fresh["a"][0] and np.array_equal(got[1], fresh["a"][1]) and np.array_equal(got[2], fresh["a"][2]), step
+    m = np.full(4 * nb, -7, dtype=np.int32)
+    k = lib.isdf_debug_plan_map(eng.h, m.ctypes.data_as(C.c_void_p), m.size)
+    assert k >= 3, "the plan must be running (fused launch with more workgroups than CUs)"
+    assert np.array_equal(np.sort(m[m >= 0]), np.arange(ns)) and np.count_nonzero(m == -1) == 4 * nb - ns, "not a permutation"
+    assert not np.array_equal(m[:ns], np.arange(ns)), "the order should differ from the plain one in a map with obstacles"
+    for step in range(4):                                   # the plan keeps running across a changed trajectory
+        got = eng.eval_single(Tb, cb)
+        assert got[0] == fresh["b"][0] and np.array_equal(got[2], fresh["b"][2]), step
+    # a different launch geometry resets it, and coming back starts it again
+    T3, c3 = traj(pkg, occ, res, N=9, seed=8)
+    eng.eval_single(T3, c3)
+    for step in range(4):
+        got = eng.eval_single(Ta, ca)
+        assert got[0] == fresh["a"][0] and np.array_equal(got[2], fresh["a"][2]), step
+    # two trajectories in one fused launch
+    T2, c2 = traj(pkg, occ, res, N=35, seed=9)
+    e1 = pkg.Engine(cfg); e1.set_grid(esdf, (0, 0, 0), res, capi.GRID_ESDF); e1.set_shape(shape)
+    one = e1.eval_single(T2, c2)
+    for step in range(5):
+        cost, gTs, gCs = eng.eval([T2, T2], [c2, c2])
+        assert cost[0] == one[0] and cost[1] == one[0] and np.array_equal(gCs[1], one[2]), step

@@ -1,0 +1,165 @@
+#!/usr/bin/env python
+"""Developer experiment: does a balanced dispatch order of the tile sweep's samples shorten the single-trajectory step?
+Measures the step with the identity order, then with orders built from the PREVIOUS step's per-sample work (row-scan cycles,
+candidate counts from ISDF_DEBUG_TIMING), dealt so that every workgroup gets one sample of each quartile."""
+import os, sys, ctypes as C
+import numpy as np
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import __graft_entry__ as graft
+import torch
+pkg = graft.load_package(); capi, synth = pkg.capi, pkg.synth
+from bench import build_workload
+
+
+def step_us(eng, N, d_T, d_C, d_out, st, n=300):
+    for _ in range(20):
+        eng.eval_device(1, N, d_T.data_ptr(), d_C.data_ptr(), d_out.data_ptr(), 0, st)
+    torch.cuda.synchronize()
+    e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(n):
+        eng.eval_device(1, N, d_T.data_ptr(), d_C.data_ptr(), d_out.data_ptr(), 0, st)
+    e1.record(); torch.cuda.synchronize()
+    return 1e3 * e0.elapsed_time(e1) / n
+
+
+def main():
+    shape_name = sys.argv[1] if len(sys.argv) > 1 else "box"
+    res = 0.2
+    occ, esdf, T, cm = build_workload(pkg, 40, 256, res)
+    shape = synth.bench_box_shape() if shape_name == "box" else synth.bench_rounded_cone_shape()
+    cfg = synth.default_config(capi.V3_ESDF_TILE, kernel_size=21, integral_intervs=64, safety_hor=(3 ** 0.5 / 2) * res,
+                               weight_p=4000.0, smoothing_eps=0.01)
+    dev = torch.device("cuda", 0)
+    torch.zeros(1, device=dev)
+    N = T.size
+    d_T = torch.from_numpy(T).to(dev); d_C = torch.from_numpy(cm).to(dev)
+    st = torch.cuda.current_stream().cuda_stream
+
+    # pass 1: per-sample work of one step (timing build of the same kernel)
+    os.environ["ISDF_DEBUG_TIMING"] = "1"
+    eng = pkg.Engine(cfg)
+    eng.set_grid(esdf, (0, 0, 0), res, capi.GRID_ESDF); eng.set_shape(shape)
+    d_out = torch.zeros(eng.out_stride(N), dtype=torch.float64, device=dev)
+    for _ in range(3):
+        eng.eval_device(1, N, d_T.data_ptr(), d_C.data_ptr(), d_out.data_ptr(), 0, st)
+    torch.cuda.synchronize()
+    lib = eng.lib
+    lib.isdf_debug_timing.restype = C.c_longlong
+    lib.isdf_debug_timing.argtypes = [C.c_void_p, C.c_void_p, C.c_longlong]
+    n = lib.isdf_debug_timing(eng.h, None, 0)
+    buf = np.zeros(n, dtype=np.uint64)
+    lib.isdf_debug_timing(eng.h, buf.ctypes.data_as(C.c_void_p), n)
+    ns = N * 65
+    sc = buf[:ns * 8].reshape(ns, 8).astype(np.int64)
+    rows = np.maximum(sc[:, 4] - sc[:, 2], 0)
+    cand = (sc[:, 3] >> 44) & 0xFFFFF
+    rounds = sc[:, 3] & 255
+    passes = (sc[:, 3] >> 8) & 255
+    ref = d_out.cpu().numpy().copy()
+    del eng
+    os.environ["ISDF_DEBUG_TIMING"] = "0"
+
+    eng = pkg.Engine(cfg)
+    eng.set_grid(esdf, (0, 0, 0), res, capi.GRID_ESDF); eng.set_shape(shape)
+    lib = eng.lib
+    lib.isdf_debug_set_sample_map.argtypes = [C.c_void_p, C.c_void_p, C.c_longlong]
+    nb = (ns + 3) // 4
+    print(f"{shape_name}: identity order            {step_us(eng, N, d_T, d_C, d_out, st):7.2f} us/step")
+
+    def deal(order, snake):
+        """order: sample ids, heaviest first.  rank r of the launch = workgroup r % nb, wave r // nb."""
+        m = np.zeros(ns, dtype=np.int32)
+        for w in range(4):
+            seg = order[w * nb:(w + 1) * nb]
+            if snake and (w & 1):
+                seg = seg[::-1]
+            m[w * nb: w * nb + seg.size] = seg
+        return m
+
+    keys = {"rows cycles": rows, "candidates": cand, "rounds*4+passes": rounds * 4 + passes, "rows + 50*cand": rows + 50 * cand,
+            "chunks": (cand + 63) // 64}
+    for name, key in keys.items():
+        order = np.argsort(-key, kind="stable").astype(np.int32)
+        for snake in (False, True):
+            m = deal(order, snake)
+            assert np.array_equal(np.sort(m), np.arange(ns))
+            lib.isdf_debug_set_sample_map(eng.h, m.ctypes.data_as(C.c_void_p), ns)
+            t = step_us(eng, N, d_T, d_C, d_out, st)
+            same = np.array_equal(d_out.cpu().numpy(), ref)
+            print(f"{shape_name}: by {name:18s} {'snake' if snake else 'plain'}  {t:7.2f} us/step   bitwise same: {same}")
+    # identity THROUGH the table: the cost of the lookup alone
+    m = np.arange(ns, dtype=np.int32)
+    lib.isdf_debug_set_sample_map(eng.h, m.ctypes.data_as(C.c_void_p), ns)
+    print(f"{shape_name}: identity through the table {step_us(eng, N, d_T, d_C, d_out, st):7.2f} us/step")
+    # sorted within groups of 8 consecutive workgroups' samples only (keeps neighbours together)
+    for G in (2, 8, 32):
+        key = cand
+        m = np.arange(ns, dtype=np.int32).reshape(4, nb) if ns == 4 * nb else None
+        if m is not None:
+            m = m.copy()
+            for g0 in range(0, nb, G):
+                blk = m[:, g0:g0 + G]                  # the 4 x G samples of G neighbouring workgroups
+                ids = blk.reshape(-1)
+                o = ids[np.argsort(-key[ids], kind="stable")]
+                g = blk.shape[1]
+                for w in range(4):
+                    seg = o[w * g:(w + 1) * g]
+                    blk[w, :] = seg[::-1] if (w & 1) else seg
+            mm = m.reshape(-1).astype(np.int32)
+            assert np.array_equal(np.sort(mm), np.arange(ns))
+            lib.isdf_debug_set_sample_map(eng.h, mm.ctypes.data_as(C.c_void_p), ns)
+            print(f"{shape_name}: balanced within {G:3d} neighbouring workgroups {step_us(eng, N, d_T, d_C, d_out, st):7.2f} us/step")
+    # the workgroups beyond 2 per CU (index >= 512) get the lightest samples; trajectory order kept inside both groups
+    for name, key in (("candidates", cand), ("chunks", (cand + 63) // 64), ("rows + 50*cand", rows + 50 * cand)):
+        for nfull in (512, 256):
+            n3 = nb - nfull
+            if n3 <= 0:
+                continue
+            o = np.argsort(key, kind="stable")
+            light = np.sort(o[:4 * n3]); heavy = np.sort(o[4 * n3:])
+            m = np.zeros(ns, dtype=np.int32)
+            for w in range(4):
+                m[w * nb: w * nb + nfull] = heavy[w * nfull:(w + 1) * nfull]
+                m[w * nb + nfull: (w + 1) * nb] = light[w * n3:(w + 1) * n3]
+            assert np.array_equal(np.sort(m), np.arange(ns))
+            lib.isdf_debug_set_sample_map(eng.h, m.ctypes.data_as(C.c_void_p), ns)
+            t = step_us(eng, N, d_T, d_C, d_out, st)
+            print(f"{shape_name}: lightest {4 * n3} samples (by {name}) to workgroups >= {nfull}, order kept: {t:7.2f} us/step  bitwise same: {np.array_equal(d_out.cpu().numpy(), ref)}")
+    chunks = (cand + 63) // 64
+    def zone_map(pos_order, sizes):
+        """pos_order: sample ids in zone-filling order; sizes: workgroups per zone; inside a zone position q -> wave q // size, workgroup q % size"""
+        m = np.full(4 * nb, -1, dtype=np.int64)
+        p0 = 0; boff = 0
+        for sz in sizes:
+            ids = pos_order[p0:p0 + 4 * sz]
+            for w in range(4):
+                seg = ids[w * sz:(w + 1) * sz]
+                m[w * nb + boff: w * nb + boff + seg.size] = seg
+            p0 += 4 * sz; boff += sz
+        return m
+    def run(label, m):
+        mm = m[:ns].astype(np.int32)
+        if not np.array_equal(np.sort(mm), np.arange(ns)):
+            print("  (not a permutation of the first ns ranks, skipped)", label); return
+        lib.isdf_debug_set_sample_map(eng.h, mm.ctypes.data_as(C.c_void_p), ns)
+        t = step_us(eng, N, d_T, d_C, d_out, st)
+        print(f"{shape_name}: {label}: {t:7.2f} us/step  bitwise same: {np.array_equal(d_out.cpu().numpy(), ref)}")
+    for name, key in (("chunks", np.minimum(chunks, 7)), ("min(chunks,3)", np.minimum(chunks, 3)), ("pairs/32", np.minimum((cand + 31) // 32, 7))):
+        st_sorted = np.argsort(-key, kind="stable")          # classes descending, trajectory order inside a class
+        run(f"stable sort by {name}, zones (256, rest)", zone_map(st_sorted, (256, nb - 256)))
+        run(f"stable sort by {name}, zones (256, 256, rest)", zone_map(st_sorted, (256, 256, nb - 512)))
+        run(f"stable sort by {name}, one zone", zone_map(st_sorted, (nb,)))
+        # heaviest 1024 in trajectory order, rest in trajectory order (the earlier winner)
+        o = np.argsort(key, kind="stable"); n3 = nb - 256
+        order = np.concatenate([np.sort(o[4 * n3:]), np.sort(o[:4 * n3])])
+        run(f"heaviest 1024 by {name} (order kept) -> workgroups < 256", zone_map(order, (256, n3)))
+    # random order as a control
+    rng = np.random.default_rng(1)
+    m = rng.permutation(ns).astype(np.int32)
+    lib.isdf_debug_set_sample_map(eng.h, m.ctypes.data_as(C.c_void_p), ns)
+    print(f"{shape_name}: random order              {step_us(eng, N, d_T, d_C, d_out, st):7.2f} us/step")
+
+
+if __name__ == "__main__":
+    main()
