@@ -161,7 +161,7 @@ extern "C" int isdf_destroy(isdf_ctx *c) {
     isdf_xchg_release(c);
     void *ptrs[] = {c->d_cb, c->d_esdf, c->d_occ, c->d_points, c->d_tstar, c->d_acc, c->d_sample_info, c->d_bits, c->d_piece_cost, c->d_in, c->d_out, c->d_stats,
                     c->d_traj_duration, c->d_coarse_t, c->d_coarse_pose, c->d_n_coarse, c->d_point_partial, c->d_point_piece, c->d_point_stat, c->d_point_nr, c->d_task_buf,
-                    c->d_task_map, c->d_v1_words, c->d_point_lmask, c->d_hist, c->d_dbg, c->d_stage, c->d_stage_flags, c->d_sample_map, c->d_plan_cls, c->d_plan_map};
+                    c->d_task_map, c->d_v1_words, c->d_point_lmask, c->d_hist, c->d_dbg, c->d_stage, c->d_stage_flags, c->d_sample_map, c->d_plan_cls, c->d_plan_map, c->d_plan_lr, c->d_plan_hist};
     for (void *p : ptrs) if (p) (void)hipFree(p);
     free_mesh(c);
     if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -627,25 +627,39 @@ static int eval_device_impl(isdf_ctx *c, int n_traj, int N, const double *d_T, c
     }
     // longest-first dispatch order of a fused step whose workgroups outnumber the CUs (tile_sweep.hip, plan_piece)
     P.plan_cls_in = nullptr; P.plan_cls_out = nullptr; P.plan_map_out = nullptr; P.plan_zone = 0;
+    P.plan_lr_in = P.plan_hist_in = nullptr; P.plan_lr_out = P.plan_hist_out = nullptr;
     {
         const long long ns_local = (long long)(pe - pb) * (cfg.integral_intervs + 1);
         const int nb = (int)((ns_local + 3) / 4);
         if (c->n_cus == 0) { hipDeviceProp_t pr; c->n_cus = (hipGetDeviceProperties(&pr, c->device) == hipSuccess && pr.multiProcessorCount > 0) ? pr.multiProcessorCount : 256; }
         static const bool no_plan = [] { const char *e = getenv("ISDF_NO_LPT"); return e && e[0] == '1'; }();
-        const bool plan = fused && !no_plan && !P.sample_map && P.xf.world <= 1 && pb == 0 && pe == total_pieces && ns_local <= PLAN_MAX_SAMPLES && nb > c->n_cus;
+        const bool plan = fused && !no_plan && !P.sample_map && P.xf.world <= 1 && pb == 0 && pe == total_pieces && ns_local <= PLAN_MAX_SAMPLES &&
+                          total_pieces <= PLAN_MAX_PIECES && cfg.integral_intervs + 1 <= 128 && nb > c->n_cus;
         if (!plan) c->plan_k = 0;
         else {
             if (!c->d_plan_cls) {
                 HIPCHK(c, hipMalloc(&c->d_plan_cls, 2 * (size_t)PLAN_MAX_SAMPLES));
                 HIPCHK(c, hipMalloc(&c->d_plan_map, 2 * (size_t)PLAN_MAX_SAMPLES * sizeof(int)));
+                HIPCHK(c, hipMalloc(&c->d_plan_lr, 2 * (size_t)PLAN_MAX_SAMPLES * sizeof(unsigned short)));
+                HIPCHK(c, hipMalloc(&c->d_plan_hist, 2 * (size_t)PLAN_MAX_PIECES * PLAN_CLASSES * sizeof(unsigned short)));
             }
             if (c->plan_ns != ns_local || c->plan_nb != nb) { c->plan_k = 0; c->plan_ns = ns_local; c->plan_nb = nb; }
-            const int par = c->plan_k & 1;
+            // step k: the sweep leaves generation k's classes; the tail workgroups turn generation k - 1's classes into records,
+            // generation k - 2's records into the order of step k + 1; the launch itself runs in the order made in step k - 1
+            const int k = c->plan_k, par = k & 1;
             P.plan_zone = c->n_cus;
             P.plan_cls_out = c->d_plan_cls + (size_t)par * PLAN_MAX_SAMPLES;
-            P.plan_map_out = c->d_plan_map + (size_t)(1 - par) * PLAN_MAX_SAMPLES;
-            if (c->plan_k >= 1) P.plan_cls_in = c->d_plan_cls + (size_t)(1 - par) * PLAN_MAX_SAMPLES;
-            if (c->plan_k >= 2) P.sample_map = c->d_plan_map + (size_t)par * PLAN_MAX_SAMPLES;
+            if (k >= 1) {
+                P.plan_cls_in = c->d_plan_cls + (size_t)(1 - par) * PLAN_MAX_SAMPLES;
+                P.plan_lr_out = c->d_plan_lr + (size_t)(1 - par) * PLAN_MAX_SAMPLES;
+                P.plan_hist_out = c->d_plan_hist + (size_t)(1 - par) * PLAN_MAX_PIECES * PLAN_CLASSES;
+            }
+            if (k >= 2) {
+                P.plan_lr_in = c->d_plan_lr + (size_t)par * PLAN_MAX_SAMPLES;
+                P.plan_hist_in = c->d_plan_hist + (size_t)par * PLAN_MAX_PIECES * PLAN_CLASSES;
+                P.plan_map_out = c->d_plan_map + (size_t)(1 - par) * PLAN_MAX_SAMPLES;
+            }
+            if (k >= 3) P.sample_map = c->d_plan_map + (size_t)par * PLAN_MAX_SAMPLES;
             if (c->plan_k < (1 << 30)) c->plan_k++;
         }
     }
@@ -1241,7 +1255,7 @@ extern "C" int isdf_debug_set_sample_map(isdf_ctx *c, const int *map, long long 
 // developer tool (not declared in the ABI header): the longest-first dispatch order the NEXT fused step would use
 // (4 * workgroups entries, -1 = none); returns the number of consecutive steps the plan has been running, 0 = inactive
 extern "C" int isdf_debug_plan_map(isdf_ctx *c, int *out, long long cap) {
-    if (!c || c->plan_k < 2 || !c->d_plan_map) return 0;
+    if (!c || c->plan_k < 3 || !c->d_plan_map) return 0;
     (void)hipSetDevice(c->device);
     (void)hipDeviceSynchronize();
     const long long n = 4LL * c->plan_nb < cap ? 4LL * c->plan_nb : cap;

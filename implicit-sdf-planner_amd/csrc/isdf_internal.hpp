@@ -16,6 +16,8 @@ struct DevGrid {
     const unsigned *bits;     // qualifier bit-grid of the active variant, ZW dwords per z-row
     int ZW;                   // ceil(Z / 32)
 };
+constexpr int PLAN_CLASSES = 8;          // work classes of the longest-first order
+constexpr int PLAN_MAX_PIECES = 256;
 constexpr int PLAN_MAX_SAMPLES = 4096;   // longest-first order: samples of a fused single-launch step (<= 4 x 1024 workgroups)
 constexpr int ACC_STRIDE = 8;       // costp, dL/dpos(3), dL/dquat(4) of one pose, before weight_p
 constexpr int PARTIAL_STRIDE = 20;  // V1: per-point record = 18 gradC entries (d*6 + r), gdT, pena
@@ -73,8 +75,10 @@ struct SweepParams {
     // (workgroup b, wave w: b + w * n_sweep_blocks) -> local sample, -1 = none.  The tail workgroups of step k build the order
     // for step k + 1 from the work classes the sweep waves of step k - 1 left (plan_piece, tile_sweep.hip).
     const int *sample_map;
-    const unsigned char *plan_cls_in;   // work classes of the step before (null: none yet)
-    unsigned char *plan_cls_out;        // this step's work classes, one per local sample
+    unsigned char *plan_cls_out;        // this step's work classes, one per local sample (sweep waves)
+    const unsigned char *plan_cls_in;   // the classes of the step before -> plan_lr_out / plan_hist_out (tail workgroups)
+    unsigned short *plan_lr_out, *plan_hist_out;
+    const unsigned short *plan_lr_in, *plan_hist_in;   // the records made one step ago -> plan_map_out
     int *plan_map_out;                  // the next step's order
     int plan_zone;                      // workgroups that get the heaviest samples: one per CU
     int dbg_flags;              // developer switches (ISDF_DEBUG_FLAGS): 1 = skip the exact pass body

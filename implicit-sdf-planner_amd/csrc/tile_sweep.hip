@@ -244,78 +244,80 @@ constexpr int sweep_waves_per_simd(int kind, bool ident) {
 // dispatcher hands workgroup b to XCD b % 8 and, there, to the next CU in turn, so workgroups [0, #CUs) are the first on their
 // CU: they get the heaviest samples, everyone after them the lighter ones (measured with orders built on the host,
 // tools/lpt_experiment.py: rounded cone 33.1 -> 26.3 us per step, box 22.2 -> 21.5; orders that only even out the workgroups, or
-// per-piece quotas, gain nothing).  Order = stable counting sort of the samples by work class (exact pairs / 32 of the step
-// BEFORE the last - the trajectory moves little between optimizer steps), classes descending, trajectory order inside a class
-// (neighbouring workgroups keep neighbouring tiles).  Built by the tail workgroups while they wait for the sweep: every one of
-// them scans all classes (<= 4 KB) and writes the entries of its own piece's samples.  Scheduling only: which wave evaluates a
-// sample has no influence on any result.
+// per-piece quotas, gain nothing).  Order = stable counting sort of the samples by work class (exact pairs / 32 of an EARLIER
+// step - the trajectory moves little between optimizer steps), classes descending, trajectory order inside a class
+// (neighbouring workgroups keep neighbouring tiles).  Built by the tail workgroups beside their own work, in two generations
+// so that no workgroup needs another one's output of the same launch (and none scans more than its own piece):
+//   step k:     sweep waves leave the class of every sample (cls);
+//   step k + 1: the tail workgroup of piece i turns its samples' classes into (class, rank inside piece and class) records
+//               and the piece's class histogram (lr, hist);
+//   step k + 2: it adds the other pieces' histograms - total per class, pieces before i - and writes the rank of each of its
+//               samples in the launch (map); step k + 3 is dispatched in that order.
+// Scheduling only: which wave evaluates a sample has no influence on any result.
 __device__ __forceinline__ int plan_rank(int pos, int Z, int nb) {
     const int q0 = 4 * Z;
     if (pos < q0) { const int w = pos / Z; return w * nb + (pos - w * Z); }
     const int n3 = nb - Z, p1 = pos - q0, w = p1 / n3;
     return w * nb + Z + (p1 - w * n3);
 }
-__device__ __forceinline__ unsigned plan_field(unsigned long long lo, unsigned long long hi, int c) {
-    return (unsigned)(((c < 4 ? lo : hi) >> (16 * (c & 3))) & 0xFFFFull);
+// One wavefront per piece does it (the tail's fourth wave, which otherwise only keeps the barriers), with wave-level operations
+// only: lane l looks after samples l and l + 64 of the piece, and after pieces l, l + 64, ... when the histograms are added.
+__device__ __forceinline__ uint4 plan_add(uint4 a, uint4 b) {      // 8 counts of 16 bits; no sum exceeds PLAN_MAX_SAMPLES
+    return make_uint4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w);
 }
-__device__ void plan_piece(const SweepParams &P, const int t) {
-    constexpr int SEG = PLAN_MAX_SAMPLES / (64 * SW_SAMPLES);       // samples per thread
-    __shared__ unsigned long long s_wsum[SW_SAMPLES][2];
-    const int K1 = P.K + 1;
-    const int ns = (P.piece_end - P.piece_begin) * K1, nb = P.n_sweep_blocks, Z = P.plan_zone;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    // classes of this thread's stretch of samples, counted per class in 16-bit fields (classes 0-3 | 4-7)
-    unsigned char cls[SEG];
-    unsigned long long lo = 0, hi = 0;
-    {
-        const uint4 v = (tid * SEG < ns) ? reinterpret_cast<const uint4 *>(P.plan_cls_in)[tid] : make_uint4(0, 0, 0, 0);
-        const unsigned wds[4] = {v.x, v.y, v.z, v.w};
+__device__ __forceinline__ uint4 plan_wave_sum(uint4 v) {
 #pragma unroll
-        for (int e = 0; e < SEG; e++) {
-            cls[e] = (unsigned char)((wds[e >> 2] >> (8 * (e & 3))) & 7u);
-            if (tid * SEG + e < ns) { if (cls[e] < 4) lo += 1ull << (16 * cls[e]); else hi += 1ull << (16 * (cls[e] - 4)); }
+    for (int d = 1; d < 64; d <<= 1) v = plan_add(v, make_uint4(__shfl_xor(v.x, d), __shfl_xor(v.y, d), __shfl_xor(v.z, d), __shfl_xor(v.w, d)));
+    return v;
+}
+__device__ __forceinline__ unsigned plan_count(uint4 v, int q) {
+    const unsigned w = (q >> 1) == 0 ? v.x : (q >> 1) == 1 ? v.y : (q >> 1) == 2 ? v.z : v.w;
+    return (w >> (16 * (q & 1))) & 0xFFFFu;
+}
+__device__ void plan_wave(const SweepParams &P, const int t, const int lane) {
+    const int K1 = P.K + 1, n_pieces = P.piece_end - P.piece_begin;
+    const int ns = n_pieces * K1, nb = P.n_sweep_blocks, Z = P.plan_zone;
+    const int s0 = t * K1 + lane, s1 = s0 + 64;     // (all pieces are local: t = piece)
+    const bool h0 = lane < K1, h1 = lane + 64 < K1;
+    if (P.plan_cls_in) {
+        // ---- generation g: classes -> (class, rank inside piece and class) records, histogram of the piece
+        const int c0 = h0 ? (int)(P.plan_cls_in[s0] & (PLAN_CLASSES - 1)) : -1, c1 = h1 ? (int)(P.plan_cls_in[s1] & (PLAN_CLASSES - 1)) : -1;
+        int r0 = 0, r1 = 0, hist = 0;
+        const unsigned long long lt = (1ull << lane) - 1ull;
+#pragma unroll
+        for (int q = 0; q < PLAN_CLASSES; q++) {
+            const unsigned long long m0 = __ballot(c0 == q), m1 = __ballot(c1 == q);
+            if (c0 == q) r0 = __popcll(m0 & lt);
+            if (c1 == q) r1 = __popcll(m0) + __popcll(m1 & lt);
+            if (lane == q) hist = __popcll(m0) + __popcll(m1);
         }
+        if (h0) P.plan_lr_out[s0] = (unsigned short)(c0 | (r0 << 3));
+        if (h1) P.plan_lr_out[s1] = (unsigned short)(c1 | (r1 << 3));
+        if (lane < PLAN_CLASSES) P.plan_hist_out[t * PLAN_CLASSES + lane] = (unsigned short)hist;
     }
-    // inclusive scan over the workgroup's threads
-    unsigned long long ilo = lo, ihi = hi;
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        const unsigned long long a = __shfl_up(ilo, d), b = __shfl_up(ihi, d);
-        if (lane >= d) { ilo += a; ihi += b; }
-    }
-    if (lane == 63) { s_wsum[wave][0] = ilo; s_wsum[wave][1] = ihi; }
-    __syncthreads();
-    unsigned long long tlo = 0, thi = 0;          // totals per class
-#pragma unroll
-    for (int w = 0; w < SW_SAMPLES; w++) {
-        if (w < wave) { ilo += s_wsum[w][0]; ihi += s_wsum[w][1]; }
-        tlo += s_wsum[w][0]; thi += s_wsum[w][1];
-    }
-    unsigned long long rlo = ilo - lo, rhi = ihi - hi;      // samples of each class before this thread's stretch
-    // first position of each class: classes descending
-    unsigned long long blo = 0, bhi = 0;
-    {
-        unsigned run = 0;
-#pragma unroll
-        for (int c = 7; c >= 0; c--) {
-            if (c < 4) blo |= (unsigned long long)run << (16 * c); else bhi |= (unsigned long long)run << (16 * (c - 4));
-            run += plan_field(tlo, thi, c);
+    if (P.plan_lr_in) {
+        // ---- generation g - 1: all pieces' histograms -> first position of this piece's samples of each class -> ranks
+        uint4 tot = make_uint4(0, 0, 0, 0), bef = tot;
+        for (int i = lane; i < n_pieces; i += 64) {
+            const uint4 h = reinterpret_cast<const uint4 *>(P.plan_hist_in)[i];
+            tot = plan_add(tot, h);
+            if (i < t) bef = plan_add(bef, h);
         }
-    }
-    const int s_lo = t * K1, s_hi = s_lo + K1;    // this workgroup writes its own piece's samples (t = local piece: all pieces are local)
+        tot = plan_wave_sum(tot); bef = plan_wave_sum(bef);
+        int base = 0;                                // lane q < 8: classes descending
+        if (lane < PLAN_CLASSES) {
+            base = (int)plan_count(bef, lane);
 #pragma unroll
-    for (int e = 0; e < SEG; e++) {
-        const int s = tid * SEG + e;
-        if (s < ns) {
-            const int c = cls[e];
-            const int pos = (int)(plan_field(blo, bhi, c) + plan_field(rlo, rhi, c));
-            if (c < 4) rlo += 1ull << (16 * c); else rhi += 1ull << (16 * (c - 4));
-            if (s >= s_lo && s < s_hi) P.plan_map_out[plan_rank(pos, Z, nb)] = s;
+            for (int q = 1; q < PLAN_CLASSES; q++) if (q > lane) base += (int)plan_count(tot, q);
         }
+        // (the shuffles run with all lanes: a lane may need the base a lane without a sample holds)
+        const unsigned v0 = h0 ? P.plan_lr_in[s0] : 0u, v1 = h1 ? P.plan_lr_in[s1] : 0u;
+        const int b0 = __shfl(base, (int)(v0 & 7u)), b1 = __shfl(base, (int)(v1 & 7u));
+        if (h0) P.plan_map_out[plan_rank(b0 + (int)(v0 >> 3), Z, nb)] = s0;
+        if (h1) P.plan_map_out[plan_rank(b1 + (int)(v1 >> 3), Z, nb)] = s1;
+        // ranks behind the last sample stay empty
+        if (t == 0) for (int pos = ns + lane; pos < 4 * nb; pos += 64) P.plan_map_out[plan_rank(pos, Z, nb)] = -1;
     }
-    // ranks behind the last sample stay empty
-    if (t == 0) for (int pos = ns + tid; pos < 4 * nb; pos += 64 * SW_SAMPLES) P.plan_map_out[plan_rank(pos, Z, nb)] = -1;
-    __syncthreads();
 }
 
 // IDENT: the shape's body offset is the identity (poly_params all zero - every shipped config): those instantiations drop
@@ -332,7 +334,7 @@ __global__ __launch_bounds__(64 * SW_SAMPLES, FUSED ? 3 : sweep_waves_per_simd(K
     if constexpr (FUSED) {
         __shared__ double s_tail[TL_THREADS][PARTIAL_STRIDE + 1];
         if ((int)blockIdx.x >= n_blocks) {
-            if (P.plan_cls_in) plan_piece(P, (int)blockIdx.x - n_blocks);       // while the sweep works: the NEXT step's dispatch order
+            if ((P.plan_cls_in || P.plan_lr_in) && !(P.dbg_flags & 2) && (threadIdx.x >> 6) == SW_SAMPLES - 1) plan_wave(P, (int)blockIdx.x - n_blocks, threadIdx.x & 63);       // while the sweep works: the NEXT step's dispatch order
             if (P.xf.world > 1) tail_piece<false, true>(P, (int)blockIdx.x - n_blocks, s_tail);      // multi-GPU step: exchange inside
             else tail_piece<false, false>(P, (int)blockIdx.x - n_blocks, s_tail);
             return;
@@ -766,7 +768,7 @@ __global__ __launch_bounds__(64 * SW_SAMPLES, FUSED ? 3 : sweep_waves_per_simd(K
         }
         else if (lane == ACC_STRIDE) {
             P.sample_info[2 * sl] = tot_n;
-            if (P.plan_cls_out) P.plan_cls_out[sl] = (unsigned char)min((tot_n + 31) >> 5, 7);     // work class: exact pairs / 32
+            if (P.plan_cls_out && !(P.dbg_flags & 4)) P.plan_cls_out[sl] = (unsigned char)min((tot_n + 31) >> 5, PLAN_CLASSES - 1);     // work class: exact pairs / 32
         }
         else if (lane == ACC_STRIDE + 1) P.sample_info[2 * sl + 1] = tot_n | ((flags & 2) ? (int)0x80000000 : 0);
     }

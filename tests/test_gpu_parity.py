@@ -330,20 +330,20 @@ def test_crowded_tiles_fill_the_candidate_ring(pkg, orc, product_lib, shape_name
     assert_close(gT, gT0, "crowded gradT"); assert_close(gC, gC0, "crowded gradC")
 
 
-@pytest.mark.parametrize("shape_name", ["RoundedCone", "Box"])
-def test_longest_first_order_is_scheduling_only(pkg, orc, product_lib, shape_name):
+@pytest.mark.parametrize("shape_name,N,K", [("RoundedCone", 70, 16), ("Box", 70, 16), ("Box", 40, 64), ("RoundedCone", 24, 99)])
+def test_longest_first_order_is_scheduling_only(pkg, orc, product_lib, shape_name, N, K):
     """A fused single-launch step with more workgroups than CUs dispatches its samples longest-first from the third step on
     (tile_sweep.hip, plan_piece).  The order is a permutation built on the device from the previous steps' work; results must
     be bit for bit those of the plain order - same trajectory repeated, trajectory changed under a running plan, batch of two."""
     import ctypes as C
     capi, synth = pkg.capi, pkg.synth
     occ, esdf, res = small_world(pkg)
-    cfg = synth.default_config(capi.V3_ESDF_TILE, kernel_size=9, integral_intervs=16, safety_hor=0.5)
+    cfg = synth.default_config(capi.V3_ESDF_TILE, kernel_size=9, integral_intervs=K, safety_hor=0.5)
     if shape_name == "Box":
         shape = synth.make_shape("Box", params=(1.2, 0.4, 0.3), grad_mode=capi.GRAD_CENTRAL)
     else:
         shape = synth.make_shape("RoundedCone", params=(0.8, 0.3, 1.6))
-    N, K1 = 70, 17
+    K1 = K + 1                       # samples per piece: one wavefront covers up to 128 of them, lanes l and l + 64
     ns, nb = N * K1, (N * K1 + 3) // 4
     Ta, ca = traj(pkg, occ, res, N=N, seed=5)
     Tb, cb = traj(pkg, occ, res, N=N, seed=6)
@@ -377,7 +377,7 @@ def test_longest_first_order_is_scheduling_only(pkg, orc, product_lib, shape_nam
         got = eng.eval_single(Ta, ca)
         assert got[0] == fresh["a"][0] and np.array_equal(got[2], fresh["a"][2]), step
     # two trajectories in one fused launch
-    T2, c2 = traj(pkg, occ, res, N=35, seed=9)
+    T2, c2 = traj(pkg, occ, res, N=N // 2, seed=9)
     e1 = pkg.Engine(cfg); e1.set_grid(esdf, (0, 0, 0), res, capi.GRID_ESDF); e1.set_shape(shape)
     one = e1.eval_single(T2, c2)
     for step in range(5):

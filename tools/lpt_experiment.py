@@ -67,6 +67,18 @@ def main():
     nb = (ns + 3) // 4
     print(f"{shape_name}: identity order            {step_us(eng, N, d_T, d_C, d_out, st):7.2f} us/step")
 
+    # the order the device builds by itself (plan_piece), then the same order fed back as a fixed table (no building)
+    lib.isdf_debug_plan_map.restype = C.c_int
+    lib.isdf_debug_plan_map.argtypes = [C.c_void_p, C.c_void_p, C.c_longlong]
+    dm = np.full(4 * nb, -7, dtype=np.int32)
+    kk = lib.isdf_debug_plan_map(eng.h, dm.ctypes.data_as(C.c_void_p), dm.size)
+    if kk >= 3:
+        lib.isdf_debug_set_sample_map(eng.h, dm.ctypes.data_as(C.c_void_p), dm.size)
+        print(f"{shape_name}: the device-built order as a fixed table {step_us(eng, N, d_T, d_C, d_out, st):7.2f} us/step")
+        ident = np.arange(4 * nb, dtype=np.int32); ident[ns:] = -1
+        lib.isdf_debug_set_sample_map(eng.h, ident.ctypes.data_as(C.c_void_p), ident.size)
+        print(f"{shape_name}: plain order as a fixed table            {step_us(eng, N, d_T, d_C, d_out, st):7.2f} us/step")
+
     def deal(order, snake):
         """order: sample ids, heaviest first.  rank r of the launch = workgroup r % nb, wave r // nb."""
         m = np.zeros(ns, dtype=np.int32)
@@ -154,6 +166,43 @@ def main():
         o = np.argsort(key, kind="stable"); n3 = nb - 256
         order = np.concatenate([np.sort(o[4 * n3:]), np.sort(o[:4 * n3])])
         run(f"heaviest 1024 by {name} (order kept) -> workgroups < 256", zone_map(order, (256, n3)))
+    # per-CU model: workgroup b -> XCD b % 8, there CU (b // 8) % 32; CUs that hold 3 workgroups should give each of them 2/3 of
+    # the load a workgroup gets on a CU that holds 2
+    import heapq
+    for fixed in (1.0, 2.0, 3.0):
+        for key_name, key in (("pairs/32", np.minimum((cand + 31) // 32, 7)), ("chunks", np.minimum(chunks, 7))):
+            wgt = fixed + key.astype(float)
+            per_xcd = [len(range(x, nb, 8)) for x in range(8)]
+            on3 = np.zeros(nb, dtype=bool)
+            for b in range(nb):
+                x, j = b % 8, b // 8
+                n_cu3 = per_xcd[x] - 64                     # CUs of this XCD that get a third workgroup
+                on3[b] = (j % 32) < n_cu3
+            L = wgt.sum() / (on3.sum() / 3.0 + (~on3).sum() / 2.0)
+            target = np.where(on3, L / 3.0, L / 2.0)
+            load = np.zeros(nb); cnt = np.zeros(nb, dtype=int)
+            slots = [[] for _ in range(nb)]
+            heap = [(-(target[b]), b) for b in range(nb)]
+            heapq.heapify(heap)
+            for sidx_ in np.argsort(-wgt, kind="stable"):
+                while True:
+                    d, b = heapq.heappop(heap)
+                    if cnt[b] < 4 and abs(-d - (target[b] - load[b])) < 1e-9:
+                        break
+                    if cnt[b] < 4:
+                        heapq.heappush(heap, (-(target[b] - load[b]), b))
+                slots[b].append(int(sidx_)); cnt[b] += 1; load[b] += wgt[sidx_]
+                if cnt[b] < 4:
+                    heapq.heappush(heap, (-(target[b] - load[b]), b))
+            m = np.full(4 * nb, -1, dtype=np.int64)
+            for b in range(nb):
+                for w, sidx_ in enumerate(slots[b]):
+                    m[w * nb + b] = sidx_
+            if np.count_nonzero(m[:ns] < 0):
+                # the launch needs its empty ranks at the end: move samples from the tail ranks into the holes
+                holes = np.where(m[:ns] < 0)[0]; extra = np.where(m[ns:] >= 0)[0] + ns
+                m[holes] = m[extra]; m[extra] = -1
+            run(f"per-CU model, weight {fixed} + {key_name}", m)
     # random order as a control
     rng = np.random.default_rng(1)
     m = rng.permutation(ns).astype(np.int32)
