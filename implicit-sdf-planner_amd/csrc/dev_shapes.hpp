@@ -83,10 +83,13 @@ template <typename T> __device__ __forceinline__ T sdf_roundedcone(const T *P, v
     const T b = (r1 - r2) / h;
     const T a = m_sqrt(T(1) - b * b);
     const T k = -b * qx + a * qy;
-    const T c1 = m_sqrt(qx * qx + qy * qy) - r1;
-    const T c2 = m_sqrt(qx * qx + (qy - h) * (qy - h)) - r2;
+    // c1 = |q| - r1 below the cone's base, c2 = |q - (0, h)| - r2 beyond its tip, c3 on the flank: the two square roots are
+    // never both needed, so the ARGUMENT is selected and one root is taken (the value returned is the same bit for bit)
+    const bool low = k < 0, high = k > a * h;
+    const T dy = low ? qy : qy - h;
+    const T c12 = m_sqrt(qx * qx + dy * dy) - (low ? r1 : r2);
     const T c3 = (a * qx + b * qy) - r1;
-    return (k < 0) ? c1 : ((k > a * h) ? c2 : c3);
+    return (low || high) ? c12 : c3;
 }
 template <typename T> __device__ __forceinline__ T sdf_wireframebox(const T *P, v3<T> p) {
     const T th = P[3];
