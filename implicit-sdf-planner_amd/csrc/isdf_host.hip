@@ -581,16 +581,19 @@ static int eval_device_impl(isdf_ctx *c, int n_traj, int N, const double *d_T, c
         P.dbg = c->d_dbg;
     }
     if (cfg.enable_pos && c->bits_dirty) {
-        const size_t nw = (size_t)c->grid.X * c->grid.Y * ((c->grid.Z + 31) / 32);
+        const int zw = (c->grid.Z + 31) / 32, xw = (c->grid.X + 31) / 32, yw = (c->grid.Y + 31) / 32;
+        const size_t nwz = (size_t)c->grid.X * c->grid.Y * zw, nwx = (size_t)c->grid.Y * c->grid.Z * xw, nwy = (size_t)c->grid.X * c->grid.Z * yw;
+        const size_t nw = nwz + nwx + nwy;
         if (c->bits_cap < nw) {
             if (c->d_bits) (void)hipFree(c->d_bits);
             c->d_bits = nullptr; c->bits_cap = 0;
             HIPCHK(c, hipMalloc(&c->d_bits, nw * sizeof(unsigned)));
             c->bits_cap = nw;
         }
-        c->grid.ZW = (c->grid.Z + 31) / 32;
-        c->grid.bits = c->d_bits;
+        c->grid.ZW = zw; c->grid.XW = xw; c->grid.YW = yw;
+        c->grid.bits = c->d_bits; c->grid.bits_x = c->d_bits + nwz; c->grid.bits_y = c->d_bits + nwz + nwx;
         launch_build_bits(c->grid, cfg.variant == ISDF_V3_ESDF_TILE ? 1 : 0, (float)cfg.occ_thresh, c->d_bits, st);
+        launch_build_bits_xy(c->grid, cfg.variant == ISDF_V3_ESDF_TILE ? 1 : 0, (float)cfg.occ_thresh, c->d_bits + nwz, c->d_bits + nwz + nwx, st);
         c->bits_dirty = false;
         P.grid = c->grid;
     }

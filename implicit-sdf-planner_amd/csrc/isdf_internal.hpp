@@ -13,8 +13,12 @@ struct DevGrid {
     double bmin[3], bmax[3];
     const float *esdf;        // metres, unsigned; z fastest (GridMap3D.h:194)
     const uint8_t *occ;       // 1 = occupied
-    const unsigned *bits;     // qualifier bit-grid of the active variant, ZW dwords per z-row
+    const unsigned *bits;     // qualifier bit-grid of the active variant, ZW dwords per z-row: row (x, y), bit z
     int ZW;                   // ceil(Z / 32)
+    // the same bits packed along the other two axes, so that a tile can be scanned along the axis its robot is longest on:
+    const unsigned *bits_x;   // row (y, z): dword (y * Z + z) * XW + (x >> 5), bit x & 31
+    const unsigned *bits_y;   // row (x, z): dword (x * Z + z) * YW + (y >> 5), bit y & 31
+    int XW, YW;
 };
 constexpr int PLAN_CLASSES = 8;          // work classes of the longest-first order
 constexpr int PLAN_MAX_PIECES = 256;
@@ -92,6 +96,7 @@ bool sweep_can_fuse(const SweepParams &P);      // small launch, analytic shape 
 void launch_sweep(const SweepParams &P, hipStream_t stream, hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr, bool fused = false);
 void launch_stats(const SweepParams &P, hipStream_t stream);   // on demand, not part of the step
 void launch_build_bits(const DevGrid &G, int use_esdf, float thresh, unsigned *out, hipStream_t stream);
+void launch_build_bits_xy(const DevGrid &G, int use_esdf, float thresh, unsigned *out_x, unsigned *out_y, hipStream_t stream);
 void launch_tail(const SweepParams &P, hipStream_t stream, hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr);
 
 // ---- V1 (swept volume) ----

@@ -208,10 +208,10 @@ struct SweepPose {                 // LDS record of one sample, written by the p
     double R[9];                   // row-major body->world rotation
     double quat[4];                // w x y z
     int lo[3];                     // first voxel of the tile (getPointsInAABB box)
-    int nzt;                       // tile extent along z
-    int rx0, ry0, rnx, rny;        // window of tile rows (lx, ly) that can reach the shape's inflated bounding box
+    int nzt;                       // tile extent along the scan axis
+    int rx0, ry0, rnx, rny;        // window of tile rows (u, v) that can reach the shape's inflated bounding box
     int flags;                     // bit0 active, bit1 culled
-    int pad;
+    int sa;                        // scan axis: rows run along world axis sa, (u, v) = the other two axes, ascending
 };
 
 __device__ __forceinline__ double uni(double v) {     // wave-uniform double -> scalar registers
@@ -411,38 +411,45 @@ __global__ __launch_bounds__(64 * SW_SAMPLES, FUSED ? 3 : sweep_waves_per_simd(K
                 if (hi[0] >= lo[0] && hi[1] >= lo[1] && hi[2] >= lo[2]) flags |= 1;
             }
         }
-        const int nx = hi[0] - lo[0] + 1, ny = hi[1] - lo[1] + 1;
-        int rx0 = 0, ry0 = 0, rnx = (flags & 1) ? nx : 0, rny = (flags & 1) ? ny : 0;
+        // Rows run along the world axis on which the shape's inflated bounding box is LONGEST (the bit-grid exists packed along
+        // each axis): the window of rows spans the two short extents - a 3.2 m robot lying along x needs ~50 rows of ~20 voxels
+        // instead of ~140 rows of ~6.
+        const int nn[3] = {hi[0] - lo[0] + 1, hi[1] - lo[1] + 1, hi[2] - lo[2] + 1};
+        int w0[3] = {0, 0, 0}, w1[3] = {nn[0] - 1, nn[1] - 1, nn[2] - 1};
+        int sa = 2;
         if ((flags & 1) && P.shape.prune_rows) {
             // world-frame extent of the shape's body-frame bounding box inflated by the penalty band: rows whose
-            // (x, y) lies outside it cannot hold a voxel with a non-zero penalty (conservative: +-1 voxel, NaN keeps all)
+            // (u, v) lies outside it cannot hold a voxel with a non-zero penalty (conservative: +-1 voxel, NaN keeps all)
             const double infl = P.safety_hor * mesh_band_scale(P.shape.kind) + 4.0e-3 + 0.05 * G.res;
-            const double inv_res = m_rcp(G.res);     // the window has 0.05 voxel of slack: one reciprocal serves its four quotients
+            const double inv_res = m_rcp(G.res);     // the window has 0.05 voxel of slack: one reciprocal serves its quotients
             const double hb[3] = {0.5 * ((double)P.shape.bbox_hi[0] - (double)P.shape.bbox_lo[0]) + infl,
                                   0.5 * ((double)P.shape.bbox_hi[1] - (double)P.shape.bbox_lo[1]) + infl,
                                   0.5 * ((double)P.shape.bbox_hi[2] - (double)P.shape.bbox_lo[2]) + infl};
             const double cb[3] = {0.5 * ((double)P.shape.bbox_hi[0] + (double)P.shape.bbox_lo[0]),
                                   0.5 * ((double)P.shape.bbox_hi[1] + (double)P.shape.bbox_lo[1]),
                                   0.5 * ((double)P.shape.bbox_hi[2] + (double)P.shape.bbox_lo[2])};
-            const double p[2] = {pos.x, pos.y};
-            const int nn[2] = {nx, ny};
-            int w0[2], w1[2];
+            const double p[3] = {pos.x, pos.y, pos.z};
 #pragma unroll
-            for (int a = 0; a < 2; a++) {
+            for (int a = 0; a < 3; a++) {
                 const double ctr = p[a] + R.a[3 * a] * cb[0] + R.a[3 * a + 1] * cb[1] + R.a[3 * a + 2] * cb[2];
                 const double ext = fabs(R.a[3 * a]) * hb[0] + fabs(R.a[3 * a + 1]) * hb[1] + fabs(R.a[3 * a + 2]) * hb[2];
                 const double l0 = (ctr - ext - G.bmin[a]) * inv_res - 0.5 - lo[a], l1 = (ctr + ext - G.bmin[a]) * inv_res - 0.5 - lo[a];
-                w0[a] = 0; w1[a] = nn[a] - 1;
                 if (l0 > 0.0) w0[a] = (int)fmin(floor(l0), (double)nn[a]);          // > nn-1 -> empty window
                 if (l1 < (double)(nn[a] - 1)) w1[a] = (int)fmax(ceil(l1), -1.0);
             }
-            rx0 = w0[0]; ry0 = w0[1];
-            rnx = max(0, w1[0] - w0[0] + 1); rny = max(0, w1[1] - w0[1] + 1);
+            const int e0 = w1[0] - w0[0], e1 = w1[1] - w0[1], e2 = w1[2] - w0[2];
+            sa = (e2 >= e0 && e2 >= e1) ? 2 : (e0 >= e1 ? 0 : 1);
         }
+        // (u, v): the axes other than sa, ascending
+        const int u0 = sa == 0 ? w0[1] : w0[0], u1 = sa == 0 ? w1[1] : w1[0];
+        const int v0 = sa == 2 ? w0[1] : w0[2], v1 = sa == 2 ? w1[1] : w1[2];
+        int rx0 = 0, ry0 = 0, rnx = 0, rny = 0;
+        if (flags & 1) { rx0 = u0; ry0 = v0; rnx = max(0, u1 - u0 + 1); rny = max(0, v1 - v0 + 1); }
         sp.lo[0] = lo[0]; sp.lo[1] = lo[1]; sp.lo[2] = lo[2];
-        sp.nzt = hi[2] - lo[2] + 1;
+        sp.nzt = sa == 2 ? nn[2] : (sa == 0 ? nn[0] : nn[1]);
         sp.rx0 = rx0; sp.ry0 = ry0; sp.rnx = rnx; sp.rny = rny;
         sp.flags = flags;
+        sp.sa = sa;
     }
     __syncthreads();
     if (dbg && lane == 0) dbg[2] = clock64();
@@ -478,6 +485,12 @@ __global__ __launch_bounds__(64 * SW_SAMPLES, FUSED ? 3 : sweep_waves_per_simd(K
     const int lox = __builtin_amdgcn_readfirstlane(sp.lo[0]), loy = __builtin_amdgcn_readfirstlane(sp.lo[1]),
               loz = __builtin_amdgcn_readfirstlane(sp.lo[2]), nzt = __builtin_amdgcn_readfirstlane(sp.nzt);
     const int rx0 = __builtin_amdgcn_readfirstlane(sp.rx0), ry0 = __builtin_amdgcn_readfirstlane(sp.ry0);
+    // scan axis sa (rows run along it), row coordinates (u, v) = the other two axes; everything below is wave-uniform
+    const int sa = __builtin_amdgcn_readfirstlane(sp.sa);
+    const int lo_u = sa == 0 ? loy : lox, lo_v = sa == 2 ? loy : loz, lo_w = sa == 2 ? loz : (sa == 0 ? lox : loy);
+    const int dim_v = sa == 2 ? G.Y : G.Z, n_ww = sa == 2 ? G.ZW : (sa == 0 ? G.XW : G.YW);
+    const unsigned *const bits_a = sa == 2 ? G.bits : (sa == 0 ? G.bits_x : G.bits_y);
+    const unsigned sh_u = sa == 0 ? 10u : 0u, sh_v = sa == 2 ? 10u : 20u, sh_w = 10u * (unsigned)sa;     // fields of a ring entry: x | y << 10 | z << 20
     const float inv_rny = 1.0f / (float)max(rny, 1);
     const bool small = n_rows < (1 << 24);
     // Box: the row masks already cut the rows to the box's own inflated extent, which IS the set the fp32 test would keep (but
@@ -496,7 +509,7 @@ __global__ __launch_bounds__(64 * SW_SAMPLES, FUSED ? 3 : sweep_waves_per_simd(K
     const float pvy = unif((float)(sp.pos[1] - G.bmin[1] - (0.5 + loy) * G.res));
     const float pvz = unif((float)(sp.pos[2] - G.bmin[2] - (0.5 + loz) * G.res));
 
-    // (lx, ly) of window row t, packed lx | ly << 10
+    // tile coordinates (u, v) of window row t, already in their fields of the ring entry
     auto row_xy = [&](int t) -> unsigned {
         unsigned wx, wy;
         if (small) {
@@ -505,39 +518,48 @@ __global__ __launch_bounds__(64 * SW_SAMPLES, FUSED ? 3 : sweep_waves_per_simd(K
             if (rem < 0) { wx--; rem += rny; } else if (rem >= rny) { wx++; rem -= rny; }
             wy = (unsigned)rem;
         } else { wx = (unsigned)(t / rny); wy = (unsigned)(t - (int)wx * rny); }
-        return (wx + (unsigned)rx0) | ((wy + (unsigned)ry0) << 10);
+        return ((wx + (unsigned)rx0) << sh_u) | ((wy + (unsigned)ry0) << sh_v);
     };
-    // the <= 32 qualifier bits of z-block zb of tile row pk: 1-2 dwords of the bit-grid
+    // the <= 32 qualifier bits of block zb of tile row pk: 1-2 dwords of the bit-grid packed along the scan axis
     auto row_bits = [&](unsigned pk, int zb) -> unsigned {
-        const int z0 = loz + (zb << 5);
+        const int z0 = lo_w + (zb << 5);
         const int nz = min(32, nzt - (zb << 5));
-        const size_t rowbase = ((size_t)(lox + (int)(pk & 1023u)) * G.Y + (loy + (int)(pk >> 10))) * G.ZW;
+        const size_t rowbase = ((size_t)(lo_u + (int)((pk >> sh_u) & 1023u)) * dim_v + (lo_v + (int)((pk >> sh_v) & 1023u))) * n_ww;
         const int w0 = z0 >> 5, sh = z0 & 31;
-        const unsigned b0 = G.bits[rowbase + w0];
-        const unsigned b1 = G.bits[rowbase + min(w0 + 1, G.ZW - 1)];
-        unsigned bits = sh ? ((b0 >> sh) | (b1 << (32 - sh))) : b0;     // when w0+1 == ZW the b1 bits are masked off below
+        const unsigned b0 = bits_a[rowbase + w0];
+        const unsigned b1 = bits_a[rowbase + min(w0 + 1, n_ww - 1)];
+        unsigned bits = sh ? ((b0 >> sh) | (b1 << (32 - sh))) : b0;     // when w0+1 == n_ww the b1 bits are masked off below
         if (nz < 32) bits &= (1u << nz) - 1u;
         return bits;
     };
-    // Row pruning: in the body frame the voxels of one z-row lie on the line o + lz*dz.  Only the part of the line
+    // Row pruning: in the body frame the voxels of one row lie on the line o + lw*dz.  Only the part of the line
     // inside (shape bounding box inflated by safety_hor) ∩ (the |p_rel| <= bd/2 cube) can carry a penalty
     // (isdf_shape.bbox_* guarantee), so the rest of the row never enters the list.  Conservative by construction.
     const bool prune = P.shape.prune_rows != 0;
+    // body-frame components of the three tile axes as the rows see them: along u, along v, along the scan axis
+    float Ru[3], Rv[3], Rw[3];
+#pragma unroll
+    for (int a = 0; a < 3; a++) {
+        Ru[a] = sa == 0 ? Rf[3 + a] : Rf[a];
+        Rv[a] = sa == 2 ? Rf[3 + a] : Rf[6 + a];
+        Rw[a] = sa == 2 ? Rf[6 + a] : (sa == 0 ? Rf[a] : Rf[3 + a]);
+    }
+    const float pv_u = sa == 0 ? pvy : pvx, pv_v = sa == 2 ? pvy : pvz, pv_w = sa == 2 ? pvz : (sa == 0 ? pvx : pvy);
     float blo[3], bhi[3], dzv[3], dzi[3];
 #pragma unroll
     for (int a = 0; a < 3; a++) {
         blo[a] = fmaxf(P.shape.bbox_lo[a] - thr_f, -bdh_f);
         bhi[a] = fminf(P.shape.bbox_hi[a] + thr_f, bdh_f);
-        dzv[a] = Rf[6 + a] * resf;
+        dzv[a] = Rw[a] * resf;
         dzi[a] = 1.0f / dzv[a];
     }
     auto row_mask = [&](unsigned pk, int zb) -> unsigned {
-        const float mx = fmaf((float)(pk & 1023u), resf, -pvx), my = fmaf((float)(pk >> 10), resf, -pvy);
+        const float mx = fmaf((float)((pk >> sh_u) & 1023u), resf, -pv_u), my = fmaf((float)((pk >> sh_v) & 1023u), resf, -pv_v);
         float tmin = -1.0e30f, tmax = 1.0e30f;
         bool empty = false;
 #pragma unroll
         for (int a = 0; a < 3; a++) {
-            const float o = Rf[a] * mx + Rf[3 + a] * my - Rf[6 + a] * pvz;
+            const float o = Ru[a] * mx + Rv[a] * my - Rw[a] * pv_w;
             if (fabsf(dzv[a]) > 1.0e-12f) {
                 const float t1 = (blo[a] - o) * dzi[a], t2 = (bhi[a] - o) * dzi[a];
                 tmin = fmaxf(tmin, fminf(t1, t2));      // fmaxf/fminf drop NaNs: never tightens on garbage
@@ -621,7 +643,7 @@ __global__ __launch_bounds__(64 * SW_SAMPLES, FUSED ? 3 : sweep_waves_per_simd(K
                     while (take) {
                         const unsigned z = (unsigned)__ffs(take) - 1u;
                         take &= take - 1u;
-                        s_near[wave][(wpos++) & (SW_NEAR_CAP - 1)] = pk | ((zoff + z) << 20);
+                        s_near[wave][(wpos++) & (SW_NEAR_CAP - 1)] = pk | ((zoff + z) << sh_w);
                     }
                     near_cnt += total;
                     cnt_passes++; cnt_listed += (unsigned)total; cnt_cand += (unsigned)total;
@@ -639,7 +661,7 @@ __global__ __launch_bounds__(64 * SW_SAMPLES, FUSED ? 3 : sweep_waves_per_simd(K
                 while (take) {
                     const unsigned z = (unsigned)__ffs(take) - 1u;
                     take &= take - 1u;
-                    s_list[wave][(wpos++) & (SW_LIST_CAP - 1)] = pk | ((zoff + z) << 20);
+                    s_list[wave][(wpos++) & (SW_LIST_CAP - 1)] = pk | ((zoff + z) << sh_w);
                 }
                 pend += total;
                 cnt_passes++; cnt_listed += (unsigned)total;
@@ -1131,6 +1153,33 @@ __global__ __launch_bounds__(256) void build_bits_kernel(DevGrid G, int use_esdf
         }
     }
 }
+// The same qualifier bits packed along x (AX = 0: row (y, z)) or along y (AX = 1: row (x, z)).  One lane per (row, 32-voxel
+// block): lanes run along z, so the 32 reads of a lane are each coalesced across the wavefront.
+template <int AX>
+__global__ __launch_bounds__(256) void build_bits_axis_kernel(DevGrid G, int use_esdf, float thresh, unsigned *out) {
+    const int NW = AX == 0 ? G.XW : G.YW, NA = AX == 0 ? G.X : G.Y, NU = AX == 0 ? G.Y : G.X;
+    const size_t n_work = (size_t)NU * NW * G.Z;
+    for (size_t w = (size_t)blockIdx.x * blockDim.x + threadIdx.x; w < n_work; w += (size_t)gridDim.x * blockDim.x) {
+        const int z = (int)(w % G.Z);
+        const size_t r = w / G.Z;
+        const int blk = (int)(r % NW), u = (int)(r / NW);
+        unsigned m = 0u;
+        for (int k = 0; k < 32; k++) {
+            const int a = blk * 32 + k;
+            if (a < NA) {
+                const size_t idx = AX == 0 ? ((size_t)a * G.Y + u) * G.Z + z : ((size_t)u * G.Y + a) * G.Z + z;
+                const bool q = use_esdf ? (G.esdf[idx] <= thresh) : (G.occ[idx] != 0);
+                m |= (q ? 1u : 0u) << k;
+            }
+        }
+        out[((size_t)u * G.Z + z) * NW + blk] = m;
+    }
+}
+void launch_build_bits_xy(const DevGrid &G, int use_esdf, float thresh, unsigned *out_x, unsigned *out_y, hipStream_t stream) {
+    hipLaunchKernelGGL(build_bits_axis_kernel<0>, dim3(4096), dim3(256), 0, stream, G, use_esdf, thresh, out_x);
+    hipLaunchKernelGGL(build_bits_axis_kernel<1>, dim3(4096), dim3(256), 0, stream, G, use_esdf, thresh, out_y);
+}
+
 void launch_build_bits(const DevGrid &G, int use_esdf, float thresh, unsigned *out, hipStream_t stream) {
     hipLaunchKernelGGL(build_bits_kernel, dim3(2048), dim3(256), 0, stream, G, use_esdf, thresh, out);
 }
