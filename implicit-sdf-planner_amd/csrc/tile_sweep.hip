@@ -243,8 +243,8 @@ constexpr int sweep_waves_per_simd(int kind, bool ident) {
 // and a CU's instruction issue is what its workgroups share: the step lasts as long as the CU with the most work.  The
 // dispatcher hands workgroup b to XCD b % 8 and, there, to the next CU in turn, so workgroups [0, #CUs) are the first on their
 // CU: they get the heaviest samples, everyone after them the lighter ones (measured with orders built on the host,
-// tools/lpt_experiment.py: rounded cone 33.1 -> 26.3 us per step, box 22.2 -> 21.5; orders that only even out the workgroups, or
-// per-piece quotas, gain nothing).  Order = stable counting sort of the samples by work class (exact pairs / 32 of an EARLIER
+// tools/lpt_experiment.py: rounded cone 33.1 -> 26.3 us per step, box 22.2 -> 21.5; orders that only even out the workgroups,
+// per-piece quotas, or a launch padded to the same number of workgroups on every CU with evened-out workgroups gain less or nothing).  Order = stable counting sort of the samples by work class (exact pairs / 32 of an EARLIER
 // step - the trajectory moves little between optimizer steps), classes descending, trajectory order inside a class
 // (neighbouring workgroups keep neighbouring tiles).  Built by the tail workgroups beside their own work, in two generations
 // so that no workgroup needs another one's output of the same launch (and none scans more than its own piece):

@@ -362,10 +362,12 @@ def test_longest_first_order_is_scheduling_only(pkg, orc, product_lib, shape_nam
     for step in range(6):
         got = eng.eval_single(Ta, ca)
         assert got[0] == fresh["a"][0] and np.array_equal(got[1], fresh["a"][1]) and np.array_equal(got[2], fresh["a"][2]), step
-    m = np.full(4 * nb, -7, dtype=np.int32)
+    m = np.full(4096, -7, dtype=np.int32)
     k = lib.isdf_debug_plan_map(eng.h, m.ctypes.data_as(C.c_void_p), m.size)
     assert k >= 3, "the plan must be running (fused launch with more workgroups than CUs)"
-    assert np.array_equal(np.sort(m[m >= 0]), np.arange(ns)) and np.count_nonzero(m == -1) == 4 * nb - ns, "not a permutation"
+    m = m[m != -7]                     # 4 x the sweep workgroups of the launch (it may run more of them than the samples need)
+    assert m.size % 4 == 0 and m.size >= 4 * nb
+    assert np.array_equal(np.sort(m[m >= 0]), np.arange(ns)) and np.count_nonzero(m == -1) == m.size - ns, "not a permutation"
     assert not np.array_equal(m[:ns], np.arange(ns)), "the order should differ from the plain one in a map with obstacles"
     for step in range(4):                                   # the plan keeps running across a changed trajectory
         got = eng.eval_single(Tb, cb)
