@@ -26,6 +26,7 @@ python $REPO/tools/pmc_sq.py "$(finddb /tmp/prof_sq3)" $OUT/${TAG}_pmc_sq3.txt "
 # one JSON with the dominant kernel's counters, stamped with the kernel sources' hash: bench.py reads profiles/pmc_counters.json
 python $REPO/tools/pmc_collect.py $OUT/${TAG}_pmc_counters.json "$(finddb /tmp/prof_kt)" "$(finddb /tmp/prof_f)" "$(finddb /tmp/prof_w)" "$(finddb /tmp/prof_sq)" "$(finddb /tmp/prof_sq2)" "$(finddb /tmp/prof_sq3)" > $OUT/${TAG}_pmc_collect.log 2>&1
 cd $REPO
+cp $OUT/${TAG}_pmc_counters.json $REPO/profiles/pmc_counters.json     # (on the box: so that the bench line below carries them)
 python bench.py > $OUT/${TAG}_bench.log 2>&1
 tail -1 $OUT/${TAG}_bench.log > $OUT/${TAG}_bench.json
 python tools/configs_bench.py > $OUT/${TAG}_configs.txt 2>&1
