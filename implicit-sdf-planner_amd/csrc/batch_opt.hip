@@ -21,6 +21,7 @@
 #include <cstdlib>
 #include <condition_variable>
 #include <cstring>
+#include <memory>
 #include <mutex>
 #include <thread>
 
@@ -45,7 +46,8 @@ struct Batch {
     std::vector<Worker> workers;
     // round state (guarded by m)
     std::mutex m;
-    std::condition_variable cv_workers, cv_coord;
+    std::condition_variable cv_coord;
+    std::unique_ptr<std::condition_variable[]> cv_worker;      // one per trajectory: a delivered round wakes its own trajectories only
     std::vector<char> submitted, finished, ready;     // ready[t]: the round trajectory t joined has been evaluated
     int n_submitted = 0, n_finished = 0, n_inflight = 0;
     double min_share = 0.25;      // a round starts when this share of the live trajectories waits (1.0: all of them)
@@ -77,7 +79,7 @@ double worker_evaluate(void *instance, const double *x, double *g, const int n) 
             b.submitted[w.id] = 1;
             b.n_submitted++;
             b.cv_coord.notify_one();
-            b.cv_workers.wait(lk, [&] { return b.ready[w.id] != 0; });
+            b.cv_worker[w.id].wait(lk, [&] { return b.ready[w.id] != 0; });
             b.ready[w.id] = 0;
             if (b.error != ISDF_OK) return INFINITY;
         }
@@ -99,7 +101,7 @@ double worker_evaluate(void *instance, const double *x, double *g, const int n) 
         b.submitted[w.id] = 1;
         b.n_submitted++;
         b.cv_coord.notify_one();
-        b.cv_workers.wait(lk, [&] { return b.ready[w.id] != 0; });
+        b.cv_worker[w.id].wait(lk, [&] { return b.ready[w.id] != 0; });
         b.ready[w.id] = 0;
         if (b.error != ISDF_OK) return INFINITY;
     }
@@ -122,6 +124,7 @@ extern "C" int isdf_optimize_lbfgs_batch(isdf_ctx *c, int n_traj, int N, const d
     b.ostride = isdf_out_stride(N);
     b.workers.resize(n_traj);
     b.submitted.assign(n_traj, 0); b.finished.assign(n_traj, 0); b.ready.assign(n_traj, 0);
+    b.cv_worker.reset(new std::condition_variable[n_traj]);
     if (const char *e = getenv("ISDF_BATCH_MIN_SHARE")) { const double v = atof(e); if (v > 0.0 && v <= 1.0) b.min_share = v; }
     b.stage_x.assign((size_t)n_traj * b.n, 0.0);
     b.stage_res.assign((size_t)n_traj * (1 + b.n), 0.0);
@@ -267,7 +270,8 @@ extern "C" int isdf_optimize_lbfgs_batch(isdf_ctx *c, int n_traj, int N, const d
         for (int t : q.active) b.ready[t] = 1;
         b.n_inflight -= na;
         q.busy = false;
-        b.cv_workers.notify_all();
+        if (rc != ISDF_OK) { for (int t = 0; t < b.n_traj; t++) b.cv_worker[t].notify_one(); }     // an error ends every wait
+        else for (int t : q.active) b.cv_worker[t].notify_one();
     };
     const int round_cap = b.device_minco ? std::max(8, (n_traj + 3) / 4) : n_traj;
     const int slots_used = b.device_minco ? N_SLOTS : 2;
