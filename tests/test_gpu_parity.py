@@ -385,3 +385,29 @@ def test_longest_first_order_is_scheduling_only(pkg, orc, product_lib, shape_nam
     for step in range(5):
         cost, gTs, gCs = eng.eval([T2, T2], [c2, c2])
         assert cost[0] == one[0] and cost[1] == one[0] and np.array_equal(gCs[1], one[2]), step
+
+
+@pytest.mark.parametrize("long_axis", [0, 1, 2])
+@pytest.mark.parametrize("variant", ["V3", "V2"])
+def test_rows_along_every_axis_and_clipped_tiles(pkg, orc, product_lib, long_axis, variant):
+    """The tile rows run along the world axis the robot is longest on, read from the bit-grid packed along that axis
+    (tile_sweep.hip).  Robots long in body x, y and z, a grid whose extents differ and are no multiples of 32 (41 x 70 x 36:
+    2, 3 and 2 dwords per row), trajectories hugging the map boundary (tiles clipped on every side, non-trivial bmax), a dense
+    map - against the oracle; pair counts must agree exactly (no voxel lost or visited twice)."""
+    capi, synth = pkg.capi, pkg.synth
+    res = 0.5
+    occ = synth.random_box_map((41, 70, 36), res=res, occupancy=0.3, seed=17 + long_axis, edge=(0.5, 2.0))
+    esdf = synth.esdf_from_occupancy(occ, res)
+    half = [0.35, 0.35, 0.35]
+    half[long_axis] = 1.7
+    shape = synth.make_shape("Box", params=tuple(half), grad_mode=capi.GRAD_CENTRAL)
+    v = capi.V3_ESDF_TILE if variant == "V3" else capi.V2_OCC_TILE
+    cfg = synth.default_config(v, kernel_size=11, integral_intervs=12, safety_hor=0.5)
+    bmax = np.array(occ.shape) * res - 0.2
+    kw = dict(esdf=esdf) if variant == "V3" else dict(occ=occ)
+    eng, o = make_pair(pkg, orc, cfg, shape, res=res, bmax=bmax, **kw)
+    for seed, margin in ((3, 0.6), (4, 0.6), (5, 3.0)):
+        T, cm = traj(pkg, np.zeros_like(occ), res, N=5, seed=seed + 10 * long_axis, margin=margin)
+        cost, st0 = _check(eng, o, T, cm, f"axis {long_axis} {variant} seed {seed}")
+        st = eng.stats()
+        assert cost > 0 and st["units"] == st0[0] and st["grad_pairs"] == st0[3] and st["pairs"] == st0[2], (st, st0)
