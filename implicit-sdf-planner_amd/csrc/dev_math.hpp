@@ -387,25 +387,38 @@ __device__ __forceinline__ double wave_sum(double v) {
 // in `v[0]` of lane wave_sum8_lane(k) (and of every lane with the same bits 3..5).  Halves the register set at each
 // of the first three steps (xor 32, 16, 8), so it needs 7 + 3 exchanges instead of 8 x 6.  Fixed summation order.
 __device__ __forceinline__ int wave_sum8_lane(int k) { return ((k & 1) << 3) | (((k >> 1) & 1) << 4) | ((k >> 2) << 5); }
+// Lane exchanges without LDS round trips: gfx950's v_permlane32_swap / v_permlane16_swap trade half wavefronts / odd and even
+// rows of two registers in place - with A = the component the lower half keeps and B = the one the upper half keeps,
+// swap(A, B) leaves {A_low, B_low} and {A_high, B_high}, whose lane-wise sum IS the butterfly step (same operands as
+// keep + shfl_xor(send): same bits) - and DPP row operations inside a row of 16.
+template <int CTRL> __device__ __forceinline__ double dpp_mov_f64(double v) {
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, 0xf, 0xf, false);
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xf, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double swap32_sum(double a, double b) {
+    const auto lo = __builtin_amdgcn_permlane32_swap(__double2loint(a), __double2loint(b), false, false);
+    const auto hi = __builtin_amdgcn_permlane32_swap(__double2hiint(a), __double2hiint(b), false, false);
+    return __hiloint2double(hi[0], lo[0]) + __hiloint2double(hi[1], lo[1]);
+}
+__device__ __forceinline__ double swap16_sum(double a, double b) {
+    const auto lo = __builtin_amdgcn_permlane16_swap(__double2loint(a), __double2loint(b), false, false);
+    const auto hi = __builtin_amdgcn_permlane16_swap(__double2hiint(a), __double2hiint(b), false, false);
+    return __hiloint2double(hi[0], lo[0]) + __hiloint2double(hi[1], lo[1]);
+}
 __device__ __forceinline__ void wave_sum8(double (&v)[8], int lane) {
-    const bool b5 = (lane & 32) != 0, b4 = (lane & 16) != 0, b3 = (lane & 8) != 0;
+    const bool b3 = (lane & 8) != 0;
 #pragma unroll
-    for (int i = 0; i < 4; i++) {       // keep components 4*b5 + i
-        const double send = b5 ? v[i] : v[4 + i], keep = b5 ? v[4 + i] : v[i];
-        v[i] = keep + __shfl_xor(send, 32, 64);
-    }
+    for (int i = 0; i < 4; i++) v[i] = swap32_sum(v[i], v[4 + i]);      // lanes 0-31 keep components i, lanes 32-63 components 4 + i
 #pragma unroll
-    for (int i = 0; i < 2; i++) {       // keep components 4*b5 + 2*b4 + i
-        const double send = b4 ? v[i] : v[2 + i], keep = b4 ? v[2 + i] : v[i];
-        v[i] = keep + __shfl_xor(send, 16, 64);
-    }
-    {                                   // keep component 4*b5 + 2*b4 + b3
+    for (int i = 0; i < 2; i++) v[i] = swap16_sum(v[i], v[2 + i]);      // even rows keep i, odd rows 2 + i
+    {                                   // keep component 4*b5 + 2*b4 + b3: partner = lane ^ 8 = the row rotated by 8
         const double send = b3 ? v[0] : v[1], keep = b3 ? v[1] : v[0];
-        v[0] = keep + __shfl_xor(send, 8, 64);
+        v[0] = keep + dpp_mov_f64<0x128>(send);       // row_ror:8
     }
-    v[0] += __shfl_xor(v[0], 4, 64);
-    v[0] += __shfl_xor(v[0], 2, 64);
-    v[0] += __shfl_xor(v[0], 1, 64);
+    v[0] += dpp_mov_f64<0x141>(v[0]);   // row_half_mirror: lane i + lane 7 - i of its group of 8
+    v[0] += dpp_mov_f64<0x4E>(v[0]);    // quad_perm [2,3,0,1]
+    v[0] += dpp_mov_f64<0xB1>(v[0]);    // quad_perm [1,0,3,2]
 }
 
 } // namespace isdf
