@@ -131,8 +131,22 @@ __global__ __launch_bounds__(1024) void swept_prepare_kernel(const SweptParams P
 // first lane holding the minimum of `v` over the active prefix [0, n); returns the minimum
 __device__ __forceinline__ double wave_first_min(double v, int lane, int n, int &arg) {
     double m = (lane < n) ? v : 1.7976931348623157e308;
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) m = fmin(m, __shfl_xor(m, off, 64));
+    // butterfly without LDS round trips (a minimum does not depend on the order it is taken in): halves and rows of the
+    // wavefront through gfx950's permlane swaps, the rest through DPP row operations
+    {
+        const auto lo = __builtin_amdgcn_permlane32_swap(__double2loint(m), __double2loint(m), false, false);
+        const auto hi = __builtin_amdgcn_permlane32_swap(__double2hiint(m), __double2hiint(m), false, false);
+        m = fmin(__hiloint2double(hi[0], lo[0]), __hiloint2double(hi[1], lo[1]));
+    }
+    {
+        const auto lo = __builtin_amdgcn_permlane16_swap(__double2loint(m), __double2loint(m), false, false);
+        const auto hi = __builtin_amdgcn_permlane16_swap(__double2hiint(m), __double2hiint(m), false, false);
+        m = fmin(__hiloint2double(hi[0], lo[0]), __hiloint2double(hi[1], lo[1]));
+    }
+    m = fmin(m, dpp_mov_f64<0x128>(m));      // row_ror:8
+    m = fmin(m, dpp_mov_f64<0x141>(m));      // row_half_mirror
+    m = fmin(m, dpp_mov_f64<0x4E>(m));       // quad_perm [2,3,0,1]
+    m = fmin(m, dpp_mov_f64<0xB1>(m));       // quad_perm [1,0,3,2]
     const unsigned long long eq = __ballot((lane < n) && (v == m));
     arg = eq ? (__ffsll((long long)eq) - 1) : -1;
     return m;
