@@ -212,6 +212,9 @@ struct SweepPose {                 // LDS record of one sample, written by the p
     int rx0, ry0, rnx, rny;        // window of tile rows (u, v) that can reach the shape's inflated bounding box
     int flags;                     // bit0 active, bit1 culled
     int sa;                        // scan axis: rows run along world axis sa, (u, v) = the other two axes, ascending
+    int nn[3];                     // tile extent per axis (0 or less: no tile)
+    int pad;
+    double L0[3], L1[3];           // extent of the shape's inflated bounding box on each world axis, in voxels from the map's first
 };
 
 __device__ __forceinline__ double uni(double v) {     // wave-uniform double -> scalar registers
@@ -366,12 +369,19 @@ __global__ __launch_bounds__(64 * SW_SAMPLES, FUSED ? 3 : sweep_waves_per_simd(K
     if (dbg && lane == 0) { dbg[0] = wall_clock64(); dbg[1] = clock64(); }
 
     // ---- poses of the workgroup's samples: one LANE per sample (the serial fp64 chain is issued once, not per wave)
+    // ---- poses of the workgroup's samples.  Three parties share the serial fp64 work (it is the launch's first 2.5 us, with
+    // nothing else to run beside it):
+    //   wave 0, one LANE per sample: quintic, flatness forward, rotation, and - in floating point - where the shape's
+    //                                inflated bounding box lies on each world axis;
+    //   wave 1, one lane per (sample, axis): position component -> the tile's index box on that axis, exactly as
+    //                                getPointsInAABB (PCSmap_manager.h:150-155);
+    //   after the barrier every wave finishes ITS sample: integer window of rows, scan axis.
+    auto sample_of_rank = [&](long long rank) -> long long {
+        if (P.sample_map) { const int m = P.sample_map[rank]; return m >= 0 ? s_begin + m : s_end; }
+        return s_begin + rank;
+    };
     long long pose_sidx = s_end;
-    if (wave == 0 && lane < SW_SAMPLES) {
-        const long long rank_l = (long long)blockIdx.x + (long long)lane * n_blocks;
-        pose_sidx = s_begin + rank_l;
-        if (P.sample_map) { const int m = P.sample_map[rank_l]; pose_sidx = m >= 0 ? s_begin + m : s_end; }
-    }
+    if (wave == 0 && lane < SW_SAMPLES) pose_sidx = sample_of_rank((long long)blockIdx.x + (long long)lane * n_blocks);
     if (pose_sidx < s_end) {
         const SampleId id = decode_sample(P, pose_sidx);
         bool staged = true;
@@ -393,30 +403,12 @@ __global__ __launch_bounds__(64 * SW_SAMPLES, FUSED ? 3 : sweep_waves_per_simd(K
 #pragma unroll
         for (int k = 0; k < 9; k++) sp.R[k] = R.a[k];
         sp.quat[0] = quat.w; sp.quat[1] = quat.x; sp.quat[2] = quat.y; sp.quat[3] = quat.z;
-        int lo[3] = {0, 0, 0}, hi[3] = {-1, -1, -1};
         int flags = 0;
         if (P.enable_pos) {
-            bool active = true;
-            if (P.cull_threshold > 0.0 && esdf_trilinear(G, pos) > P.cull_threshold) { active = false; flags |= 2; }
-            if (active) {
-                // getPointsInAABB(pos, bd/2): corners projected into the map, floor-indexed (PCSmap_manager.h:150-155)
-                const double p[3] = {pos.x, pos.y, pos.z};
-                const int dim[3] = {G.X, G.Y, G.Z};
-#pragma unroll
-                for (int a = 0; a < 3; a++) {
-                    lo[a] = axis_index(clampd(p[a] - P.bd_half, G.bmin[a], G.bmax[a]), G.bmin[a], G.res, dim[a]);
-                    hi[a] = axis_index(clampd(p[a] + P.bd_half, G.bmin[a], G.bmax[a]), G.bmin[a], G.res, dim[a]);
-                }
-                // NaN poses make every comparison false: keep the box sane
-                if (hi[0] >= lo[0] && hi[1] >= lo[1] && hi[2] >= lo[2]) flags |= 1;
-            }
+            flags = 1;
+            if (P.cull_threshold > 0.0 && esdf_trilinear(G, pos) > P.cull_threshold) flags = 2;
         }
-        // Rows run along the world axis on which the shape's inflated bounding box is LONGEST (the bit-grid exists packed along
-        // each axis): the window of rows spans the two short extents - a 3.2 m robot lying along x needs ~50 rows of ~20 voxels
-        // instead of ~140 rows of ~6.
-        const int nn[3] = {hi[0] - lo[0] + 1, hi[1] - lo[1] + 1, hi[2] - lo[2] + 1};
-        int w0[3] = {0, 0, 0}, w1[3] = {nn[0] - 1, nn[1] - 1, nn[2] - 1};
-        int sa = 2;
+        sp.flags = flags;      // bit 0 is confirmed by the wave that finishes the sample (the tile must exist)
         if ((flags & 1) && P.shape.prune_rows) {
             // world-frame extent of the shape's body-frame bounding box inflated by the penalty band: rows whose
             // (u, v) lies outside it cannot hold a voxel with a non-zero penalty (conservative: +-1 voxel, NaN keeps all)
@@ -433,29 +425,76 @@ __global__ __launch_bounds__(64 * SW_SAMPLES, FUSED ? 3 : sweep_waves_per_simd(K
             for (int a = 0; a < 3; a++) {
                 const double ctr = p[a] + R.a[3 * a] * cb[0] + R.a[3 * a + 1] * cb[1] + R.a[3 * a + 2] * cb[2];
                 const double ext = fabs(R.a[3 * a]) * hb[0] + fabs(R.a[3 * a + 1]) * hb[1] + fabs(R.a[3 * a + 2]) * hb[2];
-                const double l0 = (ctr - ext - G.bmin[a]) * inv_res - 0.5 - lo[a], l1 = (ctr + ext - G.bmin[a]) * inv_res - 0.5 - lo[a];
-                if (l0 > 0.0) w0[a] = (int)fmin(floor(l0), (double)nn[a]);          // > nn-1 -> empty window
-                if (l1 < (double)(nn[a] - 1)) w1[a] = (int)fmax(ceil(l1), -1.0);
+                sp.L0[a] = (ctr - ext - G.bmin[a]) * inv_res - 0.5;
+                sp.L1[a] = (ctr + ext - G.bmin[a]) * inv_res - 0.5;
             }
-            const int e0 = w1[0] - w0[0], e1 = w1[1] - w0[1], e2 = w1[2] - w0[2];
-            sa = (e2 >= e0 && e2 >= e1) ? 2 : (e0 >= e1 ? 0 : 1);
         }
-        // (u, v): the axes other than sa, ascending
-        const int u0 = sa == 0 ? w0[1] : w0[0], u1 = sa == 0 ? w1[1] : w1[0];
-        const int v0 = sa == 2 ? w0[1] : w0[2], v1 = sa == 2 ? w1[1] : w1[2];
-        int rx0 = 0, ry0 = 0, rnx = 0, rny = 0;
-        if (flags & 1) { rx0 = u0; ry0 = v0; rnx = max(0, u1 - u0 + 1); rny = max(0, v1 - v0 + 1); }
-        sp.lo[0] = lo[0]; sp.lo[1] = lo[1]; sp.lo[2] = lo[2];
-        sp.nzt = sa == 2 ? nn[2] : (sa == 0 ? nn[0] : nn[1]);
-        sp.rx0 = rx0; sp.ry0 = ry0; sp.rnx = rnx; sp.rny = rny;
-        sp.flags = flags;
-        sp.sa = sa;
+    }
+    if (wave == 1 && lane < 3 * SW_SAMPLES && P.enable_pos) {
+        const int ps = lane / 3, a = lane - 3 * ps;
+        const long long sx = sample_of_rank((long long)blockIdx.x + (long long)ps * n_blocks);
+        if (sx < s_end) {
+            const SampleId id = decode_sample(P, sx);
+            if constexpr (FUSED) if (P.host_T) (void)stage_wait(P, id.b * P.N + id.i);      // (a miss is reported by wave 0)
+            const PieceIn pin = piece_in(P, id.b, id.i);
+            const double step = pin.T * P.inv_K;
+            Basis B;
+            poly_basis(id.j * step, B);
+            const double *ca = pin.c + (size_t)a * pin.ld;
+            double pa = 0.0;
+#pragma unroll
+            for (int k = 0; k < 6; k++) pa += ca[k] * B.b0[k];                   // component a of ct_beta(c, ld, b0): same operations
+            const double bmn = a == 0 ? G.bmin[0] : (a == 1 ? G.bmin[1] : G.bmin[2]), bmx = a == 0 ? G.bmax[0] : (a == 1 ? G.bmax[1] : G.bmax[2]);
+            const int dim = a == 0 ? G.X : (a == 1 ? G.Y : G.Z);
+            // getPointsInAABB(pos, bd/2): corners projected into the map, floor-indexed (PCSmap_manager.h:150-155)
+            const int lo = axis_index(clampd(pa - P.bd_half, bmn, bmx), bmn, G.res, dim);
+            const int hi = axis_index(clampd(pa + P.bd_half, bmn, bmx), bmn, G.res, dim);
+            s_pose[ps].lo[a] = lo;
+            s_pose[ps].nn[a] = hi - lo + 1;             // NaN poses make every comparison false: the extent then says "no tile"
+        }
     }
     __syncthreads();
     if (dbg && lane == 0) dbg[2] = clock64();
 
     const bool have_sample = sidx < s_end;
-    const SweepPose &sp = s_pose[wave];
+    SweepPose &sp = s_pose[wave];
+    {
+        // ---- this wave's sample: window of rows and scan axis (wave-uniform; every lane computes the same)
+        // Rows run along the world axis on which the shape's inflated bounding box is LONGEST (the bit-grid exists packed along
+        // each axis): the window of rows spans the two short extents - a 3.2 m robot lying along x needs ~50 rows of ~20 voxels
+        // instead of ~140 rows of ~6.
+        // lane a < 3 works on axis a; the three results come back as scalars
+        const int ax = min(lane, 2);
+        int flags_w = have_sample ? __builtin_amdgcn_readfirstlane(sp.flags) : 0;
+        const int nn_a = have_sample ? sp.nn[ax] : 0;
+        const int nn[3] = {__builtin_amdgcn_readlane(nn_a, 0), __builtin_amdgcn_readlane(nn_a, 1), __builtin_amdgcn_readlane(nn_a, 2)};
+        if ((flags_w & 1) && !(nn[0] > 0 && nn[1] > 0 && nn[2] > 0)) flags_w &= ~1;
+        int w0a = 0, w1a = nn_a - 1;
+        const bool windowed = (flags_w & 1) && P.shape.prune_rows;
+        if (windowed) {
+            const double l0 = sp.L0[ax] - sp.lo[ax], l1 = sp.L1[ax] - sp.lo[ax];
+            if (l0 > 0.0) w0a = (int)fmin(floor(l0), (double)nn_a);          // > nn-1 -> empty window
+            if (l1 < (double)(nn_a - 1)) w1a = (int)fmax(ceil(l1), -1.0);
+        }
+        const int w0[3] = {__builtin_amdgcn_readlane(w0a, 0), __builtin_amdgcn_readlane(w0a, 1), __builtin_amdgcn_readlane(w0a, 2)};
+        const int w1[3] = {__builtin_amdgcn_readlane(w1a, 0), __builtin_amdgcn_readlane(w1a, 1), __builtin_amdgcn_readlane(w1a, 2)};
+        int sa_w = 2;
+        if (windowed) {
+            const int e0 = w1[0] - w0[0], e1 = w1[1] - w0[1], e2 = w1[2] - w0[2];
+            sa_w = (e2 >= e0 && e2 >= e1) ? 2 : (e0 >= e1 ? 0 : 1);
+        }
+        // (u, v): the axes other than sa, ascending
+        const int u0 = sa_w == 0 ? w0[1] : w0[0], u1 = sa_w == 0 ? w1[1] : w1[0];
+        const int v0 = sa_w == 2 ? w0[1] : w0[2], v1 = sa_w == 2 ? w1[1] : w1[2];
+        if (have_sample && lane == 0) {
+            sp.rx0 = (flags_w & 1) ? u0 : 0; sp.ry0 = (flags_w & 1) ? v0 : 0;
+            sp.rnx = (flags_w & 1) ? max(0, u1 - u0 + 1) : 0; sp.rny = (flags_w & 1) ? max(0, v1 - v0 + 1) : 0;
+            sp.nzt = sa_w == 2 ? nn[2] : (sa_w == 0 ? nn[0] : nn[1]);
+            sp.flags = flags_w;
+            sp.sa = sa_w;
+        }
+        wave_lds_sync();
+    }
     const int flags = have_sample ? __builtin_amdgcn_readfirstlane(sp.flags) : 0;
     const int rnx = have_sample ? __builtin_amdgcn_readfirstlane(sp.rnx) : 0, rny = have_sample ? __builtin_amdgcn_readfirstlane(sp.rny) : 0;
     const int n_rows = (flags & 1) ? rnx * rny : 0;
