@@ -228,16 +228,25 @@ __global__ __launch_bounds__(64 * SW_WAVES) void swept_scan_kernel(const SweptPa
     int n_ranges = 0;
     bool in_range = false;
     double tou_lb = 0.0, range_mindis = 1e9;
+    // Coarse samples whose pose is farther from the point than the robot's bounding sphere plus the band cannot be in range
+    // (isdf_shape.bound_radius: sdf(q) >= |q| - R for every body-frame q, and |R^T (p - x)| = |p - x|): they skip the rotation
+    // and the SDF - a whole 64-sample window does when none of its poses is near, which is most windows of most points.
+    const size_t cst = (size_t)P.max_coarse;
+    // (the mesh kind's sdf is (1 - 2 w) * distance with libigl's APPROXIMATE winding number, |w error| a few 1e-3: its band is widened by 5 %)
+    const double far_r = P.shape.bound_radius + inf * (KIND == ISDF_SHAPE_MESH ? 1.05 : 1.0);
+    const double far2 = P.shape.bound_radius > 0.0 ? far_r * far_r : 1.0e300;
     for (int base = 0; base < n_coarse; base += 64) {
         const int k = base + lane;
+        const int kc = min(k, n_coarse - 1);
+        const double ct = P.coarse_t[kc];         // travels with the lane: the run boundaries below come out of a register
+        const double *o = P.coarse_pose + kc;     // component-major table: coalesced across the lanes
+        const d3 dxp = p - mk3(o[0], o[cst], o[2 * cst]);
         double dis = 1e9;
-        if (k < n_coarse) {
-            const double *o = P.coarse_pose + k;          // component-major table: coalesced across the lanes
-            const size_t st = (size_t)P.max_coarse;
+        if (k < n_coarse && !(dot3(dxp, dxp) > far2)) {
             m3 R;
 #pragma unroll
-            for (int q = 0; q < 9; q++) R.a[q] = o[(3 + q) * st];
-            const d3 pr = mat_tmul(R, p - mk3(o[0], o[st], o[2 * st]));
+            for (int q = 0; q < 9; q++) R.a[q] = o[(3 + q) * cst];
+            const d3 pr = mat_tmul(R, dxp);
             if constexpr (KIND == ISDF_SHAPE_MESH) {
                 // the scan only asks "dis < inf?" (and keeps dis where the answer is yes): far samples are rejected by the
                 // hierarchy's distance cutoff without a full query
@@ -258,15 +267,15 @@ __global__ __launch_bounds__(64 * SW_WAVES) void swept_scan_kernel(const SweptPa
                 if (!rest) break;                                  // no further entry in this window
                 b += __ffsll((long long)rest) - 1;                 // first in-range sample: run entry
                 in_range = true;
-                range_mindis = __shfl(dis, b, 64);
-                tou_lb = fmax(0.0, P.coarse_t[base + b] - rough_dt);
+                range_mindis = rlane(dis, __builtin_amdgcn_readfirstlane(b));
+                tou_lb = fmax(0.0, rlane(ct, __builtin_amdgcn_readfirstlane(b)) - rough_dt);
                 b++;
             } else {
                 const unsigned long long nrest = (~rest) & ((nvalid - b >= 64) ? ~0ull : ((1ull << (nvalid - b)) - 1ull));
                 if (!nrest) break;                                 // run continues past this window
                 b += __ffsll((long long)nrest) - 1;                // first out-of-range sample: run exit
                 in_range = false;
-                const double tou_ub = fmin(D, P.coarse_t[base + b] + rough_dt);
+                const double tou_ub = fmin(D, rlane(ct, __builtin_amdgcn_readfirstlane(b)) + rough_dt);
                 if (n_ranges < SW_MAX_RANGES) {
                     if (lane == 0) { s_rl[wave][n_ranges] = tou_lb; s_rr[wave][n_ranges] = tou_ub; }
                 } else if (lane == 0) {
@@ -302,9 +311,9 @@ __global__ __launch_bounds__(64 * SW_WAVES) void swept_scan_kernel(const SweptPa
             const int nv = __popcll(__ballot(act));                  // valid lanes form a prefix (t is increasing)
             int arg;
             const double m = wave_first_min(val, lane, nv, arg);
-            if (arg >= 0 && m < range_mindis) { range_mindis = m; range_time_seed = __shfl(te, arg, 64); }
+            if (arg >= 0 && m < range_mindis) { range_mindis = m; range_time_seed = rlane(te, __builtin_amdgcn_readfirstlane(arg)); }
             if (nv < 64) break;
-            t_base = __shfl(te, 63, 64) + dt;
+            t_base = rlane(te, 63) + dt;
         }
         if (lane == 0) { double *o = slots + (size_t)r * TASK_STRIDE; o[0] = lb; o[1] = ub; o[2] = range_time_seed; }
     }
