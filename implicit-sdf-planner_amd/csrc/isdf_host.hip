@@ -646,7 +646,9 @@ static int eval_device_impl(isdf_ctx *c, int n_traj, int N, const double *d_T, c
                 HIPCHK(c, hipMalloc(&c->d_plan_lr, 2 * (size_t)PLAN_MAX_SAMPLES * sizeof(unsigned short)));
                 HIPCHK(c, hipMalloc(&c->d_plan_hist, 2 * (size_t)PLAN_MAX_PIECES * PLAN_CLASSES * sizeof(unsigned short)));
             }
-            if (c->plan_ns != ns_local || c->plan_nb != nb) { c->plan_k = 0; c->plan_ns = ns_local; c->plan_nb = nb; }
+            // the records of earlier steps are laid out by piece: they only carry over to a launch of the same geometry
+            const long long geo = ((long long)total_pieces << 20) | (long long)cfg.integral_intervs;
+            if (c->plan_ns != ns_local || c->plan_nb != nb || c->plan_geo != geo) { c->plan_k = 0; c->plan_ns = ns_local; c->plan_nb = nb; c->plan_geo = geo; }
             // step k: the sweep leaves generation k's classes; the tail workgroups turn generation k - 1's classes into records,
             // generation k - 2's records into the order of step k + 1; the launch itself runs in the order made in step k - 1
             const int k = c->plan_k, par = k & 1;
