@@ -287,6 +287,8 @@ def main():
     issue = None
     hbm_meas = None
     bound = "unknown (no counters for this version of the kernel; nominal figure only)"
+    if not (world == 1 and N == 40 and args.grid == 256 and args.kernel_size == 21):
+        bound = "valu-issue / latency on the N = 1 workload by the counters (profiles/pmc_counters.json); counters are not collected for this geometry"
     tpath = os.path.join(ROOT, "profiles", "pmc_counters.json")
     if world == 1 and N == 40 and args.grid == 256 and args.kernel_size == 21 and os.path.exists(tpath):
         try:
