@@ -367,6 +367,15 @@ def main():
             run_cfg("C3 (configs[2]): 128 trajectories x 40 pieces, shared 256^3 map, one batched launch pair", eng, 128, 40, np.concatenate(Ts), np.concatenate(Cs), 20)
             _, _, T4, cm4 = build_workload(pkg, 400, args.grid, res)
             run_cfg("C4 on ONE GPU (configs[3]'s trajectory unsharded): 1 x 400 pieces", eng, 1, 400, T4, cm4, 50)
+            # another robot of SURVEY 8(d) on the headline geometry: the 0.4x rounded cone (three branches, a square root each)
+            try:
+                ec = pkg.Engine(cfg)
+                ec.set_grid(esdf, (0, 0, 0), res, capi.GRID_ESDF)
+                ec.set_shape(synth.bench_rounded_cone_shape())
+                run_cfg("C2 geometry (1 x 40 pieces) with the rounded-cone robot (r1 0.6, r2 0.24, h 1.8)", ec, 1, 40, T, cm, 200)
+                del ec
+            except Exception as e:      # noqa: BLE001
+                extra.append({"name": "rounded cone", "error": str(e)})
             # 512^3 map at 0.1 m (512 MiB fp32 ESDF, built on the device), the robot and the tile halved with the voxel
             try:
                 res5 = 0.1
