@@ -211,7 +211,9 @@ int isdf_eval(isdf_ctx *ctx, int n_traj, const int *N, const double *const *T,
  * and leaves a NaN cost.  isdf_eval reports that as ISDF_ERR_OVERFLOW by itself; a caller of THIS entry point must look:
  * a non-finite d_out[0], or isdf_get_stats(...).overflow != 0 (reading it drains the device, clears the word and empties
  * every slot again, so that a producer that published late cannot feed the next step; the in-kernel exchange of a
- * multi-GPU step should be switched off after an overflow, isdf_xchg_fuse(ctx, 0)). */
+ * multi-GPU step should be switched off after an overflow, isdf_xchg_fuse(ctx, 0)).
+ * Steps of one ctx share its scratch (result slots, the dispatch order the device derives from earlier steps): they have to
+ * execute one after the other - the same stream, or streams ordered by events as isdf_optimize_lbfgs_batch does. */
 int isdf_eval_device(isdf_ctx *ctx, int n_traj, int N, const double *d_T, const double *d_coeffs,
                      double *d_out, double *d_tstar, void *stream);
 size_t isdf_out_stride(int N);   /* 1 + N + 18N */
