@@ -628,43 +628,68 @@ static int eval_device_impl(isdf_ctx *c, int n_traj, int N, const double *d_T, c
         if (!hd->via_bar) { P.host_T = hd->T; P.host_coeffs = hd->coeffs; P.stage = c->d_stage; P.stage_flags = c->d_stage_flags; }
         c->last_P = P;
     }
-    // longest-first dispatch order of a fused step whose workgroups outnumber the CUs (tile_sweep.hip, plan_piece)
-    P.plan_cls_in = nullptr; P.plan_cls_out = nullptr; P.plan_map_out = nullptr; P.plan_zone = 0;
+    // dispatch order built on the device from the work of earlier steps (tile_sweep.hip, plan_wave): a resident (fused) launch
+    // gives the heaviest samples to the workgroups that are first on their CU; every other launch groups samples of like weight
+    // into workgroups and dispatches the heaviest first
+    P.plan_cls_in = nullptr; P.plan_cls_out = nullptr; P.plan_map_out = nullptr; P.plan_zone = 0; P.plan_group = 1;
     P.plan_lr_in = P.plan_hist_in = nullptr; P.plan_lr_out = P.plan_hist_out = nullptr;
     {
-        const long long ns_local = (long long)(pe - pb) * (cfg.integral_intervs + 1);
+        const int K1 = cfg.integral_intervs + 1;
+        const long long n_loc = pe - pb, ns_local = n_loc * K1;
         const int nb = (int)((ns_local + 3) / 4);
+        P.n_sweep_blocks = nb;                  // (launch_sweep sets it again for its own copy; the tail launch needs it for the order it writes)
         if (c->n_cus == 0) { hipDeviceProp_t pr; c->n_cus = (hipGetDeviceProperties(&pr, c->device) == hipSuccess && pr.multiProcessorCount > 0) ? pr.multiProcessorCount : 256; }
         static const bool no_plan = [] { const char *e = getenv("ISDF_NO_LPT"); return e && e[0] == '1'; }();
-        const bool plan = fused && !no_plan && !P.sample_map && P.xf.world <= 1 && pb == 0 && pe == total_pieces && ns_local <= PLAN_MAX_SAMPLES &&
-                          total_pieces <= PLAN_MAX_PIECES && cfg.integral_intervs + 1 <= 128 && nb > c->n_cus;
+        bool plan = cfg.enable_pos && !no_plan && !P.sample_map && K1 <= 128 && nb > c->n_cus && ns_local < (1LL << 28);
+        long long group = n_loc;
+        int zone = 0;
+        if (plan) {
+            if (fused) {
+                // resident launch: zones; the exchange inside a fused multi-GPU launch keeps the plain order
+                plan = P.xf.world <= 1 && pb == 0 && pe == total_pieces && ns_local <= PLAN_GROUP_MAX_SAMPLES;
+                zone = c->n_cus;
+            } else if (ns_local > PLAN_GROUP_MAX_SAMPLES) {
+                // a batch: every trajectory is sorted by itself (the shard must hold whole trajectories)
+                group = N;
+                plan = (long long)N * K1 <= PLAN_GROUP_MAX_SAMPLES && pb % N == 0 && pe % N == 0;
+            }
+        }
         if (!plan) c->plan_k = 0;
         else {
-            if (!c->d_plan_cls) {
-                HIPCHK(c, hipMalloc(&c->d_plan_cls, 2 * (size_t)PLAN_MAX_SAMPLES));
-                HIPCHK(c, hipMalloc(&c->d_plan_map, 2 * (size_t)PLAN_MAX_SAMPLES * sizeof(int)));
-                HIPCHK(c, hipMalloc(&c->d_plan_lr, 2 * (size_t)PLAN_MAX_SAMPLES * sizeof(unsigned short)));
-                HIPCHK(c, hipMalloc(&c->d_plan_hist, 2 * (size_t)PLAN_MAX_PIECES * PLAN_CLASSES * sizeof(unsigned short)));
+            const size_t ns_cap = (size_t)4 * nb, np_cap = (size_t)n_loc;
+            if (c->plan_ns_cap < ns_cap || c->plan_np_cap < np_cap) {
+                HIPCHK(c, hipStreamSynchronize(st));
+                for (void *q : {(void *)c->d_plan_cls, (void *)c->d_plan_map, (void *)c->d_plan_lr, (void *)c->d_plan_hist}) if (q) (void)hipFree(q);
+                c->d_plan_cls = nullptr; c->d_plan_map = nullptr; c->d_plan_lr = nullptr; c->d_plan_hist = nullptr;
+                c->plan_ns_cap = c->plan_np_cap = 0; c->plan_k = 0;
+                const size_t nsc = std::max(ns_cap, (size_t)4096), npc = std::max(np_cap, (size_t)256);
+                HIPCHK(c, hipMalloc(&c->d_plan_cls, 2 * nsc));
+                HIPCHK(c, hipMalloc(&c->d_plan_map, 2 * nsc * sizeof(int)));
+                HIPCHK(c, hipMalloc(&c->d_plan_lr, 2 * nsc * sizeof(unsigned short)));
+                HIPCHK(c, hipMalloc(&c->d_plan_hist, 2 * npc * PLAN_CLASSES * sizeof(unsigned short)));
+                c->plan_ns_cap = nsc; c->plan_np_cap = npc;
             }
             // the records of earlier steps are laid out by piece: they only carry over to a launch of the same geometry
-            const long long geo = ((long long)total_pieces << 20) | (long long)cfg.integral_intervs;
+            const long long geo = ((long long)n_loc << 32) | ((long long)K1 << 20) | ((long long)(fused ? 1 : 0) << 19) | (long long)(group & 0x7FFFF);
             if (c->plan_ns != ns_local || c->plan_nb != nb || c->plan_geo != geo) { c->plan_k = 0; c->plan_ns = ns_local; c->plan_nb = nb; c->plan_geo = geo; }
             // step k: the sweep leaves generation k's classes; the tail workgroups turn generation k - 1's classes into records,
             // generation k - 2's records into the order of step k + 1; the launch itself runs in the order made in step k - 1
             const int k = c->plan_k, par = k & 1;
-            P.plan_zone = c->n_cus;
-            P.plan_cls_out = c->d_plan_cls + (size_t)par * PLAN_MAX_SAMPLES;
+            const size_t nsc = c->plan_ns_cap, hc = c->plan_np_cap * PLAN_CLASSES;
+            P.plan_zone = zone;
+            P.plan_group = (int)group;
+            P.plan_cls_out = c->d_plan_cls + (size_t)par * nsc;
             if (k >= 1) {
-                P.plan_cls_in = c->d_plan_cls + (size_t)(1 - par) * PLAN_MAX_SAMPLES;
-                P.plan_lr_out = c->d_plan_lr + (size_t)(1 - par) * PLAN_MAX_SAMPLES;
-                P.plan_hist_out = c->d_plan_hist + (size_t)(1 - par) * PLAN_MAX_PIECES * PLAN_CLASSES;
+                P.plan_cls_in = c->d_plan_cls + (size_t)(1 - par) * nsc;
+                P.plan_lr_out = c->d_plan_lr + (size_t)(1 - par) * nsc;
+                P.plan_hist_out = c->d_plan_hist + (size_t)(1 - par) * hc;
             }
             if (k >= 2) {
-                P.plan_lr_in = c->d_plan_lr + (size_t)par * PLAN_MAX_SAMPLES;
-                P.plan_hist_in = c->d_plan_hist + (size_t)par * PLAN_MAX_PIECES * PLAN_CLASSES;
-                P.plan_map_out = c->d_plan_map + (size_t)(1 - par) * PLAN_MAX_SAMPLES;
+                P.plan_lr_in = c->d_plan_lr + (size_t)par * nsc;
+                P.plan_hist_in = c->d_plan_hist + (size_t)par * hc;
+                P.plan_map_out = c->d_plan_map + (size_t)(1 - par) * nsc;
             }
-            if (k >= 3) P.sample_map = c->d_plan_map + (size_t)par * PLAN_MAX_SAMPLES;
+            if (k >= 3) P.sample_map = c->d_plan_map + (size_t)par * nsc;
             if (c->plan_k < (1 << 30)) c->plan_k++;
         }
     }
@@ -1264,7 +1289,7 @@ extern "C" int isdf_debug_plan_map(isdf_ctx *c, int *out, long long cap) {
     (void)hipSetDevice(c->device);
     (void)hipDeviceSynchronize();
     const long long n = 4LL * c->plan_nb < cap ? 4LL * c->plan_nb : cap;
-    if (out && n > 0) (void)hipMemcpy(out, c->d_plan_map + (size_t)(c->plan_k & 1) * PLAN_MAX_SAMPLES, (size_t)n * sizeof(int), hipMemcpyDeviceToHost);
+    if (out && n > 0) (void)hipMemcpy(out, c->d_plan_map + (size_t)(c->plan_k & 1) * c->plan_ns_cap, (size_t)n * sizeof(int), hipMemcpyDeviceToHost);
     return c->plan_k;
 }
 

@@ -21,8 +21,7 @@ struct DevGrid {
     int XW, YW;
 };
 constexpr int PLAN_CLASSES = 8;          // work classes of the longest-first order
-constexpr int PLAN_MAX_PIECES = 256;
-constexpr int PLAN_MAX_SAMPLES = 4096;   // longest-first order: samples of a fused single-launch step (<= 4 x 1024 workgroups)
+constexpr int PLAN_GROUP_MAX_SAMPLES = 65535;   // samples sorted together: their per-class counts are added in packed 16-bit fields
 constexpr int ACC_STRIDE = 8;       // costp, dL/dpos(3), dL/dquat(4) of one pose, before weight_p
 constexpr int PARTIAL_STRIDE = 20;  // V1: per-point record = 18 gradC entries (d*6 + r), gdT, pena
 
@@ -84,7 +83,8 @@ struct SweepParams {
     unsigned short *plan_lr_out, *plan_hist_out;
     const unsigned short *plan_lr_in, *plan_hist_in;   // the records made one step ago -> plan_map_out
     int *plan_map_out;                  // the next step's order
-    int plan_zone;                      // workgroups that get the heaviest samples: one per CU
+    int plan_zone;                      // resident launch: workgroups that get the heaviest samples (one per CU); 0: workgroups of four neighbours of the sorted order, heaviest first
+    int plan_group;                     // pieces sorted together (the whole launch, or one trajectory of a batch)
     int dbg_flags;              // developer switches (ISDF_DEBUG_FLAGS): 1 = skip the exact pass body
     unsigned long long *dbg;    // developer timing buffer (ISDF_DEBUG_TIMING=1), null on the product path
 };

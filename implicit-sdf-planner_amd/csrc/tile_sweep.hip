@@ -277,10 +277,17 @@ __device__ __forceinline__ unsigned plan_count(uint4 v, int q) {
     const unsigned w = (q >> 1) == 0 ? v.x : (q >> 1) == 1 ? v.y : (q >> 1) == 2 ? v.z : v.w;
     return (w >> (16 * (q & 1))) & 0xFFFFu;
 }
-__device__ void plan_wave(const SweepParams &P, const int t, const int lane) {
+// Launches that are NOT resident as a whole (a 400-piece trajectory, a batch, the shard of a multi-GPU step, every two-launch
+// step) use the same records differently (plan_zone = 0): the sorted order is cut into workgroups of four NEIGHBOURS - samples
+// of like weight share a workgroup, so its four scans end together instead of three waves idling at the barrier for the
+// fourth, and the heaviest workgroups are dispatched first, so the launch does not end on them (measured with host-built
+// orders, tools/lpt_big_experiment.py: 400 pieces 106 -> 94 us, 100 pieces 37.8 -> 33.8).  Sorting is per GROUP of pieces (the
+// whole launch, or one trajectory of a batch: at most 65 535 samples, so that the packed 16-bit counts cannot overflow).
+__device__ void plan_wave(const SweepParams &P, const int t, const int lane) {      // t: local piece (0 = this rank's first)
     const int K1 = P.K + 1, n_pieces = P.piece_end - P.piece_begin;
     const int ns = n_pieces * K1, nb = P.n_sweep_blocks, Z = P.plan_zone;
-    const int s0 = t * K1 + lane, s1 = s0 + 64;     // (all pieces are local: t = piece)
+    const int G = P.plan_group, gp0 = (t / G) * G, gn = min(G, n_pieces - gp0);      // this piece's group: pieces [gp0, gp0 + gn)
+    const int s0 = t * K1 + lane, s1 = s0 + 64;
     const bool h0 = lane < K1, h1 = lane + 64 < K1;
     if (P.plan_cls_in) {
         // ---- generation g: classes -> (class, rank inside piece and class) records, histogram of the piece
@@ -299,9 +306,9 @@ __device__ void plan_wave(const SweepParams &P, const int t, const int lane) {
         if (lane < PLAN_CLASSES) P.plan_hist_out[t * PLAN_CLASSES + lane] = (unsigned short)hist;
     }
     if (P.plan_lr_in) {
-        // ---- generation g - 1: all pieces' histograms -> first position of this piece's samples of each class -> ranks
+        // ---- generation g - 1: the group's histograms -> first position of this piece's samples of each class -> ranks
         uint4 tot = make_uint4(0, 0, 0, 0), bef = tot;
-        for (int i = lane; i < n_pieces; i += 64) {
+        for (int i = gp0 + lane; i < gp0 + gn; i += 64) {
             const uint4 h = reinterpret_cast<const uint4 *>(P.plan_hist_in)[i];
             tot = plan_add(tot, h);
             if (i < t) bef = plan_add(bef, h);
@@ -316,10 +323,16 @@ __device__ void plan_wave(const SweepParams &P, const int t, const int lane) {
         // (the shuffles run with all lanes: a lane may need the base a lane without a sample holds)
         const unsigned v0 = h0 ? P.plan_lr_in[s0] : 0u, v1 = h1 ? P.plan_lr_in[s1] : 0u;
         const int b0 = __shfl(base, (int)(v0 & 7u)), b1 = __shfl(base, (int)(v1 & 7u));
-        if (h0) P.plan_map_out[plan_rank(b0 + (int)(v0 >> 3), Z, nb)] = s0;
-        if (h1) P.plan_map_out[plan_rank(b1 + (int)(v1 >> 3), Z, nb)] = s1;
-        // ranks behind the last sample stay empty
-        if (t == 0) for (int pos = ns + lane; pos < 4 * nb; pos += 64) P.plan_map_out[plan_rank(pos, Z, nb)] = -1;
+        const int p0 = gp0 * K1 + b0 + (int)(v0 >> 3), p1 = gp0 * K1 + b1 + (int)(v1 >> 3);      // positions in the launch's order
+        if (Z > 0) {
+            if (h0) P.plan_map_out[plan_rank(p0, Z, nb)] = s0;
+            if (h1) P.plan_map_out[plan_rank(p1, Z, nb)] = s1;
+            if (t == 0) for (int pos = ns + lane; pos < 4 * nb; pos += 64) P.plan_map_out[plan_rank(pos, Z, nb)] = -1;     // ranks behind the last sample stay empty
+        } else {
+            if (h0) P.plan_map_out[(p0 & 3) * nb + (p0 >> 2)] = s0;
+            if (h1) P.plan_map_out[(p1 & 3) * nb + (p1 >> 2)] = s1;
+            if (t == 0) for (int pos = ns + lane; pos < 4 * nb; pos += 64) P.plan_map_out[(pos & 3) * nb + (pos >> 2)] = -1;
+        }
     }
 }
 
@@ -1113,15 +1126,26 @@ template <bool EARLY, bool XF> __device__ __forceinline__ void tail_piece(const 
     if (dbg && tid == 0) dbg[1] = wall_clock64();
 }
 
-__global__ __launch_bounds__(TL_THREADS) void tail_kernel(const SweepParams P) {
+// The separate tail launch carries one more wavefront than its samples need: it builds the next step's dispatch order
+// (plan_wave) beside the tail's own work.
+constexpr int TL_LAUNCH_THREADS = TL_THREADS + 64;
+template <bool XF> __device__ __forceinline__ void tail_plan(const SweepParams &P) {
+    if (!(P.plan_cls_in || P.plan_lr_in) || (P.dbg_flags & 2) || (int)(threadIdx.x >> 6) != TL_THREADS / 64) return;
+    int gp = (int)blockIdx.x;
+    if constexpr (XF) { const int n_own = P.piece_end - P.piece_begin, t = gp; gp = t < n_own ? P.piece_begin + t : (t - n_own < P.piece_begin ? t - n_own : t); }
+    if (gp >= P.piece_begin && gp < P.piece_end) plan_wave(P, gp - P.piece_begin, (int)(threadIdx.x & 63));
+}
+__global__ __launch_bounds__(TL_LAUNCH_THREADS) void tail_kernel(const SweepParams P) {
     __shared__ double s_val[TL_THREADS][PARTIAL_STRIDE + 1];   // +1: column reads by 20 threads hit distinct banks
+    tail_plan<false>(P);
     tail_piece<true, false>(P, (int)blockIdx.x, s_val);        // one workgroup per piece of the launch
 }
 // Multi-GPU step that is NOT one fused launch (a 50-piece shard of a 400-piece trajectory: 813 + 50 workgroups, beyond what is
 // resident at once; mesh robots; body offsets): the exchange rides in the tail launch instead - the workgroups of this
 // rank's pieces (dispatched first) store their rows into every peer's board, the others poll theirs out of this rank's.
-__global__ __launch_bounds__(TL_THREADS) void tail_kernel_xf(const SweepParams P) {
+__global__ __launch_bounds__(TL_LAUNCH_THREADS) void tail_kernel_xf(const SweepParams P) {
     __shared__ double s_val[TL_THREADS][PARTIAL_STRIDE + 1];
+    tail_plan<true>(P);
     tail_piece<true, true>(P, (int)blockIdx.x, s_val);
 }
 
@@ -1224,8 +1248,8 @@ void launch_build_bits(const DevGrid &G, int use_esdf, float thresh, unsigned *o
 }
 
 void launch_tail(const SweepParams &P, hipStream_t stream, hipEvent_t ev_start, hipEvent_t ev_stop) {
-    if (P.xf.world > 1) hipExtLaunchKernelGGL(tail_kernel_xf, dim3(P.n_traj * P.N), dim3(TL_THREADS), 0, stream, ev_start, ev_stop, 0, P);
-    else hipExtLaunchKernelGGL(tail_kernel, dim3(P.n_traj * P.N), dim3(TL_THREADS), 0, stream, ev_start, ev_stop, 0, P);
+    if (P.xf.world > 1) hipExtLaunchKernelGGL(tail_kernel_xf, dim3(P.n_traj * P.N), dim3(TL_LAUNCH_THREADS), 0, stream, ev_start, ev_stop, 0, P);
+    else hipExtLaunchKernelGGL(tail_kernel, dim3(P.n_traj * P.N), dim3(TL_LAUNCH_THREADS), 0, stream, ev_start, ev_stop, 0, P);
 }
 
 } // namespace isdf

@@ -411,3 +411,67 @@ def test_rows_along_every_axis_and_clipped_tiles(pkg, orc, product_lib, long_axi
         cost, st0 = _check(eng, o, T, cm, f"axis {long_axis} {variant} seed {seed}")
         st = eng.stats()
         assert cost > 0 and st["units"] == st0[0] and st["grad_pairs"] == st0[3] and st["pairs"] == st0[2], (st, st0)
+
+
+def _plan_map(eng, cap):
+    import ctypes as C
+    lib = eng.lib
+    lib.isdf_debug_plan_map.restype = C.c_int
+    lib.isdf_debug_plan_map.argtypes = [C.c_void_p, C.c_void_p, C.c_longlong]
+    m = np.full(cap, -7, dtype=np.int32)
+    k = lib.isdf_debug_plan_map(eng.h, m.ctypes.data_as(C.c_void_p), m.size)
+    return k, m[m != -7]
+
+
+@pytest.mark.parametrize("case", ["long trajectory", "body offset", "batch", "shard"])
+def test_dispatch_order_of_two_launch_steps_is_scheduling_only(pkg, orc, product_lib, case):
+    """Steps that are sweep launch + tail launch (too many workgroups to be resident, a shape that cannot be fused, a batch, a
+    shard) are dispatched, from the fourth step on, in workgroups of like weight, heaviest first (tile_sweep.hip, plan_wave;
+    a batch sorts every trajectory by itself).  Results must be bit for bit those of the plain order, and the order the
+    device built must be a permutation of the launch's samples."""
+    capi, synth = pkg.capi, pkg.synth
+    occ, esdf, res = small_world(pkg)
+    cfg = synth.default_config(capi.V3_ESDF_TILE, kernel_size=9, integral_intervs=16, safety_hor=0.5)
+    K1 = 17
+    shape = synth.make_shape("Box", params=(1.2, 0.4, 0.3), grad_mode=capi.GRAD_CENTRAL)
+    n_traj, N, shard = 1, 200, None
+    if case == "body offset":
+        N = 70
+        shape = synth.make_shape("Box", params=(1.2, 0.4, 0.3), grad_mode=capi.GRAD_CENTRAL, poly_params=(0.1, -0.2, 0.05, 0.3, 0.2, -0.4))
+    elif case == "batch":
+        n_traj, N = 100, 40            # 68 000 samples: more than one sorting group holds -> every trajectory by itself
+    elif case == "shard":
+        N, shard = 600, (1, 3)         # 200 pieces per rank: sweep launch + tail launch
+    trajs = [traj(pkg, occ, res, N=N, seed=60 + b) for b in range(min(n_traj, 3))]
+    Ts = [trajs[b % len(trajs)][0] for b in range(n_traj)]
+    Cs = [trajs[b % len(trajs)][1] for b in range(n_traj)]
+
+    def engine():
+        e = pkg.Engine(cfg); e.set_grid(esdf, (0, 0, 0), res, capi.GRID_ESDF); e.set_shape(shape)
+        if shard:
+            e.set_shard(*shard)
+        return e
+    first = engine().eval(Ts, Cs)                     # first step of a context: plain order
+    if not shard and n_traj == 1:
+        o = orc.Oracle(cfg, threads=4); o.set_grid(esdf, (0, 0, 0), res, capi.GRID_ESDF); o.set_shape(shape)
+        c0, gT0, gC0, _ = o.eval(Ts[0], Cs[0])
+        assert abs(first[0][0] - c0) <= REL_TOL * max(abs(c0), 1e-9)
+        assert_close(first[2][0], gC0, "gradC vs oracle")
+    eng = engine()
+    for step in range(7):
+        got = eng.eval(Ts, Cs)
+        assert np.array_equal(got[0], first[0]), (case, step)
+        for b in range(n_traj):
+            assert np.array_equal(got[1][b], first[1][b]) and np.array_equal(got[2][b], first[2][b]), (case, step, b)
+    k, m = _plan_map(eng, 4 * ((n_traj * N * K1 + 3) // 4) + 64)
+    assert k >= 4, "the plan must be running"
+    live = m[m >= 0]
+    assert live.size > 0 and np.array_equal(np.sort(live), np.arange(live.size)) and np.count_nonzero(m == -1) == m.size - live.size, "not a permutation"
+    if not shard:
+        assert live.size == n_traj * N * K1
+    if case == "batch":       # every trajectory's samples stay inside its own stretch of the order
+        pos = np.empty(live.size, dtype=np.int64)
+        nb = m.size // 4
+        r = np.where(m >= 0)[0]
+        pos[m[r]] = 4 * (r % nb) + r // nb               # rank = wave * nb + workgroup, position = 4 * workgroup + wave
+        assert np.array_equal(pos // (N * K1), np.arange(live.size) // (N * K1))
