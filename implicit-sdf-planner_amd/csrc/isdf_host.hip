@@ -648,6 +648,8 @@ static int eval_device_impl(isdf_ctx *c, int n_traj, int N, const double *d_T, c
                 // resident launch: zones; the exchange inside a fused multi-GPU launch keeps the plain order
                 plan = P.xf.world <= 1 && pb == 0 && pe == total_pieces && ns_local <= PLAN_GROUP_MAX_SAMPLES;
                 zone = c->n_cus;
+            } else if (nb <= sweep_resident_blocks(P, c->n_cus) && ns_local <= PLAN_GROUP_MAX_SAMPLES) {
+                zone = c->n_cus;          // a two-launch step whose sweep is resident anyway (a 50-piece shard): zones as well
             } else if (ns_local > PLAN_GROUP_MAX_SAMPLES) {
                 // a batch: every trajectory is sorted by itself (the shard must hold whole trajectories)
                 group = N;

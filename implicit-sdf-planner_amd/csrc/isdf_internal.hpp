@@ -92,7 +92,8 @@ struct SweepParams {
 // one optimizer step of the integral sweep = sweep, tail, in order, on `stream`
 // ev_start / ev_stop (nullable): HIP events attached to the kernel dispatch itself (hipExtLaunchKernelGGL), i.e. its begin and
 // end timestamps - the same interval rocprofv3 reports for the kernel
-bool sweep_can_fuse(const SweepParams &P);      // small launch, analytic shape with identity body offset: sweep + tail in one launch
+bool sweep_can_fuse(const SweepParams &P);
+int sweep_resident_blocks(const SweepParams &P, int n_cus);      // small launch, analytic shape with identity body offset: sweep + tail in one launch
 void launch_sweep(const SweepParams &P, hipStream_t stream, hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr, bool fused = false);
 void launch_stats(const SweepParams &P, hipStream_t stream);   // on demand, not part of the step
 void launch_build_bits(const DevGrid &G, int use_esdf, float thresh, unsigned *out, hipStream_t stream);

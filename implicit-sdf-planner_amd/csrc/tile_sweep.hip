@@ -1156,6 +1156,13 @@ static int fused_max_blocks() {
     return v;
 }
 
+// Workgroups of a NON-fused sweep launch that are resident at once (its instantiation's waves per SIMD = workgroups per CU)
+int sweep_resident_blocks(const SweepParams &P, int n_cus) {
+    const bool ident = P.shape.d.ident != 0;
+    const int kind = P.shape.kind == ISDF_SHAPE_MESH ? ISDF_SHAPE_MESH : P.shape.kind;
+    return sweep_waves_per_simd(kind, kind == ISDF_SHAPE_MESH ? false : ident) * n_cus;
+}
+
 bool sweep_can_fuse(const SweepParams &P) {
     if (!P.enable_pos || P.shape.kind == ISDF_SHAPE_MESH || P.shape.d.ident == 0) return false;
     const long long n_samples = (long long)(P.piece_end - P.piece_begin) * (P.K + 1);
