@@ -61,7 +61,7 @@ struct isdf_ctx {
     int *d_sample_map = nullptr; size_t sample_map_n = 0;      // developer override of the tile sweep's dispatch order
     // longest-first order of fused single-launch steps: two generations of work classes and of orders, the geometry they belong to
     unsigned char *d_plan_cls = nullptr; int *d_plan_map = nullptr; unsigned short *d_plan_lr = nullptr, *d_plan_hist = nullptr;
-    long long plan_ns = -1, plan_geo = -1; int plan_nb = -1; int plan_k = 0; int n_cus = 0; size_t plan_ns_cap = 0, plan_np_cap = 0;
+    long long plan_ns = -1, plan_geo = -1; int plan_nb = -1; int plan_k = 0; int plan_cur = 0; int n_cus = 0; size_t plan_ns_cap = 0, plan_np_cap = 0;
     unsigned long long *d_dbg = nullptr; size_t dbg_cap = 0; size_t dbg_used = 0;   // ISDF_DEBUG_TIMING=1 (developer tool)
     // full objective callback (costFunctionLmbm): MINCO on the host, sweeps on the device
     isdf_host::MincoS3 minco; bool have_traj = false; double rho = 0.0;

@@ -665,7 +665,7 @@ static int eval_device_impl(isdf_ctx *c, int n_traj, int N, const double *d_T, c
                 HIPCHK(c, hipStreamSynchronize(st));
                 for (void *q : {(void *)c->d_plan_cls, (void *)c->d_plan_map, (void *)c->d_plan_lr, (void *)c->d_plan_hist}) if (q) (void)hipFree(q);
                 c->d_plan_cls = nullptr; c->d_plan_map = nullptr; c->d_plan_lr = nullptr; c->d_plan_hist = nullptr;
-                c->plan_ns_cap = c->plan_np_cap = 0; c->plan_k = 0;
+                c->plan_ns_cap = c->plan_np_cap = 0; c->plan_k = 0; c->plan_cur = 0;
                 const size_t nsc = std::max(ns_cap, (size_t)4096), npc = std::max(np_cap, (size_t)256);
                 HIPCHK(c, hipMalloc(&c->d_plan_cls, 2 * nsc));
                 HIPCHK(c, hipMalloc(&c->d_plan_map, 2 * nsc * sizeof(int)));
@@ -676,24 +676,20 @@ static int eval_device_impl(isdf_ctx *c, int n_traj, int N, const double *d_T, c
             // the records of earlier steps are laid out by piece: they only carry over to a launch of the same geometry
             const long long geo = ((long long)n_loc << 32) | ((long long)K1 << 20) | ((long long)(fused ? 1 : 0) << 19) | (long long)(group & 0x7FFFF);
             if (c->plan_ns != ns_local || c->plan_nb != nb || c->plan_geo != geo) { c->plan_k = 0; c->plan_ns = ns_local; c->plan_nb = nb; c->plan_geo = geo; }
-            // step k: the sweep leaves generation k's classes; the tail workgroups turn generation k - 1's classes into records,
-            // generation k - 2's records into the order of step k + 1; the launch itself runs in the order made in step k - 1
-            const int k = c->plan_k, par = k & 1;
-            const size_t nsc = c->plan_ns_cap, hc = c->plan_np_cap * PLAN_CLASSES;
+            // The order is rebuilt once per cycle of PLAN_CYCLE steps (the trajectory moves little between optimizer steps, and
+            // building costs the step 0.4 us): step 0 of a cycle - the sweep leaves the classes; step 1 - the tail workgroups
+            // turn them into records; step 2 - into the order, written into the buffer NOT in use; from step 3 on the launches
+            // run in it.  Single copies of classes / records suffice: each is written in one step and read in the next.
+            constexpr int PLAN_CYCLE = 8;
+            const int k = c->plan_k, ph = k % PLAN_CYCLE;
+            const size_t nsc = c->plan_ns_cap;
             P.plan_zone = zone;
             P.plan_group = (int)group;
-            P.plan_cls_out = c->d_plan_cls + (size_t)par * nsc;
-            if (k >= 1) {
-                P.plan_cls_in = c->d_plan_cls + (size_t)(1 - par) * nsc;
-                P.plan_lr_out = c->d_plan_lr + (size_t)(1 - par) * nsc;
-                P.plan_hist_out = c->d_plan_hist + (size_t)(1 - par) * hc;
-            }
-            if (k >= 2) {
-                P.plan_lr_in = c->d_plan_lr + (size_t)par * nsc;
-                P.plan_hist_in = c->d_plan_hist + (size_t)par * hc;
-                P.plan_map_out = c->d_plan_map + (size_t)(1 - par) * nsc;
-            }
-            if (k >= 3) P.sample_map = c->d_plan_map + (size_t)par * nsc;
+            if (ph == 0) P.plan_cls_out = c->d_plan_cls;
+            if (ph == 1) { P.plan_cls_in = c->d_plan_cls; P.plan_lr_out = c->d_plan_lr; P.plan_hist_out = c->d_plan_hist; }
+            if (ph == 2) { P.plan_lr_in = c->d_plan_lr; P.plan_hist_in = c->d_plan_hist; P.plan_map_out = c->d_plan_map + (size_t)(1 - c->plan_cur) * nsc; }
+            if (ph == 3) c->plan_cur = 1 - c->plan_cur;          // the order written by the previous step is complete
+            if (k >= 3) P.sample_map = c->d_plan_map + (size_t)c->plan_cur * nsc;
             if (c->plan_k < (1 << 30)) c->plan_k++;
         }
     }
@@ -1289,11 +1285,11 @@ extern "C" int isdf_debug_set_sample_map(isdf_ctx *c, const int *map, long long 
 // developer tool (not declared in the ABI header): the longest-first dispatch order the NEXT fused step would use
 // (4 * workgroups entries, -1 = none); returns the number of consecutive steps the plan has been running, 0 = inactive
 extern "C" int isdf_debug_plan_map(isdf_ctx *c, int *out, long long cap) {
-    if (!c || c->plan_k < 3 || !c->d_plan_map) return 0;
+    if (!c || c->plan_k < 4 || !c->d_plan_map) return 0;
     (void)hipSetDevice(c->device);
     (void)hipDeviceSynchronize();
     const long long n = 4LL * c->plan_nb < cap ? 4LL * c->plan_nb : cap;
-    if (out && n > 0) (void)hipMemcpy(out, c->d_plan_map + (size_t)(c->plan_k & 1) * c->plan_ns_cap, (size_t)n * sizeof(int), hipMemcpyDeviceToHost);
+    if (out && n > 0) (void)hipMemcpy(out, c->d_plan_map + (size_t)c->plan_cur * c->plan_ns_cap, (size_t)n * sizeof(int), hipMemcpyDeviceToHost);
     return c->plan_k;
 }
 

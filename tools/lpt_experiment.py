@@ -203,6 +203,29 @@ def main():
                 holes = np.where(m[:ns] < 0)[0]; extra = np.where(m[ns:] >= 0)[0] + ns
                 m[holes] = m[extra]; m[extra] = -1
             run(f"per-CU model, weight {fixed} + {key_name}", m)
+    # like weights per workgroup inside the zones (what the two-launch steps use), against the strided zones of the product
+    key = np.minimum((cand + 31) // 32, 7)
+    st_sorted = np.argsort(-key, kind="stable")
+    def grouped(ids, b0, sz):
+        """ids -> workgroups b0 .. b0+sz-1, four neighbours each"""
+        out = {}
+        for q, sidx_ in enumerate(ids):
+            out[(q % 4) * nb + b0 + q // 4] = sidx_
+        return out
+    for label, z0_grouped, rest_grouped in (("zone 0 strided, rest grouped", False, True), ("zone 0 grouped, rest strided", True, False), ("both grouped", True, True)):
+        m = np.full(4 * nb, -1, dtype=np.int64)
+        z0 = st_sorted[:1024]; rest = st_sorted[1024:]
+        if z0_grouped:
+            for r, v in grouped(z0, 0, 256).items(): m[r] = v
+        else:
+            for w in range(4): m[w * nb: w * nb + 256] = z0[w * 256:(w + 1) * 256]
+        n3 = nb - 256
+        if rest_grouped:
+            for r, v in grouped(rest, 256, n3).items(): m[r] = v
+        else:
+            for w in range(4):
+                seg = rest[w * n3:(w + 1) * n3]; m[w * nb + 256: w * nb + 256 + seg.size] = seg
+        run(label, m)
     # random order as a control
     rng = np.random.default_rng(1)
     m = rng.permutation(ns).astype(np.int32)
