@@ -112,7 +112,7 @@ def load_library(path=None):
     global _lib
     if _lib is not None and path is None:
         return _lib
-    p = path or LIB_PATH
+    p = path or os.environ.get("ISDF_ACCEL_LIB") or LIB_PATH      # ISDF_ACCEL_LIB: developer A/B of two builds on one box
     if not os.path.exists(p):
         raise RuntimeError(f"{p} not found: build the HIP extension first (python -c 'import __graft_entry__ as g; g.build()'). "
                            "There is no CPU fallback for the product path.")
