@@ -494,7 +494,9 @@ __global__ __launch_bounds__(64 * SW_SAMPLES, FUSED ? 3 : sweep_waves_per_simd(K
         int sa_w = 2;
         if (windowed) {
             const int e0 = w1[0] - w0[0], e1 = w1[1] - w0[1], e2 = w1[2] - w0[2];
-            sa_w = (e2 >= e0 && e2 >= e1) ? 2 : (e0 >= e1 ? 0 : 1);
+            // (the mesh kind keeps z: measured 231 -> 217 us per step with 20 faces, 16.4 -> 14.4 ms with 4 992 - its hierarchy walks
+            // are more coherent over voxels that follow each other along z)
+            if (KIND != ISDF_SHAPE_MESH) sa_w = (e2 >= e0 && e2 >= e1) ? 2 : (e0 >= e1 ? 0 : 1);
         }
         // (u, v): the axes other than sa, ascending
         const int u0 = sa_w == 0 ? w0[1] : w0[0], u1 = sa_w == 0 ? w1[1] : w1[0];
