@@ -792,7 +792,9 @@ __global__ __launch_bounds__(64 * SW_SAMPLES, FUSED ? 3 : sweep_waves_per_simd(K
                 const d3 ctr = mk3((gx + 0.5) * G.res + G.bmin[0], (gy + 0.5) * G.res + G.bmin[1], (gz + 0.5) * G.res + G.bmin[2]);
                 const d3 pm = ctr - pos;
                 const d3 prel = mat_tmul(R, pm);
-                if (!(fabs(prel.x) > P.bd_half || fabs(prel.y) > P.bd_half || fabs(prel.z) > P.bd_half)) {
+                // the cube cull (:800-803) as ONE test: three short-circuit comparisons compile to three nested masked regions, each
+                // re-creating the eight result registers (fmax drops a NaN like the comparisons it replaces treat it: inside)
+                if (!(fmax(fmax(fabs(prel.x), fabs(prel.y)), fabs(prel.z)) > P.bd_half)) {
                     is_pair = true;
                     double f = 0.0, df = 0.0;
                     d3 g = mk3(0, 0, 0);
