@@ -608,19 +608,55 @@ __global__ __launch_bounds__(64 * SW_SAMPLES, FUSED ? 3 : sweep_waves_per_simd(K
         dzv[a] = Rw[a] * resf;
         dzi[a] = 1.0f / dzv[a];
     }
+    // RoundedCone (Shape.hpp:1018-1029; axis z, sphere r1 at the origin, r2 at z = h): inflated by the band it is still a rounded
+    // cone, and it lies inside the cone that is tangent to both spheres, rho <= A - B z with B = b / a, A = (r1 + band) / a,
+    // b = (r1 - r2) / h, a = sqrt(1 - b^2).  A row's part inside that cone is one more interval (a quadratic in the row
+    // coordinate), much tighter than the bounding box around the thin end: 141 -> ~70 listed voxels per sample.  Conservative
+    // like the box test (the band carries the filter's 2 mm; a negative discriminant of a row that really touches would need
+    // rounding errors a thousand times larger); only where the row is flatter than the cone (alpha > 0: the inside is BETWEEN
+    // the roots).
+    float cone_A = 0.0f, cone_B = 0.0f, cone_alpha = 0.0f, cone_ia = 0.0f;
+    bool cone_on = false;
+    if constexpr (KIND == ISDF_SHAPE_ROUNDEDCONE && IDENT) {
+        const float r1 = P.shape.f.p[0], r2 = P.shape.f.p[1], hh = P.shape.f.p[2];
+        const float b = (r1 - r2) / hh, a2 = 1.0f - b * b;
+        if (prune && hh > 0.0f && a2 > 1.0e-3f) {
+            const float ia = 1.0f / sqrtf(a2);
+            cone_A = (r1 + thr_f) * ia; cone_B = b * ia;
+            cone_alpha = dzv[0] * dzv[0] + dzv[1] * dzv[1] - cone_B * cone_B * dzv[2] * dzv[2];
+            cone_on = cone_alpha > 1.0e-3f * (dzv[0] * dzv[0] + dzv[1] * dzv[1] + dzv[2] * dzv[2]);
+            cone_ia = 1.0f / cone_alpha;
+        }
+    }
     auto row_mask = [&](unsigned pk, int zb) -> unsigned {
         const float mx = fmaf((float)((pk >> sh_u) & 1023u), resf, -pv_u), my = fmaf((float)((pk >> sh_v) & 1023u), resf, -pv_v);
         float tmin = -1.0e30f, tmax = 1.0e30f;
         bool empty = false;
+        float ob[3];
 #pragma unroll
         for (int a = 0; a < 3; a++) {
             const float o = Ru[a] * mx + Rv[a] * my - Rw[a] * pv_w;
+            ob[a] = o;
             if (fabsf(dzv[a]) > 1.0e-12f) {
                 const float t1 = (blo[a] - o) * dzi[a], t2 = (bhi[a] - o) * dzi[a];
                 tmin = fmaxf(tmin, fminf(t1, t2));      // fmaxf/fminf drop NaNs: never tightens on garbage
                 tmax = fminf(tmax, fmaxf(t1, t2));
             } else {
                 empty = empty | (o < blo[a] - 1.0e-3f) | (o > bhi[a] + 1.0e-3f);
+            }
+        }
+        if constexpr (KIND == ISDF_SHAPE_ROUNDEDCONE && IDENT) {
+            if (cone_on) {
+                const float e = cone_A - cone_B * ob[2];
+                const float beta = ob[0] * dzv[0] + ob[1] * dzv[1] + cone_B * dzv[2] * e;
+                const float gamma = ob[0] * ob[0] + ob[1] * ob[1] - e * e;
+                const float disc = beta * beta - cone_alpha * gamma;
+                if (disc < 0.0f) empty = true;           // (a NaN fails the comparison: the row stays)
+                else {
+                    const float sq = sqrtf(disc);
+                    tmin = fmaxf(tmin, (-beta - sq) * cone_ia);
+                    tmax = fminf(tmax, (-beta + sq) * cone_ia);
+                }
             }
         }
         const float off = (float)(zb << 5);
