@@ -31,7 +31,9 @@ template <typename T> __device__ __forceinline__ T dot3(v3<T> a, v3<T> b) { retu
 // arithmetic, hence the same bits, for arguments in the normal range - which sums of squares of metre-scale lengths are -
 // and 0 -> 0.  10 instructions instead of 18.
 __device__ __forceinline__ double m_sqrt(double x) {
-    const double y = __builtin_amdgcn_rsq(x);
+    // the reciprocal root of max(|x|, DBL_MIN) (one instruction, |.| is an operand modifier) instead of a compare and two
+    // selects behind the sequence: x = 0 gives 0 * finite = 0 through every step, a NaN stays a NaN, x > 0 is untouched
+    const double y = __builtin_amdgcn_rsq(fmax(fabs(x), 2.2250738585072014e-308));
     double g = x * y, h = 0.5 * y;
     const double r = fma(-h, g, 0.5);
     g = fma(g, r, g);
@@ -40,7 +42,7 @@ __device__ __forceinline__ double m_sqrt(double x) {
     g = fma(d, h, g);
     d = fma(-g, g, x);
     g = fma(d, h, g);
-    return x > 0.0 ? g : x;
+    return g;
 }
 // 1 / x for the shared-divisor quotients below: rcp + two Newton steps (<= 1 ulp, normal range; 5 instructions instead of
 // the 11 of the correctly-rounded division with its scaling and fix-up).
