@@ -139,32 +139,20 @@ __device__ __forceinline__ bool smoothed_l1(double x, double mu, double &f, doub
 
 // g^T * dR^T/dq_k * d for k = w,x,y,z (the four matrices of back_end_optimizer.hpp:127-173, multiplied out)
 __device__ __forceinline__ d4 quat_step_grad(d4 q, d3 g, d3 d) {
-    const double w = q.w, x = q.x, y = q.y, z = q.z;
+    // With u = (x, y, z), c = g x d the four products g^T (dR^T/dq_k) d of back_end_optimizer.hpp:127-173 are
+    //   k = w:      2 u.c
+    //   k = x,y,z:  -4 (g.d) u + 2 (u.d) g + 2 (u.g) d + 2 w c
+    // (term by term the same monomials as the matrices multiplied out; 33 operations instead of 45, rounding-level differences)
+    const d3 c = mk3(g.y * d.z - g.z * d.y, g.z * d.x - g.x * d.z, g.x * d.y - g.y * d.x);
+    const double gd = g.x * d.x + g.y * d.y + g.z * d.z;
+    const double ud = q.x * d.x + q.y * d.y + q.z * d.z;
+    const double ug = q.x * g.x + q.y * g.y + q.z * g.z;
+    const double A = -4.0 * gd, B = 2.0 * ud, C = 2.0 * ug, W = 2.0 * q.w;
     d4 r;
-    {   // DW = [0 2z -2y; -2z 0 2x; 2y -2x 0];  (g^T DW) = columns
-        const double c0 = g.y * (-2 * z) + g.z * (2 * y);
-        const double c1 = g.x * (2 * z) + g.z * (-2 * x);
-        const double c2 = g.x * (-2 * y) + g.y * (2 * x);
-        r.w = c0 * d.x + c1 * d.y + c2 * d.z;
-    }
-    {   // DX = [0 2y 2z; 2y -4x 2w; 2z -2w -4x]
-        const double c0 = g.y * (2 * y) + g.z * (2 * z);
-        const double c1 = g.x * (2 * y) + g.y * (-4 * x) + g.z * (-2 * w);
-        const double c2 = g.x * (2 * z) + g.y * (2 * w) + g.z * (-4 * x);
-        r.x = c0 * d.x + c1 * d.y + c2 * d.z;
-    }
-    {   // DY = [-4y 2x -2w; 2x 0 2z; 2w 2z -4y]
-        const double c0 = g.x * (-4 * y) + g.y * (2 * x) + g.z * (2 * w);
-        const double c1 = g.x * (2 * x) + g.z * (2 * z);
-        const double c2 = g.x * (-2 * w) + g.y * (2 * z) + g.z * (-4 * y);
-        r.y = c0 * d.x + c1 * d.y + c2 * d.z;
-    }
-    {   // DZ = [-4z 2w 2x; -2w -4z 2y; 2x 2y 0]
-        const double c0 = g.x * (-4 * z) + g.y * (-2 * w) + g.z * (2 * x);
-        const double c1 = g.x * (2 * w) + g.y * (-4 * z) + g.z * (2 * y);
-        const double c2 = g.x * (2 * x) + g.y * (2 * y);
-        r.z = c0 * d.x + c1 * d.y + c2 * d.z;
-    }
+    r.w = 2.0 * (q.x * c.x + q.y * c.y + q.z * c.z);
+    r.x = A * q.x + B * g.x + C * d.x + W * c.x;
+    r.y = A * q.y + B * g.y + C * d.y + W * c.y;
+    r.z = A * q.z + B * g.z + C * d.z + W * c.z;
     return r;
 }
 
