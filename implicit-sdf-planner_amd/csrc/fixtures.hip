@@ -66,7 +66,8 @@ extern "C" long long isdf_read_pcd(const char *path, float *xyz_out, long long c
     FILE *f = std::fopen(path, "rb");
     if (!f) return ISDF_ERR_INVALID_ARG;
     char line[4096];
-    int ix = -1, iy = -1, iz = -1, n_fields = 0;
+    int ix = -1, iy = -1, iz = -1, n_fields = 0;      // ix / iy / iz: FIELD positions first, token columns after the header
+    std::vector<int> counts;                          // COUNT line (pcl: elements per field; absent = all 1)
     long long points = -1;
     bool ascii = false, have_data = false;
     while (std::fgets(line, sizeof(line), f)) {
@@ -81,6 +82,9 @@ extern "C" long long isdf_read_pcd(const char *path, float *xyz_out, long long c
                 k++;
             }
             n_fields = k;
+        } else if (!std::strcmp(key, "COUNT")) {
+            char *save = nullptr, *tok = strtok_r(line, " \t\r\n", &save);
+            while ((tok = strtok_r(nullptr, " \t\r\n", &save))) counts.push_back(std::atoi(tok));
         } else if (!std::strcmp(key, "POINTS")) {
             std::sscanf(line, "%*s %lld", &points);
         } else if (!std::strcmp(key, "DATA")) {
@@ -93,6 +97,17 @@ extern "C" long long isdf_read_pcd(const char *path, float *xyz_out, long long c
     }
     if (!have_data || ix < 0 || iy < 0 || iz < 0) { std::fclose(f); return ISDF_ERR_INVALID_ARG; }
     if (!ascii) { std::fclose(f); return ISDF_ERR_UNSUPPORTED; }      // the shipped maps are DATA ascii
+    // a field with COUNT c occupies c tokens of a data line (pcl's ascii reader walks fields x counts): x / y / z themselves
+    // must be single values, the columns after a wider field shift accordingly
+    if (!counts.empty()) {
+        if ((int)counts.size() != n_fields) { std::fclose(f); return ISDF_ERR_INVALID_ARG; }
+        std::vector<int> col(n_fields, 0);
+        int c0 = 0;
+        for (int k = 0; k < n_fields; k++) { if (counts[k] < 1) { std::fclose(f); return ISDF_ERR_INVALID_ARG; } col[k] = c0; c0 += counts[k]; }
+        if (counts[ix] != 1 || counts[iy] != 1 || counts[iz] != 1) { std::fclose(f); return ISDF_ERR_UNSUPPORTED; }
+        ix = col[ix]; iy = col[iy]; iz = col[iz];
+        n_fields = c0;
+    }
     long long n = 0;
     while (std::fgets(line, sizeof(line), f)) {
         float v[3] = {0, 0, 0};

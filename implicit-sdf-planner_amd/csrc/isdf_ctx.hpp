@@ -54,6 +54,11 @@ struct isdf_ctx {
     double *d_hist = nullptr; size_t hist_cap = 0;
     // profiling
     bool fuse_small = true;     // developer switch ISDF_NO_FUSE=1: always sweep + tail as two launches
+    // developer / fallback switches, ALL read once per ctx in isdf_create (so a process can hold ctxs of either kind):
+    // ISDF_NO_HOST_DIRECT=1 (isdf_eval and the callback take the copy path), ISDF_NO_BAR_WRITES=1 (host-direct steps fetch their
+    // inputs from host-mapped memory instead of receiving them through the PCIe BAR), ISDF_NO_LPT=1 (plain dispatch order)
+    bool env_no_direct = false, env_no_bar = false, env_no_lpt = false;
+    int last_host_path = 0;     // isdf_host_path(): how the last host-array step crossed PCIe
     bool prof_on = false, prof_secondary = false; int prof_every = 1; long long prof_tick = 0;
     std::vector<ProfEvent> prof_events;
     size_t prof_used = 0;

@@ -130,6 +130,13 @@ extern "C" int isdf_create(isdf_ctx **out, const isdf_config *cfg) {
     if (!c) return fail(nullptr, ISDF_ERR_HIP, "out of host memory");
     c->cfg = *cfg;
     c->device = cfg->device;
+    {   // every environment switch of the host paths is read HERE, once per ctx
+        auto on = [](const char *name) { const char *e = getenv(name); return e && e[0] == '1'; };
+        c->fuse_small = !on("ISDF_NO_FUSE");
+        c->env_no_direct = on("ISDF_NO_HOST_DIRECT");
+        c->env_no_bar = on("ISDF_NO_BAR_WRITES");
+        c->env_no_lpt = on("ISDF_NO_LPT");
+    }
     if (hipSetDevice(c->device) != hipSuccess || hipMalloc(&c->d_stats, 8 * sizeof(unsigned long long)) != hipSuccess ||
         hipMalloc(&c->d_traj_duration, sizeof(double)) != hipSuccess || hipMalloc(&c->d_n_coarse, sizeof(int)) != hipSuccess ||
         hipMemset(c->d_traj_duration, 0, sizeof(double)) != hipSuccess || hipMemset(c->d_stats, 0, 8 * sizeof(unsigned long long)) != hipSuccess || hipStreamCreate(&c->stream) != hipSuccess) {
@@ -560,14 +567,13 @@ static int eval_device_impl(isdf_ctx *c, int n_traj, int N, const double *d_T, c
     P.occ_thresh = (float)cfg.occ_thresh;
     P.cull_threshold = 0.0;
     if (cfg.variant == ISDF_V3_ESDF_TILE && cfg.enable_cull && c->shape.bound_radius > 0)
-        P.cull_threshold = c->shape.bound_radius + cfg.safety_hor + std::sqrt(3.0) * P.grid.res;
+        P.cull_threshold = c->shape.bound_radius + cfg.safety_hor + std::sqrt(3.0) * P.grid.res + (cfg.occ_thresh > 0 ? cfg.occ_thresh : 0.0);   // a qualifying voxel lies within occ_thresh of an occupied one
     P.T = d_T; P.coeffs = d_coeffs; P.acc = c->d_acc; P.sample_info = c->d_sample_info; P.piece_cost = c->d_piece_cost;
     P.out = d_out; P.stats = c->d_stats;
     P.dbg = nullptr;
     P.sample_map = (c->d_sample_map && c->sample_map_n == 4 * (((size_t)(pe - pb) * (cfg.integral_intervs + 1) + 3) / 4)) ? c->d_sample_map : nullptr;
     P.dbg_flags = 0;
     if (const char *e = getenv("ISDF_DEBUG_FLAGS")) P.dbg_flags = atoi(e);
-    if (const char *e = getenv("ISDF_NO_FUSE")) c->fuse_small = e[0] != '1';
     if (const char *e = getenv("ISDF_DEBUG_TIMING")) if (e[0] == '1') {
         const size_t need = n_samples * 8 + (size_t)total_pieces * 4 + 4;
         if (c->dbg_cap < need) {
@@ -592,8 +598,8 @@ static int eval_device_impl(isdf_ctx *c, int n_traj, int N, const double *d_T, c
         }
         c->grid.ZW = zw; c->grid.XW = xw; c->grid.YW = yw;
         c->grid.bits = c->d_bits; c->grid.bits_x = c->d_bits + nwz; c->grid.bits_y = c->d_bits + nwz + nwx;
-        launch_build_bits(c->grid, cfg.variant == ISDF_V3_ESDF_TILE ? 1 : 0, (float)cfg.occ_thresh, c->d_bits, st);
-        launch_build_bits_xy(c->grid, cfg.variant == ISDF_V3_ESDF_TILE ? 1 : 0, (float)cfg.occ_thresh, c->d_bits + nwz, c->d_bits + nwz + nwx, st);
+        launch_build_bits(c->grid, cfg.variant == ISDF_V3_ESDF_TILE ? 1 : 0, cfg.occ_thresh, c->d_bits, st);
+        launch_build_bits_xy(c->grid, cfg.variant == ISDF_V3_ESDF_TILE ? 1 : 0, cfg.occ_thresh, c->d_bits + nwz, c->d_bits + nwz + nwx, st);
         c->bits_dirty = false;
         P.grid = c->grid;
     }
@@ -639,7 +645,7 @@ static int eval_device_impl(isdf_ctx *c, int n_traj, int N, const double *d_T, c
         const int nb = (int)((ns_local + 3) / 4);
         P.n_sweep_blocks = nb;                  // (launch_sweep sets it again for its own copy; the tail launch needs it for the order it writes)
         if (c->n_cus == 0) { hipDeviceProp_t pr; c->n_cus = (hipGetDeviceProperties(&pr, c->device) == hipSuccess && pr.multiProcessorCount > 0) ? pr.multiProcessorCount : 256; }
-        static const bool no_plan = [] { const char *e = getenv("ISDF_NO_LPT"); return e && e[0] == '1'; }();
+        const bool no_plan = c->env_no_lpt;
         // (not for the mesh kind: the cost of a mesh sample is its hierarchy walks, which the pair count does not predict -
         // measured 230 -> 256 us per step with the order on, 20-face mesh)
         bool plan = cfg.enable_pos && !no_plan && !P.sample_map && K1 <= 128 && nb > c->n_cus && ns_local < (1LL << 28) && c->shape.kind != ISDF_SHAPE_MESH;
@@ -772,8 +778,7 @@ static int ensure_eval_pin(isdf_ctx *c, size_t doubles) {
 
 // ---- host-direct steps -----------------------------------------------------------------------------------------------
 static bool direct_enabled(const isdf_ctx *c) {
-    static const bool off = [] { const char *e = getenv("ISDF_NO_HOST_DIRECT"); return e && e[0] == '1'; }();
-    return !off && !c->prof_on && c->world == 1 && c->cfg.variant != ISDF_V1_SWEPT && c->cfg.enable_pos;
+    return !c->env_no_direct && !c->prof_on && c->world == 1 && c->cfg.variant != ISDF_V1_SWEPT && c->cfg.enable_pos;
 }
 // pinned, device-mapped [inputs 19 n nb | outputs (1 + 19 n) nb | nb flags]
 static int direct_reserve(isdf_ctx *c, int nb, int n) {
@@ -789,25 +794,51 @@ static int direct_reserve(isdf_ctx *c, int nb, int n) {
     c->dir_in = in; c->dir_out = out; c->dir_flags = (size_t)nb;
     return ISDF_OK;
 }
-// Can the host write device memory directly (large PCIe BAR)?  Verified once per ctx: a pattern written by the CPU into a
-// device buffer must come back through hipMemcpy.  Writes only - host READS over the BAR cost ~1 us per access.
+// Can the host write device memory directly (large PCIe BAR)?  Verified once per ctx THE WAY THE STEPS USE IT: a kernel reads
+// the buffer (its lines may now sit in an L2) and raises a host-mapped flag; the host, which waited for nothing but that flag,
+// overwrites the buffer through the BAR and launches the kernel again without any host-side synchronisation in between; the
+// second launch must see the second pattern (and the first launch the first).  Writes only - host READS over the BAR cost
+// ~1 us per access.
+__global__ void bar_probe_kernel(const double *buf, int m, double *copy, volatile unsigned long long *host_flag, unsigned long long seq) {
+    for (int i = threadIdx.x; i < m; i += blockDim.x) copy[i] = buf[i];
+    __syncthreads();
+    if (threadIdx.x == 0) { __threadfence_system(); *host_flag = seq; }
+}
 static bool bar_usable(isdf_ctx *c, double *d_buf, size_t n) {
     if (c->bar_state != 0) return c->bar_state > 0;
     c->bar_state = -1;
-    if (getenv("ISDF_NO_BAR_WRITES") && getenv("ISDF_NO_BAR_WRITES")[0] == '1') return false;
+    if (c->env_no_bar) return false;
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, c->device) != hipSuccess || !prop.isLargeBar) return false;
     hipPointerAttribute_t at;
     if (hipPointerGetAttributes(&at, d_buf) != hipSuccess) { (void)hipGetLastError(); return false; }
-    const size_t m = n < 64 ? n : 64;
-    std::vector<double> pat(m), back(m, 0.0);
-    for (size_t i = 0; i < m; i++) pat[i] = 1.0 + (double)i * 0.5;
-    std::memcpy(d_buf, pat.data(), m * sizeof(double));          // CPU stores into device memory
-    __sync_synchronize();
-    if (hipMemcpy(back.data(), d_buf, m * sizeof(double), hipMemcpyDeviceToHost) != hipSuccess) { (void)hipGetLastError(); return false; }
-    if (std::memcmp(pat.data(), back.data(), m * sizeof(double)) != 0) return false;
-    c->bar_state = 1;
-    return true;
+    const int m = (int)(n < 64 ? n : 64);
+    double *d_copy = nullptr;
+    unsigned long long *h_flag = nullptr, *h_flag_dev = nullptr;
+    bool ok = hipMalloc(&d_copy, 2 * 64 * sizeof(double)) == hipSuccess &&
+              hipHostMalloc((void **)&h_flag, 64, hipHostMallocDefault) == hipSuccess &&
+              hipHostGetDevicePointer((void **)&h_flag_dev, h_flag, 0) == hipSuccess;
+    std::vector<double> pat(2 * (size_t)m), back(2 * (size_t)m, 0.0);
+    for (int i = 0; i < m; i++) { pat[i] = 1.0 + (double)i * 0.5; pat[m + i] = -3.0 - (double)i * 0.25; }
+    for (int round = 0; ok && round < 2; round++) {
+        *(volatile unsigned long long *)h_flag = 0ull;
+        std::memcpy(d_buf, pat.data() + (size_t)round * m, (size_t)m * sizeof(double));          // CPU stores into device memory
+        __sync_synchronize();
+        hipLaunchKernelGGL(bar_probe_kernel, dim3(1), dim3(64), 0, c->stream, d_buf, m, d_copy + (size_t)round * 64, h_flag_dev, (unsigned long long)(round + 1));
+        ok = hipGetLastError() == hipSuccess;
+        const auto t0 = std::chrono::steady_clock::now();
+        while (ok && *(volatile unsigned long long *)h_flag != (unsigned long long)(round + 1))       // the steps' own hand-over: no stream sync
+            if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > 2.0) ok = false;
+    }
+    if (ok) ok = hipMemcpy(back.data(), d_copy, (size_t)m * sizeof(double), hipMemcpyDeviceToHost) == hipSuccess &&
+                 hipMemcpy(back.data() + m, d_copy + 64, (size_t)m * sizeof(double), hipMemcpyDeviceToHost) == hipSuccess &&
+                 std::memcmp(pat.data(), back.data(), 2 * (size_t)m * sizeof(double)) == 0;
+    (void)hipStreamSynchronize(c->stream);
+    (void)hipGetLastError();
+    if (d_copy) (void)hipFree(d_copy);
+    if (h_flag) (void)hipHostFree(h_flag);
+    if (ok) c->bar_state = 1;
+    return ok;
 }
 // Places the inputs of nb trajectories of n pieces for a host-direct step and launches it.  ISDF_DIRECT_NA: not applicable
 // (the step is not one fused launch), nothing launched.  T / coeffs: per-trajectory host arrays (trajectory `first` onwards).
@@ -832,7 +863,7 @@ static int direct_launch(isdf_ctx *c, int nb, int n, const double *const *T, con
     hd.flags = (unsigned long long *)(c->h_dir_dev + c->dir_in + c->dir_out);
     hd.seq = ++c->dir_seq;
     rc = eval_device_impl(c, nb, n, c->d_in, c->d_in + (size_t)n * nb, hd.out, nullptr, st, mode, false, &hd);
-    if (rc == ISDF_OK) { c->dir_pending = true; c->dir_nb = nb; c->dir_n = n; }
+    if (rc == ISDF_OK) { c->dir_pending = true; c->dir_nb = nb; c->dir_n = n; c->last_host_path = hd.via_bar ? ISDF_HOST_PATH_DIRECT_BAR : ISDF_HOST_PATH_DIRECT_MAPPED; }
     return rc;
 }
 // the host's side of the hand-over: spin on the trajectories' flags (the launch stores them last); bounded - a launch that
@@ -858,6 +889,8 @@ static int direct_wait(isdf_ctx *c, hipStream_t st, bool *overflow) {
     std::atomic_thread_fence(std::memory_order_acquire);
     return ISDF_OK;
 }
+
+extern "C" int isdf_host_path(const isdf_ctx *c) { return c ? c->last_host_path : ISDF_ERR_INVALID_ARG; }
 
 extern "C" int isdf_eval(isdf_ctx *c, int n_traj, const int *N, const double *const *T, const double *const *coeffs,
                          double *cost_inout, double *const *gradT_inout, double *const *gradC_inout, double *tstar_inout) {
@@ -916,6 +949,7 @@ extern "C" int isdf_eval(isdf_ctx *c, int n_traj, const int *N, const double *co
             }
             // ISDF_DIRECT_NA: this step is not one fused launch - the copy path below
         }
+        c->last_host_path = ISDF_HOST_PATH_COPY;
         int rc = ensure(c, &c->d_in, &c->in_cap, in_all);
         if (rc) return rc;
         rc = ensure(c, &c->d_out, &c->out_cap, out_all);
@@ -1046,6 +1080,7 @@ static int cost_function_launch(isdf_ctx *c, const double *x, int n, hipStream_t
         if (rcd < 0) return rcd;
         if (rcd == ISDF_OK) { c->cb_direct = true; c->cb_pending = true; return ISDF_OK; }
     }
+    c->last_host_path = ISDF_HOST_PATH_COPY;
     const size_t need = in_len + c->cb_n_out * ostride;
     if (c->pin_cap < need) {
         if (c->h_pin) (void)hipHostFree(c->h_pin);

@@ -54,7 +54,7 @@ struct SweepParams {
     double vel_sqr_max, omg_sqr_max, theta_max, mu, inv_mu;
     int n_sweep_blocks;         // set by launch_sweep: sweep workgroups of the launch (a fused launch appends one tail workgroup per piece)
     double inv_K;               // 1.0 / K formed on the host (the reference's integralFrac, correctly rounded)
-    float occ_thresh;
+    float occ_thresh;           // (informational; the qualifier bit-grid is built with the double)
     double cull_threshold;      // <= 0: cull disabled
     const double *T;            // n_traj * N
     const double *coeffs;       // n_traj * (6N x 3 col-major)
@@ -96,8 +96,8 @@ bool sweep_can_fuse(const SweepParams &P);
 int sweep_resident_blocks(const SweepParams &P, int n_cus);      // small launch, analytic shape with identity body offset: sweep + tail in one launch
 void launch_sweep(const SweepParams &P, hipStream_t stream, hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr, bool fused = false);
 void launch_stats(const SweepParams &P, hipStream_t stream);   // on demand, not part of the step
-void launch_build_bits(const DevGrid &G, int use_esdf, float thresh, unsigned *out, hipStream_t stream);
-void launch_build_bits_xy(const DevGrid &G, int use_esdf, float thresh, unsigned *out_x, unsigned *out_y, hipStream_t stream);
+void launch_build_bits(const DevGrid &G, int use_esdf, double thresh, unsigned *out, hipStream_t stream);
+void launch_build_bits_xy(const DevGrid &G, int use_esdf, double thresh, unsigned *out_x, unsigned *out_y, hipStream_t stream);
 void launch_tail(const SweepParams &P, hipStream_t stream, hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr);
 
 // ---- V1 (swept volume) ----

@@ -173,7 +173,7 @@ __global__ __launch_bounds__(64) void gather_emit_kernel(DevGrid G, const unsign
     }
 }
 
-void launch_build_bits(const DevGrid &G, int use_esdf, float thresh, unsigned *out, hipStream_t stream);   // tile_sweep.hip
+void launch_build_bits(const DevGrid &G, int use_esdf, double thresh, unsigned *out, hipStream_t stream);   // tile_sweep.hip
 
 } // namespace isdf
 
@@ -188,7 +188,7 @@ static int occupancy_bits(isdf_ctx *c, unsigned **out_bits) {
     unsigned *b = nullptr;
     HIPCHK(c, hipMalloc(&b, n_bit_words(G) * sizeof(unsigned)));
     G.occ = c->d_occ;
-    launch_build_bits(G, 0, 0.0f, b, c->stream);
+    launch_build_bits(G, 0, 0.0, b, c->stream);
     *out_bits = b;
     return ISDF_OK;
 }

@@ -252,3 +252,48 @@ void launch_minco_backward(const MincoDevParams &P, int n_active, hipStream_t st
 }
 
 }  // namespace isdf
+
+// The two kernels by themselves, behind the C ABI (include/isdf_accel.h): what the batch optimizer runs around every sweep,
+// callable on its own so that the device MINCO can be checked against the reference's minco.hpp piece by piece.
+#include "isdf_ctx.hpp"
+#include <vector>
+extern "C" int isdf_minco_device(isdf_ctx *c, int n_traj, int N, const double *heads_pva, const double *tails_pva, double rho,
+                                 const double *x, const double *sweep_out, double *T_out, double *coeffs_out, double *cost_g_out) {
+    if (!c) return ISDF_ERR_INVALID_ARG;
+    if (n_traj < 1 || N < 1 || !heads_pva || !tails_pva || !x) return isdf_fail(c, ISDF_ERR_INVALID_ARG, "bad arguments");
+    if (isdf::minco_backward_lds(N) > 64 * 1024) return isdf_fail(c, ISDF_ERR_UNSUPPORTED, "a trajectory's band system must fit in 64 KB of LDS (N <= 46)");
+    HIPCHK(c, hipSetDevice(c->device));
+    const size_t nv = (size_t)N + 3 * (size_t)(N - 1), n6 = (size_t)6 * N, ostride = isdf_out_stride(N);
+    const size_t x_all = (size_t)n_traj * nv, T_all = (size_t)n_traj * N, C_all = (size_t)n_traj * 3 * n6, lu_all = (size_t)n_traj * 13 * n6,
+                 out_all = (size_t)n_traj * ostride, res_all = (size_t)n_traj * (1 + nv), cond_all = (size_t)n_traj * 18;
+    double *d = nullptr; int *d_ids = nullptr;
+    HIPCHK(c, hipMalloc(&d, (x_all + T_all + C_all + lu_all + out_all + res_all + cond_all) * sizeof(double)));
+    if (hipMalloc(&d_ids, (size_t)n_traj * sizeof(int)) != hipSuccess) { (void)hipFree(d); return isdf_fail(c, ISDF_ERR_HIP, "hipMalloc"); }
+    double *d_x = d, *d_T = d_x + x_all, *d_C = d_T + T_all, *d_lu = d_C + C_all, *d_out = d_lu + lu_all, *d_res = d_out + out_all, *d_cond = d_res + res_all;
+    std::vector<double> cond(cond_all);
+    std::vector<int> ids(n_traj);
+    for (int t = 0; t < n_traj; t++) {
+        for (int k = 0; k < 9; k++) { cond[(size_t)18 * t + k] = heads_pva[9 * t + k]; cond[(size_t)18 * t + 9 + k] = tails_pva[9 * t + k]; }
+        ids[t] = t;
+    }
+    int rc = ISDF_OK;
+    auto chk = [&](hipError_t e) { if (e != hipSuccess && rc == ISDF_OK) { c->err = hipGetErrorString(e); rc = ISDF_ERR_HIP; } };
+    chk(hipMemcpy(d_x, x, x_all * sizeof(double), hipMemcpyHostToDevice));
+    chk(hipMemcpy(d_cond, cond.data(), cond_all * sizeof(double), hipMemcpyHostToDevice));
+    chk(hipMemcpy(d_ids, ids.data(), (size_t)n_traj * sizeof(int), hipMemcpyHostToDevice));
+    if (sweep_out) chk(hipMemcpy(d_out, sweep_out, out_all * sizeof(double), hipMemcpyHostToDevice));
+    else chk(hipMemset(d_out, 0, out_all * sizeof(double)));
+    isdf::MincoDevParams P{};
+    P.N = N; P.rho = rho; P.x = d_x; P.ids = d_ids; P.cond = d_cond; P.T = d_T; P.coeffs = d_C; P.lu = d_lu; P.out = d_out; P.res = d_res;
+    if (rc == ISDF_OK) {
+        isdf::launch_minco_forward(P, n_traj, c->stream);
+        isdf::launch_minco_backward(P, n_traj, c->stream);
+        chk(hipGetLastError());
+        chk(hipStreamSynchronize(c->stream));
+    }
+    if (rc == ISDF_OK && T_out) chk(hipMemcpy(T_out, d_T, T_all * sizeof(double), hipMemcpyDeviceToHost));
+    if (rc == ISDF_OK && coeffs_out) chk(hipMemcpy(coeffs_out, d_C, C_all * sizeof(double), hipMemcpyDeviceToHost));
+    if (rc == ISDF_OK && cost_g_out) chk(hipMemcpy(cost_g_out, d_res, res_all * sizeof(double), hipMemcpyDeviceToHost));
+    (void)hipFree(d); (void)hipFree(d_ids);
+    return rc;
+}

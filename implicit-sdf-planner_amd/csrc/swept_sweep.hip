@@ -112,7 +112,7 @@ __global__ __launch_bounds__(1024) void swept_prepare_kernel(const SweptParams P
         for (double t = 0; t < D && n < P.max_coarse; t += 0.2) P.coarse_t[n++] = t;   // choiceTInit :392
         s_n = n;
         *P.n_coarse = n;
-        for (int k = 0; k < 8; k++) P.stats[k] = 0ull;
+        for (int k = 0; k < 8; k++) if (k != 4) P.stats[k] = 0ull;      // [4] = overflow: sticky until the host reads it
     }
     __syncthreads();
     const int n = s_n;

@@ -1242,7 +1242,7 @@ void launch_stats(const SweepParams &P, hipStream_t stream) {
 
 // qualifier bit-grid: bit z&31 of dword (ix*Y + iy)*ZW + (z>>5) is set iff the voxel qualifies.
 // One lane per voxel, 64 consecutive z per wavefront: coalesced reads, the ballot is the two output dwords.
-__global__ __launch_bounds__(256) void build_bits_kernel(DevGrid G, int use_esdf, float thresh, unsigned *out) {
+__global__ __launch_bounds__(256) void build_bits_kernel(DevGrid G, int use_esdf, double thresh, unsigned *out) {
     const int lane = threadIdx.x & 63;
     const size_t n_rows = (size_t)G.X * G.Y;
     const int chunks = (G.Z + 63) >> 6;                       // 64-voxel chunks per z-row
@@ -1255,7 +1255,7 @@ __global__ __launch_bounds__(256) void build_bits_kernel(DevGrid G, int use_esdf
         bool q = false;
         if (z < G.Z) {
             const size_t a = row * G.Z + z;
-            q = use_esdf ? (G.esdf[a] <= thresh) : (G.occ[a] != 0);
+            q = use_esdf ? ((double)G.esdf[a] <= thresh) : (G.occ[a] != 0);      // esdf <= occ_thresh, compared in double (the stored value is exact there)
         }
         const unsigned long long m = __ballot(q);
         if (lane == 0) {
@@ -1267,7 +1267,7 @@ __global__ __launch_bounds__(256) void build_bits_kernel(DevGrid G, int use_esdf
 // The same qualifier bits packed along x (AX = 0: row (y, z)) or along y (AX = 1: row (x, z)).  One lane per (row, 32-voxel
 // block): lanes run along z, so the 32 reads of a lane are each coalesced across the wavefront.
 template <int AX>
-__global__ __launch_bounds__(256) void build_bits_axis_kernel(DevGrid G, int use_esdf, float thresh, unsigned *out) {
+__global__ __launch_bounds__(256) void build_bits_axis_kernel(DevGrid G, int use_esdf, double thresh, unsigned *out) {
     const int NW = AX == 0 ? G.XW : G.YW, NA = AX == 0 ? G.X : G.Y, NU = AX == 0 ? G.Y : G.X;
     const size_t n_work = (size_t)NU * NW * G.Z;
     for (size_t w = (size_t)blockIdx.x * blockDim.x + threadIdx.x; w < n_work; w += (size_t)gridDim.x * blockDim.x) {
@@ -1279,19 +1279,19 @@ __global__ __launch_bounds__(256) void build_bits_axis_kernel(DevGrid G, int use
             const int a = blk * 32 + k;
             if (a < NA) {
                 const size_t idx = AX == 0 ? ((size_t)a * G.Y + u) * G.Z + z : ((size_t)u * G.Y + a) * G.Z + z;
-                const bool q = use_esdf ? (G.esdf[idx] <= thresh) : (G.occ[idx] != 0);
+                const bool q = use_esdf ? ((double)G.esdf[idx] <= thresh) : (G.occ[idx] != 0);
                 m |= (q ? 1u : 0u) << k;
             }
         }
         out[((size_t)u * G.Z + z) * NW + blk] = m;
     }
 }
-void launch_build_bits_xy(const DevGrid &G, int use_esdf, float thresh, unsigned *out_x, unsigned *out_y, hipStream_t stream) {
+void launch_build_bits_xy(const DevGrid &G, int use_esdf, double thresh, unsigned *out_x, unsigned *out_y, hipStream_t stream) {
     hipLaunchKernelGGL(build_bits_axis_kernel<0>, dim3(4096), dim3(256), 0, stream, G, use_esdf, thresh, out_x);
     hipLaunchKernelGGL(build_bits_axis_kernel<1>, dim3(4096), dim3(256), 0, stream, G, use_esdf, thresh, out_y);
 }
 
-void launch_build_bits(const DevGrid &G, int use_esdf, float thresh, unsigned *out, hipStream_t stream) {
+void launch_build_bits(const DevGrid &G, int use_esdf, double thresh, unsigned *out, hipStream_t stream) {
     hipLaunchKernelGGL(build_bits_kernel, dim3(2048), dim3(256), 0, stream, G, use_esdf, thresh, out);
 }
 

@@ -202,6 +202,21 @@ int isdf_eval(isdf_ctx *ctx, int n_traj, const int *N, const double *const *T,
               const double *const *coeffs, double *cost_inout, double *const *gradT_inout,
               double *const *gradC_inout, double *tstar_inout);
 
+/* How the LAST host-array step (isdf_eval, isdf_cost_function) crossed PCIe - for callers that want to know which of the
+ * boundary's latencies they are getting (INTEGRATION.md "Boundary cost"):
+ *   COPY           one H2D copy, the launches, one D2H copy, one stream synchronisation (batches, V1, mesh robots, small-BAR
+ *                  systems with ISDF_NO_HOST_DIRECT=1, any step that is not one fused launch)
+ *   DIRECT_MAPPED  ONE launch: its first workgroups fetch the inputs from host-mapped memory, its last store the results and a
+ *                  completion flag into host-mapped memory (no large PCIe BAR, or ISDF_NO_BAR_WRITES=1)
+ *   DIRECT_BAR     ONE launch: the CPU has written the inputs straight into device memory through the PCIe BAR (verified per
+ *                  ctx by a kernel-visible probe), results and flag as above
+ * The three environment switches ISDF_NO_HOST_DIRECT / ISDF_NO_BAR_WRITES / ISDF_NO_FUSE are read once per ctx, in isdf_create.
+ * Replaces nothing in the reference (its sweeps run in the caller's address space). */
+#define ISDF_HOST_PATH_COPY 0
+#define ISDF_HOST_PATH_DIRECT_MAPPED 1
+#define ISDF_HOST_PATH_DIRECT_BAR 2
+int isdf_host_path(const isdf_ctx *ctx);
+
 /* Device-resident entry point, asynchronous on `stream` (a hipStream_t passed as void*; NULL = default
  * stream).  All trajectories have N pieces.  d_T: n_traj*N, d_coeffs: n_traj * (6N x 3 col-major),
  * d_out: n_traj * (1 + N + 18N) doubles, OVERWRITTEN with [cost | gradT | gradC(col-major)] per trajectory
@@ -316,6 +331,20 @@ int isdf_optimize_lbfgs(isdf_ctx *ctx, double *x_inout, int n, const isdf_lbfgs_
  * a sharded ctx (shard the batch across ranks instead). */
 int isdf_optimize_lbfgs_batch(isdf_ctx *ctx, int n_traj, int N, const double *heads_pva, const double *tails_pva, double rho,
                               double *x_inout, const isdf_lbfgs_params *p, isdf_lbfgs_result *results, double *wall_ms_out);
+
+/* MINCO on the device BY ITSELF (csrc/minco_dev.hip) - the two kernels the batch optimizer runs around every
+ * sweep when MINCO is on the device, callable on their own: for each of n_traj trajectories (boundary states like
+ * isdf_optimize_lbfgs_batch, variables x[t*n .. ), n = N + 3(N-1)),
+ *   forward : T = forwardT(tau) (back_end_optimizer.hpp:228-241), MINCO_S3NU::setParameters (minco.hpp:433-513: band system,
+ *             BandedSystem::factorizeLU :93-131, solve :137-165)             -> T_out[t*N ..], coeffs_out[t*18N ..] (6N x 3 column-major)
+ *   backward: getEnergy + partials (:530-582) + sweep_out[t*(1+19N) ..] = [cost | gradT | gradC] of the sweeps (NULL: zeros),
+ *             propogateGrad (:584-654, solveAdj :169-197), rho * sum(T), backwardGradT / backwardGradP (:283-330)
+ *                                                                            -> cost_g_out[t*(1+n) ..] = [cost | g]
+ * i.e. TrajOptimizer::costFunctionLmbm (:358-430) with the sweeps' sums handed in.  Outputs may be NULL.  Same operations
+ * in the same order as the host MINCO of isdf_cost_function (results are bitwise equal).  N <= 46 (one trajectory's band system
+ * lives in 64 KB of LDS). */
+int isdf_minco_device(isdf_ctx *ctx, int n_traj, int N, const double *heads_pva, const double *tails_pva, double rho,
+                      const double *x, const double *sweep_out, double *T_out, double *coeffs_out, double *cost_g_out);
 
 /* ---- front end: pose feasibility by kernel convolution ------------------------------------- */
 /* The A* front end decides whether the robot fits at a voxel by AND-ing a bit-packed voxelisation of the robot at a

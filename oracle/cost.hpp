@@ -72,8 +72,9 @@ struct CostParams {
     double bd() const { return kernel_size * grid->res; }
     // whole-tile cull threshold of V3 (DESIGN.md "cull"): every voxel centre within reach of a non-zero penalty
     // lies closer than bound_radius + safety_hor to the pose; the trilinear sample can over-estimate the distance
-    // to the nearest qualifying voxel centre by at most sqrt(3)*res.
-    double cull_threshold() const { return shape.bound_radius + safety_hor + std::sqrt(3.0) * grid->res; }
+    // to the nearest OCCUPIED voxel centre by at most sqrt(3)*res, and a voxel that qualifies (esdf <= occ_thresh) lies within
+    // occ_thresh of an occupied one.
+    double cull_threshold() const { return shape.bound_radius + safety_hor + std::sqrt(3.0) * grid->res + (occ_thresh > 0 ? occ_thresh : 0.0); }
 };
 
 struct SweepStats { long long units = 0, culled = 0, pairs = 0, grad_pairs = 0; };
@@ -90,7 +91,7 @@ inline bool grad_cost_p(const CostParams &P, const V3 &pos, const M3 &R, const V
     }
     int lo[3], hi[3];
     G.aabb_index_box(pos, bd / 2, lo, hi);
-    const float thresh = (float)P.occ_thresh;
+    const double thresh = P.occ_thresh;
     for (int i = lo[0]; i <= hi[0]; i++)
         for (int j = lo[1]; j <= hi[1]; j++)
             for (int k = lo[2]; k <= hi[2]; k++) {

@@ -59,10 +59,11 @@ struct Grid {
         if (!index_valid(ix, iy, iz)) return true;
         return occ[addr(ix, iy, iz)] != 0;
     }
-    // V3 qualification: esdf <= thresh (float compare against the stored float)
-    bool index_qualifies_esdf(int ix, int iy, int iz, float thresh) const {
+    // V3 qualification: esdf <= thresh, compared in double like the reference's double grid_esdf would be
+    // (GridMap3D.h:155-193 reads doubles); the stored fp32 value converts exactly
+    bool index_qualifies_esdf(int ix, int iy, int iz, double thresh) const {
         if (!index_valid(ix, iy, iz)) return true;
-        return esdf[addr(ix, iy, iz)] <= thresh;
+        return (double)esdf[addr(ix, iy, iz)] <= thresh;
     }
     // getGridSDFValue(Vector3i): invalid -> 0 (Gridmap3D.cpp:535-542)
     double esdf_at(int ix, int iy, int iz) const {

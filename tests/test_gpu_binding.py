@@ -99,3 +99,49 @@ def test_stub_swept_sweep_vs_reference_code(pkg, orc, stub):
     assert abs((c - cost0) - c_r) <= REL_TOL * abs(c_r)
     assert np.abs(ts - ts_r).max() <= 1e-7
     assert_close(gT - gT0, gT_r, "binding: addSafty... gradT"); assert_close(gC - gC0, gC_r, "binding: addSafty... gradC")
+
+
+def test_stub_every_boundary_path_gives_the_same_sums(pkg, orc, stub, monkeypatch):
+    """The three ways a host-array step can cross PCIe (include/isdf_accel.h, isdf_host_path): the CPU writes the inputs through
+    the PCIe BAR, the launch fetches them from host-mapped memory (ISDF_NO_BAR_WRITES=1: what a box without a large BAR gets), or
+    the copy path (ISDF_NO_HOST_DIRECT=1).  All three through the compiled binding's addTimeIntPenaltyParallel with the collision
+    term on, repeated (the BAR path overwrites device memory between back-to-back launches), against the oracle and against
+    each other bit for bit - they run the same kernel arithmetic."""
+    capi, synth = pkg.capi, pkg.synth
+    occ, esdf, res = small_world(pkg, seed=5)
+    N = 7
+    cfg = synth.default_config(capi.V3_ESDF_TILE, kernel_size=9, integral_intervs=16, safety_hor=0.5)
+    shape = synth.make_shape("Box", params=(1.2, 0.4, 0.3), bound_radius=1.4)
+    o = orc.Oracle(cfg, threads=4)
+    o.set_grid(esdf, (0, 0, 0), res, capi.GRID_ESDF); o.set_shape(shape)
+    trajs = [traj(pkg, occ, res, N=N, seed=60 + k) for k in range(4)]
+    want = []
+    for T, cm in trajs:
+        c0, gT0, gC0, _ = o.eval(T, cm)
+        want.append((c0, gT0, gC0))
+    assert any(w[0] > 0 for w in want)
+    results, paths = {}, {}
+    for name, env in (("bar", {}), ("mapped", {"ISDF_NO_BAR_WRITES": "1"}), ("copy", {"ISDF_NO_HOST_DIRECT": "1"})):
+        for k in ("ISDF_NO_BAR_WRITES", "ISDF_NO_HOST_DIRECT"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        eng = pkg.Engine(cfg)                      # the switches are read per ctx, in isdf_create
+        eng.set_grid(esdf, (0, 0, 0), res, capi.GRID_ESDF); eng.set_shape(shape)
+        got = []
+        for rep in range(3):                       # back-to-back steps with CHANGING inputs
+            for (T, cm), (c0, gT0, gC0) in zip(trajs, want):
+                c, gT, gC = _call(stub, eng, 0, T, cm, 0.0, np.zeros(N), np.zeros(18 * N))
+                assert abs(c - c0) <= REL_TOL * max(1.0, abs(c0)), (name, rep)
+                assert_close(gT, gT0, f"{name}: gradT"); assert_close(gC, gC0, f"{name}: gradC")
+                got.append((c, gT, gC))
+        results[name] = got
+        paths[name] = eng.host_path()
+        eng.close()
+    assert paths["copy"] == capi.HOST_PATH_COPY
+    assert paths["mapped"] == capi.HOST_PATH_DIRECT_MAPPED
+    assert paths["bar"] in (capi.HOST_PATH_DIRECT_BAR, capi.HOST_PATH_DIRECT_MAPPED)     # BAR only where the box has a large one
+    print(f"\nboundary paths exercised: {paths}")
+    for name in ("mapped", "copy"):
+        for a, b in zip(results["bar"], results[name]):
+            assert a[0] == b[0] and np.array_equal(a[1], b[1]) and np.array_equal(a[2], b[2]), f"{name} differs from the BAR path"

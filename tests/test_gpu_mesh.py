@@ -4,7 +4,7 @@ from oracle/_ref/libref_fwn.so = the vendored HDK FastWindingNumberForSoups.h): 
 import numpy as np
 import pytest
 
-from common import REL_TOL, assert_close, make_pair, small_world, traj
+from common import REL_TOL, assert_close, assert_mesh_v1_free_running, make_pair, small_world, traj
 
 pytestmark = pytest.mark.gpu
 
@@ -80,10 +80,7 @@ def test_mesh_sweeps_with_a_720_face_robot(pkg, orc, product_lib):
     # the float solid angle moved by 40 x 2^-23 (the |dw| <= 4e-7 by which the device's w differs from the host library's,
     # test_mesh_shape_plugin_vs_reference_library) - the reference does not reproduce its own t* / gradients any better.
     sp = _reference_spread(pkg, orc, cfg1, res, T, cm, pts, V, F)
-    dt = np.abs(tg - to)
-    assert dt.max() <= max(2e-5, 2 * sp["dt_max"]) and (dt > 1e-6).mean() <= max(0.01, 2 * sp["dt_frac_gt_1e-6"]), (dt.max(), (dt > 1e-6).sum(), sp)
-    assert_close(gT, gT0, "mesh-720 V1 gradT", tol=max(REL_TOL, 2 * sp["gradT_rel"]))
-    assert_close(gC, gC0, "mesh-720 V1 gradC", tol=max(REL_TOL, 2 * sp["gradC_rel"]))
+    assert_mesh_v1_free_running("mesh-720 V1 (test_gpu_mesh)", sp, tg, to, gT, gT0, gC, gC0)
 
 
 def _reference_spread(pkg, orc, cfg, res, T, cm, pts, V, F, ulps=40):

@@ -480,3 +480,56 @@ def test_dispatch_order_of_two_launch_steps_is_scheduling_only(pkg, orc, product
         r = np.where(m >= 0)[0]
         pos[m[r]] = 4 * (r % nb) + r // nb               # rank = wave * nb + workgroup, position = 4 * workgroup + wave
         assert np.array_equal(pos // (N * K1), np.arange(live.size) // (N * K1))
+
+
+# ---- V3 with a REAL ESDF threshold (Gridmap3D.cpp:361-414,494-533, GridMap3D.h:155-193) ----------------------------
+def _thresh_shape(pkg, name):
+    synth, capi = pkg.synth, pkg.capi
+    if name == "Box":
+        return synth.make_shape("Box", params=(1.2, 0.4, 0.3), grad_mode=capi.GRAD_CENTRAL, bound_radius=1.4,
+                                bbox=((0, 0, 0), (1.2, 0.4, 0.3)))
+    if name == "RoundedCone":
+        return synth.make_shape("RoundedCone", params=(0.8, 0.3, 1.6), bound_radius=1.95, bbox=((0, 0, 0.55), (0.8, 0.8, 1.35)))
+    V, F = synth.l_prism_mesh()
+    return synth.make_mesh_shape(V, F)
+
+
+@pytest.mark.parametrize("frac", [0.5, 1.0, 1.7])
+@pytest.mark.parametrize("shape_name", ["Box", "RoundedCone", "mesh"])
+def test_v3_with_a_real_esdf_threshold(pkg, orc, product_lib, shape_name, frac):
+    """occ_thresh > 0 is what distinguishes V3 from V2: the qualifier is `esdf(i,j,k) <= occ_thresh` on the ESDF grid, a shell of
+    voxels around every obstacle.  Three checks per (robot, threshold): (a) device vs oracle at 1e-5 with the SAME set of
+    active pairs, cull off and on; (b) the whole-tile cull changes nothing (it has to allow for the shell: cull threshold +
+    occ_thresh); (c) V3(threshold) == V2 on the occupancy grid {esdf <= threshold} BIT FOR BIT - the V2 term is the reference's
+    own grad_cost_p (pinned against its code, tests/test_oracle_ref.py), so this ties the thresholded qualifier to it."""
+    capi, synth = pkg.capi, pkg.synth
+    occ, esdf, res = small_world(pkg, seed=9, occupancy=0.05)
+    T, cm = traj(pkg, occ, res, seed=31)
+    thresh = frac * res
+    shape = _thresh_shape(pkg, shape_name)
+    got = {}
+    for cull in (0, 1):
+        cfg = synth.default_config(capi.V3_ESDF_TILE, kernel_size=9, integral_intervs=16, safety_hor=0.5, enable_cull=cull)
+        cfg.occ_thresh = thresh
+        eng, o = make_pair(pkg, orc, cfg, shape, esdf=esdf, res=res, threads=8)
+        if shape_name == "mesh" and o.mesh_backend() != 1:
+            pytest.skip("oracle/_ref/libref_fwn.so not built")
+        cost, st0 = _check(eng, o, T, cm, f"V3 thresh={frac} res/{shape_name}/cull={cull}")
+        st = eng.stats()
+        assert st["units"] == st0[0] and st["grad_pairs"] == st0[3] and st0[3] <= st["pairs"] <= st0[2], (st, st0)
+        got[cull] = (eng.eval_single(T, cm), st, st0)
+    assert got[0][0][0] > 0, "scenario must exercise the collision term"
+    # the shell really is there: more active pairs than with the bare occupancy
+    cfg0 = synth.default_config(capi.V3_ESDF_TILE, kernel_size=9, integral_intervs=16, safety_hor=0.5)
+    o0 = orc.Oracle(cfg0, threads=8); o0.set_grid(esdf, (0, 0, 0), res, capi.GRID_ESDF); o0.set_shape(shape)
+    assert got[0][2][3] > o0.eval(T, cm)[3][3], "threshold must qualify voxels the occupancy does not"
+    # (b) cull on == cull off (the cull only skips poses whose sums are exact zeros)
+    if shape.bound_radius > 0:
+        assert got[1][1]["culled"] > 0, "scenario must cull something"
+    assert got[1][0][0] == got[0][0][0] and np.array_equal(got[1][0][1], got[0][0][1]) and np.array_equal(got[1][0][2], got[0][0][2])
+    # (c) the same voxel set handed over as an occupancy grid to the V2 term
+    shell = (esdf.astype(np.float64) <= thresh).astype(np.uint8)
+    cfg2 = synth.default_config(capi.V2_OCC_TILE, kernel_size=9, integral_intervs=16, safety_hor=0.5)
+    e2 = pkg.Engine(cfg2); e2.set_grid(shell, (0, 0, 0), res, capi.GRID_OCCUPANCY); e2.set_shape(shape)
+    c2, gT2, gC2 = e2.eval_single(T, cm)
+    assert c2 == got[0][0][0] and np.array_equal(gT2, got[0][0][1]) and np.array_equal(gC2, got[0][0][2])
