@@ -36,6 +36,67 @@ __device__ __forceinline__ d3 closest_on_triangle(d3 p, d3 a, d3 b, d3 c) {
 }
 
 
+// atan2f the way the reference's host computes it.  UTsignedSolidAngleTri ends in SYSatan2(float, float) = ::atan2f of the C
+// library (FastWindingNumberForSoups.h:325-326, :6083), and the swept-volume argmin compares SDF values that differ by less than
+// one float ulp of w - so WHICH atan2f matters.  glibc's (2.31 of the reference's ROS-noetic platform through 2.35
+// of this image: sysdeps/ieee754/flt-32/e_atan2f.c + s_atanf.c, the fdlibm algorithm) is a short chain of IEEE float
+// operations: restated here with contraction off it returns the same bits (checked against libm on 2e8 arguments on the host,
+// tests/test_fwn_host.py::test_atan2f_restatement_is_glibcs), where the device library's own atan2f differs in the last ulp.
+__host__ __device__ __forceinline__ float glibc_atanf(float x) {
+#pragma clang fp contract(off)
+    const float hi0 = 4.6364760399e-01f, hi1 = 7.8539812565e-01f, hi2 = 9.8279368877e-01f, hi3 = 1.5707962513e+00f;
+    const float lo0 = 5.0121582440e-09f, lo1 = 3.7748947079e-08f, lo2 = 3.4473217170e-08f, lo3 = 7.5497894159e-08f;
+    const int hx = __builtin_bit_cast(int, x), ix = hx & 0x7fffffff;
+    float ahi = 0.f, alo = 0.f;
+    int id = -1;
+    if (ix >= 0x4c000000) {                               // |x| >= 2^25
+        if (ix > 0x7f800000) return x + x;
+        return hx > 0 ? hi3 + lo3 : -hi3 - lo3;
+    }
+    if (ix < 0x3ee00000) {                                // |x| < 0.4375
+        if (ix < 0x31000000) return x;                    // |x| < 2^-29
+    } else {
+        x = __builtin_fabsf(x);
+        if (ix < 0x3f980000) {
+            if (ix < 0x3f300000) { id = 0; ahi = hi0; alo = lo0; x = (2.0f * x - 1.0f) / (2.0f + x); }
+            else { id = 1; ahi = hi1; alo = lo1; x = (x - 1.0f) / (x + 1.0f); }
+        } else {
+            if (ix < 0x401c0000) { id = 2; ahi = hi2; alo = lo2; x = (x - 1.5f) / (1.0f + 1.5f * x); }
+            else { id = 3; ahi = hi3; alo = lo3; x = -1.0f / x; }
+        }
+    }
+    const float z = x * x, w = z * z;
+    const float s1 = z * (3.3333334327e-01f + w * (1.4285714924e-01f + w * (9.0908870101e-02f + w * (6.6610731184e-02f + w * (4.9768779427e-02f + w * 1.6285819933e-02f)))));
+    const float s2 = w * (-2.0000000298e-01f + w * (-1.1111110449e-01f + w * (-7.6918758452e-02f + w * (-5.8335702866e-02f + w * -3.6531571299e-02f))));
+    if (id < 0) return x - x * (s1 + s2);
+    const float r = ahi - ((x * (s1 + s2) - alo) - x);
+    return hx < 0 ? -r : r;
+}
+__host__ __device__ __forceinline__ float glibc_atan2f(float y, float x) {
+#pragma clang fp contract(off)
+    const float tiny = 1.0e-30f, pi_o_4 = 7.8539818525e-01f, pi_o_2 = 1.5707963705e+00f, pi = 3.1415927410e+00f, pi_lo = -8.7422776573e-08f;
+    const int hx = __builtin_bit_cast(int, x), ix = hx & 0x7fffffff, hy = __builtin_bit_cast(int, y), iy = hy & 0x7fffffff;
+    if (ix > 0x7f800000 || iy > 0x7f800000) return x + y;
+    if (hx == 0x3f800000) return glibc_atanf(y);
+    const int m = ((hy >> 31) & 1) | ((hx >> 30) & 2);
+    if (iy == 0) return m < 2 ? y : (m == 2 ? pi + tiny : -pi - tiny);
+    if (ix == 0) return hy < 0 ? -pi_o_2 - tiny : pi_o_2 + tiny;
+    if (ix == 0x7f800000) {
+        if (iy == 0x7f800000) return m == 0 ? pi_o_4 + tiny : (m == 1 ? -pi_o_4 - tiny : (m == 2 ? 3.0f * pi_o_4 + tiny : -3.0f * pi_o_4 - tiny));
+        return m == 0 ? 0.0f : (m == 1 ? -0.0f : (m == 2 ? pi + tiny : -pi - tiny));
+    }
+    if (iy == 0x7f800000) return hy < 0 ? -pi_o_2 - tiny : pi_o_2 + tiny;
+    const int k = (iy - ix) >> 23;
+    float z;
+    if (k > 60) z = pi_o_2 + 0.5f * pi_lo;
+    else if (hx < 0 && k < -60) z = 0.0f;
+    else z = glibc_atanf(__builtin_fabsf(y / x));
+    if (m == 0) return z;
+    if (m == 1) return __builtin_bit_cast(float, __builtin_bit_cast(int, z) ^ (int)0x80000000);
+    if (m == 2) return pi - (z - pi_lo);
+    return (z - pi_lo) - pi;
+}
+
 // UTsignedSolidAngleTri (FastWindingNumberForSoups.h:6044-6082), float
 __device__ __forceinline__ float mesh_tri_solid_angle(const float *u, float qx, float qy, float qz) {
 #pragma clang fp contract(off)
@@ -49,7 +110,7 @@ __device__ __forceinline__ float mesh_tri_solid_angle(const float *u, float qx, 
     const float num = ax * (uy * vz - uz * vy) + ay * (uz * vx - ux * vz) + az * (ux * vy - uy * vx);
     if (num == 0) return 0.f;
     const float den = 1.0f + (ax * bx + ay * by + az * bz) + (ax * cx + ay * cy + az * cz) + (bx * cx + by * cy + bz * cz);
-    return 2.0f * atan2f(num, den);
+    return 2.0f * glibc_atan2f(num, den);
 }
 
 // UT_SolidAngle::computeSolidAngle, order 2 (SolidAngleFunctors, :7119-7258); returns the solid angle (w = it / 4 pi)

@@ -45,3 +45,11 @@ extern "C" int isdf_shape_eval(isdf_ctx *c, const double *p_rel, int n, double *
     (void)hipFree(d);
     return rc;
 }
+
+// Host evaluation of the float atan2 the device's winding number uses (dev_mesh.hpp: the C library's algorithm restated) - so the
+// CPU tests can hold it against libm bit for bit; n pairs, out[i] = atan2f(y[i], x[i]).
+extern "C" int isdf_mesh_atan2f(const float *y, const float *x, long long n, float *out) {
+    if (n < 0 || (n > 0 && (!y || !x || !out))) return ISDF_ERR_INVALID_ARG;
+    for (long long i = 0; i < n; i++) out[i] = isdf::glibc_atan2f(y[i], x[i]);
+    return ISDF_OK;
+}

@@ -193,6 +193,12 @@ int isdf_get_points(isdf_ctx *ctx, double *xyz_out, int capacity);
  * w = igl::fast_winding_number(fwn_bvh, 2.0, ...)).  Either output may be NULL.  Evaluated on the device. */
 int isdf_shape_eval(isdf_ctx *ctx, const double *p_rel, int n, double *sdf_out, double *grad_out);
 
+/* The float atan2 inside the mesh kind's winding number, evaluated on the HOST (no device needed; for tests): the reference's
+ * UTsignedSolidAngleTri ends in the C library's atan2f (FastWindingNumberForSoups.h:325-326, :6083) and the swept-volume
+ * argmin is sensitive to its last bit, so the device restates glibc's algorithm (sysdeps/ieee754/flt-32/e_atan2f.c,
+ * s_atanf.c) operation for operation; out[i] = that function at (y[i], x[i]). */
+int isdf_mesh_atan2f(const float *y, const float *x, long long n, float *out);
+
 /* ---- per-step evaluation ----------------------------------------------------------------------------------- */
 /* Host entry point, synchronous, drop-in for the reference sweeps.  n_traj trajectories (1 in the reference);
  * N[b] pieces each; T[b] -> N[b] doubles; coeffs[b] -> 6N[b] x 3 column-major.

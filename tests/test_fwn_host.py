@@ -68,3 +68,24 @@ def test_hierarchy_matches_hdk(pkg, orc, shim):
         shim.shim_fwn_eval(h, Q.ctypes.data_as(dp), Q.shape[0], C.c_double(2.0), w.ctypes.data_as(dp))
         assert np.abs(w - w_ref).max() < 5e-6, (name, np.abs(w - w_ref).max())
         shim.shim_fwn_destroy(h)
+
+
+def test_atan2f_restatement_is_glibcs(pkg, product_lib):
+    """The mesh kind's float atan2 (csrc/dev_mesh.hpp, restating glibc's e_atan2f.c / s_atanf.c) against this image's libm, bit
+    for bit: uniform pairs in the solid angle's range, random bit patterns over the whole float range, and the special cases."""
+    import ctypes as C
+    libm = C.CDLL("libm.so.6")
+    libm.atan2f.restype = C.c_float; libm.atan2f.argtypes = [C.c_float, C.c_float]
+    rng = np.random.default_rng(3)
+    n = 100000
+    y = np.concatenate([rng.uniform(-4, 4, n), rng.integers(0, 2 ** 32, n, dtype=np.uint64).astype(np.uint32).view(np.float32).astype(np.float64),
+                        [0.0, -0.0, 0.0, -0.0, 1.0, -1.0, np.inf, -np.inf, np.inf, 1e-30, 1e30, 3.0, np.nan]]).astype(np.float32)
+    x = np.concatenate([rng.uniform(-4, 4, n), rng.integers(0, 2 ** 32, n, dtype=np.uint64).astype(np.uint32).view(np.float32).astype(np.float64),
+                        [1.0, 1.0, -1.0, -1.0, 0.0, -0.0, np.inf, -np.inf, 1.0, 1e30, 1e-30, 1.0, 1.0]]).astype(np.float32)
+    out = np.zeros_like(y)
+    fp = C.POINTER(C.c_float)
+    assert product_lib.isdf_mesh_atan2f(y.ctypes.data_as(fp), x.ctypes.data_as(fp), y.size, out.ctypes.data_as(fp)) == 0
+    want = np.array([libm.atan2f(float(a), float(b)) for a, b in zip(y, x)], dtype=np.float32)      # (numpy's float32 arctan2 is NOT libm's)
+    both_nan = np.isnan(out) & np.isnan(want)
+    same = (out.view(np.uint32) == want.view(np.uint32)) | both_nan
+    assert same.all(), (np.flatnonzero(~same)[:5], y[~same][:5], x[~same][:5], out[~same][:5], want[~same][:5])

@@ -494,7 +494,7 @@ def _thresh_shape(pkg, name):
     return synth.make_mesh_shape(V, F)
 
 
-@pytest.mark.parametrize("frac", [0.5, 1.0, 1.7])
+@pytest.mark.parametrize("frac", [0.5, 1.0, 1.7, 2.3])
 @pytest.mark.parametrize("shape_name", ["Box", "RoundedCone", "mesh"])
 def test_v3_with_a_real_esdf_threshold(pkg, orc, product_lib, shape_name, frac):
     """occ_thresh > 0 is what distinguishes V3 from V2: the qualifier is `esdf(i,j,k) <= occ_thresh` on the ESDF grid, a shell of
@@ -504,7 +504,7 @@ def test_v3_with_a_real_esdf_threshold(pkg, orc, product_lib, shape_name, frac):
     own grad_cost_p (pinned against its code, tests/test_oracle_ref.py), so this ties the thresholded qualifier to it."""
     capi, synth = pkg.capi, pkg.synth
     occ, esdf, res = small_world(pkg, seed=9, occupancy=0.05)
-    T, cm = traj(pkg, occ, res, seed=31)
+    T, cm = traj(pkg, occ, res, seed=13)
     thresh = frac * res
     shape = _thresh_shape(pkg, shape_name)
     got = {}
@@ -519,10 +519,18 @@ def test_v3_with_a_real_esdf_threshold(pkg, orc, product_lib, shape_name, frac):
         assert st["units"] == st0[0] and st["grad_pairs"] == st0[3] and st0[3] <= st["pairs"] <= st0[2], (st, st0)
         got[cull] = (eng.eval_single(T, cm), st, st0)
     assert got[0][0][0] > 0, "scenario must exercise the collision term"
-    # the shell really is there: more active pairs than with the bare occupancy
+    # the shell really is there: more active pairs than with the bare occupancy.  The ESDF of a voxel grid takes the values
+    # res * sqrt(integer): a threshold below one voxel (0.5 res) qualifies nothing new and must reproduce threshold 0 exactly,
+    # 1.0 res is the TIE case (the six face neighbours sit at exactly res), 1.7 / 2.3 res reach d^2 <= 2 / <= 5
     cfg0 = synth.default_config(capi.V3_ESDF_TILE, kernel_size=9, integral_intervs=16, safety_hor=0.5)
-    o0 = orc.Oracle(cfg0, threads=8); o0.set_grid(esdf, (0, 0, 0), res, capi.GRID_ESDF); o0.set_shape(shape)
-    assert got[0][2][3] > o0.eval(T, cm)[3][3], "threshold must qualify voxels the occupancy does not"
+    e0, o0 = make_pair(pkg, orc, cfg0, shape, esdf=esdf, res=res, threads=8)
+    base_pairs = o0.eval(T, cm)[3][3]
+    if frac < 1.0:
+        assert got[0][2][3] == base_pairs
+        c0_, gT0_, gC0_ = e0.eval_single(T, cm)
+        assert c0_ == got[0][0][0] and np.array_equal(gC0_, got[0][0][2])
+    else:
+        assert got[0][2][3] > base_pairs, "threshold must qualify voxels the occupancy does not"
     # (b) cull on == cull off (the cull only skips poses whose sums are exact zeros)
     if shape.bound_radius > 0:
         assert got[1][1]["culled"] > 0, "scenario must cull something"
