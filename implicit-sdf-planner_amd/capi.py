@@ -101,11 +101,12 @@ EXPORTED_SYMBOLS = [
     "isdf_frontend_build", "isdf_frontend_get_shape_kernels", "isdf_frontend_get_map_kernel", "isdf_frontend_check", "isdf_frontend_cspace",
     "isdf_read_pcd", "isdf_read_obj", "isdf_poly_rotation", "isdf_body_transform", "isdf_plan_config_default", "isdf_load_yaml_config",
     "isdf_shape_from_config",
-    "isdf_host_path", "isdf_minco_device", "isdf_mesh_atan2f",
+    "isdf_host_path", "isdf_minco_device", "isdf_mesh_atan2f", "isdf_create_multi", "isdf_multi_info",
     "isdf_xchg_create", "isdf_xchg_connect", "isdf_xchg_allreduce", "isdf_xchg_fuse", "isdf_xchg_status", "isdf_xchg_destroy",
 ]
 
 HOST_PATH_COPY, HOST_PATH_DIRECT_MAPPED, HOST_PATH_DIRECT_BAR = 0, 1, 2
+MULTI_NONE, MULTI_PEER_SUM, MULTI_STAGED, MULTI_RCCL = 0, 1, 2, 3
 
 _lib = None
 
@@ -127,6 +128,8 @@ def load_library(path=None):
     lib.isdf_shape_from_name.argtypes = [C.POINTER(IsdfShape), C.c_char_p]
     lib.isdf_create.argtypes = [C.POINTER(C.c_void_p), C.POINTER(IsdfConfig)]
     lib.isdf_destroy.argtypes = [C.c_void_p]
+    lib.isdf_create_multi.argtypes = [C.POINTER(C.c_void_p), C.POINTER(IsdfConfig), C.POINTER(C.c_int), C.c_int]
+    lib.isdf_multi_info.argtypes = [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int)]
     lib.isdf_last_error.argtypes = [C.c_void_p]
     lib.isdf_last_error.restype = C.c_char_p
     lib.isdf_set_grid.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, dp, dp, C.c_double, C.c_int]

@@ -105,7 +105,9 @@ __device__ __forceinline__ float mesh_tri_solid_angle(const float *u, float qx, 
     float cx = u[6] - qx, cy = u[7] - qy, cz = u[8] - qz;
     const float la = sqrtf(ax * ax + ay * ay + az * az), lb = sqrtf(bx * bx + by * by + bz * bz), lc = sqrtf(cx * cx + cy * cy + cz * cz);
     if (la == 0 || lb == 0 || lc == 0) return 0.f;
-    ax /= la; ay /= la; az /= la; bx /= lb; by /= lb; bz /= lb; cx /= lc; cy /= lc; cz /= lc;
+    // UT_FixedVector::operator/=(T): the reciprocal, then three products (:3405-3417) - not three divisions
+    const float ia = 1.0f / la, ib = 1.0f / lb, ic = 1.0f / lc;
+    ax *= ia; ay *= ia; az *= ia; bx *= ib; by *= ib; bz *= ib; cx *= ic; cy *= ic; cz *= ic;
     const float ux = bx - ax, uy = by - ay, uz = bz - az, vx = cx - ax, vy = cy - ay, vz = cz - az;
     const float num = ax * (uy * vz - uz * vy) + ay * (uz * vx - ux * vz) + az * (ux * vy - uy * vx);
     if (num == 0) return 0.f;
@@ -113,44 +115,79 @@ __device__ __forceinline__ float mesh_tri_solid_angle(const float *u, float qx, 
     return 2.0f * glibc_atan2f(num, den);
 }
 
-// UT_SolidAngle::computeSolidAngle, order 2 (SolidAngleFunctors, :7119-7258); returns the solid angle (w = it / 4 pi)
+// UT_SolidAngle::computeSolidAngle, order 2 (SolidAngleFunctors, :7119-7258); returns the solid angle (w = it / 4 pi).
+// The library's traversal (BVH<4>::traverseVectorHelper, :4794-4826) gives every node a VALUE: pre() = the sum of the far-field
+// approximations of the children that are far enough (lanes 0..3 in order, zeros for the others), post() adds the values of the
+// children it descended into, in lane order - so the float sum has the SHAPE OF THE TREE.  The device keeps that shape (an
+// explicit stack of frames: node, lanes still to visit, the two partial sums) - with it, the glibc atan2f above and the same
+// coefficients (csrc/fwn_host.hpp, bitwise the library's) w comes out bit for bit the host library's
+// (tests/test_fwn_host.py on the host, tests/test_gpu_mesh.py on the device).
+__device__ inline unsigned mesh_node_pre(const DevMesh *m, int nodei, float qx, float qy, float qz, float acc2, float &A) {
+#pragma clang fp contract(off)
+    const float *r = m->fwn_box + (size_t)92 * nodei;
+    const int *ch = m->fwn_child + 4 * nodei;
+    unsigned descend = 0;
+    float sum = 0.f;
+    for (int l = 0; l < 4; l++) {
+        if (ch[l] == -1) break;                                   // empty children are last
+        float x = qx - r[4 + l], y = qy - r[8 + l], z = qz - r[12 + l];
+        const float ql2 = x * x + y * y + z * z;
+        float om = 0.f;
+        bool use = false;
+        if (!(ql2 <= r[l] * acc2)) {
+            const float m2 = 1.0f / ql2, m1 = sqrtf(m2);
+            x *= m1; y *= m1; z *= m1;
+            om = -m2 * (x * r[16 + l] + y * r[20 + l] + z * r[24 + l]);
+            const float x2 = x * x, y2 = y * y, z2 = z * z;
+            const float m3 = m2 * m1;
+            om += m3 * (r[28 + l] + r[32 + l] + r[36 + l]
+                        - 3.0f * ((x2 * r[28 + l] + y2 * r[32 + l] + z2 * r[36 + l]) + x * y * r[40 + l] + x * z * r[48 + l] + y * z * r[44 + l]));
+            const float x3 = x2 * x, y3 = y2 * y, z3 = z2 * z;
+            const float m4 = m2 * m2;
+            const float t0x = r[80 + l] + r[84 + l], t0y = r[88 + l] + r[68 + l], t0z = r[72 + l] + r[76 + l];
+            const float t1x = y * r[68 + l] + z * r[72 + l], t1y = z * r[76 + l] + x * r[80 + l], t1z = x * r[84 + l] + y * r[88 + l];
+            om += m4 * (1.5f * (x * (3.0f * r[52 + l] + t0x) + y * (3.0f * r[56 + l] + t0y) + z * (3.0f * r[60 + l] + t0z))
+                        - 7.5f * ((x3 * r[52 + l] + y3 * r[56 + l] + z3 * r[60 + l]) + x * y * z * r[64 + l] + (x2 * t1x + y2 * t1y + z2 * t1z)));
+            use = isfinite(om);
+        }
+        if (!use) { om = 0.f; descend |= 1u << l; }
+        sum = l == 0 ? om : sum + om;
+    }
+    A = sum;
+    return descend;
+}
 __device__ inline float mesh_solid_angle(const DevMesh *m, float qx, float qy, float qz) {
 #pragma clang fp contract(off)
     const float acc2 = MESH_FWN_ACCURACY * MESH_FWN_ACCURACY;
-    int stk[MESH_STACK];
+    int f_node[MESH_FRAMES];
+    unsigned f_bits[MESH_FRAMES];
+    float f_A[MESH_FRAMES], f_D[MESH_FRAMES];
+    float A;
+    unsigned d = mesh_node_pre(m, 0, qx, qy, qz, acc2, A);
+    if (!d) return A;
     int sp = 0;
-    float total = 0.f;
-    stk[sp++] = 0;
-    while (sp > 0) {
-        const int nodei = stk[--sp];
-        const float *r = m->fwn_box + (size_t)92 * nodei;
-        const int *ch = m->fwn_child + 4 * nodei;
-        for (int l = 0; l < 4; l++) {
-            const int ci = ch[l];
-            if (ci == -1) break;                                  // empty children are last
-            float x = qx - r[4 + l], y = qy - r[8 + l], z = qz - r[12 + l];
-            const float ql2 = x * x + y * y + z * z;
-            if (!(ql2 <= r[l] * acc2)) {
-                const float m2 = 1.0f / ql2, m1 = sqrtf(m2);
-                x *= m1; y *= m1; z *= m1;
-                float om = -m2 * (x * r[16 + l] + y * r[20 + l] + z * r[24 + l]);
-                const float x2 = x * x, y2 = y * y, z2 = z * z;
-                const float m3 = m2 * m1;
-                om += m3 * (r[28 + l] + r[32 + l] + r[36 + l]
-                            - 3.0f * ((x2 * r[28 + l] + y2 * r[32 + l] + z2 * r[36 + l]) + x * y * r[40 + l] + x * z * r[48 + l] + y * z * r[44 + l]));
-                const float x3 = x2 * x, y3 = y2 * y, z3 = z2 * z;
-                const float m4 = m2 * m2;
-                const float t0x = r[80 + l] + r[84 + l], t0y = r[88 + l] + r[68 + l], t0z = r[72 + l] + r[76 + l];
-                const float t1x = y * r[68 + l] + z * r[72 + l], t1y = z * r[76 + l] + x * r[80 + l], t1z = x * r[84 + l] + y * r[88 + l];
-                om += m4 * (1.5f * (x * (3.0f * r[52 + l] + t0x) + y * (3.0f * r[56 + l] + t0y) + z * (3.0f * r[60 + l] + t0z))
-                            - 7.5f * ((x3 * r[52 + l] + y3 * r[56 + l] + z3 * r[60 + l]) + x * y * z * r[64 + l] + (x2 * t1x + y2 * t1y + z2 * t1z)));
-                if (isfinite(om)) { total += om; continue; }
-            }
-            if (ci < 0) stk[sp++] = ci & 0x7fffffff;
-            else total += mesh_tri_solid_angle(m->trif + (size_t)9 * ci, qx, qy, qz);
+    f_node[0] = 0; f_bits[0] = d; f_A[0] = A; f_D[0] = 0.f;
+    for (;;) {
+        const unsigned bits = f_bits[sp];
+        if (bits == 0) {                                          // every lane of this node visited: post()
+            const float v = f_A[sp] + f_D[sp];
+            if (sp == 0) return v;
+            --sp;
+            f_D[sp] += v;
+            continue;
+        }
+        const int l = __ffs(bits) - 1;
+        f_bits[sp] = bits & (bits - 1);
+        const int ci = m->fwn_child[4 * f_node[sp] + l];
+        if (ci >= 0) f_D[sp] += mesh_tri_solid_angle(m->trif + (size_t)9 * ci, qx, qy, qz);
+        else {
+            const int child = ci & 0x7fffffff;
+            float A2;
+            const unsigned d2 = mesh_node_pre(m, child, qx, qy, qz, acc2, A2);
+            if (!d2) f_D[sp] += A2;
+            else { ++sp; f_node[sp] = child; f_bits[sp] = d2; f_A[sp] = A2; f_D[sp] = 0.f; }
         }
     }
-    return total;
 }
 
 // squared distance to the closest triangle and that point: branch and bound over the hierarchy's bounding spheres

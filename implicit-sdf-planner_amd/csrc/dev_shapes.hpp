@@ -13,6 +13,7 @@ namespace isdf {
 
 // mesh kind (functions in dev_mesh.hpp)
 constexpr int MESH_STACK = 64;             // per-lane traversal stack: >= 3 * depth + 1, checked by isdf_set_shape
+constexpr int MESH_FRAMES = (MESH_STACK - 1) / 3;      // frames of the winding-number walk: one per level of the hierarchy
 constexpr float MESH_FWN_ACCURACY = 2.0f;  // accuracy_scale of igl::fast_winding_number(fwn_bvh, 2.0, ...), Shape.cpp:110
 struct DevMesh {
     const double *tri;   // nF x 9: a.xyz b.xyz c.xyz

@@ -93,6 +93,17 @@ struct isdf_ctx {
         unsigned *d_cspace = nullptr;                                                    // 4 dwords per voxel
     } fe;
     struct isdf_xchg *xchg = nullptr;           // peer-to-peer exchange of the multi-GPU path (csrc/xchg.hip)
+    // ONE host process driving SEVERAL devices (isdf_create_multi): this ctx is the lead (shard 0 of n on devices[0]) and owns
+    // one plain ctx per further device (shard r of n).  Once-per-plan state set on the lead is replicated; a step launches every
+    // shard on its own device's stream from the calling thread and sums the shards' packed outputs on the lead (one kernel
+    // reading the peers' buffers over xGMI in rank order, or RCCL's all-reduce) - SURVEY 8(b) "Threading".
+    std::vector<isdf_ctx *> peers;
+    bool is_peer = false;                       // owned by a lead: not handed to the caller
+    hipEvent_t mev_in = nullptr, mev_done = nullptr;      // lead: inputs ready on the caller's stream; peer: shard finished
+    int multi_collective = 0;                   // ISDF_MULTI_*: how the shards' outputs are summed
+    void *rccl_lib = nullptr; void *rccl_comm = nullptr;  // RCCL by dlopen (only when asked for): this device's communicator
+    double *d_mpart = nullptr; size_t mpart_cap = 0;     // every shard of a multi-device step writes [packed outputs | 8 statistics as doubles] here
+    double *d_mstage = nullptr; size_t mstage_cap = 0;   // lead, staged mode: the peers' parts copied next to each other
 };
 namespace isdf { struct XFuse; }
 // xchg.hip: fills the in-kernel exchange block of a fused step when isdf_xchg_fuse is on (returns false: not requested;
@@ -104,6 +115,15 @@ void isdf_xchg_reset_board(isdf_ctx *c);  // xchg.hip: empties this rank's board
 int isdf_reset_result_slots(isdf_ctx *c); // isdf_host.hip: drains the device and empties every self-resetting slot again (after an overflow)
 void isdf_xchg_release(isdf_ctx *c);          // xchg.hip: closes the peer mappings, frees the mailbox (isdf_destroy)
 void isdf_frontend_release(isdf_ctx *c);      // frontend.hip: frees the tables (isdf_destroy)
+
+// every setter of once-per-plan state ends with this: the same call on every owned peer ctx (isdf_create_multi)
+#define ISDF_REPLICATE(ctx, call)                                                                  \
+    do {                                                                                           \
+        for (isdf_ctx *p_ : (ctx)->peers) {                                                        \
+            const int r_ = (call);                                                                 \
+            if (r_ != ISDF_OK) { (ctx)->err = "device " + std::to_string(p_->device) + ": " + p_->err; return r_; } \
+        }                                                                                          \
+    } while (0)
 
 #define HIPCHK(ctx, call)                                                                          \
     do {                                                                                           \

@@ -5,6 +5,7 @@
 #include "isdf_ctx.hpp"
 #include "lbfgs_host.hpp"
 #include <atomic>
+#include <dlfcn.h>
 #include <chrono>
 #include <cmath>
 #include <cstdio>
@@ -156,9 +157,13 @@ static void free_mesh(isdf_ctx *c) {
     c->d_mesh = nullptr; c->d_mesh_tri = nullptr; c->d_mesh_trif = nullptr; c->d_fwn_child = nullptr; c->d_fwn_box = nullptr;
 }
 
+static void multi_release(isdf_ctx *c);
 extern "C" int isdf_destroy(isdf_ctx *c) {
     if (!c) return ISDF_OK;
+    for (isdf_ctx *p : c->peers) { p->is_peer = false; (void)isdf_destroy(p); }
+    c->peers.clear();
     (void)hipSetDevice(c->device);
+    multi_release(c);
     (void)hipDeviceSynchronize();
     for (auto &p : c->prof_events) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); (void)hipEventDestroy(p.c); (void)hipEventDestroy(p.d); }
     if (c->h_pin) (void)hipHostFree(c->h_pin);
@@ -225,6 +230,7 @@ extern "C" int isdf_set_grid(isdf_ctx *c, const void *vox, int dtype, int nx, in
     c->grid.esdf = c->d_esdf;
     c->grid.occ = c->d_occ;
     c->bits_dirty = true;
+    ISDF_REPLICATE(c, isdf_set_grid(p_, vox, dtype, nx, ny, nz, origin, bmax, res, kind));
     return ISDF_OK;
 }
 
@@ -325,6 +331,7 @@ extern "C" int isdf_set_shape(isdf_ctx *c, const isdf_shape *s) {
     c->shape_host.mesh_vertices = nullptr;
     c->shape_host.mesh_faces = nullptr;
     c->have_shape = true;
+    ISDF_REPLICATE(c, isdf_set_shape(p_, s));
     return ISDF_OK;
 }
 
@@ -342,12 +349,14 @@ extern "C" int isdf_set_points(isdf_ctx *c, const double *xyz, int M) {
         HIPCHK(c, hipMalloc(&c->d_tstar, (size_t)M * sizeof(double)));
         HIPCHK(c, hipMemset(c->d_tstar, 0, (size_t)M * sizeof(double)));   // lastTstar starts at 0 (plan_manager.cpp:254)
     }
+    ISDF_REPLICATE(c, isdf_set_points(p_, xyz, M));
     return ISDF_OK;
 }
 
 extern "C" int isdf_set_shard(isdf_ctx *c, int rank, int world) {
     if (!c) return ISDF_ERR_INVALID_ARG;
     if (world < 1 || rank < 0 || rank >= world) return fail(c, ISDF_ERR_INVALID_ARG, "bad shard");
+    if (!c->peers.empty() || c->is_peer) return fail(c, ISDF_ERR_STATE, "a multi-device ctx (isdf_create_multi) shards by itself");
     c->rank = rank; c->world = world;
     return ISDF_OK;
 }
@@ -430,6 +439,12 @@ int isdf_reset_result_slots(isdf_ctx *c) {
     if (c->d_piece_cost) HIPCHK(c, hipMemset(c->d_piece_cost, 0xFF, c->piece_cap * sizeof(double)));
     isdf_xchg_reset_board(c);
     HIPCHK(c, hipDeviceSynchronize());
+    for (isdf_ctx *p : c->peers) {                  // a multi-device ctx: the peers' sticky overflow words and slots as well
+        const int rc = isdf_reset_result_slots(p);
+        if (rc) { c->err = p->err; return rc; }
+        HIPCHK(c, hipMemset(p->d_stats + 4, 0, sizeof(unsigned long long)));
+    }
+    if (!c->peers.empty()) HIPCHK(c, hipSetDevice(c->device));
     return ISDF_OK;
 }
 
@@ -705,10 +720,219 @@ static int eval_device_impl(isdf_ctx *c, int n_traj, int N, const double *d_T, c
     return ISDF_OK;
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------
+// ONE host process, SEVERAL devices (isdf_create_multi; SURVEY 8(b) "Threading": launch -> all-reduce -> D2H from the calling
+// thread, no extra host threads).  The lead ctx is shard 0 on devices[0]; every further device has a plain ctx of its own
+// (shard r of n) that the lead owns.  A step: the inputs go to every device (peer copies ordered behind the caller's stream by
+// an event), every shard is queued on its own device's stream FROM THE CALLING THREAD, every shard leaves [packed outputs | its 8
+// statistics words as doubles] in its part buffer, and the parts are summed on the lead in rank order -
+//   ISDF_MULTI_PEER_SUM  one kernel on the lead that reads the peers' parts straight over xGMI (peer access),
+//   ISDF_MULTI_STAGED    peer copies into a staging buffer on the lead + the same kernel locally (no peer access needed),
+//   ISDF_MULTI_RCCL      ncclAllReduce(sum, ncclDouble) over the part buffers in one group call (librccl.so by dlopen, so the
+//                        library neither links nor needs RCCL unless asked: ISDF_MULTI_COLLECTIVE=rccl),
+// after which the caller's stream holds the full [cost | gradT | gradC] - exactly what the single-device step leaves.
+// ---------------------------------------------------------------------------------------------------------------------------
+constexpr int MULTI_TAIL = 8;
+struct MultiParts { const double *p[XCHG_MAX_WORLD]; int n; };
+// the 8 statistics words of a shard behind its packed outputs, as doubles: they ride through whichever sum is in force
+__global__ void multi_tail_kernel(const unsigned long long *stats, double *tail) {
+    if (threadIdx.x < MULTI_TAIL) tail[threadIdx.x] = (double)stats[threadIdx.x];
+}
+// out[i] = part_0[i] + part_1[i] + ... (rank order: bitwise reproducible); the summed tail back into the lead's statistics words
+__global__ __launch_bounds__(256) void multi_sum_kernel(double *out, MultiParts parts, size_t count, unsigned long long *stats) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < count + MULTI_TAIL) {
+        double s = parts.p[0][i];
+        for (int r = 1; r < parts.n; r++) s += parts.p[r][i];
+        if (i < count) out[i] = s;
+        else {
+            const int k = (int)(i - count);
+            if (k == 4) { if (s != 0.0) stats[4] = 1ull; }                 // overflow: sticky until read
+            else stats[k] = (unsigned long long)s;
+        }
+    }
+}
+
+namespace {
+struct RcclApi {
+    void *lib = nullptr;
+    int (*CommInitAll)(void **, int, const int *) = nullptr;
+    int (*CommDestroy)(void *) = nullptr;
+    int (*AllReduce)(const void *, void *, size_t, int, int, void *, hipStream_t) = nullptr;
+    int (*GroupStart)() = nullptr;
+    int (*GroupEnd)() = nullptr;
+    const char *(*GetErrorString)(int) = nullptr;
+};
+RcclApi g_rccl;
+bool rccl_load() {
+    if (g_rccl.lib) return g_rccl.AllReduce != nullptr;
+    for (const char *name : {"librccl.so", "librccl.so.1", "/opt/rocm/lib/librccl.so"}) { g_rccl.lib = dlopen(name, RTLD_NOW | RTLD_LOCAL); if (g_rccl.lib) break; }
+    if (!g_rccl.lib) return false;
+    g_rccl.CommInitAll = (int (*)(void **, int, const int *))dlsym(g_rccl.lib, "ncclCommInitAll");
+    g_rccl.CommDestroy = (int (*)(void *))dlsym(g_rccl.lib, "ncclCommDestroy");
+    g_rccl.AllReduce = (int (*)(const void *, void *, size_t, int, int, void *, hipStream_t))dlsym(g_rccl.lib, "ncclAllReduce");
+    g_rccl.GroupStart = (int (*)())dlsym(g_rccl.lib, "ncclGroupStart");
+    g_rccl.GroupEnd = (int (*)())dlsym(g_rccl.lib, "ncclGroupEnd");
+    g_rccl.GetErrorString = (const char *(*)(int))dlsym(g_rccl.lib, "ncclGetErrorString");
+    if (!g_rccl.CommInitAll || !g_rccl.CommDestroy || !g_rccl.AllReduce || !g_rccl.GroupStart || !g_rccl.GroupEnd) { g_rccl.AllReduce = nullptr; return false; }
+    return true;
+}
+}  // namespace
+
+static void multi_release(isdf_ctx *c) {
+    if (c->rccl_comm && g_rccl.CommDestroy) { (void)g_rccl.CommDestroy(c->rccl_comm); c->rccl_comm = nullptr; }
+    if (c->mev_in) { (void)hipEventDestroy(c->mev_in); c->mev_in = nullptr; }
+    if (c->mev_done) { (void)hipEventDestroy(c->mev_done); c->mev_done = nullptr; }
+    if (c->d_mpart) { (void)hipFree(c->d_mpart); c->d_mpart = nullptr; }
+    if (c->d_mstage) { (void)hipFree(c->d_mstage); c->d_mstage = nullptr; }
+}
+
+extern "C" int isdf_create_multi(isdf_ctx **out, const isdf_config *cfg, const int *devices, int n_devices) {
+    if (!out || !cfg || !devices) return fail(nullptr, ISDF_ERR_INVALID_ARG, "null argument");
+    *out = nullptr;
+    if (n_devices < 1 || n_devices > XCHG_MAX_WORLD) return fail(nullptr, ISDF_ERR_INVALID_ARG, "1 .. 16 devices");
+    std::vector<isdf_ctx *> all;
+    auto bail = [&](int code, const std::string &msg) { for (isdf_ctx *q : all) { q->is_peer = false; q->peers.clear(); (void)isdf_destroy(q); } return fail(nullptr, code, msg.c_str()); };
+    for (int r = 0; r < n_devices; r++) {
+        isdf_config cr = *cfg;
+        cr.device = devices[r];
+        isdf_ctx *q = nullptr;
+        const int rc = isdf_create(&q, &cr);
+        if (rc != ISDF_OK) return bail(rc, std::string("device ") + std::to_string(devices[r]) + ": " + isdf_last_error(nullptr));
+        all.push_back(q);
+        q->rank = r; q->world = n_devices;
+        if (hipSetDevice(q->device) != hipSuccess || hipEventCreateWithFlags(&q->mev_done, hipEventDisableTiming) != hipSuccess ||
+            hipEventCreateWithFlags(&q->mev_in, hipEventDisableTiming) != hipSuccess)
+            return bail(ISDF_ERR_HIP, "event creation failed");
+    }
+    isdf_ctx *lead = all[0];
+    // how the parts are summed: the lead reads the peers' buffers directly when every peer is reachable
+    int mode = ISDF_MULTI_PEER_SUM;
+    (void)hipSetDevice(lead->device);
+    for (int r = 1; r < n_devices && mode == ISDF_MULTI_PEER_SUM; r++) {
+        if (devices[r] == lead->device) continue;                         // the same device listed again (tests): plain pointers
+        int can = 0;
+        if (hipDeviceCanAccessPeer(&can, lead->device, devices[r]) != hipSuccess || !can) { mode = ISDF_MULTI_STAGED; break; }
+        const hipError_t e = hipDeviceEnablePeerAccess(devices[r], 0);
+        if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled) mode = ISDF_MULTI_STAGED;
+        (void)hipGetLastError();
+    }
+    if (const char *e = getenv("ISDF_MULTI_COLLECTIVE")) {
+        if (!std::strcmp(e, "staged")) mode = ISDF_MULTI_STAGED;
+        else if (!std::strcmp(e, "peer")) { if (mode != ISDF_MULTI_PEER_SUM) return bail(ISDF_ERR_UNSUPPORTED, "ISDF_MULTI_COLLECTIVE=peer: no peer access between the listed devices"); }
+        else if (!std::strcmp(e, "rccl")) {
+            for (int a = 0; a < n_devices; a++) for (int b = a + 1; b < n_devices; b++)
+                if (devices[a] == devices[b]) return bail(ISDF_ERR_UNSUPPORTED, "ISDF_MULTI_COLLECTIVE=rccl needs DISTINCT devices (one communicator rank per GPU)");
+            if (!rccl_load()) return bail(ISDF_ERR_UNSUPPORTED, "ISDF_MULTI_COLLECTIVE=rccl: librccl.so could not be loaded");
+            std::vector<void *> comms(n_devices, nullptr);
+            const int rr = g_rccl.CommInitAll(comms.data(), n_devices, devices);
+            if (rr != 0) return bail(ISDF_ERR_UNSUPPORTED, std::string("ncclCommInitAll: ") + (g_rccl.GetErrorString ? g_rccl.GetErrorString(rr) : "failed") + " (one communicator per DISTINCT device)");
+            for (int r = 0; r < n_devices; r++) all[r]->rccl_comm = comms[r];
+            mode = ISDF_MULTI_RCCL;
+        } else return bail(ISDF_ERR_INVALID_ARG, "ISDF_MULTI_COLLECTIVE must be peer, staged or rccl");
+    }
+    for (int r = 1; r < n_devices; r++) { all[r]->is_peer = true; lead->peers.push_back(all[r]); }
+    lead->multi_collective = mode;
+    (void)hipSetDevice(lead->device);
+    *out = lead;
+    return ISDF_OK;
+}
+extern "C" int isdf_multi_info(const isdf_ctx *c, int *n_devices_out, int *collective_out) {
+    if (!c) return ISDF_ERR_INVALID_ARG;
+    if (n_devices_out) *n_devices_out = 1 + (int)c->peers.size();
+    if (collective_out) *collective_out = c->peers.empty() ? ISDF_MULTI_NONE : c->multi_collective;
+    return ISDF_OK;
+}
+
+// One step on every device.  d_T / d_coeffs / d_out / d_tstar live on the LEAD's device and are ordered on `st` (a stream of the
+// lead's device) like in the single-device call.
+static int multi_eval_device(isdf_ctx *c, int n_traj, int N, const double *d_T, const double *d_coeffs, double *d_out,
+                             double *d_tstar, hipStream_t st, int mode, bool fixed_tstar) {
+    const int n = 1 + (int)c->peers.size();
+    const size_t count = (size_t)n_traj * isdf_out_stride(N), in_T = (size_t)n_traj * N, in_C = (size_t)n_traj * 18 * N;
+    const bool swept = c->cfg.variant == ISDF_V1_SWEPT && mode != 2;
+    if (fixed_tstar) return fail(c, ISDF_ERR_UNSUPPORTED, "isdf_eval_swept_at_tstar on a multi-device ctx");
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipEventRecord(c->mev_in, st));                              // the caller's inputs are ready from here on
+    double *lead_ts = swept ? (d_tstar ? d_tstar : c->d_tstar) : nullptr;
+    MultiParts parts{};
+    parts.n = n;
+    for (int r = 1; r < n; r++) {
+        isdf_ctx *p = c->peers[r - 1];
+        HIPCHK(c, hipSetDevice(p->device));
+        int rc = ensure(p, &p->d_in, &p->in_cap, in_T + in_C);
+        if (rc == ISDF_OK) rc = ensure(p, &p->d_mpart, &p->mpart_cap, count + MULTI_TAIL);
+        if (rc) { c->err = p->err; return rc; }
+        HIPCHK(c, hipStreamWaitEvent(p->stream, c->mev_in, 0));
+        HIPCHK(c, hipMemcpyPeerAsync(p->d_in, p->device, d_T, c->device, in_T * sizeof(double), p->stream));
+        HIPCHK(c, hipMemcpyPeerAsync(p->d_in + in_T, p->device, d_coeffs, c->device, in_C * sizeof(double), p->stream));
+        long long pb = 0, pe = 0;
+        if (swept && p->M > 0) {                                           // lastTstar of this shard's points travels with it
+            shard_range(p->M, p->rank, p->world, pb, pe);
+            if (pe > pb && lead_ts) HIPCHK(c, hipMemcpyPeerAsync(p->d_tstar + pb, p->device, lead_ts + pb, c->device, (size_t)(pe - pb) * sizeof(double), p->stream));
+        }
+        rc = eval_device_impl(p, n_traj, N, p->d_in, p->d_in + in_T, p->d_mpart, nullptr, p->stream, mode, false);
+        if (rc) { c->err = "device " + std::to_string(p->device) + ": " + p->err; return rc; }
+        hipLaunchKernelGGL(multi_tail_kernel, dim3(1), dim3(64), 0, p->stream, p->d_stats, p->d_mpart + count);
+        if (swept && pe > pb && lead_ts) HIPCHK(c, hipMemcpyPeerAsync(lead_ts + pb, c->device, p->d_tstar + pb, p->device, (size_t)(pe - pb) * sizeof(double), p->stream));
+        HIPCHK(c, hipEventRecord(p->mev_done, p->stream));
+        parts.p[r] = p->d_mpart;
+    }
+    HIPCHK(c, hipSetDevice(c->device));
+    int rc = ensure(c, &c->d_mpart, &c->mpart_cap, count + MULTI_TAIL);
+    if (rc) return rc;
+    rc = eval_device_impl(c, n_traj, N, d_T, d_coeffs, c->d_mpart, d_tstar, st, mode, false);
+    if (rc) return rc;
+    hipLaunchKernelGGL(multi_tail_kernel, dim3(1), dim3(64), 0, st, c->d_stats, c->d_mpart + count);
+    parts.p[0] = c->d_mpart;
+    const dim3 grid((unsigned)((count + MULTI_TAIL + 255) / 256)), block(256);
+    if (c->multi_collective == ISDF_MULTI_RCCL) {
+        // ONE all-reduce of the packed vector per step: every device's part in place, issued from this thread as one group
+        for (int r = 1; r < n; r++) HIPCHK(c, hipStreamWaitEvent(st, c->peers[r - 1]->mev_done, 0));      // (the merged lastTstar)
+        if (g_rccl.GroupStart() != 0) return fail(c, ISDF_ERR_HIP, "ncclGroupStart failed");
+        for (int r = 0; r < n; r++) {
+            isdf_ctx *q = r == 0 ? c : c->peers[r - 1];
+            hipStream_t qs = r == 0 ? st : q->stream;
+            if (r > 0) HIPCHK(c, hipSetDevice(q->device));
+            const int rr = g_rccl.AllReduce(q->d_mpart, q->d_mpart, count + MULTI_TAIL, 8 /* ncclDouble */, 0 /* ncclSum */, q->rccl_comm, qs);
+            if (rr != 0) { (void)g_rccl.GroupEnd(); return fail(c, ISDF_ERR_HIP, "ncclAllReduce failed"); }
+        }
+        if (g_rccl.GroupEnd() != 0) return fail(c, ISDF_ERR_HIP, "ncclGroupEnd failed");
+        HIPCHK(c, hipSetDevice(c->device));
+        MultiParts one{}; one.n = 1; one.p[0] = c->d_mpart;
+        hipLaunchKernelGGL(multi_sum_kernel, grid, block, 0, st, d_out, one, count, c->d_stats);
+    } else {
+        for (int r = 1; r < n; r++) HIPCHK(c, hipStreamWaitEvent(st, c->peers[r - 1]->mev_done, 0));
+        if (c->multi_collective == ISDF_MULTI_STAGED) {
+            rc = ensure(c, &c->d_mstage, &c->mstage_cap, (size_t)(n - 1) * (count + MULTI_TAIL));
+            if (rc) return rc;
+            for (int r = 1; r < n; r++) {
+                double *dst = c->d_mstage + (size_t)(r - 1) * (count + MULTI_TAIL);
+                HIPCHK(c, hipMemcpyPeerAsync(dst, c->device, c->peers[r - 1]->d_mpart, c->peers[r - 1]->device, (count + MULTI_TAIL) * sizeof(double), st));
+                parts.p[r] = dst;
+            }
+        }
+        hipLaunchKernelGGL(multi_sum_kernel, grid, block, 0, st, d_out, parts, count, c->d_stats);
+    }
+    HIPCHK(c, hipGetLastError());
+    // the next step's peer copies overwrite the peers' inputs: they are ordered behind THIS step's kernels by the peers' own
+    // streams, and the lead's part buffer behind `st`
+    return ISDF_OK;
+}
+
+// every sweep of the host paths goes through here
+static int sweep_dispatch(isdf_ctx *c, int n_traj, int N, const double *d_T, const double *d_coeffs, double *d_out, double *d_tstar,
+                          hipStream_t st, int mode = 0, bool fixed_tstar = false) {
+    // (a one-device ctx created with the RCCL collective takes the multi-device path too: the all-reduce of a world of one)
+    if (!c->peers.empty() || c->rccl_comm) return multi_eval_device(c, n_traj, N, d_T, d_coeffs, d_out, d_tstar, st, mode, fixed_tstar);
+    return eval_device_impl(c, n_traj, N, d_T, d_coeffs, d_out, d_tstar, st, mode, fixed_tstar);
+}
+
 extern "C" int isdf_eval_device(isdf_ctx *c, int n_traj, int N, const double *d_T, const double *d_coeffs, double *d_out,
                                 double *d_tstar, void *stream) {
     if (!c) return ISDF_ERR_INVALID_ARG;
-    return eval_device_impl(c, n_traj, N, d_T, d_coeffs, d_out, d_tstar, (hipStream_t)stream);
+    if (c->is_peer) return fail(c, ISDF_ERR_STATE, "this ctx belongs to a multi-device ctx");
+    return sweep_dispatch(c, n_traj, N, d_T, d_coeffs, d_out, d_tstar, (hipStream_t)stream);
 }
 
 // The swept-volume sweep's back-prop with the minimisers GIVEN: for every obstacle point the robot SDF and its body-frame
@@ -971,7 +1195,7 @@ extern "C" int isdf_eval(isdf_ctx *c, int n_traj, const int *N, const double *co
             dts = c->d_tstar;
             HIPCHK(c, hipMemcpyAsync(dts, tstar_inout, (size_t)c->M * sizeof(double), hipMemcpyHostToDevice, c->stream));
         }
-        rc = eval_device_impl(c, nb, n, dT, dC, c->d_out, dts, c->stream);
+        rc = sweep_dispatch(c, nb, n, dT, dC, c->d_out, dts, c->stream);
         if (rc) return rc;
         HIPCHK(c, hipMemcpyAsync(hout, c->d_out, out_all * sizeof(double), hipMemcpyDeviceToHost, c->stream));
         HIPCHK(c, hipMemcpyAsync(hstat, c->d_stats, 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost, c->stream));
@@ -1095,11 +1319,11 @@ static int cost_function_launch(isdf_ctx *c, const double *x, int n, hipStream_t
     HIPCHK(c, hipMemcpyAsync(c->d_cb, c->h_pin, in_len * sizeof(double), hipMemcpyHostToDevice, st));
     double *d_T = c->d_cb, *d_C = c->d_cb + N, *d_o = c->d_cb + in_len;
     if (swept) {
-        rc = eval_device_impl(c, 1, N, d_T, d_C, d_o, nullptr, st, 1);
+        rc = sweep_dispatch(c, 1, N, d_T, d_C, d_o, nullptr, st, 1);
         if (rc) return rc;
-        rc = eval_device_impl(c, 1, N, d_T, d_C, d_o + ostride, nullptr, st, 2);
+        rc = sweep_dispatch(c, 1, N, d_T, d_C, d_o + ostride, nullptr, st, 2);
     } else {
-        rc = eval_device_impl(c, 1, N, d_T, d_C, d_o, nullptr, st, 0);
+        rc = sweep_dispatch(c, 1, N, d_T, d_C, d_o, nullptr, st, 0);
     }
     if (rc) return rc;
     c->cb_pending = true;
@@ -1161,7 +1385,7 @@ extern "C" int isdf_cost_function(isdf_ctx *c, const double *x, double *g, int n
     if (!x || !g || !cost_out) return fail(c, ISDF_ERR_INVALID_ARG, "null argument");
     // a sharded ctx returns only this rank's partial sums from the sweeps: the un-split callback (and the drivers built on it)
     // would optimise on them without any error - the split form (_launch / all-reduce / _finish) is the one to use
-    if (c->world > 1 && !isdf_xchg_fuse_on(c))
+    if (c->world > 1 && c->peers.empty() && !isdf_xchg_fuse_on(c))
         return fail(c, ISDF_ERR_STATE, "sharded ctx: use isdf_cost_function_launch / _finish around the all-reduce (or switch the in-kernel exchange on)");
     const int rc = cost_function_launch(c, x, n, c->stream, true);
     if (rc) return rc;
@@ -1298,6 +1522,18 @@ extern "C" int isdf_get_stats(isdf_ctx *c, isdf_stats *out) {
         HIPCHK(c, hipDeviceSynchronize());
         int rc = fetch_stats(c);
         if (rc) return rc;
+        if (c->cfg.variant != ISDF_V1_SWEPT) {                 // (the V1 words of a multi-device step are already the devices' sums)
+            for (isdf_ctx *p : c->peers) {
+                HIPCHK(c, hipSetDevice(p->device));
+                HIPCHK(c, hipDeviceSynchronize());
+                rc = fetch_stats(p);
+                if (rc) { c->err = p->err; return rc; }
+                c->last_stats.n_units += p->last_stats.n_units; c->last_stats.n_units_culled += p->last_stats.n_units_culled;
+                c->last_stats.n_pairs += p->last_stats.n_pairs; c->last_stats.n_grad_pairs += p->last_stats.n_grad_pairs;
+                c->last_stats.overflow |= p->last_stats.overflow;
+            }
+            HIPCHK(c, hipSetDevice(c->device));
+        }
     }
     *out = c->last_stats;
     return ISDF_OK;

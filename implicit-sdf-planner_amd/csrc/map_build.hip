@@ -236,6 +236,7 @@ extern "C" int isdf_set_pointcloud(isdf_ctx *c, const float *xyz, long long n_po
     c->grid.esdf = nullptr; c->grid.occ = c->d_occ;
     c->bits_dirty = true;
     if (dims_out) { dims_out[0] = (int)dim[0]; dims_out[1] = (int)dim[1]; dims_out[2] = (int)dim[2]; }
+    ISDF_REPLICATE(c, isdf_set_pointcloud(p_, xyz, n_points, bmin_opt, bmax_opt, resolution, sta_threshold, nullptr));
     return ISDF_OK;
 }
 
@@ -262,6 +263,7 @@ extern "C" int isdf_generate_esdf(isdf_ctx *c) {
     (void)hipFree(a); (void)hipFree(b); (void)hipFree(bits);
     c->grid.esdf = c->d_esdf;
     c->bits_dirty = true;
+    ISDF_REPLICATE(c, isdf_generate_esdf(p_));
     return ISDF_OK;
 }
 
@@ -356,6 +358,7 @@ extern "C" int isdf_gather_points(isdf_ctx *c, const double *waypoints, int n_wa
     }
     c->M = M;
     if (M_out) *M_out = M;
+    ISDF_REPLICATE(c, isdf_gather_points(p_, waypoints, n_waypoints, half, offset_opt, nullptr));      // the same ordered set on every device
     return ISDF_OK;
 }
 

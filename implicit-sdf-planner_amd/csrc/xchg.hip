@@ -121,6 +121,7 @@ static void xchg_free(isdf_ctx *c) {
 void isdf_xchg_release(isdf_ctx *c) { xchg_free(c); }
 
 extern "C" int isdf_xchg_create(isdf_ctx *c, int rank, int world, size_t max_doubles, void *handle_out64) {
+    if (c && (!c->peers.empty() || c->is_peer)) return isdf_fail(c, ISDF_ERR_STATE, "a multi-device ctx (isdf_create_multi) exchanges by itself");
     if (!c) return ISDF_ERR_INVALID_ARG;
     if (world < 2 || world > XCHG_MAX_WORLD || rank < 0 || rank >= world || max_doubles == 0 || !handle_out64) return isdf_fail(c, ISDF_ERR_INVALID_ARG, "bad exchange setup");
     static_assert(sizeof(hipIpcMemHandle_t) == 64, "IPC handle size");

@@ -56,11 +56,16 @@ def lbfgs_minimize(fun, x0, lib=None, **params):
 
 
 class Engine:
-    def __init__(self, cfg, lib=None):
+    def __init__(self, cfg, lib=None, devices=None):
+        """devices: None = one device (cfg.device); a list = ONE ctx over those devices (isdf_create_multi), used like any other."""
         self.lib = lib or capi.load_library()
         self.cfg = cfg
         h = C.c_void_p()
-        rc = self.lib.isdf_create(C.byref(h), C.byref(cfg))
+        if devices is None:
+            rc = self.lib.isdf_create(C.byref(h), C.byref(cfg))
+        else:
+            dv = (C.c_int * len(devices))(*[int(d) for d in devices])
+            rc = self.lib.isdf_create_multi(C.byref(h), C.byref(cfg), dv, len(devices))
         if rc != capi.ISDF_OK:
             msg = self.lib.isdf_last_error(None)
             raise IsdfError(rc, (msg or b"").decode())
@@ -361,6 +366,11 @@ class Engine:
         self._check(self.lib.isdf_minco_device(self.h, nt, N, _p(H), _p(Tl), float(rho), _p(xs), None if so is None else _p(so),
                                                _p(T), _p(Cc), _p(res)))
         return T, Cc, res[:, 0].copy(), res[:, 1:].copy()
+
+    def multi_info(self):
+        n = C.c_int(0); m = C.c_int(0)
+        self._check(self.lib.isdf_multi_info(self.h, C.byref(n), C.byref(m)))
+        return n.value, m.value
 
     def host_path(self):
         """How the last host-array step crossed PCIe (capi.HOST_PATH_*)."""

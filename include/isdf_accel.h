@@ -145,6 +145,26 @@ int isdf_shape_from_name(isdf_shape *shape, const char *obj_stem); /* registry l
                                                               e.g. "RoundedCone", "Torus_big"; <0 if the
                                                               stem is not an analytic shape (=> mesh)     */
 int isdf_create(isdf_ctx **out, const isdf_config *cfg);
+/* ONE host process driving n_devices GPUs (SURVEY.md 8(b) "Threading"; the reference's caller is one ROS process,
+ * back_end_optimizer.hpp:386-391,399-405): the returned ctx is used EXACTLY like a single-device one - cfg.device is ignored,
+ * devices[0] is where device-resident arguments of isdf_eval_device live.  Once-per-plan state (isdf_set_grid / _shape /
+ * _points / _pointcloud / _generate_esdf / _gather_points) is replicated on every device; every step (isdf_eval,
+ * isdf_eval_device, isdf_cost_function[_lmbm], isdf_optimize_lbfgs) shards the constraint points by piece (V2 / V3) or by
+ * obstacle point (V1) like isdf_set_shard would, queues every shard on its own device's stream FROM THE CALLING THREAD (no host
+ * threads are created) and sums the shards' packed [cost | gradT | gradC] on devices[0] - ONE exchange per sweep:
+ *   ISDF_MULTI_PEER_SUM  a kernel on devices[0] reading the peers' buffers over xGMI in rank order (default when peer access
+ *                        exists; bitwise reproducible),
+ *   ISDF_MULTI_STAGED    peer copies to devices[0] + the same sum (no peer access needed),
+ *   ISDF_MULTI_RCCL      one ncclAllReduce(sum, ncclDouble) over all devices (environment ISDF_MULTI_COLLECTIVE=rccl; librccl.so
+ *                        is dlopen-ed then - the library itself does not link RCCL; needs DISTINCT devices).
+ * A device may be listed more than once (the shards then share it: how the single-GPU tests drive this path).
+ * Not available on such a ctx: isdf_set_shard, isdf_xchg_*, isdf_optimize_lbfgs_batch, isdf_eval_swept_at_tstar. */
+#define ISDF_MULTI_NONE 0
+#define ISDF_MULTI_PEER_SUM 1
+#define ISDF_MULTI_STAGED 2
+#define ISDF_MULTI_RCCL 3
+int isdf_create_multi(isdf_ctx **out, const isdf_config *cfg, const int *devices, int n_devices);
+int isdf_multi_info(const isdf_ctx *ctx, int *n_devices_out, int *collective_out);
 int isdf_destroy(isdf_ctx *ctx);
 const char *isdf_last_error(const isdf_ctx *ctx);          /* ctx may be NULL: last create() failure      */
 int isdf_abi_version(void);
