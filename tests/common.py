@@ -76,16 +76,13 @@ def oracle_cost_function(orc, sweeps, head, tail, rho, x, N):
     return total, np.concatenate([g_tau, gP.T.reshape(-1)])
 
 
-# ---- mesh robot x swept-volume sweep: the free-running allowance, CAPPED and LOGGED ------------------------------------------
-# The argmin over t of a mesh SDF (float winding number) is a chain of accept/reject comparisons: the reference's own code does
-# not reproduce its t* / gradients under a device-sized perturbation of w (tests/test_oracle_ref.py::mesh_v1_sensitivity_on).
-# The free-running tests allow the device 2 x that measured spread - but never more than these hard ceilings, and the spread
-# itself has to stay sane, so a noisy scenario or a broken spread function cannot make a test pass vacuously.
-MESH_V1_CAPS = {"gradC": 3e-4, "gradT": 3e-2, "dt_max": 1e-2, "dt_frac_gt_1e-6": 0.03, "cost_rel": 1e-6}     # applied tolerance never above
-MESH_V1_SPREAD_MAX = {"gradC": 2e-2, "gradT": 5e-2, "dt_max": 1e-2, "dt_frac_gt_1e-6": 0.12}                   # the reference's own spread: sanity bound
-MESH_V1_MIN_IDENTICAL = 0.97                                                                                      # share of points whose t* equals the oracle's
-
-
+# ---- mesh robot x swept-volume sweep, free-running -----------------------------------------------------------------------------
+# The argmin over t of a mesh SDF is a chain of accept/reject comparisons on values that differ by less than one float ulp of the
+# winding number: the reference's own code does not reproduce its t* under a 1-ulp perturbation of w
+# (tests/test_oracle_ref.py::test_mesh_swept_volume_argmin_is_sensitive_to_one_ulp_of_w).  Rounds 1-2 therefore allowed the device
+# the reference's measured self-spread.  Since round 3 the device computes w BIT FOR BIT like the reference's library (glibc's
+# atan2f restated, reciprocal-multiply normalisation, the tree-shaped float sum of the HDK traversal: csrc/dev_mesh.hpp), so the
+# free-running tests hold the device to the plain tolerance again: t* identical, gradients at the north-star's 1e-5.
 def _spread_log(line):
     import os
     print("\n[mesh x V1] " + line)
@@ -99,34 +96,14 @@ def _spread_log(line):
         pass
 
 
-def mesh_v1_allowance(what, sp):
-    """sp: the dict of mesh_v1_sensitivity_on.  Returns the tolerances actually applied (2 x the reference's own spread,
-    never below the north-star's 1e-5, never above the hard ceilings)."""
-    tol = {"gradC": min(MESH_V1_CAPS["gradC"], max(REL_TOL, 2 * sp["gradC_rel"])),
-           "gradT": min(MESH_V1_CAPS["gradT"], max(REL_TOL, 2 * sp["gradT_rel"])),
-           "dt_max": min(MESH_V1_CAPS["dt_max"], max(2e-5, 2 * sp["dt_max"])),
-           "dt_frac_gt_1e-6": min(MESH_V1_CAPS["dt_frac_gt_1e-6"], max(0.01, 2 * sp["dt_frac_gt_1e-6"]))}
-    return tol
-
-
-def assert_mesh_v1_free_running(what, sp, tg, to, gT, gT0, gC, gC0):
-    """Device (tg, gT, gC) vs oracle (to, gT0, gC0), free-running argmin, inside the capped allowance.  The reference's measured
-    spread, the tolerance actually applied and the device's measured deviations go to the spread log
-    (gpurun_out/r3_mesh_spread.txt -> profiles/) BEFORE anything is asserted."""
-    tol = mesh_v1_allowance(what, sp)
+def assert_mesh_v1_free_running(what, tg, to, gT, gT0, gC, gC0):
+    """Device (tg, gT, gC) vs oracle (to, gT0, gC0), both searching for their own minimisers: the measured deviations are logged
+    (gpurun_out/r3_mesh_spread.txt -> profiles/), then held to: every t* within 1e-9 s, gradients at REL_TOL."""
     dt = np.abs(np.asarray(tg) - np.asarray(to))
-    moved = float((dt > 1e-6).mean())
+    moved = float((dt > 1e-9).mean())
     eC = float(np.linalg.norm(gC - gC0) / max(np.linalg.norm(gC0), 1e-300)); eT = float(np.linalg.norm(gT - gT0) / max(np.linalg.norm(gT0), 1e-300))
-    _spread_log(f"{what}: points {sp['points']} | reference vs itself (w +- 40 x 2^-23): gradC {sp['gradC_rel']:.3e} gradT {sp['gradT_rel']:.3e} "
-                f"dt_max {sp['dt_max']:.3e} moved {sp['dt_frac_gt_1e-6']:.4f} cost {sp['cost_rel']:.1e} | applied: gradC {tol['gradC']:.3e} "
-                f"gradT {tol['gradT']:.3e} dt_max {tol['dt_max']:.3e} moved <= {tol['dt_frac_gt_1e-6']:.4f} | device vs oracle: gradC {eC:.3e} "
-                f"gradT {eT:.3e} dt_max {dt.max():.3e} moved {moved:.4f} (identical t*: {1 - moved:.2%})")
-    # the spread function itself has to be sane - a noisy scenario or a broken measurement must not pass a test vacuously
-    assert sp["points"] > 0 and all(np.isfinite(v) for v in sp.values()), sp
-    assert sp["cost_rel"] <= MESH_V1_CAPS["cost_rel"], (what, sp)
-    assert sp["gradC_rel"] <= MESH_V1_SPREAD_MAX["gradC"] and sp["gradT_rel"] <= MESH_V1_SPREAD_MAX["gradT"], (what, sp)
-    assert sp["dt_max"] <= MESH_V1_SPREAD_MAX["dt_max"] and sp["dt_frac_gt_1e-6"] <= MESH_V1_SPREAD_MAX["dt_frac_gt_1e-6"], (what, sp)
-    assert 1 - moved >= MESH_V1_MIN_IDENTICAL, f"{what}: only {1 - moved:.2%} of the points keep the oracle's t*"
-    assert dt.max() <= tol["dt_max"] and moved <= tol["dt_frac_gt_1e-6"], (what, dt.max(), moved, tol)
-    assert_close(gC, gC0, what + " gradC", tol=tol["gradC"])
-    assert_close(gT, gT0, what + " gradT", tol=tol["gradT"])
+    _spread_log(f"{what}: {len(dt)} points | device vs oracle, free-running: gradC {eC:.3e} gradT {eT:.3e} dt_max {dt.max():.3e} "
+                f"identical t*: {1 - moved:.2%} | applied: gradC, gradT <= {REL_TOL:g}, every |dt*| <= 1e-9")
+    assert dt.max() <= 1e-9, f"{what}: {moved:.2%} of the points end on another t* (max {dt.max():.3e} s)"
+    assert_close(gC, gC0, what + " gradC")
+    assert_close(gT, gT0, what + " gradT")

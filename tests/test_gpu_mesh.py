@@ -40,9 +40,9 @@ def test_mesh_shape_plugin_vs_reference_library(pkg, orc, product_lib, name):
     Q = _queries(np.asarray(V, dtype=np.float64), rng, 1500)
     s, g = eng.shape_eval(Q)
     s0, g0 = o.shape_eval(Q)
-    # w is float on both sides (UT_SolidAngle<float,float>); device and host differ in the last ulps of atan2f / the sums:
-    # |dw| ~ 4e-7  =>  |d sdf| <= 2 |dw| dist
-    assert np.all(np.abs(s - s0) <= 5e-6 * np.abs(s0) + 4e-6 * np.abs(Q).max()), (name, np.abs(s - s0).max())
+    # w is the library's bit for bit (float atan2 = glibc's, the HDK traversal's tree-shaped sum); what is left is the rounding of
+    # the fp64 closest-point distance (branch-and-bound walk here, exhaustive search in the oracle)
+    assert np.all(np.abs(s - s0) <= 1e-13 * np.abs(s0) + 1e-14), (name, np.abs(s - s0).max())
     from common import _spread_log
     _spread_log(f"shape plugin, {name}: device sdf == oracle sdf bit for bit on {np.mean(s == s0):.2%} of {len(s)} queries, max |d sdf| {np.abs(s - s0).max():.2e}")
     # gradient = normalize((1 - 2w) (p - c)): a unit vector; identical closest point => identical to rounding
@@ -76,22 +76,8 @@ def test_mesh_sweeps_with_a_720_face_robot(pkg, orc, product_lib):
     c0, gT0, gC0, st0 = o1.eval(T, cm, tstar=to)
     assert c0 > 0
     assert abs(c - c0) <= REL_TOL * abs(c0)
-    # The swept-volume query refines t* by "accept the step iff the SDF decreases" down to steps of ~1e-4 s, where the SDF
-    # changes by ~1e-8 m - below the float noise of w (UT_SolidAngle<float,float>).  The bound the device is held to is
-    # MEASURED on the reference's own code: _reference_spread() runs libref_sweeps.so's mesh path twice, the second time with
-    # the float solid angle moved by 40 x 2^-23 (the |dw| <= 4e-7 by which the device's w differs from the host library's,
-    # test_mesh_shape_plugin_vs_reference_library) - the reference does not reproduce its own t* / gradients any better.
-    sp = _reference_spread(pkg, orc, cfg1, res, T, cm, pts, V, F)
-    assert_mesh_v1_free_running("mesh-720 V1 (test_gpu_mesh)", sp, tg, to, gT, gT0, gC, gC0)
-
-
-def _reference_spread(pkg, orc, cfg, res, T, cm, pts, V, F, ulps=40):
-    """Spread of the reference's OWN mesh x swept-volume sweep, on the given scenario, under a perturbation of w of the size
-    the device's w differs by (tests/test_oracle_ref.py::mesh_v1_sensitivity_on, CPU)."""
-    import os, sys
-    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
-    from test_oracle_ref import mesh_v1_sensitivity_on
-    return mesh_v1_sensitivity_on(pkg, orc, cfg, res, T, cm, pts, V, F, ulps=ulps, threads=30)
+    # free-running argmin: since the device's winding number is the library's bit for bit, t* has to be identical
+    assert_mesh_v1_free_running("mesh-720 V1 (test_gpu_mesh)", tg, to, gT, gT0, gC, gC0)
 
 
 @pytest.mark.parametrize("name", ["L prism (20)", "blob 720", "blob 4992"])
