@@ -21,7 +21,8 @@ struct XchgParams {
     size_t slot_doubles;                  // capacity of one slot
     unsigned long long seq;               // this exchange (1, 2, ...)
     double *peer_slots[XCHG_MAX_WORLD];   // base of rank r's mailbox data: [2 parities][world slots][slot_doubles]
-    unsigned long long *peer_flags[XCHG_MAX_WORLD];   // rank r's flags: [2][world]
+    unsigned long long *peer_flags[XCHG_MAX_WORLD];   // rank r's flags: [2 parities][world] "data of exchange seq has arrived", then
+                                                      // [2 parities][world] VERDICT words (seq << 1 | "my wait timed out")
     unsigned *status;                     // device word: != 0 after a time-out
     unsigned long long *pushes;           // device counter of completed pushes (world - 1 per exchange), local to this rank
 };
@@ -65,7 +66,27 @@ __global__ __launch_bounds__(1024) void xchg_allreduce_kernel(XchgParams X, doub
                 if (++spins > XCHG_SPIN_LIMIT) { ok = false; break; }
             }
         }
-        const bool all_ok = __ballot(!ok) == 0ull;
+        bool all_ok = __ballot(!ok) == 0ull;
+        // ---- verdict round: a time-out is one-sided by nature (THIS mailbox was late; the late peer itself may have received
+        // everything), and ranks that disagree about a step would walk different optimizer paths.  So every rank tells every
+        // peer what its wait saw - one more 8-byte store per peer and one more poll, inside this kernel, instead of a host-side
+        // collective after every step - and the exchange counts as good only if EVERY rank's wait was.  Block 0 speaks for the
+        // rank (own word included, for this rank's other blocks); a verdict that does not arrive in time is a bad one.
+        unsigned long long *const verdict_own = X.peer_flags[X.rank] + (size_t)(2 + par) * X.world;
+        if (blockIdx.x == 0 && lane < X.world) {
+            const unsigned long long word = (X.seq << 1) | (all_ok ? 0ull : 1ull);
+            __hip_atomic_store(X.peer_flags[lane] + (size_t)(2 + par) * X.world + X.rank, word, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+        if (lane < X.world) {
+            long long spins = 0;
+            unsigned long long v;
+            while (((v = __hip_atomic_load(verdict_own + lane, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM)) >> 1) != X.seq) {
+                __builtin_amdgcn_s_sleep(1);
+                if (++spins > XCHG_SPIN_LIMIT) { v = 1ull; break; }
+            }
+            ok = (v & 1ull) == 0ull;
+        } else ok = true;
+        all_ok = __ballot(!ok) == 0ull;
         if (lane == 0) {
             if (!all_ok) atomicExch(X.status, 1u);
             s_ok = all_ok ? 1 : 0;
@@ -73,9 +94,8 @@ __global__ __launch_bounds__(1024) void xchg_allreduce_kernel(XchgParams X, doub
     }
     __syncthreads();
     if (!s_ok) {
-        // a peer was later than the bounded wait: buf still holds this rank's PARTIAL sums, and a late peer may well have
-        // received everybody's - make the failure visible in the data too (like the fused path does), not only in the status
-        // word: the caller sees a NaN cost and redoes the step on the group's all-reduce
+        // somebody's wait expired, and by the verdict round EVERY rank knows: all of them leave a NaN cost (and the sticky
+        // status word, which tells this NaN from a diverged iterate's) and all of them redo the step on the group's all-reduce
         if (blockIdx.x == 0 && threadIdx.x == 0) buf[0] = __longlong_as_double(0x7FF8000000000000ll);
         return;
     }
@@ -134,7 +154,7 @@ extern "C" int isdf_xchg_create(isdf_ctx *c, int rank, int world, size_t max_dou
     const size_t data_bytes = (size_t)2 * world * x->slot_doubles * sizeof(double);
     x->flags_offset = (data_bytes + 255) / 256 * 256;
     // board: XF_ROW slots per piece and parity; a packed vector of max_doubles holds at most max_doubles / 19 pieces
-    x->board_offset = (x->flags_offset + (size_t)2 * world * sizeof(unsigned long long) + 255) / 256 * 256;
+    x->board_offset = (x->flags_offset + (size_t)4 * world * sizeof(unsigned long long) + 255) / 256 * 256;      // data flags + verdict words
     x->board_doubles = (size_t)2 * XF_ROW * (max_doubles / 19 + 1);
     x->own_bytes = x->board_offset + x->board_doubles * sizeof(double);
     // uncached (fine-grained) device memory: peers' stores over xGMI become visible to this device's loads without cache games

@@ -5,6 +5,8 @@ as a kernel after the step, or INSIDE the step's fused launch (XgmiExchange.try_
 collective call follows at all.  torch.distributed is plumbing only."""
 import os
 
+import numpy as np
+
 
 def shard_range(total, rank, world):
     """Contiguous balanced partition — identical to isdf_set_shard's rule in csrc/isdf_host.hip."""
@@ -174,19 +176,18 @@ def cost_function_allreduced(engine, x, exchange=None):
     if exchange is not None and exchange.ok and getattr(exchange, "fused", False):
         pass                              # the exchange happened inside the sweep's launch (try_fused_step): already the full sums
     elif exchange is not None and exchange.ok:
-        exchange.allreduce(part)          # one-shot peer-to-peer sum over xGMI (XgmiExchange)
-        # A bounded wait that expired leaves THIS rank with its partial sums (the kernel then writes a NaN cost and raises the
-        # status word) while a late peer may hold the full ones: the ranks agree on whether anybody saw that, and if so redo
-        # the step's sum on the group's all-reduce and stay there
-        torch.cuda.current_stream().synchronize()
-        bad = engine.xchg_status() != 0 or not bool(torch.isfinite(part[0]).item())
-        flag = torch.tensor([int(bad)], dtype=torch.int32, device=exchange._pd)
-        torch.distributed.all_reduce(flag, op=torch.distributed.ReduceOp.MAX)
-        if int(flag.item()) != 0:
-            exchange.ok = False
-            ptr, count = engine.cost_function_launch(x, stream)
-            part = torch.as_tensor(_DeviceDoubles(ptr, count), device=torch.device("cuda", torch.cuda.current_device()))
-            allreduce_packed(part)
+        exchange.allreduce(part)          # one-shot peer-to-peer sum over xGMI (XgmiExchange); nothing else per step
+        # No host-side agreement per step: the exchange kernel ends with a verdict round (csrc/xchg.hip) - every rank tells
+        # every peer whether its bounded wait expired - so a failed exchange leaves a NaN cost and the sticky status word on
+        # EVERY rank.  The host looks at the status only when the cost it gets back is not finite (a diverged iterate is
+        # not finite either, with the status word clear: it is returned as it is and the exchange stays in use).
+        cost, g = engine.cost_function_finish(stream)
+        if np.isfinite(cost) or engine.xchg_status() == 0:
+            return cost, g
+        exchange.ok = False               # all ranks arrive here together: redo this step's sum on the group's all-reduce, stay there
+        ptr, count = engine.cost_function_launch(x, stream)
+        part = torch.as_tensor(_DeviceDoubles(ptr, count), device=torch.device("cuda", torch.cuda.current_device()))
+        allreduce_packed(part)
     else:
         allreduce_packed(part)
     return engine.cost_function_finish(stream)

@@ -19,3 +19,13 @@ def test_xchg_processes_sharing_one_gpu(product_lib, world):
            "--master-port", str(29600 + world), os.path.join(ROOT, "tests", "native", "xchg_worker.py")]
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "XCHG WORKERS OK" in r.stdout, (r.stdout[-3000:], r.stderr[-3000:])
+
+
+def test_xchg_failure_is_agreed_in_the_kernel(product_lib):
+    """A bounded wait that expires on ONE rank is known to ALL ranks when the exchange kernel ends (verdict round, csrc/xchg.hip):
+    no per-step host collective, and the callback's redo on the group's all-reduce is entered by every rank together."""
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+           "--master-port", "29611", os.path.join(ROOT, "tests", "native", "xchg_fail_worker.py")]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "XCHG FAILURE AGREED OK" in r.stdout, (r.stdout[-3000:], r.stderr[-3000:])
