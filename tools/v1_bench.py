@@ -11,7 +11,10 @@ from bench import build_workload
 res = 0.2
 occ, esdf, T, cm = build_workload(pkg, 40, 256, res)
 dev = torch.device("cuda", 0); st = torch.cuda.current_stream().cuda_stream
-for shape_name, shape in (("rounded cone", synth.bench_rounded_cone_shape()), ("box", synth.bench_box_shape())):
+shapes = (("rounded cone", synth.bench_rounded_cone_shape()), ("box", synth.bench_box_shape()))
+if "--only-cone" in sys.argv:
+    shapes = shapes[:1]
+for shape_name, shape in shapes:
     cfg1 = synth.default_config(capi.V1_SWEPT, safety_hor=(3 ** 0.5 / 2) * res, weight_p=4000.0)
     eng = pkg.Engine(cfg1); eng.set_grid(occ, (0, 0, 0), res, capi.GRID_OCCUPANCY); eng.set_shape(shape)
     way = cm.reshape(3, -1).T.reshape(40, 6, 3)[1:, 0, :]
