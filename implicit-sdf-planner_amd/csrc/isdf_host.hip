@@ -487,6 +487,10 @@ static int eval_device_impl(isdf_ctx *c, int n_traj, int N, const double *d_T, c
         P.tstar = (d_tstar && !fixed_tstar) ? d_tstar : c->d_tstar;
         P.traj_duration = c->d_traj_duration;
         P.max_coarse = 1536;   // traj_duration < 300 s, coarse step 0.2 s -> at most 1501 samples
+        if (!c->d_coarse_t) {
+            HIPCHK(c, hipMalloc(&c->d_coarse_t, (size_t)P.max_coarse * sizeof(double)));
+            HIPCHK(c, hipMalloc(&c->d_coarse_pose, (size_t)P.max_coarse * 12 * sizeof(double)));
+        }
         if (c->point_cap < c->M) {
             if (c->d_point_partial) (void)hipFree(c->d_point_partial);
             if (c->d_point_piece) (void)hipFree(c->d_point_piece);
@@ -511,6 +515,7 @@ static int eval_device_impl(isdf_ctx *c, int n_traj, int N, const double *d_T, c
             HIPCHK(c, hipMemset(c->d_v1_words, 0, 8 * sizeof(unsigned)));
             c->point_cap = c->M;
         }
+        P.coarse_t = c->d_coarse_t; P.coarse_pose = c->d_coarse_pose; P.n_coarse = c->d_n_coarse;
         P.point_partial = c->d_point_partial; P.point_piece = c->d_point_piece; P.point_stat = c->d_point_stat;
         P.point_nr = c->d_point_nr; P.task_buf = c->d_task_buf; P.task_map = c->d_task_map; P.words = c->d_v1_words; P.point_lmask = c->d_point_lmask;
         P.direct_records = fixed_tstar ? 1 : 0;
@@ -536,6 +541,7 @@ static int eval_device_impl(isdf_ctx *c, int n_traj, int N, const double *d_T, c
             HIPCHK(c, hipGetLastError());
             return ISDF_OK;
         }
+        launch_swept_prepare(P, st);
         ProfEvent *ev;
         int rc = prof_begin(c, st, &ev);
         if (rc) return rc;

@@ -112,7 +112,11 @@ struct SweptParams {
     const double *points;       // M x 3
     double *tstar;              // M (in/out), may be null -> internal scratch
     double *traj_duration;      // device scalar: persistent "traj_duration" state (sw_manager.hpp:287-296)
-    int max_coarse;             // bound of the coarse time table (0.2 s steps over traj_duration < 300 s)
+    // per-step scratch
+    double *coarse_t;           // [max_coarse]
+    double *coarse_pose;        // [max_coarse][12] = pos(3) + R(9)
+    int *n_coarse;              // device scalar
+    int max_coarse;
     double *point_partial;      // [M][PARTIAL_STRIDE] (gdC 18, gdT, pena)
     int *point_piece;           // [M]
     int *point_nr;              // [M] scan kernel: intervals | scan passes << 8
@@ -126,6 +130,7 @@ struct SweptParams {
     unsigned long long *dbg;    // developer timing buffer (ISDF_DEBUG_TIMING=1): 4 words per point, null on the product path
     unsigned long long *stats;  // [0]=units [2]=intervals [3]=active points [4]=overflow [5]=descent iterations [6]=reduce ticket [7]=passes
 };
+void launch_swept_prepare(const SweptParams &P, hipStream_t stream);
 void launch_swept_sweep(const SweptParams &P, hipStream_t stream, hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr);
 void launch_swept_reduce(const SweptParams &P, double *out, hipStream_t stream);      // back-prop + sums (writes every entry of `out`)
 void launch_swept_fixed(const SweptParams &P, const double *tstar_in, hipStream_t stream);   // minimisers given: replaces prepare + sweep

@@ -41,8 +41,6 @@ constexpr int SW_MAX_RANGES = 32;                // intervals kept per point (mo
 constexpr int TASK_STRIDE = 6;                   // doubles per (point, interval) slot: in (lb, ub, seed) / out (t, sdf, grad(3), counters)
 constexpr int SCAN_PER = 16;                     // points per thread and round in the task-list scan
 constexpr int LPT_TASK = 8;                      // descents of >= this many passes (last step) are dispatched first
-constexpr int COARSE_CAP = 512;                  // coarse samples (0.2 s apart) whose time and position the scan keeps in LDS: 102 s of
-                                                 // trajectory; longer ones form the tail of the table on the lanes
 
 // The trajectory as the kernels of this file see it: durations T[0..N) (LDS copies are padded to a multiple of 4 with a
 // huge value, which no time exceeds) and the 6N x 3 column-major coefficients.
@@ -97,6 +95,37 @@ __device__ __forceinline__ void pose_at(const SweptParams &P, const TrajL<LDS> &
 __device__ __forceinline__ double rlane(double v, int l) {
     const int lo = __builtin_amdgcn_readlane(__double2loint(v), l), hi = __builtin_amdgcn_readlane(__double2hiint(v), l);
     return __hiloint2double(hi, lo);
+}
+
+template <bool LDS>
+__global__ __launch_bounds__(1024) void swept_prepare_kernel(const SweptParams P) {
+    extern __shared__ double s_dyn[];
+    __shared__ int s_n;
+    TrajL<LDS> tr{P.T, P.coeffs, P.N};
+    if constexpr (LDS) tr = traj_stage(s_dyn, P.T, P.coeffs, P.N);
+    if (threadIdx.x == 0) {
+        double td = 0.0;
+        for (int i = 0; i < P.N; i++) td += tr.T[i];           // getTotalDuration, trajectory.hpp:457-466
+        double D = *P.traj_duration;
+        if (td < 3 * 1e2) { D = td; *P.traj_duration = D; }    // updateTraj, sw_manager.hpp:287-296
+        int n = 0;
+        for (double t = 0; t < D && n < P.max_coarse; t += 0.2) P.coarse_t[n++] = t;   // choiceTInit :392
+        s_n = n;
+        *P.n_coarse = n;
+        for (int k = 0; k < 8; k++) if (k != 4) P.stats[k] = 0ull;      // [4] = overflow: sticky until the host reads it
+    }
+    __syncthreads();
+    const int n = s_n;
+    for (int k = threadIdx.x; k < n; k += blockDim.x) {
+        d3 x; m3 R;
+        pose_at(P, tr, P.coarse_t[k], x, R);
+        // component-major: the scan's lanes (consecutive coarse times) read consecutive doubles
+        double *o = P.coarse_pose + k;
+        const size_t st = (size_t)P.max_coarse;
+        o[0] = x.x; o[st] = x.y; o[2 * st] = x.z;
+#pragma unroll
+        for (int q = 0; q < 9; q++) o[(3 + q) * st] = R.a[q];
+    }
 }
 
 // lane i <- lane i + 1 over the whole wavefront (DPP wave_shl:1, gfx9; the last lane keeps its own value)
@@ -186,47 +215,19 @@ __global__ __launch_bounds__(64 * SW_WAVES) void swept_scan_kernel(const SweptPa
     extern __shared__ double s_dyn[];
     __shared__ double s_rl[SW_WAVES][SW_MAX_RANGES], s_rr[SW_WAVES][SW_MAX_RANGES];
     __shared__ unsigned long long s_wt[SW_WAVES];
-    __shared__ int s_last, s_nc;
-    __shared__ double s_D;
+    __shared__ int s_last;
     const unsigned long long dbg_t0 = P.dbg ? wall_clock64() : 0ull;
     TrajL<LDS> tr{P.T, P.coeffs, P.N};
-    double *s_ct = s_dyn, *s_cpos = s_dyn + COARSE_CAP;          // coarse times, positions (component-major) of this step
-    if constexpr (LDS) tr = traj_stage(s_dyn + 4 * COARSE_CAP, P.T, P.coeffs, P.N);
+    if constexpr (LDS) tr = traj_stage(s_dyn, P.T, P.coeffs, P.N);
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    // ---- what used to be a launch of its own (one block, 12 us + a launch gap): every workgroup forms the step's coarse time
-    // table itself - the "traj_duration" state incl. the "< 300 s" staleness rule (sw_manager.hpp:287-296), t += 0.2 by REPEATED
-    // addition on one lane like the reference's loop (:392) - and the trajectory's POSITION at those times, into LDS.  The
-    // rotation is formed on demand, by the few coarse samples that pass the bounding-sphere test below.
-    if (tid == 0) {
-        double td = 0.0;
-        for (int i = 0; i < P.N; i++) td += tr.T[i];             // getTotalDuration, trajectory.hpp:457-466
-        double D = *P.traj_duration;
-        if (td < 3 * 1e2) {                                      // updateTraj, sw_manager.hpp:287-296 (every workgroup derives the same D;
-            D = td;                                              //  workgroup 0 records it for the steps to come)
-            if (blockIdx.x == 0) *P.traj_duration = D;
-        }
-        int n = 0;
-        for (double t = 0; t < D && n < P.max_coarse; t += 0.2) { if (n < COARSE_CAP) s_ct[n] = t; n++; }   // choiceTInit :392
-        s_nc = n; s_D = D;
-        if (blockIdx.x == 0) for (int k = 0; k < 8; k++) if (k != 4) P.stats[k] = 0ull;      // [4] = overflow: sticky until the host reads it
-    }
-    __syncthreads();
-    for (int k = tid; k < min(s_nc, COARSE_CAP); k += blockDim.x) {
-        double tl = s_ct[k];
-        const int pi = traj_locate_l(tr, tl);
-        d3 xt, vt, at, jt;
-        traj_eval_l(tr, pi, tl, xt, vt, at, jt);
-        s_cpos[k] = xt.x; s_cpos[COARSE_CAP + k] = xt.y; s_cpos[2 * COARSE_CAP + k] = xt.z;
-    }
-    __syncthreads();
     const int pt = P.point_begin + blockIdx.x * SW_WAVES + wave;
     if (pt < P.point_end) {
     unsigned long long *const dbg = P.dbg ? P.dbg + (size_t)pt * 4 : nullptr;
     if (dbg && lane == 0) { dbg[0] = dbg_t0; dbg[1] = wall_clock64(); }
     const d3 p = mk3(P.points[3 * pt], P.points[3 * pt + 1], P.points[3 * pt + 2]);
-    const double D = s_D;
-    const int n_coarse = s_nc;
+    const double D = *P.traj_duration;
+    const int n_coarse = *P.n_coarse;
     const double rough_dt = 0.2, dt = 0.02;
     const double inf = 2 * P.safety_hor + 0.1;
 
@@ -237,27 +238,21 @@ __global__ __launch_bounds__(64 * SW_WAVES) void swept_scan_kernel(const SweptPa
     // Coarse samples whose pose is farther from the point than the robot's bounding sphere plus the band cannot be in range
     // (isdf_shape.bound_radius: sdf(q) >= |q| - R for every body-frame q, and |R^T (p - x)| = |p - x|): they skip the rotation
     // and the SDF - a whole 64-sample window does when none of its poses is near, which is most windows of most points.
+    const size_t cst = (size_t)P.max_coarse;
     // (the mesh kind's sdf is (1 - 2 w) * distance with libigl's APPROXIMATE winding number, |w error| a few 1e-3: its band is widened by 5 %)
     const double far_r = P.shape.bound_radius + inf * (KIND == ISDF_SHAPE_MESH ? 1.05 : 1.0);
     const double far2 = P.shape.bound_radius > 0.0 ? far_r * far_r : 1.0e300;
     for (int base = 0; base < n_coarse; base += 64) {
         const int k = base + lane;
         const int kc = min(k, n_coarse - 1);
-        double ct;                                // travels with the lane: the run boundaries below come out of a register
-        d3 xk;
-        bool have_pos = false;
-        if (kc < COARSE_CAP) { ct = s_ct[kc]; xk = mk3(s_cpos[kc], s_cpos[COARSE_CAP + kc], s_cpos[2 * COARSE_CAP + kc]); have_pos = true; }
-        else {                                    // a trajectory of more than COARSE_CAP x 0.2 s: the table's tail is formed on the lane
-            ct = s_ct[COARSE_CAP - 1];
-            for (int q = COARSE_CAP - 1; q < kc; q++) ct += 0.2;
-            xk = mk3(0, 0, 0);
-        }
+        const double ct = P.coarse_t[kc];         // travels with the lane: the run boundaries below come out of a register
+        const double *o = P.coarse_pose + kc;     // component-major table: coalesced across the lanes
+        const d3 dxp = p - mk3(o[0], o[cst], o[2 * cst]);
         double dis = 1e9;
-        if (k < n_coarse && (!have_pos || !(dot3(p - xk, p - xk) > far2))) {
-            d3 x; m3 R;
-            pose_at(P, tr, ct, x, R);             // (x is the table's position again, bit for bit)
-            const d3 dxp = p - x;
-            if (have_pos || !(dot3(dxp, dxp) > far2)) {
+        if (k < n_coarse && !(dot3(dxp, dxp) > far2)) {
+            m3 R;
+#pragma unroll
+            for (int q = 0; q < 9; q++) R.a[q] = o[(3 + q) * cst];
             const d3 pr = mat_tmul(R, dxp);
             if constexpr (KIND == ISDF_SHAPE_MESH) {
                 // the scan only asks "dis < inf?" (and keeps dis where the answer is yes): far samples are rejected by the
@@ -267,7 +262,6 @@ __global__ __launch_bounds__(64 * SW_WAVES) void swept_scan_kernel(const SweptPa
                 dis = mesh_sdf_grad_below(P.shape.mesh, pr, inf, sdf, g_unused) ? sdf : 1e9;
             } else {
                 dis = shape_sdf<KIND>(P.shape, pr);
-            }
             }
         }
         unsigned long long in_mask = __ballot((k < n_coarse) && (dis < inf));
@@ -790,19 +784,22 @@ __global__ __launch_bounds__(256) void swept_reduce_kernel(const SweptParams P, 
     if (rdbg && tid == 0) rdbg[5] = wall_clock64();
 }
 
+void launch_swept_prepare(const SweptParams &P, hipStream_t stream) {
+    const size_t lds = traj_lds_bytes(P.N);
+    if (lds <= TRAJ_LDS_MAX) hipLaunchKernelGGL(swept_prepare_kernel<true>, dim3(1), dim3(1024), lds, stream, P);
+    else hipLaunchKernelGGL(swept_prepare_kernel<false>, dim3(1), dim3(1024), 0, stream, P);
+}
 void launch_swept_sweep(const SweptParams &P, hipStream_t stream, hipEvent_t ev_start, hipEvent_t ev_stop) {
     const int n = P.point_end - P.point_begin;
-    // (an empty shard still launches one workgroup: the scan's first workgroup keeps the step's bookkeeping - the persistent
-    // "traj_duration" state, the statistics words, an empty task list)
-    const dim3 grid((unsigned)((n > 0 ? n + SW_WAVES - 1 : SW_WAVES) / SW_WAVES)), block(64 * SW_WAVES);
+    if (n <= 0) return;
+    const dim3 grid((n + SW_WAVES - 1) / SW_WAVES), block(64 * SW_WAVES);
     const size_t lds = traj_lds_bytes(P.N);
     const bool in_lds = lds <= TRAJ_LDS_MAX;
     // scan, then descent (one wavefront per task while there are no more tasks than points, which is the rule); the start
     // event rides on the first dispatch, the stop event on the second
-    const size_t lds_tab = (size_t)4 * COARSE_CAP * sizeof(double);      // the scan's coarse times + positions
-#define ISDF_SWEPT_CASE(K) case K: if (in_lds) { hipExtLaunchKernelGGL((swept_scan_kernel<K, true>), grid, block, lds + lds_tab, stream, ev_start, nullptr, 0, P); \
+#define ISDF_SWEPT_CASE(K) case K: if (in_lds) { hipExtLaunchKernelGGL((swept_scan_kernel<K, true>), grid, block, lds, stream, ev_start, nullptr, 0, P); \
                                                  hipExtLaunchKernelGGL((swept_descent_kernel<K, true>), grid, block, lds, stream, nullptr, ev_stop, 0, P); } \
-                                   else { hipExtLaunchKernelGGL((swept_scan_kernel<K, false>), grid, block, lds_tab, stream, ev_start, nullptr, 0, P); \
+                                   else { hipExtLaunchKernelGGL((swept_scan_kernel<K, false>), grid, block, 0, stream, ev_start, nullptr, 0, P); \
                                           hipExtLaunchKernelGGL((swept_descent_kernel<K, false>), grid, block, 0, stream, nullptr, ev_stop, 0, P); } break;
     switch (P.shape.kind) {
     // one instantiation per shape class (each inlines exactly one SDF formula; the run-time switch of the generic kernel costs

@@ -11,6 +11,9 @@ cd /tmp && export TMPDIR=/tmp
 if [ "$CFG" = "v1" ]; then
   CMD="python $REPO/tools/v1_bench.py --no-oracle --only-cone"
   export PMC_KERNELS="swept_scan_kernel,swept_descent_kernel,swept_search_kernel" PMC_HASH=v1
+elif [ "$CFG" = "v1mesh" ]; then
+  CMD="python $REPO/tools/v1_bench.py --no-oracle --mesh720"
+  export PMC_KERNELS="swept_scan_kernel,swept_descent_kernel" PMC_HASH=v1
 else
   CMD="python $REPO/tools/c3_only.py 12"
   export PMC_KERNELS="sweep_kernel" PMC_HASH=sweep

@@ -14,6 +14,10 @@ dev = torch.device("cuda", 0); st = torch.cuda.current_stream().cuda_stream
 shapes = (("rounded cone", synth.bench_rounded_cone_shape()), ("box", synth.bench_box_shape()))
 if "--only-cone" in sys.argv:
     shapes = shapes[:1]
+if "--mesh720" in sys.argv:
+    shapes = (("mesh 720 faces", synth.make_mesh_shape(*synth.blob_mesh(24, 16, scale=0.9))),)
+if "--mesh20" in sys.argv:
+    shapes = (("mesh 20 faces", synth.make_mesh_shape(*synth.l_prism_mesh())),)
 for shape_name, shape in shapes:
     cfg1 = synth.default_config(capi.V1_SWEPT, safety_hor=(3 ** 0.5 / 2) * res, weight_p=4000.0)
     eng = pkg.Engine(cfg1); eng.set_grid(occ, (0, 0, 0), res, capi.GRID_OCCUPANCY); eng.set_shape(shape)
@@ -25,9 +29,9 @@ for shape_name, shape in shapes:
     for _ in range(3):
         eng.eval_device(1, 40, d_T.data_ptr(), d_C.data_ptr(), d_out.data_ptr(), 0, st)
     torch.cuda.synchronize(); eng.profile_enable(1); t0 = time.perf_counter()
-    for _ in range(20):
+    for _ in range(20 if 'mesh' not in shape_name else 4):
         eng.eval_device(1, 40, d_T.data_ptr(), d_C.data_ptr(), d_out.data_ptr(), 0, st)
-    torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / 20
+    torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / (20 if 'mesh' not in shape_name else 4)
     n, kms = eng.profile_read()
     out = d_out.cpu().numpy()
     if "--no-oracle" in sys.argv:

@@ -18,7 +18,15 @@ def pct(a):
 
 res = 0.2
 occ, esdf, T, cm = build_workload(pkg, 40, 256, res)
-shape = synth.bench_box_shape() if (len(sys.argv) > 1 and sys.argv[1] == "box") else synth.bench_rounded_cone_shape()
+which = sys.argv[1] if len(sys.argv) > 1 else "cone"
+if which == "box":
+    shape = synth.bench_box_shape()
+elif which == "mesh20":
+    shape = synth.make_mesh_shape(*synth.l_prism_mesh())
+elif which == "mesh720":
+    shape = synth.make_mesh_shape(*synth.blob_mesh(24, 16, scale=0.9))
+else:
+    shape = synth.bench_rounded_cone_shape()
 cfg1 = synth.default_config(capi.V1_SWEPT, safety_hor=(3 ** 0.5 / 2) * res, weight_p=4000.0)
 eng = pkg.Engine(cfg1); eng.set_grid(occ, (0, 0, 0), res, capi.GRID_OCCUPANCY); eng.set_shape(shape)
 way = cm.reshape(3, -1).T.reshape(40, 6, 3)[1:, 0, :]
@@ -26,7 +34,7 @@ M = eng.gather_points(way, 1.4)
 dev = torch.device("cuda", 0); st = torch.cuda.current_stream().cuda_stream
 d_T = torch.from_numpy(T).to(dev); d_C = torch.from_numpy(cm).to(dev)
 d_out = torch.zeros(eng.out_stride(40), dtype=torch.float64, device=dev)
-for _ in range(6):
+for _ in range(3 if which.startswith('mesh') else 6):
     eng.eval_device(1, 40, d_T.data_ptr(), d_C.data_ptr(), d_out.data_ptr(), 0, st)
 torch.cuda.synchronize()
 lib = eng.lib
