@@ -196,7 +196,7 @@ __device__ __forceinline__ void eval_lane(const SweptParams &P, const TrajL<LDS>
     if constexpr (KIND == ISDF_SHAPE_MESH) {
         // one hierarchy query per lane gives value AND gradient (the pose lanes keep the gradient)
         d3 gq;
-        val = mesh_sdf_grad(P.shape.mesh, pr, gq);
+        val = mesh_sdf_grad_wave(P.shape.mesh, pr, gq);          // the executing lanes walk the hierarchy together (dev_mesh.hpp)
         if (pose_lane) g_direct = gq;
     } else {
         val = shape_sdf<KIND>(P.shape, pr);
@@ -259,7 +259,7 @@ __global__ __launch_bounds__(64 * SW_WAVES) void swept_scan_kernel(const SweptPa
                 // hierarchy's distance cutoff without a full query
                 d3 g_unused;
                 double sdf;
-                dis = mesh_sdf_grad_below(P.shape.mesh, pr, inf, sdf, g_unused) ? sdf : 1e9;
+                dis = mesh_sdf_grad_below_wave(P.shape.mesh, pr, inf, sdf, g_unused) ? sdf : 1e9;
             } else {
                 dis = shape_sdf<KIND>(P.shape, pr);
             }

@@ -838,7 +838,7 @@ __global__ __launch_bounds__(64 * SW_SAMPLES, FUSED ? 3 : sweep_waves_per_simd(K
                     if constexpr (KIND == ISDF_SHAPE_MESH) {
                         // one hierarchy query gives sdf AND gradient, and proves "no penalty" early for far voxels
                         double sdf;
-                        if (mesh_sdf_grad_below(P.shape.mesh, prel, P.safety_hor, sdf, g)) smoothed_l1_inv(P.safety_hor - sdf, P.mu, P.inv_mu, f, df);
+                        if (mesh_sdf_grad_below_wave(P.shape.mesh, prel, P.safety_hor, sdf, g)) smoothed_l1_inv(P.safety_hor - sdf, P.mu, P.inv_mu, f, df);
                     } else {
                         smoothed_l1_inv(P.safety_hor - shape_sdf<KIND, IDENT>(P.shape, prel), P.mu, P.inv_mu, f, df);
                     }
