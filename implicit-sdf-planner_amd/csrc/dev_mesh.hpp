@@ -98,7 +98,20 @@ __host__ __device__ __forceinline__ float glibc_atan2f(float y, float x) {
 }
 
 // UTsignedSolidAngleTri (FastWindingNumberForSoups.h:6044-6082), float
-__device__ __forceinline__ float mesh_tri_solid_angle(const float *u, float qx, float qy, float qz) {
+// Pointers into the hierarchy as the wave-cooperative walks use them: CONSTANT address space - a load whose address is
+// wave-uniform then becomes a scalar load (one request for the wavefront, the result in scalar registers) instead of 64
+// identical vector loads; the compiler cannot prove that for a plain global pointer in a kernel that also stores.
+template <typename T> using mesh_cptr = const T __attribute__((address_space(4))) *;
+template <typename T> __device__ __forceinline__ mesh_cptr<T> mesh_const(const T *p) { return (mesh_cptr<T>)(unsigned long long)p; }
+// ... and wave-uniform as far as the compiler is concerned (arguments of a device FUNCTION count as divergent)
+template <typename T> __device__ __forceinline__ mesh_cptr<T> mesh_const_uni(const T *p) {
+    const unsigned long long a = (unsigned long long)p;
+    const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)a), hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(a >> 32));
+    return (mesh_cptr<T>)(((unsigned long long)hi << 32) | lo);
+}
+
+template <typename FP>
+__device__ __forceinline__ float mesh_tri_solid_angle(FP u, float qx, float qy, float qz) {
 #pragma clang fp contract(off)
     float ax = u[0] - qx, ay = u[1] - qy, az = u[2] - qz;
     float bx = u[3] - qx, by = u[4] - qy, bz = u[5] - qz;
@@ -122,10 +135,9 @@ __device__ __forceinline__ float mesh_tri_solid_angle(const float *u, float qx, 
 // explicit stack of frames: node, lanes still to visit, the two partial sums) - with it, the glibc atan2f above and the same
 // coefficients (csrc/fwn_host.hpp, bitwise the library's) w comes out bit for bit the host library's
 // (tests/test_fwn_host.py on the host, tests/test_gpu_mesh.py on the device).
-__device__ inline unsigned mesh_node_pre(const DevMesh *m, int nodei, float qx, float qy, float qz, float acc2, float &A) {
+template <typename FP, typename IP>
+__device__ inline unsigned mesh_node_pre_t(FP r, IP ch, float qx, float qy, float qz, float acc2, float &A) {
 #pragma clang fp contract(off)
-    const float *r = m->fwn_box + (size_t)92 * nodei;
-    const int *ch = m->fwn_child + 4 * nodei;
     unsigned descend = 0;
     float sum = 0.f;
     for (int l = 0; l < 4; l++) {
@@ -155,6 +167,9 @@ __device__ inline unsigned mesh_node_pre(const DevMesh *m, int nodei, float qx, 
     }
     A = sum;
     return descend;
+}
+__device__ inline unsigned mesh_node_pre(const DevMesh *m, int nodei, float qx, float qy, float qz, float acc2, float &A) {
+    return mesh_node_pre_t(m->fwn_box + (size_t)92 * nodei, m->fwn_child + 4 * nodei, qx, qy, qz, acc2, A);
 }
 __device__ inline float mesh_solid_angle(const DevMesh *m, float qx, float qy, float qz) {
 #pragma clang fp contract(off)
@@ -289,63 +304,61 @@ __device__ inline double mesh_sdf_grad(const DevMesh *m, d3 p, d3 &g) {
 // All lanes that execute the call take part (ballot): it may sit inside divergent code, as long as those lanes reach it together.
 __device__ __forceinline__ int mesh_uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
 
-// pre() of the node `nodei` (uniform) for this lane: far-field sum A and the 4-bit set of children the lane descends into
-__device__ inline unsigned mesh_node_pre_u(const DevMesh *m, int nodei, float qx, float qy, float qz, float acc2, float &A) {
-    return mesh_node_pre(m, nodei, qx, qy, qz, acc2, A);      // (same arithmetic; with a uniform node the loads are scalar)
-}
-
 __device__ inline float mesh_solid_angle_wave(const DevMesh *m, float qx, float qy, float qz) {
 #pragma clang fp contract(off)
     const float acc2 = MESH_FWN_ACCURACY * MESH_FWN_ACCURACY;
+    // frames of the levels ABOVE the current one (written on the way down, read back on the way up; the index is wave-uniform,
+    // so these private arrays are one coalesced access each); the current level lives in registers
     int f_node[MESH_FRAMES], f_cur[MESH_FRAMES];
     unsigned long long f_set[MESH_FRAMES];
     unsigned f_dm[MESH_FRAMES];
     float f_A[MESH_FRAMES], f_D[MESH_FRAMES];
     const int lane = (int)__lane_id();
-    float A;
-    unsigned dm = mesh_node_pre_u(m, 0, qx, qy, qz, acc2, A);
-    int sp = 0;
-    f_node[0] = 0; f_cur[0] = 0; f_set[0] = __ballot(1); f_dm[0] = dm; f_A[0] = A; f_D[0] = 0.f;
-    float result = 0.f;
+    // the hierarchy's arrays, fetched ONCE (m itself lives in global memory: every m->field is a load)
+    const mesh_cptr<DevMesh> mu = mesh_const_uni(m);
+    const mesh_cptr<float> box = mesh_const_uni(mu->fwn_box), trif = mesh_const_uni(mu->trif);
+    const mesh_cptr<int> chl = mesh_const_uni(mu->fwn_child);
+    int L = 0, node = 0, cur = 0;
+    unsigned long long S = __ballot(1);
+    float A, D = 0.f;
+    unsigned dm = mesh_node_pre_t(box, chl, qx, qy, qz, acc2, A);
     for (;;) {
-        const int L = mesh_uni(sp);
-        const int node = mesh_uni(f_node[L]);
-        const unsigned long long S = f_set[L];
         const bool inS = (S >> lane) & 1ull;
-        const unsigned mydm = inS ? f_dm[L] : 0u;
-        int l = mesh_uni(f_cur[L]);
+        const unsigned mydm = inS ? dm : 0u;
         unsigned long long U = 0ull;
-        for (; l < 4; l++) { U = __ballot((mydm >> l) & 1u); if (U) break; }
-        if (l >= 4) {                                             // every child some lane descends into has been visited: post()
-            const float v = f_A[L] + f_D[L];
-            if (L == 0) { result = v; break; }
-            sp = L - 1;
-            if (inS) f_D[L - 1] = f_D[L - 1] + v;
+        for (; cur < 4; cur++) { U = __ballot((mydm >> cur) & 1u); if (U) break; }
+        if (cur >= 4) {                                           // every child some lane descends into has been visited: post()
+            const float v = A + D;
+            if (L == 0) return v;
+            --L;
+            node = mesh_uni(f_node[L]); cur = mesh_uni(f_cur[L]); S = f_set[L]; dm = f_dm[L]; A = f_A[L];
+            D = inS ? f_D[L] + v : f_D[L];                         // (the lanes of the child's set are a subset of the parent's)
             continue;
         }
-        f_cur[L] = l + 1;
+        const int l = cur++;
         const bool inU = (U >> lane) & 1ull;
-        const int ci = mesh_uni(m->fwn_child[4 * node + l]);
-        if (ci == -1) { f_cur[L] = 4; continue; }                 // (empty children are last; never marked by pre)
+        const int ci = mesh_uni(chl[4 * node + l]);
+        if (ci == -1) { cur = 4; continue; }                      // (empty children are last; never marked by pre)
         if (ci >= 0) {
-            if (inU) f_D[L] = f_D[L] + mesh_tri_solid_angle(m->trif + (size_t)9 * ci, qx, qy, qz);
+            if (inU) D = D + mesh_tri_solid_angle(trif + (size_t)9 * ci, qx, qy, qz);
         } else {
             const int child = ci & 0x7fffffff;
             float A2 = 0.f;
             unsigned d2 = 0u;
-            if (inU) d2 = mesh_node_pre_u(m, child, qx, qy, qz, acc2, A2);
-            if (!__ballot(d2 != 0u)) { if (inU) f_D[L] = f_D[L] + A2; }      // nobody goes deeper: the child's value is its pre()
+            if (inU) d2 = mesh_node_pre_t(box + (size_t)92 * child, chl + 4 * child, qx, qy, qz, acc2, A2);
+            if (!__ballot(d2 != 0u)) { if (inU) D = D + A2; }      // nobody goes deeper: the child's value is its pre()
             else {
-                sp = L + 1;
-                f_node[L + 1] = child; f_cur[L + 1] = 0; f_set[L + 1] = U; f_dm[L + 1] = d2; f_A[L + 1] = A2; f_D[L + 1] = 0.f;
+                f_node[L] = node; f_cur[L] = cur; f_set[L] = S; f_dm[L] = dm; f_A[L] = A; f_D[L] = D;
+                ++L;
+                node = child; cur = 0; S = U; dm = d2; A = A2; D = 0.f;
             }
         }
     }
-    return result;
 }
 
 // per-lane lower bound (squared) of the distance from p to child l of the node whose record is r
-__device__ __forceinline__ double mesh_child_lb2(const float *r, int l, d3 p) {
+template <typename FP>
+__device__ __forceinline__ double mesh_child_lb2(FP r, int l, d3 p) {
     const double px = r[4 + l], py = r[8 + l], pz = r[12 + l];
     const double dx = p.x - px, dy = p.y - py, dz = p.z - pz;
     const double rad = (double)sqrtf(r[l]) * 1.00001 + 1e-6 * (fabs(px) + fabs(py) + fabs(pz) + 1.0);
@@ -355,18 +368,25 @@ __device__ __forceinline__ double mesh_child_lb2(const float *r, int l, d3 p) {
 // `best` in: the lane's cutoff (squared), out: min(exact squared distance, cutoff); `closest` written when a triangle beat it
 __device__ inline double mesh_closest_wave(const DevMesh *m, d3 p, bool act, d3 &closest, double best) {
     int s_node[MESH_STACK], s_par[MESH_STACK];
+    const mesh_cptr<DevMesh> mu = mesh_const_uni(m);
+    const mesh_cptr<float> box = mesh_const_uni(mu->fwn_box);
+    const mesh_cptr<int> chl = mesh_const_uni(mu->fwn_child);
+    const mesh_cptr<double> tri = mesh_const_uni(mu->tri);
     int sp = 1;
     s_node[0] = 0; s_par[0] = -1;
     while (sp > 0) {
         sp = mesh_uni(sp) - 1;
         const int node = mesh_uni(s_node[sp]), par = mesh_uni(s_par[sp]);
         if (par >= 0) {                                           // the bests may have improved since this node was pushed
-            const double lb2 = mesh_child_lb2(m->fwn_box + (size_t)92 * (par >> 2), par & 3, p);
+            const double lb2 = mesh_child_lb2(box + (size_t)92 * (par >> 2), par & 3, p);
             if (!__ballot(act && lb2 < best)) continue;
         }
-        const float *r = m->fwn_box + (size_t)92 * node;
-        const int *ch = m->fwn_child + 4 * node;
-        int cid[4]; double crep[4]; int n = 0;
+        const mesh_cptr<float> r = box + (size_t)92 * node;
+        const mesh_cptr<int> ch = chl + 4 * node;
+        // (up to four internal children, kept sorted by decreasing bound in NAMED scalars: a dynamically indexed private
+        // array would live in scratch memory)
+        int c0 = -1, c1 = -1, c2 = -1, c3 = -1;
+        double r0 = -1.0, r1 = -1.0, r2 = -1.0;
         for (int l = 0; l < 4; l++) {
             const int ci = mesh_uni(ch[l]);
             if (ci == -1) break;
@@ -376,23 +396,28 @@ __device__ inline double mesh_closest_wave(const DevMesh *m, d3 p, bool act, d3 
             if (!U) continue;
             if (ci >= 0) {
                 if (want) {
-                    const double *t = m->tri + (size_t)9 * ci;
+                    const mesh_cptr<double> t = tri + (size_t)9 * ci;
                     const d3 c = closest_on_triangle(p, mk3(t[0], t[1], t[2]), mk3(t[3], t[4], t[5]), mk3(t[6], t[7], t[8]));
                     const d3 dd = p - c;
                     const double d = dot3(dd, dd);
                     if (d < best) { best = d; closest = c; }
                 }
             } else {
-                // visiting order: by the bound of the first lane that wants the child (the lanes are neighbours)
+                // visiting order: by the bound of the first lane that wants the child (the lanes are neighbours); rep >= 0
                 const int fl = __ffsll((long long)U) - 1;
                 const int lo = __builtin_amdgcn_readlane(__double2loint(lb2), fl), hi = __builtin_amdgcn_readlane(__double2hiint(lb2), fl);
                 const double rep = __hiloint2double(hi, lo);
-                int k = n++;
-                while (k > 0 && crep[k - 1] < rep) { crep[k] = crep[k - 1]; cid[k] = cid[k - 1]; --k; }
-                crep[k] = rep; cid[k] = ((ci & 0x7fffffff) << 2) | l;
+                const int cw = ((ci & 0x7fffffff) << 2) | l;
+                if (rep > r0) { c3 = c2; c2 = c1; r2 = r1; c1 = c0; r1 = r0; c0 = cw; r0 = rep; }
+                else if (rep > r1) { c3 = c2; c2 = c1; r2 = r1; c1 = cw; r1 = rep; }
+                else if (rep > r2) { c3 = c2; c2 = cw; r2 = rep; }
+                else c3 = cw;
             }
         }
-        for (int k = 0; k < n; k++) { s_node[sp] = cid[k] >> 2; s_par[sp] = (node << 2) | (cid[k] & 3); ++sp; }      // nearest child on top
+        if (c0 >= 0) { s_node[sp] = c0 >> 2; s_par[sp] = (node << 2) | (c0 & 3); ++sp; }      // farthest first: the nearest child ends on top
+        if (c1 >= 0) { s_node[sp] = c1 >> 2; s_par[sp] = (node << 2) | (c1 & 3); ++sp; }
+        if (c2 >= 0) { s_node[sp] = c2 >> 2; s_par[sp] = (node << 2) | (c2 & 3); ++sp; }
+        if (c3 >= 0) { s_node[sp] = c3 >> 2; s_par[sp] = (node << 2) | (c3 & 3); ++sp; }
     }
     return best;
 }
