@@ -538,7 +538,7 @@ def main():
                         if o1.mesh_backend() == 1:
                             oracle = (o1, thr)
                     run_v1(f"C5 (configs[4]) shape: V1 sweep, 512^3 occupancy @ 0.1 m, mesh robot ({nm}) through the fast winding number, 20 pieces", e1, 20, T5, cm5, stp, oracle,
-                           note="free-running argmin of a float-noise SDF: rel_err_vs_oracle is bounded by the reference's own spread (tests/common.py MESH_V1_CAPS), 1e-5 with t* given")
+                           note="both sides search their own minimisers; the device's winding number is the reference library's bit for bit (csrc/dev_mesh.hpp), so t* is identical and rel_err_vs_oracle is rounding")
                     del e1
                 del occ5
             except Exception as e:      # noqa: BLE001

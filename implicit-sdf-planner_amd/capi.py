@@ -101,12 +101,15 @@ EXPORTED_SYMBOLS = [
     "isdf_frontend_build", "isdf_frontend_get_shape_kernels", "isdf_frontend_get_map_kernel", "isdf_frontend_check", "isdf_frontend_cspace",
     "isdf_read_pcd", "isdf_read_obj", "isdf_poly_rotation", "isdf_body_transform", "isdf_plan_config_default", "isdf_load_yaml_config",
     "isdf_shape_from_config",
-    "isdf_host_path", "isdf_minco_device", "isdf_mesh_atan2f", "isdf_create_multi", "isdf_multi_info",
+    "isdf_host_path", "isdf_minco_device", "isdf_mesh_atan2f", "isdf_create_multi", "isdf_multi_info", "isdf_set_shape_grid", "isdf_set_shape_sampled",
     "isdf_xchg_create", "isdf_xchg_connect", "isdf_xchg_allreduce", "isdf_xchg_fuse", "isdf_xchg_status", "isdf_xchg_destroy",
 ]
 
 HOST_PATH_COPY, HOST_PATH_DIRECT_MAPPED, HOST_PATH_DIRECT_BAR = 0, 1, 2
 MULTI_NONE, MULTI_PEER_SUM, MULTI_STAGED, MULTI_RCCL = 0, 1, 2, 3
+
+SDF_WITH_GRAD_FN = C.CFUNCTYPE(C.c_double, C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_double))   # isdf_sdf_with_grad_fn
+SHAPE_GRID, GRAD_GRID = 16, 4
 
 _lib = None
 
@@ -135,6 +138,8 @@ def load_library(path=None):
     lib.isdf_set_grid.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, dp, dp, C.c_double, C.c_int]
     lib.isdf_set_shape.argtypes = [C.c_void_p, C.POINTER(IsdfShape)]
     lib.isdf_set_points.argtypes = [C.c_void_p, dp, C.c_int]
+    lib.isdf_set_shape_grid.argtypes = [C.c_void_p, dp, C.c_int, C.c_int, C.c_int, dp, C.c_double, C.c_double, dp, dp]
+    lib.isdf_set_shape_sampled.argtypes = [C.c_void_p, SDF_WITH_GRAD_FN, C.c_void_p, C.c_double, C.c_double, C.c_double, C.c_double, C.c_double, dp, dp]
     lib.isdf_set_shard.argtypes = [C.c_void_p, C.c_int, C.c_int]
     lib.isdf_eval.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_int), C.POINTER(dp), C.POINTER(dp), dp,
                               C.POINTER(dp), C.POINTER(dp), dp]

@@ -41,6 +41,10 @@ struct DevShape {
     ShapeP<float> f;
     double bound_radius;
     const DevMesh *mesh;
+    // ISDF_SHAPE_GRID: num_sdf_map of BasicShape (Shape.hpp:376-404): 4 doubles per node (unit gradient, distance)
+    const double *grid;
+    int gn[3];
+    double gres, gmin[3];
 };
 
 template <typename T> __device__ __forceinline__ T clipT(T v, T lo, T hi) { return m_max(m_min(v, hi), lo); }
@@ -209,6 +213,59 @@ __device__ __forceinline__ T analytic_sdf(const ShapeP<T> &S, int kind_rt, v3<T>
     return analytic_local<KIND, T>(S, kind_rt, body_offset<IDENT>(S, pr));
 }
 
+// ---- ISDF_SHAPE_GRID: getonlySDFNum / getonlyGrad1Num / getSDFwithGrad1Num (Shape.hpp:481-600), operation for operation
+struct GridCellRef { int base[8]; double xd, yd, zd; bool inside; };
+__device__ __forceinline__ GridCellRef grid_locate(const DevShape &S, d3 p) {
+    GridCellRef c;
+    const double fx = (p.x - S.gmin[0]) / S.gres, fy = (p.y - S.gmin[1]) / S.gres, fz = (p.z - S.gmin[2]) / S.gres;
+    const int i = (int)floor(fx), j = (int)floor(fy), k = (int)floor(fz);
+    const int X = S.gn[0], Y = S.gn[1], Z = S.gn[2];
+    c.inside = i >= 0 && i < X - 1 && j >= 0 && j < Y - 1 && k >= 0 && k < Z - 1;
+    c.xd = fx - i; c.yd = fy - j; c.zd = fz - k;
+    const int ijk = (i * Y + j) * Z + k;
+    c.base[0] = ijk;              c.base[1] = ijk + Y * Z;          // ijk, i1_jk
+    c.base[2] = ijk + Z;          c.base[3] = ijk + Y * Z + Z;      // ij1_k, i1_j1_k
+    c.base[4] = ijk + 1;          c.base[5] = ijk + Y * Z + 1;      // ij_k1, i1_j_k1
+    c.base[6] = ijk + Z + 1;      c.base[7] = ijk + Y * Z + Z + 1;  // ij1_k1, i1_j1_k1
+    return c;
+}
+__device__ __forceinline__ double grid_value(const DevShape &S, const GridCellRef &c) {
+    const double *G = S.grid;
+    const double xd = c.xd, yd = c.yd, zd = c.zd;
+    const double c00 = G[4 * (size_t)c.base[0] + 3] * (1 - xd) + G[4 * (size_t)c.base[1] + 3] * xd;
+    const double c10 = G[4 * (size_t)c.base[2] + 3] * (1 - xd) + G[4 * (size_t)c.base[3] + 3] * xd;
+    const double c01 = G[4 * (size_t)c.base[4] + 3] * (1 - xd) + G[4 * (size_t)c.base[5] + 3] * xd;
+    const double c11 = G[4 * (size_t)c.base[6] + 3] * (1 - xd) + G[4 * (size_t)c.base[7] + 3] * xd;
+    const double c0 = c00 * (1 - yd) + c10 * yd;
+    const double c1 = c01 * (1 - yd) + c11 * yd;
+    return c0 * (1 - zd) + c1 * zd;
+}
+__device__ __forceinline__ d3 grid_gradient(const DevShape &S, const GridCellRef &c) {
+    const double *G = S.grid;
+    const double xd = c.xd, yd = c.yd, zd = c.zd;
+    // g000 * (1-xd) * (1-yd) * (1-zd) + g100 * xd * (1-yd) * (1-zd) + ...: Eigen multiplies a vector by its scalars from the left,
+    // component by component - ((g a) b) c - and adds the eight terms from the left
+    const double fa[8] = {1 - xd, xd, 1 - xd, xd, 1 - xd, xd, 1 - xd, xd};
+    const double fb[8] = {1 - yd, 1 - yd, yd, yd, 1 - yd, 1 - yd, yd, yd};
+    const double fc[8] = {1 - zd, 1 - zd, 1 - zd, 1 - zd, zd, zd, zd, zd};
+    d3 g = mk3(0, 0, 0);
+#pragma unroll
+    for (int q = 0; q < 8; q++) {
+        const double *n = G + 4 * (size_t)c.base[q];
+        const d3 t = mk3(((n[0] * fa[q]) * fb[q]) * fc[q], ((n[1] * fa[q]) * fb[q]) * fc[q], ((n[2] * fa[q]) * fb[q]) * fc[q]);
+        g = q == 0 ? t : mk3(g.x + t.x, g.y + t.y, g.z + t.z);
+    }
+    return normalized3(g);
+}
+__device__ __forceinline__ double grid_sdf(const DevShape &S, d3 p) {
+    const GridCellRef c = grid_locate(S, p);
+    return c.inside ? grid_value(S, c) : 1e20;
+}
+__device__ __forceinline__ d3 grid_grad(const DevShape &S, d3 p) {
+    const GridCellRef c = grid_locate(S, p);
+    return c.inside ? grid_gradient(S, c) : mk3(0, 0, 0);
+}
+
 __device__ double mesh_sdf(const DevMesh *m, d3 p);              // dev_mesh.hpp
 __device__ double mesh_sdf_grad(const DevMesh *m, d3 p, d3 &g);  // dev_mesh.hpp
 
@@ -216,7 +273,10 @@ __device__ double mesh_sdf_grad(const DevMesh *m, d3 p, d3 &g);  // dev_mesh.hpp
 template <int KIND, bool IDENT = false>
 __device__ __forceinline__ double shape_sdf(const DevShape &S, d3 pr) {
     if constexpr (KIND == ISDF_SHAPE_MESH) return mesh_sdf(S.mesh, pr);     // the mesh kind has its own instantiation
-    else return analytic_sdf<KIND, double, IDENT>(S.d, S.kind, pr);
+    else {
+        if constexpr (KIND < 0) if (S.kind == ISDF_SHAPE_GRID) return grid_sdf(S, pr);      // (run-time kinds: Ball, sampled grid)
+        return analytic_sdf<KIND, double, IDENT>(S.d, S.kind, pr);
+    }
 }
 
 // BasicShape::getonlySDF(pos, R_obj) (Shape.hpp:470), the form the front end's kernel generation uses (:451): every
@@ -228,6 +288,8 @@ __device__ __forceinline__ double shape_sdf_rotated(const DevShape &S, d3 pos, c
         return mesh_sdf(S.mesh, mk3(pos.x * Ro[0] + pos.y * Ro[3] + pos.z * Ro[6], pos.x * Ro[1] + pos.y * Ro[4] + pos.z * Ro[7], pos.x * Ro[2] + pos.y * Ro[5] + pos.z * Ro[8]));
     } else {
         if (S.kind == ISDF_SHAPE_BALL) return norm3(pos) - S.d.p[0];
+        if constexpr (KIND < 0) if (S.kind == ISDF_SHAPE_GRID)       // the lattice holds the shape incl. its body offset: sampled at pos * R_obj
+            return grid_sdf(S, mk3(pos.x * Ro[0] + pos.y * Ro[3] + pos.z * Ro[6], pos.x * Ro[1] + pos.y * Ro[4] + pos.z * Ro[7], pos.x * Ro[2] + pos.y * Ro[5] + pos.z * Ro[8]));
         const d3 q = body_offset(S.d, pos);
         return analytic_local<KIND, double>(S.d, S.kind, mk3(q.x * Ro[0] + q.y * Ro[3] + q.z * Ro[6], q.x * Ro[1] + q.y * Ro[4] + q.z * Ro[7], q.x * Ro[2] + q.y * Ro[5] + q.z * Ro[8]));
     }
@@ -240,6 +302,7 @@ __device__ __forceinline__ d3 shape_grad(const DevShape &S, d3 pr) {
     if constexpr (KIND == ISDF_SHAPE_MESH) { d3 g; mesh_sdf_grad(S.mesh, pr, g); return g; }
     const int mode = S.grad_mode;   // resolved (never DEFAULT) by the host
     if (mode == ISDF_GRAD_ANALYTIC_BALL) return normalized3(pr);
+    if constexpr (KIND < 0) if (mode == ISDF_GRAD_GRID) return grid_grad(S, pr);
     if (mode == ISDF_GRAD_BOX_FORWARD) {
         const double dx = 0.01;
         const double s0 = shape_sdf<KIND, IDENT>(S, pr);

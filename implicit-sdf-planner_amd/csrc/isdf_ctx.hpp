@@ -28,6 +28,7 @@ struct isdf_ctx {
     float *d_mesh_trif = nullptr;
     int *d_fwn_child = nullptr;
     float *d_fwn_box = nullptr;
+    double *d_shape_grid = nullptr;      // ISDF_SHAPE_GRID: the sampled lattice
     // points (V1)
     double *d_points = nullptr;
     int M = 0;

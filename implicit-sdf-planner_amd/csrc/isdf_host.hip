@@ -173,7 +173,7 @@ extern "C" int isdf_destroy(isdf_ctx *c) {
     isdf_xchg_release(c);
     void *ptrs[] = {c->d_cb, c->d_esdf, c->d_occ, c->d_points, c->d_tstar, c->d_acc, c->d_sample_info, c->d_bits, c->d_piece_cost, c->d_in, c->d_out, c->d_stats,
                     c->d_traj_duration, c->d_coarse_t, c->d_coarse_pose, c->d_n_coarse, c->d_point_partial, c->d_point_piece, c->d_point_stat, c->d_point_nr, c->d_task_buf,
-                    c->d_task_map, c->d_v1_words, c->d_point_lmask, c->d_hist, c->d_dbg, c->d_stage, c->d_stage_flags, c->d_sample_map, c->d_plan_cls, c->d_plan_map, c->d_plan_lr, c->d_plan_hist};
+                    c->d_task_map, c->d_v1_words, c->d_point_lmask, c->d_hist, c->d_shape_grid, c->d_dbg, c->d_stage, c->d_stage_flags, c->d_sample_map, c->d_plan_cls, c->d_plan_map, c->d_plan_lr, c->d_plan_hist};
     for (void *p : ptrs) if (p) (void)hipFree(p);
     free_mesh(c);
     if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -260,6 +260,7 @@ extern "C" int isdf_set_shape(isdf_ctx *c, const isdf_shape *s) {
     if (!c) return ISDF_ERR_INVALID_ARG;
     if (!s || s->kind < 0 || s->kind >= ISDF_SHAPE_KIND_COUNT) return fail(c, ISDF_ERR_INVALID_ARG, "bad shape kind");
     if (s->grad_mode < ISDF_GRAD_DEFAULT || s->grad_mode > ISDF_GRAD_ANALYTIC_BALL) return fail(c, ISDF_ERR_INVALID_ARG, "bad grad_mode");
+    if (s->kind == ISDF_SHAPE_GRID) return fail(c, ISDF_ERR_INVALID_ARG, "ISDF_SHAPE_GRID is installed with isdf_set_shape_grid / isdf_set_shape_sampled");
     HIPCHK(c, hipSetDevice(c->device));
     DevShape d{};
     d.kind = s->kind;
@@ -333,6 +334,72 @@ extern "C" int isdf_set_shape(isdf_ctx *c, const isdf_shape *s) {
     c->have_shape = true;
     ISDF_REPLICATE(c, isdf_set_shape(p_, s));
     return ISDF_OK;
+}
+
+// A shape the library has no formula for, as the lattice BasicShape::initShape tabulates (Shape.hpp:361-404); sampled on the
+// device like getonlySDFNum / getonlyGrad1Num / getSDFwithGrad1Num (:481-600).
+extern "C" int isdf_set_shape_grid(isdf_ctx *c, const double *cells, int nx, int ny, int nz, const double grid_min[3], double nres,
+                                   double bound_radius, const double *bbox_center, const double *bbox_half) {
+    if (!c) return ISDF_ERR_INVALID_ARG;
+    if (!cells || !grid_min || nx < 2 || ny < 2 || nz < 2 || !(nres > 0)) return fail(c, ISDF_ERR_INVALID_ARG, "bad lattice (at least 2 nodes per axis)");
+    if ((double)nx * ny * nz > 2.0e8) return fail(c, ISDF_ERR_INVALID_ARG, "lattice too large");
+    HIPCHK(c, hipSetDevice(c->device));
+    const size_t n = (size_t)nx * ny * nz;
+    free_mesh(c);
+    if (c->d_shape_grid) { (void)hipFree(c->d_shape_grid); c->d_shape_grid = nullptr; }
+    HIPCHK(c, hipMalloc(&c->d_shape_grid, n * 4 * sizeof(double)));
+    HIPCHK(c, hipMemcpy(c->d_shape_grid, cells, n * 4 * sizeof(double), hipMemcpyHostToDevice));
+    DevShape d{};
+    d.kind = ISDF_SHAPE_GRID; d.grad_mode = ISDF_GRAD_GRID;
+    d.d.ident = d.f.ident = 1;
+    for (int i = 0; i < 9; i++) { d.d.rot[i] = (i % 4 == 0) ? 1.0 : 0.0; d.f.rot[i] = (float)d.d.rot[i]; }
+    d.grid = c->d_shape_grid; d.gn[0] = nx; d.gn[1] = ny; d.gn[2] = nz; d.gres = nres;
+    for (int a = 0; a < 3; a++) d.gmin[a] = grid_min[a];
+    // outside the lattice the sampler returns 1e20: the lattice box bounds everything that can carry a penalty
+    const int dims[3] = {nx, ny, nz};
+    double bb_c[3], bb_h[3], r2 = 0.0;
+    for (int a = 0; a < 3; a++) {
+        const double lo = grid_min[a], hi = grid_min[a] + (dims[a] - 1) * nres;
+        bb_c[a] = 0.5 * (lo + hi); bb_h[a] = 0.5 * (hi - lo) + 1e-9;
+        const double far = std::max(std::fabs(lo), std::fabs(hi));
+        r2 += far * far;
+    }
+    if (bbox_center && bbox_half && bbox_half[0] > 0 && bbox_half[1] > 0 && bbox_half[2] > 0)
+        for (int a = 0; a < 3; a++) { bb_c[a] = bbox_center[a]; bb_h[a] = bbox_half[a]; }
+    d.bound_radius = bound_radius > 0 ? bound_radius : std::sqrt(r2);
+    d.prune_rows = !(getenv("ISDF_NO_ROW_PRUNE") && getenv("ISDF_NO_ROW_PRUNE")[0] == '1');
+    for (int a = 0; a < 3; a++) { d.bbox_lo[a] = (float)(bb_c[a] - bb_h[a]); d.bbox_hi[a] = (float)(bb_c[a] + bb_h[a]); }
+    d.filter_f32 = 0;                      // no fp32 formula to pre-filter with
+    d.mesh = nullptr;
+    isdf_frontend_release(c);
+    c->shape = d;
+    c->shape_host = isdf_shape{};
+    c->shape_host.kind = ISDF_SHAPE_GRID; c->shape_host.grad_mode = ISDF_GRAD_GRID;
+    c->shape_host.bound_radius = d.bound_radius;
+    for (int a = 0; a < 3; a++) { c->shape_host.bbox_center[a] = bb_c[a]; c->shape_host.bbox_half[a] = bb_h[a]; }
+    c->have_shape = true;
+    ISDF_REPLICATE(c, isdf_set_shape_grid(p_, cells, nx, ny, nz, grid_min, nres, bound_radius, bbox_center, bbox_half));
+    return ISDF_OK;
+}
+extern "C" int isdf_set_shape_sampled(isdf_ctx *c, isdf_sdf_with_grad_fn fn, void *user, double ndx, double ndy, double ndz, double nres,
+                                      double bound_radius, const double *bbox_center, const double *bbox_half) {
+    if (!c) return ISDF_ERR_INVALID_ARG;
+    if (!fn || !(ndx > 0) || !(ndy > 0) || !(ndz > 0) || !(nres > 0)) return fail(c, ISDF_ERR_INVALID_ARG, "bad sampling arguments");
+    // initShape (Shape.hpp:368-376): sizes ceil(nd / nres), the lattice starts at -nd / 2
+    const int X = (int)std::ceil(ndx / nres), Y = (int)std::ceil(ndy / nres), Z = (int)std::ceil(ndz / nres);
+    if (X < 2 || Y < 2 || Z < 2 || (double)X * Y * Z > 2.0e8) return fail(c, ISDF_ERR_INVALID_ARG, "bad lattice size");
+    const double mn[3] = {-ndx / 2, -ndy / 2, -ndz / 2};
+    std::vector<double> cells((size_t)X * Y * Z * 4);
+    for (int i = 0; i < X; i++)
+        for (int j = 0; j < Y; j++)
+            for (int k = 0; k < Z; k++) {
+                const double p[3] = {mn[0] + i * nres, mn[1] + j * nres, mn[2] + k * nres};       // :390
+                double g[3] = {0, 0, 0};
+                const double dis = fn(user, p, g);                                                   // getSDFwithGrad1(p_rel, grad) :391
+                double *o = cells.data() + 4 * (((size_t)i * Y + j) * Z + k);
+                o[0] = g[0]; o[1] = g[1]; o[2] = g[2]; o[3] = dis;
+            }
+    return isdf_set_shape_grid(c, cells.data(), X, Y, Z, mn, nres, bound_radius, bbox_center, bbox_half);
 }
 
 extern "C" int isdf_set_points(isdf_ctx *c, const double *xyz, int M) {

@@ -102,6 +102,27 @@ class Engine:
         self._keep.append(shape)
         self._check(self.lib.isdf_set_shape(self.h, C.byref(shape)))
 
+    def set_shape_grid(self, cells, grid_min, nres, bound_radius=0.0, bbox=None):
+        """ISDF_SHAPE_GRID: cells [nx, ny, nz, 4] = (unit gradient xyz, distance) per lattice node (BasicShape::num_sdf_map)."""
+        cells = np.ascontiguousarray(cells, dtype=np.float64)
+        nx, ny, nz, four = cells.shape
+        assert four == 4
+        gm = np.ascontiguousarray(grid_min, dtype=np.float64)
+        bc = bh = None
+        if bbox is not None:
+            bc = np.ascontiguousarray(bbox[0], dtype=np.float64); bh = np.ascontiguousarray(bbox[1], dtype=np.float64)
+        self._check(self.lib.isdf_set_shape_grid(self.h, _p(cells), nx, ny, nz, _p(gm), float(nres), float(bound_radius),
+                                                 None if bc is None else _p(bc), None if bh is None else _p(bh)))
+
+    def set_shape_sampled(self, fn, nd, nres, bound_radius=0.0):
+        """fn(p[3]) -> (distance, gradient[3]): any host shape's getSDFwithGrad1; tabulated like BasicShape::initShape."""
+        def tramp(_u, pp, gp):
+            d, g = fn(np.array([pp[0], pp[1], pp[2]]))
+            gp[0], gp[1], gp[2] = float(g[0]), float(g[1]), float(g[2])
+            return float(d)
+        cb = capi.SDF_WITH_GRAD_FN(tramp)
+        self._check(self.lib.isdf_set_shape_sampled(self.h, cb, None, float(nd[0]), float(nd[1]), float(nd[2]), float(nres), float(bound_radius), None, None))
+
     def set_points(self, pts):
         pts = np.ascontiguousarray(pts, dtype=np.float64).reshape(-1, 3)
         self._check(self.lib.isdf_set_points(self.h, _p(pts), pts.shape[0]))

@@ -87,7 +87,8 @@ typedef enum isdf_shape_kind {
     ISDF_SHAPE_BOX = 13,
     ISDF_SHAPE_BALL = 14,
     ISDF_SHAPE_MESH = 15,
-    ISDF_SHAPE_KIND_COUNT = 16
+    ISDF_SHAPE_GRID = 16,   /* a body-frame lattice of (unit gradient, distance) sampled from ANY host shape: isdf_set_shape_grid */
+    ISDF_SHAPE_KIND_COUNT = 17
 } isdf_shape_kind;
 
 /* How getonlyGrad1 / getSDFwithGrad1 form the body-frame gradient. */
@@ -95,7 +96,8 @@ typedef enum isdf_grad_mode {
     ISDF_GRAD_DEFAULT = 0,      /* what the reference class of this kind does                                  */
     ISDF_GRAD_CENTRAL = 1,      /* DEFINE_USEFUL_FUNCTION: central difference dx=5e-6, normalised Shape.hpp:32-88 */
     ISDF_GRAD_BOX_FORWARD = 2,  /* Box::getonlyGrad1: forward difference dx=0.01, NOT normalised  Shape.hpp:2363-2377 */
-    ISDF_GRAD_ANALYTIC_BALL = 3 /* Ball/Point: p / |p|                                           Shape.hpp:622-630 */
+    ISDF_GRAD_ANALYTIC_BALL = 3,/* Ball/Point: p / |p|                                           Shape.hpp:622-630 */
+    ISDF_GRAD_GRID = 4          /* ISDF_SHAPE_GRID: trilinear blend of the nodes' gradients, normalised Shape.hpp:520-553 */
 } isdf_grad_mode;
 
 typedef struct isdf_shape {
@@ -178,6 +180,25 @@ int isdf_abi_version(void);
 int isdf_set_grid(isdf_ctx *ctx, const void *voxels, int dtype, int nx, int ny, int nz,
                   const double origin[3], const double boundary_max[3], double resolution, int grid_kind);
 int isdf_set_shape(isdf_ctx *ctx, const isdf_shape *shape);
+/* ---- a robot shape the library has never seen: the reference's plugin promise is "subclass Generalshape, add a constructor to
+ * the registry" (Shape.hpp:469-472, sw_manager.hpp:74-123); device code cannot call host virtuals, so such a shape comes in the
+ * form the reference itself tabulates at start-up: BasicShape::initShape (Shape.hpp:361-404) fills num_sdf_map, a body-frame
+ * lattice of NumSDFGridCell {unit gradient, distance} with node (i, j, k) at (-nd/2 + i*nres) per axis, ceil(nd / nres) nodes
+ * per axis, by calling the shape's own getSDFwithGrad1 once per node; getonlySDFNum / getonlyGrad1Num / getSDFwithGrad1Num
+ * (:481-600) sample it trilinearly (value: 1e20 outside the lattice; gradient: blend of the 8 nodes' gradients, normalised;
+ * zero outside).  ISDF_SHAPE_GRID is exactly that sampler on the device - a documented APPROXIMATION of the shape it was
+ * sampled from (error O(nres^2 x curvature) on the distance), exact parity with the reference's *Num functions.
+ * isdf_set_shape_grid: cells = nx*ny*nz x 4 doubles (gx, gy, gz, distance), address (i*ny + j)*nz + k like toAddr (:466);
+ * grid_min = position of node (0,0,0); bound_radius / bbox_* as in isdf_shape (0 / zeros: derived from the lattice box, which is
+ * always valid because the sampler returns 1e20 outside it).
+ * isdf_set_shape_sampled: builds the cells the way initShape does, by calling `fn` (== getSDFwithGrad1 of any host class:
+ * returns the distance, writes the gradient) at every node, then installs them. */
+typedef double (*isdf_sdf_with_grad_fn)(void *user, const double p_rel[3], double grad_out[3]);
+int isdf_set_shape_grid(isdf_ctx *ctx, const double *cells, int nx, int ny, int nz, const double grid_min[3], double nres,
+                        double bound_radius, const double *bbox_center, const double *bbox_half);
+int isdf_set_shape_sampled(isdf_ctx *ctx, isdf_sdf_with_grad_fn fn, void *user, double ndx, double ndy, double ndz, double nres,
+                           double bound_radius, const double *bbox_center, const double *bbox_half);
+
 int isdf_set_points(isdf_ctx *ctx, const double *xyz, int M);   /* V1: M x 3 row-major obstacle points  */
 /* Multi-GPU: this ctx evaluates only its share of the constraint points (pieces for V2/V3, obstacle points
  * for V1); outputs of all ranks SUM to the full result (one all-reduce of [cost|gradT|gradC] per step). */

@@ -53,6 +53,10 @@ struct HdkFwn {
 };
 
 struct MeshSdf {
+    // ISDF_SHAPE_GRID: BasicShape's num_sdf_map (Shape.hpp:267-288) - 4 doubles per node (unit gradient, distance), toAddr order
+    std::vector<double> grid_cells;
+    int gn[3] = {0, 0, 0};
+    double gres = 0.0, gmin[3] = {0, 0, 0};
     std::vector<V3> V;
     std::vector<int32_t> F;   // 3 per face
     void *hdk = nullptr;      // fwn_bvh of Shape.cpp:86 when the vendored library is available

@@ -87,6 +87,21 @@ int orc_set_shape(void *h, const isdf_shape *s) {
     return 0;
 }
 
+// ISDF_SHAPE_GRID: the lattice of isdf_set_shape_grid (cells: n x 4 doubles)
+int orc_set_shape_grid(void *h, const double *cells, int nx, int ny, int nz, const double *gmin, double nres, double bound_radius) {
+    OrcCtx &c = *(OrcCtx *)h;
+    isdf_shape s{};
+    s.kind = ISDF_SHAPE_GRID; s.grad_mode = ISDF_GRAD_GRID; s.bound_radius = bound_radius;
+    for (int i = 0; i < 9; i++) s.rotate[i] = (i % 4 == 0) ? 1.0 : 0.0;
+    c.P.shape = s;
+    c.mesh.grid_cells.assign(cells, cells + (size_t)4 * nx * ny * nz);
+    c.mesh.gn[0] = nx; c.mesh.gn[1] = ny; c.mesh.gn[2] = nz; c.mesh.gres = nres;
+    for (int a = 0; a < 3; a++) c.mesh.gmin[a] = gmin[a];
+    c.has_shape = true;
+    c.sync();
+    return 0;
+}
+
 // ---- front end (kernel convolution), oracle/frontend.hpp
 int orc_frontend_build(void *h, const isdf_frontend_config *cfg) {
     OrcCtx &c = *(OrcCtx *)h;

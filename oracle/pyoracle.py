@@ -116,6 +116,13 @@ class Oracle:
         """1: the mesh winding number comes from the vendored HDK library (oracle/_ref/libref_fwn.so); 0: exact-sum fallback."""
         return int(self.lib.orc_mesh_backend(self.h))
 
+    def set_shape_grid(self, cells, grid_min, nres, bound_radius=0.0, bbox=None):
+        cells = np.ascontiguousarray(cells, dtype=np.float64)
+        nx, ny, nz, _ = cells.shape
+        gm = np.ascontiguousarray(grid_min, dtype=np.float64)
+        self.lib.orc_set_shape_grid.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.c_int, C.c_int, C.c_int, C.POINTER(C.c_double), C.c_double, C.c_double]
+        self.lib.orc_set_shape_grid(self.h, _p(cells), nx, ny, nz, _p(gm), float(nres), float(bound_radius))
+
     def set_points(self, pts):
         pts = np.ascontiguousarray(pts, dtype=np.float64)
         self.lib.orc_set_points(self.h, _p(pts), pts.shape[0])
@@ -294,6 +301,47 @@ class RefShape:
     def __del__(self):
         try:
             self.lib.ref_shape_destroy(self.h)
+        except Exception:
+            pass
+
+    def num_grid(self, nd, nres):
+        """BasicShape::initShape<false, true>(ndx, ndy, ndz, nres) of THIS shape (Shape.hpp:361-404, the reference's own loop):
+        returns a RefNumGrid holding num_sdf_map."""
+        return RefNumGrid(self, nd, nres)
+
+
+class RefNumGrid:
+    """The reference's cached numeric SDF grid and its samplers getonlySDFNum / getonlyGrad1Num / getSDFwithGrad1Num
+    (Shape.hpp:481-600), compiled from the reference's source."""
+
+    def __init__(self, ref_shape, nd, nres):
+        self.lib = ref_shape.lib
+        self._shape = ref_shape
+        self.lib.ref_numgrid_create.restype = C.c_void_p
+        self.lib.ref_numgrid_create.argtypes = [C.c_void_p, C.c_double, C.c_double, C.c_double, C.c_double, C.POINTER(C.c_int)]
+        dims = (C.c_int * 3)()
+        self.h = C.c_void_p(self.lib.ref_numgrid_create(ref_shape.h, float(nd[0]), float(nd[1]), float(nd[2]), float(nres), dims))
+        self.dims = tuple(dims); self.nres = float(nres)
+        self.lib.ref_numgrid_cells.argtypes = [C.c_void_p, dp, dp]
+        self.lib.ref_numgrid_eval.argtypes = [C.c_void_p, dp, C.c_int, dp, dp, dp, dp]
+        self.lib.ref_numgrid_destroy.argtypes = [C.c_void_p]
+
+    def cells(self):
+        c = np.zeros(self.dims + (4,)); mn = np.zeros(3)
+        self.lib.ref_numgrid_cells(self.h, _p(c), _p(mn))
+        return c, mn
+
+    def eval(self, pts):
+        """(getonlySDFNum, getonlyGrad1Num, getSDFwithGrad1Num value, its gradient [7 where untouched])"""
+        pts = np.ascontiguousarray(pts, dtype=np.float64).reshape(-1, 3)
+        n = pts.shape[0]
+        sa = np.zeros(n); ga = np.zeros((n, 3)); sb = np.zeros(n); gb = np.zeros((n, 3))
+        self.lib.ref_numgrid_eval(self.h, _p(pts), n, _p(sa), _p(ga), _p(sb), _p(gb))
+        return sa, ga, sb, gb
+
+    def __del__(self):
+        try:
+            self.lib.ref_numgrid_destroy(self.h)
         except Exception:
             pass
 

@@ -222,8 +222,49 @@ inline double analytic_local(const isdf_shape &S, const V3 &p) {
     }
 }
 
+// ---- ISDF_SHAPE_GRID: getonlySDFNum (Shape.hpp:481-513), getonlyGrad1Num (:515-553), getSDFwithGrad1Num (:555-600)
+struct GridRef { int idx[8]; double xd, yd, zd; bool inside; };
+inline GridRef grid_locate(const MeshSdf &G, const V3 &p) {
+    GridRef c;
+    const int X = G.gn[0], Y = G.gn[1], Z = G.gn[2];
+    const int i = (int)std::floor((p.x - G.gmin[0]) / G.gres), j = (int)std::floor((p.y - G.gmin[1]) / G.gres), k = (int)std::floor((p.z - G.gmin[2]) / G.gres);
+    c.inside = i >= 0 && i < X - 1 && j >= 0 && j < Y - 1 && k >= 0 && k < Z - 1;
+    c.xd = (p.x - G.gmin[0]) / G.gres - i; c.yd = (p.y - G.gmin[1]) / G.gres - j; c.zd = (p.z - G.gmin[2]) / G.gres - k;
+    const int ijk = i * Y * Z + j * Z + k;
+    c.idx[0] = ijk; c.idx[1] = ijk + Y * Z; c.idx[2] = ijk + Z; c.idx[3] = ijk + Y * Z + Z;
+    c.idx[4] = ijk + 1; c.idx[5] = ijk + Y * Z + 1; c.idx[6] = ijk + Z + 1; c.idx[7] = ijk + Y * Z + Z + 1;
+    return c;
+}
+inline double grid_value(const MeshSdf &G, const GridRef &c) {
+    const double *m = G.grid_cells.data();
+    auto D = [&](int q) { return m[4 * (size_t)c.idx[q] + 3]; };
+    const double xd = c.xd, yd = c.yd, zd = c.zd;
+    const double c00 = D(0) * (1 - xd) + D(1) * xd, c10 = D(2) * (1 - xd) + D(3) * xd;
+    const double c01 = D(4) * (1 - xd) + D(5) * xd, c11 = D(6) * (1 - xd) + D(7) * xd;
+    const double c0 = c00 * (1 - yd) + c10 * yd, c1 = c01 * (1 - yd) + c11 * yd;
+    return c0 * (1 - zd) + c1 * zd;
+}
+inline V3 grid_gradient(const MeshSdf &G, const GridRef &c) {
+    const double *m = G.grid_cells.data();
+    const double xd = c.xd, yd = c.yd, zd = c.zd;
+    // Eigen evaluates g * a * b * c component-wise from the left: ((g a) b) c; the eight terms are added from the left
+    const double fa[8] = {1 - xd, xd, 1 - xd, xd, 1 - xd, xd, 1 - xd, xd};
+    const double fb[8] = {1 - yd, 1 - yd, yd, yd, 1 - yd, 1 - yd, yd, yd};
+    const double fc[8] = {1 - zd, 1 - zd, 1 - zd, 1 - zd, zd, zd, zd, zd};
+    V3 g;
+    for (int q = 0; q < 8; q++) {
+        const double *n = m + 4 * (size_t)c.idx[q];
+        for (int a = 0; a < 3; a++) {
+            const double t = ((n[a] * fa[q]) * fb[q]) * fc[q];
+            g[a] = q == 0 ? t : g[a] + t;
+        }
+    }
+    return normalized(g);
+}
+
 // BasicShape::getonlySDF(pos_rel)  (Shape.hpp:469)
 inline double shape_sdf(const isdf_shape &S, const MeshSdf *mesh, const V3 &p_rel) {
+    if (S.kind == ISDF_SHAPE_GRID) { const GridRef c = grid_locate(*mesh, p_rel); return c.inside ? grid_value(*mesh, c) : 1e20; }
     if (S.kind == ISDF_SHAPE_MESH) return mesh->sdf(p_rel);          // vertices are already body-frame
     if (S.kind == ISDF_SHAPE_BALL) return norm(p_rel) - S.params[0]; // Ball/Point ignore trans/Rotate :617-620
     return analytic_local(S, body_offset(S, p_rel));
@@ -234,6 +275,8 @@ inline double shape_sdf(const isdf_shape &S, const MeshSdf *mesh, const V3 &p_re
 // (:621-624); the mesh Generalshape uses pos * R_obj (Shape.cpp:115-124).  R_obj row-major.
 inline double shape_sdf_rotated(const isdf_shape &S, const MeshSdf *mesh, const V3 &pos, const double *Ro) {
     if (S.kind == ISDF_SHAPE_BALL) return norm(pos) - S.params[0];
+    if (S.kind == ISDF_SHAPE_GRID)
+        return shape_sdf(S, mesh, V3(pos.x * Ro[0] + pos.y * Ro[3] + pos.z * Ro[6], pos.x * Ro[1] + pos.y * Ro[4] + pos.z * Ro[7], pos.x * Ro[2] + pos.y * Ro[5] + pos.z * Ro[8]));
     if (S.kind == ISDF_SHAPE_MESH)
         return mesh->sdf(V3(pos.x * Ro[0] + pos.y * Ro[3] + pos.z * Ro[6], pos.x * Ro[1] + pos.y * Ro[4] + pos.z * Ro[7], pos.x * Ro[2] + pos.y * Ro[5] + pos.z * Ro[8]));
     const V3 q = body_offset(S, pos);
@@ -251,6 +294,7 @@ inline int effective_grad_mode(const isdf_shape &S) {
 // sequence is reproduced literally), Box::getonlyGrad1 :2363-2377, Ball :622-625, mesh Shape.cpp:127-139.
 inline V3 shape_grad(const isdf_shape &S, const MeshSdf *mesh, const V3 &p_rel) {
     if (S.kind == ISDF_SHAPE_MESH) { V3 g; mesh->sdf_grad(p_rel, g); return g; }
+    if (S.kind == ISDF_SHAPE_GRID) { const GridRef c = grid_locate(*mesh, p_rel); return c.inside ? grid_gradient(*mesh, c) : V3(); }
     const int mode = effective_grad_mode(S);
     if (mode == ISDF_GRAD_ANALYTIC_BALL) return normalized(p_rel);
     if (mode == ISDF_GRAD_BOX_FORWARD) {

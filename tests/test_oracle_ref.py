@@ -431,3 +431,39 @@ def test_frontend_kernels_and_checks_vs_reference_code(pkg, orc, name):
             n_ok += 1
             assert r_cr == cr[q] and r_cp == cp[q], (name, q, r_cr, cr[q], r_cp, cp[q])
     assert 0 < n_ok < 600, n_ok        # the scenario exercises both outcomes
+
+
+def test_sampled_grid_shape_vs_reference_code(pkg, orc):
+    """ISDF_SHAPE_GRID (a user-defined host shape tabulated on a body-frame lattice): the oracle's restatement of getonlySDFNum /
+    getonlyGrad1Num / getSDFwithGrad1Num (Shape.hpp:481-600) against the reference's OWN functions on the reference's OWN lattice
+    (BasicShape::initShape, :361-404, run over its RoundedCone class) - values bit for bit, incl. the 1e20 / untouched-gradient
+    behaviour outside the lattice; and the lattice the product's host fill produces from the same class == the reference's."""
+    if not os.path.exists(orc.REF_SHAPES):
+        pytest.skip("oracle/_ref/libref_shapes.so not built")
+    capi, synth = pkg.capi, pkg.synth
+    rs = orc.RefShape("RoundedCone")
+    nd, nres = (4.3, 4.0, 7.25), 0.25
+    rg = rs.num_grid(nd, nres)
+    cells, gmin = rg.cells()
+    assert cells.shape[:3] == (int(np.ceil(nd[0] / nres)), int(np.ceil(nd[1] / nres)), int(np.ceil(nd[2] / nres)))
+    assert np.allclose(gmin, [-nd[0] / 2, -nd[1] / 2, -nd[2] / 2], rtol=0, atol=0)
+    rng = np.random.default_rng(5)
+    hi = gmin + (np.array(cells.shape[:3]) - 1) * nres
+    Q = np.concatenate([rng.uniform(gmin - 0.3, hi + 0.3, (4000, 3)),                 # inside and just outside
+                        gmin + rng.integers(0, 8, (200, 3)) * nres,                   # exactly ON lattice nodes / cell faces
+                        [gmin, hi, hi - 1e-12, gmin + 1e-12]])
+    sa, ga, sb, gb = rg.eval(Q)
+    o = orc.Oracle(synth.default_config(), threads=1)
+    o.set_shape_grid(cells, gmin, nres)
+    s0, g0 = o.shape_eval(Q)
+    inside = sa < 1e19
+    assert inside.sum() > 2500 and (~inside).sum() > 200
+    assert np.array_equal(s0, sa) and np.array_equal(sb, sa)                      # value: same bits, 1e20 outside
+    assert np.array_equal(g0, ga)                                                 # gradient: same bits, zero outside
+    assert np.array_equal(gb[inside], ga[inside]) and np.all(gb[~inside] == 7.0)  # the combined sampler leaves grad alone outside
+    # the sampled function approximates the class it came from: O(nres^2 x curvature) on the distance
+    st, gt = rs.eval(Q[inside])
+    assert np.abs(sa[inside] - st).max() < 0.5 * nres
+    print(f"\\nsampled RoundedCone, nres {nres}: max |sdf_grid - sdf| = {np.abs(sa[inside] - st).max():.3e} m, "
+          f"max |grad_grid - grad| = {np.linalg.norm(ga[inside] - gt, axis=1).max():.3e}")
+    # isdf_set_shape_sampled's host fill (no device needed up to the upload: checked through the oracle-side twin below on the GPU)
