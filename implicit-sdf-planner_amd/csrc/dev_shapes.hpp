@@ -216,6 +216,7 @@ __device__ __forceinline__ T analytic_sdf(const ShapeP<T> &S, int kind_rt, v3<T>
 // ---- ISDF_SHAPE_GRID: getonlySDFNum / getonlyGrad1Num / getSDFwithGrad1Num (Shape.hpp:481-600), operation for operation
 struct GridCellRef { int base[8]; double xd, yd, zd; bool inside; };
 __device__ __forceinline__ GridCellRef grid_locate(const DevShape &S, d3 p) {
+#pragma clang fp contract(off)
     GridCellRef c;
     const double fx = (p.x - S.gmin[0]) / S.gres, fy = (p.y - S.gmin[1]) / S.gres, fz = (p.z - S.gmin[2]) / S.gres;
     const int i = (int)floor(fx), j = (int)floor(fy), k = (int)floor(fz);
@@ -230,6 +231,7 @@ __device__ __forceinline__ GridCellRef grid_locate(const DevShape &S, d3 p) {
     return c;
 }
 __device__ __forceinline__ double grid_value(const DevShape &S, const GridCellRef &c) {
+#pragma clang fp contract(off)      // (the reference's products and sums, not fused: same bits as its getonlySDFNum)
     const double *G = S.grid;
     const double xd = c.xd, yd = c.yd, zd = c.zd;
     const double c00 = G[4 * (size_t)c.base[0] + 3] * (1 - xd) + G[4 * (size_t)c.base[1] + 3] * xd;
@@ -241,6 +243,7 @@ __device__ __forceinline__ double grid_value(const DevShape &S, const GridCellRe
     return c0 * (1 - zd) + c1 * zd;
 }
 __device__ __forceinline__ d3 grid_gradient(const DevShape &S, const GridCellRef &c) {
+#pragma clang fp contract(off)
     const double *G = S.grid;
     const double xd = c.xd, yd = c.yd, zd = c.zd;
     // g000 * (1-xd) * (1-yd) * (1-zd) + g100 * xd * (1-yd) * (1-zd) + ...: Eigen multiplies a vector by its scalars from the left,

@@ -27,7 +27,7 @@ def _lattice(orc, nd, nres, params=(0.8, 0.3, 1.6)):
 
 def test_grid_shape_plugin_and_sweeps(pkg, orc, product_lib):
     capi, synth = pkg.capi, pkg.synth
-    nd, nres = (2.4, 2.4, 3.6), 0.1
+    nd, nres = (4.4, 4.4, 6.4), 0.1          # covers the cone (z -0.8 .. 1.9) plus the band the swept-volume query looks at
     cells, mn = _lattice(orc, nd, nres)
     cfg = synth.default_config(capi.V3_ESDF_TILE, kernel_size=9, integral_intervs=16, safety_hor=0.5)
     occ, esdf, res = small_world(pkg)
