@@ -29,6 +29,7 @@ struct isdf_ctx {
     int *d_fwn_child = nullptr;
     float *d_fwn_box = nullptr;
     double *d_shape_grid = nullptr;      // ISDF_SHAPE_GRID: the sampled lattice
+    void *d_pose = nullptr; size_t pose_cap = 0;      // pose records of a non-fused integral step (bytes)
     // points (V1)
     double *d_points = nullptr;
     int M = 0;

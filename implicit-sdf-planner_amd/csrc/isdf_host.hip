@@ -173,7 +173,7 @@ extern "C" int isdf_destroy(isdf_ctx *c) {
     isdf_xchg_release(c);
     void *ptrs[] = {c->d_cb, c->d_esdf, c->d_occ, c->d_points, c->d_tstar, c->d_acc, c->d_sample_info, c->d_bits, c->d_piece_cost, c->d_in, c->d_out, c->d_stats,
                     c->d_traj_duration, c->d_coarse_t, c->d_coarse_pose, c->d_n_coarse, c->d_point_partial, c->d_point_piece, c->d_point_stat, c->d_point_nr, c->d_task_buf,
-                    c->d_task_map, c->d_v1_words, c->d_point_lmask, c->d_hist, c->d_shape_grid, c->d_dbg, c->d_stage, c->d_stage_flags, c->d_sample_map, c->d_plan_cls, c->d_plan_map, c->d_plan_lr, c->d_plan_hist};
+                    c->d_task_map, c->d_v1_words, c->d_point_lmask, c->d_hist, c->d_shape_grid, c->d_pose, c->d_dbg, c->d_stage, c->d_stage_flags, c->d_sample_map, c->d_plan_cls, c->d_plan_map, c->d_plan_lr, c->d_plan_hist};
     for (void *p : ptrs) if (p) (void)hipFree(p);
     free_mesh(c);
     if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -780,6 +780,17 @@ static int eval_device_impl(isdf_ctx *c, int n_traj, int N, const double *d_T, c
             if (k >= 3) P.sample_map = c->d_plan_map + (size_t)c->plan_cur * nsc;
             if (c->plan_k < (1 << 30)) c->plan_k++;
         }
+    }
+    if (!fused && cfg.enable_pos) {                 // the poses of a non-fused launch come from pose_kernel (tile_sweep.hip)
+        const size_t need = (size_t)(pe - pb) * (cfg.integral_intervs + 1) * sweep_pose_bytes();
+        if (c->pose_cap < need) {
+            HIPCHK(c, hipStreamSynchronize(st));
+            if (c->d_pose) (void)hipFree(c->d_pose);
+            c->d_pose = nullptr; c->pose_cap = 0;
+            HIPCHK(c, hipMalloc(&c->d_pose, need));
+            c->pose_cap = need;
+        }
+        P.poses = c->d_pose;
     }
     launch_sweep(P, st, ev ? ev->a : nullptr, ev ? ev->b : nullptr, fused);
     if (!fused) launch_tail(P, st, ev2 ? ev->c : nullptr, ev2 ? ev->d : nullptr);
@@ -1629,6 +1640,17 @@ extern "C" int isdf_debug_plan_map(isdf_ctx *c, int *out, long long cap) {
     const long long n = 4LL * c->plan_nb < cap ? 4LL * c->plan_nb : cap;
     if (out && n > 0) (void)hipMemcpy(out, c->d_plan_map + (size_t)c->plan_cur * c->plan_ns_cap, (size_t)n * sizeof(int), hipMemcpyDeviceToHost);
     return c->plan_k;
+}
+
+// developer tool (not declared in the ABI header): per-sample (exact pairs, active pairs | culled << 31) of the last integral step
+extern "C" long long isdf_debug_sample_info(isdf_ctx *c, int *out, long long cap) {
+    if (!c || !c->d_sample_info || !c->have_last_P) return 0;
+    (void)hipSetDevice(c->device);
+    (void)hipDeviceSynchronize();
+    const long long n = (long long)(c->last_P.piece_end - c->last_P.piece_begin) * (c->last_P.K + 1);
+    const long long m = 2 * n < cap ? 2 * n : cap;
+    if (out && m > 0) (void)hipMemcpy(out, c->d_sample_info, (size_t)m * sizeof(int), hipMemcpyDeviceToHost);
+    return n;
 }
 
 // developer tool (not declared in the ABI header): the HIP runtime's pending error of the calling thread, without clearing it

@@ -77,6 +77,7 @@ struct SweepParams {
     // Dispatch order of a fused single-launch step (scheduling only; results cannot depend on it): rank in the launch
     // (workgroup b, wave w: b + w * n_sweep_blocks) -> local sample, -1 = none.  The tail workgroups of step k build the order
     // for step k + 1 from the work classes the sweep waves of step k - 1 left (plan_piece, tile_sweep.hip).
+    void *poses;                // non-fused launches: [local samples] pose records (tile_sweep.hip SweepPose) written by pose_kernel
     const int *sample_map;
     unsigned char *plan_cls_out;        // this step's work classes, one per local sample (sweep waves)
     const unsigned char *plan_cls_in;   // the classes of the step before -> plan_lr_out / plan_hist_out (tail workgroups)
@@ -92,6 +93,7 @@ struct SweepParams {
 // one optimizer step of the integral sweep = sweep, tail, in order, on `stream`
 // ev_start / ev_stop (nullable): HIP events attached to the kernel dispatch itself (hipExtLaunchKernelGGL), i.e. its begin and
 // end timestamps - the same interval rocprofv3 reports for the kernel
+size_t sweep_pose_bytes();      // sizeof(SweepPose)
 bool sweep_can_fuse(const SweepParams &P);
 int sweep_resident_blocks(const SweepParams &P, int n_cus);      // small launch, analytic shape with identity body offset: sweep + tail in one launch
 void launch_sweep(const SweepParams &P, hipStream_t stream, hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr, bool fused = false);

@@ -28,6 +28,9 @@
 //                   XFuse, fetch the owner's rows) so that every rank ends up with, or sums to, the full result.
 // Everything that reaches the result is fp64 except the stored ESDF (fp32).  No MFMA: gather/interpolate work.
 #define ISDF_LEAN_MATH 1      // dev_math.hpp / dev_shapes.hpp: lean sqrt and normalisation in this translation unit
+#ifndef ISDF_POSE_LDS
+#define ISDF_POSE_LDS 1
+#endif
 #include "isdf_internal.hpp"
 #include "dev_mesh.hpp"
 
@@ -337,6 +340,99 @@ __device__ void plan_wave(const SweepParams &P, const int t, const int lane) {  
     }
 }
 
+// Poses of a launch that is not one fused step, one THREAD per sample: exactly the record the fused kernel's first stage builds
+// in LDS (same functions, same operations: a batch stays bitwise equal to its trajectories evaluated one by one) - the serial
+// chain position -> flatness -> rotation -> where the shape's inflated bounding box lies on each axis, the tile's index box as
+// getPointsInAABB (PCSmap_manager.h:150-155), the window of rows and the scan axis.
+__global__ __launch_bounds__(256) void pose_kernel(const SweepParams P) {
+    const int K1 = P.K + 1;
+    const long long s_begin = (long long)P.piece_begin * K1, s_end = (long long)P.piece_end * K1;
+    const long long sidx = s_begin + (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (sidx >= s_end) return;
+    const DevGrid &G = P.grid;
+    SweepPose sp;
+    for (int k = 0; k < (int)(sizeof(SweepPose) / 8); k++) ((double *)&sp)[k] = 0.0;
+    const SampleId id = decode_sample(P, sidx);
+    const PieceIn pin = piece_in(P, id.b, id.i);
+    const double *c = pin.c;
+    const int ld = pin.ld;
+    const double step = pin.T * P.inv_K;
+    Basis B;
+    poly_basis(id.j * step, B);
+    const d3 pos = ct_beta(c, ld, B.b0), vel = ct_beta<1>(c, ld, B.b1), acc = ct_beta<2>(c, ld, B.b2);
+    FlatS fs;
+    flat_core(P.flat, vel, acc, fs);
+    const d4 quat = flat_quat(fs);
+    const m3 R = quat_to_rot(quat);
+    sp.pos[0] = pos.x; sp.pos[1] = pos.y; sp.pos[2] = pos.z;
+#pragma unroll
+    for (int k = 0; k < 9; k++) sp.R[k] = R.a[k];
+    sp.quat[0] = quat.w; sp.quat[1] = quat.x; sp.quat[2] = quat.y; sp.quat[3] = quat.z;
+    int flags = 0;
+    if (P.enable_pos) {
+        flags = 1;
+        if (P.cull_threshold > 0.0 && esdf_trilinear(G, pos) > P.cull_threshold) flags = 2;
+    }
+    if ((flags & 1) && P.shape.prune_rows) {
+        const double infl = P.safety_hor * mesh_band_scale(P.shape.kind) + 4.0e-3 + 0.05 * G.res;
+        const double inv_res = m_rcp(G.res);
+        const double hb[3] = {0.5 * ((double)P.shape.bbox_hi[0] - (double)P.shape.bbox_lo[0]) + infl,
+                              0.5 * ((double)P.shape.bbox_hi[1] - (double)P.shape.bbox_lo[1]) + infl,
+                              0.5 * ((double)P.shape.bbox_hi[2] - (double)P.shape.bbox_lo[2]) + infl};
+        const double cb[3] = {0.5 * ((double)P.shape.bbox_hi[0] + (double)P.shape.bbox_lo[0]),
+                              0.5 * ((double)P.shape.bbox_hi[1] + (double)P.shape.bbox_lo[1]),
+                              0.5 * ((double)P.shape.bbox_hi[2] + (double)P.shape.bbox_lo[2])};
+        const double p[3] = {pos.x, pos.y, pos.z};
+#pragma unroll
+        for (int a = 0; a < 3; a++) {
+            const double ctr = p[a] + R.a[3 * a] * cb[0] + R.a[3 * a + 1] * cb[1] + R.a[3 * a + 2] * cb[2];
+            const double ext = fabs(R.a[3 * a]) * hb[0] + fabs(R.a[3 * a + 1]) * hb[1] + fabs(R.a[3 * a + 2]) * hb[2];
+            sp.L0[a] = (ctr - ext - G.bmin[a]) * inv_res - 0.5;
+            sp.L1[a] = (ctr + ext - G.bmin[a]) * inv_res - 0.5;
+        }
+    }
+    int nn[3] = {0, 0, 0};
+    if (P.enable_pos) {
+        const double pa[3] = {pos.x, pos.y, pos.z};
+        const int dims[3] = {G.X, G.Y, G.Z};
+#pragma unroll
+        for (int a = 0; a < 3; a++) {
+            const int lo = axis_index(clampd(pa[a] - P.bd_half, G.bmin[a], G.bmax[a]), G.bmin[a], G.res, dims[a]);
+            const int hi = axis_index(clampd(pa[a] + P.bd_half, G.bmin[a], G.bmax[a]), G.bmin[a], G.res, dims[a]);
+            sp.lo[a] = lo;
+            sp.nn[a] = nn[a] = hi - lo + 1;
+        }
+    }
+    // window of rows and scan axis (the fused kernel's per-wave finish)
+    int flags_w = flags;
+    if ((flags_w & 1) && !(nn[0] > 0 && nn[1] > 0 && nn[2] > 0)) flags_w &= ~1;
+    int w0[3] = {0, 0, 0}, w1[3] = {nn[0] - 1, nn[1] - 1, nn[2] - 1};
+    const bool windowed = (flags_w & 1) && P.shape.prune_rows;
+    if (windowed) {
+#pragma unroll
+        for (int a = 0; a < 3; a++) {
+            const double l0 = sp.L0[a] - sp.lo[a], l1 = sp.L1[a] - sp.lo[a];
+            if (l0 > 0.0) w0[a] = (int)fmin(floor(l0), (double)nn[a]);
+            if (l1 < (double)(nn[a] - 1)) w1[a] = (int)fmax(ceil(l1), -1.0);
+        }
+    }
+    int sa_w = 2;
+    if (windowed) {
+        const int e0 = w1[0] - w0[0], e1 = w1[1] - w0[1], e2 = w1[2] - w0[2];
+        if (P.shape.kind != ISDF_SHAPE_MESH) sa_w = (e2 >= e0 && e2 >= e1) ? 2 : (e0 >= e1 ? 0 : 1);
+    }
+    const int u0 = sa_w == 0 ? w0[1] : w0[0], u1 = sa_w == 0 ? w1[1] : w1[0];
+    const int v0 = sa_w == 2 ? w0[1] : w0[2], v1 = sa_w == 2 ? w1[1] : w1[2];
+    sp.rx0 = (flags_w & 1) ? u0 : 0; sp.ry0 = (flags_w & 1) ? v0 : 0;
+    sp.rnx = (flags_w & 1) ? max(0, u1 - u0 + 1) : 0; sp.rny = (flags_w & 1) ? max(0, v1 - v0 + 1) : 0;
+    sp.nzt = sa_w == 2 ? nn[2] : (sa_w == 0 ? nn[0] : nn[1]);
+    sp.flags = flags_w;
+    sp.sa = sa_w;
+    double *dst = (double *)((SweepPose *)P.poses + (sidx - s_begin));
+    for (int k = 0; k < (int)(sizeof(SweepPose) / 8); k++) dst[k] = ((const double *)&sp)[k];
+}
+size_t sweep_pose_bytes() { return sizeof(SweepPose); }
+
 // IDENT: the shape's body offset is the identity (poly_params all zero - every shipped config): those instantiations drop
 // the offset and the 24 scalar registers it pins, which takes Box to 91 VGPRs and a fifth wave per SIMD.
 template <bool EARLY, bool XF> __device__ __forceinline__ void tail_piece(const SweepParams &P, const int t, double (*s_val)[PARTIAL_STRIDE + 1]);
@@ -394,6 +490,7 @@ __global__ __launch_bounds__(64 * SW_SAMPLES, FUSED ? 3 : sweep_waves_per_simd(K
         if (P.sample_map) { const int m = P.sample_map[rank]; return m >= 0 ? s_begin + m : s_end; }
         return s_begin + rank;
     };
+    if constexpr (FUSED) {
     long long pose_sidx = s_end;
     if (wave == 0 && lane < SW_SAMPLES) pose_sidx = sample_of_rank((long long)blockIdx.x + (long long)lane * n_blocks);
     if (pose_sidx < s_end) {
@@ -467,12 +564,21 @@ __global__ __launch_bounds__(64 * SW_SAMPLES, FUSED ? 3 : sweep_waves_per_simd(K
             s_pose[ps].nn[a] = hi - lo + 1;             // NaN poses make every comparison false: the extent then says "no tile"
         }
     }
+    } else {
+        // a launch that is not one resident fused step (a batch, a long trajectory, a shard): the poses of ALL its samples were formed
+        // by pose_kernel, one THREAD per sample - here the serial chain above would be issued once per workgroup for four active
+        // lanes, a quarter of this kernel's instruction issue (profiles/r3a_c3_*) - and every wave only fetches its sample's record
+        const SweepPose *gp = (const SweepPose *)P.poses;
+        double *dst = (double *)&s_pose[wave];
+        if (sidx < s_end) { const double *src = (const double *)(gp + (sidx - s_begin)); if (lane < (int)(sizeof(SweepPose) / 8)) dst[lane] = src[lane]; }
+        else if (lane == 0) s_pose[wave].flags = 0;
+    }
     __syncthreads();
     if (dbg && lane == 0) dbg[2] = clock64();
 
     const bool have_sample = sidx < s_end;
     SweepPose &sp = s_pose[wave];
-    {
+    if constexpr (FUSED) {
         // ---- this wave's sample: window of rows and scan axis (wave-uniform; every lane computes the same)
         // Rows run along the world axis on which the shape's inflated bounding box is LONGEST (the bit-grid exists packed along
         // each axis): the window of rows spans the two short extents - a 3.2 m robot lying along x needs ~50 rows of ~20 voxels
@@ -791,10 +897,13 @@ __global__ __launch_bounds__(64 * SW_SAMPLES, FUSED ? 3 : sweep_waves_per_simd(K
             }
         }
         int cur_s = -1;
-        d3 pos = mk3(0, 0, 0); m3 R; d4 quat; int clx = 0, cly = 0, clz = 0;
+        int clx = 0, cly = 0, clz = 0;
+#if !ISDF_POSE_LDS
+        d3 pos = mk3(0, 0, 0); m3 R; d4 quat;
 #pragma unroll
         for (int k = 0; k < 9; k++) R.a[k] = 0.0;
         quat.w = quat.x = quat.y = quat.z = 0.0;
+#endif
         for (int it = 0; it < my_own + my_spare; it++) {
             // (sample, chunk) of this wave's it-th work item
             int cs = wave, cc = it;
@@ -808,12 +917,14 @@ __global__ __launch_bounds__(64 * SW_SAMPLES, FUSED ? 3 : sweep_waves_per_simd(K
                 }
                 if (cs < 0) break;                     // no leftover chunk for this slot
             }
-            if (cs != cur_s) {                         // pose of the chunk's sample -> scalar registers
+            if (cs != cur_s) {                         // tile origin of the chunk's sample -> scalar registers
                 const SweepPose &q = s_pose[cs];
+#if !ISDF_POSE_LDS
                 pos = mk3(uni(q.pos[0]), uni(q.pos[1]), uni(q.pos[2]));
 #pragma unroll
                 for (int k = 0; k < 9; k++) R.a[k] = uni(q.R[k]);
                 quat.w = uni(q.quat[0]); quat.x = uni(q.quat[1]); quat.y = uni(q.quat[2]); quat.z = uni(q.quat[3]);
+#endif
                 clx = __builtin_amdgcn_readfirstlane(q.lo[0]); cly = __builtin_amdgcn_readfirstlane(q.lo[1]);
                 clz = __builtin_amdgcn_readfirstlane(q.lo[2]);
                 cur_s = cs;
@@ -827,6 +938,19 @@ __global__ __launch_bounds__(64 * SW_SAMPLES, FUSED ? 3 : sweep_waves_per_simd(K
             if (lane < n && !(P.dbg_flags & 1)) {
                 const int gx = clx + (int)(ent & 1023u), gy = cly + (int)((ent >> 10) & 1023u), gz = clz + (int)(ent >> 20);
                 const d3 ctr = mk3((gx + 0.5) * G.res + G.bmin[0], (gy + 0.5) * G.res + G.bmin[1], (gz + 0.5) * G.res + G.bmin[2]);
+#if ISDF_POSE_LDS
+                // The pose (16 doubles) is READ FROM LDS where it is used - once here, once more for the force terms below -
+                // instead of living in 32 scalar registers for the whole loop: the loop's scalar state no longer fits the SGPR
+                // file with it, and every spilled scalar costs a v_readlane, i.e. a VALU issue slot of this issue-bound kernel
+                // (broadcast ds_reads go down the LDS pipe).  The index is laundered so that the two reads stay two reads.
+                int csa = cs;
+                asm volatile("" : "+v"(csa));
+                const SweepPose &qa = s_pose[csa];
+                const d3 pos = mk3(qa.pos[0], qa.pos[1], qa.pos[2]);
+                m3 R;
+#pragma unroll
+                for (int k = 0; k < 9; k++) R.a[k] = qa.R[k];
+#endif
                 const d3 pm = ctr - pos;
                 const d3 prel = mat_tmul(R, pm);
                 // the cube cull (:800-803) as ONE test: three short-circuit comparisons compile to three nested masked regions, each
@@ -848,6 +972,15 @@ __global__ __launch_bounds__(64 * SW_SAMPLES, FUSED ? 3 : sweep_waves_per_simd(K
                         if constexpr (KIND != ISDF_SHAPE_MESH) g = shape_grad<KIND, IDENT>(P.shape, prel);
                         is_grad = true;
                         v[0] = f;
+#if ISDF_POSE_LDS
+                        int csb = cs;
+                        asm volatile("" : "+v"(csb));
+                        const SweepPose &qb = s_pose[csb];
+                        m3 R;
+#pragma unroll
+                        for (int k = 0; k < 9; k++) R.a[k] = qb.R[k];
+                        d4 quat; quat.w = qb.quat[0]; quat.x = qb.quat[1]; quat.y = qb.quat[2]; quat.z = qb.quat[3];
+#endif
                         const d3 wg = mat_mul(R, g);
                         v[1] = df * wg.x; v[2] = df * wg.y; v[3] = df * wg.z;
                         const d4 sq = quat_step_grad(quat, g, pm);
@@ -1222,6 +1355,7 @@ void launch_sweep(const SweepParams &P0, hipStream_t stream, hipEvent_t ev_start
     P.n_sweep_blocks = (int)((n_samples + SW_SAMPLES - 1) / SW_SAMPLES);
     const dim3 grid((unsigned)(P.n_sweep_blocks + (fused ? P.n_traj * P.N : 0))), block(64 * SW_SAMPLES);
     const bool ident = P.shape.d.ident != 0;
+    if (!fused) hipLaunchKernelGGL(pose_kernel, dim3((unsigned)((n_samples + 255) / 256)), dim3(256), 0, stream, P);      // the poses of every sample, one thread each
 #define ISDF_LAUNCH_SWEEP(K, I, F) hipExtLaunchKernelGGL((sweep_kernel<K, I, F>), grid, block, 0, stream, ev_start, ev_stop, 0, P)
 #define ISDF_SWEEP_CASE(K) case K: if (fused) ISDF_LAUNCH_SWEEP(K, true, true); else if (ident) ISDF_LAUNCH_SWEEP(K, true, false); else ISDF_LAUNCH_SWEEP(K, false, false); break;
     switch (P.shape.kind) {
