@@ -10,7 +10,7 @@
 //       in 124 ms = 2.95e8 point-evals/s end to end, 97 % of the sweep kernel's own rate (tools/batch_opt_bench.py), or
 //   on the device (csrc/minco_dev.hip: one wavefront per trajectory, only x goes up and (cost, g) comes down): a round is then
 //       [forward 148 us | sweep | backward 93 us] - 6N dependent pivots per solve - and the same batch takes 209-324 ms; it is
-//       selected when the batch outnumbers the host's cores four to one, or with ISDF_BATCH_DEVICE_MINCO=1.
+//       an experiment behind ISDF_BATCH_DEVICE_MINCO=1, never selected by itself (tested: tests/test_gpu_minco_dev.py).
 // Which trajectories share a round has no influence on results, and the device MINCO performs the host MINCO's operations one
 // for one: either way the iterates are bitwise those of isdf_optimize_lbfgs on each trajectory alone.
 #include "isdf_ctx.hpp"
@@ -128,8 +128,11 @@ extern "C" int isdf_optimize_lbfgs_batch(isdf_ctx *c, int n_traj, int N, const d
     if (const char *e = getenv("ISDF_BATCH_MIN_SHARE")) { const double v = atof(e); if (v > 0.0 && v <= 1.0) b.min_share = v; }
     b.stage_x.assign((size_t)n_traj * b.n, 0.0);
     b.stage_res.assign((size_t)n_traj * (1 + b.n), 0.0);
-    // Where MINCO runs (see the head of this file): the host threads unless the batch outnumbers the cores four to one.
-    b.device_minco = n_traj > 4 * (int)std::max(1u, std::thread::hardware_concurrency());
+    // Where MINCO runs: on the trajectories' host threads.  The device form (csrc/minco_dev.hip: same operations, bitwise the same
+    // iterates - tests/test_gpu_minco_dev.py) is an EXPERIMENT kept behind ISDF_BATCH_DEVICE_MINCO=1 and never selected by itself:
+    // a factorisation is a chain of 6N dependent pivots and one wavefront walks it in 148 + 93 us per round, against ~10 us per
+    // solve on a CPU core - 128 trajectories take 209-324 ms that way against ~100 ms with host threads.
+    b.device_minco = false;
     if (const char *e = getenv("ISDF_BATCH_DEVICE_MINCO")) b.device_minco = e[0] == '1';
     if (isdf::minco_backward_lds(N) > 64 * 1024) b.device_minco = false;       // a trajectory's band system must fit in LDS
     b.in_per = (size_t)19 * N;

@@ -371,9 +371,10 @@ int isdf_optimize_lbfgs(isdf_ctx *ctx, double *x_inout, int n, const isdf_lbfgs_
  * boundary states heads_pva[9t..], tails_pva[9t..] (3x3 column-major each, like isdf_set_trajectory) and its own
  * variables x_inout[t*n .. (t+1)*n), n = N + 3(N-1); all share N, rho and the ctx's map / robot / weights.  Each runs
  * the same L-BFGS driver on its own callback; the callbacks of a round are evaluated as ONE batched integral sweep on the
- * device, several rounds in flight.  MINCO runs on the trajectories' host threads or - ISDF_BATCH_DEVICE_MINCO=1, or a batch
- * that outnumbers the host's cores four to one - on the device too (one wavefront per trajectory; only x goes up, (cost, g)
- * comes down); it performs the same operations either way.  The iterates are identical to optimising every trajectory alone
+ * device, several rounds in flight.  MINCO runs on the trajectories' host threads; ISDF_BATCH_DEVICE_MINCO=1 moves it to the device
+ * too (one wavefront per trajectory; only x goes up, (cost, g) comes down; the same operations, hence the same iterates) - an
+ * experiment that is measured SLOWER than the host threads and is never selected by itself (isdf_minco_device runs those two
+ * kernels on their own).  The iterates are identical to optimising every trajectory alone
  * with isdf_optimize_lbfgs.  results[t].reserved = number of device rounds of the whole batch.  V2 / V3 contexts only; not on
  * a sharded ctx (shard the batch across ranks instead). */
 int isdf_optimize_lbfgs_batch(isdf_ctx *ctx, int n_traj, int N, const double *heads_pva, const double *tails_pva, double rho,
