@@ -572,6 +572,7 @@ def main():
 
         # ---- through the drop-in boundary (PCIe inclusive, synchronous, accumulate) - informational, never `value`
         host_ms = None
+        host_ms_multi = None
         host_timer = None
         cb_native_ms = None
         x0 = None
@@ -590,6 +591,16 @@ def main():
             elif nat is not None:
                 host_ms, cb_native_ms = nat
                 host_timer = "native: median of 1000 isdf_eval calls inside the compiled reference-side binding (tests/native/binding_stub.cpp)"
+                # the same call on a ctx over TWO 'devices' (this GPU listed twice: isdf_create_multi) - what the single-process
+                # multi-GPU path adds on top of the copy path (input broadcast, two shard launches, the rank-ordered sum kernel)
+                try:
+                    em = pkg.Engine(cfg, devices=[local_rank, local_rank])
+                    em.set_grid(esdf, (0, 0, 0), res, capi.GRID_ESDF); em.set_shape(shape)
+                    natm = native_boundary_ms(pkg, em, N, T, cm, None)
+                    host_ms_multi = None if natm is None else round(natm[0], 4)
+                    del em
+                except Exception:       # noqa: BLE001
+                    host_ms_multi = None
             else:
                 eng.eval_single(T, cm)
                 th0 = time.perf_counter()
@@ -671,6 +682,7 @@ def main():
                        "rccl_all_reduce_ms_per_step": None if rccl_ms is None else round(rccl_ms, 5)},
             "roofline": roofline, "roofline_issue": issue, "cpu_baseline": cpu, "configs": extra,
             "value_steady": value_steady, "parity_rel_err_vs_oracle": parity, "host_api_ms": None if host_ms is None else round(host_ms, 4), "host_api_timer": host_timer,
+            "host_api_ms_two_shards_one_gpu": host_ms_multi,
             "stats_last_step_rank0": stats, "lbfgs": lbfgs, "hbm_copy_gbs_measured": hbm_copy,
         }
         print(json.dumps(result), flush=True)
