@@ -413,4 +413,44 @@ __device__ __forceinline__ void wave_sum8(double (&v)[8], int lane) {
     v[0] += dpp_mov_f64<0xB1>(v[0]);    // quad_perm [1,0,3,2]
 }
 
+// The same butterfly for a wavefront that holds TWO independent blocks of 32 lanes / FOUR blocks of 16 (the rows): the levels
+// that would combine lanes of different blocks (xor 32 / xor 32 and 16) are left out and the register set is halved at the
+// following levels instead.  Per component the operands of every remaining addition are those of wave_sum8 run on the block
+// alone in lanes 0.. of an otherwise zero wavefront (the levels left out only add those zeros), so the sums carry the same bits.
+// halves: component k of a block -> v[0] of its lanes with ((lane >> 2) & 7) == k;  rows: ((lane >> 1) & 7) == k.
+__device__ __forceinline__ void wave_sum8_halves(double (&v)[8], int lane) {
+    const bool b3 = (lane & 8) != 0, b2 = (lane & 4) != 0;
+#pragma unroll
+    for (int i = 0; i < 4; i++) v[i] = swap16_sum(v[i], v[4 + i]);      // even rows keep components i, odd rows 4 + i
+#pragma unroll
+    for (int j = 0; j < 2; j++) {                                       // partner lane ^ 8: keep j (bit 3 clear) or 2 + j
+        const double send = b3 ? v[j] : v[2 + j], keep = b3 ? v[2 + j] : v[j];
+        v[j] = keep + dpp_mov_f64<0x128>(send);
+    }
+    {                                                                   // partner 7 - i of the group of 8 (the other bit 2): keep 0 or 1
+        const double send = b2 ? v[0] : v[1], keep = b2 ? v[1] : v[0];
+        v[0] = keep + dpp_mov_f64<0x141>(send);
+    }
+    v[0] += dpp_mov_f64<0x4E>(v[0]);
+    v[0] += dpp_mov_f64<0xB1>(v[0]);
+}
+__device__ __forceinline__ void wave_sum8_rows(double (&v)[8], int lane) {
+    const bool b3 = (lane & 8) != 0, b2 = (lane & 4) != 0, b1 = (lane & 2) != 0;
+#pragma unroll
+    for (int i = 0; i < 4; i++) {                                       // partner lane ^ 8: keep i (bit 3 clear) or 4 + i
+        const double send = b3 ? v[i] : v[4 + i], keep = b3 ? v[4 + i] : v[i];
+        v[i] = keep + dpp_mov_f64<0x128>(send);
+    }
+#pragma unroll
+    for (int j = 0; j < 2; j++) {                                       // partner 7 - i: keep j (bit 2 clear) or 2 + j
+        const double send = b2 ? v[j] : v[2 + j], keep = b2 ? v[2 + j] : v[j];
+        v[j] = keep + dpp_mov_f64<0x141>(send);
+    }
+    {                                                                   // partner lane ^ 2: keep 0 (bit 1 clear) or 1
+        const double send = b1 ? v[0] : v[1], keep = b1 ? v[1] : v[0];
+        v[0] = keep + dpp_mov_f64<0x4E>(send);
+    }
+    v[0] += dpp_mov_f64<0xB1>(v[0]);
+}
+
 } // namespace isdf

@@ -461,7 +461,7 @@ __global__ __launch_bounds__(64 * SW_SAMPLES, FUSED ? 3 : sweep_waves_per_simd(K
     __shared__ SweepPose s_pose[SW_SAMPLES];
     __shared__ unsigned s_list[SW_SAMPLES][SW_LIST_CAP];          // ring of compacted voxels awaiting the fp32 test
     __shared__ unsigned s_near[SW_SAMPLES][SW_NEAR_CAP];          // ring of candidates awaiting the exact pass
-    __shared__ int s_plan[SW_SAMPLES][4];                         // per sample: candidates, ring head, finished
+    __shared__ __attribute__((aligned(16))) int s_plan[SW_SAMPLES][4];                         // per sample: candidates, ring head, finished
     __shared__ double s_res[SW_SAMPLES][SW_NEAR_CAP / 64][ACC_STRIDE];   // per chunk: the 8 collision sums
     __shared__ int s_resn[SW_SAMPLES][SW_NEAR_CAP / 64][2];       // per chunk: exact pairs, active pairs
 
@@ -871,86 +871,94 @@ __global__ __launch_bounds__(64 * SW_SAMPLES, FUSED ? 3 : sweep_waves_per_simd(K
         if (lane == 0) { s_plan[wave][0] = near_cnt; s_plan[wave][1] = near_head; s_plan[wave][2] = finished ? 1 : 0; }
         __syncthreads();
 
-        // ================= exact phase: the workgroup's candidate chunks (64 voxels of one sample), spread evenly
-        // over its waves.  Plan (identical in every wave): each wave keeps up to `quota` chunks of its own sample,
-        // the rest go to the waves with spare room, in sample order.
-        // (the per-sample chunk counts are kept packed, 4 bits each, and everything else is re-derived where needed: scalar
-        // registers are the scarce resource of this kernel - what does not fit is spilled through VALU lanes)
-        int nch_pk = 0, C = 0, all_done = 1;
-#pragma unroll
-        for (int w = 0; w < SW_SAMPLES; w++) {
-            const int n_w = (__builtin_amdgcn_readfirstlane(s_plan[w][0]) + 63) >> 6;
-            all_done &= __builtin_amdgcn_readfirstlane(s_plan[w][2]);
-            nch_pk |= n_w << (4 * w);
-            C += n_w;
-        }
-        const int quota = (C + SW_SAMPLES - 1) / SW_SAMPLES;
-        int my_off = 0, my_spare = 0, my_own = 0;      // this wave: first leftover index it takes, how many, own chunks
+        // ================= exact phase: the workgroup's candidates in blocks of up to 64 of one sample, dealt round-robin to its
+        // waves.  A sample's FULL blocks are one wavefront iteration each.  Its last, partial block is classed by size - whole
+        // (> 32 candidates), half (<= 32) or quarter (<= 16) - and blocks of the same class share an iteration: two halves on lanes
+        // 0-31 / 32-63, four quarters on the four rows of 16.  A block's sums are reduced by the SAME butterfly whatever it shares
+        // the wavefront with (wave_sum8_halves / _rows only leave out the levels that add the zeros of a part-filled wavefront),
+        // so a sample's result does not depend on its neighbours in the workgroup: 17-19 % fewer iterations at C2 / C3
+        // (tools/chunk_hist.py) with every bitwise identity (batch == single, shards, cull on == off) kept.
+        // The plan is identical in every wave.  It is worked out on the lanes (lane l looks at sample l & 3: one LDS read, a few
+        // compares whose wave-wide ballots ARE the class masks, two quad exchanges) and kept packed in scalars:
+        // f_pk = full blocks per sample (4 bits each), cls_m = samples whose partial block is whole (bits 0-3), half (4-7), quarter (8-11).
+        int f_pk, n_full, cls_m, all_done;
         {
-            int off = 0;
-#pragma unroll
-            for (int w = 0; w < SW_SAMPLES; w++) {
-                const int own_w = min((nch_pk >> (4 * w)) & 15, quota);
-                const int spare = quota - own_w;
-                if (w == wave) { my_off = off; my_spare = spare; my_own = own_w; }
-                off += spare;
-            }
+            const int4 pl = *reinterpret_cast<const int4 *>(&s_plan[lane & 3][0]);       // candidates, ring head, finished
+            const int r = pl.x & 63;
+            const int m_w = (int)__ballot(r > 32) & 15, m_h = (int)__ballot(r > 16 && r <= 32) & 15, m_q = (int)__ballot(r > 0 && r <= 16) & 15;
+            cls_m = m_w | (m_h << 4) | (m_q << 8);
+            all_done = ((int)__ballot(pl.z != 0) & 15) == 15;
+            int f = pl.x >> 6, fp = f << (4 * (lane & 3));
+            f += __builtin_amdgcn_update_dpp(0, f, 0xB1, 0xf, 0xf, false);   fp |= __builtin_amdgcn_update_dpp(0, fp, 0xB1, 0xf, 0xf, false);
+            f += __builtin_amdgcn_update_dpp(0, f, 0x4E, 0xf, 0xf, false);   fp |= __builtin_amdgcn_update_dpp(0, fp, 0x4E, 0xf, 0xf, false);
+            n_full = __builtin_amdgcn_readfirstlane(f); f_pk = __builtin_amdgcn_readfirstlane(fp);
         }
-        int cur_s = -1;
-        int clx = 0, cly = 0, clz = 0;
-#if !ISDF_POSE_LDS
-        d3 pos = mk3(0, 0, 0); m3 R; d4 quat;
+        const int n_w = __builtin_popcount(cls_m & 15), n_hb = (__builtin_popcount((cls_m >> 4) & 15) + 1) >> 1;
+        const int n_items = n_full + n_w + n_hb + ((cls_m >> 8) != 0);
+        const int lane_q3 = 3 * (lane >> 4);
+        for (int e = wave; e < n_items; e += SW_SAMPLES) {
+            // this item: owner of each row of 16 lanes (3 bits each, 7 = nobody), lanes per block - 1, block index (-1: the partial one).
+            // Items in order: full blocks by sample; whole partial blocks; pairs of halves (in sample order); the quarters
+            // (all in one item, sample s on row s).
+            int ob, lmask = 63, cc_u = -1;
+            {
+                int t = e;
+                if (t < n_full) {
+                    int cs = 0;
 #pragma unroll
-        for (int k = 0; k < 9; k++) R.a[k] = 0.0;
-        quat.w = quat.x = quat.y = quat.z = 0.0;
-#endif
-        for (int it = 0; it < my_own + my_spare; it++) {
-            // (sample, chunk) of this wave's it-th work item
-            int cs = wave, cc = it;
-            if (it >= my_own) {
-                int e = my_off + (it - my_own);
-                cs = -1;
-#pragma unroll
-                for (int w = 0; w < SW_SAMPLES; w++) {
-                    const int nch_w = (nch_pk >> (4 * w)) & 15, own_w = min(nch_w, quota), left = nch_w - own_w;
-                    if (cs < 0) { if (e < left) { cs = w; cc = own_w + e; } else e -= left; }
+                    for (int w = 0; w < SW_SAMPLES; w++) {
+                        const int f_w = (f_pk >> (4 * w)) & 15;
+                        const bool hit = t >= 0 && t < f_w;
+                        cs = hit ? w : cs; cc_u = hit ? t : cc_u;
+                        t -= f_w;
+                    }
+                    ob = cs * 0x249;
+                } else if ((t -= n_full) < n_w) {
+                    int m = cls_m & 15;
+                    if (t >= 1) m &= m - 1;
+                    if (t >= 2) m &= m - 1;
+                    if (t >= 3) m &= m - 1;
+                    ob = __builtin_ctz(m) * 0x249;
+                } else if ((t -= n_w) < n_hb) {
+                    lmask = 31;
+                    int m = (cls_m >> 4) & 15;
+                    if (t >= 1) { m &= m - 1; m &= m - 1; }
+                    const int a = __builtin_ctz(m);
+                    m &= m - 1;
+                    const int b = m ? __builtin_ctz(m) : 7;
+                    ob = a * 0x9 | b * (0x9 << 6);
+                } else {
+                    lmask = 15;
+                    const int inv = ~(cls_m >> 8) & 15;
+                    ob = 0x688 | 7 * ((inv & 1) | ((inv & 2) << 2) | ((inv & 4) << 4) | ((inv & 8) << 6));
                 }
-                if (cs < 0) break;                     // no leftover chunk for this slot
             }
-            if (cs != cur_s) {                         // tile origin of the chunk's sample -> scalar registers
-                const SweepPose &q = s_pose[cs];
-#if !ISDF_POSE_LDS
-                pos = mk3(uni(q.pos[0]), uni(q.pos[1]), uni(q.pos[2]));
-#pragma unroll
-                for (int k = 0; k < 9; k++) R.a[k] = uni(q.R[k]);
-                quat.w = uni(q.quat[0]); quat.x = uni(q.quat[1]); quat.y = uni(q.quat[2]); quat.z = uni(q.quat[3]);
-#endif
-                clx = __builtin_amdgcn_readfirstlane(q.lo[0]); cly = __builtin_amdgcn_readfirstlane(q.lo[1]);
-                clz = __builtin_amdgcn_readfirstlane(q.lo[2]);
-                cur_s = cs;
-            }
-            // ---- (4) exact fp64 pass over one chunk: grad_cost_p (:766-824)
-            const int ccnt = __builtin_amdgcn_readfirstlane(s_plan[cs][0]), chead = __builtin_amdgcn_readfirstlane(s_plan[cs][1]);
+            // ---- (4) exact fp64 pass over one wavefront of candidates: grad_cost_p (:766-824)
+            int ls = (ob >> lane_q3) & 7;                    // this lane's sample (of the workgroup's four)
+            const bool seg_valid = ls != 7;
+            ls &= 3;
+            const int l = lane & lmask;                      // lane inside its block
+            const int2 pl = *reinterpret_cast<const int2 *>(&s_plan[ls][0]);      // candidates, ring head: one LDS round trip
+            const int ccnt = pl.x, chead = pl.y;
+            const int cc = cc_u >= 0 ? cc_u : (ccnt >> 6);
             const int n = min(64, ccnt - (cc << 6));
-            const unsigned ent = s_near[cs][(chead + (cc << 6) + min(lane, n - 1)) & (SW_NEAR_CAP - 1)];
+            const unsigned ent = s_near[ls][(chead + (cc << 6) + min(l, n - 1)) & (SW_NEAR_CAP - 1)];
             double v[ACC_STRIDE] = {0, 0, 0, 0, 0, 0, 0, 0};
             bool is_pair = false, is_grad = false;
-            if (lane < n && !(P.dbg_flags & 1)) {
-                const int gx = clx + (int)(ent & 1023u), gy = cly + (int)((ent >> 10) & 1023u), gz = clz + (int)(ent >> 20);
-                const d3 ctr = mk3((gx + 0.5) * G.res + G.bmin[0], (gy + 0.5) * G.res + G.bmin[1], (gz + 0.5) * G.res + G.bmin[2]);
-#if ISDF_POSE_LDS
+            if (seg_valid && l < n && !(P.dbg_flags & 1)) {
                 // The pose (16 doubles) is READ FROM LDS where it is used - once here, once more for the force terms below -
                 // instead of living in 32 scalar registers for the whole loop: the loop's scalar state no longer fits the SGPR
                 // file with it, and every spilled scalar costs a v_readlane, i.e. a VALU issue slot of this issue-bound kernel
                 // (broadcast ds_reads go down the LDS pipe).  The index is laundered so that the two reads stay two reads.
-                int csa = cs;
+                int csa = ls;
                 asm volatile("" : "+v"(csa));
                 const SweepPose &qa = s_pose[csa];
+                const int gx = qa.lo[0] + (int)(ent & 1023u), gy = qa.lo[1] + (int)((ent >> 10) & 1023u), gz = qa.lo[2] + (int)(ent >> 20);
+                const d3 ctr = mk3((gx + 0.5) * G.res + G.bmin[0], (gy + 0.5) * G.res + G.bmin[1], (gz + 0.5) * G.res + G.bmin[2]);
                 const d3 pos = mk3(qa.pos[0], qa.pos[1], qa.pos[2]);
                 m3 R;
 #pragma unroll
                 for (int k = 0; k < 9; k++) R.a[k] = qa.R[k];
-#endif
                 const d3 pm = ctr - pos;
                 const d3 prel = mat_tmul(R, pm);
                 // the cube cull (:800-803) as ONE test: three short-circuit comparisons compile to three nested masked regions, each
@@ -972,15 +980,13 @@ __global__ __launch_bounds__(64 * SW_SAMPLES, FUSED ? 3 : sweep_waves_per_simd(K
                         if constexpr (KIND != ISDF_SHAPE_MESH) g = shape_grad<KIND, IDENT>(P.shape, prel);
                         is_grad = true;
                         v[0] = f;
-#if ISDF_POSE_LDS
-                        int csb = cs;
+                        int csb = ls;
                         asm volatile("" : "+v"(csb));
                         const SweepPose &qb = s_pose[csb];
                         m3 R;
 #pragma unroll
                         for (int k = 0; k < 9; k++) R.a[k] = qb.R[k];
                         d4 quat; quat.w = qb.quat[0]; quat.x = qb.quat[1]; quat.y = qb.quat[2]; quat.z = qb.quat[3];
-#endif
                         const d3 wg = mat_mul(R, g);
                         v[1] = df * wg.x; v[2] = df * wg.y; v[3] = df * wg.z;
                         const d4 sq = quat_step_grad(quat, g, pm);
@@ -988,16 +994,28 @@ __global__ __launch_bounds__(64 * SW_SAMPLES, FUSED ? 3 : sweep_waves_per_simd(K
                     }
                 }
             }
-            wave_sum8(v, lane);                        // component k -> lane wave_sum8_lane(k)
-            const int np = __popcll(__ballot(is_pair)), ng = __popcll(__ballot(is_grad));
-            if ((lane & 7) == 0) s_res[cs][cc][((lane >> 3) & 1) | (((lane >> 4) & 1) << 1) | ((lane >> 5) << 2)] = v[0];
-            if (lane == 0) { s_resn[cs][cc][0] = np; s_resn[cs][cc][1] = ng; }
+            // sums per block: component k of a block ends up in v[0] of its lanes with `comp == k`
+            // (the lane index is laundered: otherwise every lane-bit predicate of the three butterflies is hoisted out of all loops
+            // and sits in a scalar register pair for the whole kernel - spilled scalars cost VALU slots in the scan loop)
+            int ln = lane;
+            asm volatile("" : "+v"(ln));
+            int comp; bool writer;
+            if (lmask == 63)      { wave_sum8(v, ln);        writer = (ln & 7) == 0; comp = ((ln >> 3) & 1) | (((ln >> 4) & 1) << 1) | ((ln >> 5) << 2); }
+            else if (lmask == 31) { wave_sum8_halves(v, ln); writer = (ln & 3) == 0; comp = (ln >> 2) & 7; }
+            else                  { wave_sum8_rows(v, ln);   writer = (ln & 1) == 0; comp = (ln >> 1) & 7; }
+            const unsigned long long blk = lmask == 63 ? ~0ull : ((1ull << (lmask + 1)) - 1ull);
+            const int first = ln & ~lmask;                   // first lane of this lane's block
+            const int np = __popcll((__ballot(is_pair) >> first) & blk), ng = __popcll((__ballot(is_grad) >> first) & blk);
+            if (seg_valid) {
+                if (writer) s_res[ls][cc][comp] = v[0];
+                if (l == 0) { s_resn[ls][cc][0] = np; s_resn[ls][cc][1] = ng; }
+            }
             n_rounds++;
         }
         __syncthreads();
         // chunk results of this wave's sample, in chunk order
         {
-            const int my_nch = (nch_pk >> (4 * wave)) & 15;
+            const int my_nch = (near_cnt + 63) >> 6;
             for (int cidx = 0; cidx < my_nch; cidx++) {
                 if (lane < ACC_STRIDE) tot += s_res[wave][cidx][lane];
                 else if (lane < ACC_STRIDE + 2) tot_n += s_resn[wave][cidx][lane - ACC_STRIDE];

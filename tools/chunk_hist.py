@@ -31,3 +31,17 @@ for name, shape in (("box", synth.bench_box_shape()), ("rounded cone", synth.ben
     # halves/quarters packing of the LAST block only (canonical trees kept): leftover sizes
     left = pairs % 64
     print("   leftover block sizes: <=16:", (left[left > 0] <= 16).mean(), " <=32:", (left[left > 0] <= 32).mean())
+    # aligned power-of-two packing of the last (partial) block: quarter (<= 16), half (<= 32) or whole wavefront; blocks of the
+    # same class share a wavefront iteration (canonical summation trees kept: the skipped butterfly levels only add zeros)
+    def packed_iters(p4, mixed):
+        full = sum(p // 64 for p in p4)
+        rem = [p % 64 for p in p4 if p % 64]
+        q = sum(1 for r in rem if r <= 16); h = sum(1 for r in rem if 16 < r <= 32); w = sum(1 for r in rem if r > 32)
+        if mixed:
+            return full + w + -(-(2 * h + q) // 4)
+        return full + w + -(-h // 2) + -(-q // 4)
+    m = (n // 4) * 4
+    now = ch[:m].sum()
+    for mixed in (False, True):
+        it = sum(packed_iters(pairs[i:i + 4], mixed) for i in range(0, m, 4))
+        print(f"   aligned packing ({'mixed' if mixed else 'same-class'} bins): {it} iterations vs {now} ({it / now:.3f}x)")
