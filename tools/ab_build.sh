@@ -1,3 +1,7 @@
+#!/bin/bash
+# Developer tool (GPU box): A/B of two builds of the library on one box - the previous build saved as
+# implicit-sdf-planner_amd/lib/libisdf_accel_prev.so (git-ignored) against the tree's: C3 step time with a hash of the outputs
+# (bitwise comparison of the two builds), the bench line, the per-wave phase timing.
 P=$PWD/implicit-sdf-planner_amd/lib/libisdf_accel_prev.so
 for i in 1 2; do
 ISDF_ACCEL_LIB=$P python tools/c3_only.py 30 | sed 's/^/prev /'
