@@ -206,6 +206,10 @@ __device__ __forceinline__ void stage_in(const SweepParams &P, int blk) {
     }
 }
 
+// Row pruning needs "sdf(p) >= distance(p, bbox)".  The mesh kind's sdf is (1 - 2 w) * distance with libigl's APPROXIMATE
+// winding number (|w error| up to a few 1e-3 outside, Shape.cpp:110), so its penalty band is widened by 5 % for pruning.
+__device__ __forceinline__ double mesh_band_scale(int kind) { return kind == ISDF_SHAPE_MESH ? 1.05 : 1.0; }
+
 struct SweepPose {                 // LDS record of one sample, written by the pose lane
     double pos[3];
     double R[9];                   // row-major body->world rotation
@@ -218,7 +222,74 @@ struct SweepPose {                 // LDS record of one sample, written by the p
     int nn[3];                     // tile extent per axis (0 or less: no tile)
     int pad;
     double L0[3], L1[3];           // extent of the shape's inflated bounding box on each world axis, in voxels from the map's first
+    // fp32 constants of the scan stage (scan_consts): filled by pose_kernel, one THREAD per sample, and fetched by the sweep's waves
+    // with scalar loads - worked out per wave they are ~150 wave-uniform VALU / LDS instructions of a kernel that is bound by its
+    // instruction count.  (A fused step works them out per wave, from the record in LDS: these fields are unused there.)
+    float Rf[9], pv[3];            // rotation; position in the tile's voxel frame, pre-multiplied (fp32 filter)
+    float Ru[3], Rv[3], Rw[3];     // body-frame components of the tile axes as the rows see them: along u, along v, along the scan axis
+    float pvu, pvv, pvw;
+    float dzv[3], dzi[3];          // body-frame step of one voxel along a row, and its reciprocals
+    float inv_rny;
+    float cone_alpha, cone_ia;     // rounded cone: the row's quadratic (see row_mask)
+    int cone_on;
 };
+static_assert(sizeof(SweepPose) % 8 == 0 && sizeof(SweepPose) <= 64 * 8, "the record is copied by one wavefront, 8 bytes per lane");
+
+// launch-wide fp32 constants of the scan stage
+struct ScanLaunch { float resf, bdh_f, thr_f, cone_A, cone_B; bool cone_shape; };
+__device__ __forceinline__ ScanLaunch scan_launch_consts(const SweepParams &P, int kind) {
+#pragma clang fp contract(off)
+    ScanLaunch L;
+    L.resf = (float)P.grid.res;
+    L.bdh_f = (float)P.bd_half + TS_FILTER_EPS;
+    L.thr_f = (float)P.safety_hor * (float)mesh_band_scale(kind) + TS_FILTER_EPS;
+    L.cone_A = 0.0f; L.cone_B = 0.0f; L.cone_shape = false;
+    if (kind == ISDF_SHAPE_ROUNDEDCONE) {
+        // RoundedCone (Shape.hpp:1018-1029; axis z, sphere r1 at the origin, r2 at z = h): inflated by the band it is still a rounded
+        // cone, and it lies inside the cone that is tangent to both spheres, rho <= A - B z with B = b / a, A = (r1 + band) / a,
+        // b = (r1 - r2) / h, a = sqrt(1 - b^2).
+        const float r1 = P.shape.f.p[0], r2 = P.shape.f.p[1], hh = P.shape.f.p[2];
+        const float b = (r1 - r2) / hh, a2 = 1.0f - b * b;
+        if (P.shape.prune_rows != 0 && hh > 0.0f && a2 > 1.0e-3f) {
+            const float ia = 1.0f / sqrtf(a2);
+            L.cone_A = (r1 + L.thr_f) * ia; L.cone_B = b * ia; L.cone_shape = true;
+        }
+    }
+    return L;
+}
+// The per-sample fp32 constants of the scan stage from the pose record's position, rotation, tile origin, scan axis and window.
+// ONE definition for pose_kernel and the fused step, contraction off: both must produce the same bits (the candidate lists, and
+// with them the summation order of the exact pass, depend on them - a batch stays bitwise equal to its trajectories one by one).
+__device__ __forceinline__ void scan_consts(const SweepParams &P, const ScanLaunch &L, const double *pos, const double *R, const int *lo, int sa, int rny,
+                                            bool cone_ident, SweepPose &o) {
+#pragma clang fp contract(off)
+    const DevGrid &G = P.grid;
+#pragma unroll
+    for (int k = 0; k < 9; k++) o.Rf[k] = (float)R[k];
+    // m = l*res - pvr,  pvr = ((pos - bmin)/res - 0.5 - lo)*res  (fp32 filter stage only: conservative by TS_FILTER_EPS, so the
+    // algebraically equal form without divisions is fine)
+#pragma unroll
+    for (int a = 0; a < 3; a++) o.pv[a] = (float)(pos[a] - G.bmin[a] - (0.5 + lo[a]) * G.res);
+#pragma unroll
+    for (int a = 0; a < 3; a++) {
+        o.Ru[a] = sa == 0 ? o.Rf[3 + a] : o.Rf[a];
+        o.Rv[a] = sa == 2 ? o.Rf[3 + a] : o.Rf[6 + a];
+        o.Rw[a] = sa == 2 ? o.Rf[6 + a] : (sa == 0 ? o.Rf[a] : o.Rf[3 + a]);
+        o.dzv[a] = o.Rw[a] * L.resf;
+        o.dzi[a] = 1.0f / o.dzv[a];
+    }
+    o.pvu = sa == 0 ? o.pv[1] : o.pv[0]; o.pvv = sa == 2 ? o.pv[1] : o.pv[2]; o.pvw = sa == 2 ? o.pv[2] : (sa == 0 ? o.pv[0] : o.pv[1]);
+    o.inv_rny = 1.0f / (float)max(rny, 1);
+    o.cone_alpha = 0.0f; o.cone_ia = 0.0f; o.cone_on = 0;
+    if (cone_ident && L.cone_shape) {
+        // a row's part inside the tangent cone is one more interval (a quadratic in the row coordinate), much tighter than the
+        // bounding box around the thin end: 141 -> ~70 listed voxels per sample.  Only where the row is flatter than the cone
+        // (alpha > 0: the inside is BETWEEN the roots).
+        o.cone_alpha = o.dzv[0] * o.dzv[0] + o.dzv[1] * o.dzv[1] - L.cone_B * L.cone_B * o.dzv[2] * o.dzv[2];
+        o.cone_on = o.cone_alpha > 1.0e-3f * (o.dzv[0] * o.dzv[0] + o.dzv[1] * o.dzv[1] + o.dzv[2] * o.dzv[2]) ? 1 : 0;
+        o.cone_ia = 1.0f / o.cone_alpha;
+    }
+}
 
 __device__ __forceinline__ double uni(double v) {     // wave-uniform double -> scalar registers
     const int lo = __builtin_amdgcn_readfirstlane(__double2loint(v)), hi = __builtin_amdgcn_readfirstlane(__double2hiint(v));
@@ -226,9 +297,6 @@ __device__ __forceinline__ double uni(double v) {     // wave-uniform double -> 
 }
 __device__ __forceinline__ float unif(float v) { return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v))); }
 
-// Row pruning needs "sdf(p) >= distance(p, bbox)".  The mesh kind's sdf is (1 - 2 w) * distance with libigl's APPROXIMATE
-// winding number (|w error| up to a few 1e-3 outside, Shape.cpp:110), so its penalty band is widened by 5 % for pruning.
-__device__ __forceinline__ double mesh_band_scale(int kind) { return kind == ISDF_SHAPE_MESH ? 1.05 : 1.0; }
 
 // Dedicated instantiations (Box, RoundedCone and the robots of the shipped configs) are held to 128 VGPRs (4 waves per SIMD),
 // their identity-offset variants to 102 (5 waves) - worth 10-30 % when the device is full (C3); the generic and mesh
@@ -344,11 +412,17 @@ __device__ void plan_wave(const SweepParams &P, const int t, const int lane) {  
 // in LDS (same functions, same operations: a batch stays bitwise equal to its trajectories evaluated one by one) - the serial
 // chain position -> flatness -> rotation -> where the shape's inflated bounding box lies on each axis, the tile's index box as
 // getPointsInAABB (PCSmap_manager.h:150-155), the window of rows and the scan axis.
-__global__ __launch_bounds__(256) void pose_kernel(const SweepParams P) {
+constexpr int POSE_THREADS = 64;
+constexpr int POSE_REC = (int)(sizeof(SweepPose) / 8);       // doubles per record
+__global__ __launch_bounds__(POSE_THREADS) void pose_kernel(const SweepParams P) {
+    // the records leave through LDS: a thread's own record is 368 bytes away from its neighbour's - stored from the registers it
+    // is 46 scattered 8-byte writes per thread; the workgroup's records are one contiguous range, written out lane after lane
+    __shared__ double s_rec[POSE_THREADS][POSE_REC + 1];
     const int K1 = P.K + 1;
     const long long s_begin = (long long)P.piece_begin * K1, s_end = (long long)P.piece_end * K1;
-    const long long sidx = s_begin + (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (sidx >= s_end) return;
+    const long long s_first = s_begin + (long long)blockIdx.x * POSE_THREADS;
+    const long long sidx = s_first + threadIdx.x;
+    if (sidx < s_end) {
     const DevGrid &G = P.grid;
     SweepPose sp;
     for (int k = 0; k < (int)(sizeof(SweepPose) / 8); k++) ((double *)&sp)[k] = 0.0;
@@ -428,8 +502,14 @@ __global__ __launch_bounds__(256) void pose_kernel(const SweepParams P) {
     sp.nzt = sa_w == 2 ? nn[2] : (sa_w == 0 ? nn[0] : nn[1]);
     sp.flags = flags_w;
     sp.sa = sa_w;
-    double *dst = (double *)((SweepPose *)P.poses + (sidx - s_begin));
-    for (int k = 0; k < (int)(sizeof(SweepPose) / 8); k++) dst[k] = ((const double *)&sp)[k];
+    scan_consts(P, scan_launch_consts(P, P.shape.kind), sp.pos, sp.R, sp.lo, sa_w, sp.rny, P.shape.kind == ISDF_SHAPE_ROUNDEDCONE && P.shape.f.ident != 0, sp);
+#pragma unroll
+    for (int k = 0; k < POSE_REC; k++) s_rec[threadIdx.x][k] = ((const double *)&sp)[k];
+    }
+    __syncthreads();
+    const int n_rec = (int)min((long long)POSE_THREADS, s_end - s_first);
+    double *dst = (double *)((SweepPose *)P.poses + (s_first - s_begin));
+    for (int i = threadIdx.x; i < n_rec * POSE_REC; i += POSE_THREADS) dst[i] = s_rec[i / POSE_REC][i % POSE_REC];
 }
 size_t sweep_pose_bytes() { return sizeof(SweepPose); }
 
@@ -617,13 +697,21 @@ __global__ __launch_bounds__(64 * SW_SAMPLES, FUSED ? 3 : sweep_waves_per_simd(K
         }
         wave_lds_sync();
     }
-    const int flags = have_sample ? __builtin_amdgcn_readfirstlane(sp.flags) : 0;
-    const int rnx = have_sample ? __builtin_amdgcn_readfirstlane(sp.rnx) : 0, rny = have_sample ? __builtin_amdgcn_readfirstlane(sp.rny) : 0;
+    // What is wave-uniform about the sample comes (non-fused) from its record in global memory by SCALAR loads - no LDS round
+    // trips, no v_readfirstlane; a fused step reads the record its first stage left in LDS.
+    const mesh_cptr<SweepPose> rec = mesh_const_uni((const SweepPose *)P.poses + (have_sample && !FUSED ? sidx - s_begin : 0));
+    int flags = 0, rnx = 0, rny = 0, nzt0 = 0;
+    if (have_sample) {
+        if constexpr (FUSED) {
+            flags = __builtin_amdgcn_readfirstlane(sp.flags);
+            rnx = __builtin_amdgcn_readfirstlane(sp.rnx); rny = __builtin_amdgcn_readfirstlane(sp.rny); nzt0 = __builtin_amdgcn_readfirstlane(sp.nzt);
+        } else { flags = rec->flags; rnx = rec->rnx; rny = rec->rny; nzt0 = rec->nzt; }
+    }
     const int n_rows = (flags & 1) ? rnx * rny : 0;
     const bool scanning = n_rows > 0;
 
     // scan state of this wave's sample
-    const int n_zb = ((have_sample ? __builtin_amdgcn_readfirstlane(sp.nzt) : 0) + 31) >> 5;   // 32-voxel blocks along z (1 for kernel_size <= 31)
+    const int n_zb = (nzt0 + 31) >> 5;   // 32-voxel blocks along z (1 for kernel_size <= 31)
     int near_head = 0, near_cnt = 0;             // ring of candidates awaiting the exact pass
     int pend_head = 0, pend = 0;                 // ring of compacted voxels awaiting the fp32 test
     int fzb = 0, ft = 0;                         // fetch cursor: z-block and first window row of the next round
@@ -643,32 +731,57 @@ __global__ __launch_bounds__(64 * SW_SAMPLES, FUSED ? 3 : sweep_waves_per_simd(K
         if (!finished) {
         // The scan-stage constants live only inside this block: they are rebuilt from the LDS pose record when the scan is
         // (re)entered, so that they do not hold scalar registers during the exact phase (SGPR spills cost VALU issue slots).
-    const int lox = __builtin_amdgcn_readfirstlane(sp.lo[0]), loy = __builtin_amdgcn_readfirstlane(sp.lo[1]),
-              loz = __builtin_amdgcn_readfirstlane(sp.lo[2]), nzt = __builtin_amdgcn_readfirstlane(sp.nzt);
-    const int rx0 = __builtin_amdgcn_readfirstlane(sp.rx0), ry0 = __builtin_amdgcn_readfirstlane(sp.ry0);
+    int lox, loy, loz, nzt, rx0, ry0, sa;
+    if constexpr (FUSED) {
+        lox = __builtin_amdgcn_readfirstlane(sp.lo[0]); loy = __builtin_amdgcn_readfirstlane(sp.lo[1]); loz = __builtin_amdgcn_readfirstlane(sp.lo[2]);
+        nzt = __builtin_amdgcn_readfirstlane(sp.nzt);
+        rx0 = __builtin_amdgcn_readfirstlane(sp.rx0); ry0 = __builtin_amdgcn_readfirstlane(sp.ry0);
+        sa = __builtin_amdgcn_readfirstlane(sp.sa);
+    } else { lox = rec->lo[0]; loy = rec->lo[1]; loz = rec->lo[2]; nzt = rec->nzt; rx0 = rec->rx0; ry0 = rec->ry0; sa = rec->sa; }
     // scan axis sa (rows run along it), row coordinates (u, v) = the other two axes; everything below is wave-uniform
-    const int sa = __builtin_amdgcn_readfirstlane(sp.sa);
     const int lo_u = sa == 0 ? loy : lox, lo_v = sa == 2 ? loy : loz, lo_w = sa == 2 ? loz : (sa == 0 ? lox : loy);
     const int dim_v = sa == 2 ? G.Y : G.Z, n_ww = sa == 2 ? G.ZW : (sa == 0 ? G.XW : G.YW);
     const unsigned *const bits_a = sa == 2 ? G.bits : (sa == 0 ? G.bits_x : G.bits_y);
     const unsigned sh_u = sa == 0 ? 10u : 0u, sh_v = sa == 2 ? 10u : 20u, sh_w = 10u * (unsigned)sa;     // fields of a ring entry: x | y << 10 | z << 20
-    const float inv_rny = 1.0f / (float)max(rny, 1);
     const bool small = n_rows < (1 << 24);
     // Box: the row masks already cut the rows to the box's own inflated extent, which IS the set the fp32 test would keep (but
     // for the rounded corners): measured 52 listed -> 48 kept, so the test is skipped for this kind
     constexpr bool DIRECT = (KIND == ISDF_SHAPE_BOX);
     const bool use_filter = !DIRECT && P.shape.filter_f32 != 0;
-    float Rf[9];
+    // the fp32 constants of the scan stage (scan_consts)
+    const ScanLaunch SL = scan_launch_consts(P, KIND >= 0 ? KIND : P.shape.kind);
+    const float resf = SL.resf, bdh_f = SL.bdh_f, thr_f = SL.thr_f;
+    float Rf[9], pvx, pvy, pvz, Ru[3], Rv[3], Rw[3], pv_u, pv_v, pv_w, dzv[3], dzi[3], inv_rny, cone_alpha, cone_ia;
+    bool cone_on;
+    if constexpr (FUSED) {
+        double pos_[3], R_[9];
+        const int lo_[3] = {lox, loy, loz};
 #pragma unroll
-    for (int k = 0; k < 9; k++) Rf[k] = unif((float)sp.R[k]);
-    const float resf = (float)G.res;
-    const float bdh_f = (float)P.bd_half + TS_FILTER_EPS;
-    const float thr_f = (float)P.safety_hor * (float)mesh_band_scale(KIND >= 0 ? KIND : P.shape.kind) + TS_FILTER_EPS;
-    // pose in the tile's voxel frame, pre-multiplied: m = l*res - pvr,  pvr = ((pos - bmin)/res - 0.5 - lo)*res
-    // (fp32 filter stage only: conservative by TS_FILTER_EPS, so the algebraically equal form without divisions is fine)
-    const float pvx = unif((float)(sp.pos[0] - G.bmin[0] - (0.5 + lox) * G.res));
-    const float pvy = unif((float)(sp.pos[1] - G.bmin[1] - (0.5 + loy) * G.res));
-    const float pvz = unif((float)(sp.pos[2] - G.bmin[2] - (0.5 + loz) * G.res));
+        for (int a = 0; a < 3; a++) pos_[a] = sp.pos[a];
+#pragma unroll
+        for (int k = 0; k < 9; k++) R_[k] = sp.R[k];
+        SweepPose w;
+        scan_consts(P, SL, pos_, R_, lo_, sa, rny, KIND == ISDF_SHAPE_ROUNDEDCONE && IDENT, w);
+#pragma unroll
+        for (int k = 0; k < 9; k++) Rf[k] = unif(w.Rf[k]);
+        pvx = unif(w.pv[0]); pvy = unif(w.pv[1]); pvz = unif(w.pv[2]);
+#pragma unroll
+        for (int a = 0; a < 3; a++) { Ru[a] = w.Ru[a]; Rv[a] = w.Rv[a]; Rw[a] = w.Rw[a]; dzv[a] = w.dzv[a]; dzi[a] = w.dzi[a]; }
+        pv_u = w.pvu; pv_v = w.pvv; pv_w = w.pvw; inv_rny = w.inv_rny;
+        cone_alpha = w.cone_alpha; cone_ia = w.cone_ia; cone_on = w.cone_on != 0;
+    } else {
+#pragma unroll
+        for (int k = 0; k < 9; k++) Rf[k] = rec->Rf[k];
+        pvx = rec->pv[0]; pvy = rec->pv[1]; pvz = rec->pv[2];
+#pragma unroll
+        for (int a = 0; a < 3; a++) { Ru[a] = rec->Ru[a]; Rv[a] = rec->Rv[a]; Rw[a] = rec->Rw[a]; dzv[a] = rec->dzv[a]; dzi[a] = rec->dzi[a]; }
+        pv_u = rec->pvu; pv_v = rec->pvv; pv_w = rec->pvw; inv_rny = rec->inv_rny;
+        cone_alpha = rec->cone_alpha; cone_ia = rec->cone_ia; cone_on = rec->cone_on != 0;
+        // (held in vector registers, like the values a fused step computes: the scalar file is the scarcer one)
+#pragma unroll
+        for (int a = 0; a < 3; a++) { asm volatile("" : "+v"(dzv[a])); asm volatile("" : "+v"(dzi[a])); }
+    }
+    const float cone_A = SL.cone_A, cone_B = SL.cone_B;
 
     // tile coordinates (u, v) of window row t, already in their fields of the ring entry
     auto row_xy = [&](int t) -> unsigned {
@@ -697,43 +810,15 @@ __global__ __launch_bounds__(64 * SW_SAMPLES, FUSED ? 3 : sweep_waves_per_simd(K
     // inside (shape bounding box inflated by safety_hor) ∩ (the |p_rel| <= bd/2 cube) can carry a penalty
     // (isdf_shape.bbox_* guarantee), so the rest of the row never enters the list.  Conservative by construction.
     const bool prune = P.shape.prune_rows != 0;
-    // body-frame components of the three tile axes as the rows see them: along u, along v, along the scan axis
-    float Ru[3], Rv[3], Rw[3];
-#pragma unroll
-    for (int a = 0; a < 3; a++) {
-        Ru[a] = sa == 0 ? Rf[3 + a] : Rf[a];
-        Rv[a] = sa == 2 ? Rf[3 + a] : Rf[6 + a];
-        Rw[a] = sa == 2 ? Rf[6 + a] : (sa == 0 ? Rf[a] : Rf[3 + a]);
-    }
-    const float pv_u = sa == 0 ? pvy : pvx, pv_v = sa == 2 ? pvy : pvz, pv_w = sa == 2 ? pvz : (sa == 0 ? pvx : pvy);
-    float blo[3], bhi[3], dzv[3], dzi[3];
+    float blo[3], bhi[3];
 #pragma unroll
     for (int a = 0; a < 3; a++) {
         blo[a] = fmaxf(P.shape.bbox_lo[a] - thr_f, -bdh_f);
         bhi[a] = fminf(P.shape.bbox_hi[a] + thr_f, bdh_f);
-        dzv[a] = Rw[a] * resf;
-        dzi[a] = 1.0f / dzv[a];
     }
-    // RoundedCone (Shape.hpp:1018-1029; axis z, sphere r1 at the origin, r2 at z = h): inflated by the band it is still a rounded
-    // cone, and it lies inside the cone that is tangent to both spheres, rho <= A - B z with B = b / a, A = (r1 + band) / a,
-    // b = (r1 - r2) / h, a = sqrt(1 - b^2).  A row's part inside that cone is one more interval (a quadratic in the row
-    // coordinate), much tighter than the bounding box around the thin end: 141 -> ~70 listed voxels per sample.  Conservative
-    // like the box test (the band carries the filter's 2 mm; a negative discriminant of a row that really touches would need
-    // rounding errors a thousand times larger); only where the row is flatter than the cone (alpha > 0: the inside is BETWEEN
-    // the roots).
-    float cone_A = 0.0f, cone_B = 0.0f, cone_alpha = 0.0f, cone_ia = 0.0f;
-    bool cone_on = false;
-    if constexpr (KIND == ISDF_SHAPE_ROUNDEDCONE && IDENT) {
-        const float r1 = P.shape.f.p[0], r2 = P.shape.f.p[1], hh = P.shape.f.p[2];
-        const float b = (r1 - r2) / hh, a2 = 1.0f - b * b;
-        if (prune && hh > 0.0f && a2 > 1.0e-3f) {
-            const float ia = 1.0f / sqrtf(a2);
-            cone_A = (r1 + thr_f) * ia; cone_B = b * ia;
-            cone_alpha = dzv[0] * dzv[0] + dzv[1] * dzv[1] - cone_B * cone_B * dzv[2] * dzv[2];
-            cone_on = cone_alpha > 1.0e-3f * (dzv[0] * dzv[0] + dzv[1] * dzv[1] + dzv[2] * dzv[2]);
-            cone_ia = 1.0f / cone_alpha;
-        }
-    }
+    // RoundedCone: inside the cone that is tangent to both inflated spheres a row's part is one more interval (a quadratic in the
+    // row coordinate: scan_launch_consts / scan_consts).  Conservative like the box test (the band carries the filter's 2 mm; a
+    // negative discriminant of a row that really touches would need rounding errors a thousand times larger).
     auto row_mask = [&](unsigned pk, int zb) -> unsigned {
         const float mx = fmaf((float)((pk >> sh_u) & 1023u), resf, -pv_u), my = fmaf((float)((pk >> sh_v) & 1023u), resf, -pv_v);
         float tmin = -1.0e30f, tmax = 1.0e30f;
@@ -1373,7 +1458,7 @@ void launch_sweep(const SweepParams &P0, hipStream_t stream, hipEvent_t ev_start
     P.n_sweep_blocks = (int)((n_samples + SW_SAMPLES - 1) / SW_SAMPLES);
     const dim3 grid((unsigned)(P.n_sweep_blocks + (fused ? P.n_traj * P.N : 0))), block(64 * SW_SAMPLES);
     const bool ident = P.shape.d.ident != 0;
-    if (!fused) hipLaunchKernelGGL(pose_kernel, dim3((unsigned)((n_samples + 255) / 256)), dim3(256), 0, stream, P);      // the poses of every sample, one thread each
+    if (!fused) hipLaunchKernelGGL(pose_kernel, dim3((unsigned)((n_samples + POSE_THREADS - 1) / POSE_THREADS)), dim3(POSE_THREADS), 0, stream, P);      // the poses of every sample, one thread each
 #define ISDF_LAUNCH_SWEEP(K, I, F) hipExtLaunchKernelGGL((sweep_kernel<K, I, F>), grid, block, 0, stream, ev_start, ev_stop, 0, P)
 #define ISDF_SWEEP_CASE(K) case K: if (fused) ISDF_LAUNCH_SWEEP(K, true, true); else if (ident) ISDF_LAUNCH_SWEEP(K, true, false); else ISDF_LAUNCH_SWEEP(K, false, false); break;
     switch (P.shape.kind) {

@@ -12,7 +12,7 @@ dev = torch.device("cuda", 0); torch.zeros(1, device=dev)
 st = torch.cuda.current_stream().cuda_stream
 occ, esdf, T, cm = build_workload(pkg, 40, 256, res)
 cfg = synth.default_config(capi.V3_ESDF_TILE, kernel_size=21, integral_intervs=64, safety_hor=(3 ** 0.5 / 2) * res, weight_p=4000.0, smoothing_eps=0.01)
-eng = pkg.Engine(cfg); eng.set_grid(esdf, (0, 0, 0), res, capi.GRID_ESDF); eng.set_shape(synth.bench_box_shape())
+eng = pkg.Engine(cfg, devices=[0, 0] if '--split' in sys.argv else None); eng.set_grid(esdf, (0, 0, 0), res, capi.GRID_ESDF); eng.set_shape(synth.bench_box_shape())
 ext = np.array(occ.shape) * res
 Ts, Cs = [], []
 for b in range(128):
@@ -21,7 +21,7 @@ for b in range(128):
 Ts = np.concatenate(Ts); Cs = np.concatenate(Cs)
 d_T = torch.from_numpy(Ts).to(dev); d_C = torch.from_numpy(Cs).to(dev)
 d_out = torch.zeros(128 * eng.out_stride(40), dtype=torch.float64, device=dev)
-steps = int(sys.argv[1]) if len(sys.argv) > 1 else 12
+steps = int(sys.argv[1]) if len(sys.argv) > 1 and sys.argv[1].isdigit() else 12
 for _ in range(steps):
     eng.eval_device(128, 40, d_T.data_ptr(), d_C.data_ptr(), d_out.data_ptr(), 0, st)
 torch.cuda.synchronize(); t0 = time.perf_counter()
