@@ -382,10 +382,10 @@ __device__ __forceinline__ int wave_sum8_lane(int k) { return ((k & 1) << 3) | (
 // swap(A, B) leaves {A_low, B_low} and {A_high, B_high}, whose lane-wise sum IS the butterfly step (same operands as
 // keep + shfl_xor(send): same bits) - and DPP row operations inside a row of 16.
 template <int CTRL> __device__ __forceinline__ double dpp_mov_f64(double v) {
-    // (every lane of these row patterns has a source, so the "old" operand is never seen: passing v itself instead of 0 saves
-    // the v_mov that would materialise the zero in front of every DPP move)
-    const int lo = __builtin_amdgcn_update_dpp(__double2loint(v), __double2loint(v), CTRL, 0xf, 0xf, false);
-    const int hi = __builtin_amdgcn_update_dpp(__double2hiint(v), __double2hiint(v), CTRL, 0xf, 0xf, false);
+    // (every lane of these row patterns has a source, so there is no "old" operand to preserve: v_mov_dpp straight from the source
+    // register - with an old operand, 0 or v itself, the compiler emits a v_mov in front of every DPP move)
+    const int lo = __builtin_amdgcn_mov_dpp(__double2loint(v), CTRL, 0xf, 0xf, false);
+    const int hi = __builtin_amdgcn_mov_dpp(__double2hiint(v), CTRL, 0xf, 0xf, false);
     return __hiloint2double(hi, lo);
 }
 __device__ __forceinline__ double swap32_sum(double a, double b) {

@@ -671,8 +671,9 @@ __global__ __launch_bounds__(128) void swept_backprop_kernel(const SweptParams P
 constexpr int RED_U = 8;
 // wave-wide sum with DPP lane exchanges (fixed shape: quads, half rows, rows, then the four row totals in row order)
 template <int CTRL> __device__ __forceinline__ double dpp_f64(double v) {
-    const int lo = __builtin_amdgcn_update_dpp(__double2loint(v), __double2loint(v), CTRL, 0xf, 0xf, false);
-    const int hi = __builtin_amdgcn_update_dpp(__double2hiint(v), __double2hiint(v), CTRL, 0xf, 0xf, false);
+    // (every lane of these patterns has a source: the move needs no "old" operand - with one, the value is copied first)
+    const int lo = __builtin_amdgcn_mov_dpp(__double2loint(v), CTRL, 0xf, 0xf, false);
+    const int hi = __builtin_amdgcn_mov_dpp(__double2hiint(v), CTRL, 0xf, 0xf, false);
     return __hiloint2double(hi, lo);
 }
 __device__ __forceinline__ double wave_sum_dpp(double v) {

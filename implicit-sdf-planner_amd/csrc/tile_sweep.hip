@@ -974,8 +974,8 @@ __global__ __launch_bounds__(64 * SW_SAMPLES, FUSED ? 3 : sweep_waves_per_simd(K
             cls_m = m_w | (m_h << 4) | (m_q << 8);
             all_done = ((int)__ballot(pl.z != 0) & 15) == 15;
             int f = pl.x >> 6, fp = f << (4 * (lane & 3));
-            f += __builtin_amdgcn_update_dpp(0, f, 0xB1, 0xf, 0xf, false);   fp |= __builtin_amdgcn_update_dpp(0, fp, 0xB1, 0xf, 0xf, false);
-            f += __builtin_amdgcn_update_dpp(0, f, 0x4E, 0xf, 0xf, false);   fp |= __builtin_amdgcn_update_dpp(0, fp, 0x4E, 0xf, 0xf, false);
+            f += __builtin_amdgcn_mov_dpp(f, 0xB1, 0xf, 0xf, false);   fp |= __builtin_amdgcn_mov_dpp(fp, 0xB1, 0xf, 0xf, false);
+            f += __builtin_amdgcn_mov_dpp(f, 0x4E, 0xf, 0xf, false);   fp |= __builtin_amdgcn_mov_dpp(fp, 0x4E, 0xf, 0xf, false);
             n_full = __builtin_amdgcn_readfirstlane(f); f_pk = __builtin_amdgcn_readfirstlane(fp);
         }
         const int n_w = __builtin_popcount(cls_m & 15), n_hb = (__builtin_popcount((cls_m >> 4) & 15) + 1) >> 1;
