@@ -28,8 +28,8 @@
 //                   XFuse, fetch the owner's rows) so that every rank ends up with, or sums to, the full result.
 // Everything that reaches the result is fp64 except the stored ESDF (fp32).  No MFMA: gather/interpolate work.
 #define ISDF_LEAN_MATH 1      // dev_math.hpp / dev_shapes.hpp: lean sqrt and normalisation in this translation unit
-#ifndef ISDF_POSE_LDS
-#define ISDF_POSE_LDS 1
+#ifndef ISDF_SWEEP_STATS
+#define ISDF_SWEEP_STATS 0   // 1: per-wave statistics for tools/timing.py (developer builds)
 #endif
 #include "isdf_internal.hpp"
 #include "dev_mesh.hpp"
@@ -722,8 +722,15 @@ __global__ __launch_bounds__(64 * SW_SAMPLES, FUSED ? 3 : sweep_waves_per_simd(K
     bool primed = false;
     double tot = 0.0;                            // wave `s`, lane k < 8: component k of sample s's collision sums
     int tot_n = 0;                               // lanes 8 / 9: exact pairs / active pairs
-    int n_rounds = 0;
-    unsigned cnt_rounds = 0, cnt_passes = 0, cnt_filters = 0, cnt_listed = 0, cnt_cand = 0;      // ISDF_DEBUG_TIMING only
+    // per-wave statistics of tools/timing.py (row rounds, passes, listed voxels, candidates, exact iterations): six scalar
+    // registers held through the whole kernel and an increment per loop iteration - compiled in with -DISDF_SWEEP_STATS=1 only
+#if ISDF_SWEEP_STATS
+#define SW_STAT(x) x
+#else
+#define SW_STAT(x)
+#endif
+    SW_STAT(int n_rounds = 0;)
+    SW_STAT(unsigned cnt_rounds = 0; unsigned cnt_passes = 0; unsigned cnt_filters = 0; unsigned cnt_listed = 0; unsigned cnt_cand = 0;)
 
     for (;;) {
         // ================= scan phase: produce -> fp32 filter -> candidate ring, until done or the ring is full
@@ -877,11 +884,11 @@ __global__ __launch_bounds__(64 * SW_SAMPLES, FUSED ? 3 : sweep_waves_per_simd(K
                 }
                 pend_head = (pend_head + n) & (SW_LIST_CAP - 1);
                 pend -= n;
-                cnt_filters++;
+                SW_STAT(cnt_filters++;)
                 const unsigned long long nm = __ballot(cand);
                 if (cand) s_near[wave][(near_head + near_cnt + __popcll(nm & ((1ull << lane) - 1ull))) & (SW_NEAR_CAP - 1)] = ent;
                 near_cnt += __popcll(nm);
-                cnt_cand += (unsigned)__popcll(nm);
+                SW_STAT(cnt_cand += (unsigned)__popcll(nm);)
             } else if (!__ballot(hb != 0u)) {
                 // ---- (2a) take the round requested earlier, request the one after it
                 if (primed && rounds_left == 0) {
@@ -889,7 +896,7 @@ __global__ __launch_bounds__(64 * SW_SAMPLES, FUSED ? 3 : sweep_waves_per_simd(K
                     if (dbg && lane == 0) dbg[4] = clock64();
                 } else {
                     if (primed) {
-                        cnt_rounds++;
+                        SW_STAT(cnt_rounds++;)
                         rounds_left--;
                         hb = nbits & nmask;          // waits for the loads requested one round ago
                         pk = npk; zoff = nzoff;
@@ -928,7 +935,7 @@ __global__ __launch_bounds__(64 * SW_SAMPLES, FUSED ? 3 : sweep_waves_per_simd(K
                         s_near[wave][(wpos++) & (SW_NEAR_CAP - 1)] = pk | ((zoff + z) << sh_w);
                     }
                     near_cnt += total;
-                    cnt_passes++; cnt_listed += (unsigned)total; cnt_cand += (unsigned)total;
+                    SW_STAT(cnt_passes++; cnt_listed += (unsigned)total; cnt_cand += (unsigned)total;)
                 } else {
                 unsigned take = hb;
                 if (__ballot(__popc(hb) > SW_PASS)) {
@@ -946,7 +953,7 @@ __global__ __launch_bounds__(64 * SW_SAMPLES, FUSED ? 3 : sweep_waves_per_simd(K
                     s_list[wave][(wpos++) & (SW_LIST_CAP - 1)] = pk | ((zoff + z) << sh_w);
                 }
                 pend += total;
-                cnt_passes++; cnt_listed += (unsigned)total;
+                SW_STAT(cnt_passes++; cnt_listed += (unsigned)total;)
                 }
                 wave_lds_sync();
             }
@@ -1095,7 +1102,7 @@ __global__ __launch_bounds__(64 * SW_SAMPLES, FUSED ? 3 : sweep_waves_per_simd(K
                 if (writer) s_res[ls][cc][comp] = v[0];
                 if (l == 0) { s_resn[ls][cc][0] = np; s_resn[ls][cc][1] = ng; }
             }
-            n_rounds++;
+            SW_STAT(n_rounds++;)
         }
         __syncthreads();
         // chunk results of this wave's sample, in chunk order
@@ -1126,8 +1133,9 @@ __global__ __launch_bounds__(64 * SW_SAMPLES, FUSED ? 3 : sweep_waves_per_simd(K
         else if (lane == ACC_STRIDE + 1) P.sample_info[2 * sl + 1] = tot_n | ((flags & 2) ? (int)0x80000000 : 0);
     }
     if (dbg && lane == 0) {
-        dbg[5] = clock64(); dbg[6] = wall_clock64(); dbg[7] = (unsigned long long)n_rounds;
-        dbg[3] = (unsigned long long)cnt_rounds | ((unsigned long long)cnt_passes << 8) | ((unsigned long long)cnt_filters << 16) | ((unsigned long long)cnt_listed << 24) | ((unsigned long long)cnt_cand << 44);
+        dbg[5] = clock64(); dbg[6] = wall_clock64();
+        SW_STAT(dbg[7] = (unsigned long long)n_rounds;)
+        SW_STAT(dbg[3] = (unsigned long long)cnt_rounds | ((unsigned long long)cnt_passes << 8) | ((unsigned long long)cnt_filters << 16) | ((unsigned long long)cnt_listed << 24) | ((unsigned long long)cnt_cand << 44);)
     }
 }
 

@@ -1,6 +1,7 @@
 #!/usr/bin/env python
 """Developer tool: per-wave phase timing of one optimizer step (ISDF_DEBUG_TIMING=1), bench workload.
-wall_clock64 = 100 MHz; clock64 = shader cycles."""
+wall_clock64 = 100 MHz; clock64 = shader cycles.  The per-wave statistics (row rounds, passes, listed voxels, candidates,
+exact iterations) are compiled in only with `make -C implicit-sdf-planner_amd/csrc EXTRA=-DISDF_SWEEP_STATS=1` - zeros otherwise."""
 import os, sys, ctypes as C
 os.environ["ISDF_DEBUG_TIMING"] = "1"
 import numpy as np
