@@ -555,7 +555,8 @@ __global__ __launch_bounds__(64 * SW_SAMPLES, FUSED ? 3 : sweep_waves_per_simd(K
     const long long rank_w = (long long)blockIdx.x + (long long)wave * n_blocks;
     long long sidx = s_begin + rank_w;
     if (P.sample_map) { const int m = __builtin_amdgcn_readfirstlane(P.sample_map[rank_w]); sidx = m >= 0 ? s_begin + m : s_end; }
-    unsigned long long *const dbg = (P.dbg && sidx < s_end) ? P.dbg + (size_t)(sidx - s_begin) * 8 : nullptr;
+    // (time stamps and developer switches: ISDF_SWEEP_STATS builds only - the pointer alone is two scalar registers for the whole kernel)
+    unsigned long long *const dbg = (ISDF_SWEEP_STATS && P.dbg && sidx < s_end) ? P.dbg + (size_t)(sidx - s_begin) * 8 : nullptr;
     if (dbg && lane == 0) { dbg[0] = wall_clock64(); dbg[1] = clock64(); }
 
     // ---- poses of the workgroup's samples: one LANE per sample (the serial fp64 chain is issued once, not per wave)
@@ -1037,7 +1038,7 @@ __global__ __launch_bounds__(64 * SW_SAMPLES, FUSED ? 3 : sweep_waves_per_simd(K
             const unsigned ent = s_near[ls][(chead + (cc << 6) + min(l, n - 1)) & (SW_NEAR_CAP - 1)];
             double v[ACC_STRIDE] = {0, 0, 0, 0, 0, 0, 0, 0};
             bool is_pair = false, is_grad = false;
-            if (seg_valid && l < n && !(P.dbg_flags & 1)) {
+            if (seg_valid && l < n && !(ISDF_SWEEP_STATS && (P.dbg_flags & 1))) {
                 // The pose (16 doubles) is READ FROM LDS where it is used - once here, once more for the force terms below -
                 // instead of living in 32 scalar registers for the whole loop: the loop's scalar state no longer fits the SGPR
                 // file with it, and every spilled scalar costs a v_readlane, i.e. a VALU issue slot of this issue-bound kernel
@@ -1175,7 +1176,7 @@ template <bool EARLY, bool XF> __device__ __forceinline__ void tail_piece(const 
     double *const my_board = XF ? P.xf.board[P.xf.rank] + (size_t)P.xf.parity * P.xf.parity_stride : nullptr;
     bool lost = false;     // a result slot that never arrived
     const bool mine = i >= p0 && i < p1;
-    unsigned long long *const dbg = (P.dbg && mine) ? P.dbg + (size_t)(P.piece_end - P.piece_begin) * K1 * 8 + (size_t)(gp - P.piece_begin) * 4 : nullptr;
+    unsigned long long *const dbg = (ISDF_SWEEP_STATS && P.dbg && mine) ? P.dbg + (size_t)(P.piece_end - P.piece_begin) * K1 * 8 + (size_t)(gp - P.piece_begin) * 4 : nullptr;
     if (!mine) {
         const int q = tid;
         if constexpr (XF) {
