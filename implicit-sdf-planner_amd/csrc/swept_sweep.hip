@@ -31,6 +31,9 @@
 //                         gradT(j) = sum over points with piece > j.
 //   swept_fixed_kernel    (isdf_eval_swept_at_tstar) replaces prepare + sweep when the minimisers t* are GIVEN.
 // Compute-/latency-bound: fp64 throughout, no tile traffic.
+#ifndef ISDF_SWEEP_STATS
+#define ISDF_SWEEP_STATS 0   // 1: per-wave time stamps for tools/v1_timing.py (developer builds; the debug pointer and the start stamps hold scalar registers)
+#endif
 #include "isdf_internal.hpp"
 #include "dev_mesh.hpp"
 
@@ -216,14 +219,14 @@ __global__ __launch_bounds__(64 * SW_WAVES) void swept_scan_kernel(const SweptPa
     __shared__ double s_rl[SW_WAVES][SW_MAX_RANGES], s_rr[SW_WAVES][SW_MAX_RANGES];
     __shared__ unsigned long long s_wt[SW_WAVES];
     __shared__ int s_last;
-    const unsigned long long dbg_t0 = P.dbg ? wall_clock64() : 0ull;
+    const unsigned long long dbg_t0 = (ISDF_SWEEP_STATS && P.dbg) ? wall_clock64() : 0ull;
     TrajL<LDS> tr{P.T, P.coeffs, P.N};
     if constexpr (LDS) tr = traj_stage(s_dyn, P.T, P.coeffs, P.N);
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int pt = P.point_begin + blockIdx.x * SW_WAVES + wave;
     if (pt < P.point_end) {
-    unsigned long long *const dbg = P.dbg ? P.dbg + (size_t)pt * 4 : nullptr;
+    unsigned long long *const dbg = (ISDF_SWEEP_STATS && P.dbg) ? P.dbg + (size_t)pt * 4 : nullptr;
     if (dbg && lane == 0) { dbg[0] = dbg_t0; dbg[1] = wall_clock64(); }
     const d3 p = mk3(P.points[3 * pt], P.points[3 * pt + 1], P.points[3 * pt + 2]);
     const double D = *P.traj_duration;
@@ -418,9 +421,9 @@ __global__ __launch_bounds__(64 * SW_WAVES) void swept_descent_kernel(const Swep
     if constexpr (LDS) tr = traj_stage(s_dyn, P.T, P.coeffs, P.N);
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const unsigned n_tasks = P.words[0], n_front = P.words[2];
+    const unsigned n_tasks = (unsigned)__builtin_amdgcn_readfirstlane((int)P.words[0]), n_front = (unsigned)__builtin_amdgcn_readfirstlane((int)P.words[2]);
     const unsigned cap = (unsigned)(P.point_end - P.point_begin) * SW_MAX_RANGES;
-    const unsigned n_waves = gridDim.x * SW_WAVES;
+    const unsigned n_waves = (unsigned)__builtin_amdgcn_readfirstlane((int)(gridDim.x * SW_WAVES));
     const double D = *P.traj_duration;
     const int gmode = P.shape.grad_mode;
     const bool fd_central = (KIND != ISDF_SHAPE_MESH) && gmode == ISDF_GRAD_CENTRAL;
@@ -430,8 +433,8 @@ __global__ __launch_bounds__(64 * SW_WAVES) void swept_descent_kernel(const Swep
     const int gd_blk = lane < 18 ? -1 : (lane < 25 ? 0 : (lane < 60 ? (lane - 25) / 7 + 1 : (lane == 60 ? GD_SPEC + 1 : -1)));
     const int gd_off = lane < 18 ? 0 : (lane < 25 ? lane - 18 : (lane < 60 ? (lane - 25) % 7 : 0));
     for (unsigned task = blockIdx.x * SW_WAVES + wave, rounds = 0; task < n_tasks && rounds < (1u << 16); task += n_waves, rounds++) {
-        const unsigned tm = task < n_front ? P.task_map[task] : P.task_map[cap - 1u - (task - n_front)];
-        const unsigned long long dbg_t0 = P.dbg ? wall_clock64() : 0ull;
+        const unsigned tm = (unsigned)__builtin_amdgcn_readfirstlane((int)(task < n_front ? P.task_map[task] : P.task_map[cap - 1u - (task - n_front)]));
+        const unsigned long long dbg_t0 = (ISDF_SWEEP_STATS && P.dbg) ? wall_clock64() : 0ull;
         const int rel = (int)(tm >> 5), r = (int)(tm & 31u);
         const int pt = P.point_begin + rel;
         double *const slot = P.task_buf + ((size_t)rel * SW_MAX_RANGES + r) * TASK_STRIDE;
@@ -551,7 +554,7 @@ __global__ __launch_bounds__(64 * SW_WAVES) void swept_descent_kernel(const Swep
             slot[0] = x; slot[1] = fx; slot[2] = g1_at_x.x; slot[3] = g1_at_x.y; slot[4] = g1_at_x.z;
             slot[5] = __longlong_as_double((long long)(((unsigned long long)n_pass & 0xFFFFull) | ((unsigned long long)iter << 16)));
             if (n_pass >= LPT_TASK) atomicOr(&P.point_lmask[pt], 1u << r);      // next step: dispatch this interval's descent early
-            if (P.dbg && task < (unsigned)P.M) {      // developer timing (ISDF_DEBUG_TIMING=1): start, end, passes of this task
+            if (ISDF_SWEEP_STATS && P.dbg && task < (unsigned)P.M) {      // developer timing (ISDF_DEBUG_TIMING=1): start, end, passes of this task
                 unsigned long long *d = P.dbg + (size_t)P.M * 4 + (size_t)(P.N + 1) * 8 + (size_t)task * 3;
                 d[0] = dbg_t0; d[1] = wall_clock64(); d[2] = (unsigned long long)n_pass | ((unsigned long long)(task < n_front) << 32);
             }
@@ -694,7 +697,7 @@ __global__ __launch_bounds__(256) void swept_reduce_kernel(const SweptParams P, 
     for (int q = 0; q < 20; q++) acc[q] = 0.0;
     unsigned long long n_act = 0, n_rng = 0, n_pass = 0, n_it = 0;
     const bool cost_block = (i == P.N);
-    unsigned long long *const rdbg = P.dbg ? P.dbg + (size_t)P.M * 4 + (size_t)i * 8 : nullptr;
+    unsigned long long *const rdbg = (ISDF_SWEEP_STATS && P.dbg) ? P.dbg + (size_t)P.M * 4 + (size_t)i * 8 : nullptr;
     if (rdbg && tid == 0) rdbg[0] = wall_clock64();
     for (int base = P.point_begin + tid; base < P.point_end; base += 256 * RED_U) {
         if (cost_block) {
