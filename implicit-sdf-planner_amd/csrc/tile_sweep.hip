@@ -424,8 +424,9 @@ __global__ __launch_bounds__(POSE_THREADS) void pose_kernel(const SweepParams P)
     const long long sidx = s_first + threadIdx.x;
     if (sidx < s_end) {
     const DevGrid &G = P.grid;
-    SweepPose sp;
-    for (int k = 0; k < (int)(sizeof(SweepPose) / 8); k++) ((double *)&sp)[k] = 0.0;
+    SweepPose &sp = *reinterpret_cast<SweepPose *>(&s_rec[threadIdx.x][0]);       // built in place (a local copy ends up in scratch memory)
+#pragma unroll
+    for (int k = 0; k < POSE_REC; k++) s_rec[threadIdx.x][k] = 0.0;
     const SampleId id = decode_sample(P, sidx);
     const PieceIn pin = piece_in(P, id.b, id.i);
     const double *c = pin.c;
@@ -503,8 +504,6 @@ __global__ __launch_bounds__(POSE_THREADS) void pose_kernel(const SweepParams P)
     sp.flags = flags_w;
     sp.sa = sa_w;
     scan_consts(P, scan_launch_consts(P, P.shape.kind), sp.pos, sp.R, sp.lo, sa_w, sp.rny, P.shape.kind == ISDF_SHAPE_ROUNDEDCONE && P.shape.f.ident != 0, sp);
-#pragma unroll
-    for (int k = 0; k < POSE_REC; k++) s_rec[threadIdx.x][k] = ((const double *)&sp)[k];
     }
     __syncthreads();
     const int n_rec = (int)min((long long)POSE_THREADS, s_end - s_first);
