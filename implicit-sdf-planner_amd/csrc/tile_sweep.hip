@@ -13,8 +13,8 @@
 //                         qualifier bits (1-2 dwords of the bit-grid, requested one round ahead), DPP prefix-sum
 //                         compaction of the surviving voxels into an LDS ring;
 //                     (3) conservative fp32 filter on full wavefronts (body-frame transform, cube cull, robot SDF);
-//                     (4) survivors, 64 at a time, get the exact fp64 treatment of grad_cost_p, dealt over the workgroup's
-//                         waves: voxel centre, R^T(c - x), cube cull (:800-803), robot SDF, smoothedL1 and - when the
+//                     (4) survivors, in blocks of up to 64 of one sample (partial blocks of like size share a wavefront
+//                         iteration), get the exact fp64 treatment of grad_cost_p, dealt over the workgroup's waves: voxel centre, R^T(c - x), cube cull (:800-803), robot SDF, smoothedL1 and - when the
 //                         penalty is active - the central-difference gradient and the pose-gradient terms (:805-820);
 //                     (5) wave butterfly -> acc[sample][8].
 //                   No read-modify-write atomics, no work lists: results are bitwise reproducible.

@@ -1,7 +1,8 @@
 #!/usr/bin/env python
 """Developer experiment: does a balanced dispatch order of the tile sweep's samples shorten the single-trajectory step?
 Measures the step with the identity order, then with orders built from the PREVIOUS step's per-sample work (row-scan cycles,
-candidate counts from ISDF_DEBUG_TIMING), dealt so that every workgroup gets one sample of each quartile."""
+candidate counts from ISDF_DEBUG_TIMING), dealt so that every workgroup gets one sample of each quartile.
+Needs the statistics build: `make -C implicit-sdf-planner_amd/csrc EXTRA=-DISDF_SWEEP_STATS=1` after touching the kernel sources."""
 import os, sys, ctypes as C
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))

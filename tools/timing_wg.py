@@ -1,6 +1,7 @@
 #!/usr/bin/env python
 """Developer tool: per-WORKGROUP view of the sweep kernel's phase timing (ISDF_DEBUG_TIMING=1): which workgroups set the
-kernel's makespan, and with what (pose / rows / exact)."""
+kernel's makespan, and with what (pose / rows / exact).
+Needs the statistics build: `make -C implicit-sdf-planner_amd/csrc EXTRA=-DISDF_SWEEP_STATS=1` after touching the kernel sources."""
 import os, sys, ctypes as C
 os.environ["ISDF_DEBUG_TIMING"] = "1"
 import numpy as np

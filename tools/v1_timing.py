@@ -1,6 +1,7 @@
 #!/usr/bin/env python
 """Developer tool: per-wavefront timestamps of one V1 step (ISDF_DEBUG_TIMING=1; wall_clock64 = 100 MHz): where the scan and the
-descent launches spend their time.  usage: v1_timing.py [cone|box]"""
+descent launches spend their time.  usage: v1_timing.py [cone|box]
+Needs the statistics build: `make -C implicit-sdf-planner_amd/csrc EXTRA=-DISDF_SWEEP_STATS=1` after touching the kernel sources."""
 import os, sys, ctypes as C
 os.environ["ISDF_DEBUG_TIMING"] = "1"
 import numpy as np
