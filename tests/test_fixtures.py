@@ -113,3 +113,42 @@ def test_golden_demo_fixtures_are_self_consistent(pkg, orc):
     assert occ.shape == (51, 51, 35)
     assert g["Lthick_V"].shape == (60, 3) and g["Lthick_F"].shape == (20, 3) and g["mybox_V"].shape == (8, 3)
     assert float(g["CappedCone_yaml_safety_hor"]) == 0.866 and int(g["CappedCone_yaml_kernel_size"]) == 13
+
+
+def _write_pcd(path, fields, counts, rows, data="ascii"):
+    with open(path, "w") as f:
+        f.write("# .PCD v0.7 - Point Cloud Data file format\nVERSION 0.7\n")
+        f.write("FIELDS " + " ".join(fields) + "\n")
+        f.write("SIZE " + " ".join("4" for _ in fields) + "\nTYPE " + " ".join("F" for _ in fields) + "\n")
+        if counts is not None:
+            f.write("COUNT " + " ".join(str(c) for c in counts) + "\n")
+        f.write(f"WIDTH {len(rows)}\nHEIGHT 1\nVIEWPOINT 0 0 0 1 0 0 0\nPOINTS {len(rows)}\nDATA {data}\n")
+        for r in rows:
+            f.write(" ".join(repr(float(v)) for v in r) + "\n")
+
+
+def test_pcd_reader_honours_count(pkg, product_lib, tmp_path):
+    """ADVICE (round 2): a field with COUNT > 1 occupies that many tokens of a data line (pcl's ascii reader walks fields x
+    counts) - the columns of x / y / z shift accordingly; malformed COUNT lines are refused, not mis-read."""
+    fx, capi = pkg.fixtures, pkg.capi
+    rng = np.random.default_rng(5)
+    xyz = rng.uniform(-10, 10, (37, 3)).astype(np.float32)
+    nrm = rng.uniform(-1, 1, (37, 3)).astype(np.float32)
+    # plain layout, with and without a COUNT line of ones
+    for counts in (None, (1, 1, 1)):
+        p = str(tmp_path / f"plain_{counts is None}.pcd")
+        _write_pcd(p, ("x", "y", "z"), counts, xyz)
+        assert np.array_equal(fx.read_pcd(p), xyz)
+    # a 3-wide field in FRONT of the coordinates and a 2-wide one between y and z
+    p = str(tmp_path / "wide.pcd")
+    rows = [np.concatenate([n, [a[0], a[1]], [7.0, 8.0], [a[2]]]) for a, n in zip(xyz, nrm)]
+    _write_pcd(p, ("normal", "x", "y", "pad", "z"), (3, 1, 1, 2, 1), rows)
+    assert np.array_equal(fx.read_pcd(p), xyz)
+    # refused: COUNT of a coordinate != 1 (unsupported), COUNT line of the wrong length / a zero count (invalid), binary data
+    lib = product_lib
+    def rc(path):
+        return lib.isdf_read_pcd(path.encode(), None, 0)
+    p = str(tmp_path / "xwide.pcd"); _write_pcd(p, ("x", "y", "z"), (2, 1, 1), [np.r_[a[0], a] for a in xyz]); assert rc(p) == capi.ISDF_ERR_UNSUPPORTED
+    p = str(tmp_path / "short.pcd"); _write_pcd(p, ("x", "y", "z"), (1, 1), xyz); assert rc(p) == capi.ISDF_ERR_INVALID_ARG
+    p = str(tmp_path / "zero.pcd"); _write_pcd(p, ("x", "y", "z", "w"), (1, 1, 1, 0), xyz); assert rc(p) == capi.ISDF_ERR_INVALID_ARG
+    p = str(tmp_path / "bin.pcd"); _write_pcd(p, ("x", "y", "z"), None, xyz, data="binary"); assert rc(p) == capi.ISDF_ERR_UNSUPPORTED
