@@ -1211,7 +1211,9 @@ template <bool EARLY, bool XF> __device__ __forceinline__ void tail_piece(const 
     unsigned long long tl_c0 = 0, tl_marks = 0;
     if (dbg && tid == 0) { dbg[0] = wall_clock64(); tl_c0 = clock64(); }
 #define TL_MARK(k) do { if (dbg && tid == 0) tl_marks |= (((clock64() - tl_c0) >> 4) & 0xFFFFull) << (16 * (k)); } while (0)
-    for (int j0 = 0; j0 < K1; j0 += TL_THREADS) {
+    // (a fused step has K + 1 <= TL_THREADS - sweep_can_fuse - and says so: with a loop the compiler hoists the constants of the
+    // penalties' polynomials out of it, runs out of the fused kernels' 168 vector registers and spills them to scratch memory)
+    for (int j0 = 0; j0 < (EARLY ? K1 : min(K1, 1)); j0 += TL_THREADS) {
         const int j = j0 + tid;
         if (tid < TL_THREADS && j < K1) {
             const long long s = (long long)gp * K1 + j;
@@ -1453,7 +1455,7 @@ int sweep_resident_blocks(const SweepParams &P, int n_cus) {
 bool sweep_can_fuse(const SweepParams &P) {
     if (!P.enable_pos || P.shape.kind == ISDF_SHAPE_MESH || P.shape.d.ident == 0) return false;
     const long long n_samples = (long long)(P.piece_end - P.piece_begin) * (P.K + 1);
-    if (n_samples <= 0) return false;
+    if (n_samples <= 0 || P.K + 1 > TL_THREADS) return false;      // (the fused tail makes ONE pass over a piece's samples)
     // tail workgroups of OTHER ranks' pieces only write zeros and leave: they do not count
     return (n_samples + SW_SAMPLES - 1) / SW_SAMPLES + (long long)(P.piece_end - P.piece_begin) <= fused_max_blocks() && (long long)P.n_traj * P.N <= 8 * fused_max_blocks();
 }
