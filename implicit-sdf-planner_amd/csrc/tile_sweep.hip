@@ -922,13 +922,20 @@ __global__ __launch_bounds__(64 * SW_SAMPLES, FUSED ? 3 : sweep_waves_per_simd(K
                     // no fp32 test for this kind: the listed voxels ARE the candidates, written straight into the candidate ring
                     const int room = SW_NEAR_CAP - near_cnt;
                     if (room < 64) break;                              // ring full: the workgroup drains it first
-                    const int lim = min(SW_PASS, room >> 6);           // bits per lane that are guaranteed to fit
-                    unsigned t = hb;
-                    for (int k = 0; k < lim; k++) t &= t - 1u;
-                    unsigned take = hb ^ t;
-                    hb = t;
+                    // the whole round at once when it fits (nearly always: one pass per round, no per-lane limit to work out);
+                    // otherwise the lowest bits of every lane that are guaranteed to fit, the rest in later passes
+                    unsigned take = hb;
                     int total;
-                    int wpos = wave_excl_scan(__popc(take), lane, total) + near_head + near_cnt;
+                    int wpos = wave_excl_scan(__popc(take), lane, total);
+                    if (total > room) {
+                        const int lim = min(SW_PASS, room >> 6);
+                        unsigned t = hb;
+                        for (int k = 0; k < lim; k++) t &= t - 1u;
+                        take = hb ^ t;
+                        wpos = wave_excl_scan(__popc(take), lane, total);
+                    }
+                    hb ^= take;
+                    wpos += near_head + near_cnt;
                     while (take) {
                         const unsigned z = (unsigned)__ffs(take) - 1u;
                         take &= take - 1u;
