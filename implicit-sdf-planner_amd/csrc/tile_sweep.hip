@@ -944,16 +944,19 @@ __global__ __launch_bounds__(64 * SW_SAMPLES, FUSED ? 3 : sweep_waves_per_simd(K
                     near_cnt += total;
                     SW_STAT(cnt_passes++; cnt_listed += (unsigned)total; cnt_cand += (unsigned)total;)
                 } else {
+                // (like the direct form above: the whole round when it fits the list, else <= SW_PASS voxels per lane)
                 unsigned take = hb;
-                if (__ballot(__popc(hb) > SW_PASS)) {
+                int total;
+                int wpos = wave_excl_scan(__popc(take), lane, total);
+                if (total > SW_LIST_CAP - pend) {
                     unsigned t = hb;
 #pragma unroll
                     for (int k = 0; k < SW_PASS; k++) t &= t - 1u;
                     take = hb ^ t;
+                    wpos = wave_excl_scan(__popc(take), lane, total);
                 }
                 hb ^= take;
-                int total;
-                int wpos = wave_excl_scan(__popc(take), lane, total) + pend_head + pend;
+                wpos += pend_head + pend;
                 while (take) {
                     const unsigned z = (unsigned)__ffs(take) - 1u;
                     take &= take - 1u;
