@@ -38,6 +38,23 @@ def test_tile_sweep_matches_oracle(pkg, orc, product_lib, variant, shape_name):
     assert st["units"] == st0[0] and st["grad_pairs"] == st0[3] and st0[3] <= st["pairs"] <= st0[2], (st, st0)
 
 
+@pytest.mark.parametrize("K", [127, 128, 150, 300])
+def test_more_samples_per_piece_than_one_tail_pass(pkg, orc, product_lib, K):
+    """integral_intervs beyond what one pass of the tail's 128 threads covers: K + 1 <= 128 is a condition of the fused single launch
+    (its tail makes ONE pass); from K = 128 on the step takes the two-launch path, whose tail walks a piece's samples in passes
+    of 128 - and the result is still the oracle's (also with the dynamics penalties, which the tail owns)."""
+    capi, synth = pkg.capi, pkg.synth
+    occ, esdf, res = small_world(pkg, seed=4)
+    T, cm = traj(pkg, occ, res, seed=21)
+    cfg = synth.default_config(capi.V3_ESDF_TILE, kernel_size=9, integral_intervs=K, safety_hor=0.5)
+    shape = synth.make_shape("Box", params=(1.2, 0.4, 0.3), grad_mode=capi.GRAD_CENTRAL)
+    eng, o = make_pair(pkg, orc, cfg, shape, occ=occ, esdf=esdf, res=res)
+    cost, st0 = _check(eng, o, T, cm, f"K={K}")
+    assert cost > 0
+    st = eng.stats()
+    assert st["units"] == st0[0] and st["grad_pairs"] == st0[3], (st, st0)
+
+
 def test_v3_equals_v2_at_zero_threshold(pkg, orc, product_lib):
     """V3 with occ_thresh = 0 and culling off is V2 up to summation order."""
     capi, synth = pkg.capi, pkg.synth
