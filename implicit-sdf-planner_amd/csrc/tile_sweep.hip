@@ -889,7 +889,10 @@ __global__ __launch_bounds__(64 * SW_SAMPLES, FUSED ? 3 : sweep_waves_per_simd(K
                 if (cand) s_near[wave][(near_head + near_cnt + __popcll(nm & ((1ull << lane) - 1ull))) & (SW_NEAR_CAP - 1)] = ent;
                 near_cnt += __popcll(nm);
                 SW_STAT(cnt_cand += (unsigned)__popcll(nm);)
-            } else if (!__ballot(hb != 0u)) {
+            } else {
+            // (a round that has just been taken is compacted in the same turn of this loop: the same sequence of operations, one
+            // turn of the state machine - a back edge, its conditions, the moves of the loop-carried scalars - per round less)
+            if (!__ballot(hb != 0u)) {
                 // ---- (2a) take the round requested earlier, request the one after it
                 if (primed && rounds_left == 0) {
                     rows_left = false;
@@ -916,7 +919,8 @@ __global__ __launch_bounds__(64 * SW_SAMPLES, FUSED ? 3 : sweep_waves_per_simd(K
                         if (ft >= n_rows) { ft = 0; fzb++; }
                     }
                 }
-            } else {
+            }
+            if (__ballot(hb != 0u)) {
                 // ---- (2b) one pass: every lane moves its lowest <= SW_PASS set bits into the ring
                 if constexpr (DIRECT) {
                     // no fp32 test for this kind: the listed voxels ARE the candidates, written straight into the candidate ring
@@ -966,6 +970,9 @@ __global__ __launch_bounds__(64 * SW_SAMPLES, FUSED ? 3 : sweep_waves_per_simd(K
                 SW_STAT(cnt_passes++; cnt_listed += (unsigned)total;)
                 }
                 wave_lds_sync();
+            }
+            // (the last round has been taken and nothing of it is left: what a further turn would find out)
+            if (primed && rounds_left == 0 && !__ballot(hb != 0u)) rows_left = false;
             }
             finished = !rows_left && pend == 0;
         }
