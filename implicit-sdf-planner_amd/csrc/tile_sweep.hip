@@ -750,7 +750,6 @@ __global__ __launch_bounds__(64 * SW_SAMPLES, FUSED ? 3 : sweep_waves_per_simd(K
     const int dim_v = sa == 2 ? G.Y : G.Z, n_ww = sa == 2 ? G.ZW : (sa == 0 ? G.XW : G.YW);
     const unsigned *const bits_a = sa == 2 ? G.bits : (sa == 0 ? G.bits_x : G.bits_y);
     const unsigned sh_u = sa == 0 ? 10u : 0u, sh_v = sa == 2 ? 10u : 20u, sh_w = 10u * (unsigned)sa;     // fields of a ring entry: x | y << 10 | z << 20
-    const bool small = n_rows < (1 << 24);
     // Box: the row masks already cut the rows to the box's own inflated extent, which IS the set the fp32 test would keep (but
     // for the rounded corners): measured 52 listed -> 48 kept, so the test is skipped for this kind
     constexpr bool DIRECT = (KIND == ISDF_SHAPE_BOX);
@@ -792,13 +791,12 @@ __global__ __launch_bounds__(64 * SW_SAMPLES, FUSED ? 3 : sweep_waves_per_simd(K
 
     // tile coordinates (u, v) of window row t, already in their fields of the ring entry
     auto row_xy = [&](int t) -> unsigned {
-        unsigned wx, wy;
-        if (small) {
-            wx = (unsigned)((float)t * inv_rny);
-            int rem = t - (int)wx * rny;
-            if (rem < 0) { wx--; rem += rny; } else if (rem >= rny) { wx++; rem -= rny; }
-            wy = (unsigned)rem;
-        } else { wx = (unsigned)(t / rny); wy = (unsigned)(t - (int)wx * rny); }
+        // t / rny through fp32 with a one-step correction: exact for t < 2^24, and a window has at most 1024 x 1024 rows (the
+        // 10-bit fields of a ring entry)
+        unsigned wx = (unsigned)((float)t * inv_rny);
+        int rem = t - (int)wx * rny;
+        if (rem < 0) { wx--; rem += rny; } else if (rem >= rny) { wx++; rem -= rny; }
+        const unsigned wy = (unsigned)rem;
         return ((wx + (unsigned)rx0) << sh_u) | ((wy + (unsigned)ry0) << sh_v);
     };
     // the <= 32 qualifier bits of block zb of tile row pk: 1-2 dwords of the bit-grid packed along the scan axis
