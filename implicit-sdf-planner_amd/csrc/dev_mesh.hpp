@@ -289,7 +289,261 @@ __device__ inline double mesh_sdf_grad(const DevMesh *m, d3 p, d3 &g) {
 }
 
 // ---------------------------------------------------------------------------------------------------------------------------
-// WAVE-COOPERATIVE queries.  The per-lane walks above make every lane chase its own node: 64 different 368-byte records per
+// QUAD-COOPERATIVE queries (round 4), for robots of more than a handful of faces.  Per-wavefront time stamps of the swept-volume
+// sweep with a 720-face robot (profiles/r4_v1_timing_mesh720_base.txt) showed both launches ending on a TAIL: every workgroup
+// resident within 1.5 ms, the median wavefront done after 0.8 ms, the last after 4.9 ms - single descent passes of up to 1.1 ms,
+// i.e. one wavefront issuing ~1.6e5 dependent instructions for a point next to the surface (every cluster within twice its
+// radius is opened, every triangle's solid angle taken, one after the other).  The hierarchy is 4-wide, so the FOUR CHILDREN of
+// a node are now evaluated side by side:
+//   lanes 4q .. 4q+3 of a wavefront work on query q (16 queries per wavefront), lane l of the quad on child l of the node -
+//   its far-field term / descend test (mesh_quad_pre: ~75 instead of ~300 instructions per node), its triangle's solid angle,
+//   its bounding-sphere bound and closest-point-on-triangle; the quad combines through DPP quad_perm moves (no LDS).
+// The walk itself stays wave-uniform (node and stack in scalar registers, a node visited when ANY query needs it), and every
+// query keeps exactly its own arithmetic:
+//   winding number: A = ((om0 + om1) + om2) + om3 over the node's present children and D += value(child) in child order, per
+//                   LEVEL - the tree-shaped float sum of the library (mesh_solid_angle), so w stays the library's bit for bit;
+//   closest point : branch and bound with one best per LANE (the triangles that lane has seen) and the quad's minimum as the
+//                   pruning bound; the minimum over the triangles is exact in any visiting order.
+// The swept-volume kernels give one (point, interval) task to a WORKGROUP of four wavefronts and deal the active queries of a
+// pass to them (swept_sweep.hip mesh_eval_wg).
+// A first version of this walk was LATENCY bound (profiles/r4_v1_timing_mesh720_quad2.txt: 1.3 us per node visit = the child
+// word, then the record, then the triangle - three dependent trips to L2 - plus the frames in scratch memory).  So:
+//   * ONE trip per node: DevMesh::fwn_boxq holds, per (node, child), 40 floats = the 23 numbers of the record, the child word
+//     and - for a triangle child - its nine float coordinates; DevMesh::fwn_triq the fp64 triangle for the closest point.  A lane
+//     asks for all of it at once (the addresses depend on (node, l) only);
+//   * the frames of the levels above (per quad: A, D, descend mask; per lane: its triangle's solid angle) and the closest-point
+//     stack live in LDS (MeshFrames, 12 levels: the reference's 12 000-face Trefoil.obj needs 9).
+struct MeshFrames {                            // one per WAVEFRONT, in LDS
+    float A[MESH_Q_LEVELS][16], D[MESH_Q_LEVELS][16], T[MESH_Q_LEVELS][64];
+    unsigned dm[MESH_Q_LEVELS][16];
+    unsigned long long set[MESH_Q_LEVELS];
+    int node[MESH_Q_LEVELS], cur[MESH_Q_LEVELS], cw[MESH_Q_LEVELS][4];
+    int s_node[3 * MESH_Q_LEVELS + 4], s_par[3 * MESH_Q_LEVELS + 4];
+};
+__device__ __forceinline__ int mesh_uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
+template <int K> __device__ __forceinline__ float quad_bcast(float v) {      // lane K of every quad -> its four lanes
+    return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), K * 0x55, 0xf, 0xf, false));
+}
+template <int K> __device__ __forceinline__ int quad_bcast(int v) { return __builtin_amdgcn_mov_dpp(v, K * 0x55, 0xf, 0xf, false); }
+__device__ __forceinline__ float quad_bcast_dyn(float v, int k) {            // k wave-uniform
+    return k == 0 ? quad_bcast<0>(v) : (k == 1 ? quad_bcast<1>(v) : (k == 2 ? quad_bcast<2>(v) : quad_bcast<3>(v)));
+}
+__device__ __forceinline__ double quad_min(double v) {
+    v = fmin(v, dpp_mov_f64<0xB1>(v));      // quad_perm [1,0,3,2]
+    return fmin(v, dpp_mov_f64<0x4E>(v));   // quad_perm [2,3,0,1]
+}
+
+// pre() of `node` for the quads that are `on`: lane l forms child l's term.  A = the node's far-field sum, dm = the quad's
+// descend mask (bit l: child l has to be opened), T = the solid angle of child l when that child is a TRIANGLE to be opened,
+// cw = the quad's four child words (cw[k] on every lane).  Called by all 64 lanes.
+__device__ __forceinline__ void mesh_quad_pre(const float *boxq, int node, bool on, int l, int qsh,
+                                              float qx, float qy, float qz, float acc2, float &A, unsigned &dm, float &T, int (&cw)[4]) {
+#pragma clang fp contract(off)
+    const float4 *r4 = reinterpret_cast<const float4 *>(boxq + ((size_t)4 * node + l) * MESH_Q_REC);
+    // everything this lane can need from this node, requested together (one trip)
+    const float4 a0 = r4[0], a1 = r4[1], a2 = r4[2], a3 = r4[3], a4 = r4[4], a5 = r4[5], t0 = r4[6], t1 = r4[7], t2 = r4[8];
+    const int ci = __builtin_bit_cast(int, a5.w);
+    float om = 0.f;
+    bool desc = false;
+    if (on && ci != -1) {
+        const float rc[24] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w, a2.x, a2.y, a2.z, a2.w,
+                              a3.x, a3.y, a3.z, a3.w, a4.x, a4.y, a4.z, a4.w, a5.x, a5.y, a5.z, 0.f};
+#define RC(i) rc[(i) >> 2]                  /* r[i + l] of the node-major record (mesh_node_pre_t) */
+        float x = qx - RC(4), y = qy - RC(8), z = qz - RC(12);
+        const float ql2 = x * x + y * y + z * z;
+        bool use = false;
+        if (!(ql2 <= RC(0) * acc2)) {
+            const float m2 = 1.0f / ql2, m1 = sqrtf(m2);
+            x *= m1; y *= m1; z *= m1;
+            om = -m2 * (x * RC(16) + y * RC(20) + z * RC(24));
+            const float x2 = x * x, y2 = y * y, z2 = z * z;
+            const float m3 = m2 * m1;
+            om += m3 * (RC(28) + RC(32) + RC(36)
+                        - 3.0f * ((x2 * RC(28) + y2 * RC(32) + z2 * RC(36)) + x * y * RC(40) + x * z * RC(48) + y * z * RC(44)));
+            const float x3 = x2 * x, y3 = y2 * y, z3 = z2 * z;
+            const float m4 = m2 * m2;
+            const float t0x = RC(80) + RC(84), t0y = RC(88) + RC(68), t0z = RC(72) + RC(76);
+            const float t1x = y * RC(68) + z * RC(72), t1y = z * RC(76) + x * RC(80), t1z = x * RC(84) + y * RC(88);
+            om += m4 * (1.5f * (x * (3.0f * RC(52) + t0x) + y * (3.0f * RC(56) + t0y) + z * (3.0f * RC(60) + t0z))
+                        - 7.5f * ((x3 * RC(52) + y3 * RC(56) + z3 * RC(60)) + x * y * z * RC(64) + (x2 * t1x + y2 * t1y + z2 * t1z)));
+            use = isfinite(om);
+        }
+#undef RC
+        if (!use) { om = 0.f; desc = true; }
+    }
+    // the library's lane-order sum over the PRESENT children (empty children are last; an empty node sums to 0)
+    const float o0 = quad_bcast<0>(om), o1 = quad_bcast<1>(om), o2 = quad_bcast<2>(om), o3 = quad_bcast<3>(om);
+    cw[0] = quad_bcast<0>(ci); cw[1] = quad_bcast<1>(ci); cw[2] = quad_bcast<2>(ci); cw[3] = quad_bcast<3>(ci);
+    float sum = o0;
+    if (cw[1] != -1) { sum = sum + o1; if (cw[2] != -1) { sum = sum + o2; if (cw[3] != -1) sum = sum + o3; } }
+    A = sum;
+    dm = (unsigned)((__ballot(desc) >> qsh) & 0xFull);
+    T = 0.f;
+    if (desc && ci >= 0) {
+        const float u[9] = {t0.x, t0.y, t0.z, t0.w, t1.x, t1.y, t1.z, t1.w, t2.x};
+        T = mesh_tri_solid_angle(u, qx, qy, qz);
+    }
+}
+
+// UT_SolidAngle::computeSolidAngle for 16 queries: the four lanes of a quad pass the same (qx, qy, qz, act) and get the same
+// result.  Called by all 64 lanes; F = this wavefront's frames in LDS.
+__device__ inline float mesh_solid_angle_quad(const DevMesh *m, MeshFrames *F, float qx, float qy, float qz, bool act) {
+#pragma clang fp contract(off)
+    const float acc2 = MESH_FWN_ACCURACY * MESH_FWN_ACCURACY;
+    const int lane = (int)__lane_id(), l = lane & 3, qsh = lane & 60, qd = lane >> 2;
+    const mesh_cptr<DevMesh> mu = mesh_const_uni(m);
+    const float *boxq = mu->fwn_boxq;
+    int L = 0, node = 0, cur = 0;
+    unsigned long long S = __ballot(act);
+    if (!S) return 0.f;
+    float A, D = 0.f, T;
+    unsigned dm;
+    int cw[4];
+    mesh_quad_pre(boxq, 0, act, l, qsh, qx, qy, qz, acc2, A, dm, T, cw);
+    for (;;) {
+        const bool inS = (S >> lane) & 1ull;
+        const unsigned mydm = inS ? dm : 0u;
+        unsigned long long U = 0ull;
+        for (; cur < 4; cur++) { U = __ballot((mydm >> cur) & 1u); if (U) break; }
+        if (cur >= 4) {                                           // every child some query opens has been visited: post()
+            const float v = A + D;
+            if (L == 0) return v;
+            --L;
+            node = mesh_uni(F->node[L]); cur = mesh_uni(F->cur[L]); S = F->set[L];
+            dm = F->dm[L][qd]; A = F->A[L][qd]; T = F->T[L][lane];
+            const float Dp = F->D[L][qd];
+            D = inS ? Dp + v : Dp;                                 // (the quads of the child's set are a subset of the parent's)
+            cw[0] = F->cw[L][0]; cw[1] = F->cw[L][1]; cw[2] = F->cw[L][2]; cw[3] = F->cw[L][3];
+            continue;
+        }
+        const int c = cur++;
+        const bool inU = (U >> lane) & 1ull;
+        const int ci = mesh_uni(c == 0 ? cw[0] : (c == 1 ? cw[1] : (c == 2 ? cw[2] : cw[3])));
+        if (ci == -1) { cur = 4; continue; }                      // (empty children are last; never marked by pre)
+        if (ci >= 0) {
+            const float t = quad_bcast_dyn(T, c);                  // the triangle's solid angle sits on lane c of the quad
+            if (inU) D = D + t;
+        } else {
+            const int child = ci & 0x7fffffff;
+            float A2, T2;
+            unsigned d2;
+            int cw2[4];
+            mesh_quad_pre(boxq, child, inU, l, qsh, qx, qy, qz, acc2, A2, d2, T2, cw2);
+            if (!__ballot(inU && d2 != 0u)) { if (inU) D = D + A2; }      // nobody goes deeper: the child's value is its pre()
+            else {
+                if (lane == 0) { F->node[L] = node; F->cur[L] = cur; F->set[L] = S; F->cw[L][0] = cw[0]; F->cw[L][1] = cw[1]; F->cw[L][2] = cw[2]; F->cw[L][3] = cw[3]; }
+                if (l == 0) { F->dm[L][qd] = dm; F->A[L][qd] = A; F->D[L][qd] = D; }
+                F->T[L][lane] = T;
+                ++L;
+                node = child; cur = 0; S = U; dm = d2; A = A2; D = 0.f; T = T2;
+                cw[0] = cw2[0]; cw[1] = cw2[1]; cw[2] = cw2[2]; cw[3] = cw2[3];
+            }
+        }
+    }
+}
+
+// Closest point for 16 queries.  `best` in: the query's cutoff (squared), out: min(exact squared distance, cutoff); `closest`
+// is written when a triangle beat the cutoff.  The four lanes of a quad pass the same arguments and get the same results.
+__device__ inline double mesh_closest_quad(const DevMesh *m, MeshFrames *F, d3 p, bool act, d3 &closest, double best) {
+    const int lane = (int)__lane_id(), l = lane & 3, qsh = lane & 60;
+    const mesh_cptr<DevMesh> mu = mesh_const_uni(m);
+    const float *boxq = mu->fwn_boxq;
+    const double *triq = mu->fwn_triq;
+    const double cutoff = best;
+    double mine = best;                    // the best of the triangles THIS lane has evaluated
+    d3 myc = mk3(0, 0, 0);
+    int sp = __ballot(act) ? 1 : 0;
+    if (lane == 0) { F->s_node[0] = 0; F->s_par[0] = -1; }
+    while (sp > 0) {
+        sp = mesh_uni(sp) - 1;
+        const int node = mesh_uni(F->s_node[sp]), par = mesh_uni(F->s_par[sp]);
+        // this lane's child: bound, child word, fp64 triangle - and the bound of the node itself (from its parent's record), all
+        // requested together
+        const float *rq = boxq + ((size_t)4 * node + l) * MESH_Q_REC;
+        const float4 a = *reinterpret_cast<const float4 *>(rq);          // maxP2, P.xyz
+        const int ci = __builtin_bit_cast(int, rq[23]);
+        const double *t = triq + ((size_t)4 * node + l) * MESH_Q_TRI;
+        const double2 u0 = *reinterpret_cast<const double2 *>(t), u1 = *reinterpret_cast<const double2 *>(t + 2), u2 = *reinterpret_cast<const double2 *>(t + 4),
+                      u3 = *reinterpret_cast<const double2 *>(t + 6), u4 = *reinterpret_cast<const double2 *>(t + 8);
+        float4 ap = a;
+        if (par >= 0) ap = *reinterpret_cast<const float4 *>(boxq + (size_t)par * MESH_Q_REC);          // par = 4 * parent + child index
+        auto lb2_of = [&](const float4 &r) {
+            const double px = r.y, py = r.z, pz = r.w;
+            const double dx = p.x - px, dy = p.y - py, dz = p.z - pz;
+            // radius padded for the float rounding of P / maxP2 and the float copies of the vertices they were built from
+            const double rad = (double)sqrtf(r.x) * 1.00001 + 1e-6 * (fabs(px) + fabs(py) + fabs(pz) + 1.0);
+            const double lb = fmax(sqrt(dx * dx + dy * dy + dz * dz) - rad, 0.0);
+            return lb * lb;
+        };
+        if (par >= 0) {                                           // the bests may have improved since this node was pushed
+            if (!__ballot(act && lb2_of(ap) < best)) continue;
+        }
+        double lb2 = 1.7976931348623157e308;
+        if (act && ci != -1) lb2 = lb2_of(a);
+        if (ci >= 0 && lb2 < best) {                              // my child is a triangle that can still beat the query's best
+            const d3 c = closest_on_triangle(p, mk3(u0.x, u0.y, u1.x), mk3(u1.y, u2.x, u2.y), mk3(u3.x, u3.y, u4.x));
+            const d3 dd = p - c;
+            const double d = dot3(dd, dd);
+            if (d < mine) { mine = d; myc = c; }
+        }
+        best = quad_min(mine);
+        // internal children some query still wants, farthest first on the stack (the nearest ends on top); order by the bound of
+        // the first wanting query (the queries of a wavefront are neighbours)
+        const unsigned long long W = __ballot(ci < -1 && lb2 < best);
+        if (!W) continue;
+        int c0 = -1, c1 = -1, c2 = -1, c3 = -1;
+        double r0 = -1.0, r1 = -1.0, r2 = -1.0;
+        for (int k = 0; k < 4; k++) {
+            const unsigned long long Uk = W & (0x1111111111111111ull << k);
+            if (!Uk) continue;
+            const int fl = __ffsll((long long)Uk) - 1;
+            const int lo = __builtin_amdgcn_readlane(__double2loint(lb2), fl), hi = __builtin_amdgcn_readlane(__double2hiint(lb2), fl);
+            const double rep = __hiloint2double(hi, lo);
+            const int cwk = ((__builtin_amdgcn_readlane(ci, fl) & 0x7fffffff) << 2) | k;
+            if (rep > r0) { c3 = c2; c2 = c1; r2 = r1; c1 = c0; r1 = r0; c0 = cwk; r0 = rep; }
+            else if (rep > r1) { c3 = c2; c2 = c1; r2 = r1; c1 = cwk; r1 = rep; }
+            else if (rep > r2) { c3 = c2; c2 = cwk; r2 = rep; }
+            else c3 = cwk;
+        }
+        if (lane == 0) {
+            int q = sp;
+            if (c0 >= 0) { F->s_node[q] = c0 >> 2; F->s_par[q] = (node << 2) | (c0 & 3); ++q; }
+            if (c1 >= 0) { F->s_node[q] = c1 >> 2; F->s_par[q] = (node << 2) | (c1 & 3); ++q; }
+            if (c2 >= 0) { F->s_node[q] = c2 >> 2; F->s_par[q] = (node << 2) | (c2 & 3); ++q; }
+            if (c3 >= 0) { F->s_node[q] = c3 >> 2; F->s_par[q] = (node << 2) | (c3 & 3); ++q; }
+        }
+        sp += (c0 >= 0) + (c1 >= 0) + (c2 >= 0) + (c3 >= 0);
+    }
+    // the quad's winner: the lowest lane holding the minimum hands its point to the other three
+    best = quad_min(mine);
+    const unsigned hit = (unsigned)((__ballot(mine == best) >> qsh) & 0xFull);
+    const int src = qsh + (hit ? __ffs((int)hit) - 1 : 0);
+    const double wx = __shfl(myc.x, src, 64), wy = __shfl(myc.y, src, 64), wz = __shfl(myc.z, src, 64);
+    if (best < cutoff) closest = mk3(wx, wy, wz);
+    return best;
+}
+
+// mesh_sdf_grad / mesh_sdf_grad_below for 16 queries (all 64 lanes call; a quad passes the same arguments); cap = +infinity
+// gives the plain query.  Returns false when sdf >= cap is proven (or the query is not `act`).
+__device__ inline bool mesh_sdf_grad_below_quad(const DevMesh *m, MeshFrames *F, d3 p, bool act, double cap, double &sdf, d3 &g) {
+    const float sa = mesh_solid_angle_quad(m, F, (float)p.x, (float)p.y, (float)p.z, act);
+    const double w = (double)sa / (4.0 * 3.14159265358979323846);
+    const double s = 1. - 2. * w;
+    double cutoff2 = 1.7976931348623157e308;
+    if (s > 0.0 && cap < 1.0e300) {
+        if (!(cap > 0.0)) act = false;                  // outside and sdf >= 0 >= cap
+        else { const double dc = cap / s; cutoff2 = dc * dc * (1.0 + 1e-12); }
+    }
+    d3 c = mk3(0, 0, 0);
+    const double d2 = mesh_closest_quad(m, F, p, act, c, cutoff2);
+    if (!act || d2 >= cutoff2) return false;
+    sdf = s * sqrt(d2);
+    g = normalized3(s * (p - c));
+    return true;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// WAVE-COOPERATIVE queries (round 3; small robots and hierarchies deeper than MESH_Q_LEVELS keep them).  The per-lane walks above make every lane chase its own node: 64 different 368-byte records per
 // step of the loop and a private stack per lane - measured on the swept-volume sweep with a 720-face robot: 1.5e8 vector memory
 // instructions per launch, 53-70 % of the wave cycles waiting, VALU 15 % busy (profiles/r3b_v1mesh_pmc_*).  But the lanes of a
 // wavefront ask about NEIGHBOURING points (one obstacle point seen from poses a few centimetres apart in the descent; the
@@ -302,7 +556,6 @@ __device__ inline double mesh_sdf_grad(const DevMesh *m, d3 p, d3 &g) {
 //   closest point : branch and bound with per-lane best distances; a subtree is skipped when NO lane can improve in it, so
 //                   every lane still sees every triangle that could be its closest (the minimum is exact either way).
 // All lanes that execute the call take part (ballot): it may sit inside divergent code, as long as those lanes reach it together.
-__device__ __forceinline__ int mesh_uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
 
 __device__ inline float mesh_solid_angle_wave(const DevMesh *m, float qx, float qy, float qz) {
 #pragma clang fp contract(off)

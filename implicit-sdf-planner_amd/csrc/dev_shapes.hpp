@@ -14,6 +14,9 @@ namespace isdf {
 // mesh kind (functions in dev_mesh.hpp)
 constexpr int MESH_STACK = 64;             // per-lane traversal stack: >= 3 * depth + 1, checked by isdf_set_shape
 constexpr int MESH_FRAMES = (MESH_STACK - 1) / 3;      // frames of the winding-number walk: one per level of the hierarchy
+constexpr int MESH_Q_LEVELS = 12;          // quad-cooperative walks (dev_mesh.hpp): levels of frames kept in LDS; deeper hierarchies take the wave-cooperative walks
+constexpr int MESH_Q_REC = 40;             // floats per (node, child) in DevMesh::fwn_boxq
+constexpr int MESH_Q_TRI = 10;             // doubles per (node, child) in DevMesh::fwn_triq
 constexpr float MESH_FWN_ACCURACY = 2.0f;  // accuracy_scale of igl::fast_winding_number(fwn_bvh, 2.0, ...), Shape.cpp:110
 struct DevMesh {
     const double *tri;   // nF x 9: a.xyz b.xyz c.xyz
@@ -22,6 +25,11 @@ struct DevMesh {
     const int *fwn_child;   // 4 per node: triangle index | -1 empty | node number with the top bit set (csrc/fwn_host.hpp)
     const float *fwn_box;   // 92 per node: per-child radius^2, centre and order-2 expansion coefficients
     int fwn_nodes;
+    // for the quad-cooperative walks (dev_mesh.hpp), child-major so that ONE round of loads gives a lane all it needs of a node:
+    const float *fwn_boxq;  // 40 per (node, child): [k] = fwn_box[92 * node + 4 * k + child], k = 0..22; [23] = the child word
+                            // (fwn_child) as bits; [24..32] = the child's triangle (trif) when it is one; pad
+    const double *fwn_triq; // 10 per (node, child): the child's triangle (tri) when it is one; pad
+    int depth;              // levels of the hierarchy
 };
 
 template <typename T> struct ShapeP {
@@ -41,6 +49,7 @@ struct DevShape {
     ShapeP<float> f;
     double bound_radius;
     const DevMesh *mesh;
+    int mesh_wg;              // 1: the swept-volume kernels give this mesh one task per WORKGROUP (quad-cooperative walks)
     // ISDF_SHAPE_GRID: num_sdf_map of BasicShape (Shape.hpp:376-404): 4 doubles per node (unit gradient, distance)
     const double *grid;
     int gn[3];

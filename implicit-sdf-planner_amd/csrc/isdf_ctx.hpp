@@ -27,7 +27,8 @@ struct isdf_ctx {
     double *d_mesh_tri = nullptr;
     float *d_mesh_trif = nullptr;
     int *d_fwn_child = nullptr;
-    float *d_fwn_box = nullptr;
+    float *d_fwn_box = nullptr, *d_fwn_boxq = nullptr;
+    double *d_fwn_triq = nullptr;
     double *d_shape_grid = nullptr;      // ISDF_SHAPE_GRID: the sampled lattice
     void *d_pose = nullptr; size_t pose_cap = 0;      // pose records of a non-fused integral step (bytes)
     // points (V1)
@@ -101,7 +102,8 @@ struct isdf_ctx {
     // reading the peers' buffers over xGMI in rank order, or RCCL's all-reduce) - SURVEY 8(b) "Threading".
     std::vector<isdf_ctx *> peers;
     bool is_peer = false;                       // owned by a lead: not handed to the caller
-    hipEvent_t mev_in = nullptr, mev_done = nullptr;      // lead: inputs ready on the caller's stream; peer: shard finished
+    hipEvent_t mev_in = nullptr, mev_done = nullptr;      // lead: inputs ready on the caller's stream / the step's sum has run; peer: shard finished
+    bool msum_recorded = false;                           // lead: mev_done has been recorded at least once
     int multi_collective = 0;                   // ISDF_MULTI_*: how the shards' outputs are summed
     void *rccl_lib = nullptr; void *rccl_comm = nullptr;  // RCCL by dlopen (only when asked for): this device's communicator
     double *d_mpart = nullptr; size_t mpart_cap = 0;     // every shard of a multi-device step writes [packed outputs | 8 statistics as doubles] here

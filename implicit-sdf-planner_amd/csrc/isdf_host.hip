@@ -154,7 +154,9 @@ static void free_mesh(isdf_ctx *c) {
     if (c->d_mesh_trif) (void)hipFree(c->d_mesh_trif);
     if (c->d_fwn_child) (void)hipFree(c->d_fwn_child);
     if (c->d_fwn_box) (void)hipFree(c->d_fwn_box);
-    c->d_mesh = nullptr; c->d_mesh_tri = nullptr; c->d_mesh_trif = nullptr; c->d_fwn_child = nullptr; c->d_fwn_box = nullptr;
+    if (c->d_fwn_boxq) (void)hipFree(c->d_fwn_boxq);
+    if (c->d_fwn_triq) (void)hipFree(c->d_fwn_triq);
+    c->d_mesh = nullptr; c->d_mesh_tri = nullptr; c->d_mesh_trif = nullptr; c->d_fwn_child = nullptr; c->d_fwn_box = nullptr; c->d_fwn_boxq = nullptr; c->d_fwn_triq = nullptr;
 }
 
 static void multi_release(isdf_ctx *c);
@@ -295,6 +297,7 @@ extern "C" int isdf_set_shape(isdf_ctx *c, const isdf_shape *s) {
     // the fp32 pre-filter of tile_kernel needs a continuous analytic SDF; ISDF_NO_F32_FILTER=1 disables it (A/B runs)
     d.filter_f32 = (s->kind != ISDF_SHAPE_MESH) && !(getenv("ISDF_NO_F32_FILTER") && getenv("ISDF_NO_F32_FILTER")[0] == '1');
     d.mesh = nullptr;
+    d.mesh_wg = 0;
     if (s->kind == ISDF_SHAPE_MESH) {
         if (!s->mesh_vertices || !s->mesh_faces || s->n_faces < 1 || s->n_vertices < 3) return fail(c, ISDF_ERR_INVALID_ARG, "mesh shape needs vertices and faces");
         std::vector<double> tri((size_t)9 * s->n_faces);
@@ -322,7 +325,30 @@ extern "C" int isdf_set_shape(isdf_ctx *c, const isdf_shape *s) {
         HIPCHK(c, hipMalloc(&c->d_mesh, sizeof(DevMesh)));
         HIPCHK(c, hipMemcpy(c->d_mesh_tri, tri.data(), tri.size() * sizeof(double), hipMemcpyHostToDevice));
         HIPCHK(c, hipMemcpy(c->d_mesh_trif, trif.data(), trif.size() * sizeof(float), hipMemcpyHostToDevice));
-        DevMesh hm{c->d_mesh_tri, c->d_mesh_trif, s->n_faces, c->d_fwn_child, c->d_fwn_box, tree.n_nodes()};
+        // child-major copies for the quad-cooperative walks (csrc/dev_mesh.hpp): lane l of a quad reads child l's record, child
+        // word and triangle in one round of loads
+        const int depth = isdf_host::fwn_depth(tree);
+        std::vector<float> boxq((size_t)4 * isdf::MESH_Q_REC * tree.n_nodes(), 0.f);
+        std::vector<double> triq((size_t)4 * isdf::MESH_Q_TRI * tree.n_nodes(), 0.0);
+        for (int nd = 0; nd < tree.n_nodes(); nd++)
+            for (int ch = 0; ch < 4; ch++) {
+                float *rq = boxq.data() + ((size_t)4 * nd + ch) * isdf::MESH_Q_REC;
+                for (int k = 0; k < 23; k++) rq[k] = tree.box[(size_t)92 * nd + 4 * k + ch];
+                const int32_t ci = tree.child[(size_t)4 * nd + ch];
+                std::memcpy(&rq[23], &ci, 4);
+                if (ci >= 0) {
+                    for (int k = 0; k < 9; k++) rq[24 + k] = trif[(size_t)9 * ci + k];
+                    for (int k = 0; k < 9; k++) triq[((size_t)4 * nd + ch) * isdf::MESH_Q_TRI + k] = tri[(size_t)9 * ci + k];
+                }
+            }
+        HIPCHK(c, hipMalloc(&c->d_fwn_boxq, boxq.size() * sizeof(float)));
+        HIPCHK(c, hipMemcpy(c->d_fwn_boxq, boxq.data(), boxq.size() * sizeof(float), hipMemcpyHostToDevice));
+        HIPCHK(c, hipMalloc(&c->d_fwn_triq, triq.size() * sizeof(double)));
+        HIPCHK(c, hipMemcpy(c->d_fwn_triq, triq.data(), triq.size() * sizeof(double), hipMemcpyHostToDevice));
+        DevMesh hm{c->d_mesh_tri, c->d_mesh_trif, s->n_faces, c->d_fwn_child, c->d_fwn_box, tree.n_nodes(), c->d_fwn_boxq, c->d_fwn_triq, depth};
+        // one task per workgroup pays when a pass is long (measured: 20 faces 1.15 -> 1.95 ms, 720 faces faster); ISDF_MESH_WG=0/1 forces
+        d.mesh_wg = (s->n_faces >= 64 && depth <= isdf::MESH_Q_LEVELS) ? 1 : 0;
+        if (const char *e = getenv("ISDF_MESH_WG")) d.mesh_wg = (e[0] == '1' && depth <= isdf::MESH_Q_LEVELS) ? 1 : 0;
         HIPCHK(c, hipMemcpy(c->d_mesh, &hm, sizeof(hm), hipMemcpyHostToDevice));
         d.mesh = c->d_mesh;
     }
@@ -817,7 +843,9 @@ __global__ void multi_tail_kernel(const unsigned long long *stats, double *tail)
     if (threadIdx.x < MULTI_TAIL) tail[threadIdx.x] = (double)stats[threadIdx.x];
 }
 // out[i] = part_0[i] + part_1[i] + ... (rank order: bitwise reproducible); the summed tail back into the lead's statistics words
-__global__ __launch_bounds__(256) void multi_sum_kernel(double *out, MultiParts parts, size_t count, unsigned long long *stats) {
+// (`all_stats`: V1 counts straight into the statistics words, so their device sums are the step's statistics; V2 / V3 words are
+// filled on demand by isdf_get_stats and only the overflow word [4] travels)
+__global__ __launch_bounds__(256) void multi_sum_kernel(double *out, MultiParts parts, size_t count, unsigned long long *stats, int all_stats) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < count + MULTI_TAIL) {
         double s = parts.p[0][i];
@@ -826,7 +854,7 @@ __global__ __launch_bounds__(256) void multi_sum_kernel(double *out, MultiParts 
         else {
             const int k = (int)(i - count);
             if (k == 4) { if (s != 0.0) stats[4] = 1ull; }                 // overflow: sticky until read
-            else stats[k] = (unsigned long long)s;
+            else if (all_stats) stats[k] = (unsigned long long)s;
         }
     }
 }
@@ -931,6 +959,9 @@ static int multi_eval_device(isdf_ctx *c, int n_traj, int N, const double *d_T, 
     const bool swept = c->cfg.variant == ISDF_V1_SWEPT && mode != 2;
     if (fixed_tstar) return fail(c, ISDF_ERR_UNSUPPORTED, "isdf_eval_swept_at_tstar on a multi-device ctx");
     HIPCHK(c, hipSetDevice(c->device));
+    // the previous step's sum read the peers' part buffers and this ctx's own: a step issued on ANOTHER caller stream must not
+    // overwrite them before that sum has run (the peers' streams follow through mev_in below)
+    if (c->msum_recorded) HIPCHK(c, hipStreamWaitEvent(st, c->mev_done, 0));
     HIPCHK(c, hipEventRecord(c->mev_in, st));                              // the caller's inputs are ready from here on
     double *lead_ts = swept ? (d_tstar ? d_tstar : c->d_tstar) : nullptr;
     MultiParts parts{};
@@ -978,7 +1009,7 @@ static int multi_eval_device(isdf_ctx *c, int n_traj, int N, const double *d_T, 
         if (g_rccl.GroupEnd() != 0) return fail(c, ISDF_ERR_HIP, "ncclGroupEnd failed");
         HIPCHK(c, hipSetDevice(c->device));
         MultiParts one{}; one.n = 1; one.p[0] = c->d_mpart;
-        hipLaunchKernelGGL(multi_sum_kernel, grid, block, 0, st, d_out, one, count, c->d_stats);
+        hipLaunchKernelGGL(multi_sum_kernel, grid, block, 0, st, d_out, one, count, c->d_stats, swept ? 1 : 0);
     } else {
         for (int r = 1; r < n; r++) HIPCHK(c, hipStreamWaitEvent(st, c->peers[r - 1]->mev_done, 0));
         if (c->multi_collective == ISDF_MULTI_STAGED) {
@@ -990,11 +1021,13 @@ static int multi_eval_device(isdf_ctx *c, int n_traj, int N, const double *d_T, 
                 parts.p[r] = dst;
             }
         }
-        hipLaunchKernelGGL(multi_sum_kernel, grid, block, 0, st, d_out, parts, count, c->d_stats);
+        hipLaunchKernelGGL(multi_sum_kernel, grid, block, 0, st, d_out, parts, count, c->d_stats, swept ? 1 : 0);
     }
     HIPCHK(c, hipGetLastError());
     // the next step's peer copies overwrite the peers' inputs: they are ordered behind THIS step's kernels by the peers' own
-    // streams, and the lead's part buffer behind `st`
+    // streams; the part buffers behind the lead's "sum done" event (its own mev_done: the lead records no other use of it)
+    HIPCHK(c, hipEventRecord(c->mev_done, st));
+    c->msum_recorded = true;
     return ISDF_OK;
 }
 
@@ -1019,6 +1052,8 @@ extern "C" int isdf_eval_swept_at_tstar(isdf_ctx *c, int N, const double *d_T, c
                                         const double *d_tstar, void *stream) {
     if (!c) return ISDF_ERR_INVALID_ARG;
     if (!d_tstar) return fail(c, ISDF_ERR_INVALID_ARG, "null t* buffer");
+    // (a multi-device ctx would return its lead's shard only: refused, as the header says)
+    if (!c->peers.empty() || c->is_peer || c->rccl_comm) return fail(c, ISDF_ERR_UNSUPPORTED, "isdf_eval_swept_at_tstar on a multi-device ctx");
     return eval_device_impl(c, 1, N, d_T, d_coeffs, d_out, const_cast<double *>(d_tstar), (hipStream_t)stream, 1, true);
 }
 
@@ -1027,6 +1062,7 @@ extern "C" int isdf_eval_swept_at_tstar_host(isdf_ctx *c, int N, const double *T
                                              double *cost_inout, double *gradT_inout, double *gradC_inout) {
     if (!c) return ISDF_ERR_INVALID_ARG;
     if (N < 1 || !T || !coeffs || !tstar || !cost_inout || !gradT_inout || !gradC_inout) return fail(c, ISDF_ERR_INVALID_ARG, "null argument");
+    if (!c->peers.empty() || c->is_peer || c->rccl_comm) return fail(c, ISDF_ERR_UNSUPPORTED, "isdf_eval_swept_at_tstar on a multi-device ctx");
     if (c->M <= 0) return ISDF_OK;
     HIPCHK(c, hipSetDevice(c->device));
     const size_t in_all = (size_t)19 * N, ostride = isdf_out_stride(N);
@@ -1048,6 +1084,23 @@ extern "C" int isdf_eval_swept_at_tstar_host(isdf_ctx *c, int N, const double *T
     return ISDF_OK;
 }
 
+static int fetch_stats(isdf_ctx *c);
+// the peers' pair statistics of the last launch added to the lead's last_stats (V2 / V3; the V1 words of a multi-device step are
+// already the devices' sums)
+static int add_peer_stats(isdf_ctx *c) {
+    if (c->cfg.variant == ISDF_V1_SWEPT || c->peers.empty()) return ISDF_OK;
+    for (isdf_ctx *p : c->peers) {
+        HIPCHK(c, hipSetDevice(p->device));
+        HIPCHK(c, hipDeviceSynchronize());
+        const int rc = fetch_stats(p);
+        if (rc) { c->err = p->err; return rc; }
+        c->last_stats.n_units += p->last_stats.n_units; c->last_stats.n_units_culled += p->last_stats.n_units_culled;
+        c->last_stats.n_pairs += p->last_stats.n_pairs; c->last_stats.n_grad_pairs += p->last_stats.n_grad_pairs;
+        c->last_stats.overflow |= p->last_stats.overflow;
+    }
+    HIPCHK(c, hipSetDevice(c->device));
+    return ISDF_OK;
+}
 static int fetch_stats(isdf_ctx *c) {
     unsigned long long h[8];
     if (c->cfg.variant != ISDF_V1_SWEPT && c->have_last_P) {
@@ -1290,6 +1343,7 @@ extern "C" int isdf_eval(isdf_ctx *c, int n_traj, const int *N, const double *co
             total.n_pairs += (int64_t)hstat[2]; total.n_grad_pairs += (int64_t)hstat[3];
         } else if (groups > 1) {
             rc = fetch_stats(c);                 // ragged input: the per-group counts have to be added up now
+            if (rc == ISDF_OK) rc = add_peer_stats(c);
             if (rc) return rc;
             total.n_units += c->last_stats.n_units; total.n_units_culled += c->last_stats.n_units_culled;
             total.n_pairs += c->last_stats.n_pairs; total.n_grad_pairs += c->last_stats.n_grad_pairs;
@@ -1600,18 +1654,8 @@ extern "C" int isdf_get_stats(isdf_ctx *c, isdf_stats *out) {
         HIPCHK(c, hipDeviceSynchronize());
         int rc = fetch_stats(c);
         if (rc) return rc;
-        if (c->cfg.variant != ISDF_V1_SWEPT) {                 // (the V1 words of a multi-device step are already the devices' sums)
-            for (isdf_ctx *p : c->peers) {
-                HIPCHK(c, hipSetDevice(p->device));
-                HIPCHK(c, hipDeviceSynchronize());
-                rc = fetch_stats(p);
-                if (rc) { c->err = p->err; return rc; }
-                c->last_stats.n_units += p->last_stats.n_units; c->last_stats.n_units_culled += p->last_stats.n_units_culled;
-                c->last_stats.n_pairs += p->last_stats.n_pairs; c->last_stats.n_grad_pairs += p->last_stats.n_grad_pairs;
-                c->last_stats.overflow |= p->last_stats.overflow;
-            }
-            HIPCHK(c, hipSetDevice(c->device));
-        }
+        rc = add_peer_stats(c);
+        if (rc) return rc;
     }
     *out = c->last_stats;
     return ISDF_OK;

@@ -162,11 +162,62 @@ __device__ __forceinline__ double wave_first_min(double v, int lane, int n, int 
     return m;
 }
 
+// ---- mesh robots: ONE (point / interval) per WORKGROUP.  The four wavefronts of the workgroup run the same control flow on the
+// same numbers (so every ballot, every branch and every barrier below is taken by all of them alike); where the lanes of a pass
+// evaluate the mesh SDF, the ACTIVE queries are dealt to the four wavefronts - each takes ceil(n / 4) of them, 4 lanes per query
+// (dev_mesh.hpp, quad-cooperative walks) - and the results come back through LDS.  A pass next to the surface (all of the
+// hierarchy opened by 25-64 queries) was one wavefront's 1e5 dependent instructions; it is now four wavefronts' 1e4 each.
+struct MeshWG {
+    double *stage;       // this wavefront's [64][3] compacted query points (wave-private: no barrier)
+    double *res;         // the workgroup's [2 parities][64][5] results: (below, sdf, g.xyz)
+    int parity, wave;
+    MeshFrames *frames;  // this wavefront's walk frames (dev_mesh.hpp)
+    int n_waves;         // wavefronts of the workgroup (4 in the scan: up to 64 queries per pass; 2 in the descent: 25)
+};
+constexpr int MESH_WG_RES = 2 * 64 * 5;
+constexpr int mesh_wg_stage(int nw) { return nw * 64 * 3; }
+// every lane of all four wavefronts calls; returns "sdf < cap proven / evaluated" like mesh_sdf_grad_below (cap = +inf: plain query)
+__device__ inline bool mesh_eval_wg(MeshWG &X, const DevMesh *m, d3 pr, bool act, double cap, double &sdf, d3 &g) {
+    const int lane = (int)__lane_id();
+    const unsigned long long mask = __ballot(act);
+    if (!mask) return false;                               // (the same in all four wavefronts)
+    const int n_act = __popcll(mask);
+    const int rank = __popcll(mask & ((1ull << lane) - 1ull));
+    if (act) { X.stage[3 * rank] = pr.x; X.stage[3 * rank + 1] = pr.y; X.stage[3 * rank + 2] = pr.z; }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    // FULL wavefronts first (16 queries, 4 lanes each): the queries of a pass are neighbours, so every wavefront that takes part
+    // opens nearly the same set of nodes - dealing 25 queries as 7 + 7 + 7 + 4 cost four walks of 28 lanes (counters: lane
+    // utilisation 0.48, 1.6x the instructions of round 3), 16 + 9 costs two
+    double *R = X.res + (size_t)X.parity * 64 * 5;
+    for (int base = 0; base < n_act; base += 16 * X.n_waves) {
+        const int q = lane >> 2, r = base + X.wave * 16 + q;
+        const bool on = r < n_act;
+        if (!__ballot(on)) continue;                       // (wave-uniform; no barrier inside this loop)
+        const int rr = on ? r : 0;
+        const d3 qp = mk3(X.stage[3 * rr], X.stage[3 * rr + 1], X.stage[3 * rr + 2]);
+        double s2 = 0.0;
+        d3 g2 = mk3(0, 0, 0);
+        const bool below = mesh_sdf_grad_below_quad(m, X.frames, qp, on, cap, s2, g2);
+        if (on && (lane & 3) == 0) { double *o = R + 5 * r; o[0] = below ? 1.0 : 0.0; o[1] = s2; o[2] = g2.x; o[3] = g2.y; o[4] = g2.z; }
+    }
+    __syncthreads();
+    // (double-buffered by parity: a wavefront that races ahead writes the OTHER half, which every wavefront finished reading
+    // before it passed this barrier)
+    X.parity ^= 1;
+    bool ret = false;
+    if (act) { const double *o = R + 5 * rank; ret = o[0] != 0.0; sdf = o[1]; g = mk3(o[2], o[3], o[4]); }
+    return ret;
+}
+
 // ---- the ONE pose + SDF evaluation both kernels below are built around: pose at `te`, body-frame point (perturbed for a
-// gradient sample), shape SDF; pose lanes also form the body-frame point velocity (getSDF_DOTAtTimeStampOptimized :593-662)
-template <int KIND, bool LDS>
+// gradient sample), shape SDF; pose lanes also form the body-frame point velocity (getSDF_DOTAtTimeStampOptimized :593-662).
+// Analytic kinds: called by the lanes that evaluate.  Mesh kind: called by ALL lanes of the workgroup, `act` says which evaluate.
+template <int KIND, bool LDS, bool WG = false>
 __device__ __forceinline__ void eval_lane(const SweptParams &P, const TrajL<LDS> &tr, const d3 p, const double te, const int pert,
-                                          const bool pose_lane, const bool own_grad, double &val, d3 &pvel, d3 &g_direct) {
+                                          const bool pose_lane, const bool own_grad, double &val, d3 &pvel, d3 &g_direct,
+                                          MeshWG *X = nullptr, const bool act = true) {
     double tl = te;
     const int pi = traj_locate_l(tr, tl);
     d3 xt, vt, at, jt;
@@ -196,8 +247,14 @@ __device__ __forceinline__ void eval_lane(const SweptParams &P, const TrajL<LDS>
         const int a = pert - 7;
         if (a == 0) pr.x += 0.01; else if (a == 1) pr.y += 0.01; else pr.z += 0.01;
     }
-    if constexpr (KIND == ISDF_SHAPE_MESH) {
-        // one hierarchy query per lane gives value AND gradient (the pose lanes keep the gradient)
+    if constexpr (WG) {
+        // one hierarchy query per evaluating lane gives value AND gradient (the pose lanes keep the gradient)
+        d3 gq = mk3(0, 0, 0);
+        double v = 1e300;
+        mesh_eval_wg(*X, P.shape.mesh, pr, act, __builtin_inf(), v, gq);
+        if (act) val = v;
+        if (act && pose_lane) g_direct = gq;
+    } else if constexpr (KIND == ISDF_SHAPE_MESH) {
         d3 gq;
         val = mesh_sdf_grad_wave(P.shape.mesh, pr, gq);          // the executing lanes walk the hierarchy together (dev_mesh.hpp)
         if (pose_lane) g_direct = gq;
@@ -213,21 +270,28 @@ __device__ __forceinline__ void eval_lane(const SweptParams &P, const TrajL<LDS>
 // other because the running minimum and the seed are carried ACROSS runs (quirk q1).  Leaves, per point, the number of
 // intervals and per interval (lb, ub, seed) in the point's task slots.  The workgroup that finishes last turns the interval
 // counts into the task list of the descent kernel (exclusive scan in point order: deterministic).
-template <int KIND, bool LDS>
-__global__ __launch_bounds__(64 * SW_WAVES) void swept_scan_kernel(const SweptParams P) {
+// (WGM: at least 4 wavefronts per SIMD - without the cap the compiler spends 450 registers, one workgroup per CU)
+template <int KIND, bool LDS, int WGM = 0>
+__global__ __launch_bounds__(64 * SW_WAVES, WGM ? 4 : 1) void swept_scan_kernel(const SweptParams P) {
+    constexpr bool MESH = WGM != 0;      // one point per WORKGROUP of WGM wavefronts (mesh_eval_wg above: larger mesh robots), else one per wavefront
+    static_assert(!WGM || KIND == ISDF_SHAPE_MESH, "workgroup-cooperative evaluation is the mesh kind's");
     extern __shared__ double s_dyn[];
     __shared__ double s_rl[SW_WAVES][SW_MAX_RANGES], s_rr[SW_WAVES][SW_MAX_RANGES];
     __shared__ unsigned long long s_wt[SW_WAVES];
     __shared__ int s_last;
+    __shared__ double s_mesh[MESH ? mesh_wg_stage(WGM) + MESH_WG_RES : 1];
+    __shared__ MeshFrames s_frames[MESH ? WGM : 1];
     const unsigned long long dbg_t0 = (ISDF_SWEEP_STATS && P.dbg) ? wall_clock64() : 0ull;
     TrajL<LDS> tr{P.T, P.coeffs, P.N};
     if constexpr (LDS) tr = traj_stage(s_dyn, P.T, P.coeffs, P.N);
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int pt = P.point_begin + blockIdx.x * SW_WAVES + wave;
+    const int pt = P.point_begin + (MESH ? (int)blockIdx.x : (int)blockIdx.x * SW_WAVES + wave);
+    const bool writer = lane == 0 && (!MESH || wave == 0);       // (the four wavefronts of a mesh workgroup hold the same results)
+    MeshWG mwg{s_mesh + wave * 64 * 3, s_mesh + (MESH ? mesh_wg_stage(WGM) : 0), 0, wave, &s_frames[MESH ? wave : 0], WGM};
     if (pt < P.point_end) {
     unsigned long long *const dbg = (ISDF_SWEEP_STATS && P.dbg) ? P.dbg + (size_t)pt * 4 : nullptr;
-    if (dbg && lane == 0) { dbg[0] = dbg_t0; dbg[1] = wall_clock64(); }
+    if (dbg && writer) { dbg[0] = dbg_t0; dbg[1] = wall_clock64(); }
     const d3 p = mk3(P.points[3 * pt], P.points[3 * pt + 1], P.points[3 * pt + 2]);
     const double D = *P.traj_duration;
     const int n_coarse = *P.n_coarse;
@@ -252,14 +316,25 @@ __global__ __launch_bounds__(64 * SW_WAVES) void swept_scan_kernel(const SweptPa
         const double *o = P.coarse_pose + kc;     // component-major table: coalesced across the lanes
         const d3 dxp = p - mk3(o[0], o[cst], o[2 * cst]);
         double dis = 1e9;
-        if (k < n_coarse && !(dot3(dxp, dxp) > far2)) {
+        const bool near = k < n_coarse && !(dot3(dxp, dxp) > far2);
+        if constexpr (MESH) {
+            if (__ballot(near)) {
+                m3 R;
+#pragma unroll
+                for (int q = 0; q < 9; q++) R.a[q] = o[(3 + q) * cst];
+                const d3 pr = mat_tmul(R, dxp);
+                // the scan only asks "dis < inf?" (and keeps dis where the answer is yes): far samples are rejected by the
+                // hierarchy's distance cutoff without a full query
+                d3 g_unused;
+                double sdf = 1e9;
+                if (mesh_eval_wg(mwg, P.shape.mesh, pr, near, inf, sdf, g_unused)) dis = sdf;
+            }
+        } else if (near) {
             m3 R;
 #pragma unroll
             for (int q = 0; q < 9; q++) R.a[q] = o[(3 + q) * cst];
             const d3 pr = mat_tmul(R, dxp);
             if constexpr (KIND == ISDF_SHAPE_MESH) {
-                // the scan only asks "dis < inf?" (and keeps dis where the answer is yes): far samples are rejected by the
-                // hierarchy's distance cutoff without a full query
                 d3 g_unused;
                 double sdf;
                 dis = mesh_sdf_grad_below_wave(P.shape.mesh, pr, inf, sdf, g_unused) ? sdf : 1e9;
@@ -288,7 +363,7 @@ __global__ __launch_bounds__(64 * SW_WAVES) void swept_scan_kernel(const SweptPa
                 const double tou_ub = fmin(D, rlane(ct, __builtin_amdgcn_readfirstlane(b)) + rough_dt);
                 if (n_ranges < SW_MAX_RANGES) {
                     if (lane == 0) { s_rl[wave][n_ranges] = tou_lb; s_rr[wave][n_ranges] = tou_ub; }
-                } else if (lane == 0) {
+                } else if (writer) {
                     atomicOr((unsigned int *)&P.stats[4], 1u);
                 }
                 n_ranges++;
@@ -297,7 +372,7 @@ __global__ __launch_bounds__(64 * SW_WAVES) void swept_scan_kernel(const SweptPa
         }
     }
     n_ranges = min(n_ranges, SW_MAX_RANGES);
-    if (dbg && lane == 0) dbg[2] = wall_clock64();
+    if (dbg && writer) dbg[2] = wall_clock64();
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -316,7 +391,8 @@ __global__ __launch_bounds__(64 * SW_WAVES) void swept_scan_kernel(const SweptPa
             if (!__ballot(act)) break;          // nothing (left) to scan in this interval
             double val = 1e300;
             d3 pv_unused = mk3(0, 0, 0), g_unused = pv_unused;
-            if (act) eval_lane<KIND, LDS>(P, tr, p, te, 0, false, false, val, pv_unused, g_unused);
+            if constexpr (MESH) eval_lane<KIND, LDS, true>(P, tr, p, act ? te : lb, 0, false, false, val, pv_unused, g_unused, &mwg, act);
+            else if (act) eval_lane<KIND, LDS>(P, tr, p, te, 0, false, false, val, pv_unused, g_unused);
             n_pass++;
             const int nv = __popcll(__ballot(act));                  // valid lanes form a prefix (t is increasing)
             int arg;
@@ -325,9 +401,9 @@ __global__ __launch_bounds__(64 * SW_WAVES) void swept_scan_kernel(const SweptPa
             if (nv < 64) break;
             t_base = rlane(te, 63) + dt;
         }
-        if (lane == 0) { double *o = slots + (size_t)r * TASK_STRIDE; o[0] = lb; o[1] = ub; o[2] = range_time_seed; }
+        if (writer) { double *o = slots + (size_t)r * TASK_STRIDE; o[0] = lb; o[1] = ub; o[2] = range_time_seed; }
     }
-    if (lane == 0) {
+    if (writer) {
         P.point_nr[pt] = n_ranges | (n_pass << 8);
         if (dbg) dbg[3] = (wall_clock64() << 16) | (unsigned long long)(n_pass & 0xFFF) | ((unsigned long long)(n_ranges & 0xF) << 12);
     }
@@ -414,16 +490,21 @@ __global__ __launch_bounds__(64 * SW_WAVES) void swept_scan_kernel(const SweptPa
 constexpr int GD_SPEC = 5;                       // look-ahead blocks
 __device__ __forceinline__ int gd_block_base(int m) { return m == 0 ? 18 : 25 + 7 * (m - 1); }
 
-template <int KIND, bool LDS>
-__global__ __launch_bounds__(64 * SW_WAVES) void swept_descent_kernel(const SweptParams P) {
+template <int KIND, bool LDS, int WGM = 0>
+__global__ __launch_bounds__(64 * SW_WAVES, WGM ? 4 : 1) void swept_descent_kernel(const SweptParams P) {
+    constexpr bool MESH = WGM != 0;      // one task per WORKGROUP of WGM wavefronts (mesh_eval_wg), else one per wavefront
     extern __shared__ double s_dyn[];
+    __shared__ double s_mesh[MESH ? mesh_wg_stage(WGM) + MESH_WG_RES : 1];
+    __shared__ MeshFrames s_frames[MESH ? WGM : 1];
     TrajL<LDS> tr{P.T, P.coeffs, P.N};
     if constexpr (LDS) tr = traj_stage(s_dyn, P.T, P.coeffs, P.N);
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const bool writer = lane == 0 && (!MESH || wave == 0);
+    MeshWG mwg{s_mesh + wave * 64 * 3, s_mesh + (MESH ? mesh_wg_stage(WGM) : 0), 0, wave, &s_frames[MESH ? wave : 0], WGM};
     const unsigned n_tasks = (unsigned)__builtin_amdgcn_readfirstlane((int)P.words[0]), n_front = (unsigned)__builtin_amdgcn_readfirstlane((int)P.words[2]);
     const unsigned cap = (unsigned)(P.point_end - P.point_begin) * SW_MAX_RANGES;
-    const unsigned n_waves = (unsigned)__builtin_amdgcn_readfirstlane((int)(gridDim.x * SW_WAVES));
+    const unsigned n_waves = (unsigned)__builtin_amdgcn_readfirstlane((int)(MESH ? gridDim.x : gridDim.x * SW_WAVES));
     const double D = *P.traj_duration;
     const int gmode = P.shape.grad_mode;
     const bool fd_central = (KIND != ISDF_SHAPE_MESH) && gmode == ISDF_GRAD_CENTRAL;
@@ -432,7 +513,7 @@ __global__ __launch_bounds__(64 * SW_WAVES) void swept_descent_kernel(const Swep
     // this lane's role in a pass: block (0..6) and offset inside it (0 = the pose lane)
     const int gd_blk = lane < 18 ? -1 : (lane < 25 ? 0 : (lane < 60 ? (lane - 25) / 7 + 1 : (lane == 60 ? GD_SPEC + 1 : -1)));
     const int gd_off = lane < 18 ? 0 : (lane < 25 ? lane - 18 : (lane < 60 ? (lane - 25) % 7 : 0));
-    for (unsigned task = blockIdx.x * SW_WAVES + wave, rounds = 0; task < n_tasks && rounds < (1u << 16); task += n_waves, rounds++) {
+    for (unsigned task = MESH ? blockIdx.x : blockIdx.x * SW_WAVES + wave, rounds = 0; task < n_tasks && rounds < (1u << 16); task += n_waves, rounds++) {
         const unsigned tm = (unsigned)__builtin_amdgcn_readfirstlane((int)(task < n_front ? P.task_map[task] : P.task_map[cap - 1u - (task - n_front)]));
         const unsigned long long dbg_t0 = (ISDF_SWEEP_STATS && P.dbg) ? wall_clock64() : 0ull;
         const int rel = (int)(tm >> 5), r = (int)(tm & 31u);
@@ -471,7 +552,8 @@ __global__ __launch_bounds__(64 * SW_WAVES) void swept_descent_kernel(const Swep
             }
             double val = 1e300;
             d3 pvel = mk3(0, 0, 0), g_direct = mk3(0, 0, 0);
-            if (act) eval_lane<KIND, LDS>(P, tr, p, te, pert, pose_lane, own_grad, val, pvel, g_direct);
+            if constexpr (MESH) eval_lane<KIND, LDS, true>(P, tr, p, act ? te : x, pert, pose_lane, own_grad, val, pvel, g_direct, &mwg, act);
+            else if (act) eval_lane<KIND, LDS>(P, tr, p, te, pert, pose_lane, own_grad, val, pvel, g_direct);
             n_pass++;
             // Shape gradient (getonlyGrad1) and dSDF/dt = grad . (body-frame point velocity) of EVERY block at once: the pose lane
             // of a block pulls the six samples to its right across the wavefront (wave_shl DPP: no LDS), forms the gradient with
@@ -550,7 +632,7 @@ __global__ __launch_bounds__(64 * SW_WAVES) void swept_descent_kernel(const Swep
         const int gl = g_src >= 0 ? g_src : 18;
         const d3 g1_at_x = mk3(rlane(g_keep.x, gl), rlane(g_keep.y, gl), rlane(g_keep.z, gl));
         // interval result: (t_r, sdf_r, gradient at t_r) - the best interval is picked in order by the back-prop kernel (:739-744)
-        if (lane == 0) {
+        if (writer) {
             slot[0] = x; slot[1] = fx; slot[2] = g1_at_x.x; slot[3] = g1_at_x.y; slot[4] = g1_at_x.z;
             slot[5] = __longlong_as_double((long long)(((unsigned long long)n_pass & 0xFFFFull) | ((unsigned long long)iter << 16)));
             if (n_pass >= LPT_TASK) atomicOr(&P.point_lmask[pt], 1u << r);      // next step: dispatch this interval's descent early
@@ -796,7 +878,9 @@ void launch_swept_prepare(const SweptParams &P, hipStream_t stream) {
 void launch_swept_sweep(const SweptParams &P, hipStream_t stream, hipEvent_t ev_start, hipEvent_t ev_stop) {
     const int n = P.point_end - P.point_begin;
     if (n <= 0) return;
-    const dim3 grid((n + SW_WAVES - 1) / SW_WAVES), block(64 * SW_WAVES);
+    // (larger mesh robots: one point / task per workgroup)
+    const bool mesh_wg = P.shape.kind == ISDF_SHAPE_MESH && P.shape.mesh_wg;
+    const dim3 grid(mesh_wg ? n : (n + SW_WAVES - 1) / SW_WAVES), block(64 * SW_WAVES);
     const size_t lds = traj_lds_bytes(P.N);
     const bool in_lds = lds <= TRAJ_LDS_MAX;
     // scan, then descent (one wavefront per task while there are no more tasks than points, which is the rule); the start
@@ -805,6 +889,15 @@ void launch_swept_sweep(const SweptParams &P, hipStream_t stream, hipEvent_t ev_
                                                  hipExtLaunchKernelGGL((swept_descent_kernel<K, true>), grid, block, lds, stream, nullptr, ev_stop, 0, P); } \
                                    else { hipExtLaunchKernelGGL((swept_scan_kernel<K, false>), grid, block, 0, stream, ev_start, nullptr, 0, P); \
                                           hipExtLaunchKernelGGL((swept_descent_kernel<K, false>), grid, block, 0, stream, nullptr, ev_stop, 0, P); } break;
+    if (mesh_wg) {
+        // scan: 4 wavefronts per point (a fine pass has up to 64 queries); descent: 2 per task (25 queries per pass = 16 + 9)
+        const dim3 block2(128);
+        if (in_lds) { hipExtLaunchKernelGGL((swept_scan_kernel<ISDF_SHAPE_MESH, true, 4>), grid, block, lds, stream, ev_start, nullptr, 0, P);
+                      hipExtLaunchKernelGGL((swept_descent_kernel<ISDF_SHAPE_MESH, true, 2>), grid, block2, lds, stream, nullptr, ev_stop, 0, P); }
+        else { hipExtLaunchKernelGGL((swept_scan_kernel<ISDF_SHAPE_MESH, false, 4>), grid, block, 0, stream, ev_start, nullptr, 0, P);
+               hipExtLaunchKernelGGL((swept_descent_kernel<ISDF_SHAPE_MESH, false, 2>), grid, block2, 0, stream, nullptr, ev_stop, 0, P); }
+        return;
+    }
     switch (P.shape.kind) {
     // one instantiation per shape class (each inlines exactly one SDF formula; the run-time switch of the generic kernel costs
     // 272 VGPRs = one wave per SIMD)

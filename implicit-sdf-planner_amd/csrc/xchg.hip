@@ -25,6 +25,7 @@ struct XchgParams {
                                                       // [2 parities][world] VERDICT words (seq << 1 | "my wait timed out")
     unsigned *status;                     // device word: != 0 after a time-out
     unsigned long long *pushes;           // device counter of completed pushes (world - 1 per exchange), local to this rank
+    unsigned long long *decision;         // device word (seq << 1 | bad): block 0's verdict for exchange seq, read by this rank's other blocks
 };
 
 // grid: one block per PEER pushes (blockIdx.x < world - 1), then every block takes part in the wait + rank-order sum
@@ -44,11 +45,13 @@ __global__ __launch_bounds__(1024) void xchg_allreduce_kernel(XchgParams X, doub
         }
         __syncthreads();
     }
-    // ---- wait (bounded): lane r of the first wavefront polls peer r's flag in MY mailbox, lane `world` this rank's own push
-    // counter (the sum below overwrites buf: every push of THIS rank, possibly by another block, must have read it first) -
-    // all at once, one round trip instead of one per peer
+    // ---- wait (bounded) + verdict round: BLOCK 0 decides for the whole rank.  Lane r of its first wavefront polls peer r's flag
+    // in MY mailbox, lane `world` this rank's own push counter (the sum below overwrites buf: every push of THIS rank, possibly
+    // by another block, must have read it first) - all at once, one round trip instead of one per peer.  The other blocks have
+    // no timer of their own: they wait for block 0's published decision (a per-block time-out could let ONE block give up
+    // while block 0 - the only writer of the NaN cost - did not: a finite cost over a gradient slice that was never summed).
     __shared__ int s_ok;
-    if (threadIdx.x < 64) {
+    if (blockIdx.x == 0 && threadIdx.x < 64) {
         const int lane = threadIdx.x;
         bool ok = true;
         if (lane < X.world && lane != X.rank) {
@@ -70,14 +73,12 @@ __global__ __launch_bounds__(1024) void xchg_allreduce_kernel(XchgParams X, doub
         // ---- verdict round: a time-out is one-sided by nature (THIS mailbox was late; the late peer itself may have received
         // everything), and ranks that disagree about a step would walk different optimizer paths.  So every rank tells every
         // peer what its wait saw - one more 8-byte store per peer and one more poll, inside this kernel, instead of a host-side
-        // collective after every step - and the exchange counts as good only if EVERY rank's wait was.  Block 0 speaks for the
-        // rank (own word included, for this rank's other blocks); a verdict that does not arrive in time is a bad one.
+        // collective after every step - and the exchange counts as good only if EVERY rank's wait was.  A verdict that does
+        // not arrive in time is a bad one.
         unsigned long long *const verdict_own = X.peer_flags[X.rank] + (size_t)(2 + par) * X.world;
-        if (blockIdx.x == 0 && lane < X.world) {
+        if (lane < X.world) {
             const unsigned long long word = (X.seq << 1) | (all_ok ? 0ull : 1ull);
             __hip_atomic_store(X.peer_flags[lane] + (size_t)(2 + par) * X.world + X.rank, word, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-        }
-        if (lane < X.world) {
             long long spins = 0;
             unsigned long long v;
             while (((v = __hip_atomic_load(verdict_own + lane, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM)) >> 1) != X.seq) {
@@ -90,7 +91,13 @@ __global__ __launch_bounds__(1024) void xchg_allreduce_kernel(XchgParams X, doub
         if (lane == 0) {
             if (!all_ok) atomicExch(X.status, 1u);
             s_ok = all_ok ? 1 : 0;
+            // the rank's ONE decision for exchange seq, for its other blocks (release: they read the mailbox after it)
+            __hip_atomic_store(X.decision, (X.seq << 1) | (all_ok ? 0ull : 1ull), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
         }
+    } else if (blockIdx.x != 0 && threadIdx.x == 0) {
+        unsigned long long v;
+        while (((v = __hip_atomic_load(X.decision, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT)) >> 1) != X.seq) __builtin_amdgcn_s_sleep(1);   // bounded by block 0's bounded waits
+        s_ok = (v & 1ull) == 0ull ? 1 : 0;
     }
     __syncthreads();
     if (!s_ok) {
@@ -123,7 +130,7 @@ struct isdf_xchg {
     unsigned long long fuse_seq = 0;
     void *peer_base[XCHG_MAX_WORLD] = {nullptr};
     bool opened[XCHG_MAX_WORLD] = {false};
-    unsigned *d_status = nullptr;               // [status word | pad | 64-bit push counter]
+    unsigned *d_status = nullptr;               // [status word | pad | 64-bit push counter | 64-bit decision word]
     unsigned long long seq = 0;
     bool connected = false;
 };
@@ -161,8 +168,8 @@ extern "C" int isdf_xchg_create(isdf_ctx *c, int rank, int world, size_t max_dou
     if (hipExtMallocWithFlags(&x->own, x->own_bytes, hipDeviceMallocUncached) != hipSuccess) { xchg_free(c); return isdf_fail(c, ISDF_ERR_HIP, "uncached mailbox allocation failed"); }
     HIPCHK(c, hipMemset(x->own, 0, x->own_bytes));
     HIPCHK(c, hipMemset((char *)x->own + x->board_offset, 0xFF, x->board_doubles * sizeof(double)));    // every slot empty
-    HIPCHK(c, hipMalloc(&x->d_status, 16));
-    HIPCHK(c, hipMemset(x->d_status, 0, 16));
+    HIPCHK(c, hipMalloc(&x->d_status, 32));
+    HIPCHK(c, hipMemset(x->d_status, 0, 32));
     HIPCHK(c, hipDeviceSynchronize());
     hipIpcMemHandle_t h;
     if (hipIpcGetMemHandle(&h, x->own) != hipSuccess) { xchg_free(c); return isdf_fail(c, ISDF_ERR_HIP, "hipIpcGetMemHandle failed"); }
@@ -196,7 +203,7 @@ extern "C" int isdf_xchg_allreduce(isdf_ctx *c, double *d_buf, size_t count, voi
     if (!x || !x->connected) return isdf_fail(c, ISDF_ERR_STATE, "exchange not connected");
     if (count > x->slot_doubles) return isdf_fail(c, ISDF_ERR_INVALID_ARG, "vector longer than the exchange was created for");
     XchgParams X{};
-    X.rank = x->rank; X.world = x->world; X.slot_doubles = x->slot_doubles; X.seq = ++x->seq; X.status = x->d_status; X.pushes = (unsigned long long *)((char *)x->d_status + 8);
+    X.rank = x->rank; X.world = x->world; X.slot_doubles = x->slot_doubles; X.seq = ++x->seq; X.status = x->d_status; X.pushes = (unsigned long long *)((char *)x->d_status + 8); X.decision = (unsigned long long *)((char *)x->d_status + 16);
     for (int r = 0; r < x->world; r++) {
         X.peer_slots[r] = (double *)x->peer_base[r];
         X.peer_flags[r] = (unsigned long long *)((char *)x->peer_base[r] + x->flags_offset);

@@ -35,15 +35,24 @@ def main():
         res["commit"] = subprocess.check_output(["git", "-C", ROOT, "rev-parse", "--short", "HEAD"], text=True).strip()
     except Exception:
         res["commit"] = None
-    for db in dbs:
+    seen = {}                # counter -> index of the pass it was first collected in (a counter repeated in a later pass is kept apart)
+    for di, db in enumerate(dbs):
         if not db or not os.path.exists(db):
             continue
         c = sqlite3.connect(db).cursor()
         for k, ctr, n, a in c.execute("select kernel_name, counter_name, count(*), avg(value) from counters_collection group by kernel_name, counter_name"):
             if k in names:
-                res["counters"][ctr] = res["counters"].get(ctr, 0.0) + a
-                res["per_kernel_counters"].setdefault(k[:80], {})[ctr] = a
-                res["n_dispatches"][ctr] = n
+                key = ctr if seen.setdefault(ctr, di) == di else f"{ctr}@pass{di}"
+                res["counters"][key] = res["counters"].get(key, 0.0) + a
+                res["per_kernel_counters"].setdefault(k[:80], {})[key] = a
+                res["n_dispatches"][key] = n
+    # lane utilisation of the VALU instructions: both counters from the SAME pass (the last one that holds SQ_THREAD_CYCLES_VALU)
+    tc = res["counters"].get("SQ_THREAD_CYCLES_VALU")
+    if tc:
+        di = seen["SQ_THREAD_CYCLES_VALU"]
+        act = res["counters"].get("SQ_ACTIVE_INST_VALU" if seen.get("SQ_ACTIVE_INST_VALU") == di else f"SQ_ACTIVE_INST_VALU@pass{di}")
+        if act:
+            res["lane_utilisation_valu"] = tc / (64.0 * act)
     with open(out, "w") as f:
         json.dump(res, f, indent=1)
     print(json.dumps(res, indent=1))

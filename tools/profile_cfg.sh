@@ -26,5 +26,9 @@ timeout 600 rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU 
 python $REPO/tools/pmc_sq.py "$(finddb /tmp/pc_a)" $OUT/${TAG}_${CFG}_pmc_sq.txt "$CMD" > /dev/null 2>&1
 timeout 600 rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU_ADD_F64 SQ_INSTS_VALU_MUL_F64 SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VALU_TRANS_F64 SQ_INSTS_LDS SQ_INSTS_SMEM SQ_INSTS_VMEM SQ_BUSY_CYCLES -d /tmp/pc_b -- $CMD > /dev/null 2>&1
 python $REPO/tools/pmc_sq.py "$(finddb /tmp/pc_b)" $OUT/${TAG}_${CFG}_pmc_sq2.txt "$CMD" > /dev/null 2>&1
-python $REPO/tools/pmc_collect.py $OUT/${TAG}_pmc_counters_${CFG}.json "$(finddb /tmp/pc_kt)" "$(finddb /tmp/pc_a)" "$(finddb /tmp/pc_b)" > $OUT/${TAG}_${CFG}_pmc_collect.log 2>&1
+# lane utilisation of the VALU instructions = SQ_THREAD_CYCLES_VALU / (64 x SQ_ACTIVE_INST_VALU) (both from the SAME pass)
+rm -rf /tmp/pc_c
+timeout 600 rocprofv3 --kernel-trace --pmc SQ_THREAD_CYCLES_VALU SQ_ACTIVE_INST_VALU -d /tmp/pc_c -- $CMD > /dev/null 2>&1
+python $REPO/tools/pmc_sq.py "$(finddb /tmp/pc_c)" $OUT/${TAG}_${CFG}_pmc_sq3.txt "$CMD" > /dev/null 2>&1
+python $REPO/tools/pmc_collect.py $OUT/${TAG}_pmc_counters_${CFG}.json "$(finddb /tmp/pc_kt)" "$(finddb /tmp/pc_a)" "$(finddb /tmp/pc_b)" "$(finddb /tmp/pc_c)" > $OUT/${TAG}_${CFG}_pmc_collect.log 2>&1
 cat $OUT/${TAG}_${CFG}_kernel_stats.txt | head -12
