@@ -228,6 +228,15 @@ int isdf_gather_points(isdf_ctx *ctx, const double *waypoints, int n_waypoints, 
 /* Copies up to `capacity` points (M x 3 row-major) and returns M (>= 0), or a negative isdf_status. */
 int isdf_get_points(isdf_ctx *ctx, double *xyz_out, int capacity);
 
+/* The environment ESDF sampled at n WORLD points (xyz: n x 3 row-major): value_out[i] = GridMap3D::getSDFValue(pos)
+ * (src/map_manager/include/map_manager/GridMap3D.h:114-146), grad_out[i] (n x 3) the analytic gradient of the trilinear interpolant
+ * as getSDFValueWithGrad returns it (:155-193) - including the reference's quirks: base cell of pos - res/2, a position outside
+ * the map reads cell (0,0,0) (Gridmap3D.cpp:137-140), an invalid corner reads 0 (:535-542).  Needs an ESDF grid (isdf_set_grid
+ * with ISDF_GRID_ESDF, or isdf_generate_esdf).  Either output may be NULL.  Bit for bit the reference's doubles on the float32
+ * grid.  The _device form takes device pointers and a stream (asynchronous). */
+int isdf_esdf_sample(isdf_ctx *ctx, const double *xyz, long long n, double *value_out, double *grad_out);
+int isdf_esdf_sample_device(isdf_ctx *ctx, const double *d_xyz, long long n, double *d_value_out, double *d_grad_out, void *stream);
+
 /* The installed robot shape by itself, on n BODY-FRAME points (p_rel: n x 3 row-major): sdf_out[i] =
  * BasicShape::getonlySDF(pos_rel) and grad_out[i] (n x 3) = getonlyGrad1(pos_rel) (Shape.hpp:32-57: central difference
  * dx = 5e-6, normalised; Box :2363-2377; Ball :622-625; mesh Generalshape Shape.cpp:105-139: (1 - 2 w) * distance with
