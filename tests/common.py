@@ -83,11 +83,15 @@ def oracle_cost_function(orc, sweeps, head, tail, rho, x, N):
 # the reference's measured self-spread.  Since round 3 the device computes w BIT FOR BIT like the reference's library (glibc's
 # atan2f restated, reciprocal-multiply normalisation, the tree-shaped float sum of the HDK traversal: csrc/dev_mesh.hpp), so the
 # free-running tests hold the device to the plain tolerance again: t* identical, gradients at the north-star's 1e-5.
+SPREAD_LINES = []       # printed by conftest.py's pytest_terminal_summary: the measured deviations end up in the pytest log itself
+
+
 def _spread_log(line):
     import os
     print("\n[mesh x V1] " + line)
+    SPREAD_LINES.append(line)
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    path = os.environ.get("ISDF_MESH_SPREAD_LOG", os.path.join(root, "gpurun_out", "r3_mesh_spread.txt"))
+    path = os.environ.get("ISDF_MESH_SPREAD_LOG", os.path.join(root, "gpurun_out", "r4_mesh_spread.txt"))
     try:
         os.makedirs(os.path.dirname(path), exist_ok=True)
         with open(path, "a") as f:
@@ -98,7 +102,7 @@ def _spread_log(line):
 
 def assert_mesh_v1_free_running(what, tg, to, gT, gT0, gC, gC0):
     """Device (tg, gT, gC) vs oracle (to, gT0, gC0), both searching for their own minimisers: the measured deviations are logged
-    (gpurun_out/r3_mesh_spread.txt -> profiles/), then held to: every t* within 1e-9 s, gradients at REL_TOL."""
+    (the pytest log's "mesh x V1" summary section; gpurun_out/r4_mesh_spread.txt -> profiles/), then held to: every t* within 1e-9 s, gradients at REL_TOL."""
     dt = np.abs(np.asarray(tg) - np.asarray(to))
     moved = float((dt > 1e-9).mean())
     eC = float(np.linalg.norm(gC - gC0) / max(np.linalg.norm(gC0), 1e-300)); eT = float(np.linalg.norm(gT - gT0) / max(np.linalg.norm(gT0), 1e-300))

@@ -12,6 +12,19 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+def pytest_terminal_summary(terminalreporter):
+    """The measured device-vs-oracle deviations of the mesh x V1 tests (tests/common.py::_spread_log), in the pytest log itself."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    try:
+        import common
+    except Exception:       # noqa: BLE001
+        return
+    if common.SPREAD_LINES:
+        terminalreporter.write_sep("-", "mesh x V1: measured deviations (device vs oracle)")
+        for l in common.SPREAD_LINES:
+            terminalreporter.write_line(l)
+
+
 @pytest.fixture(scope="session", autouse=True)
 def _torch_first():
     """PyTorch bundles its own HIP runtime; when the product library (linked against /opt/rocm's) initialises the device

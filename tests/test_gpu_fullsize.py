@@ -46,6 +46,39 @@ def test_c2_full_size_vs_oracle(pkg, orc, product_lib, world256):
         assert st["units"] == 2600 == st0[0] and st["grad_pairs"] == st0[3]
 
 
+def test_v3_on_a_512_cubed_map(pkg, orc, product_lib):
+    """The tile sweep on the 512^3 map of configs[4] (0.1 m voxels: 8x the voxels of C2, three 16 MiB qualifier bit-grids, the
+    ESDF built on the device): one 40-piece trajectory vs the oracle, then a batch of 16 == each one alone, bitwise - the bench's
+    two 512^3 entries carry no other parity evidence."""
+    capi, synth = pkg.capi, pkg.synth
+    res5 = 0.1
+    occ5 = synth.random_box_map((512,) * 3, res=res5, occupancy=0.15, seed=12345, edge=(0.4, 2.0))
+    cfg5 = synth.default_config(capi.V3_ESDF_TILE, kernel_size=21, integral_intervs=64, safety_hor=(3 ** 0.5 / 2) * res5,
+                                weight_p=4000.0, smoothing_eps=0.01, enable_dyn=1, enable_pos=1)
+    shape5 = synth.make_shape("Box", params=(0.8, 0.15, 0.15), grad_mode=capi.GRAD_CENTRAL, bound_radius=0.83, bbox=((0, 0, 0), (0.8, 0.15, 0.15)))
+    eng = pkg.Engine(cfg5)
+    eng.set_grid(occ5, (0, 0, 0), res5, capi.GRID_OCCUPANCY)
+    eng.generate_esdf()
+    eng.set_shape(shape5)
+    esdf5, _, _ = eng.get_grid(capi.GRID_ESDF)
+    ext5 = np.array(occ5.shape) * res5
+    Ts, Cs = [], []
+    for b in range(16):
+        Tb, Cf = synth.random_trajectory(ext5, 40, seed=900 + b, piece_T=1.0, jitter=0.5, margin=4.0, occ=occ5, res=res5)
+        Ts.append(Tb); Cs.append(synth.colmajor(Cf))
+    o = orc.Oracle(cfg5, threads=30)
+    o.set_grid(esdf5, (0, 0, 0), res5, capi.GRID_ESDF); o.set_shape(shape5)
+    c, gT, gC = eng.eval_single(Ts[0], Cs[0])
+    c0, gT0, gC0, st0 = o.eval(Ts[0], Cs[0])
+    assert c0 > 0 and st0[3] > 0 and abs(c - c0) <= REL_TOL * abs(c0)
+    assert_close(gT, gT0, "512^3 V3 gradT"); assert_close(gC, gC0, "512^3 V3 gradC")
+    assert eng.stats()["grad_pairs"] == st0[3]
+    cost, gTs, gCs = eng.eval(Ts, Cs)
+    for b in (0, 7, 15):
+        c1, gT1, gC1 = eng.eval_single(Ts[b], Cs[b])
+        assert c1 == cost[b] and np.array_equal(gT1, gTs[b]) and np.array_equal(gC1, gCs[b])
+
+
 def test_c3_batch_is_independent(pkg, orc, product_lib, world256):
     """configs[2]: 128 trajectories evaluated concurrently == each one evaluated alone, bitwise; spot checks vs the oracle."""
     capi, synth = pkg.capi, pkg.synth

@@ -108,6 +108,44 @@ def test_mesh_v1_arithmetic_at_the_reference_minimisers(pkg, orc, product_lib, n
     assert_close(gT, gT0, f"{name} gradT at the reference's t*")
 
 
+@pytest.mark.parametrize("stem", ["Trefoil", "Lthick"])
+def test_reference_meshes_through_the_mesh_kind(pkg, orc, product_lib, stem):
+    """"C5 mesh Lthick.obj (concave, 20 tris) and Trefoil.obj (12 k tris) scaled to the same bound, through the FWN
+    path" - the reference's own files (tests/golden/ref_meshes.npz; isdf_read_obj's view of src/plan_manager/shapes/*.obj), as
+    Generalshape would load them (sw_manager.hpp:255-275 falls through to the mesh class for a stem the registry does not
+    know; Shape.cpp:27-151): shape plugin, then the swept-volume sweep with both sides searching their own minimisers."""
+    capi, synth = pkg.capi, pkg.synth
+    V, F = synth.reference_mesh(stem, bound_radius=1.66)
+    assert len(F) == {"Trefoil": 12000, "Lthick": 20}[stem]
+    shape = synth.make_mesh_shape(V, F)
+    cfg = synth.default_config()
+    eng = pkg.Engine(cfg); o = orc.Oracle(cfg, threads=30)
+    eng.set_shape(shape); o.set_shape(shape)
+    _need_hdk(o)
+    rng = np.random.default_rng(5)
+    Q = _queries(V, rng, 600 if stem == "Trefoil" else 1500)
+    s, g = eng.shape_eval(Q)
+    s0, g0 = o.shape_eval(Q)
+    assert np.all(np.abs(s - s0) <= 1e-13 * np.abs(s0) + 1e-14), (stem, np.abs(s - s0).max())
+    assert (np.linalg.norm(g - g0, axis=1) <= 1e-6).mean() > 0.995
+    # V1 sweep
+    occ, esdf, res = small_world(pkg, seed=14)
+    T, cm = traj(pkg, occ, res, N=4, seed=23, piece_T=1.0)
+    way = cm.reshape(3, -1).T.reshape(4, 6, 3)[1:, 0, :]
+    pts = synth.constraint_points(occ, (0, 0, 0), res, way, half=2.5)
+    if stem == "Trefoil":
+        pts = np.ascontiguousarray(pts[::4])               # (the oracle's exhaustive closest-point search over 12 000 faces)
+    cfg1 = synth.default_config(capi.V1_SWEPT, safety_hor=0.5)
+    eng1, o1 = make_pair(pkg, orc, cfg1, shape, occ=occ, res=res, points=pts, threads=30)
+    tg = -np.ones(len(pts)); to = -np.ones(len(pts))
+    c, gT, gC = eng1.eval_single(T, cm, tstar=tg)
+    c0, gT0, gC0, _ = o1.eval(T, cm, tstar=to)
+    assert c0 > 0 and (to >= 0).sum() > 20
+    assert abs(c - c0) <= REL_TOL * abs(c0), (c, c0)
+    from common import assert_mesh_v1_free_running
+    assert_mesh_v1_free_running(f"{stem}.obj V1", tg, to, gT, gT0, gC, gC0)
+
+
 def test_mesh_with_degenerate_and_duplicate_triangles(pkg, orc, product_lib):
     """Zero-area triangles, duplicated triangles and an open surface: the winding-number hierarchy (zero-area items get zero
     coefficients, HDK :6700) and the closest-point walk must still agree with the reference library / the exact search."""

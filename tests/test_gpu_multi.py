@@ -20,6 +20,18 @@ def stub(pkg, product_lib, tmp_path_factory):
     return build_stub(pkg, tmp_path_factory.mktemp("stub_multi"))
 
 
+def _n_gpus():
+    import torch
+    return torch.cuda.device_count()
+
+
+def _devs(n):
+    """n device ordinals: DISTINCT GPUs wherever the node has them (on an 8-GPU node these tests run real peer copies / peer reads
+    over xGMI), the test GPU listed repeatedly otherwise."""
+    k = max(1, _n_gpus())
+    return [i % k for i in range(n)]
+
+
 def _mk(pkg, cfg, devices, shape, esdf=None, occ=None, res=0.5, points=None):
     capi = pkg.capi
     eng = pkg.Engine(cfg, devices=devices)
@@ -48,7 +60,7 @@ def test_multi_integral_sweep_through_the_binding(pkg, orc, stub, monkeypatch, n
     single, o = make_pair(pkg, orc, cfg, shape, esdf=esdf, res=res, threads=4)
     c1, gT1, gC1 = single.eval_single(T, cm)
     c0, gT0, gC0, st0 = o.eval(T, cm)
-    multi = _mk(pkg, cfg, [0] * n_dev, shape, esdf=esdf, res=res)
+    multi = _mk(pkg, cfg, _devs(n_dev), shape, esdf=esdf, res=res)
     nd, mode = multi.multi_info()
     assert nd == n_dev and mode == (capi.MULTI_PEER_SUM if collective == "peer" else capi.MULTI_STAGED)
     rng = np.random.default_rng(4)
@@ -82,7 +94,7 @@ def test_multi_swept_sweep_through_the_binding(pkg, orc, stub, n_dev):
     shape = synth.make_shape("RoundedCone", params=(1.5, 0.6, 4.5), poly_params=(0.1, -0.05, 0.08, 20, -10, 40))
     single, o = make_pair(pkg, orc, cfg, shape, points=pts, threads=4)
     ts1 = np.zeros(len(pts)); c1, gT1, gC1 = single.eval_single(T, cm, tstar=ts1)
-    multi = _mk(pkg, cfg, [0] * n_dev, shape, points=pts)
+    multi = _mk(pkg, cfg, _devs(n_dev), shape, points=pts)
     ts = np.full(len(pts), -7.0)                           # every entry has to be overwritten or kept per the reference's rule
     ts_single = np.full(len(pts), -7.0); single.eval_single(T, cm, tstar=ts_single)
     c, gT, gC = _call(stub, multi, 1, T, cm, 0.25, np.zeros(N), np.zeros(18 * N), tstar=ts)
@@ -165,3 +177,59 @@ def test_multi_rccl_collective_world_of_one(pkg, orc, product_lib, monkeypatch):
     monkeypatch.setenv("ISDF_MULTI_COLLECTIVE", "rccl")
     with pytest.raises(pkg.engine.IsdfError):
         _mk(pkg, cfg, [0, 0], shape, esdf=esdf, res=res)
+
+
+def test_multi_refuses_the_fixed_minimiser_entry_points(pkg, orc, product_lib):
+    """isdf_eval_swept_at_tstar[_host] on a multi-device ctx would return the lead's shard only: ISDF_ERR_UNSUPPORTED, as the header says."""
+    import torch
+    capi, synth = pkg.capi, pkg.synth
+    occ, esdf, res = small_world(pkg, seed=3)
+    N = 6
+    T, cm = traj(pkg, occ, res, N=N, seed=43)
+    way = cm.reshape(3, -1).T.reshape(N, 6, 3)[1:, 0, :]
+    pts = synth.constraint_points(occ, (0, 0, 0), res, way, half=3.0)
+    cfg = synth.default_config(capi.V1_SWEPT, safety_hor=0.5)
+    shape = synth.make_shape("RoundedCone", params=(1.5, 0.6, 4.5))
+    multi = _mk(pkg, cfg, _devs(2), shape, points=pts)
+    with pytest.raises(pkg.engine.IsdfError) as ei:
+        multi.eval_swept_at_tstar_host(T, cm, np.zeros(len(pts)))
+    assert ei.value.code == capi.ISDF_ERR_UNSUPPORTED
+    dT = torch.from_numpy(T).cuda(); dC = torch.from_numpy(cm).cuda(); dts = torch.zeros(len(pts), dtype=torch.float64, device="cuda")
+    dO = torch.zeros(multi.out_stride(N), dtype=torch.float64, device="cuda")
+    with pytest.raises(pkg.engine.IsdfError) as ei:
+        multi.eval_swept_at_tstar(N, dT.data_ptr(), dC.data_ptr(), dO.data_ptr(), dts.data_ptr(), 0)
+    assert ei.value.code == capi.ISDF_ERR_UNSUPPORTED
+    # the sweep itself still works on that ctx
+    c, gT, gC = multi.eval_single(T, cm)
+    assert np.isfinite(c)
+
+
+@pytest.mark.parametrize("collective", ["rccl", "staged", "peer"])
+def test_multi_on_distinct_gpus(pkg, orc, product_lib, monkeypatch, collective):
+    """Upgrades itself on a node with >= 2 GPUs (the driver's 8-GPU box): every listed device is a DIFFERENT GPU - real
+    hipMemcpyPeerAsync of the inputs, the lead reading the peers' parts over xGMI / staged copies / ONE grouped ncclAllReduce with
+    more than one rank - against the single-device ctx, bitwise in the rank-ordered modes."""
+    n = _n_gpus()
+    if n < 2:
+        pytest.skip("one GPU on this box: the same code runs with the device listed repeatedly (tests above)")
+    capi, synth = pkg.capi, pkg.synth
+    monkeypatch.setenv("ISDF_MULTI_COLLECTIVE", collective)
+    occ, esdf, res = small_world(pkg, seed=5)
+    N = 16
+    T, cm = traj(pkg, occ, res, N=N, seed=61)
+    cfg = synth.default_config(capi.V3_ESDF_TILE, kernel_size=9, integral_intervs=16, safety_hor=0.5)
+    shape = synth.make_shape("RoundedCone", params=(0.8, 0.3, 1.6))
+    try:
+        multi = _mk(pkg, cfg, list(range(min(n, 8))), shape, esdf=esdf, res=res)
+    except pkg.engine.IsdfError as e:
+        if e.code == capi.ISDF_ERR_UNSUPPORTED:
+            pytest.skip(f"{collective} not usable between these devices: {e}")
+        raise
+    monkeypatch.delenv("ISDF_MULTI_COLLECTIVE")
+    single = _mk(pkg, cfg, None, shape, esdf=esdf, res=res)
+    b = single.eval_single(T, cm)
+    for _ in range(4):
+        a = multi.eval_single(T, cm)
+        assert abs(a[0] - b[0]) <= 1e-12 * abs(b[0])
+        assert_close(a[1], b[1], f"{collective} gradT", tol=1e-11); assert_close(a[2], b[2], f"{collective} gradC", tol=1e-11)
+    assert multi.stats()["units"] == single.stats()["units"]
