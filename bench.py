@@ -57,28 +57,41 @@ def v1_source_hash():
     return h.hexdigest()[:16]
 
 
-def issue_from_counters(path, want_hash):
-    """roofline_issue block from a tools/pmc_collect.py JSON (per-dispatch means of the SQ counters, summed over the kernels it
-    lists); None when the file is missing, unreadable or was measured on other kernel sources."""
+def issue_from_counters(path, want_hash, live_kernel_us=None):
+    """Issue-slot roofline block from a tools/pmc_collect.py JSON (per-dispatch means of the SQ counters, summed over the kernels it
+    lists); None when the file is missing, unreadable or was measured on other kernel sources.  The counters are properties of
+    the kernel + workload (instructions issued per launch); the DURATION they are divided by is `live_kernel_us` when given (the
+    kernel's duration measured in this run with HIP events), the rocprofv3 average of the counter run otherwise."""
     try:
         with open(path) as f:
             pj = json.load(f)
         if pj.get("source_hash") != want_hash:
             return None
         c = pj["counters"]
-        k_us = pj["avg_kernel_us"]
+        k_us = live_kernel_us if live_kernel_us else pj["avg_kernel_us"]
         cyc = k_us * 1e-6 * PEAK_CLOCK_HZ
         f64 = c["SQ_INSTS_VALU_ADD_F64"] + c["SQ_INSTS_VALU_MUL_F64"] + c["SQ_INSTS_VALU_FMA_F64"] + c["SQ_INSTS_VALU_TRANS_F64"]
         flops64 = (c["SQ_INSTS_VALU_ADD_F64"] + c["SQ_INSTS_VALU_MUL_F64"] + 2 * c["SQ_INSTS_VALU_FMA_F64"] + c["SQ_INSTS_VALU_TRANS_F64"]) * 64
-        return {"kernels": pj.get("kernel"), "valu_issue_busy_frac": round(4.0 * c["SQ_ACTIVE_INST_VALU"] / (N_SIMD * cyc), 4),
+        busy = 4.0 * c["SQ_ACTIVE_INST_VALU"] / (N_SIMD * cyc)
+        lane = pj.get("lane_utilisation_valu")
+        if lane is None and "SQ_THREAD_CYCLES_VALU" in c:
+            lane = c["SQ_THREAD_CYCLES_VALU"] / (64.0 * c["SQ_ACTIVE_INST_VALU"])
+        share64 = f64 / c["SQ_INSTS_VALU"]
+        return {"kernels": pj.get("kernel"), "valu_issue_busy_frac": round(busy, 4),
+                "lane_utilisation": None if lane is None else round(lane, 4),
+                "fp64_share_of_valu_insts": round(share64, 4),
+                "useful_fp64_frac": None if lane is None else round(busy * share64 * lane, 4),
                 "wait_frac_of_wave_cycles": round(c["SQ_WAIT_ANY"] / c["SQ_WAVE_CYCLES"], 4),
-                "waves_per_simd_avg": round(4.0 * c["SQ_WAVE_CYCLES"] / (N_SIMD * cyc), 3),
+                "waves_per_simd_avg": round(4.0 * c["SQ_WAVE_CYCLES"] / (N_SIMD * pj["avg_kernel_us"] * 1e-6 * PEAK_CLOCK_HZ), 3),
                 "valu_insts_per_step": int(c["SQ_INSTS_VALU"]), "salu_insts_per_step": int(c["SQ_INSTS_SALU"]),
-                "fp64_share_of_valu_insts": round(f64 / c["SQ_INSTS_VALU"], 4),
-                "fp64_tflops_upper": round(flops64 / (k_us * 1e-6) / 1e12, 3), "fp64_valu_peak_tflops": FP64_VALU_PEAK_TFLOPS,
-                "fp64_frac_of_peak_upper": round(flops64 / (k_us * 1e-6) / 1e12 / FP64_VALU_PEAK_TFLOPS, 4),
-                "definition": "fp64 flops = (ADD + MUL + 2 FMA + TRANS wave-instructions) x 64 lanes (an UPPER figure: inactive lanes count) / the kernels' summed duration under rocprofv3; valu_issue_busy = SQ_ACTIVE_INST_VALU x 4 / (1024 SIMDs x duration x 2.4 GHz)",
-                "kernel_us_under_rocprof": round(k_us, 3), "measured_on_commit": pj.get("commit"), "source": os.path.relpath(path, ROOT)}
+                "fp64_tflops": None if lane is None else round(lane * flops64 / (k_us * 1e-6) / 1e12, 3),
+                "fp64_valu_peak_tflops": FP64_VALU_PEAK_TFLOPS,
+                "fp64_frac_of_peak": None if lane is None else round(lane * flops64 / (k_us * 1e-6) / 1e12 / FP64_VALU_PEAK_TFLOPS, 4),
+                "definition": "valu_issue_busy = SQ_ACTIVE_INST_VALU (quad-cycles per launch, PMC) x 4 / (1024 SIMDs x kernel duration x 2.4 GHz): 1.0 = a VALU instruction "
+                              "issuing on every SIMD in every cycle; lane_utilisation = SQ_THREAD_CYCLES_VALU / (64 x SQ_ACTIVE_INST_VALU); useful_fp64_frac = busy x fp64 share "
+                              "of the VALU instructions x lane utilisation; fp64 flops = (ADD + MUL + 2 FMA + TRANS wave-instructions) x 64 lanes x lane utilisation",
+                "kernel_us": round(k_us, 3), "kernel_us_source": "HIP events, this run" if live_kernel_us else "rocprofv3 average of the counter run",
+                "kernel_us_under_rocprof": round(pj["avg_kernel_us"], 3), "measured_on_commit": pj.get("commit"), "source": os.path.relpath(path, ROOT)}
     except Exception:       # noqa: BLE001
         return None
 
@@ -319,6 +332,76 @@ def main():
         if mode == "fused":
             eng.xchg_fuse(True)
 
+    # ---- N > 1: a scaling line that can be READ.  (1) the SAME workload (the N-piece trajectory) unsharded on ONE GPU, measured on
+    # rank 0 in this run -> `one_gpu_same_workload` + `speedup` (the N = 1 line of this bench is another workload: C2, 40 pieces);
+    # (2) the workload of BASELINE's configs that CAN scale - configs[2], 128 trajectories - sharded by TRAJECTORY (no exchange:
+    # every trajectory's outputs stay on its rank, as in the batch optimiser), with its own one-GPU figure from rank 0.
+    one_gpu = None
+    c3_sharded = None
+    if world > 1 and not args.weak:
+        def plain_timed(fn, steps, warm=5):
+            for _ in range(warm):
+                fn()
+            torch.cuda.synchronize(); dist.barrier(); torch.cuda.synchronize()
+            t0_ = time.perf_counter()
+            for _ in range(steps):
+                fn()
+            torch.cuda.synchronize(); dist.barrier()
+            return time.perf_counter() - t0_
+
+        fused_was_on = mode == "fused"
+        if fused_was_on:
+            eng.xchg_fuse(False)
+        e1g = None
+        if rank == 0:
+            e1g = pkg.Engine(cfg); e1g.set_grid(esdf, (0, 0, 0), res, capi.GRID_ESDF); e1g.set_shape(shape)
+            d_o1 = torch.zeros(e1g.out_stride(N), dtype=torch.float64, device=dev)
+        st1 = max(20, args.steps // 4)
+        el1 = plain_timed((lambda: e1g.eval_device(1, N, d_T.data_ptr(), d_C.data_ptr(), d_o1.data_ptr(), 0, stream)) if rank == 0 else (lambda: None), st1)
+        if rank == 0:
+            one_gpu = {"ms_per_step": round(1e3 * el1 / st1, 5), "evals_per_s": round(N * (K + 1) * st1 / el1, 1), "steps": st1,
+                       "what": f"the same {N}-piece trajectory UNSHARDED on rank 0's GPU while the other ranks wait, same run"}
+        # (2) configs[2] sharded by trajectory
+        n_traj_all = 128
+        tb, te = par.shard_range(n_traj_all, rank, world)
+        ext_ = np.array(occ.shape) * res
+        Tl, Cl = [], []
+        for b in range(n_traj_all if rank == 0 else 0):     # rank 0 also needs all of them for the one-GPU figure
+            Tb_, Cf_ = synth.random_trajectory(ext_, 40, seed=777 + b, piece_T=1.0, jitter=0.5, margin=4.0, occ=occ, res=res)
+            Tl.append(Tb_); Cl.append(synth.colmajor(Cf_))
+        if rank != 0:
+            for b in range(tb, te):
+                Tb_, Cf_ = synth.random_trajectory(ext_, 40, seed=777 + b, piece_T=1.0, jitter=0.5, margin=4.0, occ=occ, res=res)
+                Tl.append(Tb_); Cl.append(synth.colmajor(Cf_))
+            Tm, Cm_ = Tl, Cl
+        else:
+            Tm, Cm_ = Tl[tb:te], Cl[tb:te]
+        e3 = pkg.Engine(cfg); e3.set_grid(esdf, (0, 0, 0), res, capi.GRID_ESDF); e3.set_shape(shape)
+        nb_ = te - tb
+        if nb_ > 0:
+            d3T = torch.from_numpy(np.concatenate(Tm)).to(dev); d3C = torch.from_numpy(np.concatenate(Cm_)).to(dev)
+            d3O = torch.zeros(nb_ * e3.out_stride(40), dtype=torch.float64, device=dev)
+        st3 = 20
+        el3 = plain_timed((lambda: e3.eval_device(nb_, 40, d3T.data_ptr(), d3C.data_ptr(), d3O.data_ptr(), 0, stream)) if nb_ > 0 else (lambda: None), st3)
+        t3 = torch.tensor([el3], dtype=torch.float64, device=dev); dist.all_reduce(t3, op=dist.ReduceOp.MAX); el3 = float(t3.item())
+        if rank == 0:
+            dAT = torch.from_numpy(np.concatenate(Tl)).to(dev); dAC = torch.from_numpy(np.concatenate(Cl)).to(dev)
+            dAO = torch.zeros(n_traj_all * e3.out_stride(40), dtype=torch.float64, device=dev)
+        el3one = plain_timed((lambda: e3.eval_device(n_traj_all, 40, dAT.data_ptr(), dAC.data_ptr(), dAO.data_ptr(), 0, stream)) if rank == 0 else (lambda: None), st3)
+        if rank == 0:
+            ev3 = n_traj_all * 40 * (K + 1)
+            # parity of the sharded launch: rank 0's first trajectory, sharded launch vs the 128-trajectory launch (bitwise: one trajectory's
+            # result does not depend on its neighbours in the batch, tests/test_gpu_fullsize.py::test_c3_batch_is_independent)
+            same = bool(torch.equal(d3O[:e3.out_stride(40)], dAO[:e3.out_stride(40)]))
+            c3_sharded = {"name": f"C3 (configs[2]) sharded by TRAJECTORY over {world} GPUs: 128 trajectories x 40 pieces, {nb_} per rank, no exchange (outputs stay with their trajectory's rank)",
+                          "evals_per_step": ev3, "ms_per_step": round(1e3 * el3 / st3, 5), "evals_per_s": round(ev3 * st3 / el3, 1), "scaling": "strong",
+                          "one_gpu_same_workload": {"ms_per_step": round(1e3 * el3one / st3, 5), "evals_per_s": round(ev3 * st3 / el3one, 1),
+                                                    "what": "all 128 trajectories in one batched launch on rank 0's GPU while the other ranks wait, same run"},
+                          "speedup": round(el3one / el3, 3), "sharded_equals_unsharded_bitwise_traj0": same}
+        del e3
+        if fused_was_on:
+            eng.xchg_fuse(True)
+
     evals_this_rank = (par.shard_range(N, rank, world)[1] - par.shard_range(N, rank, world)[0]) * (K + 1)
     one_launch = evals_this_rank // 4 + (N // world) <= 768 and world == 1
     # two live bounds of the kernel's duration, both from above: the dispatch-attached events (an instrumented dispatch runs
@@ -327,71 +410,85 @@ def main():
     B = algorithmic_bytes_per_eval(args.kernel_size)
     achieved = (evals_this_rank * B) / (kern_ms * 1e-3) / 1e9 if kern_ms > 0 else 0.0
 
-    # ---- what the counters say (profiles/pmc_counters.json: rocprofv3 PMC passes of THIS command, tools/profile_round.sh),
-    # used only while the kernel sources are the ones it was measured on
+    # ---- the roofline of the dominant kernel.  What bounds this design is NOT HBM: the sweep reads a 1-bit qualifier grid that
+    # lives in L2 (three 2 MiB arrays at 256^3), its HBM traffic is ~2 MB per launch (PMC) - the kernel is bound by VALU
+    # instruction ISSUE (and, on the 2 600-wave C2 launch, by latency at ~2 waves per SIMD).  So `roofline` is the issue-slot
+    # model: frac = the share of SIMD-cycles in which a VALU instruction issues, from the committed counter passes of THIS
+    # command (profiles/pmc_counters.json, tools/profile_round.sh; used only while the kernel sources are the ones it was
+    # measured on) over the kernel duration measured live with HIP events.  SURVEY 8(d)'s byte model (k^3 x 4 B per eval: bytes
+    # this kernel never moves) is kept as `nominal_bytes` - a work-rate proxy that EXCEEDS the HBM peak on the batch configs.
     traffic = None
-    issue = None
     hbm_meas = None
-    bound = "unknown (no counters for this version of the kernel; nominal figure only)"
-    if not (world == 1 and N == 40 and args.grid == 256 and args.kernel_size == 21):
-        bound = "valu-issue / latency on the N = 1 workload by the counters (profiles/pmc_counters.json); counters are not collected for this geometry"
+    issue = None
+    geom_has_counters = world == 1 and N == 40 and args.grid == 256 and args.kernel_size == 21
     tpath = os.path.join(ROOT, "profiles", "pmc_counters.json")
-    if world == 1 and N == 40 and args.grid == 256 and args.kernel_size == 21 and os.path.exists(tpath):
-        try:
-            with open(tpath) as f:
-                pj = json.load(f)
-            if pj.get("source_hash") == kernel_source_hash():
-                c = pj["counters"]
+    if geom_has_counters:
+        issue = issue_from_counters(tpath, kernel_source_hash(), live_kernel_us=kern_ms * 1e3 if kern_ms > 0 else None)
+        if issue is not None:
+            try:
+                with open(tpath) as f:
+                    c = json.load(f)["counters"]
                 traffic = int(round((2.0 * c["FETCH_SIZE"] + c["WRITE_SIZE"]) * 1024))        # gfx950: FETCH_SIZE x 2 (guide, HBM)
-                k_us = pj["avg_kernel_us"]
-                hbm_meas = traffic / (k_us * 1e-6) / 1e9
-                # kernel duration in shader cycles at the 2.4 GHz peak clock (GRBM_GUI_ACTIVE also counts the dispatch overhead
-                # around a 20 us kernel; a lower actual clock makes the busy fractions below slightly LOW, never high)
-                cyc = k_us * 1e-6 * PEAK_CLOCK_HZ
-                f64 = c["SQ_INSTS_VALU_ADD_F64"] + c["SQ_INSTS_VALU_MUL_F64"] + c["SQ_INSTS_VALU_FMA_F64"] + c["SQ_INSTS_VALU_TRANS_F64"]
-                flops64 = (c["SQ_INSTS_VALU_ADD_F64"] + c["SQ_INSTS_VALU_MUL_F64"] + 2 * c["SQ_INSTS_VALU_FMA_F64"] + c["SQ_INSTS_VALU_TRANS_F64"]) * 64
-                issue = {"valu_issue_busy_frac": round(4.0 * c["SQ_ACTIVE_INST_VALU"] / (N_SIMD * cyc), 4),
-                         "any_inst_active_frac_of_wave_cycles": round(c["SQ_ACTIVE_INST_ANY"] / c["SQ_WAVE_CYCLES"], 4),
-                         "wait_frac_of_wave_cycles": round(c["SQ_WAIT_ANY"] / c["SQ_WAVE_CYCLES"], 4),
-                         "issue_stall_frac_of_wave_cycles": round(c["SQ_WAIT_INST_ANY"] / c["SQ_WAVE_CYCLES"], 4),
-                         "waves_per_simd_avg": round(4.0 * c["SQ_WAVE_CYCLES"] / (N_SIMD * cyc), 3),
-                         "valu_insts_per_launch": int(c["SQ_INSTS_VALU"]), "fp64_share_of_valu_insts": round(f64 / c["SQ_INSTS_VALU"], 4),
-                         "salu_insts_per_launch": int(c["SQ_INSTS_SALU"]),
-                         "fp64_tflops_upper": round(flops64 / (k_us * 1e-6) / 1e12, 3), "fp64_valu_peak_tflops": FP64_VALU_PEAK_TFLOPS,
-                         "fp64_frac_of_peak_upper": round(flops64 / (k_us * 1e-6) / 1e12 / FP64_VALU_PEAK_TFLOPS, 4),
-                         "peak": "1.0 = a VALU instruction issuing on every SIMD in every cycle (fp64 instructions hold the SIMD 4 cycles each)",
-                         "kernel_us_under_rocprof": round(k_us, 3), "clock_assumed_ghz": PEAK_CLOCK_HZ / 1e9,
-                         "measured_on_commit": pj.get("commit"), "source": "profiles/pmc_counters.json"}
-                bound = ("valu-issue" if issue["valu_issue_busy_frac"] > hbm_meas / HBM_PEAK_GBS else "hbm") + \
-                        " (by the counters: see roofline_issue / hbm_frac_measured; the `frac` below is SURVEY 8(d)'s nominal byte model, not traffic)"
-        except Exception as e:          # noqa: BLE001
-            bound = f"unknown (counter file unreadable: {e})"
+                hbm_meas = traffic / (kern_ms * 1e-3) / 1e9
+            except Exception:       # noqa: BLE001
+                traffic = None
     # SURVEY.md 8(d) asks for the COMPULSORY lower bound next to the algorithmic figure: the unique voxels that the tiles of
     # this rank's launch touch (neighbouring samples' tiles overlap heavily) x 4 B, plus the per-sample inputs / outputs
     compulsory = None
     if world == 1:
         compulsory = compulsory_bytes(T, cm, N, K, args.kernel_size, args.grid, res)
-    roofline = {"bound": bound, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-                "definition": "achieved = ALGORITHMIC bytes (SURVEY 8(d): k^3 x 4 B tile + corners + coefficients + outputs per eval) x evals per launch / kernel duration - a work-rate proxy; the kernel reads a 1-bit qualifier grid, its real HBM traffic is `traffic` (PMC)",
-                "hbm_frac_measured": None if hbm_meas is None else round(hbm_meas / HBM_PEAK_GBS, 5),
-                "hbm_gbs_measured": None if hbm_meas is None else round(hbm_meas, 1),
-                "kernel": "sweep_kernel", "kernel_ms": round(kern_ms, 5), "launches": n_launch,
-                "kernel_ms_dispatch_events": round(kern_ms_dispatch, 5), "kernel_ms_region_events": round(region_ms, 5),
-                "algorithmic_bytes_per_eval": B, "algorithmic_bytes_per_launch": evals_this_rank * B,
-                "compulsory_bytes_per_launch": compulsory,
-                # secondary figure of SURVEY 8(d): robot-SDF evaluations per second inside the tiles (every pair costs one
-                # evaluation, every pair with a non-zero penalty six more for the central-difference gradient)
-                "pair_sdf_evals_per_s": round((stats["pairs"] + 6 * stats["grad_pairs"]) / (ms_per_step * 1e-3), 1)}
+    nominal = {"achieved_gbs": round(achieved, 2), "frac_of_hbm_peak": round(achieved / HBM_PEAK_GBS, 4),
+               "algorithmic_bytes_per_eval": B, "algorithmic_bytes_per_launch": evals_this_rank * B, "compulsory_bytes_per_launch": compulsory,
+               "is_a_bound": False,
+               "definition": "SURVEY 8(d): (k^3 x 4 B tile + corners + coefficients + outputs) x evals per launch / kernel duration / 8 TB/s - a work-rate "
+                             "proxy in the north-star's unit, NOT traffic and NOT a bound: the kernel reads a 1-bit qualifier grid, its HBM bytes are `traffic`",
+               "exceeds_1_on": "filled below from `configs` (every entry whose nominal_bytes_frac > 1)"}
+    if issue is not None:
+        roofline = {"bound": "valu-issue", "achieved": issue["valu_issue_busy_frac"], "peak": 1.0,
+                    "unit": "VALU instructions issued per SIMD-cycle (1.0 = one on every one of the 1 024 SIMDs in every cycle at 2.4 GHz)",
+                    "frac": issue["valu_issue_busy_frac"], "traffic": traffic,
+                    "lane_utilisation": issue["lane_utilisation"], "useful_fp64_frac": issue["useful_fp64_frac"],
+                    "fp64_share_of_valu_insts": issue["fp64_share_of_valu_insts"], "waves_per_simd_avg": issue["waves_per_simd_avg"],
+                    "wait_frac_of_wave_cycles": issue["wait_frac_of_wave_cycles"],
+                    "note": "C2 is ONE launch of 2 600 wavefronts for 1 024 SIMDs: at ~2 waves per SIMD it is latency-floored; the same kernel reaches its issue bound on the batch (configs[0].roofline)",
+                    "definition": issue["definition"], "counters": issue["source"], "counters_measured_on_commit": issue["measured_on_commit"]}
+    else:
+        roofline = {"bound": "valu-issue (by the committed counters of the N = 1 workload; none for this geometry / this version of the kernel sources)",
+                    "achieved": None, "peak": 1.0, "unit": "VALU instructions issued per SIMD-cycle", "frac": None, "traffic": None}
+    roofline.update({"hbm_frac_measured": None if hbm_meas is None else round(hbm_meas / HBM_PEAK_GBS, 5),
+                     "hbm_gbs_measured": None if hbm_meas is None else round(hbm_meas, 1),
+                     "kernel": "sweep_kernel", "kernel_ms": round(kern_ms, 5), "launches": n_launch,
+                     "kernel_ms_dispatch_events": round(kern_ms_dispatch, 5), "kernel_ms_region_events": round(region_ms, 5),
+                     "nominal_bytes": nominal,
+                     # secondary figure of SURVEY 8(d): robot-SDF evaluations per second inside the tiles (every pair costs one
+                     # evaluation, every pair with a non-zero penalty six more for the central-difference gradient)
+                     "pair_sdf_evals_per_s": round((stats["pairs"] + 6 * stats["grad_pairs"]) / (ms_per_step * 1e-3), 1)})
 
     result = None
     if rank == 0:
         # ---- the other single-GPU configurations SURVEY 7 names as the memory-side-heavy ones, same JSON (device resident)
         extra = None
+        if world > 1 and c3_sharded is not None:
+            extra = [c3_sharded]
         if world == 1 and not args.no_extra_configs:
             extra = []
 
-            def run_cfg(name, e, n_traj, Np, Ts, Cs, steps, kk=args.kernel_size):
+            def parity_first(e, Np, Ts, Cs, dO, oc):
+                """rel. error of the FIRST trajectory of the entry's last launch vs the oracle (oc = (cfg, grid, kind, res, shape));
+                outside every timed region"""
+                if args.no_cpu_baseline or oc is None:
+                    return None
+                try:
+                    ocfg, ogrid, okind, ores, oshape = oc
+                    oo = graft.load_oracle().Oracle(ocfg, threads=min(30, os.cpu_count() or 1))
+                    oo.set_grid(ogrid, (0, 0, 0), ores, okind); oo.set_shape(oshape)
+                    c0, gT0, gC0, _ = oo.eval(Ts[:Np], Cs[:18 * Np])
+                    ref = np.concatenate([[c0], gT0, gC0]); got = dO[:e.out_stride(Np)].cpu().numpy()[:ref.size]
+                    return float(np.linalg.norm(got - ref) / max(np.linalg.norm(ref), 1e-300))
+                except Exception as ex:      # noqa: BLE001
+                    return f"oracle failed: {ex}"
+
+            def run_cfg(name, e, n_traj, Np, Ts, Cs, steps, kk=args.kernel_size, oc=None):
                 dT = torch.from_numpy(Ts).to(dev); dC = torch.from_numpy(Cs).to(dev)
                 dO = torch.zeros(n_traj * e.out_stride(Np), dtype=torch.float64, device=dev)
                 for _ in range(5):
@@ -403,22 +500,27 @@ def main():
                 units = n_traj * Np * (K + 1)
                 nom = units * algorithmic_bytes_per_eval(kk) / dt / 1e9
                 extra.append({"name": name, "evals_per_step": units, "ms_per_step": round(dt * 1e3, 5), "evals_per_s": round(units / dt, 1),
-                              "nominal_gbs": round(nom, 1), "nominal_frac": round(nom / HBM_PEAK_GBS, 4)})
+                              "nominal_bytes_gbs": round(nom, 1), "nominal_bytes_frac": round(nom / HBM_PEAK_GBS, 4),
+                              "nominal_bytes_exceeds_hbm_peak": bool(nom > HBM_PEAK_GBS),
+                              "rel_err_vs_oracle": parity_first(e, Np, Ts, Cs, dO, oc),
+                              "rel_err_vs_oracle_of": "trajectory 0 of the launch" if n_traj > 1 else "the launch"})
+                return extra[-1]
 
             Ts, Cs = [], []
             ext = np.array(occ.shape) * res
             for b in range(128):
                 Tb, Cf = synth.random_trajectory(ext, 40, seed=777 + b, piece_T=1.0, jitter=0.5, margin=4.0, occ=occ, res=res)
                 Ts.append(Tb); Cs.append(synth.colmajor(Cf))
-            run_cfg("C3 (configs[2]): 128 trajectories x 40 pieces, shared 256^3 map, one batched launch pair", eng, 128, 40, np.concatenate(Ts), np.concatenate(Cs), 20)
+            oc2 = (cfg, esdf, capi.GRID_ESDF, res, shape)
+            run_cfg("C3 (configs[2]): 128 trajectories x 40 pieces, shared 256^3 map, one batched launch pair", eng, 128, 40, np.concatenate(Ts), np.concatenate(Cs), 20, oc=oc2)
             _, _, T4, cm4 = build_workload(pkg, 400, args.grid, res)
-            run_cfg("C4 on ONE GPU (configs[3]'s trajectory unsharded): 1 x 400 pieces", eng, 1, 400, T4, cm4, 50)
+            run_cfg("C4 on ONE GPU (configs[3]'s trajectory unsharded): 1 x 400 pieces", eng, 1, 400, T4, cm4, 50, oc=oc2)
             # another robot of SURVEY 8(d) on the headline geometry: the 0.4x rounded cone (three branches, a square root each)
             try:
                 ec = pkg.Engine(cfg)
                 ec.set_grid(esdf, (0, 0, 0), res, capi.GRID_ESDF)
                 ec.set_shape(synth.bench_rounded_cone_shape())
-                run_cfg("C2 geometry (1 x 40 pieces) with the rounded-cone robot (r1 0.6, r2 0.24, h 1.8)", ec, 1, 40, T, cm, 200)
+                run_cfg("C2 geometry (1 x 40 pieces) with the rounded-cone robot (r1 0.6, r2 0.24, h 1.8)", ec, 1, 40, T, cm, 200, oc=(cfg, esdf, capi.GRID_ESDF, res, synth.bench_rounded_cone_shape()))
                 del ec
             except Exception as e:      # noqa: BLE001
                 extra.append({"name": "rounded cone", "error": str(e)})
@@ -431,16 +533,17 @@ def main():
                 e5 = pkg.Engine(cfg5)
                 e5.set_grid(occ5, (0, 0, 0), res5, capi.GRID_OCCUPANCY)
                 e5.generate_esdf()
-                e5.set_shape(synth.make_shape("Box", params=(0.8, 0.15, 0.15), grad_mode=capi.GRAD_CENTRAL, bound_radius=0.83,
-                                              bbox=((0, 0, 0), (0.8, 0.15, 0.15))))
+                shape5 = synth.make_shape("Box", params=(0.8, 0.15, 0.15), grad_mode=capi.GRAD_CENTRAL, bound_radius=0.83, bbox=((0, 0, 0), (0.8, 0.15, 0.15)))
+                e5.set_shape(shape5)
+                oc5 = None if args.no_cpu_baseline else (cfg5, e5.get_grid(capi.GRID_ESDF)[0], capi.GRID_ESDF, res5, shape5)
                 ext5 = np.array(occ5.shape) * res5
                 Ts, Cs = [], []
                 for b in range(128):
                     Tb, Cf = synth.random_trajectory(ext5, 40, seed=900 + b, piece_T=1.0, jitter=0.5, margin=4.0, occ=occ5, res=res5)
                     Ts.append(Tb); Cs.append(synth.colmajor(Cf))
-                run_cfg("512^3 map @ 0.1 m (512 MiB fp32 ESDF built on the device), 1 x 40 pieces, robot and tile scaled with the voxel", e5, 1, 40, Ts[0], Cs[0], 100)
-                run_cfg("512^3 map @ 0.1 m, batch of 128 x 40 pieces", e5, 128, 40, np.concatenate(Ts), np.concatenate(Cs), 20)
-                del e5
+                run_cfg("512^3 map @ 0.1 m (512 MiB fp32 ESDF built on the device), 1 x 40 pieces, robot and tile scaled with the voxel", e5, 1, 40, Ts[0], Cs[0], 100, oc=oc5)
+                run_cfg("512^3 map @ 0.1 m, batch of 128 x 40 pieces", e5, 128, 40, np.concatenate(Ts), np.concatenate(Cs), 20, oc=oc5)
+                del e5, oc5
             except Exception as e:      # noqa: BLE001
                 extra.append({"name": "512^3 map", "error": str(e)})
 
@@ -449,7 +552,7 @@ def main():
                 cfgc = synth.default_config(capi.V3_ESDF_TILE, device=local_rank, kernel_size=args.kernel_size, integral_intervs=K,
                                             safety_hor=(3 ** 0.5 / 2) * res, weight_p=4000.0, smoothing_eps=0.01, enable_dyn=1, enable_pos=1, enable_cull=1)
                 ecu = pkg.Engine(cfgc); ecu.set_grid(esdf, (0, 0, 0), res, capi.GRID_ESDF); ecu.set_shape(shape)
-                run_cfg("C2 with the V3 whole-tile cull ON (trilinear esdf(pos) > bound radius + safety + sqrt(3) res skips the pose)", ecu, 1, 40, T, cm, 300)
+                run_cfg("C2 with the V3 whole-tile cull ON (trilinear esdf(pos) > bound radius + safety + sqrt(3) res skips the pose)", ecu, 1, 40, T, cm, 300, oc=(cfgc, esdf, capi.GRID_ESDF, res, shape))
                 extra[-1]["poses_culled"] = ecu.stats()["culled"]
                 del ecu
             except Exception as e:      # noqa: BLE001
@@ -515,8 +618,8 @@ def main():
                         oracle = (o1, thr)
                     ent = run_v1(f"V1 swept-volume sweep (the reference's live collision term), 40 pieces / 40 s, 256^3 occupancy, {nm}", e1, 40, T, cm, 50, oracle)
                     if nm.startswith("rounded"):
-                        ent["roofline_issue"] = issue_from_counters(os.path.join(ROOT, "profiles", "pmc_counters_v1.json"), v1_source_hash())
-                        ent["bound"] = "compute / dependent-instruction latency (SURVEY 8(d): 24 B point + trajectory per workgroup - no HBM roof); see roofline_issue.fp64_frac_of_peak_upper"
+                        ent["roofline_issue"] = issue_from_counters(os.path.join(ROOT, "profiles", "pmc_counters_v1.json"), v1_source_hash(), live_kernel_us=ent["kernel_ms_search_launches"] * 1e3)
+                        ent["bound"] = "valu-issue / dependent-instruction latency (SURVEY 8(d): 24 B point + trajectory per workgroup - no HBM roof); see roofline_issue"
                     del e1
             except Exception as e:      # noqa: BLE001
                 extra.append({"name": "V1 analytic", "error": str(e)})
@@ -529,23 +632,88 @@ def main():
                 T5, Cf5 = synth.random_trajectory(ext5, 20, seed=780, piece_T=1.0, jitter=0.5, margin=4.0, occ=occ5, res=res5)
                 cm5 = synth.colmajor(Cf5)
                 way5 = cm5.reshape(3, -1).T.reshape(20, 6, 3)[1:, 0, :]
-                for nm, (Vm, Fm), stp in (("concave L prism, 20 faces", synth.l_prism_mesh(), 20), ("blob, 720 faces", synth.blob_mesh(24, 16, scale=0.9), 5)):
+                # SURVEY 8(d) names the reference's own Lthick.obj (concave, 20 faces) and Trefoil.obj (12 000 faces), "scaled to the same
+                # bound" (tests/golden/ref_meshes.npz: isdf_read_obj's view of src/plan_manager/shapes/*.obj); the synthetic L prism and
+                # the 720-face blob are the round-3 entries, kept for comparison
+                meshes = [("concave L prism, 20 faces (synthetic)", synth.l_prism_mesh(), 20, "all"),
+                          ("blob, 720 faces (synthetic)", synth.blob_mesh(24, 16, scale=0.9), 5, "all")]
+                try:
+                    meshes += [("the reference's Lthick.obj, 20 faces, scaled to a 0.83 m bound", synth.reference_mesh("Lthick", 0.83), 20, "all"),
+                               ("the reference's Trefoil.obj, 12 000 faces, scaled to a 0.83 m bound", synth.reference_mesh("Trefoil", 0.83), 3, "sample")]
+                except Exception as e:      # noqa: BLE001
+                    extra.append({"name": "reference meshes", "error": str(e)})
+                for nm, (Vm, Fm), stp, omode in meshes:
                     cfg1 = synth.default_config(capi.V1_SWEPT, device=local_rank, safety_hor=(3 ** 0.5 / 2) * res5, weight_p=4000.0)
                     shp = synth.make_mesh_shape(Vm, Fm)
                     e1 = pkg.Engine(cfg1); e1.set_grid(occ5, (0, 0, 0), res5, capi.GRID_OCCUPANCY); e1.set_shape(shp)
                     e1.gather_points(way5, 0.9)
                     oracle = None
+                    o1 = None
                     if not args.no_cpu_baseline:
                         thr = min(30, os.cpu_count() or 1)
-                        o1 = orc_v1.Oracle(cfg1, threads=thr); o1.set_grid(occ5, (0, 0, 0), res5, capi.GRID_OCCUPANCY); o1.set_shape(shp); o1.set_points(e1.get_points())
-                        if o1.mesh_backend() == 1:
-                            oracle = (o1, thr)
-                    run_v1(f"C5 (configs[4]) shape: V1 sweep, 512^3 occupancy @ 0.1 m, mesh robot ({nm}) through the fast winding number, 20 pieces", e1, 20, T5, cm5, stp, oracle,
-                           note="both sides search their own minimisers; the device's winding number is the reference library's bit for bit (csrc/dev_mesh.hpp), so t* is identical and rel_err_vs_oracle is rounding")
+                        o1 = orc_v1.Oracle(cfg1, threads=thr); o1.set_grid(occ5, (0, 0, 0), res5, capi.GRID_OCCUPANCY); o1.set_shape(shp)
+                        if o1.mesh_backend() != 1:
+                            o1 = None
+                        elif omode == "all":
+                            o1.set_points(e1.get_points()); oracle = (o1, thr)
+                    ent = run_v1(f"C5 (configs[4]) shape: V1 sweep, 512^3 occupancy @ 0.1 m, mesh robot ({nm}) through the fast winding number, 20 pieces", e1, 20, T5, cm5, stp, oracle,
+                                 note="both sides search their own minimisers; the device's winding number is the reference library's bit for bit (csrc/dev_mesh.hpp), so t* is identical and rel_err_vs_oracle is rounding")
+                    ent["faces"] = int(len(Fm))
+                    if o1 is not None and omode == "sample":
+                        # the oracle's exhaustive closest-point search over 12 000 faces: a SAMPLE of the obstacle points, both sides on the same subset
+                        ps = np.ascontiguousarray(e1.get_points()[::40])
+                        e1.set_points(ps); o1.set_points(ps)
+                        cs, gTs, gCs = e1.eval_single(T5, cm5)
+                        c0, gT0, gC0, _ = o1.eval(T5, cm5)
+                        ref1 = np.concatenate([[c0], gT0, gC0]); got1 = np.concatenate([[cs], gTs, gCs])
+                        ent["rel_err_vs_oracle"] = float(np.linalg.norm(got1 - ref1) / max(np.linalg.norm(ref1), 1e-300))
+                        ent["rel_err_vs_oracle_of"] = f"every 40th obstacle point ({len(ps)} points), both sides on that subset"
+                    if "720" in nm:
+                        ent["roofline_issue"] = issue_from_counters(os.path.join(ROOT, "profiles", "pmc_counters_v1mesh.json"), v1_source_hash())
+                        if ent["roofline_issue"]:
+                            ent["roofline_issue"]["workload_of_the_counters"] = "tools/v1_bench.py --mesh720: the same 720-face robot on the 256^3 bench map, 7 773 points"
                     del e1
                 del occ5
             except Exception as e:      # noqa: BLE001
                 extra.append({"name": "C5 V1 mesh", "error": str(e)})
+            # ---- the ESDF point sampler (GridMap3D::getSDFValue / getSDFValueWithGrad, A13): the one pure gather of the path -
+            # measured against the HBM peak by its algorithmic bytes (24 B point + 8 x 4 B corners + 8 B value + 24 B gradient)
+            try:
+                npt = 20_000_000
+                gen = torch.Generator(device=dev); gen.manual_seed(7)
+                ext_m = args.grid * res
+                m_ = npt // 4096
+                a_ = torch.rand(4096, 1, 3, dtype=torch.float64, device=dev, generator=gen) * ext_m
+                d_ = torch.nn.functional.normalize(torch.randn(4096, 1, 3, dtype=torch.float64, device=dev, generator=gen), dim=2)
+                sets = (("trajectory-like points (4 096 straight lines, consecutive points 2 cm apart)", (a_ + d_ * (torch.arange(m_, dtype=torch.float64, device=dev).view(1, m_, 1) * 0.02)).reshape(-1, 3).contiguous()),
+                        ("uniform random points", torch.rand(npt, 3, dtype=torch.float64, device=dev, generator=gen) * ext_m))
+                for nm_, pts_ in sets:
+                    n_ = pts_.shape[0]
+                    dv_ = torch.empty(n_, dtype=torch.float64, device=dev); dg_ = torch.empty(n_, 3, dtype=torch.float64, device=dev)
+                    for _ in range(2):
+                        eng.esdf_sample_device(pts_.data_ptr(), n_, dv_.data_ptr(), dg_.data_ptr(), stream)
+                    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    ev0.record()
+                    for _ in range(5):
+                        eng.esdf_sample_device(pts_.data_ptr(), n_, dv_.data_ptr(), dg_.data_ptr(), stream)
+                    ev1.record(); torch.cuda.synchronize()
+                    ms_ = ev0.elapsed_time(ev1) / 5
+                    ent = {"name": f"ESDF point sampler isdf_esdf_sample_device (value + gradient), {args.grid}^3 float32 ESDF, {n_:.3g} {nm_}",
+                           "points": n_, "ms_per_launch": round(ms_, 4), "points_per_s": round(n_ / ms_ * 1e3, 1), "unit": "ESDF samples/s",
+                           "roofline": {"bound": "hbm", "achieved": round(n_ * 88 / ms_ / 1e6, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                        "frac": round(n_ * 88 / ms_ / 1e6 / HBM_PEAK_GBS, 4), "algorithmic_bytes_per_point": 88,
+                                        "definition": "24 B point + 8 corner values x 4 B + 8 B value + 24 B gradient per point / launch duration (HIP events)"}}
+                    if not args.no_cpu_baseline:
+                        oo_ = graft.load_oracle().Oracle(cfg); oo_.set_grid(esdf, (0, 0, 0), res, capi.GRID_ESDF)
+                        ph = pts_[:2000].cpu().numpy()
+                        rr_ = np.array([np.concatenate([[dd], gg]) for dd, gg in (oo_.esdf_trilinear(q_) for q_ in ph)])
+                        got_ = np.concatenate([dv_[:2000].cpu().numpy()[:, None], dg_[:2000].cpu().numpy()], axis=1)
+                        ent["rel_err_vs_oracle"] = float(np.linalg.norm(got_ - rr_) / max(np.linalg.norm(rr_), 1e-300))
+                        ent["rel_err_vs_oracle_of"] = "the first 2 000 points (bitwise equal = 0.0)"
+                    extra.append(ent)
+                    del pts_, dv_, dg_
+            except Exception as e:      # noqa: BLE001
+                extra.append({"name": "ESDF sampler", "error": str(e)})
             # configs[2] END TO END: the 128 trajectories optimised concurrently (isdf_optimize_lbfgs_batch: host MINCO + L-BFGS per
             # trajectory, one batched device sweep per round, PCIe included) - 30 iterations each
             try:
@@ -568,11 +736,14 @@ def main():
             except Exception as e:      # noqa: BLE001
                 extra.append({"name": "C3 end to end", "error": str(e)})
             if extra and isinstance(extra[0], dict) and "error" not in extra[0]:
-                extra[0]["roofline_issue"] = issue_from_counters(os.path.join(ROOT, "profiles", "pmc_counters_c3.json"), kernel_source_hash())
+                extra[0]["roofline"] = issue_from_counters(os.path.join(ROOT, "profiles", "pmc_counters_c3.json"), kernel_source_hash())
+            # the nominal byte model, spelled out where it stops being a bound
+            roofline["nominal_bytes"]["exceeds_1_on"] = [e_["name"] for e_ in extra if isinstance(e_, dict) and e_.get("nominal_bytes_exceeds_hbm_peak")]
 
         # ---- through the drop-in boundary (PCIe inclusive, synchronous, accumulate) - informational, never `value`
         host_ms = None
         host_ms_multi = None
+        host_ms_multi8 = None
         host_timer = None
         cb_native_ms = None
         x0 = None
@@ -599,6 +770,11 @@ def main():
                     natm = native_boundary_ms(pkg, em, N, T, cm, None)
                     host_ms_multi = None if natm is None else round(natm[0], 4)
                     del em
+                    em8 = pkg.Engine(cfg, devices=[local_rank] * 8)
+                    em8.set_grid(esdf, (0, 0, 0), res, capi.GRID_ESDF); em8.set_shape(shape)
+                    natm8 = native_boundary_ms(pkg, em8, N, T, cm, None)
+                    host_ms_multi8 = None if natm8 is None else round(natm8[0], 4)
+                    del em8
                 except Exception:       # noqa: BLE001
                     host_ms_multi = None
             else:
@@ -675,14 +851,19 @@ def main():
             "config": {"workload": f"V3 ESDF-tile sweep: 1 trajectory x {N} pieces x {K + 1} samples/piece, {args.grid}^3 fp32 ESDF "
                                    f"@ {res:g} m, kernel_size {args.kernel_size}, box robot (1.6,0.3,0.3) central-diff grad, "
                                    f"occ_thresh = 0, cull {'on' if args.cull else 'off'}"
-                                   + ("" if world == 1 else (f" = BASELINE configs[3], {N // world}-{-(-N // world)} pieces per rank" if N == 400 else "")),
+                                   + (" = BASELINE configs[1]" if (world == 1 and N == 40) else "")
+                                   + ("" if world == 1 else (f" = BASELINE configs[3], {N // world}-{-(-N // world)} pieces per rank" if N == 400 else ""))
+                                   + ("" if world == 1 else ".  NOTE: the --gpus 1 line of this bench is ANOTHER workload (configs[1]: 40 pieces, 2 600 evals per step): "
+                                      "value(N) / value(1) is not a scaling efficiency - use `speedup` (= value / one_gpu_same_workload.evals_per_s, same run) "
+                                      "and configs[0] (configs[2] sharded by trajectory, with its own one-GPU figure)"),
                        "pieces": N, "samples_per_piece": K + 1, "grid": args.grid, "kernel_size": args.kernel_size,
                        "sharding": ("none" if world == 1 else ("pieces contiguous by rank; each piece's 19 rows + cost stored by its owner into every peer's output inside the step's launches" if mode == "fused" else "pieces contiguous by rank + all_reduce(sum) of 1+19N doubles")),
                        "collective": collective,
                        "rccl_all_reduce_ms_per_step": None if rccl_ms is None else round(rccl_ms, 5)},
             "roofline": roofline, "roofline_issue": issue, "cpu_baseline": cpu, "configs": extra,
+            "one_gpu_same_workload": one_gpu, "speedup": None if one_gpu is None else round(value / one_gpu["evals_per_s"], 3),
             "value_steady": value_steady, "parity_rel_err_vs_oracle": parity, "host_api_ms": None if host_ms is None else round(host_ms, 4), "host_api_timer": host_timer,
-            "host_api_ms_two_shards_one_gpu": host_ms_multi,
+            "host_api_ms_two_shards_one_gpu": host_ms_multi, "host_api_ms_eight_shards_one_gpu": host_ms_multi8,
             "stats_last_step_rank0": stats, "lbfgs": lbfgs, "hbm_copy_gbs_measured": hbm_copy,
         }
         print(json.dumps(result), flush=True)
