@@ -123,9 +123,10 @@ struct SweptParams {
     int *point_piece;           // [M]
     int *point_nr;              // [M] scan kernel: intervals | scan passes << 8
     double *task_buf;           // [M][32][6] per (point, interval): in (lb, ub, seed), out (t, sdf, gradient, counters)
-    unsigned *task_map;         // [<= 32 M] task list of the descent kernel: point (relative to point_begin) << 5 | interval
+    unsigned *task_map;         // [<= 32 M] task list of the descent: point (relative to point_begin) << 5 | interval
     unsigned *point_lmask;      // [M] bit r: the descent of interval r was long last step (set by the descent kernel, consumed by the scan's list builder)
-    unsigned *words;            // [0] tasks [1] scan ticket [2] tasks at the front of the list
+    unsigned *words;            // [0] tasks at the front of the list (long last step) [2] tasks at its back: zeroed by the prepare kernel, reserved by the
+                                // scan kernel's workgroups
     int direct_records;         // 1: the records in point_partial were written by the fixed-t* kernel (no task slots)
     unsigned long long *point_stat;   // [M] active | intervals << 1 | passes << 9 | descent iterations << 25 (statistics)
     double *hist;               // [N] per-piece sum of gdT

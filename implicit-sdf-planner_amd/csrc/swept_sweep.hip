@@ -4,7 +4,7 @@
 //   (getSDFofSweptVolume :710-747, choiceTInit :367-445, gradientDescent :1000-1062,
 //    getSDF_DOTAtTimeStampOptimized :593-662, getStateOnTrajStamp :332-341).
 //
-// One optimizer step = five launches (prepare, scan, descent, back-prop, reduce):
+// One optimizer step = five launches (prepare, scan, descent, back-prop, reduce; ~1.5 us between two of them on this system):
 //   swept_prepare_kernel  one block: the "traj_duration" state (refreshed only when the total is < 300 s, :287-296),
 //                         the coarse time table t += 0.2 by repeated fp64 addition (one lane, like the reference loop),
 //                         then the pose (position + rotation) at every coarse time, shared by all obstacle points.
@@ -42,7 +42,6 @@ namespace isdf {
 constexpr int SW_WAVES = 4;
 constexpr int SW_MAX_RANGES = 32;                // intervals kept per point (more set the overflow flag); 5 bits of a task word
 constexpr int TASK_STRIDE = 6;                   // doubles per (point, interval) slot: in (lb, ub, seed) / out (t, sdf, grad(3), counters)
-constexpr int SCAN_PER = 16;                     // points per thread and round in the task-list scan
 constexpr int LPT_TASK = 8;                      // descents of >= this many passes (last step) are dispatched first
 
 // The trajectory as the kernels of this file see it: durations T[0..N) (LDS copies are padded to a multiple of 4 with a
@@ -116,6 +115,7 @@ __global__ __launch_bounds__(1024) void swept_prepare_kernel(const SweptParams P
         s_n = n;
         *P.n_coarse = n;
         for (int k = 0; k < 8; k++) if (k != 4) P.stats[k] = 0ull;      // [4] = overflow: sticky until the host reads it
+        P.words[0] = 0u; P.words[2] = 0u;                               // the scan kernel's task counters (front / back of the list)
     }
     __syncthreads();
     const int n = s_n;
@@ -271,14 +271,12 @@ __device__ __forceinline__ void eval_lane(const SweptParams &P, const TrajL<LDS>
 // intervals and per interval (lb, ub, seed) in the point's task slots.  The workgroup that finishes last turns the interval
 // counts into the task list of the descent kernel (exclusive scan in point order: deterministic).
 // (WGM: at least 4 wavefronts per SIMD - without the cap the compiler spends 450 registers, one workgroup per CU)
-template <int KIND, bool LDS, int WGM = 0>
-__global__ __launch_bounds__(64 * SW_WAVES, WGM ? 4 : 1) void swept_scan_kernel(const SweptParams P) {
+template <int KIND, bool LDS, int WGM>
+__device__ __forceinline__ void scan_body(const SweptParams &P, double *s_dyn, const int block) {
     constexpr bool MESH = WGM != 0;      // one point per WORKGROUP of WGM wavefronts (mesh_eval_wg above: larger mesh robots), else one per wavefront
     static_assert(!WGM || KIND == ISDF_SHAPE_MESH, "workgroup-cooperative evaluation is the mesh kind's");
-    extern __shared__ double s_dyn[];
     __shared__ double s_rl[SW_WAVES][SW_MAX_RANGES], s_rr[SW_WAVES][SW_MAX_RANGES];
-    __shared__ unsigned long long s_wt[SW_WAVES];
-    __shared__ int s_last;
+    __shared__ unsigned s_cnt[SW_WAVES][2], s_base[2];
     __shared__ double s_mesh[MESH ? mesh_wg_stage(WGM) + MESH_WG_RES : 1];
     __shared__ MeshFrames s_frames[MESH ? WGM : 1];
     const unsigned long long dbg_t0 = (ISDF_SWEEP_STATS && P.dbg) ? wall_clock64() : 0ull;
@@ -286,9 +284,10 @@ __global__ __launch_bounds__(64 * SW_WAVES, WGM ? 4 : 1) void swept_scan_kernel(
     if constexpr (LDS) tr = traj_stage(s_dyn, P.T, P.coeffs, P.N);
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int pt = P.point_begin + (MESH ? (int)blockIdx.x : (int)blockIdx.x * SW_WAVES + wave);
+    const int pt = P.point_begin + (MESH ? block : block * SW_WAVES + wave);
     const bool writer = lane == 0 && (!MESH || wave == 0);       // (the four wavefronts of a mesh workgroup hold the same results)
     MeshWG mwg{s_mesh + wave * 64 * 3, s_mesh + (MESH ? mesh_wg_stage(WGM) : 0), 0, wave, &s_frames[MESH ? wave : 0], WGM};
+    int my_nr = 0;
     if (pt < P.point_end) {
     unsigned long long *const dbg = (ISDF_SWEEP_STATS && P.dbg) ? P.dbg + (size_t)pt * 4 : nullptr;
     if (dbg && writer) { dbg[0] = dbg_t0; dbg[1] = wall_clock64(); }
@@ -407,75 +406,50 @@ __global__ __launch_bounds__(64 * SW_WAVES, WGM ? 4 : 1) void swept_scan_kernel(
         P.point_nr[pt] = n_ranges | (n_pass << 8);
         if (dbg) dbg[3] = (wall_clock64() << 16) | (unsigned long long)(n_pass & 0xFFF) | ((unsigned long long)(n_ranges & 0xF) << 12);
     }
+    my_nr = n_ranges;
     }   // pt < point_end
 
-    // ---------------- the last workgroup builds the descent kernel's task list.
-    // The descent launch lasts as long as its longest wavefront, and wavefronts that start late make that worse; the
-    // trajectory moves little between optimizer steps, so the previous step's pass counts say which descents are long: tasks
-    // that took >= LPT_TASK passes last step go to the FRONT of the list, the others fill it from the BACK, in reverse
-    // (124 -> 92 us on the bench map).  Scheduling only: which wavefront evaluates what has no influence on any result.  One
-    // exclusive scan in point order: deterministic.  (The same ordering applied to THIS kernel's points made it slower -
-    // the heavy wavefronts then sit together on the same CUs - and was dropped.)
-    __syncthreads();
-    if (tid == 0) {
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-        const unsigned t = atomicAdd(&P.words[1], 1u);
-        s_last = t == gridDim.x - 1 ? 1 : 0;
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-    }
-    __syncthreads();
-    if (!s_last) return;
-    const int n = P.point_end - P.point_begin;
-    const unsigned cap = (unsigned)n * SW_MAX_RANGES;           // task_map region of this shard: [0, cap)
-    unsigned long long run_t = 0;                                // running (long << 32 | short) task counts
-    for (int sb = 0; sb < n; sb += 256 * SCAN_PER) {
-        const int p0 = sb + tid * SCAN_PER;
-        unsigned vt[SCAN_PER];                                   // per point: bit r set = task r was long last step; count in bits 32..
-        int nr[SCAN_PER];
-        unsigned long long loc_t = 0;
-#pragma unroll
-        for (int k = 0; k < SCAN_PER; k++) {
-            nr[k] = 0; vt[k] = 0u;
-            if (p0 + k < n) {
-                const int w = P.point_nr[P.point_begin + p0 + k];         // plain loads: the acquire fence above made the other workgroups' stores visible
-                nr[k] = w & 0xFF;
-                // bit r: the descent of interval r took >= LPT_TASK passes last step (left by the descent kernel, cleared here)
-                const unsigned m = P.point_lmask[P.point_begin + p0 + k];
-                vt[k] = nr[k] >= 32 ? m : (m & ((1u << nr[k]) - 1u));
-                if (m) P.point_lmask[P.point_begin + p0 + k] = 0u;
-                const unsigned nl = (unsigned)__popc(vt[k]);
-                loc_t += ((unsigned long long)nl << 32) | (unsigned long long)(nr[k] - (int)nl);
-            }
+    // ---------------- this workgroup's intervals join the descent kernel's task list.
+    // The descent launch lasts as long as its longest wavefront, and wavefronts that start late make that worse; the trajectory
+    // moves little between optimizer steps, so the previous step's pass counts say which descents are long: tasks that took
+    // >= LPT_TASK passes last step go to the FRONT of the list, the others fill it from the BACK (124 -> 92 us on the bench map).
+    // Scheduling only: which wavefront evaluates what has no influence on any result (every task has its own result slot), so
+    // the list needs no particular order within the two classes: ONE reservation per workgroup and class (two atomics; round 3
+    // built the list in point order in the workgroup that finished last - 15 us of one workgroup between the two launches).
+    // (words[0] / words[2]: tasks at the front / at the back, zeroed by the prepare kernel.)
+    {
+        unsigned vt = 0u;                                       // bit r: task r of my point was long last step
+        if (pt < P.point_end && my_nr > 0 && (!MESH || wave == 0)) {
+            const unsigned m = P.point_lmask[pt];
+            vt = my_nr >= 32 ? m : (m & ((1u << my_nr) - 1u));
+            if (m && lane == 0) P.point_lmask[pt] = 0u;         // consumed (the descent kernel sets it again)
         }
-        unsigned long long inc_t = loc_t;
-#pragma unroll
-        for (int off = 1; off < 64; off <<= 1) {
-            const unsigned long long ut = __shfl_up(inc_t, off, 64);
-            if (lane >= off) inc_t += ut;
+        const int nr_w = (pt < P.point_end && (!MESH || wave == 0)) ? my_nr : 0;
+        const unsigned nl = (unsigned)__popc(vt), ns = (unsigned)nr_w - nl;
+        if (lane == 0) { s_cnt[wave][0] = nl; s_cnt[wave][1] = ns; }
+        __syncthreads();
+        if (tid == 0) {
+            unsigned tl = 0, ts = 0;
+            for (int w = 0; w < SW_WAVES; w++) { tl += s_cnt[w][0]; ts += s_cnt[w][1]; }
+            s_base[0] = tl ? atomicAdd(&P.words[0], tl) : 0u;
+            s_base[1] = ts ? atomicAdd(&P.words[2], ts) : 0u;
         }
-        if (lane == 63) s_wt[wave] = inc_t;
         __syncthreads();
-        unsigned long long base_t = run_t, tile_t = 0;
-#pragma unroll
-        for (int w = 0; w < SW_WAVES; w++) { if (w < wave) base_t += s_wt[w]; tile_t += s_wt[w]; }
-        base_t += inc_t - loc_t;
-        unsigned o_tl = (unsigned)(base_t >> 32), o_ts = (unsigned)base_t;
-#pragma unroll
-        for (int k = 0; k < SCAN_PER; k++)
-            if (p0 + k < n) {
-                for (int r = 0; r < nr[k]; r++) {
-                    const unsigned word = ((unsigned)(p0 + k) << 5) | (unsigned)r;
-                    if ((vt[k] >> r) & 1u) P.task_map[o_tl++] = word; else P.task_map[cap - 1u - (o_ts++)] = word;
-                }
-            }
-        run_t += tile_t;
-        __syncthreads();
+        unsigned o_l = s_base[0], o_s = s_base[1];
+        for (int w = 0; w < wave; w++) { o_l += s_cnt[w][0]; o_s += s_cnt[w][1]; }
+        const unsigned cap = (unsigned)(P.point_end - P.point_begin) * SW_MAX_RANGES;      // task_map region of this shard: [0, cap)
+        if (lane < nr_w) {
+            const unsigned word = ((unsigned)(pt - P.point_begin) << 5) | (unsigned)lane;
+            const unsigned below = (1u << lane) - 1u;
+            if ((vt >> lane) & 1u) P.task_map[o_l + (unsigned)__popc(vt & below)] = word;
+            else P.task_map[cap - 1u - (o_s + (unsigned)__popc(~vt & below))] = word;
+        }
     }
-    if (tid == 0) {
-        P.words[0] = (unsigned)(run_t >> 32) + (unsigned)run_t;   // tasks
-        P.words[2] = (unsigned)(run_t >> 32);                     // ... of which at the front
-        P.words[1] = 0u;
-    }
+}
+template <int KIND, bool LDS, int WGM = 0>
+__global__ __launch_bounds__(64 * SW_WAVES, WGM ? 4 : 1) void swept_scan_kernel(const SweptParams P) {
+    extern __shared__ double s_dyn[];
+    scan_body<KIND, LDS, WGM>(P, s_dyn, (int)blockIdx.x);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -490,10 +464,13 @@ __global__ __launch_bounds__(64 * SW_WAVES, WGM ? 4 : 1) void swept_scan_kernel(
 constexpr int GD_SPEC = 5;                       // look-ahead blocks
 __device__ __forceinline__ int gd_block_base(int m) { return m == 0 ? 18 : 25 + 7 * (m - 1); }
 
-template <int KIND, bool LDS, int WGM = 0>
-__global__ __launch_bounds__(64 * SW_WAVES, WGM ? 4 : 1) void swept_descent_kernel(const SweptParams P) {
+// (Round 4, measured and dropped: scan and descent as ONE launch - the descent workgroups riding behind the scan's, taking every
+// interval the moment it is published through task words that are their own ready flags.  Correct, but the fused kernel needs the
+// descent's 125 registers for the scan role too (4 instead of 6 wavefronts per SIMD: scan span 75 -> 167 us) and its 1 944 descent
+// workgroups do not fit beside each other: 0.43 ms against 0.129 ms for the two launches, profiles/r4_v1_timing_fused_search_dropped.txt.)
+template <int KIND, bool LDS, int WGM>
+__device__ __forceinline__ void descent_body(const SweptParams &P, double *s_dyn, const unsigned block, const unsigned n_blocks) {
     constexpr bool MESH = WGM != 0;      // one task per WORKGROUP of WGM wavefronts (mesh_eval_wg), else one per wavefront
-    extern __shared__ double s_dyn[];
     __shared__ double s_mesh[MESH ? mesh_wg_stage(WGM) + MESH_WG_RES : 1];
     __shared__ MeshFrames s_frames[MESH ? WGM : 1];
     TrajL<LDS> tr{P.T, P.coeffs, P.N};
@@ -502,9 +479,10 @@ __global__ __launch_bounds__(64 * SW_WAVES, WGM ? 4 : 1) void swept_descent_kern
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const bool writer = lane == 0 && (!MESH || wave == 0);
     MeshWG mwg{s_mesh + wave * 64 * 3, s_mesh + (MESH ? mesh_wg_stage(WGM) : 0), 0, wave, &s_frames[MESH ? wave : 0], WGM};
-    const unsigned n_tasks = (unsigned)__builtin_amdgcn_readfirstlane((int)P.words[0]), n_front = (unsigned)__builtin_amdgcn_readfirstlane((int)P.words[2]);
     const unsigned cap = (unsigned)(P.point_end - P.point_begin) * SW_MAX_RANGES;
-    const unsigned n_waves = (unsigned)__builtin_amdgcn_readfirstlane((int)(MESH ? gridDim.x : gridDim.x * SW_WAVES));
+    const unsigned n_front = (unsigned)__builtin_amdgcn_readfirstlane((int)P.words[0]);
+    const unsigned n_tasks = n_front + (unsigned)__builtin_amdgcn_readfirstlane((int)P.words[2]);
+    const unsigned n_waves = (unsigned)__builtin_amdgcn_readfirstlane((int)(MESH ? n_blocks : n_blocks * SW_WAVES));
     const double D = *P.traj_duration;
     const int gmode = P.shape.grad_mode;
     const bool fd_central = (KIND != ISDF_SHAPE_MESH) && gmode == ISDF_GRAD_CENTRAL;
@@ -513,7 +491,7 @@ __global__ __launch_bounds__(64 * SW_WAVES, WGM ? 4 : 1) void swept_descent_kern
     // this lane's role in a pass: block (0..6) and offset inside it (0 = the pose lane)
     const int gd_blk = lane < 18 ? -1 : (lane < 25 ? 0 : (lane < 60 ? (lane - 25) / 7 + 1 : (lane == 60 ? GD_SPEC + 1 : -1)));
     const int gd_off = lane < 18 ? 0 : (lane < 25 ? lane - 18 : (lane < 60 ? (lane - 25) % 7 : 0));
-    for (unsigned task = MESH ? blockIdx.x : blockIdx.x * SW_WAVES + wave, rounds = 0; task < n_tasks && rounds < (1u << 16); task += n_waves, rounds++) {
+    for (unsigned task = MESH ? block : block * SW_WAVES + wave, rounds = 0; task < n_tasks && rounds < (1u << 16); task += n_waves, rounds++) {
         const unsigned tm = (unsigned)__builtin_amdgcn_readfirstlane((int)(task < n_front ? P.task_map[task] : P.task_map[cap - 1u - (task - n_front)]));
         const unsigned long long dbg_t0 = (ISDF_SWEEP_STATS && P.dbg) ? wall_clock64() : 0ull;
         const int rel = (int)(tm >> 5), r = (int)(tm & 31u);
@@ -644,6 +622,11 @@ __global__ __launch_bounds__(64 * SW_WAVES, WGM ? 4 : 1) void swept_descent_kern
     }
 }
 
+template <int KIND, bool LDS, int WGM = 0>
+__global__ __launch_bounds__(64 * SW_WAVES, WGM ? 4 : 1) void swept_descent_kernel(const SweptParams P) {
+    extern __shared__ double s_dyn[];
+    descent_body<KIND, LDS, WGM>(P, s_dyn, blockIdx.x, gridDim.x);
+}
 // The minimisers are GIVEN (isdf_eval_swept_at_tstar): one thread per obstacle point evaluates the robot SDF and its
 // body-frame gradient at tstar[pt] (getSDFAtTimeStamp :550-556, getGradPrelAtTimeStamp :566-572) and leaves the same record
 // the sweep kernel leaves; a negative or NaN tstar means "no interval qualified" (min sdf 10, no penalty; :717).
@@ -670,8 +653,7 @@ __global__ __launch_bounds__(64) void swept_fixed_kernel(const SweptParams P, co
 
 // Back-prop at t* (back_end_optimizer.hpp:578-646): one THREAD per obstacle point - penalty (mu = 0.01), pose Jacobians,
 // flatness reverse mode, the 18 + 1 + 1 doubles the reduction sums.
-__global__ __launch_bounds__(128) void swept_backprop_kernel(const SweptParams P) {
-    const int pt = P.point_begin + blockIdx.x * blockDim.x + threadIdx.x;
+__device__ __forceinline__ void backprop_body(const SweptParams &P, const int pt) {
     if (pt >= P.point_end) return;
     const TrajView tr{P.T, P.coeffs, P.N};
     double *o = P.point_partial + (size_t)pt * PARTIAL_STRIDE;
@@ -768,11 +750,10 @@ __device__ __forceinline__ double wave_sum_dpp(double v) {
     v += dpp_f64<0x140>(v);       // row_mirror: every lane of a row of 16 holds the row total
     return ((rlane(v, 0) + rlane(v, 16)) + rlane(v, 32)) + rlane(v, 48);
 }
-__global__ __launch_bounds__(256) void swept_reduce_kernel(const SweptParams P, double *out, double *hist) {
+__device__ __forceinline__ void reduce_body(const SweptParams &P, double *out, double *hist, const int i) {
     __shared__ double s_red[4][20];
     __shared__ unsigned long long s_cnt[4][4];
     __shared__ int s_last;
-    const int i = blockIdx.x;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     double acc[20];
 #pragma unroll
@@ -868,6 +849,15 @@ __global__ __launch_bounds__(256) void swept_reduce_kernel(const SweptParams P, 
         }
     }
     if (rdbg && tid == 0) rdbg[5] = wall_clock64();
+}
+
+// (Round 4, measured and dropped: back-prop and sums as ONE launch, the reduction workgroups waiting behind the back-prop workgroups
+// for a counter - 29.0 us against 10.3 + 12.7 us for the two launches, whose gap on this system is ~1.5 us.)
+__global__ __launch_bounds__(128) void swept_backprop_kernel(const SweptParams P) {
+    backprop_body(P, P.point_begin + (int)(blockIdx.x * blockDim.x + threadIdx.x));
+}
+__global__ __launch_bounds__(256) void swept_reduce_kernel(const SweptParams P, double *out, double *hist) {
+    reduce_body(P, out, hist, (int)blockIdx.x);
 }
 
 void launch_swept_prepare(const SweptParams &P, hipStream_t stream) {
