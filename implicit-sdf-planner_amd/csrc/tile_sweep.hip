@@ -543,6 +543,7 @@ __global__ __launch_bounds__(64 * SW_SAMPLES, FUSED ? 3 : sweep_waves_per_simd(K
     __shared__ __attribute__((aligned(16))) int s_plan[SW_SAMPLES][4];                         // per sample: candidates, ring head, finished
     __shared__ double s_res[SW_SAMPLES][SW_NEAR_CAP / 64][ACC_STRIDE];   // per chunk: the 8 collision sums
     __shared__ int s_resn[SW_SAMPLES][SW_NEAR_CAP / 64][2];       // per chunk: exact pairs, active pairs
+    __shared__ MeshFrames s_mframes[KIND == ISDF_SHAPE_MESH ? SW_SAMPLES : 1];   // mesh robots: the quad walks' frames, one set per wavefront
 
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -1052,6 +1053,64 @@ __global__ __launch_bounds__(64 * SW_SAMPLES, FUSED ? 3 : sweep_waves_per_simd(K
             const unsigned ent = s_near[ls][(chead + (cc << 6) + min(l, n - 1)) & (SW_NEAR_CAP - 1)];
             double v[ACC_STRIDE] = {0, 0, 0, 0, 0, 0, 0, 0};
             bool is_pair = false, is_grad = false;
+            if constexpr (KIND == ISDF_SHAPE_MESH) {
+                // Mesh robot: the hierarchy is walked by QUADS (dev_mesh.hpp: 4 lanes per voxel, one per child of the node, the walk
+                // wave-uniform, frames in LDS) - 16 voxels of the chunk at a time; consecutive ring entries are neighbouring voxels of
+                // a row, so the 16 open nearly the same nodes.  The per-lane walk of round 3 (every lane chasing its own 368-byte
+                // records with an 800-byte private stack, node and triangle branches serialised) ran at 16 % of the VALU issue rate.
+                bool want = false;
+                d3 prel = mk3(0, 0, 0), pm = prel;
+                int csa = ls;
+                asm volatile("" : "+v"(csa));
+                if (seg_valid && l < n && !(ISDF_SWEEP_STATS && (P.dbg_flags & 1))) {
+                    const SweepPose &qa = s_pose[csa];
+                    const int gx = qa.lo[0] + (int)(ent & 1023u), gy = qa.lo[1] + (int)((ent >> 10) & 1023u), gz = qa.lo[2] + (int)(ent >> 20);
+                    const d3 ctr = mk3((gx + 0.5) * G.res + G.bmin[0], (gy + 0.5) * G.res + G.bmin[1], (gz + 0.5) * G.res + G.bmin[2]);
+                    const d3 pos = mk3(qa.pos[0], qa.pos[1], qa.pos[2]);
+                    m3 R;
+#pragma unroll
+                    for (int k = 0; k < 9; k++) R.a[k] = qa.R[k];
+                    pm = ctr - pos;
+                    prel = mat_tmul(R, pm);
+                    if (!(fmax(fmax(fabs(prel.x), fabs(prel.y)), fabs(prel.z)) > P.bd_half)) { is_pair = true; want = true; }
+                }
+                double sdf = 0.0;
+                d3 g = mk3(0, 0, 0);
+                bool below = false;
+                const unsigned long long wm = __ballot(want);
+                for (int r = 0; r < 4; r++) {
+                    if (!((wm >> (16 * r)) & 0xFFFFull)) continue;                       // (wave-uniform)
+                    const int src = 16 * r + (lane >> 2);                                // the voxel this quad works on
+                    const d3 qp = mk3(__shfl(prel.x, src, 64), __shfl(prel.y, src, 64), __shfl(prel.z, src, 64));
+                    const bool on = (wm >> src) & 1ull;
+                    double s2 = 0.0;
+                    d3 g2 = mk3(0, 0, 0);
+                    const bool b2 = mesh_sdf_grad_below_quad(P.shape.mesh, &s_mframes[wave], qp, on, P.safety_hor, s2, g2);
+                    const int from = 4 * (lane & 15);                                    // back to the voxel's own lane
+                    const double s3 = __shfl(s2, from, 64), gx3 = __shfl(g2.x, from, 64), gy3 = __shfl(g2.y, from, 64), gz3 = __shfl(g2.z, from, 64);
+                    const int b3 = __shfl(b2 ? 1 : 0, from, 64);
+                    if ((lane >> 4) == r) { sdf = s3; g = mk3(gx3, gy3, gz3); below = b3 != 0; }
+                }
+                if (want && below) {
+                    double f = 0.0, df = 0.0;
+                    smoothed_l1_inv(P.safety_hor - sdf, P.mu, P.inv_mu, f, df);
+                    if (f > 0.0) {
+                        is_grad = true;
+                        v[0] = f;
+                        int csb = ls;
+                        asm volatile("" : "+v"(csb));
+                        const SweepPose &qb = s_pose[csb];
+                        m3 R;
+#pragma unroll
+                        for (int k = 0; k < 9; k++) R.a[k] = qb.R[k];
+                        d4 quat; quat.w = qb.quat[0]; quat.x = qb.quat[1]; quat.y = qb.quat[2]; quat.z = qb.quat[3];
+                        const d3 wg = mat_mul(R, g);
+                        v[1] = df * wg.x; v[2] = df * wg.y; v[3] = df * wg.z;
+                        const d4 sq = quat_step_grad(quat, g, pm);
+                        v[4] = -df * sq.w; v[5] = -df * sq.x; v[6] = -df * sq.y; v[7] = -df * sq.z;
+                    }
+                }
+            } else
             if (seg_valid && l < n && !(ISDF_SWEEP_STATS && (P.dbg_flags & 1))) {
                 // The pose (16 doubles) is READ FROM LDS where it is used - once here, once more for the force terms below -
                 // instead of living in 32 scalar registers for the whole loop: the loop's scalar state no longer fits the SGPR
@@ -1074,15 +1133,7 @@ __global__ __launch_bounds__(64 * SW_SAMPLES, FUSED ? 3 : sweep_waves_per_simd(K
                     is_pair = true;
                     double f = 0.0, df = 0.0;
                     d3 g = mk3(0, 0, 0);
-                    if constexpr (KIND == ISDF_SHAPE_MESH) {
-                        // one hierarchy query gives sdf AND gradient, and proves "no penalty" early for far voxels
-                        double sdf;
-                        // (per lane: the 64 voxels of a chunk lie all around the robot - the wave-cooperative walk of dev_mesh.hpp,
-                        // which pays off between the neighbouring queries of the swept-volume sweep, measured 2x SLOWER here)
-                        if (mesh_sdf_grad_below(P.shape.mesh, prel, P.safety_hor, sdf, g)) smoothed_l1_inv(P.safety_hor - sdf, P.mu, P.inv_mu, f, df);
-                    } else {
-                        smoothed_l1_inv(P.safety_hor - shape_sdf<KIND, IDENT>(P.shape, prel), P.mu, P.inv_mu, f, df);
-                    }
+                    smoothed_l1_inv(P.safety_hor - shape_sdf<KIND, IDENT>(P.shape, prel), P.mu, P.inv_mu, f, df);
                     if (f > 0.0) {
                         if constexpr (KIND != ISDF_SHAPE_MESH) g = shape_grad<KIND, IDENT>(P.shape, prel);
                         is_grad = true;
