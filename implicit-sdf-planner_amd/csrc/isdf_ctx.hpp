@@ -103,6 +103,7 @@ struct isdf_ctx {
     std::vector<isdf_ctx *> peers;
     bool is_peer = false;                       // owned by a lead: not handed to the caller
     hipEvent_t mev_in = nullptr, mev_done = nullptr;      // lead: inputs ready on the caller's stream / the step's sum has run; peer: shard finished
+    bool multi_pull = false;                              // lead: the peers read the lead's inputs in place (peer access both ways)
     bool msum_recorded = false;                           // lead: mev_done has been recorded at least once
     int multi_collective = 0;                   // ISDF_MULTI_*: how the shards' outputs are summed
     void *rccl_lib = nullptr; void *rccl_comm = nullptr;  // RCCL by dlopen (only when asked for): this device's communicator

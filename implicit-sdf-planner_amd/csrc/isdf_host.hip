@@ -837,7 +837,7 @@ static int eval_device_impl(isdf_ctx *c, int n_traj, int N, const double *d_T, c
 // after which the caller's stream holds the full [cost | gradT | gradC] - exactly what the single-device step leaves.
 // ---------------------------------------------------------------------------------------------------------------------------
 constexpr int MULTI_TAIL = 8;
-struct MultiParts { const double *p[XCHG_MAX_WORLD]; int n; };
+struct MultiParts { const double *p[XCHG_MAX_WORLD]; const unsigned long long *st[XCHG_MAX_WORLD]; int n; };   // st[0] != null: the shards' statistics words are read in place
 // the 8 statistics words of a shard behind its packed outputs, as doubles: they ride through whichever sum is in force
 __global__ void multi_tail_kernel(const unsigned long long *stats, double *tail) {
     if (threadIdx.x < MULTI_TAIL) tail[threadIdx.x] = (double)stats[threadIdx.x];
@@ -848,8 +848,14 @@ __global__ void multi_tail_kernel(const unsigned long long *stats, double *tail)
 __global__ __launch_bounds__(256) void multi_sum_kernel(double *out, MultiParts parts, size_t count, unsigned long long *stats, int all_stats) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < count + MULTI_TAIL) {
-        double s = parts.p[0][i];
-        for (int r = 1; r < parts.n; r++) s += parts.p[r][i];
+        double s;
+        if (i >= count && parts.st[0]) {                                    // (peer access: no tail launches, the words are read where they are)
+            s = (double)parts.st[0][i - count];
+            for (int r = 1; r < parts.n; r++) s += (double)parts.st[r][i - count];
+        } else {
+            s = parts.p[0][i];
+            for (int r = 1; r < parts.n; r++) s += parts.p[r][i];
+        }
         if (i < count) out[i] = s;
         else {
             const int k = (int)(i - count);
@@ -937,6 +943,19 @@ extern "C" int isdf_create_multi(isdf_ctx **out, const isdf_config *cfg, const i
             mode = ISDF_MULTI_RCCL;
         } else return bail(ISDF_ERR_INVALID_ARG, "ISDF_MULTI_COLLECTIVE must be peer, staged or rccl");
     }
+    // PULL: with peer access in BOTH directions the peers' kernels read T | coeffs (and, for the swept-volume sweep, read and write
+    // their points' lastTstar) straight in the lead's memory over xGMI - 152 N bytes per step - instead of two to four peer copies
+    // per device and step queued from the calling thread; the lead's sum reads the peers' statistics words in place
+    bool pull = mode == ISDF_MULTI_PEER_SUM && !(getenv("ISDF_MULTI_NO_PULL") && getenv("ISDF_MULTI_NO_PULL")[0] == '1');
+    for (int r = 1; r < n_devices && pull; r++) {
+        if (devices[r] == lead->device) continue;
+        int can = 0;
+        if (hipSetDevice(devices[r]) != hipSuccess || hipDeviceCanAccessPeer(&can, devices[r], lead->device) != hipSuccess || !can) { pull = false; break; }
+        const hipError_t e = hipDeviceEnablePeerAccess(lead->device, 0);
+        if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled) pull = false;
+        (void)hipGetLastError();
+    }
+    lead->multi_pull = pull;
     for (int r = 1; r < n_devices; r++) { all[r]->is_peer = true; lead->peers.push_back(all[r]); }
     lead->multi_collective = mode;
     (void)hipSetDevice(lead->device);
@@ -964,26 +983,34 @@ static int multi_eval_device(isdf_ctx *c, int n_traj, int N, const double *d_T, 
     if (c->msum_recorded) HIPCHK(c, hipStreamWaitEvent(st, c->mev_done, 0));
     HIPCHK(c, hipEventRecord(c->mev_in, st));                              // the caller's inputs are ready from here on
     double *lead_ts = swept ? (d_tstar ? d_tstar : c->d_tstar) : nullptr;
+    const bool pull = c->multi_pull && c->multi_collective == ISDF_MULTI_PEER_SUM;
     MultiParts parts{};
     parts.n = n;
     for (int r = 1; r < n; r++) {
         isdf_ctx *p = c->peers[r - 1];
         HIPCHK(c, hipSetDevice(p->device));
-        int rc = ensure(p, &p->d_in, &p->in_cap, in_T + in_C);
+        int rc = pull ? ISDF_OK : ensure(p, &p->d_in, &p->in_cap, in_T + in_C);
         if (rc == ISDF_OK) rc = ensure(p, &p->d_mpart, &p->mpart_cap, count + MULTI_TAIL);
         if (rc) { c->err = p->err; return rc; }
         HIPCHK(c, hipStreamWaitEvent(p->stream, c->mev_in, 0));
-        HIPCHK(c, hipMemcpyPeerAsync(p->d_in, p->device, d_T, c->device, in_T * sizeof(double), p->stream));
-        HIPCHK(c, hipMemcpyPeerAsync(p->d_in + in_T, p->device, d_coeffs, c->device, in_C * sizeof(double), p->stream));
         long long pb = 0, pe = 0;
-        if (swept && p->M > 0) {                                           // lastTstar of this shard's points travels with it
-            shard_range(p->M, p->rank, p->world, pb, pe);
-            if (pe > pb && lead_ts) HIPCHK(c, hipMemcpyPeerAsync(p->d_tstar + pb, p->device, lead_ts + pb, c->device, (size_t)(pe - pb) * sizeof(double), p->stream));
+        if (pull) {
+            // the shard reads the lead's inputs in place (peer access); lastTstar likewise - every point belongs to ONE shard
+            rc = eval_device_impl(p, n_traj, N, d_T, d_coeffs, p->d_mpart, lead_ts, p->stream, mode, false);
+            if (rc) { c->err = "device " + std::to_string(p->device) + ": " + p->err; return rc; }
+            parts.st[r] = p->d_stats;
+        } else {
+            HIPCHK(c, hipMemcpyPeerAsync(p->d_in, p->device, d_T, c->device, in_T * sizeof(double), p->stream));
+            HIPCHK(c, hipMemcpyPeerAsync(p->d_in + in_T, p->device, d_coeffs, c->device, in_C * sizeof(double), p->stream));
+            if (swept && p->M > 0) {                                           // lastTstar of this shard's points travels with it
+                shard_range(p->M, p->rank, p->world, pb, pe);
+                if (pe > pb && lead_ts) HIPCHK(c, hipMemcpyPeerAsync(p->d_tstar + pb, p->device, lead_ts + pb, c->device, (size_t)(pe - pb) * sizeof(double), p->stream));
+            }
+            rc = eval_device_impl(p, n_traj, N, p->d_in, p->d_in + in_T, p->d_mpart, nullptr, p->stream, mode, false);
+            if (rc) { c->err = "device " + std::to_string(p->device) + ": " + p->err; return rc; }
+            hipLaunchKernelGGL(multi_tail_kernel, dim3(1), dim3(64), 0, p->stream, p->d_stats, p->d_mpart + count);
+            if (swept && pe > pb && lead_ts) HIPCHK(c, hipMemcpyPeerAsync(lead_ts + pb, c->device, p->d_tstar + pb, p->device, (size_t)(pe - pb) * sizeof(double), p->stream));
         }
-        rc = eval_device_impl(p, n_traj, N, p->d_in, p->d_in + in_T, p->d_mpart, nullptr, p->stream, mode, false);
-        if (rc) { c->err = "device " + std::to_string(p->device) + ": " + p->err; return rc; }
-        hipLaunchKernelGGL(multi_tail_kernel, dim3(1), dim3(64), 0, p->stream, p->d_stats, p->d_mpart + count);
-        if (swept && pe > pb && lead_ts) HIPCHK(c, hipMemcpyPeerAsync(lead_ts + pb, c->device, p->d_tstar + pb, p->device, (size_t)(pe - pb) * sizeof(double), p->stream));
         HIPCHK(c, hipEventRecord(p->mev_done, p->stream));
         parts.p[r] = p->d_mpart;
     }
@@ -992,7 +1019,8 @@ static int multi_eval_device(isdf_ctx *c, int n_traj, int N, const double *d_T, 
     if (rc) return rc;
     rc = eval_device_impl(c, n_traj, N, d_T, d_coeffs, c->d_mpart, d_tstar, st, mode, false);
     if (rc) return rc;
-    hipLaunchKernelGGL(multi_tail_kernel, dim3(1), dim3(64), 0, st, c->d_stats, c->d_mpart + count);
+    if (pull) parts.st[0] = c->d_stats;
+    else hipLaunchKernelGGL(multi_tail_kernel, dim3(1), dim3(64), 0, st, c->d_stats, c->d_mpart + count);
     parts.p[0] = c->d_mpart;
     const dim3 grid((unsigned)((count + MULTI_TAIL + 255) / 256)), block(256);
     if (c->multi_collective == ISDF_MULTI_RCCL) {
