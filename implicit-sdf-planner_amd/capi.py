@@ -102,7 +102,7 @@ EXPORTED_SYMBOLS = [
     "isdf_frontend_build", "isdf_frontend_get_shape_kernels", "isdf_frontend_get_map_kernel", "isdf_frontend_check", "isdf_frontend_cspace",
     "isdf_read_pcd", "isdf_read_obj", "isdf_poly_rotation", "isdf_body_transform", "isdf_plan_config_default", "isdf_load_yaml_config",
     "isdf_shape_from_config",
-    "isdf_host_path", "isdf_minco_device", "isdf_mesh_atan2f", "isdf_create_multi", "isdf_multi_info", "isdf_set_shape_grid", "isdf_set_shape_sampled",
+    "isdf_host_path", "isdf_mesh_atan2f", "isdf_create_multi", "isdf_multi_info", "isdf_set_shape_grid", "isdf_set_shape_sampled",
     "isdf_xchg_create", "isdf_xchg_connect", "isdf_xchg_allreduce", "isdf_xchg_fuse", "isdf_xchg_status", "isdf_xchg_destroy",
 ]
 
@@ -155,7 +155,6 @@ def load_library(path=None):
     lib.isdf_get_stats.argtypes = [C.c_void_p, C.POINTER(IsdfStats)]
     lib.isdf_host_path.argtypes = [C.c_void_p]
     lib.isdf_mesh_atan2f.argtypes = [C.POINTER(C.c_float), C.POINTER(C.c_float), C.c_longlong, C.POINTER(C.c_float)]
-    lib.isdf_minco_device.argtypes = [C.c_void_p, C.c_int, C.c_int, dp, dp, C.c_double, dp, dp, dp, dp, dp]
     lib.isdf_set_trajectory.argtypes = [C.c_void_p, C.c_int, dp, dp, C.c_double]
     lib.isdf_num_variables.argtypes = [C.c_void_p]
     lib.isdf_pack_variables.argtypes = [C.c_void_p, dp, dp, dp]

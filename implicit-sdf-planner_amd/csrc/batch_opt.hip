@@ -5,17 +5,16 @@
 // evaluated TOGETHER as one batched integral sweep.  Rounds are GREEDY (a round starts as soon as a share of the trajectories
 // that can submit is waiting) and several are in flight, each on its own stream, the sweeps ordered by events because they
 // share the ctx's scratch - so one round's uploads, downloads and host work run under another round's sweep.
-// MINCO (tau -> T, setParameters, energy; propogateGrad, chain rule) runs
-//   on the trajectories' host threads (csrc/minco_host.hpp; ~10 us per solve on a CPU core) - the default: 128 x 30 iterations
-//       in 124 ms = 2.95e8 point-evals/s end to end, 97 % of the sweep kernel's own rate (tools/batch_opt_bench.py), or
-//   on the device (csrc/minco_dev.hip: one wavefront per trajectory, only x goes up and (cost, g) comes down): a round is then
-//       [forward 148 us | sweep | backward 93 us] - 6N dependent pivots per solve - and the same batch takes 209-324 ms; it is
-//       an experiment behind ISDF_BATCH_DEVICE_MINCO=1, never selected by itself (tested: tests/test_gpu_minco_dev.py).
-// Which trajectories share a round has no influence on results, and the device MINCO performs the host MINCO's operations one
-// for one: either way the iterates are bitwise those of isdf_optimize_lbfgs on each trajectory alone.
+// MINCO (tau -> T, setParameters, energy; propogateGrad, chain rule) runs on the trajectories' host threads
+// (csrc/minco_host.hpp; ~10 us per solve on a CPU core): 128 x 30 iterations in 84-92 ms = 4.0-4.3e8 point-evals/s end to end
+// (tools/batch_opt_bench.py).  A device form (one wavefront per trajectory) existed through round 4 and was REMOVED: a solve
+// is a chain of 3 x 6N dependent steps with an IEEE fp64 division on the critical path of most of them - 140 + 105 us per
+// round even with the band window and the right-hand sides held in registers (round 3, through LDS: 148 + 93 us), the same batch in
+// 200 ms against 88 ms with host threads (DESIGN_HISTORY.md).
+// Which trajectories share a round has no influence on results: the iterates are bitwise those of isdf_optimize_lbfgs on each
+// trajectory alone.
 #include "isdf_ctx.hpp"
 #include "lbfgs_host.hpp"
-#include "minco_dev.hpp"
 #include <chrono>
 #include <cmath>
 #include <cstdlib>
@@ -32,7 +31,6 @@ struct Worker {
     Batch *batch = nullptr;
     int id = 0;
     isdf_host::LbfgsResult result;
-    // host-MINCO rounds only
     isdf_host::MincoS3 minco;
     std::vector<double> T, gdC, gdT, gradP, gradT;
     double energy = 0.0;
@@ -52,10 +50,7 @@ struct Batch {
     int n_submitted = 0, n_finished = 0, n_inflight = 0;
     double min_share = 0.25;      // a round starts when this share of the live trajectories waits (1.0: all of them)
     int error = ISDF_OK;
-    bool device_minco = true;
-    // staging, device MINCO: slot t holds the variables x (n) of trajectory t; res slot t holds [cost | g(n)]
-    std::vector<double> stage_x, stage_res;
-    // staging, host MINCO: slot t holds [T(N) | coeffs(18N)]; out slot t holds the sweep's [cost | gradT | gradC]
+    // staging: slot t holds [T(N) | coeffs(18N)]; out slot t holds the sweep's [cost | gradT | gradC]
     size_t in_per = 0;
     std::vector<double> stage_in, stage_out;
     long long rounds_run = 0, evals_run = 0;
@@ -65,37 +60,14 @@ struct Batch {
 double worker_evaluate(void *instance, const double *x, double *g, const int n) {
     Worker &w = *(Worker *)instance;
     Batch &b = *w.batch;
-    if (!b.device_minco) {
-        // serial part on this trajectory's host thread (tau -> T, MINCO, energy), the sweep in the round, then the adjoint here
-        const int N = b.N;
-        for (int i = 0; i < N; i++) w.T[i] = isdf_host::tau_to_T(x[i]);
-        w.minco.set_parameters(x + N, w.T.data());
-        w.energy = w.minco.energy(w.gdC.data(), w.gdT.data());
-        double *in = b.stage_in.data() + (size_t)w.id * b.in_per;
-        std::memcpy(in, w.T.data(), (size_t)N * sizeof(double));
-        std::memcpy(in + N, w.minco.c.data(), (size_t)18 * N * sizeof(double));
-        {
-            std::unique_lock<std::mutex> lk(b.m);
-            b.submitted[w.id] = 1;
-            b.n_submitted++;
-            b.cv_coord.notify_one();
-            b.cv_worker[w.id].wait(lk, [&] { return b.ready[w.id] != 0; });
-            b.ready[w.id] = 0;
-            if (b.error != ISDF_OK) return INFINITY;
-        }
-        const double *o = b.stage_out.data() + (size_t)w.id * b.ostride;
-        double cost = w.energy + o[0];
-        for (int i = 0; i < N; i++) w.gdT[i] += o[1 + i];
-        for (int i = 0; i < 18 * N; i++) w.gdC[i] += o[1 + N + i];
-        w.minco.propagate_grad(w.gdC.data(), w.gdT.data(), w.gradP.data(), w.gradT.data());
-        double tsum = 0.0;
-        for (int i = 0; i < N; i++) tsum += w.T[i];
-        cost += b.rho * tsum;
-        for (int i = 0; i < N; i++) g[i] = isdf_host::grad_T_to_tau(x[i], w.gradT[i] + b.rho);
-        for (int i = 0; i < 3 * (N - 1); i++) g[N + i] = w.gradP[i];
-        return cost;
-    }
-    std::memcpy(b.stage_x.data() + (size_t)w.id * b.n, x, (size_t)n * sizeof(double));
+    // serial part on this trajectory's host thread (tau -> T, MINCO, energy), the sweep in the round, then the adjoint here
+    const int N = b.N;
+    for (int i = 0; i < N; i++) w.T[i] = isdf_host::tau_to_T(x[i]);
+    w.minco.set_parameters(x + N, w.T.data());
+    w.energy = w.minco.energy(w.gdC.data(), w.gdT.data());
+    double *in = b.stage_in.data() + (size_t)w.id * b.in_per;
+    std::memcpy(in, w.T.data(), (size_t)N * sizeof(double));
+    std::memcpy(in + N, w.minco.c.data(), (size_t)18 * N * sizeof(double));
     {
         std::unique_lock<std::mutex> lk(b.m);
         b.submitted[w.id] = 1;
@@ -105,9 +77,17 @@ double worker_evaluate(void *instance, const double *x, double *g, const int n) 
         b.ready[w.id] = 0;
         if (b.error != ISDF_OK) return INFINITY;
     }
-    const double *r = b.stage_res.data() + (size_t)w.id * (1 + b.n);
-    std::memcpy(g, r + 1, (size_t)n * sizeof(double));
-    return r[0];
+    const double *o = b.stage_out.data() + (size_t)w.id * b.ostride;
+    double cost = w.energy + o[0];
+    for (int i = 0; i < N; i++) w.gdT[i] += o[1 + i];
+    for (int i = 0; i < 18 * N; i++) w.gdC[i] += o[1 + N + i];
+    w.minco.propagate_grad(w.gdC.data(), w.gdT.data(), w.gradP.data(), w.gradT.data());
+    double tsum = 0.0;
+    for (int i = 0; i < N; i++) tsum += w.T[i];
+    cost += b.rho * tsum;
+    for (int i = 0; i < N; i++) g[i] = isdf_host::grad_T_to_tau(x[i], w.gradT[i] + b.rho);
+    for (int i = 0; i < 3 * (N - 1); i++) g[N + i] = w.gradP[i];
+    return cost;
 }
 
 }  // namespace
@@ -126,61 +106,37 @@ extern "C" int isdf_optimize_lbfgs_batch(isdf_ctx *c, int n_traj, int N, const d
     b.submitted.assign(n_traj, 0); b.finished.assign(n_traj, 0); b.ready.assign(n_traj, 0);
     b.cv_worker.reset(new std::condition_variable[n_traj]);
     if (const char *e = getenv("ISDF_BATCH_MIN_SHARE")) { const double v = atof(e); if (v > 0.0 && v <= 1.0) b.min_share = v; }
-    b.stage_x.assign((size_t)n_traj * b.n, 0.0);
-    b.stage_res.assign((size_t)n_traj * (1 + b.n), 0.0);
-    // Where MINCO runs: on the trajectories' host threads.  The device form (csrc/minco_dev.hip: same operations, bitwise the same
-    // iterates - tests/test_gpu_minco_dev.py) is an EXPERIMENT kept behind ISDF_BATCH_DEVICE_MINCO=1 and never selected by itself:
-    // a factorisation is a chain of 6N dependent pivots and one wavefront walks it in 148 + 93 us per round, against ~10 us per
-    // solve on a CPU core - 128 trajectories take 209-324 ms that way against ~100 ms with host threads.
-    b.device_minco = false;
-    if (const char *e = getenv("ISDF_BATCH_DEVICE_MINCO")) b.device_minco = e[0] == '1';
-    if (isdf::minco_backward_lds(N) > 64 * 1024) b.device_minco = false;       // a trajectory's band system must fit in LDS
     b.in_per = (size_t)19 * N;
     for (int t = 0; t < n_traj; t++) {
         Worker &w = b.workers[t];
         w.batch = &b; w.id = t;
-        if (!b.device_minco) {
-            w.minco.set_conditions(heads_pva + 9 * t, tails_pva + 9 * t, N);
-            w.T.assign(N, 0.0); w.gdC.assign((size_t)18 * N, 0.0); w.gdT.assign(N, 0.0);
-            w.gradP.assign((size_t)3 * (N > 1 ? N - 1 : 1), 0.0); w.gradT.assign(N, 0.0);
-        }
+        w.minco.set_conditions(heads_pva + 9 * t, tails_pva + 9 * t, N);
+        w.T.assign(N, 0.0); w.gdC.assign((size_t)18 * N, 0.0); w.gdT.assign(N, 0.0);
+        w.gradP.assign((size_t)3 * (N > 1 ? N - 1 : 1), 0.0); w.gradT.assign(N, 0.0);
     }
-    if (!b.device_minco) { b.stage_in.assign((size_t)n_traj * b.in_per, 0.0); b.stage_out.assign((size_t)n_traj * b.ostride, 0.0); }
-    // device + pinned buffers for a full batch per slot: up to N_SLOTS rounds are in flight, each on its own stream
-    constexpr int N_SLOTS = 6;
-    const size_t nv = (size_t)b.n, n6 = (size_t)6 * N;
+    b.stage_in.assign((size_t)n_traj * b.in_per, 0.0); b.stage_out.assign((size_t)n_traj * b.ostride, 0.0);
+    // device + pinned buffers for a full batch per slot: N_SLOTS rounds are in flight, each on its own stream
+    constexpr int N_SLOTS = 2;
     struct Slot {
-        double *h_pin = nullptr, *d_buf = nullptr; int *d_ids = nullptr; int *h_ids = nullptr;
+        double *h_pin = nullptr, *d_buf = nullptr;
         std::vector<int> active; hipStream_t stream = nullptr; hipEvent_t done = nullptr, sweep_done = nullptr; bool busy = false;
     } slots[N_SLOTS];
-    double *d_cond = nullptr;
-    const size_t x_all = (size_t)n_traj * nv, res_all = (size_t)n_traj * (1 + nv), T_all = (size_t)n_traj * N, C_all = (size_t)n_traj * 3 * n6,
-                 lu_all = (size_t)n_traj * 13 * n6, out_all = (size_t)n_traj * b.ostride;
+    const size_t in_all = (size_t)n_traj * b.in_per, out_all = (size_t)n_traj * b.ostride, word_at = in_all + out_all;
     auto release = [&] {
         for (Slot &q : slots) {
-            if (q.h_pin) (void)hipHostFree(q.h_pin); if (q.h_ids) (void)hipHostFree(q.h_ids);
-            if (q.d_buf) (void)hipFree(q.d_buf); if (q.d_ids) (void)hipFree(q.d_ids);
+            if (q.h_pin) (void)hipHostFree(q.h_pin);
+            if (q.d_buf) (void)hipFree(q.d_buf);
             if (q.done) (void)hipEventDestroy(q.done); if (q.sweep_done) (void)hipEventDestroy(q.sweep_done);
             if (q.stream) (void)hipStreamDestroy(q.stream);
         }
-        if (d_cond) (void)hipFree(d_cond);
     };
     for (Slot &q : slots) {
-        // pinned: [x | res | overflow word]; device: [x | res | T | coeffs | band factors | sweep out]
-        if (hipHostMalloc((void **)&q.h_pin, (std::max(x_all + res_all, (size_t)n_traj * b.in_per + out_all) + 1) * sizeof(double), hipHostMallocDefault) != hipSuccess ||
-            hipHostMalloc((void **)&q.h_ids, (size_t)n_traj * sizeof(int), hipHostMallocDefault) != hipSuccess ||
-            hipMalloc(&q.d_buf, (x_all + res_all + T_all + C_all + lu_all + out_all) * sizeof(double)) != hipSuccess ||
-            hipMalloc(&q.d_ids, (size_t)n_traj * sizeof(int)) != hipSuccess ||
+        // pinned: [T | coeffs of the round | sweep out | overflow word]; device: [T | coeffs | sweep out]
+        if (hipHostMalloc((void **)&q.h_pin, (in_all + out_all + 1) * sizeof(double), hipHostMallocDefault) != hipSuccess ||
+            hipMalloc(&q.d_buf, (in_all + out_all) * sizeof(double)) != hipSuccess ||
             hipStreamCreate(&q.stream) != hipSuccess ||
             hipEventCreateWithFlags(&q.done, hipEventDisableTiming) != hipSuccess ||
             hipEventCreateWithFlags(&q.sweep_done, hipEventDisableTiming) != hipSuccess) { release(); return isdf_fail(c, ISDF_ERR_HIP, "batch buffers: allocation failed"); }
-    }
-    {   // boundary states of every trajectory: head (9) | tail (9)
-        std::vector<double> cond((size_t)n_traj * 18);
-        for (int t = 0; t < n_traj; t++) { std::memcpy(&cond[(size_t)t * 18], heads_pva + 9 * t, 9 * sizeof(double)); std::memcpy(&cond[(size_t)t * 18 + 9], tails_pva + 9 * t, 9 * sizeof(double)); }
-        if (hipMalloc(&d_cond, cond.size() * sizeof(double)) != hipSuccess || hipMemcpy(d_cond, cond.data(), cond.size() * sizeof(double), hipMemcpyHostToDevice) != hipSuccess) {
-            release(); return isdf_fail(c, ISDF_ERR_HIP, "batch buffers: allocation failed");
-        }
     }
     { int rc0 = isdf_reserve_sweep_buffers(c, (long long)n_traj * N); if (rc0) { release(); return rc0; } }
     (void)hipDeviceSynchronize();
@@ -209,47 +165,21 @@ extern "C" int isdf_optimize_lbfgs_batch(isdf_ctx *c, int n_traj, int N, const d
     // coordinator: greedy rounds, N_SLOTS in flight
     int rc = ISDF_OK;
     hipEvent_t last_sweep = nullptr;          // the sweeps share the ctx's scratch: each waits for the one issued before it
-    const size_t in_all = (size_t)n_traj * b.in_per, word_at = std::max(x_all + res_all, in_all + out_all);
     auto issue = [&](Slot &q) {               // q.active holds the trajectories of the round; their staging slots are quiescent
         const int na = (int)q.active.size();
-        if (!b.device_minco) {
-            double *hT = q.h_pin, *hC = q.h_pin + (size_t)na * N;          // compacted [T of all | coeffs of all]
-            for (int k = 0; k < na; k++) {
-                const double *in = b.stage_in.data() + (size_t)q.active[k] * b.in_per;
-                std::memcpy(hT + (size_t)k * N, in, (size_t)N * sizeof(double));
-                std::memcpy(hC + (size_t)k * 18 * N, in + N, (size_t)18 * N * sizeof(double));
-            }
-            double *dT = q.d_buf, *dC = q.d_buf + (size_t)na * N, *dO = q.d_buf + in_all;
-            if (rc == ISDF_OK && hipMemcpyAsync(q.d_buf, q.h_pin, (size_t)na * b.in_per * sizeof(double), hipMemcpyHostToDevice, q.stream) != hipSuccess) rc = ISDF_ERR_HIP;
-            if (rc == ISDF_OK && last_sweep && hipStreamWaitEvent(q.stream, last_sweep, 0) != hipSuccess) rc = ISDF_ERR_HIP;
-            if (rc == ISDF_OK) rc = isdf_eval_device(c, na, N, dT, dC, dO, nullptr, q.stream);
-            if (rc == ISDF_OK && hipEventRecord(q.sweep_done, q.stream) != hipSuccess) rc = ISDF_ERR_HIP;
-            last_sweep = q.sweep_done;
-            if (rc == ISDF_OK && hipMemcpyAsync(q.h_pin + in_all, dO, (size_t)na * b.ostride * sizeof(double), hipMemcpyDeviceToHost, q.stream) != hipSuccess) rc = ISDF_ERR_HIP;
-            if (rc == ISDF_OK && hipMemcpyAsync(q.h_pin + word_at, c->d_stats + 4, sizeof(double), hipMemcpyDeviceToHost, q.stream) != hipSuccess) rc = ISDF_ERR_HIP;
-            if (rc == ISDF_OK && hipEventRecord(q.done, q.stream) != hipSuccess) rc = ISDF_ERR_HIP;
-            q.busy = true;
-            b.rounds_run++;
-            b.evals_run += na;
-            return;
-        }
+        double *hT = q.h_pin, *hC = q.h_pin + (size_t)na * N;          // compacted [T of all | coeffs of all]
         for (int k = 0; k < na; k++) {
-            std::memcpy(q.h_pin + (size_t)k * nv, b.stage_x.data() + (size_t)q.active[k] * nv, nv * sizeof(double));
-            q.h_ids[k] = q.active[k];
+            const double *in = b.stage_in.data() + (size_t)q.active[k] * b.in_per;
+            std::memcpy(hT + (size_t)k * N, in, (size_t)N * sizeof(double));
+            std::memcpy(hC + (size_t)k * 18 * N, in + N, (size_t)18 * N * sizeof(double));
         }
-        double *dX = q.d_buf, *dR = dX + x_all, *dT = dR + res_all, *dC = dT + T_all, *dL = dC + C_all, *dO = dL + lu_all;
-        isdf::MincoDevParams M{};
-        M.N = N; M.rho = rho; M.x = dX; M.ids = q.d_ids; M.cond = d_cond; M.T = dT; M.coeffs = dC; M.lu = dL; M.out = dO; M.res = dR;
-        if (rc == ISDF_OK && hipMemcpyAsync(dX, q.h_pin, (size_t)na * nv * sizeof(double), hipMemcpyHostToDevice, q.stream) != hipSuccess) rc = ISDF_ERR_HIP;
-        if (rc == ISDF_OK && hipMemcpyAsync(q.d_ids, q.h_ids, (size_t)na * sizeof(int), hipMemcpyHostToDevice, q.stream) != hipSuccess) rc = ISDF_ERR_HIP;
-        if (rc == ISDF_OK) isdf::launch_minco_forward(M, na, q.stream);
+        double *dT = q.d_buf, *dC = q.d_buf + (size_t)na * N, *dO = q.d_buf + in_all;
+        if (rc == ISDF_OK && hipMemcpyAsync(q.d_buf, q.h_pin, (size_t)na * b.in_per * sizeof(double), hipMemcpyHostToDevice, q.stream) != hipSuccess) rc = ISDF_ERR_HIP;
         if (rc == ISDF_OK && last_sweep && hipStreamWaitEvent(q.stream, last_sweep, 0) != hipSuccess) rc = ISDF_ERR_HIP;
         if (rc == ISDF_OK) rc = isdf_eval_device(c, na, N, dT, dC, dO, nullptr, q.stream);
         if (rc == ISDF_OK && hipEventRecord(q.sweep_done, q.stream) != hipSuccess) rc = ISDF_ERR_HIP;
         last_sweep = q.sweep_done;
-        if (rc == ISDF_OK) isdf::launch_minco_backward(M, na, q.stream);
-        if (rc == ISDF_OK && hipMemcpyAsync(q.h_pin + x_all, dR, (size_t)na * (1 + nv) * sizeof(double), hipMemcpyDeviceToHost, q.stream) != hipSuccess) rc = ISDF_ERR_HIP;
-        // the overflow word of the sweeps (a bounded wait that expired): a round that saw it is not delivered as a result
+        if (rc == ISDF_OK && hipMemcpyAsync(q.h_pin + in_all, dO, (size_t)na * b.ostride * sizeof(double), hipMemcpyDeviceToHost, q.stream) != hipSuccess) rc = ISDF_ERR_HIP;
         if (rc == ISDF_OK && hipMemcpyAsync(q.h_pin + word_at, c->d_stats + 4, sizeof(double), hipMemcpyDeviceToHost, q.stream) != hipSuccess) rc = ISDF_ERR_HIP;
         if (rc == ISDF_OK && hipEventRecord(q.done, q.stream) != hipSuccess) rc = ISDF_ERR_HIP;
         q.busy = true;
@@ -265,8 +195,7 @@ extern "C" int isdf_optimize_lbfgs_batch(isdf_ctx *c, int n_traj, int N, const d
             if (ovf) { rc = ISDF_ERR_OVERFLOW; (void)hipMemset(c->d_stats + 4, 0, sizeof(unsigned long long)); (void)isdf_reset_result_slots(c); }
         }
         for (int k = 0; k < na && rc == ISDF_OK; k++) {
-            if (b.device_minco) std::memcpy(b.stage_res.data() + (size_t)q.active[k] * (1 + nv), q.h_pin + x_all + (size_t)k * (1 + nv), (1 + nv) * sizeof(double));
-            else std::memcpy(b.stage_out.data() + (size_t)q.active[k] * b.ostride, q.h_pin + in_all + (size_t)k * b.ostride, b.ostride * sizeof(double));
+            std::memcpy(b.stage_out.data() + (size_t)q.active[k] * b.ostride, q.h_pin + in_all + (size_t)k * b.ostride, b.ostride * sizeof(double));
         }
         std::unique_lock<std::mutex> lk(b.m);
         if (rc != ISDF_OK) b.error = rc;
@@ -276,8 +205,8 @@ extern "C" int isdf_optimize_lbfgs_batch(isdf_ctx *c, int n_traj, int N, const d
         if (rc != ISDF_OK) { for (int t = 0; t < b.n_traj; t++) b.cv_worker[t].notify_one(); }     // an error ends every wait
         else for (int t : q.active) b.cv_worker[t].notify_one();
     };
-    const int round_cap = b.device_minco ? std::max(8, (n_traj + 3) / 4) : n_traj;
-    const int slots_used = b.device_minco ? N_SLOTS : 2;
+    const int round_cap = n_traj;
+    const int slots_used = N_SLOTS;
     int head_slot = 0, tail_slot = 0, n_busy = 0;      // ring: rounds are delivered in the order they were issued
     for (;;) {
         if (n_busy == slots_used) { deliver(slots[tail_slot]); tail_slot = (tail_slot + 1) % slots_used; n_busy--; }

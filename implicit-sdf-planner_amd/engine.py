@@ -387,19 +387,6 @@ class Engine:
         return x, out, wall.value
 
     # ---- instrumentation
-    def minco_device(self, N, heads, tails, rho, xs, sweep_out=None):
-        """csrc/minco_dev.hip by itself: heads/tails n_traj x 3 x 3 (columns pos, vel, acc), xs n_traj x n, sweep_out n_traj x
-        (1 + 19 N) or None.  Returns (T [n_traj, N], coeffs [n_traj, 18 N] column-major, cost [n_traj], g [n_traj, n])."""
-        xs = np.ascontiguousarray(xs, dtype=np.float64)
-        nt, n = xs.shape
-        H = np.ascontiguousarray([np.asarray(h, dtype=np.float64).T.reshape(-1) for h in heads])     # column-major 3x3
-        Tl = np.ascontiguousarray([np.asarray(t, dtype=np.float64).T.reshape(-1) for t in tails])
-        so = None if sweep_out is None else np.ascontiguousarray(sweep_out, dtype=np.float64)
-        T = np.zeros((nt, N)); Cc = np.zeros((nt, 18 * N)); res = np.zeros((nt, 1 + n))
-        self._check(self.lib.isdf_minco_device(self.h, nt, N, _p(H), _p(Tl), float(rho), _p(xs), None if so is None else _p(so),
-                                               _p(T), _p(Cc), _p(res)))
-        return T, Cc, res[:, 0].copy(), res[:, 1:].copy()
-
     def multi_info(self):
         n = C.c_int(0); m = C.c_int(0)
         self._check(self.lib.isdf_multi_info(self.h, C.byref(n), C.byref(m)))

@@ -380,28 +380,13 @@ int isdf_optimize_lbfgs(isdf_ctx *ctx, double *x_inout, int n, const isdf_lbfgs_
  * boundary states heads_pva[9t..], tails_pva[9t..] (3x3 column-major each, like isdf_set_trajectory) and its own
  * variables x_inout[t*n .. (t+1)*n), n = N + 3(N-1); all share N, rho and the ctx's map / robot / weights.  Each runs
  * the same L-BFGS driver on its own callback; the callbacks of a round are evaluated as ONE batched integral sweep on the
- * device, several rounds in flight.  MINCO runs on the trajectories' host threads; ISDF_BATCH_DEVICE_MINCO=1 moves it to the device
- * too (one wavefront per trajectory; only x goes up, (cost, g) comes down; the same operations, hence the same iterates) - an
- * experiment that is measured SLOWER than the host threads and is never selected by itself (isdf_minco_device runs those two
- * kernels on their own).  The iterates are identical to optimising every trajectory alone
+ * device, two rounds in flight.  MINCO (minco.hpp:43-198,433-513,530-654) runs on the trajectories' host threads (a solve is a
+ * chain of 3 x 6N dependent fp64 steps: ~10 us on a CPU core; a device form measured 2.3x slower for the whole batch and was
+ * removed in round 4).  The iterates are identical to optimising every trajectory alone
  * with isdf_optimize_lbfgs.  results[t].reserved = number of device rounds of the whole batch.  V2 / V3 contexts only; not on
  * a sharded ctx (shard the batch across ranks instead). */
 int isdf_optimize_lbfgs_batch(isdf_ctx *ctx, int n_traj, int N, const double *heads_pva, const double *tails_pva, double rho,
                               double *x_inout, const isdf_lbfgs_params *p, isdf_lbfgs_result *results, double *wall_ms_out);
-
-/* MINCO on the device BY ITSELF (csrc/minco_dev.hip) - the two kernels the batch optimizer runs around every
- * sweep when MINCO is on the device, callable on their own: for each of n_traj trajectories (boundary states like
- * isdf_optimize_lbfgs_batch, variables x[t*n .. ), n = N + 3(N-1)),
- *   forward : T = forwardT(tau) (back_end_optimizer.hpp:228-241), MINCO_S3NU::setParameters (minco.hpp:433-513: band system,
- *             BandedSystem::factorizeLU :93-131, solve :137-165)             -> T_out[t*N ..], coeffs_out[t*18N ..] (6N x 3 column-major)
- *   backward: getEnergy + partials (:530-582) + sweep_out[t*(1+19N) ..] = [cost | gradT | gradC] of the sweeps (NULL: zeros),
- *             propogateGrad (:584-654, solveAdj :169-197), rho * sum(T), backwardGradT / backwardGradP (:283-330)
- *                                                                            -> cost_g_out[t*(1+n) ..] = [cost | g]
- * i.e. TrajOptimizer::costFunctionLmbm (:358-430) with the sweeps' sums handed in.  Outputs may be NULL.  Same operations
- * in the same order as the host MINCO of isdf_cost_function (results are bitwise equal).  N <= 46 (one trajectory's band system
- * lives in 64 KB of LDS). */
-int isdf_minco_device(isdf_ctx *ctx, int n_traj, int N, const double *heads_pva, const double *tails_pva, double rho,
-                      const double *x, const double *sweep_out, double *T_out, double *coeffs_out, double *cost_g_out);
 
 /* ---- front end: pose feasibility by kernel convolution ------------------------------------- */
 /* The A* front end decides whether the robot fits at a voxel by AND-ing a bit-packed voxelisation of the robot at a
