@@ -103,6 +103,13 @@ struct isdf_ctx {
     std::vector<isdf_ctx *> peers;
     bool is_peer = false;                       // owned by a lead: not handed to the caller
     hipEvent_t mev_in = nullptr, mev_done = nullptr;      // lead: inputs ready on the caller's stream / the step's sum has run; peer: shard finished
+    // mesh robots on the tile sweep: the queue of 64-voxel blocks between the scan launch and the exact launch
+    unsigned *d_mq_entries = nullptr, *d_mq_count = nullptr;
+    void *d_mq_items = nullptr;
+    double *d_mq_res = nullptr;
+    int *d_mq_sample_items = nullptr, *d_mq_sample_n = nullptr;
+    size_t mq_cap = 0, mq_samples_cap = 0;
+    int mq_kmax = 0;
     bool multi_pull = false;                              // lead: the peers read the lead's inputs in place (peer access both ways)
     bool msum_recorded = false;                           // lead: mev_done has been recorded at least once
     int multi_collective = 0;                   // ISDF_MULTI_*: how the shards' outputs are summed

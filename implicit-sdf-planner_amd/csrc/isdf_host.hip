@@ -175,7 +175,7 @@ extern "C" int isdf_destroy(isdf_ctx *c) {
     isdf_xchg_release(c);
     void *ptrs[] = {c->d_cb, c->d_esdf, c->d_occ, c->d_points, c->d_tstar, c->d_acc, c->d_sample_info, c->d_bits, c->d_piece_cost, c->d_in, c->d_out, c->d_stats,
                     c->d_traj_duration, c->d_coarse_t, c->d_coarse_pose, c->d_n_coarse, c->d_point_partial, c->d_point_piece, c->d_point_stat, c->d_point_nr, c->d_task_buf,
-                    c->d_task_map, c->d_v1_words, c->d_point_lmask, c->d_hist, c->d_shape_grid, c->d_pose, c->d_dbg, c->d_stage, c->d_stage_flags, c->d_sample_map, c->d_plan_cls, c->d_plan_map, c->d_plan_lr, c->d_plan_hist};
+                    c->d_task_map, c->d_v1_words, c->d_point_lmask, c->d_hist, c->d_shape_grid, c->d_pose, c->d_mq_entries, c->d_mq_items, c->d_mq_res, c->d_mq_sample_items, c->d_mq_sample_n, c->d_mq_count, c->d_dbg, c->d_stage, c->d_stage_flags, c->d_sample_map, c->d_plan_cls, c->d_plan_map, c->d_plan_lr, c->d_plan_hist};
     for (void *p : ptrs) if (p) (void)hipFree(p);
     free_mesh(c);
     if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -817,6 +817,43 @@ static int eval_device_impl(isdf_ctx *c, int n_traj, int N, const double *d_T, c
             c->pose_cap = need;
         }
         P.poses = c->d_pose;
+    }
+    // ---- mesh robots: the exact pass runs as its own launch over a queue of 64-voxel blocks (every block an independent work item:
+    // the launch is balanced over the whole device instead of ending on its heaviest workgroup).  Sized for the worst case the
+    // geometry allows - every voxel of the robot's inflated bounding box (or of the tile, if smaller) occupied; beyond 4 GiB the
+    // exact pass stays inside the sweep kernel (ISDF_MESH_QUEUE=0 forces that).
+    P.mq_items = nullptr;
+    if (c->shape.kind == ISDF_SHAPE_MESH && cfg.enable_pos && !fused && !(getenv("ISDF_MESH_QUEUE") && getenv("ISDF_MESH_QUEUE")[0] == '0')) {
+        const size_t ns_loc = (size_t)(pe - pb) * (cfg.integral_intervs + 1);
+        const double k3 = (double)cfg.kernel_size * cfg.kernel_size * cfg.kernel_size;
+        double vox = k3;
+        if (c->shape.prune_rows) {
+            double v = 1.0;
+            for (int a = 0; a < 3; a++) v *= ((double)c->shape.bbox_hi[a] - (double)c->shape.bbox_lo[a] + 2.2 * cfg.safety_hor) / P.grid.res + 3.0;
+            vox = std::min(k3, v * 1.8);                  // (rows are pruned by the box's extent on the WORLD axes: up to sqrt(3) per axis for a rotated box)
+        }
+        const int kmax = (int)(k3 / 16.0) + 2;            // items are 16 voxels (tile_sweep.hip MQ_BLOCK)
+        const size_t per_sample = (size_t)(vox / 16.0) + 2;
+        const size_t cap = ns_loc * per_sample;
+        const size_t bytes = cap * (16 * 4 + 8 + 80) + ns_loc * ((size_t)kmax * 4 + 4);
+        if (ns_loc > 0 && bytes <= (size_t)4 << 30 && cap < 0x7fffffffull) {
+            if (c->mq_cap < cap || c->mq_samples_cap < ns_loc || c->mq_kmax != kmax) {
+                HIPCHK(c, hipDeviceSynchronize());               // (an earlier step may still be reading the old queue)
+                for (void *q : {(void *)c->d_mq_entries, c->d_mq_items, (void *)c->d_mq_res, (void *)c->d_mq_sample_items, (void *)c->d_mq_sample_n}) if (q) (void)hipFree(q);
+                c->d_mq_entries = nullptr; c->d_mq_items = nullptr; c->d_mq_res = nullptr; c->d_mq_sample_items = nullptr; c->d_mq_sample_n = nullptr;
+                c->mq_cap = 0; c->mq_samples_cap = 0;
+                HIPCHK(c, hipMalloc(&c->d_mq_entries, cap * 16 * sizeof(unsigned)));
+                HIPCHK(c, hipMalloc(&c->d_mq_items, cap * 8));
+                HIPCHK(c, hipMalloc(&c->d_mq_res, cap * 10 * sizeof(double)));
+                HIPCHK(c, hipMalloc(&c->d_mq_sample_items, ns_loc * (size_t)kmax * sizeof(int)));
+                HIPCHK(c, hipMalloc(&c->d_mq_sample_n, ns_loc * sizeof(int)));
+                if (!c->d_mq_count) HIPCHK(c, hipMalloc(&c->d_mq_count, 4 * sizeof(unsigned)));
+                c->mq_cap = cap; c->mq_samples_cap = ns_loc; c->mq_kmax = kmax;
+            }
+            P.mq_entries = c->d_mq_entries; P.mq_items = (int2 *)c->d_mq_items; P.mq_res = c->d_mq_res;
+            P.mq_sample_items = c->d_mq_sample_items; P.mq_sample_n = c->d_mq_sample_n; P.mq_count = c->d_mq_count;
+            P.mq_cap = (unsigned)c->mq_cap; P.mq_kmax = kmax;
+        }
     }
     launch_sweep(P, st, ev ? ev->a : nullptr, ev ? ev->b : nullptr, fused);
     if (!fused) launch_tail(P, st, ev2 ? ev->c : nullptr, ev2 ? ev->d : nullptr);

@@ -88,6 +88,15 @@ struct SweepParams {
     int plan_group;                     // pieces sorted together (the whole launch, or one trajectory of a batch)
     int dbg_flags;              // developer switches (ISDF_DEBUG_FLAGS): 1 = skip the exact pass body
     unsigned long long *dbg;    // developer timing buffer (ISDF_DEBUG_TIMING=1), null on the product path
+    // mesh robots: the exact pass as its own launch over a QUEUE of 16-voxel blocks (tile_sweep.hip mesh_exact_kernel); mq_items null: in the sweep kernel
+    unsigned *mq_entries;       // [mq_cap][16] ring entries (x | y << 10 | z << 20 inside the tile)
+    int2 *mq_items;             // [mq_cap] (local sample, voxels of the block)
+    double *mq_res;             // [mq_cap][10] per block: the 8 collision sums, exact pairs, active pairs
+    int *mq_sample_items;       // [local samples][mq_kmax] the item numbers of a sample's blocks, in block order
+    int *mq_sample_n;           // [local samples] blocks of the sample | culled << 30
+    unsigned *mq_count;         // device counters: [0] items queued this step, [1] items claimed by the exact launch (zeroed by pose_kernel)
+    unsigned mq_cap;
+    int mq_kmax;
 };
 
 // one optimizer step of the integral sweep = sweep, tail, in order, on `stream`

@@ -37,6 +37,7 @@
 namespace isdf {
 
 constexpr int SW_LIST_CAP = 1024;                         // ring of compacted voxels (one pass adds <= 64 * SW_PASS)
+constexpr int MQ_BLOCK = 16;                             // mesh robots, queued exact pass: voxels per work item = one quad round (dev_mesh.hpp)
 constexpr int SW_PASS = 8;                                // voxels one lane contributes to the ring per pass
 constexpr int SW_NEAR_CAP = 512;                          // per-sample candidate ring (drained by the whole workgroup)
 constexpr float TS_FILTER_EPS = 2e-3f;                    // slack (m) of the fp32 pre-filter, >> its rounding error
@@ -422,6 +423,7 @@ __global__ __launch_bounds__(POSE_THREADS) void pose_kernel(const SweepParams P)
     const long long s_begin = (long long)P.piece_begin * K1, s_end = (long long)P.piece_end * K1;
     const long long s_first = s_begin + (long long)blockIdx.x * POSE_THREADS;
     const long long sidx = s_first + threadIdx.x;
+    if (P.mq_items && blockIdx.x == 0 && threadIdx.x == 0) { P.mq_count[0] = 0u; P.mq_count[1] = 0u; }      // mesh robots: this step's queue of exact-pass blocks starts empty (items queued / items claimed)
     if (sidx < s_end) {
     const DevGrid &G = P.grid;
     SweepPose &sp = *reinterpret_cast<SweepPose *>(&s_rec[threadIdx.x][0]);       // built in place (a local copy ends up in scratch memory)
@@ -723,6 +725,7 @@ __global__ __launch_bounds__(64 * SW_SAMPLES, FUSED ? 3 : sweep_waves_per_simd(K
     bool primed = false;
     double tot = 0.0;                            // wave `s`, lane k < 8: component k of sample s's collision sums
     int tot_n = 0;                               // lanes 8 / 9: exact pairs / active pairs
+    int mq_seq = 0;                              // mesh robots, queued exact pass: blocks of this sample queued so far
     // per-wave statistics of tools/timing.py (row rounds, passes, listed voxels, candidates, exact iterations): six scalar
     // registers held through the whole kernel and an increment per loop iteration - compiled in with -DISDF_SWEEP_STATS=1 only
 #if ISDF_SWEEP_STATS
@@ -978,6 +981,41 @@ __global__ __launch_bounds__(64 * SW_SAMPLES, FUSED ? 3 : sweep_waves_per_simd(K
         }
         if (lane == 0) { s_plan[wave][0] = near_cnt; s_plan[wave][1] = near_head; s_plan[wave][2] = finished ? 1 : 0; }
         __syncthreads();
+        if constexpr (KIND == ISDF_SHAPE_MESH) {
+            if (P.mq_items) {
+                // Mesh robot, queued exact pass: this wavefront's candidates leave as BLOCKS of 64 consecutive voxels of its sample's
+                // stream (the last one partial, when the sample is finished) - independent work items of mesh_exact_kernel, whose
+                // results mesh_sum_kernel adds per sample in block order.  A sample's blocks depend on its own candidates only.
+                const bool all_fin = (s_plan[0][2] & s_plan[1][2] & s_plan[2][2] & s_plan[3][2]) != 0;
+                const int nb = near_cnt / MQ_BLOCK + ((finished && (near_cnt % MQ_BLOCK)) ? 1 : 0);
+                if (nb > 0 && have_sample) {
+                    const int sl = (int)(sidx - s_begin);
+                    unsigned base = 0u;
+                    if (lane == 0) base = atomicAdd(&P.mq_count[0], (unsigned)nb);
+                    base = (unsigned)__builtin_amdgcn_readfirstlane((int)base);
+                    const bool fits = base + (unsigned)nb <= P.mq_cap && mq_seq + nb <= P.mq_kmax;
+                    if (!fits && lane == 0) atomicMax(&P.stats[4], 1ull);                  // (cannot happen with the host's sizing; the result is flagged invalid)
+                    const int used = min(near_cnt, nb * MQ_BLOCK);
+                    if (fits) {
+                        // the entries of the nb blocks are contiguous in the queue: 64 lanes copy them, lane k < nb writes block k's header
+                        for (int e0 = 0; e0 < used; e0 += 64) {
+                            const int e = e0 + lane;
+                            if (e < used) P.mq_entries[(size_t)base * MQ_BLOCK + e] = s_near[wave][(near_head + e) & (SW_NEAR_CAP - 1)];
+                        }
+                        for (int bk = lane; bk < nb; bk += 64) {
+                            P.mq_items[base + bk] = make_int2(sl, min(MQ_BLOCK, used - bk * MQ_BLOCK));
+                            P.mq_sample_items[(size_t)sl * P.mq_kmax + mq_seq + bk] = (int)(base + bk);
+                        }
+                        mq_seq += nb;
+                    }
+                    near_head = (near_head + used) & (SW_NEAR_CAP - 1);
+                    near_cnt -= used;
+                }
+                if (all_fin) break;
+                __syncthreads();        // s_plan is rewritten by the next round
+                continue;
+            }
+        }
 
         // ================= exact phase: the workgroup's candidates in blocks of up to 64 of one sample, dealt round-robin to its
         // waves.  A sample's FULL blocks are one wavefront iteration each.  Its last, partial block is classed by size - whole
@@ -1186,6 +1224,12 @@ __global__ __launch_bounds__(64 * SW_SAMPLES, FUSED ? 3 : sweep_waves_per_simd(K
     }
 
     // ---- (5) results of this wave's sample
+    if constexpr (KIND == ISDF_SHAPE_MESH) {
+        if (P.mq_items) {            // queued exact pass: mesh_sum_kernel writes the sample's sums; here only how many blocks it has
+            if (have_sample && lane == 0) P.mq_sample_n[sidx - s_begin] = mq_seq | ((flags & 2) ? (1 << 30) : 0);
+            return;
+        }
+    }
     if (have_sample) {
         const long long sl = sidx - s_begin;
         if (lane < ACC_STRIDE) {
@@ -1203,6 +1247,91 @@ __global__ __launch_bounds__(64 * SW_SAMPLES, FUSED ? 3 : sweep_waves_per_simd(K
         SW_STAT(dbg[7] = (unsigned long long)n_rounds;)
         SW_STAT(dbg[3] = (unsigned long long)cnt_rounds | ((unsigned long long)cnt_passes << 8) | ((unsigned long long)cnt_filters << 16) | ((unsigned long long)cnt_listed << 24) | ((unsigned long long)cnt_cand << 44);)
     }
+}
+
+// Mesh robots, queued exact pass (round 4).  With the exact pass inside the sweep kernel a C2 step was ONE resident launch of 650
+// workgroups, each walking the hierarchy for its own four samples' voxels: 40 % of the VALU issue rate, 1.4 wavefronts per SIMD on
+// average.  Here a work item is ONE quad round - MQ_BLOCK = 16 consecutive voxels of a sample's candidate stream, 4 lanes per voxel -
+// and the wavefronts of the launch CLAIM items one at a time (an atomic counter): the device stays full until the queue is empty.
+// grad_cost_p (:766-824) per voxel exactly as the in-kernel pass forms it; a block's 8 sums by the same butterfly (the empty lanes add zeros).
+__global__ __launch_bounds__(64 * SW_SAMPLES, 5) void mesh_exact_kernel(const SweepParams P) {
+    __shared__ MeshFrames s_mframes[SW_SAMPLES];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const DevGrid &G = P.grid;
+    const unsigned n_items = min((unsigned)__builtin_amdgcn_readfirstlane((int)P.mq_count[0]), P.mq_cap);
+    const int qv = lane >> 2;                                                    // this quad's voxel of the item
+    for (;;) {
+        unsigned it = 0u;
+        if (lane == 0) it = atomicAdd(&P.mq_count[1], 1u);
+        it = (unsigned)__builtin_amdgcn_readfirstlane((int)it);
+        if (it >= n_items) break;
+        const int2 item = P.mq_items[it];
+        const int sl = __builtin_amdgcn_readfirstlane(item.x), n = __builtin_amdgcn_readfirstlane(item.y);
+        if (sl < 0 || sl >= (P.piece_end - P.piece_begin) * (P.K + 1) || n < 1 || n > MQ_BLOCK) {      // (a header nobody wrote: flagged, not followed)
+            if (lane == 0) atomicMax(&P.stats[4], 1ull);
+            continue;
+        }
+        const mesh_cptr<SweepPose> q = mesh_const_uni((const SweepPose *)P.poses + sl);        // the sample's pose record: scalar loads
+        double v[ACC_STRIDE] = {0, 0, 0, 0, 0, 0, 0, 0};
+        bool want = false;
+        d3 prel = mk3(0, 0, 0), pm = prel;
+        m3 R;
+#pragma unroll
+        for (int k = 0; k < 9; k++) R.a[k] = q->R[k];
+        if (qv < n) {                                                            // (the four lanes of a quad form the same numbers)
+            const unsigned ent = P.mq_entries[(size_t)it * MQ_BLOCK + qv];
+            const int gx = q->lo[0] + (int)(ent & 1023u), gy = q->lo[1] + (int)((ent >> 10) & 1023u), gz = q->lo[2] + (int)(ent >> 20);
+            const d3 ctr = mk3((gx + 0.5) * G.res + G.bmin[0], (gy + 0.5) * G.res + G.bmin[1], (gz + 0.5) * G.res + G.bmin[2]);
+            const d3 pos = mk3(q->pos[0], q->pos[1], q->pos[2]);
+            pm = ctr - pos;
+            prel = mat_tmul(R, pm);
+            want = !(fmax(fmax(fabs(prel.x), fabs(prel.y)), fabs(prel.z)) > P.bd_half);       // the cube cull (:800-803)
+        }
+        double sdf = 0.0;
+        d3 g = mk3(0, 0, 0);
+        const bool below = mesh_sdf_grad_below_quad(P.shape.mesh, &s_mframes[wave], prel, want, P.safety_hor, sdf, g);
+        const bool owner = (lane & 3) == 0;                                      // one lane per voxel carries its terms into the sums
+        bool is_grad = false;
+        if (owner && want && below) {
+            double f = 0.0, df = 0.0;
+            smoothed_l1_inv(P.safety_hor - sdf, P.mu, P.inv_mu, f, df);
+            if (f > 0.0) {
+                is_grad = true;
+                v[0] = f;
+                d4 quat; quat.w = q->quat[0]; quat.x = q->quat[1]; quat.y = q->quat[2]; quat.z = q->quat[3];
+                const d3 wg = mat_mul(R, g);
+                v[1] = df * wg.x; v[2] = df * wg.y; v[3] = df * wg.z;
+                const d4 sq = quat_step_grad(quat, g, pm);
+                v[4] = -df * sq.w; v[5] = -df * sq.x; v[6] = -df * sq.y; v[7] = -df * sq.z;
+            }
+        }
+        wave_sum8(v, lane);                                                      // component comp in v[0] of the lanes with (lane & 7) == 0
+        const int comp = ((lane >> 3) & 1) | (((lane >> 4) & 1) << 1) | ((lane >> 5) << 2);
+        const int np = __popcll(__ballot(owner && want)), ng = __popcll(__ballot(is_grad));
+        double *o = P.mq_res + (size_t)it * 10;
+        if ((lane & 7) == 0) o[comp] = v[0];
+        if (lane == 1) { o[8] = (double)np; o[9] = (double)ng; }
+    }
+}
+// ... and the sample's sums: its blocks' results added in block order (one thread per sample)
+__global__ __launch_bounds__(256) void mesh_sum_kernel(const SweepParams P) {
+    const long long n_samples = (long long)(P.piece_end - P.piece_begin) * (P.K + 1);
+    const long long sl = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (sl >= n_samples) return;
+    const int w = P.mq_sample_n[sl], nb = w & 0x3fffffff;
+    double tot[ACC_STRIDE] = {0, 0, 0, 0, 0, 0, 0, 0};
+    int np = 0, ng = 0;
+    for (int bk = 0; bk < nb; bk++) {
+        const double *o = P.mq_res + (size_t)P.mq_sample_items[(size_t)sl * P.mq_kmax + bk] * 10;
+#pragma unroll
+        for (int k = 0; k < ACC_STRIDE; k++) tot[k] += o[k];
+        np += (int)o[8]; ng += (int)o[9];
+    }
+#pragma unroll
+    for (int k = 0; k < ACC_STRIDE; k++) P.acc[(size_t)sl * ACC_STRIDE + k] = tot[k];
+    P.sample_info[2 * sl] = np;
+    P.sample_info[2 * sl + 1] = ng | ((w & (1 << 30)) ? (int)0x80000000 : 0);
 }
 
 // on-demand statistics (isdf_get_stats / host API): culled poses, exact pairs, active pairs.  Not on the timed path.
@@ -1526,6 +1655,15 @@ bool sweep_can_fuse(const SweepParams &P) {
     return (n_samples + SW_SAMPLES - 1) / SW_SAMPLES + (long long)(P.piece_end - P.piece_begin) <= fused_max_blocks() && (long long)P.n_traj * P.N <= 8 * fused_max_blocks();
 }
 
+static int sweep_target_blocks_mesh() {      // persistent workgroups of mesh_exact_kernel: 5 per CU (96 registers; at 6 the spills cost more than the sixth wavefront brings: 2.43 -> 3.01 ms)
+    static int cus = 0;                       // (asked once: the property query costs milliseconds)
+    if (cus == 0) {
+        int dev = 0, n = 0;
+        cus = 256;
+        if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0) cus = n;
+    }
+    return 5 * cus;
+}
 // fused = true: sweep workgroups + one tail workgroup per piece in ONE launch (the caller then skips launch_tail)
 void launch_sweep(const SweepParams &P0, hipStream_t stream, hipEvent_t ev_start, hipEvent_t ev_stop, bool fused) {
     SweepParams P = P0;
@@ -1544,7 +1682,13 @@ void launch_sweep(const SweepParams &P0, hipStream_t stream, hipEvent_t ev_start
     ISDF_SWEEP_CASE(ISDF_SHAPE_TWISTBOX) ISDF_SWEEP_CASE(ISDF_SHAPE_BENDBOX) ISDF_SWEEP_CASE(ISDF_SHAPE_TABLE)
     ISDF_SWEEP_CASE(ISDF_SHAPE_TREFOIL) ISDF_SWEEP_CASE(ISDF_SHAPE_SMOOTHDIFFERENCE) ISDF_SWEEP_CASE(ISDF_SHAPE_SMOOTHINTERSECTION)
     ISDF_SWEEP_CASE(ISDF_SHAPE_CSG) ISDF_SWEEP_CASE(ISDF_SHAPE_BOX)
-    case ISDF_SHAPE_MESH: ISDF_LAUNCH_SWEEP(ISDF_SHAPE_MESH, false, false); break;
+    case ISDF_SHAPE_MESH:
+        if (P.mq_items) {      // scan launch -> queue -> exact launch -> per-sample sums (the events span the three)
+            hipExtLaunchKernelGGL((sweep_kernel<ISDF_SHAPE_MESH, false, false>), grid, block, 0, stream, ev_start, nullptr, 0, P);
+            hipLaunchKernelGGL(mesh_exact_kernel, dim3((unsigned)std::min<long long>((long long)sweep_target_blocks_mesh(), ((long long)P.mq_cap + SW_SAMPLES - 1) / SW_SAMPLES)), block, 0, stream, P);
+            hipExtLaunchKernelGGL(mesh_sum_kernel, dim3((unsigned)((n_samples + 255) / 256)), dim3(256), 0, stream, nullptr, ev_stop, 0, P);
+        } else ISDF_LAUNCH_SWEEP(ISDF_SHAPE_MESH, false, false);
+        break;
     default: if (fused) ISDF_LAUNCH_SWEEP(-1, true, true); else if (ident) ISDF_LAUNCH_SWEEP(-1, true, false); else ISDF_LAUNCH_SWEEP(-1, false, false); break;      // Ball (and anything new)
     }
 #undef ISDF_SWEEP_CASE
