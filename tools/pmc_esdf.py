@@ -1,0 +1,24 @@
+#!/usr/bin/env python
+"""Developer tool: HBM bytes per launch of esdf_sample_kernel from two rocprofv3 PMC passes (FETCH_SIZE, WRITE_SIZE; separate runs as
+MI355X_MICROARCH.md prescribes; gfx950: traffic = 2 x FETCH_SIZE + WRITE_SIZE, KB) of tools/esdf_sample_bench.py <n>, per dispatch in
+launch order (the bench runs, per map and point set, value-only then value + gradient launches: 2 warm-up + 5 timed each).
+usage: pmc_esdf.py <fetch.db> <write.db>"""
+import sqlite3, sys
+
+
+def rows(db, ctr):
+    cur = sqlite3.connect(db).cursor()
+    cols = [r[1] for r in cur.execute("pragma table_info(counters_collection)")]
+    key = next((c for c in ("dispatch_id", "dispatch_index", "id", "start") if c in cols), "rowid")
+    return cur.execute(f"select {key}, value from counters_collection where counter_name = ? and kernel_name like '%esdf_sample_kernel%' order by {key}", (ctr,)).fetchall()
+
+
+f = rows(sys.argv[1], "FETCH_SIZE"); w = rows(sys.argv[2], "WRITE_SIZE")
+print("# esdf_sample_kernel: HBM traffic per launch = (2 x FETCH_SIZE + WRITE_SIZE) KB; groups of 7 launches = one line of tools/esdf_sample_bench.py 2e7")
+n = min(len(f), len(w))
+for g in range(0, n, 7):
+    fs = [v for _, v in f[g:g + 7]][2:]; ws = [v for _, v in w[g:g + 7]][2:]
+    if not fs:
+        continue
+    fk = sum(fs) / len(fs); wk = sum(ws) / len(ws)
+    print(f"launch group {g // 7}: FETCH_SIZE {fk:12.1f} KB  WRITE_SIZE {wk:12.1f} KB  -> traffic {(2 * fk + wk) * 1024 / 1e6:10.2f} MB per launch")

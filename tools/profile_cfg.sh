@@ -1,7 +1,7 @@
 #!/bin/bash
 # Developer tool (GPU box): counters of ONE configuration's dominant kernel(s) -> gpurun_out/<tag>_pmc_counters_<cfg>.json (hashed),
 # plus the kernel-trace summary.  Two PMC passes, never combined with other trace domains.
-#   usage: tools/profile_cfg.sh <tag> v1|c3
+#   usage: tools/profile_cfg.sh <tag> v1|v1mesh|v3mesh|c3
 set -u
 TAG=${1:-rX}; CFG=${2:-v1}
 REPO=${GRAFT_REPO_ROOT:-/root/repo}
@@ -14,6 +14,9 @@ if [ "$CFG" = "v1" ]; then
 elif [ "$CFG" = "v1mesh" ]; then
   CMD="python $REPO/tools/v1_bench.py --no-oracle --mesh720"
   export PMC_KERNELS="swept_scan_kernel,swept_descent_kernel" PMC_HASH=v1
+elif [ "$CFG" = "v3mesh" ]; then
+  CMD="python $REPO/tools/mesh720_only.py"
+  export PMC_KERNELS="mesh_exact_kernel" PMC_HASH=sweep
 else
   CMD="python $REPO/tools/c3_only.py 12"
   export PMC_KERNELS="sweep_kernel" PMC_HASH=sweep
