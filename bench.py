@@ -547,6 +547,17 @@ def main():
             except Exception as e:      # noqa: BLE001
                 extra.append({"name": "512^3 map", "error": str(e)})
 
+            # ---- the tile sweep with a MESH robot (720 faces through the fast-winding-number hierarchy): scan launch -> queue of
+            # 16-voxel blocks -> exact launch (quad-cooperative walks) -> per-sample sums
+            try:
+                shm = synth.make_mesh_shape(*synth.blob_mesh(24, 16, scale=0.9))
+                em = pkg.Engine(cfg); em.set_grid(esdf, (0, 0, 0), res, capi.GRID_ESDF); em.set_shape(shm)
+                ent = run_cfg("C2 geometry (1 x 40 pieces) with a MESH robot (blob, 720 faces, fast-winding-number hierarchy)", em, 1, 40, T, cm, 10, oc=(cfg, esdf, capi.GRID_ESDF, res, shm))
+                ent["roofline"] = issue_from_counters(os.path.join(ROOT, "profiles", "pmc_counters_v3mesh.json"), kernel_source_hash())
+                ent["faces"] = 720
+                del em
+            except Exception as e:      # noqa: BLE001
+                extra.append({"name": "V3 mesh", "error": str(e)})
             # ---- the whole-tile cull on (never `value`: it skips poses, the headline evaluates every pose)
             try:
                 cfgc = synth.default_config(capi.V3_ESDF_TILE, device=local_rank, kernel_size=args.kernel_size, integral_intervs=K,
