@@ -166,3 +166,47 @@ def test_mesh_with_degenerate_and_duplicate_triangles(pkg, orc, product_lib):
     assert np.all(np.isfinite(s)) and np.all(np.isfinite(s0))
     assert np.all(np.abs(s - s0) <= 5e-6 * np.abs(s0) + 4e-6 * np.abs(Q).max())
     assert (np.linalg.norm(g - g0, axis=1) <= 1e-6).mean() > 0.995     # doubled faces tie exactly: either copy's closest point
+
+
+def test_mesh_walk_forms_agree(pkg, orc, product_lib, monkeypatch):
+    """The mesh kind has two forms of each sweep: V1 with one task per wavefront (wave-cooperative walks, small meshes) or per
+    workgroup (quad-cooperative walks; ISDF_MESH_WG forces either), and the tile sweep with its exact pass inside the sweep kernel
+    or as its own launch over a queue of 16-voxel blocks (ISDF_MESH_QUEUE=0 forces the former).  Every query sees the same
+    arithmetic either way: V1 must agree BITWISE (t*, cost, gradients - the reduction over the points is the same), the tile
+    sweep to rounding (its per-sample sums are partitioned into blocks of 16 / of up to 64 voxels)."""
+    capi, synth = pkg.capi, pkg.synth
+    occ, esdf, res = small_world(pkg, seed=14)
+    T, cm = traj(pkg, occ, res, N=5, seed=23)
+    V, F = synth.blob_mesh(24, 16, scale=0.9)
+    way = cm.reshape(3, -1).T.reshape(5, 6, 3)[1:, 0, :]
+    pts = synth.constraint_points(occ, (0, 0, 0), res, way, half=3.0)
+    out = {}
+    for wg in ("0", "1"):
+        monkeypatch.setenv("ISDF_MESH_WG", wg)
+        cfg1 = synth.default_config(capi.V1_SWEPT, safety_hor=0.5)
+        e1 = pkg.Engine(cfg1); e1.set_grid(occ, (0, 0, 0), res, capi.GRID_OCCUPANCY); e1.set_shape(synth.make_mesh_shape(V, F)); e1.set_points(pts)
+        ts = -np.ones(len(pts))
+        c, gT, gC = e1.eval_single(T, cm, tstar=ts)
+        out[wg] = (c, gT, gC, ts, e1.stats())
+    monkeypatch.delenv("ISDF_MESH_WG")
+    a, b = out["0"], out["1"]
+    assert a[0] == b[0] and np.array_equal(a[1], b[1]) and np.array_equal(a[2], b[2]) and np.array_equal(a[3], b[3])
+    assert a[4]["pairs"] == b[4]["pairs"] and a[4]["grad_pairs"] == b[4]["grad_pairs"] > 0
+    cfg = synth.default_config(capi.V3_ESDF_TILE, kernel_size=9, integral_intervs=12, safety_hor=0.5)
+    res3 = {}
+    for q in ("1", "0"):
+        monkeypatch.setenv("ISDF_MESH_QUEUE", q)
+        e = pkg.Engine(cfg); e.set_grid(esdf, (0, 0, 0), res, capi.GRID_ESDF); e.set_shape(synth.make_mesh_shape(V, F))
+        res3[q] = e.eval_single(T, cm) + (e.stats(),)
+    monkeypatch.delenv("ISDF_MESH_QUEUE")
+    a, b = res3["1"], res3["0"]
+    assert a[0] > 0 and abs(a[0] - b[0]) <= 1e-12 * abs(b[0])
+    assert_close(a[1], b[1], "queued vs in-kernel exact pass gradT", tol=1e-11); assert_close(a[2], b[2], "queued vs in-kernel exact pass gradC", tol=1e-11)
+    assert a[3]["pairs"] == b[3]["pairs"] and a[3]["grad_pairs"] == b[3]["grad_pairs"] and a[3]["overflow"] == 0
+    # a batch through the queue == each trajectory alone, bitwise (a sample's blocks depend on its own candidates only)
+    Ts, Cs = zip(*[traj(pkg, occ, res, N=5, seed=40 + k) for k in range(4)])
+    e = pkg.Engine(cfg); e.set_grid(esdf, (0, 0, 0), res, capi.GRID_ESDF); e.set_shape(synth.make_mesh_shape(V, F))
+    cost, gTs, gCs = e.eval(list(Ts), list(Cs))
+    for k in range(4):
+        c1, gT1, gC1 = e.eval_single(Ts[k], Cs[k])
+        assert c1 == cost[k] and np.array_equal(gT1, gTs[k]) and np.array_equal(gC1, gCs[k])
