@@ -250,27 +250,37 @@ def main():
                     par.allreduce_packed(d_out)
         return step
 
-    def timed(step, steps):
-        """warm-up, then EXACTLY `steps` steps between barrier + synchronize on both sides; nothing else in the region.  Also
-        returns the region's duration on the launch stream itself (HIP events: torch's current stream IS the stream handed to
-        isdf_eval_device) / steps - for a one-launch step that bounds the kernel's duration from above without touching it."""
+    def timed(step, steps, with_events=False):
+        """warm-up, then EXACTLY `steps` steps between barrier + synchronize on both sides; nothing else in the region.  The host
+        SPINS on the stream (query) before the closing synchronise, which then returns at once instead of adding the scheduler's
+        wake-up latency to a region that lasts 0.3 ms at 20 steps.  with_events (the long steady-state run only): the region's
+        duration on the launch stream itself (HIP events: torch's current stream IS the stream handed to isdf_eval_device) / steps -
+        for a one-launch step that bounds the kernel's duration from above; the two event records cost the host ~10 us, so the
+        headline region carries none."""
         for _ in range(args.warmup):
             step()
         torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        cur = torch.cuda.current_stream()
+        e0 = e1 = None
+        if with_events:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         t0 = time.perf_counter()
-        e0.record()
+        if with_events:
+            e0.record()
         for _ in range(steps):
             step()
-        e1.record()
+        if with_events:
+            e1.record()
+        while not cur.query():
+            pass
         torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
         t1 = time.perf_counter()
-        return t1 - t0, e0.elapsed_time(e1) / steps
+        return t1 - t0, (e0.elapsed_time(e1) / steps if with_events else 0.0)
 
     def any_rank(flag):
         t = torch.tensor([int(flag)], dtype=torch.int32, device=dev)
@@ -316,7 +326,9 @@ def main():
     # region long enough to be in steady state, as an EXTRA key - `value` stays what the K steps measured
     value_steady = None
     if world == 1 and args.steady_steps > 0:
-        el_s, _ = timed(make_step(mode), args.steady_steps)
+        el_s, region_steady = timed(make_step(mode), args.steady_steps, with_events=True)
+        if region_steady > 0:
+            region_ms = region_steady
         value_steady = {"value": round(evals_per_step * args.steady_steps / el_s, 1), "steps": args.steady_steps,
                         "ms_per_step": round(1e3 * el_s / args.steady_steps, 5)}
 
@@ -406,7 +418,7 @@ def main():
     one_launch = evals_this_rank // 4 + (N // world) <= 768 and world == 1
     # two live bounds of the kernel's duration, both from above: the dispatch-attached events (an instrumented dispatch runs
     # 1-3 us longer than a plain one) and - when the step IS one launch - the timed region's own stream duration / steps
-    kern_ms = min(kern_ms_dispatch, region_ms) if (one_launch and kern_ms_dispatch > 0) else (kern_ms_dispatch if kern_ms_dispatch > 0 else region_ms)
+    kern_ms = (min(kern_ms_dispatch, region_ms) if region_ms > 0 else kern_ms_dispatch) if (one_launch and kern_ms_dispatch > 0) else (kern_ms_dispatch if kern_ms_dispatch > 0 else region_ms)
     B = algorithmic_bytes_per_eval(args.kernel_size)
     achieved = (evals_this_rank * B) / (kern_ms * 1e-3) / 1e9 if kern_ms > 0 else 0.0
 
