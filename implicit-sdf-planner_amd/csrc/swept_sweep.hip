@@ -43,6 +43,8 @@ constexpr int SW_WAVES = 4;
 constexpr int SW_MAX_RANGES = 32;                // intervals kept per point (more set the overflow flag); 5 bits of a task word
 constexpr int TASK_STRIDE = 6;                   // doubles per (point, interval) slot: in (lb, ub, seed) / out (t, sdf, grad(3), counters)
 constexpr int LPT_TASK = 8;                      // descents of >= this many passes (last step) are dispatched first
+// ... mesh robots: descents that lasted at least TWICE the mean of the step before (words[4..6]: sum of the durations in 1.28 us units,
+// their count, the threshold the prepare kernel forms from them; wall_clock64 = 100 MHz)
 
 // The trajectory as the kernels of this file see it: durations T[0..N) (LDS copies are padded to a multiple of 4 with a
 // huge value, which no time exceeds) and the 6N x 3 column-major coefficients.
@@ -116,6 +118,9 @@ __global__ __launch_bounds__(1024) void swept_prepare_kernel(const SweptParams P
         *P.n_coarse = n;
         for (int k = 0; k < 8; k++) if (k != 4) P.stats[k] = 0ull;      // [4] = overflow: sticky until the host reads it
         P.words[0] = 0u; P.words[2] = 0u;                               // the scan kernel's task counters (front / back of the list)
+        // mesh robots: "long" = a descent of at least twice last step's mean duration (0: no step yet)
+        P.words[6] = P.words[5] ? max(1u, 2u * (P.words[4] / P.words[5])) : 0u;
+        P.words[4] = 0u; P.words[5] = 0u;
     }
     __syncthreads();
     const int n = s_n;
@@ -482,6 +487,7 @@ __device__ __forceinline__ void descent_body(const SweptParams &P, double *s_dyn
     const unsigned cap = (unsigned)(P.point_end - P.point_begin) * SW_MAX_RANGES;
     const unsigned n_front = (unsigned)__builtin_amdgcn_readfirstlane((int)P.words[0]);
     const unsigned n_tasks = n_front + (unsigned)__builtin_amdgcn_readfirstlane((int)P.words[2]);
+    const unsigned lpt_thr = KIND == ISDF_SHAPE_MESH ? (unsigned)__builtin_amdgcn_readfirstlane((int)P.words[6]) : 0u;
     const unsigned n_waves = (unsigned)__builtin_amdgcn_readfirstlane((int)(MESH ? n_blocks : n_blocks * SW_WAVES));
     const double D = *P.traj_duration;
     const int gmode = P.shape.grad_mode;
@@ -493,7 +499,7 @@ __device__ __forceinline__ void descent_body(const SweptParams &P, double *s_dyn
     const int gd_off = lane < 18 ? 0 : (lane < 25 ? lane - 18 : (lane < 60 ? (lane - 25) % 7 : 0));
     for (unsigned task = MESH ? block : block * SW_WAVES + wave, rounds = 0; task < n_tasks && rounds < (1u << 16); task += n_waves, rounds++) {
         const unsigned tm = (unsigned)__builtin_amdgcn_readfirstlane((int)(task < n_front ? P.task_map[task] : P.task_map[cap - 1u - (task - n_front)]));
-        const unsigned long long dbg_t0 = (ISDF_SWEEP_STATS && P.dbg) ? wall_clock64() : 0ull;
+        const unsigned long long dbg_t0 = ((ISDF_SWEEP_STATS && P.dbg) || KIND == ISDF_SHAPE_MESH) ? wall_clock64() : 0ull;
         const int rel = (int)(tm >> 5), r = (int)(tm & 31u);
         const int pt = P.point_begin + rel;
         double *const slot = P.task_buf + ((size_t)rel * SW_MAX_RANGES + r) * TASK_STRIDE;
@@ -613,7 +619,15 @@ __device__ __forceinline__ void descent_body(const SweptParams &P, double *s_dyn
         if (writer) {
             slot[0] = x; slot[1] = fx; slot[2] = g1_at_x.x; slot[3] = g1_at_x.y; slot[4] = g1_at_x.z;
             slot[5] = __longlong_as_double((long long)(((unsigned long long)n_pass & 0xFFFFull) | ((unsigned long long)iter << 16)));
-            if (n_pass >= LPT_TASK) atomicOr(&P.point_lmask[pt], 1u << r);      // next step: dispatch this interval's descent early
+            // next step: dispatch this interval's descent early.  Analytic robots: by its pass count (a pass costs the same everywhere);
+            // mesh robots: by its DURATION (a pass next to the surface costs ten times one far from it; 100 MHz clock)
+            bool long_task = n_pass >= LPT_TASK;
+            if constexpr (KIND == ISDF_SHAPE_MESH) {
+                const unsigned dur = (unsigned)min((wall_clock64() - dbg_t0) >> 7, 0xFFFFFull);      // 1.28 us units
+                atomicAdd(&P.words[4], dur); atomicAdd(&P.words[5], 1u);
+                if (lpt_thr != 0u) long_task = dur >= lpt_thr;                   // (first step: the pass-count rule)
+            }
+            if (long_task) atomicOr(&P.point_lmask[pt], 1u << r);
             if (ISDF_SWEEP_STATS && P.dbg && task < (unsigned)P.M) {      // developer timing (ISDF_DEBUG_TIMING=1): start, end, passes of this task
                 unsigned long long *d = P.dbg + (size_t)P.M * 4 + (size_t)(P.N + 1) * 8 + (size_t)task * 3;
                 d[0] = dbg_t0; d[1] = wall_clock64(); d[2] = (unsigned long long)n_pass | ((unsigned long long)(task < n_front) << 32);
