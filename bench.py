@@ -767,6 +767,7 @@ def main():
         host_ms = None
         host_ms_multi = None
         host_ms_multi8 = None
+        host_queue_multi8 = None
         host_timer = None
         cb_native_ms = None
         x0 = None
@@ -797,6 +798,17 @@ def main():
                     em8.set_grid(esdf, (0, 0, 0), res, capi.GRID_ESDF); em8.set_shape(shape)
                     natm8 = native_boundary_ms(pkg, em8, N, T, cm, None)
                     host_ms_multi8 = None if natm8 is None else round(natm8[0], 4)
+                    # what the calling thread spends QUEUEING a device-resident step on those 8 shards (isdf_eval_device on a
+                    # caller stream, no synchronisation; the figure above is the synchronous host-pointer call and contains the
+                    # eight shards' kernels running on this ONE GPU)
+                    qs = torch.cuda.Stream(); torch.cuda.synchronize()
+                    dTq = torch.from_numpy(T).cuda(); dCq = torch.from_numpy(cm).cuda(); dOq = torch.zeros(em8.out_stride(N), dtype=torch.float64, device="cuda")
+                    for _ in range(50): em8.eval_device(1, N, dTq.data_ptr(), dCq.data_ptr(), dOq.data_ptr(), 0, qs.cuda_stream)
+                    torch.cuda.synchronize()
+                    tq = time.perf_counter()
+                    for _ in range(300): em8.eval_device(1, N, dTq.data_ptr(), dCq.data_ptr(), dOq.data_ptr(), 0, qs.cuda_stream)
+                    host_queue_multi8 = round(1e3 * (time.perf_counter() - tq) / 300, 4)
+                    torch.cuda.synchronize()
                     del em8
                 except Exception:       # noqa: BLE001
                     host_ms_multi = None
@@ -886,7 +898,7 @@ def main():
             "roofline": roofline, "roofline_issue": issue, "cpu_baseline": cpu, "configs": extra,
             "one_gpu_same_workload": one_gpu, "speedup": None if one_gpu is None else round(value / one_gpu["evals_per_s"], 3),
             "value_steady": value_steady, "parity_rel_err_vs_oracle": parity, "host_api_ms": None if host_ms is None else round(host_ms, 4), "host_api_timer": host_timer,
-            "host_api_ms_two_shards_one_gpu": host_ms_multi, "host_api_ms_eight_shards_one_gpu": host_ms_multi8,
+            "host_api_ms_two_shards_one_gpu": host_ms_multi, "host_api_ms_eight_shards_one_gpu": host_ms_multi8, "host_queue_ms_eight_shards_one_gpu": host_queue_multi8,
             "stats_last_step_rank0": stats, "lbfgs": lbfgs, "hbm_copy_gbs_measured": hbm_copy,
         }
         print(json.dumps(result), flush=True)

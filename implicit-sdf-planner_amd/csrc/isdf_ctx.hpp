@@ -75,6 +75,11 @@ struct isdf_ctx {
     isdf_host::MincoS3 minco; bool have_traj = false; double rho = 0.0;
     std::vector<double> cb_T, cb_gdC, cb_gdT, cb_gradP, cb_gradT;
     double *h_eval_pin = nullptr; size_t eval_pin_cap = 0;   // pinned staging of isdf_eval: [inputs | outputs | statistics]
+    double *h_eval_pin_dev = nullptr;                        // ... as the devices see it
+    // multi-device ctx, isdf_eval: the sum kernel writes the step's outputs, the statistics words and a completion word straight
+    // into the pinned buffer (no download commands, no stream synchronisation: the calling thread spins on the word)
+    double *mh_out = nullptr; unsigned long long *mh_words = nullptr; unsigned long long mh_seq = 0; unsigned *d_msum_blocks = nullptr;
+    bool env_multi_no_hostout = false;
     double *h_pin = nullptr; size_t pin_cap = 0;      // pinned staging: [T | coeffs | out_a | out_b]
     double *d_cb = nullptr; size_t cb_cap = 0;        // device twin of the staging buffer
     // host-direct steps (isdf_eval / isdf_cost_function on one GPU when the step is one fused launch): pinned, device-mapped

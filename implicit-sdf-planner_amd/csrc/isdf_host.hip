@@ -135,6 +135,7 @@ extern "C" int isdf_create(isdf_ctx **out, const isdf_config *cfg) {
         auto on = [](const char *name) { const char *e = getenv(name); return e && e[0] == '1'; };
         c->fuse_small = !on("ISDF_NO_FUSE");
         c->env_no_direct = on("ISDF_NO_HOST_DIRECT");
+        c->env_multi_no_hostout = on("ISDF_MULTI_NO_HOST_OUT");
         c->env_no_bar = on("ISDF_NO_BAR_WRITES");
         c->env_no_lpt = on("ISDF_NO_LPT");
     }
@@ -175,7 +176,7 @@ extern "C" int isdf_destroy(isdf_ctx *c) {
     isdf_xchg_release(c);
     void *ptrs[] = {c->d_cb, c->d_esdf, c->d_occ, c->d_points, c->d_tstar, c->d_acc, c->d_sample_info, c->d_bits, c->d_piece_cost, c->d_in, c->d_out, c->d_stats,
                     c->d_traj_duration, c->d_coarse_t, c->d_coarse_pose, c->d_n_coarse, c->d_point_partial, c->d_point_piece, c->d_point_stat, c->d_point_nr, c->d_task_buf,
-                    c->d_task_map, c->d_v1_words, c->d_point_lmask, c->d_hist, c->d_shape_grid, c->d_pose, c->d_mq_entries, c->d_mq_items, c->d_mq_res, c->d_mq_sample_items, c->d_mq_sample_n, c->d_mq_count, c->d_dbg, c->d_stage, c->d_stage_flags, c->d_sample_map, c->d_plan_cls, c->d_plan_map, c->d_plan_lr, c->d_plan_hist};
+                    c->d_task_map, c->d_v1_words, c->d_point_lmask, c->d_hist, c->d_shape_grid, c->d_pose, c->d_mq_entries, c->d_mq_items, c->d_mq_res, c->d_mq_sample_items, c->d_mq_sample_n, c->d_mq_count, c->d_msum_blocks, c->d_dbg, c->d_stage, c->d_stage_flags, c->d_sample_map, c->d_plan_cls, c->d_plan_map, c->d_plan_lr, c->d_plan_hist};
     for (void *p : ptrs) if (p) (void)hipFree(p);
     free_mesh(c);
     if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -882,7 +883,10 @@ __global__ void multi_tail_kernel(const unsigned long long *stats, double *tail)
 // out[i] = part_0[i] + part_1[i] + ... (rank order: bitwise reproducible); the summed tail back into the lead's statistics words
 // (`all_stats`: V1 counts straight into the statistics words, so their device sums are the step's statistics; V2 / V3 words are
 // filled on demand by isdf_get_stats and only the overflow word [4] travels)
-__global__ __launch_bounds__(256) void multi_sum_kernel(double *out, MultiParts parts, size_t count, unsigned long long *stats, int all_stats) {
+// host_words != null: `out` is host-mapped; the step's 8 statistics words follow it into host_words[0..7] and, once every block of
+// this launch has written, host_words[8] = seq tells the spinning host that the step is complete
+__global__ __launch_bounds__(256) void multi_sum_kernel(double *out, MultiParts parts, size_t count, unsigned long long *stats, int all_stats,
+                                                        unsigned long long *host_words, unsigned *blocks_done, unsigned long long seq) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < count + MULTI_TAIL) {
         double s;
@@ -898,6 +902,16 @@ __global__ __launch_bounds__(256) void multi_sum_kernel(double *out, MultiParts 
             const int k = (int)(i - count);
             if (k == 4) { if (s != 0.0) stats[4] = 1ull; }                 // overflow: sticky until read
             else if (all_stats) stats[k] = (unsigned long long)s;
+            if (host_words) host_words[k] = k == 4 ? ((s != 0.0 || stats[4] != 0ull) ? 1ull : 0ull) : (unsigned long long)s;
+        }
+    }
+    if (host_words) {
+        __threadfence_system();
+        __syncthreads();
+        if (threadIdx.x == 0 && atomicAdd(blocks_done, 1u) == gridDim.x - 1u) {
+            *blocks_done = 0u;
+            __threadfence_system();
+            *(volatile unsigned long long *)(host_words + 8) = seq;
         }
     }
 }
@@ -1023,6 +1037,8 @@ static int multi_eval_device(isdf_ctx *c, int n_traj, int N, const double *d_T, 
     const bool pull = c->multi_pull && c->multi_collective == ISDF_MULTI_PEER_SUM;
     MultiParts parts{};
     parts.n = n;
+    unsigned long long *const mh_words = c->mh_words;          // (isdf_eval arms this per step)
+    c->mh_words = nullptr;
     for (int r = 1; r < n; r++) {
         isdf_ctx *p = c->peers[r - 1];
         HIPCHK(c, hipSetDevice(p->device));
@@ -1074,7 +1090,7 @@ static int multi_eval_device(isdf_ctx *c, int n_traj, int N, const double *d_T, 
         if (g_rccl.GroupEnd() != 0) return fail(c, ISDF_ERR_HIP, "ncclGroupEnd failed");
         HIPCHK(c, hipSetDevice(c->device));
         MultiParts one{}; one.n = 1; one.p[0] = c->d_mpart;
-        hipLaunchKernelGGL(multi_sum_kernel, grid, block, 0, st, d_out, one, count, c->d_stats, swept ? 1 : 0);
+        hipLaunchKernelGGL(multi_sum_kernel, grid, block, 0, st, d_out, one, count, c->d_stats, swept ? 1 : 0, mh_words, c->d_msum_blocks, c->mh_seq);
     } else {
         for (int r = 1; r < n; r++) HIPCHK(c, hipStreamWaitEvent(st, c->peers[r - 1]->mev_done, 0));
         if (c->multi_collective == ISDF_MULTI_STAGED) {
@@ -1086,7 +1102,7 @@ static int multi_eval_device(isdf_ctx *c, int n_traj, int N, const double *d_T, 
                 parts.p[r] = dst;
             }
         }
-        hipLaunchKernelGGL(multi_sum_kernel, grid, block, 0, st, d_out, parts, count, c->d_stats, swept ? 1 : 0);
+        hipLaunchKernelGGL(multi_sum_kernel, grid, block, 0, st, d_out, parts, count, c->d_stats, swept ? 1 : 0, mh_words, c->d_msum_blocks, c->mh_seq);
     }
     HIPCHK(c, hipGetLastError());
     // the next step's peer copies overwrite the peers' inputs: they are ordered behind THIS step's kernels by the peers' own
@@ -1192,6 +1208,8 @@ static int ensure_eval_pin(isdf_ctx *c, size_t doubles) {
     if (c->h_eval_pin) (void)hipHostFree(c->h_eval_pin);
     c->h_eval_pin = nullptr; c->eval_pin_cap = 0;
     HIPCHK(c, hipHostMalloc((void **)&c->h_eval_pin, doubles * sizeof(double), hipHostMallocDefault));
+    HIPCHK(c, hipHostGetDevicePointer((void **)&c->h_eval_pin_dev, c->h_eval_pin, 0));
+    std::memset(c->h_eval_pin, 0, doubles * sizeof(double));
     c->eval_pin_cap = doubles;
     return ISDF_OK;
 }
@@ -1374,7 +1392,7 @@ extern "C" int isdf_eval(isdf_ctx *c, int n_traj, const int *N, const double *co
         if (rc) return rc;
         rc = ensure(c, &c->d_out, &c->out_cap, out_all);
         if (rc) return rc;
-        rc = ensure_eval_pin(c, in_all + out_all + 8);
+        rc = ensure_eval_pin(c, in_all + out_all + 16);
         if (rc) return rc;
         double *hin = c->h_eval_pin, *hout = c->h_eval_pin + in_all;
         unsigned long long *hstat = (unsigned long long *)(c->h_eval_pin + in_all + out_all);
@@ -1391,12 +1409,32 @@ extern "C" int isdf_eval(isdf_ctx *c, int n_traj, const int *N, const double *co
             dts = c->d_tstar;
             HIPCHK(c, hipMemcpyAsync(dts, tstar_inout, (size_t)c->M * sizeof(double), hipMemcpyHostToDevice, c->stream));
         }
-        rc = sweep_dispatch(c, nb, n, dT, dC, c->d_out, dts, c->stream);
-        if (rc) return rc;
+        // a multi-device step ends in a sum kernel on the lead: it writes straight into the pinned buffer and raises a word there
+        const bool host_out = (!c->peers.empty() || c->rccl_comm) && !dts && !c->env_multi_no_hostout && !c->prof_on;
+        if (host_out) {
+            if (!c->d_msum_blocks) { HIPCHK(c, hipMalloc(&c->d_msum_blocks, sizeof(unsigned))); HIPCHK(c, hipMemset(c->d_msum_blocks, 0, sizeof(unsigned))); }
+            c->mh_words = (unsigned long long *)(c->h_eval_pin_dev + in_all + out_all);
+            c->mh_seq++;
+        }
+        rc = sweep_dispatch(c, nb, n, dT, dC, host_out ? c->h_eval_pin_dev + in_all : c->d_out, dts, c->stream);
+        if (rc) { c->mh_words = nullptr; return rc; }
+        if (host_out) {
+            volatile unsigned long long *word = hstat + 8;
+            const auto t0 = std::chrono::steady_clock::now();
+            for (unsigned spin = 0; *word != c->mh_seq; spin++) {
+                if ((spin & 0x3FFFu) == 0x3FFFu && std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > 5.0) {
+                    (void)hipStreamSynchronize(c->stream);
+                    if (*word == c->mh_seq) break;
+                    return fail(c, ISDF_ERR_HIP, "multi-device step did not complete (its completion word never arrived)");
+                }
+            }
+            std::atomic_thread_fence(std::memory_order_acquire);
+        } else {
         HIPCHK(c, hipMemcpyAsync(hout, c->d_out, out_all * sizeof(double), hipMemcpyDeviceToHost, c->stream));
         HIPCHK(c, hipMemcpyAsync(hstat, c->d_stats, 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost, c->stream));
         if (dts) HIPCHK(c, hipMemcpyAsync(tstar_inout, dts, (size_t)c->M * sizeof(double), hipMemcpyDeviceToHost, c->stream));
         HIPCHK(c, hipStreamSynchronize(c->stream));
+        }
         if (hstat[4]) {   // sticky until read; slots a late producer may still fill are emptied again
             overflow = true;
             HIPCHK(c, hipMemset(c->d_stats + 4, 0, sizeof(unsigned long long)));

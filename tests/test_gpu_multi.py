@@ -81,6 +81,30 @@ def test_multi_integral_sweep_through_the_binding(pkg, orc, stub, monkeypatch, n
     assert abs(a[0] - c1) <= 1e-12 * abs(c1)
 
 
+def test_multi_host_written_outputs_equal_the_downloaded_ones(pkg, orc, product_lib, monkeypatch):
+    """isdf_eval on a multi-device ctx: the sum kernel writes outputs, statistics words and a completion word into the pinned
+    buffer (default) - bitwise what the download commands + stream synchronisation deliver (ISDF_MULTI_NO_HOST_OUT=1)."""
+    capi, synth = pkg.capi, pkg.synth
+    occ, esdf, res = small_world(pkg, seed=5)
+    cfg = synth.default_config(capi.V3_ESDF_TILE, kernel_size=9, integral_intervs=16, safety_hor=0.5, vmax=2.0, omgmax=1.0, thetamax=0.3)
+    shape = synth.make_shape("RoundedCone", params=(0.8, 0.3, 1.6))
+    a = _mk(pkg, cfg, _devs(3), shape, esdf=esdf, res=res)
+    monkeypatch.setenv("ISDF_MULTI_NO_HOST_OUT", "1")
+    b = _mk(pkg, cfg, _devs(3), shape, esdf=esdf, res=res)
+    monkeypatch.delenv("ISDF_MULTI_NO_HOST_OUT")
+    for N, seed in ((7, 61), (12, 62), (7, 63)):
+        T, cm = traj(pkg, occ, res, N=N, seed=seed)
+        ra = a.eval_single(T, cm); rb = b.eval_single(T, cm)
+        assert ra[0] == rb[0] and np.array_equal(ra[1], rb[1]) and np.array_equal(ra[2], rb[2])
+        assert a.stats() == b.stats()
+    # ragged batch (group by group, statistics added up per group)
+    Ts, Cs = zip(*[traj(pkg, occ, res, N=n, seed=70 + n) for n in (5, 5, 9)])
+    ra = a.eval(list(Ts), list(Cs)); rb = b.eval(list(Ts), list(Cs))
+    assert np.array_equal(ra[0], rb[0])
+    for x, y in zip(ra[2], rb[2]): assert np.array_equal(x, y)
+    assert a.stats() == b.stats()
+
+
 @pytest.mark.parametrize("n_dev", [2, 4])
 def test_multi_swept_sweep_through_the_binding(pkg, orc, stub, n_dev):
     """addSaftyPenaOnSweptVolumeParallel: obstacle points sharded over the devices, lastTstar merged back in point order."""

@@ -17,3 +17,18 @@ for nd in (1, 2, 8):
     e.set_grid(esdf, (0, 0, 0), res, capi.GRID_ESDF); e.set_shape(shape)
     r = bench.native_boundary_ms(pkg, e, 40, T, cm, None)
     print(nd, "devices: isdf_eval", None if r is None else round(r[0] * 1e3, 1), "us", "pull" if nd > 1 and os.environ.get("ISDF_MULTI_NO_PULL") != "1" else "")
+    # the device-resident step: what the calling thread spends QUEUEING a step (no synchronisation), the steps' throughput, one step's latency
+    import time
+    dT = torch.from_numpy(T).cuda(); dC = torch.from_numpy(cm).cuda(); dO = torch.zeros(e.out_stride(40), dtype=torch.float64, device="cuda")
+    ts_ = torch.cuda.Stream(); torch.cuda.synchronize()
+    st = ts_.cuda_stream                 # (not the null stream: its implicit synchronisation with every other stream is not what a caller would time)
+    for _ in range(50): e.eval_device(1, 40, dT.data_ptr(), dC.data_ptr(), dO.data_ptr(), 0, st)
+    torch.cuda.synchronize()
+    n = 300
+    t0 = time.perf_counter()
+    for _ in range(n): e.eval_device(1, 40, dT.data_ptr(), dC.data_ptr(), dO.data_ptr(), 0, st)
+    t1 = time.perf_counter(); torch.cuda.synchronize(); t2 = time.perf_counter()
+    lat = []
+    for _ in range(100):
+        a = time.perf_counter(); e.eval_device(1, 40, dT.data_ptr(), dC.data_ptr(), dO.data_ptr(), 0, st); torch.cuda.synchronize(); lat.append(time.perf_counter() - a)
+    print(f"   device-resident: queueing {1e6 * (t1 - t0) / n:.1f} us/step, throughput {1e6 * (t2 - t0) / n:.1f} us/step, one step + synchronise {1e6 * np.median(lat):.1f} us")
