@@ -213,6 +213,7 @@ __device__ inline double mesh_closest(const DevMesh *m, d3 p, d3 &closest, doubl
     double stk_lb[MESH_STACK];
     int sp = 0;
     double best = cutoff2;
+    int bestf = -1;
     stk[0] = 0; stk_lb[0] = 0.0; sp = 1;
     while (sp > 0) {
         --sp;
@@ -235,7 +236,7 @@ __device__ inline double mesh_closest(const DevMesh *m, d3 p, d3 &closest, doubl
                 const d3 c = closest_on_triangle(p, mk3(t[0], t[1], t[2]), mk3(t[3], t[4], t[5]), mk3(t[6], t[7], t[8]));
                 const d3 dd = p - c;
                 const double d = dot3(dd, dd);
-                if (d < best) { best = d; closest = c; }
+                if (d < best || (d == best && bestf >= 0 && ci < bestf)) { best = d; closest = c; bestf = ci; }      // equal distances: the lower face (every walk form, whatever its order)
             } else {
                 int k = n++;                                       // keep (cid, clb) sorted by decreasing bound
                 while (k > 0 && clb[k - 1] < lb2) { clb[k] = clb[k - 1]; cid[k] = cid[k - 1]; --k; }
@@ -451,6 +452,7 @@ __device__ inline double mesh_closest_quad(const DevMesh *m, MeshFrames *F, d3 p
     const double *triq = mu->fwn_triq;
     const double cutoff = best;
     double mine = best;                    // the best of the triangles THIS lane has evaluated
+    int myf = -1;                          // ... and its face
     d3 myc = mk3(0, 0, 0);
     int sp = __ballot(act) ? 1 : 0;
     if (lane == 0) { F->s_node[0] = 0; F->s_par[0] = -1; }
@@ -460,31 +462,36 @@ __device__ inline double mesh_closest_quad(const DevMesh *m, MeshFrames *F, d3 p
         // this lane's child: bound, child word, fp64 triangle - and the bound of the node itself (from its parent's record), all
         // requested together
         const float *rq = boxq + ((size_t)4 * node + l) * MESH_Q_REC;
-        const float4 a = *reinterpret_cast<const float4 *>(rq);          // maxP2, P.xyz
+        const float2 a0 = *reinterpret_cast<const float2 *>(rq + 34);    // the child's bounding box: lo.x lo.y | lo.z hi.x hi.y hi.z
+        const float4 a1 = *reinterpret_cast<const float4 *>(rq + 36);
         const int ci = __builtin_bit_cast(int, rq[23]);
         const double *t = triq + ((size_t)4 * node + l) * MESH_Q_TRI;
         const double2 u0 = *reinterpret_cast<const double2 *>(t), u1 = *reinterpret_cast<const double2 *>(t + 2), u2 = *reinterpret_cast<const double2 *>(t + 4),
                       u3 = *reinterpret_cast<const double2 *>(t + 6), u4 = *reinterpret_cast<const double2 *>(t + 8);
-        float4 ap = a;
-        if (par >= 0) ap = *reinterpret_cast<const float4 *>(boxq + (size_t)par * MESH_Q_REC);          // par = 4 * parent + child index
-        auto lb2_of = [&](const float4 &r) {
-            const double px = r.y, py = r.z, pz = r.w;
-            const double dx = p.x - px, dy = p.y - py, dz = p.z - pz;
-            // radius padded for the float rounding of P / maxP2 and the float copies of the vertices they were built from
-            const double rad = (double)sqrtf(r.x) * 1.00001 + 1e-6 * (fabs(px) + fabs(py) + fabs(pz) + 1.0);
-            const double lb = fmax(sqrt(dx * dx + dy * dy + dz * dz) - rad, 0.0);
-            return lb * lb;
+        float2 p0 = a0; float4 p1 = a1;
+        if (par >= 0) {                                                   // par = 4 * parent + child index
+            p0 = *reinterpret_cast<const float2 *>(boxq + (size_t)par * MESH_Q_REC + 34);
+            p1 = *reinterpret_cast<const float4 *>(boxq + (size_t)par * MESH_Q_REC + 36);
+        }
+        // squared distance from p to the box (round 4: boxes instead of the winding number's bounding spheres - a sphere around a
+        // flat patch of the surface contains every query within the patch's radius of it, the box only those within its thickness;
+        // no square roots either).  The host rounds the boxes outwards; the factor covers the rounding of this sum.
+        auto lb2_of = [&](const float2 &b0, const float4 &b1) {
+            const double ex = fmax(fmax((double)b0.x - p.x, p.x - (double)b1.y), 0.0);
+            const double ey = fmax(fmax((double)b0.y - p.y, p.y - (double)b1.z), 0.0);
+            const double ez = fmax(fmax((double)b1.x - p.z, p.z - (double)b1.w), 0.0);
+            return (ex * ex + ey * ey + ez * ez) * 0.999999999999;
         };
         if (par >= 0) {                                           // the bests may have improved since this node was pushed
-            if (!__ballot(act && lb2_of(ap) < best)) continue;
+            if (!__ballot(act && lb2_of(p0, p1) < best)) continue;
         }
         double lb2 = 1.7976931348623157e308;
-        if (act && ci != -1) lb2 = lb2_of(a);
+        if (act && ci != -1) lb2 = lb2_of(a0, a1);
         if (ci >= 0 && lb2 < best) {                              // my child is a triangle that can still beat the query's best
             const d3 c = closest_on_triangle(p, mk3(u0.x, u0.y, u1.x), mk3(u1.y, u2.x, u2.y), mk3(u3.x, u3.y, u4.x));
             const d3 dd = p - c;
             const double d = dot3(dd, dd);
-            if (d < mine) { mine = d; myc = c; }
+            if (d < mine || (d == mine && myf >= 0 && ci < myf)) { mine = d; myc = c; myf = ci; }
         }
         best = quad_min(mine);
         // internal children some query still wants, farthest first on the stack (the nearest ends on top); order by the bound of
@@ -516,7 +523,10 @@ __device__ inline double mesh_closest_quad(const DevMesh *m, MeshFrames *F, d3 p
     }
     // the quad's winner: the lowest lane holding the minimum hands its point to the other three
     best = quad_min(mine);
-    const unsigned hit = (unsigned)((__ballot(mine == best) >> qsh) & 0xFull);
+    int fkey = (mine == best && myf >= 0) ? myf : 0x7fffffff;                      // equal distances: the lower face
+    fkey = min(fkey, __builtin_amdgcn_mov_dpp(fkey, 0xB1, 0xf, 0xf, false));
+    fkey = min(fkey, __builtin_amdgcn_mov_dpp(fkey, 0x4E, 0xf, 0xf, false));
+    const unsigned hit = (unsigned)((__ballot(mine == best && myf == fkey) >> qsh) & 0xFull);
     const int src = qsh + (hit ? __ffs((int)hit) - 1 : 0);
     const double wx = __shfl(myc.x, src, 64), wy = __shfl(myc.y, src, 64), wz = __shfl(myc.z, src, 64);
     if (best < cutoff) closest = mk3(wx, wy, wz);
@@ -526,7 +536,10 @@ __device__ inline double mesh_closest_quad(const DevMesh *m, MeshFrames *F, d3 p
 // mesh_sdf_grad / mesh_sdf_grad_below for 16 queries (all 64 lanes call; a quad passes the same arguments); cap = +infinity
 // gives the plain query.  Returns false when sdf >= cap is proven (or the query is not `act`).
 __device__ inline bool mesh_sdf_grad_below_quad(const DevMesh *m, MeshFrames *F, d3 p, bool act, double cap, double &sdf, d3 &g) {
-    const float sa = mesh_solid_angle_quad(m, F, (float)p.x, (float)p.y, (float)p.z, act);
+    float sa = mesh_solid_angle_quad(m, F, (float)p.x, (float)p.y, (float)p.z, act);
+#if ISDF_MESH_DUP == 1
+    { float sb = mesh_solid_angle_quad(m, F, (float)p.x + 1e-30f, (float)p.y, (float)p.z, act); asm volatile("" : "+v"(sb)); if (sb == 12345.f) sa = sb; }
+#endif
     const double w = (double)sa / (4.0 * 3.14159265358979323846);
     const double s = 1. - 2. * w;
     double cutoff2 = 1.7976931348623157e308;
@@ -535,7 +548,10 @@ __device__ inline bool mesh_sdf_grad_below_quad(const DevMesh *m, MeshFrames *F,
         else { const double dc = cap / s; cutoff2 = dc * dc * (1.0 + 1e-12); }
     }
     d3 c = mk3(0, 0, 0);
-    const double d2 = mesh_closest_quad(m, F, p, act, c, cutoff2);
+    double d2 = mesh_closest_quad(m, F, p, act, c, cutoff2);
+#if ISDF_MESH_DUP == 2
+    { d3 c2 = mk3(0, 0, 0); double e2 = mesh_closest_quad(m, F, mk3(p.x + 1e-300, p.y, p.z), act, c2, cutoff2); asm volatile("" : "+v"(e2)); if (e2 == -1.0) d2 = e2; }
+#endif
     if (!act || d2 >= cutoff2) return false;
     sdf = s * sqrt(d2);
     g = normalized3(s * (p - c));
@@ -625,6 +641,7 @@ __device__ inline double mesh_closest_wave(const DevMesh *m, d3 p, bool act, d3 
     const mesh_cptr<float> box = mesh_const_uni(mu->fwn_box);
     const mesh_cptr<int> chl = mesh_const_uni(mu->fwn_child);
     const mesh_cptr<double> tri = mesh_const_uni(mu->tri);
+    int bestf = -1;
     int sp = 1;
     s_node[0] = 0; s_par[0] = -1;
     while (sp > 0) {
@@ -653,7 +670,7 @@ __device__ inline double mesh_closest_wave(const DevMesh *m, d3 p, bool act, d3 
                     const d3 c = closest_on_triangle(p, mk3(t[0], t[1], t[2]), mk3(t[3], t[4], t[5]), mk3(t[6], t[7], t[8]));
                     const d3 dd = p - c;
                     const double d = dot3(dd, dd);
-                    if (d < best) { best = d; closest = c; }
+                    if (d < best || (d == best && bestf >= 0 && ci < bestf)) { best = d; closest = c; bestf = ci; }      // equal distances: the lower face (every walk form, whatever its order)
                 }
             } else {
                 // visiting order: by the bound of the first lane that wants the child (the lanes are neighbours); rep >= 0

@@ -10,6 +10,7 @@
 #include <cmath>
 #include <cstdio>
 #include <cstring>
+#include <functional>
 #include <cstdlib>
 #include <string>
 #include <vector>
@@ -331,9 +332,41 @@ extern "C" int isdf_set_shape(isdf_ctx *c, const isdf_shape *s) {
         const int depth = isdf_host::fwn_depth(tree);
         std::vector<float> boxq((size_t)4 * isdf::MESH_Q_REC * tree.n_nodes(), 0.f);
         std::vector<double> triq((size_t)4 * isdf::MESH_Q_TRI * tree.n_nodes(), 0.0);
+        // bounding box of every (node, child) from the fp64 vertices, rounded OUTWARDS to float (the closest-point walk's bound);
+        // children have higher node numbers than their parents in this layout or not - a memoised recursion does not care
+        std::vector<double> aabb((size_t)4 * 6 * tree.n_nodes());
+        std::vector<char> aabb_done((size_t)tree.n_nodes(), 0);
+        std::function<void(int)> node_boxes = [&](int nd) {
+            if (aabb_done[nd]) return;
+            aabb_done[nd] = 1;
+            for (int ch = 0; ch < 4; ch++) {
+                double *bb = aabb.data() + ((size_t)4 * nd + ch) * 6;
+                for (int a = 0; a < 3; a++) { bb[a] = 1.0e300; bb[3 + a] = -1.0e300; }
+                const int32_t ci = tree.child[(size_t)4 * nd + ch];
+                if (ci == -1) continue;
+                if (ci >= 0) {
+                    for (int k = 0; k < 3; k++) for (int a = 0; a < 3; a++) { const double v = tri[(size_t)9 * ci + 3 * k + a]; bb[a] = std::min(bb[a], v); bb[3 + a] = std::max(bb[3 + a], v); }
+                } else {
+                    const int sub = ci & 0x7fffffff;
+                    node_boxes(sub);
+                    for (int c2 = 0; c2 < 4; c2++) {
+                        const double *sb = aabb.data() + ((size_t)4 * sub + c2) * 6;
+                        for (int a = 0; a < 3; a++) { bb[a] = std::min(bb[a], sb[a]); bb[3 + a] = std::max(bb[3 + a], sb[3 + a]); }
+                    }
+                }
+            }
+        };
+        node_boxes(0);
+        auto f_down = [](double v) { float f = (float)v; if ((double)f > v) f = std::nextafterf(f, -INFINITY); return f; };
+        auto f_up = [](double v) { float f = (float)v; if ((double)f < v) f = std::nextafterf(f, INFINITY); return f; };
         for (int nd = 0; nd < tree.n_nodes(); nd++)
             for (int ch = 0; ch < 4; ch++) {
                 float *rq = boxq.data() + ((size_t)4 * nd + ch) * isdf::MESH_Q_REC;
+                {
+                    const double *bb = aabb.data() + ((size_t)4 * nd + ch) * 6;
+                    const bool any = bb[0] <= bb[3];
+                    for (int a = 0; a < 3; a++) { rq[34 + a] = any ? f_down(bb[a]) : 3.0e38f; rq[37 + a] = any ? f_up(bb[3 + a]) : -3.0e38f; }
+                }
                 for (int k = 0; k < 23; k++) rq[k] = tree.box[(size_t)92 * nd + 4 * k + ch];
                 const int32_t ci = tree.child[(size_t)4 * nd + ch];
                 std::memcpy(&rq[23], &ci, 4);

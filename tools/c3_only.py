@@ -9,10 +9,10 @@ pkg = graft.load_package(); capi, synth = pkg.capi, pkg.synth
 from bench import build_workload
 res = 0.2
 dev = torch.device("cuda", 0); torch.zeros(1, device=dev)
-st = torch.cuda.current_stream().cuda_stream
+ts_ = torch.cuda.Stream(); st = ts_.cuda_stream       # (not the null stream: it synchronises implicitly with every other stream)
 occ, esdf, T, cm = build_workload(pkg, 40, 256, res)
 cfg = synth.default_config(capi.V3_ESDF_TILE, kernel_size=21, integral_intervs=64, safety_hor=(3 ** 0.5 / 2) * res, weight_p=4000.0, smoothing_eps=0.01)
-eng = pkg.Engine(cfg, devices=[0, 0] if '--split' in sys.argv else None); eng.set_grid(esdf, (0, 0, 0), res, capi.GRID_ESDF); eng.set_shape(synth.bench_box_shape())
+eng = pkg.Engine(cfg, devices=[0] * int(os.environ.get('C3_SPLIT', '2')) if '--split' in sys.argv else None); eng.set_grid(esdf, (0, 0, 0), res, capi.GRID_ESDF); eng.set_shape(synth.bench_box_shape())
 ext = np.array(occ.shape) * res
 Ts, Cs = [], []
 for b in range(128):
