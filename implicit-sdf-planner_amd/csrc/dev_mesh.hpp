@@ -443,6 +443,9 @@ __device__ inline float mesh_solid_angle_quad(const DevMesh *m, MeshFrames *F, f
     }
 }
 
+// (Round 4, measured and dropped: SEEDING a walk with the triangle that was closest to the quad's previous query - a valid upper
+// bound from the first node on.  The nearest-first descent finds as good a bound within its first few nodes; the seed's own
+// triangle test in front of the walk cost more: C5-shaped blob 13.6 -> 15.3 ms, Trefoil.obj 11.8 -> 13.0 ms.)
 // Closest point for 16 queries.  `best` in: the query's cutoff (squared), out: min(exact squared distance, cutoff); `closest`
 // is written when a triangle beat the cutoff.  The four lanes of a quad pass the same arguments and get the same results.
 __device__ inline double mesh_closest_quad(const DevMesh *m, MeshFrames *F, d3 p, bool act, d3 &closest, double best) {
