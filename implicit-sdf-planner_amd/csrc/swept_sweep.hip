@@ -222,7 +222,7 @@ __device__ inline bool mesh_eval_wg(MeshWG &X, const DevMesh *m, d3 pr, bool act
 template <int KIND, bool LDS, bool WG = false>
 __device__ __forceinline__ void eval_lane(const SweptParams &P, const TrajL<LDS> &tr, const d3 p, const double te, const int pert,
                                           const bool pose_lane, const bool own_grad, double &val, d3 &pvel, d3 &g_direct,
-                                          MeshWG *X = nullptr, const bool act = true) {
+                                          MeshWG *X = nullptr, const bool act = true, const double cap = __builtin_inf()) {
     double tl = te;
     const int pi = traj_locate_l(tr, tl);
     d3 xt, vt, at, jt;
@@ -256,8 +256,8 @@ __device__ __forceinline__ void eval_lane(const SweptParams &P, const TrajL<LDS>
         // one hierarchy query per evaluating lane gives value AND gradient (the pose lanes keep the gradient)
         d3 gq = mk3(0, 0, 0);
         double v = 1e300;
-        mesh_eval_wg(*X, P.shape.mesh, pr, act, __builtin_inf(), v, gq);
-        if (act) val = v;
+        const bool below = mesh_eval_wg(*X, P.shape.mesh, pr, act, cap, v, gq);      // (cap: "sdf >= cap" may be answered without the value)
+        if (act && below) val = v;
         if (act && pose_lane) g_direct = gq;
     } else if constexpr (KIND == ISDF_SHAPE_MESH) {
         d3 gq;
@@ -395,7 +395,8 @@ __device__ __forceinline__ void scan_body(const SweptParams &P, double *s_dyn, c
             if (!__ballot(act)) break;          // nothing (left) to scan in this interval
             double val = 1e300;
             d3 pv_unused = mk3(0, 0, 0), g_unused = pv_unused;
-            if constexpr (MESH) eval_lane<KIND, LDS, true>(P, tr, p, act ? te : lb, 0, false, false, val, pv_unused, g_unused, &mwg, act);
+            // (mesh robots: only a value BELOW the running minimum can change it - the hierarchy's distance cutoff answers the rest)
+            if constexpr (MESH) eval_lane<KIND, LDS, true>(P, tr, p, act ? te : lb, 0, false, false, val, pv_unused, g_unused, &mwg, act, range_mindis);
             else if (act) eval_lane<KIND, LDS>(P, tr, p, te, 0, false, false, val, pv_unused, g_unused);
             n_pass++;
             const int nv = __popcll(__ballot(act));                  // valid lanes form a prefix (t is increasing)
@@ -435,7 +436,7 @@ __device__ __forceinline__ void scan_body(const SweptParams &P, double *s_dyn, c
         __syncthreads();
         if (tid == 0) {
             unsigned tl = 0, ts = 0;
-            for (int w = 0; w < SW_WAVES; w++) { tl += s_cnt[w][0]; ts += s_cnt[w][1]; }
+            for (int w = 0; w < (MESH ? WGM : SW_WAVES); w++) { tl += s_cnt[w][0]; ts += s_cnt[w][1]; }
             s_base[0] = tl ? atomicAdd(&P.words[0], tl) : 0u;
             s_base[1] = ts ? atomicAdd(&P.words[2], ts) : 0u;
         }
@@ -896,9 +897,9 @@ void launch_swept_sweep(const SweptParams &P, hipStream_t stream, hipEvent_t ev_
     if (mesh_wg) {
         // scan: 4 wavefronts per point (a fine pass has up to 64 queries); descent: 2 per task (25 queries per pass = 16 + 9)
         const dim3 block2(128);
-        if (in_lds) { hipExtLaunchKernelGGL((swept_scan_kernel<ISDF_SHAPE_MESH, true, 4>), grid, block, lds, stream, ev_start, nullptr, 0, P);
+        if (in_lds) { hipExtLaunchKernelGGL((swept_scan_kernel<ISDF_SHAPE_MESH, true, 2>), grid, block2, lds, stream, ev_start, nullptr, 0, P);
                       hipExtLaunchKernelGGL((swept_descent_kernel<ISDF_SHAPE_MESH, true, 2>), grid, block2, lds, stream, nullptr, ev_stop, 0, P); }
-        else { hipExtLaunchKernelGGL((swept_scan_kernel<ISDF_SHAPE_MESH, false, 4>), grid, block, 0, stream, ev_start, nullptr, 0, P);
+        else { hipExtLaunchKernelGGL((swept_scan_kernel<ISDF_SHAPE_MESH, false, 2>), grid, block2, 0, stream, ev_start, nullptr, 0, P);
                hipExtLaunchKernelGGL((swept_descent_kernel<ISDF_SHAPE_MESH, false, 2>), grid, block2, 0, stream, nullptr, ev_stop, 0, P); }
         return;
     }
