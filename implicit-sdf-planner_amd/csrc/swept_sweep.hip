@@ -173,14 +173,14 @@ __device__ __forceinline__ double wave_first_min(double v, int lane, int n, int 
 // (dev_mesh.hpp, quad-cooperative walks) - and the results come back through LDS.  A pass next to the surface (all of the
 // hierarchy opened by 25-64 queries) was one wavefront's 1e5 dependent instructions; it is now four wavefronts' 1e4 each.
 struct MeshWG {
-    double *stage;       // this wavefront's [64][3] compacted query points (wave-private: no barrier)
+    double *stage;       // this wavefront's [64][4] compacted queries: point, cap (wave-private: no barrier)
     double *res;         // the workgroup's [2 parities][64][5] results: (below, sdf, g.xyz)
     int parity, wave;
     MeshFrames *frames;  // this wavefront's walk frames (dev_mesh.hpp)
     int n_waves;         // wavefronts of the workgroup (4 in the scan: up to 64 queries per pass; 2 in the descent: 25)
 };
 constexpr int MESH_WG_RES = 2 * 64 * 5;
-constexpr int mesh_wg_stage(int nw) { return nw * 64 * 3; }
+constexpr int mesh_wg_stage(int nw) { return nw * 64 * 4; }
 // every lane of all four wavefronts calls; returns "sdf < cap proven / evaluated" like mesh_sdf_grad_below (cap = +inf: plain query)
 __device__ inline bool mesh_eval_wg(MeshWG &X, const DevMesh *m, d3 pr, bool act, double cap, double &sdf, d3 &g) {
     const int lane = (int)__lane_id();
@@ -188,7 +188,7 @@ __device__ inline bool mesh_eval_wg(MeshWG &X, const DevMesh *m, d3 pr, bool act
     if (!mask) return false;                               // (the same in all four wavefronts)
     const int n_act = __popcll(mask);
     const int rank = __popcll(mask & ((1ull << lane) - 1ull));
-    if (act) { X.stage[3 * rank] = pr.x; X.stage[3 * rank + 1] = pr.y; X.stage[3 * rank + 2] = pr.z; }
+    if (act) { X.stage[4 * rank] = pr.x; X.stage[4 * rank + 1] = pr.y; X.stage[4 * rank + 2] = pr.z; X.stage[4 * rank + 3] = cap; }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -201,10 +201,11 @@ __device__ inline bool mesh_eval_wg(MeshWG &X, const DevMesh *m, d3 pr, bool act
         const bool on = r < n_act;
         if (!__ballot(on)) continue;                       // (wave-uniform; no barrier inside this loop)
         const int rr = on ? r : 0;
-        const d3 qp = mk3(X.stage[3 * rr], X.stage[3 * rr + 1], X.stage[3 * rr + 2]);
+        const d3 qp = mk3(X.stage[4 * rr], X.stage[4 * rr + 1], X.stage[4 * rr + 2]);
+        const double qcap = X.stage[4 * rr + 3];                  // (a query's own cap: the lanes of a pass may ask different questions)
         double s2 = 0.0;
         d3 g2 = mk3(0, 0, 0);
-        const bool below = mesh_sdf_grad_below_quad(m, X.frames, qp, on, cap, s2, g2);
+        const bool below = mesh_sdf_grad_below_quad(m, X.frames, qp, on, qcap, s2, g2);
         if (on && (lane & 3) == 0) { double *o = R + 5 * r; o[0] = below ? 1.0 : 0.0; o[1] = s2; o[2] = g2.x; o[3] = g2.y; o[4] = g2.z; }
     }
     __syncthreads();
@@ -291,7 +292,7 @@ __device__ __forceinline__ void scan_body(const SweptParams &P, double *s_dyn, c
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int pt = P.point_begin + (MESH ? block : block * SW_WAVES + wave);
     const bool writer = lane == 0 && (!MESH || wave == 0);       // (the four wavefronts of a mesh workgroup hold the same results)
-    MeshWG mwg{s_mesh + wave * 64 * 3, s_mesh + (MESH ? mesh_wg_stage(WGM) : 0), 0, wave, &s_frames[MESH ? wave : 0], WGM};
+    MeshWG mwg{s_mesh + wave * 64 * 4, s_mesh + (MESH ? mesh_wg_stage(WGM) : 0), 0, wave, &s_frames[MESH ? wave : 0], WGM};
     int my_nr = 0;
     if (pt < P.point_end) {
     unsigned long long *const dbg = (ISDF_SWEEP_STATS && P.dbg) ? P.dbg + (size_t)pt * 4 : nullptr;
@@ -484,7 +485,7 @@ __device__ __forceinline__ void descent_body(const SweptParams &P, double *s_dyn
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const bool writer = lane == 0 && (!MESH || wave == 0);
-    MeshWG mwg{s_mesh + wave * 64 * 3, s_mesh + (MESH ? mesh_wg_stage(WGM) : 0), 0, wave, &s_frames[MESH ? wave : 0], WGM};
+    MeshWG mwg{s_mesh + wave * 64 * 4, s_mesh + (MESH ? mesh_wg_stage(WGM) : 0), 0, wave, &s_frames[MESH ? wave : 0], WGM};
     const unsigned cap = (unsigned)(P.point_end - P.point_begin) * SW_MAX_RANGES;
     const unsigned n_front = (unsigned)__builtin_amdgcn_readfirstlane((int)P.words[0]);
     const unsigned n_tasks = n_front + (unsigned)__builtin_amdgcn_readfirstlane((int)P.words[2]);
@@ -537,7 +538,11 @@ __device__ __forceinline__ void descent_body(const SweptParams &P, double *s_dyn
             }
             double val = 1e300;
             d3 pvel = mk3(0, 0, 0), g_direct = mk3(0, 0, 0);
-            if constexpr (MESH) eval_lane<KIND, LDS, true>(P, tr, p, act ? te : x, pert, pose_lane, own_grad, val, pvel, g_direct, &mwg, act);
+            // (mesh robots: every test below asks "val < f(x)?" of the lanes other than 18 - the halving candidates directly, the look-ahead
+            // blocks through a chain of strictly decreasing values that starts at f(x) - and uses a value only when the answer is yes: f(x),
+            // once known, is those queries' cutoff in the hierarchy)
+            if constexpr (MESH) eval_lane<KIND, LDS, true>(P, tr, p, act ? te : x, pert, pose_lane, own_grad, val, pvel, g_direct, &mwg, act,
+                                                           (iter > 0 && lane != 18) ? fx : __builtin_inf());
             else if (act) eval_lane<KIND, LDS>(P, tr, p, te, pert, pose_lane, own_grad, val, pvel, g_direct);
             n_pass++;
             // Shape gradient (getonlyGrad1) and dSDF/dt = grad . (body-frame point velocity) of EVERY block at once: the pose lane
