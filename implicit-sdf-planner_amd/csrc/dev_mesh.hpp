@@ -314,13 +314,23 @@ __device__ inline double mesh_sdf_grad(const DevMesh *m, d3 p, d3 &g) {
 //     asks for all of it at once (the addresses depend on (node, l) only);
 //   * the frames of the levels above (per quad: A, D, descend mask; per lane: its triangle's solid angle) and the closest-point
 //     stack live in LDS (MeshFrames, 12 levels: the reference's 12 000-face Trefoil.obj needs 9).
-struct MeshFrames {                            // one per WAVEFRONT, in LDS
-    float A[MESH_Q_LEVELS][16], D[MESH_Q_LEVELS][16], T[MESH_Q_LEVELS][64];
-    unsigned dm[MESH_Q_LEVELS][16];
-    unsigned long long set[MESH_Q_LEVELS];
-    int node[MESH_Q_LEVELS], cur[MESH_Q_LEVELS], cw[MESH_Q_LEVELS][4];
-    int s_node[3 * MESH_Q_LEVELS + 4], s_par[3 * MESH_Q_LEVELS + 4];
+// MeshFrames is a VIEW of one wavefront's frames: `lv` levels (the hierarchy's depth, so a 720-face robot pays for 6 levels of LDS,
+// not for the 12 the deepest supported hierarchy needs - the swept-volume kernels are latency bound and every workgroup more per CU
+// counts), 126 lv + 8 words at `w`.
+struct MeshFrames {
+    unsigned *w; int lv;
+    __device__ __forceinline__ unsigned long long &set(int L) const { return reinterpret_cast<unsigned long long *>(w)[L]; }
+    __device__ __forceinline__ float &A(int L, int q) const { return reinterpret_cast<float *>(w)[2 * lv + 16 * L + q]; }
+    __device__ __forceinline__ float &D(int L, int q) const { return reinterpret_cast<float *>(w)[18 * lv + 16 * L + q]; }
+    __device__ __forceinline__ unsigned &dm(int L, int q) const { return w[34 * lv + 16 * L + q]; }
+    __device__ __forceinline__ float &T(int L, int lane) const { return reinterpret_cast<float *>(w)[50 * lv + 64 * L + lane]; }
+    __device__ __forceinline__ int &cw(int L, int k) const { return reinterpret_cast<int *>(w)[114 * lv + 4 * L + k]; }
+    __device__ __forceinline__ int &node(int L) const { return reinterpret_cast<int *>(w)[118 * lv + L]; }
+    __device__ __forceinline__ int &cur(int L) const { return reinterpret_cast<int *>(w)[119 * lv + L]; }
+    __device__ __forceinline__ int &s_node(int i) const { return reinterpret_cast<int *>(w)[120 * lv + i]; }
+    __device__ __forceinline__ int &s_par(int i) const { return reinterpret_cast<int *>(w)[123 * lv + 4 + i]; }
 };
+__host__ __device__ constexpr int mesh_frames_words(int lv) { return 126 * lv + 8; }      // (even: the next wavefront's `set` stays 8-byte aligned)
 __device__ __forceinline__ int mesh_uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
 template <int K> __device__ __forceinline__ float quad_bcast(float v) {      // lane K of every quad -> its four lanes
     return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), K * 0x55, 0xf, 0xf, false));
@@ -388,7 +398,7 @@ __device__ __forceinline__ void mesh_quad_pre(const float *boxq, int node, bool 
 
 // UT_SolidAngle::computeSolidAngle for 16 queries: the four lanes of a quad pass the same (qx, qy, qz, act) and get the same
 // result.  Called by all 64 lanes; F = this wavefront's frames in LDS.
-__device__ inline float mesh_solid_angle_quad(const DevMesh *m, MeshFrames *F, float qx, float qy, float qz, bool act) {
+__device__ inline float mesh_solid_angle_quad(const DevMesh *m, MeshFrames F, float qx, float qy, float qz, bool act) {
 #pragma clang fp contract(off)
     const float acc2 = MESH_FWN_ACCURACY * MESH_FWN_ACCURACY;
     const int lane = (int)__lane_id(), l = lane & 3, qsh = lane & 60, qd = lane >> 2;
@@ -410,11 +420,11 @@ __device__ inline float mesh_solid_angle_quad(const DevMesh *m, MeshFrames *F, f
             const float v = A + D;
             if (L == 0) return v;
             --L;
-            node = mesh_uni(F->node[L]); cur = mesh_uni(F->cur[L]); S = F->set[L];
-            dm = F->dm[L][qd]; A = F->A[L][qd]; T = F->T[L][lane];
-            const float Dp = F->D[L][qd];
+            node = mesh_uni(F.node(L)); cur = mesh_uni(F.cur(L)); S = F.set(L);
+            dm = F.dm(L, qd); A = F.A(L, qd); T = F.T(L, lane);
+            const float Dp = F.D(L, qd);
             D = inS ? Dp + v : Dp;                                 // (the quads of the child's set are a subset of the parent's)
-            cw[0] = F->cw[L][0]; cw[1] = F->cw[L][1]; cw[2] = F->cw[L][2]; cw[3] = F->cw[L][3];
+            cw[0] = F.cw(L, 0); cw[1] = F.cw(L, 1); cw[2] = F.cw(L, 2); cw[3] = F.cw(L, 3);
             continue;
         }
         const int c = cur++;
@@ -432,9 +442,9 @@ __device__ inline float mesh_solid_angle_quad(const DevMesh *m, MeshFrames *F, f
             mesh_quad_pre(boxq, child, inU, l, qsh, qx, qy, qz, acc2, A2, d2, T2, cw2);
             if (!__ballot(inU && d2 != 0u)) { if (inU) D = D + A2; }      // nobody goes deeper: the child's value is its pre()
             else {
-                if (lane == 0) { F->node[L] = node; F->cur[L] = cur; F->set[L] = S; F->cw[L][0] = cw[0]; F->cw[L][1] = cw[1]; F->cw[L][2] = cw[2]; F->cw[L][3] = cw[3]; }
-                if (l == 0) { F->dm[L][qd] = dm; F->A[L][qd] = A; F->D[L][qd] = D; }
-                F->T[L][lane] = T;
+                if (lane == 0) { F.node(L) = node; F.cur(L) = cur; F.set(L) = S; F.cw(L, 0) = cw[0]; F.cw(L, 1) = cw[1]; F.cw(L, 2) = cw[2]; F.cw(L, 3) = cw[3]; }
+                if (l == 0) { F.dm(L, qd) = dm; F.A(L, qd) = A; F.D(L, qd) = D; }
+                F.T(L, lane) = T;
                 ++L;
                 node = child; cur = 0; S = U; dm = d2; A = A2; D = 0.f; T = T2;
                 cw[0] = cw2[0]; cw[1] = cw2[1]; cw[2] = cw2[2]; cw[3] = cw2[3];
@@ -448,7 +458,7 @@ __device__ inline float mesh_solid_angle_quad(const DevMesh *m, MeshFrames *F, f
 // triangle test in front of the walk cost more: C5-shaped blob 13.6 -> 15.3 ms, Trefoil.obj 11.8 -> 13.0 ms.)
 // Closest point for 16 queries.  `best` in: the query's cutoff (squared), out: min(exact squared distance, cutoff); `closest`
 // is written when a triangle beat the cutoff.  The four lanes of a quad pass the same arguments and get the same results.
-__device__ inline double mesh_closest_quad(const DevMesh *m, MeshFrames *F, d3 p, bool act, d3 &closest, double best) {
+__device__ inline double mesh_closest_quad(const DevMesh *m, MeshFrames F, d3 p, bool act, d3 &closest, double best) {
     const int lane = (int)__lane_id(), l = lane & 3, qsh = lane & 60;
     const mesh_cptr<DevMesh> mu = mesh_const_uni(m);
     const float *boxq = mu->fwn_boxq;
@@ -458,10 +468,10 @@ __device__ inline double mesh_closest_quad(const DevMesh *m, MeshFrames *F, d3 p
     int myf = -1;                          // ... and its face
     d3 myc = mk3(0, 0, 0);
     int sp = __ballot(act) ? 1 : 0;
-    if (lane == 0) { F->s_node[0] = 0; F->s_par[0] = -1; }
+    if (lane == 0) { F.s_node(0) = 0; F.s_par(0) = -1; }
     while (sp > 0) {
         sp = mesh_uni(sp) - 1;
-        const int node = mesh_uni(F->s_node[sp]), par = mesh_uni(F->s_par[sp]);
+        const int node = mesh_uni(F.s_node(sp)), par = mesh_uni(F.s_par(sp));
         // this lane's child: bound, child word, fp64 triangle - and the bound of the node itself (from its parent's record), all
         // requested together
         const float *rq = boxq + ((size_t)4 * node + l) * MESH_Q_REC;
@@ -517,10 +527,10 @@ __device__ inline double mesh_closest_quad(const DevMesh *m, MeshFrames *F, d3 p
         }
         if (lane == 0) {
             int q = sp;
-            if (c0 >= 0) { F->s_node[q] = c0 >> 2; F->s_par[q] = (node << 2) | (c0 & 3); ++q; }
-            if (c1 >= 0) { F->s_node[q] = c1 >> 2; F->s_par[q] = (node << 2) | (c1 & 3); ++q; }
-            if (c2 >= 0) { F->s_node[q] = c2 >> 2; F->s_par[q] = (node << 2) | (c2 & 3); ++q; }
-            if (c3 >= 0) { F->s_node[q] = c3 >> 2; F->s_par[q] = (node << 2) | (c3 & 3); ++q; }
+            if (c0 >= 0) { F.s_node(q) = c0 >> 2; F.s_par(q) = (node << 2) | (c0 & 3); ++q; }
+            if (c1 >= 0) { F.s_node(q) = c1 >> 2; F.s_par(q) = (node << 2) | (c1 & 3); ++q; }
+            if (c2 >= 0) { F.s_node(q) = c2 >> 2; F.s_par(q) = (node << 2) | (c2 & 3); ++q; }
+            if (c3 >= 0) { F.s_node(q) = c3 >> 2; F.s_par(q) = (node << 2) | (c3 & 3); ++q; }
         }
         sp += (c0 >= 0) + (c1 >= 0) + (c2 >= 0) + (c3 >= 0);
     }
@@ -538,7 +548,7 @@ __device__ inline double mesh_closest_quad(const DevMesh *m, MeshFrames *F, d3 p
 
 // mesh_sdf_grad / mesh_sdf_grad_below for 16 queries (all 64 lanes call; a quad passes the same arguments); cap = +infinity
 // gives the plain query.  Returns false when sdf >= cap is proven (or the query is not `act`).
-__device__ inline bool mesh_sdf_grad_below_quad(const DevMesh *m, MeshFrames *F, d3 p, bool act, double cap, double &sdf, d3 &g) {
+__device__ inline bool mesh_sdf_grad_below_quad(const DevMesh *m, MeshFrames F, d3 p, bool act, double cap, double &sdf, d3 &g) {
     float sa = mesh_solid_angle_quad(m, F, (float)p.x, (float)p.y, (float)p.z, act);
 #if ISDF_MESH_DUP == 1
     { float sb = mesh_solid_angle_quad(m, F, (float)p.x + 1e-30f, (float)p.y, (float)p.z, act); asm volatile("" : "+v"(sb)); if (sb == 12345.f) sa = sb; }

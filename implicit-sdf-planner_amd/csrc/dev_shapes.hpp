@@ -50,6 +50,7 @@ struct DevShape {
     double bound_radius;
     const DevMesh *mesh;
     int mesh_wg;              // 1: the swept-volume kernels give this mesh one task per WORKGROUP (quad-cooperative walks)
+    int mesh_levels;          // ... and the levels of walk frames a wavefront needs for it (the hierarchy's depth)
     // ISDF_SHAPE_GRID: num_sdf_map of BasicShape (Shape.hpp:376-404): 4 doubles per node (unit gradient, distance)
     const double *grid;
     int gn[3];

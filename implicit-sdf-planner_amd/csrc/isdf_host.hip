@@ -300,6 +300,7 @@ extern "C" int isdf_set_shape(isdf_ctx *c, const isdf_shape *s) {
     d.filter_f32 = (s->kind != ISDF_SHAPE_MESH) && !(getenv("ISDF_NO_F32_FILTER") && getenv("ISDF_NO_F32_FILTER")[0] == '1');
     d.mesh = nullptr;
     d.mesh_wg = 0;
+    d.mesh_levels = isdf::MESH_Q_LEVELS;
     if (s->kind == ISDF_SHAPE_MESH) {
         if (!s->mesh_vertices || !s->mesh_faces || s->n_faces < 1 || s->n_vertices < 3) return fail(c, ISDF_ERR_INVALID_ARG, "mesh shape needs vertices and faces");
         std::vector<double> tri((size_t)9 * s->n_faces);
@@ -381,6 +382,7 @@ extern "C" int isdf_set_shape(isdf_ctx *c, const isdf_shape *s) {
         HIPCHK(c, hipMemcpy(c->d_fwn_triq, triq.data(), triq.size() * sizeof(double), hipMemcpyHostToDevice));
         DevMesh hm{c->d_mesh_tri, c->d_mesh_trif, s->n_faces, c->d_fwn_child, c->d_fwn_box, tree.n_nodes(), c->d_fwn_boxq, c->d_fwn_triq, depth};
         // one task per workgroup pays when a pass is long (measured: 20 faces 1.15 -> 1.95 ms, 720 faces faster); ISDF_MESH_WG=0/1 forces
+        d.mesh_levels = std::max(2, std::min(depth, isdf::MESH_Q_LEVELS));
         d.mesh_wg = (s->n_faces >= 64 && depth <= isdf::MESH_Q_LEVELS) ? 1 : 0;
         if (const char *e = getenv("ISDF_MESH_WG")) d.mesh_wg = (e[0] == '1' && depth <= isdf::MESH_Q_LEVELS) ? 1 : 0;
         HIPCHK(c, hipMemcpy(c->d_mesh, &hm, sizeof(hm), hipMemcpyHostToDevice));

@@ -81,7 +81,7 @@ __device__ __forceinline__ TrajL<true> traj_stage(double *lds, const double *T, 
     __syncthreads();
     return TrajL<true>{lds, lds + Npad, N};
 }
-static size_t traj_lds_bytes(int N) { return ((size_t)((N + 3) & ~3) + (size_t)18 * N) * sizeof(double); }
+__host__ __device__ static inline size_t traj_lds_bytes(int N) { return ((size_t)((N + 3) & ~3) + (size_t)18 * N) * sizeof(double); }
 constexpr size_t TRAJ_LDS_MAX = 60 * 1024;      // beyond this (N > ~400) the kernels read the trajectory from global memory
 
 template <bool LDS>
@@ -176,7 +176,7 @@ struct MeshWG {
     double *stage;       // this wavefront's [64][4] compacted queries: point, cap (wave-private: no barrier)
     double *res;         // the workgroup's [2 parities][64][5] results: (below, sdf, g.xyz)
     int parity, wave;
-    MeshFrames *frames;  // this wavefront's walk frames (dev_mesh.hpp)
+    MeshFrames frames;   // this wavefront's walk frames (dev_mesh.hpp): a view into the dynamic LDS, as many levels as the hierarchy has
     int n_waves;         // wavefronts of the workgroup (4 in the scan: up to 64 queries per pass; 2 in the descent: 25)
 };
 constexpr int MESH_WG_RES = 2 * 64 * 5;
@@ -284,7 +284,6 @@ __device__ __forceinline__ void scan_body(const SweptParams &P, double *s_dyn, c
     __shared__ double s_rl[SW_WAVES][SW_MAX_RANGES], s_rr[SW_WAVES][SW_MAX_RANGES];
     __shared__ unsigned s_cnt[SW_WAVES][2], s_base[2];
     __shared__ double s_mesh[MESH ? mesh_wg_stage(WGM) + MESH_WG_RES : 1];
-    __shared__ MeshFrames s_frames[MESH ? WGM : 1];
     const unsigned long long dbg_t0 = (ISDF_SWEEP_STATS && P.dbg) ? wall_clock64() : 0ull;
     TrajL<LDS> tr{P.T, P.coeffs, P.N};
     if constexpr (LDS) tr = traj_stage(s_dyn, P.T, P.coeffs, P.N);
@@ -292,7 +291,9 @@ __device__ __forceinline__ void scan_body(const SweptParams &P, double *s_dyn, c
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int pt = P.point_begin + (MESH ? block : block * SW_WAVES + wave);
     const bool writer = lane == 0 && (!MESH || wave == 0);       // (the four wavefronts of a mesh workgroup hold the same results)
-    MeshWG mwg{s_mesh + wave * 64 * 4, s_mesh + (MESH ? mesh_wg_stage(WGM) : 0), 0, wave, &s_frames[MESH ? wave : 0], WGM};
+    const int m_lv = MESH ? P.shape.mesh_levels : 1;       // frames: behind the staged trajectory in the dynamic LDS, one set per wavefront
+    MeshWG mwg{s_mesh + wave * 64 * 4, s_mesh + (MESH ? mesh_wg_stage(WGM) : 0), 0, wave,
+               MeshFrames{reinterpret_cast<unsigned *>(reinterpret_cast<char *>(s_dyn) + (LDS ? traj_lds_bytes(P.N) : 0)) + (MESH ? wave * mesh_frames_words(m_lv) : 0), m_lv}, WGM};
     int my_nr = 0;
     if (pt < P.point_end) {
     unsigned long long *const dbg = (ISDF_SWEEP_STATS && P.dbg) ? P.dbg + (size_t)pt * 4 : nullptr;
@@ -479,13 +480,14 @@ template <int KIND, bool LDS, int WGM>
 __device__ __forceinline__ void descent_body(const SweptParams &P, double *s_dyn, const unsigned block, const unsigned n_blocks) {
     constexpr bool MESH = WGM != 0;      // one task per WORKGROUP of WGM wavefronts (mesh_eval_wg), else one per wavefront
     __shared__ double s_mesh[MESH ? mesh_wg_stage(WGM) + MESH_WG_RES : 1];
-    __shared__ MeshFrames s_frames[MESH ? WGM : 1];
     TrajL<LDS> tr{P.T, P.coeffs, P.N};
     if constexpr (LDS) tr = traj_stage(s_dyn, P.T, P.coeffs, P.N);
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const bool writer = lane == 0 && (!MESH || wave == 0);
-    MeshWG mwg{s_mesh + wave * 64 * 4, s_mesh + (MESH ? mesh_wg_stage(WGM) : 0), 0, wave, &s_frames[MESH ? wave : 0], WGM};
+    const int m_lv = MESH ? P.shape.mesh_levels : 1;       // frames: behind the staged trajectory in the dynamic LDS, one set per wavefront
+    MeshWG mwg{s_mesh + wave * 64 * 4, s_mesh + (MESH ? mesh_wg_stage(WGM) : 0), 0, wave,
+               MeshFrames{reinterpret_cast<unsigned *>(reinterpret_cast<char *>(s_dyn) + (LDS ? traj_lds_bytes(P.N) : 0)) + (MESH ? wave * mesh_frames_words(m_lv) : 0), m_lv}, WGM};
     const unsigned cap = (unsigned)(P.point_end - P.point_begin) * SW_MAX_RANGES;
     const unsigned n_front = (unsigned)__builtin_amdgcn_readfirstlane((int)P.words[0]);
     const unsigned n_tasks = n_front + (unsigned)__builtin_amdgcn_readfirstlane((int)P.words[2]);
@@ -900,12 +902,13 @@ void launch_swept_sweep(const SweptParams &P, hipStream_t stream, hipEvent_t ev_
                                    else { hipExtLaunchKernelGGL((swept_scan_kernel<K, false>), grid, block, 0, stream, ev_start, nullptr, 0, P); \
                                           hipExtLaunchKernelGGL((swept_descent_kernel<K, false>), grid, block, 0, stream, nullptr, ev_stop, 0, P); } break;
     if (mesh_wg) {
-        // scan: 4 wavefronts per point (a fine pass has up to 64 queries); descent: 2 per task (25 queries per pass = 16 + 9)
+        // two wavefronts per point / task (a fine pass of the scan has up to 64 queries: two rounds each; a descent pass 25 = 16 + 9)
         const dim3 block2(128);
-        if (in_lds) { hipExtLaunchKernelGGL((swept_scan_kernel<ISDF_SHAPE_MESH, true, 2>), grid, block2, lds, stream, ev_start, nullptr, 0, P);
-                      hipExtLaunchKernelGGL((swept_descent_kernel<ISDF_SHAPE_MESH, true, 2>), grid, block2, lds, stream, nullptr, ev_stop, 0, P); }
-        else { hipExtLaunchKernelGGL((swept_scan_kernel<ISDF_SHAPE_MESH, false, 2>), grid, block2, 0, stream, ev_start, nullptr, 0, P);
-               hipExtLaunchKernelGGL((swept_descent_kernel<ISDF_SHAPE_MESH, false, 2>), grid, block2, 0, stream, nullptr, ev_stop, 0, P); }
+        const size_t fr2 = (size_t)2 * mesh_frames_words(P.shape.mesh_levels) * sizeof(unsigned);      // two wavefronts' frames
+        // (the trajectory stays in global memory for these launches: a pass is dominated by the hierarchy walks, and the 6 KB of staged
+        // coefficients per workgroup were a workgroup less per CU - Trefoil.obj 9.0 -> 8.1 ms, 720 faces 4.75 -> 4.49 ms)
+        hipExtLaunchKernelGGL((swept_scan_kernel<ISDF_SHAPE_MESH, false, 2>), grid, block2, fr2, stream, ev_start, nullptr, 0, P);
+        hipExtLaunchKernelGGL((swept_descent_kernel<ISDF_SHAPE_MESH, false, 2>), grid, block2, fr2, stream, nullptr, ev_stop, 0, P);
         return;
     }
     switch (P.shape.kind) {

@@ -545,7 +545,7 @@ __global__ __launch_bounds__(64 * SW_SAMPLES, FUSED ? 3 : sweep_waves_per_simd(K
     __shared__ __attribute__((aligned(16))) int s_plan[SW_SAMPLES][4];                         // per sample: candidates, ring head, finished
     __shared__ double s_res[SW_SAMPLES][SW_NEAR_CAP / 64][ACC_STRIDE];   // per chunk: the 8 collision sums
     __shared__ int s_resn[SW_SAMPLES][SW_NEAR_CAP / 64][2];       // per chunk: exact pairs, active pairs
-    __shared__ MeshFrames s_mframes[KIND == ISDF_SHAPE_MESH ? SW_SAMPLES : 1];   // mesh robots: the quad walks' frames, one set per wavefront
+    __shared__ __attribute__((aligned(8))) unsigned s_mframes[KIND == ISDF_SHAPE_MESH ? SW_SAMPLES : 1][KIND == ISDF_SHAPE_MESH ? mesh_frames_words(MESH_Q_LEVELS) : 2];   // mesh robots: the quad walks' frames, one set per wavefront
 
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -1123,7 +1123,7 @@ __global__ __launch_bounds__(64 * SW_SAMPLES, FUSED ? 3 : sweep_waves_per_simd(K
                     const bool on = (wm >> src) & 1ull;
                     double s2 = 0.0;
                     d3 g2 = mk3(0, 0, 0);
-                    const bool b2 = mesh_sdf_grad_below_quad(P.shape.mesh, &s_mframes[wave], qp, on, P.safety_hor, s2, g2);
+                    const bool b2 = mesh_sdf_grad_below_quad(P.shape.mesh, MeshFrames{&s_mframes[wave][0], MESH_Q_LEVELS}, qp, on, P.safety_hor, s2, g2);
                     const int from = 4 * (lane & 15);                                    // back to the voxel's own lane
                     const double s3 = __shfl(s2, from, 64), gx3 = __shfl(g2.x, from, 64), gy3 = __shfl(g2.y, from, 64), gz3 = __shfl(g2.z, from, 64);
                     const int b3 = __shfl(b2 ? 1 : 0, from, 64);
@@ -1255,7 +1255,7 @@ __global__ __launch_bounds__(64 * SW_SAMPLES, FUSED ? 3 : sweep_waves_per_simd(K
 // and the wavefronts of the launch CLAIM items one at a time (an atomic counter): the device stays full until the queue is empty.
 // grad_cost_p (:766-824) per voxel exactly as the in-kernel pass forms it; a block's 8 sums by the same butterfly (the empty lanes add zeros).
 __global__ __launch_bounds__(64 * SW_SAMPLES, 5) void mesh_exact_kernel(const SweepParams P) {
-    __shared__ MeshFrames s_mframes[SW_SAMPLES];
+    __shared__ __attribute__((aligned(8))) unsigned s_mframes[SW_SAMPLES][mesh_frames_words(MESH_Q_LEVELS)];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const DevGrid &G = P.grid;
@@ -1290,7 +1290,7 @@ __global__ __launch_bounds__(64 * SW_SAMPLES, 5) void mesh_exact_kernel(const Sw
         }
         double sdf = 0.0;
         d3 g = mk3(0, 0, 0);
-        const bool below = mesh_sdf_grad_below_quad(P.shape.mesh, &s_mframes[wave], prel, want, P.safety_hor, sdf, g);
+        const bool below = mesh_sdf_grad_below_quad(P.shape.mesh, MeshFrames{&s_mframes[wave][0], MESH_Q_LEVELS}, prel, want, P.safety_hor, sdf, g);
         const bool owner = (lane & 3) == 0;                                      // one lane per voxel carries its terms into the sums
         bool is_grad = false;
         if (owner && want && below) {
