@@ -177,7 +177,7 @@ extern "C" int isdf_destroy(isdf_ctx *c) {
     isdf_xchg_release(c);
     void *ptrs[] = {c->d_cb, c->d_esdf, c->d_occ, c->d_points, c->d_tstar, c->d_acc, c->d_sample_info, c->d_bits, c->d_piece_cost, c->d_in, c->d_out, c->d_stats,
                     c->d_traj_duration, c->d_coarse_t, c->d_coarse_pose, c->d_n_coarse, c->d_point_partial, c->d_point_piece, c->d_point_stat, c->d_point_nr, c->d_task_buf,
-                    c->d_task_map, c->d_v1_words, c->d_point_lmask, c->d_hist, c->d_shape_grid, c->d_pose, c->d_mq_entries, c->d_mq_items, c->d_mq_res, c->d_mq_sample_items, c->d_mq_sample_n, c->d_mq_count, c->d_msum_blocks, c->d_dbg, c->d_stage, c->d_stage_flags, c->d_sample_map, c->d_plan_cls, c->d_plan_map, c->d_plan_lr, c->d_plan_hist};
+                    c->d_task_map, c->d_v1_words, c->d_point_lmask, c->d_scan_ticks, c->d_scan_order, c->d_hist, c->d_shape_grid, c->d_pose, c->d_mq_entries, c->d_mq_items, c->d_mq_res, c->d_mq_sample_items, c->d_mq_sample_n, c->d_mq_count, c->d_msum_blocks, c->d_dbg, c->d_stage, c->d_stage_flags, c->d_sample_map, c->d_plan_cls, c->d_plan_map, c->d_plan_lr, c->d_plan_hist};
     for (void *p : ptrs) if (p) (void)hipFree(p);
     free_mesh(c);
     if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -629,6 +629,9 @@ static int eval_device_impl(isdf_ctx *c, int n_traj, int N, const double *d_T, c
             if (c->d_task_map) (void)hipFree(c->d_task_map);
             if (c->d_point_lmask) (void)hipFree(c->d_point_lmask);
             c->d_point_lmask = nullptr;
+            if (c->d_scan_ticks) (void)hipFree(c->d_scan_ticks);
+            if (c->d_scan_order) (void)hipFree(c->d_scan_order);
+            c->d_scan_ticks = nullptr; c->d_scan_order = nullptr;
             c->d_point_partial = nullptr; c->d_point_piece = nullptr; c->d_point_stat = nullptr; c->point_cap = 0;
             c->d_point_nr = nullptr; c->d_task_buf = nullptr; c->d_task_map = nullptr;
             HIPCHK(c, hipMalloc(&c->d_point_partial, (size_t)c->M * PARTIAL_STRIDE * sizeof(double)));
@@ -640,6 +643,9 @@ static int eval_device_impl(isdf_ctx *c, int n_traj, int N, const double *d_T, c
             HIPCHK(c, hipMalloc(&c->d_task_map, (size_t)c->M * 32 * sizeof(unsigned)));
             HIPCHK(c, hipMalloc(&c->d_point_lmask, (size_t)c->M * sizeof(unsigned)));
             HIPCHK(c, hipMemset(c->d_point_lmask, 0, (size_t)c->M * sizeof(unsigned)));
+            HIPCHK(c, hipMalloc(&c->d_scan_ticks, (size_t)c->M * sizeof(unsigned)));
+            HIPCHK(c, hipMemset(c->d_scan_ticks, 0, (size_t)c->M * sizeof(unsigned)));
+            HIPCHK(c, hipMalloc(&c->d_scan_order, (size_t)c->M * sizeof(int)));
             if (!c->d_v1_words) HIPCHK(c, hipMalloc(&c->d_v1_words, 8 * sizeof(unsigned)));
             HIPCHK(c, hipMemset(c->d_v1_words, 0, 8 * sizeof(unsigned)));
             c->point_cap = c->M;
@@ -647,6 +653,8 @@ static int eval_device_impl(isdf_ctx *c, int n_traj, int N, const double *d_T, c
         P.coarse_t = c->d_coarse_t; P.coarse_pose = c->d_coarse_pose; P.n_coarse = c->d_n_coarse;
         P.point_partial = c->d_point_partial; P.point_piece = c->d_point_piece; P.point_stat = c->d_point_stat;
         P.point_nr = c->d_point_nr; P.task_buf = c->d_task_buf; P.task_map = c->d_task_map; P.words = c->d_v1_words; P.point_lmask = c->d_point_lmask;
+        const bool scan_lpt = c->shape.kind == ISDF_SHAPE_MESH && c->shape.mesh_wg && !c->env_no_lpt;
+        P.scan_ticks = scan_lpt ? c->d_scan_ticks : nullptr; P.scan_order = scan_lpt ? c->d_scan_order : nullptr;
         P.direct_records = fixed_tstar ? 1 : 0;
         { int rc2 = ensure(c, &c->d_hist, &c->hist_cap, (size_t)N); if (rc2) return rc2; }
         P.hist = c->d_hist;

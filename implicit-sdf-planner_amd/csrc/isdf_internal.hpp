@@ -133,6 +133,8 @@ struct SweptParams {
     int *point_nr;              // [M] scan kernel: intervals | scan passes << 8
     double *task_buf;           // [M][32][6] per (point, interval): in (lb, ub, seed), out (t, sdf, gradient, counters)
     unsigned *task_map;         // [<= 32 M] task list of the descent: point (relative to point_begin) << 5 | interval
+    unsigned *scan_ticks;       // [M] mesh robots: how long the scan of point i took last step (1.28 us units); null: scan in point order
+    int *scan_order;            // [M] ... and this step's dispatch order of the scan, longest first (built by the prepare kernel)
     unsigned *point_lmask;      // [M] bit r: the descent of interval r was long last step (set by the descent kernel, consumed by the scan's list builder)
     unsigned *words;            // [0] tasks at the front of the list (long last step) [2] tasks at its back: zeroed by the prepare kernel, reserved by the
                                 // scan kernel's workgroups

@@ -123,6 +123,20 @@ __global__ __launch_bounds__(1024) void swept_prepare_kernel(const SweptParams P
         P.words[4] = 0u; P.words[5] = 0u;
     }
     __syncthreads();
+    // Mesh robots: the scan's dispatch order, longest first by last step's measured duration (a point next to the robot's path scans
+    // for a millisecond, most for 50 us: in point order the launch ended on a tail as long as the rest of it).  A counting sort into
+    // 16 classes (bit length of the duration); the order inside a class does not matter - scheduling only.
+    if (P.scan_order) {
+        __shared__ unsigned s_cls[16];
+        const int np = P.point_end - P.point_begin;
+        if (threadIdx.x < 16) s_cls[threadIdx.x] = 0u;
+        __syncthreads();
+        for (int i = threadIdx.x; i < np; i += blockDim.x) atomicAdd(&s_cls[15 - min(15, 32 - __clz((int)P.scan_ticks[i]))], 1u);
+        __syncthreads();
+        if (threadIdx.x == 0) { unsigned run = 0u; for (int k = 0; k < 16; k++) { const unsigned h = s_cls[k]; s_cls[k] = run; run += h; } }
+        __syncthreads();
+        for (int i = threadIdx.x; i < np; i += blockDim.x) P.scan_order[atomicAdd(&s_cls[15 - min(15, 32 - __clz((int)P.scan_ticks[i]))], 1u)] = i;
+    }
     const int n = s_n;
     for (int k = threadIdx.x; k < n; k += blockDim.x) {
         d3 x; m3 R;
@@ -289,7 +303,8 @@ __device__ __forceinline__ void scan_body(const SweptParams &P, double *s_dyn, c
     if constexpr (LDS) tr = traj_stage(s_dyn, P.T, P.coeffs, P.N);
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int pt = P.point_begin + (MESH ? block : block * SW_WAVES + wave);
+    const unsigned long long scan_t0 = MESH ? wall_clock64() : 0ull;
+    const int pt = P.point_begin + (MESH ? (P.scan_order ? __builtin_amdgcn_readfirstlane(P.scan_order[block]) : block) : block * SW_WAVES + wave);
     const bool writer = lane == 0 && (!MESH || wave == 0);       // (the four wavefronts of a mesh workgroup hold the same results)
     const int m_lv = MESH ? P.shape.mesh_levels : 1;       // frames: behind the staged trajectory in the dynamic LDS, one set per wavefront
     MeshWG mwg{s_mesh + wave * 64 * 4, s_mesh + (MESH ? mesh_wg_stage(WGM) : 0), 0, wave,
@@ -412,6 +427,7 @@ __device__ __forceinline__ void scan_body(const SweptParams &P, double *s_dyn, c
     }
     if (writer) {
         P.point_nr[pt] = n_ranges | (n_pass << 8);
+        if constexpr (MESH) if (P.scan_ticks) P.scan_ticks[pt - P.point_begin] = (unsigned)min((wall_clock64() - scan_t0) >> 7, 0x7FFFFFFFull);
         if (dbg) dbg[3] = (wall_clock64() << 16) | (unsigned long long)(n_pass & 0xFFF) | ((unsigned long long)(n_ranges & 0xF) << 12);
     }
     my_nr = n_ranges;
