@@ -520,6 +520,7 @@ __device__ __forceinline__ void descent_body(const SweptParams &P, double *s_dyn
     for (unsigned task = MESH ? block : block * SW_WAVES + wave, rounds = 0; task < n_tasks && rounds < (1u << 16); task += n_waves, rounds++) {
         const unsigned tm = (unsigned)__builtin_amdgcn_readfirstlane((int)(task < n_front ? P.task_map[task] : P.task_map[cap - 1u - (task - n_front)]));
         const unsigned long long dbg_t0 = ((ISDF_SWEEP_STATS && P.dbg) || KIND == ISDF_SHAPE_MESH) ? wall_clock64() : 0ull;
+        // (measured: raising the issue priority of the tasks at the front of the list changes nothing - the walks wait for loads, not for issue slots)
         const int rel = (int)(tm >> 5), r = (int)(tm & 31u);
         const int pt = P.point_begin + rel;
         double *const slot = P.task_buf + ((size_t)rel * SW_MAX_RANGES + r) * TASK_STRIDE;
@@ -654,7 +655,7 @@ __device__ __forceinline__ void descent_body(const SweptParams &P, double *s_dyn
             if (long_task) atomicOr(&P.point_lmask[pt], 1u << r);
             if (ISDF_SWEEP_STATS && P.dbg && task < (unsigned)P.M) {      // developer timing (ISDF_DEBUG_TIMING=1): start, end, passes of this task
                 unsigned long long *d = P.dbg + (size_t)P.M * 4 + (size_t)(P.N + 1) * 8 + (size_t)task * 3;
-                d[0] = dbg_t0; d[1] = wall_clock64(); d[2] = (unsigned long long)n_pass | ((unsigned long long)(task < n_front) << 32);
+                d[0] = dbg_t0; d[1] = wall_clock64(); d[2] = (unsigned long long)n_pass | ((unsigned long long)(task < n_front) << 32) | ((unsigned long long)(iter & 0xFFFF) << 40);
             }
         }
     }

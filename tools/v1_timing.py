@@ -67,5 +67,10 @@ ts, te, tp = tk[ok, 0].astype(np.int64), tk[ok, 1].astype(np.int64), (tk[ok, 2] 
 b2 = ts.min()
 print(f"V1 descent kernel: {ok.sum()} tasks recorded, span {us(te.max() - b2):.1f} us; gap scan end -> descent start {us(b2 - t3.max()):.1f} us")
 print("  task start :", pct(us(ts - b2))); print("  task time  :", pct(us(te - ts))); print("  passes     :", pct(tp))
+ti = ((tk[ok, 2] >> np.uint64(40)) & np.uint64(0xFFFF)).astype(int)
+dur = us(te - ts)
+lg = np.argsort(-dur)[:12]
+print("  the 12 longest tasks (us, passes, sign-descent iterations):", ", ".join(f"{dur[i]:.0f}/{tp[i]}/{ti[i]}" for i in lg))
+print("  iterations per pass:", pct(ti / np.maximum(tp, 1)))
 print("  us per pass:", pct(us(te - ts) / np.maximum(tp, 1)))
 print("  task end   :", pct(us(te - b2)))
