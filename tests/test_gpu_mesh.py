@@ -168,6 +168,43 @@ def test_mesh_with_degenerate_and_duplicate_triangles(pkg, orc, product_lib):
     assert (np.linalg.norm(g - g0, axis=1) <= 1e-6).mean() > 0.995     # doubled faces tie exactly: either copy's closest point
 
 
+def test_mesh_v1_does_not_depend_on_the_dispatch_orders(pkg, orc, product_lib, monkeypatch):
+    """Mesh robots, V1: the scan's points and the descents are dispatched longest-first by LAST step's measured durations (the
+    prepare kernel's counting sort, the task list's front / back) - scheduling only: repeated steps on one ctx (whose orders
+    change from step to step), a fresh ctx and ISDF_NO_LPT=1 return the same bits, t* included."""
+    capi, synth = pkg.capi, pkg.synth
+    occ, esdf, res = small_world(pkg, seed=14)
+    T, cm = traj(pkg, occ, res, N=5, seed=23)
+    V, F = synth.blob_mesh(24, 16, scale=0.9)
+    way = cm.reshape(3, -1).T.reshape(5, 6, 3)[1:, 0, :]
+    pts = synth.constraint_points(occ, (0, 0, 0), res, way, half=3.0)
+    cfg1 = synth.default_config(capi.V1_SWEPT, safety_hor=0.5)
+
+    def mk():
+        e = pkg.Engine(cfg1); e.set_grid(occ, (0, 0, 0), res, capi.GRID_OCCUPANCY); e.set_shape(synth.make_mesh_shape(V, F)); e.set_points(pts)
+        return e
+
+    def step(e, T_, cm_):
+        ts = -np.ones(len(pts))
+        c, gT, gC = e.eval_single(T_, cm_, tstar=ts)
+        return c, gT, gC, ts
+
+    e = mk()
+    ref = step(e, T, cm)
+    assert ref[0] > 0 and (ref[3] >= 0).any()
+    T2, cm2 = traj(pkg, occ, res, N=5, seed=29)
+    other = step(e, T2, cm2)                               # another trajectory in between: the durations it leaves order the next step
+    for _ in range(3):
+        again = step(e, T, cm)
+        assert again[0] == ref[0] and all(np.array_equal(x, y) for x, y in zip(again[1:], ref[1:]))
+    monkeypatch.setenv("ISDF_NO_LPT", "1")
+    plain = mk()
+    monkeypatch.delenv("ISDF_NO_LPT")
+    for want, (T_, cm_) in ((ref, (T, cm)), (other, (T2, cm2))):
+        got = step(plain, T_, cm_)
+        assert got[0] == want[0] and all(np.array_equal(x, y) for x, y in zip(got[1:], want[1:]))
+
+
 def test_mesh_walk_forms_agree(pkg, orc, product_lib, monkeypatch):
     """The mesh kind has two forms of each sweep: V1 with one task per wavefront (wave-cooperative walks, small meshes) or per
     workgroup (quad-cooperative walks; ISDF_MESH_WG forces either), and the tile sweep with its exact pass inside the sweep kernel
