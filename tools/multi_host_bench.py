@@ -2,7 +2,7 @@
 """Developer tool: isdf_eval through the compiled binding on a ctx over 1 / 2 / 8 devices (this GPU listed repeatedly): what the
 one-process multi-device step costs the calling thread.  ISDF_MULTI_NO_PULL=1: the peer-copy form."""
 import os, sys
-sys.path.insert(0, "/root/repo")
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 import __graft_entry__ as graft
 import torch

@@ -1,5 +1,5 @@
 import os, sys
-sys.path.insert(0, "/root/repo"); sys.path.insert(0, "/root/repo/tools")
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__)))); sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 import numpy as np, torch
 import __graft_entry__ as graft
 pkg = graft.load_package(); capi, synth = pkg.capi, pkg.synth
