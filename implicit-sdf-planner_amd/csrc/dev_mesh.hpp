@@ -205,7 +205,18 @@ __device__ inline float mesh_solid_angle(const DevMesh *m, float qx, float qy, f
     }
 }
 
-// squared distance to the closest triangle and that point: branch and bound over the hierarchy's bounding spheres
+// per-lane lower bound (squared) of the distance from p to the bounding box of child l of `node` (the child-major record's floats
+// 34..39, rounded outwards on the host - the same bound as the quad walks': around the flat faces of a small robot a box has no
+// thickness where the winding number's sphere has the face's radius)
+template <typename FP>
+__device__ __forceinline__ double mesh_child_lb2_box(FP boxq, int node, int l, d3 p) {
+    const FP q = boxq + ((size_t)4 * node + l) * MESH_Q_REC + 34;
+    const double ex = fmax(fmax((double)q[0] - p.x, p.x - (double)q[3]), 0.0);
+    const double ey = fmax(fmax((double)q[1] - p.y, p.y - (double)q[4]), 0.0);
+    const double ez = fmax(fmax((double)q[2] - p.z, p.z - (double)q[5]), 0.0);
+    return (ex * ex + ey * ey + ez * ez) * 0.999999999999;
+}
+// squared distance to the closest triangle and that point: branch and bound over the hierarchy's bounding boxes
 // `cutoff2`: only triangles closer than sqrt(cutoff2) are of interest; the result is min(exact squared distance, cutoff2)
 // and `closest` is written only when a triangle beat the cutoff (the walk prunes against it from the start)
 __device__ inline double mesh_closest(const DevMesh *m, d3 p, d3 &closest, double cutoff2 = 1.7976931348623157e308) {
@@ -219,17 +230,12 @@ __device__ inline double mesh_closest(const DevMesh *m, d3 p, d3 &closest, doubl
         --sp;
         if (stk_lb[sp] >= best) continue;
         const int nodei = stk[sp];
-        const float *r = m->fwn_box + (size_t)92 * nodei;
         const int *ch = m->fwn_child + 4 * nodei;
         int cid[4]; double clb[4]; int n = 0;
         for (int l = 0; l < 4; l++) {
             const int ci = ch[l];
             if (ci == -1) break;
-            const double px = r[4 + l], py = r[8 + l], pz = r[12 + l];
-            const double dx = p.x - px, dy = p.y - py, dz = p.z - pz;
-            // radius padded for the float rounding of P / maxP2 and the float copies of the vertices they were built from
-            const double rad = (double)sqrtf(r[l]) * 1.00001 + 1e-6 * (fabs(px) + fabs(py) + fabs(pz) + 1.0);
-            const double lb = fmax(sqrt(dx * dx + dy * dy + dz * dz) - rad, 0.0), lb2 = lb * lb;
+            const double lb2 = mesh_child_lb2_box(m->fwn_boxq, nodei, l, p);
             if (lb2 >= best) continue;
             if (ci >= 0) {
                 const double *t = m->tri + (size_t)9 * ci;
@@ -651,7 +657,7 @@ __device__ __forceinline__ double mesh_child_lb2(FP r, int l, d3 p) {
 __device__ inline double mesh_closest_wave(const DevMesh *m, d3 p, bool act, d3 &closest, double best) {
     int s_node[MESH_STACK], s_par[MESH_STACK];
     const mesh_cptr<DevMesh> mu = mesh_const_uni(m);
-    const mesh_cptr<float> box = mesh_const_uni(mu->fwn_box);
+    const mesh_cptr<float> boxq = mesh_const_uni(mu->fwn_boxq);
     const mesh_cptr<int> chl = mesh_const_uni(mu->fwn_child);
     const mesh_cptr<double> tri = mesh_const_uni(mu->tri);
     int bestf = -1;
@@ -661,10 +667,9 @@ __device__ inline double mesh_closest_wave(const DevMesh *m, d3 p, bool act, d3 
         sp = mesh_uni(sp) - 1;
         const int node = mesh_uni(s_node[sp]), par = mesh_uni(s_par[sp]);
         if (par >= 0) {                                           // the bests may have improved since this node was pushed
-            const double lb2 = mesh_child_lb2(box + (size_t)92 * (par >> 2), par & 3, p);
+            const double lb2 = mesh_child_lb2_box(boxq, par >> 2, par & 3, p);
             if (!__ballot(act && lb2 < best)) continue;
         }
-        const mesh_cptr<float> r = box + (size_t)92 * node;
         const mesh_cptr<int> ch = chl + 4 * node;
         // (up to four internal children, kept sorted by decreasing bound in NAMED scalars: a dynamically indexed private
         // array would live in scratch memory)
@@ -673,7 +678,7 @@ __device__ inline double mesh_closest_wave(const DevMesh *m, d3 p, bool act, d3 
         for (int l = 0; l < 4; l++) {
             const int ci = mesh_uni(ch[l]);
             if (ci == -1) break;
-            const double lb2 = mesh_child_lb2(r, l, p);
+            const double lb2 = mesh_child_lb2_box(boxq, node, l, p);
             const bool want = act && lb2 < best;
             const unsigned long long U = __ballot(want);
             if (!U) continue;
