@@ -303,8 +303,10 @@ __device__ __forceinline__ void scan_body(const SweptParams &P, double *s_dyn, c
     if constexpr (LDS) tr = traj_stage(s_dyn, P.T, P.coeffs, P.N);
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const unsigned long long scan_t0 = MESH ? wall_clock64() : 0ull;
-    const int pt = P.point_begin + (MESH ? (P.scan_order ? __builtin_amdgcn_readfirstlane(P.scan_order[block]) : block) : block * SW_WAVES + wave);
+    const unsigned long long scan_t0 = KIND == ISDF_SHAPE_MESH ? wall_clock64() : 0ull;
+    int pt_rel = MESH ? block : block * SW_WAVES + wave;      // mesh robots: through the longest-first order of the prepare kernel
+    if constexpr (KIND == ISDF_SHAPE_MESH) if (P.scan_order && pt_rel < P.point_end - P.point_begin) pt_rel = __builtin_amdgcn_readfirstlane(P.scan_order[pt_rel]);
+    const int pt = P.point_begin + pt_rel;
     const bool writer = lane == 0 && (!MESH || wave == 0);       // (the four wavefronts of a mesh workgroup hold the same results)
     const int m_lv = MESH ? P.shape.mesh_levels : 1;       // frames: behind the staged trajectory in the dynamic LDS, one set per wavefront
     MeshWG mwg{s_mesh + wave * 64 * 4, s_mesh + (MESH ? mesh_wg_stage(WGM) : 0), 0, wave,
@@ -427,7 +429,7 @@ __device__ __forceinline__ void scan_body(const SweptParams &P, double *s_dyn, c
     }
     if (writer) {
         P.point_nr[pt] = n_ranges | (n_pass << 8);
-        if constexpr (MESH) if (P.scan_ticks) P.scan_ticks[pt - P.point_begin] = (unsigned)min((wall_clock64() - scan_t0) >> 7, 0x7FFFFFFFull);
+        if constexpr (KIND == ISDF_SHAPE_MESH) if (P.scan_ticks) P.scan_ticks[pt - P.point_begin] = (unsigned)min((wall_clock64() - scan_t0) >> 7, 0x7FFFFFFFull);
         if (dbg) dbg[3] = (wall_clock64() << 16) | (unsigned long long)(n_pass & 0xFFF) | ((unsigned long long)(n_ranges & 0xF) << 12);
     }
     my_nr = n_ranges;
