@@ -234,7 +234,7 @@ __device__ inline bool mesh_eval_wg(MeshWG &X, const DevMesh *m, d3 pr, bool act
 // ---- the ONE pose + SDF evaluation both kernels below are built around: pose at `te`, body-frame point (perturbed for a
 // gradient sample), shape SDF; pose lanes also form the body-frame point velocity (getSDF_DOTAtTimeStampOptimized :593-662).
 // Analytic kinds: called by the lanes that evaluate.  Mesh kind: called by ALL lanes of the workgroup, `act` says which evaluate.
-template <int KIND, bool LDS, bool WG = false>
+template <int KIND, bool LDS, bool WG = false, bool CAPPED = false>
 __device__ __forceinline__ void eval_lane(const SweptParams &P, const TrajL<LDS> &tr, const d3 p, const double te, const int pert,
                                           const bool pose_lane, const bool own_grad, double &val, d3 &pvel, d3 &g_direct,
                                           MeshWG *X = nullptr, const bool act = true, const double cap = __builtin_inf()) {
@@ -275,8 +275,11 @@ __device__ __forceinline__ void eval_lane(const SweptParams &P, const TrajL<LDS>
         if (act && below) val = v;
         if (act && pose_lane) g_direct = gq;
     } else if constexpr (KIND == ISDF_SHAPE_MESH) {
-        d3 gq;
-        val = mesh_sdf_grad_wave(P.shape.mesh, pr, gq);          // the executing lanes walk the hierarchy together (dev_mesh.hpp)
+        d3 gq = mk3(0, 0, 0);
+        if constexpr (CAPPED) {                                  // (the scan's fine passes: only "val < cap?" and the value when yes)
+            double v = 1e300;
+            if (mesh_sdf_grad_below_wave(P.shape.mesh, pr, cap, v, gq)) val = v;
+        } else val = mesh_sdf_grad_wave(P.shape.mesh, pr, gq);   // the executing lanes walk the hierarchy together (dev_mesh.hpp)
         if (pose_lane) g_direct = gq;
     } else {
         val = shape_sdf<KIND>(P.shape, pr);
@@ -416,7 +419,7 @@ __device__ __forceinline__ void scan_body(const SweptParams &P, double *s_dyn, c
             d3 pv_unused = mk3(0, 0, 0), g_unused = pv_unused;
             // (mesh robots: only a value BELOW the running minimum can change it - the hierarchy's distance cutoff answers the rest)
             if constexpr (MESH) eval_lane<KIND, LDS, true>(P, tr, p, act ? te : lb, 0, false, false, val, pv_unused, g_unused, &mwg, act, range_mindis);
-            else if (act) eval_lane<KIND, LDS>(P, tr, p, te, 0, false, false, val, pv_unused, g_unused);
+            else if (act) eval_lane<KIND, LDS, false, KIND == ISDF_SHAPE_MESH>(P, tr, p, te, 0, false, false, val, pv_unused, g_unused, nullptr, true, range_mindis);
             n_pass++;
             const int nv = __popcll(__ballot(act));                  // valid lanes form a prefix (t is increasing)
             int arg;
