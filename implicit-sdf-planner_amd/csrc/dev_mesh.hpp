@@ -518,13 +518,13 @@ __device__ inline double mesh_closest_quad(const DevMesh *m, MeshFrames F, d3 p,
         const unsigned long long W = __ballot(ci < -1 && lb2 < best);
         if (!W) continue;
         int c0 = -1, c1 = -1, c2 = -1, c3 = -1;
-        double r0 = -1.0, r1 = -1.0, r2 = -1.0;
+        int r0 = -1, r1 = -1, r2 = -1;                           // (the bounds as float BITS: non-negative floats order like integers - scalar compares)
+        const int lbf = __builtin_bit_cast(int, (float)lb2);      // the visiting order needs no more than a float of the bound
         for (int k = 0; k < 4; k++) {
             const unsigned long long Uk = W & (0x1111111111111111ull << k);
             if (!Uk) continue;
             const int fl = __ffsll((long long)Uk) - 1;
-            const int lo = __builtin_amdgcn_readlane(__double2loint(lb2), fl), hi = __builtin_amdgcn_readlane(__double2hiint(lb2), fl);
-            const double rep = __hiloint2double(hi, lo);
+            const int rep = __builtin_amdgcn_readlane(lbf, fl);
             const int cwk = ((__builtin_amdgcn_readlane(ci, fl) & 0x7fffffff) << 2) | k;
             if (rep > r0) { c3 = c2; c2 = c1; r2 = r1; c1 = c0; r1 = r0; c0 = cwk; r0 = rep; }
             else if (rep > r1) { c3 = c2; c2 = c1; r2 = r1; c1 = cwk; r1 = rep; }
@@ -674,7 +674,7 @@ __device__ inline double mesh_closest_wave(const DevMesh *m, d3 p, bool act, d3 
         // (up to four internal children, kept sorted by decreasing bound in NAMED scalars: a dynamically indexed private
         // array would live in scratch memory)
         int c0 = -1, c1 = -1, c2 = -1, c3 = -1;
-        double r0 = -1.0, r1 = -1.0, r2 = -1.0;
+        int r0 = -1, r1 = -1, r2 = -1;
         for (int l = 0; l < 4; l++) {
             const int ci = mesh_uni(ch[l]);
             if (ci == -1) break;
@@ -693,8 +693,7 @@ __device__ inline double mesh_closest_wave(const DevMesh *m, d3 p, bool act, d3 
             } else {
                 // visiting order: by the bound of the first lane that wants the child (the lanes are neighbours); rep >= 0
                 const int fl = __ffsll((long long)U) - 1;
-                const int lo = __builtin_amdgcn_readlane(__double2loint(lb2), fl), hi = __builtin_amdgcn_readlane(__double2hiint(lb2), fl);
-                const double rep = __hiloint2double(hi, lo);
+                const int rep = __builtin_amdgcn_readlane(__builtin_bit_cast(int, (float)lb2), fl);      // float bits of a non-negative bound: ordered like integers
                 const int cw = ((ci & 0x7fffffff) << 2) | l;
                 if (rep > r0) { c3 = c2; c2 = c1; r2 = r1; c1 = c0; r1 = r0; c0 = cw; r0 = rep; }
                 else if (rep > r1) { c3 = c2; c2 = c1; r2 = r1; c1 = cw; r1 = rep; }
