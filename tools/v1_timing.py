@@ -17,26 +17,33 @@ def pct(a):
     return "(none)" if a.size == 0 else "min %.2f p50 %.2f p90 %.2f p99 %.2f max %.2f" % (a.min(), np.percentile(a, 50), np.percentile(a, 90), np.percentile(a, 99), a.max())
 
 
-res = 0.2
-occ, esdf, T, cm = build_workload(pkg, 40, 256, res)
 which = sys.argv[1] if len(sys.argv) > 1 else "cone"
+NP = 40
+if which == "c5blob":          # the C5-shaped bench entry: 512^3 occupancy @ 0.1 m, 20 pieces, the 720-face blob
+    res = 0.1; NP = 20
+    occ = synth.random_box_map((512,) * 3, res=res, occupancy=0.15, seed=12345, edge=(0.4, 2.0))
+    T, Cf = synth.random_trajectory(np.array(occ.shape) * res, NP, seed=780, piece_T=1.0, jitter=0.5, margin=4.0, occ=occ, res=res)
+    cm = synth.colmajor(Cf)
+else:
+    res = 0.2
+    occ, esdf, T, cm = build_workload(pkg, 40, 256, res)
 if which == "box":
     shape = synth.bench_box_shape()
 elif which == "mesh20":
     shape = synth.make_mesh_shape(*synth.l_prism_mesh())
-elif which == "mesh720":
+elif which in ("mesh720", "c5blob"):
     shape = synth.make_mesh_shape(*synth.blob_mesh(24, 16, scale=0.9))
 else:
     shape = synth.bench_rounded_cone_shape()
 cfg1 = synth.default_config(capi.V1_SWEPT, safety_hor=(3 ** 0.5 / 2) * res, weight_p=4000.0)
 eng = pkg.Engine(cfg1); eng.set_grid(occ, (0, 0, 0), res, capi.GRID_OCCUPANCY); eng.set_shape(shape)
-way = cm.reshape(3, -1).T.reshape(40, 6, 3)[1:, 0, :]
-M = eng.gather_points(way, 1.4)
+way = cm.reshape(3, -1).T.reshape(NP, 6, 3)[1:, 0, :]
+M = eng.gather_points(way, 0.9 if which == 'c5blob' else 1.4)
 dev = torch.device("cuda", 0); st = torch.cuda.current_stream().cuda_stream
 d_T = torch.from_numpy(T).to(dev); d_C = torch.from_numpy(cm).to(dev)
-d_out = torch.zeros(eng.out_stride(40), dtype=torch.float64, device=dev)
+d_out = torch.zeros(eng.out_stride(NP), dtype=torch.float64, device=dev)
 for _ in range(3 if which.startswith('mesh') else 6):
-    eng.eval_device(1, 40, d_T.data_ptr(), d_C.data_ptr(), d_out.data_ptr(), 0, st)
+    eng.eval_device(1, NP, d_T.data_ptr(), d_C.data_ptr(), d_out.data_ptr(), 0, st)
 torch.cuda.synchronize()
 lib = eng.lib
 lib.isdf_debug_timing.restype = C.c_longlong
@@ -44,7 +51,7 @@ lib.isdf_debug_timing.argtypes = [C.c_void_p, C.c_void_p, C.c_longlong]
 n = lib.isdf_debug_timing(eng.h, None, 0)
 buf = np.zeros(n, dtype=np.uint64)
 lib.isdf_debug_timing(eng.h, buf.ctypes.data_as(C.c_void_p), n)
-N = 40
+N = NP
 pt = buf[:M * 4].reshape(M, 4)
 t0 = pt[:, 0].astype(np.int64); t1 = pt[:, 1].astype(np.int64); t2 = pt[:, 2].astype(np.int64)
 t3 = (pt[:, 3] >> np.uint64(16)).astype(np.int64); npass = (pt[:, 3] & np.uint64(0xFFF)).astype(int); nrng = ((pt[:, 3] >> np.uint64(12)) & np.uint64(0xF)).astype(int)
