@@ -95,7 +95,7 @@ EXPORTED_SYMBOLS = [
     "isdf_profile_read", "isdf_profile_read_secondary", "isdf_get_stats",
     "isdf_set_trajectory", "isdf_num_variables", "isdf_pack_variables", "isdf_unpack_variables",
     "isdf_cost_function", "isdf_cost_function_lmbm", "isdf_cost_parts",
-    "isdf_cost_function_launch", "isdf_cost_function_finish",
+    "isdf_cost_function_launch", "isdf_cost_function_finish", "isdf_set_minco_mode", "isdf_minco_path",
     "isdf_lbfgs_params_default", "isdf_lbfgs_minimize", "isdf_optimize_lbfgs", "isdf_optimize_lbfgs_batch",
     "isdf_set_pointcloud", "isdf_generate_esdf", "isdf_get_grid", "isdf_gather_points", "isdf_get_points", "isdf_shape_eval",
     "isdf_esdf_sample", "isdf_esdf_sample_device",
@@ -106,7 +106,8 @@ EXPORTED_SYMBOLS = [
     "isdf_xchg_create", "isdf_xchg_connect", "isdf_xchg_allreduce", "isdf_xchg_fuse", "isdf_xchg_status", "isdf_xchg_destroy",
 ]
 
-HOST_PATH_COPY, HOST_PATH_DIRECT_MAPPED, HOST_PATH_DIRECT_BAR = 0, 1, 2
+HOST_PATH_COPY, HOST_PATH_DIRECT_MAPPED, HOST_PATH_DIRECT_BAR, HOST_PATH_DEVICE_CALLBACK = 0, 1, 2, 3
+MINCO_DEVICE, MINCO_HOST = 0, 1
 MULTI_NONE, MULTI_PEER_SUM, MULTI_STAGED, MULTI_RCCL = 0, 1, 2, 3
 
 SDF_WITH_GRAD_FN = C.CFUNCTYPE(C.c_double, C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_double))   # isdf_sdf_with_grad_fn
@@ -165,6 +166,8 @@ def load_library(path=None):
     lib.isdf_cost_parts.argtypes = [C.c_void_p, dp]
     lib.isdf_cost_function_launch.argtypes = [C.c_void_p, dp, C.c_int, C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]
     lib.isdf_cost_function_finish.argtypes = [C.c_void_p, dp, dp, C.c_void_p]
+    lib.isdf_set_minco_mode.argtypes = [C.c_void_p, C.c_int]
+    lib.isdf_minco_path.argtypes = [C.c_void_p]
     ip = C.POINTER(C.c_int)
     lib.isdf_set_pointcloud.argtypes = [C.c_void_p, C.POINTER(C.c_float), C.c_longlong, dp, dp, C.c_double, C.c_int, ip]
     lib.isdf_generate_esdf.argtypes = [C.c_void_p]

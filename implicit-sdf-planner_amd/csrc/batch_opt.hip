@@ -5,16 +5,17 @@
 // evaluated TOGETHER as one batched integral sweep.  Rounds are GREEDY (a round starts as soon as a share of the trajectories
 // that can submit is waiting) and several are in flight, each on its own stream, the sweeps ordered by events because they
 // share the ctx's scratch - so one round's uploads, downloads and host work run under another round's sweep.
-// MINCO (tau -> T, setParameters, energy; propogateGrad, chain rule) runs on the trajectories' host threads
-// (csrc/minco_host.hpp; ~10 us per solve on a CPU core): 128 x 30 iterations in 84-92 ms = 4.0-4.3e8 point-evals/s end to end
-// (tools/batch_opt_bench.py).  A device form (one wavefront per trajectory) existed through round 4 and was REMOVED: a solve
-// is a chain of 3 x 6N dependent steps with an IEEE fp64 division on the critical path of most of them - 140 + 105 us per
-// round even with the band window and the right-hand sides held in registers (round 3, through LDS: 148 + 93 us), the same batch in
-// 200 ms against 88 ms with host threads (DESIGN_HISTORY.md).
+// MINCO (tau -> T, setParameters, energy; propogateGrad, chain rule) runs ON THE DEVICE, one workgroup per trajectory of the
+// round, in the two small kernels of csrc/minco_dev.hip either side of the batched sweep (log-depth junction-state form,
+// csrc/minco_pcr.hpp): a round moves n doubles per trajectory down and n + 5 up, and the trajectories' host threads only run
+// the L-BFGS vector updates.  isdf_set_minco_mode(ctx, 1) keeps the round-4 form - MINCO on the trajectories' host threads
+// (csrc/minco_host.hpp, the reference's band LU pivot for pivot; ~10 us per solve on a CPU core).  (The device form of rounds
+// 2-4 walked that 6N-pivot chain with one wavefront per trajectory - 140 + 105 us per round - and was removed.)
 // Which trajectories share a round has no influence on results: the iterates are bitwise those of isdf_optimize_lbfgs on each
 // trajectory alone.
 #include "isdf_ctx.hpp"
 #include "lbfgs_host.hpp"
+#include "minco_dev.hpp"
 #include <chrono>
 #include <cmath>
 #include <cstdlib>
@@ -53,6 +54,10 @@ struct Batch {
     // staging: slot t holds [T(N) | coeffs(18N)]; out slot t holds the sweep's [cost | gradT | gradC]
     size_t in_per = 0;
     std::vector<double> stage_in, stage_out;
+    // device MINCO: slot t of stage_x holds x (n), of stage_res [cost | g (n) | 4 cost parts]
+    bool dev = false;
+    size_t rs = 0;
+    std::vector<double> stage_x, stage_res, ends;
     long long rounds_run = 0, evals_run = 0;
 };
 
@@ -62,6 +67,21 @@ double worker_evaluate(void *instance, const double *x, double *g, const int n) 
     Batch &b = *w.batch;
     // serial part on this trajectory's host thread (tau -> T, MINCO, energy), the sweep in the round, then the adjoint here
     const int N = b.N;
+    if (b.dev) {
+        std::memcpy(b.stage_x.data() + (size_t)w.id * b.n, x, (size_t)n * sizeof(double));
+        {
+            std::unique_lock<std::mutex> lk(b.m);
+            b.submitted[w.id] = 1;
+            b.n_submitted++;
+            b.cv_coord.notify_one();
+            b.cv_worker[w.id].wait(lk, [&] { return b.ready[w.id] != 0; });
+            b.ready[w.id] = 0;
+            if (b.error != ISDF_OK) return INFINITY;
+        }
+        const double *res = b.stage_res.data() + (size_t)w.id * b.rs;
+        std::memcpy(g, res + 1, (size_t)n * sizeof(double));
+        return res[0];
+    }
     for (int i = 0; i < N; i++) w.T[i] = isdf_host::tau_to_T(x[i]);
     w.minco.set_parameters(x + N, w.T.data());
     w.energy = w.minco.energy(w.gdC.data(), w.gdT.data());
@@ -107,6 +127,16 @@ extern "C" int isdf_optimize_lbfgs_batch(isdf_ctx *c, int n_traj, int N, const d
     b.cv_worker.reset(new std::condition_variable[n_traj]);
     if (const char *e = getenv("ISDF_BATCH_MIN_SHARE")) { const double v = atof(e); if (v > 0.0 && v <= 1.0) b.min_share = v; }
     b.in_per = (size_t)19 * N;
+    b.dev = c->minco_mode == 0 && N <= isdf::CB_MAX_N;
+    b.rs = (size_t)1 + (size_t)b.n + 4;
+    if (b.dev) {
+        b.stage_x.assign((size_t)n_traj * b.n, 0.0); b.stage_res.assign((size_t)n_traj * b.rs, 0.0); b.ends.assign((size_t)n_traj * 18, 0.0);
+        for (int t = 0; t < n_traj; t++) {
+            std::memcpy(b.ends.data() + (size_t)18 * t, heads_pva + 9 * t, 9 * sizeof(double));
+            std::memcpy(b.ends.data() + (size_t)18 * t + 9, tails_pva + 9 * t, 9 * sizeof(double));
+        }
+    }
+    c->last_minco_path = b.dev ? 1 : 0;
     for (int t = 0; t < n_traj; t++) {
         Worker &w = b.workers[t];
         w.batch = &b; w.id = t;
@@ -121,7 +151,14 @@ extern "C" int isdf_optimize_lbfgs_batch(isdf_ctx *c, int n_traj, int N, const d
         double *h_pin = nullptr, *d_buf = nullptr;
         std::vector<int> active; hipStream_t stream = nullptr; hipEvent_t done = nullptr, sweep_done = nullptr; bool busy = false;
     } slots[N_SLOTS];
-    const size_t in_all = (size_t)n_traj * b.in_per, out_all = (size_t)n_traj * b.ostride, word_at = in_all + out_all;
+    const size_t in_all = (size_t)n_traj * b.in_per, out_all = (size_t)n_traj * b.ostride;
+    // device MINCO: further device regions behind [T | coeffs | sweep out] - x + ends of the round (compacted), junction states,
+    // energy block, multipliers, results; the pinned buffer then holds [x + ends of the round | ... | results | overflow word]
+    const size_t xe_all = (size_t)n_traj * (b.n + 18), u_all = (size_t)n_traj * 6 * (N + 1), f_all = (size_t)n_traj * N * isdf::CB_FAC_STRIDE, res_all = (size_t)n_traj * b.rs;
+    const size_t off_xe = in_all + out_all, off_u = off_xe + xe_all, off_e = off_u + u_all, off_f = off_e + out_all, off_res = off_f + f_all;
+    const size_t dev_all = b.dev ? off_res + res_all : in_all + out_all;
+    const size_t pin_res = b.dev ? std::max(xe_all, in_all + out_all) : 0;        // results of a device round in the pinned buffer
+    const size_t word_at = b.dev ? pin_res + res_all : in_all + out_all;
     auto release = [&] {
         for (Slot &q : slots) {
             if (q.h_pin) (void)hipHostFree(q.h_pin);
@@ -132,8 +169,8 @@ extern "C" int isdf_optimize_lbfgs_batch(isdf_ctx *c, int n_traj, int N, const d
     };
     for (Slot &q : slots) {
         // pinned: [T | coeffs of the round | sweep out | overflow word]; device: [T | coeffs | sweep out]
-        if (hipHostMalloc((void **)&q.h_pin, (in_all + out_all + 1) * sizeof(double), hipHostMallocDefault) != hipSuccess ||
-            hipMalloc(&q.d_buf, (in_all + out_all) * sizeof(double)) != hipSuccess ||
+        if (hipHostMalloc((void **)&q.h_pin, (word_at + 1) * sizeof(double), hipHostMallocDefault) != hipSuccess ||
+            hipMalloc(&q.d_buf, dev_all * sizeof(double)) != hipSuccess ||
             hipStreamCreate(&q.stream) != hipSuccess ||
             hipEventCreateWithFlags(&q.done, hipEventDisableTiming) != hipSuccess ||
             hipEventCreateWithFlags(&q.sweep_done, hipEventDisableTiming) != hipSuccess) { release(); return isdf_fail(c, ISDF_ERR_HIP, "batch buffers: allocation failed"); }
@@ -167,6 +204,35 @@ extern "C" int isdf_optimize_lbfgs_batch(isdf_ctx *c, int n_traj, int N, const d
     hipEvent_t last_sweep = nullptr;          // the sweeps share the ctx's scratch: each waits for the one issued before it
     auto issue = [&](Slot &q) {               // q.active holds the trajectories of the round; their staging slots are quiescent
         const int na = (int)q.active.size();
+        if (b.dev) {
+            // compacted [x of the round | their boundary states] down, pre -> sweep -> post on this slot's stream, results up
+            double *hx = q.h_pin, *he = q.h_pin + (size_t)na * b.n;
+            for (int k = 0; k < na; k++) {
+                std::memcpy(hx + (size_t)k * b.n, b.stage_x.data() + (size_t)q.active[k] * b.n, (size_t)b.n * sizeof(double));
+                std::memcpy(he + (size_t)k * 18, b.ends.data() + (size_t)q.active[k] * 18, 18 * sizeof(double));
+            }
+            isdf::CbDev P{};
+            P.N = N; P.nb = na; P.n_out = 1; P.res_stride = (int)b.rs;
+            P.x = q.d_buf + off_xe; P.ends = q.d_buf + off_xe + (size_t)na * b.n;
+            P.T = q.d_buf; P.coeffs = q.d_buf + (size_t)na * N; P.sweep = q.d_buf + in_all;
+            P.u = q.d_buf + off_u; P.epart = q.d_buf + off_e; P.fac = q.d_buf + off_f;
+            P.rho = b.rho; P.res = q.d_buf + off_res; P.flag = nullptr; P.seq = 0; P.stats = nullptr;
+            if (rc == ISDF_OK && hipMemcpyAsync(q.d_buf + off_xe, q.h_pin, (size_t)na * (b.n + 18) * sizeof(double), hipMemcpyHostToDevice, q.stream) != hipSuccess) rc = ISDF_ERR_HIP;
+            if (rc == ISDF_OK) isdf::launch_cb_pre(P, q.stream);
+            if (rc == ISDF_OK && last_sweep && hipStreamWaitEvent(q.stream, last_sweep, 0) != hipSuccess) rc = ISDF_ERR_HIP;
+            if (rc == ISDF_OK) rc = isdf_eval_device(c, na, N, P.T, P.coeffs, q.d_buf + in_all, nullptr, q.stream);
+            if (rc == ISDF_OK && hipEventRecord(q.sweep_done, q.stream) != hipSuccess) rc = ISDF_ERR_HIP;
+            last_sweep = q.sweep_done;
+            if (rc == ISDF_OK) isdf::launch_cb_post(P, q.stream);
+            if (rc == ISDF_OK && hipGetLastError() != hipSuccess) rc = ISDF_ERR_HIP;
+            if (rc == ISDF_OK && hipMemcpyAsync(q.h_pin + pin_res, q.d_buf + off_res, (size_t)na * b.rs * sizeof(double), hipMemcpyDeviceToHost, q.stream) != hipSuccess) rc = ISDF_ERR_HIP;
+            if (rc == ISDF_OK && hipMemcpyAsync(q.h_pin + word_at, c->d_stats + 4, sizeof(double), hipMemcpyDeviceToHost, q.stream) != hipSuccess) rc = ISDF_ERR_HIP;
+            if (rc == ISDF_OK && hipEventRecord(q.done, q.stream) != hipSuccess) rc = ISDF_ERR_HIP;
+            q.busy = true;
+            b.rounds_run++;
+            b.evals_run += na;
+            return;
+        }
         double *hT = q.h_pin, *hC = q.h_pin + (size_t)na * N;          // compacted [T of all | coeffs of all]
         for (int k = 0; k < na; k++) {
             const double *in = b.stage_in.data() + (size_t)q.active[k] * b.in_per;
@@ -195,7 +261,8 @@ extern "C" int isdf_optimize_lbfgs_batch(isdf_ctx *c, int n_traj, int N, const d
             if (ovf) { rc = ISDF_ERR_OVERFLOW; (void)hipMemset(c->d_stats + 4, 0, sizeof(unsigned long long)); (void)isdf_reset_result_slots(c); }
         }
         for (int k = 0; k < na && rc == ISDF_OK; k++) {
-            std::memcpy(b.stage_out.data() + (size_t)q.active[k] * b.ostride, q.h_pin + in_all + (size_t)k * b.ostride, b.ostride * sizeof(double));
+            if (b.dev) std::memcpy(b.stage_res.data() + (size_t)q.active[k] * b.rs, q.h_pin + pin_res + (size_t)k * b.rs, b.rs * sizeof(double));
+            else std::memcpy(b.stage_out.data() + (size_t)q.active[k] * b.ostride, q.h_pin + in_all + (size_t)k * b.ostride, b.ostride * sizeof(double));
         }
         std::unique_lock<std::mutex> lk(b.m);
         if (rc != ISDF_OK) b.error = rc;

@@ -3,6 +3,7 @@
 // (back_end_optimizer.hpp:59-62 parallel_points/lastTstar, :667-725 setParam/setEnvironment/setGridMap) and the
 // shape registry lookup of sw_manager.hpp:74-123,:255-275.  No CPU compute path exists here.
 #include "isdf_ctx.hpp"
+#include "minco_dev.hpp"
 #include "lbfgs_host.hpp"
 #include <atomic>
 #include <dlfcn.h>
@@ -139,6 +140,7 @@ extern "C" int isdf_create(isdf_ctx **out, const isdf_config *cfg) {
         c->env_multi_no_hostout = on("ISDF_MULTI_NO_HOST_OUT");
         c->env_no_bar = on("ISDF_NO_BAR_WRITES");
         c->env_no_lpt = on("ISDF_NO_LPT");
+        c->minco_mode = on("ISDF_HOST_MINCO") ? 1 : 0;
     }
     if (hipSetDevice(c->device) != hipSuccess || hipMalloc(&c->d_stats, 8 * sizeof(unsigned long long)) != hipSuccess ||
         hipMalloc(&c->d_traj_duration, sizeof(double)) != hipSuccess || hipMalloc(&c->d_n_coarse, sizeof(int)) != hipSuccess ||
@@ -173,9 +175,10 @@ extern "C" int isdf_destroy(isdf_ctx *c) {
     if (c->h_pin) (void)hipHostFree(c->h_pin);
     if (c->h_eval_pin) (void)hipHostFree(c->h_eval_pin);
     if (c->h_dir) (void)hipHostFree(c->h_dir);
+    if (c->h_cbres) (void)hipHostFree(c->h_cbres);
     isdf_frontend_release(c);
     isdf_xchg_release(c);
-    void *ptrs[] = {c->d_cb, c->d_esdf, c->d_occ, c->d_points, c->d_tstar, c->d_acc, c->d_sample_info, c->d_bits, c->d_piece_cost, c->d_in, c->d_out, c->d_stats,
+    void *ptrs[] = {c->d_cb, c->d_cbdev, c->d_esdf, c->d_occ, c->d_points, c->d_tstar, c->d_acc, c->d_sample_info, c->d_bits, c->d_piece_cost, c->d_in, c->d_out, c->d_stats,
                     c->d_traj_duration, c->d_coarse_t, c->d_coarse_pose, c->d_n_coarse, c->d_point_partial, c->d_point_piece, c->d_point_stat, c->d_point_nr, c->d_task_buf,
                     c->d_task_map, c->d_v1_words, c->d_point_lmask, c->d_scan_ticks, c->d_scan_order, c->d_hist, c->d_shape_grid, c->d_pose, c->d_mq_entries, c->d_mq_items, c->d_mq_res, c->d_mq_sample_items, c->d_mq_sample_n, c->d_mq_count, c->d_msum_blocks, c->d_dbg, c->d_stage, c->d_stage_flags, c->d_sample_map, c->d_plan_cls, c->d_plan_map, c->d_plan_lr, c->d_plan_hist};
     for (void *p : ptrs) if (p) (void)hipFree(p);
@@ -1523,6 +1526,8 @@ extern "C" int isdf_set_trajectory(isdf_ctx *c, int N, const double head_pva[9],
     c->minco.set_conditions(head_pva, tail_pva, N);
     c->rho = rho;
     c->have_traj = true;
+    std::memcpy(c->cb_ends, head_pva, 9 * sizeof(double)); std::memcpy(c->cb_ends + 9, tail_pva, 9 * sizeof(double));
+    c->cb_ends_dirty = true;
     c->cb_T.assign(N, 0.0); c->cb_gdC.assign((size_t)18 * N, 0.0); c->cb_gdT.assign(N, 0.0);
     c->cb_gradP.assign((size_t)3 * (N > 1 ? N - 1 : 1), 0.0); c->cb_gradT.assign(N, 0.0);
     return ISDF_OK;
@@ -1558,12 +1563,121 @@ extern "C" int isdf_unpack_variables(isdf_ctx *c, const double *x, double *T, do
 
 // First half of the callback: tau -> T, MINCO, energy, and the sweeps queued on `st`.  Leaves this rank's partial sums
 // ([cost | gradT | gradC] per sweep, cb_n_out blocks) in c->d_cb + 19N on the device.
+// ---- the callback with its MINCO half on the device (csrc/minco_dev.hip): x goes down (through the PCIe BAR when the host can
+// write device memory, else the first kernel fetches it from host-mapped memory), cb_pre_kernel writes (T, coefficients) where
+// the sweeps read them, the sweeps accumulate as ever, cb_post_kernel leaves (cost, g, the four cost parts) and a completion
+// word in host-mapped memory.  No copy commands, no stream synchronisation.
+static size_t cb_res_stride(int N) { return (size_t)1 + (size_t)(N + 3 * (N - 1)) + 4; }
+static int cb_dev_fill(isdf_ctx *c, int N, CbDev *P, hipStream_t st) {
+    const size_t nvar = (size_t)N + 3 * (size_t)(N - 1), ostride = isdf_out_stride(N), in_len = (size_t)19 * N;
+    // device: [x | ends | u | energy block | multipliers]
+    const size_t off_ends = nvar, off_u = off_ends + 18, off_e = off_u + (size_t)6 * (N + 1), off_f = off_e + ostride;
+    const size_t need = off_f + (size_t)N * CB_FAC_STRIDE;
+    if (c->cbdev_cap < need) { c->cb_ends_dirty = true; }
+    int rc = ensure(c, &c->d_cbdev, &c->cbdev_cap, need);
+    if (rc) return rc;
+    rc = ensure(c, &c->d_cb, &c->cb_cap, in_len + 2 * ostride);
+    if (rc) return rc;
+    const size_t rs = cb_res_stride(N), pin_need = nvar + rs + 2;
+    if (c->cbres_cap < pin_need) {
+        if (c->h_cbres) (void)hipHostFree(c->h_cbres);
+        c->h_cbres = nullptr; c->cbres_cap = 0;
+        HIPCHK(c, hipHostMalloc((void **)&c->h_cbres, pin_need * sizeof(double), hipHostMallocDefault));
+        HIPCHK(c, hipHostGetDevicePointer((void **)&c->h_cbres_dev, c->h_cbres, 0));
+        std::memset(c->h_cbres, 0, pin_need * sizeof(double));
+        c->cbres_cap = pin_need;
+    }
+    if (c->cb_ends_dirty) {
+        HIPCHK(c, hipMemcpyAsync(c->d_cbdev + off_ends, c->cb_ends, 18 * sizeof(double), hipMemcpyHostToDevice, st));
+        HIPCHK(c, hipStreamSynchronize(st));            // (cb_ends may change before an asynchronous copy has read it)
+        c->cb_ends_dirty = false;
+    }
+    P->N = N; P->nb = 1; P->n_out = c->cb_n_out; P->res_stride = (int)rs;
+    P->x = c->d_cbdev; P->ends = c->d_cbdev + off_ends; P->u = c->d_cbdev + off_u; P->epart = c->d_cbdev + off_e; P->fac = c->d_cbdev + off_f;
+    P->T = c->d_cb; P->coeffs = c->d_cb + N; P->sweep = c->d_cb + in_len;
+    P->rho = c->rho;
+    P->res = c->h_cbres_dev + nvar; P->flag = (unsigned long long *)(c->h_cbres_dev + nvar + rs);
+    P->seq = c->cb_seq; P->stats = c->d_stats;
+    return ISDF_OK;
+}
+static bool cb_device_minco(const isdf_ctx *c) { return c->minco_mode == 0 && c->have_traj && c->minco.N <= CB_MAX_N && !c->prof_on; }
+
+static int cost_function_launch_dev(isdf_ctx *c, const double *x, int n, hipStream_t st, bool whole) {
+    const int N = c->minco.N;
+    const bool swept = c->cfg.variant == ISDF_V1_SWEPT;
+    c->cb_n_out = swept ? 2 : 1;
+    c->cb_direct = false; c->cb_dev = true; c->cb_post_queued = false;
+    c->cb_seq++;
+    CbDev P{};
+    int rc = cb_dev_fill(c, N, &P, st);
+    if (rc) return rc;
+    const size_t nvar = (size_t)n;
+    if (bar_usable(c, c->d_cbdev, nvar)) std::memcpy(c->d_cbdev, x, nvar * sizeof(double));      // CPU stores into device memory
+    else { std::memcpy(c->h_cbres, x, nvar * sizeof(double)); P.x = c->h_cbres_dev; }
+    __sync_synchronize();
+    launch_cb_pre(P, st);
+    const size_t ostride = isdf_out_stride(N);
+    double *d_T = c->d_cb, *d_C = c->d_cb + N, *d_o = c->d_cb + (size_t)19 * N;
+    if (swept) {
+        rc = sweep_dispatch(c, 1, N, d_T, d_C, d_o, nullptr, st, 1);
+        if (rc) return rc;
+        rc = sweep_dispatch(c, 1, N, d_T, d_C, d_o + ostride, nullptr, st, 2);
+    } else {
+        rc = sweep_dispatch(c, 1, N, d_T, d_C, d_o, nullptr, st, 0);
+    }
+    if (rc) return rc;
+    if (whole) { launch_cb_post(P, st); c->cb_post_queued = true; }      // the split form queues it in _finish, behind the caller's all-reduce
+    HIPCHK(c, hipGetLastError());
+    c->last_host_path = ISDF_HOST_PATH_DEVICE_CALLBACK;
+    c->last_minco_path = 1;
+    c->cb_pending = true;
+    return ISDF_OK;
+}
+static int cost_function_finish_dev(isdf_ctx *c, double *g, double *cost_out, hipStream_t st) {
+    c->cb_pending = false;
+    const int N = c->minco.N;
+    const size_t nvar = (size_t)N + 3 * (size_t)(N - 1), rs = cb_res_stride(N);
+    if (!c->cb_post_queued) {
+        CbDev P{};
+        const int rc = cb_dev_fill(c, N, &P, st);
+        if (rc) return rc;
+        if (!bar_usable(c, c->d_cbdev, nvar)) P.x = c->h_cbres_dev;
+        launch_cb_post(P, st);
+        HIPCHK(c, hipGetLastError());
+    }
+    volatile unsigned long long *flag = (volatile unsigned long long *)(c->h_cbres + nvar + rs);
+    const auto t0 = std::chrono::steady_clock::now();
+    unsigned long long f;
+    for (unsigned spin = 0;; spin++) {
+        f = *flag;
+        if ((f & ~HOST_FLAG_OVERFLOW) == c->cb_seq) break;
+        if ((spin & 0x3FFFu) == 0x3FFFu && std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > 5.0) {
+            (void)hipStreamSynchronize(st);
+            if ((*flag & ~HOST_FLAG_OVERFLOW) == c->cb_seq) { f = *flag; break; }
+            return fail(c, ISDF_ERR_HIP, "device callback did not complete (its completion word never arrived)");
+        }
+    }
+    std::atomic_thread_fence(std::memory_order_acquire);
+    if (f & HOST_FLAG_OVERFLOW) {
+        (void)hipMemset(c->d_stats + 4, 0, sizeof(unsigned long long));
+        (void)isdf_reset_result_slots(c);
+        return fail(c, ISDF_ERR_OVERFLOW, "a bounded device work list overflowed; result invalid");
+    }
+    const double *res = c->h_cbres + nvar;
+    *cost_out = res[0];
+    std::memcpy(g, res + 1, nvar * sizeof(double));
+    for (int q = 0; q < 4; q++) c->last_parts[q] = res[1 + nvar + q];
+    return ISDF_OK;
+}
+
 static int cost_function_launch(isdf_ctx *c, const double *x, int n, hipStream_t st, bool allow_direct = false) {
     if (!x) return fail(c, ISDF_ERR_INVALID_ARG, "null argument");
     if (!c->have_traj) return fail(c, ISDF_ERR_STATE, "isdf_set_trajectory not called");
     const int N = c->minco.N;
     if (n != N + 3 * (N - 1)) return fail(c, ISDF_ERR_INVALID_ARG, "n must be N + 3(N-1)");
     HIPCHK(c, hipSetDevice(c->device));
+    if (cb_device_minco(c)) return cost_function_launch_dev(c, x, n, st, allow_direct);
+    c->cb_dev = false; c->last_minco_path = 0;
     // tau -> T, xi -> waypoints, MINCO coefficients, energy and its partials (:363-381)
     c->cb_x.assign(x, x + n);
     for (int i = 0; i < N; i++) c->cb_T[i] = isdf_host::tau_to_T(x[i]);
@@ -1612,6 +1726,7 @@ static int cost_function_launch(isdf_ctx *c, const double *x, int n, hipStream_t
 static int cost_function_finish(isdf_ctx *c, double *g, double *cost_out, hipStream_t st) {
     if (!g || !cost_out) return fail(c, ISDF_ERR_INVALID_ARG, "null argument");
     if (!c->cb_pending) return fail(c, ISDF_ERR_STATE, "no callback evaluation in flight");
+    if (c->cb_dev) { HIPCHK(c, hipSetDevice(c->device)); return cost_function_finish_dev(c, g, cost_out, st); }
     c->cb_pending = false;
     const int N = c->minco.N;
     const size_t in_len = (size_t)19 * N, ostride = isdf_out_stride(N);
@@ -1678,7 +1793,7 @@ extern "C" int isdf_cost_function_launch(isdf_ctx *c, const double *x, int n, vo
     if (!d_partial_out || !count_out) return fail(c, ISDF_ERR_INVALID_ARG, "null argument");
     const int rc = cost_function_launch(c, x, n, (hipStream_t)stream);
     if (rc) return rc;
-    *d_partial_out = c->d_cb + (size_t)19 * c->minco.N;
+    *d_partial_out = c->d_cb + (size_t)19 * c->minco.N;       // (both MINCO paths keep the sweeps' sums here)
     *count_out = (size_t)c->cb_n_out * isdf_out_stride(c->minco.N);
     return ISDF_OK;
 }
@@ -1694,6 +1809,17 @@ extern "C" double isdf_cost_function_lmbm(void *instance, const double *x, doubl
     const int rc = isdf_cost_function((isdf_ctx *)instance, x, g, n, &cost);
     return rc == ISDF_OK ? cost : INFINITY;
 }
+
+// where MINCO runs: 0 = on the device whenever the trajectory fits (N <= 400), 1 = on the host (band LU, the reference's
+// elimination order bit for bit).  Results agree to rounding (1e-10 relative on the coefficients).
+extern "C" int isdf_set_minco_mode(isdf_ctx *c, int mode) {
+    if (!c) return ISDF_ERR_INVALID_ARG;
+    if (mode != 0 && mode != 1) return fail(c, ISDF_ERR_INVALID_ARG, "minco mode must be 0 (device) or 1 (host)");
+    if (c->cb_pending) return fail(c, ISDF_ERR_STATE, "a callback evaluation is in flight");
+    c->minco_mode = mode;
+    return ISDF_OK;
+}
+extern "C" int isdf_minco_path(const isdf_ctx *c) { return c ? c->last_minco_path : ISDF_ERR_INVALID_ARG; }
 
 // energy | swept-volume sweep | integral sweep | rho * sum(T) of the last isdf_cost_function call
 extern "C" int isdf_cost_parts(const isdf_ctx *c, double parts[4]) {

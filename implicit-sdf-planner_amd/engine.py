@@ -359,6 +359,14 @@ class Engine:
         self._check(self.lib.isdf_cost_function_finish(self.h, _p(g), C.byref(cost), C.c_void_p(stream)))
         return cost.value, g
 
+    def set_minco_mode(self, mode):
+        """capi.MINCO_DEVICE (default): the callback's MINCO half on the device; capi.MINCO_HOST: the host's band LU."""
+        self._check(self.lib.isdf_set_minco_mode(self.h, int(mode)))
+
+    def minco_path(self):
+        """Where the last callback ran MINCO: 1 = device, 0 = host."""
+        return int(self.lib.isdf_minco_path(self.h))
+
     def cost_parts(self):
         p = np.zeros(4)
         self._check(self.lib.isdf_cost_parts(self.h, _p(p)))

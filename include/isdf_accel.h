@@ -271,6 +271,9 @@ int isdf_eval(isdf_ctx *ctx, int n_traj, const int *N, const double *const *T,
 #define ISDF_HOST_PATH_COPY 0
 #define ISDF_HOST_PATH_DIRECT_MAPPED 1
 #define ISDF_HOST_PATH_DIRECT_BAR 2
+/*   DEVICE_CALLBACK  isdf_cost_function with its MINCO half on the device: x goes down (through the BAR, or fetched from
+ *                  host-mapped memory), (cost, g) and a completion word come back into host-mapped memory; no copy commands */
+#define ISDF_HOST_PATH_DEVICE_CALLBACK 3
 int isdf_host_path(const isdf_ctx *ctx);
 
 /* Device-resident entry point, asynchronous on `stream` (a hipStream_t passed as void*; NULL = default
@@ -302,10 +305,15 @@ int isdf_eval_swept_at_tstar_host(isdf_ctx *ctx, int N, const double *T, const d
 
 /* ---- full objective callback ------------------------------------------------------------------------------ */
 /* TrajOptimizer::costFunctionLmbm (back_end_optimizer.hpp:358-430): x = [tau(N) | inner waypoints 3(N-1)] ->
- * cost, g.  MINCO (minco.hpp:397-655: setParameters, energy and its partials, propogateGrad) runs on the host - a chain
- * of 6N dependent pivots - and the sweeps on the device: for ISDF_V1_SWEPT the swept-volume sweep followed by the
- * integral sweep without a collision term (the reference's live configuration), otherwise the integral sweep of
- * cfg.variant.  cost = energy + sweeps + rho * sum(T).
+ * cost, g.  The whole callback runs on the device: MINCO (minco.hpp:397-655: setParameters, energy and its partials,
+ * propogateGrad) in LOG depth - the trajectory in its junction states, a symmetric positive definite block-tridiagonal system
+ * solved by parallel cyclic reduction (csrc/minco_pcr.hpp, minco_dev.hip) - in two small kernels either side of the sweeps:
+ * for ISDF_V1_SWEPT the swept-volume sweep followed by the integral sweep without a collision term (the reference's live
+ * configuration), otherwise the integral sweep of cfg.variant.  cost = energy + sweeps + rho * sum(T).  Per call n doubles
+ * go down and n + 5 come up.  isdf_set_minco_mode(ctx, 1) (or ISDF_HOST_MINCO=1 at isdf_create) keeps MINCO on the host
+ * instead - the reference's banded LU, a chain of 6N dependent pivots, pivot for pivot; trajectories of more than 400 pieces
+ * always take it.  The two agree to rounding (coefficients 1e-10 relative, tests/test_minco_pcr.py); isdf_minco_path tells
+ * which one the last callback took (1 = device).
  * isdf_set_trajectory == minco.setConditions + the `rho` of setParam (head/tail: 3x3 column-major, columns =
  * position, velocity, acceleration).  isdf_pack_variables == backwardT/backwardP (back_end_optimizer.cpp:22-28),
  * isdf_unpack_variables == forwardT/forwardP + setParameters (T: N, coeffs: 6N x 3 column-major; either may be NULL). */
@@ -314,6 +322,8 @@ int isdf_num_variables(const isdf_ctx *ctx);               /* N + 3(N-1), 0 befo
 int isdf_pack_variables(isdf_ctx *ctx, const double *T, const double *waypoints, double *x);
 int isdf_unpack_variables(isdf_ctx *ctx, const double *x, double *T, double *coeffs);
 int isdf_cost_function(isdf_ctx *ctx, const double *x, double *g, int n, double *cost_out);
+int isdf_set_minco_mode(isdf_ctx *ctx, int mode);          /* 0 = device (default), 1 = host band LU          */
+int isdf_minco_path(const isdf_ctx *ctx);                  /* of the last callback: 1 = device, 0 = host      */
 /* the same with the lmbm_evaluate_t signature (src/utils/include/utils/lmbm.h:206-209); instance = isdf_ctx*,
  * returns +inf on error */
 double isdf_cost_function_lmbm(void *instance, const double *x, double *g, const int n);

@@ -194,14 +194,17 @@ def test_callback_launch_finish_shards(pkg, orc, product_lib):
     assert ei.value.code == capi.ISDF_ERR_STATE
 
 
-def test_optimize_lbfgs_batch_equals_individual(pkg, orc, product_lib):
+@pytest.mark.parametrize("minco", ["device", "host"])
+def test_optimize_lbfgs_batch_equals_individual(pkg, orc, product_lib, minco):
     """configs[2] at test size: 6 trajectories with different boundary states optimised concurrently (one batched device
-    sweep per round) end on exactly the iterates they reach when optimised one at a time."""
+    sweep per round) end on exactly the iterates they reach when optimised one at a time - with the callback's MINCO half on
+    the device (one workgroup per trajectory of the round) and with it on the trajectories' host threads."""
     capi, synth = pkg.capi, pkg.synth
     occ, esdf, res = small_world(pkg, seed=16)
     N = 4
     shape = synth.make_shape("RoundedCone", params=(0.8, 0.3, 1.6))
     cfg, eng, _ = _engines(pkg, orc, capi.V3_ESDF_TILE, occ, esdf, res, shape)
+    eng.set_minco_mode(capi.MINCO_DEVICE if minco == "device" else capi.MINCO_HOST)
     heads, tails, x0s = [], [], []
     rho = 5.0
     for b in range(6):
@@ -213,6 +216,7 @@ def test_optimize_lbfgs_batch_equals_individual(pkg, orc, product_lib):
     xs, results, wall = eng.optimize_lbfgs_batch(N, np.array(heads), np.array(tails), rho, np.array(x0s), max_iterations=7,
                                                  g_epsilon=0.0, past=0)
     assert results[0]["rounds"] >= 8
+    assert eng.minco_path() == (1 if minco == "device" else 0)
     for b in range(6):
         eng.set_trajectory(N, heads[b], tails[b], rho)
         x1, r1 = eng.optimize_lbfgs(x0s[b], max_iterations=7, g_epsilon=0.0, past=0)
@@ -224,3 +228,92 @@ def test_optimize_lbfgs_batch_equals_individual(pkg, orc, product_lib):
     with pytest.raises(pkg.engine.IsdfError) as ei:
         eng1.optimize_lbfgs_batch(N, np.array(heads), np.array(tails), rho, np.array(x0s))
     assert ei.value.code == capi.ISDF_ERR_UNSUPPORTED
+
+
+# ---- the callback's MINCO half on the device (csrc/minco_dev.hip) vs the host's band LU (csrc/minco_host.hpp) -----------------
+def _rel_inf(a, b):
+    return float(np.abs(np.asarray(a) - np.asarray(b)).max() / max(np.abs(np.asarray(b)).max(), 1e-300))
+
+
+@pytest.mark.parametrize("variant,N,piece_scale", [("V3", 1, 1.0), ("V3", 2, 1.0), ("V3", 6, 1.0), ("V3", 40, 1.0), ("V3", 40, 0.2),
+                                                   ("V3", 65, 0.5), ("V2", 6, 1.0), ("V1", 6, 1.0), ("V1", 17, 1.0)])
+def test_device_minco_callback_equals_host_minco_callback(pkg, orc, product_lib, variant, N, piece_scale):
+    """Same x through both forms of the callback: MINCO in log depth on the device (junction states + parallel cyclic reduction)
+    and the reference's band LU on the host.  Different elimination orders, so equal to rounding, not bitwise: 1e-9 relative
+    on (cost, g) - and both against the oracle at the north-star tolerance."""
+    capi, synth = pkg.capi, pkg.synth
+    occ, esdf, res = small_world(pkg)
+    head, tail, way, T0 = _setup(pkg, occ, res, N, 300 + N)
+    T0 = T0 * piece_scale
+    shape = synth.make_shape("RoundedCone", params=(0.8, 0.3, 1.6))
+    v = {"V3": capi.V3_ESDF_TILE, "V2": capi.V2_OCC_TILE, "V1": capi.V1_SWEPT}[variant]
+    points = None
+    if variant == "V1":
+        pts_way = np.vstack([head[:, 0], way, tail[:, 0]])
+        points = synth.constraint_points(occ, (0, 0, 0), res, pts_way, half=2.0)
+    cfg, eng, o = _engines(pkg, orc, v, occ, esdf, res, shape, points=points)
+    rho = 2.5
+    eng.set_trajectory(N, head, tail, rho)
+    x = eng.pack_variables(T0, way)
+    cost_d, g_d = eng.cost_function(x)
+    assert eng.minco_path() == 1 and eng.host_path() == capi.HOST_PATH_DEVICE_CALLBACK
+    parts_d = eng.cost_parts()
+    cost_d2, g_d2 = eng.cost_function(x)                       # deterministic: the same bits again
+    assert cost_d2 == cost_d and np.array_equal(g_d2, g_d)
+    eng.set_minco_mode(capi.MINCO_HOST)
+    cost_h, g_h = eng.cost_function(x)
+    assert eng.minco_path() == 0
+    parts_h = eng.cost_parts()
+    # (V1: the argmin over t is a chain of accept / reject comparisons with a 1e-5 s stopping rule - coefficients that differ in
+    # the 13th digit may stop it one halving apart)
+    tol = 1e-6 if variant == "V1" else 1e-9
+    assert abs(cost_d - cost_h) <= tol * abs(cost_h), (cost_d, cost_h)
+    assert _rel_inf(g_d, g_h) <= tol, _rel_inf(g_d, g_h)
+    for k in parts_h:
+        assert abs(parts_d[k] - parts_h[k]) <= tol * max(abs(parts_h[k]), 1e-9 * abs(cost_h)), (k, parts_d[k], parts_h[k])
+    if variant != "V1":
+        c0, g0 = oracle_cost_function(orc, [o], head, tail, rho, x, N)
+        assert abs(cost_d - c0) <= REL_TOL * abs(c0)
+        assert_close(g_d, g0, "g (device MINCO) vs oracle")
+    eng.set_minco_mode(capi.MINCO_DEVICE)
+    cost_d3, g_d3 = eng.cost_function(x)
+    assert cost_d3 == cost_d and np.array_equal(g_d3, g_d) and eng.minco_path() == 1
+
+
+def test_device_minco_callback_largest_trajectory_and_fallback(pkg, orc, product_lib):
+    """N = 400 (BASELINE configs[3]) is the largest trajectory the device form takes (19 N doubles of LDS); N = 401 falls back to
+    the host's band LU without being asked."""
+    capi, synth = pkg.capi, pkg.synth
+    occ, esdf, res = small_world(pkg)
+    shape = synth.make_shape("RoundedCone", params=(0.8, 0.3, 1.6))
+    for N, want in ((400, 1), (401, 0)):
+        head, tail, way, T0 = _setup(pkg, occ, res, N, 900 + N)
+        T0 = T0 * 0.1
+        cfg, eng, o = _engines(pkg, orc, capi.V3_ESDF_TILE, occ, esdf, res, shape)
+        eng.set_trajectory(N, head, tail, 1.0)
+        x = eng.pack_variables(T0, way)
+        cost, g = eng.cost_function(x)
+        assert eng.minco_path() == want
+        eng.set_minco_mode(capi.MINCO_HOST)
+        cost_h, g_h = eng.cost_function(x)
+        assert abs(cost - cost_h) <= 1e-9 * abs(cost_h) and _rel_inf(g, g_h) <= 1e-9, (N, cost, cost_h, _rel_inf(g, g_h))
+
+
+def test_device_minco_gradient_is_the_derivative(pkg, orc, product_lib):
+    """Directional central difference of the device-resident callback (x -> cost, g entirely on the device)."""
+    capi, synth = pkg.capi, pkg.synth
+    occ, esdf, res = small_world(pkg, seed=5)
+    N = 5
+    head, tail, way, T0 = _setup(pkg, occ, res, N, 31)
+    shape = synth.make_shape("RoundedCone", params=(0.8, 0.3, 1.6))
+    cfg, eng, o = _engines(pkg, orc, capi.V3_ESDF_TILE, occ, esdf, res, shape)
+    eng.set_trajectory(N, head, tail, 4.0)
+    x = eng.pack_variables(T0, way)
+    cost, g = eng.cost_function(x)
+    assert eng.minco_path() == 1
+    rng = np.random.default_rng(0)
+    for _ in range(3):
+        d = rng.normal(0, 1, x.size); d /= np.linalg.norm(d)
+        eps = 1e-6
+        fd = (eng.cost_function(x + eps * d)[0] - eng.cost_function(x - eps * d)[0]) / (2 * eps)
+        assert abs(fd - g @ d) <= 2e-4 * max(1.0, abs(fd)), (fd, g @ d)
