@@ -141,6 +141,7 @@ extern "C" int isdf_create(isdf_ctx **out, const isdf_config *cfg) {
         c->env_no_bar = on("ISDF_NO_BAR_WRITES");
         c->env_no_lpt = on("ISDF_NO_LPT");
         c->minco_mode = on("ISDF_HOST_MINCO") ? 1 : 0;
+        c->env_no_cb_conc = on("ISDF_NO_CB_CONCURRENT");
     }
     if (hipSetDevice(c->device) != hipSuccess || hipMalloc(&c->d_stats, 8 * sizeof(unsigned long long)) != hipSuccess ||
         hipMalloc(&c->d_traj_duration, sizeof(double)) != hipSuccess || hipMalloc(&c->d_n_coarse, sizeof(int)) != hipSuccess ||
@@ -178,12 +179,14 @@ extern "C" int isdf_destroy(isdf_ctx *c) {
     if (c->h_cbres) (void)hipHostFree(c->h_cbres);
     isdf_frontend_release(c);
     isdf_xchg_release(c);
-    void *ptrs[] = {c->d_cb, c->d_cbdev, c->d_esdf, c->d_occ, c->d_points, c->d_tstar, c->d_acc, c->d_sample_info, c->d_bits, c->d_piece_cost, c->d_in, c->d_out, c->d_stats,
+    void *ptrs[] = {c->d_cb, c->d_cbdev, c->d_cbflag, c->d_esdf, c->d_occ, c->d_points, c->d_tstar, c->d_acc, c->d_sample_info, c->d_bits, c->d_piece_cost, c->d_in, c->d_out, c->d_stats,
                     c->d_traj_duration, c->d_coarse_t, c->d_coarse_pose, c->d_n_coarse, c->d_point_partial, c->d_point_piece, c->d_point_stat, c->d_point_nr, c->d_task_buf,
                     c->d_task_map, c->d_v1_words, c->d_point_lmask, c->d_scan_ticks, c->d_scan_order, c->d_hist, c->d_shape_grid, c->d_pose, c->d_mq_entries, c->d_mq_items, c->d_mq_res, c->d_mq_sample_items, c->d_mq_sample_n, c->d_mq_count, c->d_msum_blocks, c->d_dbg, c->d_stage, c->d_stage_flags, c->d_sample_map, c->d_plan_cls, c->d_plan_map, c->d_plan_lr, c->d_plan_hist};
     for (void *p : ptrs) if (p) (void)hipFree(p);
     free_mesh(c);
     if (c->stream) (void)hipStreamDestroy(c->stream);
+    if (c->stream_aux) (void)hipStreamDestroy(c->stream_aux);
+    if (c->cb_ev) (void)hipEventDestroy(c->cb_ev);
     delete c;
     return ISDF_OK;
 }
@@ -583,7 +586,21 @@ int isdf_reset_result_slots(isdf_ctx *c) {
 // mode 0: the sweep cfg.variant names; 1: the swept-volume sweep; 2: the integral sweep with the collision term off
 // (modes 1 + 2 together are what costFunctionLmbm runs for the reference's live configuration)
 // host-direct step (see isdf_ctx.hpp): device-visible addresses of the pinned inputs / outputs / flags of this step
-struct HostDirect { const double *T, *coeffs; double *out; unsigned long long *flags; unsigned long long seq; bool via_bar; };
+// ext_stage: the inputs come through the staging buffer, filled by ANOTHER kernel (the callback's cb_pre_kernel, on a second
+// stream, already queued); `out` and `flags` are then device memory and the step keeps room for that kernel's workgroups
+struct HostDirect { const double *T, *coeffs; double *out; unsigned long long *flags; unsigned long long seq; bool via_bar; bool ext_stage = false; };
+static int ensure_stage(isdf_ctx *c, size_t total_pieces) {
+    const size_t n_groups = (total_pieces + STAGE_G - 1) / STAGE_G;
+    { int rc1 = isdf_ensure_doubles(c, &c->d_stage, &c->stage_cap, total_pieces * 19); if (rc1) return rc1; }
+    if (c->stage_flags_cap < n_groups) {
+        if (c->d_stage_flags) (void)hipFree(c->d_stage_flags);
+        c->d_stage_flags = nullptr; c->stage_flags_cap = 0;
+        HIPCHK(c, hipMalloc(&c->d_stage_flags, n_groups * sizeof(unsigned long long)));
+        HIPCHK(c, hipMemset(c->d_stage_flags, 0, n_groups * sizeof(unsigned long long)));
+        c->stage_flags_cap = n_groups;
+    }
+    return ISDF_OK;
+}
 constexpr int ISDF_DIRECT_NA = 1;        // eval_device_impl: the step cannot run host-direct (nothing was launched)
 
 static int eval_device_impl(isdf_ctx *c, int n_traj, int N, const double *d_T, const double *d_coeffs, double *d_out,
@@ -776,17 +793,11 @@ static int eval_device_impl(isdf_ctx *c, int n_traj, int N, const double *d_T, c
     }
     if (hd) {
         if (!fused || P.xf.world > 1 || P.dbg) return ISDF_DIRECT_NA;
-        const size_t n_groups = ((size_t)total_pieces + STAGE_G - 1) / STAGE_G;
-        { int rc1 = ensure(c, &c->d_stage, &c->stage_cap, (size_t)total_pieces * 19); if (rc1) return rc1; }
-        if (c->stage_flags_cap < n_groups) {
-            if (c->d_stage_flags) (void)hipFree(c->d_stage_flags);
-            c->d_stage_flags = nullptr; c->stage_flags_cap = 0;
-            HIPCHK(c, hipMalloc(&c->d_stage_flags, n_groups * sizeof(unsigned long long)));
-            HIPCHK(c, hipMemset(c->d_stage_flags, 0, n_groups * sizeof(unsigned long long)));
-            c->stage_flags_cap = n_groups;
-        }
+        if (hd->ext_stage && sweep_fused_headroom(P) < 8) return ISDF_DIRECT_NA;     // the callback's two workgroups must fit beside the resident launch
+        { int rc1 = ensure_stage(c, (size_t)total_pieces); if (rc1) return rc1; }
         P.out = hd->out; P.host_flag = hd->flags; P.seq = hd->seq;
-        if (!hd->via_bar) { P.host_T = hd->T; P.host_coeffs = hd->coeffs; P.stage = c->d_stage; P.stage_flags = c->d_stage_flags; }
+        if (hd->ext_stage) { P.host_T = d_T; P.host_coeffs = d_coeffs; P.stage = c->d_stage; P.stage_flags = c->d_stage_flags; P.stage_ext = 1; }
+        else if (!hd->via_bar) { P.host_T = hd->T; P.host_coeffs = hd->coeffs; P.stage = c->d_stage; P.stage_flags = c->d_stage_flags; }
         c->last_P = P;
     }
     // dispatch order built on the device from the work of earlier steps (tile_sweep.hip, plan_wave): a resident (fused) launch
@@ -1607,7 +1618,17 @@ static int cost_function_launch_dev(isdf_ctx *c, const double *x, int n, hipStre
     const bool swept = c->cfg.variant == ISDF_V1_SWEPT;
     c->cb_n_out = swept ? 2 : 1;
     c->cb_direct = false; c->cb_dev = true; c->cb_post_queued = false;
-    c->cb_seq++;
+    c->cb_seq = ++c->dir_seq;          // (one counter with the host-direct steps: they share the staging buffer's ready flags)
+    // A callback whose sweep is one fused launch runs its three kernels CONCURRENTLY: cb_pre_kernel and cb_post_kernel on a second
+    // stream, the sweep on `st`, chained through the staging buffer's ready flags and a device word (csrc/minco_dev.hip)
+    bool conc = whole && !swept && direct_enabled(c) && !c->env_no_cb_conc && c->peers.empty();
+    if (conc) {
+        if (!c->stream_aux) HIPCHK(c, hipStreamCreateWithFlags(&c->stream_aux, hipStreamNonBlocking));
+        if (!c->cb_ev) HIPCHK(c, hipEventCreateWithFlags(&c->cb_ev, hipEventDisableTiming));
+        if (!c->d_cbflag) { HIPCHK(c, hipMalloc(&c->d_cbflag, 2 * sizeof(unsigned long long))); HIPCHK(c, hipMemset(c->d_cbflag, 0, 2 * sizeof(unsigned long long))); }
+        const int rs0 = ensure_stage(c, (size_t)N);
+        if (rs0) return rs0;
+    }
     CbDev P{};
     int rc = cb_dev_fill(c, N, &P, st);
     if (rc) return rc;
@@ -1615,9 +1636,31 @@ static int cost_function_launch_dev(isdf_ctx *c, const double *x, int n, hipStre
     if (bar_usable(c, c->d_cbdev, nvar)) std::memcpy(c->d_cbdev, x, nvar * sizeof(double));      // CPU stores into device memory
     else { std::memcpy(c->h_cbres, x, nvar * sizeof(double)); P.x = c->h_cbres_dev; }
     __sync_synchronize();
-    launch_cb_pre(P, st);
+    if (conc) { P.stage = c->d_stage; P.stage_flags = c->d_stage_flags; }
+    launch_cb_pre(P, conc ? c->stream_aux : st);
     const size_t ostride = isdf_out_stride(N);
     double *d_T = c->d_cb, *d_C = c->d_cb + N, *d_o = c->d_cb + (size_t)19 * N;
+    if (conc) {
+        HostDirect hd{};
+        hd.ext_stage = true; hd.out = d_o; hd.flags = c->d_cbflag; hd.seq = c->cb_seq;
+        rc = eval_device_impl(c, 1, N, d_T, d_C, d_o, nullptr, st, 0, false, &hd);
+        if (rc < 0) return rc;
+        if (rc == ISDF_OK) {
+            P.wait_flag = c->d_cbflag;
+            launch_cb_post(P, c->stream_aux);       // resident beside the sweep, waiting for its collector's word
+            HIPCHK(c, hipGetLastError());
+            c->cb_post_queued = true;
+            c->last_host_path = ISDF_HOST_PATH_DEVICE_CALLBACK_CONCURRENT;
+            c->last_minco_path = 1;
+            c->cb_pending = true;
+            c->cb_conc = true;
+            return ISDF_OK;
+        }
+        // not one fused launch after all: one after the other on `st`, behind cb_pre_kernel
+        HIPCHK(c, hipEventRecord(c->cb_ev, c->stream_aux));
+        HIPCHK(c, hipStreamWaitEvent(st, c->cb_ev, 0));
+    }
+    c->cb_conc = false;
     if (swept) {
         rc = sweep_dispatch(c, 1, N, d_T, d_C, d_o, nullptr, st, 1);
         if (rc) return rc;

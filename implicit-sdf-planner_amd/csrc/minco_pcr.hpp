@@ -30,10 +30,25 @@
 
 namespace mpcr {
 
+// 1 / x.  On the device: v_rcp_f64 + two Newton steps (<= 1 ulp in the normal range, where determinants of the junction blocks
+// and durations live) - 5 dependent instructions instead of the ~11 of the correctly rounded quotient, on the critical path of
+// every elimination round.
+MPCR_HD double rcp(double x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    double r = __builtin_amdgcn_rcp(x);
+    double e = __builtin_fma(-x, r, 1.0);
+    r = __builtin_fma(r, e, r);
+    e = __builtin_fma(-x, r, 1.0);
+    return __builtin_fma(r, e, r);
+#else
+    return 1.0 / x;
+#endif
+}
+
 struct M2 { double a, b, c, d; };                    // [[a, b], [c, d]]
 MPCR_HD M2 mul(const M2 &x, const M2 &y) { return {x.a * y.a + x.b * y.c, x.a * y.b + x.b * y.d, x.c * y.a + x.d * y.c, x.c * y.b + x.d * y.d}; }
 MPCR_HD M2 inv(const M2 &x) {
-    const double r = 1.0 / (x.a * x.d - x.b * x.c);
+    const double r = rcp(x.a * x.d - x.b * x.c);
     return {x.d * r, -x.b * r, -x.c * r, x.a * r};
 }
 
@@ -50,12 +65,13 @@ MPCR_HD void junction_blocks(double hl, double hr, M2 &L, M2 &D, M2 &U) {
     D = {192.0 * (hl3 + hr3), 36.0 * (hr2 - hl2), 36.0 * (hr2 - hl2), 9.0 * (hl + hr)};
     U = {168.0 * hr3, -24.0 * hr2, 24.0 * hr2, -3.0 * hr};
 }
-MPCR_HD void junction_rhs(double hl, double hr, const double dpl[3], const double dpr[3], double r[3][2]) {
+MPCR_HD void junction_rhs1(double hl, double hr, double dpl, double dpr, double r[2]) {      // one axis
     const double hl3 = hl * hl * hl, hr3 = hr * hr * hr, hl4 = hl3 * hl, hr4 = hr3 * hr;
-    for (int d = 0; d < 3; d++) {
-        r[d][0] = 360.0 * (hl4 * dpl[d] + hr4 * dpr[d]);
-        r[d][1] = 60.0 * (hr3 * dpr[d] - hl3 * dpl[d]);
-    }
+    r[0] = 360.0 * (hl4 * dpl + hr4 * dpr);
+    r[1] = 60.0 * (hr3 * dpr - hl3 * dpl);
+}
+MPCR_HD void junction_rhs(double hl, double hr, const double dpl[3], const double dpr[3], double r[3][2]) {
+    for (int d = 0; d < 3; d++) junction_rhs1(hl, hr, dpl[d], dpr[d], r[d]);
 }
 // known end state (v, a) on the left of the first row / on the right of the last row moves to the right-hand side
 MPCR_HD void rhs_minus(const M2 &B, const double va[3][2], double r[3][2]) {
@@ -139,6 +155,19 @@ MPCR_HD double piece_energy(double T, const double c[3][6], double gc[3][6], dou
     return 36.0 * d33 * t1 + 144.0 * d43 * t2 + 192.0 * d44 * t3 + 240.0 * d53 * t3 + 720.0 * d54 * t4 + 720.0 * d55 * t5;
 }
 
+// the same, ONE axis at a time (the device's axis-per-thread form): the axes' shares are added afterwards, so the sums associate
+// differently from the reference's row_dot - equal to rounding
+MPCR_HD double piece_energy1(double T, const double c[6], double gc[6], double &gT) {
+    const double t1 = T, t2 = t1 * t1, t3 = t2 * t1, t4 = t2 * t2, t5 = t4 * t1;
+    const double d33 = c[3] * c[3], d43 = c[4] * c[3], d44 = c[4] * c[4], d53 = c[5] * c[3], d54 = c[5] * c[4], d55 = c[5] * c[5];
+    gc[0] = gc[1] = gc[2] = 0.0;
+    gc[3] = 72.0 * c[3] * t1 + 144.0 * c[4] * t2 + 240.0 * c[5] * t3;
+    gc[4] = 144.0 * c[3] * t2 + 384.0 * c[4] * t3 + 720.0 * c[5] * t4;
+    gc[5] = 240.0 * c[3] * t3 + 720.0 * c[4] * t4 + 1440.0 * c[5] * t5;
+    gT = 36.0 * d33 + 288.0 * d43 * t1 + 576.0 * d44 * t2 + 720.0 * d53 * t2 + 2880.0 * d54 * t3 + 3600.0 * d55 * t4;
+    return 36.0 * d33 * t1 + 144.0 * d43 * t2 + 192.0 * d44 * t3 + 240.0 * d53 * t3 + 720.0 * d54 * t4 + 720.0 * d55 * t5;
+}
+
 // ---- adjoint of one piece ------------------------------------------------------------------------------------------------
 // G[6] = dCost/dc of the piece (one axis) -> dCost/d(p0, v0, a0, p1, v1, a1) at fixed T (transpose of `hermite`)
 MPCR_HD void piece_adjoint(double h, const double G[6], double ge[6]) {
@@ -179,6 +208,11 @@ MPCR_HD double piece_w(double h, const double mu_l[2], const double mu_r[2]) {
 
 // tau <-> T of the optimizer (back_end_optimizer.hpp:216-300)
 MPCR_HD double tau_to_T(double tau) { return tau > 0.0 ? ((0.5 * tau + 1.0) * tau + 1.0) : 1.0 / ((0.5 * tau - 1.0) * tau + 1.0); }
+// T and 1 / T together (one reciprocal): the device's form; 1 ulp off the quotient above for tau <= 0
+MPCR_HD void tau_to_T_h(double tau, double &T, double &h) {
+    if (tau > 0.0) { T = (0.5 * tau + 1.0) * tau + 1.0; h = rcp(T); }
+    else { h = (0.5 * tau - 1.0) * tau + 1.0; T = rcp(h); }
+}
 MPCR_HD double grad_T_to_tau(double tau, double gT) {
     if (tau > 0) return gT * (tau + 1.0);
     const double den = (0.5 * tau - 1.0) * tau + 1.0;

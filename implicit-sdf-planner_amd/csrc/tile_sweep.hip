@@ -537,7 +537,7 @@ __global__ __launch_bounds__(64 * SW_SAMPLES, FUSED ? 3 : sweep_waves_per_simd(K
     if constexpr (FUSED) {
         // host-direct step: the first workgroups bring the inputs in (one PCIe read round trip, instead of a copy command and
         // its completion in front of the launch)
-        if (P.host_T && (int)blockIdx.x < (P.n_traj * P.N + STAGE_G - 1) / STAGE_G) stage_in(P, (int)blockIdx.x);
+        if (P.host_T && !P.stage_ext && (int)blockIdx.x < (P.n_traj * P.N + STAGE_G - 1) / STAGE_G) stage_in(P, (int)blockIdx.x);
     }
     __shared__ SweepPose s_pose[SW_SAMPLES];
     __shared__ unsigned s_list[SW_SAMPLES][SW_LIST_CAP];          // ring of compacted voxels awaiting the fp32 test
@@ -1653,6 +1653,11 @@ bool sweep_can_fuse(const SweepParams &P) {
     if (n_samples <= 0 || P.K + 1 > TL_THREADS) return false;      // (the fused tail makes ONE pass over a piece's samples)
     // tail workgroups of OTHER ranks' pieces only write zeros and leave: they do not count
     return (n_samples + SW_SAMPLES - 1) / SW_SAMPLES + (long long)(P.piece_end - P.piece_begin) <= fused_max_blocks() && (long long)P.n_traj * P.N <= 8 * fused_max_blocks();
+}
+
+int sweep_fused_headroom(const SweepParams &P) {
+    const long long n_samples = (long long)(P.piece_end - P.piece_begin) * (P.K + 1);
+    return fused_max_blocks() - (int)((n_samples + SW_SAMPLES - 1) / SW_SAMPLES + (long long)P.n_traj * P.N);
 }
 
 static int sweep_target_blocks_mesh() {      // persistent workgroups of mesh_exact_kernel: 5 per CU (96 registers; at 6 the spills cost more than the sixth wavefront brings: 2.43 -> 3.01 ms)

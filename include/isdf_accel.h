@@ -274,6 +274,9 @@ int isdf_eval(isdf_ctx *ctx, int n_traj, const int *N, const double *const *T,
 /*   DEVICE_CALLBACK  isdf_cost_function with its MINCO half on the device: x goes down (through the BAR, or fetched from
  *                  host-mapped memory), (cost, g) and a completion word come back into host-mapped memory; no copy commands */
 #define ISDF_HOST_PATH_DEVICE_CALLBACK 3
+/*   DEVICE_CALLBACK_CONCURRENT  the same when the sweep is ONE fused launch: the callback's two kernels run on a second stream
+ *                  beside it, chained through device flags (launch latencies overlap); ISDF_NO_CB_CONCURRENT=1 switches it off */
+#define ISDF_HOST_PATH_DEVICE_CALLBACK_CONCURRENT 4
 int isdf_host_path(const isdf_ctx *ctx);
 
 /* Device-resident entry point, asynchronous on `stream` (a hipStream_t passed as void*; NULL = default
