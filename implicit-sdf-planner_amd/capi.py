@@ -106,7 +106,7 @@ EXPORTED_SYMBOLS = [
     "isdf_xchg_create", "isdf_xchg_connect", "isdf_xchg_allreduce", "isdf_xchg_fuse", "isdf_xchg_status", "isdf_xchg_destroy",
 ]
 
-HOST_PATH_COPY, HOST_PATH_DIRECT_MAPPED, HOST_PATH_DIRECT_BAR, HOST_PATH_DEVICE_CALLBACK, HOST_PATH_DEVICE_CALLBACK_CONCURRENT = 0, 1, 2, 3, 4
+HOST_PATH_COPY, HOST_PATH_DIRECT_MAPPED, HOST_PATH_DIRECT_BAR, HOST_PATH_DEVICE_CALLBACK, HOST_PATH_DEVICE_CALLBACK_FUSED = 0, 1, 2, 3, 4
 MINCO_DEVICE, MINCO_HOST = 0, 1
 MULTI_NONE, MULTI_PEER_SUM, MULTI_STAGED, MULTI_RCCL = 0, 1, 2, 3
 

@@ -101,10 +101,9 @@ struct isdf_ctx {
     double *h_cbres = nullptr, *h_cbres_dev = nullptr; size_t cbres_cap = 0;   // pinned, device-mapped: [x staging | cost, g, parts | flag]
     unsigned long long cb_seq = 0; bool cb_dev = false, cb_post_queued = false; bool cb_ends_dirty = true;
     double cb_ends[18] = {0};
-    // concurrent form of the device callback (its sweep is ONE fused launch): cb_pre / cb_post on stream_aux, the sweep on the
-    // caller's stream; d_cbflag = the word the sweep's collector raises for cb_post_kernel.  ISDF_NO_CB_CONCURRENT=1: always one
-    // after the other on one stream
-    hipStream_t stream_aux = nullptr; hipEvent_t cb_ev = nullptr; unsigned long long *d_cbflag = nullptr; bool env_no_cb_conc = false, cb_conc = false;
+    // the device callback INSIDE a fused sweep launch: d_cbflag = the device word that stands in for the host flag of a host-direct
+    // step (so that the launch's release / acquire chain runs).  ISDF_NO_CB_FUSE=1: always the three-kernel form
+    unsigned long long *d_cbflag = nullptr; bool env_no_cb_fuse = false;
     // front end (csrc/frontend.hip): attitude kernels of the robot, inflated bit-packed occupancy, breadth-first order tables
     struct FrontEnd {
         isdf_frontend_config cfg{}; int xk = 0, yk = 0; double margin = 0.0; bool built = false;

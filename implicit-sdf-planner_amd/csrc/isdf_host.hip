@@ -141,7 +141,7 @@ extern "C" int isdf_create(isdf_ctx **out, const isdf_config *cfg) {
         c->env_no_bar = on("ISDF_NO_BAR_WRITES");
         c->env_no_lpt = on("ISDF_NO_LPT");
         c->minco_mode = on("ISDF_HOST_MINCO") ? 1 : 0;
-        c->env_no_cb_conc = on("ISDF_NO_CB_CONCURRENT");
+        c->env_no_cb_fuse = on("ISDF_NO_CB_FUSE");
     }
     if (hipSetDevice(c->device) != hipSuccess || hipMalloc(&c->d_stats, 8 * sizeof(unsigned long long)) != hipSuccess ||
         hipMalloc(&c->d_traj_duration, sizeof(double)) != hipSuccess || hipMalloc(&c->d_n_coarse, sizeof(int)) != hipSuccess ||
@@ -185,8 +185,6 @@ extern "C" int isdf_destroy(isdf_ctx *c) {
     for (void *p : ptrs) if (p) (void)hipFree(p);
     free_mesh(c);
     if (c->stream) (void)hipStreamDestroy(c->stream);
-    if (c->stream_aux) (void)hipStreamDestroy(c->stream_aux);
-    if (c->cb_ev) (void)hipEventDestroy(c->cb_ev);
     delete c;
     return ISDF_OK;
 }
@@ -586,9 +584,9 @@ int isdf_reset_result_slots(isdf_ctx *c) {
 // mode 0: the sweep cfg.variant names; 1: the swept-volume sweep; 2: the integral sweep with the collision term off
 // (modes 1 + 2 together are what costFunctionLmbm runs for the reference's live configuration)
 // host-direct step (see isdf_ctx.hpp): device-visible addresses of the pinned inputs / outputs / flags of this step
-// ext_stage: the inputs come through the staging buffer, filled by ANOTHER kernel (the callback's cb_pre_kernel, on a second
-// stream, already queued); `out` and `flags` are then device memory and the step keeps room for that kernel's workgroups
-struct HostDirect { const double *T, *coeffs; double *out; unsigned long long *flags; unsigned long long seq; bool via_bar; bool ext_stage = false; };
+// ext_stage + cb: the objective callback inside the fused launch (csrc/minco_dev_body.hpp) - the launch's first workgroup fills
+// the staging buffer from x, its collector runs the adjoint; `out` and `flags` are then device memory
+struct HostDirect { const double *T, *coeffs; double *out; unsigned long long *flags; unsigned long long seq; bool via_bar; bool ext_stage = false; const CbDev *cb = nullptr; };
 static int ensure_stage(isdf_ctx *c, size_t total_pieces) {
     const size_t n_groups = (total_pieces + STAGE_G - 1) / STAGE_G;
     { int rc1 = isdf_ensure_doubles(c, &c->d_stage, &c->stage_cap, total_pieces * 19); if (rc1) return rc1; }
@@ -793,10 +791,12 @@ static int eval_device_impl(isdf_ctx *c, int n_traj, int N, const double *d_T, c
     }
     if (hd) {
         if (!fused || P.xf.world > 1 || P.dbg) return ISDF_DIRECT_NA;
-        if (hd->ext_stage && sweep_fused_headroom(P) < 8) return ISDF_DIRECT_NA;     // the callback's two workgroups must fit beside the resident launch
         { int rc1 = ensure_stage(c, (size_t)total_pieces); if (rc1) return rc1; }
         P.out = hd->out; P.host_flag = hd->flags; P.seq = hd->seq;
-        if (hd->ext_stage) { P.host_T = d_T; P.host_coeffs = d_coeffs; P.stage = c->d_stage; P.stage_flags = c->d_stage_flags; P.stage_ext = 1; }
+        if (hd->ext_stage) {
+            P.host_T = d_T; P.host_coeffs = d_coeffs; P.stage = c->d_stage; P.stage_flags = c->d_stage_flags; P.stage_ext = 1;
+            if (hd->cb) { P.cb = *hd->cb; P.cb_on = 1; }
+        }
         else if (!hd->via_bar) { P.host_T = hd->T; P.host_coeffs = hd->coeffs; P.stage = c->d_stage; P.stage_flags = c->d_stage_flags; }
         c->last_P = P;
     }
@@ -1619,12 +1619,10 @@ static int cost_function_launch_dev(isdf_ctx *c, const double *x, int n, hipStre
     c->cb_n_out = swept ? 2 : 1;
     c->cb_direct = false; c->cb_dev = true; c->cb_post_queued = false;
     c->cb_seq = ++c->dir_seq;          // (one counter with the host-direct steps: they share the staging buffer's ready flags)
-    // A callback whose sweep is one fused launch runs its three kernels CONCURRENTLY: cb_pre_kernel and cb_post_kernel on a second
-    // stream, the sweep on `st`, chained through the staging buffer's ready flags and a device word (csrc/minco_dev.hip)
-    bool conc = whole && !swept && direct_enabled(c) && !c->env_no_cb_conc && c->peers.empty();
-    if (conc) {
-        if (!c->stream_aux) HIPCHK(c, hipStreamCreateWithFlags(&c->stream_aux, hipStreamNonBlocking));
-        if (!c->cb_ev) HIPCHK(c, hipEventCreateWithFlags(&c->cb_ev, hipEventDisableTiming));
+    // A callback whose sweep is one fused launch runs ENTIRELY inside that launch (tile_sweep.hip, SweepParams::cb_on): its first
+    // workgroup turns x into (T, coefficients) and publishes them through the staging buffer, its collector runs the adjoint
+    const bool in_launch = whole && !swept && direct_enabled(c) && !c->env_no_cb_fuse && c->peers.empty() && N <= CB_FUSED_MAX_N;
+    if (in_launch) {
         if (!c->d_cbflag) { HIPCHK(c, hipMalloc(&c->d_cbflag, 2 * sizeof(unsigned long long))); HIPCHK(c, hipMemset(c->d_cbflag, 0, 2 * sizeof(unsigned long long))); }
         const int rs0 = ensure_stage(c, (size_t)N);
         if (rs0) return rs0;
@@ -1636,31 +1634,25 @@ static int cost_function_launch_dev(isdf_ctx *c, const double *x, int n, hipStre
     if (bar_usable(c, c->d_cbdev, nvar)) std::memcpy(c->d_cbdev, x, nvar * sizeof(double));      // CPU stores into device memory
     else { std::memcpy(c->h_cbres, x, nvar * sizeof(double)); P.x = c->h_cbres_dev; }
     __sync_synchronize();
-    if (conc) { P.stage = c->d_stage; P.stage_flags = c->d_stage_flags; }
-    launch_cb_pre(P, conc ? c->stream_aux : st);
     const size_t ostride = isdf_out_stride(N);
     double *d_T = c->d_cb, *d_C = c->d_cb + N, *d_o = c->d_cb + (size_t)19 * N;
-    if (conc) {
+    if (in_launch) {
+        CbDev Pf = P;
+        Pf.stage = c->d_stage; Pf.stage_flags = c->d_stage_flags;
         HostDirect hd{};
-        hd.ext_stage = true; hd.out = d_o; hd.flags = c->d_cbflag; hd.seq = c->cb_seq;
+        hd.ext_stage = true; hd.out = d_o; hd.flags = c->d_cbflag; hd.seq = c->cb_seq; hd.cb = &Pf;
         rc = eval_device_impl(c, 1, N, d_T, d_C, d_o, nullptr, st, 0, false, &hd);
         if (rc < 0) return rc;
         if (rc == ISDF_OK) {
-            P.wait_flag = c->d_cbflag;
-            launch_cb_post(P, c->stream_aux);       // resident beside the sweep, waiting for its collector's word
-            HIPCHK(c, hipGetLastError());
             c->cb_post_queued = true;
-            c->last_host_path = ISDF_HOST_PATH_DEVICE_CALLBACK_CONCURRENT;
+            c->last_host_path = ISDF_HOST_PATH_DEVICE_CALLBACK_FUSED;
             c->last_minco_path = 1;
             c->cb_pending = true;
-            c->cb_conc = true;
             return ISDF_OK;
         }
-        // not one fused launch after all: one after the other on `st`, behind cb_pre_kernel
-        HIPCHK(c, hipEventRecord(c->cb_ev, c->stream_aux));
-        HIPCHK(c, hipStreamWaitEvent(st, c->cb_ev, 0));
+        // (ISDF_DIRECT_NA: not one fused launch - nothing was launched; the three-kernel form below)
     }
-    c->cb_conc = false;
+    launch_cb_pre(P, st);
     if (swept) {
         rc = sweep_dispatch(c, 1, N, d_T, d_C, d_o, nullptr, st, 1);
         if (rc) return rc;

@@ -4,6 +4,7 @@
 #include <hip/hip_ext.h>
 #include <cstdint>
 #include "dev_shapes.hpp"
+#include "minco_dev.hpp"
 
 namespace isdf {
 
@@ -74,7 +75,11 @@ struct SweepParams {
     unsigned long long *stage_flags;
     unsigned long long seq;
     unsigned long long *host_flag;
-    int stage_ext;              // 1: another kernel fills `stage` and raises stage_flags (the callback's cb_pre_kernel on a second stream): no stage_in here
+    int stage_ext;              // 1: the inputs come through `stage`, but not from the host (cb_on): no stage_in
+    // the objective callback INSIDE this fused launch (csrc/minco_dev_body.hpp): workgroup 0 first runs cb_pre_body (x -> T,
+    // coefficients into `stage`, ready flags), the trajectory's collector runs cb_post_body on the finished sums
+    int cb_on;
+    CbDev cb;
     // Dispatch order of a fused single-launch step (scheduling only; results cannot depend on it): rank in the launch
     // (workgroup b, wave w: b + w * n_sweep_blocks) -> local sample, -1 = none.  The tail workgroups of step k build the order
     // for step k + 1 from the work classes the sweep waves of step k - 1 left (plan_piece, tile_sweep.hip).
@@ -105,7 +110,6 @@ struct SweepParams {
 // end timestamps - the same interval rocprofv3 reports for the kernel
 size_t sweep_pose_bytes();      // sizeof(SweepPose)
 bool sweep_can_fuse(const SweepParams &P);
-int sweep_fused_headroom(const SweepParams &P);                 // workgroups that still fit beside this step's fused (resident) launch
 int sweep_resident_blocks(const SweepParams &P, int n_cus);      // small launch, analytic shape with identity body offset: sweep + tail in one launch
 void launch_sweep(const SweepParams &P, hipStream_t stream, hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr, bool fused = false);
 void launch_stats(const SweepParams &P, hipStream_t stream);   // on demand, not part of the step

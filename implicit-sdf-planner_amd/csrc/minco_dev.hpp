@@ -8,6 +8,7 @@ namespace isdf {
 constexpr int CB_MAX_N = 400;             // pieces per trajectory the device callback takes (LDS: 19 N doubles); beyond it MINCO runs on the host
 constexpr int CB_SPLIT_MAX_N = 320;       // up to here the three axes of a row sit in three wavefront groups (3 x 320 threads)
 constexpr int CB_MAX_ROUNDS = 9;          // ceil(log2(CB_MAX_N - 1))
+constexpr int CB_FUSED_MAX_N = 64;         // the in-launch form runs the bodies with 3 x 64 of the fused kernel's 256 threads
 constexpr int CB_FAC_STRIDE = 8 * CB_MAX_ROUNDS + 4;   // per row: the two multiplier blocks of every round, then inv(D) of the last
 
 struct CbDev {
@@ -26,12 +27,10 @@ struct CbDev {
     unsigned long long *flag;   // [nb] completion words (res and flag host-mapped), or null
     unsigned long long seq;
     const unsigned long long *stats;   // the sweeps' statistics words ([4] = overflow), or null
-    // concurrent form (nb == 1, the sweep is ONE fused launch on another stream): cb_pre_kernel also fills the fused launch's
-    // staging buffer ([piece][19] = T, c(6 x 3)) and raises its ready flags with `seq`; cb_post_kernel first waits for
-    // wait_flag[0] == seq, which the sweep's collector stores when the trajectory's sums are complete
+    // callback inside the fused sweep launch (nb == 1, tile_sweep.hip): cb_pre_body also fills the launch's staging buffer
+    // ([piece][19] = T, c(6 x 3)) and raises its ready flags with `seq`; null otherwise
     double *stage;
     unsigned long long *stage_flags;
-    const unsigned long long *wait_flag;
 };
 
 void launch_cb_pre(const CbDev &P, hipStream_t st);

@@ -32,6 +32,7 @@
 #define ISDF_SWEEP_STATS 0   // 1: per-wave statistics for tools/timing.py (developer builds)
 #endif
 #include "isdf_internal.hpp"
+#include "minco_dev_body.hpp"
 #include "dev_mesh.hpp"
 
 namespace isdf {
@@ -532,6 +533,14 @@ __global__ __launch_bounds__(64 * SW_SAMPLES, FUSED ? 3 : sweep_waves_per_simd(K
             if (P.xf.world > 1) tail_piece<false, true>(P, (int)blockIdx.x - n_blocks, s_tail);      // multi-GPU step: exchange inside
             else tail_piece<false, false>(P, (int)blockIdx.x - n_blocks, s_tail);
             return;
+        }
+        // the objective callback inside this launch: the first workgroup turns x into (T, coefficients) and publishes them
+        // through the staging buffer every consumer of the launch waits on - then joins the sweep like any other workgroup
+        // (s_tail is idle in sweep workgroups: its 21 KB are the body's scratch)
+        if (P.cb_on && blockIdx.x == 0) {
+            __shared__ double s_cbpart[16];
+            cbd::cb_pre_body<true>(P.cb, 0, 64, &s_tail[0][0], s_cbpart);
+            __syncthreads();
         }
     }
     if constexpr (FUSED) {
@@ -1607,6 +1616,16 @@ template <bool EARLY, bool XF> __device__ __forceinline__ void tail_piece(const 
             __hip_atomic_store(&P.host_flag[b], P.seq | (ovf ? HOST_FLAG_OVERFLOW : 0ull), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
         }
     }
+    if constexpr (!XF && !EARLY) {
+        // the objective callback inside this launch: every row of [cost | gradT | gradC] is in place (the collector has taken
+        // every piece's cost, which its workgroup released after its rows) - energy partials + sums -> adjoint -> (cost, g)
+        // and the completion word into host-mapped memory (csrc/minco_dev_body.hpp)
+        if (P.cb_on && collector) {
+            __shared__ double s_cbpart2[16];
+            __syncthreads();
+            cbd::cb_post_body<true>(P.cb, 0, 1, 64, &s_val[0][0], s_cbpart2);
+        }
+    }
     if (dbg && tid == 0) dbg[1] = wall_clock64();
 }
 
@@ -1653,11 +1672,6 @@ bool sweep_can_fuse(const SweepParams &P) {
     if (n_samples <= 0 || P.K + 1 > TL_THREADS) return false;      // (the fused tail makes ONE pass over a piece's samples)
     // tail workgroups of OTHER ranks' pieces only write zeros and leave: they do not count
     return (n_samples + SW_SAMPLES - 1) / SW_SAMPLES + (long long)(P.piece_end - P.piece_begin) <= fused_max_blocks() && (long long)P.n_traj * P.N <= 8 * fused_max_blocks();
-}
-
-int sweep_fused_headroom(const SweepParams &P) {
-    const long long n_samples = (long long)(P.piece_end - P.piece_begin) * (P.K + 1);
-    return fused_max_blocks() - (int)((n_samples + SW_SAMPLES - 1) / SW_SAMPLES + (long long)P.n_traj * P.N);
 }
 
 static int sweep_target_blocks_mesh() {      // persistent workgroups of mesh_exact_kernel: 5 per CU (96 registers; at 6 the spills cost more than the sixth wavefront brings: 2.43 -> 3.01 ms)

@@ -274,9 +274,10 @@ int isdf_eval(isdf_ctx *ctx, int n_traj, const int *N, const double *const *T,
 /*   DEVICE_CALLBACK  isdf_cost_function with its MINCO half on the device: x goes down (through the BAR, or fetched from
  *                  host-mapped memory), (cost, g) and a completion word come back into host-mapped memory; no copy commands */
 #define ISDF_HOST_PATH_DEVICE_CALLBACK 3
-/*   DEVICE_CALLBACK_CONCURRENT  the same when the sweep is ONE fused launch: the callback's two kernels run on a second stream
- *                  beside it, chained through device flags (launch latencies overlap); ISDF_NO_CB_CONCURRENT=1 switches it off */
-#define ISDF_HOST_PATH_DEVICE_CALLBACK_CONCURRENT 4
+/*   DEVICE_CALLBACK_FUSED  the same in ONE launch, when the sweep is one fused launch and N <= 64: its first workgroup runs
+ *                  MINCO and hands (T, coefficients) to the rest through the staging buffer, its last runs the adjoint;
+ *                  ISDF_NO_CB_FUSE=1 switches it off */
+#define ISDF_HOST_PATH_DEVICE_CALLBACK_FUSED 4
 int isdf_host_path(const isdf_ctx *ctx);
 
 /* Device-resident entry point, asynchronous on `stream` (a hipStream_t passed as void*; NULL = default

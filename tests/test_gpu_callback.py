@@ -256,8 +256,8 @@ def test_device_minco_callback_equals_host_minco_callback(pkg, orc, product_lib,
     eng.set_trajectory(N, head, tail, rho)
     x = eng.pack_variables(T0, way)
     cost_d, g_d = eng.cost_function(x)
-    # (a V2 / V3 step of this size is one fused launch: the callback's kernels then run beside it on a second stream)
-    assert eng.minco_path() == 1 and eng.host_path() == (capi.HOST_PATH_DEVICE_CALLBACK if variant == "V1" else capi.HOST_PATH_DEVICE_CALLBACK_CONCURRENT)
+    # (a V2 / V3 step of this size is one fused launch: up to 64 pieces the whole callback then runs inside that launch)
+    assert eng.minco_path() == 1 and eng.host_path() == (capi.HOST_PATH_DEVICE_CALLBACK if variant == "V1" or N > 64 else capi.HOST_PATH_DEVICE_CALLBACK_FUSED)
     parts_d = eng.cost_parts()
     cost_d2, g_d2 = eng.cost_function(x)                       # deterministic: the same bits again
     assert cost_d2 == cost_d and np.array_equal(g_d2, g_d)
@@ -300,9 +300,9 @@ def test_device_minco_callback_largest_trajectory_and_fallback(pkg, orc, product
         assert abs(cost - cost_h) <= 1e-9 * abs(cost_h) and _rel_inf(g, g_h) <= 1e-9, (N, cost, cost_h, _rel_inf(g, g_h))
 
 
-def test_device_callback_concurrent_equals_serial(pkg, orc, product_lib, monkeypatch):
-    """The two forms of the device callback - its kernels beside the fused sweep launch on a second stream, or one after the
-    other on one stream (ISDF_NO_CB_CONCURRENT=1, read at isdf_create) - give the same bits, call after call."""
+def test_device_callback_in_launch_equals_three_kernels(pkg, orc, product_lib, monkeypatch):
+    """The two forms of the device callback - everything inside the fused sweep launch, or three kernels one after the other
+    (ISDF_NO_CB_FUSE=1, read at isdf_create) - give the same bits, call after call."""
     capi, synth = pkg.capi, pkg.synth
     occ, esdf, res = small_world(pkg)
     N = 12
@@ -310,9 +310,9 @@ def test_device_callback_concurrent_equals_serial(pkg, orc, product_lib, monkeyp
     shape = synth.make_shape("RoundedCone", params=(0.8, 0.3, 1.6))
     rng = np.random.default_rng(4)
     out = {}
-    for form in ("concurrent", "serial"):
+    for form in ("in-launch", "serial"):
         if form == "serial":
-            monkeypatch.setenv("ISDF_NO_CB_CONCURRENT", "1")
+            monkeypatch.setenv("ISDF_NO_CB_FUSE", "1")
         cfg, eng, o = _engines(pkg, orc, capi.V3_ESDF_TILE, occ, esdf, res, shape)
         eng.set_trajectory(N, head, tail, 2.0)
         x = eng.pack_variables(T0, way)
@@ -322,7 +322,7 @@ def test_device_callback_concurrent_equals_serial(pkg, orc, product_lib, monkeyp
             xi = x + 0.02 * rs.normal(0, 1, x.size)
             c, g = eng.cost_function(xi)
             rows.append(np.concatenate([[c], g]))
-        want = capi.HOST_PATH_DEVICE_CALLBACK_CONCURRENT if form == "concurrent" else capi.HOST_PATH_DEVICE_CALLBACK
+        want = capi.HOST_PATH_DEVICE_CALLBACK_FUSED if form == "in-launch" else capi.HOST_PATH_DEVICE_CALLBACK
         assert eng.host_path() == want
         # interleaved with the other host entry points of the same ctx (they share the staging buffer's flags)
         Tn, cm = eng.unpack_variables(x)
@@ -332,7 +332,7 @@ def test_device_callback_concurrent_equals_serial(pkg, orc, product_lib, monkeyp
         assert e1[0] == e2[0] and np.array_equal(e1[2], e2[2])
         rows.append(np.concatenate([[c2], g2]))
         out[form] = np.array(rows)
-    assert np.array_equal(out["concurrent"], out["serial"])
+    assert np.array_equal(out["in-launch"], out["serial"])
 
 
 def test_device_minco_gradient_is_the_derivative(pkg, orc, product_lib):
