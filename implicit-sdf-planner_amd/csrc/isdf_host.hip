@@ -584,9 +584,9 @@ int isdf_reset_result_slots(isdf_ctx *c) {
 // mode 0: the sweep cfg.variant names; 1: the swept-volume sweep; 2: the integral sweep with the collision term off
 // (modes 1 + 2 together are what costFunctionLmbm runs for the reference's live configuration)
 // host-direct step (see isdf_ctx.hpp): device-visible addresses of the pinned inputs / outputs / flags of this step
-// ext_stage + cb: the objective callback inside the fused launch (csrc/minco_dev_body.hpp) - the launch's first workgroup fills
-// the staging buffer from x, its collector runs the adjoint; `out` and `flags` are then device memory
-struct HostDirect { const double *T, *coeffs; double *out; unsigned long long *flags; unsigned long long seq; bool via_bar; bool ext_stage = false; const CbDev *cb = nullptr; };
+// cb: the objective callback inside the fused launch (csrc/minco_dev_body.hpp) - every workgroup forms (T, coefficients) from x,
+// the collector runs the adjoint; `out` and `flags` are then device memory
+struct HostDirect { const double *T, *coeffs; double *out; unsigned long long *flags; unsigned long long seq; bool via_bar; const CbDev *cb = nullptr; };
 static int ensure_stage(isdf_ctx *c, size_t total_pieces) {
     const size_t n_groups = (total_pieces + STAGE_G - 1) / STAGE_G;
     { int rc1 = isdf_ensure_doubles(c, &c->d_stage, &c->stage_cap, total_pieces * 19); if (rc1) return rc1; }
@@ -793,10 +793,7 @@ static int eval_device_impl(isdf_ctx *c, int n_traj, int N, const double *d_T, c
         if (!fused || P.xf.world > 1 || P.dbg) return ISDF_DIRECT_NA;
         { int rc1 = ensure_stage(c, (size_t)total_pieces); if (rc1) return rc1; }
         P.out = hd->out; P.host_flag = hd->flags; P.seq = hd->seq;
-        if (hd->ext_stage) {
-            P.host_T = d_T; P.host_coeffs = d_coeffs; P.stage = c->d_stage; P.stage_flags = c->d_stage_flags; P.stage_ext = 1;
-            if (hd->cb) { P.cb = *hd->cb; P.cb_on = 1; }
-        }
+        if (hd->cb) { P.cb = *hd->cb; P.cb_on = 1; }          // (T, coefficients) are formed inside the launch, from x
         else if (!hd->via_bar) { P.host_T = hd->T; P.host_coeffs = hd->coeffs; P.stage = c->d_stage; P.stage_flags = c->d_stage_flags; }
         c->last_P = P;
     }
@@ -1624,8 +1621,6 @@ static int cost_function_launch_dev(isdf_ctx *c, const double *x, int n, hipStre
     const bool in_launch = whole && !swept && direct_enabled(c) && !c->env_no_cb_fuse && c->peers.empty() && N <= CB_FUSED_MAX_N;
     if (in_launch) {
         if (!c->d_cbflag) { HIPCHK(c, hipMalloc(&c->d_cbflag, 2 * sizeof(unsigned long long))); HIPCHK(c, hipMemset(c->d_cbflag, 0, 2 * sizeof(unsigned long long))); }
-        const int rs0 = ensure_stage(c, (size_t)N);
-        if (rs0) return rs0;
     }
     CbDev P{};
     int rc = cb_dev_fill(c, N, &P, st);
@@ -1637,10 +1632,8 @@ static int cost_function_launch_dev(isdf_ctx *c, const double *x, int n, hipStre
     const size_t ostride = isdf_out_stride(N);
     double *d_T = c->d_cb, *d_C = c->d_cb + N, *d_o = c->d_cb + (size_t)19 * N;
     if (in_launch) {
-        CbDev Pf = P;
-        Pf.stage = c->d_stage; Pf.stage_flags = c->d_stage_flags;
         HostDirect hd{};
-        hd.ext_stage = true; hd.out = d_o; hd.flags = c->d_cbflag; hd.seq = c->cb_seq; hd.cb = &Pf;
+        hd.via_bar = true; hd.out = d_o; hd.flags = c->d_cbflag; hd.seq = c->cb_seq; hd.cb = &P;
         rc = eval_device_impl(c, 1, N, d_T, d_C, d_o, nullptr, st, 0, false, &hd);
         if (rc < 0) return rc;
         if (rc == ISDF_OK) {

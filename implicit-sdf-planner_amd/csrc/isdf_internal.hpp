@@ -75,9 +75,8 @@ struct SweepParams {
     unsigned long long *stage_flags;
     unsigned long long seq;
     unsigned long long *host_flag;
-    int stage_ext;              // 1: the inputs come through `stage`, but not from the host (cb_on): no stage_in
-    // the objective callback INSIDE this fused launch (csrc/minco_dev_body.hpp): workgroup 0 first runs cb_pre_body (x -> T,
-    // coefficients into `stage`, ready flags), the trajectory's collector runs cb_post_body on the finished sums
+    // the objective callback INSIDE this fused launch (csrc/minco_dev_body.hpp): every workgroup first runs cb_pre_body (x -> T,
+    // coefficients, into an LDS table it then takes its inputs from), the trajectory's collector runs cb_post_body on the finished sums
     int cb_on;
     CbDev cb;
     // Dispatch order of a fused single-launch step (scheduling only; results cannot depend on it): rank in the launch

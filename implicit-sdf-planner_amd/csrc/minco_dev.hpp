@@ -27,10 +27,6 @@ struct CbDev {
     unsigned long long *flag;   // [nb] completion words (res and flag host-mapped), or null
     unsigned long long seq;
     const unsigned long long *stats;   // the sweeps' statistics words ([4] = overflow), or null
-    // callback inside the fused sweep launch (nb == 1, tile_sweep.hip): cb_pre_body also fills the launch's staging buffer
-    // ([piece][19] = T, c(6 x 3)) and raises its ready flags with `seq`; null otherwise
-    double *stage;
-    unsigned long long *stage_flags;
 };
 
 void launch_cb_pre(const CbDev &P, hipStream_t st);

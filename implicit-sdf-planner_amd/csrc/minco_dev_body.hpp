@@ -20,12 +20,13 @@
 // durations only: the way forward stores every round's two multiplier blocks per row, and the adjoint solve (same matrix: it is
 // symmetric) replays them on its right-hand sides.
 //
-// A callback whose sweep is ONE fused launch (C2) runs both bodies INSIDE that launch (tile_sweep.hip, SweepParams::cb_on): its
-// first workgroup runs cb_pre_body and publishes (T, coefficients) through the launch's staging buffer, on whose ready flags every
-// consumer of the launch already waits (stage_wait); the trajectory's collector - the workgroup that has seen every piece's sums
-// arrive - runs cb_post_body.  One launch per callback.  (Measured and dropped: the three kernels on two streams, chained by the
-// same flags - queue switches cost more than the overlapped launch latencies bring: 44.7 us against 36.8 one after the other,
-// profiles/r5_callback_concurrent_streams_dropped.txt.)
+// A callback whose sweep is ONE fused launch (C2) runs both bodies INSIDE that launch (tile_sweep.hip, SweepParams::cb_on): EVERY
+// workgroup of the launch first runs cb_pre_body into an LDS table of (T, coefficients) - the solve repeated 690 times side by
+// side costs the step one solve's latency and no communication - and only workgroup 0 writes the global outputs; the
+// trajectory's collector - the workgroup that has seen every piece's sums arrive - runs cb_post_body.  One launch per callback.
+// Measured and dropped on the way (profiles/r5_callback_*_dropped.txt): the three kernels on two streams chained by device
+// flags (queue switches cost more than the overlapped launch latencies: 44.7 us against 36.8 one after the other); workgroup 0
+// alone solving while the launch's other 2 700 wavefronts poll its ready flags (46.9 us: the polling starves the solve).
 #pragma once
 #include "isdf_internal.hpp"
 #include "dev_math.hpp"
@@ -63,7 +64,10 @@ constexpr int SH_ROW = 18;      // LDS record of a row during a round: inv(D) (4
 
 // SPLIT: three wavefront groups, one per axis (threads [0, 3 NT), NT >= pieces, a multiple of 64); the workgroup's further threads
 // only keep the barriers.  b: trajectory of the launch; s_mem: 19 N + 6 doubles of LDS, s_part: 16.
-template <bool SPLIT> __device__ __forceinline__ void cb_pre_body(const CbDev &P, const int b, const int NT, double *s_mem, double *s_part) {
+// s_tab (LDS, nullable): [piece][19] = T, c(6 x 3) - the table the fused launch's workgroups take their inputs from.
+// glob: write the global outputs (false for the workgroups of a fused launch that only need the table: every workgroup of the
+// launch repeats the solve rather than wait for one of them - 2 600 wavefronts polling a flag cost more than the solve).
+template <bool SPLIT> __device__ __forceinline__ void cb_pre_body(const CbDev &P, const int b, const int NT, double *s_mem, double *s_part, double *s_tab = nullptr, const bool glob = true) {
     const int N = P.N, n = N - 1;
     const int ax = (int)threadIdx.x / NT;
     const int k = ax < (SPLIT ? 3 : 1) ? (int)threadIdx.x % NT : N;
@@ -80,7 +84,7 @@ template <bool SPLIT> __device__ __forceinline__ void cb_pre_body(const CbDev &P
     double T = 1.0, h = 1.0;
     if (k < N) {
         mpcr::tau_to_T_h(x[k], T, h);
-        if (lead) { s_h[k] = h; P.T[(size_t)b * N + k] = T; }
+        if (lead) { s_h[k] = h; if (glob) P.T[(size_t)b * N + k] = T; }
     }
     __syncthreads();
 
@@ -137,7 +141,7 @@ template <bool SPLIT> __device__ __forceinline__ void cb_pre_body(const CbDev &P
                 _Pragma("unroll") for (int l = 0, d = d0; l < ND; l++, d++) { double y[2]; mv(B, w + 12 + 2 * d, y); r[l][0] -= y[0]; r[l][1] -= y[1]; }
             }
             L = Ln; U = Un;
-            if (lead) {
+            if (lead && glob) {
                 double *f = fac + 8 * rd;
                 f[0] = A.a; f[1] = A.b; f[2] = A.c; f[3] = A.d; f[4] = B.a; f[5] = B.b; f[6] = B.c; f[7] = B.d;
             }
@@ -150,46 +154,42 @@ template <bool SPLIT> __device__ __forceinline__ void cb_pre_body(const CbDev &P
     double uk[ND][2] = {};
     if (row) {
         const M2 i = mpcr::inv(D);
-        if (lead) { double *f = fac + 8 * CB_MAX_ROUNDS; f[0] = i.a; f[1] = i.b; f[2] = i.c; f[3] = i.d; }
+        if (lead && glob) { double *f = fac + 8 * CB_MAX_ROUNDS; f[0] = i.a; f[1] = i.b; f[2] = i.c; f[3] = i.d; }
         _Pragma("unroll") for (int l = 0, d = d0; l < ND; l++, d++) mv(i, r[l], uk[l]);
     } else if (k == 0) {
         _Pragma("unroll") for (int l = 0, d = d0; l < ND; l++, d++) { uk[l][0] = ends[3 + d]; uk[l][1] = ends[6 + d]; }
     }
     double *gu = P.u + (size_t)b * (N + 1) * 6;
-    if (k < N) _Pragma("unroll") for (int l = 0, d = d0; l < ND; l++, d++) { s_u[6 * k + 2 * d] = uk[l][0]; s_u[6 * k + 2 * d + 1] = uk[l][1]; gu[6 * k + 2 * d] = uk[l][0]; gu[6 * k + 2 * d + 1] = uk[l][1]; }
+    if (k < N) _Pragma("unroll") for (int l = 0, d = d0; l < ND; l++, d++) { s_u[6 * k + 2 * d] = uk[l][0]; s_u[6 * k + 2 * d + 1] = uk[l][1]; if (glob) { gu[6 * k + 2 * d] = uk[l][0]; gu[6 * k + 2 * d + 1] = uk[l][1]; } }
     if (k == 0) _Pragma("unroll") for (int l = 0, d = d0; l < ND; l++, d++) {
         const double v = ends[9 + 3 + d], a = ends[9 + 6 + d];
-        s_u[6 * N + 2 * d] = v; s_u[6 * N + 2 * d + 1] = a; gu[6 * N + 2 * d] = v; gu[6 * N + 2 * d + 1] = a;
+        s_u[6 * N + 2 * d] = v; s_u[6 * N + 2 * d + 1] = a; if (glob) { gu[6 * N + 2 * d] = v; gu[6 * N + 2 * d + 1] = a; }
     }
     __syncthreads();
-    // ---- piece k: coefficients into the sweeps' input array (and the fused launch's staging buffer), energy and its partials
-    // into the energy block
+    // ---- piece k: coefficients into the sweeps' input array / the fused launch's LDS table, energy and its partials into the
+    // energy block
     double e = 0.0;
     if (k < N) {
         double *C = P.coeffs + (size_t)b * 18 * N + 6 * k;
         double *E = P.epart + (size_t)b * ostride;
-        double *S = P.stage ? P.stage + ((size_t)b * N + k) * 19 : nullptr;
+        double *S = s_tab ? s_tab + (size_t)k * 19 : nullptr;
         if (S && lead) S[0] = T;
         _Pragma("unroll") for (int l = 0, d = d0; l < ND; l++, d++) {
             double c[6], gc[6], gT;
             mpcr::hermite(T, h, pk[l], uk[l][0], uk[l][1], pn[l], s_u[6 * (k + 1) + 2 * d], s_u[6 * (k + 1) + 2 * d + 1], c);
-            e += mpcr::piece_energy1(T, c, gc, gT);
-            s_gt[3 * k + d] = gT;
-            for (int q = 0; q < 6; q++) { C[(size_t)d * 6 * N + q] = c[q]; E[1 + N + (size_t)d * 6 * N + 6 * k + q] = gc[q]; }
             if (S) for (int q = 0; q < 6; q++) S[1 + 6 * d + q] = c[q];
+            if (glob) {
+                e += mpcr::piece_energy1(T, c, gc, gT);
+                s_gt[3 * k + d] = gT;
+                for (int q = 0; q < 6; q++) { C[(size_t)d * 6 * N + q] = c[q]; E[1 + N + (size_t)d * 6 * N + 6 * k + q] = gc[q]; }
+            }
         }
     }
-    if (P.stage) {
-        // the fused sweep launch is already polling: publish (agent scope), then one flag per group of STAGE_G pieces
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-        __syncthreads();
-        const int groups = (N + STAGE_G - 1) / STAGE_G;
-        for (int g = threadIdx.x; g < groups; g += blockDim.x)
-            __hip_atomic_store(P.stage_flags + g, P.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (glob) {                                     // (workgroup-uniform)
+        e = block_sum(e, s_part);                   // (its barriers also order s_gt)
+        if (k < N && lead) P.epart[(size_t)b * ostride + 1 + k] = s_gt[3 * k] + s_gt[3 * k + 1] + s_gt[3 * k + 2];
+        if (threadIdx.x == 0) P.epart[(size_t)b * ostride] = e;
     }
-    e = block_sum(e, s_part);                   // (its barriers also order s_gt)
-    if (k < N && lead) P.epart[(size_t)b * ostride + 1 + k] = s_gt[3 * k] + s_gt[3 * k + 1] + s_gt[3 * k + 2];
-    if (threadIdx.x == 0) P.epart[(size_t)b * ostride] = e;
 }
 
 // s_mem: 15 N + 12 doubles of LDS.  n_traj: trajectories of the launch (the sweeps' blocks are [sweep][trajectory]).

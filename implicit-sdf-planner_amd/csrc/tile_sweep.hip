@@ -171,9 +171,12 @@ __device__ __forceinline__ bool xslot_take(double *slot, double &v) {        // 
 // ---- inputs of one piece: from the caller's device arrays, or - host-direct step - from the staging buffer the first
 // workgroups of the launch fill from host-mapped memory
 struct PieceIn { const double *c; int ld; double T; };
-__device__ __forceinline__ PieceIn piece_in(const SweepParams &P, int b, int i) {
+// tab (callback inside the launch, one trajectory): this workgroup's LDS table [piece][19], or - tail workgroups - the piece's own
+// 19 doubles (tab_one)
+__device__ __forceinline__ PieceIn piece_in(const SweepParams &P, int b, int i, const double *tab = nullptr, bool tab_one = false) {
     PieceIn r;
-    if (P.host_T) { const double *s = P.stage + ((size_t)b * P.N + i) * 19; r.c = s + 1; r.ld = 6; r.T = s[0]; }
+    if (tab) { const double *s = tab_one ? tab : tab + (size_t)i * 19; r.c = s + 1; r.ld = 6; r.T = s[0]; }
+    else if (P.host_T) { const double *s = P.stage + ((size_t)b * P.N + i) * 19; r.c = s + 1; r.ld = 6; r.T = s[0]; }
     else { r.c = P.coeffs + (size_t)b * 18 * P.N + 6 * i; r.ld = 6 * P.N; r.T = P.T[(size_t)b * P.N + i]; }
     return r;
 }
@@ -517,7 +520,7 @@ size_t sweep_pose_bytes() { return sizeof(SweepPose); }
 
 // IDENT: the shape's body offset is the identity (poly_params all zero - every shipped config): those instantiations drop
 // the offset and the 24 scalar registers it pins, which takes Box to 91 VGPRs and a fifth wave per SIMD.
-template <bool EARLY, bool XF> __device__ __forceinline__ void tail_piece(const SweepParams &P, const int t, double (*s_val)[PARTIAL_STRIDE + 1]);
+template <bool EARLY, bool XF> __device__ __forceinline__ void tail_piece(const SweepParams &P, const int t, double (*s_val)[PARTIAL_STRIDE + 1], const double *s_piece = nullptr);
 
 // FUSED: the launch carries, after its P.n_sweep_blocks sweep workgroups, one workgroup per piece that runs the tail
 // (tail_piece) - dispatched last, it does the collision-independent part of its samples while the sweep works and picks the
@@ -526,27 +529,38 @@ template <bool EARLY, bool XF> __device__ __forceinline__ void tail_piece(const 
 template <int KIND, bool IDENT, bool FUSED>
 __global__ __launch_bounds__(64 * SW_SAMPLES, FUSED ? 3 : sweep_waves_per_simd(KIND, IDENT)) void sweep_kernel(const SweepParams P) {
     const int n_blocks = FUSED ? P.n_sweep_blocks : (int)gridDim.x;       // sweep workgroups of this launch
+    __shared__ double s_tail[FUSED ? TL_THREADS : 1][PARTIAL_STRIDE + 1];
+    // The objective callback inside this launch (csrc/minco_dev_body.hpp): EVERY workgroup turns x into (T, coefficients) - an LDS
+    // table [piece][19] behind the body's scratch in s_tail - instead of waiting for one of them; workgroup 0 also writes what the
+    // adjoint at the end of the launch needs.
+    constexpr int CB_TAB_AT = 19 * CB_FUSED_MAX_N + 8;
+    static_assert(!FUSED || CB_TAB_AT + 19 * CB_FUSED_MAX_N <= TL_THREADS * (PARTIAL_STRIDE + 1), "the callback's scratch and table live in s_tail");
+    const double *cb_tab = nullptr;
     if constexpr (FUSED) {
-        __shared__ double s_tail[TL_THREADS][PARTIAL_STRIDE + 1];
-        if ((int)blockIdx.x >= n_blocks) {
-            if ((P.plan_cls_in || P.plan_lr_in) && !(P.dbg_flags & 2) && (threadIdx.x >> 6) == SW_SAMPLES - 1) plan_wave(P, (int)blockIdx.x - n_blocks, threadIdx.x & 63);       // while the sweep works: the NEXT step's dispatch order
-            if (P.xf.world > 1) tail_piece<false, true>(P, (int)blockIdx.x - n_blocks, s_tail);      // multi-GPU step: exchange inside
-            else tail_piece<false, false>(P, (int)blockIdx.x - n_blocks, s_tail);
-            return;
-        }
-        // the objective callback inside this launch: the first workgroup turns x into (T, coefficients) and publishes them
-        // through the staging buffer every consumer of the launch waits on - then joins the sweep like any other workgroup
-        // (s_tail is idle in sweep workgroups: its 21 KB are the body's scratch)
-        if (P.cb_on && blockIdx.x == 0) {
+        if (P.cb_on) {
             __shared__ double s_cbpart[16];
-            cbd::cb_pre_body<true>(P.cb, 0, 64, &s_tail[0][0], s_cbpart);
+            double *tab = &s_tail[0][0] + CB_TAB_AT;
+            cbd::cb_pre_body<true>(P.cb, 0, 64, &s_tail[0][0], s_cbpart, tab, blockIdx.x == 0);
             __syncthreads();
+            cb_tab = tab;
+        }
+        if ((int)blockIdx.x >= n_blocks) {
+            const int t = (int)blockIdx.x - n_blocks;
+            __shared__ double s_piece[19];
+            if (cb_tab) {                         // the table shares s_tail with the tail's sums: this piece's 19 doubles move out
+                if (threadIdx.x < 19) s_piece[threadIdx.x] = cb_tab[(size_t)t * 19 + threadIdx.x];
+                __syncthreads();
+            }
+            if ((P.plan_cls_in || P.plan_lr_in) && !(P.dbg_flags & 2) && (threadIdx.x >> 6) == SW_SAMPLES - 1) plan_wave(P, t, threadIdx.x & 63);       // while the sweep works: the NEXT step's dispatch order
+            if (P.xf.world > 1) tail_piece<false, true>(P, t, s_tail);      // multi-GPU step: exchange inside
+            else tail_piece<false, false>(P, t, s_tail, cb_tab ? s_piece : nullptr);
+            return;
         }
     }
     if constexpr (FUSED) {
         // host-direct step: the first workgroups bring the inputs in (one PCIe read round trip, instead of a copy command and
         // its completion in front of the launch)
-        if (P.host_T && !P.stage_ext && (int)blockIdx.x < (P.n_traj * P.N + STAGE_G - 1) / STAGE_G) stage_in(P, (int)blockIdx.x);
+        if (P.host_T && (int)blockIdx.x < (P.n_traj * P.N + STAGE_G - 1) / STAGE_G) stage_in(P, (int)blockIdx.x);
     }
     __shared__ SweepPose s_pose[SW_SAMPLES];
     __shared__ unsigned s_list[SW_SAMPLES][SW_LIST_CAP];          // ring of compacted voxels awaiting the fp32 test
@@ -590,7 +604,7 @@ __global__ __launch_bounds__(64 * SW_SAMPLES, FUSED ? 3 : sweep_waves_per_simd(K
         bool staged = true;
         if constexpr (FUSED) if (P.host_T) staged = stage_wait(P, id.b * P.N + id.i);
         if (!staged && P.stats) atomicMax(&P.stats[4], 1ull);
-        const PieceIn pin = piece_in(P, id.b, id.i);
+        const PieceIn pin = piece_in(P, id.b, id.i, cb_tab);
         const double *c = pin.c;
         const int ld = pin.ld;
         const double step = pin.T * P.inv_K;
@@ -639,7 +653,7 @@ __global__ __launch_bounds__(64 * SW_SAMPLES, FUSED ? 3 : sweep_waves_per_simd(K
         if (sx < s_end) {
             const SampleId id = decode_sample(P, sx);
             if constexpr (FUSED) if (P.host_T) (void)stage_wait(P, id.b * P.N + id.i);      // (a miss is reported by wave 0)
-            const PieceIn pin = piece_in(P, id.b, id.i);
+            const PieceIn pin = piece_in(P, id.b, id.i, cb_tab);
             const double step = pin.T * P.inv_K;
             Basis B;
             poly_basis(id.j * step, B);
@@ -1366,7 +1380,7 @@ __global__ __launch_bounds__(256) void stats_kernel(const SweepParams P) {
 // EARLY: the collision sums are already there (separate launch after the sweep): request them before the forward pass.
 // XF: multi-GPU step with the exchange inside the launch (XFuse): tail workgroup t takes this rank's pieces first (they have
 // work to overlap with the sweep), then the other ranks' pieces, whose rows it fetches from this rank's board.
-template <bool EARLY, bool XF> __device__ __forceinline__ void tail_piece(const SweepParams &P, const int t, double (*s_val)[PARTIAL_STRIDE + 1]) {
+template <bool EARLY, bool XF> __device__ __forceinline__ void tail_piece(const SweepParams &P, const int t, double (*s_val)[PARTIAL_STRIDE + 1], const double *s_piece) {
     const int K1 = P.K + 1;
     const int tid = threadIdx.x;                     // threads >= TL_THREADS (fused launch: 256 per workgroup) only keep the barriers
     const int n_own = P.piece_end - P.piece_begin;
@@ -1406,7 +1420,7 @@ template <bool EARLY, bool XF> __device__ __forceinline__ void tail_piece(const 
             lost = lost || !s_staged;
         }
     }
-    const PieceIn pin = piece_in(P, b, i);
+    const PieceIn pin = piece_in(P, b, i, s_piece, true);
     const double *c = pin.c;
     const int ld = pin.ld;
     const double integral_frac = P.inv_K;
