@@ -153,9 +153,9 @@ extern "C" int isdf_optimize_lbfgs_batch(isdf_ctx *c, int n_traj, int N, const d
     } slots[N_SLOTS];
     const size_t in_all = (size_t)n_traj * b.in_per, out_all = (size_t)n_traj * b.ostride;
     // device MINCO: further device regions behind [T | coeffs | sweep out] - x + ends of the round (compacted), junction states,
-    // energy block, multipliers, results; the pinned buffer then holds [x + ends of the round | ... | results | overflow word]
-    const size_t xe_all = (size_t)n_traj * (b.n + 18), u_all = (size_t)n_traj * 6 * (N + 1), f_all = (size_t)n_traj * N * isdf::CB_FAC_STRIDE, res_all = (size_t)n_traj * b.rs;
-    const size_t off_xe = in_all + out_all, off_u = off_xe + xe_all, off_e = off_u + u_all, off_f = off_e + out_all, off_res = off_f + f_all;
+    // energy block, results; the pinned buffer then holds [x + ends of the round | ... | results | overflow word]
+    const size_t xe_all = (size_t)n_traj * (b.n + 18), u_all = (size_t)n_traj * 6 * (N + 1), res_all = (size_t)n_traj * b.rs;
+    const size_t off_xe = in_all + out_all, off_u = off_xe + xe_all, off_e = off_u + u_all, off_res = off_e + out_all;
     const size_t dev_all = b.dev ? off_res + res_all : in_all + out_all;
     const size_t pin_res = b.dev ? std::max(xe_all, in_all + out_all) : 0;        // results of a device round in the pinned buffer
     const size_t word_at = b.dev ? pin_res + res_all : in_all + out_all;
@@ -215,7 +215,7 @@ extern "C" int isdf_optimize_lbfgs_batch(isdf_ctx *c, int n_traj, int N, const d
             P.N = N; P.nb = na; P.n_out = 1; P.res_stride = (int)b.rs;
             P.x = q.d_buf + off_xe; P.ends = q.d_buf + off_xe + (size_t)na * b.n;
             P.T = q.d_buf; P.coeffs = q.d_buf + (size_t)na * N; P.sweep = q.d_buf + in_all;
-            P.u = q.d_buf + off_u; P.epart = q.d_buf + off_e; P.fac = q.d_buf + off_f;
+            P.u = q.d_buf + off_u; P.epart = q.d_buf + off_e;
             P.rho = b.rho; P.res = q.d_buf + off_res; P.flag = nullptr; P.seq = 0; P.stats = nullptr;
             if (rc == ISDF_OK && hipMemcpyAsync(q.d_buf + off_xe, q.h_pin, (size_t)na * (b.n + 18) * sizeof(double), hipMemcpyHostToDevice, q.stream) != hipSuccess) rc = ISDF_ERR_HIP;
             if (rc == ISDF_OK) isdf::launch_cb_pre(P, q.stream);

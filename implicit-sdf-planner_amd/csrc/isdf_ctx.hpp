@@ -97,7 +97,7 @@ struct isdf_ctx {
     // of the sweeps - a callback moves n doubles down and n + 1 up.  minco_mode 0: on the device whenever N <= CB_MAX_N
     // (ISDF_HOST_MINCO=1 / isdf_set_minco_mode(ctx, 1): the host's band LU, bitwise the reference's elimination order)
     int minco_mode = 0; int last_minco_path = 0;          // last_minco_path: 1 = the last callback ran MINCO on the device
-    double *d_cbdev = nullptr; size_t cbdev_cap = 0;      // [x | ends(18) | u | energy block | multipliers]
+    double *d_cbdev = nullptr; size_t cbdev_cap = 0;      // [x | ends(18) | u | energy block]
     double *h_cbres = nullptr, *h_cbres_dev = nullptr; size_t cbres_cap = 0;   // pinned, device-mapped: [x staging | cost, g, parts | flag]
     unsigned long long cb_seq = 0; bool cb_dev = false, cb_post_queued = false; bool cb_ends_dirty = true;
     double cb_ends[18] = {0};

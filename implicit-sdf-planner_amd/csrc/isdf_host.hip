@@ -1578,9 +1578,9 @@ extern "C" int isdf_unpack_variables(isdf_ctx *c, const double *x, double *T, do
 static size_t cb_res_stride(int N) { return (size_t)1 + (size_t)(N + 3 * (N - 1)) + 4; }
 static int cb_dev_fill(isdf_ctx *c, int N, CbDev *P, hipStream_t st) {
     const size_t nvar = (size_t)N + 3 * (size_t)(N - 1), ostride = isdf_out_stride(N), in_len = (size_t)19 * N;
-    // device: [x | ends | u | energy block | multipliers]
-    const size_t off_ends = nvar, off_u = off_ends + 18, off_e = off_u + (size_t)6 * (N + 1), off_f = off_e + ostride;
-    const size_t need = off_f + (size_t)N * CB_FAC_STRIDE;
+    // device: [x | ends | u | energy block]
+    const size_t off_ends = nvar, off_u = off_ends + 18, off_e = off_u + (size_t)6 * (N + 1);
+    const size_t need = off_e + ostride;
     if (c->cbdev_cap < need) { c->cb_ends_dirty = true; }
     int rc = ensure(c, &c->d_cbdev, &c->cbdev_cap, need);
     if (rc) return rc;
@@ -1601,7 +1601,7 @@ static int cb_dev_fill(isdf_ctx *c, int N, CbDev *P, hipStream_t st) {
         c->cb_ends_dirty = false;
     }
     P->N = N; P->nb = 1; P->n_out = c->cb_n_out; P->res_stride = (int)rs;
-    P->x = c->d_cbdev; P->ends = c->d_cbdev + off_ends; P->u = c->d_cbdev + off_u; P->epart = c->d_cbdev + off_e; P->fac = c->d_cbdev + off_f;
+    P->x = c->d_cbdev; P->ends = c->d_cbdev + off_ends; P->u = c->d_cbdev + off_u; P->epart = c->d_cbdev + off_e;
     P->T = c->d_cb; P->coeffs = c->d_cb + N; P->sweep = c->d_cb + in_len;
     P->rho = c->rho;
     P->res = c->h_cbres_dev + nvar; P->flag = (unsigned long long *)(c->h_cbres_dev + nvar + rs);

@@ -5,11 +5,9 @@
 
 namespace isdf {
 
-constexpr int CB_MAX_N = 400;             // pieces per trajectory the device callback takes (LDS: 19 N doubles); beyond it MINCO runs on the host
+constexpr int CB_MAX_N = 400;             // pieces per trajectory the device callback takes (LDS: 19 N doubles, + 4 N for the staged inputs up to 320 pieces); beyond it MINCO runs on the host
 constexpr int CB_SPLIT_MAX_N = 320;       // up to here the three axes of a row sit in three wavefront groups (3 x 320 threads)
-constexpr int CB_MAX_ROUNDS = 9;          // ceil(log2(CB_MAX_N - 1))
 constexpr int CB_FUSED_MAX_N = 64;         // the in-launch form runs the bodies with 3 x 64 of the fused kernel's 256 threads
-constexpr int CB_FAC_STRIDE = 8 * CB_MAX_ROUNDS + 4;   // per row: the two multiplier blocks of every round, then inv(D) of the last
 
 struct CbDev {
     int N, nb, n_out;           // pieces per trajectory, trajectories of the launch, packed sweep blocks to add per trajectory
@@ -19,7 +17,6 @@ struct CbDev {
     double *T;                  // [nb * N]          } the sweeps' inputs
     double *coeffs;             // [nb][6N x 3 col-major]
     double *u;                  // [nb][N + 1][3][2] junction states (v, a)
-    double *fac;                // [nb][N][CB_FAC_STRIDE]
     double *epart;              // [nb][1 + 19 N] energy | its partial by T | by the coefficients (the sweeps' packed layout)
     const double *sweep;        // [n_out][nb][1 + 19 N] what the sweeps accumulated
     double rho;

@@ -16,9 +16,8 @@
 // repeats the small matrix part; trajectories of more than 320 pieces keep all three axes in one thread: the workgroup size).
 // The linear algebra is csrc/minco_pcr.hpp: the trajectory in its junction states (a symmetric positive definite
 // block-tridiagonal system) solved by parallel cyclic reduction - ceil(log2(N - 1)) rounds, against the 6N dependent pivots of
-// the reference's band LU (which one wavefront walks in 140 us at N = 40: rounds 2-4, removed).  The matrix depends on the
-// durations only: the way forward stores every round's two multiplier blocks per row, and the adjoint solve (same matrix: it is
-// symmetric) replays them on its right-hand sides.
+// the reference's band LU (which one wavefront walks in 140 us at N = 40: rounds 2-4, removed).  The adjoint system of
+// propogateGrad is the same matrix (it is symmetric) with another right-hand side.
 //
 // A callback whose sweep is ONE fused launch (C2) runs both bodies INSIDE that launch (tile_sweep.hip, SweepParams::cb_on): EVERY
 // workgroup of the launch first runs cb_pre_body into an LDS table of (T, coefficients) - the solve repeated 690 times side by
@@ -62,8 +61,66 @@ __device__ __forceinline__ double block_sum(double v, double *s_part) {
 
 constexpr int SH_ROW = 18;      // LDS record of a row during a round: inv(D) (4), L (4), U (4), r (3 x 2)
 
+// LDS of one body (doubles): [x | ends staged: 4 N + 15, SPLIT only][1 / T: N][rows: 18 N] (+ padding)
+__host__ __device__ constexpr size_t cb_lds_doubles(int N, bool split) { return (split ? (size_t)4 * N + 16 : 0) + (size_t)19 * N + 8; }
+
+// Parallel cyclic reduction of K x = r for this thread's axes: ceil(log2(n)) rounds in which row k eliminates its neighbours at
+// distance s = 1, 2, 4 ...; on return the row stands alone (x = D^-1 r).  s_row: [N][SH_ROW].  Ends on a barrier.
+template <int ND> __device__ __forceinline__ void pcr_rounds(const bool row, const bool lead, const int k, const int n, const int d0,
+                                                             M2 &L, M2 &D, M2 &U, double (&r)[ND][2], double *s_row) {
+    for (int s = 1; s < n; s <<= 1) {
+        if (row) {
+            double *w = s_row + (size_t)k * SH_ROW;
+            if (lead) {
+                const M2 i = mpcr::inv(D);
+                w[0] = i.a; w[1] = i.b; w[2] = i.c; w[3] = i.d;
+                w[4] = L.a; w[5] = L.b; w[6] = L.c; w[7] = L.d;
+                w[8] = U.a; w[9] = U.b; w[10] = U.c; w[11] = U.d;
+            }
+            _Pragma("unroll") for (int l = 0, d = d0; l < ND; l++, d++) { w[12 + 2 * d] = r[l][0]; w[13 + 2 * d] = r[l][1]; }
+        }
+        __syncthreads();
+        if (row) {
+            M2 Ln{0, 0, 0, 0}, Un{0, 0, 0, 0};
+            if (k - s >= 1) {
+                const double *w = s_row + (size_t)(k - s) * SH_ROW;
+                const M2 il{w[0], w[1], w[2], w[3]}, Ll{w[4], w[5], w[6], w[7]}, Ul{w[8], w[9], w[10], w[11]};
+                const M2 A = mpcr::mul(L, il);
+                const M2 t = mpcr::mul(A, Ul), ll = mpcr::mul(A, Ll);
+                D.a -= t.a; D.b -= t.b; D.c -= t.c; D.d -= t.d;
+                Ln = {-ll.a, -ll.b, -ll.c, -ll.d};
+                _Pragma("unroll") for (int l = 0, d = d0; l < ND; l++, d++) { double y[2]; mv(A, w + 12 + 2 * d, y); r[l][0] -= y[0]; r[l][1] -= y[1]; }
+            }
+            if (k + s <= n) {
+                const double *w = s_row + (size_t)(k + s) * SH_ROW;
+                const M2 ih{w[0], w[1], w[2], w[3]}, Lh{w[4], w[5], w[6], w[7]}, Uh{w[8], w[9], w[10], w[11]};
+                const M2 B = mpcr::mul(U, ih);
+                const M2 t = mpcr::mul(B, Lh), u = mpcr::mul(B, Uh);
+                D.a -= t.a; D.b -= t.b; D.c -= t.c; D.d -= t.d;
+                Un = {-u.a, -u.b, -u.c, -u.d};
+                _Pragma("unroll") for (int l = 0, d = d0; l < ND; l++, d++) { double y[2]; mv(B, w + 12 + 2 * d, y); r[l][0] -= y[0]; r[l][1] -= y[1]; }
+            }
+            L = Ln; U = Un;
+        }
+        __syncthreads();
+    }
+}
+
+// the launch's inputs into LDS in ONE round of loads (SPLIT: trajectories of up to 320 pieces); returns where x / ends now live
+template <bool SPLIT> __device__ __forceinline__ void cb_stage_inputs(const CbDev &P, const int b, double *&s_mem, const double *&x, const double *&ends) {
+    const int nvar = P.N + 3 * (P.N - 1);
+    x = P.x + (size_t)b * nvar;
+    ends = P.ends + (size_t)b * 18;
+    if constexpr (SPLIT) {
+        for (int i = threadIdx.x; i < nvar + 18; i += blockDim.x) s_mem[i] = i < nvar ? x[i] : ends[i - nvar];
+        x = s_mem; ends = s_mem + nvar;
+        s_mem += (size_t)4 * P.N + 16;
+        __syncthreads();
+    }
+}
+
 // SPLIT: three wavefront groups, one per axis (threads [0, 3 NT), NT >= pieces, a multiple of 64); the workgroup's further threads
-// only keep the barriers.  b: trajectory of the launch; s_mem: 19 N + 6 doubles of LDS, s_part: 16.
+// only keep the barriers.  b: trajectory of the launch; s_mem: cb_lds_doubles(N, SPLIT) doubles of LDS, s_part: 16.
 // s_tab (LDS, nullable): [piece][19] = T, c(6 x 3) - the table the fused launch's workgroups take their inputs from.
 // glob: write the global outputs (false for the workgroups of a fused launch that only need the table: every workgroup of the
 // launch repeats the solve rather than wait for one of them - 2 600 wavefronts polling a flag cost more than the solve).
@@ -74,11 +131,10 @@ template <bool SPLIT> __device__ __forceinline__ void cb_pre_body(const CbDev &P
     constexpr int ND = SPLIT ? 1 : 3;           // axes of this thread: d0 .. d0 + ND - 1 (local arrays are indexed by l = d - d0)
     const int d0 = SPLIT ? ax : 0;
     const bool lead = ax == 0;                  // the thread of a row that writes what the axes share
-    const int nvar = N + 3 * n;
+    const double *x, *ends;
+    cb_stage_inputs<SPLIT>(P, b, s_mem, x, ends);
     double *s_h = s_mem;                        // [N]
     double *s_row = s_mem + N;                  // [N][SH_ROW] rows 1..N-1; later the junction states [(N + 1)][6] and the pieces' dE/dT shares [N][3]
-    const double *x = P.x + (size_t)b * nvar;
-    const double *ends = P.ends + (size_t)b * 18;
     const size_t ostride = (size_t)1 + 19 * (size_t)N;
 
     double T = 1.0, h = 1.0;
@@ -105,56 +161,13 @@ template <bool SPLIT> __device__ __forceinline__ void cb_pre_body(const CbDev &P
         if (k == 1) L = {0, 0, 0, 0};
         if (k == n) U = {0, 0, 0, 0};
     }
-    // ---- parallel cyclic reduction: round `rd` eliminates the neighbours at distance s
-    double *fac = P.fac + ((size_t)b * N + k) * CB_FAC_STRIDE;
-    int rd = 0;
-    for (int s = 1; s < n; s <<= 1, rd++) {
-        if (row) {
-            double *w = s_row + (size_t)k * SH_ROW;
-            if (lead) {
-                const M2 i = mpcr::inv(D);
-                w[0] = i.a; w[1] = i.b; w[2] = i.c; w[3] = i.d;
-                w[4] = L.a; w[5] = L.b; w[6] = L.c; w[7] = L.d;
-                w[8] = U.a; w[9] = U.b; w[10] = U.c; w[11] = U.d;
-            }
-            _Pragma("unroll") for (int l = 0, d = d0; l < ND; l++, d++) { w[12 + 2 * d] = r[l][0]; w[13 + 2 * d] = r[l][1]; }
-        }
-        __syncthreads();
-        if (row) {
-            M2 A{0, 0, 0, 0}, B{0, 0, 0, 0}, Ln{0, 0, 0, 0}, Un{0, 0, 0, 0};
-            if (k - s >= 1) {
-                const double *w = s_row + (size_t)(k - s) * SH_ROW;
-                const M2 il{w[0], w[1], w[2], w[3]}, Ll{w[4], w[5], w[6], w[7]}, Ul{w[8], w[9], w[10], w[11]};
-                A = mpcr::mul(L, il);
-                const M2 t = mpcr::mul(A, Ul), ll = mpcr::mul(A, Ll);
-                D.a -= t.a; D.b -= t.b; D.c -= t.c; D.d -= t.d;
-                Ln = {-ll.a, -ll.b, -ll.c, -ll.d};
-                _Pragma("unroll") for (int l = 0, d = d0; l < ND; l++, d++) { double y[2]; mv(A, w + 12 + 2 * d, y); r[l][0] -= y[0]; r[l][1] -= y[1]; }
-            }
-            if (k + s <= n) {
-                const double *w = s_row + (size_t)(k + s) * SH_ROW;
-                const M2 ih{w[0], w[1], w[2], w[3]}, Lh{w[4], w[5], w[6], w[7]}, Uh{w[8], w[9], w[10], w[11]};
-                B = mpcr::mul(U, ih);
-                const M2 t = mpcr::mul(B, Lh), u = mpcr::mul(B, Uh);
-                D.a -= t.a; D.b -= t.b; D.c -= t.c; D.d -= t.d;
-                Un = {-u.a, -u.b, -u.c, -u.d};
-                _Pragma("unroll") for (int l = 0, d = d0; l < ND; l++, d++) { double y[2]; mv(B, w + 12 + 2 * d, y); r[l][0] -= y[0]; r[l][1] -= y[1]; }
-            }
-            L = Ln; U = Un;
-            if (lead && glob) {
-                double *f = fac + 8 * rd;
-                f[0] = A.a; f[1] = A.b; f[2] = A.c; f[3] = A.d; f[4] = B.a; f[5] = B.b; f[6] = B.c; f[7] = B.d;
-            }
-        }
-        __syncthreads();
-    }
+    pcr_rounds<ND>(row, lead, k, n, d0, L, D, U, r, s_row);
     // ---- the rows stand alone: u = D^-1 r; junction states of every waypoint into LDS and global memory
     double *s_u = s_row;                        // [(N + 1)][6]: (v, a) per axis
     double *s_gt = s_row + (size_t)6 * (N + 1); // [N][3]
     double uk[ND][2] = {};
     if (row) {
         const M2 i = mpcr::inv(D);
-        if (lead && glob) { double *f = fac + 8 * CB_MAX_ROUNDS; f[0] = i.a; f[1] = i.b; f[2] = i.c; f[3] = i.d; }
         _Pragma("unroll") for (int l = 0, d = d0; l < ND; l++, d++) mv(i, r[l], uk[l]);
     } else if (k == 0) {
         _Pragma("unroll") for (int l = 0, d = d0; l < ND; l++, d++) { uk[l][0] = ends[3 + d]; uk[l][1] = ends[6 + d]; }
@@ -192,7 +205,10 @@ template <bool SPLIT> __device__ __forceinline__ void cb_pre_body(const CbDev &P
     }
 }
 
-// s_mem: 15 N + 12 doubles of LDS.  n_traj: trajectories of the launch (the sweeps' blocks are [sweep][trajectory]).
+// The way back.  The junction matrix depends on the durations only and is symmetric: the adjoint system is the forward system
+// with another right-hand side - its elimination is simply run again (a round is ~70 instructions; replaying multipliers stored by
+// the forward pass was measured slower: one dependent L2 round trip per round).
+// s_mem: cb_lds_doubles(N, SPLIT) doubles of LDS.  n_traj: trajectories of the launch (the sweeps' blocks are [sweep][trajectory]).
 template <bool SPLIT> __device__ __forceinline__ void cb_post_body(const CbDev &P, const int b, const int n_traj, const int NT, double *s_mem, double *s_part) {
     const int N = P.N, n = N - 1;
     const int ax = (int)threadIdx.x / NT;
@@ -201,65 +217,63 @@ template <bool SPLIT> __device__ __forceinline__ void cb_post_body(const CbDev &
     const int d0 = SPLIT ? ax : 0;
     const bool lead = ax == 0;
     const int nvar = N + 3 * n;
-    double *s_a = s_mem;                         // [9 N]: the pieces' end-half adjoints, then the rounds' right-hand sides, then mu [(N + 1)][6]
-    double *s_w = s_mem + (size_t)9 * N + 6;     // [3 N]
-    double *s_gt = s_w + (size_t)3 * N;          // [3 N]
-    const double *x = P.x + (size_t)b * nvar;
-    const double *ends = P.ends + (size_t)b * 18;
     const size_t ostride = (size_t)1 + 19 * (size_t)N;
     const bool piece = k < N, row = k >= 1 && k <= n;
-
-    // what does not depend on the sweeps: on its way while they still run
-    const double *fac = P.fac + ((size_t)b * N + k) * CB_FAC_STRIDE;
-    double fa[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    if (row && n > 1) for (int q = 0; q < 8; q++) fa[q] = fac[q];
-    double T = 0.0, h = 1.0, G[ND][6], gTp = 0.0;
-    // ---- dCost/dc of piece k: energy partials + the sweeps' sums, in the reference's order (energy, swept volume, integral)
-    double ge[ND][6];
+    // ---- everything this thread needs from global memory, requested in one go: dCost/dc of piece k = energy partials + the
+    // sweeps' sums, in the reference's order (energy, swept volume, integral); the junction states of its two ends
+    double G[ND][6], gTp = 0.0, uu[ND][4] = {};
     if (piece) {
-        T = P.T[(size_t)b * N + k];
-        h = mpcr::rcp(T);
         const double *E = P.epart + (size_t)b * ostride;
+        const double *u = P.u + (size_t)b * (N + 1) * 6 + 6 * k;
         if (lead) gTp = E[1 + k];
-        _Pragma("unroll") for (int l = 0, d = d0; l < ND; l++, d++) for (int q = 0; q < 6; q++) G[l][q] = E[1 + N + (size_t)d * 6 * N + 6 * k + q];
+        _Pragma("unroll") for (int l = 0, d = d0; l < ND; l++, d++) {
+            for (int q = 0; q < 6; q++) G[l][q] = E[1 + N + (size_t)d * 6 * N + 6 * k + q];
+            uu[l][0] = u[2 * d]; uu[l][1] = u[2 * d + 1]; uu[l][2] = u[6 + 2 * d]; uu[l][3] = u[6 + 2 * d + 1];
+        }
         for (int o = 0; o < P.n_out; o++) {
             const double *S = P.sweep + ((size_t)o * n_traj + b) * ostride;
             if (lead) gTp += S[1 + k];
             _Pragma("unroll") for (int l = 0, d = d0; l < ND; l++, d++) for (int q = 0; q < 6; q++) G[l][q] += S[1 + N + (size_t)d * 6 * N + 6 * k + q];
         }
-        _Pragma("unroll") for (int l = 0, d = d0; l < ND; l++, d++) {
-            mpcr::piece_adjoint(h, G[l], ge[l]);
-            s_a[9 * k + 3 * d] = ge[l][3]; s_a[9 * k + 3 * d + 1] = ge[l][4]; s_a[9 * k + 3 * d + 2] = ge[l][5];
-        }
+    }
+    const double *x, *ends;
+    cb_stage_inputs<SPLIT>(P, b, s_mem, x, ends);
+    double *s_h = s_mem;                         // [N]
+    double *s_row = s_mem + N;                   // [N][SH_ROW]; before the rounds the pieces' end-half adjoints [N][9]; after them mu [(N + 1)][6], w [N][3], dT shares [N][3]
+    double *s_a = s_row;
+
+    double T = 0.0, h = 1.0;
+    if (piece) {
+        mpcr::tau_to_T_h(x[k], T, h);            // the same bits as on the way forward
+        if (lead) s_h[k] = h;
+    }
+    double ge[ND][6];
+    if (piece) _Pragma("unroll") for (int l = 0, d = d0; l < ND; l++, d++) {
+        mpcr::piece_adjoint(h, G[l], ge[l]);
+        s_a[9 * k + 3 * d] = ge[l][3]; s_a[9 * k + 3 * d + 1] = ge[l][4]; s_a[9 * k + 3 * d + 2] = ge[l][5];
     }
     __syncthreads();
+    M2 L{0, 0, 0, 0}, D{1, 0, 0, 1}, U{0, 0, 0, 0};
     double r[ND][2] = {}, baseP[ND] = {};
-    if (row) _Pragma("unroll") for (int l = 0, d = d0; l < ND; l++, d++) {
-        const double *lf = s_a + 9 * (k - 1) + 3 * d;       // end half of the piece on the left
-        baseP[l] = lf[0] + ge[l][0];
-        r[l][0] = lf[1] + ge[l][1];
-        r[l][1] = lf[2] + ge[l][2];
+    if (row) {
+        mpcr::junction_blocks(s_h[k - 1], h, L, D, U);
+        if (k == 1) L = {0, 0, 0, 0};
+        if (k == n) U = {0, 0, 0, 0};
+        _Pragma("unroll") for (int l = 0, d = d0; l < ND; l++, d++) {
+            const double *lf = s_a + 9 * (k - 1) + 3 * d;       // end half of the piece on the left
+            baseP[l] = lf[0] + ge[l][0];
+            r[l][0] = lf[1] + ge[l][1];
+            r[l][1] = lf[2] + ge[l][2];
+        }
     }
     __syncthreads();
-    // ---- mu = K^-1 g_u: the forward elimination's rounds replayed on this right-hand side
-    int rd = 0;
-    for (int s = 1; s < n; s <<= 1, rd++) {
-        if (row) _Pragma("unroll") for (int l = 0, d = d0; l < ND; l++, d++) { s_a[6 * k + 2 * d] = r[l][0]; s_a[6 * k + 2 * d + 1] = r[l][1]; }
-        double fn[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-        if (row && (s << 1) < n) for (int q = 0; q < 8; q++) fn[q] = fac[8 * (rd + 1) + q];
-        __syncthreads();
-        if (row) {
-            const M2 A{fa[0], fa[1], fa[2], fa[3]}, B{fa[4], fa[5], fa[6], fa[7]};
-            if (k - s >= 1) _Pragma("unroll") for (int l = 0, d = d0; l < ND; l++, d++) { double y[2]; mv(A, s_a + 6 * (k - s) + 2 * d, y); r[l][0] -= y[0]; r[l][1] -= y[1]; }
-            if (k + s <= n) _Pragma("unroll") for (int l = 0, d = d0; l < ND; l++, d++) { double y[2]; mv(B, s_a + 6 * (k + s) + 2 * d, y); r[l][0] -= y[0]; r[l][1] -= y[1]; }
-        }
-        for (int q = 0; q < 8; q++) fa[q] = fn[q];
-        __syncthreads();
-    }
-    double *s_mu = s_a;                          // [(N + 1)][6], zero at the trajectory's ends
+    // ---- mu = K^-1 g_u
+    pcr_rounds<ND>(row, lead, k, n, d0, L, D, U, r, s_row);
+    double *s_mu = s_row;                        // [(N + 1)][6], zero at the trajectory's ends
+    double *s_w = s_row + (size_t)6 * (N + 1);   // [N][3]
+    double *s_gt = s_w + (size_t)3 * N;          // [N][3]
     if (row) {
-        const double *f = fac + 8 * CB_MAX_ROUNDS;
-        const M2 i{f[0], f[1], f[2], f[3]};
+        const M2 i = mpcr::inv(D);
         _Pragma("unroll") for (int l = 0, d = d0; l < ND; l++, d++) { double y[2]; mv(i, r[l], y); s_mu[6 * k + 2 * d] = y[0]; s_mu[6 * k + 2 * d + 1] = y[1]; }
     }
     if (k == 0) _Pragma("unroll") for (int l = 0, d = d0; l < ND; l++, d++) { s_mu[2 * d] = 0.0; s_mu[2 * d + 1] = 0.0; s_mu[6 * N + 2 * d] = 0.0; s_mu[6 * N + 2 * d + 1] = 0.0; }
@@ -267,11 +281,10 @@ template <bool SPLIT> __device__ __forceinline__ void cb_post_body(const CbDev &
     // ---- piece k: its share of dCost/dT and of the waypoint gradients
     double *res = P.res + (size_t)b * P.res_stride;
     if (piece) {
-        const double *u = P.u + (size_t)b * (N + 1) * 6 + 6 * k;
         _Pragma("unroll") for (int l = 0, d = d0; l < ND; l++, d++) {
             const double *ml = s_mu + 6 * k + 2 * d, *mr = s_mu + 6 * (k + 1) + 2 * d;
             const double dp = waypoint(N, x, ends, k + 1, d) - waypoint(N, x, ends, k, d);
-            s_gt[3 * k + d] = mpcr::piece_grad_T(h, G[l], dp, u[2 * d], u[2 * d + 1], u[6 + 2 * d], u[6 + 2 * d + 1], ml, mr);
+            s_gt[3 * k + d] = mpcr::piece_grad_T(h, G[l], dp, uu[l][0], uu[l][1], uu[l][2], uu[l][3], ml, mr);
             s_w[3 * k + d] = mpcr::piece_w(h, ml, mr);
         }
     }

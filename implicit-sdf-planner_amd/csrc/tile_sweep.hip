@@ -529,12 +529,14 @@ template <bool EARLY, bool XF> __device__ __forceinline__ void tail_piece(const 
 template <int KIND, bool IDENT, bool FUSED>
 __global__ __launch_bounds__(64 * SW_SAMPLES, FUSED ? 3 : sweep_waves_per_simd(KIND, IDENT)) void sweep_kernel(const SweepParams P) {
     const int n_blocks = FUSED ? P.n_sweep_blocks : (int)gridDim.x;       // sweep workgroups of this launch
-    __shared__ double s_tail[FUSED ? TL_THREADS : 1][PARTIAL_STRIDE + 1];
+    // (the tail's sums; in a launch that carries the objective callback also that body's scratch and its table of inputs)
+    constexpr int CB_TAB_AT = (int)cbd::cb_lds_doubles(CB_FUSED_MAX_N, true);
+    constexpr int S_TAIL_DOUBLES = FUSED ? (TL_THREADS * (PARTIAL_STRIDE + 1) > CB_TAB_AT + 19 * CB_FUSED_MAX_N ? TL_THREADS * (PARTIAL_STRIDE + 1) : CB_TAB_AT + 19 * CB_FUSED_MAX_N) : PARTIAL_STRIDE + 1;
+    __shared__ double s_tail_raw[S_TAIL_DOUBLES];
+    double (*const s_tail)[PARTIAL_STRIDE + 1] = reinterpret_cast<double (*)[PARTIAL_STRIDE + 1]>(s_tail_raw);
     // The objective callback inside this launch (csrc/minco_dev_body.hpp): EVERY workgroup turns x into (T, coefficients) - an LDS
     // table [piece][19] behind the body's scratch in s_tail - instead of waiting for one of them; workgroup 0 also writes what the
     // adjoint at the end of the launch needs.
-    constexpr int CB_TAB_AT = 19 * CB_FUSED_MAX_N + 8;
-    static_assert(!FUSED || CB_TAB_AT + 19 * CB_FUSED_MAX_N <= TL_THREADS * (PARTIAL_STRIDE + 1), "the callback's scratch and table live in s_tail");
     const double *cb_tab = nullptr;
     if constexpr (FUSED) {
         if (P.cb_on) {
