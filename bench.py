@@ -752,7 +752,7 @@ def main():
                     x0b.append(eng.pack_variables(Tb, c6b[1:, 0, :])); heads.append(hb); tails.append(tb)
                 eng.set_shard(0, 1)
                 ent_b = None
-                for mode_b, label_b in ((capi.MINCO_DEVICE, "device"), (capi.MINCO_HOST, "host")):
+                for mode_b, label_b in ((capi.MINCO_AUTO, "device"), (capi.MINCO_HOST, "host")):
                     eng.set_minco_mode(mode_b)
                     best = None
                     for _rep in range(2):             # (the first run of a mode also pays its buffers' first touch)
@@ -768,7 +768,7 @@ def main():
                         ent_b.update(rec)
                     else:
                         ent_b["host_minco"] = rec
-                eng.set_minco_mode(capi.MINCO_DEVICE)
+                eng.set_minco_mode(capi.MINCO_AUTO)
                 extra.append(ent_b)
             except Exception as e:      # noqa: BLE001
                 extra.append({"name": "C3 end to end", "error": str(e)})
@@ -780,6 +780,8 @@ def main():
         # ---- through the drop-in boundary (PCIe inclusive, synchronous, accumulate) - informational, never `value`
         host_ms = None
         cb_native_host_minco_ms = None
+        cb_native_device_minco_ms = None
+        cb_minco_auto = None
         host_ms_multi = None
         host_ms_multi8 = None
         host_queue_multi8 = None
@@ -800,13 +802,18 @@ def main():
                 pass
             elif nat is not None:
                 host_ms, cb_native_ms = nat
-                # the same callback with MINCO on the host (the reference's band LU; isdf_set_minco_mode(ctx, 1)) - the A/B of N1
+                # the same callback with MINCO forced onto the host (the reference's band LU) / onto the device (minco_dev.hip) - the
+                # A/B of N1; left to itself (above) the library takes the faster one for the configuration
+                cb_minco_auto = "device" if eng.minco_path() == 1 else "host"
                 try:
                     eng.set_minco_mode(capi.MINCO_HOST)
                     nat_h = native_boundary_ms(pkg, eng, N, T, cm, x0, eval_too=False)
                     cb_native_host_minco_ms = None if nat_h is None else nat_h[1]
-                finally:
                     eng.set_minco_mode(capi.MINCO_DEVICE)
+                    nat_d = native_boundary_ms(pkg, eng, N, T, cm, x0, eval_too=False)
+                    cb_native_device_minco_ms = None if nat_d is None else nat_d[1]
+                finally:
+                    eng.set_minco_mode(capi.MINCO_AUTO)
                 host_timer = "native: median of 1000 isdf_eval calls inside the compiled reference-side binding (tests/native/binding_stub.cpp)"
                 # the same call on a ctx over TWO 'devices' (this GPU listed twice: isdf_create_multi) - what the single-process
                 # multi-GPU path adds on top of the copy path (input broadcast, two shard launches, the rank-ordered sum kernel)
@@ -851,21 +858,23 @@ def main():
         if world == 1 and args.lbfgs_iters > 0:
             c_first = eng.cost_function(x0)[0]
             xo, r = eng.optimize_lbfgs(x0, max_iterations=args.lbfgs_iters, g_epsilon=0.0, past=0)
-            lbfgs = {"minco": "device (csrc/minco_dev.hip: x -> (cost, g) without leaving the device)" if eng.minco_path() == 1 else "host",
+            lbfgs = {"minco": "device (csrc/minco_dev.hip: x -> (cost, g) without leaving the device)" if eng.minco_path() == 1 else "host (the library's choice for a single trajectory of <= 64 pieces: the band LU's 10 us beat two more launches)",
                      "iterations": r["iterations"], "evaluations": r["evaluations"], "status": r["status"],
                      "ms_per_iteration": round(r["wall_ms"] / max(1, r["iterations"]), 4),
                      "ms_per_evaluation": round(r["wall_ms"] / max(1, r["evaluations"]), 4),
                      "callback_ms_native": None if cb_native_ms is None else round(cb_native_ms, 4),
                      "callback_ms_native_host_minco": None if cb_native_host_minco_ms is None else round(cb_native_host_minco_ms, 4),
+                     "callback_ms_native_device_minco": None if cb_native_device_minco_ms is None else round(cb_native_device_minco_ms, 4),
                      "cost_first": c_first, "cost_last": r["f"]}
-            try:        # the same driver with MINCO on the host (round 4's form)
-                eng.set_minco_mode(capi.MINCO_HOST)
+            try:        # the same driver with MINCO forced the other way
+                other = capi.MINCO_HOST if eng.minco_path() == 1 else capi.MINCO_DEVICE
+                eng.set_minco_mode(other)
                 _, rh = eng.optimize_lbfgs(x0, max_iterations=args.lbfgs_iters, g_epsilon=0.0, past=0)
-                lbfgs["host_minco"] = {"iterations": rh["iterations"], "evaluations": rh["evaluations"],
+                lbfgs["host_minco" if other == capi.MINCO_HOST else "device_minco"] = {"iterations": rh["iterations"], "evaluations": rh["evaluations"],
                                        "ms_per_iteration": round(rh["wall_ms"] / max(1, rh["iterations"]), 4),
                                        "ms_per_evaluation": round(rh["wall_ms"] / max(1, rh["evaluations"]), 4), "cost_last": rh["f"]}
             finally:
-                eng.set_minco_mode(capi.MINCO_DEVICE)
+                eng.set_minco_mode(capi.MINCO_AUTO)
 
         # measured HBM copy rate of this box next to the spec peak the roofline uses
         hbm_copy = None

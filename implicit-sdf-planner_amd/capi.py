@@ -106,8 +106,8 @@ EXPORTED_SYMBOLS = [
     "isdf_xchg_create", "isdf_xchg_connect", "isdf_xchg_allreduce", "isdf_xchg_fuse", "isdf_xchg_status", "isdf_xchg_destroy",
 ]
 
-HOST_PATH_COPY, HOST_PATH_DIRECT_MAPPED, HOST_PATH_DIRECT_BAR, HOST_PATH_DEVICE_CALLBACK, HOST_PATH_DEVICE_CALLBACK_FUSED = 0, 1, 2, 3, 4
-MINCO_DEVICE, MINCO_HOST = 0, 1
+HOST_PATH_COPY, HOST_PATH_DIRECT_MAPPED, HOST_PATH_DIRECT_BAR, HOST_PATH_DEVICE_CALLBACK = 0, 1, 2, 3
+MINCO_AUTO, MINCO_HOST, MINCO_DEVICE = 0, 1, 2
 MULTI_NONE, MULTI_PEER_SUM, MULTI_STAGED, MULTI_RCCL = 0, 1, 2, 3
 
 SDF_WITH_GRAD_FN = C.CFUNCTYPE(C.c_double, C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_double))   # isdf_sdf_with_grad_fn

@@ -125,9 +125,10 @@ extern "C" int isdf_optimize_lbfgs_batch(isdf_ctx *c, int n_traj, int N, const d
     b.workers.resize(n_traj);
     b.submitted.assign(n_traj, 0); b.finished.assign(n_traj, 0); b.ready.assign(n_traj, 0);
     b.cv_worker.reset(new std::condition_variable[n_traj]);
+    if (c->minco_mode != 1 && N <= isdf::CB_MAX_N) b.min_share = 0.5;       // device MINCO: trajectories come back sooner, fuller rounds pay (measured 80 ms against 88 at 0.25)
     if (const char *e = getenv("ISDF_BATCH_MIN_SHARE")) { const double v = atof(e); if (v > 0.0 && v <= 1.0) b.min_share = v; }
     b.in_per = (size_t)19 * N;
-    b.dev = c->minco_mode == 0 && N <= isdf::CB_MAX_N;
+    b.dev = c->minco_mode != 1 && N <= isdf::CB_MAX_N;
     b.rs = (size_t)1 + (size_t)b.n + 4;
     if (b.dev) {
         b.stage_x.assign((size_t)n_traj * b.n, 0.0); b.stage_res.assign((size_t)n_traj * b.rs, 0.0); b.ends.assign((size_t)n_traj * 18, 0.0);

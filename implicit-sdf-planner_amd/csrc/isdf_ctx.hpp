@@ -94,16 +94,14 @@ struct isdf_ctx {
     double last_parts[4] = {0, 0, 0, 0};
     std::vector<double> cb_x; double cb_energy = 0.0; int cb_n_out = 1; bool cb_pending = false;
     // device half of the callback (csrc/minco_dev.hip): MINCO, energy, adjoint and chain rule in two small kernels either side
-    // of the sweeps - a callback moves n doubles down and n + 1 up.  minco_mode 0: on the device whenever N <= CB_MAX_N
-    // (ISDF_HOST_MINCO=1 / isdf_set_minco_mode(ctx, 1): the host's band LU, bitwise the reference's elimination order)
+    // of the sweeps - a callback moves n doubles down and n + 5 up.  minco_mode 0: wherever it is faster (isdf_host.hip
+    // cb_device_minco), 1 (ISDF_HOST_MINCO=1): the host's band LU, bitwise the reference's elimination order, 2
+    // (ISDF_DEVICE_MINCO=1): on the device whenever N <= CB_MAX_N
     int minco_mode = 0; int last_minco_path = 0;          // last_minco_path: 1 = the last callback ran MINCO on the device
     double *d_cbdev = nullptr; size_t cbdev_cap = 0;      // [x | ends(18) | u | energy block]
     double *h_cbres = nullptr, *h_cbres_dev = nullptr; size_t cbres_cap = 0;   // pinned, device-mapped: [x staging | cost, g, parts | flag]
     unsigned long long cb_seq = 0; bool cb_dev = false, cb_post_queued = false; bool cb_ends_dirty = true;
     double cb_ends[18] = {0};
-    // the device callback INSIDE a fused sweep launch: d_cbflag = the device word that stands in for the host flag of a host-direct
-    // step (so that the launch's release / acquire chain runs).  ISDF_NO_CB_FUSE=1: always the three-kernel form
-    unsigned long long *d_cbflag = nullptr; bool env_no_cb_fuse = false;
     // front end (csrc/frontend.hip): attitude kernels of the robot, inflated bit-packed occupancy, breadth-first order tables
     struct FrontEnd {
         isdf_frontend_config cfg{}; int xk = 0, yk = 0; double margin = 0.0; bool built = false;

@@ -140,8 +140,7 @@ extern "C" int isdf_create(isdf_ctx **out, const isdf_config *cfg) {
         c->env_multi_no_hostout = on("ISDF_MULTI_NO_HOST_OUT");
         c->env_no_bar = on("ISDF_NO_BAR_WRITES");
         c->env_no_lpt = on("ISDF_NO_LPT");
-        c->minco_mode = on("ISDF_HOST_MINCO") ? 1 : 0;
-        c->env_no_cb_fuse = on("ISDF_NO_CB_FUSE");
+        c->minco_mode = on("ISDF_HOST_MINCO") ? 1 : (on("ISDF_DEVICE_MINCO") ? 2 : 0);
     }
     if (hipSetDevice(c->device) != hipSuccess || hipMalloc(&c->d_stats, 8 * sizeof(unsigned long long)) != hipSuccess ||
         hipMalloc(&c->d_traj_duration, sizeof(double)) != hipSuccess || hipMalloc(&c->d_n_coarse, sizeof(int)) != hipSuccess ||
@@ -179,7 +178,7 @@ extern "C" int isdf_destroy(isdf_ctx *c) {
     if (c->h_cbres) (void)hipHostFree(c->h_cbres);
     isdf_frontend_release(c);
     isdf_xchg_release(c);
-    void *ptrs[] = {c->d_cb, c->d_cbdev, c->d_cbflag, c->d_esdf, c->d_occ, c->d_points, c->d_tstar, c->d_acc, c->d_sample_info, c->d_bits, c->d_piece_cost, c->d_in, c->d_out, c->d_stats,
+    void *ptrs[] = {c->d_cb, c->d_cbdev, c->d_esdf, c->d_occ, c->d_points, c->d_tstar, c->d_acc, c->d_sample_info, c->d_bits, c->d_piece_cost, c->d_in, c->d_out, c->d_stats,
                     c->d_traj_duration, c->d_coarse_t, c->d_coarse_pose, c->d_n_coarse, c->d_point_partial, c->d_point_piece, c->d_point_stat, c->d_point_nr, c->d_task_buf,
                     c->d_task_map, c->d_v1_words, c->d_point_lmask, c->d_scan_ticks, c->d_scan_order, c->d_hist, c->d_shape_grid, c->d_pose, c->d_mq_entries, c->d_mq_items, c->d_mq_res, c->d_mq_sample_items, c->d_mq_sample_n, c->d_mq_count, c->d_msum_blocks, c->d_dbg, c->d_stage, c->d_stage_flags, c->d_sample_map, c->d_plan_cls, c->d_plan_map, c->d_plan_lr, c->d_plan_hist};
     for (void *p : ptrs) if (p) (void)hipFree(p);
@@ -584,9 +583,7 @@ int isdf_reset_result_slots(isdf_ctx *c) {
 // mode 0: the sweep cfg.variant names; 1: the swept-volume sweep; 2: the integral sweep with the collision term off
 // (modes 1 + 2 together are what costFunctionLmbm runs for the reference's live configuration)
 // host-direct step (see isdf_ctx.hpp): device-visible addresses of the pinned inputs / outputs / flags of this step
-// cb: the objective callback inside the fused launch (csrc/minco_dev_body.hpp) - every workgroup forms (T, coefficients) from x,
-// the collector runs the adjoint; `out` and `flags` are then device memory
-struct HostDirect { const double *T, *coeffs; double *out; unsigned long long *flags; unsigned long long seq; bool via_bar; const CbDev *cb = nullptr; };
+struct HostDirect { const double *T, *coeffs; double *out; unsigned long long *flags; unsigned long long seq; bool via_bar; };
 static int ensure_stage(isdf_ctx *c, size_t total_pieces) {
     const size_t n_groups = (total_pieces + STAGE_G - 1) / STAGE_G;
     { int rc1 = isdf_ensure_doubles(c, &c->d_stage, &c->stage_cap, total_pieces * 19); if (rc1) return rc1; }
@@ -793,8 +790,7 @@ static int eval_device_impl(isdf_ctx *c, int n_traj, int N, const double *d_T, c
         if (!fused || P.xf.world > 1 || P.dbg) return ISDF_DIRECT_NA;
         { int rc1 = ensure_stage(c, (size_t)total_pieces); if (rc1) return rc1; }
         P.out = hd->out; P.host_flag = hd->flags; P.seq = hd->seq;
-        if (hd->cb) { P.cb = *hd->cb; P.cb_on = 1; }          // (T, coefficients) are formed inside the launch, from x
-        else if (!hd->via_bar) { P.host_T = hd->T; P.host_coeffs = hd->coeffs; P.stage = c->d_stage; P.stage_flags = c->d_stage_flags; }
+        if (!hd->via_bar) { P.host_T = hd->T; P.host_coeffs = hd->coeffs; P.stage = c->d_stage; P.stage_flags = c->d_stage_flags; }
         c->last_P = P;
     }
     // dispatch order built on the device from the work of earlier steps (tile_sweep.hip, plan_wave): a resident (fused) launch
@@ -1608,7 +1604,17 @@ static int cb_dev_fill(isdf_ctx *c, int N, CbDev *P, hipStream_t st) {
     P->seq = c->cb_seq; P->stats = c->d_stats;
     return ISDF_OK;
 }
-static bool cb_device_minco(const isdf_ctx *c) { return c->minco_mode == 0 && c->have_traj && c->minco.N <= CB_MAX_N && !c->prof_on; }
+// Where a callback's MINCO half runs.  Forced either way by isdf_set_minco_mode; left to itself (mode 0) the device takes it unless
+// the step is the small single-trajectory kind whose sweep is one fused host-direct launch (C2: N <= 64, one GPU, tile sweep) -
+// there the host's band LU (10 us at N = 40, growing with N) still beats two more kernels either side of a 16 us launch
+// (measured: 35 us against 38; profiles/r5_callback_bench.txt), everywhere else the device form is the faster one
+// (N = 400: 135 us against 216; swept-volume ctx; the batched optimiser's rounds).
+static bool cb_device_minco(const isdf_ctx *c) {
+    if (!c->have_traj || c->minco.N > CB_MAX_N || c->prof_on || c->minco_mode == 1) return false;
+    if (c->minco_mode == 2) return true;
+    const bool small_fused = c->cfg.variant != ISDF_V1_SWEPT && direct_enabled(c) && c->peers.empty() && c->minco.N <= CB_AUTO_HOST_MAX_N;
+    return !small_fused;
+}
 
 static int cost_function_launch_dev(isdf_ctx *c, const double *x, int n, hipStream_t st, bool whole) {
     const int N = c->minco.N;
@@ -1616,12 +1622,6 @@ static int cost_function_launch_dev(isdf_ctx *c, const double *x, int n, hipStre
     c->cb_n_out = swept ? 2 : 1;
     c->cb_direct = false; c->cb_dev = true; c->cb_post_queued = false;
     c->cb_seq = ++c->dir_seq;          // (one counter with the host-direct steps: they share the staging buffer's ready flags)
-    // A callback whose sweep is one fused launch runs ENTIRELY inside that launch (tile_sweep.hip, SweepParams::cb_on): its first
-    // workgroup turns x into (T, coefficients) and publishes them through the staging buffer, its collector runs the adjoint
-    const bool in_launch = whole && !swept && direct_enabled(c) && !c->env_no_cb_fuse && c->peers.empty() && N <= CB_FUSED_MAX_N;
-    if (in_launch) {
-        if (!c->d_cbflag) { HIPCHK(c, hipMalloc(&c->d_cbflag, 2 * sizeof(unsigned long long))); HIPCHK(c, hipMemset(c->d_cbflag, 0, 2 * sizeof(unsigned long long))); }
-    }
     CbDev P{};
     int rc = cb_dev_fill(c, N, &P, st);
     if (rc) return rc;
@@ -1631,20 +1631,6 @@ static int cost_function_launch_dev(isdf_ctx *c, const double *x, int n, hipStre
     __sync_synchronize();
     const size_t ostride = isdf_out_stride(N);
     double *d_T = c->d_cb, *d_C = c->d_cb + N, *d_o = c->d_cb + (size_t)19 * N;
-    if (in_launch) {
-        HostDirect hd{};
-        hd.via_bar = true; hd.out = d_o; hd.flags = c->d_cbflag; hd.seq = c->cb_seq; hd.cb = &P;
-        rc = eval_device_impl(c, 1, N, d_T, d_C, d_o, nullptr, st, 0, false, &hd);
-        if (rc < 0) return rc;
-        if (rc == ISDF_OK) {
-            c->cb_post_queued = true;
-            c->last_host_path = ISDF_HOST_PATH_DEVICE_CALLBACK_FUSED;
-            c->last_minco_path = 1;
-            c->cb_pending = true;
-            return ISDF_OK;
-        }
-        // (ISDF_DIRECT_NA: not one fused launch - nothing was launched; the three-kernel form below)
-    }
     launch_cb_pre(P, st);
     if (swept) {
         rc = sweep_dispatch(c, 1, N, d_T, d_C, d_o, nullptr, st, 1);
@@ -1838,11 +1824,11 @@ extern "C" double isdf_cost_function_lmbm(void *instance, const double *x, doubl
     return rc == ISDF_OK ? cost : INFINITY;
 }
 
-// where MINCO runs: 0 = on the device whenever the trajectory fits (N <= 400), 1 = on the host (band LU, the reference's
-// elimination order bit for bit).  Results agree to rounding (1e-10 relative on the coefficients).
+// where MINCO runs: 0 = wherever it is faster (cb_device_minco), 1 = on the host (band LU, the reference's elimination order bit
+// for bit), 2 = on the device whenever the trajectory fits (N <= 400).  Results agree to rounding (1e-10 relative on the coefficients).
 extern "C" int isdf_set_minco_mode(isdf_ctx *c, int mode) {
     if (!c) return ISDF_ERR_INVALID_ARG;
-    if (mode != 0 && mode != 1) return fail(c, ISDF_ERR_INVALID_ARG, "minco mode must be 0 (device) or 1 (host)");
+    if (mode < 0 || mode > 2) return fail(c, ISDF_ERR_INVALID_ARG, "minco mode must be 0 (auto), 1 (host) or 2 (device)");
     if (c->cb_pending) return fail(c, ISDF_ERR_STATE, "a callback evaluation is in flight");
     c->minco_mode = mode;
     return ISDF_OK;

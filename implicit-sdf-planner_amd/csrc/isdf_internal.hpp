@@ -4,7 +4,6 @@
 #include <hip/hip_ext.h>
 #include <cstdint>
 #include "dev_shapes.hpp"
-#include "minco_dev.hpp"
 
 namespace isdf {
 
@@ -75,10 +74,6 @@ struct SweepParams {
     unsigned long long *stage_flags;
     unsigned long long seq;
     unsigned long long *host_flag;
-    // the objective callback INSIDE this fused launch (csrc/minco_dev_body.hpp): every workgroup first runs cb_pre_body (x -> T,
-    // coefficients, into an LDS table it then takes its inputs from), the trajectory's collector runs cb_post_body on the finished sums
-    int cb_on;
-    CbDev cb;
     // Dispatch order of a fused single-launch step (scheduling only; results cannot depend on it): rank in the launch
     // (workgroup b, wave w: b + w * n_sweep_blocks) -> local sample, -1 = none.  The tail workgroups of step k build the order
     // for step k + 1 from the work classes the sweep waves of step k - 1 left (plan_piece, tile_sweep.hip).

@@ -7,7 +7,7 @@ namespace isdf {
 
 constexpr int CB_MAX_N = 400;             // pieces per trajectory the device callback takes (LDS: 19 N doubles, + 4 N for the staged inputs up to 320 pieces); beyond it MINCO runs on the host
 constexpr int CB_SPLIT_MAX_N = 320;       // up to here the three axes of a row sit in three wavefront groups (3 x 320 threads)
-constexpr int CB_FUSED_MAX_N = 64;         // the in-launch form runs the bodies with 3 x 64 of the fused kernel's 256 threads
+constexpr int CB_AUTO_HOST_MAX_N = 64;    // minco mode 0: single-trajectory fused steps up to this many pieces keep MINCO on the host
 
 struct CbDev {
     int N, nb, n_out;           // pieces per trajectory, trajectories of the launch, packed sweep blocks to add per trajectory

@@ -1,5 +1,4 @@
-// Device half of the objective callback - the two kernel BODIES (included by minco_dev.hip, which wraps them in kernels of their
-// own, and by tile_sweep.hip, whose fused single-launch step runs them inside the launch).
+// Device half of the objective callback - the two kernel BODIES (minco_dev.hip wraps them in kernels).
 //
 // Device half of the objective callback: everything TrajOptimizer::costFunctionLmbm does around the two
 // sweeps (back_end_optimizer.hpp:358-430) - tau -> T, MINCO setParameters (minco.hpp:397-513), the jerk energy and its
@@ -19,13 +18,13 @@
 // the reference's band LU (which one wavefront walks in 140 us at N = 40: rounds 2-4, removed).  The adjoint system of
 // propogateGrad is the same matrix (it is symmetric) with another right-hand side.
 //
-// A callback whose sweep is ONE fused launch (C2) runs both bodies INSIDE that launch (tile_sweep.hip, SweepParams::cb_on): EVERY
-// workgroup of the launch first runs cb_pre_body into an LDS table of (T, coefficients) - the solve repeated 690 times side by
-// side costs the step one solve's latency and no communication - and only workgroup 0 writes the global outputs; the
-// trajectory's collector - the workgroup that has seen every piece's sums arrive - runs cb_post_body.  One launch per callback.
-// Measured and dropped on the way (profiles/r5_callback_*_dropped.txt): the three kernels on two streams chained by device
-// flags (queue switches cost more than the overlapped launch latencies: 44.7 us against 36.8 one after the other); workgroup 0
-// alone solving while the launch's other 2 700 wavefronts poll its ready flags (46.9 us: the polling starves the solve).
+// Tried for the callback whose sweep is ONE fused launch (C2, 16 us), measured, dropped (profiles/r5_callback_*_dropped.txt):
+// the three kernels on two streams chained by device flags (44.7 us per callback against 36.8 one after the other: queue
+// switches cost more than the overlapped launch latencies bring); the bodies INSIDE the fused launch, workgroup 0 solving while
+// the launch's other 2 700 wavefronts poll its ready flags (46.9 us: the polling starves the solve); the same with EVERY
+// workgroup repeating the solve into an LDS table (39.0 us: no polling, but three workgroups per CU share its SIMDs for the
+// solve, and the adjoint still sits behind the last sample).  The host's band LU costs 10 us at N = 40: that configuration keeps
+// it (isdf_host.hip cb_device_minco).
 #pragma once
 #include "isdf_internal.hpp"
 #include "dev_math.hpp"
@@ -121,9 +120,7 @@ template <bool SPLIT> __device__ __forceinline__ void cb_stage_inputs(const CbDe
 
 // SPLIT: three wavefront groups, one per axis (threads [0, 3 NT), NT >= pieces, a multiple of 64); the workgroup's further threads
 // only keep the barriers.  b: trajectory of the launch; s_mem: cb_lds_doubles(N, SPLIT) doubles of LDS, s_part: 16.
-// s_tab (LDS, nullable): [piece][19] = T, c(6 x 3) - the table the fused launch's workgroups take their inputs from.
-// glob: write the global outputs (false for the workgroups of a fused launch that only need the table: every workgroup of the
-// launch repeats the solve rather than wait for one of them - 2 600 wavefronts polling a flag cost more than the solve).
+// s_tab (LDS, nullable): additionally [piece][19] = T, c(6 x 3); glob = false: LDS outputs only.
 template <bool SPLIT> __device__ __forceinline__ void cb_pre_body(const CbDev &P, const int b, const int NT, double *s_mem, double *s_part, double *s_tab = nullptr, const bool glob = true) {
     const int N = P.N, n = N - 1;
     const int ax = (int)threadIdx.x / NT;

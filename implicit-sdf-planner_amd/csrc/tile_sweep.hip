@@ -32,7 +32,6 @@
 #define ISDF_SWEEP_STATS 0   // 1: per-wave statistics for tools/timing.py (developer builds)
 #endif
 #include "isdf_internal.hpp"
-#include "minco_dev_body.hpp"
 #include "dev_mesh.hpp"
 
 namespace isdf {
@@ -171,12 +170,9 @@ __device__ __forceinline__ bool xslot_take(double *slot, double &v) {        // 
 // ---- inputs of one piece: from the caller's device arrays, or - host-direct step - from the staging buffer the first
 // workgroups of the launch fill from host-mapped memory
 struct PieceIn { const double *c; int ld; double T; };
-// tab (callback inside the launch, one trajectory): this workgroup's LDS table [piece][19], or - tail workgroups - the piece's own
-// 19 doubles (tab_one)
-__device__ __forceinline__ PieceIn piece_in(const SweepParams &P, int b, int i, const double *tab = nullptr, bool tab_one = false) {
+__device__ __forceinline__ PieceIn piece_in(const SweepParams &P, int b, int i) {
     PieceIn r;
-    if (tab) { const double *s = tab_one ? tab : tab + (size_t)i * 19; r.c = s + 1; r.ld = 6; r.T = s[0]; }
-    else if (P.host_T) { const double *s = P.stage + ((size_t)b * P.N + i) * 19; r.c = s + 1; r.ld = 6; r.T = s[0]; }
+    if (P.host_T) { const double *s = P.stage + ((size_t)b * P.N + i) * 19; r.c = s + 1; r.ld = 6; r.T = s[0]; }
     else { r.c = P.coeffs + (size_t)b * 18 * P.N + 6 * i; r.ld = 6 * P.N; r.T = P.T[(size_t)b * P.N + i]; }
     return r;
 }
@@ -520,7 +516,7 @@ size_t sweep_pose_bytes() { return sizeof(SweepPose); }
 
 // IDENT: the shape's body offset is the identity (poly_params all zero - every shipped config): those instantiations drop
 // the offset and the 24 scalar registers it pins, which takes Box to 91 VGPRs and a fifth wave per SIMD.
-template <bool EARLY, bool XF> __device__ __forceinline__ void tail_piece(const SweepParams &P, const int t, double (*s_val)[PARTIAL_STRIDE + 1], const double *s_piece = nullptr);
+template <bool EARLY, bool XF> __device__ __forceinline__ void tail_piece(const SweepParams &P, const int t, double (*s_val)[PARTIAL_STRIDE + 1]);
 
 // FUSED: the launch carries, after its P.n_sweep_blocks sweep workgroups, one workgroup per piece that runs the tail
 // (tail_piece) - dispatched last, it does the collision-independent part of its samples while the sweep works and picks the
@@ -529,33 +525,12 @@ template <bool EARLY, bool XF> __device__ __forceinline__ void tail_piece(const 
 template <int KIND, bool IDENT, bool FUSED>
 __global__ __launch_bounds__(64 * SW_SAMPLES, FUSED ? 3 : sweep_waves_per_simd(KIND, IDENT)) void sweep_kernel(const SweepParams P) {
     const int n_blocks = FUSED ? P.n_sweep_blocks : (int)gridDim.x;       // sweep workgroups of this launch
-    // (the tail's sums; in a launch that carries the objective callback also that body's scratch and its table of inputs)
-    constexpr int CB_TAB_AT = (int)cbd::cb_lds_doubles(CB_FUSED_MAX_N, true);
-    constexpr int S_TAIL_DOUBLES = FUSED ? (TL_THREADS * (PARTIAL_STRIDE + 1) > CB_TAB_AT + 19 * CB_FUSED_MAX_N ? TL_THREADS * (PARTIAL_STRIDE + 1) : CB_TAB_AT + 19 * CB_FUSED_MAX_N) : PARTIAL_STRIDE + 1;
-    __shared__ double s_tail_raw[S_TAIL_DOUBLES];
-    double (*const s_tail)[PARTIAL_STRIDE + 1] = reinterpret_cast<double (*)[PARTIAL_STRIDE + 1]>(s_tail_raw);
-    // The objective callback inside this launch (csrc/minco_dev_body.hpp): EVERY workgroup turns x into (T, coefficients) - an LDS
-    // table [piece][19] behind the body's scratch in s_tail - instead of waiting for one of them; workgroup 0 also writes what the
-    // adjoint at the end of the launch needs.
-    const double *cb_tab = nullptr;
     if constexpr (FUSED) {
-        if (P.cb_on) {
-            __shared__ double s_cbpart[16];
-            double *tab = &s_tail[0][0] + CB_TAB_AT;
-            cbd::cb_pre_body<true>(P.cb, 0, 64, &s_tail[0][0], s_cbpart, tab, blockIdx.x == 0);
-            __syncthreads();
-            cb_tab = tab;
-        }
+        __shared__ double s_tail[TL_THREADS][PARTIAL_STRIDE + 1];
         if ((int)blockIdx.x >= n_blocks) {
-            const int t = (int)blockIdx.x - n_blocks;
-            __shared__ double s_piece[19];
-            if (cb_tab) {                         // the table shares s_tail with the tail's sums: this piece's 19 doubles move out
-                if (threadIdx.x < 19) s_piece[threadIdx.x] = cb_tab[(size_t)t * 19 + threadIdx.x];
-                __syncthreads();
-            }
-            if ((P.plan_cls_in || P.plan_lr_in) && !(P.dbg_flags & 2) && (threadIdx.x >> 6) == SW_SAMPLES - 1) plan_wave(P, t, threadIdx.x & 63);       // while the sweep works: the NEXT step's dispatch order
-            if (P.xf.world > 1) tail_piece<false, true>(P, t, s_tail);      // multi-GPU step: exchange inside
-            else tail_piece<false, false>(P, t, s_tail, cb_tab ? s_piece : nullptr);
+            if ((P.plan_cls_in || P.plan_lr_in) && !(P.dbg_flags & 2) && (threadIdx.x >> 6) == SW_SAMPLES - 1) plan_wave(P, (int)blockIdx.x - n_blocks, threadIdx.x & 63);       // while the sweep works: the NEXT step's dispatch order
+            if (P.xf.world > 1) tail_piece<false, true>(P, (int)blockIdx.x - n_blocks, s_tail);      // multi-GPU step: exchange inside
+            else tail_piece<false, false>(P, (int)blockIdx.x - n_blocks, s_tail);
             return;
         }
     }
@@ -606,7 +581,7 @@ __global__ __launch_bounds__(64 * SW_SAMPLES, FUSED ? 3 : sweep_waves_per_simd(K
         bool staged = true;
         if constexpr (FUSED) if (P.host_T) staged = stage_wait(P, id.b * P.N + id.i);
         if (!staged && P.stats) atomicMax(&P.stats[4], 1ull);
-        const PieceIn pin = piece_in(P, id.b, id.i, cb_tab);
+        const PieceIn pin = piece_in(P, id.b, id.i);
         const double *c = pin.c;
         const int ld = pin.ld;
         const double step = pin.T * P.inv_K;
@@ -655,7 +630,7 @@ __global__ __launch_bounds__(64 * SW_SAMPLES, FUSED ? 3 : sweep_waves_per_simd(K
         if (sx < s_end) {
             const SampleId id = decode_sample(P, sx);
             if constexpr (FUSED) if (P.host_T) (void)stage_wait(P, id.b * P.N + id.i);      // (a miss is reported by wave 0)
-            const PieceIn pin = piece_in(P, id.b, id.i, cb_tab);
+            const PieceIn pin = piece_in(P, id.b, id.i);
             const double step = pin.T * P.inv_K;
             Basis B;
             poly_basis(id.j * step, B);
@@ -1382,7 +1357,7 @@ __global__ __launch_bounds__(256) void stats_kernel(const SweepParams P) {
 // EARLY: the collision sums are already there (separate launch after the sweep): request them before the forward pass.
 // XF: multi-GPU step with the exchange inside the launch (XFuse): tail workgroup t takes this rank's pieces first (they have
 // work to overlap with the sweep), then the other ranks' pieces, whose rows it fetches from this rank's board.
-template <bool EARLY, bool XF> __device__ __forceinline__ void tail_piece(const SweepParams &P, const int t, double (*s_val)[PARTIAL_STRIDE + 1], const double *s_piece) {
+template <bool EARLY, bool XF> __device__ __forceinline__ void tail_piece(const SweepParams &P, const int t, double (*s_val)[PARTIAL_STRIDE + 1]) {
     const int K1 = P.K + 1;
     const int tid = threadIdx.x;                     // threads >= TL_THREADS (fused launch: 256 per workgroup) only keep the barriers
     const int n_own = P.piece_end - P.piece_begin;
@@ -1422,7 +1397,7 @@ template <bool EARLY, bool XF> __device__ __forceinline__ void tail_piece(const 
             lost = lost || !s_staged;
         }
     }
-    const PieceIn pin = piece_in(P, b, i, s_piece, true);
+    const PieceIn pin = piece_in(P, b, i);
     const double *c = pin.c;
     const int ld = pin.ld;
     const double integral_frac = P.inv_K;
@@ -1630,16 +1605,6 @@ template <bool EARLY, bool XF> __device__ __forceinline__ void tail_piece(const 
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
             const unsigned long long ovf = P.stats ? __hip_atomic_load(&P.stats[4], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ull;
             __hip_atomic_store(&P.host_flag[b], P.seq | (ovf ? HOST_FLAG_OVERFLOW : 0ull), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-        }
-    }
-    if constexpr (!XF && !EARLY) {
-        // the objective callback inside this launch: every row of [cost | gradT | gradC] is in place (the collector has taken
-        // every piece's cost, which its workgroup released after its rows) - energy partials + sums -> adjoint -> (cost, g)
-        // and the completion word into host-mapped memory (csrc/minco_dev_body.hpp)
-        if (P.cb_on && collector) {
-            __shared__ double s_cbpart2[16];
-            __syncthreads();
-            cbd::cb_post_body<true>(P.cb, 0, 1, 64, &s_val[0][0], s_cbpart2);
         }
     }
     if (dbg && tid == 0) dbg[1] = wall_clock64();

@@ -360,7 +360,7 @@ class Engine:
         return cost.value, g
 
     def set_minco_mode(self, mode):
-        """capi.MINCO_DEVICE (default): the callback's MINCO half on the device; capi.MINCO_HOST: the host's band LU."""
+        """capi.MINCO_AUTO (default): wherever it is faster; capi.MINCO_HOST: the host's band LU; capi.MINCO_DEVICE: the device kernels."""
         self._check(self.lib.isdf_set_minco_mode(self.h, int(mode)))
 
     def minco_path(self):

@@ -274,10 +274,6 @@ int isdf_eval(isdf_ctx *ctx, int n_traj, const int *N, const double *const *T,
 /*   DEVICE_CALLBACK  isdf_cost_function with its MINCO half on the device: x goes down (through the BAR, or fetched from
  *                  host-mapped memory), (cost, g) and a completion word come back into host-mapped memory; no copy commands */
 #define ISDF_HOST_PATH_DEVICE_CALLBACK 3
-/*   DEVICE_CALLBACK_FUSED  the same in ONE launch, when the sweep is one fused launch and N <= 64: its first workgroup runs
- *                  MINCO and hands (T, coefficients) to the rest through the staging buffer, its last runs the adjoint;
- *                  ISDF_NO_CB_FUSE=1 switches it off */
-#define ISDF_HOST_PATH_DEVICE_CALLBACK_FUSED 4
 int isdf_host_path(const isdf_ctx *ctx);
 
 /* Device-resident entry point, asynchronous on `stream` (a hipStream_t passed as void*; NULL = default
@@ -309,15 +305,17 @@ int isdf_eval_swept_at_tstar_host(isdf_ctx *ctx, int N, const double *T, const d
 
 /* ---- full objective callback ------------------------------------------------------------------------------ */
 /* TrajOptimizer::costFunctionLmbm (back_end_optimizer.hpp:358-430): x = [tau(N) | inner waypoints 3(N-1)] ->
- * cost, g.  The whole callback runs on the device: MINCO (minco.hpp:397-655: setParameters, energy and its partials,
- * propogateGrad) in LOG depth - the trajectory in its junction states, a symmetric positive definite block-tridiagonal system
- * solved by parallel cyclic reduction (csrc/minco_pcr.hpp, minco_dev.hip) - in two small kernels either side of the sweeps:
- * for ISDF_V1_SWEPT the swept-volume sweep followed by the integral sweep without a collision term (the reference's live
- * configuration), otherwise the integral sweep of cfg.variant.  cost = energy + sweeps + rho * sum(T).  Per call n doubles
- * go down and n + 5 come up.  isdf_set_minco_mode(ctx, 1) (or ISDF_HOST_MINCO=1 at isdf_create) keeps MINCO on the host
- * instead - the reference's banded LU, a chain of 6N dependent pivots, pivot for pivot; trajectories of more than 400 pieces
- * always take it.  The two agree to rounding (coefficients 1e-10 relative, tests/test_minco_pcr.py); isdf_minco_path tells
- * which one the last callback took (1 = device).
+ * cost, g.  MINCO (minco.hpp:397-655: setParameters, energy and its partials, propogateGrad) and the sweeps: for
+ * ISDF_V1_SWEPT the swept-volume sweep followed by the integral sweep without a collision term (the reference's live
+ * configuration), otherwise the integral sweep of cfg.variant.  cost = energy + sweeps + rho * sum(T).
+ * MINCO has two forms here.  On the DEVICE (csrc/minco_dev.hip, minco_pcr.hpp): the trajectory in its junction states - a
+ * symmetric positive definite block-tridiagonal system with 2 x 2 blocks - solved by parallel cyclic reduction in
+ * ceil(log2(N - 1)) rounds, as two small kernels either side of the sweeps; the callback then moves n doubles down and n + 5
+ * up and nothing else crosses PCIe.  On the HOST (csrc/minco_host.hpp): the reference's banded LU, a chain of 6N dependent
+ * pivots, pivot for pivot.  They agree to rounding (coefficients 1e-10 relative, tests/test_minco_pcr.py).
+ * isdf_set_minco_mode: 0 = whichever is faster for the configuration (default: the device, except single-trajectory tile-sweep
+ * steps of <= 64 pieces on one GPU, where the host's 10 us beat two more kernel launches), 1 = host, 2 = device (trajectories of
+ * more than 400 pieces always take the host).  isdf_minco_path tells which one the last callback took (1 = device).
  * isdf_set_trajectory == minco.setConditions + the `rho` of setParam (head/tail: 3x3 column-major, columns =
  * position, velocity, acceleration).  isdf_pack_variables == backwardT/backwardP (back_end_optimizer.cpp:22-28),
  * isdf_unpack_variables == forwardT/forwardP + setParameters (T: N, coeffs: 6N x 3 column-major; either may be NULL). */
@@ -326,7 +324,7 @@ int isdf_num_variables(const isdf_ctx *ctx);               /* N + 3(N-1), 0 befo
 int isdf_pack_variables(isdf_ctx *ctx, const double *T, const double *waypoints, double *x);
 int isdf_unpack_variables(isdf_ctx *ctx, const double *x, double *T, double *coeffs);
 int isdf_cost_function(isdf_ctx *ctx, const double *x, double *g, int n, double *cost_out);
-int isdf_set_minco_mode(isdf_ctx *ctx, int mode);          /* 0 = device (default), 1 = host band LU          */
+int isdf_set_minco_mode(isdf_ctx *ctx, int mode);          /* 0 = auto (default), 1 = host band LU, 2 = device */
 int isdf_minco_path(const isdf_ctx *ctx);                  /* of the last callback: 1 = device, 0 = host      */
 /* the same with the lmbm_evaluate_t signature (src/utils/include/utils/lmbm.h:206-209); instance = isdf_ctx*,
  * returns +inf on error */

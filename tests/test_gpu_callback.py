@@ -255,9 +255,12 @@ def test_device_minco_callback_equals_host_minco_callback(pkg, orc, product_lib,
     rho = 2.5
     eng.set_trajectory(N, head, tail, rho)
     x = eng.pack_variables(T0, way)
+    # left to itself the library keeps MINCO on the host for small single-trajectory tile-sweep steps (the faster form there)
+    eng.cost_function(x)
+    assert eng.minco_path() == (1 if variant == "V1" or N > 64 else 0)
+    eng.set_minco_mode(capi.MINCO_DEVICE)
     cost_d, g_d = eng.cost_function(x)
-    # (a V2 / V3 step of this size is one fused launch: up to 64 pieces the whole callback then runs inside that launch)
-    assert eng.minco_path() == 1 and eng.host_path() == (capi.HOST_PATH_DEVICE_CALLBACK if variant == "V1" or N > 64 else capi.HOST_PATH_DEVICE_CALLBACK_FUSED)
+    assert eng.minco_path() == 1 and eng.host_path() == capi.HOST_PATH_DEVICE_CALLBACK
     parts_d = eng.cost_parts()
     cost_d2, g_d2 = eng.cost_function(x)                       # deterministic: the same bits again
     assert cost_d2 == cost_d and np.array_equal(g_d2, g_d)
@@ -300,41 +303,6 @@ def test_device_minco_callback_largest_trajectory_and_fallback(pkg, orc, product
         assert abs(cost - cost_h) <= 1e-9 * abs(cost_h) and _rel_inf(g, g_h) <= 1e-9, (N, cost, cost_h, _rel_inf(g, g_h))
 
 
-def test_device_callback_in_launch_equals_three_kernels(pkg, orc, product_lib, monkeypatch):
-    """The two forms of the device callback - everything inside the fused sweep launch, or three kernels one after the other
-    (ISDF_NO_CB_FUSE=1, read at isdf_create) - give the same bits, call after call."""
-    capi, synth = pkg.capi, pkg.synth
-    occ, esdf, res = small_world(pkg)
-    N = 12
-    head, tail, way, T0 = _setup(pkg, occ, res, N, 77)
-    shape = synth.make_shape("RoundedCone", params=(0.8, 0.3, 1.6))
-    rng = np.random.default_rng(4)
-    out = {}
-    for form in ("in-launch", "serial"):
-        if form == "serial":
-            monkeypatch.setenv("ISDF_NO_CB_FUSE", "1")
-        cfg, eng, o = _engines(pkg, orc, capi.V3_ESDF_TILE, occ, esdf, res, shape)
-        eng.set_trajectory(N, head, tail, 2.0)
-        x = eng.pack_variables(T0, way)
-        rows = []
-        rs = np.random.default_rng(9)
-        for it in range(40):                                   # many steps back to back: flags, sequence numbers, the staging buffer
-            xi = x + 0.02 * rs.normal(0, 1, x.size)
-            c, g = eng.cost_function(xi)
-            rows.append(np.concatenate([[c], g]))
-        want = capi.HOST_PATH_DEVICE_CALLBACK_FUSED if form == "in-launch" else capi.HOST_PATH_DEVICE_CALLBACK
-        assert eng.host_path() == want
-        # interleaved with the other host entry points of the same ctx (they share the staging buffer's flags)
-        Tn, cm = eng.unpack_variables(x)
-        e1 = eng.eval_single(Tn, cm)
-        c2, g2 = eng.cost_function(x)
-        e2 = eng.eval_single(Tn, cm)
-        assert e1[0] == e2[0] and np.array_equal(e1[2], e2[2])
-        rows.append(np.concatenate([[c2], g2]))
-        out[form] = np.array(rows)
-    assert np.array_equal(out["in-launch"], out["serial"])
-
-
 def test_device_minco_gradient_is_the_derivative(pkg, orc, product_lib):
     """Directional central difference of the device-resident callback (x -> cost, g entirely on the device)."""
     capi, synth = pkg.capi, pkg.synth
@@ -344,6 +312,7 @@ def test_device_minco_gradient_is_the_derivative(pkg, orc, product_lib):
     shape = synth.make_shape("RoundedCone", params=(0.8, 0.3, 1.6))
     cfg, eng, o = _engines(pkg, orc, capi.V3_ESDF_TILE, occ, esdf, res, shape)
     eng.set_trajectory(N, head, tail, 4.0)
+    eng.set_minco_mode(capi.MINCO_DEVICE)
     x = eng.pack_variables(T0, way)
     cost, g = eng.cost_function(x)
     assert eng.minco_path() == 1

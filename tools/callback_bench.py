@@ -60,10 +60,13 @@ for name, N, variant, piece_T in (("C2: 40 pieces, V3 tile sweep, box", 40, capi
         c, g = eng.cost_function(x0)
         med, p10, p90, cst = time_cb(eng, x0, 300 if quick else 1500)
         out[label] = (med, p10, p90, c, g, eng.minco_path(), eng.host_path())
+    eng.set_minco_mode(capi.MINCO_AUTO)
+    eng.cost_function(x0)
+    auto = "device" if eng.minco_path() == 1 else "host"
     d, h = out["device"], out["host"]
     relc = abs(d[3] - h[3]) / abs(h[3]); relg = np.abs(d[4] - h[4]).max() / np.abs(h[4]).max()
     print(f"{name}\n    isdf_cost_function median us: device MINCO {d[0]:7.1f} (p10 {d[1]:.1f}, p90 {d[2]:.1f}; path {d[5]}/{d[6]})  |  host MINCO {h[0]:7.1f} (p10 {h[1]:.1f}, p90 {h[2]:.1f}; path {h[5]}/{h[6]})"
-          f"  |  device vs host: cost {relc:.1e}, g {relg:.1e}", flush=True)
+          f"  |  device vs host: cost {relc:.1e}, g {relg:.1e}  |  left to itself the library takes: {auto}", flush=True)
     if variant != capi.V1_SWEPT and not quick:
         for mode, label in ((capi.MINCO_DEVICE, "device"), (capi.MINCO_HOST, "host")):
             eng.set_minco_mode(mode)
