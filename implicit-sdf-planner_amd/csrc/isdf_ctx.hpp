@@ -23,7 +23,7 @@ struct isdf_ctx {
     DevShape shape{};
     isdf_shape shape_host{};
     bool have_shape = false;
-    DevMesh *d_mesh = nullptr;
+    DevMesh *d_mesh = nullptr; int mesh_depth = 0;     // levels of the mesh robot's hierarchy
     double *d_mesh_tri = nullptr;
     float *d_mesh_trif = nullptr;
     int *d_fwn_child = nullptr;

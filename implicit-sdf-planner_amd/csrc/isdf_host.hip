@@ -386,6 +386,7 @@ extern "C" int isdf_set_shape(isdf_ctx *c, const isdf_shape *s) {
         DevMesh hm{c->d_mesh_tri, c->d_mesh_trif, s->n_faces, c->d_fwn_child, c->d_fwn_box, tree.n_nodes(), c->d_fwn_boxq, c->d_fwn_triq, depth};
         // one task per workgroup pays when a pass is long (measured: 20 faces 1.15 -> 1.95 ms, 720 faces faster); ISDF_MESH_WG=0/1 forces
         d.mesh_levels = std::max(2, std::min(depth, isdf::MESH_Q_LEVELS));
+        c->mesh_depth = depth;
         d.mesh_wg = (s->n_faces >= 64 && depth <= isdf::MESH_Q_LEVELS) ? 1 : 0;
         if (const char *e = getenv("ISDF_MESH_WG")) d.mesh_wg = (e[0] == '1' && depth <= isdf::MESH_Q_LEVELS) ? 1 : 0;
         HIPCHK(c, hipMemcpy(c->d_mesh, &hm, sizeof(hm), hipMemcpyHostToDevice));
@@ -707,6 +708,10 @@ static int eval_device_impl(isdf_ctx *c, int n_traj, int N, const double *d_T, c
     }
 
     // ---- V2 / V3 integral sweep
+    // the tile sweep's mesh walks keep MESH_Q_LEVELS levels of frames in LDS: a deeper hierarchy (a strongly unbalanced mesh)
+    // would index past them - refused here, not corrupted there (the swept-volume sweep takes such meshes: wave-cooperative walks)
+    if (cfg.enable_pos && c->shape.kind == ISDF_SHAPE_MESH && c->mesh_depth > isdf::MESH_Q_LEVELS)
+        return fail(c, ISDF_ERR_UNSUPPORTED, "mesh hierarchy deeper than 12 levels: the tile sweep (V2 / V3) does not take it (the swept-volume sweep does)");
     if (cfg.enable_pos) {
         if (!c->have_geom) return fail(c, ISDF_ERR_STATE, "grid not set");
         if (cfg.variant == ISDF_V3_ESDF_TILE && !c->d_esdf) return fail(c, ISDF_ERR_STATE, "V3 needs an ESDF grid");

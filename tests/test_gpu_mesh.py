@@ -247,3 +247,34 @@ def test_mesh_walk_forms_agree(pkg, orc, product_lib, monkeypatch):
     for k in range(4):
         c1, gT1, gC1 = e.eval_single(Ts[k], Cs[k])
         assert c1 == cost[k] and np.array_equal(gT1, gTs[k]) and np.array_equal(gC1, gCs[k])
+
+
+def test_deep_unbalanced_mesh_is_refused_by_the_tile_sweep(pkg, orc, product_lib):
+    """A strongly unbalanced mesh (triangles in geometric progression: the hierarchy degenerates to 14 levels) exceeds the 12
+    levels of walk frames the tile sweep keeps in LDS: V2 / V3 refuse it with ISDF_ERR_UNSUPPORTED instead of walking past their
+    frames; the shape plugin itself and the swept-volume sweep still take it (per-lane / wave walks)."""
+    capi, synth = pkg.capi, pkg.synth
+    n = 60
+    V, F = [], []
+    for i in range(n):
+        x = 2.0 ** i * 1e-9; s = 0.1 * x
+        V += [[x, 0, 0], [x + s, 0, 0], [x, s, 0.1 * s]]
+        F.append([3 * i, 3 * i + 1, 3 * i + 2])
+    V = np.array(V); F = np.array(F, dtype=np.int32)
+    V *= 1.5 / np.abs(V).max()
+    shape = synth.make_mesh_shape(V, F)
+    occ, esdf, res = small_world(pkg)
+    T, cm = traj(pkg, occ, res, N=4)
+    cfg = synth.default_config(capi.V3_ESDF_TILE, kernel_size=9, integral_intervs=16, safety_hor=0.5)
+    eng = pkg.Engine(cfg); eng.set_grid(esdf, (0, 0, 0), res, capi.GRID_ESDF)
+    eng.set_shape(shape)
+    with pytest.raises(pkg.engine.IsdfError) as ei:
+        eng.eval_single(T, cm)
+    assert ei.value.code == capi.ISDF_ERR_UNSUPPORTED
+    # the plugin itself still evaluates it
+    o = orc.Oracle(cfg, threads=4); o.set_shape(shape)
+    _need_hdk(o)
+    Q = _queries(V, np.random.default_rng(2), 400)
+    s, g = eng.shape_eval(Q)
+    s0, g0 = o.shape_eval(Q)
+    assert np.all(np.isfinite(s)) and np.all(np.abs(s - s0) <= 5e-6 * np.abs(s0) + 4e-6 * np.abs(Q).max())
