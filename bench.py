@@ -162,6 +162,10 @@ def main():
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--pieces", type=int, default=0, help="pieces of the trajectory (default: 40 at 1 GPU = configs[1], 400 at N > 1 = configs[3])")
+    ap.add_argument("--workload", choices=("auto", "c2", "c4"), default="auto",
+                    help="headline workload: c2 = BASELINE configs[1] (1 x 40 pieces), c4 = configs[3] (1 x 400 pieces); auto = c2 on one GPU, c4 on several "
+                         "(so `--gpus 1 --workload c4` gives the one-GPU point of the N > 1 curve)")
+    ap.add_argument("--no-c5", action="store_true", help="N > 1: skip the configs[4] entry (V1, mesh robot, 512^3 map, sharded by obstacle points)")
     ap.add_argument("--weak", action="store_true", help="N > 1: 40 pieces per rank (weak scaling) instead of the fixed 400-piece trajectory")
     ap.add_argument("--grid", type=int, default=256)
     ap.add_argument("--kernel-size", type=int, default=21)
@@ -201,6 +205,8 @@ def main():
     K = 64
     if args.pieces > 0:
         n_pieces = args.pieces
+    elif args.workload != "auto":
+        n_pieces = 40 if args.workload == "c2" else 400
     elif world == 1:
         n_pieces = 40                    # configs[1]
     else:
@@ -344,12 +350,33 @@ def main():
         if mode == "fused":
             eng.xchg_fuse(True)
 
+    # what the collective library saw, and what ONE all-reduce of the step's packed vector costs by itself on this group
+    rccl_seen = None
+    if world > 1:
+        ar = torch.zeros(eng.out_stride(N), dtype=torch.float64, device=dev)
+        for _ in range(5):
+            dist.all_reduce(ar)
+        torch.cuda.synchronize(); dist.barrier(); torch.cuda.synchronize()
+        ta = time.perf_counter()
+        for _ in range(50):
+            dist.all_reduce(ar)
+        torch.cuda.synchronize()
+        ta = torch.tensor([(time.perf_counter() - ta) / 50], dtype=torch.float64, device=dev)
+        dist.all_reduce(ta, op=dist.ReduceOp.MAX)
+        devs = [torch.zeros(1, dtype=torch.int64, device=dev) for _ in range(world)]
+        dist.all_gather(devs, torch.tensor([local_rank], dtype=torch.int64, device=dev))
+        rccl_seen = {"backend": dist.get_backend(), "rccl_ranks_seen": dist.get_world_size(), "devices_by_rank": [int(d.item()) for d in devs],
+                     "distinct_devices": len({int(d.item()) for d in devs}),
+                     "all_reduce_alone_ms": round(1e3 * float(ta.item()), 5), "all_reduce_doubles": int(ar.numel())}
+        del ar
+
     # ---- N > 1: a scaling line that can be READ.  (1) the SAME workload (the N-piece trajectory) unsharded on ONE GPU, measured on
     # rank 0 in this run -> `one_gpu_same_workload` + `speedup` (the N = 1 line of this bench is another workload: C2, 40 pieces);
     # (2) the workload of BASELINE's configs that CAN scale - configs[2], 128 trajectories - sharded by TRAJECTORY (no exchange:
     # every trajectory's outputs stay on its rank, as in the batch optimiser), with its own one-GPU figure from rank 0.
     one_gpu = None
     c3_sharded = None
+    c5_sharded = None
     if world > 1 and not args.weak:
         def plain_timed(fn, steps, warm=5):
             for _ in range(warm):
@@ -411,6 +438,53 @@ def main():
                                                     "what": "all 128 trajectories in one batched launch on rank 0's GPU while the other ranks wait, same run"},
                           "speedup": round(el3one / el3, 3), "sharded_equals_unsharded_bitwise_traj0": same}
         del e3
+        # (3) configs[4]: the swept-volume sweep (V1) with a mesh robot through the fast winding number on a 512^3 map - the one
+        # north-star workload whose step lasts milliseconds.  Obstacle points sharded contiguously over the ranks (isdf_set_shard),
+        # ONE all-reduce of [cost | gradT | gradC] per step over the group, lastTstar merged once at the end (every rank writes its
+        # own points' minimisers; the optimizer never reads them: set_ts = false, sw_manager.hpp:710-747).
+        if not args.no_c5:
+            try:
+                res5 = 0.1
+                occ5 = synth.random_box_map((512,) * 3, res=res5, occupancy=0.15, seed=12345, edge=(0.4, 2.0))
+                ext5 = np.array(occ5.shape) * res5
+                T5, Cf5 = synth.random_trajectory(ext5, 20, seed=780, piece_T=1.0, jitter=0.5, margin=4.0, occ=occ5, res=res5)
+                cm5 = synth.colmajor(Cf5)
+                way5 = cm5.reshape(3, -1).T.reshape(20, 6, 3)[1:, 0, :]
+                cfg5 = synth.default_config(capi.V1_SWEPT, device=local_rank, safety_hor=(3 ** 0.5 / 2) * res5, weight_p=4000.0)
+                e5 = pkg.Engine(cfg5); e5.set_grid(occ5, (0, 0, 0), res5, capi.GRID_OCCUPANCY)
+                e5.set_shape(synth.make_mesh_shape(*synth.blob_mesh(24, 16, scale=0.9)))
+                M5 = e5.gather_points(way5, 0.9)
+                e5.set_shard(rank, world)
+                d5T = torch.from_numpy(T5).to(dev); d5C = torch.from_numpy(cm5).to(dev)
+                d5O = torch.zeros(e5.out_stride(20), dtype=torch.float64, device=dev)
+                d5ts = torch.full((M5,), -1.0, dtype=torch.float64, device=dev)
+
+                def c5_step():
+                    e5.eval_device(1, 20, d5T.data_ptr(), d5C.data_ptr(), d5O.data_ptr(), d5ts.data_ptr(), stream)
+                    par.allreduce_packed(d5O)
+                st5 = 5
+                el5 = plain_timed(c5_step, st5, warm=2)
+                t5 = torch.tensor([el5], dtype=torch.float64, device=dev); dist.all_reduce(t5, op=dist.ReduceOp.MAX); el5 = float(t5.item())
+                merged = d5ts.clone(); dist.all_reduce(merged, op=dist.ReduceOp.MAX)      # a rank's untouched entries are -1, minimisers are >= 0
+                sum5 = d5O.clone()
+                if rank == 0:
+                    e5.set_shard(0, 1)
+                    d5O1 = torch.zeros_like(d5O); d5ts1 = torch.full((M5,), -1.0, dtype=torch.float64, device=dev)
+                el5one = plain_timed((lambda: e5.eval_device(1, 20, d5T.data_ptr(), d5C.data_ptr(), d5O1.data_ptr(), d5ts1.data_ptr(), stream)) if rank == 0 else (lambda: None), st5, warm=2)
+                if rank == 0:
+                    c5_sharded = {"name": f"C5 (configs[4]) sharded by OBSTACLE POINT over {world} GPUs: V1 swept-volume sweep, 512^3 occupancy @ 0.1 m, mesh robot (blob, 720 faces, fast winding number), 20 pieces, "
+                                          f"{M5} points, one all-reduce of {int(d5O.numel())} doubles per step ({dist.get_backend()}), lastTstar merged",
+                                  "variant": "V1", "obstacle_points": int(M5), "ms_per_step": round(1e3 * el5 / st5, 5), "evals_per_s": round(M5 * st5 / el5, 1), "unit": "obstacle-point evals/s",
+                                  "scaling": "strong", "steps": st5,
+                                  "one_gpu_same_workload": {"ms_per_step": round(1e3 * el5one / st5, 5), "evals_per_s": round(M5 * st5 / el5one, 1),
+                                                            "what": "all the points unsharded on rank 0's GPU while the other ranks wait, same run"},
+                                  "speedup": round(el5one / el5, 3),
+                                  "sharded_vs_unsharded_rel_diff": float((sum5 - d5O1).norm().item() / max(float(d5O1.norm().item()), 1e-300)),
+                                  "lastTstar_merged_equals_unsharded_bitwise": bool(torch.equal(merged, d5ts1))}
+                del e5, occ5
+            except Exception as e:      # noqa: BLE001
+                if rank == 0:
+                    c5_sharded = {"name": "C5 sharded", "error": str(e)}
         if fused_was_on:
             eng.xchg_fuse(True)
 
@@ -480,8 +554,8 @@ def main():
     if rank == 0:
         # ---- the other single-GPU configurations SURVEY 7 names as the memory-side-heavy ones, same JSON (device resident)
         extra = None
-        if world > 1 and c3_sharded is not None:
-            extra = [c3_sharded]
+        if world > 1 and (c3_sharded is not None or c5_sharded is not None):
+            extra = [e_ for e_ in (c3_sharded, c5_sharded) if e_ is not None]
         if world == 1 and not args.no_extra_configs:
             extra = []
 
@@ -840,7 +914,8 @@ def main():
                         for _ in range(60): em8.eval_device(1, N, dTq.data_ptr(), dCq.data_ptr(), dOq.data_ptr(), 0, qs.cuda_stream)
                         qt.append((time.perf_counter() - tq) / 60)
                         torch.cuda.synchronize()
-                    host_queue_multi8 = round(1e3 * float(np.min(qt)), 4)       # the best burst: a burst that runs into the runtime's queue limits waits for the GPU
+                    host_queue_multi8 = {"median": round(1e3 * float(np.median(qt)), 4), "min": round(1e3 * float(np.min(qt)), 4), "max": round(1e3 * float(np.max(qt)), 4),
+                                         "bursts": len(qt), "steps_per_burst": 60}      # (a burst that runs into the runtime's queue limits waits for the GPU: the min is the calling thread's own cost)
                     del em8
                 except Exception:       # noqa: BLE001
                     host_ms_multi = None
@@ -923,6 +998,17 @@ def main():
                    "ms_per_step": round(1e3 * best[3] / best[2], 2)}
             ref = np.concatenate([[c0], gT0, gC0])
             parity = float(np.linalg.norm(out_gpu - ref) / max(np.linalg.norm(ref), 1e-300))
+        # the per-configuration issue fractions the documents quote, as top-level keys (the driver's record keeps those)
+        def _frac(pred, key):
+            for e_ in (extra or []):
+                if isinstance(e_, dict) and pred(e_.get("name", "")) and isinstance(e_.get(key), dict):
+                    return e_[key].get("valu_issue_busy_frac")
+            return None
+        issue_keys = {"c2_issue_frac": None if issue is None else issue["valu_issue_busy_frac"],
+                      "c3_issue_frac": _frac(lambda n: n.startswith("C3 (configs[2])"), "roofline"),
+                      "v3mesh_issue_frac": _frac(lambda n: "MESH robot (blob, 720" in n, "roofline"),
+                      "v1_issue_frac": _frac(lambda n: n.startswith("V1 swept-volume sweep") and "rounded cone" in n, "roofline_issue"),
+                      "v1mesh_issue_frac": _frac(lambda n: n.startswith("C5 (configs[4]) shape") and "720" in n, "roofline_issue")}
         result = {
             "metric": "SDF cost+grad point-evals/sec", "value": round(value, 1), "unit": "point-evals/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 5),
@@ -938,13 +1024,15 @@ def main():
                        "pieces": N, "samples_per_piece": K + 1, "grid": args.grid, "kernel_size": args.kernel_size,
                        "sharding": ("none" if world == 1 else ("pieces contiguous by rank; each piece's 19 rows + cost stored by its owner into every peer's output inside the step's launches" if mode == "fused" else "pieces contiguous by rank + all_reduce(sum) of 1+19N doubles")),
                        "collective": collective,
-                       "rccl_all_reduce_ms_per_step": None if rccl_ms is None else round(rccl_ms, 5)},
+                       "rccl_all_reduce_ms_per_step": None if rccl_ms is None else round(rccl_ms, 5),
+                       "group": rccl_seen},
             "roofline": roofline, "roofline_issue": issue, "cpu_baseline": cpu, "configs": extra,
             "one_gpu_same_workload": one_gpu, "speedup": None if one_gpu is None else round(value / one_gpu["evals_per_s"], 3),
             "value_steady": value_steady, "parity_rel_err_vs_oracle": parity, "host_api_ms": None if host_ms is None else round(host_ms, 4), "host_api_timer": host_timer,
             "host_api_ms_two_shards_one_gpu": host_ms_multi, "host_api_ms_eight_shards_one_gpu": host_ms_multi8, "host_queue_ms_eight_shards_one_gpu": host_queue_multi8,
             "stats_last_step_rank0": stats, "lbfgs": lbfgs, "hbm_copy_gbs_measured": hbm_copy,
         }
+        result.update(issue_keys)
         print(json.dumps(result), flush=True)
     if world > 1:
         dist.barrier()
