@@ -736,7 +736,7 @@ def main():
                           ("blob, 720 faces (synthetic)", synth.blob_mesh(24, 16, scale=0.9), 5, "all")]
                 try:
                     meshes += [("the reference's Lthick.obj, 20 faces, scaled to a 0.83 m bound", synth.reference_mesh("Lthick", 0.83), 20, "all"),
-                               ("the reference's Trefoil.obj, 12 000 faces, scaled to a 0.83 m bound", synth.reference_mesh("Trefoil", 0.83), 3, "sample")]
+                               ("the reference's Trefoil.obj, 12 000 faces, scaled to a 0.83 m bound", synth.reference_mesh("Trefoil", 0.83), 3, "all")]
                 except Exception as e:      # noqa: BLE001
                     extra.append({"name": "reference meshes", "error": str(e)})
                 for nm, (Vm, Fm), stp, omode in meshes:

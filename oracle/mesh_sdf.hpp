@@ -11,11 +11,15 @@
 //     exact float sum (Van Oosterom & Strackee 1983, the leaf formula of UT_SolidAngle) is kept only as the fallback
 //     when libref_fwn.so has not been built (backend() == 0: parity UNPINNED for the mesh kind in that case, and the
 //     mesh parity tests skip);
-//   * distance / closest point: exact geometry, brute force over triangles with the region-based
-//     closest-point-on-triangle test (Ericson, Real-Time Collision Detection 5.1.5 - the algorithm behind
-//     igl::point_simplex_squared_distance); igl::AABB only accelerates the same exact query.
+//   * distance / closest point: exact geometry, the region-based closest-point-on-triangle test (Ericson, Real-Time
+//     Collision Detection 5.1.5 - the algorithm behind igl::point_simplex_squared_distance) over ALL triangles; igl::AABB
+//     only accelerates the same exact query.  Meshes of more than 64 faces go through a plain bounding-box tree here too
+//     (branch and bound, the exhaustive search's answer bit for bit including its lowest-face tie rule; ORACLE_MESH_EXHAUSTIVE=1
+//     at set() time keeps the exhaustive loop - tests/test_oracle_selfcheck.py compares the two).
 #pragma once
 #include "vecmath.hpp"
+#include <algorithm>
+#include <cfloat>
 #include <vector>
 #include <cstdint>
 #include <cstdlib>
@@ -60,6 +64,10 @@ struct MeshSdf {
     std::vector<V3> V;
     std::vector<int32_t> F;   // 3 per face
     void *hdk = nullptr;      // fwn_bvh of Shape.cpp:86 when the vendored library is available
+    // bounding-box tree over the faces (closest point only): node = box, children (inner) or a run of `order` (leaf)
+    struct BvhNode { double lo[3], hi[3]; int left, right, first, count; };
+    std::vector<BvhNode> bvh;
+    std::vector<int> order;
 
     MeshSdf() = default;
     MeshSdf(const MeshSdf &) = delete;
@@ -74,6 +82,56 @@ struct MeshSdf {
         const HdkFwn &lib = HdkFwn::get();
         if (hdk) { lib.destroy(hdk); hdk = nullptr; }
         if (lib.ok) hdk = lib.create(verts, nV, faces, nF, 2);            // igl::fast_winding_number(V, F, 2, fwn_bvh)
+        bvh.clear(); order.clear();
+        const char *ex = std::getenv("ORACLE_MESH_EXHAUSTIVE");
+        if (nF > 64 && !(ex && ex[0] == '1')) build_bvh();
+    }
+    void face_box(int f, double lo[3], double hi[3]) const {
+        for (int a = 0; a < 3; a++) { lo[a] = DBL_MAX; hi[a] = -DBL_MAX; }
+        for (int k = 0; k < 3; k++) {
+            const V3 &v = V[F[3 * f + k]];
+            const double c[3] = {v.x, v.y, v.z};
+            for (int a = 0; a < 3; a++) { lo[a] = std::min(lo[a], c[a]); hi[a] = std::max(hi[a], c[a]); }
+        }
+    }
+    int build_node(int first, int count) {
+        BvhNode nd;
+        for (int a = 0; a < 3; a++) { nd.lo[a] = DBL_MAX; nd.hi[a] = -DBL_MAX; }
+        double clo[3] = {DBL_MAX, DBL_MAX, DBL_MAX}, chi[3] = {-DBL_MAX, -DBL_MAX, -DBL_MAX};
+        for (int k = first; k < first + count; k++) {
+            double lo[3], hi[3];
+            face_box(order[k], lo, hi);
+            for (int a = 0; a < 3; a++) {
+                nd.lo[a] = std::min(nd.lo[a], lo[a]); nd.hi[a] = std::max(nd.hi[a], hi[a]);
+                const double c = 0.5 * (lo[a] + hi[a]);
+                clo[a] = std::min(clo[a], c); chi[a] = std::max(chi[a], c);
+            }
+        }
+        nd.left = nd.right = -1; nd.first = first; nd.count = count;
+        const int me = (int)bvh.size();
+        bvh.push_back(nd);
+        if (count > 8) {
+            int ax = 0;
+            for (int a = 1; a < 3; a++) if (chi[a] - clo[a] > chi[ax] - clo[ax]) ax = a;
+            auto cen = [&](int f) { double lo[3], hi[3]; face_box(f, lo, hi); return 0.5 * (lo[ax] + hi[ax]); };
+            const int mid = first + count / 2;
+            std::nth_element(order.begin() + first, order.begin() + mid, order.begin() + first + count, [&](int x, int y) { return cen(x) < cen(y); });
+            const int l = build_node(first, mid - first), r = build_node(mid, first + count - mid);
+            bvh[me].left = l; bvh[me].right = r; bvh[me].count = 0;
+        }
+        return me;
+    }
+    void build_bvh() {
+        order.resize(n_faces());
+        for (int f = 0; f < n_faces(); f++) order[f] = f;
+        bvh.reserve(2 * (size_t)n_faces() / 4 + 8);
+        build_node(0, n_faces());
+    }
+    static double box_dist2(const BvhNode &n, const V3 &p) {
+        const double c[3] = {p.x, p.y, p.z};
+        double s = 0.0;
+        for (int a = 0; a < 3; a++) { const double e = std::max(std::max(n.lo[a] - c[a], c[a] - n.hi[a]), 0.0); s += e * e; }
+        return s * (1.0 - 1e-12);           // (never above the true distance to anything inside, rounding included)
     }
     int n_faces() const { return (int)(F.size() / 3); }
 
@@ -109,6 +167,29 @@ struct MeshSdf {
 
     double squared_distance(const V3 &p, V3 &closest) const {
         double best = DBL_MAX;
+        if (!bvh.empty()) {
+            // branch and bound; a node is skipped only when it cannot even TIE the best (equal distances go to the lowest face,
+            // which is what the exhaustive loop's strict '<' in face order amounts to)
+            int best_f = -1;
+            int stack[128], sp = 0;
+            stack[sp++] = 0;
+            while (sp > 0) {
+                const BvhNode &n = bvh[stack[--sp]];
+                if (box_dist2(n, p) > best) continue;
+                if (n.left < 0) {
+                    for (int k = n.first; k < n.first + n.count; k++) {
+                        const int f = order[k];
+                        const V3 c = closest_on_triangle(p, V[F[3 * f]], V[F[3 * f + 1]], V[F[3 * f + 2]]);
+                        const double d = sqnorm(p - c);
+                        if (d < best || (d == best && f < best_f)) { best = d; closest = c; best_f = f; }
+                    }
+                } else {
+                    const double dl = box_dist2(bvh[n.left], p), dr = box_dist2(bvh[n.right], p);
+                    if (dl <= dr) { stack[sp++] = n.right; stack[sp++] = n.left; } else { stack[sp++] = n.left; stack[sp++] = n.right; }
+                }
+            }
+            return best;
+        }
         for (int f = 0; f < n_faces(); f++) {
             const V3 c = closest_on_triangle(p, V[F[3 * f]], V[F[3 * f + 1]], V[F[3 * f + 2]]);
             const double d = sqnorm(p - c);

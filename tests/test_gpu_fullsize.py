@@ -197,6 +197,35 @@ def test_c5_swept_mesh_512_shards(pkg, orc, product_lib):
     assert_close(gC, gC0, "C5 gradC at the oracle's t*"); assert_close(gT, gT0, "C5 gradT at the oracle's t*")
 
 
+def test_c5_trefoil_512_every_point(pkg, orc, product_lib):
+    """configs[4] with the reference's own 12 000-face Trefoil.obj, full size: EVERY obstacle point of the 512^3
+    bench workload against the oracle, both sides searching their own minimisers (the oracle's closest point through its
+    bounding-box tree, which tests/test_oracle_selfcheck.py holds to the exhaustive search bit for bit)."""
+    capi, synth = pkg.capi, pkg.synth
+    res = 0.1
+    occ = synth.random_box_map((512,) * 3, res=res, occupancy=0.15, seed=12345, edge=(0.4, 2.0))
+    ext = np.array(occ.shape) * res
+    T, Cf = synth.random_trajectory(ext, 20, seed=780, piece_T=1.0, jitter=0.5, margin=4.0, occ=occ, res=res)
+    cm = synth.colmajor(Cf)
+    shape = synth.make_mesh_shape(*synth.reference_mesh("Trefoil", 0.83))
+    cfg = synth.default_config(capi.V1_SWEPT, safety_hor=(3 ** 0.5 / 2) * res, weight_p=4000.0)
+    eng = pkg.Engine(cfg)
+    eng.set_grid(occ, (0, 0, 0), res, capi.GRID_OCCUPANCY)
+    eng.set_shape(shape)
+    way = cm.reshape(3, -1).T.reshape(20, 6, 3)[1:, 0, :]
+    M = eng.gather_points(way, 0.9)
+    assert M > 10000
+    o = orc.Oracle(cfg, threads=30)
+    o.set_grid(occ, (0, 0, 0), res, capi.GRID_OCCUPANCY); o.set_shape(shape); o.set_points(eng.get_points())
+    if o.mesh_backend() != 1:
+        pytest.skip("oracle/_ref/libref_fwn.so not built")
+    tg = -np.ones(M); to = -np.ones(M)
+    c, gT, gC = eng.eval_single(T, cm, tstar=tg)
+    c0, gT0, gC0, _ = o.eval(T, cm, tstar=to)
+    assert c0 > 0 and abs(c - c0) <= REL_TOL * abs(c0)
+    assert_mesh_v1_free_running("C5 512^3 Trefoil.obj V1, all %d points" % M, tg, to, gT, gT0, gC, gC0)
+
+
 def test_c1_narrow_slit_mesh_robot(pkg, orc, product_lib):
     """configs[0] (demo1.launch): a narrow-slit map, a mesh robot (the concave L prism) and a ~20-piece trajectory through the
     slit on the reference's live path - the swept-volume sweep - device vs the oracle (reference winding-number library)."""

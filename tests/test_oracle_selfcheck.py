@@ -225,3 +225,31 @@ def test_map_product_restatements(pkg, orc):
     a = orc.gather_points(occm, np.zeros(3), np.array(occm.shape) * 0.5, 0.5, way, 1.6)
     b = synth.constraint_points(occm, (0, 0, 0), 0.5, way, 1.6)
     assert a.shape == b.shape and np.array_equal(a, b)
+
+
+@pytest.mark.parametrize("which", ["blob 720", "Trefoil.obj 12 000", "blob with doubled faces"])
+def test_mesh_closest_point_tree_equals_exhaustive_search(pkg, orc, which, monkeypatch):
+    """The oracle's mesh distance goes through a bounding-box tree for meshes of more than 64 faces (test infrastructure: the
+    exhaustive loop over the reference's 12 000-face Trefoil.obj made full-size parity runs impractical).  It must return what
+    the exhaustive search returns, bit for bit - value, gradient and therefore the closest point, ties to the lowest face."""
+    synth = pkg.synth
+    if which == "blob 720":
+        V, F = synth.blob_mesh(24, 16, scale=0.9)
+    elif which.startswith("Trefoil"):
+        V, F = synth.reference_mesh("Trefoil", 0.83)
+    else:
+        V, F = synth.blob_mesh(12, 8)
+        F = np.concatenate([F, F[:40]]).astype(np.int32)          # exact ties between a face and its copy
+    V = np.asarray(V, dtype=np.float64)
+    shape = synth.make_mesh_shape(V, F)
+    cfg = synth.default_config()
+    rng = np.random.default_rng(17)
+    ext = np.abs(V).max()
+    Q = np.concatenate([rng.uniform(-2.5 * ext, 2.5 * ext, (500, 3)),
+                        V[rng.integers(0, V.shape[0], 500)] * (1.0 + rng.normal(0, 0.1, (500, 1))) + rng.normal(0, 0.02 * ext, (500, 3))])
+    o_tree = orc.Oracle(cfg, threads=8); o_tree.set_shape(shape)
+    monkeypatch.setenv("ORACLE_MESH_EXHAUSTIVE", "1")
+    o_all = orc.Oracle(cfg, threads=8); o_all.set_shape(shape)
+    s1, g1 = o_tree.shape_eval(Q)
+    s0, g0 = o_all.shape_eval(Q)
+    assert np.array_equal(s1, s0) and np.array_equal(g1, g0)
