@@ -782,17 +782,20 @@ def main():
                 m_ = npt // 4096
                 a_ = torch.rand(4096, 1, 3, dtype=torch.float64, device=dev, generator=gen) * ext_m
                 d_ = torch.nn.functional.normalize(torch.randn(4096, 1, 3, dtype=torch.float64, device=dev, generator=gen), dim=2)
-                sets = (("trajectory-like points (4 096 straight lines, consecutive points 2 cm apart)", (a_ + d_ * (torch.arange(m_, dtype=torch.float64, device=dev).view(1, m_, 1) * 0.02)).reshape(-1, 3).contiguous()),
-                        ("uniform random points", torch.rand(npt, 3, dtype=torch.float64, device=dev, generator=gen) * ext_m))
-                for nm_, pts_ in sets:
+                rnd_ = torch.rand(npt, 3, dtype=torch.float64, device=dev, generator=gen) * ext_m
+                sets = (("trajectory-like points (4 096 straight lines, consecutive points 2 cm apart)", (a_ + d_ * (torch.arange(m_, dtype=torch.float64, device=dev).view(1, m_, 1) * 0.02)).reshape(-1, 3).contiguous(), False),
+                        ("uniform random points", rnd_, False),
+                        ("uniform random points through the BRICKED copy (isdf_esdf_sample_scattered_device: 2 x 2 x 2-cell bricks with apron, one 128-byte line per cell neighbourhood; bitwise the same results)", rnd_, True))
+                plain_rnd = None
+                for nm_, pts_, scat_ in sets:
                     n_ = pts_.shape[0]
                     dv_ = torch.empty(n_, dtype=torch.float64, device=dev); dg_ = torch.empty(n_, 3, dtype=torch.float64, device=dev)
                     for _ in range(2):
-                        eng.esdf_sample_device(pts_.data_ptr(), n_, dv_.data_ptr(), dg_.data_ptr(), stream)
+                        eng.esdf_sample_device(pts_.data_ptr(), n_, dv_.data_ptr(), dg_.data_ptr(), stream, scattered=scat_)
                     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                     ev0.record()
                     for _ in range(5):
-                        eng.esdf_sample_device(pts_.data_ptr(), n_, dv_.data_ptr(), dg_.data_ptr(), stream)
+                        eng.esdf_sample_device(pts_.data_ptr(), n_, dv_.data_ptr(), dg_.data_ptr(), stream, scattered=scat_)
                     ev1.record(); torch.cuda.synchronize()
                     ms_ = ev0.elapsed_time(ev1) / 5
                     ent = {"name": f"ESDF point sampler isdf_esdf_sample_device (value + gradient), {args.grid}^3 float32 ESDF, {n_:.3g} {nm_}",
@@ -807,8 +810,12 @@ def main():
                         got_ = np.concatenate([dv_[:2000].cpu().numpy()[:, None], dg_[:2000].cpu().numpy()], axis=1)
                         ent["rel_err_vs_oracle"] = float(np.linalg.norm(got_ - rr_) / max(np.linalg.norm(rr_), 1e-300))
                         ent["rel_err_vs_oracle_of"] = "the first 2 000 points (bitwise equal = 0.0)"
+                    if nm_.startswith("uniform random points") and not scat_:
+                        plain_rnd = (dv_.clone(), dg_.clone())
+                    if scat_ and plain_rnd is not None:
+                        ent["equals_plain_path_bitwise"] = bool(torch.equal(dv_, plain_rnd[0]) and torch.equal(dg_, plain_rnd[1]))
                     extra.append(ent)
-                    del pts_, dv_, dg_
+                    del dv_, dg_
             except Exception as e:      # noqa: BLE001
                 extra.append({"name": "ESDF sampler", "error": str(e)})
             # configs[2] END TO END: the 128 trajectories optimised concurrently (isdf_optimize_lbfgs_batch: host MINCO + L-BFGS per

@@ -98,7 +98,7 @@ EXPORTED_SYMBOLS = [
     "isdf_cost_function_launch", "isdf_cost_function_finish", "isdf_set_minco_mode", "isdf_minco_path",
     "isdf_lbfgs_params_default", "isdf_lbfgs_minimize", "isdf_optimize_lbfgs", "isdf_optimize_lbfgs_batch",
     "isdf_set_pointcloud", "isdf_generate_esdf", "isdf_get_grid", "isdf_gather_points", "isdf_get_points", "isdf_shape_eval",
-    "isdf_esdf_sample", "isdf_esdf_sample_device",
+    "isdf_esdf_sample", "isdf_esdf_sample_device", "isdf_esdf_sample_scattered", "isdf_esdf_sample_scattered_device",
     "isdf_frontend_build", "isdf_frontend_get_shape_kernels", "isdf_frontend_get_map_kernel", "isdf_frontend_check", "isdf_frontend_cspace",
     "isdf_read_pcd", "isdf_read_obj", "isdf_poly_rotation", "isdf_body_transform", "isdf_plan_config_default", "isdf_load_yaml_config",
     "isdf_shape_from_config",
@@ -177,6 +177,8 @@ def load_library(path=None):
     lib.isdf_shape_eval.argtypes = [C.c_void_p, dp, C.c_int, dp, dp]
     lib.isdf_esdf_sample.argtypes = [C.c_void_p, dp, C.c_longlong, dp, dp]
     lib.isdf_esdf_sample_device.argtypes = [C.c_void_p, C.c_void_p, C.c_longlong, C.c_void_p, C.c_void_p, C.c_void_p]
+    lib.isdf_esdf_sample_scattered.argtypes = [C.c_void_p, dp, C.c_longlong, dp, dp]
+    lib.isdf_esdf_sample_scattered_device.argtypes = [C.c_void_p, C.c_void_p, C.c_longlong, C.c_void_p, C.c_void_p, C.c_void_p]
     lib.isdf_frontend_build.argtypes = [C.c_void_p, C.POINTER(IsdfFrontendConfig)]
     lib.isdf_frontend_get_shape_kernels.argtypes = [C.c_void_p, C.c_void_p, ip]
     lib.isdf_frontend_get_map_kernel.argtypes = [C.c_void_p, C.c_void_p, ip]

@@ -16,6 +16,7 @@ struct isdf_ctx {
     // grid
     DevGrid grid{};
     float *d_esdf = nullptr;
+    float *d_esdf_bricks = nullptr; size_t bricks_cap = 0; bool bricks_stale = true;     // the ESDF as 2 x 2 x 2-cell bricks with apron, one 128-byte line each (map_build.hip: scattered points)
     uint8_t *d_occ = nullptr;
     unsigned *d_bits = nullptr; size_t bits_cap = 0; bool bits_dirty = true;
     bool have_geom = false;

@@ -178,7 +178,7 @@ extern "C" int isdf_destroy(isdf_ctx *c) {
     if (c->h_cbres) (void)hipHostFree(c->h_cbres);
     isdf_frontend_release(c);
     isdf_xchg_release(c);
-    void *ptrs[] = {c->d_cb, c->d_cbdev, c->d_esdf, c->d_occ, c->d_points, c->d_tstar, c->d_acc, c->d_sample_info, c->d_bits, c->d_piece_cost, c->d_in, c->d_out, c->d_stats,
+    void *ptrs[] = {c->d_cb, c->d_cbdev, c->d_esdf_bricks, c->d_esdf, c->d_occ, c->d_points, c->d_tstar, c->d_acc, c->d_sample_info, c->d_bits, c->d_piece_cost, c->d_in, c->d_out, c->d_stats,
                     c->d_traj_duration, c->d_coarse_t, c->d_coarse_pose, c->d_n_coarse, c->d_point_partial, c->d_point_piece, c->d_point_stat, c->d_point_nr, c->d_task_buf,
                     c->d_task_map, c->d_v1_words, c->d_point_lmask, c->d_scan_ticks, c->d_scan_order, c->d_hist, c->d_shape_grid, c->d_pose, c->d_mq_entries, c->d_mq_items, c->d_mq_res, c->d_mq_sample_items, c->d_mq_sample_n, c->d_mq_count, c->d_msum_blocks, c->d_dbg, c->d_stage, c->d_stage_flags, c->d_sample_map, c->d_plan_cls, c->d_plan_map, c->d_plan_lr, c->d_plan_hist};
     for (void *p : ptrs) if (p) (void)hipFree(p);
@@ -235,6 +235,7 @@ extern "C" int isdf_set_grid(isdf_ctx *c, const void *vox, int dtype, int nx, in
         HIPCHK(c, hipMemcpy(c->d_occ, tmp.data(), n, hipMemcpyHostToDevice));
     }
     c->grid.esdf = c->d_esdf;
+    c->bricks_stale = true;
     c->grid.occ = c->d_occ;
     c->bits_dirty = true;
     ISDF_REPLICATE(c, isdf_set_grid(p_, vox, dtype, nx, ny, nz, origin, bmax, res, kind));

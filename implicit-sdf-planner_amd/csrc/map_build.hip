@@ -263,6 +263,7 @@ extern "C" int isdf_generate_esdf(isdf_ctx *c) {
     (void)hipFree(a); (void)hipFree(b); (void)hipFree(bits);
     c->grid.esdf = c->d_esdf;
     c->bits_dirty = true;
+    c->bricks_stale = true;
     ISDF_REPLICATE(c, isdf_generate_esdf(p_));
     return ISDF_OK;
 }
@@ -276,24 +277,51 @@ extern "C" int isdf_generate_esdf(isdf_ctx *c) {
 // bit for bit the reference's doubles on a float32 ESDF.  The one operation of this path that is a pure gather: 24 B in, 8 random
 // 4-byte reads (four 32-byte sectors: the two z corners of a column are neighbours), 8-32 B out per point - HBM / L2 bound.
 namespace isdf {
+// base cell of a world point (getGridIndex of pos - res/2, Gridmap3D.cpp:135-168) and its fractional offsets
+__device__ __forceinline__ void esdf_base_cell(const DevGrid &G, double px, double py, double pz, int &ix, int &iy, int &iz, double &dx, double &dy, double &dz, double &inv) {
+#pragma clang fp contract(off)
+    const double hx = px - 0.5 * G.res * 1.0, hy = py - 0.5 * G.res * 1.0, hz = pz - 0.5 * G.res * 1.0;   // pos_w - 0.5 * res * Ones()
+    ix = 0; iy = 0; iz = 0;
+    const bool in = !(hx < G.bmin[0] || hy < G.bmin[1] || hz < G.bmin[2] || hx > G.bmax[0] || hy > G.bmax[1] || hz > G.bmax[2]);
+    if (in) {
+        ix = (int)floor((hx - G.bmin[0]) / G.res); iy = (int)floor((hy - G.bmin[1]) / G.res); iz = (int)floor((hz - G.bmin[2]) / G.res);
+        // (the reference's "iy < 0 -> ix = 0" typos cannot fire: the differences are >= 0 inside the map)
+        if (ix < 0) ix = 0;
+        if (ix >= G.X) ix = G.X - 1;
+        if (iy >= G.Y) iy = G.Y - 1;
+        if (iz >= G.Z) iz = G.Z - 1;
+    }
+    const double cx = (ix + 0.5) * G.res + G.bmin[0], cy = (iy + 0.5) * G.res + G.bmin[1], cz = (iz + 0.5) * G.res + G.bmin[2];
+    inv = 1.0 / G.res;
+    dx = (px - cx) * inv; dy = (py - cy) * inv; dz = (pz - cz) * inv;
+}
+// the reference's interpolation order and its analytic gradient of the interpolant (GridMap3D.h:133-145, :185-191)
+__device__ __forceinline__ void esdf_interpolate(const double (&v)[2][2][2], double dx, double dy, double dz, double inv, double *val, double *grad, long long i) {
+#pragma clang fp contract(off)
+    const double v00 = (1 - dx) * v[0][0][0] + dx * v[1][0][0];
+    const double v01 = (1 - dx) * v[0][0][1] + dx * v[1][0][1];
+    const double v10 = (1 - dx) * v[0][1][0] + dx * v[1][1][0];
+    const double v11 = (1 - dx) * v[0][1][1] + dx * v[1][1][1];
+    const double v0 = (1 - dy) * v00 + dy * v10;
+    const double v1 = (1 - dy) * v01 + dy * v11;
+    if (val) val[i] = (1 - dz) * v0 + dz * v1;
+    if (grad) {
+        const double gz = (v1 - v0) * inv;
+        const double gy = ((1 - dz) * (v10 - v00) + dz * (v11 - v01)) * inv;
+        double gx = (1 - dz) * (1 - dy) * (v[1][0][0] - v[0][0][0]);
+        gx += (1 - dz) * dy * (v[1][1][0] - v[0][1][0]);
+        gx += dz * (1 - dy) * (v[1][0][1] - v[0][0][1]);
+        gx += dz * dy * (v[1][1][1] - v[0][1][1]);
+        gx *= inv;
+        grad[3 * i] = gx; grad[3 * i + 1] = gy; grad[3 * i + 2] = gz;
+    }
+}
 __global__ __launch_bounds__(256) void esdf_sample_kernel(DevGrid G, const double *__restrict__ xyz, long long n, double *__restrict__ val, double *__restrict__ grad) {
 #pragma clang fp contract(off)
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
-        const double px = xyz[3 * i], py = xyz[3 * i + 1], pz = xyz[3 * i + 2];
-        const double hx = px - 0.5 * G.res * 1.0, hy = py - 0.5 * G.res * 1.0, hz = pz - 0.5 * G.res * 1.0;   // pos_w - 0.5 * res * Ones()
-        int ix = 0, iy = 0, iz = 0;
-        const bool in = !(hx < G.bmin[0] || hy < G.bmin[1] || hz < G.bmin[2] || hx > G.bmax[0] || hy > G.bmax[1] || hz > G.bmax[2]);
-        if (in) {
-            ix = (int)floor((hx - G.bmin[0]) / G.res); iy = (int)floor((hy - G.bmin[1]) / G.res); iz = (int)floor((hz - G.bmin[2]) / G.res);
-            // (the reference's "iy < 0 -> ix = 0" typos cannot fire: the differences are >= 0 inside the map)
-            if (ix < 0) ix = 0;
-            if (ix >= G.X) ix = G.X - 1;
-            if (iy >= G.Y) iy = G.Y - 1;
-            if (iz >= G.Z) iz = G.Z - 1;
-        }
-        const double cx = (ix + 0.5) * G.res + G.bmin[0], cy = (iy + 0.5) * G.res + G.bmin[1], cz = (iz + 0.5) * G.res + G.bmin[2];
-        const double inv = 1.0 / G.res;
-        const double dx = (px - cx) * inv, dy = (py - cy) * inv, dz = (pz - cz) * inv;
+        int ix, iy, iz;
+        double dx, dy, dz, inv;
+        esdf_base_cell(G, xyz[3 * i], xyz[3 * i + 1], xyz[3 * i + 2], ix, iy, iz, dx, dy, dz, inv);
         double v[2][2][2];
 #pragma unroll
         for (int a = 0; a < 2; a++)
@@ -305,23 +333,49 @@ __global__ __launch_bounds__(256) void esdf_sample_kernel(DevGrid G, const doubl
                     const bool ok = x < G.X && y < G.Y && z < G.Z;          // (lower bounds hold by construction)
                     v[a][b][c] = ok ? (double)__builtin_nontemporal_load(G.esdf + (((size_t)x * G.Y + y) * G.Z + z)) : 0.0;
                 }
-        const double v00 = (1 - dx) * v[0][0][0] + dx * v[1][0][0];
-        const double v01 = (1 - dx) * v[0][0][1] + dx * v[1][0][1];
-        const double v10 = (1 - dx) * v[0][1][0] + dx * v[1][1][0];
-        const double v11 = (1 - dx) * v[0][1][1] + dx * v[1][1][1];
-        const double v0 = (1 - dy) * v00 + dy * v10;
-        const double v1 = (1 - dy) * v01 + dy * v11;
-        if (val) val[i] = (1 - dz) * v0 + dz * v1;
-        if (grad) {
-            const double gz = (v1 - v0) * inv;
-            const double gy = ((1 - dz) * (v10 - v00) + dz * (v11 - v01)) * inv;
-            double gx = (1 - dz) * (1 - dy) * (v[1][0][0] - v[0][0][0]);
-            gx += (1 - dz) * dy * (v[1][1][0] - v[0][1][0]);
-            gx += dz * (1 - dy) * (v[1][0][1] - v[0][0][1]);
-            gx += dz * dy * (v[1][1][1] - v[0][1][1]);
-            gx *= inv;
-            grad[3 * i] = gx; grad[3 * i + 1] = gy; grad[3 * i + 2] = gz;
+        esdf_interpolate(v, dx, dy, dz, inv, val, grad, i);
+    }
+}
+
+// ---- SCATTERED points.  In the z-fastest grid the eight corners of a cell lie in four different z-rows: a point that shares no
+// cache line with its neighbours costs four 128-byte lines (measured: ~1 KB of HBM traffic per point, 5.7e9 points/s, the
+// memory system already moving 5.8 TB/s - profiles/r4_esdf_sample_pmc.txt).  The BRICKED copy stores the grid as 2 x 2 x 2-cell
+// bricks WITH their one-voxel apron - 3 x 3 x 3 = 27 floats, padded to 32 = exactly one 128-byte line - so that the eight
+// corners of ANY base cell sit in ONE line: brick (ix >> 1, iy >> 1, iz >> 1), entry ((ix & 1) + a) * 9 + ((iy & 1) + b) * 3 +
+// (iz & 1) + c.  Entries beyond the map hold the 0 the reference reads there.  Four times the grid's memory (256 MiB at 256^3),
+// built once per map on first use; the same arithmetic on the same values: bitwise the z-fastest path's results.
+constexpr int BRICK_FLOATS = 32;
+__global__ __launch_bounds__(256) void esdf_brick_build_kernel(DevGrid G, int BX, int BY, int BZ, float *__restrict__ bricks) {
+    const size_t n = (size_t)BX * BY * BZ * BRICK_FLOATS;
+    for (size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x; t < n; t += (size_t)gridDim.x * blockDim.x) {
+        const int e = (int)(t & (BRICK_FLOATS - 1));
+        size_t b = t / BRICK_FLOATS;
+        const int bz = (int)(b % BZ); b /= BZ;
+        const int by = (int)(b % BY); const int bx = (int)(b / BY);
+        float v = 0.f;
+        if (e < 27) {
+            const int x = 2 * bx + e / 9, y = 2 * by + (e / 3) % 3, z = 2 * bz + e % 3;
+            if (x < G.X && y < G.Y && z < G.Z) v = G.esdf[((size_t)x * G.Y + y) * G.Z + z];
         }
+        bricks[t] = v;
+    }
+}
+__global__ __launch_bounds__(256) void esdf_sample_bricked_kernel(DevGrid G, int BY, int BZ, const float *__restrict__ bricks, const double *__restrict__ xyz, long long n,
+                                                                  double *__restrict__ val, double *__restrict__ grad) {
+#pragma clang fp contract(off)
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        int ix, iy, iz;
+        double dx, dy, dz, inv;
+        esdf_base_cell(G, __builtin_nontemporal_load(xyz + 3 * i), __builtin_nontemporal_load(xyz + 3 * i + 1), __builtin_nontemporal_load(xyz + 3 * i + 2), ix, iy, iz, dx, dy, dz, inv);
+        const float *br = bricks + (((size_t)(ix >> 1) * BY + (iy >> 1)) * BZ + (iz >> 1)) * BRICK_FLOATS + (ix & 1) * 9 + (iy & 1) * 3 + (iz & 1);
+        double v[2][2][2];
+#pragma unroll
+        for (int a = 0; a < 2; a++)
+#pragma unroll
+            for (int b = 0; b < 2; b++)
+#pragma unroll
+                for (int c = 0; c < 2; c++) v[a][b][c] = (double)__builtin_nontemporal_load(br + a * 9 + b * 3 + c);
+        esdf_interpolate(v, dx, dy, dz, inv, val, grad, i);
     }
 }
 
@@ -341,7 +395,44 @@ extern "C" int isdf_esdf_sample_device(isdf_ctx *c, const double *d_xyz, long lo
     return ISDF_OK;
 }
 
-extern "C" int isdf_esdf_sample(isdf_ctx *c, const double *xyz, long long n, double *value_out, double *grad_out) {
+// the bricked copy, built (and rebuilt after the ESDF changed) on first use, on the caller's stream
+static int esdf_bricks_ready(isdf_ctx *c, hipStream_t st) {
+    const int BX = (c->grid.X + 1) / 2, BY = (c->grid.Y + 1) / 2, BZ = (c->grid.Z + 1) / 2;
+    const size_t need = (size_t)BX * BY * BZ * isdf::BRICK_FLOATS;
+    if (c->d_esdf_bricks && !c->bricks_stale && c->bricks_cap == need) return ISDF_OK;
+    if (c->bricks_cap != need) {
+        if (c->d_esdf_bricks) { HIPCHK(c, hipDeviceSynchronize()); (void)hipFree(c->d_esdf_bricks); }
+        c->d_esdf_bricks = nullptr; c->bricks_cap = 0;
+        HIPCHK(c, hipMalloc(&c->d_esdf_bricks, need * sizeof(float)));
+        c->bricks_cap = need;
+    }
+    DevGrid G = c->grid;
+    G.esdf = c->d_esdf;
+    hipLaunchKernelGGL(isdf::esdf_brick_build_kernel, dim3(256 * 32), dim3(256), 0, st, G, BX, BY, BZ, c->d_esdf_bricks);
+    HIPCHK(c, hipGetLastError());
+    c->bricks_stale = false;
+    return ISDF_OK;
+}
+extern "C" int isdf_esdf_sample_scattered_device(isdf_ctx *c, const double *d_xyz, long long n, double *d_value, double *d_grad, void *stream) {
+    if (!c) return ISDF_ERR_INVALID_ARG;
+    if (n < 0 || (n > 0 && !d_xyz)) return isdf_fail(c, ISDF_ERR_INVALID_ARG, "bad points");
+    if (!c->have_geom || !c->d_esdf) return isdf_fail(c, ISDF_ERR_STATE, "no ESDF grid (isdf_set_grid with ISDF_GRID_ESDF, or isdf_generate_esdf)");
+    if (n == 0 || (!d_value && !d_grad)) return ISDF_OK;
+    HIPCHK(c, hipSetDevice(c->device));
+    const int rc = esdf_bricks_ready(c, (hipStream_t)stream);
+    if (rc) return rc;
+    DevGrid G = c->grid;
+    const long long blocks = std::min<long long>((n + 255) / 256, 256ll * 64);
+    hipLaunchKernelGGL(isdf::esdf_sample_bricked_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, G, (c->grid.Y + 1) / 2, (c->grid.Z + 1) / 2,
+                       c->d_esdf_bricks, d_xyz, n, d_value, d_grad);
+    HIPCHK(c, hipGetLastError());
+    return ISDF_OK;
+}
+
+static int esdf_sample_host(isdf_ctx *c, const double *xyz, long long n, double *value_out, double *grad_out, bool scattered);
+extern "C" int isdf_esdf_sample(isdf_ctx *c, const double *xyz, long long n, double *value_out, double *grad_out) { return esdf_sample_host(c, xyz, n, value_out, grad_out, false); }
+extern "C" int isdf_esdf_sample_scattered(isdf_ctx *c, const double *xyz, long long n, double *value_out, double *grad_out) { return esdf_sample_host(c, xyz, n, value_out, grad_out, true); }
+static int esdf_sample_host(isdf_ctx *c, const double *xyz, long long n, double *value_out, double *grad_out, bool scattered) {
     if (!c) return ISDF_ERR_INVALID_ARG;
     if (n < 0 || (n > 0 && !xyz)) return isdf_fail(c, ISDF_ERR_INVALID_ARG, "bad points");
     if (!c->have_geom || !c->d_esdf) return isdf_fail(c, ISDF_ERR_STATE, "no ESDF grid (isdf_set_grid with ISDF_GRID_ESDF, or isdf_generate_esdf)");
@@ -353,7 +444,8 @@ extern "C" int isdf_esdf_sample(isdf_ctx *c, const double *xyz, long long n, dou
     int rc = ISDF_OK;
     auto chk = [&](hipError_t e, const char *what) { if (e != hipSuccess && rc == ISDF_OK) { c->err = std::string(what) + ": " + hipGetErrorString(e); rc = ISDF_ERR_HIP; } };
     chk(hipMemcpyAsync(d_p, xyz, (size_t)3 * n * sizeof(double), hipMemcpyHostToDevice, c->stream), "upload points");
-    if (rc == ISDF_OK) rc = isdf_esdf_sample_device(c, d_p, n, value_out ? d_v : nullptr, grad_out ? d_g : nullptr, c->stream);
+    if (rc == ISDF_OK) rc = scattered ? isdf_esdf_sample_scattered_device(c, d_p, n, value_out ? d_v : nullptr, grad_out ? d_g : nullptr, c->stream)
+                                      : isdf_esdf_sample_device(c, d_p, n, value_out ? d_v : nullptr, grad_out ? d_g : nullptr, c->stream);
     if (rc == ISDF_OK && value_out) chk(hipMemcpyAsync(value_out, d_v, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, c->stream), "download values");
     if (rc == ISDF_OK && grad_out) chk(hipMemcpyAsync(grad_out, d_g, (size_t)3 * n * sizeof(double), hipMemcpyDeviceToHost, c->stream), "download gradients");
     chk(hipStreamSynchronize(c->stream), "esdf_sample sync");

@@ -182,17 +182,20 @@ class Engine:
         self._check(self.lib.isdf_shape_eval(self.h, _p(p_rel), n, _p(sdf), _p(grad) if want_grad else None))
         return sdf, grad
 
-    def esdf_sample(self, xyz, want_grad=True):
-        """(value[n], grad[n, 3]) of the environment ESDF at world points (GridMap3D::getSDFValue / getSDFValueWithGrad)."""
+    def esdf_sample(self, xyz, want_grad=True, scattered=False):
+        """(value[n], grad[n, 3]) of the environment ESDF at world points (GridMap3D::getSDFValue / getSDFValueWithGrad);
+        scattered: through the bricked copy (points in no particular order) - the same bits."""
         xyz = np.ascontiguousarray(xyz, dtype=np.float64).reshape(-1, 3)
         n = xyz.shape[0]
         val = np.zeros(n); grad = np.zeros((n, 3)) if want_grad else None
-        self._check(self.lib.isdf_esdf_sample(self.h, _p(xyz), n, _p(val), _p(grad) if want_grad else None))
+        fn = self.lib.isdf_esdf_sample_scattered if scattered else self.lib.isdf_esdf_sample
+        self._check(fn(self.h, _p(xyz), n, _p(val), _p(grad) if want_grad else None))
         return val, grad
 
-    def esdf_sample_device(self, d_xyz, n, d_value, d_grad=0, stream=0):
+    def esdf_sample_device(self, d_xyz, n, d_value, d_grad=0, stream=0, scattered=False):
         """device pointers (ints), asynchronous on `stream`"""
-        self._check(self.lib.isdf_esdf_sample_device(self.h, C.c_void_p(d_xyz), n, C.c_void_p(d_value), C.c_void_p(d_grad), C.c_void_p(stream)))
+        fn = self.lib.isdf_esdf_sample_scattered_device if scattered else self.lib.isdf_esdf_sample_device
+        self._check(fn(self.h, C.c_void_p(d_xyz), n, C.c_void_p(d_value), C.c_void_p(d_grad), C.c_void_p(stream)))
 
     # ---- front end: pose feasibility by kernel convolution (SweptVolumeManager::checkKernelValue)
     def frontend_build(self, fe_cfg):

@@ -236,6 +236,12 @@ int isdf_get_points(isdf_ctx *ctx, double *xyz_out, int capacity);
  * grid.  The _device form takes device pointers and a stream (asynchronous). */
 int isdf_esdf_sample(isdf_ctx *ctx, const double *xyz, long long n, double *value_out, double *grad_out);
 int isdf_esdf_sample_device(isdf_ctx *ctx, const double *d_xyz, long long n, double *d_value_out, double *d_grad_out, void *stream);
+/* The same for points in NO particular order (a point cloud, random queries): sampled from a bricked copy of the ESDF - 2 x 2 x 2-cell
+ * bricks with their one-voxel apron, one 128-byte line each, so the eight corners of any cell come from ONE line instead of four
+ * z-rows (4x the grid's memory, built once per map on first use).  Same arithmetic on the same values: results bit for bit those
+ * of isdf_esdf_sample.  Points along a trajectory are better served by the plain form (neighbours share their lines). */
+int isdf_esdf_sample_scattered(isdf_ctx *ctx, const double *xyz, long long n, double *value_out, double *grad_out);
+int isdf_esdf_sample_scattered_device(isdf_ctx *ctx, const double *d_xyz, long long n, double *d_value_out, double *d_grad_out, void *stream);
 
 /* The installed robot shape by itself, on n BODY-FRAME points (p_rel: n x 3 row-major): sdf_out[i] =
  * BasicShape::getonlySDF(pos_rel) and grad_out[i] (n x 3) = getonlyGrad1(pos_rel) (Shape.hpp:32-57: central difference

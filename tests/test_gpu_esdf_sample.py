@@ -100,3 +100,33 @@ def test_esdf_sample_full_size_properties(pkg, product_lib):
     torch.cuda.synchronize()
     vh, gh = eng.esdf_sample(q[:5000])
     assert np.array_equal(dv[:5000].cpu().numpy(), vh) and np.array_equal(dg[:5000].cpu().numpy(), gh)
+
+
+@pytest.mark.parametrize("dims", [(48, 48, 32), (37, 21, 15), (2, 3, 1)])
+def test_esdf_sample_scattered_equals_plain_bitwise(pkg, orc, product_lib, dims):
+    """The bricked copy (2 x 2 x 2-cell bricks with apron, one 128-byte line each: isdf_esdf_sample_scattered) gives the z-fastest
+    path's bits - even and odd grid sizes, points beyond every face, a grid smaller than a brick, and again after the ESDF
+    changed (the copy is rebuilt)."""
+    capi, synth = pkg.capi, pkg.synth
+    res = 0.5
+    rng = np.random.default_rng(sum(dims))
+    occ = (rng.uniform(size=dims) < 0.1).astype(np.uint8)
+    occ[0, 0, 0] = 1
+    esdf = synth.esdf_from_occupancy(occ, res)
+    cfg = synth.default_config(capi.V3_ESDF_TILE, kernel_size=9, integral_intervs=16, safety_hor=0.5)
+    org = np.array([0.3, -1.0, 2.0])
+    eng = pkg.Engine(cfg); eng.set_grid(esdf, org, res, capi.GRID_ESDF)
+    ext = np.array(dims) * res
+    pts = _points(rng, ext, res, 6000) + org
+    v0, g0 = eng.esdf_sample(pts)
+    v1, g1 = eng.esdf_sample(pts, scattered=True)
+    assert np.array_equal(v0, v1) and np.array_equal(g0, g1)
+    o = orc.Oracle(cfg); o.set_grid(esdf, org, res, capi.GRID_ESDF)
+    ref = np.array([np.concatenate([[d], g]) for d, g in (o.esdf_trilinear(p) for p in pts[:500])])
+    assert np.array_equal(v1[:500], ref[:, 0]) and np.array_equal(g1[:500], ref[:, 1:])
+    # another ESDF on the same ctx: the copy follows
+    esdf2 = (esdf * 0.5 + 0.25).astype(np.float32)
+    eng.set_grid(esdf2, org, res, capi.GRID_ESDF)
+    v2, g2 = eng.esdf_sample(pts, scattered=True)
+    v3, g3 = eng.esdf_sample(pts)
+    assert np.array_equal(v2, v3) and np.array_equal(g2, g3) and not np.array_equal(v2, v1)

@@ -25,17 +25,17 @@ for gridn, res in ((256, 0.2), (512, 0.1)):
             pts = (a + d * (torch.arange(m, dtype=torch.float64, device="cuda").view(1, m, 1) * 0.02)).reshape(-1, 3).contiguous()
         npt = pts.shape[0]
         dv = torch.empty(npt, dtype=torch.float64, device="cuda"); dg = torch.empty(npt, 3, dtype=torch.float64, device="cuda")
-        for grad in (False, True):
+        for grad, scat in ((False, False), (True, False), (True, True)):
             for _ in range(2):
-                eng.esdf_sample_device(pts.data_ptr(), npt, dv.data_ptr(), dg.data_ptr() if grad else 0, st)
+                eng.esdf_sample_device(pts.data_ptr(), npt, dv.data_ptr(), dg.data_ptr() if grad else 0, st, scattered=scat)
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
             for _ in range(5):
-                eng.esdf_sample_device(pts.data_ptr(), npt, dv.data_ptr(), dg.data_ptr() if grad else 0, st)
+                eng.esdf_sample_device(pts.data_ptr(), npt, dv.data_ptr(), dg.data_ptr() if grad else 0, st, scattered=scat)
             e1.record(); torch.cuda.synchronize()
             ms = e0.elapsed_time(e1) / 5
             B = 24 + 32 + 8 + (24 if grad else 0)
-            print(f"{gridn}^3 {name}: {npt:.3g} points, {'value + gradient' if grad else 'value only      '}: {ms:8.3f} ms = {npt / ms / 1e6:8.2f} G points/s, "
+            print(f"{gridn}^3 {name}{' [BRICKED copy]' if scat else ''}: {npt:.3g} points, {'value + gradient' if grad else 'value only      '}: {ms:8.3f} ms = {npt / ms / 1e6:8.2f} G points/s, "
                   f"algorithmic {B} B/point = {npt * B / ms / 1e6:7.1f} GB/s = {npt * B / ms / 1e6 / 8000:.3f} of the 8 TB/s HBM peak", flush=True)
         del pts, dv, dg
     del eng

@@ -10,11 +10,11 @@ def rows(db, ctr):
     cur = sqlite3.connect(db).cursor()
     cols = [r[1] for r in cur.execute("pragma table_info(counters_collection)")]
     key = next((c for c in ("dispatch_id", "dispatch_index", "id", "start") if c in cols), "rowid")
-    return cur.execute(f"select {key}, value from counters_collection where counter_name = ? and kernel_name like '%esdf_sample_kernel%' order by {key}", (ctr,)).fetchall()
+    return cur.execute(f"select {key}, value from counters_collection where counter_name = ? and kernel_name like '%esdf_sample%kernel%' order by {key}", (ctr,)).fetchall()
 
 
 f = rows(sys.argv[1], "FETCH_SIZE"); w = rows(sys.argv[2], "WRITE_SIZE")
-print("# esdf_sample_kernel: HBM traffic per launch = (2 x FETCH_SIZE + WRITE_SIZE) KB; groups of 7 launches = one line of tools/esdf_sample_bench.py 2e7")
+print("# esdf_sample_kernel / esdf_sample_bricked_kernel: HBM traffic per launch = (2 x FETCH_SIZE + WRITE_SIZE) KB; groups of 7 launches = one line of tools/esdf_sample_bench.py 2e7")
 n = min(len(f), len(w))
 for g in range(0, n, 7):
     fs = [v for _, v in f[g:g + 7]][2:]; ws = [v for _, v in w[g:g + 7]][2:]
