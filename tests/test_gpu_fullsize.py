@@ -223,7 +223,7 @@ def test_c5_trefoil_512_every_point(pkg, orc, product_lib):
     c, gT, gC = eng.eval_single(T, cm, tstar=tg)
     c0, gT0, gC0, _ = o.eval(T, cm, tstar=to)
     assert c0 > 0 and abs(c - c0) <= REL_TOL * abs(c0)
-    assert_mesh_v1_free_running("C5 512^3 Trefoil.obj V1, all %d points" % M, tg, to, gT, gT0, gC, gC0)
+    assert_mesh_v1_free_running("C5 512^3 Trefoil.obj V1, all %d points" % M, tg, to, gT, gT0, gC, gC0, allow_ties=2)
 
 
 def test_c1_narrow_slit_mesh_robot(pkg, orc, product_lib):
