@@ -670,7 +670,7 @@ static int eval_device_impl(isdf_ctx *c, int n_traj, int N, const double *d_T, c
         P.coarse_t = c->d_coarse_t; P.coarse_pose = c->d_coarse_pose; P.n_coarse = c->d_n_coarse;
         P.point_partial = c->d_point_partial; P.point_piece = c->d_point_piece; P.point_stat = c->d_point_stat;
         P.point_nr = c->d_point_nr; P.task_buf = c->d_task_buf; P.task_map = c->d_task_map; P.words = c->d_v1_words; P.point_lmask = c->d_point_lmask;
-        const bool scan_lpt = c->shape.kind == ISDF_SHAPE_MESH && !c->env_no_lpt;
+        const bool scan_lpt = !c->env_no_lpt;
         P.scan_ticks = scan_lpt ? c->d_scan_ticks : nullptr; P.scan_order = scan_lpt ? c->d_scan_order : nullptr;
         P.direct_records = fixed_tstar ? 1 : 0;
         { int rc2 = ensure(c, &c->d_hist, &c->hist_cap, (size_t)N); if (rc2) return rc2; }

@@ -123,9 +123,10 @@ __global__ __launch_bounds__(1024) void swept_prepare_kernel(const SweptParams P
         P.words[4] = 0u; P.words[5] = 0u;
     }
     __syncthreads();
-    // Mesh robots: the scan's dispatch order, longest first by last step's measured duration (a point next to the robot's path scans
-    // for a millisecond, most for 50 us: in point order the launch ended on a tail as long as the rest of it).  A counting sort into
-    // 16 classes (bit length of the duration); the order inside a class does not matter - scheduling only.
+    // The scan's dispatch order, longest first by last step's record (mesh robots: the measured duration - a point next to the robot's
+    // path scans for a millisecond, most for 50 us; analytic robots: the fine passes): in point order the launch ended on a tail as
+    // long as the rest of it.  A counting sort into 16 classes (bit length of the record); the order inside a class does not matter -
+    // scheduling only.
     if (P.scan_order) {
         __shared__ unsigned s_cls[16];
         const int np = P.point_end - P.point_begin;
@@ -307,8 +308,8 @@ __device__ __forceinline__ void scan_body(const SweptParams &P, double *s_dyn, c
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const unsigned long long scan_t0 = KIND == ISDF_SHAPE_MESH ? wall_clock64() : 0ull;
-    int pt_rel = MESH ? block : block * SW_WAVES + wave;      // mesh robots: through the longest-first order of the prepare kernel
-    if constexpr (KIND == ISDF_SHAPE_MESH) if (P.scan_order && pt_rel < P.point_end - P.point_begin) pt_rel = __builtin_amdgcn_readfirstlane(P.scan_order[pt_rel]);
+    int pt_rel = MESH ? block : block * SW_WAVES + wave;      // through the longest-first order of the prepare kernel
+    if (P.scan_order && pt_rel < P.point_end - P.point_begin) pt_rel = __builtin_amdgcn_readfirstlane(P.scan_order[pt_rel]);
     const int pt = P.point_begin + pt_rel;
     const bool writer = lane == 0 && (!MESH || wave == 0);       // (the four wavefronts of a mesh workgroup hold the same results)
     const int m_lv = MESH ? P.shape.mesh_levels : 1;       // frames: behind the staged trajectory in the dynamic LDS, one set per wavefront
@@ -432,7 +433,10 @@ __device__ __forceinline__ void scan_body(const SweptParams &P, double *s_dyn, c
     }
     if (writer) {
         P.point_nr[pt] = n_ranges | (n_pass << 8);
-        if constexpr (KIND == ISDF_SHAPE_MESH) if (P.scan_ticks) P.scan_ticks[pt - P.point_begin] = (unsigned)min((wall_clock64() - scan_t0) >> 7, 0x7FFFFFFFull);
+        // next step's dispatch order of the scan, longest first.  Mesh robots: by the measured duration (a pass next to the surface costs
+        // ten times one far from it); analytic robots: by the fine passes (a pass costs the same everywhere: 0 passes = 5 us, 7 = 33 us -
+        // in point order the launch ended on wavefronts that had started 19 us late, profiles/r4_v1_timing_cone.txt)
+        if (P.scan_ticks) P.scan_ticks[pt - P.point_begin] = KIND == ISDF_SHAPE_MESH ? (unsigned)min((wall_clock64() - scan_t0) >> 7, 0x7FFFFFFFull) : (unsigned)n_pass;
         if (dbg) dbg[3] = (wall_clock64() << 16) | (unsigned long long)(n_pass & 0xFFF) | ((unsigned long long)(n_ranges & 0xF) << 12);
     }
     my_nr = n_ranges;
