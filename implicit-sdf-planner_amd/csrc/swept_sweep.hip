@@ -128,15 +128,36 @@ __global__ __launch_bounds__(1024) void swept_prepare_kernel(const SweptParams P
     // long as the rest of it.  A counting sort into 16 classes (bit length of the record); the order inside a class does not matter -
     // scheduling only.
     if (P.scan_order) {
+        // (one LDS atomic per wavefront and class present in it - a thread-per-point atomic on 16 counters serialised: 9.6 us at 7 773 points)
         __shared__ unsigned s_cls[16];
         const int np = P.point_end - P.point_begin;
+        const int lane = threadIdx.x & 63;
+        const unsigned long long lt = (1ull << lane) - 1ull;
         if (threadIdx.x < 16) s_cls[threadIdx.x] = 0u;
         __syncthreads();
-        for (int i = threadIdx.x; i < np; i += blockDim.x) atomicAdd(&s_cls[15 - min(15, 32 - __clz((int)P.scan_ticks[i]))], 1u);
+        for (int i0 = 0; i0 < np; i0 += blockDim.x) {
+            const int i = i0 + threadIdx.x;
+            const int cls = i < np ? 15 - min(15, 32 - __clz((int)P.scan_ticks[i])) : -1;
+            for (int c = 0; c < 16; c++) {
+                const unsigned long long m = __ballot(cls == c);
+                if (m && lane == 0) atomicAdd(&s_cls[c], (unsigned)__popcll(m));
+            }
+        }
         __syncthreads();
         if (threadIdx.x == 0) { unsigned run = 0u; for (int k = 0; k < 16; k++) { const unsigned h = s_cls[k]; s_cls[k] = run; run += h; } }
         __syncthreads();
-        for (int i = threadIdx.x; i < np; i += blockDim.x) P.scan_order[atomicAdd(&s_cls[15 - min(15, 32 - __clz((int)P.scan_ticks[i]))], 1u)] = i;
+        for (int i0 = 0; i0 < np; i0 += blockDim.x) {
+            const int i = i0 + threadIdx.x;
+            const int cls = i < np ? 15 - min(15, 32 - __clz((int)P.scan_ticks[i])) : -1;
+            for (int c = 0; c < 16; c++) {
+                const unsigned long long m = __ballot(cls == c);
+                if (!m) continue;
+                unsigned base = 0u;
+                if (lane == 0) base = atomicAdd(&s_cls[c], (unsigned)__popcll(m));
+                base = (unsigned)__builtin_amdgcn_readfirstlane((int)base);
+                if (cls == c) P.scan_order[base + (unsigned)__popcll(m & lt)] = i;
+            }
+        }
     }
     const int n = s_n;
     for (int k = threadIdx.x; k < n; k += blockDim.x) {
