@@ -128,45 +128,52 @@ __global__ __launch_bounds__(1024) void swept_prepare_kernel(const SweptParams P
     // long as the rest of it.  A counting sort into 16 classes (bit length of the record); the order inside a class does not matter -
     // scheduling only.
     if (P.scan_order) {
-        // (one LDS atomic per wavefront and class present in it - a thread-per-point atomic on 16 counters serialised; the records
-        // of a round of 8 x 1024 points are requested together - a dependent load per 1024 points was 8 trips to memory per pass)
-        __shared__ unsigned s_cls[16];
+        // No atomics (thread-per-point atomics on 16 LDS counters serialised: +10 us at 7 773 points): every wavefront counts its points
+        // per class in scalar registers (16 ballots per record), one fixed-order prefix over [class][wavefront] gives each wavefront its
+        // own output range per class, and the second pass places the points by ballot rank.  The records of a round of 8 x 1024 points
+        // are requested together (a dependent load per 1024 points was 8 trips to memory per pass).
+        __shared__ unsigned s_hist[16][16];      // [class][wavefront]
         const int np = P.point_end - P.point_begin;
-        const int lane = threadIdx.x & 63;
+        const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
         const unsigned long long lt = (1ull << lane) - 1ull;
         constexpr int SU = 8;
-        if (threadIdx.x < 16) s_cls[threadIdx.x] = 0u;
-        __syncthreads();
+        unsigned cnt[16];
+#pragma unroll
+        for (int c = 0; c < 16; c++) cnt[c] = 0u;
         for (int pass = 0; pass < 2; pass++) {
             for (int i0 = 0; i0 < np; i0 += SU * (int)blockDim.x) {
-                int cls[SU];
+                int rec[SU];
 #pragma unroll
                 for (int u = 0; u < SU; u++) {
                     const int i = i0 + u * (int)blockDim.x + (int)threadIdx.x;
-                    cls[u] = i < np ? (int)P.scan_ticks[i] : -1;
+                    rec[u] = i < np ? (int)P.scan_ticks[i] : -1;
                 }
 #pragma unroll
                 for (int u = 0; u < SU; u++) {
                     const int i = i0 + u * (int)blockDim.x + (int)threadIdx.x;
-                    const int cl = cls[u] >= 0 ? 15 - min(15, 32 - __clz(cls[u])) : -1;
-                    unsigned long long todo = __ballot(cl >= 0);
-                    while (todo) {                                  // the classes present in this wavefront, one after the other
-                        const int c = __builtin_amdgcn_readlane(cl, __ffsll((long long)todo) - 1);
+                    const int cl = rec[u] >= 0 ? 15 - min(15, 32 - __clz(rec[u])) : -1;
+#pragma unroll
+                    for (int c = 0; c < 16; c++) {
                         const unsigned long long m = __ballot(cl == c);
-                        todo &= ~m;
-                        unsigned base = 0u;
-                        if (lane == 0) base = atomicAdd(&s_cls[c], (unsigned)__popcll(m));
-                        if (pass == 1) {
-                            base = (unsigned)__builtin_amdgcn_readfirstlane((int)base);
-                            if (cl == c) P.scan_order[base + (unsigned)__popcll(m & lt)] = i;
-                        }
+                        if (pass == 1 && cl == c) P.scan_order[cnt[c] + (unsigned)__popcll(m & lt)] = i;
+                        cnt[c] += (unsigned)__popcll(m);
                     }
                 }
             }
-            __syncthreads();
             if (pass == 0) {
-                if (threadIdx.x == 0) { unsigned run = 0u; for (int k = 0; k < 16; k++) { const unsigned h = s_cls[k]; s_cls[k] = run; run += h; } }
+                if (lane == 0) {
+#pragma unroll
+                    for (int c = 0; c < 16; c++) s_hist[c][wv] = cnt[c];
+                }
                 __syncthreads();
+                if (threadIdx.x == 0) {
+                    unsigned run = 0u;
+                    const int nw = (int)blockDim.x >> 6;
+                    for (int c = 0; c < 16; c++) for (int w = 0; w < nw; w++) { const unsigned h = s_hist[c][w]; s_hist[c][w] = run; run += h; }
+                }
+                __syncthreads();
+#pragma unroll
+                for (int c = 0; c < 16; c++) cnt[c] = s_hist[c][wv];
             }
         }
     }
