@@ -164,12 +164,24 @@ __global__ __launch_bounds__(1024) void swept_prepare_kernel(const SweptParams P
                 if (lane == 0) {
 #pragma unroll
                     for (int c = 0; c < 16; c++) s_hist[c][wv] = cnt[c];
+                }       // (the launch has 16 wavefronts: every column is written)
+                __syncthreads();
+                // exclusive prefix over the 256 counters in [class][wavefront] order: one thread per counter (a single thread walking
+                // them through LDS was 20 us of dependent round trips)
+                __shared__ unsigned s_tot[4];
+                unsigned h = 0u, v = 0u;
+                if (threadIdx.x < 256) {
+                    h = (&s_hist[0][0])[threadIdx.x];
+                    v = h;
+#pragma unroll
+                    for (int o = 1; o < 64; o <<= 1) { const unsigned nb = __shfl_up(v, o, 64); if (lane >= o) v += nb; }
+                    if (lane == 63) s_tot[wv] = v;
                 }
                 __syncthreads();
-                if (threadIdx.x == 0) {
-                    unsigned run = 0u;
-                    const int nw = (int)blockDim.x >> 6;
-                    for (int c = 0; c < 16; c++) for (int w = 0; w < nw; w++) { const unsigned h = s_hist[c][w]; s_hist[c][w] = run; run += h; }
+                if (threadIdx.x < 256) {
+                    unsigned base = 0u;
+                    for (int w = 0; w < wv; w++) base += s_tot[w];
+                    (&s_hist[0][0])[threadIdx.x] = base + v - h;
                 }
                 __syncthreads();
 #pragma unroll
