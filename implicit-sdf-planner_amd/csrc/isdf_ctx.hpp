@@ -55,7 +55,8 @@ struct isdf_ctx {
     int *d_n_coarse = nullptr;
     double *d_point_partial = nullptr; int *d_point_piece = nullptr; unsigned long long *d_point_stat = nullptr; int point_cap = 0;
     int *d_point_nr = nullptr; double *d_task_buf = nullptr; unsigned *d_task_map = nullptr, *d_v1_words = nullptr, *d_point_lmask = nullptr;
-    unsigned *d_scan_ticks = nullptr; int *d_scan_order = nullptr;     // V1, mesh robots: last step's scan duration per point / this step's dispatch order of the scan
+    unsigned *d_scan_ticks = nullptr; int *d_scan_order = nullptr;     // V1: a step's scan records (class | rank per point) / the dispatch order of the NEXT step's scan built from them
+    long long scan_order_b = -1, scan_order_e = -1; unsigned long long scan_order_epoch = 0, points_epoch = 1;   // ... and the shard of which points it is for
     double *d_hist = nullptr; size_t hist_cap = 0;
     // profiling
     bool fuse_small = true;     // developer switch ISDF_NO_FUSE=1: always sweep + tail as two launches

@@ -476,6 +476,7 @@ extern "C" int isdf_set_points(isdf_ctx *c, const double *xyz, int M) {
     if (c->d_points) { (void)hipFree(c->d_points); c->d_points = nullptr; }
     if (c->d_tstar) { (void)hipFree(c->d_tstar); c->d_tstar = nullptr; }
     c->M = M;
+    c->points_epoch++;
     if (c->d_v1_words) HIPCHK(c, hipMemset(c->d_v1_words, 0, 8 * sizeof(unsigned)));
     if (M > 0) {
         HIPCHK(c, hipMalloc(&c->d_points, (size_t)3 * M * sizeof(double)));
@@ -663,15 +664,20 @@ static int eval_device_impl(isdf_ctx *c, int n_traj, int N, const double *d_T, c
             HIPCHK(c, hipMalloc(&c->d_scan_ticks, (size_t)c->M * sizeof(unsigned)));
             HIPCHK(c, hipMemset(c->d_scan_ticks, 0, (size_t)c->M * sizeof(unsigned)));
             HIPCHK(c, hipMalloc(&c->d_scan_order, (size_t)c->M * sizeof(int)));
-            if (!c->d_v1_words) HIPCHK(c, hipMalloc(&c->d_v1_words, 8 * sizeof(unsigned)));
-            HIPCHK(c, hipMemset(c->d_v1_words, 0, 8 * sizeof(unsigned)));
+            if (!c->d_v1_words) HIPCHK(c, hipMalloc(&c->d_v1_words, 32 * sizeof(unsigned)));
+            HIPCHK(c, hipMemset(c->d_v1_words, 0, 32 * sizeof(unsigned)));
+            c->scan_order_b = c->scan_order_e = -1;
             c->point_cap = c->M;
         }
         P.coarse_t = c->d_coarse_t; P.coarse_pose = c->d_coarse_pose; P.n_coarse = c->d_n_coarse;
         P.point_partial = c->d_point_partial; P.point_piece = c->d_point_piece; P.point_stat = c->d_point_stat;
         P.point_nr = c->d_point_nr; P.task_buf = c->d_task_buf; P.task_map = c->d_task_map; P.words = c->d_v1_words; P.point_lmask = c->d_point_lmask;
-        const bool scan_lpt = !c->env_no_lpt;
-        P.scan_ticks = scan_lpt ? c->d_scan_ticks : nullptr; P.scan_order = scan_lpt ? c->d_scan_order : nullptr;
+        // the scan's dispatch order: built by step k (ranks in the scan kernel, places in the back-prop kernel) for step k + 1 - valid
+        // only for the same shard of the same points
+        const bool scan_lpt = !c->env_no_lpt && !fixed_tstar;
+        P.scan_rank = scan_lpt ? c->d_scan_ticks : nullptr; P.scan_order_out = scan_lpt ? c->d_scan_order : nullptr;
+        P.scan_order = (scan_lpt && c->scan_order_b == (long long)b && c->scan_order_e == (long long)e && c->scan_order_epoch == c->points_epoch) ? c->d_scan_order : nullptr;
+        if (scan_lpt) { c->scan_order_b = b; c->scan_order_e = e; c->scan_order_epoch = c->points_epoch; }
         P.direct_records = fixed_tstar ? 1 : 0;
         { int rc2 = ensure(c, &c->d_hist, &c->hist_cap, (size_t)N); if (rc2) return rc2; }
         P.hist = c->d_hist;

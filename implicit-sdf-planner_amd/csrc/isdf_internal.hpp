@@ -133,10 +133,11 @@ struct SweptParams {
     int *point_nr;              // [M] scan kernel: intervals | scan passes << 8
     double *task_buf;           // [M][32][6] per (point, interval): in (lb, ub, seed), out (t, sdf, gradient, counters)
     unsigned *task_map;         // [<= 32 M] task list of the descent: point (relative to point_begin) << 5 | interval
-    unsigned *scan_ticks;       // [M] mesh robots: how long the scan of point i took last step (1.28 us units); null: scan in point order
-    int *scan_order;            // [M] ... and this step's dispatch order of the scan, longest first (built by the prepare kernel)
+    unsigned *scan_rank;        // [M] this step's scan record of point i: class << 27 | rank in its class (null: no order is being built)
+    const int *scan_order;      // [M] this step's dispatch order of the scan, longest first by LAST step's records (null: point order)
+    int *scan_order_out;        // [M] the next step's, written by the back-prop kernel from scan_rank and the class counts words[8..24)
     unsigned *point_lmask;      // [M] bit r: the descent of interval r was long last step (set by the descent kernel, consumed by the scan's list builder)
-    unsigned *words;            // [0] tasks at the front of the list (long last step) [2] tasks at its back: zeroed by the prepare kernel, reserved by the
+    unsigned *words;            // 32 words: [8..24) points per scan-order class (zeroed by the prepare kernel); [0] tasks at the front of the list (long last step) [2] tasks at its back: zeroed by the prepare kernel, reserved by the
                                 // scan kernel's workgroups
     int direct_records;         // 1: the records in point_partial were written by the fixed-t* kernel (no task slots)
     unsigned long long *point_stat;   // [M] active | intervals << 1 | passes << 9 | descent iterations << 25 (statistics)

@@ -543,6 +543,7 @@ extern "C" int isdf_gather_points(isdf_ctx *c, const double *waypoints, int n_wa
         (void)hipFree(bits); (void)hipFree(marks); (void)hipFree(chunk); (void)hipFree(d_boxes);
     }
     c->M = M;
+    c->points_epoch++;
     if (M_out) *M_out = M;
     ISDF_REPLICATE(c, isdf_gather_points(p_, waypoints, n_waypoints, half, offset_opt, nullptr));      // the same ordered set on every device
     return ISDF_OK;

@@ -123,72 +123,8 @@ __global__ __launch_bounds__(1024) void swept_prepare_kernel(const SweptParams P
         P.words[4] = 0u; P.words[5] = 0u;
     }
     __syncthreads();
-    // The scan's dispatch order, longest first by last step's record (mesh robots: the measured duration - a point next to the robot's
-    // path scans for a millisecond, most for 50 us; analytic robots: the fine passes): in point order the launch ended on a tail as
-    // long as the rest of it.  A counting sort into 16 classes (bit length of the record); the order inside a class does not matter -
-    // scheduling only.
-    if (P.scan_order) {
-        // No atomics (thread-per-point atomics on 16 LDS counters serialised: +10 us at 7 773 points): every wavefront counts its points
-        // per class in scalar registers (16 ballots per record), one fixed-order prefix over [class][wavefront] gives each wavefront its
-        // own output range per class, and the second pass places the points by ballot rank.  The records of a round of 8 x 1024 points
-        // are requested together (a dependent load per 1024 points was 8 trips to memory per pass).
-        __shared__ unsigned s_hist[16][16];      // [class][wavefront]
-        const int np = P.point_end - P.point_begin;
-        const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-        const unsigned long long lt = (1ull << lane) - 1ull;
-        constexpr int SU = 8;
-        unsigned cnt[16];
-#pragma unroll
-        for (int c = 0; c < 16; c++) cnt[c] = 0u;
-        for (int pass = 0; pass < 2; pass++) {
-            for (int i0 = 0; i0 < np; i0 += SU * (int)blockDim.x) {
-                int rec[SU];
-#pragma unroll
-                for (int u = 0; u < SU; u++) {
-                    const int i = i0 + u * (int)blockDim.x + (int)threadIdx.x;
-                    rec[u] = i < np ? (int)P.scan_ticks[i] : -1;
-                }
-#pragma unroll
-                for (int u = 0; u < SU; u++) {
-                    const int i = i0 + u * (int)blockDim.x + (int)threadIdx.x;
-                    const int cl = rec[u] >= 0 ? 15 - min(15, 32 - __clz(rec[u])) : -1;
-#pragma unroll
-                    for (int c = 0; c < 16; c++) {
-                        const unsigned long long m = __ballot(cl == c);
-                        if (pass == 1 && cl == c) P.scan_order[cnt[c] + (unsigned)__popcll(m & lt)] = i;
-                        cnt[c] += (unsigned)__popcll(m);
-                    }
-                }
-            }
-            if (pass == 0) {
-                if (lane == 0) {
-#pragma unroll
-                    for (int c = 0; c < 16; c++) s_hist[c][wv] = cnt[c];
-                }       // (the launch has 16 wavefronts: every column is written)
-                __syncthreads();
-                // exclusive prefix over the 256 counters in [class][wavefront] order: one thread per counter (a single thread walking
-                // them through LDS was 20 us of dependent round trips)
-                __shared__ unsigned s_tot[4];
-                unsigned h = 0u, v = 0u;
-                if (threadIdx.x < 256) {
-                    h = (&s_hist[0][0])[threadIdx.x];
-                    v = h;
-#pragma unroll
-                    for (int o = 1; o < 64; o <<= 1) { const unsigned nb = __shfl_up(v, o, 64); if (lane >= o) v += nb; }
-                    if (lane == 63) s_tot[wv] = v;
-                }
-                __syncthreads();
-                if (threadIdx.x < 256) {
-                    unsigned base = 0u;
-                    for (int w = 0; w < wv; w++) base += s_tot[w];
-                    (&s_hist[0][0])[threadIdx.x] = base + v - h;
-                }
-                __syncthreads();
-#pragma unroll
-                for (int c = 0; c < 16; c++) cnt[c] = s_hist[c][wv];
-            }
-        }
-    }
+    // (the scan's dispatch order for THIS step was written by the previous step's back-prop kernel; this step's class counters:)
+    if (threadIdx.x < 16) P.words[8 + threadIdx.x] = 0u;
     const int n = s_n;
     for (int k = threadIdx.x; k < n; k += blockDim.x) {
         d3 x; m3 R;
@@ -484,10 +420,17 @@ __device__ __forceinline__ void scan_body(const SweptParams &P, double *s_dyn, c
     }
     if (writer) {
         P.point_nr[pt] = n_ranges | (n_pass << 8);
-        // next step's dispatch order of the scan, longest first.  Mesh robots: by the measured duration (a pass next to the surface costs
-        // ten times one far from it); analytic robots: by the fine passes (a pass costs the same everywhere: 0 passes = 5 us, 7 = 33 us -
-        // in point order the launch ended on wavefronts that had started 19 us late, profiles/r4_v1_timing_cone.txt)
-        if (P.scan_ticks) P.scan_ticks[pt - P.point_begin] = KIND == ISDF_SHAPE_MESH ? (unsigned)min((wall_clock64() - scan_t0) >> 7, 0x7FFFFFFFull) : (unsigned)n_pass;
+        // Next step's dispatch order of the scan, longest first (in point order the launch ended on wavefronts that had started 19 us
+        // late, profiles/r4_v1_timing_cone.txt).  Mesh robots: by the measured duration (a pass next to the surface costs ten times one
+        // far from it); analytic robots: by the fine passes (a pass costs the same everywhere: 0 passes = 5 us, 7 = 33 us).  A
+        // counting sort spread over the step: 16 classes (bit length of the record), a point takes its rank in its class here (one
+        // atomic per point), the back-prop kernel - a thread per point, after every class is complete - places it.  Scheduling
+        // only: the order inside a class is whatever the atomics made it.
+        if (P.scan_rank) {
+            const unsigned rec = KIND == ISDF_SHAPE_MESH ? (unsigned)min((wall_clock64() - scan_t0) >> 7, 0x7FFFFFFFull) : (unsigned)n_pass;
+            const unsigned cl = (unsigned)(15 - min(15, 32 - __clz((int)rec)));
+            P.scan_rank[pt - P.point_begin] = (cl << 27) | atomicAdd(&P.words[8 + cl], 1u);
+        }
         if (dbg) dbg[3] = (wall_clock64() << 16) | (unsigned long long)(n_pass & 0xFFF) | ((unsigned long long)(n_ranges & 0xF) << 12);
     }
     my_nr = n_ranges;
@@ -500,7 +443,7 @@ __device__ __forceinline__ void scan_body(const SweptParams &P, double *s_dyn, c
     // Scheduling only: which wavefront evaluates what has no influence on any result (every task has its own result slot), so
     // the list needs no particular order within the two classes: ONE reservation per workgroup and class (two atomics; round 3
     // built the list in point order in the workgroup that finished last - 15 us of one workgroup between the two launches).
-    // (words[0] / words[2]: tasks at the front / at the back, zeroed by the prepare kernel.)
+    // (words[0] / words[2]: tasks at the front / at the back, zeroed by the prepare kernel; words[8..24): the scan-order classes.)
     {
         unsigned vt = 0u;                                       // bit r: task r of my point was long last step
         if (pt < P.point_end && my_nr > 0 && (!MESH || wave == 0)) {
@@ -754,6 +697,12 @@ __global__ __launch_bounds__(64) void swept_fixed_kernel(const SweptParams P, co
 // flatness reverse mode, the 18 + 1 + 1 doubles the reduction sums.
 __device__ __forceinline__ void backprop_body(const SweptParams &P, const int pt) {
     if (pt >= P.point_end) return;
+    if (P.scan_order_out) {               // the next step's scan order: this point's place = its class's base + its rank (scan_body)
+        const unsigned cr = P.scan_rank[pt - P.point_begin], cl = cr >> 27;
+        unsigned base = 0u;
+        for (unsigned k = 0; k < cl; k++) base += P.words[8 + k];
+        P.scan_order_out[base + (cr & 0x7FFFFFFu)] = pt - P.point_begin;
+    }
     const TrajView tr{P.T, P.coeffs, P.N};
     double *o = P.point_partial + (size_t)pt * PARTIAL_STRIDE;
     const d3 p = mk3(P.points[3 * pt], P.points[3 * pt + 1], P.points[3 * pt + 2]);
