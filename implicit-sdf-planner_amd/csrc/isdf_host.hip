@@ -672,12 +672,14 @@ static int eval_device_impl(isdf_ctx *c, int n_traj, int N, const double *d_T, c
         P.coarse_t = c->d_coarse_t; P.coarse_pose = c->d_coarse_pose; P.n_coarse = c->d_n_coarse;
         P.point_partial = c->d_point_partial; P.point_piece = c->d_point_piece; P.point_stat = c->d_point_stat;
         P.point_nr = c->d_point_nr; P.task_buf = c->d_task_buf; P.task_map = c->d_task_map; P.words = c->d_v1_words; P.point_lmask = c->d_point_lmask;
-        // the scan's dispatch order: built by step k (ranks in the scan kernel, places in the back-prop kernel) for step k + 1 - valid
-        // only for the same shard of the same points
+        // The scan's dispatch order, longest first.  Mesh robots: sorted in this step's prepare kernel from last step's durations.  Analytic
+        // robots: written by step k's back-prop kernel for step k + 1 - valid only for the same shard of the same points.
         const bool scan_lpt = !c->env_no_lpt && !fixed_tstar;
-        P.scan_rank = scan_lpt ? c->d_scan_ticks : nullptr; P.scan_order_out = scan_lpt ? c->d_scan_order : nullptr;
-        P.scan_order = (scan_lpt && c->scan_order_b == (long long)b && c->scan_order_e == (long long)e && c->scan_order_epoch == c->points_epoch) ? c->d_scan_order : nullptr;
-        if (scan_lpt) { c->scan_order_b = b; c->scan_order_e = e; c->scan_order_epoch = c->points_epoch; }
+        const bool sort_here = c->shape.kind == ISDF_SHAPE_MESH;
+        P.scan_ticks = scan_lpt ? c->d_scan_ticks : nullptr; P.scan_order_out = scan_lpt ? c->d_scan_order : nullptr; P.scan_sort_here = (scan_lpt && sort_here) ? 1 : 0;
+        const bool order_valid = sort_here || (c->scan_order_b == (long long)b && c->scan_order_e == (long long)e && c->scan_order_epoch == c->points_epoch);
+        P.scan_order = (scan_lpt && order_valid) ? c->d_scan_order : nullptr;
+        if (scan_lpt) { c->scan_order_b = sort_here ? -1 : b; c->scan_order_e = sort_here ? -1 : e; c->scan_order_epoch = c->points_epoch; }
         P.direct_records = fixed_tstar ? 1 : 0;
         { int rc2 = ensure(c, &c->d_hist, &c->hist_cap, (size_t)N); if (rc2) return rc2; }
         P.hist = c->d_hist;

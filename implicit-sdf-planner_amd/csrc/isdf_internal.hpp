@@ -133,11 +133,12 @@ struct SweptParams {
     int *point_nr;              // [M] scan kernel: intervals | scan passes << 8
     double *task_buf;           // [M][32][6] per (point, interval): in (lb, ub, seed), out (t, sdf, gradient, counters)
     unsigned *task_map;         // [<= 32 M] task list of the descent: point (relative to point_begin) << 5 | interval
-    unsigned *scan_rank;        // [M] this step's scan record of point i: class << 27 | rank in its class (null: no order is being built)
+    unsigned *scan_ticks;       // [M] this step's scan record of point i (mesh robots: its duration in 1.28 us units; analytic: its fine passes); null: none kept
     const int *scan_order;      // [M] this step's dispatch order of the scan, longest first by LAST step's records (null: point order)
-    int *scan_order_out;        // [M] the next step's, written by the back-prop kernel from scan_rank and the class counts words[8..24)
+    int *scan_order_out;        // [M] where an order is written: by the prepare kernel for THIS step (scan_sort_here, mesh robots), else by the back-prop kernel for the NEXT
+    int scan_sort_here;
     unsigned *point_lmask;      // [M] bit r: the descent of interval r was long last step (set by the descent kernel, consumed by the scan's list builder)
-    unsigned *words;            // 32 words: [8..24) points per scan-order class (zeroed by the prepare kernel); [0] tasks at the front of the list (long last step) [2] tasks at its back: zeroed by the prepare kernel, reserved by the
+    unsigned *words;            // 32 words: [8], [9] the two ends of the next scan order (analytic robots); [0] tasks at the front of the list (long last step) [2] tasks at its back: zeroed by the prepare kernel, reserved by the
                                 // scan kernel's workgroups
     int direct_records;         // 1: the records in point_partial were written by the fixed-t* kernel (no task slots)
     unsigned long long *point_stat;   // [M] active | intervals << 1 | passes << 9 | descent iterations << 25 (statistics)

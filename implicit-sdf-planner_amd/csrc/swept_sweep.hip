@@ -123,8 +123,23 @@ __global__ __launch_bounds__(1024) void swept_prepare_kernel(const SweptParams P
         P.words[4] = 0u; P.words[5] = 0u;
     }
     __syncthreads();
-    // (the scan's dispatch order for THIS step was written by the previous step's back-prop kernel; this step's class counters:)
-    if (threadIdx.x < 16) P.words[8 + threadIdx.x] = 0u;
+    // The scan's dispatch order, longest first by last step's records - in point order the launch ends on a tail as long as the rest of
+    // it.  Scheduling only.  Mesh robots (a point next to the robot's path scans for a millisecond, most for 50 us): a counting sort
+    // into 16 classes (bit length of the measured duration) right here - ~10 us of LDS atomics that a millisecond step does not
+    // notice.  Analytic robots (a 0.16 ms step: 10 us would eat the gain): two classes, placed by the previous step's back-prop
+    // kernel (backprop_body); this kernel only empties that list's two counters.
+    if (threadIdx.x == 0) { P.words[8] = 0u; P.words[9] = 0u; }
+    if (P.scan_sort_here) {
+        __shared__ unsigned s_cls[16];
+        const int np = P.point_end - P.point_begin;
+        if (threadIdx.x < 16) s_cls[threadIdx.x] = 0u;
+        __syncthreads();
+        for (int i = threadIdx.x; i < np; i += blockDim.x) atomicAdd(&s_cls[15 - min(15, 32 - __clz((int)P.scan_ticks[i]))], 1u);
+        __syncthreads();
+        if (threadIdx.x == 0) { unsigned run = 0u; for (int k = 0; k < 16; k++) { const unsigned h = s_cls[k]; s_cls[k] = run; run += h; } }
+        __syncthreads();
+        for (int i = threadIdx.x; i < np; i += blockDim.x) P.scan_order_out[atomicAdd(&s_cls[15 - min(15, 32 - __clz((int)P.scan_ticks[i]))], 1u)] = i;
+    }
     const int n = s_n;
     for (int k = threadIdx.x; k < n; k += blockDim.x) {
         d3 x; m3 R;
@@ -420,17 +435,9 @@ __device__ __forceinline__ void scan_body(const SweptParams &P, double *s_dyn, c
     }
     if (writer) {
         P.point_nr[pt] = n_ranges | (n_pass << 8);
-        // Next step's dispatch order of the scan, longest first (in point order the launch ended on wavefronts that had started 19 us
-        // late, profiles/r4_v1_timing_cone.txt).  Mesh robots: by the measured duration (a pass next to the surface costs ten times one
-        // far from it); analytic robots: by the fine passes (a pass costs the same everywhere: 0 passes = 5 us, 7 = 33 us).  A
-        // counting sort spread over the step: 16 classes (bit length of the record), a point takes its rank in its class here (one
-        // atomic per point), the back-prop kernel - a thread per point, after every class is complete - places it.  Scheduling
-        // only: the order inside a class is whatever the atomics made it.
-        if (P.scan_rank) {
-            const unsigned rec = KIND == ISDF_SHAPE_MESH ? (unsigned)min((wall_clock64() - scan_t0) >> 7, 0x7FFFFFFFull) : (unsigned)n_pass;
-            const unsigned cl = (unsigned)(15 - min(15, 32 - __clz((int)rec)));
-            P.scan_rank[pt - P.point_begin] = (cl << 27) | atomicAdd(&P.words[8 + cl], 1u);
-        }
+        // this point's record for the next step's dispatch order of the scan: mesh robots the measured duration (a pass next to the
+        // surface costs ten times one far from it), analytic robots the fine passes (a pass costs the same everywhere)
+        if (P.scan_ticks) P.scan_ticks[pt - P.point_begin] = KIND == ISDF_SHAPE_MESH ? (unsigned)min((wall_clock64() - scan_t0) >> 7, 0x7FFFFFFFull) : (unsigned)n_pass;
         if (dbg) dbg[3] = (wall_clock64() << 16) | (unsigned long long)(n_pass & 0xFFF) | ((unsigned long long)(n_ranges & 0xF) << 12);
     }
     my_nr = n_ranges;
@@ -443,7 +450,7 @@ __device__ __forceinline__ void scan_body(const SweptParams &P, double *s_dyn, c
     // Scheduling only: which wavefront evaluates what has no influence on any result (every task has its own result slot), so
     // the list needs no particular order within the two classes: ONE reservation per workgroup and class (two atomics; round 3
     // built the list in point order in the workgroup that finished last - 15 us of one workgroup between the two launches).
-    // (words[0] / words[2]: tasks at the front / at the back, zeroed by the prepare kernel; words[8..24): the scan-order classes.)
+    // (words[0] / words[2]: tasks at the front / at the back, zeroed by the prepare kernel.)
     {
         unsigned vt = 0u;                                       // bit r: task r of my point was long last step
         if (pt < P.point_end && my_nr > 0 && (!MESH || wave == 0)) {
@@ -696,13 +703,23 @@ __global__ __launch_bounds__(64) void swept_fixed_kernel(const SweptParams P, co
 // Back-prop at t* (back_end_optimizer.hpp:578-646): one THREAD per obstacle point - penalty (mu = 0.01), pose Jacobians,
 // flatness reverse mode, the 18 + 1 + 1 doubles the reduction sums.
 __device__ __forceinline__ void backprop_body(const SweptParams &P, const int pt) {
-    if (pt >= P.point_end) return;
-    if (P.scan_order_out) {               // the next step's scan order: this point's place = its class's base + its rank (scan_body)
-        const unsigned cr = P.scan_rank[pt - P.point_begin], cl = cr >> 27;
-        unsigned base = 0u;
-        for (unsigned k = 0; k < cl; k++) base += P.words[8 + k];
-        P.scan_order_out[base + (cr & 0x7FFFFFFu)] = pt - P.point_begin;
+    // Analytic robots: the NEXT step's dispatch order of the scan (this kernel is the step's thread-per-point pass that runs after
+    // the scan).  Two classes - a point whose scan made 3 or more fine passes is heavy (17-33 us against 5-13) - as a two-ended list:
+    // heavy points fill it from the front, the others from the back; one reservation per wavefront and class (words[8], words[9],
+    // emptied by the prepare kernel).  In point order the scan launch ended on wavefronts that had started 19 us late
+    // (profiles/r4_v1_timing_cone.txt: 47.6 us; longest first: 34 us).
+    if (P.scan_order_out && !P.scan_sort_here) {
+        const int lane = (int)__lane_id();
+        const bool ok = pt < P.point_end;
+        const bool heavy = ok && P.scan_ticks[ok ? pt - P.point_begin : 0] >= 3u;
+        const unsigned long long mh = __ballot(heavy), ml = __ballot(ok && !heavy), lt = (1ull << lane) - 1ull;
+        unsigned bh = 0u, bl = 0u;
+        if (lane == 0) { if (mh) bh = atomicAdd(&P.words[8], (unsigned)__popcll(mh)); if (ml) bl = atomicAdd(&P.words[9], (unsigned)__popcll(ml)); }
+        bh = (unsigned)__builtin_amdgcn_readfirstlane((int)bh); bl = (unsigned)__builtin_amdgcn_readfirstlane((int)bl);
+        if (heavy) P.scan_order_out[bh + (unsigned)__popcll(mh & lt)] = pt - P.point_begin;
+        else if (ok) P.scan_order_out[(unsigned)(P.point_end - P.point_begin) - 1u - (bl + (unsigned)__popcll(ml & lt))] = pt - P.point_begin;
     }
+    if (pt >= P.point_end) return;
     const TrajView tr{P.T, P.coeffs, P.N};
     double *o = P.point_partial + (size_t)pt * PARTIAL_STRIDE;
     const d3 p = mk3(P.points[3 * pt], P.points[3 * pt + 1], P.points[3 * pt + 2]);
