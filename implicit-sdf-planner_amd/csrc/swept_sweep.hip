@@ -702,24 +702,7 @@ __global__ __launch_bounds__(64) void swept_fixed_kernel(const SweptParams P, co
 
 // Back-prop at t* (back_end_optimizer.hpp:578-646): one THREAD per obstacle point - penalty (mu = 0.01), pose Jacobians,
 // flatness reverse mode, the 18 + 1 + 1 doubles the reduction sums.
-__device__ __forceinline__ void backprop_body(const SweptParams &P, const int pt) {
-    // Analytic robots: the NEXT step's dispatch order of the scan (this kernel is the step's thread-per-point pass that runs after
-    // the scan).  Two classes - a point whose scan made 3 or more fine passes is heavy (17-33 us against 5-13) - as a two-ended list:
-    // heavy points fill it from the front, the others from the back; one reservation per wavefront and class (words[8], words[9],
-    // emptied by the prepare kernel).  In point order the scan launch ended on wavefronts that had started 19 us late
-    // (profiles/r4_v1_timing_cone.txt: 47.6 us; longest first: 34 us).
-    if (P.scan_order_out && !P.scan_sort_here) {
-        const int lane = (int)__lane_id();
-        const bool ok = pt < P.point_end;
-        const bool heavy = ok && P.scan_ticks[ok ? pt - P.point_begin : 0] >= 3u;
-        const unsigned long long mh = __ballot(heavy), ml = __ballot(ok && !heavy), lt = (1ull << lane) - 1ull;
-        unsigned bh = 0u, bl = 0u;
-        if (lane == 0) { if (mh) bh = atomicAdd(&P.words[8], (unsigned)__popcll(mh)); if (ml) bl = atomicAdd(&P.words[9], (unsigned)__popcll(ml)); }
-        bh = (unsigned)__builtin_amdgcn_readfirstlane((int)bh); bl = (unsigned)__builtin_amdgcn_readfirstlane((int)bl);
-        if (heavy) P.scan_order_out[bh + (unsigned)__popcll(mh & lt)] = pt - P.point_begin;
-        else if (ok) P.scan_order_out[(unsigned)(P.point_end - P.point_begin) - 1u - (bl + (unsigned)__popcll(ml & lt))] = pt - P.point_begin;
-    }
-    if (pt >= P.point_end) return;
+__device__ __forceinline__ void backprop_point(const SweptParams &P, const int pt) {
     const TrajView tr{P.T, P.coeffs, P.N};
     double *o = P.point_partial + (size_t)pt * PARTIAL_STRIDE;
     const d3 p = mk3(P.points[3 * pt], P.points[3 * pt + 1], P.points[3 * pt + 2]);
@@ -792,6 +775,31 @@ __device__ __forceinline__ void backprop_body(const SweptParams &P, const int pt
     P.point_piece[pt] = all_zero ? -1 : i;
     P.point_stat[pt] = (counters << 1) | (active ? 1ull : 0ull);
     P.tstar[pt] = tstar;
+}
+__device__ __forceinline__ void backprop_body(const SweptParams &P, const int pt) {
+    // Analytic robots: the NEXT step's dispatch order of the scan (this kernel is the step's thread-per-point pass that runs after
+    // the scan).  Two classes - a point whose scan made 3 or more fine passes is heavy (17-33 us against 5-13) - as a two-ended list:
+    // heavy points fill it from the front, the others from the back; one reservation per wavefront and class (words[8], words[9],
+    // emptied by the prepare kernel), requested here and used after the point's own work (their round trip hides behind it).  In
+    // point order the scan launch ended on wavefronts that had started 19 us late (profiles/r4_v1_timing_cone.txt).
+    const bool build = P.scan_order_out && !P.scan_sort_here;
+    const int lane = (int)__lane_id();
+    const bool ok = pt < P.point_end;
+    bool heavy = false;
+    unsigned long long mh = 0ull, ml = 0ull;
+    unsigned bh = 0u, bl = 0u;
+    if (build) {
+        heavy = ok && P.scan_ticks[ok ? pt - P.point_begin : 0] >= 3u;
+        mh = __ballot(heavy); ml = __ballot(ok && !heavy);
+        if (lane == 0) { if (mh) bh = atomicAdd(&P.words[8], (unsigned)__popcll(mh)); if (ml) bl = atomicAdd(&P.words[9], (unsigned)__popcll(ml)); }
+    }
+    if (ok) backprop_point(P, pt);
+    if (build) {
+        const unsigned long long lt = (1ull << lane) - 1ull;
+        bh = (unsigned)__builtin_amdgcn_readfirstlane((int)bh); bl = (unsigned)__builtin_amdgcn_readfirstlane((int)bl);
+        if (heavy) P.scan_order_out[bh + (unsigned)__popcll(mh & lt)] = pt - P.point_begin;
+        else if (ok) P.scan_order_out[(unsigned)(P.point_end - P.point_begin) - 1u - (bl + (unsigned)__popcll(ml & lt))] = pt - P.point_begin;
+    }
 }
 
 // Deterministic reduction.  Blocks [0, N): gradC rows of piece i and H[i] = sum of gdT over the points whose t* lies in
