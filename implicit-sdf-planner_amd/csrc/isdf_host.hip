@@ -885,8 +885,8 @@ static int eval_device_impl(isdf_ctx *c, int n_traj, int N, const double *d_T, c
     }
     // ---- mesh robots: the exact pass runs as its own launch over a queue of 64-voxel blocks (every block an independent work item:
     // the launch is balanced over the whole device instead of ending on its heaviest workgroup).  Sized for the worst case the
-    // geometry allows - every voxel of the robot's inflated bounding box (or of the tile, if smaller) occupied; beyond 4 GiB the
-    // exact pass stays inside the sweep kernel (ISDF_MESH_QUEUE=0 forces that).
+    // geometry allows - every voxel of the robot's inflated bounding box (or of the tile, if smaller) occupied; beyond the budget
+    // below the exact pass stays inside the sweep kernel (ISDF_MESH_QUEUE=0 forces that).
     P.mq_items = nullptr;
     if (c->shape.kind == ISDF_SHAPE_MESH && cfg.enable_pos && !fused && !(getenv("ISDF_MESH_QUEUE") && getenv("ISDF_MESH_QUEUE")[0] == '0')) {
         const size_t ns_loc = (size_t)(pe - pb) * (cfg.integral_intervs + 1);
@@ -901,7 +901,10 @@ static int eval_device_impl(isdf_ctx *c, int n_traj, int N, const double *d_T, c
         const size_t per_sample = (size_t)(vox / 16.0) + 2;
         const size_t cap = ns_loc * per_sample;
         const size_t bytes = cap * (16 * 4 + 8 + 80) + ns_loc * ((size_t)kmax * 4 + 4);
-        if (ns_loc > 0 && bytes <= (size_t)4 << 30 && cap < 0x7fffffffull) {
+        // budget: 1 GiB per ctx (ISDF_MESH_QUEUE_MAX_MB overrides).  A launch whose worst case needs more keeps the exact pass inside
+        // the sweep kernel (whose 64-voxel blocks partition a sample's sums differently: equal to rounding, not bitwise)
+        static const size_t mq_budget = [] { const char *e = getenv("ISDF_MESH_QUEUE_MAX_MB"); const long v = e ? atol(e) : 0; return (size_t)(v > 0 ? v : 1024) << 20; }();
+        if (ns_loc > 0 && bytes <= mq_budget && cap < 0x7fffffffull) {
             if (c->mq_cap < cap || c->mq_samples_cap < ns_loc || c->mq_kmax != kmax) {
                 HIPCHK(c, hipDeviceSynchronize());               // (an earlier step may still be reading the old queue)
                 for (void *q : {(void *)c->d_mq_entries, c->d_mq_items, (void *)c->d_mq_res, (void *)c->d_mq_sample_items, (void *)c->d_mq_sample_n}) if (q) (void)hipFree(q);

@@ -659,7 +659,9 @@ __device__ __forceinline__ void descent_body(const SweptParams &P, double *s_dyn
             bool long_task = n_pass >= LPT_TASK;
             if constexpr (KIND == ISDF_SHAPE_MESH) {
                 const unsigned dur = (unsigned)min((wall_clock64() - dbg_t0) >> 7, 0xFFFFFull);      // 1.28 us units
-                atomicAdd(&P.words[4], dur); atomicAdd(&P.words[5], 1u);
+                // (32-bit sum of 1.28 us units: saturating - 2^32 units are 90 minutes of descents per step - and only ever a dispatch hint)
+                if (atomicAdd(&P.words[4], dur) > 0xFFFFFFFFu - dur) atomicMax(&P.words[4], 0xFFFFFFFFu);
+                atomicAdd(&P.words[5], 1u);
                 if (lpt_thr != 0u) long_task = dur >= lpt_thr;                   // (first step: the pass-count rule)
             }
             if (long_task) atomicOr(&P.point_lmask[pt], 1u << r);

@@ -95,8 +95,14 @@ __global__ __launch_bounds__(1024) void xchg_allreduce_kernel(XchgParams X, doub
             __hip_atomic_store(X.decision, (X.seq << 1) | (all_ok ? 0ull : 1ull), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
         }
     } else if (blockIdx.x != 0 && threadIdx.x == 0) {
+        // bounded like block 0's own waits (three of them, one after the other) plus slack: if block 0 of this launch never ran to
+        // its decision (not resident, faulted), the other blocks must not hang the stream - they take the failure path and say so
         unsigned long long v;
-        while (((v = __hip_atomic_load(X.decision, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT)) >> 1) != X.seq) __builtin_amdgcn_s_sleep(1);   // bounded by block 0's bounded waits
+        long long spins = 0;
+        while (((v = __hip_atomic_load(X.decision, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT)) >> 1) != X.seq) {
+            __builtin_amdgcn_s_sleep(1);
+            if (++spins > 4 * XCHG_SPIN_LIMIT) { v = 1ull; atomicExch(X.status, 1u); break; }
+        }
         s_ok = (v & 1ull) == 0ull ? 1 : 0;
     }
     __syncthreads();
