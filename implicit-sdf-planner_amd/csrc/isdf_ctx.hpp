@@ -93,6 +93,7 @@ struct isdf_ctx {
     unsigned long long dir_seq = 0;
     int bar_state = 0;          // 0: untested, 1: the host can write device memory through the PCIe BAR (verified), -1: it cannot
     bool dir_pending = false; int dir_nb = 0, dir_n = 0; bool cb_direct = false;
+    double *h_v1_pin = nullptr, *h_v1_pin_dev = nullptr; size_t v1_pin_cap = 0;     // host-direct swept-volume step: [out | statistics | flag | lastTstar], device-mapped
     double last_parts[4] = {0, 0, 0, 0};
     std::vector<double> cb_x; double cb_energy = 0.0; int cb_n_out = 1; bool cb_pending = false;
     // device half of the callback (csrc/minco_dev.hip): MINCO, energy, adjoint and chain rule in two small kernels either side

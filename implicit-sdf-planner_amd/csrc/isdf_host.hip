@@ -176,6 +176,7 @@ extern "C" int isdf_destroy(isdf_ctx *c) {
     if (c->h_eval_pin) (void)hipHostFree(c->h_eval_pin);
     if (c->h_dir) (void)hipHostFree(c->h_dir);
     if (c->h_cbres) (void)hipHostFree(c->h_cbres);
+    if (c->h_v1_pin) (void)hipHostFree(c->h_v1_pin);
     isdf_frontend_release(c);
     isdf_xchg_release(c);
     void *ptrs[] = {c->d_cb, c->d_cbdev, c->d_esdf_bricks, c->d_esdf, c->d_occ, c->d_points, c->d_tstar, c->d_acc, c->d_sample_info, c->d_bits, c->d_piece_cost, c->d_in, c->d_out, c->d_stats,
@@ -1395,6 +1396,70 @@ static int direct_wait(isdf_ctx *c, hipStream_t st, bool *overflow) {
     return ISDF_OK;
 }
 
+// ---- host-direct form of the steps that are SEVERAL launches (the swept-volume sweep: prepare, scan, descent, back-prop, reduce):
+// the inputs go down through the PCIe BAR, the launches run as ever, and one small kernel behind them copies [cost | gradT |
+// gradC], the statistics words and lastTstar into host-mapped memory and raises a flag there - no copy commands (each a DMA
+// packet with its own completion), no stream synchronisation (a scheduler wake-up).
+__global__ __launch_bounds__(1024) void publish_kernel(const double *out, size_t count, const unsigned long long *stats, const double *tstar, int M,
+                                                       double *h_out, unsigned long long *h_stats, double *h_tstar, unsigned long long *h_flag, unsigned long long seq) {
+    for (size_t i = threadIdx.x; i < count; i += blockDim.x) h_out[i] = out[i];
+    if (threadIdx.x < 8) h_stats[threadIdx.x] = stats[threadIdx.x];
+    if (tstar) for (int i = threadIdx.x; i < M; i += blockDim.x) h_tstar[i] = tstar[i];
+    __threadfence_system();
+    __syncthreads();
+    if (threadIdx.x == 0) __hip_atomic_store(h_flag, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+static bool v1_direct_enabled(const isdf_ctx *c) {
+    return !c->env_no_direct && !c->prof_on && c->world == 1 && c->peers.empty() && !c->rccl_comm && c->cfg.variant == ISDF_V1_SWEPT;
+}
+// returns ISDF_DIRECT_NA when the host cannot write device memory (no large BAR): the copy path then
+static int v1_direct_eval(isdf_ctx *c, int n, const double *T, const double *coeffs, double *tstar_inout, const double **h_out, const unsigned long long **h_stat) {
+    const size_t in_all = (size_t)19 * n, ostride = isdf_out_stride(n);
+    const bool ts = tstar_inout && c->M > 0;
+    int rc = ensure(c, &c->d_in, &c->in_cap, in_all);
+    if (rc) return rc;
+    rc = ensure(c, &c->d_out, &c->out_cap, ostride);
+    if (rc) return rc;
+    if (!bar_usable(c, c->d_in, in_all)) return ISDF_DIRECT_NA;
+    // pinned, device-mapped: [out | 8 statistics words | flag | lastTstar]
+    const size_t need = ostride + 8 + 2 + (size_t)(ts ? c->M : 0);
+    if (c->v1_pin_cap < need) {
+        if (c->h_v1_pin) (void)hipHostFree(c->h_v1_pin);
+        c->h_v1_pin = nullptr; c->v1_pin_cap = 0;
+        HIPCHK(c, hipHostMalloc((void **)&c->h_v1_pin, need * sizeof(double), hipHostMallocDefault));
+        HIPCHK(c, hipHostGetDevicePointer((void **)&c->h_v1_pin_dev, c->h_v1_pin, 0));
+        std::memset(c->h_v1_pin, 0, need * sizeof(double));
+        c->v1_pin_cap = need;
+    }
+    std::memcpy(c->d_in, T, (size_t)n * sizeof(double));                       // CPU stores into device memory
+    std::memcpy(c->d_in + n, coeffs, (size_t)18 * n * sizeof(double));
+    if (ts) std::memcpy(c->d_tstar, tstar_inout, (size_t)c->M * sizeof(double));
+    __sync_synchronize();
+    rc = eval_device_impl(c, 1, n, c->d_in, c->d_in + n, c->d_out, ts ? c->d_tstar : nullptr, c->stream, 0);
+    if (rc) return rc;
+    const unsigned long long seq = ++c->dir_seq;
+    double *ho = c->h_v1_pin_dev;
+    unsigned long long *hs = (unsigned long long *)(c->h_v1_pin_dev + ostride);
+    hipLaunchKernelGGL(publish_kernel, dim3(1), dim3(1024), 0, c->stream, c->d_out, ostride, c->d_stats, ts ? c->d_tstar : nullptr, c->M,
+                       ho, hs, c->h_v1_pin_dev + ostride + 10, hs + 8, seq);
+    HIPCHK(c, hipGetLastError());
+    volatile unsigned long long *flag = (volatile unsigned long long *)(c->h_v1_pin + ostride) + 8;
+    const auto t0 = std::chrono::steady_clock::now();
+    for (unsigned spin = 0; *flag != seq; spin++) {
+        if ((spin & 0x3FFFu) == 0x3FFFu && std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > 10.0) {
+            (void)hipStreamSynchronize(c->stream);
+            if (*flag == seq) break;
+            return fail(c, ISDF_ERR_HIP, "host-direct swept-volume step did not complete (its flag never arrived)");
+        }
+    }
+    std::atomic_thread_fence(std::memory_order_acquire);
+    if (ts) std::memcpy(tstar_inout, c->h_v1_pin + ostride + 10, (size_t)c->M * sizeof(double));
+    *h_out = c->h_v1_pin;
+    *h_stat = (const unsigned long long *)(c->h_v1_pin + ostride);
+    c->last_host_path = ISDF_HOST_PATH_DIRECT_BAR;
+    return ISDF_OK;
+}
+
 extern "C" int isdf_host_path(const isdf_ctx *c) { return c ? c->last_host_path : ISDF_ERR_INVALID_ARG; }
 
 extern "C" int isdf_eval(isdf_ctx *c, int n_traj, const int *N, const double *const *T, const double *const *coeffs,
@@ -1453,6 +1518,27 @@ extern "C" int isdf_eval(isdf_ctx *c, int n_traj, const int *N, const double *co
                 continue;
             }
             // ISDF_DIRECT_NA: this step is not one fused launch - the copy path below
+        }
+        if (nb == 1 && v1_direct_enabled(c)) {
+            const double *ho = nullptr; const unsigned long long *hs = nullptr;
+            const int rcv = v1_direct_eval(c, n, T[start], coeffs[start], tstar_inout, &ho, &hs);
+            if (rcv < 0) return rcv;
+            if (rcv == ISDF_OK) {
+                if (hs[4]) {
+                    overflow = true;
+                    HIPCHK(c, hipMemset(c->d_stats + 4, 0, sizeof(unsigned long long)));
+                    const int rr = isdf_reset_result_slots(c);
+                    if (rr) return rr;
+                }
+                total.n_units += (int64_t)hs[0]; total.n_units_culled += (int64_t)hs[1];
+                total.n_pairs += (int64_t)hs[2]; total.n_grad_pairs += (int64_t)hs[3];
+                cost_inout[start] += ho[0];
+                double *gT = gradT_inout[start], *gC = gradC_inout[start];
+                for (int i = 0; i < n; i++) gT[i] += ho[1 + i];
+                for (int i = 0; i < 18 * n; i++) gC[i] += ho[1 + n + i];
+                start = end;
+                continue;
+            }
         }
         c->last_host_path = ISDF_HOST_PATH_COPY;
         int rc = ensure(c, &c->d_in, &c->in_cap, in_all);

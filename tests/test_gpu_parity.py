@@ -295,6 +295,34 @@ def test_swept_sweep_matches_oracle(pkg, orc, product_lib, shape_name):
     assert_close(gT2, gT20, "V1 gradT second call")
 
 
+def test_swept_host_paths_agree_bitwise(pkg, orc, product_lib, monkeypatch):
+    """isdf_eval on a swept-volume ctx: host-direct (inputs through the PCIe BAR, a publish kernel behind the five launches, a flag
+    in host-mapped memory) against the copy path (ISDF_NO_HOST_DIRECT=1, read at isdf_create) - cost, gradients, lastTstar and the
+    statistics are the same bits; with and without a lastTstar array; accumulate semantics kept."""
+    capi, synth = pkg.capi, pkg.synth
+    occ, esdf, res, T, cm, pts = _swept_world(pkg)
+    shape = synth.make_shape("RoundedCone", params=(0.8, 0.3, 1.6))
+    cfg = synth.default_config(capi.V1_SWEPT, safety_hor=0.5)
+    got = {}
+    for name in ("direct", "copy"):
+        if name == "copy":
+            monkeypatch.setenv("ISDF_NO_HOST_DIRECT", "1")
+        eng = pkg.Engine(cfg); eng.set_shape(shape); eng.set_points(pts)
+        ts = np.full(pts.shape[0], 0.25)
+        r1 = eng.eval_single(T, cm, tstar=ts)
+        st = eng.stats()
+        path = eng.host_path()
+        r2 = eng.eval_single(T * 1.05, cm, tstar=ts)            # lastTstar carried over
+        r3 = eng.eval_single(T, cm)                            # no lastTstar array
+        got[name] = (r1, r2, r3, ts.copy(), st, path)
+    d, c = got["direct"], got["copy"]
+    assert c[5] == capi.HOST_PATH_COPY and d[5] in (capi.HOST_PATH_DIRECT_BAR, capi.HOST_PATH_COPY)
+    for k in range(3):
+        assert d[k][0] == c[k][0] and np.array_equal(d[k][1], c[k][1]) and np.array_equal(d[k][2], c[k][2])
+    assert np.array_equal(d[3], c[3]) and d[4] == c[4]
+    assert d[0][0] > 0
+
+
 def test_swept_shards_and_empty(pkg, orc, product_lib):
     capi, synth = pkg.capi, pkg.synth
     occ, esdf, res, T, cm, pts = _swept_world(pkg, seed=5)

@@ -67,6 +67,19 @@ for name, N, variant, piece_T in (("C2: 40 pieces, V3 tile sweep, box", 40, capi
     relc = abs(d[3] - h[3]) / abs(h[3]); relg = np.abs(d[4] - h[4]).max() / np.abs(h[4]).max()
     print(f"{name}\n    isdf_cost_function median us: device MINCO {d[0]:7.1f} (p10 {d[1]:.1f}, p90 {d[2]:.1f}; path {d[5]}/{d[6]})  |  host MINCO {h[0]:7.1f} (p10 {h[1]:.1f}, p90 {h[2]:.1f}; path {h[5]}/{h[6]})"
           f"  |  device vs host: cost {relc:.1e}, g {relg:.1e}  |  left to itself the library takes: {auto}", flush=True)
+    if variant == capi.V1_SWEPT:
+        # isdf_eval itself through the compiled binding: host-direct (BAR in, publish kernel + flag out) - and, in a second ctx, the copy path
+        lat = np.zeros(600)
+        stub.stub_time_eval.argtypes = [C.c_void_p, C.c_int, dpt, dpt, C.c_int, dpt]
+        stub.stub_time_eval(eng.h, N, Tn.ctypes.data_as(dpt), cmn.ctypes.data_as(dpt), lat.size, lat.ctypes.data_as(dpt))
+        p_direct = eng.host_path()
+        os.environ["ISDF_NO_HOST_DIRECT"] = "1"
+        e2 = pkg.Engine(cfg); e2.set_grid(esdf, (0, 0, 0), res, capi.GRID_ESDF); e2.set_shape(synth.bench_rounded_cone_shape()); e2.set_points(pts)
+        del os.environ["ISDF_NO_HOST_DIRECT"]
+        lat2 = np.zeros(600)
+        stub.stub_time_eval(e2.h, N, Tn.ctypes.data_as(dpt), cmn.ctypes.data_as(dpt), lat2.size, lat2.ctypes.data_as(dpt))
+        print(f"    isdf_eval (host arrays, accumulate) median us: host-direct {np.median(lat):7.1f} (path {p_direct})  |  copy path {np.median(lat2):7.1f} (path {e2.host_path()})", flush=True)
+        del e2
     if variant != capi.V1_SWEPT and not quick:
         for mode, label in ((capi.MINCO_DEVICE, "device"), (capi.MINCO_HOST, "host")):
             eng.set_minco_mode(mode)
