@@ -32,128 +32,10 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 import __graft_entry__ as graft  # noqa: E402
 
-HBM_PEAK_GBS = 8000.0        # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md
-FP64_VALU_PEAK_TFLOPS = 78.6  # fp64 vector peak: half the 157.3 TFLOP/s fp32 vector rate of the same guide
-N_SIMD = 1024                # 256 CUs x 4 SIMDs
-PEAK_CLOCK_HZ = 2.4e9        # max shader clock (same guide)
-
-
-def kernel_source_hash():
-    """sha256 over the sources the step's dominant kernel is compiled from: PMC counters measured on another version of them
-    are not reported (profiles/pmc_counters.json carries the hash it was measured on)."""
-    h = hashlib.sha256()
-    for f in ("tile_sweep.hip", "dev_math.hpp", "dev_shapes.hpp", "dev_mesh.hpp", "isdf_internal.hpp"):
-        with open(os.path.join(ROOT, "implicit-sdf-planner_amd", "csrc", f), "rb") as fh:
-            h.update(fh.read())
-    return h.hexdigest()[:16]
-
-
-def v1_source_hash():
-    """the same for the swept-volume sweep's kernels (profiles/pmc_counters_v1.json)"""
-    h = hashlib.sha256()
-    for f in ("swept_sweep.hip", "dev_math.hpp", "dev_shapes.hpp", "dev_mesh.hpp", "isdf_internal.hpp"):
-        with open(os.path.join(ROOT, "implicit-sdf-planner_amd", "csrc", f), "rb") as fh:
-            h.update(fh.read())
-    return h.hexdigest()[:16]
-
-
-def issue_from_counters(path, want_hash, live_kernel_us=None):
-    """Issue-slot roofline block from a tools/pmc_collect.py JSON (per-dispatch means of the SQ counters, summed over the kernels it
-    lists); None when the file is missing, unreadable or was measured on other kernel sources.  The counters are properties of
-    the kernel + workload (instructions issued per launch); the DURATION they are divided by is `live_kernel_us` when given (the
-    kernel's duration measured in this run with HIP events), the rocprofv3 average of the counter run otherwise."""
-    try:
-        with open(path) as f:
-            pj = json.load(f)
-        if pj.get("source_hash") != want_hash:
-            return None
-        c = pj["counters"]
-        k_us = live_kernel_us if live_kernel_us else pj["avg_kernel_us"]
-        cyc = k_us * 1e-6 * PEAK_CLOCK_HZ
-        f64 = c["SQ_INSTS_VALU_ADD_F64"] + c["SQ_INSTS_VALU_MUL_F64"] + c["SQ_INSTS_VALU_FMA_F64"] + c["SQ_INSTS_VALU_TRANS_F64"]
-        flops64 = (c["SQ_INSTS_VALU_ADD_F64"] + c["SQ_INSTS_VALU_MUL_F64"] + 2 * c["SQ_INSTS_VALU_FMA_F64"] + c["SQ_INSTS_VALU_TRANS_F64"]) * 64
-        busy = 4.0 * c["SQ_ACTIVE_INST_VALU"] / (N_SIMD * cyc)
-        lane = pj.get("lane_utilisation_valu")
-        if lane is None and "SQ_THREAD_CYCLES_VALU" in c:
-            lane = c["SQ_THREAD_CYCLES_VALU"] / (64.0 * c["SQ_ACTIVE_INST_VALU"])
-        share64 = f64 / c["SQ_INSTS_VALU"]
-        return {"kernels": pj.get("kernel"), "valu_issue_busy_frac": round(busy, 4),
-                "lane_utilisation": None if lane is None else round(lane, 4),
-                "fp64_share_of_valu_insts": round(share64, 4),
-                "useful_fp64_frac": None if lane is None else round(busy * share64 * lane, 4),
-                "wait_frac_of_wave_cycles": round(c["SQ_WAIT_ANY"] / c["SQ_WAVE_CYCLES"], 4),
-                "waves_per_simd_avg": round(4.0 * c["SQ_WAVE_CYCLES"] / (N_SIMD * pj["avg_kernel_us"] * 1e-6 * PEAK_CLOCK_HZ), 3),
-                "valu_insts_per_step": int(c["SQ_INSTS_VALU"]), "salu_insts_per_step": int(c["SQ_INSTS_SALU"]),
-                "fp64_tflops": None if lane is None else round(lane * flops64 / (k_us * 1e-6) / 1e12, 3),
-                "fp64_valu_peak_tflops": FP64_VALU_PEAK_TFLOPS,
-                "fp64_frac_of_peak": None if lane is None else round(lane * flops64 / (k_us * 1e-6) / 1e12 / FP64_VALU_PEAK_TFLOPS, 4),
-                "definition": "valu_issue_busy = SQ_ACTIVE_INST_VALU (quad-cycles per launch, PMC) x 4 / (1024 SIMDs x kernel duration x 2.4 GHz): 1.0 = a VALU instruction "
-                              "issuing on every SIMD in every cycle; lane_utilisation = SQ_THREAD_CYCLES_VALU / (64 x SQ_ACTIVE_INST_VALU); useful_fp64_frac = busy x fp64 share "
-                              "of the VALU instructions x lane utilisation; fp64 flops = (ADD + MUL + 2 FMA + TRANS wave-instructions) x 64 lanes x lane utilisation",
-                "kernel_us": round(k_us, 3), "kernel_us_source": "HIP events, this run" if live_kernel_us else "rocprofv3 average of the counter run",
-                "kernel_us_under_rocprof": round(pj["avg_kernel_us"], 3), "measured_on_commit": pj.get("commit"), "source": os.path.relpath(path, ROOT)}
-    except Exception:       # noqa: BLE001
-        return None
-
-
-def compulsory_bytes(T, cm, N, K, k, grid, res):
-    """Unique ESDF voxels under the tiles of all N*(K+1) samples x 4 B + per-sample coefficients / T / outputs (the
-    compulsory traffic if every byte were read once): numpy restatement of the tile boxes (getPointsInAABB floor indexing)."""
-    c6 = cm.reshape(3, 6 * N).T.reshape(N, 6, 3)                   # piece, power, axis
-    touched = np.zeros((grid, grid, grid), dtype=bool)
-    half = k * res / 2
-    for i in range(N):
-        t = np.arange(K + 1) * (T[i] / K)
-        pw = np.stack([t ** p for p in range(6)], axis=1)          # (K+1, 6)
-        pos = pw @ c6[i]                                           # (K+1, 3)
-        lo = np.clip(np.floor((np.clip(pos - half, 0, grid * res)) / res).astype(int), 0, grid - 1)
-        hi = np.clip(np.floor((np.clip(pos + half, 0, grid * res)) / res).astype(int), 0, grid - 1)
-        for a, b in zip(lo, hi):
-            touched[a[0]:b[0] + 1, a[1]:b[1] + 1, a[2]:b[2] + 1] = True
-    return int(touched.sum()) * 4 + N * (K + 1) * (144 + 8 + 152)
-
-
-def algorithmic_bytes_per_eval(k, s_vox=4):
-    """tile staged once + trilinear corners + 6x3 coefficients + T_i + 19 partial outputs."""
-    return k ** 3 * s_vox + 8 * s_vox + 144 + 8 + 152
-
-
-def build_workload(pkg, n_pieces, grid_n, res, seed_map=12345, seed_traj=777):
-    synth = pkg.synth
-    occ = synth.random_box_map((grid_n,) * 3, res=res, occupancy=0.15, seed=seed_map)
-    esdf = synth.esdf_from_occupancy(occ, res)
-    ext = np.array(occ.shape) * res
-    T, Cf = synth.random_trajectory(ext, n_pieces, seed=seed_traj, piece_T=1.0, jitter=0.5, margin=4.0, occ=occ, res=res)
-    return occ, esdf, T, synth.colmajor(Cf)
-
-
-def native_boundary_ms(pkg, eng, N, T, cm, x0, eval_too=True):
-    """isdf_eval and the lmbm_evaluate_t callback as a C++ caller sees them: timed inside the compiled reference-side
-    binding (tests/native/binding_stub.cpp, built here with g++) - ctypes marshalling costs as much as the call itself.
-    Returns (eval_ms, callback_ms) medians, or None when no compiler is at hand."""
-    import ctypes as C
-    try:
-        out = os.path.join(tempfile.mkdtemp(), "libbinding_stub.so")
-        libdir = os.path.dirname(pkg.capi.LIB_PATH)
-        subprocess.check_call(["g++", "-O2", "-std=c++14", "-fPIC", "-shared", "-I", os.path.join(ROOT, "include"),
-                               "-I", os.path.join(ROOT, "oracle", "ref_build", "eigen_shim"),
-                               os.path.join(ROOT, "tests", "native", "binding_stub.cpp"), "-o", out,
-                               "-L", libdir, "-lisdf_accel", f"-Wl,-rpath,{libdir}"], stderr=subprocess.DEVNULL)
-        stub = C.CDLL(out)
-    except Exception:
-        return None
-    dp = C.POINTER(C.c_double)
-    stub.stub_time_eval.argtypes = [C.c_void_p, C.c_int, dp, dp, C.c_int, dp]
-    stub.stub_time_callback.argtypes = [C.c_void_p, C.c_int, dp, C.c_int, dp, dp]
-    lat = np.zeros(1000 if eval_too else 4)
-    if stub.stub_time_eval(eng.h, N, T.ctypes.data_as(dp), cm.ctypes.data_as(dp), lat.size, lat.ctypes.data_as(dp)) != 0:
-        return None
-    cb = None
-    if x0 is not None:
-        cbl = np.zeros(500); cst = np.zeros(1)
-        stub.stub_time_callback(eng.h, x0.size, x0.ctypes.data_as(dp), cbl.size, cbl.ctypes.data_as(dp), cst.ctypes.data_as(dp))
-        cb = float(np.median(cbl)) * 1e-3
-    return float(np.median(lat)) * 1e-3, cb
+from benchlib.roofline import (FP64_VALU_PEAK_TFLOPS, HBM_PEAK_GBS, N_SIMD, PEAK_CLOCK_HZ, algorithmic_bytes_per_eval, compulsory_bytes,      # noqa: E402,F401
+                               issue_from_counters, kernel_source_hash, v1_source_hash)
+from benchlib.workloads import build_workload      # noqa: E402,F401  (the developer tools import these names from here)
+from benchlib.timing import native_boundary_ms     # noqa: E402,F401
 
 
 def main():
@@ -350,143 +232,14 @@ def main():
         if mode == "fused":
             eng.xchg_fuse(True)
 
-    # what the collective library saw, and what ONE all-reduce of the step's packed vector costs by itself on this group
-    rccl_seen = None
+    # ---- N > 1: the group's facts and a scaling line that can be READ (benchlib/multi.py)
+    rccl_seen = one_gpu = c3_sharded = c5_sharded = None
     if world > 1:
-        ar = torch.zeros(eng.out_stride(N), dtype=torch.float64, device=dev)
-        for _ in range(5):
-            dist.all_reduce(ar)
-        torch.cuda.synchronize(); dist.barrier(); torch.cuda.synchronize()
-        ta = time.perf_counter()
-        for _ in range(50):
-            dist.all_reduce(ar)
-        torch.cuda.synchronize()
-        ta = torch.tensor([(time.perf_counter() - ta) / 50], dtype=torch.float64, device=dev)
-        dist.all_reduce(ta, op=dist.ReduceOp.MAX)
-        devs = [torch.zeros(1, dtype=torch.int64, device=dev) for _ in range(world)]
-        dist.all_gather(devs, torch.tensor([local_rank], dtype=torch.int64, device=dev))
-        rccl_seen = {"backend": dist.get_backend(), "rccl_ranks_seen": dist.get_world_size(), "devices_by_rank": [int(d.item()) for d in devs],
-                     "distinct_devices": len({int(d.item()) for d in devs}),
-                     "all_reduce_alone_ms": round(1e3 * float(ta.item()), 5), "all_reduce_doubles": int(ar.numel())}
-        del ar
-
-    # ---- N > 1: a scaling line that can be READ.  (1) the SAME workload (the N-piece trajectory) unsharded on ONE GPU, measured on
-    # rank 0 in this run -> `one_gpu_same_workload` + `speedup` (the N = 1 line of this bench is another workload: C2, 40 pieces);
-    # (2) the workload of BASELINE's configs that CAN scale - configs[2], 128 trajectories - sharded by TRAJECTORY (no exchange:
-    # every trajectory's outputs stay on its rank, as in the batch optimiser), with its own one-GPU figure from rank 0.
-    one_gpu = None
-    c3_sharded = None
-    c5_sharded = None
-    if world > 1 and not args.weak:
-        def plain_timed(fn, steps, warm=5):
-            for _ in range(warm):
-                fn()
-            torch.cuda.synchronize(); dist.barrier(); torch.cuda.synchronize()
-            t0_ = time.perf_counter()
-            for _ in range(steps):
-                fn()
-            torch.cuda.synchronize(); dist.barrier()
-            return time.perf_counter() - t0_
-
-        fused_was_on = mode == "fused"
-        if fused_was_on:
-            eng.xchg_fuse(False)
-        e1g = None
-        if rank == 0:
-            e1g = pkg.Engine(cfg); e1g.set_grid(esdf, (0, 0, 0), res, capi.GRID_ESDF); e1g.set_shape(shape)
-            d_o1 = torch.zeros(e1g.out_stride(N), dtype=torch.float64, device=dev)
-        st1 = max(20, args.steps // 4)
-        el1 = plain_timed((lambda: e1g.eval_device(1, N, d_T.data_ptr(), d_C.data_ptr(), d_o1.data_ptr(), 0, stream)) if rank == 0 else (lambda: None), st1)
-        if rank == 0:
-            one_gpu = {"ms_per_step": round(1e3 * el1 / st1, 5), "evals_per_s": round(N * (K + 1) * st1 / el1, 1), "steps": st1,
-                       "what": f"the same {N}-piece trajectory UNSHARDED on rank 0's GPU while the other ranks wait, same run"}
-        # (2) configs[2] sharded by trajectory
-        n_traj_all = 128
-        tb, te = par.shard_range(n_traj_all, rank, world)
-        ext_ = np.array(occ.shape) * res
-        Tl, Cl = [], []
-        for b in range(n_traj_all if rank == 0 else 0):     # rank 0 also needs all of them for the one-GPU figure
-            Tb_, Cf_ = synth.random_trajectory(ext_, 40, seed=777 + b, piece_T=1.0, jitter=0.5, margin=4.0, occ=occ, res=res)
-            Tl.append(Tb_); Cl.append(synth.colmajor(Cf_))
-        if rank != 0:
-            for b in range(tb, te):
-                Tb_, Cf_ = synth.random_trajectory(ext_, 40, seed=777 + b, piece_T=1.0, jitter=0.5, margin=4.0, occ=occ, res=res)
-                Tl.append(Tb_); Cl.append(synth.colmajor(Cf_))
-            Tm, Cm_ = Tl, Cl
-        else:
-            Tm, Cm_ = Tl[tb:te], Cl[tb:te]
-        e3 = pkg.Engine(cfg); e3.set_grid(esdf, (0, 0, 0), res, capi.GRID_ESDF); e3.set_shape(shape)
-        nb_ = te - tb
-        if nb_ > 0:
-            d3T = torch.from_numpy(np.concatenate(Tm)).to(dev); d3C = torch.from_numpy(np.concatenate(Cm_)).to(dev)
-            d3O = torch.zeros(nb_ * e3.out_stride(40), dtype=torch.float64, device=dev)
-        st3 = 20
-        el3 = plain_timed((lambda: e3.eval_device(nb_, 40, d3T.data_ptr(), d3C.data_ptr(), d3O.data_ptr(), 0, stream)) if nb_ > 0 else (lambda: None), st3)
-        t3 = torch.tensor([el3], dtype=torch.float64, device=dev); dist.all_reduce(t3, op=dist.ReduceOp.MAX); el3 = float(t3.item())
-        if rank == 0:
-            dAT = torch.from_numpy(np.concatenate(Tl)).to(dev); dAC = torch.from_numpy(np.concatenate(Cl)).to(dev)
-            dAO = torch.zeros(n_traj_all * e3.out_stride(40), dtype=torch.float64, device=dev)
-        el3one = plain_timed((lambda: e3.eval_device(n_traj_all, 40, dAT.data_ptr(), dAC.data_ptr(), dAO.data_ptr(), 0, stream)) if rank == 0 else (lambda: None), st3)
-        if rank == 0:
-            ev3 = n_traj_all * 40 * (K + 1)
-            # parity of the sharded launch: rank 0's first trajectory, sharded launch vs the 128-trajectory launch (bitwise: one trajectory's
-            # result does not depend on its neighbours in the batch, tests/test_gpu_fullsize.py::test_c3_batch_is_independent)
-            same = bool(torch.equal(d3O[:e3.out_stride(40)], dAO[:e3.out_stride(40)]))
-            c3_sharded = {"name": f"C3 (configs[2]) sharded by TRAJECTORY over {world} GPUs: 128 trajectories x 40 pieces, {nb_} per rank, no exchange (outputs stay with their trajectory's rank)",
-                          "evals_per_step": ev3, "ms_per_step": round(1e3 * el3 / st3, 5), "evals_per_s": round(ev3 * st3 / el3, 1), "scaling": "strong",
-                          "one_gpu_same_workload": {"ms_per_step": round(1e3 * el3one / st3, 5), "evals_per_s": round(ev3 * st3 / el3one, 1),
-                                                    "what": "all 128 trajectories in one batched launch on rank 0's GPU while the other ranks wait, same run"},
-                          "speedup": round(el3one / el3, 3), "sharded_equals_unsharded_bitwise_traj0": same}
-        del e3
-        # (3) configs[4]: the swept-volume sweep (V1) with a mesh robot through the fast winding number on a 512^3 map - the one
-        # north-star workload whose step lasts milliseconds.  Obstacle points sharded contiguously over the ranks (isdf_set_shard),
-        # ONE all-reduce of [cost | gradT | gradC] per step over the group, lastTstar merged once at the end (every rank writes its
-        # own points' minimisers; the optimizer never reads them: set_ts = false, sw_manager.hpp:710-747).
-        if not args.no_c5:
-            try:
-                res5 = 0.1
-                occ5 = synth.random_box_map((512,) * 3, res=res5, occupancy=0.15, seed=12345, edge=(0.4, 2.0))
-                ext5 = np.array(occ5.shape) * res5
-                T5, Cf5 = synth.random_trajectory(ext5, 20, seed=780, piece_T=1.0, jitter=0.5, margin=4.0, occ=occ5, res=res5)
-                cm5 = synth.colmajor(Cf5)
-                way5 = cm5.reshape(3, -1).T.reshape(20, 6, 3)[1:, 0, :]
-                cfg5 = synth.default_config(capi.V1_SWEPT, device=local_rank, safety_hor=(3 ** 0.5 / 2) * res5, weight_p=4000.0)
-                e5 = pkg.Engine(cfg5); e5.set_grid(occ5, (0, 0, 0), res5, capi.GRID_OCCUPANCY)
-                e5.set_shape(synth.make_mesh_shape(*synth.blob_mesh(24, 16, scale=0.9)))
-                M5 = e5.gather_points(way5, 0.9)
-                e5.set_shard(rank, world)
-                d5T = torch.from_numpy(T5).to(dev); d5C = torch.from_numpy(cm5).to(dev)
-                d5O = torch.zeros(e5.out_stride(20), dtype=torch.float64, device=dev)
-                d5ts = torch.full((M5,), -1.0, dtype=torch.float64, device=dev)
-
-                def c5_step():
-                    e5.eval_device(1, 20, d5T.data_ptr(), d5C.data_ptr(), d5O.data_ptr(), d5ts.data_ptr(), stream)
-                    par.allreduce_packed(d5O)
-                st5 = 5
-                el5 = plain_timed(c5_step, st5, warm=2)
-                t5 = torch.tensor([el5], dtype=torch.float64, device=dev); dist.all_reduce(t5, op=dist.ReduceOp.MAX); el5 = float(t5.item())
-                merged = d5ts.clone(); dist.all_reduce(merged, op=dist.ReduceOp.MAX)      # a rank's untouched entries are -1, minimisers are >= 0
-                sum5 = d5O.clone()
-                if rank == 0:
-                    e5.set_shard(0, 1)
-                    d5O1 = torch.zeros_like(d5O); d5ts1 = torch.full((M5,), -1.0, dtype=torch.float64, device=dev)
-                el5one = plain_timed((lambda: e5.eval_device(1, 20, d5T.data_ptr(), d5C.data_ptr(), d5O1.data_ptr(), d5ts1.data_ptr(), stream)) if rank == 0 else (lambda: None), st5, warm=2)
-                if rank == 0:
-                    c5_sharded = {"name": f"C5 (configs[4]) sharded by OBSTACLE POINT over {world} GPUs: V1 swept-volume sweep, 512^3 occupancy @ 0.1 m, mesh robot (blob, 720 faces, fast winding number), 20 pieces, "
-                                          f"{M5} points, one all-reduce of {int(d5O.numel())} doubles per step ({dist.get_backend()}), lastTstar merged",
-                                  "variant": "V1", "obstacle_points": int(M5), "ms_per_step": round(1e3 * el5 / st5, 5), "evals_per_s": round(M5 * st5 / el5, 1), "unit": "obstacle-point evals/s",
-                                  "scaling": "strong", "steps": st5,
-                                  "one_gpu_same_workload": {"ms_per_step": round(1e3 * el5one / st5, 5), "evals_per_s": round(M5 * st5 / el5one, 1),
-                                                            "what": "all the points unsharded on rank 0's GPU while the other ranks wait, same run"},
-                                  "speedup": round(el5one / el5, 3),
-                                  "sharded_vs_unsharded_rel_diff": float((sum5 - d5O1).norm().item() / max(float(d5O1.norm().item()), 1e-300)),
-                                  "lastTstar_merged_equals_unsharded_bitwise": bool(torch.equal(merged, d5ts1))}
-                del e5, occ5
-            except Exception as e:      # noqa: BLE001
-                if rank == 0:
-                    c5_sharded = {"name": "C5 sharded", "error": str(e)}
-        if fused_was_on:
-            eng.xchg_fuse(True)
+        from benchlib.multi import scaling_entries
+        from types import SimpleNamespace
+        rccl_seen, one_gpu, c3_sharded, c5_sharded = scaling_entries(SimpleNamespace(
+            args=args, pkg=pkg, capi=capi, synth=synth, par=par, world=world, rank=rank, local_rank=local_rank, dev=dev, stream=stream, eng=eng, cfg=cfg,
+            shape=shape, occ=occ, esdf=esdf, res=res, K=K, N=N, d_T=d_T, d_C=d_C, mode=mode))
 
     evals_this_rank = (par.shard_range(N, rank, world)[1] - par.shard_range(N, rank, world)[0]) * (K + 1)
     one_launch = evals_this_rank // 4 + (N // world) <= 768 and world == 1
@@ -557,306 +310,10 @@ def main():
         if world > 1 and (c3_sharded is not None or c5_sharded is not None):
             extra = [e_ for e_ in (c3_sharded, c5_sharded) if e_ is not None]
         if world == 1 and not args.no_extra_configs:
-            extra = []
-
-            def parity_first(e, Np, Ts, Cs, dO, oc):
-                """rel. error of the FIRST trajectory of the entry's last launch vs the oracle (oc = (cfg, grid, kind, res, shape));
-                outside every timed region"""
-                if args.no_cpu_baseline or oc is None:
-                    return None
-                try:
-                    ocfg, ogrid, okind, ores, oshape = oc
-                    oo = graft.load_oracle().Oracle(ocfg, threads=min(30, os.cpu_count() or 1))
-                    oo.set_grid(ogrid, (0, 0, 0), ores, okind); oo.set_shape(oshape)
-                    c0, gT0, gC0, _ = oo.eval(Ts[:Np], Cs[:18 * Np])
-                    ref = np.concatenate([[c0], gT0, gC0]); got = dO[:e.out_stride(Np)].cpu().numpy()[:ref.size]
-                    return float(np.linalg.norm(got - ref) / max(np.linalg.norm(ref), 1e-300))
-                except Exception as ex:      # noqa: BLE001
-                    return f"oracle failed: {ex}"
-
-            def run_cfg(name, e, n_traj, Np, Ts, Cs, steps, kk=args.kernel_size, oc=None):
-                dT = torch.from_numpy(Ts).to(dev); dC = torch.from_numpy(Cs).to(dev)
-                dO = torch.zeros(n_traj * e.out_stride(Np), dtype=torch.float64, device=dev)
-                for _ in range(5):
-                    e.eval_device(n_traj, Np, dT.data_ptr(), dC.data_ptr(), dO.data_ptr(), 0, stream)
-                torch.cuda.synchronize(); t0 = time.perf_counter()
-                for _ in range(steps):
-                    e.eval_device(n_traj, Np, dT.data_ptr(), dC.data_ptr(), dO.data_ptr(), 0, stream)
-                torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / steps
-                units = n_traj * Np * (K + 1)
-                nom = units * algorithmic_bytes_per_eval(kk) / dt / 1e9
-                extra.append({"name": name, "evals_per_step": units, "ms_per_step": round(dt * 1e3, 5), "evals_per_s": round(units / dt, 1),
-                              "nominal_bytes_gbs": round(nom, 1), "nominal_bytes_frac": round(nom / HBM_PEAK_GBS, 4),
-                              "nominal_bytes_exceeds_hbm_peak": bool(nom > HBM_PEAK_GBS),
-                              "rel_err_vs_oracle": parity_first(e, Np, Ts, Cs, dO, oc),
-                              "rel_err_vs_oracle_of": "trajectory 0 of the launch" if n_traj > 1 else "the launch"})
-                return extra[-1]
-
-            Ts, Cs = [], []
-            ext = np.array(occ.shape) * res
-            for b in range(128):
-                Tb, Cf = synth.random_trajectory(ext, 40, seed=777 + b, piece_T=1.0, jitter=0.5, margin=4.0, occ=occ, res=res)
-                Ts.append(Tb); Cs.append(synth.colmajor(Cf))
-            oc2 = (cfg, esdf, capi.GRID_ESDF, res, shape)
-            run_cfg("C3 (configs[2]): 128 trajectories x 40 pieces, shared 256^3 map, one batched launch pair", eng, 128, 40, np.concatenate(Ts), np.concatenate(Cs), 20, oc=oc2)
-            _, _, T4, cm4 = build_workload(pkg, 400, args.grid, res)
-            run_cfg("C4 on ONE GPU (configs[3]'s trajectory unsharded): 1 x 400 pieces", eng, 1, 400, T4, cm4, 50, oc=oc2)
-            # another robot of SURVEY 8(d) on the headline geometry: the 0.4x rounded cone (three branches, a square root each)
-            try:
-                ec = pkg.Engine(cfg)
-                ec.set_grid(esdf, (0, 0, 0), res, capi.GRID_ESDF)
-                ec.set_shape(synth.bench_rounded_cone_shape())
-                run_cfg("C2 geometry (1 x 40 pieces) with the rounded-cone robot (r1 0.6, r2 0.24, h 1.8)", ec, 1, 40, T, cm, 200, oc=(cfg, esdf, capi.GRID_ESDF, res, synth.bench_rounded_cone_shape()))
-                del ec
-            except Exception as e:      # noqa: BLE001
-                extra.append({"name": "rounded cone", "error": str(e)})
-            # 512^3 map at 0.1 m (512 MiB fp32 ESDF, built on the device), the robot and the tile halved with the voxel
-            try:
-                res5 = 0.1
-                occ5 = synth.random_box_map((512,) * 3, res=res5, occupancy=0.15, seed=12345, edge=(0.4, 2.0))
-                cfg5 = synth.default_config(capi.V3_ESDF_TILE, device=local_rank, kernel_size=21, integral_intervs=K, safety_hor=(3 ** 0.5 / 2) * res5,
-                                            weight_p=4000.0, smoothing_eps=0.01, enable_dyn=1, enable_pos=1)
-                e5 = pkg.Engine(cfg5)
-                e5.set_grid(occ5, (0, 0, 0), res5, capi.GRID_OCCUPANCY)
-                e5.generate_esdf()
-                shape5 = synth.make_shape("Box", params=(0.8, 0.15, 0.15), grad_mode=capi.GRAD_CENTRAL, bound_radius=0.83, bbox=((0, 0, 0), (0.8, 0.15, 0.15)))
-                e5.set_shape(shape5)
-                oc5 = None if args.no_cpu_baseline else (cfg5, e5.get_grid(capi.GRID_ESDF)[0], capi.GRID_ESDF, res5, shape5)
-                ext5 = np.array(occ5.shape) * res5
-                Ts, Cs = [], []
-                for b in range(128):
-                    Tb, Cf = synth.random_trajectory(ext5, 40, seed=900 + b, piece_T=1.0, jitter=0.5, margin=4.0, occ=occ5, res=res5)
-                    Ts.append(Tb); Cs.append(synth.colmajor(Cf))
-                run_cfg("512^3 map @ 0.1 m (512 MiB fp32 ESDF built on the device), 1 x 40 pieces, robot and tile scaled with the voxel", e5, 1, 40, Ts[0], Cs[0], 100, oc=oc5)
-                run_cfg("512^3 map @ 0.1 m, batch of 128 x 40 pieces", e5, 128, 40, np.concatenate(Ts), np.concatenate(Cs), 20, oc=oc5)
-                del e5, oc5
-            except Exception as e:      # noqa: BLE001
-                extra.append({"name": "512^3 map", "error": str(e)})
-
-            # ---- the tile sweep with a MESH robot (720 faces through the fast-winding-number hierarchy): scan launch -> queue of
-            # 16-voxel blocks -> exact launch (quad-cooperative walks) -> per-sample sums
-            try:
-                shm = synth.make_mesh_shape(*synth.blob_mesh(24, 16, scale=0.9))
-                em = pkg.Engine(cfg); em.set_grid(esdf, (0, 0, 0), res, capi.GRID_ESDF); em.set_shape(shm)
-                ent = run_cfg("C2 geometry (1 x 40 pieces) with a MESH robot (blob, 720 faces, fast-winding-number hierarchy)", em, 1, 40, T, cm, 10, oc=(cfg, esdf, capi.GRID_ESDF, res, shm))
-                ent["roofline"] = issue_from_counters(os.path.join(ROOT, "profiles", "pmc_counters_v3mesh.json"), kernel_source_hash())
-                ent["faces"] = 720
-                del em
-            except Exception as e:      # noqa: BLE001
-                extra.append({"name": "V3 mesh", "error": str(e)})
-            # ---- the whole-tile cull on (never `value`: it skips poses, the headline evaluates every pose)
-            try:
-                cfgc = synth.default_config(capi.V3_ESDF_TILE, device=local_rank, kernel_size=args.kernel_size, integral_intervs=K,
-                                            safety_hor=(3 ** 0.5 / 2) * res, weight_p=4000.0, smoothing_eps=0.01, enable_dyn=1, enable_pos=1, enable_cull=1)
-                ecu = pkg.Engine(cfgc); ecu.set_grid(esdf, (0, 0, 0), res, capi.GRID_ESDF); ecu.set_shape(shape)
-                run_cfg("C2 with the V3 whole-tile cull ON (trilinear esdf(pos) > bound radius + safety + sqrt(3) res skips the pose)", ecu, 1, 40, T, cm, 300, oc=(cfgc, esdf, capi.GRID_ESDF, res, shape))
-                extra[-1]["poses_culled"] = ecu.stats()["culled"]
-                del ecu
-            except Exception as e:      # noqa: BLE001
-                extra.append({"name": "cull on", "error": str(e)})
-
-            # ---- V1: the reference's LIVE collision term (addSaftyPenaOnSweptVolumeParallel, back_end_optimizer.hpp:557-649):
-            # one unit = one obstacle point (argmin over t + back-prop).  Device resident like `value`; the oracle's OpenMP sweep
-            # of the same points at 30 threads beside it.
-            def run_v1(name, e1, Np, Tv, Cv, steps, oracle=None, note=None):
-                Mv = e1.stats_points if hasattr(e1, "stats_points") else None
-                dT = torch.from_numpy(Tv).to(dev); dC = torch.from_numpy(Cv).to(dev)
-                dO = torch.zeros(e1.out_stride(Np), dtype=torch.float64, device=dev)
-                for _ in range(3):
-                    e1.eval_device(1, Np, dT.data_ptr(), dC.data_ptr(), dO.data_ptr(), 0, stream)
-                torch.cuda.synchronize(); t0 = time.perf_counter()
-                for _ in range(steps):
-                    e1.eval_device(1, Np, dT.data_ptr(), dC.data_ptr(), dO.data_ptr(), 0, stream)
-                torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / steps
-                st1 = e1.stats()
-                Mv = st1["units"]
-                # kernel split, separate pass: the search launches (scan + descent, or the single fused search) / what follows
-                e1.profile_enable(1, secondary=True)
-                for _ in range(min(steps, 10)):
-                    e1.eval_device(1, Np, dT.data_ptr(), dC.data_ptr(), dO.data_ptr(), 0, stream)
-                torch.cuda.synchronize()
-                _, k_search = e1.profile_read(); k_rest = e1.profile_read_secondary()
-                e1.profile_enable(0)
-                ent = {"name": name, "variant": "V1", "obstacle_points": Mv, "pieces": Np, "ms_per_step": round(dt * 1e3, 5),
-                       "evals_per_s": round(Mv / dt, 1), "unit": "obstacle-point evals/s",
-                       "kernel_ms_search_launches": round(k_search, 5), "kernel_ms_backprop_reduce": round(k_rest, 5),
-                       "active_points": st1["grad_pairs"], "intervals": st1["pairs"]}
-                if note:
-                    ent["note"] = note
-                if oracle is not None:
-                    o1, thr = oracle
-                    c0, gT0, gC0, _ = o1.eval(Tv, Cv)
-                    ref1 = np.concatenate([[c0], gT0, gC0]); got1 = dO.cpu().numpy()
-                    ent["rel_err_vs_oracle"] = float(np.linalg.norm(got1 - ref1) / max(np.linalg.norm(ref1), 1e-300))
-                    nrep = 0; tc0 = time.perf_counter()
-                    while True:
-                        o1.eval(Tv, Cv); nrep += 1
-                        if time.perf_counter() - tc0 > 3.0:
-                            break
-                    dc = (time.perf_counter() - tc0) / nrep
-                    ent["cpu_baseline_v1"] = {"value": round(Mv / dc, 1), "unit": "obstacle-point evals/s", "cores": thr, "kind": "port",
-                                              "ms_per_step": round(dc * 1e3, 3),
-                                              "sample": f"{nrep} full V1 sweeps of the same {Mv} points, oracle OpenMP schedule(dynamic) + critical-section merge like the reference"}
-                extra.append(ent)
-                return ent
-
-            if not args.no_cpu_baseline:
-                orc_v1 = graft.load_oracle()
-            try:
-                way40 = cm.reshape(3, -1).T.reshape(40, 6, 3)[1:, 0, :]
-                for nm, shp in (("rounded cone (r1 0.6, r2 0.24, h 1.8)", synth.bench_rounded_cone_shape()), ("box (1.6, 0.3, 0.3)", shape)):
-                    cfg1 = synth.default_config(capi.V1_SWEPT, device=local_rank, safety_hor=(3 ** 0.5 / 2) * res, weight_p=4000.0)
-                    e1 = pkg.Engine(cfg1); e1.set_grid(occ, (0, 0, 0), res, capi.GRID_OCCUPANCY); e1.set_shape(shp)
-                    e1.gather_points(way40, 1.4)
-                    oracle = None
-                    if not args.no_cpu_baseline:
-                        thr = min(30, os.cpu_count() or 1)
-                        o1 = orc_v1.Oracle(cfg1, threads=thr); o1.set_grid(occ, (0, 0, 0), res, capi.GRID_OCCUPANCY); o1.set_shape(shp); o1.set_points(e1.get_points())
-                        oracle = (o1, thr)
-                    ent = run_v1(f"V1 swept-volume sweep (the reference's live collision term), 40 pieces / 40 s, 256^3 occupancy, {nm}", e1, 40, T, cm, 50, oracle)
-                    if nm.startswith("rounded"):
-                        ent["roofline_issue"] = issue_from_counters(os.path.join(ROOT, "profiles", "pmc_counters_v1.json"), v1_source_hash(), live_kernel_us=ent["kernel_ms_search_launches"] * 1e3)
-                        ent["bound"] = "valu-issue / dependent-instruction latency (SURVEY 8(d): 24 B point + trajectory per workgroup - no HBM roof); see roofline_issue"
-                    del e1
-            except Exception as e:      # noqa: BLE001
-                extra.append({"name": "V1 analytic", "error": str(e)})
-            # configs[4]-shaped: V1 on the 512^3 occupancy map (0.1 m), concave 20-face mesh and a 720-face mesh through the
-            # fast-winding-number path, obstacle points gathered on the device along a 20-piece trajectory
-            try:
-                res5 = 0.1
-                occ5 = synth.random_box_map((512,) * 3, res=res5, occupancy=0.15, seed=12345, edge=(0.4, 2.0))
-                ext5 = np.array(occ5.shape) * res5
-                T5, Cf5 = synth.random_trajectory(ext5, 20, seed=780, piece_T=1.0, jitter=0.5, margin=4.0, occ=occ5, res=res5)
-                cm5 = synth.colmajor(Cf5)
-                way5 = cm5.reshape(3, -1).T.reshape(20, 6, 3)[1:, 0, :]
-                # SURVEY 8(d) names the reference's own Lthick.obj (concave, 20 faces) and Trefoil.obj (12 000 faces), "scaled to the same
-                # bound" (tests/golden/ref_meshes.npz: isdf_read_obj's view of src/plan_manager/shapes/*.obj); the synthetic L prism and
-                # the 720-face blob are the round-3 entries, kept for comparison
-                meshes = [("concave L prism, 20 faces (synthetic)", synth.l_prism_mesh(), 20, "all"),
-                          ("blob, 720 faces (synthetic)", synth.blob_mesh(24, 16, scale=0.9), 5, "all")]
-                try:
-                    meshes += [("the reference's Lthick.obj, 20 faces, scaled to a 0.83 m bound", synth.reference_mesh("Lthick", 0.83), 20, "all"),
-                               ("the reference's Trefoil.obj, 12 000 faces, scaled to a 0.83 m bound", synth.reference_mesh("Trefoil", 0.83), 3, "all")]
-                except Exception as e:      # noqa: BLE001
-                    extra.append({"name": "reference meshes", "error": str(e)})
-                for nm, (Vm, Fm), stp, omode in meshes:
-                    cfg1 = synth.default_config(capi.V1_SWEPT, device=local_rank, safety_hor=(3 ** 0.5 / 2) * res5, weight_p=4000.0)
-                    shp = synth.make_mesh_shape(Vm, Fm)
-                    e1 = pkg.Engine(cfg1); e1.set_grid(occ5, (0, 0, 0), res5, capi.GRID_OCCUPANCY); e1.set_shape(shp)
-                    e1.gather_points(way5, 0.9)
-                    oracle = None
-                    o1 = None
-                    if not args.no_cpu_baseline:
-                        thr = min(30, os.cpu_count() or 1)
-                        o1 = orc_v1.Oracle(cfg1, threads=thr); o1.set_grid(occ5, (0, 0, 0), res5, capi.GRID_OCCUPANCY); o1.set_shape(shp)
-                        if o1.mesh_backend() != 1:
-                            o1 = None
-                        elif omode == "all":
-                            o1.set_points(e1.get_points()); oracle = (o1, thr)
-                    ent = run_v1(f"C5 (configs[4]) shape: V1 sweep, 512^3 occupancy @ 0.1 m, mesh robot ({nm}) through the fast winding number, 20 pieces", e1, 20, T5, cm5, stp, oracle,
-                                 note="both sides search their own minimisers; the device's winding number is the reference library's bit for bit (csrc/dev_mesh.hpp), so t* is identical and rel_err_vs_oracle is rounding")
-                    ent["faces"] = int(len(Fm))
-                    if o1 is not None and omode == "sample":
-                        # the oracle's exhaustive closest-point search over 12 000 faces: a SAMPLE of the obstacle points, both sides on the same subset
-                        ps = np.ascontiguousarray(e1.get_points()[::40])
-                        e1.set_points(ps); o1.set_points(ps)
-                        cs, gTs, gCs = e1.eval_single(T5, cm5)
-                        c0, gT0, gC0, _ = o1.eval(T5, cm5)
-                        ref1 = np.concatenate([[c0], gT0, gC0]); got1 = np.concatenate([[cs], gTs, gCs])
-                        ent["rel_err_vs_oracle"] = float(np.linalg.norm(got1 - ref1) / max(np.linalg.norm(ref1), 1e-300))
-                        ent["rel_err_vs_oracle_of"] = f"every 40th obstacle point ({len(ps)} points), both sides on that subset"
-                    if "720" in nm:
-                        ent["roofline_issue"] = issue_from_counters(os.path.join(ROOT, "profiles", "pmc_counters_v1mesh.json"), v1_source_hash())
-                        if ent["roofline_issue"]:
-                            ent["roofline_issue"]["workload_of_the_counters"] = "tools/v1_bench.py --mesh720: the same 720-face robot on the 256^3 bench map, 7 773 points"
-                    del e1
-                del occ5
-            except Exception as e:      # noqa: BLE001
-                extra.append({"name": "C5 V1 mesh", "error": str(e)})
-            # ---- the ESDF point sampler (GridMap3D::getSDFValue / getSDFValueWithGrad, A13): the one pure gather of the path -
-            # measured against the HBM peak by its algorithmic bytes (24 B point + 8 x 4 B corners + 8 B value + 24 B gradient)
-            try:
-                npt = 20_000_000
-                gen = torch.Generator(device=dev); gen.manual_seed(7)
-                ext_m = args.grid * res
-                m_ = npt // 4096
-                a_ = torch.rand(4096, 1, 3, dtype=torch.float64, device=dev, generator=gen) * ext_m
-                d_ = torch.nn.functional.normalize(torch.randn(4096, 1, 3, dtype=torch.float64, device=dev, generator=gen), dim=2)
-                rnd_ = torch.rand(npt, 3, dtype=torch.float64, device=dev, generator=gen) * ext_m
-                sets = (("trajectory-like points (4 096 straight lines, consecutive points 2 cm apart)", (a_ + d_ * (torch.arange(m_, dtype=torch.float64, device=dev).view(1, m_, 1) * 0.02)).reshape(-1, 3).contiguous(), False),
-                        ("uniform random points", rnd_, False),
-                        ("uniform random points through the BRICKED copy (isdf_esdf_sample_scattered_device: 2 x 2 x 2-cell bricks with apron, one 128-byte line per cell neighbourhood; bitwise the same results)", rnd_, True))
-                plain_rnd = None
-                for nm_, pts_, scat_ in sets:
-                    n_ = pts_.shape[0]
-                    dv_ = torch.empty(n_, dtype=torch.float64, device=dev); dg_ = torch.empty(n_, 3, dtype=torch.float64, device=dev)
-                    for _ in range(2):
-                        eng.esdf_sample_device(pts_.data_ptr(), n_, dv_.data_ptr(), dg_.data_ptr(), stream, scattered=scat_)
-                    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                    ev0.record()
-                    for _ in range(5):
-                        eng.esdf_sample_device(pts_.data_ptr(), n_, dv_.data_ptr(), dg_.data_ptr(), stream, scattered=scat_)
-                    ev1.record(); torch.cuda.synchronize()
-                    ms_ = ev0.elapsed_time(ev1) / 5
-                    ent = {"name": f"ESDF point sampler isdf_esdf_sample_device (value + gradient), {args.grid}^3 float32 ESDF, {n_:.3g} {nm_}",
-                           "points": n_, "ms_per_launch": round(ms_, 4), "points_per_s": round(n_ / ms_ * 1e3, 1), "unit": "ESDF samples/s",
-                           "roofline": {"bound": "hbm", "achieved": round(n_ * 88 / ms_ / 1e6, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                                        "frac": round(n_ * 88 / ms_ / 1e6 / HBM_PEAK_GBS, 4), "algorithmic_bytes_per_point": 88,
-                                        "definition": "24 B point + 8 corner values x 4 B + 8 B value + 24 B gradient per point / launch duration (HIP events)"}}
-                    if not args.no_cpu_baseline:
-                        oo_ = graft.load_oracle().Oracle(cfg); oo_.set_grid(esdf, (0, 0, 0), res, capi.GRID_ESDF)
-                        ph = pts_[:2000].cpu().numpy()
-                        rr_ = np.array([np.concatenate([[dd], gg]) for dd, gg in (oo_.esdf_trilinear(q_) for q_ in ph)])
-                        got_ = np.concatenate([dv_[:2000].cpu().numpy()[:, None], dg_[:2000].cpu().numpy()], axis=1)
-                        ent["rel_err_vs_oracle"] = float(np.linalg.norm(got_ - rr_) / max(np.linalg.norm(rr_), 1e-300))
-                        ent["rel_err_vs_oracle_of"] = "the first 2 000 points (bitwise equal = 0.0)"
-                    if nm_.startswith("uniform random points") and not scat_:
-                        plain_rnd = (dv_.clone(), dg_.clone())
-                    if scat_ and plain_rnd is not None:
-                        ent["equals_plain_path_bitwise"] = bool(torch.equal(dv_, plain_rnd[0]) and torch.equal(dg_, plain_rnd[1]))
-                    extra.append(ent)
-                    del dv_, dg_
-            except Exception as e:      # noqa: BLE001
-                extra.append({"name": "ESDF sampler", "error": str(e)})
-            # configs[2] END TO END: the 128 trajectories optimised concurrently (isdf_optimize_lbfgs_batch: host MINCO + L-BFGS per
-            # trajectory, one batched device sweep per round, PCIe included) - 30 iterations each
-            try:
-                heads, tails, x0b = [], [], []
-                for b in range(128):
-                    Tb, Cfb = synth.random_trajectory(ext, 40, seed=777 + b, piece_T=1.0, jitter=0.5, margin=4.0, occ=occ, res=res)
-                    c6b = Cfb.reshape(40, 6, 3)
-                    hb = np.stack([c6b[0, 0], c6b[0, 1], 2.0 * c6b[0, 2]], axis=1)
-                    tlb = Tb[-1]
-                    pwb = lambda k: sum(np.prod([p - q for q in range(k)]) * c6b[39, p] * tlb ** (p - k) for p in range(k, 6))
-                    tb = np.stack([pwb(0), pwb(1), pwb(2)], axis=1)
-                    eng.set_trajectory(40, hb, tb, 1000.0)
-                    x0b.append(eng.pack_variables(Tb, c6b[1:, 0, :])); heads.append(hb); tails.append(tb)
-                eng.set_shard(0, 1)
-                ent_b = None
-                for mode_b, label_b in ((capi.MINCO_AUTO, "device"), (capi.MINCO_HOST, "host")):
-                    eng.set_minco_mode(mode_b)
-                    best = None
-                    for _rep in range(2):             # (the first run of a mode also pays its buffers' first touch)
-                        _, resb, wallb = eng.optimize_lbfgs_batch(40, np.array(heads), np.array(tails), 1000.0, np.array(x0b), max_iterations=30, g_epsilon=0.0, past=0)
-                        if best is None or wallb < best[1]:
-                            best = (resb, wallb)
-                    resb, wallb = best
-                    evb = sum(r["evaluations"] for r in resb); itb = sum(r["iterations"] for r in resb)
-                    rec = {"wall_ms": round(wallb, 2), "device_rounds": resb[0]["rounds"], "iterations": itb, "evaluations": evb,
-                           "evals_per_s": round(1e3 * evb * 40 * (K + 1) / wallb, 1), "trajectory_iterations_per_s": round(1e3 * itb / wallb, 1)}
-                    if ent_b is None:
-                        ent_b = {"name": "C3 END TO END (configs[2]): 128 trajectories x 40 pieces optimised concurrently, 30 L-BFGS iterations each (isdf_optimize_lbfgs_batch: the callback's MINCO half on the device, L-BFGS on host threads, PCIe included; best of 2 runs)", "minco": label_b}
-                        ent_b.update(rec)
-                    else:
-                        ent_b["host_minco"] = rec
-                eng.set_minco_mode(capi.MINCO_AUTO)
-                extra.append(ent_b)
-            except Exception as e:      # noqa: BLE001
-                extra.append({"name": "C3 end to end", "error": str(e)})
-            if extra and isinstance(extra[0], dict) and "error" not in extra[0]:
-                extra[0]["roofline"] = issue_from_counters(os.path.join(ROOT, "profiles", "pmc_counters_c3.json"), kernel_source_hash())
-            # the nominal byte model, spelled out where it stops being a bound
-            roofline["nominal_bytes"]["exceeds_1_on"] = [e_["name"] for e_ in extra if isinstance(e_, dict) and e_.get("nominal_bytes_exceeds_hbm_peak")]
+            from benchlib.configs import extra_configs
+            from types import SimpleNamespace
+            extra = extra_configs(SimpleNamespace(args=args, graft=graft, pkg=pkg, capi=capi, synth=synth, dev=dev, stream=stream, local_rank=local_rank, eng=eng, cfg=cfg,
+                                                  shape=shape, occ=occ, esdf=esdf, res=res, T=T, cm=cm, K=K, roofline=roofline))
 
         # ---- through the drop-in boundary (PCIe inclusive, synchronous, accumulate) - informational, never `value`
         host_ms = None
