@@ -124,20 +124,37 @@ def scaling_entries(B):
                 def c5_step():
                     e5.eval_device(1, 20, d5T.data_ptr(), d5C.data_ptr(), d5O.data_ptr(), d5ts.data_ptr(), stream)
                     par.allreduce_packed(d5O)
-                st5 = 5
-                el5 = plain_timed(c5_step, st5, warm=2)
-                t5 = torch.tensor([el5], dtype=torch.float64, device=dev); dist.all_reduce(t5, op=dist.ReduceOp.MAX); el5 = float(t5.item())
+                # a step lasts milliseconds: every step timed by itself (barrier, step, synchronise; MAX over the ranks per step), the
+                # MEDIAN reported - one scheduler hiccup in a five-step region had read as a 40x slowdown in a rehearsal
+                def stepwise(fn, steps, warm=2):
+                    for _ in range(warm):
+                        fn()
+                    ts_ = []
+                    for _ in range(steps):
+                        torch.cuda.synchronize(); dist.barrier()
+                        t0_ = time.perf_counter()
+                        fn()
+                        torch.cuda.synchronize()
+                        ts_.append(time.perf_counter() - t0_)
+                    tt_ = torch.tensor(ts_, dtype=torch.float64, device=dev)
+                    dist.all_reduce(tt_, op=dist.ReduceOp.MAX)
+                    return tt_.cpu().numpy()
+                st5 = 7
+                per5 = stepwise(c5_step, st5)
+                el5 = float(np.median(per5)) * st5
                 merged = d5ts.clone(); dist.all_reduce(merged, op=dist.ReduceOp.MAX)      # a rank's untouched entries are -1, minimisers are >= 0
                 sum5 = d5O.clone()
                 if rank == 0:
                     e5.set_shard(0, 1)
                     d5O1 = torch.zeros_like(d5O); d5ts1 = torch.full((M5,), -1.0, dtype=torch.float64, device=dev)
-                el5one = plain_timed((lambda: e5.eval_device(1, 20, d5T.data_ptr(), d5C.data_ptr(), d5O1.data_ptr(), d5ts1.data_ptr(), stream)) if rank == 0 else (lambda: None), st5, warm=2)
+                per5one = stepwise((lambda: e5.eval_device(1, 20, d5T.data_ptr(), d5C.data_ptr(), d5O1.data_ptr(), d5ts1.data_ptr(), stream)) if rank == 0 else (lambda: None), st5)
+                el5one = float(np.median(per5one)) * st5
                 if rank == 0:
                     c5_sharded = {"name": f"C5 (configs[4]) sharded by OBSTACLE POINT over {world} GPUs: V1 swept-volume sweep, 512^3 occupancy @ 0.1 m, mesh robot (blob, 720 faces, fast winding number), 20 pieces, "
                                           f"{M5} points, one all-reduce of {int(d5O.numel())} doubles per step ({dist.get_backend()}), lastTstar merged",
                                   "variant": "V1", "obstacle_points": int(M5), "ms_per_step": round(1e3 * el5 / st5, 5), "evals_per_s": round(M5 * st5 / el5, 1), "unit": "obstacle-point evals/s",
-                                  "scaling": "strong", "steps": st5,
+                                  "scaling": "strong", "steps": st5, "ms_per_step_is": "median of the steps (each timed by itself, MAX over the ranks)",
+                                  "ms_per_step_min_max": [round(1e3 * float(per5.min()), 5), round(1e3 * float(per5.max()), 5)],
                                   "one_gpu_same_workload": {"ms_per_step": round(1e3 * el5one / st5, 5), "evals_per_s": round(M5 * st5 / el5one, 1),
                                                             "what": "all the points unsharded on rank 0's GPU while the other ranks wait, same run"},
                                   "speedup": round(el5one / el5, 3),
