@@ -49,7 +49,12 @@ struct Batch {
     std::unique_ptr<std::condition_variable[]> cv_worker;      // one per trajectory: a delivered round wakes its own trajectories only
     std::vector<char> submitted, finished, ready;     // ready[t]: the round trajectory t joined has been evaluated
     int n_submitted = 0, n_finished = 0, n_inflight = 0;
-    double min_share = 0.25;      // a round starts when this share of the live trajectories waits (1.0: all of them)
+    double min_share = 0.25;      // greedy rounds: a round starts when this share of the live trajectories waits (1.0: all of them)
+    // GROUP rounds (the default): the trajectories are dealt into `groups` fixed groups; a group's round starts when ALL its live
+    // members wait, so every round is full, and while one group's sweep runs the other groups' host threads do their L-BFGS updates
+    // (greedy rounds ran a third full on average: 14 000 evaluations in 450 rounds).  0: greedy rounds.
+    int groups = 2;
+    std::vector<int> sub_g, live_g, busy_g;
     int error = ISDF_OK;
     // staging: slot t holds [T(N) | coeffs(18N)]; out slot t holds the sweep's [cost | gradT | gradC]
     size_t in_per = 0;
@@ -73,6 +78,7 @@ double worker_evaluate(void *instance, const double *x, double *g, const int n) 
             std::unique_lock<std::mutex> lk(b.m);
             b.submitted[w.id] = 1;
             b.n_submitted++;
+            if (b.groups > 0) b.sub_g[w.id % b.groups]++;
             b.cv_coord.notify_one();
             b.cv_worker[w.id].wait(lk, [&] { return b.ready[w.id] != 0; });
             b.ready[w.id] = 0;
@@ -92,6 +98,7 @@ double worker_evaluate(void *instance, const double *x, double *g, const int n) 
         std::unique_lock<std::mutex> lk(b.m);
         b.submitted[w.id] = 1;
         b.n_submitted++;
+        if (b.groups > 0) b.sub_g[w.id % b.groups]++;
         b.cv_coord.notify_one();
         b.cv_worker[w.id].wait(lk, [&] { return b.ready[w.id] != 0; });
         b.ready[w.id] = 0;
@@ -126,6 +133,12 @@ extern "C" int isdf_optimize_lbfgs_batch(isdf_ctx *c, int n_traj, int N, const d
     b.submitted.assign(n_traj, 0); b.finished.assign(n_traj, 0); b.ready.assign(n_traj, 0);
     b.cv_worker.reset(new std::condition_variable[n_traj]);
     if (c->minco_mode != 1 && N <= isdf::CB_MAX_N) b.min_share = 0.5;       // device MINCO: trajectories come back sooner, fuller rounds pay (measured 80 ms against 88 at 0.25)
+    if (const char *e = getenv("ISDF_BATCH_GROUPS")) { const int v = atoi(e); if (v >= 0 && v <= 16) b.groups = v; }
+    if (b.groups > n_traj) b.groups = n_traj;
+    if (b.groups > 0) {
+        b.sub_g.assign(b.groups, 0); b.live_g.assign(b.groups, 0); b.busy_g.assign(b.groups, 0);
+        for (int t = 0; t < n_traj; t++) b.live_g[t % b.groups]++;
+    }
     if (const char *e = getenv("ISDF_BATCH_MIN_SHARE")) { const double v = atof(e); if (v > 0.0 && v <= 1.0) b.min_share = v; }
     b.in_per = (size_t)19 * N;
     b.dev = c->minco_mode != 1 && N <= isdf::CB_MAX_N;
@@ -150,7 +163,7 @@ extern "C" int isdf_optimize_lbfgs_batch(isdf_ctx *c, int n_traj, int N, const d
     constexpr int N_SLOTS = 2;
     struct Slot {
         double *h_pin = nullptr, *d_buf = nullptr;
-        std::vector<int> active; hipStream_t stream = nullptr; hipEvent_t done = nullptr, sweep_done = nullptr; bool busy = false;
+        std::vector<int> active; int group = -1; hipStream_t stream = nullptr; hipEvent_t done = nullptr, sweep_done = nullptr; bool busy = false;
     } slots[N_SLOTS];
     const size_t in_all = (size_t)n_traj * b.in_per, out_all = (size_t)n_traj * b.ostride;
     // device MINCO: further device regions behind [T | coeffs | sweep out] - x + ends of the round (compacted), junction states,
@@ -197,6 +210,7 @@ extern "C" int isdf_optimize_lbfgs_batch(isdf_ctx *c, int n_traj, int N, const d
             std::unique_lock<std::mutex> lk(b.m);
             b.finished[t] = 1;
             b.n_finished++;
+            if (b.groups > 0) b.live_g[t % b.groups]--;
             b.cv_coord.notify_one();
         });
     }
@@ -269,6 +283,7 @@ extern "C" int isdf_optimize_lbfgs_batch(isdf_ctx *c, int n_traj, int N, const d
         if (rc != ISDF_OK) b.error = rc;
         for (int t : q.active) b.ready[t] = 1;
         b.n_inflight -= na;
+        if (q.group >= 0) b.busy_g[q.group] = 0;
         q.busy = false;
         if (rc != ISDF_OK) { for (int t = 0; t < b.n_traj; t++) b.cv_worker[t].notify_one(); }     // an error ends every wait
         else for (int t : q.active) b.cv_worker[t].notify_one();
@@ -279,13 +294,20 @@ extern "C" int isdf_optimize_lbfgs_batch(isdf_ctx *c, int n_traj, int N, const d
     for (;;) {
         if (n_busy == slots_used) { deliver(slots[tail_slot]); tail_slot = (tail_slot + 1) % slots_used; n_busy--; }
         bool take = false, done = false;
+        int take_group = -1;
         {
             std::unique_lock<std::mutex> lk(b.m);
             for (;;) {
+                if (b.groups > 0) {
+                    for (int g = 0; g < b.groups && take_group < 0; g++)
+                        if (!b.busy_g[g] && b.live_g[g] > 0 && b.sub_g[g] == b.live_g[g]) take_group = g;
+                    if (take_group >= 0) { take = true; break; }
+                } else {
                 // trajectories in flight cannot submit: the share refers to those that can
                 const int free_live = b.n_traj - b.n_finished - b.n_inflight;
                 const int need = std::max(1, (int)std::ceil(b.min_share * free_live));
                 if (b.n_submitted > 0 && b.n_submitted >= std::min(need, free_live)) { take = true; break; }
+                }
                 if (n_busy > 0) {
                     if (rc != ISDF_OK || hipEventQuery(slots[tail_slot].done) != hipErrorNotReady) break;   // finished (or failed): deliver it - that is where new work comes from
                     b.cv_coord.wait_for(lk, std::chrono::microseconds(20));
@@ -299,6 +321,11 @@ extern "C" int isdf_optimize_lbfgs_batch(isdf_ctx *c, int n_traj, int N, const d
                 // at most round_cap trajectories per round: a herd that submits together is split into several rounds whose
                 // MINCO kernels run side by side and whose sweeps follow each other without a gap
                 q.active.clear();
+                q.group = take_group;
+                if (take_group >= 0) {
+                    for (int t = take_group; t < n_traj; t += b.groups) if (b.submitted[t]) { q.active.push_back(t); b.submitted[t] = 0; }
+                    b.busy_g[take_group] = 1; b.sub_g[take_group] = 0;
+                } else
                 for (int t = 0; t < n_traj && (int)q.active.size() < round_cap; t++) if (b.submitted[t]) { q.active.push_back(t); b.submitted[t] = 0; }
                 b.n_inflight += (int)q.active.size();
                 b.n_submitted -= (int)q.active.size();
