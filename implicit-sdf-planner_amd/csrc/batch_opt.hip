@@ -160,7 +160,7 @@ extern "C" int isdf_optimize_lbfgs_batch(isdf_ctx *c, int n_traj, int N, const d
     }
     b.stage_in.assign((size_t)n_traj * b.in_per, 0.0); b.stage_out.assign((size_t)n_traj * b.ostride, 0.0);
     // device + pinned buffers for a full batch per slot: N_SLOTS rounds are in flight, each on its own stream
-    constexpr int N_SLOTS = 2;
+    constexpr int N_SLOTS = 4;          // rounds in flight at most (slots_used of them are used)
     struct Slot {
         double *h_pin = nullptr, *d_buf = nullptr;
         std::vector<int> active; int group = -1; hipStream_t stream = nullptr; hipEvent_t done = nullptr, sweep_done = nullptr; bool busy = false;
@@ -289,7 +289,8 @@ extern "C" int isdf_optimize_lbfgs_batch(isdf_ctx *c, int n_traj, int N, const d
         else for (int t : q.active) b.cv_worker[t].notify_one();
     };
     const int round_cap = n_traj;
-    const int slots_used = N_SLOTS;
+    int slots_used = 2;
+    if (const char *e = getenv("ISDF_BATCH_SLOTS")) { const int v = atoi(e); if (v >= 1 && v <= N_SLOTS) slots_used = v; }
     int head_slot = 0, tail_slot = 0, n_busy = 0;      // ring: rounds are delivered in the order they were issued
     for (;;) {
         if (n_busy == slots_used) { deliver(slots[tail_slot]); tail_slot = (tail_slot + 1) % slots_used; n_busy--; }

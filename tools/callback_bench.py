@@ -101,8 +101,8 @@ if not quick:
         eng.set_trajectory(N, head, tail, 1000.0)
         x0s.append(eng.pack_variables(Tb, way)); heads.append(head); tails.append(tail)
     x0s = np.array(x0s)
-    for groups in ("2", "0", "1", "3", "4"):
-        os.environ["ISDF_BATCH_GROUPS"] = groups
+    for groups, slots in (("3", "2"), ("3", "3"), ("4", "3"), ("5", "3"), ("6", "3"), ("4", "4"), ("2", "2"), ("0", "2")):
+        os.environ["ISDF_BATCH_GROUPS"] = groups; os.environ["ISDF_BATCH_SLOTS"] = slots
         for mode, label in ((capi.MINCO_DEVICE, "device"), (capi.MINCO_HOST, "host")):
             eng.set_minco_mode(mode)
             walls = []
@@ -110,6 +110,6 @@ if not quick:
                 xs, results, wall = eng.optimize_lbfgs_batch(N, np.array(heads), np.array(tails), 1000.0, x0s, max_iterations=30, g_epsilon=0.0, past=0)
                 walls.append(wall)
             ev = sum(r["evaluations"] for r in results)
-            print(f"C3 end to end, 128 x 40 pieces, 30 iterations, {label:6s} MINCO, {'greedy rounds' if groups == '0' else groups + ' group(s), full rounds'}: wall ms {', '.join(f'{w:.1f}' for w in walls)}; {results[0]['rounds']} rounds, {ev} evaluations "
+            print(f"C3 end to end, 128 x 40 pieces, 30 iterations, {label:6s} MINCO, {'greedy rounds' if groups == '0' else groups + ' group(s), full rounds'}, {slots} rounds in flight: wall ms {', '.join(f'{w:.1f}' for w in walls)}; {results[0]['rounds']} rounds, {ev} evaluations "
                   f"-> {1e3 * ev * N * 65 / min(walls):.4g} point-evals/s (best), mean f {np.mean([r['f'] for r in results]):.9g}", flush=True)
-    os.environ.pop("ISDF_BATCH_GROUPS", None)
+    os.environ.pop("ISDF_BATCH_GROUPS", None); os.environ.pop("ISDF_BATCH_SLOTS", None)
