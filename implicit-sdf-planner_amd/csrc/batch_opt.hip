@@ -52,8 +52,11 @@ struct Batch {
     double min_share = 0.25;      // greedy rounds: a round starts when this share of the live trajectories waits (1.0: all of them)
     // GROUP rounds (the default): the trajectories are dealt into `groups` fixed groups; a group's round starts when ALL its live
     // members wait, so every round is full, and while one group's sweep runs the other groups' host threads do their L-BFGS updates
-    // (greedy rounds ran a third full on average: 14 000 evaluations in 450 rounds).  0: greedy rounds.
-    int groups = 2;
+    // (greedy rounds ran a third full on average: 14 000 evaluations in 450 rounds).  Measured on two boxes, 128 x 40 pieces x 30
+    // iterations, device MINCO (profiles/r5_callback_bench.txt): 4 groups with three rounds in flight 75 ms on both (= 93 % of the
+    // batched sweep's own rate), 3 groups / two in flight 75-83, 2 groups 74-95, 5-6 groups 97-103, one group 120, greedy 80-105; with
+    // MINCO on the host threads 75-89.  0 (ISDF_BATCH_GROUPS=0): greedy rounds.
+    int groups = 4;
     std::vector<int> sub_g, live_g, busy_g;
     int error = ISDF_OK;
     // staging: slot t holds [T(N) | coeffs(18N)]; out slot t holds the sweep's [cost | gradT | gradC]
@@ -289,7 +292,7 @@ extern "C" int isdf_optimize_lbfgs_batch(isdf_ctx *c, int n_traj, int N, const d
         else for (int t : q.active) b.cv_worker[t].notify_one();
     };
     const int round_cap = n_traj;
-    int slots_used = 2;
+    int slots_used = 3;
     if (const char *e = getenv("ISDF_BATCH_SLOTS")) { const int v = atoi(e); if (v >= 1 && v <= N_SLOTS) slots_used = v; }
     int head_slot = 0, tail_slot = 0, n_busy = 0;      // ring: rounds are delivered in the order they were issued
     for (;;) {
