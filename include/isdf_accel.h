@@ -397,12 +397,16 @@ int isdf_optimize_lbfgs(isdf_ctx *ctx, double *x_inout, int n, const isdf_lbfgs_
 /* A batch of trajectories optimised CONCURRENTLY on the shared map (BASELINE.json configs[2]): trajectory t has its own
  * boundary states heads_pva[9t..], tails_pva[9t..] (3x3 column-major each, like isdf_set_trajectory) and its own
  * variables x_inout[t*n .. (t+1)*n), n = N + 3(N-1); all share N, rho and the ctx's map / robot / weights.  Each runs
- * the same L-BFGS driver on its own callback; the callbacks of a round are evaluated as ONE batched integral sweep on the
- * device, two rounds in flight.  MINCO (minco.hpp:43-198,433-513,530-654) runs on the trajectories' host threads (a solve is a
- * chain of 3 x 6N dependent fp64 steps: ~10 us on a CPU core; a device form measured 2.3x slower for the whole batch and was
- * removed in round 4).  The iterates are identical to optimising every trajectory alone
- * with isdf_optimize_lbfgs.  results[t].reserved = number of device rounds of the whole batch.  V2 / V3 contexts only; not on
- * a sharded ctx (shard the batch across ranks instead). */
+ * the same L-BFGS driver on its own callback (one host thread per trajectory); the callbacks of a round are evaluated as ONE
+ * batched integral sweep on the device.  The trajectories are dealt into 4 fixed groups (ISDF_BATCH_GROUPS), a group's round
+ * starts when all its live members wait - every round is full - and up to three rounds are in flight (ISDF_BATCH_SLOTS), so that
+ * one group's sweep runs while the others' host threads do their L-BFGS updates: 128 x 40 pieces x 30 iterations in 75 ms = 4.9e8
+ * point-evals/s end to end, 93 % of the batched sweep's own rate.  MINCO (minco.hpp:43-198,433-513,530-654) of a round runs on
+ * the device, one workgroup per trajectory, either side of the sweep (csrc/minco_dev.hip); isdf_set_minco_mode(ctx, 1) keeps it on
+ * the trajectories' host threads.  The iterates are bit for bit those of optimising every trajectory alone with
+ * isdf_optimize_lbfgs UNDER THE SAME MINCO MODE (mode 0 picks the host form for a single trajectory of <= 64 pieces and the
+ * device form for the batch: set the mode explicitly to compare).  results[t].reserved = number of device rounds of the whole
+ * batch.  V2 / V3 contexts only; not on a sharded ctx (shard the batch across ranks instead). */
 int isdf_optimize_lbfgs_batch(isdf_ctx *ctx, int n_traj, int N, const double *heads_pva, const double *tails_pva, double rho,
                               double *x_inout, const isdf_lbfgs_params *p, isdf_lbfgs_result *results, double *wall_ms_out);
 

@@ -27,6 +27,8 @@ x0s = np.array(x0s)
 c_first = []
 for b in range(min(n_traj, 8)):
     eng.set_trajectory(N, heads[b], tails[b], 1000.0); c_first.append(eng.cost_function(x0s[b])[0])
+eng.set_minco_mode(capi.MINCO_DEVICE)          # (the batch runs MINCO on the device by default; the one-at-a-time runs below are held to the same form: bitwise equal iterates)
+eng.optimize_lbfgs_batch(N, np.array(heads), np.array(tails), 1000.0, x0s, max_iterations=iters, g_epsilon=0.0, past=0)      # warm-up: buffers' first touch
 xs, results, wall = eng.optimize_lbfgs_batch(N, np.array(heads), np.array(tails), 1000.0, x0s, max_iterations=iters, g_epsilon=0.0, past=0)
 it = sum(r["iterations"] for r in results); ev = sum(r["evaluations"] for r in results)
 print(f"batch of {n_traj} x {N} pieces, {iters} L-BFGS iterations each: {wall:9.1f} ms wall, {results[0]['rounds']} device rounds, "
