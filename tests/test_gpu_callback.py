@@ -237,11 +237,13 @@ def _rel_inf(a, b):
 
 @pytest.mark.parametrize("variant,N,piece_scale", [("V3", 1, 1.0), ("V3", 2, 1.0), ("V3", 6, 1.0), ("V3", 40, 1.0), ("V3", 40, 0.2),
                                                    ("V3", 65, 0.5), ("V2", 6, 1.0), ("V1", 6, 1.0), ("V1", 17, 1.0)])
-def test_device_minco_callback_equals_host_minco_callback(pkg, orc, product_lib, variant, N, piece_scale):
+def test_device_minco_callback_equals_host_minco_callback(pkg, orc, product_lib, variant, N, piece_scale, monkeypatch):
     """Same x through both forms of the callback: MINCO in log depth on the device (junction states + parallel cyclic reduction)
     and the reference's band LU on the host.  Different elimination orders, so equal to rounding, not bitwise: 1e-9 relative
     on (cost, g) - and both against the oracle at the north-star tolerance."""
     capi, synth = pkg.capi, pkg.synth
+    for k in ("ISDF_HOST_MINCO", "ISDF_DEVICE_MINCO"):           # (the library's own choice is part of what is tested)
+        monkeypatch.delenv(k, raising=False)
     occ, esdf, res = small_world(pkg)
     head, tail, way, T0 = _setup(pkg, occ, res, N, 300 + N)
     T0 = T0 * piece_scale
