@@ -392,7 +392,7 @@ def main():
                 host_timer = "python/ctypes (no C++ compiler at hand): includes ~15 us of marshalling per call"
 
         # second half of BASELINE.json's metric: "L-BFGS iter ms" - the optimizer driver (isdf_optimize_lbfgs) on the
-        # full objective callback (host MINCO + the device sweeps), same map / robot / piece count.  Informational.
+        # full objective callback (MINCO where the library puts it - `lbfgs.minco` says - + the device sweeps), same map / robot / piece count.  Informational.
         lbfgs = None
         if world == 1 and args.lbfgs_iters > 0:
             c_first = eng.cost_function(x0)[0]

@@ -277,7 +277,7 @@ def extra_configs(B):
             del dv_, dg_
     except Exception as e:      # noqa: BLE001
         extra.append({"name": "ESDF sampler", "error": str(e)})
-    # configs[2] END TO END: the 128 trajectories optimised concurrently (isdf_optimize_lbfgs_batch: host MINCO + L-BFGS per
+    # configs[2] END TO END: the 128 trajectories optimised concurrently (isdf_optimize_lbfgs_batch: L-BFGS on a host thread per
     # trajectory, one batched device sweep per round, PCIe included) - 30 iterations each
     try:
         heads, tails, x0b = [], [], []

@@ -2,11 +2,11 @@
 // it around the two device sweeps (back_end_optimizer.hpp:358-430):
 //   minco.setParameters / getEnergy / getEnergyPartialGradByCoeffs / getEnergyPartialGradByTimes / propogateGrad
 //   (src/utils/include/utils/minco.hpp:397-655) on the banded LU of :43-198 (no pivoting, 6 sub- and super-diagonals).
-// Why it runs on the host (DESIGN.md "N1"): the banded factorisation is a chain of 6N dependent pivots; one CPU core
-// walks it in ~10 us at N = 40, a single GPU wavefront needs >= 60 us for the same chain (measured pivot step ~250
-// cycles), and the chain is the same length for every trajectory of a batch.  The device does the parallel part of the
-// callback (the sweeps); this file is the serial glue either side of it, written so that every element sees the same
-// sequence of floating-point operations as the reference's loops (same elimination order, same skipped zeros).
+// This is the HOST form of the callback's MINCO half (isdf_set_minco_mode(ctx, 1), and the library's own choice for a single
+// trajectory of <= 64 pieces on the tile sweep): the reference's banded factorisation, a chain of 6N dependent pivots that one
+// CPU core walks in ~10 us at N = 40 - written so that every element sees the same sequence of floating-point operations as the
+// reference's loops (same elimination order, same skipped zeros).  The DEVICE form (csrc/minco_dev.hip, minco_pcr.hpp) solves the
+// same trajectory in its junction states by parallel cyclic reduction and agrees with this one to rounding (1e-10 relative).
 #pragma once
 #include <algorithm>
 #include <cmath>
