@@ -81,3 +81,8 @@ print("  the 12 longest tasks (us, passes, sign-descent iterations):", ", ".join
 print("  iterations per pass:", pct(ti / np.maximum(tp, 1)))
 print("  us per pass:", pct(us(te - ts) / np.maximum(tp, 1)))
 print("  task end   :", pct(us(te - b2)))
+idx = np.nonzero(ok)[0]
+for lo, hi in ((0, 4096), (4096, 1 << 30)):      # the tasks that start with the launch / behind them (4 096 wavefronts are resident)
+    m = (idx >= lo) & (idx < hi)
+    if m.any():
+        print(f"  tasks [{lo}, {min(hi, M)}): {m.sum()}  start {pct(us(ts[m] - b2))} | time {pct(dur[m])} | us per pass {pct(dur[m] / np.maximum(tp[m], 1))}")
