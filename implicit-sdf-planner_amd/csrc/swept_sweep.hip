@@ -184,17 +184,17 @@ __device__ __forceinline__ double wave_first_min(double v, int lane, int n, int 
     return m;
 }
 
-// ---- mesh robots: ONE (point / interval) per WORKGROUP.  The four wavefronts of the workgroup run the same control flow on the
-// same numbers (so every ballot, every branch and every barrier below is taken by all of them alike); where the lanes of a pass
-// evaluate the mesh SDF, the ACTIVE queries are dealt to the four wavefronts - each takes ceil(n / 4) of them, 4 lanes per query
-// (dev_mesh.hpp, quad-cooperative walks) - and the results come back through LDS.  A pass next to the surface (all of the
-// hierarchy opened by 25-64 queries) was one wavefront's 1e5 dependent instructions; it is now four wavefronts' 1e4 each.
+// ---- mesh robots: ONE (point / interval) per WORKGROUP.  The wavefronts of the workgroup (two in the scan, one in the descent) run
+// the same control flow on the same numbers (so every ballot, every branch and every barrier below is taken by all of them alike);
+// where the lanes of a pass evaluate the mesh SDF, the ACTIVE queries are dealt to the wavefronts, 16 per wavefront and round, 4 lanes
+// per query (dev_mesh.hpp, quad-cooperative walks) - and the results come back through LDS.  A pass next to the surface (all of the
+// hierarchy opened by 25-64 queries) was one wavefront's 1e5 dependent instructions in round 3.
 struct MeshWG {
     double *stage;       // this wavefront's [64][4] compacted queries: point, cap (wave-private: no barrier)
     double *res;         // the workgroup's [2 parities][64][5] results: (below, sdf, g.xyz)
     int parity, wave;
     MeshFrames frames;   // this wavefront's walk frames (dev_mesh.hpp): a view into the dynamic LDS, as many levels as the hierarchy has
-    int n_waves;         // wavefronts of the workgroup (4 in the scan: up to 64 queries per pass; 2 in the descent: 25)
+    int n_waves;         // wavefronts of the workgroup (2 in the scan: up to 64 queries per pass; 1 in the descent: at most 14, 19 in a first pass without a seed)
 };
 constexpr int MESH_WG_RES = 2 * 64 * 5;
 constexpr int mesh_wg_stage(int nw) { return nw * 64 * 4; }
@@ -408,6 +408,9 @@ __device__ __forceinline__ void scan_body(const SweptParams &P, double *s_dyn, c
 
     // ---------------- fine scans (:423-438): lanes = 0.02 s steps, each accumulating its own t by repeated addition
     double range_time_seed = 0.0;
+    // (mesh robots, workgroup form: the seed also carries its SDF value and dSDF/dt there - the descent's first pass then knows f(x)
+    // and on which side its candidates lie, see descent_body; NaN: no fine sample has been the minimum yet)
+    double seed_f = 0.0, seed_gd = __builtin_nan("");
     int n_pass = 0;
     double *const slots = P.task_buf + (size_t)(pt - P.point_begin) * SW_MAX_RANGES * TASK_STRIDE;
     for (int r = 0; r < n_ranges; r++) {
@@ -421,17 +424,23 @@ __device__ __forceinline__ void scan_body(const SweptParams &P, double *s_dyn, c
             double val = 1e300;
             d3 pv_unused = mk3(0, 0, 0), g_unused = pv_unused;
             // (mesh robots: only a value BELOW the running minimum can change it - the hierarchy's distance cutoff answers the rest)
-            if constexpr (MESH) eval_lane<KIND, LDS, true>(P, tr, p, act ? te : lb, 0, false, false, val, pv_unused, g_unused, &mwg, act, range_mindis);
+            if constexpr (MESH) eval_lane<KIND, LDS, true>(P, tr, p, act ? te : lb, 0, true, true, val, pv_unused, g_unused, &mwg, act, range_mindis);
             else if (act) eval_lane<KIND, LDS, false, KIND == ISDF_SHAPE_MESH>(P, tr, p, te, 0, false, false, val, pv_unused, g_unused, nullptr, true, range_mindis);
             n_pass++;
             const int nv = __popcll(__ballot(act));                  // valid lanes form a prefix (t is increasing)
             int arg;
             const double m = wave_first_min(val, lane, nv, arg);
-            if (arg >= 0 && m < range_mindis) { range_mindis = m; range_time_seed = rlane(te, __builtin_amdgcn_readfirstlane(arg)); }
+            if (arg >= 0 && m < range_mindis) {
+                range_mindis = m; range_time_seed = rlane(te, __builtin_amdgcn_readfirstlane(arg));
+                if constexpr (MESH) { seed_f = m; seed_gd = rlane(dot3(g_unused, pv_unused), __builtin_amdgcn_readfirstlane(arg)); }
+            }
             if (nv < 64) break;
             t_base = rlane(te, 63) + dt;
         }
-        if (writer) { double *o = slots + (size_t)r * TASK_STRIDE; o[0] = lb; o[1] = ub; o[2] = range_time_seed; }
+        if (writer) {
+            double *o = slots + (size_t)r * TASK_STRIDE; o[0] = lb; o[1] = ub; o[2] = range_time_seed;
+            if constexpr (MESH) { o[3] = seed_f; o[4] = seed_gd; }
+        }
     }
     if (writer) {
         P.point_nr[pt] = n_ranges | (n_pass << 8);
@@ -524,6 +533,7 @@ __device__ __forceinline__ void descent_body(const SweptParams &P, double *s_dyn
     const bool fd_central = (KIND != ISDF_SHAPE_MESH) && gmode == ISDF_GRAD_CENTRAL;
     const bool fd_forward = (KIND != ISDF_SHAPE_MESH) && gmode == ISDF_GRAD_BOX_FORWARD;
     const bool own_grad = !fd_central && !fd_forward;
+    constexpr bool DIRECTED = MESH;                          // workgroup-cooperative mesh descents (see the task loop; the wave-cooperative walks of small meshes: measured slower with it)
     // this lane's role in a pass: block (0..6) and offset inside it (0 = the pose lane)
     const int gd_blk = lane < 18 ? -1 : (lane < 25 ? 0 : (lane < 60 ? (lane - 25) / 7 + 1 : (lane == 60 ? GD_SPEC + 1 : -1)));
     const int gd_off = lane < 18 ? 0 : (lane < 25 ? lane - 18 : (lane < 60 ? (lane - 25) % 7 : 0));
@@ -543,7 +553,82 @@ __device__ __forceinline__ void descent_body(const SweptParams &P, double *s_dyn
         int iter = 0, n_pass = 0;
         int s_spec = 0;                            // direction of the look-ahead blocks (0: none)
         bool grad_only = false;                    // final pass: lanes 18-24 only, the gradient at the final x
+        // Mesh robots: DIRECTED passes.  A hierarchy query returns the gradient with the value, so every candidate lane can form
+        // dSDF/dt at ITS time as well (the pose and the point velocity are computed by the wavefront anyway): the accepted candidate
+        // hands the next iterate its gradient and the sign of dSDF/dt - the next pass knows on which side its nine halving candidates
+        // lie before it starts.  Lanes of a directed pass: 0-8 candidates x - tau_k * dir; 9-13 poses at y_2 .. y_6 when the last
+        // step was a full step in this direction (y_1 IS candidate 0).  At most 14 hierarchy queries = ONE quad round (the regular
+        // pass: 25 = two), no query at x itself, and never a gradient-only pass: 10 -> 6 walks for a descent of five passes.  Same
+        // evaluations (a candidate's arithmetic at time t is the pose lane's at x = t), same accept tests, same t*.
+        // The first pass is directed as well: the scan's fine pass that found the seed evaluated the very same point at the very same
+        // time (swept_scan_kernel leaves f and dSDF/dt with the seed) - only a descent that accepts no step at all still needs the
+        // gradient at its seed (one query).
+        bool dir_known = false, g_valid = false;
+        int dir = 0;                               // sign of dSDF/dt at x
+        d3 g_x = mk3(0, 0, 0);                     // shape gradient at x (wave-uniform; g_valid)
+        if constexpr (DIRECTED) {
+            const double gd0 = slot[4];
+            if (gd0 == gd0) { fx = slot[3]; dir = (int)(gd0 > 0) - (int)(gd0 < 0); dir_known = true; }
+        }
         for (int guard = 0; guard < 4096; guard++) {
+            if (DIRECTED && dir_known) {
+                if (dir == 0) {                                           // no candidate set (:1040): the descent stops here
+                    iter += 9;
+                    if (g_valid) break;
+                    grad_only = true; dir_known = false; continue;
+                }
+                const bool ahead = s_spec != 0 && s_spec == dir;
+                double te = x;
+                const bool act = lane < 9 || (ahead && lane < 14);
+                if (lane < 9) {
+                    double tau = 0.02;
+                    for (int q = 0; q < 8; q++) if (q < lane) tau = 0.5 * tau;
+                    te = x - tau * (dir > 0 ? 1 : -1);
+                    te = fmax(fmin(te, t_max), t_min);
+                } else if (act) {
+                    for (int st = 0; st < GD_SPEC + 1; st++) if (st < lane - 7) te = fmax(fmin(te - 0.02 * dir, t_max), t_min);      // lane 7 + m: y_m
+                }
+                double val = 1e300;
+                d3 pvel = mk3(0, 0, 0), gq = mk3(0, 0, 0);
+                if constexpr (MESH) eval_lane<KIND, LDS, true>(P, tr, p, te, 0, true, true, val, pvel, gq, &mwg, act, fx);
+                else if (act) eval_lane<KIND, LDS>(P, tr, p, te, 0, true, true, val, pvel, gq, nullptr, true, fx);
+                n_pass++;
+                const double gdot = dot3(gq, pvel);
+                prev_x = x;
+                const unsigned long long accm = __ballot(lane < 9 && ((val - fx) < 0));
+                if (!accm) {                                              // no step decreases the SDF
+                    iter += 9;
+                    if (g_valid) break;
+                    grad_only = true; dir_known = false; continue;        // (stopped at its seed: the gradient there)
+                }
+                int src = __ffsll((long long)accm) - 1;                   // first (largest) step that does
+                iter += src + 1;
+                x = rlane(te, src);
+                fx = rlane(val, src);
+                bool full = src == 0, done = false;
+                s_spec = full ? dir : 0;
+                if (!(iter < 300 && fabs(x - prev_x) > 1e-5)) done = true;
+                // marching: while the step at y_m is again the full step in this direction (y_1 on lane 0, y_m on lane 7 + m)
+                for (int m = 1; !done && full && ahead && m <= GD_SPEC; m++) {
+                    const double gm = rlane(gdot, src);
+                    if (((int)(gm > 0) - (int)(gm < 0)) != dir) { s_spec = 0; break; }    // direction changes at y_m: a pass without look-ahead from there
+                    const int nb = 8 + m;                                 // y_(m+1)
+                    const double fc = rlane(val, nb);
+                    if (!((fc - fx) < 0)) { s_spec = 0; break; }          // full step rejected: its halvings are the next pass
+                    prev_x = x;
+                    iter += 1;
+                    x = rlane(te, nb);
+                    fx = fc;
+                    src = nb;
+                    if (!(iter < 300 && fabs(x - prev_x) > 1e-5)) done = true;
+                }
+                const double gs = rlane(gdot, src);
+                dir = (int)(gs > 0) - (int)(gs < 0);
+                g_x = mk3(rlane(gq.x, src), rlane(gq.y, src), rlane(gq.z, src));
+                g_valid = true;
+                if (done) break;
+                continue;
+            }
             // ---- what this lane evaluates
             double te = 0.0;
             int pert = 0;                 // 0: the body-frame point itself; 1..6: central-difference sample; 7..9: forward difference
@@ -556,6 +641,7 @@ __device__ __forceinline__ void descent_body(const SweptParams &P, double *s_dyn
                     te = x - tau * (lane < 9 ? 1 : -1);
                     te = fmax(fmin(te, t_max), t_min);
                     act = true;
+                    pose_lane = DIRECTED;          // (directed passes: a candidate forms dSDF/dt at its own time as well)
                 }
             } else if (gd_blk == 0 || (gd_blk > 0 && !grad_only && s_spec != 0)) {
                 // y_blk: gd_blk full steps from x in the direction s_spec, clamped like every candidate (:1046-1047)
@@ -618,6 +704,12 @@ __device__ __forceinline__ void descent_body(const SweptParams &P, double *s_dyn
                         g_src = -1;
                         full = d == 0;
                         if (full) spec_next = sgn;
+                        if constexpr (DIRECTED) {
+                            const double gs = rlane(gdot, src);
+                            dir = (int)(gs > 0) - (int)(gs < 0); dir_known = true;
+                            g_x = mk3(rlane(gq.x, src), rlane(gq.y, src), rlane(gq.z, src));
+                            g_valid = true;
+                        }
                     } else {
                         iter += 9;
                         stop = true;
@@ -643,13 +735,14 @@ __device__ __forceinline__ void descent_body(const SweptParams &P, double *s_dyn
             g_keep = gq;
             s_spec = spec_next;
             if (finished) {
-                if (g_src >= 0) break;
+                if (g_src >= 0 || (DIRECTED && g_valid)) break;
                 grad_only = true;          // the last step moved x: one more pass for the gradient there
             }
         }
         // the gradient at the final x: on the pose lane of the block that evaluated there (lane 18 after a grad_only pass)
         const int gl = g_src >= 0 ? g_src : 18;
-        const d3 g1_at_x = mk3(rlane(g_keep.x, gl), rlane(g_keep.y, gl), rlane(g_keep.z, gl));
+        d3 g1_at_x = mk3(rlane(g_keep.x, gl), rlane(g_keep.y, gl), rlane(g_keep.z, gl));
+        if (DIRECTED && g_valid) g1_at_x = g_x;
         // interval result: (t_r, sdf_r, gradient at t_r) - the best interval is picked in order by the back-prop kernel (:739-744)
         if (writer) {
             slot[0] = x; slot[1] = fx; slot[2] = g1_at_x.x; slot[3] = g1_at_x.y; slot[4] = g1_at_x.z;
@@ -955,13 +1048,17 @@ void launch_swept_sweep(const SweptParams &P, hipStream_t stream, hipEvent_t ev_
                                    else { hipExtLaunchKernelGGL((swept_scan_kernel<K, false>), grid, block, 0, stream, ev_start, nullptr, 0, P); \
                                           hipExtLaunchKernelGGL((swept_descent_kernel<K, false>), grid, block, 0, stream, nullptr, ev_stop, 0, P); } break;
     if (mesh_wg) {
-        // two wavefronts per point / task (a fine pass of the scan has up to 64 queries: two rounds each; a descent pass 25 = 16 + 9)
+        // scan: two wavefronts per point (a fine pass has up to 64 queries: two quad rounds each)
         const dim3 block2(128);
         const size_t fr2 = (size_t)2 * mesh_frames_words(P.shape.mesh_levels) * sizeof(unsigned);      // two wavefronts' frames
         // (the trajectory stays in global memory for these launches: a pass is dominated by the hierarchy walks, and the 6 KB of staged
         // coefficients per workgroup were a workgroup less per CU - Trefoil.obj 9.0 -> 8.1 ms, 720 faces 4.75 -> 4.49 ms)
         hipExtLaunchKernelGGL((swept_scan_kernel<ISDF_SHAPE_MESH, false, 2>), grid, block2, fr2, stream, ev_start, nullptr, 0, P);
-        hipExtLaunchKernelGGL((swept_descent_kernel<ISDF_SHAPE_MESH, false, 2>), grid, block2, fr2, stream, nullptr, ev_stop, 0, P);
+        // The descent's passes are directed (descent_body): at most 14 queries = one quad round on ONE wavefront - one-wavefront
+        // workgroups, twice the tasks in flight.  Measured against two wavefronts per task (the second one idle but for a first pass
+        // without a usable seed): 16 611 points, blob 9.63 -> 7.78 ms, Trefoil.obj 6.62 -> 5.68; an eighth of them (a rank's shard of
+        // an 8-GPU step) 1.98 -> 1.94 / 2.45 -> 2.44; bench map, 7 773 points, 3.71 -> 3.65 ms.
+        hipExtLaunchKernelGGL((swept_descent_kernel<ISDF_SHAPE_MESH, false, 1>), grid, dim3(64), fr2 / 2, stream, nullptr, ev_stop, 0, P);
         return;
     }
     switch (P.shape.kind) {
