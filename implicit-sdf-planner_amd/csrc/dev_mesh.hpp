@@ -464,7 +464,9 @@ __device__ inline float mesh_solid_angle_quad(const DevMesh *m, MeshFrames F, fl
 // triangle test in front of the walk cost more: C5-shaped blob 13.6 -> 15.3 ms, Trefoil.obj 11.8 -> 13.0 ms.)
 // Closest point for 16 queries.  `best` in: the query's cutoff (squared), out: min(exact squared distance, cutoff); `closest`
 // is written when a triangle beat the cutoff.  The four lanes of a quad pass the same arguments and get the same results.
-__device__ inline double mesh_closest_quad(const DevMesh *m, MeshFrames F, d3 p, bool act, d3 &closest, double best) {
+// `floor2`: a query whose distance (squared) is proven to be AT MOST this has its answer (an inside query that only asks "deeper
+// than ...?") and leaves the walk; the value returned for it is then an upper bound <= floor2, not the distance.
+__device__ inline double mesh_closest_quad(const DevMesh *m, MeshFrames F, d3 p, bool act, d3 &closest, double best, const double floor2 = -1.0) {
     const int lane = (int)__lane_id(), l = lane & 3, qsh = lane & 60;
     const mesh_cptr<DevMesh> mu = mesh_const_uni(m);
     const float *boxq = mu->fwn_boxq;
@@ -513,6 +515,7 @@ __device__ inline double mesh_closest_quad(const DevMesh *m, MeshFrames F, d3 p,
             if (d < mine || (d == mine && myf >= 0 && ci < myf)) { mine = d; myc = c; myf = ci; }
         }
         best = quad_min(mine);
+        if (best <= floor2) act = false;
         // internal children some query still wants, farthest first on the stack (the nearest ends on top); order by the bound of
         // the first wanting query (the queries of a wavefront are neighbours)
         const unsigned long long W = __ballot(ci < -1 && lb2 < best);
@@ -561,17 +564,22 @@ __device__ inline bool mesh_sdf_grad_below_quad(const DevMesh *m, MeshFrames F, 
 #endif
     const double w = (double)sa / (4.0 * 3.14159265358979323846);
     const double s = 1. - 2. * w;
-    double cutoff2 = 1.7976931348623157e308;
+    double cutoff2 = 1.7976931348623157e308, floor2 = -1.0;
     if (s > 0.0 && cap < 1.0e300) {
         if (!(cap > 0.0)) act = false;                  // outside and sdf >= 0 >= cap
         else { const double dc = cap / s; cutoff2 = dc * dc * (1.0 + 1e-12); }
+    } else if (s < 0.0 && cap < 0.0) {
+        // inside, and the question is "deeper than cap?": sdf = s * dist < cap <=> dist > cap / s - a triangle within that distance
+        // answers no (the swept-volume scans ask it of every sample against the running minimum); a hair below: errs towards "evaluate"
+        const double dc = cap / s;
+        floor2 = dc * dc * (1.0 - 1e-12);
     }
     d3 c = mk3(0, 0, 0);
-    double d2 = mesh_closest_quad(m, F, p, act, c, cutoff2);
+    double d2 = mesh_closest_quad(m, F, p, act, c, cutoff2, floor2);
 #if ISDF_MESH_DUP == 2
-    { d3 c2 = mk3(0, 0, 0); double e2 = mesh_closest_quad(m, F, mk3(p.x + 1e-300, p.y, p.z), act, c2, cutoff2); asm volatile("" : "+v"(e2)); if (e2 == -1.0) d2 = e2; }
+    { d3 c2 = mk3(0, 0, 0); double e2 = mesh_closest_quad(m, F, mk3(p.x + 1e-300, p.y, p.z), act, c2, cutoff2, floor2); asm volatile("" : "+v"(e2)); if (e2 == -1.0) d2 = e2; }
 #endif
-    if (!act || d2 >= cutoff2) return false;
+    if (!act || d2 >= cutoff2 || d2 <= floor2) return false;
     sdf = s * sqrt(d2);
     g = normalized3(s * (p - c));
     return true;
