@@ -30,6 +30,7 @@ struct isdf_ctx {
     int *d_fwn_child = nullptr;
     float *d_fwn_box = nullptr, *d_fwn_boxq = nullptr;
     double *d_fwn_triq = nullptr;
+    float *d_mesh_dl = nullptr;          // the mesh kind's distance lattice (DevMesh::dl)
     double *d_shape_grid = nullptr;      // ISDF_SHAPE_GRID: the sampled lattice
     void *d_pose = nullptr; size_t pose_cap = 0;      // pose records of a non-fused integral step (bytes)
     // points (V1)
@@ -145,6 +146,7 @@ void isdf_xchg_reset_board(isdf_ctx *c);  // xchg.hip: empties this rank's board
 int isdf_reset_result_slots(isdf_ctx *c); // isdf_host.hip: drains the device and empties every self-resetting slot again (after an overflow)
 void isdf_xchg_release(isdf_ctx *c);          // xchg.hip: closes the peer mappings, frees the mailbox (isdf_destroy)
 void isdf_frontend_release(isdf_ctx *c);      // frontend.hip: frees the tables (isdf_destroy)
+int isdf_mesh_lattice_build(isdf_ctx *c, isdf::DevMesh *hm, const double lo[3], const double hi[3], int n);      // shape_eval.hip: the mesh kind's distance lattice (DevMesh::dl)
 
 // every setter of once-per-plan state ends with this: the same call on every owned peer ctx (isdf_create_multi)
 #define ISDF_REPLICATE(ctx, call)                                                                  \

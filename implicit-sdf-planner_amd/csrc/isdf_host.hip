@@ -160,6 +160,8 @@ static void free_mesh(isdf_ctx *c) {
     if (c->d_fwn_box) (void)hipFree(c->d_fwn_box);
     if (c->d_fwn_boxq) (void)hipFree(c->d_fwn_boxq);
     if (c->d_fwn_triq) (void)hipFree(c->d_fwn_triq);
+    if (c->d_mesh_dl) (void)hipFree(c->d_mesh_dl);
+    c->d_mesh_dl = nullptr;
     c->d_mesh = nullptr; c->d_mesh_tri = nullptr; c->d_mesh_trif = nullptr; c->d_fwn_child = nullptr; c->d_fwn_box = nullptr; c->d_fwn_boxq = nullptr; c->d_fwn_triq = nullptr;
 }
 
@@ -385,7 +387,7 @@ extern "C" int isdf_set_shape(isdf_ctx *c, const isdf_shape *s) {
         HIPCHK(c, hipMemcpy(c->d_fwn_boxq, boxq.data(), boxq.size() * sizeof(float), hipMemcpyHostToDevice));
         HIPCHK(c, hipMalloc(&c->d_fwn_triq, triq.size() * sizeof(double)));
         HIPCHK(c, hipMemcpy(c->d_fwn_triq, triq.data(), triq.size() * sizeof(double), hipMemcpyHostToDevice));
-        DevMesh hm{c->d_mesh_tri, c->d_mesh_trif, s->n_faces, c->d_fwn_child, c->d_fwn_box, tree.n_nodes(), c->d_fwn_boxq, c->d_fwn_triq, depth};
+        DevMesh hm{c->d_mesh_tri, c->d_mesh_trif, s->n_faces, c->d_fwn_child, c->d_fwn_box, tree.n_nodes(), c->d_fwn_boxq, c->d_fwn_triq, depth, nullptr, {0, 0, 0}, {0.f, 0.f, 0.f}, 0.f, 0.f};
         // one task per workgroup pays when a pass is long (measured: 20 faces 1.15 -> 1.95 ms, 720 faces faster); ISDF_MESH_WG=0/1 forces
         d.mesh_levels = std::max(2, std::min(depth, isdf::MESH_Q_LEVELS));
         c->mesh_depth = depth;
@@ -393,6 +395,34 @@ extern "C" int isdf_set_shape(isdf_ctx *c, const isdf_shape *s) {
         if (const char *e = getenv("ISDF_MESH_WG")) d.mesh_wg = (e[0] == '1' && depth <= isdf::MESH_Q_LEVELS) ? 1 : 0;
         HIPCHK(c, hipMemcpy(c->d_mesh, &hm, sizeof(hm), hipMemcpyHostToDevice));
         d.mesh = c->d_mesh;
+        // The tile sweep's pre-filter for this kind: a lattice of distances over the box the row pruning lets voxels come from (the
+        // shape's box inflated by the penalty band), 64 cells along its longest side.  A voxel whose nearest node is farther from the
+        // surface than the widened band + the node spacing, on the outside, cannot carry a penalty (DevMesh::dl) - most of the listed
+        // voxels of a mesh robot, each of which would cost a hierarchy query.  ISDF_NO_F32_FILTER=1 leaves it out.
+        // (closed meshes only: next to an OPEN surface the winding number is a fraction, and (1 - 2 w) * distance says nothing
+        // about the distance)
+        bool closed = true;
+        {
+            std::vector<std::pair<long long, int>> edges;
+            edges.reserve((size_t)3 * s->n_faces);
+            for (int f = 0; f < s->n_faces; f++)
+                for (int k = 0; k < 3; k++) {
+                    const long long a = s->mesh_faces[3 * f + k], b = s->mesh_faces[3 * f + (k + 1) % 3];
+                    edges.emplace_back(std::min(a, b) * (long long)s->n_vertices + std::max(a, b), a < b ? 1 : -1);
+                }
+            std::sort(edges.begin(), edges.end());
+            for (size_t i = 0; i < edges.size() && closed; i += 2)       // every edge twice, once in each direction
+                closed = i + 1 < edges.size() && edges[i].first == edges[i + 1].first && edges[i].second + edges[i + 1].second == 0 &&
+                         (i + 2 >= edges.size() || edges[i + 2].first != edges[i].first);
+        }
+        if (closed && d.prune_rows && !(getenv("ISDF_NO_F32_FILTER") && getenv("ISDF_NO_F32_FILTER")[0] == '1')) {
+            const double margin = 1.05 * c->cfg.safety_hor + 0.01;
+            double llo[3], lhi[3];
+            for (int a = 0; a < 3; a++) { llo[a] = (double)d.bbox_lo[a] - margin; lhi[a] = (double)d.bbox_hi[a] + margin; }
+            const int rc = isdf_mesh_lattice_build(c, &hm, llo, lhi, 64);
+            if (rc) return rc;
+            if (hm.dl) { HIPCHK(c, hipMemcpy(c->d_mesh, &hm, sizeof(hm), hipMemcpyHostToDevice)); d.filter_f32 = 1; }
+        }
     }
     isdf_frontend_release(c);       // the attitude kernels were voxelised from the previous shape
     c->shape = d;

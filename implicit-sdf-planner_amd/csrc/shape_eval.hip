@@ -19,7 +19,43 @@ __global__ __launch_bounds__(256) void shape_eval_kernel(DevShape S, const doubl
     }
 }
 
+// the mesh kind's distance lattice (DevMesh::dl): one thread per node, the per-lane walks
+__global__ __launch_bounds__(256) void mesh_lattice_kernel(const DevMesh *m, float *out, int nx, int ny, int nz, float mx, float my, float mz, float cell) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (long long)nx * ny * nz) return;
+    const int iz = (int)(i % nz), iy = (int)((i / nz) % ny), ix = (int)(i / ((long long)nz * ny));
+    // (the node's position exactly as the filter forms it: float arithmetic)
+    const d3 p = mk3((double)(mx + (float)ix * cell), (double)(my + (float)iy * cell), (double)(mz + (float)iz * cell));
+    d3 c;
+    double s;
+    const double d = sqrt(mesh_query(m, p, c, s)) * (1.0 - 1.0e-6);
+    float f = (float)d;
+    if ((double)f > d) f = __int_as_float(__float_as_int(f) - 1);      // (f > d >= 0: the next float towards zero)
+    out[i] = s > 0.0 ? f : -1.0f - f;
+}
+
 }  // namespace isdf
+
+// builds the lattice over `lo .. hi` (body frame) with `n` cells along the longest axis; fills the DevMesh fields (host copy `hm`)
+int isdf_mesh_lattice_build(isdf_ctx *c, isdf::DevMesh *hm, const double lo[3], const double hi[3], int n) {
+    double ext = 0.0;
+    for (int a = 0; a < 3; a++) ext = std::max(ext, hi[a] - lo[a]);
+    if (!(ext > 0.0) || n < 2) return ISDF_OK;
+    const float cell = (float)(ext / n);
+    int dims[3];
+    for (int a = 0; a < 3; a++) dims[a] = (int)std::ceil((hi[a] - lo[a]) / cell) + 1;
+    const size_t total = (size_t)dims[0] * dims[1] * dims[2];
+    HIPCHK(c, hipMalloc(&c->d_mesh_dl, total * sizeof(float)));
+    hipLaunchKernelGGL(isdf::mesh_lattice_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, c->stream, c->d_mesh, c->d_mesh_dl, dims[0], dims[1], dims[2],
+                       (float)lo[0], (float)lo[1], (float)lo[2], cell);
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    hm->dl = c->d_mesh_dl;
+    for (int a = 0; a < 3; a++) { hm->dln[a] = dims[a]; hm->dl_min[a] = (float)lo[a]; }
+    hm->dl_inv = 1.0f / cell;
+    hm->dl_h = 0.5f * 1.7320508f * cell * 1.001f + 1.0e-5f * (float)ext;      // half a cell diagonal, + the float rounding of positions of this size
+    return ISDF_OK;
+}
 
 extern "C" int isdf_shape_eval(isdf_ctx *c, const double *p_rel, int n, double *sdf_out, double *grad_out) {
     if (!c) return ISDF_ERR_INVALID_ARG;

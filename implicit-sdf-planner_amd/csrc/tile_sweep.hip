@@ -758,6 +758,17 @@ __global__ __launch_bounds__(64 * SW_SAMPLES, FUSED ? 3 : sweep_waves_per_simd(K
     // for the rounded corners): measured 52 listed -> 48 kept, so the test is skipped for this kind
     constexpr bool DIRECT = (KIND == ISDF_SHAPE_BOX);
     const bool use_filter = !DIRECT && P.shape.filter_f32 != 0;
+    // mesh robots: the filter is the distance lattice of isdf_set_shape (DevMesh::dl; wave-uniform: scalar loads)
+    [[maybe_unused]] const float *ml_dl = nullptr;
+    [[maybe_unused]] int ml_n0 = 0, ml_n1 = 0, ml_n2 = 0;
+    [[maybe_unused]] float ml_m0 = 0.f, ml_m1 = 0.f, ml_m2 = 0.f, ml_inv = 0.f, ml_h = 0.f;
+    if constexpr (KIND == ISDF_SHAPE_MESH) {
+        if (use_filter) {
+            const mesh_cptr<DevMesh> mm = mesh_const_uni(P.shape.mesh);
+            ml_dl = mm->dl; ml_n0 = mm->dln[0]; ml_n1 = mm->dln[1]; ml_n2 = mm->dln[2];
+            ml_m0 = mm->dl_min[0]; ml_m1 = mm->dl_min[1]; ml_m2 = mm->dl_min[2]; ml_inv = mm->dl_inv; ml_h = mm->dl_h;
+        }
+    }
     // the fp32 constants of the scan stage (scan_consts)
     const ScanLaunch SL = scan_launch_consts(P, KIND >= 0 ? KIND : P.shape.kind);
     const float resf = SL.resf, bdh_f = SL.bdh_f, thr_f = SL.thr_f;
@@ -881,7 +892,17 @@ __global__ __launch_bounds__(64 * SW_SAMPLES, FUSED ? 3 : sweep_waves_per_simd(K
                     const f3 pr = mkv<float>(Rf[0] * mx + Rf[3] * my + Rf[6] * mz, Rf[1] * mx + Rf[4] * my + Rf[7] * mz,
                                              Rf[2] * mx + Rf[5] * my + Rf[8] * mz);
                     const bool incube = fmaxf(fabsf(pr.x), fmaxf(fabsf(pr.y), fabsf(pr.z))) <= bdh_f;
-                    const float sdf = analytic_sdf<KIND, float, IDENT>(P.shape.f, P.shape.kind, pr);
+                    float sdf;
+                    if constexpr (KIND == ISDF_SHAPE_MESH) {
+                        // nearest lattice node: outside the mesh and farther from it than the node spacing -> the voxel is at least
+                        // (that distance - spacing) away, on the outside (thr_f carries the 5 % by which the approximate winding
+                        // number may scale the distance, like the row pruning); anything else, or a NaN, stays a candidate
+                        const float fx = (pr.x - ml_m0) * ml_inv, fy = (pr.y - ml_m1) * ml_inv, fz = (pr.z - ml_m2) * ml_inv;
+                        const bool in = fx > -0.5f && fx < (float)ml_n0 - 0.5f && fy > -0.5f && fy < (float)ml_n1 - 0.5f && fz > -0.5f && fz < (float)ml_n2 - 0.5f;
+                        const int ix = in ? (int)rintf(fx) : 0, iy = in ? (int)rintf(fy) : 0, iz = in ? (int)rintf(fz) : 0;
+                        const float v = in ? ml_dl[((size_t)ix * ml_n1 + iy) * ml_n2 + iz] : -1.0f;
+                        sdf = v > 0.0f ? v - ml_h : -1.0e30f;
+                    } else sdf = analytic_sdf<KIND, float, IDENT>(P.shape.f, P.shape.kind, pr);
                     cand = cand & incube & !(sdf >= thr_f);   // reject only what provably has zero penalty; NaN => candidate
                 }
                 pend_head = (pend_head + n) & (SW_LIST_CAP - 1);

@@ -278,3 +278,29 @@ def test_deep_unbalanced_mesh_is_refused_by_the_tile_sweep(pkg, orc, product_lib
     s, g = eng.shape_eval(Q)
     s0, g0 = o.shape_eval(Q)
     assert np.all(np.isfinite(s)) and np.all(np.abs(s - s0) <= 5e-6 * np.abs(s0) + 4e-6 * np.abs(Q).max())
+
+
+def test_mesh_distance_lattice_filter_rejects_only_zero_penalties(pkg, orc, product_lib, monkeypatch):
+    """The tile sweep's pre-filter for mesh robots (a lattice of node-to-surface distances built by isdf_set_shape) may only drop
+    voxels without a penalty: with it and without it (ISDF_NO_F32_FILTER=1) the same active pairs, cost and gradients to rounding
+    (a sample's candidates are cut into blocks of 16 at other places), fewer exact pairs.  An OPEN mesh gets no lattice - next to
+    it the winding number is a fraction and (1 - 2 w) * distance says nothing about the distance."""
+    capi, synth = pkg.capi, pkg.synth
+    occ, esdf, res = small_world(pkg, seed=14)
+    T, cm = traj(pkg, occ, res, N=5, seed=23)
+    cfg = synth.default_config(capi.V3_ESDF_TILE, kernel_size=9, integral_intervs=12, safety_hor=0.5)
+    V, F = synth.blob_mesh(24, 16, scale=0.9)
+    F_open = np.ascontiguousarray(F[: len(F) - 40])                  # the same surface with a hole
+    for faces, closed in ((F, True), (F_open, False)):
+        out = {}
+        for off in ("0", "1"):
+            monkeypatch.setenv("ISDF_NO_F32_FILTER", off)
+            e = pkg.Engine(cfg); e.set_grid(esdf, (0, 0, 0), res, capi.GRID_ESDF); e.set_shape(synth.make_mesh_shape(V, faces))
+            out[off] = e.eval_single(T, cm) + (e.stats(),)
+        monkeypatch.delenv("ISDF_NO_F32_FILTER")
+        a, b = out["0"], out["1"]
+        assert a[0] > 0 and abs(a[0] - b[0]) <= 1e-12 * abs(b[0])
+        assert_close(a[1], b[1], "lattice filter on / off gradT", tol=1e-11); assert_close(a[2], b[2], "lattice filter on / off gradC", tol=1e-11)
+        assert a[3]["grad_pairs"] == b[3]["grad_pairs"] > 0 and a[3]["overflow"] == 0
+        if closed: assert a[3]["pairs"] < b[3]["pairs"]
+        else: assert a[3]["pairs"] == b[3]["pairs"]
