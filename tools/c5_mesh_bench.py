@@ -1,7 +1,7 @@
 #!/usr/bin/env python
 """Developer tool: the C5-shaped V1 entries of bench.py alone (512^3 occupancy @ 0.1 m, 20-piece trajectory, mesh robots), under
 ISDF_MESH_WG = 0 / 1 (wave-cooperative / quad-cooperative walks).  usage: c5_mesh_bench.py [--shards=N] [blob720|trefoil|lthick|lprism ...]
---shards=N: the step of rank 0 of N (its contiguous share of the obstacle points), as one rank of an N-GPU run executes it."""
+--shards=N [--rank=R]: the step of rank R (default 0) of N (its contiguous share of the obstacle points), as one rank of an N-GPU run executes it."""
 import os, sys, time
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -19,6 +19,7 @@ dT = torch.from_numpy(T5).to(dev); dC = torch.from_numpy(cm5).to(dev)
 meshes = {"lprism": synth.l_prism_mesh, "blob720": lambda: synth.blob_mesh(24, 16, scale=0.9), "lthick": lambda: synth.reference_mesh("Lthick", 0.83),
           "trefoil": lambda: synth.reference_mesh("Trefoil", 0.83)}
 shards = [int(a.split("=")[1]) for a in sys.argv[1:] if a.startswith("--shards=")]
+rank = ([int(a.split("=")[1]) for a in sys.argv[1:] if a.startswith("--rank=")] or [0])[0]
 names = [a for a in sys.argv[1:] if not a.startswith("--")]
 for nm in (names or ["blob720", "trefoil"]):
     V, F = meshes[nm]()
@@ -27,7 +28,7 @@ for nm in (names or ["blob720", "trefoil"]):
         cfg1 = synth.default_config(capi.V1_SWEPT, safety_hor=(3 ** 0.5 / 2) * res5, weight_p=4000.0)
         e1 = pkg.Engine(cfg1); e1.set_grid(occ5, (0, 0, 0), res5, capi.GRID_OCCUPANCY); e1.set_shape(synth.make_mesh_shape(V, F))
         M = e1.gather_points(way5, 0.9)
-        if shards: e1.set_shard(0, shards[0])
+        if shards: e1.set_shard(rank, shards[0])
         dO = torch.zeros(e1.out_stride(20), dtype=torch.float64, device=dev)
         for _ in range(2):
             e1.eval_device(1, 20, dT.data_ptr(), dC.data_ptr(), dO.data_ptr(), 0, st)
@@ -40,5 +41,5 @@ for nm in (names or ["blob720", "trefoil"]):
             e1.eval_device(1, 20, dT.data_ptr(), dC.data_ptr(), dO.data_ptr(), 0, st)
         torch.cuda.synchronize()
         _, k_search = e1.profile_read(); e1.profile_enable(0)
-        print(f"{nm} ({len(F)} faces) ISDF_MESH_WG={wg}{' rank 0 of %d' % shards[0] if shards else ''}: M = {M}, {dt * 1e3:8.3f} ms/step (search launches {k_search:8.3f} ms) cost {float(dO[0].item()):.12g} stats {e1.stats()}", flush=True)
+        print(f"{nm} ({len(F)} faces) ISDF_MESH_WG={wg}{' rank %d of %d' % (rank, shards[0]) if shards else ''}: M = {M}, {dt * 1e3:8.3f} ms/step (search launches {k_search:8.3f} ms) cost {float(dO[0].item()):.12g} stats {e1.stats()}", flush=True)
         del e1
