@@ -555,6 +555,27 @@ __device__ inline double mesh_closest_quad(const DevMesh *m, MeshFrames F, d3 p,
     return best;
 }
 
+// "sdf(p) < cap?" answered NO from the distance lattice alone (DevMesh::dl: distances at the nodes, rounded down; h = the farthest a
+// point is from its nearest node), without a walk.  sdf = (1 - 2 w) * dist with |1 - 2 w| <= 1.05 (what the approximate winding
+// number of a closed mesh may add, as in the tile sweep's band) and dist 1-Lipschitz:
+//   cap > 0: a node outside, farther from the surface than h, has p on its side of it and dist(p) >= d_node - h;
+//   cap < 0: "deeper than |cap|?" needs dist(p) > |cap| / 1.05, and dist(p) <= d_node + h wherever the node lies.
+// false = not decided (no lattice, p outside it, an uncapped query).
+__device__ __forceinline__ bool mesh_lattice_not_below(const DevMesh *m, d3 p, double cap) {
+    if (!(cap < 1.0e300) || cap == 0.0) return false;
+    const mesh_cptr<DevMesh> ml = mesh_const_uni(m);
+    const float *dl = ml->dl;
+    if (!dl) return false;
+    const int n0 = ml->dln[0], n1 = ml->dln[1], n2 = ml->dln[2];
+    const float inv = ml->dl_inv, fx = ((float)p.x - ml->dl_min[0]) * inv, fy = ((float)p.y - ml->dl_min[1]) * inv, fz = ((float)p.z - ml->dl_min[2]) * inv;
+    if (!(fx > -0.5f && fx < (float)n0 - 0.5f && fy > -0.5f && fy < (float)n1 - 0.5f && fz > -0.5f && fz < (float)n2 - 0.5f)) return false;
+    const float v = dl[((size_t)(int)rintf(fx) * n1 + (int)rintf(fy)) * n2 + (int)rintf(fz)];
+    const double h = (double)ml->dl_h;
+    if (cap > 0.0) return v > 0.0f && ((double)v - h) * 0.952 >= cap * (1.0 + 1e-9);
+    const double dn = (v > 0.0f ? (double)v : -(double)v - 1.0) * (1.0 + 4.0e-6);      // an upper bound of the node's distance
+    return 1.05 * (dn + h) <= -cap * (1.0 - 1e-9);
+}
+
 // mesh_sdf_grad / mesh_sdf_grad_below for 16 queries (all 64 lanes call; a quad passes the same arguments); cap = +infinity
 // gives the plain query.  Returns false when sdf >= cap is proven (or the query is not `act`).
 __device__ inline bool mesh_sdf_grad_below_quad(const DevMesh *m, MeshFrames F, d3 p, bool act, double cap, double &sdf, d3 &g) {

@@ -396,7 +396,7 @@ extern "C" int isdf_set_shape(isdf_ctx *c, const isdf_shape *s) {
         HIPCHK(c, hipMemcpy(c->d_mesh, &hm, sizeof(hm), hipMemcpyHostToDevice));
         d.mesh = c->d_mesh;
         // The tile sweep's pre-filter for this kind: a lattice of distances over the box the row pruning lets voxels come from (the
-        // shape's box inflated by the penalty band), 64 cells along its longest side.  A voxel whose nearest node is farther from the
+        // shape's box inflated by the penalty band), 96 cells along its longest side.  A voxel whose nearest node is farther from the
         // surface than the widened band + the node spacing, on the outside, cannot carry a penalty (DevMesh::dl) - most of the listed
         // voxels of a mesh robot, each of which would cost a hierarchy query.  ISDF_NO_F32_FILTER=1 leaves it out.
         // (closed meshes only: next to an OPEN surface the winding number is a fraction, and (1 - 2 w) * distance says nothing
@@ -416,10 +416,11 @@ extern "C" int isdf_set_shape(isdf_ctx *c, const isdf_shape *s) {
                          (i + 2 >= edges.size() || edges[i + 2].first != edges[i].first);
         }
         if (closed && d.prune_rows && !(getenv("ISDF_NO_F32_FILTER") && getenv("ISDF_NO_F32_FILTER")[0] == '1')) {
-            const double margin = 1.05 * c->cfg.safety_hor + 0.01;
+            // (wide enough for the swept-volume scans' band, 2 safety_hor + 0.1, as well: mesh_lattice_not_below)
+            const double margin = 1.05 * std::max(c->cfg.safety_hor, 2.0 * c->cfg.safety_hor + 0.1) + 0.01;
             double llo[3], lhi[3];
             for (int a = 0; a < 3; a++) { llo[a] = (double)d.bbox_lo[a] - margin; lhi[a] = (double)d.bbox_hi[a] + margin; }
-            const int rc = isdf_mesh_lattice_build(c, &hm, llo, lhi, 64);
+            const int rc = isdf_mesh_lattice_build(c, &hm, llo, lhi, 96);
             if (rc) return rc;
             if (hm.dl) { HIPCHK(c, hipMemcpy(c->d_mesh, &hm, sizeof(hm), hipMemcpyHostToDevice)); d.filter_f32 = 1; }
         }

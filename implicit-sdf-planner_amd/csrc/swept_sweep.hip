@@ -201,6 +201,8 @@ constexpr int mesh_wg_stage(int nw) { return nw * 64 * 4; }
 // every lane of all four wavefronts calls; returns "sdf < cap proven / evaluated" like mesh_sdf_grad_below (cap = +inf: plain query)
 __device__ inline bool mesh_eval_wg(MeshWG &X, const DevMesh *m, d3 pr, bool act, double cap, double &sdf, d3 &g) {
     const int lane = (int)__lane_id();
+    // (a capped query the distance lattice already answers leaves here: fewer queries, fewer rounds)
+    if (act && mesh_lattice_not_below(m, pr, cap)) act = false;
     const unsigned long long mask = __ballot(act);
     if (!mask) return false;                               // (the same in all four wavefronts)
     const int n_act = __popcll(mask);
