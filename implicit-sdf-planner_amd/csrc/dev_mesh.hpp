@@ -576,6 +576,26 @@ __device__ __forceinline__ bool mesh_lattice_not_below(const DevMesh *m, d3 p, d
     return 1.05 * (dn + h) <= -cap * (1.0 - 1e-9);
 }
 
+// lb <= sdf(p) <= ub from the lattice under the same two assumptions (false: nothing known - no lattice, or p outside it)
+__device__ __forceinline__ bool mesh_lattice_bounds(const DevMesh *m, d3 p, double &lb, double &ub) {
+    lb = -1.7976931348623157e308; ub = 1.7976931348623157e308;
+    const mesh_cptr<DevMesh> ml = mesh_const_uni(m);
+    const float *dl = ml->dl;
+    if (!dl) return false;
+    const int n0 = ml->dln[0], n1 = ml->dln[1], n2 = ml->dln[2];
+    const float inv = ml->dl_inv, fx = ((float)p.x - ml->dl_min[0]) * inv, fy = ((float)p.y - ml->dl_min[1]) * inv, fz = ((float)p.z - ml->dl_min[2]) * inv;
+    if (!(fx > -0.5f && fx < (float)n0 - 0.5f && fy > -0.5f && fy < (float)n1 - 0.5f && fz > -0.5f && fz < (float)n2 - 0.5f)) return false;
+    const float v = dl[((size_t)(int)rintf(fx) * n1 + (int)rintf(fy)) * n2 + (int)rintf(fz)];
+    const double h = (double)ml->dl_h;
+    const double dlo = (v > 0.0f ? (double)v : -(double)v - 1.0), dhi = dlo * (1.0 + 4.0e-6);      // the node's distance, from below / above
+    const double far = fmax(dlo - h, 0.0), near = dhi + h;                                            // dist(p) lies in [far, near]
+    if (dlo > h) {                      // p on the node's side of the surface
+        if (v > 0.0f) { lb = 0.952 * far; ub = 1.05 * near; }
+        else { lb = -1.05 * near; ub = -0.952 * far; }
+    } else { lb = -1.05 * near; ub = 1.05 * near; }
+    return true;
+}
+
 // mesh_sdf_grad / mesh_sdf_grad_below for 16 queries (all 64 lanes call; a quad passes the same arguments); cap = +infinity
 // gives the plain query.  Returns false when sdf >= cap is proven (or the query is not `act`).
 __device__ inline bool mesh_sdf_grad_below_quad(const DevMesh *m, MeshFrames F, d3 p, bool act, double cap, double &sdf, d3 &g) {

@@ -20,7 +20,9 @@ __global__ __launch_bounds__(256) void shape_eval_kernel(DevShape S, const doubl
 }
 
 // the mesh kind's distance lattice (DevMesh::dl): one thread per node, the per-lane walks
-__global__ __launch_bounds__(256) void mesh_lattice_kernel(const DevMesh *m, float *out, int nx, int ny, int nz, float mx, float my, float mz, float cell) {
+// (flag: raised when a node farther than `clear` from the surface has |1 - 2 w| outside [0.96, 1.04] - a surface covered twice, an
+// inverted one: the assumption the lattice's users make about the winding number does not hold for this mesh, and it gets no lattice)
+__global__ __launch_bounds__(256) void mesh_lattice_kernel(const DevMesh *m, float *out, int nx, int ny, int nz, float mx, float my, float mz, float cell, float clear, unsigned *flag) {
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= (long long)nx * ny * nz) return;
     const int iz = (int)(i % nz), iy = (int)((i / nz) % ny), ix = (int)(i / ((long long)nz * ny));
@@ -32,6 +34,7 @@ __global__ __launch_bounds__(256) void mesh_lattice_kernel(const DevMesh *m, flo
     float f = (float)d;
     if ((double)f > d) f = __int_as_float(__float_as_int(f) - 1);      // (f > d >= 0: the next float towards zero)
     out[i] = s > 0.0 ? f : -1.0f - f;
+    if (d > (double)clear && !(fabs(s) >= 0.96 && fabs(s) <= 1.04)) atomicOr(flag, 1u);
 }
 
 }  // namespace isdf
@@ -45,15 +48,21 @@ int isdf_mesh_lattice_build(isdf_ctx *c, isdf::DevMesh *hm, const double lo[3], 
     int dims[3];
     for (int a = 0; a < 3; a++) dims[a] = (int)std::ceil((hi[a] - lo[a]) / cell) + 1;
     const size_t total = (size_t)dims[0] * dims[1] * dims[2];
-    HIPCHK(c, hipMalloc(&c->d_mesh_dl, total * sizeof(float)));
+    HIPCHK(c, hipMalloc(&c->d_mesh_dl, (total + 1) * sizeof(float)));      // (+ the flag word)
+    unsigned *d_flag = reinterpret_cast<unsigned *>(c->d_mesh_dl + total);
+    HIPCHK(c, hipMemsetAsync(d_flag, 0, sizeof(unsigned), c->stream));
+    const float h = 0.5f * 1.7320508f * cell * 1.001f + 1.0e-5f * (float)ext;      // half a cell diagonal, + the float rounding of positions of this size
     hipLaunchKernelGGL(isdf::mesh_lattice_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, c->stream, c->d_mesh, c->d_mesh_dl, dims[0], dims[1], dims[2],
-                       (float)lo[0], (float)lo[1], (float)lo[2], cell);
+                       (float)lo[0], (float)lo[1], (float)lo[2], cell, h, d_flag);
     HIPCHK(c, hipGetLastError());
+    unsigned flag = 0;
+    HIPCHK(c, hipMemcpyAsync(&flag, d_flag, sizeof(unsigned), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (flag) { (void)hipFree(c->d_mesh_dl); c->d_mesh_dl = nullptr; return ISDF_OK; }      // not a mesh the lattice's users can reason about
     hm->dl = c->d_mesh_dl;
     for (int a = 0; a < 3; a++) { hm->dln[a] = dims[a]; hm->dl_min[a] = (float)lo[a]; }
     hm->dl_inv = 1.0f / cell;
-    hm->dl_h = 0.5f * 1.7320508f * cell * 1.001f + 1.0e-5f * (float)ext;      // half a cell diagonal, + the float rounding of positions of this size
+    hm->dl_h = h;
     return ISDF_OK;
 }
 

@@ -426,7 +426,21 @@ __device__ __forceinline__ void scan_body(const SweptParams &P, double *s_dyn, c
             double val = 1e300;
             d3 pv_unused = mk3(0, 0, 0), g_unused = pv_unused;
             // (mesh robots: only a value BELOW the running minimum can change it - the hierarchy's distance cutoff answers the rest)
-            if constexpr (MESH) eval_lane<KIND, LDS, true>(P, tr, p, act ? te : lb, 0, true, true, val, pv_unused, g_unused, &mwg, act, range_mindis);
+            if constexpr (MESH) {
+                // Which samples of this pass can hold its minimum?  The distance lattice brackets every sample's SDF (dev_mesh.hpp,
+                // mesh_lattice_bounds: a few centimetres); a sample whose lower bound lies above the smallest UPPER bound of the pass
+                // cannot be the first minimum, nor tie with it - it needs no query.  An obstacle point the robot passes over keeps
+                // the samples around the deepest one, a handful of 64.
+                const double te_q = act ? te : lb;
+                d3 xq; m3 Rq;
+                pose_at(P, tr, te_q, xq, Rq);
+                double s_lb, s_ub;
+                const bool known = mesh_lattice_bounds(P.shape.mesh, mat_tmul(Rq, p - xq), s_lb, s_ub);
+                int a_ub;
+                const double ub_min = wave_first_min((act && known) ? s_ub : 1.7976931348623157e308, lane, 64, a_ub);
+                const bool keep = act && !(known && s_lb > ub_min);
+                eval_lane<KIND, LDS, true>(P, tr, p, te_q, 0, true, true, val, pv_unused, g_unused, &mwg, keep, range_mindis);
+            }
             else if (act) eval_lane<KIND, LDS, false, KIND == ISDF_SHAPE_MESH>(P, tr, p, te, 0, false, false, val, pv_unused, g_unused, nullptr, true, range_mindis);
             n_pass++;
             const int nv = __popcll(__ballot(act));                  // valid lanes form a prefix (t is increasing)
