@@ -340,6 +340,7 @@ __device__ __forceinline__ void scan_body(const SweptParams &P, double *s_dyn, c
     // (the mesh kind's sdf is (1 - 2 w) * distance with libigl's APPROXIMATE winding number, |w error| a few 1e-3: its band is widened by 5 %)
     const double far_r = P.shape.bound_radius + inf * (KIND == ISDF_SHAPE_MESH ? 1.05 : 1.0);
     const double far2 = P.shape.bound_radius > 0.0 ? far_r * far_r : 1.0e300;
+    bool carry_din = false;          // (mesh robots) the previous window's last sample is in range by the lattice's bounds
     for (int base = 0; base < n_coarse; base += 64) {
         const int k = base + lane;
         const int kc = min(k, n_coarse - 1);
@@ -355,11 +356,19 @@ __device__ __forceinline__ void scan_body(const SweptParams &P, double *s_dyn, c
                 for (int q = 0; q < 9; q++) R.a[q] = o[(3 + q) * cst];
                 const d3 pr = mat_tmul(R, dxp);
                 // the scan only asks "dis < inf?" (and keeps dis where the answer is yes): far samples are rejected by the
-                // hierarchy's distance cutoff without a full query
+                // hierarchy's distance cutoff without a full query - or by the distance lattice (mesh_eval_wg).  A sample the
+                // lattice puts INSIDE the band, right behind another such sample, needs no query either: it is in range, and it
+                // cannot be the first sample of a run - the only one whose value is used (:405-408)
+                double s_lb, s_ub;
+                const bool din = near && mesh_lattice_bounds(P.shape.mesh, pr, s_lb, s_ub) && s_ub < inf * (1.0 - 1e-9);
+                const unsigned long long dmask = __ballot(din);
+                const bool skip = din && (lane == 0 ? carry_din : (bool)((dmask >> (lane - 1)) & 1ull));
+                carry_din = (dmask >> 63) & 1ull;
                 d3 g_unused;
                 double sdf = 1e9;
-                if (mesh_eval_wg(mwg, P.shape.mesh, pr, near, inf, sdf, g_unused)) dis = sdf;
-            }
+                if (mesh_eval_wg(mwg, P.shape.mesh, pr, near && !skip, inf, sdf, g_unused)) dis = sdf;
+                if (skip) dis = s_ub;
+            } else carry_din = false;
         } else if (near) {
             m3 R;
 #pragma unroll
