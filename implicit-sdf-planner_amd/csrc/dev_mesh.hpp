@@ -769,6 +769,7 @@ __device__ inline double mesh_sdf_grad_wave(const DevMesh *m, d3 p, d3 &g) {
     return s * sqrt(d2);
 }
 __device__ inline bool mesh_sdf_grad_below_wave(const DevMesh *m, d3 p, double cap, double &sdf, d3 &g) {
+    if (mesh_lattice_not_below(m, p, cap)) return false;       // (answered by the distance lattice: this lane stays out of the walks)
     const float sa = mesh_solid_angle_wave(m, (float)p.x, (float)p.y, (float)p.z);
     const double w = (double)sa / (4.0 * 3.14159265358979323846);
     const double s = 1. - 2. * w;

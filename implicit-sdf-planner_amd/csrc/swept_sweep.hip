@@ -377,7 +377,7 @@ __device__ __forceinline__ void scan_body(const SweptParams &P, double *s_dyn, c
             if constexpr (KIND == ISDF_SHAPE_MESH) {
                 d3 g_unused;
                 double sdf;
-                dis = mesh_sdf_grad_below_wave(P.shape.mesh, pr, inf, sdf, g_unused) ? sdf : 1e9;
+                dis = mesh_sdf_grad_below_wave(P.shape.mesh, pr, inf, sdf, g_unused) ? sdf : 1e9;      // (the lattice answers the far ones: dev_mesh.hpp)
             } else {
                 dis = shape_sdf<KIND>(P.shape, pr);
             }
@@ -435,7 +435,7 @@ __device__ __forceinline__ void scan_body(const SweptParams &P, double *s_dyn, c
             double val = 1e300;
             d3 pv_unused = mk3(0, 0, 0), g_unused = pv_unused;
             // (mesh robots: only a value BELOW the running minimum can change it - the hierarchy's distance cutoff answers the rest)
-            if constexpr (MESH) {
+            if constexpr (KIND == ISDF_SHAPE_MESH) {
                 // Which samples of this pass can hold its minimum?  The distance lattice brackets every sample's SDF (dev_mesh.hpp,
                 // mesh_lattice_bounds: a few centimetres); a sample whose lower bound lies above the smallest UPPER bound of the pass
                 // cannot be the first minimum, nor tie with it - it needs no query.  An obstacle point the robot passes over keeps
@@ -448,9 +448,10 @@ __device__ __forceinline__ void scan_body(const SweptParams &P, double *s_dyn, c
                 int a_ub;
                 const double ub_min = wave_first_min((act && known) ? s_ub : 1.7976931348623157e308, lane, 64, a_ub);
                 const bool keep = act && !(known && s_lb > ub_min);
-                eval_lane<KIND, LDS, true>(P, tr, p, te_q, 0, true, true, val, pv_unused, g_unused, &mwg, keep, range_mindis);
+                if constexpr (MESH) eval_lane<KIND, LDS, true>(P, tr, p, te_q, 0, true, true, val, pv_unused, g_unused, &mwg, keep, range_mindis);
+                else if (keep) eval_lane<KIND, LDS, false, true>(P, tr, p, te, 0, false, false, val, pv_unused, g_unused, nullptr, true, range_mindis);
             }
-            else if (act) eval_lane<KIND, LDS, false, KIND == ISDF_SHAPE_MESH>(P, tr, p, te, 0, false, false, val, pv_unused, g_unused, nullptr, true, range_mindis);
+            else if (act) eval_lane<KIND, LDS, false, false>(P, tr, p, te, 0, false, false, val, pv_unused, g_unused, nullptr, true, range_mindis);
             n_pass++;
             const int nv = __popcll(__ballot(act));                  // valid lanes form a prefix (t is increasing)
             int arg;
