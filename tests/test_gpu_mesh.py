@@ -291,7 +291,8 @@ def test_mesh_distance_lattice_filter_rejects_only_zero_penalties(pkg, orc, prod
     cfg = synth.default_config(capi.V3_ESDF_TILE, kernel_size=9, integral_intervs=12, safety_hor=0.5)
     V, F = synth.blob_mesh(24, 16, scale=0.9)
     F_open = np.ascontiguousarray(F[: len(F) - 40])                  # the same surface with a hole
-    for faces, closed in ((F, True), (F_open, False)):
+    F_flip = np.ascontiguousarray(F[:, ::-1])                        # closed, but inside out: the winding number is -1 inside
+    for faces, closed in ((F, True), (F_open, False), (F_flip, False)):
         out = {}
         for off in ("0", "1"):
             monkeypatch.setenv("ISDF_NO_F32_FILTER", off)
@@ -304,3 +305,33 @@ def test_mesh_distance_lattice_filter_rejects_only_zero_penalties(pkg, orc, prod
         assert a[3]["grad_pairs"] == b[3]["grad_pairs"] > 0 and a[3]["overflow"] == 0
         if closed: assert a[3]["pairs"] < b[3]["pairs"]
         else: assert a[3]["pairs"] == b[3]["pairs"]
+
+
+def test_mesh_v1_distance_lattice_changes_no_result(pkg, orc, product_lib, monkeypatch):
+    """The swept-volume sweep uses the same lattice to leave queries out whose answer cannot matter (a capped query the lattice
+    already answers; fine samples that cannot hold their pass's minimum; coarse samples inside the band behind another such
+    sample).  What is left out is never looked at: with and without the lattice (ISDF_NO_F32_FILTER=1 builds none) t*, cost and
+    gradients are the same BITS, in both forms of the walks."""
+    capi, synth = pkg.capi, pkg.synth
+    occ, esdf, res = small_world(pkg, seed=14)
+    T, cm = traj(pkg, occ, res, N=5, seed=23)
+    V, F = synth.blob_mesh(24, 16, scale=0.9)
+    way = cm.reshape(3, -1).T.reshape(5, 6, 3)[1:, 0, :]
+    pts = synth.constraint_points(occ, (0, 0, 0), res, way, half=3.0)
+    for wg in ("1", "0"):
+        monkeypatch.setenv("ISDF_MESH_WG", wg)
+        out = {}
+        for off in ("0", "1"):
+            monkeypatch.setenv("ISDF_NO_F32_FILTER", off)
+            cfg1 = synth.default_config(capi.V1_SWEPT, safety_hor=0.5)
+            e1 = pkg.Engine(cfg1); e1.set_grid(occ, (0, 0, 0), res, capi.GRID_OCCUPANCY); e1.set_shape(synth.make_mesh_shape(V, F)); e1.set_points(pts)
+            ts = -np.ones(len(pts))
+            steps = []
+            for _ in range(3):                       # (lastTstar and the dispatch orders carry over from step to step)
+                c, gT, gC = e1.eval_single(T, cm, tstar=ts)
+                steps.append((c, gT.copy(), gC.copy(), ts.copy()))
+            out[off] = (steps, e1.stats())
+        for a, b in zip(out["0"][0], out["1"][0]):
+            assert a[0] == b[0] and np.array_equal(a[1], b[1]) and np.array_equal(a[2], b[2]) and np.array_equal(a[3], b[3])
+        assert out["0"][1]["grad_pairs"] == out["1"][1]["grad_pairs"] > 0
+    monkeypatch.delenv("ISDF_MESH_WG"); monkeypatch.delenv("ISDF_NO_F32_FILTER")
