@@ -113,9 +113,10 @@ typedef struct isdf_shape {
                            /* does.  All bbox_half > 0 lets the scan prune voxel rows that cannot reach the      */
                            /* penalty band; zeros disable the pruning.  Results are identical either way.        */
     /* MESH only (already transformed into the body frame exactly as Generalshape's constructor does).  For a CLOSED mesh
-       isdf_set_shape also samples a lattice of node-to-surface distances on the device (a few milliseconds): the tile sweep's
-       pre-filter for this kind - it drops listed voxels that provably carry no penalty; results agree to rounding with and
-       without it (ISDF_NO_F32_FILTER=1). */
+       isdf_set_shape also samples a lattice of node-to-surface distances on the device (a few milliseconds, 4 MB): the tile
+       sweep's pre-filter for this kind (it drops listed voxels that provably carry no penalty; results agree to rounding with
+       and without it) and the swept-volume scans' way of telling which samples need a hierarchy query at all (bitwise the same
+       results).  ISDF_NO_F32_FILTER=1 builds none. */
     const double *mesh_vertices;  /* nV x 3 row-major */
     const int32_t *mesh_faces;    /* nF x 3 row-major */
     int32_t n_vertices;
