@@ -1,4 +1,4 @@
-"""Worker of tests/test_gpu_xchg.py::test_xchg_failure_is_agreed_in_the_kernel: two processes on GPU 0.  Rank 1 shows up two seconds
+"""Worker of tests/test_gpu_xchg.py::test_xchg_failure_is_agreed_in_the_kernel: two processes on GPU 0.  Rank 1 shows up six seconds
 late for one exchange: rank 0's bounded wait expires, and through the kernel's verdict round BOTH ranks end that exchange with
 the status word set and a NaN in slot 0 - without any host-side collective.  At callback level both ranks then redo the step's
 sum on the group's all-reduce and return the right (cost, g)."""
@@ -12,6 +12,7 @@ import __graft_entry__ as graft
 
 pkg = graft.load_package(); capi, synth, par = pkg.capi, pkg.synth, pkg.parallel
 rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+LATE = 6.0      # seconds rank 1 shows up late: several times the exchange's bounded wait (~0.5-2 s of polling, depending on the box)
 dist.init_process_group("gloo", rank=rank, world_size=world)
 dev = torch.device("cuda", 0); torch.cuda.set_device(dev)
 occ = synth.random_box_map((48, 48, 32), res=0.5, occupancy=0.12, seed=3, edge=(1.0, 3.0))
@@ -38,7 +39,7 @@ assert abs(c - c_ref) <= 1e-12 * abs(c_ref) and np.allclose(g, g_ref, rtol=0, at
 v = torch.full((64,), float(rank + 1), dtype=torch.float64, device=dev)
 dist.barrier()
 if rank == 1:
-    time.sleep(2.0)
+    time.sleep(LATE)
 t0 = time.perf_counter()
 x.allreduce(v); torch.cuda.synchronize()
 assert eng.xchg_status() == 1 and not np.isfinite(float(v[0].item())), (rank, eng.xchg_status(), float(v[0].item()))
@@ -52,7 +53,7 @@ for _ in range(4):
 dist.barrier()
 # 2) callback level: a late peer during a step -> both ranks redo the sum on the group's all-reduce and agree
 if rank == 1:
-    time.sleep(2.0)
+    time.sleep(LATE)
 c, g = par.cost_function_allreduced(eng, xv, x)
 assert not x.ok, "the failed exchange must have been abandoned on every rank"
 assert abs(c - c_ref) <= 1e-12 * abs(c_ref) and np.allclose(g, g_ref, rtol=0, atol=1e-11 * np.abs(g_ref).max()), (rank, c, c_ref)

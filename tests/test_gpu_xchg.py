@@ -3,6 +3,7 @@ test box: IPC mapping, sequence flags, double buffering and the rank-order sum a
 GPUs of a node; what a single GPU cannot show is xGMI itself (parallel.XgmiExchange therefore verifies the path against the
 group's all-reduce at start-up on the real node and stays on RCCL if anything disagrees)."""
 import os
+import socket
 import subprocess
 import sys
 
@@ -12,11 +13,17 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
 @pytest.mark.parametrize("world", [2, 4])
 def test_xchg_processes_sharing_one_gpu(product_lib, world):
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr", "127.0.0.1",
-           "--master-port", str(29600 + world), os.path.join(ROOT, "tests", "native", "xchg_worker.py")]
+           "--master-port", str(_free_port()), os.path.join(ROOT, "tests", "native", "xchg_worker.py")]
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "XCHG WORKERS OK" in r.stdout, (r.stdout[-3000:], r.stderr[-3000:])
 
@@ -26,6 +33,6 @@ def test_xchg_failure_is_agreed_in_the_kernel(product_lib):
     no per-step host collective, and the callback's redo on the group's all-reduce is entered by every rank together."""
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
-           "--master-port", "29611", os.path.join(ROOT, "tests", "native", "xchg_fail_worker.py")]
+           "--master-port", str(_free_port()), os.path.join(ROOT, "tests", "native", "xchg_fail_worker.py")]
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "XCHG FAILURE AGREED OK" in r.stdout, (r.stdout[-3000:], r.stderr[-3000:])
