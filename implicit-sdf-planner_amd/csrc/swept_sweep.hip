@@ -117,7 +117,7 @@ __global__ __launch_bounds__(1024) void swept_prepare_kernel(const SweptParams P
         s_n = n;
         *P.n_coarse = n;
         for (int k = 0; k < 8; k++) if (k != 4) P.stats[k] = 0ull;      // [4] = overflow: sticky until the host reads it
-        P.words[0] = 0u; P.words[2] = 0u;                               // the scan kernel's task counters (front / back of the list)
+        P.words[0] = 0u; P.words[1] = 0u;                               // the scan kernel's task counters (front / back of the list: ONE 64-bit word)
         // mesh robots: "long" = a descent of at least twice last step's mean duration (0: no step yet)
         P.words[6] = P.words[5] ? max(1u, 2u * (P.words[4] / P.words[5])) : 0u;
         P.words[4] = 0u; P.words[5] = 0u;
@@ -485,7 +485,7 @@ __device__ __forceinline__ void scan_body(const SweptParams &P, double *s_dyn, c
     // Scheduling only: which wavefront evaluates what has no influence on any result (every task has its own result slot), so
     // the list needs no particular order within the two classes: ONE reservation per workgroup and class (two atomics; round 3
     // built the list in point order in the workgroup that finished last - 15 us of one workgroup between the two launches).
-    // (words[0] / words[2]: tasks at the front / at the back, zeroed by the prepare kernel.)
+    // (words[0] / words[1]: tasks at the front / at the back - one 64-bit counter, one atomic per workgroup; zeroed by the prepare kernel.)
     {
         unsigned vt = 0u;                                       // bit r: task r of my point was long last step
         if (pt < P.point_end && my_nr > 0 && (!MESH || wave == 0)) {
@@ -500,8 +500,10 @@ __device__ __forceinline__ void scan_body(const SweptParams &P, double *s_dyn, c
         if (tid == 0) {
             unsigned tl = 0, ts = 0;
             for (int w = 0; w < (MESH ? WGM : SW_WAVES); w++) { tl += s_cnt[w][0]; ts += s_cnt[w][1]; }
-            s_base[0] = tl ? atomicAdd(&P.words[0], tl) : 0u;
-            s_base[1] = ts ? atomicAdd(&P.words[2], ts) : 0u;
+            unsigned long long got = 0ull;
+            if (tl | ts) got = atomicAdd(reinterpret_cast<unsigned long long *>(P.words), (unsigned long long)tl | ((unsigned long long)ts << 32));
+            s_base[0] = (unsigned)got;
+            s_base[1] = (unsigned)(got >> 32);
         }
         __syncthreads();
         unsigned o_l = s_base[0], o_s = s_base[1];
@@ -551,7 +553,7 @@ __device__ __forceinline__ void descent_body(const SweptParams &P, double *s_dyn
                MeshFrames{reinterpret_cast<unsigned *>(reinterpret_cast<char *>(s_dyn) + (LDS ? traj_lds_bytes(P.N) : 0)) + (MESH ? wave * mesh_frames_words(m_lv) : 0), m_lv}, WGM};
     const unsigned cap = (unsigned)(P.point_end - P.point_begin) * SW_MAX_RANGES;
     const unsigned n_front = (unsigned)__builtin_amdgcn_readfirstlane((int)P.words[0]);
-    const unsigned n_tasks = n_front + (unsigned)__builtin_amdgcn_readfirstlane((int)P.words[2]);
+    const unsigned n_tasks = n_front + (unsigned)__builtin_amdgcn_readfirstlane((int)P.words[1]);
     const unsigned lpt_thr = KIND == ISDF_SHAPE_MESH ? (unsigned)__builtin_amdgcn_readfirstlane((int)P.words[6]) : 0u;
     const unsigned n_waves = (unsigned)__builtin_amdgcn_readfirstlane((int)(MESH ? n_blocks : n_blocks * SW_WAVES));
     const double D = *P.traj_duration;
