@@ -307,15 +307,19 @@ def test_mesh_distance_lattice_filter_rejects_only_zero_penalties(pkg, orc, prod
         else: assert a[3]["pairs"] == b[3]["pairs"]
 
 
-def test_mesh_v1_distance_lattice_changes_no_result(pkg, orc, product_lib, monkeypatch):
+@pytest.mark.parametrize("case", ["blob 720", "blob 168", "Trefoil.obj"])
+def test_mesh_v1_distance_lattice_changes_no_result(pkg, orc, product_lib, monkeypatch, case):
     """The swept-volume sweep uses the same lattice to leave queries out whose answer cannot matter (a capped query the lattice
     already answers; fine samples that cannot hold their pass's minimum; coarse samples inside the band behind another such
     sample).  What is left out is never looked at: with and without the lattice (ISDF_NO_F32_FILTER=1 builds none) t*, cost and
     gradients are the same BITS, in both forms of the walks."""
     capi, synth = pkg.capi, pkg.synth
-    occ, esdf, res = small_world(pkg, seed=14)
-    T, cm = traj(pkg, occ, res, N=5, seed=23)
-    V, F = synth.blob_mesh(24, 16, scale=0.9)
+    seed_w, seed_t, safety = {"blob 720": (14, 23, 0.5), "blob 168": (14, 29, 0.35), "Trefoil.obj": (16, 31, 0.3)}[case]
+    occ, esdf, res = small_world(pkg, seed=seed_w)
+    T, cm = traj(pkg, occ, res, N=5, seed=seed_t)
+    if case == "Trefoil.obj": V, F = synth.reference_mesh("Trefoil", 0.83)
+    elif case == "blob 720": V, F = synth.blob_mesh(24, 16, scale=0.9)
+    else: V, F = synth.blob_mesh(12, 8, scale=0.9)
     way = cm.reshape(3, -1).T.reshape(5, 6, 3)[1:, 0, :]
     pts = synth.constraint_points(occ, (0, 0, 0), res, way, half=3.0)
     for wg in ("1", "0"):
@@ -323,7 +327,7 @@ def test_mesh_v1_distance_lattice_changes_no_result(pkg, orc, product_lib, monke
         out = {}
         for off in ("0", "1"):
             monkeypatch.setenv("ISDF_NO_F32_FILTER", off)
-            cfg1 = synth.default_config(capi.V1_SWEPT, safety_hor=0.5)
+            cfg1 = synth.default_config(capi.V1_SWEPT, safety_hor=safety)
             e1 = pkg.Engine(cfg1); e1.set_grid(occ, (0, 0, 0), res, capi.GRID_OCCUPANCY); e1.set_shape(synth.make_mesh_shape(V, F)); e1.set_points(pts)
             ts = -np.ones(len(pts))
             steps = []
