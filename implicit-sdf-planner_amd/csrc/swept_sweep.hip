@@ -1081,6 +1081,15 @@ void launch_swept_sweep(const SweptParams &P, hipStream_t stream, hipEvent_t ev_
         const size_t fr2 = (size_t)2 * mesh_frames_words(P.shape.mesh_levels) * sizeof(unsigned);      // two wavefronts' frames
         // (the trajectory stays in global memory for these launches: a pass is dominated by the hierarchy walks, and the 6 KB of staged
         // coefficients per workgroup were a workgroup less per CU - Trefoil.obj 9.0 -> 8.1 ms, 720 faces 4.75 -> 4.49 ms)
+        // With the distance lattice a fine pass rarely has more than 16 queries left: the second wavefront idles.  A launch of several
+        // generations of workgroups (>= 3 x the 4 096 one-wavefront workgroups the device holds) is bound by what its wavefronts
+        // issue and runs one-wavefront workgroups (16 611 points: blob 5.75 -> 5.31 ms, Trefoil.obj 4.81 -> 4.51); a smaller one is
+        // bound by its longest points and keeps two (7 773 points: 2.73 against 3.00 ms; a rank's eighth of the 16 611: 3.09 / 3.48).
+        // ISDF_MESH_SCAN_WAVES = 1 / 2 forces a form.
+        static const int sw_env = []{ const char *e = getenv("ISDF_MESH_SCAN_WAVES"); return e ? atoi(e) : 0; }();
+        const int sw = (sw_env == 1 || sw_env == 2) ? sw_env : (n >= 3 * 4096 ? 1 : 2);
+        if (sw == 1) hipExtLaunchKernelGGL((swept_scan_kernel<ISDF_SHAPE_MESH, false, 1>), grid, dim3(64), fr2 / 2, stream, ev_start, nullptr, 0, P);
+        else
         hipExtLaunchKernelGGL((swept_scan_kernel<ISDF_SHAPE_MESH, false, 2>), grid, block2, fr2, stream, ev_start, nullptr, 0, P);
         // The descent's passes are directed (descent_body): at most 14 queries = one quad round on ONE wavefront - one-wavefront
         // workgroups, twice the tasks in flight.  Measured against two wavefronts per task (the second one idle but for a first pass
