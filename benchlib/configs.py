@@ -224,6 +224,28 @@ def extra_configs(B):
                 ref1 = np.concatenate([[c0], gT0, gC0]); got1 = np.concatenate([[cs], gTs, gCs])
                 ent["rel_err_vs_oracle"] = float(np.linalg.norm(got1 - ref1) / max(np.linalg.norm(ref1), 1e-300))
                 ent["rel_err_vs_oracle_of"] = f"every 40th obstacle point ({len(ps)} points), both sides on that subset"
+            if "720" in nm or "Trefoil" in nm:
+                # What the ranks of an 8-GPU run would each execute, measured one after the other on this GPU: rank r's contiguous
+                # eighth of the obstacle points (isdf_set_shard).  The step of the real run is its slowest rank + one all-reduce.
+                try:
+                    dT8 = torch.from_numpy(T5).to(dev); dC8 = torch.from_numpy(cm5).to(dev)
+                    dO8 = torch.zeros(e1.out_stride(20), dtype=torch.float64, device=dev)
+                    per_rank = []
+                    for r8 in range(8):
+                        e1.set_shard(r8, 8)
+                        for _ in range(2):
+                            e1.eval_device(1, 20, dT8.data_ptr(), dC8.data_ptr(), dO8.data_ptr(), 0, stream)
+                        torch.cuda.synchronize(); t8 = time.perf_counter()
+                        for _ in range(3):
+                            e1.eval_device(1, 20, dT8.data_ptr(), dC8.data_ptr(), dO8.data_ptr(), 0, stream)
+                        torch.cuda.synchronize(); per_rank.append(round((time.perf_counter() - t8) / 3 * 1e3, 4))
+                    e1.set_shard(0, 1)
+                    ent["eight_way_split"] = {"ms_per_step_of_each_rank_measured_alone": per_rank, "slowest_rank_ms": max(per_rank),
+                                              "whole_step_over_slowest_rank": round(ent["ms_per_step"] / max(per_rank), 3),
+                                              "note": "a rank's 2 076 points are one generation of workgroups: its step is its longest chains (descents deep inside the robot), "
+                                                      "which the whole step hides behind seven more generations of work - the bound on this configuration's strong scaling (DESIGN.md 5)"}
+                except Exception as e8:      # noqa: BLE001
+                    ent["eight_way_split"] = {"error": str(e8)}
             if "720" in nm:
                 ent["roofline_issue"] = issue_from_counters(os.path.join(ROOT, "profiles", "pmc_counters_v1mesh.json"), v1_source_hash())
                 if ent["roofline_issue"]:
