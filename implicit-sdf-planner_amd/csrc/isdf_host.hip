@@ -420,7 +420,9 @@ extern "C" int isdf_set_shape(isdf_ctx *c, const isdf_shape *s) {
             const double margin = 1.05 * std::max(c->cfg.safety_hor, 2.0 * c->cfg.safety_hor + 0.1) + 0.01;
             double llo[3], lhi[3];
             for (int a = 0; a < 3; a++) { llo[a] = (double)d.bbox_lo[a] - margin; lhi[a] = (double)d.bbox_hi[a] + margin; }
-            const int rc = isdf_mesh_lattice_build(c, &hm, llo, lhi, 96);
+            int cells = 96;
+            if (const char *e = getenv("ISDF_MESH_LATTICE_CELLS")) { const int v = atoi(e); if (v >= 16 && v <= 256) cells = v; }      // (developer switch)
+            const int rc = isdf_mesh_lattice_build(c, &hm, llo, lhi, cells);
             if (rc) return rc;
             if (hm.dl) { HIPCHK(c, hipMemcpy(c->d_mesh, &hm, sizeof(hm), hipMemcpyHostToDevice)); d.filter_f32 = 1; }
         }
