@@ -571,8 +571,9 @@ __device__ __forceinline__ bool mesh_lattice_not_below(const DevMesh *m, d3 p, d
     if (!(fx > -0.5f && fx < (float)n0 - 0.5f && fy > -0.5f && fy < (float)n1 - 0.5f && fz > -0.5f && fz < (float)n2 - 0.5f)) return false;
     const float v = dl[((size_t)(int)rintf(fx) * n1 + (int)rintf(fy)) * n2 + (int)rintf(fz)];
     const double h = (double)ml->dl_h;
-    if (cap > 0.0) return v > 0.0f && ((double)v - h) * 0.952 >= cap * (1.0 + 1e-9);
-    const double dn = (v > 0.0f ? (double)v : -(double)v - 1.0) * (1.0 + 4.0e-6);      // an upper bound of the node's distance
+    const bool node_outside = __float_as_int(v) >= 0;                                   // (the sign bit: inside)
+    if (cap > 0.0) return node_outside && ((double)v - h) * 0.952 >= cap * (1.0 + 1e-9);
+    const double dn = (double)fabsf(v) * (1.0 + 4.0e-6);                                // an upper bound of the node's distance
     return 1.05 * (dn + h) <= -cap * (1.0 - 1e-9);
 }
 
@@ -587,10 +588,11 @@ __device__ __forceinline__ bool mesh_lattice_bounds(const DevMesh *m, d3 p, doub
     if (!(fx > -0.5f && fx < (float)n0 - 0.5f && fy > -0.5f && fy < (float)n1 - 0.5f && fz > -0.5f && fz < (float)n2 - 0.5f)) return false;
     const float v = dl[((size_t)(int)rintf(fx) * n1 + (int)rintf(fy)) * n2 + (int)rintf(fz)];
     const double h = (double)ml->dl_h;
-    const double dlo = (v > 0.0f ? (double)v : -(double)v - 1.0), dhi = dlo * (1.0 + 4.0e-6);      // the node's distance, from below / above
+    const bool node_outside = __float_as_int(v) >= 0;                                   // (the sign bit: inside)
+    const double dlo = (double)fabsf(v), dhi = dlo * (1.0 + 4.0e-6);                    // the node's distance, from below / above
     const double far = fmax(dlo - h, 0.0), near = dhi + h;                                            // dist(p) lies in [far, near]
     if (dlo > h) {                      // p on the node's side of the surface
-        if (v > 0.0f) { lb = 0.952 * far; ub = 1.05 * near; }
+        if (node_outside) { lb = 0.952 * far; ub = 1.05 * near; }
         else { lb = -1.05 * near; ub = -0.952 * far; }
     } else { lb = -1.05 * near; ub = 1.05 * near; }
     return true;

@@ -31,7 +31,7 @@ struct DevMesh {
     const double *fwn_triq; // 10 per (node, child): the child's triangle (tri) when it is one; pad
     int depth;              // levels of the hierarchy
     // The tile sweep's pre-filter for this kind (built on the device by isdf_set_shape, shape_eval.hip): a lattice of node-to-surface
-    // DISTANCES, rounded down, positive where the node lies outside the mesh and negative inside; node (i, j, k) at
+    // DISTANCES, rounded down, with the sign bit set where the node lies inside the mesh (reference SDF <= 0); node (i, j, k) at
     // dl_min + (i, j, k) / dl_inv, value dl[(i * dln[1] + j) * dln[2] + k]; dl_h = the farthest a point can be from its nearest
     // node.  A point p whose nearest node n has dl[n] - dl_h >= band is farther than `band` from the surface and on the node's
     // side of it (the segment n -> p cannot cross a surface that is farther from n than p is).  null: no lattice.

@@ -33,7 +33,7 @@ __global__ __launch_bounds__(256) void mesh_lattice_kernel(const DevMesh *m, flo
     const double d = sqrt(mesh_query(m, p, c, s)) * (1.0 - 1.0e-6);
     float f = (float)d;
     if ((double)f > d) f = __int_as_float(__float_as_int(f) - 1);      // (f > d >= 0: the next float towards zero)
-    out[i] = s > 0.0 ? f : -1.0f - f;
+    out[i] = s > 0.0 ? f : -f;                   // (the sign BIT says inside: a node on the surface is +0 or -0)
     if (d > (double)clear && !(fabs(s) >= 0.96 && fabs(s) <= 1.04)) atomicOr(flag, 1u);
 }
 
