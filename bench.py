@@ -282,18 +282,18 @@ def main():
                "definition": "SURVEY 8(d): (k^3 x 4 B tile + corners + coefficients + outputs) x evals per launch / kernel duration / 8 TB/s - a work-rate "
                              "proxy in the north-star's unit, NOT traffic and NOT a bound: the kernel reads a 1-bit qualifier grid, its HBM bytes are `traffic`",
                "exceeds_1_on": "filled below from `configs` (every entry whose nominal_bytes_frac > 1)"}
-    if issue is not None:
-        roofline = {"bound": "valu-issue", "achieved": issue["valu_issue_busy_frac"], "peak": 1.0,
-                    "unit": "VALU instructions issued per SIMD-cycle (1.0 = one on every one of the 1 024 SIMDs in every cycle at 2.4 GHz)",
-                    "frac": issue["valu_issue_busy_frac"], "traffic": traffic,
-                    "lane_utilisation": issue["lane_utilisation"], "useful_fp64_frac": issue["useful_fp64_frac"],
-                    "fp64_share_of_valu_insts": issue["fp64_share_of_valu_insts"], "waves_per_simd_avg": issue["waves_per_simd_avg"],
-                    "wait_frac_of_wave_cycles": issue["wait_frac_of_wave_cycles"],
-                    "note": "C2 is ONE launch of 2 600 wavefronts for 1 024 SIMDs: at ~2 waves per SIMD it is latency-floored; the same kernel reaches its issue bound on the batch (configs[0].roofline)",
-                    "definition": issue["definition"], "counters": issue["source"], "counters_measured_on_commit": issue["measured_on_commit"]}
-    else:
-        roofline = {"bound": "valu-issue (by the committed counters of the N = 1 workload; none for this geometry / this version of the kernel sources)",
-                    "achieved": None, "peak": 1.0, "unit": "VALU instructions issued per SIMD-cycle", "frac": None, "traffic": None}
+    # `roofline` follows the contract (SURVEY 8(d) / BASELINE.md): achieved = algorithmic bytes per launch / the kernel's duration,
+    # peak = the HBM spec peak, frac = achieved / peak.  What actually limits the kernel is instruction issue: `issue_frac`,
+    # `lane_utilisation`, the measured HBM traffic (`traffic`, `hbm_frac_measured`) stand beside it.
+    roofline = {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
+                "traffic": traffic,
+                "issue_frac": None if issue is None else issue["valu_issue_busy_frac"],
+                "lane_utilisation": None if issue is None else issue["lane_utilisation"],
+                "waves_per_simd_avg": None if issue is None else issue["waves_per_simd_avg"],
+                "wait_frac_of_wave_cycles": None if issue is None else issue["wait_frac_of_wave_cycles"],
+                "counters": None if issue is None else issue["source"],
+                "limits": "VALU instruction issue / latency (C2 is ONE launch of 2 600 wavefronts for 1 024 SIMDs); the kernel reads a 1-bit qualifier grid from L2, "
+                          "so the contract's byte figure is a work rate in the north-star's unit, not traffic"}
     roofline.update({"hbm_frac_measured": None if hbm_meas is None else round(hbm_meas / HBM_PEAK_GBS, 5),
                      "hbm_gbs_measured": None if hbm_meas is None else round(hbm_meas, 1),
                      "kernel": "sweep_kernel", "kernel_ms": round(kern_ms, 5), "launches": n_launch,
@@ -482,9 +482,7 @@ def main():
                                    f"occ_thresh = 0, cull {'on' if args.cull else 'off'}"
                                    + (" = BASELINE configs[1]" if (world == 1 and N == 40) else "")
                                    + ("" if world == 1 else (f" = BASELINE configs[3], {N // world}-{-(-N // world)} pieces per rank" if N == 400 else ""))
-                                   + ("" if world == 1 else ".  NOTE: the --gpus 1 line of this bench is ANOTHER workload (configs[1]: 40 pieces, 2 600 evals per step): "
-                                      "value(N) / value(1) is not a scaling efficiency - use `speedup` (= value / one_gpu_same_workload.evals_per_s, same run) "
-                                      "and configs[0] (configs[2] sharded by trajectory, with its own one-GPU figure)"),
+                                   + ("" if world == 1 else "; the --gpus 1 line is configs[1] (another workload): read `speedup`, not value(N)/value(1)"),
                        "pieces": N, "samples_per_piece": K + 1, "grid": args.grid, "kernel_size": args.kernel_size,
                        "sharding": ("none" if world == 1 else ("pieces contiguous by rank; each piece's 19 rows + cost stored by its owner into every peer's output inside the step's launches" if mode == "fused" else "pieces contiguous by rank + all_reduce(sum) of 1+19N doubles")),
                        "collective": collective,
@@ -497,7 +495,20 @@ def main():
             "stats_last_step_rank0": stats, "lbfgs": lbfgs, "hbm_copy_gbs_measured": hbm_copy,
         }
         result.update(issue_keys)
-        print(json.dumps(result), flush=True)
+        # the long form (every entry with its prose) goes to a file; the ONE printed line is the compact record (< 4 KB: the driver
+        # keeps an 8 KB tail of stdout - round 5's 21 KB line could not be parsed)
+        from benchlib.compact import MAX_LINE, compact_line
+        detail_rel = os.path.join("gpurun_out", f"bench_detail_n{world}.json")
+        try:
+            os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+            with open(os.path.join(ROOT, detail_rel), "w") as f:
+                json.dump(result, f, indent=1)
+            result["detail_file"] = detail_rel
+        except OSError:
+            result["detail_file"] = None
+        line = json.dumps(compact_line(result))
+        assert len(line) < MAX_LINE, len(line)
+        print(line, flush=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

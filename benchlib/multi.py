@@ -27,7 +27,7 @@ def scaling_entries(B):
         dist.all_reduce(ta, op=dist.ReduceOp.MAX)
         devs = [torch.zeros(1, dtype=torch.int64, device=dev) for _ in range(world)]
         dist.all_gather(devs, torch.tensor([local_rank], dtype=torch.int64, device=dev))
-        rccl_seen = {"backend": dist.get_backend(), "rccl_ranks_seen": dist.get_world_size(), "devices_by_rank": [int(d.item()) for d in devs],
+        rccl_seen = {"backend": dist.get_backend(), "ranks_seen": dist.get_world_size(), "devices_by_rank": [int(d.item()) for d in devs],
                      "distinct_devices": len({int(d.item()) for d in devs}),
                      "all_reduce_alone_ms": round(1e3 * float(ta.item()), 5), "all_reduce_doubles": int(ar.numel())}
         del ar

@@ -104,3 +104,31 @@ def test_product_does_not_link_the_oracle(pkg):
             if f.endswith((".py", ".hip", ".hpp", ".h", ".cpp", "Makefile")):
                 txt = open(os.path.join(dp, f), errors="ignore").read()
                 assert not bad.search(txt), f
+
+
+def test_bench_line_fits_the_driver(pkg):
+    """bench.py prints ONE compact JSON line (< 4 KB: the driver keeps an 8 KB tail of stdout; round 5's 21 KB line was lost) that carries the
+    contract's keys; the long record it is cut from is one of the committed long-form records."""
+    import json
+    import sys
+    sys.path.insert(0, ROOT)
+    from benchlib.compact import MAX_LINE, compact_line
+    assert MAX_LINE <= 4096
+    for rec in ("r5_bench.json", "r5_bench_8ranks_one_gpu.json"):
+        full = json.load(open(os.path.join(ROOT, "profiles", rec)))
+        # worst case: every entry with a long name and every optional key present
+        full["configs"] = (full.get("configs") or []) * 3
+        line = json.dumps(compact_line(full))
+        assert len(line) < MAX_LINE, (rec, len(line))
+        back = json.loads(line)
+        for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data",
+                  "config", "roofline", "cpu_baseline"):
+            assert k in back, k
+        assert set(("bound", "achieved", "peak", "unit", "frac", "traffic")) <= set(back["roofline"])
+        assert back["roofline"]["bound"] == "hbm" and back["roofline"]["unit"] == "GB/s"
+        assert abs(back["roofline"]["frac"] - back["roofline"]["achieved"] / back["roofline"]["peak"]) < 1e-3
+        assert set(("value", "unit", "cores", "kind", "sample")) <= set(back["cpu_baseline"])
+        assert isinstance(back["config"]["workload"], str) and len(back["config"]["workload"]) <= 300
+        assert not any(k in back["config"] for k in ("model", "global_batch", "seq_len"))
+    src = open(os.path.join(ROOT, "bench.py")).read()
+    assert src.count("print(line, flush=True)") == 1 and "print(json.dumps(result)" not in src
