@@ -104,6 +104,7 @@ EXPORTED_SYMBOLS = [
     "isdf_shape_from_config",
     "isdf_host_path", "isdf_mesh_atan2f", "isdf_create_multi", "isdf_multi_info", "isdf_set_shape_grid", "isdf_set_shape_sampled",
     "isdf_xchg_create", "isdf_xchg_connect", "isdf_xchg_allreduce", "isdf_xchg_fuse", "isdf_xchg_status", "isdf_xchg_destroy",
+    "isdf_xchg_timeout_ms", "isdf_xchg_set_timeout_ms",
 ]
 
 HOST_PATH_COPY, HOST_PATH_DIRECT_MAPPED, HOST_PATH_DIRECT_BAR, HOST_PATH_DEVICE_CALLBACK = 0, 1, 2, 3
@@ -188,6 +189,9 @@ def load_library(path=None):
     lib.isdf_xchg_fuse.argtypes = [C.c_void_p, C.c_int]
     lib.isdf_xchg_status.argtypes = [C.c_void_p]
     lib.isdf_xchg_destroy.argtypes = [C.c_void_p]
+    lib.isdf_xchg_timeout_ms.argtypes = [C.c_void_p]
+    lib.isdf_xchg_timeout_ms.restype = C.c_double
+    lib.isdf_xchg_set_timeout_ms.argtypes = [C.c_void_p, C.c_double]
     lib.isdf_frontend_cspace.argtypes = [C.c_void_p, C.c_void_p, dp]
     lib.isdf_frontend_check.argtypes = [C.c_void_p, C.c_int, C.c_void_p, dp, dp, C.c_void_p, dp, dp, C.c_void_p]
     lib.isdf_lbfgs_params_default.argtypes = [C.POINTER(IsdfLbfgsParams)]

@@ -34,7 +34,8 @@ constexpr unsigned long long HOST_FLAG_OVERFLOW = 1ull << 62;
 constexpr int XCHG_MAX_WORLD = 16;
 constexpr int XF_ROW = 20;
 struct XFuse {
-    int world, rank, parity, pad;
+    int world, rank, parity;
+    int timeout_ticks;                  // bound of a wait for a peer's row, in wall_clock64() ticks (isdf_xchg_timeout_ms)
     unsigned long long parity_stride;   // doubles between the two parities' regions of a board: half the board, FIXED for the
                                         // life of the exchange (a stride derived from the launch's piece count would make
                                         // consecutive steps of different size overlap while a rank is one step ahead)

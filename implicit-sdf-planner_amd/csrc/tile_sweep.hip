@@ -150,17 +150,21 @@ __device__ __forceinline__ void slot_clear(double *slot) {
     __hip_atomic_store((unsigned long long *)slot, SLOT_EMPTY, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 // the same three for slots other GPUs write or read (boards of the in-kernel exchange: IPC-mapped uncached memory)
-constexpr int XF_SPIN_MAX = 1 << 21;                   // peers may start their step later than this rank: about one second of polling
+// peers may start their step later than this rank: the wait for a row is bounded by the device wall clock (XFuse::timeout_ticks =
+// isdf_xchg_timeout_ms; 100 MHz, the same bound on every box), armed at a lane's first miss and shared by its later takes
 __device__ __forceinline__ void xslot_publish(double *slot, double v) {
     unsigned long long bits = (unsigned long long)__double_as_longlong(v);
     if (bits == SLOT_EMPTY) bits = 0x7FF8000000000000ull;
     __hip_atomic_store((unsigned long long *)slot, bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
-__device__ __forceinline__ bool xslot_take(double *slot, double &v) {        // bounded poll, then hands the slot back empty
+__device__ __forceinline__ bool xslot_take(double *slot, double &v, int timeout_ticks, unsigned long long &deadline) {        // bounded poll, then hands the slot back empty
     unsigned long long b = __hip_atomic_load((unsigned long long *)slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-    for (int spin = 0; b == SLOT_EMPTY && spin < XF_SPIN_MAX; spin++) {
-        __builtin_amdgcn_s_sleep(4);
-        b = __hip_atomic_load((unsigned long long *)slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    if (b == SLOT_EMPTY) {
+        if (deadline == 0ull) deadline = wall_clock64() + (unsigned long long)timeout_ticks;
+        while (b == SLOT_EMPTY && wall_clock64() <= deadline) {
+            __builtin_amdgcn_s_sleep(4);
+            b = __hip_atomic_load((unsigned long long *)slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
     }
     __hip_atomic_store((unsigned long long *)slot, SLOT_EMPTY, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     v = __longlong_as_double((long long)b);
@@ -1403,7 +1407,8 @@ template <bool EARLY, bool XF> __device__ __forceinline__ void tail_piece(const 
             // a piece of another rank: its owner stores the 19 rows into this rank's board (the cost slot is the collector's)
             if (q < 19) {
                 double v;
-                lost = !xslot_take(my_board + (size_t)gp * XF_ROW + q, v);
+                unsigned long long deadline = 0ull;
+                lost = !xslot_take(my_board + (size_t)gp * XF_ROW + q, v, P.xf.timeout_ticks, deadline);
                 if (q == 18) o[1 + i] = v;
                 else { const int d = q / 6, r = q - 6 * d; o[1 + P.N + (size_t)d * 6 * P.N + 6 * i + r] = v; }
             }
@@ -1603,9 +1608,10 @@ template <bool EARLY, bool XF> __device__ __forceinline__ void tail_piece(const 
     if (collector && tid < 64) {
         double sum = 0.0;
         bool gone = false;
+        unsigned long long deadline = 0ull;
         for (int k = k0 + tid; k < k1; k += 64) {
             double v;
-            if constexpr (XF) gone = !xslot_take(my_board + ((size_t)b * P.N + k) * XF_ROW + 19, v) || gone;
+            if constexpr (XF) gone = !xslot_take(my_board + ((size_t)b * P.N + k) * XF_ROW + 19, v, P.xf.timeout_ticks, deadline) || gone;
             else {
                 double *slot = &P.piece_cost[(size_t)b * P.N + k];
                 unsigned long long bits = slot_peek(slot);

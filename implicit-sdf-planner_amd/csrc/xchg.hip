@@ -14,24 +14,56 @@
 
 namespace isdf {
 
-constexpr long long XCHG_SPIN_LIMIT = 1ll << 22;       // x ~64 ns sleep + one flag load: ~0.5 s
+// Every wait is bounded by the DEVICE WALL CLOCK (wall_clock64(): a constant-rate counter, 100 MHz on gfx950; the rate is read
+// from hipDeviceAttributeWallClockRate when the exchange is created), not by a spin count: the bound is the same number of
+// milliseconds on every box, the caller can read it (isdf_xchg_timeout_ms) and set it (isdf_xchg_set_timeout_ms).
+//   T  = the time-out: how much later than this rank a peer may START the exchange (data wait, push-counter wait)
+//   2T + T/4 from this rank's start: the verdict round's bound (a peer whose data arrived started before t0 + T, its own
+//        data wait ends before its start + T, so its verdict is here before t0 + 2T)
+//   the other blocks of a launch give up only while block 0 has not STARTED (4T + T from their own start), see below
+constexpr double XCHG_DEFAULT_TIMEOUT_MS = 500.0;
 
 struct XchgParams {
     int rank, world;
     size_t slot_doubles;                  // capacity of one slot
     unsigned long long seq;               // this exchange (1, 2, ...)
+    unsigned long long t_wait;            // T in wall-clock ticks
     double *peer_slots[XCHG_MAX_WORLD];   // base of rank r's mailbox data: [2 parities][world slots][slot_doubles]
     unsigned long long *peer_flags[XCHG_MAX_WORLD];   // rank r's flags: [2 parities][world] "data of exchange seq has arrived", then
                                                       // [2 parities][world] VERDICT words (seq << 1 | "my wait timed out")
     unsigned *status;                     // device word: != 0 after a time-out
     unsigned long long *pushes;           // device counter of completed pushes (world - 1 per exchange), local to this rank
-    unsigned long long *decision;         // device word (seq << 1 | bad): block 0's verdict for exchange seq, read by this rank's other blocks
+    unsigned long long *decision;         // device word (seq << 2 | state): the rank's ONE decision for exchange seq
 };
+
+// states of the decision word for one exchange.  It moves NONE -> STARTED -> OK | BAD (block 0) or NONE -> BAD (another block
+// whose hang guard expired before block 0 ever started); every transition is a compare-and-swap, so the rank has ONE verdict:
+// whoever loses the race adopts the winner's.
+constexpr unsigned long long XD_STARTED = 1ull, XD_OK = 2ull, XD_BAD = 3ull;
+
+__device__ __forceinline__ unsigned long long xd_load(const unsigned long long *p) {
+    return __hip_atomic_load(p, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
+}
+// Move the decision word of exchange `seq` to `to` and return the state in force afterwards.  A FINAL state of this exchange is
+// never changed (the caller adopts it).  from_none_only (the other blocks' hang guard): a word that block 0 has already moved to
+// STARTED is left alone and STARTED is returned.
+__device__ __forceinline__ unsigned long long xd_move(unsigned long long *p, unsigned long long seq, unsigned long long to, bool from_none_only) {
+    unsigned long long cur = xd_load(p);
+    for (;;) {
+        if ((cur >> 2) == seq) {
+            const unsigned long long st = cur & 3ull;
+            if (st >= XD_OK || st == to || from_none_only) return st;
+        }
+        const unsigned long long want = (seq << 2) | to;
+        if (__hip_atomic_compare_exchange_strong(p, &cur, want, __ATOMIC_ACQ_REL, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT)) return to;
+    }
+}
 
 // grid: one block per PEER pushes (blockIdx.x < world - 1), then every block takes part in the wait + rank-order sum
 __global__ __launch_bounds__(1024) void xchg_allreduce_kernel(XchgParams X, double *__restrict__ buf, size_t count) {
     const int par = (int)(X.seq & 1ull);
     const int nb = gridDim.x;
+    const unsigned long long t0 = wall_clock64();
     // ---- push: this rank's vector into slot [par][rank] of every peer, then the flag
     for (int pb = blockIdx.x; pb < X.world - 1; pb += nb) {
         const int peer = pb < X.rank ? pb : pb + 1;
@@ -47,26 +79,27 @@ __global__ __launch_bounds__(1024) void xchg_allreduce_kernel(XchgParams X, doub
     }
     // ---- wait (bounded) + verdict round: BLOCK 0 decides for the whole rank.  Lane r of its first wavefront polls peer r's flag
     // in MY mailbox, lane `world` this rank's own push counter (the sum below overwrites buf: every push of THIS rank, possibly
-    // by another block, must have read it first) - all at once, one round trip instead of one per peer.  The other blocks have
-    // no timer of their own: they wait for block 0's published decision (a per-block time-out could let ONE block give up
-    // while block 0 - the only writer of the NaN cost - did not: a finite cost over a gradient slice that was never summed).
+    // by another block, must have read it first) - all at once, one round trip instead of one per peer.
     __shared__ int s_ok;
     if (blockIdx.x == 0 && threadIdx.x < 64) {
         const int lane = threadIdx.x;
-        bool ok = true;
-        if (lane < X.world && lane != X.rank) {
+        // block 0 is running: from here on its own clock bounds the exchange (<= 2T + T/4), the other blocks stop timing
+        unsigned long long st = XD_STARTED;
+        if (lane == 0) st = xd_move(X.decision, X.seq, XD_STARTED, false);
+        st = __shfl(st, 0);
+        bool ok = st != XD_BAD;             // another block gave up before this one started: the rank's verdict is already "bad"
+        const unsigned long long d_data = t0 + X.t_wait;
+        if (ok && lane < X.world && lane != X.rank) {
             const unsigned long long *mine = X.peer_flags[X.rank] + (size_t)par * X.world;
-            long long spins = 0;
             while (__hip_atomic_load(mine + lane, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) != X.seq) {
-                __builtin_amdgcn_s_sleep(1);
-                if (++spins > XCHG_SPIN_LIMIT) { ok = false; break; }
+                __builtin_amdgcn_s_sleep(2);
+                if (wall_clock64() > d_data) { ok = false; break; }
             }
-        } else if (lane == X.world) {
+        } else if (ok && lane == X.world) {
             const unsigned long long want = X.seq * (unsigned long long)(X.world - 1);
-            long long spins = 0;
             while (__hip_atomic_load(X.pushes, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < want) {
-                __builtin_amdgcn_s_sleep(1);
-                if (++spins > XCHG_SPIN_LIMIT) { ok = false; break; }
+                __builtin_amdgcn_s_sleep(2);
+                if (wall_clock64() > d_data) { ok = false; break; }
             }
         }
         bool all_ok = __ballot(!ok) == 0ull;
@@ -74,36 +107,52 @@ __global__ __launch_bounds__(1024) void xchg_allreduce_kernel(XchgParams X, doub
         // everything), and ranks that disagree about a step would walk different optimizer paths.  So every rank tells every
         // peer what its wait saw - one more 8-byte store per peer and one more poll, inside this kernel, instead of a host-side
         // collective after every step - and the exchange counts as good only if EVERY rank's wait was.  A verdict that does
-        // not arrive in time is a bad one.
+        // not arrive in time is a bad one.  A rank whose own wait failed has nothing to learn from the peers' verdicts: it
+        // posts "bad" and leaves (its kernel lasts T, not 3T).
         unsigned long long *const verdict_own = X.peer_flags[X.rank] + (size_t)(2 + par) * X.world;
         if (lane < X.world) {
             const unsigned long long word = (X.seq << 1) | (all_ok ? 0ull : 1ull);
             __hip_atomic_store(X.peer_flags[lane] + (size_t)(2 + par) * X.world + X.rank, word, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-            long long spins = 0;
-            unsigned long long v;
-            while (((v = __hip_atomic_load(verdict_own + lane, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM)) >> 1) != X.seq) {
-                __builtin_amdgcn_s_sleep(1);
-                if (++spins > XCHG_SPIN_LIMIT) { v = 1ull; break; }
+            ok = all_ok;
+            if (all_ok) {
+                const unsigned long long d_verdict = t0 + 2ull * X.t_wait + (X.t_wait >> 2);
+                unsigned long long v;
+                while (((v = __hip_atomic_load(verdict_own + lane, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM)) >> 1) != X.seq) {
+                    __builtin_amdgcn_s_sleep(2);
+                    if (wall_clock64() > d_verdict) { v = 1ull; break; }
+                }
+                ok = (v & 1ull) == 0ull;
             }
-            ok = (v & 1ull) == 0ull;
         } else ok = true;
         all_ok = __ballot(!ok) == 0ull;
         if (lane == 0) {
-            if (!all_ok) atomicExch(X.status, 1u);
-            s_ok = all_ok ? 1 : 0;
-            // the rank's ONE decision for exchange seq, for its other blocks (release: they read the mailbox after it)
-            __hip_atomic_store(X.decision, (X.seq << 1) | (all_ok ? 0ull : 1ull), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+            // the rank's ONE decision for exchange seq (release: the other blocks read the mailbox after it)
+            const unsigned long long fin = xd_move(X.decision, X.seq, all_ok ? XD_OK : XD_BAD, false);
+            if (fin != XD_OK) atomicExch(X.status, 1u);
+            s_ok = fin == XD_OK ? 1 : 0;
         }
     } else if (blockIdx.x != 0 && threadIdx.x == 0) {
-        // bounded like block 0's own waits (three of them, one after the other) plus slack: if block 0 of this launch never ran to
-        // its decision (not resident, faulted), the other blocks must not hang the stream - they take the failure path and say so
-        unsigned long long v;
-        long long spins = 0;
-        while (((v = __hip_atomic_load(X.decision, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT)) >> 1) != X.seq) {
-            __builtin_amdgcn_s_sleep(1);
-            if (++spins > 4 * XCHG_SPIN_LIMIT) { v = 1ull; atomicExch(X.status, 1u); break; }
+        // The other blocks wait for block 0's decision.  They time ONLY block 0's absence: once the word says STARTED, block 0's
+        // own clock ends the exchange within 2T + T/4, so a block here cannot give up while block 0 goes on to decide "ok" (a
+        // finite cost over a gradient slice that was never summed).  If block 0 has not even started 5T after this block did
+        // (not resident, faulted), this block moves the word NONE -> BAD: block 0, should it ever run, adopts that verdict, posts
+        // it to the peers and writes the NaN.  A second, far longer guard covers a block 0 that started and then vanished.
+        const unsigned long long d_absent = t0 + 5ull * X.t_wait, d_vanished = t0 + 16ull * X.t_wait;
+        unsigned long long fin = 0ull;
+        for (;;) {
+            const unsigned long long cur = xd_load(X.decision);
+            const bool this_seq = (cur >> 2) == X.seq;
+            if (this_seq && (cur & 3ull) >= XD_OK) { fin = cur & 3ull; break; }
+            const unsigned long long now = wall_clock64();
+            if ((!this_seq && now > d_absent) || now > d_vanished) {
+                fin = xd_move(X.decision, X.seq, XD_BAD, /*from_none_only=*/now <= d_vanished);
+                if (fin == XD_STARTED) continue;            // block 0 started in this very moment: keep waiting for it
+                if (fin != XD_OK) atomicExch(X.status, 1u);
+                break;
+            }
+            __builtin_amdgcn_s_sleep(2);
         }
-        s_ok = (v & 1ull) == 0ull ? 1 : 0;
+        s_ok = fin == XD_OK ? 1 : 0;
     }
     __syncthreads();
     if (!s_ok) {
@@ -138,6 +187,7 @@ struct isdf_xchg {
     bool opened[XCHG_MAX_WORLD] = {false};
     unsigned *d_status = nullptr;               // [status word | pad | 64-bit push counter | 64-bit decision word]
     unsigned long long seq = 0;
+    double ticks_per_ms = 1e5;                  // wall_clock64() rate of this device (hipDeviceAttributeWallClockRate, kHz): 100 MHz on gfx950
     bool connected = false;
 };
 
@@ -163,6 +213,11 @@ extern "C" int isdf_xchg_create(isdf_ctx *c, int rank, int world, size_t max_dou
     isdf_xchg *x = new isdf_xchg();
     c->xchg = x;
     x->rank = rank; x->world = world;
+    {
+        int khz = 0;
+        if (hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, c->device) == hipSuccess && khz > 0) x->ticks_per_ms = (double)khz;
+        else (void)hipGetLastError();
+    }
     x->slot_doubles = (max_doubles + 63) / 64 * 64;
     const size_t data_bytes = (size_t)2 * world * x->slot_doubles * sizeof(double);
     x->flags_offset = (data_bytes + 255) / 256 * 256;
@@ -209,7 +264,7 @@ extern "C" int isdf_xchg_allreduce(isdf_ctx *c, double *d_buf, size_t count, voi
     if (!x || !x->connected) return isdf_fail(c, ISDF_ERR_STATE, "exchange not connected");
     if (count > x->slot_doubles) return isdf_fail(c, ISDF_ERR_INVALID_ARG, "vector longer than the exchange was created for");
     XchgParams X{};
-    X.rank = x->rank; X.world = x->world; X.slot_doubles = x->slot_doubles; X.seq = ++x->seq; X.status = x->d_status; X.pushes = (unsigned long long *)((char *)x->d_status + 8); X.decision = (unsigned long long *)((char *)x->d_status + 16);
+    X.rank = x->rank; X.world = x->world; X.slot_doubles = x->slot_doubles; X.seq = ++x->seq; X.t_wait = (unsigned long long)(c->xchg_timeout_ms * x->ticks_per_ms); X.status = x->d_status; X.pushes = (unsigned long long *)((char *)x->d_status + 8); X.decision = (unsigned long long *)((char *)x->d_status + 16);
     for (int r = 0; r < x->world; r++) {
         X.peer_slots[r] = (double *)x->peer_base[r];
         X.peer_flags[r] = (unsigned long long *)((char *)x->peer_base[r] + x->flags_offset);
@@ -241,7 +296,8 @@ bool isdf_xchg_fill(isdf_ctx *c, isdf::XFuse *xf, size_t pieces, int *err) {
     if (!x || !x->fuse_on) return false;
     if (!x->connected || x->rank != c->rank || x->world != c->world) { *err = isdf_fail(c, ISDF_ERR_STATE, "in-kernel exchange: shard and exchange disagree"); return true; }
     if ((size_t)2 * XF_ROW * pieces > x->board_doubles) { *err = isdf_fail(c, ISDF_ERR_INVALID_ARG, "in-kernel exchange: more pieces than the exchange was created for"); return true; }
-    xf->world = x->world; xf->rank = x->rank; xf->parity = (int)(++x->fuse_seq & 1ull); xf->pad = 0;
+    xf->world = x->world; xf->rank = x->rank; xf->parity = (int)(++x->fuse_seq & 1ull);
+    xf->timeout_ticks = (int)std::min(2.0e9, c->xchg_timeout_ms * x->ticks_per_ms);
     xf->parity_stride = (unsigned long long)(x->board_doubles / 2);
     for (int r = 0; r < x->world; r++) xf->board[r] = (double *)((char *)x->peer_base[r] + x->board_offset);
     return true;
@@ -257,6 +313,17 @@ void isdf_xchg_reset_board(isdf_ctx *c) {
     (void)hipDeviceSynchronize();
     (void)hipMemset((char *)x->own + x->board_offset, 0xFF, x->board_doubles * sizeof(double));
     (void)hipDeviceSynchronize();
+}
+
+// The bound T of every wait of the exchange, in milliseconds of the device's wall clock (default 500): how much later than this
+// rank a peer may start an exchange before this rank calls it failed.  A failed exchange kernel ends after T on the rank whose
+// wait expired and at once on a late rank; a healthy one waits at most 2.25 T for the verdicts.
+extern "C" double isdf_xchg_timeout_ms(isdf_ctx *c) { return c ? c->xchg_timeout_ms : XCHG_DEFAULT_TIMEOUT_MS; }
+extern "C" int isdf_xchg_set_timeout_ms(isdf_ctx *c, double ms) {
+    if (!c) return ISDF_ERR_INVALID_ARG;
+    if (!(ms >= 1.0 && ms <= 10000.0)) return isdf_fail(c, ISDF_ERR_INVALID_ARG, "exchange time-out must be 1 ... 10 000 ms");
+    c->xchg_timeout_ms = ms;
+    return ISDF_OK;
 }
 
 extern "C" int isdf_xchg_status(isdf_ctx *c) {

@@ -259,6 +259,13 @@ class Engine:
     def xchg_status(self):
         return int(self.lib.isdf_xchg_status(self.h))
 
+    def xchg_timeout_ms(self):
+        """bound of every wait of the exchange, milliseconds of the device wall clock"""
+        return float(self.lib.isdf_xchg_timeout_ms(self.h))
+
+    def xchg_set_timeout_ms(self, ms):
+        self._check(self.lib.isdf_xchg_set_timeout_ms(self.h, float(ms)))
+
     def xchg_destroy(self):
         self._check(self.lib.isdf_xchg_destroy(self.h))
 

@@ -374,6 +374,13 @@ int isdf_xchg_connect(isdf_ctx *ctx, const void *ipc_handles_world_x_64bytes);
 int isdf_xchg_allreduce(isdf_ctx *ctx, double *d_buf, size_t count, void *stream);
 int isdf_xchg_status(isdf_ctx *ctx);
 int isdf_xchg_destroy(isdf_ctx *ctx);
+/* The bound T of every wait of both exchange forms, in MILLISECONDS OF THE DEVICE'S WALL CLOCK (wall_clock64(), constant rate:
+ * the same duration on every box; default 500, settable 1 ... 10 000): how much later than this rank a peer may start a step
+ * before this rank calls the exchange failed.  A failed isdf_xchg_allreduce kernel ends after T on the rank whose wait expired
+ * and at once on the late rank (which reads the first one's verdict); a healthy one waits at most 2.25 T for the verdicts.
+ * Replaces: nothing in the reference (no multi-GPU path); the counterpart of NCCL's watchdog time-out, SURVEY 8(e). */
+double isdf_xchg_timeout_ms(isdf_ctx *ctx);
+int isdf_xchg_set_timeout_ms(isdf_ctx *ctx, double milliseconds);
 
 /* ---- optimizer driver ----------------------------------------------------------------------------------------- */
 /* L-BFGS behind the callback: lbfgs::lbfgs_optimize of src/utils/include/utils/lbfgs.hpp:480-835 (the LBFGS-Lite fork

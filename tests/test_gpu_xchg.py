@@ -34,5 +34,11 @@ def test_xchg_failure_is_agreed_in_the_kernel(product_lib):
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
            "--master-port", str(_free_port()), os.path.join(ROOT, "tests", "native", "xchg_fail_worker.py")]
+    import time
+    t0 = time.perf_counter()
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
-    assert r.returncode == 0 and "XCHG FAILURE AGREED OK" in r.stdout, (r.stdout[-3000:], r.stderr[-3000:])
+    wall = time.perf_counter() - t0
+    said = "\n".join(l for l in r.stdout.splitlines() if "[xchg_fail_worker]" in l or "Error" in l or "assert" in l)
+    print(f"xchg failure test: {wall:.1f} s wall\n{said}")         # (-s / the failure report show the workers' own lines, the kernel's duration among them)
+    assert r.returncode == 0 and "XCHG FAILURE AGREED OK" in r.stdout, (said, r.stdout[-3000:], r.stderr[-3000:])
+    assert "rank 0: failed exchange took" in r.stdout and "rank 1: failed exchange took" in r.stdout
