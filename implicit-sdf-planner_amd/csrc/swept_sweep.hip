@@ -40,6 +40,9 @@
 namespace isdf {
 
 constexpr int SW_WAVES = 4;
+#ifndef ISDF_MESH_WPE
+#define ISDF_MESH_WPE 4      // wavefronts per SIMD the workgroup-form mesh kernels are compiled for (register budget 512 / this)
+#endif
 constexpr int SW_MAX_RANGES = 32;                // intervals kept per point (more set the overflow flag); 5 bits of a task word
 constexpr int TASK_STRIDE = 6;                   // doubles per (point, interval) slot: in (lb, ub, seed) / out (t, sdf, grad(3), counters)
 constexpr int LPT_TASK = 8;                      // descents of >= this many passes (last step) are dispatched first
@@ -518,7 +521,7 @@ __device__ __forceinline__ void scan_body(const SweptParams &P, double *s_dyn, c
     }
 }
 template <int KIND, bool LDS, int WGM = 0>
-__global__ __launch_bounds__(64 * SW_WAVES, WGM ? 4 : 1) void swept_scan_kernel(const SweptParams P) {
+__global__ __launch_bounds__(64 * SW_WAVES, WGM ? ISDF_MESH_WPE : 1) void swept_scan_kernel(const SweptParams P) {
     extern __shared__ double s_dyn[];
     scan_body<KIND, LDS, WGM>(P, s_dyn, (int)blockIdx.x);
 }
@@ -795,7 +798,7 @@ __device__ __forceinline__ void descent_body(const SweptParams &P, double *s_dyn
 }
 
 template <int KIND, bool LDS, int WGM = 0>
-__global__ __launch_bounds__(64 * SW_WAVES, WGM ? 4 : 1) void swept_descent_kernel(const SweptParams P) {
+__global__ __launch_bounds__(64 * SW_WAVES, WGM ? ISDF_MESH_WPE : 1) void swept_descent_kernel(const SweptParams P) {
     extern __shared__ double s_dyn[];
     descent_body<KIND, LDS, WGM>(P, s_dyn, blockIdx.x, gridDim.x);
 }

@@ -431,6 +431,18 @@ class RefWorld:
             self.lib.ref_world_points_in_aabb(self.h, _p(c), C.c_double(half), _p(out), n)
         return out
 
+    def gather_points(self, waypoints, half, offset=(0.0, 0.0, 0.0)):
+        """The reference's own getPointsInAABBOutOfLastOne (PCSmap_manager.h:182-216) driven like plan_manager.cpp:232-251.
+        Returns (ids, xyz) sorted by the reference's voxel id (unifiedID = i + X j + X Y k; the map's own order is unspecified)."""
+        way = np.ascontiguousarray(waypoints, dtype=np.float64).reshape(-1, 3)
+        h3 = np.ascontiguousarray(np.asarray(half, dtype=np.float64) * np.ones(3)); off = np.ascontiguousarray(offset, dtype=np.float64)
+        n = self.lib.ref_world_gather_points(self.h, _p(way), way.shape[0], _p(h3), _p(off), None, None, 0)
+        ids = np.zeros(n, dtype=np.int32); xyz = np.zeros((n, 3))
+        if n:
+            self.lib.ref_world_gather_points(self.h, _p(way), way.shape[0], _p(h3), _p(off), ids.ctypes.data_as(C.c_void_p), _p(xyz), n)
+        order = np.argsort(ids, kind="stable")
+        return ids[order], xyz[order]
+
     def set_points(self, pts):
         pts = np.ascontiguousarray(pts, dtype=np.float64).reshape(-1, 3)
         self.M = pts.shape[0]

@@ -5,7 +5,8 @@
 //   TrajOptimizer       getQuatTransD* back_end_optimizer.hpp:127-173, smoothedL1 :332-356,
 //                       addTimeIntPenaltyParallel :432-554, addSaftyPenaOnSweptVolumeParallel :557-649,
 //                       grad_cost_p :766-824, grad_cost_p_sw :827-866
-//   PCSmapManager       projInMap + getPointsInAABB PCSmap_manager.h:130-170
+//   PCSmapManager       projInMap + getPointsInAABB PCSmap_manager.h:130-170; unifiedID :101-108, getPointsInAABBOutOfLastOne :182-216,
+//                       aabb_points :238 (the obstacle-point set of the swept-volume sweep, driven like plan_manager.cpp:232-251)
 //   GridMap3D           Gridmap3D.cpp:41-258 (isInMap .. isIndexOccupied), generateESDF3d + fillESDF :361-533,
 //                       getGridSDFValue :535-553, trilinear samplers GridMap3D.h:114-195
 // sw_manager.hpp / back_end_optimizer.hpp / PCSmap_manager.h as a whole need ROS, PCL, libigl and yaml, so the Makefile
@@ -17,6 +18,7 @@
 #include <cfloat>
 #include <chrono>
 #include <queue>
+#include <unordered_map>
 #include <cstring>
 #include <ros/ros.h>
 #include <cassert>
@@ -184,6 +186,7 @@ public:
     GridMap3D *occupancy_map = nullptr;
     Vector3d boundary_xyzmin, boundary_xyzmax;
 #include "../_ref/gen/pcsmap.inc"             // PCSmap_manager.h:130-170 projInMap, getPointsInAABB
+#include "../_ref/gen/pcsmap_gather.inc"      // PCSmap_manager.h:101-108 unifiedID, :182-216 getPointsInAABBOutOfLastOne, :238 aabb_points
     static constexpr uint8_t or_mask[8] = {0x80, 0x40, 0x20, 0x10, 0x08, 0x04, 0x02, 0x01};      // PCSmap_manager.h:32
     uint8_t *mk = nullptr;
 #include "../_ref/gen/pcsmap_kernel.inc"      // PCSmap_manager.h:46-78 generateMapKernel
@@ -384,6 +387,27 @@ int ref_world_points_in_aabb(void *h, const double *center, double half, double 
     w->pcs.getPointsInAABB(Vector3d(center[0], center[1], center[2]), half, half, half, pts);
     const int n = (int)pts.size();
     for (int i = 0; i < std::min(n, cap); i++) for (int a = 0; a < 3; a++) out[3 * i + a] = pts[i](a);
+    return n;
+}
+// The obstacle-point set as the planner gathers it (plan_manager.cpp:232-251): aabb_points cleared, then for every waypoint
+// getPointsInAABBOutOfLastOne(wp, previous waypoint (first: (999, 999, 999)), half, offset).  Returns the number of points; ids / xyz
+// (capacity `cap`) receive the map's entries in ITS iteration order (unspecified: callers compare as sets keyed by the voxel id).
+int ref_world_gather_points(void *h, const double *way, int n_way, const double *half, const double *offset, int *ids, double *xyz, int cap) {
+    World *w = (World *)h;
+    PCSmapManager &m = w->pcs;
+    m.aabb_points.clear();
+    const Eigen::Vector3d off(offset[0], offset[1], offset[2]);
+    Eigen::Vector3d tmp_pos(999, 999, 999);
+    for (int i = 0; i < n_way; i++) {
+        const Eigen::Vector3d wp(way[3 * i], way[3 * i + 1], way[3 * i + 2]);
+        m.getPointsInAABBOutOfLastOne(wp, tmp_pos, half[0], half[1], half[2], off);
+        tmp_pos = wp;
+    }
+    int n = 0;
+    for (const auto &pair : m.aabb_points) {
+        if (n < cap) { if (ids) ids[n] = pair.first; if (xyz) for (int a = 0; a < 3; a++) xyz[3 * n + a] = pair.second(a); }
+        n++;
+    }
     return n;
 }
 void ref_world_set_points(void *h, const double *xyz, int M) {

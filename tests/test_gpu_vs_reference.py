@@ -117,3 +117,34 @@ def test_device_callback_vs_reference_pieces(pkg, orc, product_lib, variant):
     g_r = np.concatenate([g_tau, gP.T.reshape(-1)])
     assert abs(cost - total) <= REL_TOL * abs(total), (cost, total)
     assert_close(g, g_r, "g vs reference pieces")
+
+
+@pytest.mark.parametrize("case", ["zero offset", "offset", "at the map's edge"])
+def test_device_gather_points_vs_reference(pkg, orc, product_lib, case):
+    """isdf_gather_points against the reference's OWN getPointsInAABBOutOfLastOne (PCSmap_manager.h:182-216 in libref_sweeps.so, driven like
+    plan_manager.cpp:232-251): the same set of voxel centres, bit for bit; the device orders them by (ix, iy, iz), the reference's
+    unordered_map by nothing in particular - compared after sorting both by the reference's voxel id.  Includes the offset quirk (the
+    offset moves the current waypoint's box only) and corners projected into the map."""
+    _need(orc, orc.REF_SWEEPS)
+    capi = pkg.capi
+    cfg, occ, res, ref, eng = _world(pkg, orc, capi.V1_SWEPT, "RoundedCone", 12)
+    dims = np.array(occ.shape); ext = dims * res
+    rng = np.random.default_rng(77)
+    occ_ijk = np.argwhere(occ)
+    start = (occ_ijk[rng.integers(len(occ_ijk))] + 0.5) * res
+    way = np.cumsum(np.vstack([start[None, :], rng.normal(0, 1.0, (8, 3))]), axis=0).clip(0.05 * ext, 0.95 * ext)
+    half, offset = np.array([1.5, 1.2, 1.0]), None
+    if case == "offset":
+        offset = np.array([0.9, -0.7, 0.6])
+    elif case == "at the map's edge":
+        way[0] = [0.1, 0.2, ext[2] - 0.05]; way[-1] = ext - 0.01; way[4] = [-0.7, ext[1] + 2.0, 0.3]
+        offset = np.array([-0.25, 0.6, 0.0])
+    M = eng.gather_points(way, half, offset)
+    pts = eng.get_points()
+    ids_r, xyz_r = ref.gather_points(way, half, offset if offset is not None else (0, 0, 0))
+    assert M == ids_r.size and M > 5
+    ijk = np.floor(pts / res).astype(np.int64)
+    ids_d = ijk[:, 0] + dims[0] * ijk[:, 1] + dims[0] * dims[1] * ijk[:, 2]
+    order = np.argsort(ids_d, kind="stable")
+    assert np.array_equal(ids_d[order], ids_r.astype(np.int64))
+    assert np.array_equal(pts[order], xyz_r)

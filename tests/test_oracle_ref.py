@@ -467,3 +467,52 @@ def test_sampled_grid_shape_vs_reference_code(pkg, orc):
     print(f"\\nsampled RoundedCone, nres {nres}: max |sdf_grid - sdf| = {np.abs(sa[inside] - st).max():.3e} m, "
           f"max |grad_grid - grad| = {np.linalg.norm(ga[inside] - gt, axis=1).max():.3e}")
     # isdf_set_shape_sampled's host fill (no device needed up to the upload: checked through the oracle-side twin below on the GPU)
+
+
+@pytest.mark.parametrize("case", ["zero offset", "offset", "at the map's edge", "flat boxes"])
+def test_gather_points_vs_reference_code(pkg, orc, case):
+    """The obstacle-point set of the swept-volume sweep: the oracle's restatement (oracle.gather_points) against the reference's OWN
+    getPointsInAABBOutOfLastOne (PCSmap_manager.h:182-216, extracted into libref_sweeps.so) driven like plan_manager.cpp:232-251 - the same
+    SET of voxels (the reference keeps them in an unordered_map: its order is unspecified), the same centres bit for bit, the reference's
+    voxel id = i + X j + X Y k.  The offset quirk is part of it: `offset` moves the CURRENT waypoint's box only, never the previous one's."""
+    capi = pkg.capi
+    cfg, occ, res, shape, ref, o = _ref_world(pkg, orc, capi.V1_SWEPT, seed=12)
+    dims = np.array(occ.shape); ext = dims * res
+    rng = np.random.default_rng(31)
+    n_way = 7
+    # waypoints next to obstacles, a metre or so apart: consecutive boxes overlap
+    occ_ijk = np.argwhere(occ)
+    start = (occ_ijk[rng.integers(len(occ_ijk))] + 0.5) * res
+    way = np.cumsum(np.vstack([start[None, :], rng.normal(0, 1.0, (n_way - 1, 3))]), axis=0).clip(0.05 * ext, 0.95 * ext)
+    half, offset = np.array([1.5, 1.2, 1.0]), np.zeros(3)
+    if case == "offset":
+        offset = np.array([0.9, -0.7, 0.6])
+    elif case == "at the map's edge":
+        way[0] = [0.1, 0.2, ext[2] - 0.05]; way[-1] = ext - 0.01; way[3] = [-0.7, ext[1] + 2.0, 0.3]      # corners projected into the map
+        offset = np.array([-0.25, 0.6, 0.0])
+    elif case == "flat boxes":
+        half = np.array([2.1, 0.3, 0.6])
+    ids_r, xyz_r = ref.gather_points(way, half, offset)
+    want = orc.gather_points(occ, np.zeros(3), ext, res, way, half, offset)
+    assert ids_r.size > 5
+    ijk = np.floor(want / res).astype(np.int64)
+    ids_o = ijk[:, 0] + dims[0] * ijk[:, 1] + dims[0] * dims[1] * ijk[:, 2]
+    order = np.argsort(ids_o, kind="stable")
+    assert np.array_equal(ids_o[order], ids_r.astype(np.int64))
+    assert np.array_equal(want[order], xyz_r)
+    if case == "offset":
+        # the quirk matters on this input: with the offset applied to the previous box as well the set is another one
+        def shifted(prev_also):
+            ids = set()
+            last = np.array([999.0, 999.0, 999.0])
+            for w in way:
+                box = orc.gather_points(occ, np.zeros(3), ext, res, w[None, :], half, offset)
+                lo = np.floor((np.clip(last - half + (offset if prev_also else 0), 0, ext)) / res).astype(int).clip(0, dims - 1)
+                hi = np.floor((np.clip(last + half + (offset if prev_also else 0), 0, ext)) / res).astype(int).clip(0, dims - 1)
+                for p in box:
+                    i = np.floor(p / res).astype(int)
+                    if np.any(i > hi) or np.any(i < lo):
+                        ids.add(tuple(i))
+                last = w
+            return ids
+        assert shifted(False) == set(map(tuple, ijk)) and shifted(True) != shifted(False)
