@@ -67,6 +67,9 @@ struct Batch {
     size_t rs = 0;
     std::vector<double> stage_x, stage_res, ends;
     long long rounds_run = 0, evals_run = 0;
+    isdf_progress_fn progress = nullptr;      // isdf_set_progress (copied from the ctx when the batch starts)
+    void *progress_instance = nullptr;
+    size_t progress_stride = 0;
 };
 
 // the objective of one trajectory; blocks until the coordinator has evaluated the round it joined
@@ -131,6 +134,7 @@ extern "C" int isdf_optimize_lbfgs_batch(isdf_ctx *c, int n_traj, int N, const d
     HIPCHK(c, hipSetDevice(c->device));
     Batch b;
     b.ctx = c; b.n_traj = n_traj; b.N = N; b.n = N + 3 * (N - 1); b.rho = rho;
+    b.progress = c->progress; b.progress_instance = c->progress_instance; b.progress_stride = c->progress_stride;
     b.ostride = isdf_out_stride(N);
     b.workers.resize(n_traj);
     b.submitted.assign(n_traj, 0); b.finished.assign(n_traj, 0); b.ready.assign(n_traj, 0);
@@ -209,6 +213,9 @@ extern "C" int isdf_optimize_lbfgs_batch(isdf_ctx *c, int n_traj, int N, const d
             opt.param.machine_prec = p->machine_prec; opt.param.dir_norm_cap = p->dir_norm_cap;
             opt.evaluate = worker_evaluate;
             opt.instance = &w;
+            // the caller's progress / cancel hook, per trajectory (isdf_set_progress): called on this trajectory's host thread
+            opt.progress = b.progress;
+            opt.progress_instance = b.progress ? (void *)((char *)b.progress_instance + (size_t)t * b.progress_stride) : nullptr;
             w.result = opt.minimize(x_inout + (size_t)t * b.n, b.n);
             std::unique_lock<std::mutex> lk(b.m);
             b.finished[t] = 1;

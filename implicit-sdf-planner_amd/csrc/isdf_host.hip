@@ -1991,8 +1991,8 @@ extern "C" void isdf_lbfgs_params_default(isdf_lbfgs_params *p) {
     p->machine_prec = d.machine_prec; p->dir_norm_cap = d.dir_norm_cap;
 }
 
-extern "C" int isdf_lbfgs_minimize(isdf_evaluate_fn evaluate, void *instance, double *x_inout, int n,
-                                   const isdf_lbfgs_params *p, isdf_lbfgs_result *out) {
+static int lbfgs_run(isdf_evaluate_fn evaluate, void *instance, isdf_progress_fn progress, void *progress_instance, double *x_inout, int n,
+                     const isdf_lbfgs_params *p, isdf_lbfgs_result *out) {
     if (!evaluate || !x_inout || !p || !out) return ISDF_ERR_INVALID_ARG;
     isdf_host::Lbfgs opt;
     opt.param.mem_size = p->mem_size; opt.param.past = p->past; opt.param.max_iterations = p->max_iterations;
@@ -2002,6 +2002,8 @@ extern "C" int isdf_lbfgs_minimize(isdf_evaluate_fn evaluate, void *instance, do
     opt.param.machine_prec = p->machine_prec; opt.param.dir_norm_cap = p->dir_norm_cap;
     opt.evaluate = evaluate;
     opt.instance = instance;
+    opt.progress = progress;                  // (isdf_progress_fn == lbfgs_host's lbfgs_progress_fn: lbfgs_progress_t with plain pointers)
+    opt.progress_instance = progress_instance;
     const auto t0 = std::chrono::steady_clock::now();
     const isdf_host::LbfgsResult r = opt.minimize(x_inout, n);
     const auto t1 = std::chrono::steady_clock::now();
@@ -2010,12 +2012,29 @@ extern "C" int isdf_lbfgs_minimize(isdf_evaluate_fn evaluate, void *instance, do
     return ISDF_OK;
 }
 
+extern "C" int isdf_lbfgs_minimize(isdf_evaluate_fn evaluate, void *instance, double *x_inout, int n,
+                                   const isdf_lbfgs_params *p, isdf_lbfgs_result *out) {
+    return lbfgs_run(evaluate, instance, nullptr, nullptr, x_inout, n, p, out);
+}
+// ... with the reference's progress / cancel callback (lbfgs_optimize's proc_progress, lbfgs.hpp:256-262,480-492): called once per
+// iteration with the SAME instance as evaluate; non-zero return -> status LBFGS_CANCELED (2), x_inout = the iterate it was shown
+extern "C" int isdf_lbfgs_minimize_progress(isdf_evaluate_fn evaluate, isdf_progress_fn progress, void *instance, double *x_inout, int n,
+                                            const isdf_lbfgs_params *p, isdf_lbfgs_result *out) {
+    return lbfgs_run(evaluate, instance, progress, nullptr, x_inout, n, p, out);
+}
+
+extern "C" int isdf_set_progress(isdf_ctx *c, isdf_progress_fn progress, void *instance, size_t batch_instance_stride) {
+    if (!c) return ISDF_ERR_INVALID_ARG;
+    c->progress = progress; c->progress_instance = instance; c->progress_stride = batch_instance_stride;
+    return ISDF_OK;
+}
+
 extern "C" int isdf_optimize_lbfgs(isdf_ctx *c, double *x_inout, int n, const isdf_lbfgs_params *p, isdf_lbfgs_result *out) {
     if (!c) return ISDF_ERR_INVALID_ARG;
     if (!x_inout || !p || !out) return fail(c, ISDF_ERR_INVALID_ARG, "null argument");
     if (!c->have_traj) return fail(c, ISDF_ERR_STATE, "isdf_set_trajectory not called");
     if (n != isdf_num_variables(c)) return fail(c, ISDF_ERR_INVALID_ARG, "n must be N + 3(N-1)");
-    return isdf_lbfgs_minimize(isdf_cost_function_lmbm, c, x_inout, n, p, out);
+    return lbfgs_run(isdf_cost_function_lmbm, c, c->progress, c->progress_instance, x_inout, n, p, out);
 }
 
 // --------------------------------------------------------------------------------------------------------------

@@ -67,6 +67,7 @@ public:
     lbfgs_eval_fn evaluate = nullptr;
     lbfgs_progress_fn progress = nullptr;
     void *instance = nullptr;
+    void *progress_instance = nullptr;      // what `progress` gets (null: `instance`, as in the reference's callback_data_t)
     int evaluations = 0;
 
     // x (n doubles) holds the initial guess on entry and the last accepted iterate on return
@@ -106,7 +107,7 @@ public:
                 xp = x; gp = g;
                 const int ls = line_search(x, fx, g, step, d, xp, gp, param.min_step, param.max_step);
                 if (ls < 0) { x = xp; g = gp; ret = ls; break; }
-                if (progress && progress(instance, x.data(), g.data(), fx, step, k, ls)) { ret = LBFGS_CANCELED; break; }
+                if (progress && progress(progress_instance ? progress_instance : instance, x.data(), g.data(), fx, step, k, ls)) { ret = LBFGS_CANCELED; break; }
                 if (inf_norm(g) / std::max(1.0, inf_norm(x)) < param.g_epsilon) { ret = LBFGS_CONVERGENCE; break; }
                 if (0 < param.past) {
                     if (param.past <= k) {

@@ -35,8 +35,9 @@ def lbfgs_params(lib, **kw):
     return p
 
 
-def lbfgs_minimize(fun, x0, lib=None, **params):
-    """Driver on an arbitrary Python callback fun(x) -> (f, g) (host only; used by the CPU tests)."""
+def lbfgs_minimize(fun, x0, lib=None, progress=None, **params):
+    """Driver on an arbitrary Python callback fun(x) -> (f, g) (host only; used by the CPU tests).
+    progress(x, g, fx, step, k, ls) -> truthy cancels (isdf_lbfgs_minimize_progress: the reference's lbfgs_progress_t)."""
     lib = lib or capi.load_library()
     x = np.ascontiguousarray(x0, dtype=np.float64).copy()
     n = x.size
@@ -49,7 +50,13 @@ def lbfgs_minimize(fun, x0, lib=None, **params):
     cb = capi.EVALUATE_FN(tramp)
     p = lbfgs_params(lib, **params)
     r = capi.IsdfLbfgsResult()
-    rc = lib.isdf_lbfgs_minimize(cb, None, _p(x), n, C.byref(p), C.byref(r))
+    if progress is None:
+        rc = lib.isdf_lbfgs_minimize(cb, None, _p(x), n, C.byref(p), C.byref(r))
+    else:
+        def ptramp(_inst, xp, gp, fx, step, k, ls):
+            return 1 if progress(np.ctypeslib.as_array(xp, shape=(n,)).copy(), np.ctypeslib.as_array(gp, shape=(n,)).copy(), fx, step, k, ls) else 0
+        pcb = capi.PROGRESS_FN(ptramp)
+        rc = lib.isdf_lbfgs_minimize_progress(cb, pcb, None, _p(x), n, C.byref(p), C.byref(r))
     if rc != capi.ISDF_OK:
         raise IsdfError(rc, "isdf_lbfgs_minimize")
     return x, {"f": r.f, "status": r.status, "iterations": r.iterations, "evaluations": r.evaluations, "wall_ms": r.wall_ms}
@@ -383,6 +390,23 @@ class Engine:
         return {"energy": p[0], "swept": p[1], "integral": p[2], "time": p[3]}
 
     # ---- optimizer driver (lbfgs::lbfgs_optimize behind the callback)
+    def set_progress(self, fn, n_traj=1):
+        """fn(traj, x, g, fx, step, k, ls) -> truthy cancels that trajectory (isdf_set_progress; None removes the hook).  In the batch
+        driver the hook runs on the trajectories' host threads: trajectory t's instance is the t-th int of an array (stride 4)."""
+        if fn is None:
+            self._progress_keep = None
+            self._check(self.lib.isdf_set_progress(self.h, None, None, 0))
+            return
+        n = self.num_variables()
+        ids = (C.c_int * max(1, int(n_traj)))(*range(max(1, int(n_traj))))
+
+        def tramp(inst, xp, gp, fx, step, k, ls):
+            t = C.cast(inst, C.POINTER(C.c_int))[0]
+            return 1 if fn(t, np.ctypeslib.as_array(xp, shape=(n,)).copy(), np.ctypeslib.as_array(gp, shape=(n,)).copy(), fx, step, k, ls) else 0
+        cb = capi.PROGRESS_FN(tramp)
+        self._progress_keep = (cb, ids)
+        self._check(self.lib.isdf_set_progress(self.h, C.cast(cb, C.c_void_p), C.cast(ids, C.c_void_p), 4))
+
     def optimize_lbfgs(self, x0, **params):
         """Returns (x, result dict).  params override lbfgs_parameter_t defaults (mem_size, max_iterations, ...)."""
         x = np.ascontiguousarray(x0, dtype=np.float64).copy()

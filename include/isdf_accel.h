@@ -402,6 +402,20 @@ void isdf_lbfgs_params_default(isdf_lbfgs_params *p);
 /* any callback (no device needed) */
 int isdf_lbfgs_minimize(isdf_evaluate_fn evaluate, void *instance, double *x_inout, int n,
                         const isdf_lbfgs_params *p, isdf_lbfgs_result *out);
+/* Progress / cancel hook of the drivers: lbfgs_progress_t (lbfgs.hpp:256-262) with plain pointers - called once per iteration
+ * after the line search with the iterate x, its gradient g (n doubles each), the cost, the accepted step, the iteration count k
+ * and the number of evaluations ls of this line search; a non-zero return cancels the minimisation (status 2 = LBFGS_CANCELED,
+ * x_inout = the iterate the hook was shown).  The reference's callers pass one to stop or watch a run (earlyExit /
+ * earlyexitLmbm, back_end_optimizer.hpp:888-960); LMBM's lmbm_progress_t (lmbm.h:211-213) is its (instance, x, k) subset. */
+typedef int (*isdf_progress_fn)(void *instance, const double *x, const double *g, double fx, double step, int k, int ls);
+/* isdf_lbfgs_minimize with the hook; `instance` goes to both callbacks, like the reference's callback_data_t */
+int isdf_lbfgs_minimize_progress(isdf_evaluate_fn evaluate, isdf_progress_fn progress, void *instance, double *x_inout, int n,
+                                 const isdf_lbfgs_params *p, isdf_lbfgs_result *out);
+/* The hook of the ctx's own drivers (NULL: none).  isdf_optimize_lbfgs calls progress(instance, ...); in
+ * isdf_optimize_lbfgs_batch trajectory t's hook gets (char *)instance + t * batch_instance_stride (stride 0: the same pointer)
+ * and is called on that trajectory's host thread - concurrently with the other trajectories' - so that one trajectory can be
+ * cancelled (its result: status 2) while the rest of the batch runs on. */
+int isdf_set_progress(isdf_ctx *ctx, isdf_progress_fn progress, void *instance, size_t batch_instance_stride);
 /* the ctx's own objective: isdf_cost_function */
 int isdf_optimize_lbfgs(isdf_ctx *ctx, double *x_inout, int n, const isdf_lbfgs_params *p, isdf_lbfgs_result *out);
 

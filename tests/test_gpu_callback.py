@@ -230,6 +230,53 @@ def test_optimize_lbfgs_batch_equals_individual(pkg, orc, product_lib, minco):
     assert ei.value.code == capi.ISDF_ERR_UNSUPPORTED
 
 
+def test_progress_hook_on_the_ctx_drivers(pkg, orc, product_lib):
+    """isdf_set_progress: the reference's callers watch and stop an optimisation through lbfgs_progress_t / lmbm_progress_t
+    (back_end_optimizer.hpp:888-960).  On isdf_optimize_lbfgs the hook sees every iterate and can cancel; in the batch driver ONE
+    trajectory is cancelled at its third iteration (status 2, x = that iterate) while the others run to the end on exactly the
+    iterates they reach without a hook."""
+    capi, synth = pkg.capi, pkg.synth
+    occ, esdf, res = small_world(pkg, seed=16)
+    N = 4
+    shape = synth.make_shape("RoundedCone", params=(0.8, 0.3, 1.6))
+    cfg, eng, _ = _engines(pkg, orc, capi.V3_ESDF_TILE, occ, esdf, res, shape)
+    heads, tails, x0s = [], [], []
+    rho = 5.0
+    for b in range(5):
+        head, tail, way, T0 = _setup(pkg, occ, res, N, 70 + b)
+        eng.set_trajectory(N, head, tail, rho)
+        x0s.append(eng.pack_variables(T0, way)); heads.append(head); tails.append(tail)
+    kw = dict(max_iterations=7, g_epsilon=0.0, past=0)
+    xs0, res0, _ = eng.optimize_lbfgs_batch(N, np.array(heads), np.array(tails), rho, np.array(x0s), **kw)
+    import threading
+    seen, lock = {}, threading.Lock()
+
+    def hook(t, x, g, fx, step, k, ls):
+        with lock:
+            seen.setdefault(t, []).append((k, x.copy(), fx))
+        return t == 2 and k >= 3
+    eng.set_progress(hook, n_traj=5)
+    xs, res1, _ = eng.optimize_lbfgs_batch(N, np.array(heads), np.array(tails), rho, np.array(x0s), **kw)
+    assert sorted(seen) == [0, 1, 2, 3, 4]
+    for t in range(5):
+        ks = [s[0] for s in seen[t]]
+        assert ks == list(range(1, len(ks) + 1))
+        if t == 2:
+            assert res1[t]["status"] == 2 and res1[t]["iterations"] == 3 and np.array_equal(xs[t], seen[t][2][1]) and res1[t]["f"] == seen[t][2][2]
+        else:
+            assert res1[t]["status"] == res0[t]["status"] and res1[t]["f"] == res0[t]["f"] and np.array_equal(xs[t], xs0[t])
+            assert len(ks) == res1[t]["iterations"]
+    # the single-trajectory driver: same hook (instance = trajectory 0's), cancel at k = 2; then the hook removed
+    eng.set_trajectory(N, heads[0], tails[0], rho)
+    seen.clear()
+    eng.set_progress(lambda t, x, g, fx, step, k, ls: k >= 2)
+    x1, r1 = eng.optimize_lbfgs(x0s[0], **kw)
+    assert r1["status"] == 2 and r1["iterations"] == 2
+    eng.set_progress(None)
+    x2, r2 = eng.optimize_lbfgs(x0s[0], **kw)
+    assert r2["status"] == res0[0]["status"] and r2["iterations"] > 2
+
+
 # ---- the callback's MINCO half on the device (csrc/minco_dev.hip) vs the host's band LU (csrc/minco_host.hpp) -----------------
 def _rel_inf(a, b):
     return float(np.abs(np.asarray(a) - np.asarray(b)).max() / max(np.abs(np.asarray(b)).max(), 1e-300))

@@ -67,3 +67,27 @@ def test_status_codes(pkg, product_lib):
     # delta-based stop
     _, res = pkg.lbfgs_minimize(quad, np.ones(4) * 1e-3, lib=product_lib, g_epsilon=0.0, past=2, delta=0.5)
     assert res["status"] == ref.STOP
+
+
+def test_progress_hook_observes_and_cancels(pkg, product_lib):
+    """isdf_lbfgs_minimize_progress: the reference's lbfgs_progress_t (lbfgs.hpp:256-262) - called once per iteration with the iterate,
+    its gradient, the cost, the step, k and the line search's evaluation count; a non-zero return cancels (LBFGS_CANCELED = 2) and
+    leaves the iterate the hook was shown in x.  Without a cancel the run is the run without a hook, iterate for iterate."""
+    ref = _ref()
+    x0 = np.full(6, -0.01)
+    seen = []
+
+    def watch(x, g, fx, step, k, ls):
+        f, gg = rosen(x)
+        assert fx == f and np.array_equal(g, gg) and step > 0 and ls >= 1
+        seen.append((k, x.copy(), fx))
+        return 0
+    xa, ra = pkg.lbfgs_minimize(rosen, x0, lib=product_lib, max_iterations=12, g_epsilon=0.0, past=0)
+    xb, rb = pkg.lbfgs_minimize(rosen, x0, lib=product_lib, progress=watch, max_iterations=12, g_epsilon=0.0, past=0)
+    assert np.array_equal(xa, xb) and ra["f"] == rb["f"] and ra["evaluations"] == rb["evaluations"] and ra["status"] == rb["status"]
+    assert [s[0] for s in seen] == list(range(1, rb["iterations"] + 1))
+    assert all(seen[i + 1][2] <= seen[i][2] for i in range(len(seen) - 1))
+    # cancel at iteration 5: status 2, five iterations, x = the fifth iterate
+    xc, rc = pkg.lbfgs_minimize(rosen, x0, lib=product_lib, progress=lambda x, g, fx, step, k, ls: k >= 5, max_iterations=12, g_epsilon=0.0, past=0)
+    assert rc["status"] == ref.CANCELED == 2 and rc["iterations"] == 5
+    assert np.array_equal(xc, seen[4][1]) and rc["f"] == seen[4][2]
