@@ -16,6 +16,8 @@ struct isdf_ctx {
     // grid
     DevGrid grid{};
     float *d_esdf = nullptr;
+    const double *v1_tstar_stage = nullptr;     // set by the host-direct V1 step for ONE eval_device_impl call (SweptParams::tstar_stage)
+    double *d_esdf_stage = nullptr; size_t esdf_stage_cap = 0;        // isdf_esdf_sample's staging (points | values | gradients): grows only, no allocation per call
     float *d_esdf_bricks = nullptr; size_t bricks_cap = 0; bool bricks_stale = true;     // the ESDF as 2 x 2 x 2-cell bricks with apron, one 128-byte line each (map_build.hip: scattered points)
     uint8_t *d_occ = nullptr;
     unsigned *d_bits = nullptr; size_t bits_cap = 0; bool bits_dirty = true;

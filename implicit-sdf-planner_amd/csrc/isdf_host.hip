@@ -181,7 +181,7 @@ extern "C" int isdf_destroy(isdf_ctx *c) {
     if (c->h_v1_pin) (void)hipHostFree(c->h_v1_pin);
     isdf_frontend_release(c);
     isdf_xchg_release(c);
-    void *ptrs[] = {c->d_cb, c->d_cbdev, c->d_esdf_bricks, c->d_esdf, c->d_occ, c->d_points, c->d_tstar, c->d_acc, c->d_sample_info, c->d_bits, c->d_piece_cost, c->d_in, c->d_out, c->d_stats,
+    void *ptrs[] = {c->d_cb, c->d_cbdev, c->d_esdf_stage, c->d_esdf_bricks, c->d_esdf, c->d_occ, c->d_points, c->d_tstar, c->d_acc, c->d_sample_info, c->d_bits, c->d_piece_cost, c->d_in, c->d_out, c->d_stats,
                     c->d_traj_duration, c->d_coarse_t, c->d_coarse_pose, c->d_n_coarse, c->d_point_partial, c->d_point_piece, c->d_point_stat, c->d_point_nr, c->d_task_buf,
                     c->d_task_map, c->d_v1_words, c->d_point_lmask, c->d_scan_ticks, c->d_scan_order, c->d_hist, c->d_shape_grid, c->d_pose, c->d_mq_entries, c->d_mq_items, c->d_mq_res, c->d_mq_sample_items, c->d_mq_sample_n, c->d_mq_count, c->d_msum_blocks, c->d_dbg, c->d_stage, c->d_stage_flags, c->d_sample_map, c->d_plan_cls, c->d_plan_map, c->d_plan_lr, c->d_plan_hist};
     for (void *p : ptrs) if (p) (void)hipFree(p);
@@ -666,6 +666,8 @@ static int eval_device_impl(isdf_ctx *c, int n_traj, int N, const double *d_T, c
         P.safety_hor = cfg.safety_hor; P.weight_p = cfg.weight_p;
         P.T = d_T; P.coeffs = d_coeffs; P.points = c->d_points;
         P.tstar = (d_tstar && !fixed_tstar) ? d_tstar : c->d_tstar;
+        P.tstar_stage = fixed_tstar ? nullptr : c->v1_tstar_stage;
+        c->v1_tstar_stage = nullptr;
         P.traj_duration = c->d_traj_duration;
         P.max_coarse = 1536;   // traj_duration < 300 s, coarse step 0.2 s -> at most 1501 samples
         if (!c->d_coarse_t) {
@@ -713,7 +715,10 @@ static int eval_device_impl(isdf_ctx *c, int n_traj, int N, const double *d_T, c
         P.scan_ticks = scan_lpt ? c->d_scan_ticks : nullptr; P.scan_order_out = scan_lpt ? c->d_scan_order : nullptr; P.scan_sort_here = (scan_lpt && sort_here) ? 1 : 0;
         const bool order_valid = sort_here || (c->scan_order_b == (long long)b && c->scan_order_e == (long long)e && c->scan_order_epoch == c->points_epoch);
         P.scan_order = (scan_lpt && order_valid) ? c->d_scan_order : nullptr;
-        if (scan_lpt) { c->scan_order_b = sort_here ? -1 : b; c->scan_order_e = sort_here ? -1 : e; c->scan_order_epoch = c->points_epoch; }
+        // (what d_scan_order will hold once this step's launches are QUEUED; until then it counts as unwritten - a failure in between must
+        // not leave the next step scanning through an order nobody wrote)
+        const long long order_b = sort_here ? -1 : b, order_e = sort_here ? -1 : e;
+        if (scan_lpt) { c->scan_order_b = c->scan_order_e = -1; }
         P.direct_records = fixed_tstar ? 1 : 0;
         { int rc2 = ensure(c, &c->d_hist, &c->hist_cap, (size_t)N); if (rc2) return rc2; }
         P.hist = c->d_hist;
@@ -747,6 +752,7 @@ static int eval_device_impl(isdf_ctx *c, int n_traj, int N, const double *d_T, c
         launch_swept_reduce(P, d_out, st);
         if (ev2) { HIPCHK(c, hipEventRecord(ev->d, st)); }
         HIPCHK(c, hipGetLastError());
+        if (scan_lpt) { c->scan_order_b = order_b; c->scan_order_e = order_e; c->scan_order_epoch = c->points_epoch; }
         return ISDF_OK;
     }
 
@@ -1449,11 +1455,14 @@ static bool v1_direct_enabled(const isdf_ctx *c) {
 static int v1_direct_eval(isdf_ctx *c, int n, const double *T, const double *coeffs, double *tstar_inout, const double **h_out, const unsigned long long **h_stat) {
     const size_t in_all = (size_t)19 * n, ostride = isdf_out_stride(n);
     const bool ts = tstar_inout && c->M > 0;
-    int rc = ensure(c, &c->d_in, &c->in_cap, in_all);
+    // d_in: [T | coeffs | lastTstar] - CPU-written, GPU-read only.  (lastTstar does NOT go straight into d_tstar: the GPU itself wrote
+    // that array in the step before, and CPU stores through the BAR into memory the device has written are outside what bar_usable
+    // probes; the prepare kernel copies the staged values over, SweptParams::tstar_stage)
+    int rc = ensure(c, &c->d_in, &c->in_cap, in_all + (size_t)(ts ? c->M : 0));
     if (rc) return rc;
     rc = ensure(c, &c->d_out, &c->out_cap, ostride);
     if (rc) return rc;
-    if (!bar_usable(c, c->d_in, in_all)) return ISDF_DIRECT_NA;
+    if (!bar_usable(c, c->d_in, in_all + (size_t)(ts ? c->M : 0))) return ISDF_DIRECT_NA;
     // pinned, device-mapped: [out | 8 statistics words | flag | lastTstar]
     const size_t need = ostride + 8 + 2 + (size_t)(ts ? c->M : 0);
     if (c->v1_pin_cap < need) {
@@ -1466,9 +1475,10 @@ static int v1_direct_eval(isdf_ctx *c, int n, const double *T, const double *coe
     }
     std::memcpy(c->d_in, T, (size_t)n * sizeof(double));                       // CPU stores into device memory
     std::memcpy(c->d_in + n, coeffs, (size_t)18 * n * sizeof(double));
-    if (ts) std::memcpy(c->d_tstar, tstar_inout, (size_t)c->M * sizeof(double));
+    if (ts) { std::memcpy(c->d_in + in_all, tstar_inout, (size_t)c->M * sizeof(double)); c->v1_tstar_stage = c->d_in + in_all; }
     __sync_synchronize();
     rc = eval_device_impl(c, 1, n, c->d_in, c->d_in + n, c->d_out, ts ? c->d_tstar : nullptr, c->stream, 0);
+    c->v1_tstar_stage = nullptr;
     if (rc) return rc;
     const unsigned long long seq = ++c->dir_seq;
     double *ho = c->h_v1_pin_dev;

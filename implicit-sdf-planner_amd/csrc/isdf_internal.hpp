@@ -123,6 +123,8 @@ struct SweptParams {
     const double *coeffs;       // 6N x 3 col-major
     const double *points;       // M x 3
     double *tstar;              // M (in/out), may be null -> internal scratch
+    const double *tstar_stage;  // host-direct steps: the caller's lastTstar as the CPU stored it (a region the GPU never writes); the prepare
+                                // kernel copies it into tstar.  null: tstar already holds it
     double *traj_duration;      // device scalar: persistent "traj_duration" state (sw_manager.hpp:287-296)
     // per-step scratch
     double *coarse_t;           // [max_coarse]

@@ -438,8 +438,10 @@ static int esdf_sample_host(isdf_ctx *c, const double *xyz, long long n, double 
     if (!c->have_geom || !c->d_esdf) return isdf_fail(c, ISDF_ERR_STATE, "no ESDF grid (isdf_set_grid with ISDF_GRID_ESDF, or isdf_generate_esdf)");
     if (n == 0 || (!value_out && !grad_out)) return ISDF_OK;
     HIPCHK(c, hipSetDevice(c->device));
-    double *d = nullptr;
-    HIPCHK(c, hipMalloc(&d, (size_t)n * 7 * sizeof(double)));
+    // staging in the ctx (grows only): a caller that samples every optimizer step pays no allocation and no implicit device
+    // synchronisation (hipFree) per call
+    { const int rc0 = isdf_ensure_doubles(c, &c->d_esdf_stage, &c->esdf_stage_cap, (size_t)n * 7); if (rc0) return rc0; }
+    double *const d = c->d_esdf_stage;
     double *d_p = d, *d_v = d + (size_t)3 * n, *d_g = d + (size_t)4 * n;
     int rc = ISDF_OK;
     auto chk = [&](hipError_t e, const char *what) { if (e != hipSuccess && rc == ISDF_OK) { c->err = std::string(what) + ": " + hipGetErrorString(e); rc = ISDF_ERR_HIP; } };
@@ -449,7 +451,6 @@ static int esdf_sample_host(isdf_ctx *c, const double *xyz, long long n, double 
     if (rc == ISDF_OK && value_out) chk(hipMemcpyAsync(value_out, d_v, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, c->stream), "download values");
     if (rc == ISDF_OK && grad_out) chk(hipMemcpyAsync(grad_out, d_g, (size_t)3 * n * sizeof(double), hipMemcpyDeviceToHost, c->stream), "download gradients");
     chk(hipStreamSynchronize(c->stream), "esdf_sample sync");
-    (void)hipFree(d);
     return rc;
 }
 

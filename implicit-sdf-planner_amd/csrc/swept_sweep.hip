@@ -110,6 +110,8 @@ __global__ __launch_bounds__(1024) void swept_prepare_kernel(const SweptParams P
     __shared__ int s_n;
     TrajL<LDS> tr{P.T, P.coeffs, P.N};
     if constexpr (LDS) tr = traj_stage(s_dyn, P.T, P.coeffs, P.N);
+    // (host-direct step: lastTstar arrives through a staging region only the CPU writes - read by the back-prop kernel, launches later)
+    if (P.tstar_stage) for (int i = P.point_begin + (int)threadIdx.x; i < P.point_end; i += (int)blockDim.x) P.tstar[i] = P.tstar_stage[i];
     if (threadIdx.x == 0) {
         double td = 0.0;
         for (int i = 0; i < P.N; i++) td += tr.T[i];           // getTotalDuration, trajectory.hpp:457-466

@@ -314,9 +314,16 @@ def test_swept_host_paths_agree_bitwise(pkg, orc, product_lib, monkeypatch):
         path = eng.host_path()
         r2 = eng.eval_single(T * 1.05, cm, tstar=ts)            # lastTstar carried over
         r3 = eng.eval_single(T, cm)                            # no lastTstar array
-        got[name] = (r1, r2, r3, ts.copy(), st, path)
+        # a FRESH lastTstar array after steps in which the device wrote its own: the values the caller passes are the ones used
+        # (host-direct: they travel through a staging region only the CPU writes, never straight into the array the GPU wrote)
+        ts2 = np.full(pts.shape[0], 0.6); ts2[::3] = 0.05
+        r4 = eng.eval_single(T, cm, tstar=ts2)
+        got[name] = (r1, r2, r3, ts.copy(), st, path, r4, ts2.copy())
     d, c = got["direct"], got["copy"]
     assert c[5] == capi.HOST_PATH_COPY and d[5] in (capi.HOST_PATH_DIRECT_BAR, capi.HOST_PATH_COPY)
+    assert d[6][0] == c[6][0] and np.array_equal(d[6][1], c[6][1]) and np.array_equal(d[6][2], c[6][2]) and np.array_equal(d[7], c[7])
+    untouched = d[7] == np.where(np.arange(pts.shape[0]) % 3 == 0, 0.05, 0.6)      # points without an interval keep the caller's value
+    assert untouched.any() and not untouched.all()
     for k in range(3):
         assert d[k][0] == c[k][0] and np.array_equal(d[k][1], c[k][1]) and np.array_equal(d[k][2], c[k][2])
     assert np.array_equal(d[3], c[3]) and d[4] == c[4]
