@@ -7,6 +7,7 @@ import time
 import numpy as np
 
 from .roofline import HBM_PEAK_GBS, ROOT, algorithmic_bytes_per_eval, issue_from_counters, kernel_source_hash, v1_source_hash
+from .meshes import reference_mesh
 from .workloads import build_workload
 
 
@@ -194,8 +195,8 @@ def extra_configs(B):
         meshes = [("concave L prism, 20 faces (synthetic)", synth.l_prism_mesh(), 20, "all"),
                   ("blob, 720 faces (synthetic)", synth.blob_mesh(24, 16, scale=0.9), 5, "all")]
         try:
-            meshes += [("the reference's Lthick.obj, 20 faces, scaled to a 0.83 m bound", synth.reference_mesh("Lthick", 0.83), 20, "all"),
-                       ("the reference's Trefoil.obj, 12 000 faces, scaled to a 0.83 m bound", synth.reference_mesh("Trefoil", 0.83), 3, "all")]
+            meshes += [("the reference's Lthick.obj, 20 faces, scaled to a 0.83 m bound", reference_mesh("Lthick", 0.83), 20, "all"),
+                       ("the reference's Trefoil.obj, 12 000 faces, scaled to a 0.83 m bound", reference_mesh("Trefoil", 0.83), 3, "all")]
         except Exception as e:      # noqa: BLE001
             extra.append({"name": "reference meshes", "error": str(e)})
         for nm, (Vm, Fm), stp, omode in meshes:

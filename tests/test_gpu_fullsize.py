@@ -4,6 +4,8 @@ concave mesh robot on a 512^3 map.  Plus the mesh kind against the oracle at tes
 import numpy as np
 import pytest
 
+from benchlib.meshes import reference_mesh
+
 from common import REL_TOL, assert_close, assert_mesh_v1_free_running, make_pair, small_world, traj
 
 pytestmark = pytest.mark.gpu
@@ -207,7 +209,7 @@ def test_c5_trefoil_512_every_point(pkg, orc, product_lib):
     ext = np.array(occ.shape) * res
     T, Cf = synth.random_trajectory(ext, 20, seed=780, piece_T=1.0, jitter=0.5, margin=4.0, occ=occ, res=res)
     cm = synth.colmajor(Cf)
-    shape = synth.make_mesh_shape(*synth.reference_mesh("Trefoil", 0.83))
+    shape = synth.make_mesh_shape(*reference_mesh("Trefoil", 0.83))
     cfg = synth.default_config(capi.V1_SWEPT, safety_hor=(3 ** 0.5 / 2) * res, weight_p=4000.0)
     eng = pkg.Engine(cfg)
     eng.set_grid(occ, (0, 0, 0), res, capi.GRID_OCCUPANCY)

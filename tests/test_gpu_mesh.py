@@ -4,6 +4,8 @@ from oracle/_ref/libref_fwn.so = the vendored HDK FastWindingNumberForSoups.h): 
 import numpy as np
 import pytest
 
+from benchlib.meshes import reference_mesh
+
 from common import REL_TOL, assert_close, assert_mesh_v1_free_running, make_pair, small_world, traj
 
 pytestmark = pytest.mark.gpu
@@ -115,7 +117,7 @@ def test_reference_meshes_through_the_mesh_kind(pkg, orc, product_lib, stem):
     Generalshape would load them (sw_manager.hpp:255-275 falls through to the mesh class for a stem the registry does not
     know; Shape.cpp:27-151): shape plugin, then the swept-volume sweep with both sides searching their own minimisers."""
     capi, synth = pkg.capi, pkg.synth
-    V, F = synth.reference_mesh(stem, bound_radius=1.66)
+    V, F = reference_mesh(stem, bound_radius=1.66)
     assert len(F) == {"Trefoil": 12000, "Lthick": 20}[stem]
     shape = synth.make_mesh_shape(V, F)
     cfg = synth.default_config()
@@ -317,7 +319,7 @@ def test_mesh_v1_distance_lattice_changes_no_result(pkg, orc, product_lib, monke
     seed_w, seed_t, safety = {"blob 720": (14, 23, 0.5), "blob 168": (14, 29, 0.35), "Trefoil.obj": (16, 31, 0.3)}[case]
     occ, esdf, res = small_world(pkg, seed=seed_w)
     T, cm = traj(pkg, occ, res, N=5, seed=seed_t)
-    if case == "Trefoil.obj": V, F = synth.reference_mesh("Trefoil", 0.83)
+    if case == "Trefoil.obj": V, F = reference_mesh("Trefoil", 0.83)
     elif case == "blob 720": V, F = synth.blob_mesh(24, 16, scale=0.9)
     else: V, F = synth.blob_mesh(12, 8, scale=0.9)
     way = cm.reshape(3, -1).T.reshape(5, 6, 3)[1:, 0, :]

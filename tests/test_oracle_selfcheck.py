@@ -3,6 +3,8 @@ gradient checks of the whole cost, analytic known answers, ESDF == exact EDT, MI
 import numpy as np
 import pytest
 
+from benchlib.meshes import reference_mesh
+
 from common import small_world, traj
 
 
@@ -236,7 +238,7 @@ def test_mesh_closest_point_tree_equals_exhaustive_search(pkg, orc, which, monke
     if which == "blob 720":
         V, F = synth.blob_mesh(24, 16, scale=0.9)
     elif which.startswith("Trefoil"):
-        V, F = synth.reference_mesh("Trefoil", 0.83)
+        V, F = reference_mesh("Trefoil", 0.83)
     else:
         V, F = synth.blob_mesh(12, 8)
         F = np.concatenate([F, F[:40]]).astype(np.int32)          # exact ties between a face and its copy

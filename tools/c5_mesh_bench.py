@@ -6,6 +6,7 @@ import os, sys, time
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import __graft_entry__ as graft
+from benchlib.meshes import reference_mesh
 import torch
 pkg = graft.load_package(); capi, synth = pkg.capi, pkg.synth
 res5 = 0.1
@@ -16,8 +17,8 @@ cm5 = synth.colmajor(Cf5)
 way5 = cm5.reshape(3, -1).T.reshape(20, 6, 3)[1:, 0, :]
 dev = torch.device("cuda", 0); st = torch.cuda.current_stream().cuda_stream
 dT = torch.from_numpy(T5).to(dev); dC = torch.from_numpy(cm5).to(dev)
-meshes = {"lprism": synth.l_prism_mesh, "blob720": lambda: synth.blob_mesh(24, 16, scale=0.9), "lthick": lambda: synth.reference_mesh("Lthick", 0.83),
-          "trefoil": lambda: synth.reference_mesh("Trefoil", 0.83)}
+meshes = {"lprism": synth.l_prism_mesh, "blob720": lambda: synth.blob_mesh(24, 16, scale=0.9), "lthick": lambda: reference_mesh("Lthick", 0.83),
+          "trefoil": lambda: reference_mesh("Trefoil", 0.83)}
 shards = [int(a.split("=")[1]) for a in sys.argv[1:] if a.startswith("--shards=")]
 rank = ([int(a.split("=")[1]) for a in sys.argv[1:] if a.startswith("--rank=")] or [0])[0]
 names = [a for a in sys.argv[1:] if not a.startswith("--")]

@@ -6,6 +6,7 @@ import os, sys
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import __graft_entry__ as graft
+from benchlib.meshes import reference_mesh
 pkg = graft.load_package(); capi, synth = pkg.capi, pkg.synth
 n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 24
 rng = np.random.default_rng(2025)
@@ -21,7 +22,7 @@ for case in range(n_cases):
     kind = case % 3
     if kind == 0: V, F = synth.blob_mesh(24, 16, scale=float(rng.uniform(0.5, 1.1)))
     elif kind == 1: V, F = synth.blob_mesh(12, 8, scale=float(rng.uniform(0.5, 1.1)))
-    else: V, F = synth.reference_mesh("Trefoil", float(rng.uniform(0.5, 1.0)))
+    else: V, F = reference_mesh("Trefoil", float(rng.uniform(0.5, 1.0)))
     safety = float(rng.uniform(0.08, 0.6))
     way = cm.reshape(3, -1).T.reshape(N, 6, 3)[1:, 0, :]
     pts = synth.constraint_points(occ, (0, 0, 0), res, way, half=float(rng.uniform(1.0, 3.0)))

@@ -4,10 +4,11 @@ import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 import __graft_entry__ as graft
+from benchlib.meshes import reference_mesh
 pkg = graft.load_package(); capi, synth = pkg.capi, pkg.synth
 import torch
 occ = synth.random_box_map((64,) * 3, res=0.2, occupancy=0.1, seed=1, edge=(0.4, 2.0))
-for nm, mk in (("blob720", lambda: synth.blob_mesh(24, 16, scale=0.9)), ("blob4992", lambda: synth.blob_mesh(64, 40, scale=0.9)), ("trefoil", lambda: synth.reference_mesh("Trefoil", 0.83)), ("lthick", lambda: synth.reference_mesh("Lthick", 0.83))):
+for nm, mk in (("blob720", lambda: synth.blob_mesh(24, 16, scale=0.9)), ("blob4992", lambda: synth.blob_mesh(64, 40, scale=0.9)), ("trefoil", lambda: reference_mesh("Trefoil", 0.83)), ("lthick", lambda: reference_mesh("Lthick", 0.83))):
     try:
         V, F = mk()
     except Exception as e:

@@ -4,6 +4,7 @@ import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import __graft_entry__ as graft
+from benchlib.meshes import reference_mesh
 import torch  # noqa
 pkg = graft.load_package(); orc = graft.load_oracle(); capi, synth = pkg.capi, pkg.synth
 res = 0.1
@@ -11,7 +12,7 @@ occ = synth.random_box_map((512,) * 3, res=res, occupancy=0.15, seed=12345, edge
 ext = np.array(occ.shape) * res
 T, Cf = synth.random_trajectory(ext, 20, seed=780, piece_T=1.0, jitter=0.5, margin=4.0, occ=occ, res=res)
 cm = synth.colmajor(Cf)
-shape = synth.make_mesh_shape(*synth.reference_mesh("Trefoil", 0.83))
+shape = synth.make_mesh_shape(*reference_mesh("Trefoil", 0.83))
 cfg = synth.default_config(capi.V1_SWEPT, safety_hor=(3 ** 0.5 / 2) * res, weight_p=4000.0)
 eng = pkg.Engine(cfg); eng.set_grid(occ, (0, 0, 0), res, capi.GRID_OCCUPANCY); eng.set_shape(shape)
 way = cm.reshape(3, -1).T.reshape(20, 6, 3)[1:, 0, :]
