@@ -105,7 +105,7 @@ EXPORTED_SYMBOLS = [
     "isdf_shape_from_config",
     "isdf_host_path", "isdf_mesh_atan2f", "isdf_create_multi", "isdf_multi_info", "isdf_set_shape_grid", "isdf_set_shape_sampled",
     "isdf_xchg_create", "isdf_xchg_connect", "isdf_xchg_allreduce", "isdf_xchg_fuse", "isdf_xchg_status", "isdf_xchg_destroy",
-    "isdf_xchg_timeout_ms", "isdf_xchg_set_timeout_ms", "isdf_lbfgs_minimize_progress", "isdf_set_progress",
+    "isdf_xchg_timeout_ms", "isdf_xchg_set_timeout_ms", "isdf_lbfgs_minimize_progress", "isdf_set_progress", "isdf_mesh_info",
 ]
 
 HOST_PATH_COPY, HOST_PATH_DIRECT_MAPPED, HOST_PATH_DIRECT_BAR, HOST_PATH_DEVICE_CALLBACK = 0, 1, 2, 3
@@ -199,6 +199,7 @@ def load_library(path=None):
     lib.isdf_lbfgs_params_default.restype = None
     lib.isdf_lbfgs_minimize.argtypes = [EVALUATE_FN, C.c_void_p, dp, C.c_int, C.POINTER(IsdfLbfgsParams), C.POINTER(IsdfLbfgsResult)]
     lib.isdf_lbfgs_minimize_progress.argtypes = [EVALUATE_FN, PROGRESS_FN, C.c_void_p, dp, C.c_int, C.POINTER(IsdfLbfgsParams), C.POINTER(IsdfLbfgsResult)]
+    lib.isdf_mesh_info.argtypes = [C.c_void_p, C.POINTER(C.c_int)]
     lib.isdf_set_progress.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]
     lib.isdf_optimize_lbfgs_batch.argtypes = [C.c_void_p, C.c_int, C.c_int, dp, dp, C.c_double, dp, C.POINTER(IsdfLbfgsParams),
                                               C.POINTER(IsdfLbfgsResult), dp]

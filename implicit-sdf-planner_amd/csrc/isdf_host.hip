@@ -415,18 +415,39 @@ extern "C" int isdf_set_shape(isdf_ctx *c, const isdf_shape *s) {
                 closed = i + 1 < edges.size() && edges[i].first == edges[i + 1].first && edges[i].second + edges[i + 1].second == 0 &&
                          (i + 2 >= edges.size() || edges[i + 2].first != edges[i].first);
         }
-        if (closed && d.prune_rows && !(getenv("ISDF_NO_F32_FILTER") && getenv("ISDF_NO_F32_FILTER")[0] == '1')) {
+        // ... and the surface must bound a solid: exact winding number 0 / 1 on the two sides of every face (shape_eval.hip:
+        // nested sheets, overlapping or inverted components and tears show up there whatever their thickness)
+        int solid = 0;
+        float s_range[2] = {0.f, 0.f};
+        // (the edge pairing above goes by vertex INDEX: a triangle soup - the reference's Lthick.obj, box.obj, kuang.obj, drone.obj keep
+        // three vertices of their own per face - is "open" to it whatever its geometry.  The exact test below is geometric and catches
+        // open surfaces too (next to a boundary the winding number is a fraction), so it alone decides; `closed` is reported.)
+        const bool want_lattice = d.prune_rows && !(getenv("ISDF_NO_F32_FILTER") && getenv("ISDF_NO_F32_FILTER")[0] == '1');
+        if (want_lattice) {
+            double ext3 = 0.0;
+            for (int a = 0; a < 3; a++) ext3 = std::max(ext3, 2.0 * bb_h[a]);
+            const int rcv = isdf_mesh_surface_valid(c, c->d_mesh_tri, s->n_faces, ext3, &solid);
+            if (rcv) return rcv;
+        }
+        if (want_lattice && solid) {
             // (wide enough for the swept-volume scans' band, 2 safety_hor + 0.1, as well: mesh_lattice_not_below)
             const double margin = 1.05 * std::max(c->cfg.safety_hor, 2.0 * c->cfg.safety_hor + 0.1) + 0.01;
             double llo[3], lhi[3];
             for (int a = 0; a < 3; a++) { llo[a] = (double)d.bbox_lo[a] - margin; lhi[a] = (double)d.bbox_hi[a] + margin; }
             int cells = 96;
             if (const char *e = getenv("ISDF_MESH_LATTICE_CELLS")) { const int v = atoi(e); if (v >= 16 && v <= 256) cells = v; }      // (developer switch)
-            const int rc = isdf_mesh_lattice_build(c, &hm, llo, lhi, cells);
+            const int rc = isdf_mesh_lattice_build(c, &hm, llo, lhi, cells, s_range);
             if (rc) return rc;
             if (hm.dl) { HIPCHK(c, hipMemcpy(c->d_mesh, &hm, sizeof(hm), hipMemcpyHostToDevice)); d.filter_f32 = 1; }
         }
+        {   // isdf_mesh_info
+            int *mi = c->mesh_info;
+            mi[0] = s->n_faces; mi[1] = tree.n_nodes(); mi[2] = depth; mi[3] = d.mesh_wg; mi[4] = closed ? 1 : 0; mi[5] = want_lattice ? solid : -1;
+            mi[6] = hm.dl ? hm.dln[0] : 0; mi[7] = hm.dl ? hm.dln[1] : 0; mi[8] = hm.dl ? hm.dln[2] : 0;
+            mi[9] = (int)std::lround(1.0e6 * s_range[0]); mi[10] = (int)std::lround(1.0e6 * s_range[1]); mi[11] = 0;
+        }
     }
+    if (s->kind != ISDF_SHAPE_MESH) std::memset(c->mesh_info, 0, sizeof(c->mesh_info));
     isdf_frontend_release(c);       // the attitude kernels were voxelised from the previous shape
     c->shape = d;
     c->shape_host = *s;
@@ -1500,6 +1521,12 @@ static int v1_direct_eval(isdf_ctx *c, int n, const double *T, const double *coe
     *h_out = c->h_v1_pin;
     *h_stat = (const unsigned long long *)(c->h_v1_pin + ostride);
     c->last_host_path = ISDF_HOST_PATH_DIRECT_BAR;
+    return ISDF_OK;
+}
+
+extern "C" int isdf_mesh_info(const isdf_ctx *c, int info_out[12]) {
+    if (!c || !info_out) return ISDF_ERR_INVALID_ARG;
+    for (int k = 0; k < 12; k++) info_out[k] = c->mesh_info[k];
     return ISDF_OK;
 }
 

@@ -4,6 +4,7 @@
 // the parity tests) can query the installed shape directly, like the reference's planners and visualisers do.
 #include "isdf_ctx.hpp"
 #include "dev_mesh.hpp"
+#include <cstring>
 
 namespace isdf {
 
@@ -19,10 +20,61 @@ __global__ __launch_bounds__(256) void shape_eval_kernel(DevShape S, const doubl
     }
 }
 
-// the mesh kind's distance lattice (DevMesh::dl): one thread per node, the per-lane walks
-// (flag: raised when a node farther than `clear` from the surface has |1 - 2 w| outside [0.96, 1.04] - a surface covered twice, an
-// inverted one: the assumption the lattice's users make about the winding number does not hold for this mesh, and it gets no lattice)
-__global__ __launch_bounds__(256) void mesh_lattice_kernel(const DevMesh *m, float *out, int nx, int ny, int nz, float mx, float my, float mz, float cell, float clear, unsigned *flag) {
+// ---- What the distance lattice's users assume about a mesh, CHECKED before one is built (Shape.cpp:105-151).
+// sdf = (1 - 2 w) * dist tracks the distance only where the winding number of the surface is 0 outside and 1 inside.  That is a
+// property of the surface, tested here with the EXACT winding number (the sum of all triangles' solid angles in fp64, no hierarchy):
+// a hair off every face, on both sides, at the centroid and (small meshes) next to the three corners,
+//     w(outside) in {0, 1} +- 0.01,   w(inside) in {0, 1} +- 0.01,   w(inside) - w(outside) = +1 +- 0.01.
+// Every region of space the surface bounds touches a face, so a region where w is 2 (a closed sheet inside another one with the
+// same orientation, overlapping components), -1 (an inverted component) or a fraction (an open or torn surface) shows up at the
+// faces that bound it - whatever its thickness; a thin-walled hollow shell (outer sheet outwards, inner sheet inwards) passes, as it
+// should.  flag bit 0: some sample failed.
+__device__ __forceinline__ d3 cross3(d3 a, d3 b) { return mk3(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x); }
+__device__ __forceinline__ double tri_solid_angle_f64(d3 a, d3 b, d3 c) {      // Van Oosterom - Strackee, about the origin
+    const double la = sqrt(dot3(a, a)), lb = sqrt(dot3(b, b)), lc = sqrt(dot3(c, c));
+    const double det = a.x * (b.y * c.z - b.z * c.y) - a.y * (b.x * c.z - b.z * c.x) + a.z * (b.x * c.y - b.y * c.x);
+    const double den = la * lb * lc + dot3(a, b) * lc + dot3(a, c) * lb + dot3(b, c) * la;
+    return 2.0 * atan2(det, den);
+}
+__global__ __launch_bounds__(256) void mesh_validity_kernel(const double *__restrict__ tri, int nF, int samples, double eps, unsigned *flag) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (long long)nF * samples) return;
+    const int f = (int)(i / samples), k = (int)(i % samples);
+    const double *t = tri + (size_t)9 * f;
+    const d3 a = mk3(t[0], t[1], t[2]), b = mk3(t[3], t[4], t[5]), c = mk3(t[6], t[7], t[8]);
+    // barycentric sample: the centroid, then points two thirds of the way to each corner
+    const double wa = k == 0 ? 1.0 / 3 : (k == 1 ? 7.0 / 9 : 1.0 / 9), wb = k == 0 ? 1.0 / 3 : (k == 2 ? 7.0 / 9 : 1.0 / 9), wc = 1.0 - wa - wb;
+    const d3 q = wa * a + wb * b + wc * c;
+    const d3 nr = cross3(b - a, c - a);
+    const double nl = sqrt(dot3(nr, nr));
+    if (!(nl > 0.0)) return;                                       // a degenerate face bounds nothing
+    const d3 n = (1.0 / nl) * nr;
+    // (the offset also stays well inside the face's own extent: a sliver is sampled closer to its plane)
+    const double off = fmin(eps, 1.0e-3 * sqrt(nl));
+    double w[2];
+    for (int side = 0; side < 2; side++) {
+        const d3 p = q + (side ? -off : off) * n;                  // side 0: along the normal (outside of an outward-oriented face)
+        double sum = 0.0;
+        for (int g = 0; g < nF; g++) {
+            const double *u = tri + (size_t)9 * g;
+            sum += tri_solid_angle_f64(mk3(u[0], u[1], u[2]) - p, mk3(u[3], u[4], u[5]) - p, mk3(u[6], u[7], u[8]) - p);
+        }
+        w[side] = sum / (4.0 * 3.14159265358979323846);
+    }
+    auto is01 = [](double v) { return fabs(v) <= 0.01 || fabs(v - 1.0) <= 0.01; };
+    if (!is01(w[0]) || !is01(w[1]) || !(fabs((w[1] - w[0]) - 1.0) <= 0.01)) atomicOr(flag, 1u);
+}
+
+// the mesh kind's distance lattice (DevMesh::dl): one thread per node, the per-lane walks.  The same launch MEASURES what the
+// lattice's users assume about the reference's APPROXIMATE winding number (the order-2 far-field expansion moves it by a few 1e-3):
+// s = 1 - 2 w is sampled at every node, at the centre of the node's cell and at the midpoints of its three edges (the half-spacing
+// lattice but for the face centres: 5 samples per node).  flag bit 0 is raised - and the mesh gets NO lattice - when
+//   |s| > 1.04 at ANY sample (on the surface itself s = 0: no distance condition needed), or
+//   |s| < 0.96 at a sample farther than `clear` from the surface (node: its own distance; the others: the node's distance - clear,
+//   they lie within `clear` of it);
+// the users then work with [0.952, 1.05].  range[0] / range[1]: the smallest / largest |s| seen among the lower-checked samples.
+__global__ __launch_bounds__(256) void mesh_lattice_kernel(const DevMesh *m, float *out, int nx, int ny, int nz, float mx, float my, float mz, float cell, float clear, unsigned *flag,
+                                                           unsigned *range) {
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= (long long)nx * ny * nz) return;
     const int iz = (int)(i % nz), iy = (int)((i / nz) % ny), ix = (int)(i / ((long long)nz * ny));
@@ -34,13 +86,46 @@ __global__ __launch_bounds__(256) void mesh_lattice_kernel(const DevMesh *m, flo
     float f = (float)d;
     if ((double)f > d) f = __int_as_float(__float_as_int(f) - 1);      // (f > d >= 0: the next float towards zero)
     out[i] = s > 0.0 ? f : -f;                   // (the sign BIT says inside: a node on the surface is +0 or -0)
-    if (d > (double)clear && !(fabs(s) >= 0.96 && fabs(s) <= 1.04)) atomicOr(flag, 1u);
+    bool bad = fabs(s) > 1.04 || (d > (double)clear && fabs(s) < 0.96);
+    float lo = 2.0f, hi = 0.0f;
+    if (d > (double)clear) { lo = fminf(lo, (float)fabs(s)); hi = fmaxf(hi, (float)fabs(s)); }
+    const bool lower = d > 2.0 * (double)clear;
+    const double hc = 0.5 * (double)cell;
+    for (int k = 0; k < 4; k++) {                // cell centre, then the midpoints of the edges towards +x, +y, +z
+        const d3 q = mk3(p.x + ((k == 0 || k == 1) ? hc : 0.0), p.y + ((k == 0 || k == 2) ? hc : 0.0), p.z + ((k == 0 || k == 3) ? hc : 0.0));
+        const double sk = 1.0 - 2.0 * ((double)mesh_solid_angle(m, (float)q.x, (float)q.y, (float)q.z) / (4.0 * 3.14159265358979323846));
+        bad = bad || fabs(sk) > 1.04 || (lower && fabs(sk) < 0.96);
+        if (lower) { lo = fminf(lo, (float)fabs(sk)); hi = fmaxf(hi, (float)fabs(sk)); }
+    }
+    if (bad) atomicOr(flag, 1u);
+    if (hi > 0.0f) { atomicMin(&range[0], __float_as_uint(lo)); atomicMax(&range[1], __float_as_uint(hi)); }     // (non-negative floats order like their bits)
 }
 
 }  // namespace isdf
 
-// builds the lattice over `lo .. hi` (body frame) with `n` cells along the longest axis; fills the DevMesh fields (host copy `hm`)
-int isdf_mesh_lattice_build(isdf_ctx *c, isdf::DevMesh *hm, const double lo[3], const double hi[3], int n) {
+// Does the surface bound a solid the way the lattice's users need (mesh_validity_kernel)?  out: 1 yes, 0 no.
+int isdf_mesh_surface_valid(isdf_ctx *c, const double *d_tri, int nF, double extent, int *valid_out) {
+    *valid_out = 0;
+    unsigned *d_flag = nullptr;
+    HIPCHK(c, hipMalloc(&d_flag, sizeof(unsigned)));
+    HIPCHK(c, hipMemsetAsync(d_flag, 0, sizeof(unsigned), c->stream));
+    const int samples = nF <= 4096 ? 4 : 1;            // (the test is quadratic in the faces: the reference's 12 000-face Trefoil.obj takes the centroids)
+    const long long total = (long long)nF * samples;
+    hipLaunchKernelGGL(isdf::mesh_validity_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, c->stream, d_tri, nF, samples, 1.0e-5 * extent, d_flag);
+    unsigned flag = 1;
+    const hipError_t e1 = hipGetLastError();
+    const hipError_t e2 = hipMemcpyAsync(&flag, d_flag, sizeof(unsigned), hipMemcpyDeviceToHost, c->stream);
+    const hipError_t e3 = hipStreamSynchronize(c->stream);
+    (void)hipFree(d_flag);
+    HIPCHK(c, e1); HIPCHK(c, e2); HIPCHK(c, e3);
+    *valid_out = flag ? 0 : 1;
+    return ISDF_OK;
+}
+
+// builds the lattice over `lo .. hi` (body frame) with `n` cells along the longest axis; fills the DevMesh fields (host copy `hm`);
+// s_range_out: the measured range of |1 - 2 w| away from the surface (0, 0: nothing measured)
+int isdf_mesh_lattice_build(isdf_ctx *c, isdf::DevMesh *hm, const double lo[3], const double hi[3], int n, float s_range_out[2]) {
+    s_range_out[0] = s_range_out[1] = 0.f;
     double ext = 0.0;
     for (int a = 0; a < 3; a++) ext = std::max(ext, hi[a] - lo[a]);
     if (!(ext > 0.0) || n < 2) return ISDF_OK;
@@ -48,17 +133,19 @@ int isdf_mesh_lattice_build(isdf_ctx *c, isdf::DevMesh *hm, const double lo[3], 
     int dims[3];
     for (int a = 0; a < 3; a++) dims[a] = (int)std::ceil((hi[a] - lo[a]) / cell) + 1;
     const size_t total = (size_t)dims[0] * dims[1] * dims[2];
-    HIPCHK(c, hipMalloc(&c->d_mesh_dl, (total + 1) * sizeof(float)));      // (+ the flag word)
+    HIPCHK(c, hipMalloc(&c->d_mesh_dl, (total + 3) * sizeof(float)));      // (+ the flag word and the two range words)
     unsigned *d_flag = reinterpret_cast<unsigned *>(c->d_mesh_dl + total);
-    HIPCHK(c, hipMemsetAsync(d_flag, 0, sizeof(unsigned), c->stream));
+    const unsigned init[3] = {0u, 0x7F7FFFFFu, 0u};
+    HIPCHK(c, hipMemcpyAsync(d_flag, init, sizeof(init), hipMemcpyHostToDevice, c->stream));
     const float h = 0.5f * 1.7320508f * cell * 1.001f + 1.0e-5f * (float)ext;      // half a cell diagonal, + the float rounding of positions of this size
     hipLaunchKernelGGL(isdf::mesh_lattice_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, c->stream, c->d_mesh, c->d_mesh_dl, dims[0], dims[1], dims[2],
-                       (float)lo[0], (float)lo[1], (float)lo[2], cell, h, d_flag);
+                       (float)lo[0], (float)lo[1], (float)lo[2], cell, h, d_flag, d_flag + 1);
     HIPCHK(c, hipGetLastError());
-    unsigned flag = 0;
-    HIPCHK(c, hipMemcpyAsync(&flag, d_flag, sizeof(unsigned), hipMemcpyDeviceToHost, c->stream));
+    unsigned back[3] = {1u, 0u, 0u};
+    HIPCHK(c, hipMemcpyAsync(back, d_flag, sizeof(back), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
-    if (flag) { (void)hipFree(c->d_mesh_dl); c->d_mesh_dl = nullptr; return ISDF_OK; }      // not a mesh the lattice's users can reason about
+    if (back[2] != 0u) { std::memcpy(&s_range_out[0], &back[1], 4); std::memcpy(&s_range_out[1], &back[2], 4); }
+    if (back[0]) { (void)hipFree(c->d_mesh_dl); c->d_mesh_dl = nullptr; return ISDF_OK; }      // not a mesh the lattice's users can reason about
     hm->dl = c->d_mesh_dl;
     for (int a = 0; a < 3; a++) { hm->dln[a] = dims[a]; hm->dl_min[a] = (float)lo[a]; }
     hm->dl_inv = 1.0f / cell;

@@ -171,6 +171,17 @@ int isdf_create(isdf_ctx **out, const isdf_config *cfg);
 #define ISDF_MULTI_RCCL 3
 int isdf_create_multi(isdf_ctx **out, const isdf_config *cfg, const int *devices, int n_devices);
 int isdf_multi_info(const isdf_ctx *ctx, int *n_devices_out, int *collective_out);
+/* What isdf_set_shape found and decided about the installed MESH robot (all zero for another kind):
+ *   [0] faces  [1] nodes of the winding-number hierarchy  [2] its depth  [3] 1: one swept-volume task per workgroup (quad walks)
+ *   [4] 1: every edge is shared by two faces with opposite directions (closed, consistently oriented)
+ *   [5] 1: the EXACT winding number is 0 / 1 on the two sides of every face, jump +1 (the surface bounds a solid: no nested sheets
+ *       of one orientation, no overlapping or inverted components, no tears); 0: it is not; -1: not tested (no lattice wanted)
+ *   [6..8] nodes of the distance lattice per axis (0: none - the mesh failed [4], [5] or the measured range below, or
+ *       ISDF_NO_F32_FILTER=1; every query then walks the hierarchy, results are the same bits)
+ *   [9], [10] 1e6 x the smallest / largest |1 - 2 w| the reference's approximate winding number took at the lattice's sample
+ *       points away from the surface (nodes, cell centres, edge midpoints; a lattice is kept only for 0.96 ... 1.04)  [11] 0.
+ * Replaces: nothing (the reference builds its libigl structures without checks, Shape.cpp:60-103). */
+int isdf_mesh_info(const isdf_ctx *ctx, int info_out[12]);
 int isdf_destroy(isdf_ctx *ctx);
 const char *isdf_last_error(const isdf_ctx *ctx);          /* ctx may be NULL: last create() failure      */
 int isdf_abi_version(void);

@@ -1,6 +1,6 @@
 #!/usr/bin/env python
 """Generates tests/golden/ref_meshes.npz: the two robot meshes SURVEY.md 8(d) names for configs[4] - shapes/Trefoil.obj (12 000
-faces) and shapes/Lthick.obj (20 faces, concave) of the reference's src/plan_manager - as the PRODUCT's own reader
+faces) and shapes/Lthick.obj (20 faces, concave) of the reference's src/plan_manager - and its small robot meshes mybox / box / icosahedron / kuang / drone.obj (12-96 faces) - as the PRODUCT's own reader
 (isdf_read_obj = igl::read_triangle_mesh's view of the file) delivers them, untransformed.  They cannot travel to the GPU box
 with /root/reference.  tests/test_fixtures.py holds the reader against an independent parse of the files.
 Run in the build container: python tests/golden/make_golden_meshes.py"""
@@ -16,7 +16,7 @@ import __graft_entry__ as graft  # noqa: E402
 PM = "/root/reference/src/plan_manager"
 fx = graft.load_package().fixtures
 out = {}
-for stem in ("Trefoil", "Lthick"):
+for stem in ("Trefoil", "Lthick", "mybox", "box", "icosahedron", "kuang", "drone"):
     V, F = fx.read_obj(os.path.join(PM, "shapes", stem + ".obj"))
     # independent parse: "v x y z" / "f a b c" lines (both files are plain triangle soups without normals / texture indices)
     Vi, Fi = [], []

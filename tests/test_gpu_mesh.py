@@ -341,3 +341,55 @@ def test_mesh_v1_distance_lattice_changes_no_result(pkg, orc, product_lib, monke
             assert a[0] == b[0] and np.array_equal(a[1], b[1]) and np.array_equal(a[2], b[2]) and np.array_equal(a[3], b[3])
         assert out["0"][1]["grad_pairs"] == out["1"][1]["grad_pairs"] > 0
     monkeypatch.delenv("ISDF_MESH_WG"); monkeypatch.delenv("ISDF_NO_F32_FILTER")
+
+
+ADVERSARIAL = ["thin shell 1 mm", "shell in shell", "shell in shell, 2 mm apart", "two sheets a cell apart", "overlapping boxes", "inverted box", "open box",
+               "mybox.obj", "Lthick.obj x 0.1", "Lthick.obj x 10", "box.obj", "kuang.obj", "drone.obj", "icosahedron.obj"]
+
+
+@pytest.mark.parametrize("name", ADVERSARIAL)
+def test_distance_lattice_on_adversarial_meshes(pkg, orc, product_lib, monkeypatch, name):
+    """The distance lattice rests on two facts about a mesh, both CHECKED by isdf_set_shape before one is built (isdf_mesh_info): the
+    surface bounds a solid (exact winding number 0 / 1 either side of every face) and the reference's approximate winding number stays
+    within 4 % of that at the lattice's nodes, cell centres and edge midpoints.  Meshes that break the first - a closed sheet inside
+    another of the same orientation (also a hair inside it), overlapping bodies (a doubly covered slab thinner than a lattice cell),
+    an inverted body, an open one - get NO lattice; a thin-walled hollow shell, two bodies a lattice cell apart, the reference's own
+    small robot meshes (triangle soups: no shared vertices) and Lthick.obj at a tenth and ten times the bench's scale do.  Either way
+    the swept-volume sweep's t*, cost and gradients are the same BITS with and without it, in every walk form the mesh can take."""
+    from benchlib.meshes import adversarial_mesh
+    capi, synth = pkg.capi, pkg.synth
+    V, F, expect_solid = adversarial_mesh(name)
+    occ, esdf, res = small_world(pkg, seed=14)
+    T, cm = traj(pkg, occ, res, N=5, seed=23)
+    way = cm.reshape(3, -1).T.reshape(5, 6, 3)[1:, 0, :]
+    pts = synth.constraint_points(occ, (0, 0, 0), res, way, half=3.0)
+    if name == "Lthick.obj x 10":
+        pts = pts[::6]                       # (an 8 m robot covers every point of this map: a sixth of them is plenty)
+    infos = {}
+    for wg in ("1", "0"):
+        monkeypatch.setenv("ISDF_MESH_WG", wg)
+        out = {}
+        for off in ("0", "1"):
+            monkeypatch.setenv("ISDF_NO_F32_FILTER", off)
+            cfg1 = synth.default_config(capi.V1_SWEPT, safety_hor=0.3)
+            e1 = pkg.Engine(cfg1); e1.set_grid(occ, (0, 0, 0), res, capi.GRID_OCCUPANCY); e1.set_shape(synth.make_mesh_shape(V, F)); e1.set_points(pts)
+            infos[(wg, off)] = e1.mesh_info()
+            ts = -np.ones(len(pts))
+            steps = []
+            for _ in range(2):
+                c, gT, gC = e1.eval_single(T, cm, tstar=ts)
+                steps.append((c, gT.copy(), gC.copy(), ts.copy()))
+            out[off] = (steps, e1.stats())
+        for a, b in zip(out["0"][0], out["1"][0]):
+            assert a[0] == b[0] and np.array_equal(a[1], b[1]) and np.array_equal(a[2], b[2]) and np.array_equal(a[3], b[3])
+        assert out["0"][1] == out["1"][1]
+    monkeypatch.delenv("ISDF_MESH_WG"); monkeypatch.delenv("ISDF_NO_F32_FILTER")
+    on, off = infos[("1", "0")], infos[("1", "1")]
+    assert off["lattice"] == (0, 0, 0) and off["solid"] == -1
+    if expect_solid is not None:
+        assert on["solid"] == expect_solid, on
+    if on["solid"] == 1:
+        assert min(on["lattice"]) >= 2 and 0.96 <= on["s_range"][0] <= on["s_range"][1] <= 1.04, on
+    else:
+        assert on["lattice"] == (0, 0, 0), on
+    print(f"\nadversarial mesh {name!r}: {on}")
