@@ -15,24 +15,52 @@ namespace isdf {
 
 // struct DevMesh lives in dev_shapes.hpp
 
+// The closest-point arithmetic of the mesh kind is written with EXPLICIT fused multiply-adds, contraction off: every form of the
+// evaluation (per lane, wave-, quad-cooperative, flat) inlines these functions into another context, and where the compiler is free
+// to contract a * b + c * d it may fuse one product in one context and the other elsewhere - on an axis-aligned face (the reference's
+// mybox.obj) that turns an exact zero into +-1e-17, flips the region test below and moves the closest point by an ulp: the forms
+// then disagree in the last bits of the gradient (found by the flat evaluation, round 6).  Written out, every context rounds alike.
+__device__ __forceinline__ double mesh_dot(d3 a, d3 b) {
+#pragma clang fp contract(off)
+    return __builtin_fma(a.x, b.x, __builtin_fma(a.y, b.y, a.z * b.z));
+}
+// a * b - c * d
+__device__ __forceinline__ double mesh_diff2(double a, double b, double c, double d) {
+#pragma clang fp contract(off)
+    return __builtin_fma(a, b, -(c * d));
+}
+__device__ __forceinline__ d3 mesh_axpy(double t, d3 v, d3 a) {      // a + t v
+#pragma clang fp contract(off)
+    return mk3(__builtin_fma(t, v.x, a.x), __builtin_fma(t, v.y, a.y), __builtin_fma(t, v.z, a.z));
+}
 __device__ __forceinline__ d3 closest_on_triangle(d3 p, d3 a, d3 b, d3 c) {
+#pragma clang fp contract(off)
     const d3 ab = b - a, ac = c - a, ap = p - a;
-    const double d1 = dot3(ab, ap), d2 = dot3(ac, ap);
+    const double d1 = mesh_dot(ab, ap), d2 = mesh_dot(ac, ap);
     if (d1 <= 0.0 && d2 <= 0.0) return a;
     const d3 bp = p - b;
-    const double d3_ = dot3(ab, bp), d4 = dot3(ac, bp);
+    const double d3_ = mesh_dot(ab, bp), d4 = mesh_dot(ac, bp);
     if (d3_ >= 0.0 && d4 <= d3_) return b;
-    const double vc = d1 * d4 - d3_ * d2;
-    if (vc <= 0.0 && d1 >= 0.0 && d3_ <= 0.0) return a + (d1 / (d1 - d3_)) * ab;
+    const double vc = mesh_diff2(d1, d4, d3_, d2);
+    if (vc <= 0.0 && d1 >= 0.0 && d3_ <= 0.0) return mesh_axpy(d1 / (d1 - d3_), ab, a);
     const d3 cp = p - c;
-    const double d5 = dot3(ab, cp), d6 = dot3(ac, cp);
+    const double d5 = mesh_dot(ab, cp), d6 = mesh_dot(ac, cp);
     if (d6 >= 0.0 && d5 <= d6) return c;
-    const double vb = d5 * d2 - d1 * d6;
-    if (vb <= 0.0 && d2 >= 0.0 && d6 <= 0.0) return a + (d2 / (d2 - d6)) * ac;
-    const double va = d3_ * d6 - d5 * d4;
-    if (va <= 0.0 && (d4 - d3_) >= 0.0 && (d5 - d6) >= 0.0) return b + ((d4 - d3_) / ((d4 - d3_) + (d5 - d6))) * (c - b);
+    const double vb = mesh_diff2(d5, d2, d1, d6);
+    if (vb <= 0.0 && d2 >= 0.0 && d6 <= 0.0) return mesh_axpy(d2 / (d2 - d6), ac, a);
+    const double va = mesh_diff2(d3_, d6, d5, d4);
+    if (va <= 0.0 && (d4 - d3_) >= 0.0 && (d5 - d6) >= 0.0) return mesh_axpy((d4 - d3_) / ((d4 - d3_) + (d5 - d6)), c - b, b);
     const double denom = 1.0 / (va + vb + vc);
-    return a + (vb * denom) * ab + (vc * denom) * ac;
+    return mesh_axpy(vc * denom, ac, mesh_axpy(vb * denom, ab, a));
+}
+// squared distance p - c and the unit gradient s (p - c) / |.|, the same way in every form
+__device__ __forceinline__ double mesh_dist2(d3 p, d3 c) { const d3 dd = p - c; return mesh_dot(dd, dd); }
+__device__ __forceinline__ d3 mesh_unit(double s, d3 v) {
+#pragma clang fp contract(off)
+    const d3 a = mk3(s * v.x, s * v.y, s * v.z);
+    const double z = mesh_dot(a, a);
+    if (z > 0.0) { const double n = sqrt(z); return mk3(a.x / n, a.y / n, a.z / n); }
+    return a;
 }
 
 
@@ -240,8 +268,7 @@ __device__ inline double mesh_closest(const DevMesh *m, d3 p, d3 &closest, doubl
             if (ci >= 0) {
                 const double *t = m->tri + (size_t)9 * ci;
                 const d3 c = closest_on_triangle(p, mk3(t[0], t[1], t[2]), mk3(t[3], t[4], t[5]), mk3(t[6], t[7], t[8]));
-                const d3 dd = p - c;
-                const double d = dot3(dd, dd);
+                const double d = mesh_dist2(p, c);
                 if (d < best || (d == best && bestf >= 0 && ci < bestf)) { best = d; closest = c; bestf = ci; }      // equal distances: the lower face (every walk form, whatever its order)
             } else {
                 int k = n++;                                       // keep (cid, clb) sorted by decreasing bound
@@ -279,7 +306,7 @@ __device__ inline bool mesh_sdf_grad_below(const DevMesh *m, d3 p, double cap, d
     const double d2 = mesh_closest(m, p, c, cutoff2);
     if (d2 >= cutoff2) return false;
     sdf = s * sqrt(d2);
-    g = normalized3(s * (p - c));
+    g = mesh_unit(s, p - c);
     return true;
 }
 
@@ -291,7 +318,7 @@ __device__ inline double mesh_sdf(const DevMesh *m, d3 p) {
 __device__ inline double mesh_sdf_grad(const DevMesh *m, d3 p, d3 &g) {
     d3 c; double s;
     const double d2 = mesh_query(m, p, c, s);
-    g = normalized3(s * (p - c));
+    g = mesh_unit(s, p - c);
     return s * sqrt(d2);
 }
 
@@ -510,8 +537,7 @@ __device__ inline double mesh_closest_quad(const DevMesh *m, MeshFrames F, d3 p,
         if (act && ci != -1) lb2 = lb2_of(a0, a1);
         if (ci >= 0 && lb2 < best) {                              // my child is a triangle that can still beat the query's best
             const d3 c = closest_on_triangle(p, mk3(u0.x, u0.y, u1.x), mk3(u1.y, u2.x, u2.y), mk3(u3.x, u3.y, u4.x));
-            const d3 dd = p - c;
-            const double d = dot3(dd, dd);
+            const double d = mesh_dist2(p, c);
             if (d < mine || (d == mine && myf >= 0 && ci < myf)) { mine = d; myc = c; myf = ci; }
         }
         best = quad_min(mine);
@@ -624,7 +650,178 @@ __device__ inline bool mesh_sdf_grad_below_quad(const DevMesh *m, MeshFrames F, 
 #endif
     if (!act || d2 >= cutoff2 || d2 <= floor2) return false;
     sdf = s * sqrt(d2);
-    g = normalized3(s * (p - c));
+    g = mesh_unit(s, p - c);
+    return true;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// FLAT evaluation (round 6) for SMALL meshes - the reference's own robots are 12- to 52-face meshes (mybox.obj, Lthick.obj, drone.obj).
+// A walk pays per NODE VISIT: ~770 vector + ~480 scalar instructions of wave-uniform control around the four children of one node,
+// whatever the mesh - 12 nodes for the 20 faces of Lthick.obj, 9 000 instructions per round.  A hierarchy this small fits a table: its
+// (node, child) slots in level order (DevMesh::flat, built by isdf_set_shape).  Lanes 4q .. 4q+3 still work on query q, but sweep a whole
+// LEVEL's slots side by side, four at a time - no frames, no stack, no scalar control per node:
+//   winding number: level by level, every reachable slot's far-field term / descend test (and its triangle's solid angle when a
+//                   triangle is opened); a query's opened slots are one 64-bit mask in a register.  The values are then combined bottom
+//                   up in the hierarchy's own order - A = ((om0 + om1) + om2) + om3 over a node's present children (0 for an opened one),
+//                   D = 0 + value(child) ... in child order over the opened ones, value = opened children ? A + D : A - so w is the
+//                   library's bit for bit, like every other form (mesh_solid_angle).
+//   closest point : every triangle whose box can still beat the query's best, exact in any order, equal distances to the lower face.
+// om: this wavefront's [16 queries][MESH_FLAT_SLOTS] floats in LDS (a quad's lanes exchange slot values through it).
+__device__ __forceinline__ void flat_lds_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+// one slot's term: the far-field approximation of child `rec` (= 4 node + child) seen from q, or - when the child has to be opened - 0,
+// respectively its solid angle if it is a triangle; returns "has to be opened".  The arithmetic of mesh_quad_pre, contraction off.
+__device__ __forceinline__ bool mesh_slot_term(const float *boxq, int rec, bool tri, float qx, float qy, float qz, float acc2, float &omv) {
+#pragma clang fp contract(off)
+    const float4 *r4 = reinterpret_cast<const float4 *>(boxq + (size_t)rec * MESH_Q_REC);
+    const float4 a0 = r4[0], a1 = r4[1], a2 = r4[2], a3 = r4[3], a4 = r4[4], a5 = r4[5];
+    const float rc[24] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w, a2.x, a2.y, a2.z, a2.w,
+                          a3.x, a3.y, a3.z, a3.w, a4.x, a4.y, a4.z, a4.w, a5.x, a5.y, a5.z, 0.f};
+#define RC(i) rc[(i) >> 2]                  /* r[i + l] of the node-major record (mesh_node_pre_t) */
+    float x = qx - RC(4), y = qy - RC(8), z = qz - RC(12);
+    const float ql2 = x * x + y * y + z * z;
+    bool use = false;
+    omv = 0.f;
+    if (!(ql2 <= RC(0) * acc2)) {
+        const float m2 = 1.0f / ql2, m1 = sqrtf(m2);
+        x *= m1; y *= m1; z *= m1;
+        omv = -m2 * (x * RC(16) + y * RC(20) + z * RC(24));
+        const float x2 = x * x, y2 = y * y, z2 = z * z;
+        const float m3 = m2 * m1;
+        omv += m3 * (RC(28) + RC(32) + RC(36)
+                     - 3.0f * ((x2 * RC(28) + y2 * RC(32) + z2 * RC(36)) + x * y * RC(40) + x * z * RC(48) + y * z * RC(44)));
+        const float x3 = x2 * x, y3 = y2 * y, z3 = z2 * z;
+        const float m4 = m2 * m2;
+        const float t0x = RC(80) + RC(84), t0y = RC(88) + RC(68), t0z = RC(72) + RC(76);
+        const float t1x = y * RC(68) + z * RC(72), t1y = z * RC(76) + x * RC(80), t1z = x * RC(84) + y * RC(88);
+        omv += m4 * (1.5f * (x * (3.0f * RC(52) + t0x) + y * (3.0f * RC(56) + t0y) + z * (3.0f * RC(60) + t0z))
+                     - 7.5f * ((x3 * RC(52) + y3 * RC(56) + z3 * RC(60)) + x * y * z * RC(64) + (x2 * t1x + y2 * t1y + z2 * t1z)));
+        use = isfinite(omv);
+    }
+#undef RC
+    if (use) return false;
+    omv = 0.f;
+    if (tri) {                                  // an opened TRIANGLE: its solid angle is the slot's value
+        const float4 t0 = r4[6], t1 = r4[7];
+        const float u[9] = {t0.x, t0.y, t0.z, t0.w, t1.x, t1.y, t1.z, t1.w, boxq[(size_t)rec * MESH_Q_REC + 32]};
+        omv = mesh_tri_solid_angle(u, qx, qy, qz);
+    }
+    return true;
+}
+
+__device__ inline bool mesh_sdf_grad_below_flat(const DevMesh *m, float *om_lds, d3 p, bool act, double cap, double &sdf, d3 &g) {
+    const float acc2 = MESH_FWN_ACCURACY * MESH_FWN_ACCURACY;
+    const int lane = (int)__lane_id(), j = lane & 3, qsh = lane & 60, qd = lane >> 2;
+    if (!__ballot(act)) return false;
+    const mesh_cptr<DevMesh> mu = mesh_const_uni(m);
+    const float *boxq = mu->fwn_boxq;
+    const double *triq = mu->fwn_triq;
+    const mesh_cptr<int> fl = mesh_const_uni(mu->flat);
+    const int n_slots = mu->flat_slots, n_levels = mu->flat_levels, n_tris = fl[18];
+    const int *slots = (const int *)(unsigned long long)(fl + 20), *tris = slots + 4 * n_slots, *nodes = tris + n_tris;
+    float *const om = om_lds + qd * MESH_FLAT_SLOTS;
+    const float qx = (float)p.x, qy = (float)p.y, qz = (float)p.z;
+    // ---- far-field terms, level by level
+    unsigned long long opened = 0ull;              // bit s: slot s is reachable AND has to be opened (the same in the four lanes of a quad)
+    for (int l = 0; l < n_levels; l++) {
+        const int b = fl[l], e = fl[l + 1];
+        for (int s0 = b; s0 < e; s0 += 4) {
+            const int sl = s0 + j;
+            const bool valid = sl < e;
+            const int4 si = *reinterpret_cast<const int4 *>(slots + 4 * (valid ? sl : b));      // record, parent slot, triangle, level
+            const bool reach = act && valid && (si.y < 0 || ((opened >> si.y) & 1ull));
+            bool desc = false;
+            if (__ballot(reach)) {
+                if (reach) {
+                    float omv;
+                    desc = mesh_slot_term(boxq, si.x, si.z >= 0, qx, qy, qz, acc2, omv);
+                    om[sl] = omv;
+                }
+            }
+            opened |= ((__ballot(desc) >> qsh) & 0xFull) << s0;
+        }
+        flat_lds_sync();
+    }
+    // ---- the values, bottom up (a step = the nodes of one level; lane j of the quad takes every fourth of them)
+    float w_root = 0.f;
+    for (int st = 0; st < n_levels; st++) {
+        const int b = fl[9 + st], e = fl[9 + st + 1];
+        for (int n0 = b; n0 < e; n0 += 4) {
+            const int nd = n0 + j;
+            const bool valid = nd < e;
+            const int *ni = nodes + 5 * (valid ? nd : b);
+            const int own = ni[0];
+            if (act && valid && (own < 0 || ((opened >> own) & 1ull))) {
+                float A = 0.f, D = 0.f;
+                bool any = false;
+#pragma unroll
+                for (int c = 0; c < 4; c++) {
+                    const int cs = ni[1 + c];
+                    if (cs < 0) break;                                    // (empty children are last)
+                    const bool dsc = (opened >> cs) & 1ull;
+                    const float v = om[cs];
+                    const float a = dsc ? 0.f : v;
+                    A = c == 0 ? a : A + a;
+                    if (dsc) { D = D + v; any = true; }
+                }
+                const float val = any ? A + D : A;
+                if (own >= 0) om[own] = val; else w_root = val;
+            }
+        }
+        flat_lds_sync();
+    }
+    // (the root is the only node of the last step: lane 0 of the quad holds its value)
+    const float sa = quad_bcast<0>(w_root);
+    const double w = (double)sa / (4.0 * 3.14159265358979323846);
+    const double s = 1. - 2. * w;
+    double cutoff2 = 1.7976931348623157e308, floor2 = -1.0;
+    if (s > 0.0 && cap < 1.0e300) {
+        if (!(cap > 0.0)) act = false;                  // outside and sdf >= 0 >= cap
+        else { const double dc = cap / s; cutoff2 = dc * dc * (1.0 + 1e-12); }
+    } else if (s < 0.0 && cap < 0.0) {
+        const double dc = cap / s;
+        floor2 = dc * dc * (1.0 - 1e-12);
+    }
+    // ---- closest point: lane j takes every fourth triangle
+    double mine = cutoff2, best = cutoff2;
+    int myf = -1;
+    d3 myc = mk3(0, 0, 0);
+    if (__ballot(act)) {
+        for (int k0 = 0; k0 < n_tris; k0 += 4) {
+            const int k = k0 + j;
+            const bool valid = act && k < n_tris;
+            const int sl = tris[valid ? k : 0];
+            const int4 si = *reinterpret_cast<const int4 *>(slots + 4 * sl);
+            const float *rq = boxq + (size_t)si.x * MESH_Q_REC;
+            const float2 b0 = *reinterpret_cast<const float2 *>(rq + 34);
+            const float4 b1 = *reinterpret_cast<const float4 *>(rq + 36);
+            const double ex = fmax(fmax((double)b0.x - p.x, p.x - (double)b1.y), 0.0);
+            const double ey = fmax(fmax((double)b0.y - p.y, p.y - (double)b1.z), 0.0);
+            const double ez = fmax(fmax((double)b1.x - p.z, p.z - (double)b1.w), 0.0);
+            const double lb2 = (ex * ex + ey * ey + ez * ez) * 0.999999999999;
+            if (valid && lb2 < best) {
+                const double *t = triq + (size_t)si.x * MESH_Q_TRI;
+                const d3 c = closest_on_triangle(p, mk3(t[0], t[1], t[2]), mk3(t[3], t[4], t[5]), mk3(t[6], t[7], t[8]));
+                const double d = mesh_dist2(p, c);
+                if (d < mine || (d == mine && myf >= 0 && si.z < myf)) { mine = d; myc = c; myf = si.z; }
+            }
+            best = quad_min(mine);
+        }
+    }
+    best = quad_min(mine);
+    int fkey = (mine == best && myf >= 0) ? myf : 0x7fffffff;                      // equal distances: the lower face
+    fkey = min(fkey, __builtin_amdgcn_mov_dpp(fkey, 0xB1, 0xf, 0xf, false));
+    fkey = min(fkey, __builtin_amdgcn_mov_dpp(fkey, 0x4E, 0xf, 0xf, false));
+    const unsigned hit = (unsigned)((__ballot(mine == best && myf == fkey) >> qsh) & 0xFull);
+    const int src = qsh + (hit ? __ffs((int)hit) - 1 : 0);
+    const double wx = __shfl(myc.x, src, 64), wy = __shfl(myc.y, src, 64), wz = __shfl(myc.z, src, 64);
+    const d3 c = mk3(wx, wy, wz);
+    if (!act || best >= cutoff2 || best <= floor2) return false;
+    sdf = s * sqrt(best);
+    g = mesh_unit(s, p - c);
     return true;
 }
 
@@ -737,8 +934,7 @@ __device__ inline double mesh_closest_wave(const DevMesh *m, d3 p, bool act, d3 
                 if (want) {
                     const mesh_cptr<double> t = tri + (size_t)9 * ci;
                     const d3 c = closest_on_triangle(p, mk3(t[0], t[1], t[2]), mk3(t[3], t[4], t[5]), mk3(t[6], t[7], t[8]));
-                    const d3 dd = p - c;
-                    const double d = dot3(dd, dd);
+                    const double d = mesh_dist2(p, c);
                     if (d < best || (d == best && bestf >= 0 && ci < bestf)) { best = d; closest = c; bestf = ci; }      // equal distances: the lower face (every walk form, whatever its order)
                 }
             } else {
@@ -767,7 +963,7 @@ __device__ inline double mesh_sdf_grad_wave(const DevMesh *m, d3 p, d3 &g) {
     const double s = 1. - 2. * w;
     d3 c = mk3(0, 0, 0);
     const double d2 = mesh_closest_wave(m, p, true, c, 1.7976931348623157e308);
-    g = normalized3(s * (p - c));
+    g = mesh_unit(s, p - c);
     return s * sqrt(d2);
 }
 __device__ inline bool mesh_sdf_grad_below_wave(const DevMesh *m, d3 p, double cap, double &sdf, d3 &g) {
@@ -785,7 +981,7 @@ __device__ inline bool mesh_sdf_grad_below_wave(const DevMesh *m, d3 p, double c
     const double d2 = mesh_closest_wave(m, p, act, c, cutoff2);
     if (!act || d2 >= cutoff2) return false;
     sdf = s * sqrt(d2);
-    g = normalized3(s * (p - c));
+    g = mesh_unit(s, p - c);
     return true;
 }
 

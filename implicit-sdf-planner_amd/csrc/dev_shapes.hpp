@@ -38,7 +38,17 @@ struct DevMesh {
     const float *dl;
     int dln[3];
     float dl_min[3], dl_inv, dl_h;
+    // Small meshes (the reference's own robots: 12-52 faces), FLAT evaluation (dev_mesh.hpp, mesh_sdf_grad_below_flat): the whole hierarchy
+    // as a table of its (node, child) SLOTS in level order, so that the four lanes of a query sweep a level's slots side by side instead
+    // of walking node by node.  flat: [0..8] slot index where level l begins (9 entries, the last = slots), [9..17] the same for the
+    // combine steps over the nodes (deepest level first), [18] triangles, [19] 0, then per slot 4 ints (record = 4 node + child: the index into
+    // fwn_boxq / fwn_triq; parent slot or -1; triangle index or -1; level), per triangle its slot, per node (deepest first) 5 ints
+    // (own slot or -1 for the root; its four child slots or -1).  null: the mesh does not qualify (more than MESH_FLAT_SLOTS slots).
+    const int *flat;
+    int flat_slots, flat_nodes, flat_levels;
 };
+constexpr int MESH_FLAT_SLOTS = 64;        // (node, child) slots a flat-evaluated mesh may have: one bit each in a query's 64-bit "opened" mask
+constexpr int MESH_FLAT_LEVELS = 8;
 
 template <typename T> struct ShapeP {
     T p[16];
@@ -59,6 +69,7 @@ struct DevShape {
     const DevMesh *mesh;
     int mesh_wg;              // 1: the swept-volume kernels give this mesh one task per WORKGROUP (quad-cooperative walks)
     int mesh_levels;          // ... and the levels of walk frames a wavefront needs for it (the hierarchy's depth)
+    int mesh_flat;            // 1: ... as a FLAT evaluation instead (small meshes: DevMesh::flat)
     // ISDF_SHAPE_GRID: num_sdf_map of BasicShape (Shape.hpp:376-404): 4 doubles per node (unit gradient, distance)
     const double *grid;
     int gn[3];

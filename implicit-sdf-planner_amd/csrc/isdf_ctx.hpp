@@ -33,6 +33,7 @@ struct isdf_ctx {
     int *d_fwn_child = nullptr;
     float *d_fwn_box = nullptr, *d_fwn_boxq = nullptr;
     double *d_fwn_triq = nullptr;
+    int *d_mesh_flat = nullptr;          // the flat slot table of a small mesh (DevMesh::flat)
     float *d_mesh_dl = nullptr;          // the mesh kind's distance lattice (DevMesh::dl)
     double *d_shape_grid = nullptr;      // ISDF_SHAPE_GRID: the sampled lattice
     void *d_pose = nullptr; size_t pose_cap = 0;      // pose records of a non-fused integral step (bytes)

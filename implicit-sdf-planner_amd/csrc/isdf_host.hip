@@ -162,6 +162,8 @@ static void free_mesh(isdf_ctx *c) {
     if (c->d_fwn_triq) (void)hipFree(c->d_fwn_triq);
     if (c->d_mesh_dl) (void)hipFree(c->d_mesh_dl);
     c->d_mesh_dl = nullptr;
+    if (c->d_mesh_flat) (void)hipFree(c->d_mesh_flat);
+    c->d_mesh_flat = nullptr;
     c->d_mesh = nullptr; c->d_mesh_tri = nullptr; c->d_mesh_trif = nullptr; c->d_fwn_child = nullptr; c->d_fwn_box = nullptr; c->d_fwn_boxq = nullptr; c->d_fwn_triq = nullptr;
 }
 
@@ -307,6 +309,7 @@ extern "C" int isdf_set_shape(isdf_ctx *c, const isdf_shape *s) {
     d.filter_f32 = (s->kind != ISDF_SHAPE_MESH) && !(getenv("ISDF_NO_F32_FILTER") && getenv("ISDF_NO_F32_FILTER")[0] == '1');
     d.mesh = nullptr;
     d.mesh_wg = 0;
+    d.mesh_flat = 0;
     d.mesh_levels = isdf::MESH_Q_LEVELS;
     if (s->kind == ISDF_SHAPE_MESH) {
         if (!s->mesh_vertices || !s->mesh_faces || s->n_faces < 1 || s->n_vertices < 3) return fail(c, ISDF_ERR_INVALID_ARG, "mesh shape needs vertices and faces");
@@ -387,12 +390,69 @@ extern "C" int isdf_set_shape(isdf_ctx *c, const isdf_shape *s) {
         HIPCHK(c, hipMemcpy(c->d_fwn_boxq, boxq.data(), boxq.size() * sizeof(float), hipMemcpyHostToDevice));
         HIPCHK(c, hipMalloc(&c->d_fwn_triq, triq.size() * sizeof(double)));
         HIPCHK(c, hipMemcpy(c->d_fwn_triq, triq.data(), triq.size() * sizeof(double), hipMemcpyHostToDevice));
-        DevMesh hm{c->d_mesh_tri, c->d_mesh_trif, s->n_faces, c->d_fwn_child, c->d_fwn_box, tree.n_nodes(), c->d_fwn_boxq, c->d_fwn_triq, depth, nullptr, {0, 0, 0}, {0.f, 0.f, 0.f}, 0.f, 0.f};
+        DevMesh hm{c->d_mesh_tri, c->d_mesh_trif, s->n_faces, c->d_fwn_child, c->d_fwn_box, tree.n_nodes(), c->d_fwn_boxq, c->d_fwn_triq, depth, nullptr, {0, 0, 0}, {0.f, 0.f, 0.f}, 0.f, 0.f,
+                   nullptr, 0, 0, 0};
+        // Small meshes: the flat slot table (DevMesh::flat) - levels by breadth-first search from the root
+        {
+            const int nn = tree.n_nodes();
+            std::vector<int> node_level((size_t)nn, -1), node_slot((size_t)nn, -1), order;
+            node_level[0] = 0; order.push_back(0);
+            for (size_t h = 0; h < order.size(); h++) {
+                const int nd = order[h];
+                for (int ch = 0; ch < 4; ch++) {
+                    const int32_t ci = tree.child[(size_t)4 * nd + ch];
+                    if (ci != -1 && ci < 0) { const int sub = ci & 0x7fffffff; if (node_level[sub] < 0) { node_level[sub] = node_level[nd] + 1; order.push_back(sub); } }
+                }
+            }
+            int n_slots = 0;
+            for (int nd = 0; nd < nn; nd++) for (int ch = 0; ch < 4; ch++) if (tree.child[(size_t)4 * nd + ch] != -1) n_slots++;
+            if ((int)order.size() == nn && n_slots <= isdf::MESH_FLAT_SLOTS && depth <= isdf::MESH_FLAT_LEVELS) {
+                // slots in (level of their node, node in search order, child) order
+                std::vector<int> slots, tris, nodes, lvl_begin(9, 0), step_begin(9, 0);
+                int cur_level = -1;
+                for (int nd : order) {
+                    if (node_level[nd] != cur_level) { cur_level = node_level[nd]; lvl_begin[cur_level] = (int)slots.size() / 4; }
+                    for (int ch = 0; ch < 4; ch++) {
+                        const int32_t ci = tree.child[(size_t)4 * nd + ch];
+                        if (ci == -1) continue;
+                        const int sl = (int)slots.size() / 4;
+                        if (ci < 0) node_slot[ci & 0x7fffffff] = sl;
+                        else tris.push_back(sl);
+                        slots.push_back(4 * nd + ch); slots.push_back(node_slot[nd]); slots.push_back(ci >= 0 ? ci : -1); slots.push_back(node_level[nd]);
+                    }
+                }
+                const int n_levels = cur_level + 1;
+                for (int l = n_levels; l < 9; l++) lvl_begin[l] = n_slots;
+                // combine steps: the nodes of the deepest level first; per node its own slot and its four child slots
+                std::vector<std::vector<int>> child_slots((size_t)nn, std::vector<int>(4, -1));
+                for (int sl = 0; sl < n_slots; sl++) { const int rec = slots[(size_t)4 * sl]; child_slots[rec >> 2][rec & 3] = sl; }
+                int step = 0;
+                for (int l = n_levels - 1; l >= 0; l--, step++) {
+                    step_begin[step] = (int)nodes.size() / 5;
+                    for (int nd : order) if (node_level[nd] == l) { nodes.push_back(node_slot[nd]); for (int ch = 0; ch < 4; ch++) nodes.push_back(child_slots[nd][ch]); }
+                }
+                for (int st = step; st < 9; st++) step_begin[st] = nn;
+                std::vector<int> flat;
+                flat.insert(flat.end(), lvl_begin.begin(), lvl_begin.end());
+                flat.insert(flat.end(), step_begin.begin(), step_begin.end());
+                flat.push_back((int)tris.size());
+                flat.push_back(0);                                    // (pad: the slot records start 16-byte aligned)
+                flat.insert(flat.end(), slots.begin(), slots.end());
+                flat.insert(flat.end(), tris.begin(), tris.end());
+                flat.insert(flat.end(), nodes.begin(), nodes.end());
+                HIPCHK(c, hipMalloc(&c->d_mesh_flat, flat.size() * sizeof(int)));
+                HIPCHK(c, hipMemcpy(c->d_mesh_flat, flat.data(), flat.size() * sizeof(int), hipMemcpyHostToDevice));
+                hm.flat = c->d_mesh_flat; hm.flat_slots = n_slots; hm.flat_nodes = nn; hm.flat_levels = n_levels;
+            }
+        }
         // one task per workgroup pays when a pass is long (measured: 20 faces 1.15 -> 1.95 ms, 720 faces faster); ISDF_MESH_WG=0/1 forces
         d.mesh_levels = std::max(2, std::min(depth, isdf::MESH_Q_LEVELS));
         c->mesh_depth = depth;
         d.mesh_wg = (s->n_faces >= 64 && depth <= isdf::MESH_Q_LEVELS) ? 1 : 0;
         if (const char *e = getenv("ISDF_MESH_WG")) d.mesh_wg = (e[0] == '1' && depth <= isdf::MESH_Q_LEVELS) ? 1 : 0;
+        // small meshes: the flat evaluation (one task per workgroup as well); ISDF_MESH_FLAT=0 keeps the walks (A/B runs, tests)
+        d.mesh_flat = hm.flat ? 1 : 0;
+        if (const char *e = getenv("ISDF_MESH_FLAT")) if (e[0] == '0') d.mesh_flat = 0;
         HIPCHK(c, hipMemcpy(c->d_mesh, &hm, sizeof(hm), hipMemcpyHostToDevice));
         d.mesh = c->d_mesh;
         // The tile sweep's pre-filter for this kind: a lattice of distances over the box the row pruning lets voxels come from (the
@@ -444,7 +504,7 @@ extern "C" int isdf_set_shape(isdf_ctx *c, const isdf_shape *s) {
             int *mi = c->mesh_info;
             mi[0] = s->n_faces; mi[1] = tree.n_nodes(); mi[2] = depth; mi[3] = d.mesh_wg; mi[4] = closed ? 1 : 0; mi[5] = want_lattice ? solid : -1;
             mi[6] = hm.dl ? hm.dln[0] : 0; mi[7] = hm.dl ? hm.dln[1] : 0; mi[8] = hm.dl ? hm.dln[2] : 0;
-            mi[9] = (int)std::lround(1.0e6 * s_range[0]); mi[10] = (int)std::lround(1.0e6 * s_range[1]); mi[11] = 0;
+            mi[9] = (int)std::lround(1.0e6 * s_range[0]); mi[10] = (int)std::lround(1.0e6 * s_range[1]); mi[11] = d.mesh_flat ? hm.flat_slots : 0;
         }
     }
     if (s->kind != ISDF_SHAPE_MESH) std::memset(c->mesh_info, 0, sizeof(c->mesh_info));

@@ -204,6 +204,8 @@ struct MeshWG {
 constexpr int MESH_WG_RES = 2 * 64 * 5;
 constexpr int mesh_wg_stage(int nw) { return nw * 64 * 4; }
 // every lane of all four wavefronts calls; returns "sdf < cap proven / evaluated" like mesh_sdf_grad_below (cap = +inf: plain query)
+// FLAT: small meshes - the flat evaluation (dev_mesh.hpp) instead of the walks; X.frames.w is then the wavefront's [16][MESH_FLAT_SLOTS] floats
+template <bool FLAT>
 __device__ inline bool mesh_eval_wg(MeshWG &X, const DevMesh *m, d3 pr, bool act, double cap, double &sdf, d3 &g) {
     const int lane = (int)__lane_id();
     // (a capped query the distance lattice already answers leaves here: fewer queries, fewer rounds)
@@ -229,7 +231,9 @@ __device__ inline bool mesh_eval_wg(MeshWG &X, const DevMesh *m, d3 pr, bool act
         const double qcap = X.stage[4 * rr + 3];                  // (a query's own cap: the lanes of a pass may ask different questions)
         double s2 = 0.0;
         d3 g2 = mk3(0, 0, 0);
-        const bool below = mesh_sdf_grad_below_quad(m, X.frames, qp, on, qcap, s2, g2);
+        bool below;
+        if constexpr (FLAT) below = mesh_sdf_grad_below_flat(m, reinterpret_cast<float *>(X.frames.w), qp, on, qcap, s2, g2);
+        else below = mesh_sdf_grad_below_quad(m, X.frames, qp, on, qcap, s2, g2);
         if (on && (lane & 3) == 0) { double *o = R + 5 * r; o[0] = below ? 1.0 : 0.0; o[1] = s2; o[2] = g2.x; o[3] = g2.y; o[4] = g2.z; }
     }
     __syncthreads();
@@ -244,7 +248,7 @@ __device__ inline bool mesh_eval_wg(MeshWG &X, const DevMesh *m, d3 pr, bool act
 // ---- the ONE pose + SDF evaluation both kernels below are built around: pose at `te`, body-frame point (perturbed for a
 // gradient sample), shape SDF; pose lanes also form the body-frame point velocity (getSDF_DOTAtTimeStampOptimized :593-662).
 // Analytic kinds: called by the lanes that evaluate.  Mesh kind: called by ALL lanes of the workgroup, `act` says which evaluate.
-template <int KIND, bool LDS, bool WG = false, bool CAPPED = false>
+template <int KIND, bool LDS, int WG = 0, bool CAPPED = false>      // WG: 0 per lane / wave-cooperative, 1 workgroup form with the quad walks, 2 ... with the flat evaluation
 __device__ __forceinline__ void eval_lane(const SweptParams &P, const TrajL<LDS> &tr, const d3 p, const double te, const int pert,
                                           const bool pose_lane, const bool own_grad, double &val, d3 &pvel, d3 &g_direct,
                                           MeshWG *X = nullptr, const bool act = true, const double cap = __builtin_inf()) {
@@ -277,11 +281,11 @@ __device__ __forceinline__ void eval_lane(const SweptParams &P, const TrajL<LDS>
         const int a = pert - 7;
         if (a == 0) pr.x += 0.01; else if (a == 1) pr.y += 0.01; else pr.z += 0.01;
     }
-    if constexpr (WG) {
+    if constexpr (WG != 0) {
         // one hierarchy query per evaluating lane gives value AND gradient (the pose lanes keep the gradient)
         d3 gq = mk3(0, 0, 0);
         double v = 1e300;
-        const bool below = mesh_eval_wg(*X, P.shape.mesh, pr, act, cap, v, gq);      // (cap: "sdf >= cap" may be answered without the value)
+        const bool below = mesh_eval_wg<WG == 2>(*X, P.shape.mesh, pr, act, cap, v, gq);      // (cap: "sdf >= cap" may be answered without the value)
         if (act && below) val = v;
         if (act && pose_lane) g_direct = gq;
     } else if constexpr (KIND == ISDF_SHAPE_MESH) {
@@ -306,11 +310,13 @@ __device__ __forceinline__ void eval_lane(const SweptParams &P, const TrajL<LDS>
 // (WGM: at least 4 wavefronts per SIMD - without the cap the compiler spends 450 registers, one workgroup per CU)
 template <int KIND, bool LDS, int WGM>
 __device__ __forceinline__ void scan_body(const SweptParams &P, double *s_dyn, const int block) {
-    constexpr bool MESH = WGM != 0;      // one point per WORKGROUP of WGM wavefronts (mesh_eval_wg above: larger mesh robots), else one per wavefront
+    constexpr bool MESH = WGM != 0;      // one point per WORKGROUP of WGW wavefronts (mesh_eval_wg above: larger mesh robots), else one per wavefront
+    constexpr bool FLAT = WGM == 3;      // ... small meshes: one wavefront, the flat evaluation instead of the walks
+    constexpr int WGW = FLAT ? 1 : WGM, EW = FLAT ? 2 : 1;
     static_assert(!WGM || KIND == ISDF_SHAPE_MESH, "workgroup-cooperative evaluation is the mesh kind's");
     __shared__ double s_rl[SW_WAVES][SW_MAX_RANGES], s_rr[SW_WAVES][SW_MAX_RANGES];
     __shared__ unsigned s_cnt[SW_WAVES][2], s_base[2];
-    __shared__ double s_mesh[MESH ? mesh_wg_stage(WGM) + MESH_WG_RES : 1];
+    __shared__ double s_mesh[MESH ? mesh_wg_stage(WGW) + MESH_WG_RES : 1];
     const unsigned long long dbg_t0 = (ISDF_SWEEP_STATS && P.dbg) ? wall_clock64() : 0ull;
     TrajL<LDS> tr{P.T, P.coeffs, P.N};
     if constexpr (LDS) tr = traj_stage(s_dyn, P.T, P.coeffs, P.N);
@@ -322,8 +328,8 @@ __device__ __forceinline__ void scan_body(const SweptParams &P, double *s_dyn, c
     const int pt = P.point_begin + pt_rel;
     const bool writer = lane == 0 && (!MESH || wave == 0);       // (the four wavefronts of a mesh workgroup hold the same results)
     const int m_lv = MESH ? P.shape.mesh_levels : 1;       // frames: behind the staged trajectory in the dynamic LDS, one set per wavefront
-    MeshWG mwg{s_mesh + wave * 64 * 4, s_mesh + (MESH ? mesh_wg_stage(WGM) : 0), 0, wave,
-               MeshFrames{reinterpret_cast<unsigned *>(reinterpret_cast<char *>(s_dyn) + (LDS ? traj_lds_bytes(P.N) : 0)) + (MESH ? wave * mesh_frames_words(m_lv) : 0), m_lv}, WGM};
+    MeshWG mwg{s_mesh + wave * 64 * 4, s_mesh + (MESH ? mesh_wg_stage(WGW) : 0), 0, wave,
+               MeshFrames{reinterpret_cast<unsigned *>(reinterpret_cast<char *>(s_dyn) + (LDS ? traj_lds_bytes(P.N) : 0)) + (MESH ? wave * mesh_frames_words(m_lv) : 0), m_lv}, WGW};
     int my_nr = 0;
     if (pt < P.point_end) {
     unsigned long long *const dbg = (ISDF_SWEEP_STATS && P.dbg) ? P.dbg + (size_t)pt * 4 : nullptr;
@@ -371,7 +377,7 @@ __device__ __forceinline__ void scan_body(const SweptParams &P, double *s_dyn, c
                 carry_din = (dmask >> 63) & 1ull;
                 d3 g_unused;
                 double sdf = 1e9;
-                if (mesh_eval_wg(mwg, P.shape.mesh, pr, near && !skip, inf, sdf, g_unused)) dis = sdf;
+                if (mesh_eval_wg<FLAT>(mwg, P.shape.mesh, pr, near && !skip, inf, sdf, g_unused)) dis = sdf;
                 if (skip) dis = s_ub;
             } else carry_din = false;
         } else if (near) {
@@ -453,10 +459,10 @@ __device__ __forceinline__ void scan_body(const SweptParams &P, double *s_dyn, c
                 int a_ub;
                 const double ub_min = wave_first_min((act && known) ? s_ub : 1.7976931348623157e308, lane, 64, a_ub);
                 const bool keep = act && !(known && s_lb > ub_min);
-                if constexpr (MESH) eval_lane<KIND, LDS, true>(P, tr, p, te_q, 0, true, true, val, pv_unused, g_unused, &mwg, keep, range_mindis);
-                else if (keep) eval_lane<KIND, LDS, false, true>(P, tr, p, te, 0, false, false, val, pv_unused, g_unused, nullptr, true, range_mindis);
+                if constexpr (MESH) eval_lane<KIND, LDS, EW>(P, tr, p, te_q, 0, true, true, val, pv_unused, g_unused, &mwg, keep, range_mindis);
+                else if (keep) eval_lane<KIND, LDS, 0, true>(P, tr, p, te, 0, false, false, val, pv_unused, g_unused, nullptr, true, range_mindis);
             }
-            else if (act) eval_lane<KIND, LDS, false, false>(P, tr, p, te, 0, false, false, val, pv_unused, g_unused, nullptr, true, range_mindis);
+            else if (act) eval_lane<KIND, LDS, 0, false>(P, tr, p, te, 0, false, false, val, pv_unused, g_unused, nullptr, true, range_mindis);
             n_pass++;
             const int nv = __popcll(__ballot(act));                  // valid lanes form a prefix (t is increasing)
             int arg;
@@ -504,7 +510,7 @@ __device__ __forceinline__ void scan_body(const SweptParams &P, double *s_dyn, c
         __syncthreads();
         if (tid == 0) {
             unsigned tl = 0, ts = 0;
-            for (int w = 0; w < (MESH ? WGM : SW_WAVES); w++) { tl += s_cnt[w][0]; ts += s_cnt[w][1]; }
+            for (int w = 0; w < (MESH ? WGW : SW_WAVES); w++) { tl += s_cnt[w][0]; ts += s_cnt[w][1]; }
             unsigned long long got = 0ull;
             if (tl | ts) got = atomicAdd(reinterpret_cast<unsigned long long *>(P.words), (unsigned long long)tl | ((unsigned long long)ts << 32));
             s_base[0] = (unsigned)got;
@@ -546,16 +552,18 @@ __device__ __forceinline__ int gd_block_base(int m) { return m == 0 ? 18 : 25 + 
 // workgroups do not fit beside each other: 0.43 ms against 0.129 ms for the two launches, profiles/r4_v1_timing_fused_search_dropped.txt.)
 template <int KIND, bool LDS, int WGM>
 __device__ __forceinline__ void descent_body(const SweptParams &P, double *s_dyn, const unsigned block, const unsigned n_blocks) {
-    constexpr bool MESH = WGM != 0;      // one task per WORKGROUP of WGM wavefronts (mesh_eval_wg), else one per wavefront
-    __shared__ double s_mesh[MESH ? mesh_wg_stage(WGM) + MESH_WG_RES : 1];
+    constexpr bool MESH = WGM != 0;      // one task per WORKGROUP of WGW wavefronts (mesh_eval_wg), else one per wavefront
+    constexpr bool FLAT = WGM == 3;
+    constexpr int WGW = FLAT ? 1 : WGM, EW = FLAT ? 2 : 1;
+    __shared__ double s_mesh[MESH ? mesh_wg_stage(WGW) + MESH_WG_RES : 1];
     TrajL<LDS> tr{P.T, P.coeffs, P.N};
     if constexpr (LDS) tr = traj_stage(s_dyn, P.T, P.coeffs, P.N);
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const bool writer = lane == 0 && (!MESH || wave == 0);
     const int m_lv = MESH ? P.shape.mesh_levels : 1;       // frames: behind the staged trajectory in the dynamic LDS, one set per wavefront
-    MeshWG mwg{s_mesh + wave * 64 * 4, s_mesh + (MESH ? mesh_wg_stage(WGM) : 0), 0, wave,
-               MeshFrames{reinterpret_cast<unsigned *>(reinterpret_cast<char *>(s_dyn) + (LDS ? traj_lds_bytes(P.N) : 0)) + (MESH ? wave * mesh_frames_words(m_lv) : 0), m_lv}, WGM};
+    MeshWG mwg{s_mesh + wave * 64 * 4, s_mesh + (MESH ? mesh_wg_stage(WGW) : 0), 0, wave,
+               MeshFrames{reinterpret_cast<unsigned *>(reinterpret_cast<char *>(s_dyn) + (LDS ? traj_lds_bytes(P.N) : 0)) + (MESH ? wave * mesh_frames_words(m_lv) : 0), m_lv}, WGW};
     const unsigned cap = (unsigned)(P.point_end - P.point_begin) * SW_MAX_RANGES;
     const unsigned n_front = (unsigned)__builtin_amdgcn_readfirstlane((int)P.words[0]);
     const unsigned n_tasks = n_front + (unsigned)__builtin_amdgcn_readfirstlane((int)P.words[1]);
@@ -623,7 +631,7 @@ __device__ __forceinline__ void descent_body(const SweptParams &P, double *s_dyn
                 }
                 double val = 1e300;
                 d3 pvel = mk3(0, 0, 0), gq = mk3(0, 0, 0);
-                if constexpr (MESH) eval_lane<KIND, LDS, true>(P, tr, p, te, 0, true, true, val, pvel, gq, &mwg, act, fx);
+                if constexpr (MESH) eval_lane<KIND, LDS, EW>(P, tr, p, te, 0, true, true, val, pvel, gq, &mwg, act, fx);
                 else if (act) eval_lane<KIND, LDS>(P, tr, p, te, 0, true, true, val, pvel, gq, nullptr, true, fx);
                 n_pass++;
                 const double gdot = dot3(gq, pvel);
@@ -689,7 +697,7 @@ __device__ __forceinline__ void descent_body(const SweptParams &P, double *s_dyn
             // (mesh robots: every test below asks "val < f(x)?" of the lanes other than 18 - the halving candidates directly, the look-ahead
             // blocks through a chain of strictly decreasing values that starts at f(x) - and uses a value only when the answer is yes: f(x),
             // once known, is those queries' cutoff in the hierarchy)
-            if constexpr (MESH) eval_lane<KIND, LDS, true>(P, tr, p, act ? te : x, pert, pose_lane, own_grad, val, pvel, g_direct, &mwg, act,
+            if constexpr (MESH) eval_lane<KIND, LDS, EW>(P, tr, p, act ? te : x, pert, pose_lane, own_grad, val, pvel, g_direct, &mwg, act,
                                                            (iter > 0 && lane != 18) ? fx : __builtin_inf());
             else if (act) eval_lane<KIND, LDS>(P, tr, p, te, pert, pose_lane, own_grad, val, pvel, g_direct);
             n_pass++;
@@ -1080,6 +1088,14 @@ void launch_swept_sweep(const SweptParams &P, hipStream_t stream, hipEvent_t ev_
                                                  hipExtLaunchKernelGGL((swept_descent_kernel<K, true>), grid, block, lds, stream, nullptr, ev_stop, 0, P); } \
                                    else { hipExtLaunchKernelGGL((swept_scan_kernel<K, false>), grid, block, 0, stream, ev_start, nullptr, 0, P); \
                                           hipExtLaunchKernelGGL((swept_descent_kernel<K, false>), grid, block, 0, stream, nullptr, ev_stop, 0, P); } break;
+    if (P.shape.kind == ISDF_SHAPE_MESH && P.shape.mesh_flat) {
+        // small meshes: one point / task per one-wavefront workgroup, the flat evaluation; dynamic LDS = the wavefront's [16][64] slot values
+        const dim3 grid1(n);
+        const size_t om = (size_t)16 * MESH_FLAT_SLOTS * sizeof(float);
+        hipExtLaunchKernelGGL((swept_scan_kernel<ISDF_SHAPE_MESH, false, 3>), grid1, dim3(64), om, stream, ev_start, nullptr, 0, P);
+        hipExtLaunchKernelGGL((swept_descent_kernel<ISDF_SHAPE_MESH, false, 3>), grid1, dim3(64), om, stream, nullptr, ev_stop, 0, P);
+        return;
+    }
     if (mesh_wg) {
         // scan: two wavefronts per point (a fine pass has up to 64 queries: two quad rounds each)
         const dim3 block2(128);

@@ -179,7 +179,9 @@ int isdf_multi_info(const isdf_ctx *ctx, int *n_devices_out, int *collective_out
  *   [6..8] nodes of the distance lattice per axis (0: none - the mesh failed [4], [5] or the measured range below, or
  *       ISDF_NO_F32_FILTER=1; every query then walks the hierarchy, results are the same bits)
  *   [9], [10] 1e6 x the smallest / largest |1 - 2 w| the reference's approximate winding number took at the lattice's sample
- *       points away from the surface (nodes, cell centres, edge midpoints; a lattice is kept only for 0.96 ... 1.04)  [11] 0.
+ *       points away from the surface (nodes, cell centres, edge midpoints; a lattice is kept only for 0.96 ... 1.04)
+ *   [11] (node, child) slots of the FLAT evaluation small meshes get in the swept-volume sweep (<= 64 slots: the reference's
+ *       12- to 20-face robots; 0: the hierarchy is walked).
  * Replaces: nothing (the reference builds its libigl structures without checks, Shape.cpp:60-103). */
 int isdf_mesh_info(const isdf_ctx *ctx, int info_out[12]);
 int isdf_destroy(isdf_ctx *ctx);

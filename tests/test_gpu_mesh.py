@@ -366,14 +366,16 @@ def test_distance_lattice_on_adversarial_meshes(pkg, orc, product_lib, monkeypat
     if name == "Lthick.obj x 10":
         pts = pts[::6]                       # (an 8 m robot covers every point of this map: a sixth of them is plenty)
     infos = {}
-    for wg in ("1", "0"):
-        monkeypatch.setenv("ISDF_MESH_WG", wg)
+    across = []
+    # every form of the evaluation the mesh can take: flat (small meshes; ISDF_MESH_FLAT=0 switches it off), quad walks, wave walks
+    for form, flat, wg in (("flat", "1", "1"), ("quad", "0", "1"), ("wave", "0", "0")):
+        monkeypatch.setenv("ISDF_MESH_FLAT", flat); monkeypatch.setenv("ISDF_MESH_WG", wg)
         out = {}
         for off in ("0", "1"):
             monkeypatch.setenv("ISDF_NO_F32_FILTER", off)
             cfg1 = synth.default_config(capi.V1_SWEPT, safety_hor=0.3)
             e1 = pkg.Engine(cfg1); e1.set_grid(occ, (0, 0, 0), res, capi.GRID_OCCUPANCY); e1.set_shape(synth.make_mesh_shape(V, F)); e1.set_points(pts)
-            infos[(wg, off)] = e1.mesh_info()
+            infos[(wg if form != "flat" else "flat", off)] = e1.mesh_info()
             ts = -np.ones(len(pts))
             steps = []
             for _ in range(2):
@@ -381,9 +383,16 @@ def test_distance_lattice_on_adversarial_meshes(pkg, orc, product_lib, monkeypat
                 steps.append((c, gT.copy(), gC.copy(), ts.copy()))
             out[off] = (steps, e1.stats())
         for a, b in zip(out["0"][0], out["1"][0]):
-            assert a[0] == b[0] and np.array_equal(a[1], b[1]) and np.array_equal(a[2], b[2]) and np.array_equal(a[3], b[3])
+            assert a[0] == b[0] and np.array_equal(a[1], b[1]) and np.array_equal(a[2], b[2]) and np.array_equal(a[3], b[3]), form
         assert out["0"][1] == out["1"][1]
-    monkeypatch.delenv("ISDF_MESH_WG"); monkeypatch.delenv("ISDF_NO_F32_FILTER")
+        across.append((form, out["0"]))
+    for form, o in across[1:]:             # ... and the forms agree with each other, bit for bit
+        for a, b in zip(across[0][1][0], o[0]):
+            assert a[0] == b[0] and np.array_equal(a[1], b[1]) and np.array_equal(a[2], b[2]) and np.array_equal(a[3], b[3]), (across[0][0], form)
+        assert across[0][1][1] == o[1]
+    monkeypatch.delenv("ISDF_MESH_WG"); monkeypatch.delenv("ISDF_NO_F32_FILTER"); monkeypatch.delenv("ISDF_MESH_FLAT")
+    small = infos[("flat", "0")]["flat_slots"] > 0
+    assert small == (name in ("mybox.obj", "Lthick.obj x 0.1", "Lthick.obj x 10", "icosahedron.obj")), infos[("flat", "0")]
     on, off = infos[("1", "0")], infos[("1", "1")]
     assert off["lattice"] == (0, 0, 0) and off["solid"] == -1
     if expect_solid is not None:
