@@ -598,9 +598,12 @@ __device__ __forceinline__ bool mesh_lattice_not_below(const DevMesh *m, d3 p, d
     const float v = dl[((size_t)(int)rintf(fx) * n1 + (int)rintf(fy)) * n2 + (int)rintf(fz)];
     const double h = (double)ml->dl_h;
     const bool node_outside = __float_as_int(v) >= 0;                                   // (the sign bit: inside)
-    if (cap > 0.0) return node_outside && ((double)v - h) * 0.952 >= cap * (1.0 + 1e-9);
+    // (a mesh with defect pockets - DevMesh::dl_tau, dl_slack: within dl_tau of the surface a point may sit in a pocket where |sdf| <= dl_slack
+    // whatever the winding number does there.  cap > 0: the point must be farther from the surface than any pocket reaches, or the
+    // pocket's values must lie above the cap as well - they need not; cap < 0: a pocket's value is no deeper than -dl_slack.)
+    if (cap > 0.0) return node_outside && ((double)v - h) * 0.952 >= cap * (1.0 + 1e-9) && ((double)v - h) > (double)ml->dl_tau;
     const double dn = (double)fabsf(v) * (1.0 + 4.0e-6);                                // an upper bound of the node's distance
-    return 1.05 * (dn + h) <= -cap * (1.0 - 1e-9);
+    return 1.05 * (dn + h) <= -cap * (1.0 - 1e-9) && (double)ml->dl_slack <= -cap * (1.0 - 1e-9);
 }
 
 // lb <= sdf(p) <= ub from the lattice under the same two assumptions (false: nothing known - no lattice, or p outside it)
@@ -621,6 +624,8 @@ __device__ __forceinline__ bool mesh_lattice_bounds(const DevMesh *m, d3 p, doub
         if (node_outside) { lb = 0.952 * far; ub = 1.05 * near; }
         else { lb = -1.05 * near; ub = -0.952 * far; }
     } else { lb = -1.05 * near; ub = 1.05 * near; }
+    // defect pockets (DevMesh::dl_tau, dl_slack): a point within dl_tau of the surface may sit in one, with |sdf| <= dl_slack
+    if (!(far > (double)ml->dl_tau)) { lb = fmin(lb, -(double)ml->dl_slack); ub = fmax(ub, (double)ml->dl_slack); }
     return true;
 }
 
@@ -672,11 +677,11 @@ __device__ __forceinline__ void flat_lds_sync() {
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
-// one slot's term: the far-field approximation of child `rec` (= 4 node + child) seen from q, or - when the child has to be opened - 0,
+// one slot's term: the far-field approximation of the (node, child) whose record is rq, seen from q, or - when the child has to be opened - 0,
 // respectively its solid angle if it is a triangle; returns "has to be opened".  The arithmetic of mesh_quad_pre, contraction off.
-__device__ __forceinline__ bool mesh_slot_term(const float *boxq, int rec, bool tri, float qx, float qy, float qz, float acc2, float &omv) {
+__device__ __forceinline__ bool mesh_slot_term(const float *rq, bool tri, float qx, float qy, float qz, float acc2, float &omv) {
 #pragma clang fp contract(off)
-    const float4 *r4 = reinterpret_cast<const float4 *>(boxq + (size_t)rec * MESH_Q_REC);
+    const float4 *r4 = reinterpret_cast<const float4 *>(rq);
     const float4 a0 = r4[0], a1 = r4[1], a2 = r4[2], a3 = r4[3], a4 = r4[4], a5 = r4[5];
     const float rc[24] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w, a2.x, a2.y, a2.z, a2.w,
                           a3.x, a3.y, a3.z, a3.w, a4.x, a4.y, a4.z, a4.w, a5.x, a5.y, a5.z, 0.f};
@@ -706,23 +711,36 @@ __device__ __forceinline__ bool mesh_slot_term(const float *boxq, int rec, bool 
     omv = 0.f;
     if (tri) {                                  // an opened TRIANGLE: its solid angle is the slot's value
         const float4 t0 = r4[6], t1 = r4[7];
-        const float u[9] = {t0.x, t0.y, t0.z, t0.w, t1.x, t1.y, t1.z, t1.w, boxq[(size_t)rec * MESH_Q_REC + 32]};
+        const float u[9] = {t0.x, t0.y, t0.z, t0.w, t1.x, t1.y, t1.z, t1.w, rq[32]};
         omv = mesh_tri_solid_angle(u, qx, qy, qz);
     }
     return true;
 }
 
-__device__ inline bool mesh_sdf_grad_below_flat(const DevMesh *m, float *om_lds, d3 p, bool act, double cap, double &sdf, d3 &g) {
+// F: the workgroup's copy of DevMesh::flat in LDS (tables, records, fp64 triangles) and this wavefront's [16][nsp] slot values
+struct FlatLds { const int *tab; const float *rec; const double *trec; float *om; int n_slots, n_levels, nsp; };
+__device__ __forceinline__ FlatLds flat_lds_view(const DevMesh *m, int *blob, float *om) {
+    const mesh_cptr<DevMesh> mu = mesh_const_uni(m);
+    const int ns = mu->flat_slots;
+    return FlatLds{blob, reinterpret_cast<const float *>(blob + mu->flat_rec), reinterpret_cast<const double *>(blob + mu->flat_trec), om, ns, mu->flat_levels, (ns + 3) & ~3};
+}
+__host__ __device__ constexpr int flat_om_floats(int n_slots) { return 16 * ((n_slots + 3) & ~3); }
+// all threads of the workgroup: the blob into LDS (16 bytes per thread and round)
+__device__ __forceinline__ void flat_lds_stage(const DevMesh *m, int *blob) {
+    const mesh_cptr<DevMesh> mu = mesh_const_uni(m);
+    const int4 *src = reinterpret_cast<const int4 *>(mu->flat);
+    const int n4 = mu->flat_words >> 2;
+    for (int i = threadIdx.x; i < n4; i += blockDim.x) reinterpret_cast<int4 *>(blob)[i] = src[i];
+    __syncthreads();
+}
+__device__ inline bool mesh_sdf_grad_below_flat(const FlatLds &F, d3 p, bool act, double cap, double &sdf, d3 &g) {
     const float acc2 = MESH_FWN_ACCURACY * MESH_FWN_ACCURACY;
     const int lane = (int)__lane_id(), j = lane & 3, qsh = lane & 60, qd = lane >> 2;
     if (!__ballot(act)) return false;
-    const mesh_cptr<DevMesh> mu = mesh_const_uni(m);
-    const float *boxq = mu->fwn_boxq;
-    const double *triq = mu->fwn_triq;
-    const mesh_cptr<int> fl = mesh_const_uni(mu->flat);
-    const int n_slots = mu->flat_slots, n_levels = mu->flat_levels, n_tris = fl[18];
-    const int *slots = (const int *)(unsigned long long)(fl + 20), *tris = slots + 4 * n_slots, *nodes = tris + n_tris;
-    float *const om = om_lds + qd * MESH_FLAT_SLOTS;
+    const int *fl = F.tab;
+    const int n_slots = F.n_slots, n_levels = F.n_levels, n_tris = fl[18];
+    const int *slots = fl + 20, *tris = slots + 4 * n_slots, *nodes = tris + n_tris;
+    float *const om = F.om + qd * F.nsp;
     const float qx = (float)p.x, qy = (float)p.y, qz = (float)p.z;
     // ---- far-field terms, level by level
     unsigned long long opened = 0ull;              // bit s: slot s is reachable AND has to be opened (the same in the four lanes of a quad)
@@ -737,7 +755,7 @@ __device__ inline bool mesh_sdf_grad_below_flat(const DevMesh *m, float *om_lds,
             if (__ballot(reach)) {
                 if (reach) {
                     float omv;
-                    desc = mesh_slot_term(boxq, si.x, si.z >= 0, qx, qy, qz, acc2, omv);
+                    desc = mesh_slot_term(F.rec + sl * MESH_Q_REC, si.z >= 0, qx, qy, qz, acc2, omv);
                     om[sl] = omv;
                 }
             }
@@ -795,7 +813,7 @@ __device__ inline bool mesh_sdf_grad_below_flat(const DevMesh *m, float *om_lds,
             const bool valid = act && k < n_tris;
             const int sl = tris[valid ? k : 0];
             const int4 si = *reinterpret_cast<const int4 *>(slots + 4 * sl);
-            const float *rq = boxq + (size_t)si.x * MESH_Q_REC;
+            const float *rq = F.rec + sl * MESH_Q_REC;
             const float2 b0 = *reinterpret_cast<const float2 *>(rq + 34);
             const float4 b1 = *reinterpret_cast<const float4 *>(rq + 36);
             const double ex = fmax(fmax((double)b0.x - p.x, p.x - (double)b1.y), 0.0);
@@ -803,7 +821,7 @@ __device__ inline bool mesh_sdf_grad_below_flat(const DevMesh *m, float *om_lds,
             const double ez = fmax(fmax((double)b1.x - p.z, p.z - (double)b1.w), 0.0);
             const double lb2 = (ex * ex + ey * ey + ez * ez) * 0.999999999999;
             if (valid && lb2 < best) {
-                const double *t = triq + (size_t)si.x * MESH_Q_TRI;
+                const double *t = F.trec + sl * MESH_Q_TRI;
                 const d3 c = closest_on_triangle(p, mk3(t[0], t[1], t[2]), mk3(t[3], t[4], t[5]), mk3(t[6], t[7], t[8]));
                 const double d = mesh_dist2(p, c);
                 if (d < mine || (d == mine && myf >= 0 && si.z < myf)) { mine = d; myc = c; myf = si.z; }

@@ -38,14 +38,21 @@ struct DevMesh {
     const float *dl;
     int dln[3];
     float dl_min[3], dl_inv, dl_h;
+    // defects (shape_eval.hip, mesh_validity_kernel): within dl_tau of the surface a pocket may exist in which |1 - 2 w| is not ~1;
+    // a point in one has |sdf| <= dl_slack (= 1.05 x the largest |1 - 2 w| seen in a pocket x dl_tau).  0, 0 for a clean mesh.
+    float dl_tau, dl_slack;
     // Small meshes (the reference's own robots: 12-52 faces), FLAT evaluation (dev_mesh.hpp, mesh_sdf_grad_below_flat): the whole hierarchy
     // as a table of its (node, child) SLOTS in level order, so that the four lanes of a query sweep a level's slots side by side instead
     // of walking node by node.  flat: [0..8] slot index where level l begins (9 entries, the last = slots), [9..17] the same for the
     // combine steps over the nodes (deepest level first), [18] triangles, [19] 0, then per slot 4 ints (record = 4 node + child: the index into
     // fwn_boxq / fwn_triq; parent slot or -1; triangle index or -1; level), per triangle its slot, per node (deepest first) 5 ints
     // (own slot or -1 for the root; its four child slots or -1).  null: the mesh does not qualify (more than MESH_FLAT_SLOTS slots).
+    // Behind the tables, in the same allocation: the slots' records (flat_rec, in 4-byte units from `flat`: MESH_Q_REC floats per slot, the
+    // fwn_boxq record of the slot's (node, child)) and their fp64 triangles (flat_trec: MESH_Q_TRI doubles per slot).  The swept-volume
+    // kernels copy the whole blob (flat_words 4-byte words, a multiple of 4) into LDS once per workgroup.
     const int *flat;
     int flat_slots, flat_nodes, flat_levels;
+    int flat_words, flat_rec, flat_trec;
 };
 constexpr int MESH_FLAT_SLOTS = 64;        // (node, child) slots a flat-evaluated mesh may have: one bit each in a query's 64-bit "opened" mask
 constexpr int MESH_FLAT_LEVELS = 8;
@@ -70,6 +77,7 @@ struct DevShape {
     int mesh_wg;              // 1: the swept-volume kernels give this mesh one task per WORKGROUP (quad-cooperative walks)
     int mesh_levels;          // ... and the levels of walk frames a wavefront needs for it (the hierarchy's depth)
     int mesh_flat;            // 1: ... as a FLAT evaluation instead (small meshes: DevMesh::flat)
+    int mesh_flat_words, mesh_flat_slots;      // ... the size of its table blob (4-byte words) and its slot count (launch-time LDS sizing)
     // ISDF_SHAPE_GRID: num_sdf_map of BasicShape (Shape.hpp:376-404): 4 doubles per node (unit gradient, distance)
     const double *grid;
     int gn[3];

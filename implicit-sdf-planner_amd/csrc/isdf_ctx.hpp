@@ -16,7 +16,7 @@ struct isdf_ctx {
     // grid
     DevGrid grid{};
     float *d_esdf = nullptr;
-    int mesh_info[12] = {0};                    // isdf_mesh_info: what isdf_set_shape found and decided about the installed mesh
+    int mesh_info[16] = {0};                    // isdf_mesh_info: what isdf_set_shape found and decided about the installed mesh
     const double *v1_tstar_stage = nullptr;     // set by the host-direct V1 step for ONE eval_device_impl call (SweptParams::tstar_stage)
     double *d_esdf_stage = nullptr; size_t esdf_stage_cap = 0;        // isdf_esdf_sample's staging (points | values | gradients): grows only, no allocation per call
     float *d_esdf_bricks = nullptr; size_t bricks_cap = 0; bool bricks_stale = true;     // the ESDF as 2 x 2 x 2-cell bricks with apron, one 128-byte line each (map_build.hip: scattered points)
@@ -155,7 +155,7 @@ int isdf_reset_result_slots(isdf_ctx *c); // isdf_host.hip: drains the device an
 void isdf_xchg_release(isdf_ctx *c);          // xchg.hip: closes the peer mappings, frees the mailbox (isdf_destroy)
 void isdf_frontend_release(isdf_ctx *c);      // frontend.hip: frees the tables (isdf_destroy)
 int isdf_mesh_lattice_build(isdf_ctx *c, isdf::DevMesh *hm, const double lo[3], const double hi[3], int n, float s_range_out[2]);
-int isdf_mesh_surface_valid(isdf_ctx *c, const double *d_tri, int nF, double extent, int *valid_out);      // shape_eval.hip: exact winding number 0 / 1 on both sides of every face      // shape_eval.hip: the mesh kind's distance lattice (DevMesh::dl)
+int isdf_mesh_surface_valid(isdf_ctx *c, const double *d_tri, int nF, double extent, double tau_limit, int *valid_out, float defect_out[2]);      // shape_eval.hip: exact winding number 0 / 1 on both sides of every face      // shape_eval.hip: the mesh kind's distance lattice (DevMesh::dl)
 
 // every setter of once-per-plan state ends with this: the same call on every owned peer ctx (isdf_create_multi)
 #define ISDF_REPLICATE(ctx, call)                                                                  \

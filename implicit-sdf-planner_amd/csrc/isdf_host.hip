@@ -309,7 +309,7 @@ extern "C" int isdf_set_shape(isdf_ctx *c, const isdf_shape *s) {
     d.filter_f32 = (s->kind != ISDF_SHAPE_MESH) && !(getenv("ISDF_NO_F32_FILTER") && getenv("ISDF_NO_F32_FILTER")[0] == '1');
     d.mesh = nullptr;
     d.mesh_wg = 0;
-    d.mesh_flat = 0;
+    d.mesh_flat = 0; d.mesh_flat_words = 0; d.mesh_flat_slots = 0;
     d.mesh_levels = isdf::MESH_Q_LEVELS;
     if (s->kind == ISDF_SHAPE_MESH) {
         if (!s->mesh_vertices || !s->mesh_faces || s->n_faces < 1 || s->n_vertices < 3) return fail(c, ISDF_ERR_INVALID_ARG, "mesh shape needs vertices and faces");
@@ -390,8 +390,8 @@ extern "C" int isdf_set_shape(isdf_ctx *c, const isdf_shape *s) {
         HIPCHK(c, hipMemcpy(c->d_fwn_boxq, boxq.data(), boxq.size() * sizeof(float), hipMemcpyHostToDevice));
         HIPCHK(c, hipMalloc(&c->d_fwn_triq, triq.size() * sizeof(double)));
         HIPCHK(c, hipMemcpy(c->d_fwn_triq, triq.data(), triq.size() * sizeof(double), hipMemcpyHostToDevice));
-        DevMesh hm{c->d_mesh_tri, c->d_mesh_trif, s->n_faces, c->d_fwn_child, c->d_fwn_box, tree.n_nodes(), c->d_fwn_boxq, c->d_fwn_triq, depth, nullptr, {0, 0, 0}, {0.f, 0.f, 0.f}, 0.f, 0.f,
-                   nullptr, 0, 0, 0};
+        DevMesh hm{c->d_mesh_tri, c->d_mesh_trif, s->n_faces, c->d_fwn_child, c->d_fwn_box, tree.n_nodes(), c->d_fwn_boxq, c->d_fwn_triq, depth, nullptr, {0, 0, 0}, {0.f, 0.f, 0.f}, 0.f, 0.f, 0.f, 0.f,
+                   nullptr, 0, 0, 0, 0, 0, 0};
         // Small meshes: the flat slot table (DevMesh::flat) - levels by breadth-first search from the root
         {
             const int nn = tree.n_nodes();
@@ -432,6 +432,7 @@ extern "C" int isdf_set_shape(isdf_ctx *c, const isdf_shape *s) {
                     for (int nd : order) if (node_level[nd] == l) { nodes.push_back(node_slot[nd]); for (int ch = 0; ch < 4; ch++) nodes.push_back(child_slots[nd][ch]); }
                 }
                 for (int st = step; st < 9; st++) step_begin[st] = nn;
+                // ONE blob, copied into LDS as it is by every workgroup: [tables | per-slot record, 40 floats | per-slot fp64 triangle, 10 doubles]
                 std::vector<int> flat;
                 flat.insert(flat.end(), lvl_begin.begin(), lvl_begin.end());
                 flat.insert(flat.end(), step_begin.begin(), step_begin.end());
@@ -440,8 +441,19 @@ extern "C" int isdf_set_shape(isdf_ctx *c, const isdf_shape *s) {
                 flat.insert(flat.end(), slots.begin(), slots.end());
                 flat.insert(flat.end(), tris.begin(), tris.end());
                 flat.insert(flat.end(), nodes.begin(), nodes.end());
+                while (flat.size() % 4) flat.push_back(0);
+                const int rec_off = (int)flat.size();                 // (in 4-byte units)
+                flat.resize(flat.size() + (size_t)n_slots * isdf::MESH_Q_REC);
+                for (int sl = 0; sl < n_slots; sl++)
+                    std::memcpy(flat.data() + rec_off + (size_t)sl * isdf::MESH_Q_REC, boxq.data() + (size_t)slots[(size_t)4 * sl] * isdf::MESH_Q_REC, isdf::MESH_Q_REC * sizeof(float));
+                const int trec_off = (int)flat.size();
+                flat.resize(flat.size() + (size_t)n_slots * isdf::MESH_Q_TRI * 2);
+                for (int sl = 0; sl < n_slots; sl++)
+                    std::memcpy(flat.data() + trec_off + (size_t)sl * isdf::MESH_Q_TRI * 2, triq.data() + (size_t)slots[(size_t)4 * sl] * isdf::MESH_Q_TRI, isdf::MESH_Q_TRI * sizeof(double));
+                while (flat.size() % 4) flat.push_back(0);
                 HIPCHK(c, hipMalloc(&c->d_mesh_flat, flat.size() * sizeof(int)));
                 HIPCHK(c, hipMemcpy(c->d_mesh_flat, flat.data(), flat.size() * sizeof(int), hipMemcpyHostToDevice));
+                hm.flat_words = (int)flat.size(); hm.flat_rec = rec_off; hm.flat_trec = trec_off;
                 hm.flat = c->d_mesh_flat; hm.flat_slots = n_slots; hm.flat_nodes = nn; hm.flat_levels = n_levels;
             }
         }
@@ -452,6 +464,7 @@ extern "C" int isdf_set_shape(isdf_ctx *c, const isdf_shape *s) {
         if (const char *e = getenv("ISDF_MESH_WG")) d.mesh_wg = (e[0] == '1' && depth <= isdf::MESH_Q_LEVELS) ? 1 : 0;
         // small meshes: the flat evaluation (one task per workgroup as well); ISDF_MESH_FLAT=0 keeps the walks (A/B runs, tests)
         d.mesh_flat = hm.flat ? 1 : 0;
+        d.mesh_flat_words = hm.flat_words; d.mesh_flat_slots = hm.flat_slots;
         if (const char *e = getenv("ISDF_MESH_FLAT")) if (e[0] == '0') d.mesh_flat = 0;
         HIPCHK(c, hipMemcpy(c->d_mesh, &hm, sizeof(hm), hipMemcpyHostToDevice));
         d.mesh = c->d_mesh;
@@ -483,28 +496,35 @@ extern "C" int isdf_set_shape(isdf_ctx *c, const isdf_shape *s) {
         // three vertices of their own per face - is "open" to it whatever its geometry.  The exact test below is geometric and catches
         // open surfaces too (next to a boundary the winding number is a fraction), so it alone decides; `closed` is reported.)
         const bool want_lattice = d.prune_rows && !(getenv("ISDF_NO_F32_FILTER") && getenv("ISDF_NO_F32_FILTER")[0] == '1');
+        float defect[2] = {0.f, 0.f};
+        double llo[3] = {0, 0, 0}, lhi[3] = {0, 0, 0}, lat_ext = 0.0;
+        int cells = 96;
         if (want_lattice) {
+            // (the lattice's box: wide enough for the swept-volume scans' band, 2 safety_hor + 0.1, as well: mesh_lattice_not_below)
+            const double margin = 1.05 * std::max(c->cfg.safety_hor, 2.0 * c->cfg.safety_hor + 0.1) + 0.01;
+            for (int a = 0; a < 3; a++) { llo[a] = (double)d.bbox_lo[a] - margin; lhi[a] = (double)d.bbox_hi[a] + margin; lat_ext = std::max(lat_ext, lhi[a] - llo[a]); }
+            if (const char *e = getenv("ISDF_MESH_LATTICE_CELLS")) { const int v = atoi(e); if (v >= 16 && v <= 256) cells = v; }      // (developer switch)
             double ext3 = 0.0;
             for (int a = 0; a < 3; a++) ext3 = std::max(ext3, 2.0 * bb_h[a]);
-            const int rcv = isdf_mesh_surface_valid(c, c->d_mesh_tri, s->n_faces, ext3, &solid);
+            // a defect pocket may be a tenth of the lattice's reach (half a cell diagonal) thick; anything thicker is a region
+            const double tau_limit = 0.1 * 0.5 * 1.7320508 * (lat_ext / cells);
+            const int rcv = isdf_mesh_surface_valid(c, c->d_mesh_tri, s->n_faces, ext3, tau_limit, &solid, defect);
             if (rcv) return rcv;
         }
         if (want_lattice && solid) {
-            // (wide enough for the swept-volume scans' band, 2 safety_hor + 0.1, as well: mesh_lattice_not_below)
-            const double margin = 1.05 * std::max(c->cfg.safety_hor, 2.0 * c->cfg.safety_hor + 0.1) + 0.01;
-            double llo[3], lhi[3];
-            for (int a = 0; a < 3; a++) { llo[a] = (double)d.bbox_lo[a] - margin; lhi[a] = (double)d.bbox_hi[a] + margin; }
-            int cells = 96;
-            if (const char *e = getenv("ISDF_MESH_LATTICE_CELLS")) { const int v = atoi(e); if (v >= 16 && v <= 256) cells = v; }      // (developer switch)
             const int rc = isdf_mesh_lattice_build(c, &hm, llo, lhi, cells, s_range);
             if (rc) return rc;
-            if (hm.dl) { HIPCHK(c, hipMemcpy(c->d_mesh, &hm, sizeof(hm), hipMemcpyHostToDevice)); d.filter_f32 = 1; }
+            if (hm.dl) {
+                hm.dl_tau = defect[0]; hm.dl_slack = 1.05f * defect[1] * defect[0];
+                HIPCHK(c, hipMemcpy(c->d_mesh, &hm, sizeof(hm), hipMemcpyHostToDevice)); d.filter_f32 = 1;
+            }
         }
         {   // isdf_mesh_info
             int *mi = c->mesh_info;
             mi[0] = s->n_faces; mi[1] = tree.n_nodes(); mi[2] = depth; mi[3] = d.mesh_wg; mi[4] = closed ? 1 : 0; mi[5] = want_lattice ? solid : -1;
             mi[6] = hm.dl ? hm.dln[0] : 0; mi[7] = hm.dl ? hm.dln[1] : 0; mi[8] = hm.dl ? hm.dln[2] : 0;
             mi[9] = (int)std::lround(1.0e6 * s_range[0]); mi[10] = (int)std::lround(1.0e6 * s_range[1]); mi[11] = d.mesh_flat ? hm.flat_slots : 0;
+            mi[12] = (int)std::lround(1.0e9 * defect[0]); mi[13] = (int)std::lround(1.0e3 * defect[1]); mi[14] = mi[15] = 0;
         }
     }
     if (s->kind != ISDF_SHAPE_MESH) std::memset(c->mesh_info, 0, sizeof(c->mesh_info));
@@ -1584,9 +1604,9 @@ static int v1_direct_eval(isdf_ctx *c, int n, const double *T, const double *coe
     return ISDF_OK;
 }
 
-extern "C" int isdf_mesh_info(const isdf_ctx *c, int info_out[12]) {
+extern "C" int isdf_mesh_info(const isdf_ctx *c, int info_out[16]) {
     if (!c || !info_out) return ISDF_ERR_INVALID_ARG;
-    for (int k = 0; k < 12; k++) info_out[k] = c->mesh_info[k];
+    for (int k = 0; k < 16; k++) info_out[k] = c->mesh_info[k];
     return ISDF_OK;
 }
 

@@ -23,12 +23,16 @@ __global__ __launch_bounds__(256) void shape_eval_kernel(DevShape S, const doubl
 // ---- What the distance lattice's users assume about a mesh, CHECKED before one is built (Shape.cpp:105-151).
 // sdf = (1 - 2 w) * dist tracks the distance only where the winding number of the surface is 0 outside and 1 inside.  That is a
 // property of the surface, tested here with the EXACT winding number (the sum of all triangles' solid angles in fp64, no hierarchy):
-// a hair off every face, on both sides, at the centroid and (small meshes) next to the three corners,
-//     w(outside) in {0, 1} +- 0.01,   w(inside) in {0, 1} +- 0.01,   w(inside) - w(outside) = +1 +- 0.01.
+// a hair off every face, on both sides, at the centroid and (small meshes) next to the three corners, w must be 0 or 1 (+- 0.01).
 // Every region of space the surface bounds touches a face, so a region where w is 2 (a closed sheet inside another one with the
-// same orientation, overlapping components), -1 (an inverted component) or a fraction (an open or torn surface) shows up at the
-// faces that bound it - whatever its thickness; a thin-walled hollow shell (outer sheet outwards, inner sheet inwards) passes, as it
-// should.  flag bit 0: some sample failed.
+// same orientation, overlapping bodies), -1 (an inverted body) or a fraction (an open or torn surface) shows up at the faces that
+// bound it - whatever its thickness; a thin-walled hollow shell (outer sheet outwards, inner sheet inwards) passes, as it should.
+// Real meshes carry DEFECTS, though: the reference's own Trefoil.obj has 18 folded sliver faces (of 12 000) with a pocket of w = -1
+// a few micrometres thick behind them.  A sample that fails is therefore probed further out along the normal, doubling the offset: if
+// w is 0 / 1 again within tau_limit (a tenth of the lattice's node-to-point reach) the pocket is a defect of known thickness - the
+// largest such offset comes back in out[1] (float bits), the largest |1 - 2 w| seen inside a pocket in out[2] - and the lattice's
+// users widen their brackets by what a pocket that thin can do (dev_mesh.hpp: dl_tau, dl_slack).  If it is not, out[0] bit 0 is
+// raised: the mesh gets no lattice.
 __device__ __forceinline__ d3 cross3(d3 a, d3 b) { return mk3(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x); }
 __device__ __forceinline__ double tri_solid_angle_f64(d3 a, d3 b, d3 c) {      // Van Oosterom - Strackee, about the origin
     const double la = sqrt(dot3(a, a)), lb = sqrt(dot3(b, b)), lc = sqrt(dot3(c, c));
@@ -36,7 +40,15 @@ __device__ __forceinline__ double tri_solid_angle_f64(d3 a, d3 b, d3 c) {      /
     const double den = la * lb * lc + dot3(a, b) * lc + dot3(a, c) * lb + dot3(b, c) * la;
     return 2.0 * atan2(det, den);
 }
-__global__ __launch_bounds__(256) void mesh_validity_kernel(const double *__restrict__ tri, int nF, int samples, double eps, unsigned *flag) {
+__device__ inline double mesh_exact_w(const double *__restrict__ tri, int nF, d3 p) {
+    double sum = 0.0;
+    for (int g = 0; g < nF; g++) {
+        const double *u = tri + (size_t)9 * g;
+        sum += tri_solid_angle_f64(mk3(u[0], u[1], u[2]) - p, mk3(u[3], u[4], u[5]) - p, mk3(u[6], u[7], u[8]) - p);
+    }
+    return sum / (4.0 * 3.14159265358979323846);
+}
+__global__ __launch_bounds__(256) void mesh_validity_kernel(const double *__restrict__ tri, int nF, int samples, double eps, double tau_limit, unsigned *out) {
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= (long long)nF * samples) return;
     const int f = (int)(i / samples), k = (int)(i % samples);
@@ -51,18 +63,19 @@ __global__ __launch_bounds__(256) void mesh_validity_kernel(const double *__rest
     const d3 n = (1.0 / nl) * nr;
     // (the offset also stays well inside the face's own extent: a sliver is sampled closer to its plane)
     const double off = fmin(eps, 1.0e-3 * sqrt(nl));
-    double w[2];
-    for (int side = 0; side < 2; side++) {
-        const d3 p = q + (side ? -off : off) * n;                  // side 0: along the normal (outside of an outward-oriented face)
-        double sum = 0.0;
-        for (int g = 0; g < nF; g++) {
-            const double *u = tri + (size_t)9 * g;
-            sum += tri_solid_angle_f64(mk3(u[0], u[1], u[2]) - p, mk3(u[3], u[4], u[5]) - p, mk3(u[6], u[7], u[8]) - p);
-        }
-        w[side] = sum / (4.0 * 3.14159265358979323846);
-    }
     auto is01 = [](double v) { return fabs(v) <= 0.01 || fabs(v - 1.0) <= 0.01; };
-    if (!is01(w[0]) || !is01(w[1]) || !(fabs((w[1] - w[0]) - 1.0) <= 0.01)) atomicOr(flag, 1u);
+    for (int side = 0; side < 2; side++) {
+        double tt = off;
+        for (int step = 0;; step++, tt *= 2.0) {
+            const double w = mesh_exact_w(tri, nF, q + (side ? -tt : tt) * n);
+            if (is01(w)) {
+                if (step > 0) atomicMax(&out[1], __float_as_uint((float)tt * 1.0000001f));      // a pocket: w is 0 / 1 again tt off the face
+                break;
+            }
+            atomicMax(&out[2], __float_as_uint((float)fabs(1.0 - 2.0 * w) * 1.0000001f));
+            if (tt > tau_limit) { atomicOr(&out[0], 1u); break; }                               // not a defect: a region
+        }
+    }
 }
 
 // the mesh kind's distance lattice (DevMesh::dl): one thread per node, the per-lane walks.  The same launch MEASURES what the
@@ -103,22 +116,24 @@ __global__ __launch_bounds__(256) void mesh_lattice_kernel(const DevMesh *m, flo
 
 }  // namespace isdf
 
-// Does the surface bound a solid the way the lattice's users need (mesh_validity_kernel)?  out: 1 yes, 0 no.
-int isdf_mesh_surface_valid(isdf_ctx *c, const double *d_tri, int nF, double extent, int *valid_out) {
-    *valid_out = 0;
+// Does the surface bound a solid the way the lattice's users need (mesh_validity_kernel)?  valid_out: 1 yes, 0 no; defect_out: the
+// thickness of the thickest defect pocket found (0: none) and the largest |1 - 2 w| inside one
+int isdf_mesh_surface_valid(isdf_ctx *c, const double *d_tri, int nF, double extent, double tau_limit, int *valid_out, float defect_out[2]) {
+    *valid_out = 0; defect_out[0] = defect_out[1] = 0.f;
     unsigned *d_flag = nullptr;
-    HIPCHK(c, hipMalloc(&d_flag, sizeof(unsigned)));
-    HIPCHK(c, hipMemsetAsync(d_flag, 0, sizeof(unsigned), c->stream));
+    HIPCHK(c, hipMalloc(&d_flag, 3 * sizeof(unsigned)));
+    HIPCHK(c, hipMemsetAsync(d_flag, 0, 3 * sizeof(unsigned), c->stream));
     const int samples = nF <= 4096 ? 4 : 1;            // (the test is quadratic in the faces: the reference's 12 000-face Trefoil.obj takes the centroids)
     const long long total = (long long)nF * samples;
-    hipLaunchKernelGGL(isdf::mesh_validity_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, c->stream, d_tri, nF, samples, 1.0e-5 * extent, d_flag);
-    unsigned flag = 1;
+    hipLaunchKernelGGL(isdf::mesh_validity_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, c->stream, d_tri, nF, samples, 1.0e-5 * extent, tau_limit, d_flag);
+    unsigned back[3] = {1u, 0u, 0u};
     const hipError_t e1 = hipGetLastError();
-    const hipError_t e2 = hipMemcpyAsync(&flag, d_flag, sizeof(unsigned), hipMemcpyDeviceToHost, c->stream);
+    const hipError_t e2 = hipMemcpyAsync(back, d_flag, sizeof(back), hipMemcpyDeviceToHost, c->stream);
     const hipError_t e3 = hipStreamSynchronize(c->stream);
     (void)hipFree(d_flag);
     HIPCHK(c, e1); HIPCHK(c, e2); HIPCHK(c, e3);
-    *valid_out = flag ? 0 : 1;
+    *valid_out = (back[0] & 1u) ? 0 : 1;
+    std::memcpy(&defect_out[0], &back[1], 4); std::memcpy(&defect_out[1], &back[2], 4);
     return ISDF_OK;
 }
 

@@ -198,30 +198,47 @@ struct MeshWG {
     double *stage;       // this wavefront's [64][4] compacted queries: point, cap (wave-private: no barrier)
     double *res;         // the workgroup's [2 parities][64][5] results: (below, sdf, g.xyz)
     int parity, wave;
+    int count;           // queries pending in stage (mesh_wg_push ... mesh_wg_flush)
     MeshFrames frames;   // this wavefront's walk frames (dev_mesh.hpp): a view into the dynamic LDS, as many levels as the hierarchy has
     int n_waves;         // wavefronts of the workgroup (2 in the scan: up to 64 queries per pass; 1 in the descent: at most 14, 19 in a first pass without a seed)
+    FlatLds flat;        // small meshes (FLAT form: every wavefront has a task of its own, stage / res are the wavefront's): the LDS copy of the tables
 };
 constexpr int MESH_WG_RES = 2 * 64 * 5;
 constexpr int mesh_wg_stage(int nw) { return nw * 64 * 4; }
-// every lane of all four wavefronts calls; returns "sdf < cap proven / evaluated" like mesh_sdf_grad_below (cap = +inf: plain query)
-// FLAT: small meshes - the flat evaluation (dev_mesh.hpp) instead of the walks; X.frames.w is then the wavefront's [16][MESH_FLAT_SLOTS] floats
-template <bool FLAT>
-__device__ inline bool mesh_eval_wg(MeshWG &X, const DevMesh *m, d3 pr, bool act, double cap, double &sdf, d3 &g) {
+// The queries of a pass go through three steps (every lane of all the workgroup's wavefronts calls each of them):
+//   mesh_wg_push   the evaluating lanes' queries join the pending list (compacted into the wavefront's stage); returns the lane's place
+//                  in it, or -1 when the lane asks nothing (or the distance lattice answers it: fewer queries, fewer rounds)
+//   mesh_wg_flush  the pending list is evaluated, 16 queries per wavefront and round, 4 lanes per query
+//   mesh_wg_get    a lane's result: "sdf < cap proven / evaluated" like mesh_sdf_grad_below (cap = +inf: plain query), value, gradient
+// A list holds up to 64 queries (stage / res); several pushes may precede one flush - the coarse scan collects the queries of ALL its
+// 64-sample windows before it evaluates them: a round costs what the union of its queries' nodes costs, whether it holds 3 queries or 16.
+// FLAT: small meshes - the flat evaluation (dev_mesh.hpp) instead of the walks.
+__device__ __forceinline__ int mesh_wg_push(MeshWG &X, const DevMesh *m, d3 pr, bool act, double cap) {
     const int lane = (int)__lane_id();
-    // (a capped query the distance lattice already answers leaves here: fewer queries, fewer rounds)
     if (act && mesh_lattice_not_below(m, pr, cap)) act = false;
     const unsigned long long mask = __ballot(act);
-    if (!mask) return false;                               // (the same in all four wavefronts)
-    const int n_act = __popcll(mask);
-    const int rank = __popcll(mask & ((1ull << lane) - 1ull));
-    if (act) { X.stage[4 * rank] = pr.x; X.stage[4 * rank + 1] = pr.y; X.stage[4 * rank + 2] = pr.z; X.stage[4 * rank + 3] = cap; }
+    if (!mask) return -1;                                  // (the same in all the workgroup's wavefronts)
+    const int idx = X.count + __popcll(mask & ((1ull << lane) - 1ull));
+    if (act) { X.stage[4 * idx] = pr.x; X.stage[4 * idx + 1] = pr.y; X.stage[4 * idx + 2] = pr.z; X.stage[4 * idx + 3] = cap; }
+    X.count += __popcll(mask);
+    return act ? idx : -1;
+}
+template <bool FLAT>
+__device__ inline void mesh_wg_flush(MeshWG &X, const DevMesh *m) {
+    const int lane = (int)__lane_id();
+    const int n_act = X.count;
+    X.count = 0;
+    if (n_act == 0) return;                                // (the same in all the workgroup's wavefronts)
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     // FULL wavefronts first (16 queries, 4 lanes each): the queries of a pass are neighbours, so every wavefront that takes part
     // opens nearly the same set of nodes - dealing 25 queries as 7 + 7 + 7 + 4 cost four walks of 28 lanes (counters: lane
     // utilisation 0.48, 1.6x the instructions of round 3), 16 + 9 costs two
-    double *R = X.res + (size_t)X.parity * 64 * 5;
+    // (res is double-buffered by parity: a wavefront that races ahead writes the OTHER half, which every wavefront finished reading
+    // before it passed the barrier below; FLAT: one wavefront, one buffer)
+    if constexpr (!FLAT) X.parity ^= 1;
+    double *R = X.res + (FLAT ? 0 : (size_t)X.parity * 64 * 5);
     for (int base = 0; base < n_act; base += 16 * X.n_waves) {
         const int q = lane >> 2, r = base + X.wave * 16 + q;
         const bool on = r < n_act;
@@ -232,17 +249,27 @@ __device__ inline bool mesh_eval_wg(MeshWG &X, const DevMesh *m, d3 pr, bool act
         double s2 = 0.0;
         d3 g2 = mk3(0, 0, 0);
         bool below;
-        if constexpr (FLAT) below = mesh_sdf_grad_below_flat(m, reinterpret_cast<float *>(X.frames.w), qp, on, qcap, s2, g2);
+        if constexpr (FLAT) below = mesh_sdf_grad_below_flat(X.flat, qp, on, qcap, s2, g2);
         else below = mesh_sdf_grad_below_quad(m, X.frames, qp, on, qcap, s2, g2);
         if (on && (lane & 3) == 0) { double *o = R + 5 * r; o[0] = below ? 1.0 : 0.0; o[1] = s2; o[2] = g2.x; o[3] = g2.y; o[4] = g2.z; }
     }
-    __syncthreads();
-    // (double-buffered by parity: a wavefront that races ahead writes the OTHER half, which every wavefront finished reading
-    // before it passed this barrier)
-    X.parity ^= 1;
-    bool ret = false;
-    if (act) { const double *o = R + 5 * rank; ret = o[0] != 0.0; sdf = o[1]; g = mk3(o[2], o[3], o[4]); }
-    return ret;
+    // (FLAT: the wavefront works alone - its own task, its own stage / res - and the other wavefronts of the workgroup are elsewhere
+    // in their own control flow: no workgroup barrier)
+    if constexpr (FLAT) flat_lds_sync(); else __syncthreads();
+}
+template <bool FLAT>
+__device__ __forceinline__ bool mesh_wg_get(const MeshWG &X, int idx, double &sdf, d3 &g) {
+    if (idx < 0) return false;
+    const double *o = X.res + (FLAT ? 0 : (size_t)X.parity * 64 * 5) + 5 * idx;
+    sdf = o[1]; g = mk3(o[2], o[3], o[4]);
+    return o[0] != 0.0;
+}
+// one pass by itself
+template <bool FLAT>
+__device__ inline bool mesh_eval_wg(MeshWG &X, const DevMesh *m, d3 pr, bool act, double cap, double &sdf, d3 &g) {
+    const int idx = mesh_wg_push(X, m, pr, act, cap);
+    mesh_wg_flush<FLAT>(X, m);
+    return mesh_wg_get<FLAT>(X, idx, sdf, g);
 }
 
 // ---- the ONE pose + SDF evaluation both kernels below are built around: pose at `te`, body-frame point (perturbed for a
@@ -310,13 +337,14 @@ __device__ __forceinline__ void eval_lane(const SweptParams &P, const TrajL<LDS>
 // (WGM: at least 4 wavefronts per SIMD - without the cap the compiler spends 450 registers, one workgroup per CU)
 template <int KIND, bool LDS, int WGM>
 __device__ __forceinline__ void scan_body(const SweptParams &P, double *s_dyn, const int block) {
-    constexpr bool MESH = WGM != 0;      // one point per WORKGROUP of WGW wavefronts (mesh_eval_wg above: larger mesh robots), else one per wavefront
-    constexpr bool FLAT = WGM == 3;      // ... small meshes: one wavefront, the flat evaluation instead of the walks
+    constexpr bool COOP = WGM != 0;      // the evaluating lanes' mesh queries go through mesh_eval_wg (compacted, 4 lanes per query)
+    constexpr bool FLAT = WGM == 3;      // ... small meshes: the flat evaluation instead of the walks; one point per WAVEFRONT like the analytic kinds
+    constexpr bool MESH = COOP && !FLAT; // one point per WORKGROUP of WGW wavefronts (mesh_eval_wg above: larger mesh robots), else one per wavefront
     constexpr int WGW = FLAT ? 1 : WGM, EW = FLAT ? 2 : 1;
     static_assert(!WGM || KIND == ISDF_SHAPE_MESH, "workgroup-cooperative evaluation is the mesh kind's");
     __shared__ double s_rl[SW_WAVES][SW_MAX_RANGES], s_rr[SW_WAVES][SW_MAX_RANGES];
     __shared__ unsigned s_cnt[SW_WAVES][2], s_base[2];
-    __shared__ double s_mesh[MESH ? mesh_wg_stage(WGW) + MESH_WG_RES : 1];
+    __shared__ double s_mesh[FLAT ? SW_WAVES * (64 * 4 + 64 * 5) : (MESH ? mesh_wg_stage(WGW) + MESH_WG_RES : 1)];
     const unsigned long long dbg_t0 = (ISDF_SWEEP_STATS && P.dbg) ? wall_clock64() : 0ull;
     TrajL<LDS> tr{P.T, P.coeffs, P.N};
     if constexpr (LDS) tr = traj_stage(s_dyn, P.T, P.coeffs, P.N);
@@ -328,8 +356,15 @@ __device__ __forceinline__ void scan_body(const SweptParams &P, double *s_dyn, c
     const int pt = P.point_begin + pt_rel;
     const bool writer = lane == 0 && (!MESH || wave == 0);       // (the four wavefronts of a mesh workgroup hold the same results)
     const int m_lv = MESH ? P.shape.mesh_levels : 1;       // frames: behind the staged trajectory in the dynamic LDS, one set per wavefront
-    MeshWG mwg{s_mesh + wave * 64 * 4, s_mesh + (MESH ? mesh_wg_stage(WGW) : 0), 0, wave,
-               MeshFrames{reinterpret_cast<unsigned *>(reinterpret_cast<char *>(s_dyn) + (LDS ? traj_lds_bytes(P.N) : 0)) + (MESH ? wave * mesh_frames_words(m_lv) : 0), m_lv}, WGW};
+    MeshWG mwg{s_mesh + wave * 64 * 4, s_mesh + (MESH ? mesh_wg_stage(WGW) : 0), 0, wave, 0,
+               MeshFrames{reinterpret_cast<unsigned *>(reinterpret_cast<char *>(s_dyn) + (LDS ? traj_lds_bytes(P.N) : 0)) + (MESH ? wave * mesh_frames_words(m_lv) : 0), m_lv}, WGW, FlatLds{}};
+    if constexpr (FLAT) {
+        // dynamic LDS: [the mesh's table blob | SW_WAVES x this wavefront's slot values]; static: per wavefront [64][4] queries + [64][5] results
+        int *blob = reinterpret_cast<int *>(reinterpret_cast<char *>(s_dyn) + (LDS ? ((traj_lds_bytes(P.N) + 15) & ~(size_t)15) : 0));
+        flat_lds_stage(P.shape.mesh, blob);
+        mwg.stage = s_mesh + wave * (64 * 4 + 64 * 5); mwg.res = mwg.stage + 64 * 4; mwg.wave = 0;
+        mwg.flat = flat_lds_view(P.shape.mesh, blob, reinterpret_cast<float *>(blob + P.shape.mesh_flat_words) + wave * flat_om_floats(P.shape.mesh_flat_slots));
+    }
     int my_nr = 0;
     if (pt < P.point_end) {
     unsigned long long *const dbg = (ISDF_SWEEP_STATS && P.dbg) ? P.dbg + (size_t)pt * 4 : nullptr;
@@ -352,50 +387,9 @@ __device__ __forceinline__ void scan_body(const SweptParams &P, double *s_dyn, c
     const double far_r = P.shape.bound_radius + inf * (KIND == ISDF_SHAPE_MESH ? 1.05 : 1.0);
     const double far2 = P.shape.bound_radius > 0.0 ? far_r * far_r : 1.0e300;
     bool carry_din = false;          // (mesh robots) the previous window's last sample is in range by the lattice's bounds
-    for (int base = 0; base < n_coarse; base += 64) {
-        const int k = base + lane;
-        const int kc = min(k, n_coarse - 1);
-        const double ct = P.coarse_t[kc];         // travels with the lane: the run boundaries below come out of a register
-        const double *o = P.coarse_pose + kc;     // component-major table: coalesced across the lanes
-        const d3 dxp = p - mk3(o[0], o[cst], o[2 * cst]);
-        double dis = 1e9;
-        const bool near = k < n_coarse && !(dot3(dxp, dxp) > far2);
-        if constexpr (MESH) {
-            if (__ballot(near)) {
-                m3 R;
-#pragma unroll
-                for (int q = 0; q < 9; q++) R.a[q] = o[(3 + q) * cst];
-                const d3 pr = mat_tmul(R, dxp);
-                // the scan only asks "dis < inf?" (and keeps dis where the answer is yes): far samples are rejected by the
-                // hierarchy's distance cutoff without a full query - or by the distance lattice (mesh_eval_wg).  A sample the
-                // lattice puts INSIDE the band, right behind another such sample, needs no query either: it is in range, and it
-                // cannot be the first sample of a run - the only one whose value is used (:405-408)
-                double s_lb, s_ub;
-                const bool din = near && mesh_lattice_bounds(P.shape.mesh, pr, s_lb, s_ub) && s_ub < inf * (1.0 - 1e-9);
-                const unsigned long long dmask = __ballot(din);
-                const bool skip = din && (lane == 0 ? carry_din : (bool)((dmask >> (lane - 1)) & 1ull));
-                carry_din = (dmask >> 63) & 1ull;
-                d3 g_unused;
-                double sdf = 1e9;
-                if (mesh_eval_wg<FLAT>(mwg, P.shape.mesh, pr, near && !skip, inf, sdf, g_unused)) dis = sdf;
-                if (skip) dis = s_ub;
-            } else carry_din = false;
-        } else if (near) {
-            m3 R;
-#pragma unroll
-            for (int q = 0; q < 9; q++) R.a[q] = o[(3 + q) * cst];
-            const d3 pr = mat_tmul(R, dxp);
-            if constexpr (KIND == ISDF_SHAPE_MESH) {
-                d3 g_unused;
-                double sdf;
-                dis = mesh_sdf_grad_below_wave(P.shape.mesh, pr, inf, sdf, g_unused) ? sdf : 1e9;      // (the lattice answers the far ones: dev_mesh.hpp)
-            } else {
-                dis = shape_sdf<KIND>(P.shape, pr);
-            }
-        }
-        unsigned long long in_mask = __ballot((k < n_coarse) && (dis < inf));
+    // the transitions of one 64-sample window (wave-uniform scalar loop): in_mask = its in-range samples, dis / ct = the lanes' values / times
+    auto walk_window = [&](const int base, const unsigned long long in_mask, const double dis, const double ct) {
         const int nvalid = min(64, n_coarse - base);
-        // walk the transitions of this 64-sample window (wave-uniform scalar loop)
         int b = 0;
         while (b < nvalid) {
             const unsigned long long rest = (b < 64) ? (in_mask >> b) : 0ull;
@@ -421,6 +415,96 @@ __device__ __forceinline__ void scan_body(const SweptParams &P, double *s_dyn, c
                 b++;
             }
         }
+    };
+    if constexpr (COOP) {
+        // Mesh robots, cooperative forms.  Which samples need a query does not depend on any query's result (the distance lattice and
+        // the bounding sphere decide), so the queries of SEVERAL windows can be evaluated together.  FLAT evaluation: a round costs the
+        // same whether it holds 3 queries or 16 - a 20 s trajectory's two windows were two rounds per point (Lthick.obj 1.115 ->
+        // 1.074 ms).  Quad WALKS: one window per round, as before - a walk is cheap because its queries are neighbours (they open the
+        // same nodes, and the closest-point walk visits nearest-first by its FIRST query's bounds); samples 13 s apart on the trajectory
+        // share nothing (measured with groups of 8: Trefoil.obj 4.57 -> 6.03 ms, the 720-face blob 5.34 -> 5.59).  Per window three
+        // wave-uniform words are kept (asked lanes, lanes in range without a query, the first place in the list); a group ends after
+        // SW_GROUP windows or when the list (64 queries) would overflow.
+        constexpr int SW_GROUP = FLAT ? 8 : 1;
+        __shared__ unsigned long long s_wm[SW_WAVES][SW_GROUP][2];
+        __shared__ int s_wi[SW_WAVES][SW_GROUP][2];
+        int g_n = 0;
+        auto flush_group = [&]() {
+            mesh_wg_flush<FLAT>(mwg, P.shape.mesh);
+            flat_lds_sync();
+            for (int w = 0; w < g_n; w++) {
+                const int base = s_wi[wave][w][0], lbase = s_wi[wave][w][1];
+                const unsigned long long amask = s_wm[wave][w][0], smask = s_wm[wave][w][1];
+                const int k = base + lane, kc = min(k, n_coarse - 1);
+                const double ct = P.coarse_t[kc];
+                double dis = 1e9;
+                if ((amask >> lane) & 1ull) {
+                    d3 g_unused;
+                    double sdf = 1e9;
+                    if (mesh_wg_get<FLAT>(mwg, lbase + __popcll(amask & ((1ull << lane) - 1ull)), sdf, g_unused)) dis = sdf;
+                }
+                // (a sample the lattice put in range without a query - `skip` below - is never the first of a run: only its being in range is used)
+                const unsigned long long in_mask = __ballot((k < n_coarse) && (dis < inf)) | smask;
+                walk_window(base, in_mask, dis, ct);
+            }
+            g_n = 0;
+        };
+        for (int base = 0; base < n_coarse; base += 64) {
+            const int k = base + lane;
+            const int kc = min(k, n_coarse - 1);
+            const double *o = P.coarse_pose + kc;     // component-major table: coalesced across the lanes
+            const d3 dxp = p - mk3(o[0], o[cst], o[2 * cst]);
+            const bool near = k < n_coarse && !(dot3(dxp, dxp) > far2);
+            unsigned long long amask = 0ull, smask = 0ull;
+            int lbase = mwg.count;
+            if (__ballot(near)) {
+                m3 R;
+#pragma unroll
+                for (int q = 0; q < 9; q++) R.a[q] = o[(3 + q) * cst];
+                const d3 pr = mat_tmul(R, dxp);
+                // the scan only asks "dis < inf?" (and keeps dis where the answer is yes): far samples are rejected by the
+                // hierarchy's distance cutoff without a full query - or by the distance lattice (mesh_wg_push).  A sample the
+                // lattice puts INSIDE the band, right behind another such sample, needs no query either: it is in range, and it
+                // cannot be the first sample of a run - the only one whose value is used (:405-408)
+                double s_lb, s_ub;
+                const bool din = near && mesh_lattice_bounds(P.shape.mesh, pr, s_lb, s_ub) && s_ub < inf * (1.0 - 1e-9);
+                const unsigned long long dmask = __ballot(din);
+                const bool skip = din && (lane == 0 ? carry_din : (bool)((dmask >> (lane - 1)) & 1ull));
+                carry_din = (dmask >> 63) & 1ull;
+                const bool ask = near && !skip;
+                if (mwg.count + __popcll(__ballot(ask)) > 64) { flush_group(); lbase = 0; }
+                const int idx = mesh_wg_push(mwg, P.shape.mesh, pr, ask, inf);
+                amask = __ballot(idx >= 0); smask = __ballot(skip);
+            } else carry_din = false;
+            if (lane == 0) { s_wm[wave][g_n][0] = amask; s_wm[wave][g_n][1] = smask; s_wi[wave][g_n][0] = base; s_wi[wave][g_n][1] = lbase; }
+            g_n++;
+            if (g_n == SW_GROUP) flush_group();
+        }
+        flush_group();
+    } else
+    for (int base = 0; base < n_coarse; base += 64) {
+        const int k = base + lane;
+        const int kc = min(k, n_coarse - 1);
+        const double ct = P.coarse_t[kc];         // travels with the lane: the run boundaries below come out of a register
+        const double *o = P.coarse_pose + kc;     // component-major table: coalesced across the lanes
+        const d3 dxp = p - mk3(o[0], o[cst], o[2 * cst]);
+        double dis = 1e9;
+        const bool near = k < n_coarse && !(dot3(dxp, dxp) > far2);
+        if (near) {
+            m3 R;
+#pragma unroll
+            for (int q = 0; q < 9; q++) R.a[q] = o[(3 + q) * cst];
+            const d3 pr = mat_tmul(R, dxp);
+            if constexpr (KIND == ISDF_SHAPE_MESH) {
+                d3 g_unused;
+                double sdf;
+                dis = mesh_sdf_grad_below_wave(P.shape.mesh, pr, inf, sdf, g_unused) ? sdf : 1e9;      // (the lattice answers the far ones: dev_mesh.hpp)
+            } else {
+                dis = shape_sdf<KIND>(P.shape, pr);
+            }
+        }
+        const unsigned long long in_mask = __ballot((k < n_coarse) && (dis < inf));
+        walk_window(base, in_mask, dis, ct);
     }
     n_ranges = min(n_ranges, SW_MAX_RANGES);
     if (dbg && writer) dbg[2] = wall_clock64();
@@ -459,7 +543,7 @@ __device__ __forceinline__ void scan_body(const SweptParams &P, double *s_dyn, c
                 int a_ub;
                 const double ub_min = wave_first_min((act && known) ? s_ub : 1.7976931348623157e308, lane, 64, a_ub);
                 const bool keep = act && !(known && s_lb > ub_min);
-                if constexpr (MESH) eval_lane<KIND, LDS, EW>(P, tr, p, te_q, 0, true, true, val, pv_unused, g_unused, &mwg, keep, range_mindis);
+                if constexpr (COOP) eval_lane<KIND, LDS, EW>(P, tr, p, te_q, 0, true, true, val, pv_unused, g_unused, &mwg, keep, range_mindis);
                 else if (keep) eval_lane<KIND, LDS, 0, true>(P, tr, p, te, 0, false, false, val, pv_unused, g_unused, nullptr, true, range_mindis);
             }
             else if (act) eval_lane<KIND, LDS, 0, false>(P, tr, p, te, 0, false, false, val, pv_unused, g_unused, nullptr, true, range_mindis);
@@ -469,14 +553,14 @@ __device__ __forceinline__ void scan_body(const SweptParams &P, double *s_dyn, c
             const double m = wave_first_min(val, lane, nv, arg);
             if (arg >= 0 && m < range_mindis) {
                 range_mindis = m; range_time_seed = rlane(te, __builtin_amdgcn_readfirstlane(arg));
-                if constexpr (MESH) { seed_f = m; seed_gd = rlane(dot3(g_unused, pv_unused), __builtin_amdgcn_readfirstlane(arg)); }
+                if constexpr (COOP) { seed_f = m; seed_gd = rlane(dot3(g_unused, pv_unused), __builtin_amdgcn_readfirstlane(arg)); }
             }
             if (nv < 64) break;
             t_base = rlane(te, 63) + dt;
         }
         if (writer) {
             double *o = slots + (size_t)r * TASK_STRIDE; o[0] = lb; o[1] = ub; o[2] = range_time_seed;
-            if constexpr (MESH) { o[3] = seed_f; o[4] = seed_gd; }
+            if constexpr (COOP) { o[3] = seed_f; o[4] = seed_gd; }
         }
     }
     if (writer) {
@@ -552,18 +636,25 @@ __device__ __forceinline__ int gd_block_base(int m) { return m == 0 ? 18 : 25 + 
 // workgroups do not fit beside each other: 0.43 ms against 0.129 ms for the two launches, profiles/r4_v1_timing_fused_search_dropped.txt.)
 template <int KIND, bool LDS, int WGM>
 __device__ __forceinline__ void descent_body(const SweptParams &P, double *s_dyn, const unsigned block, const unsigned n_blocks) {
-    constexpr bool MESH = WGM != 0;      // one task per WORKGROUP of WGW wavefronts (mesh_eval_wg), else one per wavefront
-    constexpr bool FLAT = WGM == 3;
+    constexpr bool COOP = WGM != 0;      // mesh queries through mesh_eval_wg, DIRECTED passes
+    constexpr bool FLAT = WGM == 3;      // ... small meshes: the flat evaluation, one task per WAVEFRONT
+    constexpr bool MESH = COOP && !FLAT; // one task per WORKGROUP of WGW wavefronts (mesh_eval_wg), else one per wavefront
     constexpr int WGW = FLAT ? 1 : WGM, EW = FLAT ? 2 : 1;
-    __shared__ double s_mesh[MESH ? mesh_wg_stage(WGW) + MESH_WG_RES : 1];
+    __shared__ double s_mesh[FLAT ? SW_WAVES * (64 * 4 + 64 * 5) : (MESH ? mesh_wg_stage(WGW) + MESH_WG_RES : 1)];
     TrajL<LDS> tr{P.T, P.coeffs, P.N};
     if constexpr (LDS) tr = traj_stage(s_dyn, P.T, P.coeffs, P.N);
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const bool writer = lane == 0 && (!MESH || wave == 0);
     const int m_lv = MESH ? P.shape.mesh_levels : 1;       // frames: behind the staged trajectory in the dynamic LDS, one set per wavefront
-    MeshWG mwg{s_mesh + wave * 64 * 4, s_mesh + (MESH ? mesh_wg_stage(WGW) : 0), 0, wave,
-               MeshFrames{reinterpret_cast<unsigned *>(reinterpret_cast<char *>(s_dyn) + (LDS ? traj_lds_bytes(P.N) : 0)) + (MESH ? wave * mesh_frames_words(m_lv) : 0), m_lv}, WGW};
+    MeshWG mwg{s_mesh + wave * 64 * 4, s_mesh + (MESH ? mesh_wg_stage(WGW) : 0), 0, wave, 0,
+               MeshFrames{reinterpret_cast<unsigned *>(reinterpret_cast<char *>(s_dyn) + (LDS ? traj_lds_bytes(P.N) : 0)) + (MESH ? wave * mesh_frames_words(m_lv) : 0), m_lv}, WGW, FlatLds{}};
+    if constexpr (FLAT) {
+        int *blob = reinterpret_cast<int *>(reinterpret_cast<char *>(s_dyn) + (LDS ? ((traj_lds_bytes(P.N) + 15) & ~(size_t)15) : 0));
+        flat_lds_stage(P.shape.mesh, blob);
+        mwg.stage = s_mesh + wave * (64 * 4 + 64 * 5); mwg.res = mwg.stage + 64 * 4; mwg.wave = 0;
+        mwg.flat = flat_lds_view(P.shape.mesh, blob, reinterpret_cast<float *>(blob + P.shape.mesh_flat_words) + wave * flat_om_floats(P.shape.mesh_flat_slots));
+    }
     const unsigned cap = (unsigned)(P.point_end - P.point_begin) * SW_MAX_RANGES;
     const unsigned n_front = (unsigned)__builtin_amdgcn_readfirstlane((int)P.words[0]);
     const unsigned n_tasks = n_front + (unsigned)__builtin_amdgcn_readfirstlane((int)P.words[1]);
@@ -574,7 +665,7 @@ __device__ __forceinline__ void descent_body(const SweptParams &P, double *s_dyn
     const bool fd_central = (KIND != ISDF_SHAPE_MESH) && gmode == ISDF_GRAD_CENTRAL;
     const bool fd_forward = (KIND != ISDF_SHAPE_MESH) && gmode == ISDF_GRAD_BOX_FORWARD;
     const bool own_grad = !fd_central && !fd_forward;
-    constexpr bool DIRECTED = MESH;                          // workgroup-cooperative mesh descents (see the task loop; the wave-cooperative walks of small meshes: measured slower with it)
+    constexpr bool DIRECTED = COOP;                          // workgroup-cooperative mesh descents (see the task loop; the wave-cooperative walks of small meshes: measured slower with it)
     // this lane's role in a pass: block (0..6) and offset inside it (0 = the pose lane)
     const int gd_blk = lane < 18 ? -1 : (lane < 25 ? 0 : (lane < 60 ? (lane - 25) / 7 + 1 : (lane == 60 ? GD_SPEC + 1 : -1)));
     const int gd_off = lane < 18 ? 0 : (lane < 25 ? lane - 18 : (lane < 60 ? (lane - 25) % 7 : 0));
@@ -631,7 +722,7 @@ __device__ __forceinline__ void descent_body(const SweptParams &P, double *s_dyn
                 }
                 double val = 1e300;
                 d3 pvel = mk3(0, 0, 0), gq = mk3(0, 0, 0);
-                if constexpr (MESH) eval_lane<KIND, LDS, EW>(P, tr, p, te, 0, true, true, val, pvel, gq, &mwg, act, fx);
+                if constexpr (COOP) eval_lane<KIND, LDS, EW>(P, tr, p, te, 0, true, true, val, pvel, gq, &mwg, act, fx);
                 else if (act) eval_lane<KIND, LDS>(P, tr, p, te, 0, true, true, val, pvel, gq, nullptr, true, fx);
                 n_pass++;
                 const double gdot = dot3(gq, pvel);
@@ -697,7 +788,7 @@ __device__ __forceinline__ void descent_body(const SweptParams &P, double *s_dyn
             // (mesh robots: every test below asks "val < f(x)?" of the lanes other than 18 - the halving candidates directly, the look-ahead
             // blocks through a chain of strictly decreasing values that starts at f(x) - and uses a value only when the answer is yes: f(x),
             // once known, is those queries' cutoff in the hierarchy)
-            if constexpr (MESH) eval_lane<KIND, LDS, EW>(P, tr, p, act ? te : x, pert, pose_lane, own_grad, val, pvel, g_direct, &mwg, act,
+            if constexpr (COOP) eval_lane<KIND, LDS, EW>(P, tr, p, act ? te : x, pert, pose_lane, own_grad, val, pvel, g_direct, &mwg, act,
                                                            (iter > 0 && lane != 18) ? fx : __builtin_inf());
             else if (act) eval_lane<KIND, LDS>(P, tr, p, te, pert, pose_lane, own_grad, val, pvel, g_direct);
             n_pass++;
@@ -1078,7 +1169,7 @@ void launch_swept_sweep(const SweptParams &P, hipStream_t stream, hipEvent_t ev_
     const int n = P.point_end - P.point_begin;
     if (n <= 0) return;
     // (larger mesh robots: one point / task per workgroup)
-    const bool mesh_wg = P.shape.kind == ISDF_SHAPE_MESH && P.shape.mesh_wg;
+    const bool mesh_wg = P.shape.kind == ISDF_SHAPE_MESH && P.shape.mesh_wg && !P.shape.mesh_flat;
     const dim3 grid(mesh_wg ? n : (n + SW_WAVES - 1) / SW_WAVES), block(64 * SW_WAVES);
     const size_t lds = traj_lds_bytes(P.N);
     const bool in_lds = lds <= TRAJ_LDS_MAX;
@@ -1089,11 +1180,20 @@ void launch_swept_sweep(const SweptParams &P, hipStream_t stream, hipEvent_t ev_
                                    else { hipExtLaunchKernelGGL((swept_scan_kernel<K, false>), grid, block, 0, stream, ev_start, nullptr, 0, P); \
                                           hipExtLaunchKernelGGL((swept_descent_kernel<K, false>), grid, block, 0, stream, nullptr, ev_stop, 0, P); } break;
     if (P.shape.kind == ISDF_SHAPE_MESH && P.shape.mesh_flat) {
-        // small meshes: one point / task per one-wavefront workgroup, the flat evaluation; dynamic LDS = the wavefront's [16][64] slot values
-        const dim3 grid1(n);
-        const size_t om = (size_t)16 * MESH_FLAT_SLOTS * sizeof(float);
-        hipExtLaunchKernelGGL((swept_scan_kernel<ISDF_SHAPE_MESH, false, 3>), grid1, dim3(64), om, stream, ev_start, nullptr, 0, P);
-        hipExtLaunchKernelGGL((swept_descent_kernel<ISDF_SHAPE_MESH, false, 3>), grid1, dim3(64), om, stream, nullptr, ev_stop, 0, P);
+        // small meshes: one point / task per WAVEFRONT (four to a workgroup, like the analytic kinds), the flat evaluation; dynamic LDS = the
+        // mesh's table blob (copied once per workgroup) + per wavefront its [16][slots] values; the trajectory stays in global memory
+        const size_t lds_flat = (size_t)P.shape.mesh_flat_words * sizeof(int) + (size_t)SW_WAVES * flat_om_floats(P.shape.mesh_flat_slots) * sizeof(float);
+        const size_t lds_traj = (traj_lds_bytes(P.N) + 15) & ~(size_t)15;
+        // (the trajectory in LDS as well while it leaves room for three workgroups per CU; ISDF_FLAT_TRAJ_LDS=0 / 1 forces)
+        static const int tl_env = []{ const char *e = getenv("ISDF_FLAT_TRAJ_LDS"); return e ? atoi(e) : -1; }();
+        const bool traj_in_lds = tl_env >= 0 ? tl_env != 0 : lds_traj <= 12 * 1024;
+        if (traj_in_lds && lds_traj + lds_flat <= 40 * 1024) {
+            hipExtLaunchKernelGGL((swept_scan_kernel<ISDF_SHAPE_MESH, true, 3>), grid, block, lds_traj + lds_flat, stream, ev_start, nullptr, 0, P);
+            hipExtLaunchKernelGGL((swept_descent_kernel<ISDF_SHAPE_MESH, true, 3>), grid, block, lds_traj + lds_flat, stream, nullptr, ev_stop, 0, P);
+        } else {
+            hipExtLaunchKernelGGL((swept_scan_kernel<ISDF_SHAPE_MESH, false, 3>), grid, block, lds_flat, stream, ev_start, nullptr, 0, P);
+            hipExtLaunchKernelGGL((swept_descent_kernel<ISDF_SHAPE_MESH, false, 3>), grid, block, lds_flat, stream, nullptr, ev_stop, 0, P);
+        }
         return;
     }
     if (mesh_wg) {

@@ -431,10 +431,11 @@ class Engine:
     # ---- instrumentation
     def mesh_info(self):
         """isdf_mesh_info as a dict (faces, nodes, depth, wg, closed, solid, lattice dims, measured |1 - 2w| range)"""
-        a = (C.c_int * 12)()
+        a = (C.c_int * 16)()
         self._check(self.lib.isdf_mesh_info(self.h, a))
         return {"faces": a[0], "nodes": a[1], "depth": a[2], "wg": a[3], "closed": a[4], "solid": a[5], "lattice": (a[6], a[7], a[8]),
-                "s_range": (a[9] * 1e-6, a[10] * 1e-6), "flat_slots": a[11]}
+                "s_range": (a[9] * 1e-6, a[10] * 1e-6), "flat_slots": a[11],
+                "defect_thickness": a[12] * 1e-9, "defect_s": a[13] * 1e-3}
 
     def multi_info(self):
         n = C.c_int(0); m = C.c_int(0)

@@ -174,16 +174,20 @@ int isdf_multi_info(const isdf_ctx *ctx, int *n_devices_out, int *collective_out
 /* What isdf_set_shape found and decided about the installed MESH robot (all zero for another kind):
  *   [0] faces  [1] nodes of the winding-number hierarchy  [2] its depth  [3] 1: one swept-volume task per workgroup (quad walks)
  *   [4] 1: every edge is shared by two faces with opposite directions (closed, consistently oriented)
- *   [5] 1: the EXACT winding number is 0 / 1 on the two sides of every face, jump +1 (the surface bounds a solid: no nested sheets
- *       of one orientation, no overlapping or inverted components, no tears); 0: it is not; -1: not tested (no lattice wanted)
+ *   [5] 1: the EXACT winding number is 0 / 1 on the two sides of every face (the surface bounds a solid: no nested sheets of one
+ *       orientation, no overlapping or inverted bodies, no tears) - or becomes so within a tenth of the lattice's reach of the face:
+ *       a DEFECT pocket of known thickness ([12], [13]; the reference's Trefoil.obj has 18 folded sliver faces), which the lattice's
+ *       users allow for; 0: it is not; -1: not tested (no lattice wanted)
  *   [6..8] nodes of the distance lattice per axis (0: none - the mesh failed [4], [5] or the measured range below, or
  *       ISDF_NO_F32_FILTER=1; every query then walks the hierarchy, results are the same bits)
  *   [9], [10] 1e6 x the smallest / largest |1 - 2 w| the reference's approximate winding number took at the lattice's sample
  *       points away from the surface (nodes, cell centres, edge midpoints; a lattice is kept only for 0.96 ... 1.04)
  *   [11] (node, child) slots of the FLAT evaluation small meshes get in the swept-volume sweep (<= 64 slots: the reference's
  *       12- to 20-face robots; 0: the hierarchy is walked).
+ *   [12] 1e9 x the thickness (m) of the thickest defect pocket found next to a face (0: a clean surface)  [13] 1e3 x the largest
+ *       |1 - 2 w| inside one  [14], [15] 0.
  * Replaces: nothing (the reference builds its libigl structures without checks, Shape.cpp:60-103). */
-int isdf_mesh_info(const isdf_ctx *ctx, int info_out[12]);
+int isdf_mesh_info(const isdf_ctx *ctx, int info_out[16]);
 int isdf_destroy(isdf_ctx *ctx);
 const char *isdf_last_error(const isdf_ctx *ctx);          /* ctx may be NULL: last create() failure      */
 int isdf_abi_version(void);

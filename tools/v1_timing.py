@@ -19,7 +19,7 @@ def pct(a):
 
 which = sys.argv[1] if len(sys.argv) > 1 else "cone"
 NP = 40
-if which == "c5blob":          # the C5-shaped bench entry: 512^3 occupancy @ 0.1 m, 20 pieces, the 720-face blob
+if which in ("c5blob", "c5lthick"):          # the C5-shaped bench entries: 512^3 occupancy @ 0.1 m, 20 pieces, the 720-face blob / the reference's Lthick.obj
     res = 0.1; NP = 20
     occ = synth.random_box_map((512,) * 3, res=res, occupancy=0.15, seed=12345, edge=(0.4, 2.0))
     T, Cf = synth.random_trajectory(np.array(occ.shape) * res, NP, seed=780, piece_T=1.0, jitter=0.5, margin=4.0, occ=occ, res=res)
@@ -31,6 +31,9 @@ if which == "box":
     shape = synth.bench_box_shape()
 elif which == "mesh20":
     shape = synth.make_mesh_shape(*synth.l_prism_mesh())
+elif which == "c5lthick":
+    from benchlib.meshes import reference_mesh
+    shape = synth.make_mesh_shape(*reference_mesh("Lthick", 0.83))
 elif which in ("mesh720", "c5blob"):
     shape = synth.make_mesh_shape(*synth.blob_mesh(24, 16, scale=0.9))
 else:
@@ -38,11 +41,11 @@ else:
 cfg1 = synth.default_config(capi.V1_SWEPT, safety_hor=(3 ** 0.5 / 2) * res, weight_p=4000.0)
 eng = pkg.Engine(cfg1); eng.set_grid(occ, (0, 0, 0), res, capi.GRID_OCCUPANCY); eng.set_shape(shape)
 way = cm.reshape(3, -1).T.reshape(NP, 6, 3)[1:, 0, :]
-M = eng.gather_points(way, 0.9 if which == 'c5blob' else 1.4)
+M = eng.gather_points(way, 0.9 if which.startswith('c5') else 1.4)
 dev = torch.device("cuda", 0); st = torch.cuda.current_stream().cuda_stream
 d_T = torch.from_numpy(T).to(dev); d_C = torch.from_numpy(cm).to(dev)
 d_out = torch.zeros(eng.out_stride(NP), dtype=torch.float64, device=dev)
-for _ in range(3 if which.startswith('mesh') else 6):
+for _ in range(3 if (which.startswith('mesh') or which.startswith('c5')) else 6):
     eng.eval_device(1, NP, d_T.data_ptr(), d_C.data_ptr(), d_out.data_ptr(), 0, st)
 torch.cuda.synchronize()
 lib = eng.lib
