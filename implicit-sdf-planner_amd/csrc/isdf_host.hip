@@ -457,10 +457,13 @@ extern "C" int isdf_set_shape(isdf_ctx *c, const isdf_shape *s) {
                 hm.flat = c->d_mesh_flat; hm.flat_slots = n_slots; hm.flat_nodes = nn; hm.flat_levels = n_levels;
             }
         }
-        // one task per workgroup pays when a pass is long (measured: 20 faces 1.15 -> 1.95 ms, 720 faces faster); ISDF_MESH_WG=0/1 forces
+        // Which form the swept-volume sweep takes: the FLAT evaluation for small meshes (<= 64 slots: the reference's 12- to 20-face
+        // robots), else one task per workgroup with the quad-cooperative walks (round 6, C5 shape: drone.obj, 52 faces, 1.50 ms against
+        // 1.69 with the wave-cooperative walks, kuang.obj, 60 faces, 1.96 / 2.26, box.obj, 96 faces, 3.6 / 4.7); the wave-cooperative
+        // walks keep the hierarchies deeper than MESH_Q_LEVELS.  ISDF_MESH_WG=0/1, ISDF_MESH_FLAT=0 force.
         d.mesh_levels = std::max(2, std::min(depth, isdf::MESH_Q_LEVELS));
         c->mesh_depth = depth;
-        d.mesh_wg = (s->n_faces >= 64 && depth <= isdf::MESH_Q_LEVELS) ? 1 : 0;
+        d.mesh_wg = depth <= isdf::MESH_Q_LEVELS ? 1 : 0;
         if (const char *e = getenv("ISDF_MESH_WG")) d.mesh_wg = (e[0] == '1' && depth <= isdf::MESH_Q_LEVELS) ? 1 : 0;
         // small meshes: the flat evaluation (one task per workgroup as well); ISDF_MESH_FLAT=0 keeps the walks (A/B runs, tests)
         d.mesh_flat = hm.flat ? 1 : 0;

@@ -203,6 +203,7 @@ struct MeshWG {
     int n_waves;         // wavefronts of the workgroup (2 in the scan: up to 64 queries per pass; 1 in the descent: at most 14, 19 in a first pass without a seed)
     FlatLds flat;        // small meshes (FLAT form: every wavefront has a task of its own, stage / res are the wavefront's): the LDS copy of the tables
 };
+constexpr int MF_QUAD = 1, MF_FLAT = 2;      // forms of the cooperative evaluation (template parameter FORM below)
 constexpr int MESH_WG_RES = 2 * 64 * 5;
 constexpr int mesh_wg_stage(int nw) { return nw * 64 * 4; }
 // The queries of a pass go through three steps (every lane of all the workgroup's wavefronts calls each of them):
@@ -223,8 +224,9 @@ __device__ __forceinline__ int mesh_wg_push(MeshWG &X, const DevMesh *m, d3 pr, 
     X.count += __popcll(mask);
     return act ? idx : -1;
 }
-template <bool FLAT>
+template <int FORM>
 __device__ inline void mesh_wg_flush(MeshWG &X, const DevMesh *m) {
+    constexpr bool FLAT = FORM == MF_FLAT;
     const int lane = (int)__lane_id();
     const int n_act = X.count;
     X.count = 0;
@@ -257,25 +259,26 @@ __device__ inline void mesh_wg_flush(MeshWG &X, const DevMesh *m) {
     // in their own control flow: no workgroup barrier)
     if constexpr (FLAT) flat_lds_sync(); else __syncthreads();
 }
-template <bool FLAT>
+template <int FORM>
 __device__ __forceinline__ bool mesh_wg_get(const MeshWG &X, int idx, double &sdf, d3 &g) {
+    constexpr bool FLAT = FORM == MF_FLAT;
     if (idx < 0) return false;
     const double *o = X.res + (FLAT ? 0 : (size_t)X.parity * 64 * 5) + 5 * idx;
     sdf = o[1]; g = mk3(o[2], o[3], o[4]);
     return o[0] != 0.0;
 }
 // one pass by itself
-template <bool FLAT>
+template <int FORM>
 __device__ inline bool mesh_eval_wg(MeshWG &X, const DevMesh *m, d3 pr, bool act, double cap, double &sdf, d3 &g) {
     const int idx = mesh_wg_push(X, m, pr, act, cap);
-    mesh_wg_flush<FLAT>(X, m);
-    return mesh_wg_get<FLAT>(X, idx, sdf, g);
+    mesh_wg_flush<FORM>(X, m);
+    return mesh_wg_get<FORM>(X, idx, sdf, g);
 }
 
 // ---- the ONE pose + SDF evaluation both kernels below are built around: pose at `te`, body-frame point (perturbed for a
 // gradient sample), shape SDF; pose lanes also form the body-frame point velocity (getSDF_DOTAtTimeStampOptimized :593-662).
 // Analytic kinds: called by the lanes that evaluate.  Mesh kind: called by ALL lanes of the workgroup, `act` says which evaluate.
-template <int KIND, bool LDS, int WG = 0, bool CAPPED = false>      // WG: 0 per lane / wave-cooperative, 1 workgroup form with the quad walks, 2 ... with the flat evaluation
+template <int KIND, bool LDS, int WG = 0, bool CAPPED = false>      // WG: 0 per lane / wave-cooperative, else the cooperative form (MF_QUAD, MF_FLAT)
 __device__ __forceinline__ void eval_lane(const SweptParams &P, const TrajL<LDS> &tr, const d3 p, const double te, const int pert,
                                           const bool pose_lane, const bool own_grad, double &val, d3 &pvel, d3 &g_direct,
                                           MeshWG *X = nullptr, const bool act = true, const double cap = __builtin_inf()) {
@@ -312,7 +315,7 @@ __device__ __forceinline__ void eval_lane(const SweptParams &P, const TrajL<LDS>
         // one hierarchy query per evaluating lane gives value AND gradient (the pose lanes keep the gradient)
         d3 gq = mk3(0, 0, 0);
         double v = 1e300;
-        const bool below = mesh_eval_wg<WG == 2>(*X, P.shape.mesh, pr, act, cap, v, gq);      // (cap: "sdf >= cap" may be answered without the value)
+        const bool below = mesh_eval_wg<WG>(*X, P.shape.mesh, pr, act, cap, v, gq);      // (cap: "sdf >= cap" may be answered without the value)
         if (act && below) val = v;
         if (act && pose_lane) g_direct = gq;
     } else if constexpr (KIND == ISDF_SHAPE_MESH) {
@@ -340,7 +343,7 @@ __device__ __forceinline__ void scan_body(const SweptParams &P, double *s_dyn, c
     constexpr bool COOP = WGM != 0;      // the evaluating lanes' mesh queries go through mesh_eval_wg (compacted, 4 lanes per query)
     constexpr bool FLAT = WGM == 3;      // ... small meshes: the flat evaluation instead of the walks; one point per WAVEFRONT like the analytic kinds
     constexpr bool MESH = COOP && !FLAT; // one point per WORKGROUP of WGW wavefronts (mesh_eval_wg above: larger mesh robots), else one per wavefront
-    constexpr int WGW = FLAT ? 1 : WGM, EW = FLAT ? 2 : 1;
+    constexpr int WGW = FLAT ? 1 : WGM, EW = FLAT ? MF_FLAT : MF_QUAD;
     static_assert(!WGM || KIND == ISDF_SHAPE_MESH, "workgroup-cooperative evaluation is the mesh kind's");
     __shared__ double s_rl[SW_WAVES][SW_MAX_RANGES], s_rr[SW_WAVES][SW_MAX_RANGES];
     __shared__ unsigned s_cnt[SW_WAVES][2], s_base[2];
@@ -430,7 +433,7 @@ __device__ __forceinline__ void scan_body(const SweptParams &P, double *s_dyn, c
         __shared__ int s_wi[SW_WAVES][SW_GROUP][2];
         int g_n = 0;
         auto flush_group = [&]() {
-            mesh_wg_flush<FLAT>(mwg, P.shape.mesh);
+            mesh_wg_flush<EW>(mwg, P.shape.mesh);
             flat_lds_sync();
             for (int w = 0; w < g_n; w++) {
                 const int base = s_wi[wave][w][0], lbase = s_wi[wave][w][1];
@@ -441,7 +444,7 @@ __device__ __forceinline__ void scan_body(const SweptParams &P, double *s_dyn, c
                 if ((amask >> lane) & 1ull) {
                     d3 g_unused;
                     double sdf = 1e9;
-                    if (mesh_wg_get<FLAT>(mwg, lbase + __popcll(amask & ((1ull << lane) - 1ull)), sdf, g_unused)) dis = sdf;
+                    if (mesh_wg_get<EW>(mwg, lbase + __popcll(amask & ((1ull << lane) - 1ull)), sdf, g_unused)) dis = sdf;
                 }
                 // (a sample the lattice put in range without a query - `skip` below - is never the first of a run: only its being in range is used)
                 const unsigned long long in_mask = __ballot((k < n_coarse) && (dis < inf)) | smask;
@@ -639,7 +642,7 @@ __device__ __forceinline__ void descent_body(const SweptParams &P, double *s_dyn
     constexpr bool COOP = WGM != 0;      // mesh queries through mesh_eval_wg, DIRECTED passes
     constexpr bool FLAT = WGM == 3;      // ... small meshes: the flat evaluation, one task per WAVEFRONT
     constexpr bool MESH = COOP && !FLAT; // one task per WORKGROUP of WGW wavefronts (mesh_eval_wg), else one per wavefront
-    constexpr int WGW = FLAT ? 1 : WGM, EW = FLAT ? 2 : 1;
+    constexpr int WGW = FLAT ? 1 : WGM, EW = FLAT ? MF_FLAT : MF_QUAD;
     __shared__ double s_mesh[FLAT ? SW_WAVES * (64 * 4 + 64 * 5) : (MESH ? mesh_wg_stage(WGW) + MESH_WG_RES : 1)];
     TrajL<LDS> tr{P.T, P.coeffs, P.N};
     if constexpr (LDS) tr = traj_stage(s_dyn, P.T, P.coeffs, P.N);
@@ -1197,6 +1200,11 @@ void launch_swept_sweep(const SweptParams &P, hipStream_t stream, hipEvent_t ev_
         return;
     }
     if (mesh_wg) {
+        // (Round 6, measured and dropped: a TREE-SPLIT form for launches that do not fill the device - a rank's eighth of the points -
+        // with four wavefronts per task, one child of the hierarchy's root each, parts combined in child order (bit-exact).  The queries
+        // of a pass are neighbours: what they open lies in ONE child of the root, so one wavefront still walks the whole chain while the
+        // others find their subtree's nearest triangle for nothing: rank step of the 720-face blob 2.29 -> 2.22 ms, Trefoil.obj 2.48 ->
+        // 3.27, 2.18 -> 3.10 (profiles/r6_c5_shard_ranks.txt).)
         // scan: two wavefronts per point (a fine pass has up to 64 queries: two quad rounds each)
         const dim3 block2(128);
         const size_t fr2 = (size_t)2 * mesh_frames_words(P.shape.mesh_levels) * sizeof(unsigned);      // two wavefronts' frames
@@ -1216,7 +1224,8 @@ void launch_swept_sweep(const SweptParams &P, hipStream_t stream, hipEvent_t ev_
         // workgroups, twice the tasks in flight.  Measured against two wavefronts per task (the second one idle but for a first pass
         // without a usable seed): 16 611 points, blob 9.63 -> 7.78 ms, Trefoil.obj 6.62 -> 5.68; an eighth of them (a rank's shard of
         // an 8-GPU step) 1.98 -> 1.94 / 2.45 -> 2.44; bench map, 7 773 points, 3.71 -> 3.65 ms.
-        hipExtLaunchKernelGGL((swept_descent_kernel<ISDF_SHAPE_MESH, false, 1>), grid, dim3(64), fr2 / 2, stream, nullptr, ev_stop, 0, P);
+        // (a launch of less than a generation: workgroups for half as many tasks again as points - the excess ones find no task and leave)
+        hipExtLaunchKernelGGL((swept_descent_kernel<ISDF_SHAPE_MESH, false, 1>), n < 4096 ? dim3(n + n / 2 + 16) : grid, dim3(64), fr2 / 2, stream, nullptr, ev_stop, 0, P);
         return;
     }
     switch (P.shape.kind) {

@@ -375,7 +375,7 @@ def test_distance_lattice_on_adversarial_meshes(pkg, orc, product_lib, monkeypat
             monkeypatch.setenv("ISDF_NO_F32_FILTER", off)
             cfg1 = synth.default_config(capi.V1_SWEPT, safety_hor=0.3)
             e1 = pkg.Engine(cfg1); e1.set_grid(occ, (0, 0, 0), res, capi.GRID_OCCUPANCY); e1.set_shape(synth.make_mesh_shape(V, F)); e1.set_points(pts)
-            infos[(wg if form != "flat" else "flat", off)] = e1.mesh_info()
+            infos[(wg if form in ("quad", "wave") else form, off)] = e1.mesh_info()
             ts = -np.ones(len(pts))
             steps = []
             for _ in range(2):

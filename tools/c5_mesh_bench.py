@@ -18,7 +18,8 @@ way5 = cm5.reshape(3, -1).T.reshape(20, 6, 3)[1:, 0, :]
 dev = torch.device("cuda", 0); st = torch.cuda.current_stream().cuda_stream
 dT = torch.from_numpy(T5).to(dev); dC = torch.from_numpy(cm5).to(dev)
 meshes = {"lprism": synth.l_prism_mesh, "blob720": lambda: synth.blob_mesh(24, 16, scale=0.9), "lthick": lambda: reference_mesh("Lthick", 0.83),
-          "trefoil": lambda: reference_mesh("Trefoil", 0.83)}
+          "trefoil": lambda: reference_mesh("Trefoil", 0.83), "mybox": lambda: reference_mesh("mybox", 0.83), "drone": lambda: reference_mesh("drone", 0.83),
+          "kuang": lambda: reference_mesh("kuang", 0.83), "box96": lambda: reference_mesh("box", 0.83), "icosa": lambda: reference_mesh("icosahedron", 0.83)}
 shards = [int(a.split("=")[1]) for a in sys.argv[1:] if a.startswith("--shards=")]
 rank = ([int(a.split("=")[1]) for a in sys.argv[1:] if a.startswith("--rank=")] or [0])[0]
 names = [a for a in sys.argv[1:] if not a.startswith("--")]

@@ -42,6 +42,8 @@ cfg1 = synth.default_config(capi.V1_SWEPT, safety_hor=(3 ** 0.5 / 2) * res, weig
 eng = pkg.Engine(cfg1); eng.set_grid(occ, (0, 0, 0), res, capi.GRID_OCCUPANCY); eng.set_shape(shape)
 way = cm.reshape(3, -1).T.reshape(NP, 6, 3)[1:, 0, :]
 M = eng.gather_points(way, 0.9 if which.startswith('c5') else 1.4)
+if os.environ.get('V1_TIMING_SHARD'):      # 'rank/world': one rank's contiguous share of the points
+    r_, w_ = os.environ['V1_TIMING_SHARD'].split('/'); eng.set_shard(int(r_), int(w_))
 dev = torch.device("cuda", 0); st = torch.cuda.current_stream().cuda_stream
 d_T = torch.from_numpy(T).to(dev); d_C = torch.from_numpy(cm).to(dev)
 d_out = torch.zeros(eng.out_stride(NP), dtype=torch.float64, device=dev)
