@@ -278,10 +278,9 @@ __device__ inline bool mesh_eval_wg(MeshWG &X, const DevMesh *m, d3 pr, bool act
 // ---- the ONE pose + SDF evaluation both kernels below are built around: pose at `te`, body-frame point (perturbed for a
 // gradient sample), shape SDF; pose lanes also form the body-frame point velocity (getSDF_DOTAtTimeStampOptimized :593-662).
 // Analytic kinds: called by the lanes that evaluate.  Mesh kind: called by ALL lanes of the workgroup, `act` says which evaluate.
-template <int KIND, bool LDS, int WG = 0, bool CAPPED = false>      // WG: 0 per lane / wave-cooperative, else the cooperative form (MF_QUAD, MF_FLAT)
-__device__ __forceinline__ void eval_lane(const SweptParams &P, const TrajL<LDS> &tr, const d3 p, const double te, const int pert,
-                                          const bool pose_lane, const bool own_grad, double &val, d3 &pvel, d3 &g_direct,
-                                          MeshWG *X = nullptr, const bool act = true, const double cap = __builtin_inf()) {
+// the pose half: body-frame point of p at time te and, on pose lanes, its body-frame velocity; R comes back for the analytic kinds' own gradient
+template <bool LDS>
+__device__ __forceinline__ void eval_pose(const SweptParams &P, const TrajL<LDS> &tr, const d3 p, const double te, const bool pose_lane, d3 &pr, d3 &pvel) {
     double tl = te;
     const int pi = traj_locate_l(tr, tl);
     d3 xt, vt, at, jt;
@@ -289,7 +288,7 @@ __device__ __forceinline__ void eval_lane(const SweptParams &P, const TrajL<LDS>
     FlatS fs;
     flat_core(P.flat, vt, at, fs);
     const m3 R = quat_to_rot(flat_quat(fs));
-    d3 pr = mat_tmul(R, p - xt);
+    pr = mat_tmul(R, p - xt);
     if (pose_lane) {
         FlatS2 ft;
         flat_core2(P.flat, vt, at, jt, fs, ft);
@@ -298,8 +297,15 @@ __device__ __forceinline__ void eval_lane(const SweptParams &P, const TrajL<LDS>
                           (-omg.y) * pr.x + omg.x * pr.y + 0 * pr.z);
         const d3 rv = mat_tmul(R, vt);
         pvel = mk3(-(rv.x + wx.x), -(rv.y + wx.y), -(rv.z + wx.z));
-        if constexpr (KIND != ISDF_SHAPE_MESH) if (own_grad) g_direct = shape_grad<KIND>(P.shape, pr);     // Ball: own gradient
     }
+}
+template <int KIND, bool LDS, int WG = 0, bool CAPPED = false>      // WG: 0 per lane / wave-cooperative, else the cooperative form (MF_QUAD, MF_FLAT)
+__device__ __forceinline__ void eval_lane(const SweptParams &P, const TrajL<LDS> &tr, const d3 p, const double te, const int pert,
+                                          const bool pose_lane, const bool own_grad, double &val, d3 &pvel, d3 &g_direct,
+                                          MeshWG *X = nullptr, const bool act = true, const double cap = __builtin_inf()) {
+    d3 pr;
+    eval_pose(P, tr, p, te, pose_lane, pr, pvel);
+    if constexpr (KIND != ISDF_SHAPE_MESH) if (pose_lane && own_grad) g_direct = shape_grad<KIND>(P.shape, pr);     // Ball: own gradient
     if (pert >= 1 && pert <= 6) {            // temp(a) -= dx; [temp(a) += 2 dx]  (Shape.hpp:36-54)
         const int a = (pert - 1) >> 1;
         const double dx = 0.000005;
@@ -539,15 +545,23 @@ __device__ __forceinline__ void scan_body(const SweptParams &P, double *s_dyn, c
                 // cannot be the first minimum, nor tie with it - it needs no query.  An obstacle point the robot passes over keeps
                 // the samples around the deepest one, a handful of 64.
                 const double te_q = act ? te : lb;
-                d3 xq; m3 Rq;
-                pose_at(P, tr, te_q, xq, Rq);
+                d3 prq;
+                eval_pose(P, tr, p, te_q, COOP, prq, pv_unused);      // (ONE pose evaluation per sample: the lattice and the query see the same point)
                 double s_lb, s_ub;
-                const bool known = mesh_lattice_bounds(P.shape.mesh, mat_tmul(Rq, p - xq), s_lb, s_ub);
+                const bool known = mesh_lattice_bounds(P.shape.mesh, prq, s_lb, s_ub);
                 int a_ub;
                 const double ub_min = wave_first_min((act && known) ? s_ub : 1.7976931348623157e308, lane, 64, a_ub);
                 const bool keep = act && !(known && s_lb > ub_min);
-                if constexpr (COOP) eval_lane<KIND, LDS, EW>(P, tr, p, te_q, 0, true, true, val, pv_unused, g_unused, &mwg, keep, range_mindis);
-                else if (keep) eval_lane<KIND, LDS, 0, true>(P, tr, p, te, 0, false, false, val, pv_unused, g_unused, nullptr, true, range_mindis);
+                if constexpr (COOP) {
+                    d3 gq = mk3(0, 0, 0);
+                    double v = 1e300;
+                    if (mesh_eval_wg<EW>(mwg, P.shape.mesh, prq, keep, range_mindis, v, gq) && keep) val = v;
+                    if (keep) g_unused = gq;
+                } else if (keep) {
+                    d3 gq = mk3(0, 0, 0);
+                    double v = 1e300;
+                    if (mesh_sdf_grad_below_wave(P.shape.mesh, prq, range_mindis, v, gq)) val = v;
+                }
             }
             else if (act) eval_lane<KIND, LDS, 0, false>(P, tr, p, te, 0, false, false, val, pv_unused, g_unused, nullptr, true, range_mindis);
             n_pass++;
