@@ -719,10 +719,10 @@ __device__ __forceinline__ bool mesh_slot_term(const float *rq, bool tri, float 
 
 // F: the workgroup's copy of DevMesh::flat in LDS (tables, records, fp64 triangles) and this wavefront's [16][nsp] slot values
 struct FlatLds { const int *tab; const float *rec; const double *trec; float *om; int n_slots, n_levels, nsp; };
-__device__ __forceinline__ FlatLds flat_lds_view(const DevMesh *m, int *blob, float *om) {
-    const mesh_cptr<DevMesh> mu = mesh_const_uni(m);
-    const int ns = mu->flat_slots;
-    return FlatLds{blob, reinterpret_cast<const float *>(blob + mu->flat_rec), reinterpret_cast<const double *>(blob + mu->flat_trec), om, ns, mu->flat_levels, (ns + 3) & ~3};
+// (the blob describes itself: header ints [19] slots, [20] levels, [22] / [23] where the records / the fp64 triangles begin)
+__device__ __forceinline__ FlatLds flat_lds_view(int *blob, float *om) {
+    const int ns = mesh_uni(blob[19]);
+    return FlatLds{blob, reinterpret_cast<const float *>(blob + mesh_uni(blob[22])), reinterpret_cast<const double *>(blob + mesh_uni(blob[23])), om, ns, mesh_uni(blob[20]), (ns + 3) & ~3};
 }
 __host__ __device__ constexpr int flat_om_floats(int n_slots) { return 16 * ((n_slots + 3) & ~3); }
 // all threads of the workgroup: the blob into LDS (16 bytes per thread and round)
@@ -739,7 +739,7 @@ __device__ inline bool mesh_sdf_grad_below_flat(const FlatLds &F, d3 p, bool act
     if (!__ballot(act)) return false;
     const int *fl = F.tab;
     const int n_slots = F.n_slots, n_levels = F.n_levels, n_tris = fl[18];
-    const int *slots = fl + 20, *tris = slots + 4 * n_slots, *nodes = tris + n_tris;
+    const int *slots = fl + 24, *tris = slots + 4 * n_slots, *nodes = tris + n_tris;
     float *const om = F.om + qd * F.nsp;
     const float qx = (float)p.x, qy = (float)p.y, qz = (float)p.z;
     // ---- far-field terms, level by level

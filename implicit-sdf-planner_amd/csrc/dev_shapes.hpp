@@ -43,10 +43,8 @@ struct DevMesh {
     float dl_tau, dl_slack;
     // Small meshes (the reference's own robots: 12-52 faces), FLAT evaluation (dev_mesh.hpp, mesh_sdf_grad_below_flat): the whole hierarchy
     // as a table of its (node, child) SLOTS in level order, so that the four lanes of a query sweep a level's slots side by side instead
-    // of walking node by node.  flat: [0..8] slot index where level l begins (9 entries, the last = slots), [9..17] the same for the
-    // combine steps over the nodes (deepest level first), [18] triangles, [19] 0, then per slot 4 ints (record = 4 node + child: the index into
-    // fwn_boxq / fwn_triq; parent slot or -1; triangle index or -1; level), per triangle its slot, per node (deepest first) 5 ints
-    // (own slot or -1 for the root; its four child slots or -1).  null: the mesh does not qualify (more than MESH_FLAT_SLOTS slots).
+    // of walking node by node.  flat: a self-describing blob (isdf_host.hip build_blob: a header of 24 ints, per slot 4 ints, per triangle
+    // its slot, per node 5 ints, then the slots' records and fp64 triangles).  null: the mesh does not qualify (more than MESH_FLAT_SLOTS slots).
     // Behind the tables, in the same allocation: the slots' records (flat_rec, in 4-byte units from `flat`: MESH_Q_REC floats per slot, the
     // fwn_boxq record of the slot's (node, child)) and their fp64 triangles (flat_trec: MESH_Q_TRI doubles per slot).  The swept-volume
     // kernels copy the whole blob (flat_words 4-byte words, a multiple of 4) into LDS once per workgroup.

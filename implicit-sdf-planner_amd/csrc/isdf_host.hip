@@ -5,7 +5,9 @@
 #include "isdf_ctx.hpp"
 #include "minco_dev.hpp"
 #include "lbfgs_host.hpp"
+#include <array>
 #include <atomic>
+#include <map>
 #include <dlfcn.h>
 #include <chrono>
 #include <cmath>
@@ -392,69 +394,82 @@ extern "C" int isdf_set_shape(isdf_ctx *c, const isdf_shape *s) {
         HIPCHK(c, hipMemcpy(c->d_fwn_triq, triq.data(), triq.size() * sizeof(double), hipMemcpyHostToDevice));
         DevMesh hm{c->d_mesh_tri, c->d_mesh_trif, s->n_faces, c->d_fwn_child, c->d_fwn_box, tree.n_nodes(), c->d_fwn_boxq, c->d_fwn_triq, depth, nullptr, {0, 0, 0}, {0.f, 0.f, 0.f}, 0.f, 0.f, 0.f, 0.f,
                    nullptr, 0, 0, 0, 0, 0, 0};
-        // Small meshes: the flat slot table (DevMesh::flat) - levels by breadth-first search from the root
-        {
-            const int nn = tree.n_nodes();
-            std::vector<int> node_level((size_t)nn, -1), node_slot((size_t)nn, -1), order;
-            node_level[0] = 0; order.push_back(0);
+        // The flat slot table of a (sub)tree rooted at `root` (DevMesh::flat / DevMesh::sub) - levels by breadth-first search from it.
+        // ONE self-describing blob, copied into LDS as it is: a header of 24 ints ([0..8] the slot index where level l begins, [9..17]
+        // the same for the combine steps over the nodes, deepest level first, [18] triangles, [19] slots, [20] levels, [21] the blob's
+        // size in 4-byte words, [22] / [23] where the records / the fp64 triangles begin), per slot 4 ints (record = 4 node + child,
+        // parent slot or -1, triangle index or -1, level), per triangle its slot, per node (deepest first) 5 ints (own slot or -1 for the
+        // root, its four child slots or -1), then per slot its fwn_boxq record (MESH_Q_REC floats) and its fwn_triq triangle
+        // (MESH_Q_TRI doubles).  Empty: the subtree does not qualify (more than max_slots slots, or too deep).
+        const int nn_all = tree.n_nodes();
+        auto build_blob = [&](const int root, const int max_slots) -> std::vector<int> {
+            std::vector<int> node_level((size_t)nn_all, -1), node_slot((size_t)nn_all, -1), order;
+            node_level[root] = 0; order.push_back(root);
+            int n_slots = 0;
             for (size_t h = 0; h < order.size(); h++) {
                 const int nd = order[h];
                 for (int ch = 0; ch < 4; ch++) {
                     const int32_t ci = tree.child[(size_t)4 * nd + ch];
-                    if (ci != -1 && ci < 0) { const int sub = ci & 0x7fffffff; if (node_level[sub] < 0) { node_level[sub] = node_level[nd] + 1; order.push_back(sub); } }
+                    if (ci == -1) continue;
+                    if (++n_slots > max_slots) return {};
+                    if (ci < 0) { const int sub = ci & 0x7fffffff; if (node_level[sub] < 0) { node_level[sub] = node_level[nd] + 1; order.push_back(sub); } }
                 }
             }
-            int n_slots = 0;
-            for (int nd = 0; nd < nn; nd++) for (int ch = 0; ch < 4; ch++) if (tree.child[(size_t)4 * nd + ch] != -1) n_slots++;
-            if ((int)order.size() == nn && n_slots <= isdf::MESH_FLAT_SLOTS && depth <= isdf::MESH_FLAT_LEVELS) {
-                // slots in (level of their node, node in search order, child) order
-                std::vector<int> slots, tris, nodes, lvl_begin(9, 0), step_begin(9, 0);
-                int cur_level = -1;
-                for (int nd : order) {
-                    if (node_level[nd] != cur_level) { cur_level = node_level[nd]; lvl_begin[cur_level] = (int)slots.size() / 4; }
-                    for (int ch = 0; ch < 4; ch++) {
-                        const int32_t ci = tree.child[(size_t)4 * nd + ch];
-                        if (ci == -1) continue;
-                        const int sl = (int)slots.size() / 4;
-                        if (ci < 0) node_slot[ci & 0x7fffffff] = sl;
-                        else tris.push_back(sl);
-                        slots.push_back(4 * nd + ch); slots.push_back(node_slot[nd]); slots.push_back(ci >= 0 ? ci : -1); slots.push_back(node_level[nd]);
-                    }
+            const int nn = (int)order.size();
+            // slots in (level of their node, node in search order, child) order
+            std::vector<int> slots, tris, nodes, lvl_begin(9, 0), step_begin(9, 0);
+            int cur_level = -1;
+            for (int nd : order) {
+                if (node_level[nd] != cur_level) { cur_level = node_level[nd]; if (cur_level >= isdf::MESH_FLAT_LEVELS) return {}; lvl_begin[cur_level] = (int)slots.size() / 4; }
+                for (int ch = 0; ch < 4; ch++) {
+                    const int32_t ci = tree.child[(size_t)4 * nd + ch];
+                    if (ci == -1) continue;
+                    const int sl = (int)slots.size() / 4;
+                    if (ci < 0) node_slot[ci & 0x7fffffff] = sl;
+                    else tris.push_back(sl);
+                    slots.push_back(4 * nd + ch); slots.push_back(node_slot[nd]); slots.push_back(ci >= 0 ? ci : -1); slots.push_back(node_level[nd]);
                 }
-                const int n_levels = cur_level + 1;
-                for (int l = n_levels; l < 9; l++) lvl_begin[l] = n_slots;
-                // combine steps: the nodes of the deepest level first; per node its own slot and its four child slots
-                std::vector<std::vector<int>> child_slots((size_t)nn, std::vector<int>(4, -1));
-                for (int sl = 0; sl < n_slots; sl++) { const int rec = slots[(size_t)4 * sl]; child_slots[rec >> 2][rec & 3] = sl; }
-                int step = 0;
-                for (int l = n_levels - 1; l >= 0; l--, step++) {
-                    step_begin[step] = (int)nodes.size() / 5;
-                    for (int nd : order) if (node_level[nd] == l) { nodes.push_back(node_slot[nd]); for (int ch = 0; ch < 4; ch++) nodes.push_back(child_slots[nd][ch]); }
-                }
-                for (int st = step; st < 9; st++) step_begin[st] = nn;
-                // ONE blob, copied into LDS as it is by every workgroup: [tables | per-slot record, 40 floats | per-slot fp64 triangle, 10 doubles]
-                std::vector<int> flat;
-                flat.insert(flat.end(), lvl_begin.begin(), lvl_begin.end());
-                flat.insert(flat.end(), step_begin.begin(), step_begin.end());
-                flat.push_back((int)tris.size());
-                flat.push_back(0);                                    // (pad: the slot records start 16-byte aligned)
-                flat.insert(flat.end(), slots.begin(), slots.end());
-                flat.insert(flat.end(), tris.begin(), tris.end());
-                flat.insert(flat.end(), nodes.begin(), nodes.end());
-                while (flat.size() % 4) flat.push_back(0);
-                const int rec_off = (int)flat.size();                 // (in 4-byte units)
-                flat.resize(flat.size() + (size_t)n_slots * isdf::MESH_Q_REC);
-                for (int sl = 0; sl < n_slots; sl++)
-                    std::memcpy(flat.data() + rec_off + (size_t)sl * isdf::MESH_Q_REC, boxq.data() + (size_t)slots[(size_t)4 * sl] * isdf::MESH_Q_REC, isdf::MESH_Q_REC * sizeof(float));
-                const int trec_off = (int)flat.size();
-                flat.resize(flat.size() + (size_t)n_slots * isdf::MESH_Q_TRI * 2);
-                for (int sl = 0; sl < n_slots; sl++)
-                    std::memcpy(flat.data() + trec_off + (size_t)sl * isdf::MESH_Q_TRI * 2, triq.data() + (size_t)slots[(size_t)4 * sl] * isdf::MESH_Q_TRI, isdf::MESH_Q_TRI * sizeof(double));
-                while (flat.size() % 4) flat.push_back(0);
+            }
+            const int n_levels = cur_level + 1;
+            for (int l = n_levels; l < 9; l++) lvl_begin[l] = n_slots;
+            // combine steps: the nodes of the deepest level first; per node its own slot and its four child slots
+            std::map<int, std::array<int, 4>> child_slots;
+            for (int nd : order) child_slots[nd] = {-1, -1, -1, -1};
+            for (int sl = 0; sl < n_slots; sl++) { const int rec = slots[(size_t)4 * sl]; child_slots[rec >> 2][rec & 3] = sl; }
+            int step = 0;
+            for (int l = n_levels - 1; l >= 0; l--, step++) {
+                step_begin[step] = (int)nodes.size() / 5;
+                for (int nd : order) if (node_level[nd] == l) { nodes.push_back(node_slot[nd]); for (int ch = 0; ch < 4; ch++) nodes.push_back(child_slots[nd][ch]); }
+            }
+            for (int st = step; st < 9; st++) step_begin[st] = nn;
+            std::vector<int> flat;
+            flat.insert(flat.end(), lvl_begin.begin(), lvl_begin.end());
+            flat.insert(flat.end(), step_begin.begin(), step_begin.end());
+            flat.push_back((int)tris.size()); flat.push_back(n_slots); flat.push_back(n_levels); flat.push_back(0); flat.push_back(0); flat.push_back(0);
+            flat.insert(flat.end(), slots.begin(), slots.end());
+            flat.insert(flat.end(), tris.begin(), tris.end());
+            flat.insert(flat.end(), nodes.begin(), nodes.end());
+            while (flat.size() % 4) flat.push_back(0);
+            const int rec_off = (int)flat.size();                 // (in 4-byte units)
+            flat.resize(flat.size() + (size_t)n_slots * isdf::MESH_Q_REC);
+            for (int sl = 0; sl < n_slots; sl++)
+                std::memcpy(flat.data() + rec_off + (size_t)sl * isdf::MESH_Q_REC, boxq.data() + (size_t)slots[(size_t)4 * sl] * isdf::MESH_Q_REC, isdf::MESH_Q_REC * sizeof(float));
+            const int trec_off = (int)flat.size();
+            flat.resize(flat.size() + (size_t)n_slots * isdf::MESH_Q_TRI * 2);
+            for (int sl = 0; sl < n_slots; sl++)
+                std::memcpy(flat.data() + trec_off + (size_t)sl * isdf::MESH_Q_TRI * 2, triq.data() + (size_t)slots[(size_t)4 * sl] * isdf::MESH_Q_TRI, isdf::MESH_Q_TRI * sizeof(double));
+            while (flat.size() % 4) flat.push_back(0);
+            flat[21] = (int)flat.size(); flat[22] = rec_off; flat[23] = trec_off;
+            return flat;
+        };
+        // Small meshes: the WHOLE hierarchy as one table
+        {
+            const std::vector<int> flat = build_blob(0, isdf::MESH_FLAT_SLOTS);
+            if (!flat.empty()) {
                 HIPCHK(c, hipMalloc(&c->d_mesh_flat, flat.size() * sizeof(int)));
                 HIPCHK(c, hipMemcpy(c->d_mesh_flat, flat.data(), flat.size() * sizeof(int), hipMemcpyHostToDevice));
-                hm.flat_words = (int)flat.size(); hm.flat_rec = rec_off; hm.flat_trec = trec_off;
-                hm.flat = c->d_mesh_flat; hm.flat_slots = n_slots; hm.flat_nodes = nn; hm.flat_levels = n_levels;
+                hm.flat_words = (int)flat.size(); hm.flat_rec = flat[22]; hm.flat_trec = flat[23];
+                hm.flat = c->d_mesh_flat; hm.flat_slots = flat[19]; hm.flat_nodes = nn_all; hm.flat_levels = flat[20];
             }
         }
         // Which form the swept-volume sweep takes: the FLAT evaluation for small meshes (<= 64 slots: the reference's 12- to 20-face

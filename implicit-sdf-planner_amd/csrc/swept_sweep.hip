@@ -372,7 +372,7 @@ __device__ __forceinline__ void scan_body(const SweptParams &P, double *s_dyn, c
         int *blob = reinterpret_cast<int *>(reinterpret_cast<char *>(s_dyn) + (LDS ? ((traj_lds_bytes(P.N) + 15) & ~(size_t)15) : 0));
         flat_lds_stage(P.shape.mesh, blob);
         mwg.stage = s_mesh + wave * (64 * 4 + 64 * 5); mwg.res = mwg.stage + 64 * 4; mwg.wave = 0;
-        mwg.flat = flat_lds_view(P.shape.mesh, blob, reinterpret_cast<float *>(blob + P.shape.mesh_flat_words) + wave * flat_om_floats(P.shape.mesh_flat_slots));
+        mwg.flat = flat_lds_view(blob, reinterpret_cast<float *>(blob + P.shape.mesh_flat_words) + wave * flat_om_floats(P.shape.mesh_flat_slots));
     }
     int my_nr = 0;
     if (pt < P.point_end) {
@@ -670,7 +670,7 @@ __device__ __forceinline__ void descent_body(const SweptParams &P, double *s_dyn
         int *blob = reinterpret_cast<int *>(reinterpret_cast<char *>(s_dyn) + (LDS ? ((traj_lds_bytes(P.N) + 15) & ~(size_t)15) : 0));
         flat_lds_stage(P.shape.mesh, blob);
         mwg.stage = s_mesh + wave * (64 * 4 + 64 * 5); mwg.res = mwg.stage + 64 * 4; mwg.wave = 0;
-        mwg.flat = flat_lds_view(P.shape.mesh, blob, reinterpret_cast<float *>(blob + P.shape.mesh_flat_words) + wave * flat_om_floats(P.shape.mesh_flat_slots));
+        mwg.flat = flat_lds_view(blob, reinterpret_cast<float *>(blob + P.shape.mesh_flat_words) + wave * flat_om_floats(P.shape.mesh_flat_slots));
     }
     const unsigned cap = (unsigned)(P.point_end - P.point_begin) * SW_MAX_RANGES;
     const unsigned n_front = (unsigned)__builtin_amdgcn_readfirstlane((int)P.words[0]);
