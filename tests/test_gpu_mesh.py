@@ -110,7 +110,7 @@ def test_mesh_v1_arithmetic_at_the_reference_minimisers(pkg, orc, product_lib, n
     assert_close(gT, gT0, f"{name} gradT at the reference's t*")
 
 
-@pytest.mark.parametrize("stem", ["Trefoil", "Lthick"])
+@pytest.mark.parametrize("stem", ["Trefoil", "Lthick", "mybox", "icosahedron", "drone", "kuang", "box"])
 def test_reference_meshes_through_the_mesh_kind(pkg, orc, product_lib, stem):
     """"C5 mesh Lthick.obj (concave, 20 tris) and Trefoil.obj (12 k tris) scaled to the same bound, through the FWN
     path" - the reference's own files (tests/golden/ref_meshes.npz; isdf_read_obj's view of src/plan_manager/shapes/*.obj), as
@@ -118,7 +118,8 @@ def test_reference_meshes_through_the_mesh_kind(pkg, orc, product_lib, stem):
     know; Shape.cpp:27-151): shape plugin, then the swept-volume sweep with both sides searching their own minimisers."""
     capi, synth = pkg.capi, pkg.synth
     V, F = reference_mesh(stem, bound_radius=1.66)
-    assert len(F) == {"Trefoil": 12000, "Lthick": 20}[stem]
+    # (round 6: + the reference's small robot meshes - mybox / icosahedron take the FLAT evaluation like Lthick, drone / kuang / box the quad walks)
+    assert len(F) == {"Trefoil": 12000, "Lthick": 20, "mybox": 12, "icosahedron": 18, "drone": 52, "kuang": 60, "box": 96}[stem]
     shape = synth.make_mesh_shape(V, F)
     cfg = synth.default_config()
     eng = pkg.Engine(cfg); o = orc.Oracle(cfg, threads=30)
