@@ -48,10 +48,11 @@ __device__ inline double mesh_exact_w(const double *__restrict__ tri, int nF, d3
     }
     return sum / (4.0 * 3.14159265358979323846);
 }
-__global__ __launch_bounds__(256) void mesh_validity_kernel(const double *__restrict__ tri, int nF, int samples, double eps, double tau_limit, unsigned *out) {
+__global__ __launch_bounds__(256) void mesh_validity_kernel(const double *__restrict__ tri, int nF, int samples, int face_stride, double eps, double tau_limit, unsigned *out) {
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= (long long)nF * samples) return;
-    const int f = (int)(i / samples), k = (int)(i % samples);
+    const int n_tested = (nF + face_stride - 1) / face_stride;
+    if (i >= (long long)n_tested * samples) return;
+    const int f = (int)(i / samples) * face_stride, k = (int)(i % samples);
     const double *t = tri + (size_t)9 * f;
     const d3 a = mk3(t[0], t[1], t[2]), b = mk3(t[3], t[4], t[5]), c = mk3(t[6], t[7], t[8]);
     // barycentric sample: the centroid, then points two thirds of the way to each corner
@@ -124,8 +125,10 @@ int isdf_mesh_surface_valid(isdf_ctx *c, const double *d_tri, int nF, double ext
     HIPCHK(c, hipMalloc(&d_flag, 3 * sizeof(unsigned)));
     HIPCHK(c, hipMemsetAsync(d_flag, 0, 3 * sizeof(unsigned), c->stream));
     const int samples = nF <= 4096 ? 4 : 1;            // (the test is quadratic in the faces: the reference's 12 000-face Trefoil.obj takes the centroids)
-    const long long total = (long long)nF * samples;
-    hipLaunchKernelGGL(isdf::mesh_validity_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, c->stream, d_tri, nF, samples, 1.0e-5 * extent, tau_limit, d_flag);
+    // (... and beyond 32 768 faces every k-th face only, so that isdf_set_shape stays within ~0.1 s: 1e9 solid angles)
+    const int face_stride = nF <= 32768 ? 1 : (int)(((long long)nF * nF + (1ll << 30) - 1) >> 30);
+    const long long total = (long long)((nF + face_stride - 1) / face_stride) * samples;
+    hipLaunchKernelGGL(isdf::mesh_validity_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, c->stream, d_tri, nF, samples, face_stride, 1.0e-5 * extent, tau_limit, d_flag);
     unsigned back[3] = {1u, 0u, 0u};
     const hipError_t e1 = hipGetLastError();
     const hipError_t e2 = hipMemcpyAsync(back, d_flag, sizeof(back), hipMemcpyDeviceToHost, c->stream);

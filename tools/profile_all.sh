@@ -18,7 +18,7 @@ done
   python $REPO/tools/pmc_esdf.py "$(find /tmp/pe_f -name '*results.db' | head -1)" "$(find /tmp/pe_w -name '*results.db' | head -1)" > $REPO/gpurun_out/${TAG}_esdf_sample_pmc.txt 2>&1 )
 python tools/esdf_sample_bench.py > gpurun_out/${TAG}_esdf_sample_bench.txt 2>&1
 python tools/mesh_bench.py > gpurun_out/${TAG}_mesh_bench.txt 2>&1
-python tools/c5_mesh_bench.py blob720 trefoil lthick lprism > gpurun_out/${TAG}_c5_mesh.txt 2>&1
+python tools/c5_mesh_bench.py blob720 trefoil lthick lprism mybox icosa drone kuang box96 > gpurun_out/${TAG}_c5_mesh.txt 2>&1
 python tools/multi_host_bench.py > gpurun_out/${TAG}_multi_host.txt 2>&1
 python tools/batch_opt_bench.py 128 30 > gpurun_out/${TAG}_batch_opt_bench.txt 2>&1
 python tools/shapes_bench.py > gpurun_out/${TAG}_shapes_bench.txt 2>&1
