@@ -122,7 +122,7 @@ struct isdf_ctx {
     isdf_progress_fn progress = nullptr;        // isdf_set_progress: the optimizer drivers' progress / cancel hook
     void *progress_instance = nullptr;
     size_t progress_stride = 0;                 // batch: trajectory t's hook gets (char *)progress_instance + t * stride
-    double xchg_timeout_ms = 500.0;             // bound of the exchange's waits (isdf_xchg_set_timeout_ms), device wall clock
+    double xchg_timeout_ms = 2000.0;             // bound of the exchange's waits (isdf_xchg_set_timeout_ms), device wall clock
     // ONE host process driving SEVERAL devices (isdf_create_multi): this ctx is the lead (shard 0 of n on devices[0]) and owns
     // one plain ctx per further device (shard r of n).  Once-per-plan state set on the lead is replicated; a step launches every
     // shard on its own device's stream from the calling thread and sums the shards' packed outputs on the lead (one kernel

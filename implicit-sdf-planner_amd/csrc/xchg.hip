@@ -21,7 +21,7 @@ namespace isdf {
 //   2T + T/4 from this rank's start: the verdict round's bound (a peer whose data arrived started before t0 + T, its own
 //        data wait ends before its start + T, so its verdict is here before t0 + 2T)
 //   the other blocks of a launch give up only while block 0 has not STARTED (4T + T from their own start), see below
-constexpr double XCHG_DEFAULT_TIMEOUT_MS = 500.0;
+constexpr double XCHG_DEFAULT_TIMEOUT_MS = 2000.0;     // (a rank whose first step loads its code objects can be most of a second late: 500 ms failed a healthy first exchange on a fresh box)
 
 struct XchgParams {
     int rank, world;
@@ -315,7 +315,7 @@ void isdf_xchg_reset_board(isdf_ctx *c) {
     (void)hipDeviceSynchronize();
 }
 
-// The bound T of every wait of the exchange, in milliseconds of the device's wall clock (default 500): how much later than this
+// The bound T of every wait of the exchange, in milliseconds of the device's wall clock (default 2 000): how much later than this
 // rank a peer may start an exchange before this rank calls it failed.  A failed exchange kernel ends after T on the rank whose
 // wait expired and at once on a late rank; a healthy one waits at most 2.25 T for the verdicts.
 extern "C" double isdf_xchg_timeout_ms(isdf_ctx *c) { return c ? c->xchg_timeout_ms : XCHG_DEFAULT_TIMEOUT_MS; }
