@@ -70,6 +70,12 @@ def frontend_config(kernel_size=13, max_roll=45.0, max_pitch=45.0, ang_res=9.0, 
     return c
 
 
+class IsdfAstarResult(C.Structure):
+    """isdf_astar_result (include/isdf_accel.h)."""
+    _fields_ = [("success", C.c_int32), ("n_path", C.c_int32), ("expansions", C.c_int64), ("checks", C.c_int64),
+                ("cspace_ms", C.c_double), ("table_ms", C.c_double), ("search_ms", C.c_double)]
+
+
 class IsdfPlanConfig(C.Structure):
     """isdf_plan_config: what a plan needs from the reference's yaml files (include/isdf_accel.h)."""
     _fields_ = [("sweep", IsdfConfig), ("frontend", IsdfFrontendConfig), ("occupancy_resolution", C.c_double),
@@ -101,6 +107,7 @@ EXPORTED_SYMBOLS = [
     "isdf_set_pointcloud", "isdf_generate_esdf", "isdf_get_grid", "isdf_gather_points", "isdf_get_points", "isdf_shape_eval",
     "isdf_esdf_sample", "isdf_esdf_sample_device", "isdf_esdf_sample_scattered", "isdf_esdf_sample_scattered_device",
     "isdf_frontend_build", "isdf_frontend_get_shape_kernels", "isdf_frontend_get_map_kernel", "isdf_frontend_check", "isdf_frontend_cspace",
+    "isdf_frontend_astar_search", "isdf_frontend_astar_path",
     "isdf_read_pcd", "isdf_read_obj", "isdf_poly_rotation", "isdf_body_transform", "isdf_plan_config_default", "isdf_load_yaml_config",
     "isdf_shape_from_config",
     "isdf_host_path", "isdf_mesh_atan2f", "isdf_create_multi", "isdf_multi_info", "isdf_set_shape_grid", "isdf_set_shape_sampled",
@@ -194,6 +201,8 @@ def load_library(path=None):
     lib.isdf_xchg_timeout_ms.restype = C.c_double
     lib.isdf_xchg_set_timeout_ms.argtypes = [C.c_void_p, C.c_double]
     lib.isdf_frontend_cspace.argtypes = [C.c_void_p, C.c_void_p, dp]
+    lib.isdf_frontend_astar_search.argtypes = [C.c_void_p, dp, dp, C.POINTER(IsdfAstarResult)]
+    lib.isdf_frontend_astar_path.argtypes = [C.c_void_p, C.c_int, dp, dp, dp]
     lib.isdf_frontend_check.argtypes = [C.c_void_p, C.c_int, C.c_void_p, dp, dp, C.c_void_p, dp, dp, C.c_void_p]
     lib.isdf_lbfgs_params_default.argtypes = [C.POINTER(IsdfLbfgsParams)]
     lib.isdf_lbfgs_params_default.restype = None

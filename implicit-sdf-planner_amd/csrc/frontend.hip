@@ -9,13 +9,20 @@
 //                          attitudes are tried in the reference's breadth-first order (a host-built table per parent
 //                          attitude, visit_kernels_by_distance sw_manager.hpp:850-909): row dword AND map bits, wave ballot,
 //                          stop at the first attitude with no overlap (kernelConv<true>, :813-847).
+//   fe_cspace_kernel       the whole configuration space in one pass: 128 bits per voxel, bit a = attitude a fits;
+//   isdf_frontend_astar_*  the SE(3) A* itself (front_end_Astar.hpp:172-403) on the calling thread over that table: the search
+//                          is a chain of dependent pops, the 27 x (up to 121 attitudes x k^2 byte-ANDs) behind every pop is
+//                          what the device has already done for every voxel at once.
 // The reference's byte layouts (bit z in byte z / 8 under mask 0x80 >> (z % 8)) are produced for read-back only.
 // This file is compiled with -ffp-contract=off: the voxelisation compares an SDF with a margin, and robots aligned with
 // the grid put voxel centres exactly ON that margin - the comparison must see the reference's roundings.
 #include "isdf_ctx.hpp"
 #include "dev_mesh.hpp"
 #include <hip/hip_ext.h>
+#include <chrono>
 #include <cmath>
+#include <map>
+#include <memory>
 #include <queue>
 #include <vector>
 
@@ -248,6 +255,7 @@ void bfs_order(int xk, int yk, int sx, int sy, std::vector<unsigned short> &out)
 }
 
 void fe_free(isdf_ctx *c) {
+    if (c->fe.h_cspace) (void)hipHostFree(c->fe.h_cspace);
     void *ptrs[] = {c->fe.d_rows, c->fe.d_bits, c->fe.d_rot, c->fe.d_seq, c->fe.d_seq_len, c->fe.d_row_list, c->fe.d_row_ptr, c->fe.d_cspace};
     for (void *p : ptrs) if (p) (void)hipFree(p);
     c->fe = isdf_ctx::FrontEnd{};
@@ -322,6 +330,7 @@ extern "C" int isdf_frontend_build(isdf_ctx *c, const isdf_frontend_config *cfg)
     std::vector<int> seq_len(n_att);
     for (int a = 0; a < n_att; a++) { std::copy(orders[a].begin(), orders[a].end(), seq.begin() + (size_t)a * stride); seq_len[a] = (int)orders[a].size(); }
     fe.seq_stride = (int)stride;
+    fe.h_seq = seq; fe.h_seq_len = seq_len;
     HIPCHK(c, hipMalloc(&fe.d_seq, seq.size() * sizeof(unsigned short)));
     HIPCHK(c, hipMalloc(&fe.d_seq_len, seq_len.size() * sizeof(int)));
     HIPCHK(c, hipMemcpyAsync(fe.d_seq, seq.data(), seq.size() * sizeof(unsigned short), hipMemcpyHostToDevice, c->stream));
@@ -449,4 +458,192 @@ extern "C" int isdf_frontend_check(isdf_ctx *c, int n, const int32_t *index, con
     chk(hipStreamSynchronize(c->stream), "front-end sync");
     (void)hipFree(d);
     return rc;
+}
+
+// ---- the SE(3) A* (AstarPathSearcher, front_end_Astar.hpp:172-403) -------------------------------------------------------
+namespace {
+
+// GridNode (:12-57) without what the voxel index already says.  father: voxel index, A_START = the start node object, -1 = none
+struct ANode { double g = 0.0, f = 0.0, roll = 0.0, pitch = 0.0; int father = -1; int id = 0; };
+constexpr int A_START = -2;
+constexpr int A_PAGE_BITS = 12;
+
+// GridNodeMap (:127-152) allocates a node for every voxel of the map and reset() (:160-170) walks all of them after every
+// search; here a page of 4096 nodes appears when the search first touches it, and a fresh table is the reset
+struct ANodes {
+    std::vector<std::unique_ptr<ANode[]>> pages;
+    explicit ANodes(size_t n) : pages((n >> A_PAGE_BITS) + 1) {}
+    ANode &at(size_t i) {
+        std::unique_ptr<ANode[]> &p = pages[i >> A_PAGE_BITS];
+        if (!p) p.reset(new ANode[(size_t)1 << A_PAGE_BITS]);
+        return p[i & (((size_t)1 << A_PAGE_BITS) - 1)];
+    }
+};
+
+// getHeu (:172-188)
+inline double astar_heu(const int a[3], const int b[3]) {
+    const double p = 1.0 / 1000;
+    const int dx = std::abs(a[0] - b[0]), dy = std::abs(a[1] - b[1]), dz = std::abs(a[2] - b[2]);
+    const int dmin = std::min(dx, std::min(dy, dz)), dmax = std::max(dx, std::max(dy, dz));
+    const int dmid = dx + dy + dz - dmin - dmax;
+    const double h = std::sqrt(3.0) * dmin + std::sqrt(2.0) * (dmid - dmin) + (dmax - dmid);
+    return h * (1 + p);
+}
+
+// GridMap3D::isInMap / getGridIndex (Gridmap3D.cpp:41-69,135-175; an in-map position cannot reach the branches with the typos)
+inline bool astar_in_map(const DevGrid &G, const double p[3]) {
+    for (int a = 0; a < 3; a++) if (p[a] < G.bmin[a]) return false;
+    for (int a = 0; a < 3; a++) if (p[a] > G.bmax[a]) return false;
+    return true;
+}
+inline void astar_index(const DevGrid &G, const double p[3], int idx[3]) {
+    const int dims[3] = {G.X, G.Y, G.Z};
+    for (int a = 0; a < 3; a++) {
+        const double d = p[a] - G.bmin[a];
+        int i = (int)std::floor(d / G.res);
+        if (i < 0) i = 0;
+        if (i >= dims[a]) i = dims[a] - 1;
+        idx[a] = i;
+    }
+}
+
+}  // namespace
+
+extern "C" int isdf_frontend_astar_search(isdf_ctx *c, const double start[3], const double goal[3], isdf_astar_result *result) {
+    if (!c) return ISDF_ERR_INVALID_ARG;
+    if (!start || !goal || !result) return isdf_fail(c, ISDF_ERR_INVALID_ARG, "null start / goal / result");
+    if (!c->fe.built) return isdf_fail(c, ISDF_ERR_STATE, "isdf_frontend_build has not been called");
+    isdf_ctx::FrontEnd &fe = c->fe;
+    const DevGrid &G = c->grid;
+    const size_t n_vox = (size_t)G.X * G.Y * G.Z;
+    if (n_vox > (size_t)0x7FFFFFF0) return isdf_fail(c, ISDF_ERR_UNSUPPORTED, "the A* indexes voxels with 31 bits");
+    *result = isdf_astar_result{};
+    fe.path_xyz.clear(); fe.path_rp.clear();
+    typedef std::chrono::steady_clock clk;
+    if (!fe.h_cspace_valid) {
+        const clk::time_point t0 = clk::now();
+        HIPCHK(c, hipSetDevice(c->device));
+        if (!fe.h_cspace) HIPCHK(c, hipHostMalloc((void **)&fe.h_cspace, n_vox * 4 * sizeof(unsigned), hipHostMallocDefault));
+        double ms = 0.0;
+        const int rc = isdf_frontend_cspace(c, fe.h_cspace, &ms);
+        if (rc != ISDF_OK) return rc;
+        fe.h_cspace_valid = true;
+        result->cspace_ms = ms;
+        result->table_ms = std::chrono::duration<double, std::milli>(clk::now() - t0).count();
+    }
+    const clk::time_point t1 = clk::now();
+    if (!astar_in_map(G, start) || !astar_in_map(G, goal)) return ISDF_OK;                 // :244-249: success_flag = false
+    int si[3], gi[3];
+    astar_index(G, start, si);
+    astar_index(G, goal, gi);
+    const int xk = fe.xk, yk = fe.yk;
+    const double max_roll = fe.cfg.kernel_max_roll, max_pitch = fe.cfg.kernel_max_pitch, ang_res = fe.cfg.kernel_ang_res;
+    const unsigned *table = fe.h_cspace;
+    const unsigned short *seq = fe.h_seq.data();
+    const int *seq_len = fe.h_seq_len.data();
+    const size_t seq_stride = (size_t)fe.seq_stride;
+    const size_t YZ = (size_t)G.Y * G.Z;
+    double edge[4];                                                                         // sqrt(i*i + j*j + k*k), :230
+    for (int q = 0; q < 4; q++) edge[q] = std::sqrt((double)q);
+
+    ANodes nodes(n_vox);
+    // the start node is an object of its own (`new GridNode`, :260): IT sits in the open set and is the first successors' father;
+    // the map's node of the start cell is only marked open (:276-278) and stays that way
+    ANode start_node;
+    start_node.g = 0.0; start_node.f = astar_heu(si, gi); start_node.id = 1;
+    std::multimap<double, int> open;
+    open.insert(std::make_pair(start_node.f, A_START));
+    {
+        ANode &m = nodes.at((size_t)si[0] * YZ + (size_t)si[1] * G.Z + si[2]);
+        m.id = 1; m.g = start_node.g; m.f = start_node.f;
+    }
+    int terminate = -1;
+    bool found = false;
+    long long expansions = 0, checks = 0;
+    while (!open.empty()) {
+        const int cur = open.begin()->second;
+        open.erase(open.begin());
+        ANode &cn = cur == A_START ? start_node : nodes.at((size_t)cur);
+        cn.id = -1;
+        expansions++;
+        int ci[3];
+        if (cur == A_START) { ci[0] = si[0]; ci[1] = si[1]; ci[2] = si[2]; }
+        else { ci[2] = (int)((size_t)cur % G.Z); ci[1] = (int)(((size_t)cur / G.Z) % G.Y); ci[0] = (int)((size_t)cur / YZ); }
+        if (ci[0] == gi[0] && ci[1] == gi[1] && ci[2] == gi[2]) { terminate = cur; found = true; break; }          // :289-297
+        // AstarGetSucc (:197-236): the parent's attitude picks the breadth-first order (checkKernelValue, sw_manager.hpp:911-942)
+        const double fr = cn.roll, fp = cn.pitch, gcur = cn.g;
+        const int fi = (int)((fr + max_roll) / ang_res), fj = (int)((fp + max_pitch) / ang_res);
+        const bool parent_on_grid = fi >= 0 && fi < xk && fj >= 0 && fj < yk;             // (the reference indexes visited[][] with these)
+        const unsigned short *order = seq + (size_t)(parent_on_grid ? fi * yk + fj : 0) * seq_stride;
+        const int order_len = parent_on_grid ? seq_len[fi * yk + fj] : 0;
+        int succ[27]; double succ_ec[27];
+        int ns = 0;
+        for (int i = -1; i < 2; i++)
+            for (int j = -1; j < 2; j++)
+                for (int k = -1; k < 2; k++) {
+                    checks++;
+                    const int vx = ci[0] + i, vy = ci[1] + j, vz = ci[2] + k;
+                    if (vx < 0 || vx >= G.X || vy < 0 || vy >= G.Y || vz < 0 || vz >= G.Z) continue;               // isIndexValid
+                    const size_t v = (size_t)vx * YZ + (size_t)vy * G.Z + vz;
+                    const unsigned *m = table + 4 * v;                                                                // occupied voxels hold 0
+                    if ((m[0] | m[1] | m[2] | m[3]) == 0u) continue;
+                    int att = -1;
+                    for (int t = 0; t < order_len; t++) {
+                        const int a = order[t];
+                        if ((m[a >> 5] >> (a & 31)) & 1u) { att = a; break; }
+                    }
+                    if (att < 0) continue;
+                    const int ri = att / yk, rj = att - ri * yk;
+                    ANode &p = nodes.at(v);
+                    p.roll = fr + (ri - fi) * ang_res;                                                                // sw_manager.hpp:931-932; Astar :227-228:
+                    p.pitch = fp + (rj - fj) * ang_res;                                                               // written whatever the node's state
+                    succ[ns] = (int)v; succ_ec[ns] = edge[i * i + j * j + k * k]; ns++;
+                }
+        for (int s2 = 0; s2 < ns; s2++) {
+            ANode &nb = nodes.at((size_t)succ[s2]);
+            const double tg = succ_ec[s2] + gcur;
+            if (nb.id == 1 && !(tg < nb.g)) continue;
+            if (nb.id == -1 && !(tg < nb.g)) continue;
+            const int ni[3] = {(int)((size_t)succ[s2] / YZ), (int)(((size_t)succ[s2] / G.Z) % G.Y), (int)((size_t)succ[s2] % G.Z)};
+            nb.father = cur; nb.g = tg;
+            nb.f = tg + astar_heu(ni, gi) + 0.0;                                                                      // + getCustomCost (:192-196) = 0
+            if (nb.id != 1) {                                       // new (:306-317) or closed and reopened (:330-343); an open node keeps its OLD key (:319-328)
+                nb.id = 1;
+                open.insert(std::make_pair(nb.f, succ[s2]));
+            }
+        }
+    }
+    result->expansions = expansions; result->checks = checks;
+    if (found) {
+        // getPath (:359-376) and the (roll, pitch) chain of getastarSE3Path (:378-403): fathers back to the start node, reversed
+        std::vector<int> chain;
+        for (int p = terminate; p != -1; p = (p == A_START ? start_node.father : nodes.at((size_t)p).father)) chain.push_back(p);
+        for (size_t q = chain.size(); q-- > 0;) {
+            int ix, iy, iz;
+            const ANode *n;
+            if (chain[q] == A_START) { ix = si[0]; iy = si[1]; iz = si[2]; n = &start_node; }
+            else { const size_t v = (size_t)chain[q]; ix = (int)(v / YZ); iy = (int)((v / G.Z) % G.Y); iz = (int)(v % G.Z); n = &nodes.at(v); }
+            fe.path_xyz.push_back((ix + 0.5) * G.res + G.bmin[0]);                                                   // getGridCubeCenter, Gridmap3D.cpp:182-194
+            fe.path_xyz.push_back((iy + 0.5) * G.res + G.bmin[1]);
+            fe.path_xyz.push_back((iz + 0.5) * G.res + G.bmin[2]);
+            fe.path_rp.push_back(n->roll); fe.path_rp.push_back(n->pitch);
+        }
+        result->success = 1;
+        result->n_path = (int)chain.size();
+    }
+    result->search_ms = std::chrono::duration<double, std::milli>(clk::now() - t1).count();
+    return ISDF_OK;
+}
+
+extern "C" int isdf_frontend_astar_path(isdf_ctx *c, int capacity, double *xyz, double *roll_pitch, double *rot) {
+    if (!c) return ISDF_ERR_INVALID_ARG;
+    if (capacity < 0) return isdf_fail(c, ISDF_ERR_INVALID_ARG, "negative capacity");
+    const int n = (int)(c->fe.path_rp.size() / 2);
+    for (int i = 0; i < n && i < capacity; i++) {
+        if (xyz) for (int k = 0; k < 3; k++) xyz[3 * i + k] = c->fe.path_xyz[3 * (size_t)i + k];
+        const double roll = c->fe.path_rp[2 * (size_t)i], pitch = c->fe.path_rp[2 * (size_t)i + 1];
+        if (roll_pitch) { roll_pitch[2 * i] = roll; roll_pitch[2 * i + 1] = pitch; }
+        if (rot) attitude_rotation(roll * M_PI / 180.0, pitch * M_PI / 180.0, rot + 9 * (size_t)i);                   // :386-388
+    }
+    return n;
 }

@@ -117,6 +117,10 @@ struct isdf_ctx {
         unsigned short *d_seq = nullptr; int *d_seq_len = nullptr; int seq_stride = 0;
         void *d_row_list = nullptr; int *d_row_ptr = nullptr; int n_row_list = 0;      // non-empty rows per attitude
         unsigned *d_cspace = nullptr;                                                    // 4 dwords per voxel
+        // the A* (isdf_frontend_astar_search): the table on the host, the breadth-first attitude orders, the last path
+        unsigned *h_cspace = nullptr; bool h_cspace_valid = false;                       // pinned
+        std::vector<unsigned short> h_seq; std::vector<int> h_seq_len;
+        std::vector<double> path_xyz, path_rp;
     } fe;
     struct isdf_xchg *xchg = nullptr;           // peer-to-peer exchange of the multi-GPU path (csrc/xchg.hip)
     isdf_progress_fn progress = nullptr;        // isdf_set_progress: the optimizer drivers' progress / cancel hook

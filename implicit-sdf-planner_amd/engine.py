@@ -246,6 +246,22 @@ class Engine:
         self._check(self.lib.isdf_frontend_cspace(self.h, out.ctypes.data_as(C.c_void_p) if download else None, C.byref(ms)))
         return out, ms.value
 
+    def frontend_astar(self, start, goal):
+        """AstarPathSearcher::AstarPathSearch + getPath + getastarSE3Path (front_end_Astar.hpp:238-403) over the device-built
+        configuration space.  Returns (xyz (n, 3), roll/pitch degrees (n, 2), rot (n, 3, 3), IsdfAstarResult); the three arrays
+        are None when success == 0."""
+        s = np.ascontiguousarray(start, dtype=np.float64); g = np.ascontiguousarray(goal, dtype=np.float64)
+        r = capi.IsdfAstarResult()
+        self._check(self.lib.isdf_frontend_astar_search(self.h, _p(s), _p(g), C.byref(r)))
+        if not r.success:
+            return None, None, None, r
+        n = r.n_path
+        xyz = np.zeros((n, 3)); rp = np.zeros((n, 2)); rot = np.zeros((n, 3, 3))
+        got = self.lib.isdf_frontend_astar_path(self.h, n, _p(xyz), _p(rp), _p(rot))
+        if got != n:
+            raise RuntimeError(f"isdf_frontend_astar_path returned {got}, the search said {n}")
+        return xyz, rp, rot, r
+
     # ---- one-shot peer-to-peer exchange of the multi-GPU path (csrc/xchg.hip); see parallel.XgmiExchange
     def xchg_create(self, rank, world, max_doubles):
         h = (C.c_ubyte * 64)()

@@ -494,6 +494,33 @@ int isdf_frontend_check(isdf_ctx *ctx, int n, const int32_t *index, const double
  * bit tests in the breadth-first order instead of k^2 byte-ANDs per attitude.  kernel_ms_out (optional): device time. */
 int isdf_frontend_cspace(isdf_ctx *ctx, uint32_t *free_mask_out, double *kernel_ms_out);
 
+/* The SE(3) A* of the front end (AstarPathSearcher, planner_algorithm/front_end_Astar.hpp:172-403) over the table above, called
+ * like PlannerManager::generatePath calls the reference's (plan_manager.cpp:181-198):
+ *   isdf_frontend_astar_search  = AstarPathSearch(start, end); result->success = success_flag;
+ *   isdf_frontend_astar_path    = getPath() + getastarSE3Path() of that search (valid until the next search, which is also the
+ *                                 reference's reset()).
+ * The first search after isdf_frontend_build computes the whole configuration space on the device (isdf_frontend_cspace) and
+ * keeps it in pinned host memory; a search then runs on the calling thread and answers every neighbour test
+ * (isIndexValid && !isIndexOccupiedFlate && checkKernelValue, :214-216) with bit tests on a voxel's 128-bit word in the
+ * reference's breadth-first attitude order.  Same open-set order (a multimap keyed by the fScore at insertion, first inserted
+ * first among equals), same 26+1 neighbour order, same re-opening of closed nodes, same (roll, pitch) bookkeeping (a node's
+ * attitude is overwritten by every expansion that finds it feasible, :227-228) => the same path and attitudes, node for node.
+ * start / goal: world coordinates; outside the map => success = 0 (the reference logs an error and returns, :244-249). */
+typedef struct isdf_astar_result {
+    int32_t success;            /* AstarPathSearcher::success_flag                                                         */
+    int32_t n_path;             /* nodes on the path, start and goal cells included (0 when the search failed)             */
+    int64_t expansions;         /* nodes taken off the open set                                                            */
+    int64_t checks;             /* neighbour tests = the reference's total_kernel (:218)                                   */
+    double cspace_ms;           /* device time of the configuration-space pass when THIS call ran it, else 0               */
+    double table_ms;            /* wall time of that pass + bringing the table to the host, else 0                         */
+    double search_ms;           /* wall time of the search itself                                                          */
+} isdf_astar_result;
+int isdf_frontend_astar_search(isdf_ctx *ctx, const double start[3], const double goal[3], isdf_astar_result *result);
+/* Path of the last successful search, start -> goal: xyz = cube centres (3 doubles per node), roll_pitch = degrees (2 per
+ * node), rot = SE3State::rot = AngleAxis(roll, X) * AngleAxis(pitch, Y) as a row-major 3x3 (9 per node); any may be NULL.
+ * Writes at most `capacity` nodes; returns the number of nodes of the path (0 = no path), or a negative isdf_status. */
+int isdf_frontend_astar_path(isdf_ctx *ctx, int capacity, double *xyz, double *roll_pitch, double *rot);
+
 /* ---- the reference's own input files (host side; no device needed) ---------------------------------------------------- */
 /* ASCII .pcd global map as pcl::io::loadPCDFile<pcl::PointXYZ> reads it (src/map_manager/src/globalmap_gene.cpp:433-460;
  * the shipped src/plan_manager/map_pcds are "FIELDS x y z / DATA ascii"): xyz_out = up to `capacity` points x 3 floats (may be

@@ -7,12 +7,15 @@
 //   SweptVolumeManager::visit_kernels_by_distance        sw_manager.hpp:850-909
 //   SweptVolumeManager::checkKernelValue                 sw_manager.hpp:911-942
 //   the per-neighbour test of AstarPathSearcher::AstarGetSucc   planner_algorithm/front_end_Astar.hpp:208-222
+//   AstarPathSearcher::AstarPathSearch / getHeu / getPath / the (roll, pitch) chain of getastarSE3Path
+//                                                         front_end_Astar.hpp:172-403
 // Byte layouts are the reference's: bit z of a row lives in byte z/8 under mask 0x80 >> (z % 8).
 // Pinned against the reference's own code (oracle/_ref/libref_frontend.so, tests/test_oracle_ref.py).
 #pragma once
 #include "grid.hpp"
 #include "shapes.hpp"
 #include <cmath>
+#include <map>
 #include <queue>
 #include <vector>
 
@@ -151,6 +154,107 @@ struct FrontEnd {
         if (!g.index_valid(ind[0], ind[1], ind[2])) return false;
         if (g.occ[g.addr(ind[0], ind[1], ind[2])] == 1) return false;
         return check(fr, fp, cr, cp, ind, kidx);
+    }
+
+    // ---- the SE(3) A* itself (front_end_Astar.hpp:172-357), one search on a fresh node table (the caller's reset(), :160-170)
+    struct AstarNode { double g = 0, f = 0, roll = 0, pitch = 0; int id = 0; int father = -1; };      // father: node index, -2 = the start node object
+    struct AstarOut {
+        bool success = false;
+        std::vector<double> xyz, rp;          // path start -> goal: cube centres, (roll, pitch) in degrees
+        long checks = 0, expansions = 0;      // neighbour tests (total_kernel, :218), nodes taken off the open set
+    };
+    // :172-188
+    static double heu(const int a[3], const int b[3]) {
+        const double p = 1.0 / 1000;
+        const int dx = std::abs(a[0] - b[0]), dy = std::abs(a[1] - b[1]), dz = std::abs(a[2] - b[2]);
+        const int dmin = std::min(dx, std::min(dy, dz)), dmax = std::max(dx, std::max(dy, dz));
+        const int dmid = dx + dy + dz - dmin - dmax;
+        const double h = std::sqrt(3) * dmin + std::sqrt(2) * (dmid - dmin) + (dmax - dmid);
+        return h * (1 + p);
+    }
+    AstarOut astar(const Grid &g, const V3 &start, const V3 &goal) const {
+        AstarOut out;
+        if (!g.in_map(start) || !g.in_map(goal)) return out;                      // :244-249
+        int si[3], gi[3];
+        g.grid_index(start, si[0], si[1], si[2]);
+        g.grid_index(goal, gi[0], gi[1], gi[2]);
+        std::vector<AstarNode> nodes((size_t)g.X * g.Y * g.Z);                     // GridNodeMap after reset()
+        // the start node is an object of its own (`new GridNode`, :260): it is what sits in the open set and what the first
+        // successors get as father; the map's node of the start cell is only MARKED open (:276-278) and never leaves that state
+        AstarNode start_node;
+        const int START = -2;
+        auto node = [&](int i) -> AstarNode & { return i == START ? start_node : nodes[(size_t)i]; };
+        auto cell = [&](int i, int c[3]) {
+            if (i == START) { c[0] = si[0]; c[1] = si[1]; c[2] = si[2]; return; }
+            c[2] = i % g.Z; c[1] = (i / g.Z) % g.Y; c[0] = i / (g.Z * g.Y);
+        };
+        start_node.g = 0; start_node.f = heu(si, gi); start_node.id = 1;
+        std::multimap<double, int> open;
+        open.insert({start_node.f, START});
+        AstarNode &smap = nodes[g.addr(si[0], si[1], si[2])];
+        smap.id = 1; smap.g = 0; smap.f = start_node.f;
+        int terminate = -1;
+        bool found = false;
+        while (!open.empty()) {
+            const int cur = open.begin()->second;
+            open.erase(open.begin());
+            node(cur).id = -1;
+            out.expansions++;
+            int ci[3];
+            cell(cur, ci);
+            if (ci[0] == gi[0] && ci[1] == gi[1] && ci[2] == gi[2]) { terminate = cur; found = true; break; }       // :289
+            const double fr = node(cur).roll, fp = node(cur).pitch, gcur = node(cur).g;
+            // AstarGetSucc (:197-236) and the relaxation (:301-343) neighbour by neighbour in the loops' order
+            struct Succ { int idx; double ec; };
+            Succ succ[27];
+            int ns = 0;
+            for (int i = -1; i < 2; i++)
+                for (int j = -1; j < 2; j++)
+                    for (int k2 = -1; k2 < 2; k2++) {
+                        const int vi[3] = {ci[0] + i, ci[1] + j, ci[2] + k2};
+                        double cr = 0, cp = 0;
+                        const bool valid_free = g.index_valid(vi[0], vi[1], vi[2]) && g.occ[g.addr(vi[0], vi[1], vi[2])] != 1;
+                        // the reference evaluates checkKernelValue only behind && (:214-216) but counts every neighbour (:217)
+                        const bool cond = valid_free && check(fr, fp, cr, cp, vi);
+                        out.checks++;
+                        if (cond) {
+                            AstarNode &p = nodes[g.addr(vi[0], vi[1], vi[2])];
+                            p.pitch = cp; p.roll = cr;                                                                   // :227-228: written whatever the node's state
+                            succ[ns++] = {(int)g.addr(vi[0], vi[1], vi[2]), std::sqrt((double)(i * i + j * j + k2 * k2))};
+                        }
+                    }
+            for (int s = 0; s < ns; s++) {
+                AstarNode &nb = nodes[(size_t)succ[s].idx];
+                int ni[3];
+                cell(succ[s].idx, ni);
+                const double tg = succ[s].ec + node(cur).g;
+                (void)gcur;
+                if (nb.id == 0) {                                            // :306-317
+                    nb.father = cur; nb.g = tg; nb.f = tg + heu(ni, gi) + 0.0; nb.id = 1;
+                    open.insert({nb.f, succ[s].idx});
+                } else if (nb.id == 1) {                                     // :319-328: the key in the open set keeps the OLD fScore
+                    if (tg < nb.g) { nb.father = cur; nb.g = tg; nb.f = tg + heu(ni, gi) + 0.0; }
+                } else {                                                     // :330-343: a closed node is reopened
+                    if (tg < nb.g) {
+                        nb.father = cur; nb.g = tg; nb.f = tg + heu(ni, gi) + 0.0; nb.id = 1;
+                        open.insert({nb.f, succ[s].idx});
+                    }
+                }
+            }
+        }
+        if (!found) return out;
+        out.success = true;
+        // getPath (:359-376) / getastarSE3Path (:378-403): the father chain, reversed
+        std::vector<int> chain;
+        for (int p = terminate; p != -1; p = node(p).father) chain.push_back(p);
+        for (size_t q = chain.size(); q-- > 0;) {
+            int c[3];
+            cell(chain[q], c);
+            const V3 ctr = g.cube_center(c[0], c[1], c[2]);
+            out.xyz.push_back(ctr.x); out.xyz.push_back(ctr.y); out.xyz.push_back(ctr.z);
+            out.rp.push_back(node(chain[q]).roll); out.rp.push_back(node(chain[q]).pitch);
+        }
+        return out;
     }
 };
 

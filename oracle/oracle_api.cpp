@@ -150,6 +150,20 @@ void orc_frontend_cspace(void *h, uint32_t *out) {
                     if (c.fe.kernel_conv(a / c.fe.yk, a % c.fe.yk, ind)) m[a >> 5] |= 1u << (a & 31);
             }
 }
+// front_end_Astar.hpp:238-403 driven like PlannerManager::generatePath: -1 = no path, else the number of path nodes (written
+// up to cap); stats = [neighbour tests, nodes taken off the open set]
+int orc_frontend_astar(void *h, const double *start, const double *goal, int cap, double *path_xyz, double *path_rp, int64_t *stats) {
+    OrcCtx &c = *(OrcCtx *)h;
+    const orc::FrontEnd::AstarOut o = c.fe.astar(c.grid, orc::V3(start[0], start[1], start[2]), orc::V3(goal[0], goal[1], goal[2]));
+    if (stats) { stats[0] = o.checks; stats[1] = o.expansions; }
+    if (!o.success) return -1;
+    const int n = (int)(o.rp.size() / 2);
+    for (int i = 0; i < n && i < cap; i++) {
+        for (int k = 0; k < 3; k++) path_xyz[3 * i + k] = o.xyz[3 * (size_t)i + k];
+        path_rp[2 * i] = o.rp[2 * (size_t)i]; path_rp[2 * i + 1] = o.rp[2 * (size_t)i + 1];
+    }
+    return n;
+}
 int orc_frontend_kernel_conv(void *h, int ki, int kj, const int32_t *ind) { OrcCtx &c = *(OrcCtx *)h; const int i3[3] = {ind[0], ind[1], ind[2]}; return c.fe.kernel_conv(ki, kj, i3) ? 1 : 0; }
 
 // 1: the mesh winding number comes from the vendored HDK library (oracle/_ref/libref_fwn.so); 0: exact-sum fallback

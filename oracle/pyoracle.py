@@ -106,6 +106,17 @@ class Oracle:
                                     _p(cr), _p(cp), ki.ctypes.data_as(C.c_void_p))
         return ok, cr, cp, ki
 
+    def frontend_astar(self, start, goal, cap=65536):
+        """(path xyz (n, 3), (roll, pitch) degrees (n, 2), {checks, expansions}); path None when the search fails."""
+        s = np.ascontiguousarray(start, dtype=np.float64); g = np.ascontiguousarray(goal, dtype=np.float64)
+        xyz = np.zeros((cap, 3)); rp = np.zeros((cap, 2)); st = (C.c_int64 * 2)()
+        n = self.lib.orc_frontend_astar(self.h, _p(s), _p(g), cap, _p(xyz), _p(rp), st)
+        stats = {"checks": int(st[0]), "expansions": int(st[1])}
+        if n < 0:
+            return None, None, stats
+        assert n <= cap
+        return xyz[:n].copy(), rp[:n].copy(), stats
+
     def frontend_cspace(self, grid_shape):
         """uint32 [X, Y, Z, 4]: bit (i * yk + j) of a voxel's mask = kernelConv(i, j, voxel); occupied voxels 0."""
         out = np.zeros(tuple(grid_shape) + (4,), dtype=np.uint32)
@@ -422,6 +433,18 @@ class RefWorld:
         cr = C.c_double(0.0); cp = C.c_double(0.0)
         ok = self.lib.ref_frontend_check(self.h, ind.ctypes.data_as(C.c_void_p), C.c_double(father_roll), C.c_double(father_pitch), C.byref(cr), C.byref(cp))
         return ok, cr.value, cp.value
+
+    def astar(self, start, goal, cap=65536):
+        """The reference's own AstarPathSearch + getPath + the nodes' (roll, pitch) chain + reset (front_end_Astar.hpp:160-376),
+        driven like PlannerManager::generatePath.  Returns (path xyz (n, 3), roll/pitch degrees (n, 2), checkKernelValue calls) or
+        (None, None, calls) when the search fails."""
+        s = np.ascontiguousarray(start, dtype=np.float64); g = np.ascontiguousarray(goal, dtype=np.float64)
+        xyz = np.zeros((cap, 3)); rp = np.zeros((cap, 2)); st = (C.c_long * 1)()
+        n = self.lib.ref_astar_search(self.h, _p(s), _p(g), cap, _p(xyz), _p(rp), st)
+        if n < 0:
+            return None, None, int(st[0])
+        assert n <= cap
+        return xyz[:n].copy(), rp[:n].copy(), int(st[0])
 
     def points_in_aabb(self, center, half):
         c = np.asarray(center, dtype=np.float64)

@@ -7,6 +7,8 @@
 //                       grad_cost_p :766-824, grad_cost_p_sw :827-866
 //   PCSmapManager       projInMap + getPointsInAABB PCSmap_manager.h:130-170; unifiedID :101-108, getPointsInAABBOutOfLastOne :182-216,
 //                       aabb_points :238 (the obstacle-point set of the swept-volume sweep, driven like plan_manager.cpp:232-251)
+//   AstarPathSearcher   GridNode front_end_Astar.hpp:12-57, initGridMap :123-158, reset :160-170, getHeu / getCustomCost / AstarGetSucc /
+//                       AstarPathSearch :172-357, getPath :359-376 (the SE(3) A* loop of the front end)
 //   GridMap3D           Gridmap3D.cpp:41-258 (isInMap .. isIndexOccupied), generateESDF3d + fillESDF :361-533,
 //                       getGridSDFValue :535-553, trilinear samplers GridMap3D.h:114-195
 // sw_manager.hpp / back_end_optimizer.hpp / PCSmap_manager.h as a whole need ROS, PCL, libigl and yaml, so the Makefile
@@ -19,6 +21,7 @@
 #include <chrono>
 #include <queue>
 #include <unordered_map>
+#include <map>
 #include <cstring>
 #include <ros/ros.h>
 #include <cassert>
@@ -27,6 +30,7 @@
 #include <utils/minco.hpp>          // brings trajectory.hpp (Trajectory<5>, Piece)
 #define TRAJ_ORDER 5
 #define ROS_ERROR(...) do { } while (0)
+#define ROS_WARN(...) do { } while (0)
 using Eigen::Vector3i; using Eigen::Vector3d; using Eigen::Matrix3d;
 
 // ByteShapeKernel::generateByteKernel (Shape.hpp:238) allocates its bit array with `new uint8_t[n]` - NOT value-initialised -
@@ -183,6 +187,7 @@ public:
 // ---------------------------------------------------------------- PCSmapManager (map_manager)
 class PCSmapManager {
 public:
+    typedef PCSmapManager *Ptr;
     GridMap3D *occupancy_map = nullptr;
     Vector3d boundary_xyzmin, boundary_xyzmax;
 #include "../_ref/gen/pcsmap.inc"             // PCSmap_manager.h:130-170 projInMap, getPointsInAABB
@@ -196,6 +201,7 @@ constexpr uint8_t PCSmapManager::or_mask[8];
 // ---------------------------------------------------------------- SweptVolumeManager (swept_volume)
 class SweptVolumeManager {
 public:
+    typedef SweptVolumeManager *Ptr;
     Config config;
     Trajectory<TRAJ_ORDER> traj;
     double traj_duration = 0.0, t_min = 0.0, t_max = 0.0, momentum = 0.0;
@@ -237,8 +243,39 @@ public:
 #include "../_ref/gen/beo_f.inc"              // :827-866
 };
 
+// ---------------------------------------------------------------- AstarPathSearcher (planner_algorithm)
+using namespace Eigen;
+using namespace std;
+#include "../_ref/gen/astar_node.inc"         // front_end_Astar.hpp:12-57 GridNode
+class AstarPathSearcher {
+public:
+    GridNode ****GridNodeMap = nullptr;
+    GridNode *terminatePtr = nullptr;
+    int GLX_SIZE = 0, GLY_SIZE = 0, GLZ_SIZE = 0, GLYZ_SIZE = 0, GLXYZ_SIZE = 0;
+    uint8_t *data = nullptr;
+    double total_time = 0.0, total_kernel_time = 0.0;
+    int total_kernel = 0;
+    inline vector<Vector3d> getPath();
+    inline void reset();
+    inline void initGridMap(PCSmapManager::Ptr env, SweptVolumeManager::Ptr sv);
+    inline void AstarGetSucc(GridNode *currentPtr, vector<GridNode *> &neighborPtrSets, vector<double> &edgeCostSets);
+    inline void AstarPathSearch(Vector3d start, Vector3d end);
+    inline double getHeu(GridNode *node1, GridNode *node2);
+    inline double getCustomCost(GridNode *node_neighbor, GridNode *node_current);
+    bool success_flag = false;
+    Vector3i goalIdx;
+    Vector3d start_pt, end_pt;
+    SweptVolumeManager::Ptr sv_manager = nullptr;
+    std::multimap<double, GridNode *> openSet;
+    PCSmapManager::Ptr environment = nullptr;
+};
+#include "../_ref/gen/astar_init.inc"         // :123-158 initGridMap
+#include "../_ref/gen/astar_search.inc"       // :160-357 reset, getHeu, getCustomCost, AstarGetSucc, AstarPathSearch
+#include "../_ref/gen/astar_path.inc"         // :359-376 getPath
+
 namespace {
 struct World {
+    AstarPathSearcher *astar = nullptr;
     Config conf;
     GridMap3D grid;
     PCSmapManager pcs;
@@ -355,6 +392,35 @@ int ref_frontend_check(void *h, const int *ind, double fr, double fp, double *cr
 int ref_frontend_kernel_conv(void *h, int ki, int kj, const int *ind) {
     World *w = (World *)h;
     return w->sv.kernelConv<true>(ki, kj, Vector3i(ind[0], ind[1], ind[2])) ? 1 : 0;
+}
+
+// the SE(3) A* of the front end, driven like PlannerManager::generatePath (plan_manager.cpp:181-198): AstarPathSearch, getPath,
+// the nodes' roll / pitch along the father chain (what getastarSE3Path :378-403 turns into rotations), reset.
+// Returns -1 when the search fails, else the number of path nodes (written up to cap).  stats: [total_kernel]
+int ref_astar_search(void *h, const double *start, const double *goal, int cap, double *path_xyz, double *path_rp, long *stats) {
+    World *w = (World *)h;
+    if (!w->astar) {
+        w->astar = new AstarPathSearcher();
+        w->astar->initGridMap(&w->pcs, &w->sv);          // plan_manager.cpp:408
+    }
+    AstarPathSearcher &a = *w->astar;
+    a.total_kernel = 0;
+    a.AstarPathSearch(Vector3d(start[0], start[1], start[2]), Vector3d(goal[0], goal[1], goal[2]));
+    int n = -1;
+    if (a.success_flag) {
+        vector<Vector3d> path = a.getPath();
+        n = (int)path.size();
+        vector<GridNode *> chain;
+        for (GridNode *p = a.terminatePtr; p; p = p->father) chain.push_back(p);
+        assert((int)chain.size() == n);
+        for (int i = 0; i < n && i < cap; i++) {
+            for (int k = 0; k < 3; k++) path_xyz[3 * i + k] = path[i](k);
+            path_rp[2 * i] = chain[n - 1 - i]->roll; path_rp[2 * i + 1] = chain[n - 1 - i]->pitch;
+        }
+    }
+    if (stats) stats[0] = a.total_kernel;
+    a.reset();
+    return n;
 }
 
 // occupancy grid (uint8, z fastest) -> GridMap3D::grid_map; optionally the reference's own generateESDF3d

@@ -112,5 +112,53 @@ def main():
         print(f"ref_frontend_{name}: feasible {res_q[:, 0].mean():.2f}")
 
 
+ASTAR_WORLDS = (("Box", 13, 0.22, 9), ("Torus_big", 15, 0.14, 7))      # robot class, kernel_size, occupancy, seed
+
+
+def astar_world(pkg, name, occupancy, seed):
+    synth = pkg.synth
+    occ = synth.random_box_map((48, 40, 16), res=0.5, occupancy=occupancy, seed=seed, edge=(0.5, 2.5))
+    kwf = dict(params=(0.9, 0.35, 0.25)) if name == "Box" else {}
+    return occ, synth.make_shape(name, poly_params=(0.05, -0.1, 0.02, 12, -8, 25), **kwf)
+
+
+def astar_fixtures():
+    """ref_astar_<robot>.npz: the reference's own AstarPathSearch / getPath / attitude chain (front_end_Astar.hpp:160-376, compiled
+    into oracle/_ref/libref_sweeps.so) on seeded cluttered worlds: start / goal pairs -> path cells, (roll, pitch) per node and
+    the number of neighbour tests.  Searches that fail (goal where no attitude fits; start outside the map) are part of it."""
+    pkg = g.load_package(); orc = g.load_oracle(); capi, synth = pkg.capi, pkg.synth
+    for name, k, occupancy, seed in ASTAR_WORLDS:
+        occ, shape = astar_world(pkg, name, occupancy, seed)
+        cfg = synth.default_config(capi.V1_SWEPT)
+        fe = capi.frontend_config(kernel_size=k)
+        w = orc.RefWorld(cfg, name, shape, 0.5); w.set_occupancy(occ, (0, 0, 0), 0.5); w.frontend_build(fe, name)
+        o = orc.Oracle(cfg, threads=8)              # only to pick start / goal cells where SOME attitude fits
+        o.set_grid(occ, (0, 0, 0), 0.5, capi.GRID_OCCUPANCY); o.set_shape(shape); o.frontend_build(fe)
+        fits = (o.frontend_cspace(occ.shape) != 0).any(axis=-1)
+        good = np.argwhere(fits); bad = np.argwhere(~fits & (occ == 0))
+        rng = np.random.default_rng(seed)
+        starts, goals = [], []
+        for _ in range(12):
+            a, b = good[rng.choice(len(good), 2, replace=False)]
+            starts.append((a + rng.random(3)) * 0.5); goals.append((b + rng.random(3)) * 0.5)
+        starts.append(starts[0]); goals.append(starts[0] + 0.01)                                    # start cell == goal cell
+        starts.append(np.array([-0.2, 3.0, 3.0])); goals.append(goals[1])                          # start outside the map
+        starts.append((good[rng.choice(len(good))] + 0.5) * 0.5); goals.append((bad[rng.choice(len(bad))] + 0.5) * 0.5)      # free goal voxel where no attitude fits
+        n, xyz, rp, checks = [], [], [], []
+        for s_, g_ in zip(starts, goals):
+            x, r, c = w.astar(s_, g_)
+            n.append(-1 if x is None else len(x)); checks.append(c)
+            if x is not None:
+                xyz.append(x); rp.append(r)
+        np.savez_compressed(os.path.join(HERE, f"ref_astar_{name}.npz"), occ=occ, res=0.5, kernel_size=k, start=np.array(starts), goal=np.array(goals),
+                            n=np.array(n), checks=np.array(checks), xyz=np.concatenate(xyz), rp=np.concatenate(rp),
+                            box_params=np.array((0.9, 0.35, 0.25) if name == "Box" else (0, 0, 0)))
+        print(f"ref_astar_{name}: path lengths {n}, attitudes on paths {len(np.unique(np.concatenate(rp), axis=0))}, neighbour tests {checks}")
+
+
 if __name__ == "__main__":
-    main()
+    if sys.argv[1:] == ["astar"]:
+        astar_fixtures()
+    else:
+        main()
+        astar_fixtures()

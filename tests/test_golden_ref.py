@@ -80,6 +80,40 @@ def _check_frontend(pkg, orc, gpu, name):
     assert np.array_equal(cr[m], w["child_roll"][m]) and np.array_equal(cp[m], w["child_pitch"][m])
 
 
+def _check_astar(pkg, orc, gpu, name):
+    """The reference's own AstarPathSearch / getPath / attitude chain (tests/golden/ref_astar_*.npz): the same cells, the same
+    (roll, pitch) at every node, the same number of neighbour tests, the same failures."""
+    capi, synth = pkg.capi, pkg.synth
+    w = _load(f"ref_astar_{name}")
+    kw = dict(params=tuple(w["box_params"])) if name == "Box" else {}
+    shape = synth.make_shape(name, poly_params=(0.05, -0.1, 0.02, 12, -8, 25), **kw)
+    t = _targets(pkg, orc, gpu)(synth.default_config(capi.V1_SWEPT))
+    t.set_grid(w["occ"], (0, 0, 0), float(w["res"]), capi.GRID_OCCUPANCY)
+    t.set_shape(shape)
+    t.frontend_build(capi.frontend_config(kernel_size=int(w["kernel_size"])))
+    at = 0
+    assert (w["n"] > 1).sum() >= 8 and (w["n"] == -1).sum() >= 2 and (w["n"] == 1).sum() == 1
+    for q, (s, g, n, checks) in enumerate(zip(w["start"], w["goal"], w["n"], w["checks"])):
+        out = t.frontend_astar(s, g)
+        xyz, rp, st = out[0], out[1], out[-1]
+        got_checks = st.checks if gpu else st["checks"]
+        assert got_checks == checks, (name, q, got_checks, checks)
+        if n < 0:
+            assert xyz is None, (name, q)
+            continue
+        assert xyz is not None and len(xyz) == n, (name, q, None if xyz is None else len(xyz), n)
+        assert np.array_equal(xyz, w["xyz"][at:at + n]), (name, q)
+        assert np.array_equal(rp, w["rp"][at:at + n]), (name, q)
+        if gpu:                       # SE3State::rot of getastarSE3Path = Rx(roll) * Ry(pitch)
+            for i in (0, n // 2, n - 1):
+                a, b = np.deg2rad(rp[i])
+                Rx = np.array([[1, 0, 0], [0, np.cos(a), -np.sin(a)], [0, np.sin(a), np.cos(a)]])
+                Ry = np.array([[np.cos(b), 0, np.sin(b)], [0, 1, 0], [-np.sin(b), 0, np.cos(b)]])
+                assert np.allclose(out[2][i], Rx @ Ry, rtol=0, atol=1e-15)
+        at += n
+    assert at == len(w["xyz"])
+
+
 def _check_callback(pkg, orc, gpu):
     from common import oracle_cost_function
     capi, synth = pkg.capi, pkg.synth
@@ -131,6 +165,11 @@ def test_oracle_frontend_vs_reference_fixture(pkg, orc, name):
     _check_frontend(pkg, orc, False, name)
 
 
+@pytest.mark.parametrize("name", ["Box", "Torus_big"])
+def test_oracle_astar_vs_reference_fixture(pkg, orc, name):
+    _check_astar(pkg, orc, False, name)
+
+
 # ---- GPU: the HIP path against the reference's outputs
 @pytest.mark.gpu
 @pytest.mark.parametrize("name", mg.V1_SHAPES)
@@ -158,6 +197,12 @@ def test_hip_esdf_vs_reference_fixture(pkg, product_lib):
 @pytest.mark.parametrize("name", ["Box", "Torus_big"])
 def test_hip_frontend_vs_reference_fixture(pkg, orc, product_lib, name):
     _check_frontend(pkg, orc, True, name)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["Box", "Torus_big"])
+def test_hip_astar_vs_reference_fixture(pkg, orc, product_lib, name):
+    _check_astar(pkg, orc, True, name)
 
 
 @pytest.mark.gpu

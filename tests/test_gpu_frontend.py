@@ -160,3 +160,91 @@ def test_frontend_edge_configurations(pkg, orc, product_lib):
     # a parent attitude outside the grid: the reference would index visited[][] out of bounds; here the query is rejected
     ok, _, _, ki = eng.frontend_check(idx[:8], 500.0, 0.0)
     assert not ok.any() and (ki == -1).all()
+
+
+def _astar_pairs(table, res, rng, n):
+    good = np.argwhere((table != 0).any(axis=-1))
+    out = []
+    for _ in range(n):
+        a, b = good[rng.choice(len(good), 2, replace=False)]
+        out.append(((a + rng.random(3)) * res, (b + rng.random(3)) * res))
+    return out
+
+
+@pytest.mark.parametrize("name", ["Box", "RoundedCone", "Torus_big", "mesh"])
+def test_astar_matches_oracle_node_for_node(pkg, orc, product_lib, name):
+    """isdf_frontend_astar_search / _path (the SE(3) A* over the device-built configuration space) against the oracle's restatement
+    of AstarPathSearcher (front_end_Astar.hpp:172-403; pinned against the reference's own code in tests/test_oracle_ref.py and
+    tests/golden/ref_astar_*.npz): the same cells, the same (roll, pitch) at every node, the same number of neighbour tests and
+    expansions, the same failures."""
+    capi, synth = pkg.capi, pkg.synth
+    res = 0.5
+    occupancy = {"Box": 0.24, "RoundedCone": 0.10, "Torus_big": 0.14, "mesh": 0.20}[name]
+    occ = synth.random_box_map((44, 40, 14), res=res, occupancy=occupancy, seed=31, edge=(0.5, 2.5))
+    if name == "mesh":
+        V, F = synth.l_prism_mesh()
+        shape = synth.make_mesh_shape(V * 1.5, F)
+    elif name == "Box":
+        shape = synth.make_shape("Box", params=(0.9, 0.35, 0.25), poly_params=(0.05, -0.1, 0.02, 12, -8, 25))
+    else:
+        shape = synth.make_shape(name, poly_params=(0.05, -0.1, 0.02, 12, -8, 25))
+    fe = capi.frontend_config(kernel_size=15 if name == "Torus_big" else 13)
+    eng, o = _pair(pkg, orc, shape, occ, res, fe)
+    if name == "mesh" and o.mesh_backend() != 1:
+        pytest.skip("oracle/_ref/libref_fwn.so not built")
+    table, _ = eng.frontend_cspace()
+    rng = np.random.default_rng(12)
+    found = tilted = 0
+    first = True
+    for s, g in _astar_pairs(table, res, rng, 10) + [(np.array([1.0, 1.0, -0.1]), np.array([3.0, 3.0, 3.0]))]:
+        xyz, rp, rot, r = eng.frontend_astar(s, g)
+        x0, rp0, st = o.frontend_astar(s, g)
+        assert (r.checks, r.expansions) == (st["checks"], st["expansions"]), (name, r.checks, st)
+        assert (first and r.table_ms > 0 and r.cspace_ms > 0) or (not first and r.table_ms == 0)        # the table is computed once
+        first = False
+        assert (xyz is None) == (x0 is None)
+        if x0 is None:
+            assert r.success == 0 and r.n_path == 0
+            continue
+        found += 1
+        assert r.success == 1 and r.n_path == len(x0)
+        assert np.array_equal(xyz, x0) and np.array_equal(rp, rp0)
+        tilted += int((rp0 != 0).any())
+        # every node of the path is a cell where its attitude fits; consecutive cells are 26-neighbours
+        cells = np.floor(xyz / res).astype(int)
+        assert (np.abs(np.diff(cells, axis=0)).max(axis=1) == 1).all() or len(cells) == 1
+    assert found >= 5 and (tilted >= 2 or name == "RoundedCone"), (name, found, tilted)
+    # the path read-back: capacity shorter than the path, NULL outputs
+    C = __import__("ctypes")
+    n = eng.lib.isdf_frontend_astar_path(eng.h, 0, None, None, None)
+    assert n == (0 if xyz is None else len(xyz))
+
+
+def test_astar_follows_the_table_after_a_rebuild(pkg, orc, product_lib):
+    """A new map / robot + isdf_frontend_build drops the cached configuration space: the next search recomputes it."""
+    capi, synth = pkg.capi, pkg.synth
+    res = 0.5
+    shape = synth.make_shape("Box", params=(0.9, 0.35, 0.25))
+    fe = capi.frontend_config(kernel_size=13)
+    occ_a = synth.random_box_map((32, 32, 12), res=res, occupancy=0.15, seed=41, edge=(0.5, 2.0))
+    occ_b = synth.random_box_map((32, 32, 12), res=res, occupancy=0.15, seed=42, edge=(0.5, 2.0))
+    eng, o = _pair(pkg, orc, shape, occ_a, res, fe)
+    rng = np.random.default_rng(2)
+    for occ in (occ_a, occ_b):
+        if occ is occ_b:
+            for t in (eng, o):
+                t.set_grid(occ, (0, 0, 0), res, capi.GRID_OCCUPANCY)
+            with pytest.raises(Exception):
+                eng.frontend_astar((1.0, 1.0, 1.0), (5.0, 5.0, 3.0))         # stale tables are refused like every front-end call
+            for t in (eng, o):
+                t.frontend_build(fe)
+        table, _ = eng.frontend_cspace()
+        n_table = 0
+        for s, g in _astar_pairs(table, res, rng, 4):
+            xyz, rp, rot, r = eng.frontend_astar(s, g)
+            n_table += int(r.table_ms > 0)
+            x0, rp0, st = o.frontend_astar(s, g)
+            assert r.checks == st["checks"] and (xyz is None) == (x0 is None)
+            if x0 is not None:
+                assert np.array_equal(xyz, x0) and np.array_equal(rp, rp0)
+        assert n_table == 1

@@ -148,3 +148,38 @@ def test_device_gather_points_vs_reference(pkg, orc, product_lib, case):
     order = np.argsort(ids_d, kind="stable")
     assert np.array_equal(ids_d[order], ids_r.astype(np.int64))
     assert np.array_equal(pts[order], xyz_r)
+
+
+@pytest.mark.parametrize("name,occupancy", [("Box", 0.24), ("Table", 0.10), ("CSG", 0.12)])
+def test_device_astar_vs_reference(pkg, orc, product_lib, name, occupancy):
+    """isdf_frontend_astar_search / _path against the reference's OWN AstarPathSearch / getPath / attitude chain
+    (front_end_Astar.hpp:160-376 in libref_sweeps.so, driven like PlannerManager::generatePath): the same path, cell for cell, the
+    same (roll, pitch) at every node, the same number of neighbour tests, the same failures."""
+    _need(orc, orc.REF_SWEEPS)
+    capi, synth = pkg.capi, pkg.synth
+    res = 0.5
+    occ = synth.random_box_map((44, 40, 14), res=res, occupancy=occupancy, seed=51, edge=(0.5, 2.5))
+    kw = dict(params=(0.9, 0.35, 0.25)) if name == "Box" else {}
+    shape = synth.make_shape(name, poly_params=(0.05, -0.1, 0.02, 12, -8, 25), **kw)
+    cfg = synth.default_config(capi.V1_SWEPT)
+    fe = capi.frontend_config(kernel_size=13 if name == "Box" else 15)
+    eng = pkg.Engine(cfg)
+    eng.set_grid(occ, (0, 0, 0), res, capi.GRID_OCCUPANCY); eng.set_shape(shape); eng.frontend_build(fe)
+    w = orc.RefWorld(cfg, name, shape, res)
+    w.set_occupancy(occ, (0, 0, 0), res)
+    w.frontend_build(fe, name)
+    table, _ = eng.frontend_cspace()
+    good = np.argwhere((table != 0).any(axis=-1))
+    rng = np.random.default_rng(5)
+    found = 0
+    for q in range(10):
+        a, b = good[rng.choice(len(good), 2, replace=False)]
+        s, g = (a + rng.random(3)) * res, (b + rng.random(3)) * res
+        xyz, rp, rot, r = eng.frontend_astar(s, g)
+        x_r, rp_r, checks_r = w.astar(s, g)
+        assert r.checks == checks_r, (name, q, r.checks, checks_r)
+        assert (xyz is None) == (x_r is None), (name, q)
+        if x_r is not None:
+            found += 1
+            assert np.array_equal(xyz, x_r) and np.array_equal(rp, rp_r), (name, q)
+    assert found >= 5, found

@@ -433,6 +433,43 @@ def test_frontend_kernels_and_checks_vs_reference_code(pkg, orc, name):
     assert 0 < n_ok < 600, n_ok        # the scenario exercises both outcomes
 
 
+@pytest.mark.parametrize("name,occupancy,seed", [("RoundedCone", 0.10, 21), ("Table", 0.10, 22), ("Box", 0.24, 23)])
+def test_astar_vs_reference_code(pkg, orc, name, occupancy, seed):
+    """The SE(3) A* (AstarPathSearch / AstarGetSucc / getHeu / getPath and the nodes' attitude chain, front_end_Astar.hpp:160-376):
+    the oracle's restatement against the reference's own code on cluttered worlds - the same cells, the same (roll, pitch) at
+    every node and the same number of neighbour tests, which pins the open set's order (a multimap keyed by the fScore AT
+    INSERTION), the re-opening of closed nodes and the overwriting of a node's attitude by later expansions."""
+    if not os.path.exists(orc.REF_SWEEPS):
+        pytest.skip("oracle/_ref/libref_sweeps.so not built")
+    capi, synth = pkg.capi, pkg.synth
+    res = 0.5
+    occ = synth.random_box_map((44, 40, 14), res=res, occupancy=occupancy, seed=seed, edge=(0.5, 2.5))
+    kw = dict(params=(0.9, 0.35, 0.25)) if name == "Box" else {}
+    shape = synth.make_shape(name, poly_params=(0.05, -0.1, 0.02, 12, -8, 25), **kw)
+    cfg = synth.default_config(capi.V1_SWEPT)
+    fe = capi.frontend_config(kernel_size=13 if name in ("Box", "RoundedCone") else 15)
+    o = orc.Oracle(cfg, threads=8)
+    o.set_grid(occ, (0, 0, 0), res, capi.GRID_OCCUPANCY); o.set_shape(shape); o.frontend_build(fe)
+    w = orc.RefWorld(cfg, name, shape, res)
+    w.set_occupancy(occ, (0, 0, 0), res)
+    w.frontend_build(fe, name)
+    good = np.argwhere((o.frontend_cspace(occ.shape) != 0).any(axis=-1))
+    rng = np.random.default_rng(seed)
+    found = tilted = 0
+    for q in range(10):
+        a, b = good[rng.choice(len(good), 2, replace=False)]
+        s, g = (a + rng.random(3)) * res, (b + rng.random(3)) * res
+        x_r, rp_r, checks_r = w.astar(s, g)
+        x_o, rp_o, st = o.frontend_astar(s, g)
+        assert st["checks"] == checks_r, (name, q, st, checks_r)
+        assert (x_r is None) == (x_o is None), (name, q)
+        if x_r is not None:
+            found += 1
+            assert np.array_equal(x_o, x_r) and np.array_equal(rp_o, rp_r), (name, q)
+            tilted += int((rp_r != 0).any())
+    assert found >= 6 and tilted >= 3, (found, tilted)       # real searches through clutter, with attitudes other than level
+
+
 def test_sampled_grid_shape_vs_reference_code(pkg, orc):
     """ISDF_SHAPE_GRID (a user-defined host shape tabulated on a body-frame lattice): the oracle's restatement of getonlySDFNum /
     getonlyGrad1Num / getSDFwithGrad1Num (Shape.hpp:481-600) against the reference's OWN functions on the reference's OWN lattice
