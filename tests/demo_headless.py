@@ -3,8 +3,9 @@ PCD + yaml + robot in -> optimized trajectory out, without ROS.
 
   map       PCSmapManager::rcvGlobalMapHandler (PCSmap_manager.cpp:87-200)      -> Engine.set_pointcloud (device)
   robot     SweptVolumeManager::initShape (sw_manager.hpp:239-275)               -> registry class / mesh from the config
-  path      the reference's SE(3) A* front end is OUT OF SCOPE: a plain 26-connected A* over the occupancy grid
-            inflated by the robot's radius stands in for it - it only has to produce a collision-free voxel path
+  path      PlannerManager::generatePath (plan_manager.cpp:181-198): the SE(3) A* front end - AstarPathSearch + getPath
+            (front_end_Astar.hpp:238-376) = Engine.frontend_build + Engine.frontend_astar (attitude kernels, bit-packed map and
+            the whole configuration space on the device, the search over that table)
   waypoints PlannerManager::generateTraj (plan_manager.cpp:202-254): every index_gap-th path cell, obstacle points gathered in
             boxes of half size bd / 3 around them (Engine.gather_points, device), inittime per piece
   mid end   OUT OF SCOPE (no collision term): the waypoints themselves are the initial guess, like the first overload of
@@ -12,7 +13,6 @@ PCD + yaml + robot in -> optimized trajectory out, without ROS.
   back end  lmbm::lmbm_optimize on costFunctionLmbm (back_end_optimizer.cpp:125-132): the reference's Fortran LMBM
             (oracle/_ref/liblmbm.so, test infrastructure) drives the callback under test.
 """
-import heapq
 import math
 
 import numpy as np
@@ -40,44 +40,17 @@ def plan_config_from_golden(pkg, g, tag):
     return p
 
 
-def astar(occ, start, goal, inflate):
-    """26-connected A* on the voxel grid; a cell is blocked if an occupied cell lies within `inflate` cells (Chebyshev)."""
-    from scipy.ndimage import maximum_filter
-    blocked = maximum_filter(occ.astype(np.uint8), size=2 * inflate + 1, mode="constant", cval=1) > 0
-    start, goal = tuple(start), tuple(goal)
-    assert not blocked[start] and not blocked[goal], "start / goal not free"
-    nb = [(a, b, c) for a in (-1, 0, 1) for b in (-1, 0, 1) for c in (-1, 0, 1) if (a, b, c) != (0, 0, 0)]
-    h = lambda p: math.dist(p, goal)
-    openq = [(h(start), 0.0, start)]
-    came, gs = {}, {start: 0.0}
-    while openq:
-        _, gcur, cur = heapq.heappop(openq)
-        if cur == goal:
-            path = [cur]
-            while cur in came:
-                cur = came[cur]; path.append(cur)
-            return path[::-1]
-        if gcur > gs.get(cur, 1e300):
-            continue
-        for d in nb:
-            q = (cur[0] + d[0], cur[1] + d[1], cur[2] + d[2])
-            if min(q) < 0 or q[0] >= occ.shape[0] or q[1] >= occ.shape[1] or q[2] >= occ.shape[2] or blocked[q]:
-                continue
-            ng = gcur + math.sqrt(d[0] ** 2 + d[1] ** 2 + d[2] ** 2)
-            if ng < gs.get(q, 1e300):
-                gs[q] = ng; came[q] = cur
-                heapq.heappush(openq, (ng + h(q), ng, q))
-    raise RuntimeError("no path")
-
-
-def build_plan(pkg, eng, plan, xyz, start_cell, goal_cell, inflate):
+def build_plan(pkg, eng, plan, xyz, start_cell, goal_cell):
     """Map, path, waypoints, obstacle points, initial variables.  eng: an Engine of the plan's V1 config with the robot set."""
     capi = pkg.capi
     res = plan.occupancy_resolution
     dims = eng.set_pointcloud(xyz, res, plan.sta_threshold)
     occ, origin, bmax = eng.get_grid(capi.GRID_OCCUPANCY)
-    path_cells = astar(occ, start_cell, goal_cell, inflate)
-    path = [(np.array(c) + 0.5) * res + origin for c in path_cells]                  # getGridCubeCenter
+    eng.frontend_build(plan.frontend)                                                   # initShapeKernels + generateMapKernel (plan_manager.cpp:400-408)
+    start = (np.array(start_cell) + 0.5) * res + origin; goal = (np.array(goal_cell) + 0.5) * res + origin
+    path_xyz, path_rp, _, astar = eng.frontend_astar(start, goal)
+    assert astar.success, "the front end found no path"
+    path = [p for p in path_xyz]                                                        # recent_path: cube centres, start -> goal
     index_gap = math.ceil(plan.traj_parlength / res)                                    # plan_manager.cpp:206-213
     tpl = plan.traj_parlength
     while index_gap >= len(path) - 1:
@@ -92,5 +65,5 @@ def build_plan(pkg, eng, plan, xyz, start_cell, goal_cell, inflate):
     eng.set_trajectory(N, head, tail, plan.rho)
     T0 = np.full(N, plan.inittime)
     x0 = eng.pack_variables(T0, np.array(Q))
-    return {"occ": occ, "origin": origin, "path": np.array(path), "Q": np.array(Q), "N": N, "M": M, "head": head, "tail": tail, "x0": x0,
+    return {"occ": occ, "origin": origin, "path": np.array(path), "path_rp": path_rp, "start": start, "goal": goal, "astar": astar, "Q": np.array(Q), "N": N, "M": M, "head": head, "tail": tail, "x0": x0,
             "points": eng.get_points()}

@@ -19,7 +19,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 GOLD = os.path.join(ROOT, "tests", "golden", "ref_demo_inputs.npz")
 
 
-def _demo(pkg, tag, start=(5, 25, 17), goal=(48, 25, 17), inflate=1):
+def _demo(pkg, tag, start=(5, 25, 17), goal=(48, 25, 17)):
     """start / goal either side of the three slit walls of the map (x = 10-11, 24-26, 42-44; holes of about 8 x 5 cells)"""
     capi = pkg.capi
     g = np.load(GOLD)
@@ -31,7 +31,7 @@ def _demo(pkg, tag, start=(5, 25, 17), goal=(48, 25, 17), inflate=1):
     cfg = capi.IsdfConfig.from_buffer_copy(plan.sweep)
     eng = pkg.Engine(cfg)
     eng.set_shape(shape)
-    P = build_plan(pkg, eng, plan, g["CappedCone_xyz"], start, goal, inflate)
+    P = build_plan(pkg, eng, plan, g["CappedCone_xyz"], start, goal)
     return g, plan, cfg, shape, eng, P
 
 
@@ -51,6 +51,23 @@ def test_demo1_swept_sweep_vs_reference_code(pkg, orc, product_lib):
     assert c_r > 0 and abs(c - c_r) <= REL_TOL * abs(c_r), (c, c_r)
     assert np.abs(ts - ts_r).max() <= 2e-5
     assert_close(gC, gC_r, "demo1 gradC vs the reference's sweep"); assert_close(gT, gT_r, "demo1 gradT vs the reference's sweep")
+
+
+def test_demo1_front_end_vs_reference_code(pkg, orc, product_lib):
+    """demo1's map and robot through the front end: isdf_frontend_astar_search against the reference's own AstarPathSearch /
+    getPath (front_end_Astar.hpp in libref_sweeps.so) with the shipped front-end values (kernel_size 13, 11 x 11 attitudes of 9 degrees)."""
+    if not os.path.exists(orc.REF_SWEEPS):
+        pytest.skip("oracle/_ref/libref_sweeps.so not built")
+    g, plan, cfg, shape, eng, P = _demo(pkg, "CappedCone")
+    res = plan.occupancy_resolution
+    w = orc.RefWorld(cfg, "RoundedCone", shape, res)
+    w.set_occupancy(P["occ"], P["origin"], res, bmax=eng.get_grid(pkg.capi.GRID_OCCUPANCY)[2])
+    w.frontend_build(plan.frontend, "RoundedCone")
+    x_r, rp_r, checks = w.astar(P["start"], P["goal"])
+    assert x_r is not None and P["astar"].checks == checks
+    assert np.array_equal(P["path"], x_r) and np.array_equal(P["path_rp"], rp_r)
+    assert len(x_r) >= 40                                          # through the three slit walls
+    print(f"demo1 front end: path {len(x_r)} cells, {P['astar'].expansions} expansions, attitudes on the path {np.unique(rp_r, axis=0).tolist()}")
 
 
 def test_demo6_mesh_robot_vs_reference_code(pkg, orc, product_lib):
