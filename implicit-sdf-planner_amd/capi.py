@@ -107,7 +107,7 @@ EXPORTED_SYMBOLS = [
     "isdf_set_pointcloud", "isdf_generate_esdf", "isdf_get_grid", "isdf_gather_points", "isdf_get_points", "isdf_shape_eval",
     "isdf_esdf_sample", "isdf_esdf_sample_device", "isdf_esdf_sample_scattered", "isdf_esdf_sample_scattered_device",
     "isdf_frontend_build", "isdf_frontend_get_shape_kernels", "isdf_frontend_get_map_kernel", "isdf_frontend_check", "isdf_frontend_cspace",
-    "isdf_frontend_astar_search", "isdf_frontend_astar_path",
+    "isdf_frontend_astar_search", "isdf_frontend_astar_path", "isdf_host_info",
     "isdf_read_pcd", "isdf_read_obj", "isdf_poly_rotation", "isdf_body_transform", "isdf_plan_config_default", "isdf_load_yaml_config",
     "isdf_shape_from_config",
     "isdf_host_path", "isdf_mesh_atan2f", "isdf_create_multi", "isdf_multi_info", "isdf_set_shape_grid", "isdf_set_shape_sampled",
@@ -201,6 +201,7 @@ def load_library(path=None):
     lib.isdf_xchg_timeout_ms.restype = C.c_double
     lib.isdf_xchg_set_timeout_ms.argtypes = [C.c_void_p, C.c_double]
     lib.isdf_frontend_cspace.argtypes = [C.c_void_p, C.c_void_p, dp]
+    lib.isdf_host_info.argtypes = [C.c_void_p, C.POINTER(C.c_int64)]
     lib.isdf_frontend_astar_search.argtypes = [C.c_void_p, dp, dp, C.POINTER(IsdfAstarResult)]
     lib.isdf_frontend_astar_path.argtypes = [C.c_void_p, C.c_int, dp, dp, dp]
     lib.isdf_frontend_check.argtypes = [C.c_void_p, C.c_int, C.c_void_p, dp, dp, C.c_void_p, dp, dp, C.c_void_p]

@@ -1445,6 +1445,30 @@ static bool direct_enabled(const isdf_ctx *c) {
     return !c->env_no_direct && !c->prof_on && c->world == 1 && c->cfg.variant != ISDF_V1_SWEPT && c->cfg.enable_pos;
 }
 // pinned, device-mapped [inputs 19 n nb | outputs (1 + 19 n) nb | nb flags]
+// Results that a kernel stores into host-mapped memory, and the completion word it stores after them, are separate PCIe writes issued
+// by different wavefronts; "release, then the word" orders them for the DEVICE's view of memory, not for the order in which posted
+// writes become visible to the CPU.  Observed on MI355X: the first host-direct step of a fresh ctx, about one process in twenty when two
+// processes share the GPU - word and cost there, all gradient rows still the zeros of the fresh allocation, a wrong gradient returned
+// without any flag (tests/native/xchg_fail_worker.py caught it as a "wrong" reference).  So the word only says the kernel is done:
+// the result area is filled with a pattern no result can have (all ones: not the canonical NaN, not a count) before the launch, and
+// after the word the host waits until none of it is left - normally a scan of a few hundred doubles that finds nothing.
+static void host_rows_mark(double *p, size_t n) { std::memset((void *)p, 0xFF, n * sizeof(double)); }
+static bool host_rows_wait(isdf_ctx *c, const double *p, size_t n) {
+    const volatile unsigned long long *w = (const volatile unsigned long long *)p;
+    c->host_steps++;
+    bool late = false;
+    const auto t0 = std::chrono::steady_clock::now();
+    for (size_t i = 0; i < n; i++) {
+        for (unsigned spin = 0; w[i] == ~0ull; spin++) {
+            late = true;
+            c->host_late_spins++;
+            if ((spin & 0x3FFFu) == 0x3FFFu && std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > 5.0) return false;
+        }
+    }
+    if (late) { c->host_late++; std::atomic_thread_fence(std::memory_order_acquire); }
+    return true;
+}
+
 static int direct_reserve(isdf_ctx *c, int nb, int n) {
     const size_t in = (size_t)19 * n * nb, out = isdf_out_stride(n) * nb, need = in + out + (size_t)nb;
     if (c->dir_cap < need) {
@@ -1521,6 +1545,7 @@ static int direct_launch(isdf_ctx *c, int nb, int n, const double *const *T, con
         std::memcpy(dst + (size_t)b * n, T[first + b], (size_t)n * sizeof(double));
         std::memcpy(dst + (size_t)n * nb + (size_t)b * 18 * n, coeffs[first + b], (size_t)18 * n * sizeof(double));
     }
+    host_rows_mark(c->h_dir + c->dir_in, c->dir_out);            // (the step STORES its sums there; it never reads them)
     __sync_synchronize();
     hd.T = c->h_dir_dev; hd.coeffs = c->h_dir_dev + (size_t)n * nb;
     hd.out = c->h_dir_dev + c->dir_in;
@@ -1551,6 +1576,10 @@ static int direct_wait(isdf_ctx *c, hipStream_t st, bool *overflow) {
         if (f & HOST_FLAG_OVERFLOW) *overflow = true;
     }
     std::atomic_thread_fence(std::memory_order_acquire);
+    if (!host_rows_wait(c, c->h_dir + c->dir_in, (size_t)c->dir_nb * isdf_out_stride(c->dir_n))) {
+        (void)hipStreamSynchronize(st);
+        return fail(c, ISDF_ERR_HIP, "host-direct step: its completion word arrived but not all of its results");
+    }
     return ISDF_OK;
 }
 
@@ -1600,6 +1629,9 @@ static int v1_direct_eval(isdf_ctx *c, int n, const double *T, const double *coe
     c->v1_tstar_stage = nullptr;
     if (rc) return rc;
     const unsigned long long seq = ++c->dir_seq;
+    host_rows_mark(c->h_v1_pin, ostride);
+    if (ts) host_rows_mark(c->h_v1_pin + ostride + 10, (size_t)c->M);
+    __sync_synchronize();
     double *ho = c->h_v1_pin_dev;
     unsigned long long *hs = (unsigned long long *)(c->h_v1_pin_dev + ostride);
     hipLaunchKernelGGL(publish_kernel, dim3(1), dim3(1024), 0, c->stream, c->d_out, ostride, c->d_stats, ts ? c->d_tstar : nullptr, c->M,
@@ -1615,6 +1647,10 @@ static int v1_direct_eval(isdf_ctx *c, int n, const double *T, const double *coe
         }
     }
     std::atomic_thread_fence(std::memory_order_acquire);
+    if (!host_rows_wait(c, c->h_v1_pin, ostride) || (ts && !host_rows_wait(c, c->h_v1_pin + ostride + 10, (size_t)c->M))) {
+        (void)hipStreamSynchronize(c->stream);
+        return fail(c, ISDF_ERR_HIP, "host-direct swept-volume step: its flag arrived but not all of its results");
+    }
     if (ts) std::memcpy(tstar_inout, c->h_v1_pin + ostride + 10, (size_t)c->M * sizeof(double));
     *h_out = c->h_v1_pin;
     *h_stat = (const unsigned long long *)(c->h_v1_pin + ostride);
@@ -1629,6 +1665,12 @@ extern "C" int isdf_mesh_info(const isdf_ctx *c, int info_out[16]) {
 }
 
 extern "C" int isdf_host_path(const isdf_ctx *c) { return c ? c->last_host_path : ISDF_ERR_INVALID_ARG; }
+extern "C" int isdf_host_info(const isdf_ctx *c, int64_t info_out[8]) {
+    if (!c || !info_out) return ISDF_ERR_INVALID_ARG;
+    for (int k = 0; k < 8; k++) info_out[k] = 0;
+    info_out[0] = (int64_t)c->host_steps; info_out[1] = (int64_t)c->host_late; info_out[2] = (int64_t)c->host_late_spins;
+    return ISDF_OK;
+}
 
 extern "C" int isdf_eval(isdf_ctx *c, int n_traj, const int *N, const double *const *T, const double *const *coeffs,
                          double *cost_inout, double *const *gradT_inout, double *const *gradC_inout, double *tstar_inout) {
@@ -1736,6 +1778,9 @@ extern "C" int isdf_eval(isdf_ctx *c, int n_traj, const int *N, const double *co
             if (!c->d_msum_blocks) { HIPCHK(c, hipMalloc(&c->d_msum_blocks, sizeof(unsigned))); HIPCHK(c, hipMemset(c->d_msum_blocks, 0, sizeof(unsigned))); }
             c->mh_words = (unsigned long long *)(c->h_eval_pin_dev + in_all + out_all);
             c->mh_seq++;
+            host_rows_mark(hout, out_all);                       // (see host_rows_wait: the word does not order the results for the CPU)
+            host_rows_mark((double *)hstat, 8);
+            __sync_synchronize();
         }
         rc = sweep_dispatch(c, nb, n, dT, dC, host_out ? c->h_eval_pin_dev + in_all : c->d_out, dts, c->stream);
         if (rc) { c->mh_words = nullptr; return rc; }
@@ -1750,6 +1795,10 @@ extern "C" int isdf_eval(isdf_ctx *c, int n_traj, const int *N, const double *co
                 }
             }
             std::atomic_thread_fence(std::memory_order_acquire);
+            if (!host_rows_wait(c, hout, out_all) || !host_rows_wait(c, (const double *)hstat, 8)) {
+                (void)hipStreamSynchronize(c->stream);
+                return fail(c, ISDF_ERR_HIP, "multi-device step: its completion word arrived but not all of its results");
+            }
         } else {
         HIPCHK(c, hipMemcpyAsync(hout, c->d_out, out_all * sizeof(double), hipMemcpyDeviceToHost, c->stream));
         HIPCHK(c, hipMemcpyAsync(hstat, c->d_stats, 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost, c->stream));
@@ -1899,6 +1948,7 @@ static int cost_function_launch_dev(isdf_ctx *c, const double *x, int n, hipStre
     const size_t nvar = (size_t)n;
     if (bar_usable(c, c->d_cbdev, nvar)) std::memcpy(c->d_cbdev, x, nvar * sizeof(double));      // CPU stores into device memory
     else { std::memcpy(c->h_cbres, x, nvar * sizeof(double)); P.x = c->h_cbres_dev; }
+    host_rows_mark(c->h_cbres + nvar, cb_res_stride(N));
     __sync_synchronize();
     const size_t ostride = isdf_out_stride(N);
     double *d_T = c->d_cb, *d_C = c->d_cb + N, *d_o = c->d_cb + (size_t)19 * N;
@@ -1949,6 +1999,10 @@ static int cost_function_finish_dev(isdf_ctx *c, double *g, double *cost_out, hi
         return fail(c, ISDF_ERR_OVERFLOW, "a bounded device work list overflowed; result invalid");
     }
     const double *res = c->h_cbres + nvar;
+    if (!host_rows_wait(c, res, rs)) {
+        (void)hipStreamSynchronize(st);
+        return fail(c, ISDF_ERR_HIP, "device callback: its completion word arrived but not all of its results");
+    }
     *cost_out = res[0];
     std::memcpy(g, res + 1, nvar * sizeof(double));
     for (int q = 0; q < 4; q++) c->last_parts[q] = res[1 + nvar + q];

@@ -246,6 +246,12 @@ class Engine:
         self._check(self.lib.isdf_frontend_cspace(self.h, out.ctypes.data_as(C.c_void_p) if download else None, C.byref(ms)))
         return out, ms.value
 
+    def host_info(self):
+        """isdf_host_info: {"handovers", "late", "late_polls"} of the host-mapped result hand-overs of this ctx."""
+        a = (C.c_int64 * 8)()
+        self._check(self.lib.isdf_host_info(self.h, a))
+        return {"handovers": int(a[0]), "late": int(a[1]), "late_polls": int(a[2])}
+
     def frontend_astar(self, start, goal):
         """AstarPathSearcher::AstarPathSearch + getPath + getastarSE3Path (front_end_Astar.hpp:238-403) over the device-built
         configuration space.  Returns (xyz (n, 3), roll/pitch degrees (n, 2), rot (n, 3, 3), IsdfAstarResult); the three arrays

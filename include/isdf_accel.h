@@ -302,6 +302,13 @@ int isdf_eval(isdf_ctx *ctx, int n_traj, const int *N, const double *const *T,
  *                  host-mapped memory), (cost, g) and a completion word come back into host-mapped memory; no copy commands */
 #define ISDF_HOST_PATH_DEVICE_CALLBACK 3
 int isdf_host_path(const isdf_ctx *ctx);
+/* The DIRECT_* and DEVICE_CALLBACK hand-overs end with the kernel storing results and then a completion word into host-mapped
+ * memory.  Those are separate PCIe writes from different wavefronts: the word can be visible to the CPU before every result is
+ * (seen on MI355X for the FIRST step of a ctx, about one fresh process in twenty: cost and word there, the gradient rows still
+ * zero).  The host therefore fills the result area with an all-ones pattern no result can have before the launch and, once the
+ * word is there, waits until none of it is left.  info_out: [0] hand-overs so far, [1] how many of them had results still
+ * missing when the word arrived, [2] polls spent waiting for those; [3..7] reserved (0). */
+int isdf_host_info(const isdf_ctx *ctx, int64_t info_out[8]);
 
 /* Device-resident entry point, asynchronous on `stream` (a hipStream_t passed as void*; NULL = default
  * stream).  All trajectories have N pieces.  d_T: n_traj*N, d_coeffs: n_traj * (6N x 3 col-major),

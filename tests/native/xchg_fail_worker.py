@@ -32,13 +32,18 @@ def main():
         e.set_trajectory(6, head, tail, 2.0)
     xv = full.pack_variables(T, Cf6[1:, 0, :])
     c_ref, g_ref = full.cost_function(xv)
+    print(f"[xchg_fail_worker] rank {rank}: first step of the unsharded ctx, host hand-over {full.host_info()} (path {full.lib.isdf_host_path(full.h)})", flush=True)
     assert eng.xchg_timeout_ms() == 2000.0                      # the default: generous - a rank's FIRST step loads its code objects
     x = par.XgmiExchange(eng, eng.out_stride(6), dev)
     assert x.ok, x.why
     # healthy: the callback through the exchange, no host collective involved (twice: the first call loads kernels)
-    for _ in range(2):
+    for it in range(2):
         c, g = par.cost_function_allreduced(eng, xv, x)
-        assert abs(c - c_ref) <= 1e-12 * abs(c_ref) and np.allclose(g, g_ref, rtol=0, atol=1e-11 * np.abs(g_ref).max()) and x.ok
+        if not (abs(c - c_ref) <= 1e-12 * abs(c_ref) and np.allclose(g, g_ref, rtol=0, atol=1e-11 * np.abs(g_ref).max()) and x.ok):
+            c2, g2 = full.cost_function(xv)            # which side is wrong: the unsharded reference evaluated once more
+            bad = np.flatnonzero(np.abs(g - g_ref) > 1e-9 * np.abs(g_ref).max())
+            raise AssertionError(("healthy callback", it, "cost", c, c_ref, c2, "max |g - g_ref|", float(np.abs(g - g_ref).max()), "max |g - g_ref2|", float(np.abs(g - g2).max()),
+                                  "max |g_ref2 - g_ref|", float(np.abs(g2 - g_ref).max()), "of", float(np.abs(g_ref).max()), "entries off", bad.tolist(), "x.ok", x.ok, "status", eng.xchg_status()))
     # from here on a SHORT bound, so that the failures below take a second and not ten; the ranks are aligned by barriers
     dist.barrier()
     eng.xchg_set_timeout_ms(400.0)
