@@ -91,7 +91,7 @@ def _spread_log(line):
     print("\n[mesh x V1] " + line)
     SPREAD_LINES.append(line)
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    path = os.environ.get("ISDF_MESH_SPREAD_LOG", os.path.join(root, "gpurun_out", "r4_mesh_spread.txt"))
+    path = os.environ.get("ISDF_MESH_SPREAD_LOG", os.path.join(root, "gpurun_out", "mesh_spread.txt"))
     try:
         os.makedirs(os.path.dirname(path), exist_ok=True)
         with open(path, "a") as f:
@@ -102,7 +102,7 @@ def _spread_log(line):
 
 def assert_mesh_v1_free_running(what, tg, to, gT, gT0, gC, gC0, allow_ties=0):
     """Device (tg, gT, gC) vs oracle (to, gT0, gC0), both searching for their own minimisers: the measured deviations are logged
-    (the pytest log's "mesh x V1" summary section; gpurun_out/r4_mesh_spread.txt -> profiles/), then held to: every t* within 1e-9 s, gradients at REL_TOL."""
+    (the pytest log's "mesh x V1" summary section; gpurun_out/mesh_spread.txt -> profiles/), then held to: every t* within 1e-9 s, gradients at REL_TOL."""
     dt = np.abs(np.asarray(tg) - np.asarray(to))
     moved = float((dt > 1e-9).mean())
     eC = float(np.linalg.norm(gC - gC0) / max(np.linalg.norm(gC0), 1e-300)); eT = float(np.linalg.norm(gT - gT0) / max(np.linalg.norm(gT0), 1e-300))
