@@ -248,3 +248,45 @@ def test_astar_follows_the_table_after_a_rebuild(pkg, orc, product_lib):
             if x0 is not None:
                 assert np.array_equal(xyz, x0) and np.array_equal(rp, rp0)
         assert n_table == 1
+
+
+def test_astar_other_grids_and_origins(pkg, orc, product_lib):
+    """The A* with a map origin off zero, a 0.2 m grid, a rectangular attitude grid whose spacing is not an integer (roll +-30 in
+    steps of 7.5 -> 9, pitch +-15 -> 5 attitudes), kernel_size 9 - against the oracle, node for node; start == goal cell; a goal in an
+    occupied voxel (the search exhausts what it can reach and fails)."""
+    capi, synth = pkg.capi, pkg.synth
+    res = 0.2
+    origin = (-3.7, 12.25, 0.4)
+    occ = synth.random_box_map((60, 52, 24), res=res, occupancy=0.12, seed=77, edge=(0.4, 1.4))
+    shape = synth.make_shape("Box", params=(0.55, 0.16, 0.12), poly_params=(0.02, -0.03, 0.01, 5, -8, 10))
+    fe = capi.frontend_config(kernel_size=9, max_roll=30.0, max_pitch=15.0, ang_res=7.5, safeh=0.0)
+    cfg = synth.default_config(capi.V1_SWEPT)
+    eng = pkg.Engine(cfg); o = orc.Oracle(cfg, threads=16)
+    for t in (eng, o):
+        t.set_grid(occ, origin, res, capi.GRID_OCCUPANCY); t.set_shape(shape); t.frontend_build(fe)
+    table, _ = eng.frontend_cspace()
+    good = np.argwhere((table != 0).any(axis=-1))
+    rng = np.random.default_rng(3)
+    cases = []
+    for _ in range(8):
+        a, b = good[rng.choice(len(good), 2, replace=False)]
+        cases.append(((a + rng.random(3)) * res + origin, (b + rng.random(3)) * res + origin))
+    cases.append((cases[0][0], cases[0][0] + 1e-3))                                         # one cell
+    occv = np.argwhere(occ == 1)
+    cases.append((cases[1][0], (occv[rng.choice(len(occv))] + 0.5) * res + origin))        # goal inside an obstacle
+    cases.append((np.array(origin) - 0.01, cases[2][1]))                                    # start outside the map
+    found = tilted = 0
+    for q, (s, g) in enumerate(cases):
+        xyz, rp, rot, r = eng.frontend_astar(s, g)
+        x0, rp0, st = o.frontend_astar(s, g)
+        assert (r.checks, r.expansions) == (st["checks"], st["expansions"]), (q, r.checks, st)
+        assert (xyz is None) == (x0 is None), q
+        if x0 is not None:
+            found += 1
+            assert np.array_equal(xyz, x0) and np.array_equal(rp, rp0), q
+            tilted += int((rp0 != 0).any())
+            assert set(np.unique(rp0[:, 0])) <= set(np.arange(-30.0, 30.1, 7.5)) and set(np.unique(rp0[:, 1])) <= set(np.arange(-15.0, 15.1, 7.5))
+    assert cases and found >= 6 and tilted >= 1, (found, tilted)
+    assert eng.frontend_astar(*cases[-1])[3].success == 0 and eng.frontend_astar(*cases[-2])[3].success == 0
+    x1 = eng.frontend_astar(*cases[-3])[0]
+    assert x1 is not None and len(x1) == 1
