@@ -21,6 +21,7 @@
 #include <hip/hip_ext.h>
 #include <chrono>
 #include <cmath>
+#include <cstdlib>
 #include <map>
 #include <memory>
 #include <queue>
@@ -255,7 +256,7 @@ void bfs_order(int xk, int yk, int sx, int sy, std::vector<unsigned short> &out)
 }
 
 void fe_free(isdf_ctx *c) {
-    if (c->fe.h_cspace) (void)hipHostFree(c->fe.h_cspace);
+    if (c->fe.h_cspace) { if (c->fe.h_cspace_pinned) (void)hipHostFree(c->fe.h_cspace); else std::free(c->fe.h_cspace); }
     void *ptrs[] = {c->fe.d_rows, c->fe.d_bits, c->fe.d_rot, c->fe.d_seq, c->fe.d_seq_len, c->fe.d_row_list, c->fe.d_row_ptr, c->fe.d_cspace};
     for (void *p : ptrs) if (p) (void)hipFree(p);
     c->fe = isdf_ctx::FrontEnd{};
@@ -523,7 +524,16 @@ extern "C" int isdf_frontend_astar_search(isdf_ctx *c, const double start[3], co
     if (!fe.h_cspace_valid) {
         const clk::time_point t0 = clk::now();
         HIPCHK(c, hipSetDevice(c->device));
-        if (!fe.h_cspace) HIPCHK(c, hipHostMalloc((void **)&fe.h_cspace, n_vox * 4 * sizeof(unsigned), hipHostMallocDefault));
+        if (!fe.h_cspace) {
+            // 16 bytes per voxel (268 MB at 256^3, 2 GiB at 512^3): pinned if the host grants it, pageable otherwise (the copy is then staged by the runtime)
+            if (hipHostMalloc((void **)&fe.h_cspace, n_vox * 4 * sizeof(unsigned), hipHostMallocDefault) == hipSuccess) fe.h_cspace_pinned = true;
+            else {
+                (void)hipGetLastError();
+                fe.h_cspace = (unsigned *)std::malloc(n_vox * 4 * sizeof(unsigned));
+                fe.h_cspace_pinned = false;
+                if (!fe.h_cspace) return isdf_fail(c, ISDF_ERR_HIP, "no host memory for the configuration-space table");
+            }
+        }
         double ms = 0.0;
         const int rc = isdf_frontend_cspace(c, fe.h_cspace, &ms);
         if (rc != ISDF_OK) return rc;

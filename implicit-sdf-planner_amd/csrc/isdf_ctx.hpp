@@ -119,7 +119,7 @@ struct isdf_ctx {
         void *d_row_list = nullptr; int *d_row_ptr = nullptr; int n_row_list = 0;      // non-empty rows per attitude
         unsigned *d_cspace = nullptr;                                                    // 4 dwords per voxel
         // the A* (isdf_frontend_astar_search): the table on the host, the breadth-first attitude orders, the last path
-        unsigned *h_cspace = nullptr; bool h_cspace_valid = false;                       // pinned
+        unsigned *h_cspace = nullptr; bool h_cspace_valid = false, h_cspace_pinned = false;   // pinned when the host lets us (16 B per voxel), else pageable
         std::vector<unsigned short> h_seq; std::vector<int> h_seq_len;
         std::vector<double> path_xyz, path_rp;
     } fe;
