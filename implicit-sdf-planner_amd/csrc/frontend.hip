@@ -24,6 +24,7 @@
 #include <cstdlib>
 #include <map>
 #include <memory>
+#include <new>
 #include <queue>
 #include <vector>
 
@@ -464,20 +465,54 @@ extern "C" int isdf_frontend_check(isdf_ctx *c, int n, const int32_t *index, con
 // ---- the SE(3) A* (AstarPathSearcher, front_end_Astar.hpp:172-403) -------------------------------------------------------
 namespace {
 
-// GridNode (:12-57) without what the voxel index already says.  father: voxel index, A_START = the start node object, -1 = none
-struct ANode { double g = 0.0, f = 0.0, roll = 0.0, pitch = 0.0; int father = -1; int id = 0; };
-constexpr int A_START = -2;
-constexpr int A_PAGE_BITS = 12;
+// GridNode (:12-57) without what the voxel index already says and without fScore (the reference reads a node's fScore only where it
+// inserts the node into the open set - the key is passed along instead).  All-zero = a fresh node: `father1` is the father's voxel
+// index + 1, A_START1 the start node object, 0 none.
+struct ANode { double g, roll, pitch; int father1; int id; };
+constexpr int A_START = -2, A_START1 = -1;
+constexpr int A_PAGE_BITS = 10;
 
 // GridNodeMap (:127-152) allocates a node for every voxel of the map and reset() (:160-170) walks all of them after every
-// search; here a page of 4096 nodes appears when the search first touches it, and a fresh table is the reset
+// search; here a page of 1 024 nodes appears (zeroed) when the search first touches it, and a fresh table is the reset
 struct ANodes {
-    std::vector<std::unique_ptr<ANode[]>> pages;
-    explicit ANodes(size_t n) : pages((n >> A_PAGE_BITS) + 1) {}
+    std::vector<ANode *> pages;
+    explicit ANodes(size_t n) : pages((n >> A_PAGE_BITS) + 1, nullptr) {}
+    ~ANodes() { for (ANode *p : pages) std::free(p); }
+    ANodes(const ANodes &) = delete;
+    ANodes &operator=(const ANodes &) = delete;
     ANode &at(size_t i) {
-        std::unique_ptr<ANode[]> &p = pages[i >> A_PAGE_BITS];
-        if (!p) p.reset(new ANode[(size_t)1 << A_PAGE_BITS]);
+        ANode *&p = pages[i >> A_PAGE_BITS];
+        if (!p) { p = (ANode *)std::calloc((size_t)1 << A_PAGE_BITS, sizeof(ANode)); if (!p) throw std::bad_alloc(); }
         return p[i & (((size_t)1 << A_PAGE_BITS) - 1)];
+    }
+};
+
+// The open set: the reference's std::multimap<double, GridNode *> pops its begin() - the smallest key, and among equal keys the one
+// inserted first (equal keys are inserted at the end of their range).  A binary heap ordered by (key, insertion number) pops in
+// exactly that order without a tree node per entry.
+struct AOpen {
+    struct E { double f; unsigned long long seq; int idx; };
+    std::vector<E> h;
+    unsigned long long n_ins = 0;
+    static bool before(const E &a, const E &b) { return a.f < b.f || (a.f == b.f && a.seq < b.seq); }
+    bool empty() const { return h.empty(); }
+    void push(double f, int idx) {
+        h.push_back(E{f, n_ins++, idx});
+        size_t i = h.size() - 1;
+        while (i > 0) { const size_t p = (i - 1) >> 1; if (!before(h[i], h[p])) break; std::swap(h[i], h[p]); i = p; }
+    }
+    int pop() {
+        const int idx = h[0].idx;
+        h[0] = h.back(); h.pop_back();
+        const size_t n = h.size();
+        for (size_t i = 0;;) {
+            size_t l = 2 * i + 1, r = l + 1, m = i;
+            if (l < n && before(h[l], h[m])) m = l;
+            if (r < n && before(h[r], h[m])) m = r;
+            if (m == i) break;
+            std::swap(h[i], h[m]); i = m;
+        }
+        return idx;
     }
 };
 
@@ -556,23 +591,23 @@ extern "C" int isdf_frontend_astar_search(isdf_ctx *c, const double start[3], co
     double edge[4];                                                                         // sqrt(i*i + j*j + k*k), :230
     for (int q = 0; q < 4; q++) edge[q] = std::sqrt((double)q);
 
+    try {
     ANodes nodes(n_vox);
     // the start node is an object of its own (`new GridNode`, :260): IT sits in the open set and is the first successors' father;
     // the map's node of the start cell is only marked open (:276-278) and stays that way
-    ANode start_node;
-    start_node.g = 0.0; start_node.f = astar_heu(si, gi); start_node.id = 1;
-    std::multimap<double, int> open;
-    open.insert(std::make_pair(start_node.f, A_START));
+    ANode start_node{};
+    start_node.g = 0.0; start_node.id = 1;
+    AOpen open;
+    open.push(astar_heu(si, gi), A_START);
     {
         ANode &m = nodes.at((size_t)si[0] * YZ + (size_t)si[1] * G.Z + si[2]);
-        m.id = 1; m.g = start_node.g; m.f = start_node.f;
+        m.id = 1; m.g = start_node.g;
     }
     int terminate = -1;
     bool found = false;
     long long expansions = 0, checks = 0;
     while (!open.empty()) {
-        const int cur = open.begin()->second;
-        open.erase(open.begin());
+        const int cur = open.pop();
         ANode &cn = cur == A_START ? start_node : nodes.at((size_t)cur);
         cn.id = -1;
         expansions++;
@@ -615,11 +650,10 @@ extern "C" int isdf_frontend_astar_search(isdf_ctx *c, const double start[3], co
             if (nb.id == 1 && !(tg < nb.g)) continue;
             if (nb.id == -1 && !(tg < nb.g)) continue;
             const int ni[3] = {(int)((size_t)succ[s2] / YZ), (int)(((size_t)succ[s2] / G.Z) % G.Y), (int)((size_t)succ[s2] % G.Z)};
-            nb.father = cur; nb.g = tg;
-            nb.f = tg + astar_heu(ni, gi) + 0.0;                                                                      // + getCustomCost (:192-196) = 0
+            nb.father1 = cur == A_START ? A_START1 : cur + 1; nb.g = tg;
             if (nb.id != 1) {                                       // new (:306-317) or closed and reopened (:330-343); an open node keeps its OLD key (:319-328)
                 nb.id = 1;
-                open.insert(std::make_pair(nb.f, succ[s2]));
+                open.push(tg + astar_heu(ni, gi) + 0.0, succ[s2]);                                                   // + getCustomCost (:192-196) = 0
             }
         }
     }
@@ -627,7 +661,12 @@ extern "C" int isdf_frontend_astar_search(isdf_ctx *c, const double start[3], co
     if (found) {
         // getPath (:359-376) and the (roll, pitch) chain of getastarSE3Path (:378-403): fathers back to the start node, reversed
         std::vector<int> chain;
-        for (int p = terminate; p != -1; p = (p == A_START ? start_node.father : nodes.at((size_t)p).father)) chain.push_back(p);
+        for (int p = terminate;;) {
+            chain.push_back(p);
+            const int f1 = p == A_START ? 0 : nodes.at((size_t)p).father1;          // (the start node object has no father)
+            if (f1 == 0) break;
+            p = f1 == A_START1 ? A_START : f1 - 1;
+        }
         for (size_t q = chain.size(); q-- > 0;) {
             int ix, iy, iz;
             const ANode *n;
@@ -640,6 +679,11 @@ extern "C" int isdf_frontend_astar_search(isdf_ctx *c, const double start[3], co
         }
         result->success = 1;
         result->n_path = (int)chain.size();
+    }
+    } catch (const std::bad_alloc &) {
+        fe.path_xyz.clear(); fe.path_rp.clear();
+        *result = isdf_astar_result{};
+        return isdf_fail(c, ISDF_ERR_HIP, "the A* ran out of host memory");
     }
     result->search_ms = std::chrono::duration<double, std::milli>(clk::now() - t1).count();
     return ISDF_OK;

@@ -509,7 +509,7 @@ int isdf_frontend_cspace(isdf_ctx *ctx, uint32_t *free_mask_out, double *kernel_
  * The first search after isdf_frontend_build computes the whole configuration space on the device (isdf_frontend_cspace) and
  * keeps it in pinned host memory; a search then runs on the calling thread and answers every neighbour test
  * (isIndexValid && !isIndexOccupiedFlate && checkKernelValue, :214-216) with bit tests on a voxel's 128-bit word in the
- * reference's breadth-first attitude order.  Same open-set order (a multimap keyed by the fScore at insertion, first inserted
+ * reference's breadth-first attitude order.  Same open-set order (that of a multimap keyed by the fScore at insertion, first inserted
  * first among equals), same 26+1 neighbour order, same re-opening of closed nodes, same (roll, pitch) bookkeeping (a node's
  * attitude is overwritten by every expansion that finds it feasible, :227-228) => the same path and attitudes, node for node.
  * start / goal: world coordinates; outside the map => success = 0 (the reference logs an error and returns, :244-249). */

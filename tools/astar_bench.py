@@ -12,7 +12,7 @@ res = 0.2
 dims = (256, 256, 64)                      # 51.2 x 51.2 x 12.8 m: the demos' worlds are 50 x 50 m
 occ = synth.random_box_map(dims, res=res, occupancy=float(os.environ.get("ASTAR_OCC", "0.12")), seed=12345)
 rng = np.random.default_rng(0)
-have_ref = os.path.exists(orc.REF_SWEEPS)
+have_ref = os.path.exists(orc.REF_SWEEPS) and os.environ.get("ASTAR_SKIP_REF") != "1"
 for name, cls, shape, k in (("box 3.2x0.6x0.6 m", "Box", synth.bench_box_shape(), 21),):
     cfg = synth.default_config(capi.V1_SWEPT)
     fe = capi.frontend_config(kernel_size=k, max_roll=45.0, max_pitch=45.0, ang_res=9.0, safeh=0.0)
@@ -40,7 +40,7 @@ for name, cls, shape, k in (("box 3.2x0.6x0.6 m", "Box", synth.bench_box_shape()
         t0 = time.perf_counter(); xyz, rp, rot, r = eng.frontend_astar(s, g); tp = time.perf_counter() - t0
         line = (f"  search {q}: path {r.n_path:4d} nodes, {r.expansions:7d} expansions, {r.checks:9d} neighbour tests | device table (once) "
                 f"{r.table_ms:7.1f} ms, search {r.search_ms:8.2f} ms, call {tp*1e3:8.2f} ms")
-        if q < 3:
+        if q < 3 and os.environ.get("ASTAR_SKIP_REF") != "1":
             t0 = time.perf_counter(); x0, rp0, st = o.frontend_astar(s, g); to = time.perf_counter() - t0
             same = (xyz is None and x0 is None) or (xyz is not None and x0 is not None and np.array_equal(xyz, x0) and np.array_equal(rp, rp0))
             line += f" | oracle {to*1e3:9.1f} ms identical {same and st['checks'] == r.checks}"
