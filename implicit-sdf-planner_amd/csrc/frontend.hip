@@ -9,7 +9,7 @@
 //                          attitudes are tried in the reference's breadth-first order (a host-built table per parent
 //                          attitude, visit_kernels_by_distance sw_manager.hpp:850-909): row dword AND map bits, wave ballot,
 //                          stop at the first attitude with no overlap (kernelConv<true>, :813-847).
-//   fe_cspace_kernel       the whole configuration space in one pass: 128 bits per voxel, bit a = attitude a fits;
+//   fe_cspace_kernel       the whole configuration space in one pass: 128 bits per voxel and 128 attitudes, bit a = attitude a fits;
 //   isdf_frontend_astar_*  the SE(3) A* itself (front_end_Astar.hpp:172-403) on the calling thread over that table: the search
 //                          is a chain of dependent pops, the 27 x (up to 121 attitudes x k^2 byte-ANDs) behind every pop is
 //                          what the device has already done for every voxel at once.
@@ -165,7 +165,7 @@ __global__ __launch_bounds__(256) void fe_check_kernel(FeParams F, FeQuery Q, co
 // Whole configuration space at once: for every voxel of the map, which attitudes fit (kernelConv<true> for all of them).
 // One lane per voxel, 64 consecutive z per wavefront, so neighbouring lanes read the same map dwords; the robot's rows are
 // wave-uniform (scalar loads) and only the NON-EMPTY rows of an attitude are visited (host-built lists: the robot fills a
-// small part of its k^3 box).  Output: 4 dwords per voxel, bit a = attitude a is collision-free; occupied voxels get 0
+// small part of its k^3 box).  Output: 4 dwords per voxel and 128 attitudes, bit a = attitude a is collision-free; occupied voxels get 0
 // (AstarGetSucc never asks about them).
 struct FeRow { unsigned off, word; };      // off = (i * iY + j) * iZW: where the tile row starts relative to the voxel's own row
 
@@ -186,22 +186,26 @@ __global__ __launch_bounds__(256) void fe_cspace_kernel(FeParams F, const uint8_
     const unsigned *base = bits + ((size_t)x * F.iY + y) * F.iZW + (zc >> 5);
     const int sh = zc & 31;
     const unsigned kmask = (F.k >= 32) ? 0xFFFFFFFFu : ((1u << F.k) - 1u);
-    unsigned m[4] = {0u, 0u, 0u, 0u};
     const bool work = valid && !is_occ;
-    for (int a = 0; a < F.n_att; a++) {
-        const int r0 = row_ptr[a], r1 = row_ptr[a + 1];
-        unsigned hit = work ? 0u : 1u;
-        for (int r = r0; r < r1; r++) {
-            if ((r & 7) == 0 && __ballot(hit == 0u) == 0ull) break;          // every lane has already collided (or has no work)
-            const FeRow e = rows[r];                                           // wave-uniform
-            const unsigned *p = base + e.off;
-            const unsigned b0 = p[0], b1 = p[1];
-            const unsigned mb = (sh ? ((b0 >> sh) | (b1 << (32 - sh))) : b0) & kmask;
-            hit |= mb & e.word;
+    const int nq = (F.n_att + 127) >> 7;                  // 128-attitude groups = uint4 words per voxel
+    for (int q = 0; q < nq; q++) {
+        unsigned m[4] = {0u, 0u, 0u, 0u};
+        const int a_end = min(F.n_att, (q + 1) << 7);
+        for (int a = q << 7; a < a_end; a++) {
+            const int r0 = row_ptr[a], r1 = row_ptr[a + 1];
+            unsigned hit = work ? 0u : 1u;
+            for (int r = r0; r < r1; r++) {
+                if ((r & 7) == 0 && __ballot(hit == 0u) == 0ull) break;          // every lane has already collided (or has no work)
+                const FeRow e = rows[r];                                           // wave-uniform
+                const unsigned *p = base + e.off;
+                const unsigned b0 = p[0], b1 = p[1];
+                const unsigned mb = (sh ? ((b0 >> sh) | (b1 << (32 - sh))) : b0) & kmask;
+                hit |= mb & e.word;
+            }
+            if (hit == 0u) m[(a >> 5) & 3] |= 1u << (a & 31);
         }
-        if (hit == 0u) m[a >> 5] |= 1u << (a & 31);
+        if (valid) out[(((size_t)x * F.Y + y) * F.Z + z) * nq + q] = make_uint4(m[0], m[1], m[2], m[3]);
     }
-    if (valid) out[((size_t)x * F.Y + y) * F.Z + z] = make_uint4(m[0], m[1], m[2], m[3]);
 }
 
 }  // namespace isdf
@@ -366,17 +370,17 @@ extern "C" int isdf_frontend_cspace(isdf_ctx *c, uint32_t *free_mask_out, double
     if (!c) return ISDF_ERR_INVALID_ARG;
     if (!c->fe.built) return isdf_fail(c, ISDF_ERR_STATE, "isdf_frontend_build has not been called");
     const FeParams F = fe_params(c);
-    if (F.n_att > 128) return isdf_fail(c, ISDF_ERR_UNSUPPORTED, "the whole-map pass packs at most 128 attitudes per voxel");
+    const size_t nw = 4 * (size_t)((F.n_att + 127) / 128);             // dwords per voxel
     HIPCHK(c, hipSetDevice(c->device));
     const size_t n = (size_t)F.X * F.Y * F.Z;
-    if (!c->fe.d_cspace) HIPCHK(c, hipMalloc(&c->fe.d_cspace, n * 4 * sizeof(unsigned)));
+    if (!c->fe.d_cspace) HIPCHK(c, hipMalloc(&c->fe.d_cspace, n * nw * sizeof(unsigned)));
     hipEvent_t e0, e1;
     HIPCHK(c, hipEventCreate(&e0)); HIPCHK(c, hipEventCreate(&e1));
     const long long n_wv = (long long)F.X * F.Y * ((F.Z + 63) >> 6);
     hipExtLaunchKernelGGL(fe_cspace_kernel, dim3((unsigned)((n_wv + 3) / 4)), dim3(256), 0, c->stream, e0, e1, 0, F, c->d_occ, c->fe.d_bits,
                           (const FeRow *)c->fe.d_row_list, c->fe.d_row_ptr, (uint4 *)c->fe.d_cspace);
     hipError_t e = hipGetLastError();
-    if (e == hipSuccess && free_mask_out) e = hipMemcpyAsync(free_mask_out, c->fe.d_cspace, n * 4 * sizeof(unsigned), hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess && free_mask_out) e = hipMemcpyAsync(free_mask_out, c->fe.d_cspace, n * nw * sizeof(unsigned), hipMemcpyDeviceToHost, c->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
     float ms = 0.f;
     if (e == hipSuccess) e = hipEventElapsedTime(&ms, e0, e1);
@@ -555,16 +559,17 @@ extern "C" int isdf_frontend_astar_search(isdf_ctx *c, const double start[3], co
     if (n_vox > (size_t)0x7FFFFFF0) return isdf_fail(c, ISDF_ERR_UNSUPPORTED, "the A* indexes voxels with 31 bits");
     *result = isdf_astar_result{};
     fe.path_xyz.clear(); fe.path_rp.clear();
+    const size_t nw = 4 * (size_t)((fe.xk * fe.yk + 127) / 128);       // dwords of a voxel's word in the table
     typedef std::chrono::steady_clock clk;
     if (!fe.h_cspace_valid) {
         const clk::time_point t0 = clk::now();
         HIPCHK(c, hipSetDevice(c->device));
         if (!fe.h_cspace) {
-            // 16 bytes per voxel (268 MB at 256^3, 2 GiB at 512^3): pinned if the host grants it, pageable otherwise (the copy is then staged by the runtime)
-            if (hipHostMalloc((void **)&fe.h_cspace, n_vox * 4 * sizeof(unsigned), hipHostMallocDefault) == hipSuccess) fe.h_cspace_pinned = true;
+            // 16 bytes per voxel and 128 attitudes (268 MB at 256^3, 2 GiB at 512^3): pinned if the host grants it, pageable otherwise (the copy is then staged by the runtime)
+            if (hipHostMalloc((void **)&fe.h_cspace, n_vox * nw * sizeof(unsigned), hipHostMallocDefault) == hipSuccess) fe.h_cspace_pinned = true;
             else {
                 (void)hipGetLastError();
-                fe.h_cspace = (unsigned *)std::malloc(n_vox * 4 * sizeof(unsigned));
+                fe.h_cspace = (unsigned *)std::malloc(n_vox * nw * sizeof(unsigned));
                 fe.h_cspace_pinned = false;
                 if (!fe.h_cspace) return isdf_fail(c, ISDF_ERR_HIP, "no host memory for the configuration-space table");
             }
@@ -630,8 +635,10 @@ extern "C" int isdf_frontend_astar_search(isdf_ctx *c, const double start[3], co
                     const int vx = ci[0] + i, vy = ci[1] + j, vz = ci[2] + k;
                     if (vx < 0 || vx >= G.X || vy < 0 || vy >= G.Y || vz < 0 || vz >= G.Z) continue;               // isIndexValid
                     const size_t v = (size_t)vx * YZ + (size_t)vy * G.Z + vz;
-                    const unsigned *m = table + 4 * v;                                                                // occupied voxels hold 0
-                    if ((m[0] | m[1] | m[2] | m[3]) == 0u) continue;
+                    const unsigned *m = table + nw * v;                                                               // occupied voxels hold 0
+                    unsigned any = m[0] | m[1] | m[2] | m[3];
+                    for (size_t w = 4; w < nw; w++) any |= m[w];
+                    if (any == 0u) continue;
                     int att = -1;
                     for (int t = 0; t < order_len; t++) {
                         const int a = order[t];

@@ -237,11 +237,14 @@ class Engine:
         return ok, cr, cp, ki
 
     def frontend_cspace(self, download=True):
-        """(free_mask uint32 [X, Y, Z, 4] or None, kernel ms): bit (i * yk + j) of a voxel's 128-bit mask = attitude fits."""
+        """(free_mask uint32 [X, Y, Z, 4 * ceil(attitudes / 128)] or None, kernel ms): bit (i * yk + j) of a voxel's mask = attitude fits."""
         dims = (C.c_int * 3)()
         o = np.zeros(3); bm = np.zeros(3)
         self._check(self.lib.isdf_get_grid(self.h, capi.GRID_OCCUPANCY, None, capi.U8, dims, _p(o), _p(bm)))
-        out = np.zeros((dims[0], dims[1], dims[2], 4), dtype=np.uint32) if download else None
+        kd = (C.c_int * 3)()
+        self._check(self.lib.isdf_frontend_get_shape_kernels(self.h, None, kd))
+        nw = 4 * ((kd[0] * kd[1] + 127) // 128)
+        out = np.zeros((dims[0], dims[1], dims[2], nw), dtype=np.uint32) if download else None
         ms = C.c_double(0.0)
         self._check(self.lib.isdf_frontend_cspace(self.h, out.ctypes.data_as(C.c_void_p) if download else None, C.byref(ms)))
         return out, ms.value

@@ -496,8 +496,8 @@ int isdf_frontend_check(isdf_ctx *ctx, int n, const int32_t *index, const double
 
 /* The whole configuration space in one pass: for EVERY voxel of the map, which attitudes are collision-free
  * (kernelConv<true>(i, j, voxel), sw_manager.hpp:813-847, for all i, j).  free_mask_out (may be NULL: the table then only
- * stays on the device): 4 dwords per voxel in the grid's own order (z fastest), bit (i * ykernel + j) set = that attitude
- * fits; occupied voxels get 0.  At most 128 attitudes.  An A* that holds this table answers checkKernelValue with a few
+ * stays on the device): 4 * ceil(attitudes / 128) dwords per voxel in the grid's own order (z fastest; 4 for the shipped 11 x 11),
+ * bit (i * ykernel + j) set = that attitude fits; occupied voxels get 0.  An A* that holds this table answers checkKernelValue with a few
  * bit tests in the breadth-first order instead of k^2 byte-ANDs per attitude.  kernel_ms_out (optional): device time. */
 int isdf_frontend_cspace(isdf_ctx *ctx, uint32_t *free_mask_out, double *kernel_ms_out);
 
@@ -508,7 +508,7 @@ int isdf_frontend_cspace(isdf_ctx *ctx, uint32_t *free_mask_out, double *kernel_
  *                                 reference's reset()).
  * The first search after isdf_frontend_build computes the whole configuration space on the device (isdf_frontend_cspace) and
  * keeps it in pinned host memory; a search then runs on the calling thread and answers every neighbour test
- * (isIndexValid && !isIndexOccupiedFlate && checkKernelValue, :214-216) with bit tests on a voxel's 128-bit word in the
+ * (isIndexValid && !isIndexOccupiedFlate && checkKernelValue, :214-216) with bit tests on a voxel's word of the table (128 bits per 128 attitudes) in the
  * reference's breadth-first attitude order.  Same open-set order (that of a multimap keyed by the fScore at insertion, first inserted
  * first among equals), same 26+1 neighbour order, same re-opening of closed nodes, same (roll, pitch) bookkeeping (a node's
  * attitude is overwritten by every expansion that finds it feasible, :227-228) => the same path and attitudes, node for node.

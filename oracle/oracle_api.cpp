@@ -133,20 +133,21 @@ void orc_frontend_check(void *h, int n, const int32_t *index, const double *fr, 
         if (kidx) kidx[q] = ki;
     }
 }
-// every voxel x every attitude: kernel_conv; 4 dwords per voxel, occupied voxels 0
+// every voxel x every attitude: kernel_conv; 4 * ceil(attitudes / 128) dwords per voxel, occupied voxels 0
 void orc_frontend_cspace(void *h, uint32_t *out) {
     OrcCtx &c = *(OrcCtx *)h;
     const Grid &g = c.grid;
     const int na = c.fe.xk * c.fe.yk;
+    const int nw = 4 * ((na + 127) / 128);
 #pragma omp parallel for schedule(dynamic, 16) num_threads(c.P.threads)
     for (int x = 0; x < g.X; x++)
         for (int y = 0; y < g.Y; y++)
             for (int z = 0; z < g.Z; z++) {
-                uint32_t *m = out + 4 * g.addr(x, y, z);
-                m[0] = m[1] = m[2] = m[3] = 0;
+                uint32_t *m = out + (size_t)nw * g.addr(x, y, z);
+                for (int w = 0; w < nw; w++) m[w] = 0;
                 if (g.occ[g.addr(x, y, z)] == 1) continue;
                 const int ind[3] = {x, y, z};
-                for (int a = 0; a < na && a < 128; a++)
+                for (int a = 0; a < na; a++)
                     if (c.fe.kernel_conv(a / c.fe.yk, a % c.fe.yk, ind)) m[a >> 5] |= 1u << (a & 31);
             }
 }

@@ -118,8 +118,9 @@ class Oracle:
         return xyz[:n].copy(), rp[:n].copy(), stats
 
     def frontend_cspace(self, grid_shape):
-        """uint32 [X, Y, Z, 4]: bit (i * yk + j) of a voxel's mask = kernelConv(i, j, voxel); occupied voxels 0."""
-        out = np.zeros(tuple(grid_shape) + (4,), dtype=np.uint32)
+        """uint32 [X, Y, Z, 4 * ceil(attitudes / 128)]: bit (i * yk + j) of a voxel's mask = kernelConv(i, j, voxel); occupied voxels 0."""
+        nw = 4 * ((self.fe_dims[0] * self.fe_dims[1] + 127) // 128)
+        out = np.zeros(tuple(grid_shape) + (nw,), dtype=np.uint32)
         self.lib.orc_frontend_cspace(self.h, out.ctypes.data_as(C.c_void_p))
         return out
 

@@ -290,3 +290,36 @@ def test_astar_other_grids_and_origins(pkg, orc, product_lib):
     assert eng.frontend_astar(*cases[-1])[3].success == 0 and eng.frontend_astar(*cases[-2])[3].success == 0
     x1 = eng.frontend_astar(*cases[-3])[0]
     assert x1 is not None and len(x1) == 1
+
+
+def test_more_than_128_attitudes(pkg, orc, product_lib):
+    """kernel_ang_res 5 degrees: 19 x 19 = 361 attitudes -> 12 dwords per voxel in the configuration-space table (three 128-attitude
+    groups, the last one partly filled); table == the oracle's kernelConv per (voxel, attitude), A* == the oracle's, node for node."""
+    capi, synth = pkg.capi, pkg.synth
+    res = 0.5
+    occ = synth.random_box_map((30, 28, 12), res=res, occupancy=0.2, seed=91, edge=(0.5, 2.0))
+    shape = synth.make_shape("Box", params=(0.9, 0.35, 0.25), poly_params=(0.05, -0.1, 0.02, 12, -8, 25))
+    fe = capi.frontend_config(kernel_size=11, max_roll=45.0, max_pitch=45.0, ang_res=5.0, safeh=0.0)
+    eng, o = _pair(pkg, orc, shape, occ, res, fe)
+    assert o.fe_dims[:2] == [19, 19]
+    table, _ = eng.frontend_cspace()
+    ref = o.frontend_cspace(occ.shape)
+    assert table.shape == ref.shape == occ.shape + (12,) and np.array_equal(table, ref)
+    assert ref[..., 4:8].any() and ref[..., 8:].any() and (ref[..., 11] >> 9 == 0).all()          # bits 361 .. 383 stay clear
+    rng = np.random.default_rng(8)
+    found = high = 0
+    for s, g in _astar_pairs(table, res, rng, 8):
+        xyz, rp, rot, r = eng.frontend_astar(s, g)
+        x0, rp0, st = o.frontend_astar(s, g)
+        assert (r.checks, r.expansions) == (st["checks"], st["expansions"]) and (xyz is None) == (x0 is None)
+        if x0 is not None:
+            found += 1
+            assert np.array_equal(xyz, x0) and np.array_equal(rp, rp0)
+            high += int((np.abs(rp0) > 0).any())
+    assert found >= 4 and high >= 1, (found, high)
+    # the batched per-neighbour test agrees with the table beyond attitude 127 as well
+    idx, fr, fp = _queries(occ, rng, 4000, xk=19)
+    fr = rng.choice(np.arange(-45.0, 45.1, 5.0), len(fr)); fp = rng.choice(np.arange(-45.0, 45.1, 5.0), len(fp))
+    ok, cr, cp, ki = eng.frontend_check(idx, fr, fp)
+    ok0, cr0, cp0, ki0 = o.frontend_check(idx, fr, fp)
+    assert np.array_equal(ok, ok0) and np.array_equal(ki, ki0) and (ki0 > 127).any()
