@@ -96,7 +96,7 @@ struct isdf_ctx {
     double *d_stage = nullptr; size_t stage_cap = 0;
     unsigned long long *d_stage_flags = nullptr; size_t stage_flags_cap = 0;
     unsigned long long dir_seq = 0;
-    unsigned long long host_steps = 0, host_late = 0, host_late_spins = 0;      // isdf_host_info: host-mapped result hand-overs / those whose rows landed after the flag
+    unsigned long long host_steps = 0, host_late = 0, host_late_spins = 0, host_late_mark = 0;      // isdf_host_info: host-mapped result hand-overs / those whose rows landed after the flag
     int bar_state = 0;          // 0: untested, 1: the host can write device memory through the PCIe BAR (verified), -1: it cannot
     bool dir_pending = false; int dir_nb = 0, dir_n = 0; bool cb_direct = false;
     double *h_v1_pin = nullptr, *h_v1_pin_dev = nullptr; size_t v1_pin_cap = 0;     // host-direct swept-volume step: [out | statistics | flag | lastTstar], device-mapped

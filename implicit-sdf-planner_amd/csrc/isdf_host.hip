@@ -1453,9 +1453,9 @@ static bool direct_enabled(const isdf_ctx *c) {
 // the result area is filled with a pattern no result can have (all ones: not the canonical NaN, not a count) before the launch, and
 // after the word the host waits until none of it is left - normally a scan of a few hundred doubles that finds nothing.
 static void host_rows_mark(double *p, size_t n) { std::memset((void *)p, 0xFF, n * sizeof(double)); }
-static bool host_rows_wait(isdf_ctx *c, const double *p, size_t n) {
+static bool host_rows_wait(isdf_ctx *c, const double *p, size_t n, bool another_area_of_the_same_step = false) {
     const volatile unsigned long long *w = (const volatile unsigned long long *)p;
-    c->host_steps++;
+    if (!another_area_of_the_same_step) c->host_steps++;
     bool late = false;
     const auto t0 = std::chrono::steady_clock::now();
     for (size_t i = 0; i < n; i++) {
@@ -1465,7 +1465,7 @@ static bool host_rows_wait(isdf_ctx *c, const double *p, size_t n) {
             if ((spin & 0x3FFFu) == 0x3FFFu && std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > 5.0) return false;
         }
     }
-    if (late) { c->host_late++; std::atomic_thread_fence(std::memory_order_acquire); }
+    if (late) { if (!another_area_of_the_same_step || c->host_late_mark != c->host_steps) { c->host_late++; c->host_late_mark = c->host_steps; } std::atomic_thread_fence(std::memory_order_acquire); }
     return true;
 }
 
@@ -1647,7 +1647,7 @@ static int v1_direct_eval(isdf_ctx *c, int n, const double *T, const double *coe
         }
     }
     std::atomic_thread_fence(std::memory_order_acquire);
-    if (!host_rows_wait(c, c->h_v1_pin, ostride) || (ts && !host_rows_wait(c, c->h_v1_pin + ostride + 10, (size_t)c->M))) {
+    if (!host_rows_wait(c, c->h_v1_pin, ostride) || (ts && !host_rows_wait(c, c->h_v1_pin + ostride + 10, (size_t)c->M, true))) {
         (void)hipStreamSynchronize(c->stream);
         return fail(c, ISDF_ERR_HIP, "host-direct swept-volume step: its flag arrived but not all of its results");
     }
@@ -1795,7 +1795,7 @@ extern "C" int isdf_eval(isdf_ctx *c, int n_traj, const int *N, const double *co
                 }
             }
             std::atomic_thread_fence(std::memory_order_acquire);
-            if (!host_rows_wait(c, hout, out_all) || !host_rows_wait(c, (const double *)hstat, 8)) {
+            if (!host_rows_wait(c, hout, out_all) || !host_rows_wait(c, (const double *)hstat, 8, true)) {
                 (void)hipStreamSynchronize(c->stream);
                 return fail(c, ISDF_ERR_HIP, "multi-device step: its completion word arrived but not all of its results");
             }
