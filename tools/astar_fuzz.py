@@ -1,6 +1,6 @@
 #!/usr/bin/env python
-"""Developer tool (CPU only, needs oracle/_ref): the oracle's A* restatement against the reference's own AstarPathSearcher on random
-worlds, robots, kernel sizes and attitude grids.  usage: tools/astar_fuzz.py [n_worlds]"""
+"""Developer tool (needs oracle/_ref): the oracle's A* restatement - and, with a GPU, the product's isdf_frontend_astar_search - against the
+reference's own AstarPathSearcher on random worlds, robots, kernel sizes and attitude grids.  usage: tools/astar_fuzz.py [n_worlds]"""
 import os, sys, time
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -9,7 +9,9 @@ pkg = graft.load_package(); orc = graft.load_oracle(); capi, synth = pkg.capi, p
 n_worlds = int(sys.argv[1]) if len(sys.argv) > 1 else 12
 rng = np.random.default_rng(2026)
 names = ["Box", "RoundedCone", "Torus_big", "Table", "CSG", "Cappedtorus", "TwistBox", "WireframeBox"]
-tot = found = failed = tilted = 0
+tot = found = failed = tilted = dev_failed = 0
+import torch
+GPU = torch.cuda.is_available()
 t0 = time.time()
 for wi in range(n_worlds):
     name = names[wi % len(names)]
@@ -25,6 +27,9 @@ for wi in range(n_worlds):
     origin = tuple(float(v) * 0.125 for v in rng.integers(-40, 40, 3))
     o = orc.Oracle(cfg, threads=8); o.set_grid(occ, origin, res, capi.GRID_OCCUPANCY); o.set_shape(shape); o.frontend_build(fe)
     w = orc.RefWorld(cfg, name, shape, res); w.set_occupancy(occ, origin, res); w.frontend_build(fe, name)
+    eng = None
+    if GPU:
+        eng = pkg.Engine(cfg); eng.set_grid(occ, origin, res, capi.GRID_OCCUPANCY); eng.set_shape(shape); eng.frontend_build(fe)
     good = np.argwhere((o.frontend_cspace(occ.shape) != 0).any(axis=-1))
     if len(good) < 2:
         continue
@@ -38,7 +43,13 @@ for wi in range(n_worlds):
         if not ok:
             failed += 1
             print(f"MISMATCH world {wi} ({name}) search {q}: checks {st['checks']} vs {checks_r}", flush=True)
+        if eng is not None:
+            x_d, rp_d, _, r = eng.frontend_astar(s, g)
+            if not (r.checks == checks_r and (x_r is None) == (x_d is None) and (x_r is None or (np.array_equal(x_d, x_r) and np.array_equal(rp_d, rp_r)))):
+                dev_failed += 1
+                print(f"DEVICE MISMATCH world {wi} ({name}) search {q}: checks {r.checks} vs {checks_r}", flush=True)
         if x_r is not None:
             found += 1; tilted += int((rp_r != 0).any())
     print(f"world {wi:2d} {name:13s} dims {dims} res {res} k {fe.kernel_size} ang {ang}: searches so far {tot}, found {found}, with attitudes off level {tilted}, mismatches {failed}", flush=True)
-print(f"# {tot} searches on {n_worlds} worlds in {time.time() - t0:.0f} s: {found} paths, {tilted} with attitudes other than level, {failed} mismatches (oracle vs the reference's own code: cells, (roll, pitch) per node, neighbour tests)")
+print(f"# {tot} searches on {n_worlds} worlds in {time.time() - t0:.0f} s: {found} paths, {tilted} with attitudes other than level, {failed} mismatches (oracle vs the reference's own code: cells, (roll, pitch) per node, neighbour tests)"
+      + (f"; device (isdf_frontend_astar_search) vs the reference's own code: {dev_failed} mismatches" if GPU else ""))
