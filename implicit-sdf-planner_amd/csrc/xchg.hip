@@ -21,7 +21,7 @@ namespace isdf {
 //   2T + T/4 from this rank's start: the verdict round's bound (a peer whose data arrived started before t0 + T, its own
 //        data wait ends before its start + T, so its verdict is here before t0 + 2T)
 //   the other blocks of a launch give up only while block 0 has not STARTED (4T + T from their own start), see below
-constexpr double XCHG_DEFAULT_TIMEOUT_MS = 2000.0;     // (a rank whose first step loads its code objects can be most of a second late: 500 ms failed a healthy first exchange on a fresh box)
+constexpr double XCHG_DEFAULT_TIMEOUT_MS = 2000.0;     // generous: ranks are separate processes (a first step loads code objects, a host thread may be descheduled); a peer later than this is a failure, not jitter
 
 struct XchgParams {
     int rank, world;

@@ -399,7 +399,7 @@ int isdf_xchg_allreduce(isdf_ctx *ctx, double *d_buf, size_t count, void *stream
 int isdf_xchg_status(isdf_ctx *ctx);
 int isdf_xchg_destroy(isdf_ctx *ctx);
 /* The bound T of every wait of both exchange forms, in MILLISECONDS OF THE DEVICE'S WALL CLOCK (wall_clock64(), constant rate:
- * the same duration on every box; default 2 000 - a rank that loads its kernels for the first time can be a second late -, settable 1 ... 10 000): how much later than this rank a peer may start a step
+ * the same duration on every box; default 2 000 - generous: the ranks are separate processes -, settable 1 ... 10 000): how much later than this rank a peer may start a step
  * before this rank calls the exchange failed.  A failed isdf_xchg_allreduce kernel ends after T on the rank whose wait expired
  * and at once on the late rank (which reads the first one's verdict); a healthy one waits at most 2.25 T for the verdicts.
  * Replaces: nothing in the reference (no multi-GPU path); the counterpart of NCCL's watchdog time-out, SURVEY 8(e). */

@@ -33,7 +33,7 @@ def main():
     xv = full.pack_variables(T, Cf6[1:, 0, :])
     c_ref, g_ref = full.cost_function(xv)
     print(f"[xchg_fail_worker] rank {rank}: first step of the unsharded ctx, host hand-over {full.host_info()} (path {full.lib.isdf_host_path(full.h)})", flush=True)
-    assert eng.xchg_timeout_ms() == 2000.0                      # the default: generous - a rank's FIRST step loads its code objects
+    assert eng.xchg_timeout_ms() == 2000.0                      # the default: generous (ranks are separate processes)
     x = par.XgmiExchange(eng, eng.out_stride(6), dev)
     assert x.ok, x.why
     # healthy: the callback through the exchange, no host collective involved (twice: the first call loads kernels)
